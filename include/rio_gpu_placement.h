@@ -1,0 +1,199 @@
+/*
+ * rio_gpu_placement.h — C ABI of the MI355X batched object-placement solver.
+ *
+ * This is the drop-in boundary for rio-rs' `object_placement::*` hot path.  Nothing like it
+ * exists in the reference (pure Rust, static dispatch); these are the entry points an FFI
+ * binding for that path would call.  Every entry point cites the reference interface it
+ * replaces (paths relative to /root/reference):
+ *
+ *   trait ObjectPlacement            rio-rs/src/object_placement/mod.rs:38-56
+ *   LocalObjectPlacement (semantics) rio-rs/src/object_placement/local.rs:22-68
+ *   placement policy                 rio-rs/src/service.rs:193-298
+ *   error convention                 rio-rs/src/errors.rs:135-142
+ *
+ * Two layers are exported from the same shared library (librio_gp.so):
+ *
+ *   rio_gp_*  dense-index layer.  Objects are rows 0..n-1, nodes are 0..m-1, the table
+ *             (object: cur/load/aff) x (node: cap/alive/used) lives in HBM.  Plain
+ *             uint32_t/uint64_t arrays, caller-owned, copied in/out.  `_dev` variants take
+ *             device pointers (inputs already resident in HBM).
+ *   rio_op_*  string layer (rio_gpu_object_placement.h): (struct_name, object_id) and
+ *             "ip:port" strings, i.e. exactly the ObjectPlacement trait; interns strings
+ *             to dense ids on the host and calls the rio_gp_* layer.
+ *
+ * Conventions
+ *   - Every call returns int: 0 = ok.  Non-zero HIP status -> RIO_GP_EUPSTREAM
+ *     (ObjectPlacementError::Upstream); bad argument/index -> RIO_GP_EINVAL
+ *     (ObjectPlacementError::Unknown).  A lookup miss is RIO_GP_NONE in the output with
+ *     rc 0, never an error (local.rs:48).  Nothing throws or aborts across the ABI.
+ *   - A handle is internally synchronized (one mutex + one HIP stream per handle); calls
+ *     are synchronous on return unless the name ends in `_async`.
+ *   - There is NO CPU fallback: rio_gp_create fails with RIO_GP_ENODEV without a gfx950
+ *     device.
+ */
+#ifndef RIO_GPU_PLACEMENT_H
+#define RIO_GPU_PLACEMENT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIO_GP_ABI_VERSION 1u
+
+/* "not placed": Option::None of lookup (object_placement/mod.rs:50). */
+#define RIO_GP_NONE 0xFFFFFFFFu
+/* hard limits of the solver */
+#define RIO_GP_MAX_NODES 8192u
+#define RIO_GP_MAX_OBJECTS 0x7FFFF000ull
+/* capacity value meaning "unbounded" (the reference has no capacity at all) */
+#define RIO_GP_CAP_INF 0xFFFFFFFFFFFFFFFFull
+
+/* return codes */
+#define RIO_GP_OK 0
+#define RIO_GP_EINVAL 1    /* -> ObjectPlacementError::Unknown  (errors.rs:140-141) */
+#define RIO_GP_EUPSTREAM 2 /* -> ObjectPlacementError::Upstream (errors.rs:137-138) */
+#define RIO_GP_ENODEV 3    /* no HIP device / not gfx950: the product path fails loudly */
+#define RIO_GP_ENOMEM 4
+
+/* per-request outcome of rio_gp_place_pending (service.rs:193-298 folded into one code) */
+#define RIO_GP_FLAG_LOCAL 0u      /* already placed on the requester (sticky hit, service.rs:241-242,262-264) */
+#define RIO_GP_FLAG_REDIRECT 1u   /* already placed on another live node (ResponseError::Redirect, service.rs:286-289) */
+#define RIO_GP_FLAG_PLACED 2u     /* was unplaced/evicted, now first-touch placed on the requester (service.rs:244-252) */
+#define RIO_GP_FLAG_SPILLED 3u    /* requester full: placed on another node (capacity extension; caller redirects) */
+#define RIO_GP_FLAG_UNPLACED 4u   /* no capacity anywhere: stays RIO_GP_NONE */
+
+typedef struct rio_gp rio_gp_t;
+
+typedef struct rio_gp_cfg {
+    uint32_t struct_size;  /* = sizeof(rio_gp_cfg); ABI guard */
+    int32_t device;        /* HIP device ordinal */
+    uint64_t max_objects;  /* row capacity of the object table (<= RIO_GP_MAX_OBJECTS) */
+    uint32_t max_nodes;    /* row capacity of the node table (<= RIO_GP_MAX_NODES) */
+    uint32_t spill_rounds; /* water-fill rounds for objects their affinity node rejects; 0 -> default 2 */
+    uint32_t flags;        /* reserved, 0 */
+    uint32_t reserved;
+} rio_gp_cfg;
+
+/* Counters of one whole-table solve (rio_gp_tick / rio_gp_solve). */
+typedef struct rio_gp_stats {
+    uint64_t n_objects;
+    uint64_t kept;      /* sticky: placed on a live node (service.rs:241-242) */
+    uint64_t evicted;   /* were placed on a dead node (clean_server, service.rs:227-237) */
+    uint64_t claimed;   /* pending, admitted on their affinity node (first touch, service.rs:244-252) */
+    uint64_t spilled;   /* pending, placed on another node by the water-fill */
+    uint64_t unplaced;  /* pending, no room: stay RIO_GP_NONE */
+    uint64_t load_kept, load_claimed, load_spilled, load_unplaced;
+    uint32_t cut_nodes;   /* nodes whose claimants exceeded their free capacity */
+    uint32_t slow_path;   /* 0 = single-pass fast path, 1 = cut/spill fix-up ran */
+    uint32_t rounds_run;  /* spill rounds executed */
+    uint32_t reserved;
+} rio_gp_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* ObjectPlacement::prepare (mod.rs:42-44; SQL migrations sqlite.rs:58-66): allocate the HBM
+ * tables, create the stream.  `*out` is NULL on failure; rio_gp_last_error(NULL) has the text. */
+int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out);
+void rio_gp_destroy(rio_gp_t* h);
+/* Text of the last failure on this handle (or of the last failed create when h == NULL).
+ * The Rust adapter wraps it as ObjectPlacementError::{Upstream,Unknown}(text). */
+const char* rio_gp_last_error(rio_gp_t* h);
+/* "hip:gfx950" — there is no other backend. */
+const char* rio_gp_backend(rio_gp_t* h);
+uint32_t rio_gp_abi_version(void);
+/* hipStreamSynchronize on the handle's stream. */
+int rio_gp_sync(rio_gp_t* h);
+
+/* ---- node table: the "node" side, fed by MembershipStorage (cluster/storage/mod.rs:70-121) */
+
+/* Replace the node table: m nodes, capacity (load units) and liveness (Member.active,
+ * cluster/storage/mod.rs:20-58).  cap == NULL -> all RIO_GP_CAP_INF; alive == NULL -> all 1. */
+int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t* alive);
+/* MembershipStorage::set_is_active (cluster/storage/mod.rs:80) pushed instead of polled
+ * (is_active, mod.rs:102-110). */
+int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive);
+int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive);
+int rio_gp_get_nodes(rio_gp_t* h, uint32_t m, uint64_t* cap, uint8_t* alive, uint64_t* used);
+
+/* ---- object table ---------------------------------------------------------------------- */
+
+/* Define rows 0..n-1: per-object load and affinity (= the requesting server `self.address`
+ * of service.rs:244).  All rows start unplaced.  load == NULL -> 1; aff == NULL -> RIO_GP_NONE. */
+int rio_gp_set_objects(rio_gp_t* h, uint64_t n, const uint32_t* load, const uint32_t* aff);
+int rio_gp_set_objects_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_load, const uint32_t* d_aff);
+/* Bulk-load / dump the whole assignment column (warm start, snapshot; the on-disk twin is
+ * object_placement(struct_name, object_id, server_address), migrations/0001-sqlite-init.sql:1-9). */
+int rio_gp_set_assign(rio_gp_t* h, uint64_t n, const uint32_t* assign);
+int rio_gp_set_assign_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_assign);
+int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out_assign);
+/* Device pointer of the live assignment column (valid until the next tick/commit). */
+const uint32_t* rio_gp_assign_dev(rio_gp_t* h);
+uint64_t rio_gp_num_objects(rio_gp_t* h);
+uint32_t rio_gp_num_nodes(rio_gp_t* h);
+
+/* ---- the ObjectPlacement CRUD, batched -------------------------------------------------- */
+
+/* ObjectPlacement::lookup (mod.rs:50; local.rs:42-49): out_node[k] = node of idx[k] or
+ * RIO_GP_NONE.  idx[k] >= n is RIO_GP_EINVAL. */
+int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* out_node);
+int rio_gp_lookup_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, uint32_t* d_out_node);
+/* ObjectPlacement::update (mod.rs:46-49; local.rs:22-40): upsert idx[k] -> node[k];
+ * node[k] == RIO_GP_NONE deletes (local.rs:36-37).  Duplicate idx in one batch resolve as the
+ * sequential loop would: the highest batch position wins. */
+int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* node);
+int rio_gp_update_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node);
+/* ObjectPlacement::remove (mod.rs:55; local.rs:60-68): un-place; absent is a no-op. */
+int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx);
+int rio_gp_remove_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx);
+/* ObjectPlacement::clean_server (mod.rs:52; local.rs:51-58): un-place EVERY object whose
+ * node == `node` (one coalesced pass over the assignment column). */
+int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted);
+/* Same for any number of failed nodes in ONE pass: bit j of dead_bitmap (ceil(m/64) words). */
+int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evicted);
+
+/* ---- the placement policy, batched ------------------------------------------------------ */
+
+/* Service::get_or_create_placement + check_address_mismatch (service.rs:193-298) for a batch
+ * of requests, processed as if sequentially in batch order: request k asks for object idx[k]
+ * on server requester[k].
+ *   - object placed on a node that is not alive -> clean_server(that node) (all of its objects
+ *     are un-placed, service.rs:233-237), the object becomes pending;
+ *   - still placed -> sticky: out_node = that node, flag LOCAL / REDIRECT;
+ *   - pending -> first touch on requester[k] (service.rs:244-252), admitted while the
+ *     requester's free capacity lasts (index-ordered prefix rule), else
+ *     water-filled onto the emptiest nodes, else left RIO_GP_NONE.
+ * With every capacity = RIO_GP_CAP_INF this is exactly the reference policy.  out_flag may
+ * be NULL. */
+int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* requester,
+                         uint32_t* out_node, uint32_t* out_flag);
+
+/* Whole-table solve: every row gets a decision in one call (the eager form of the lazy
+ * per-request path of service.rs:193-254 + the clean_server stream of SURVEY §3.2):
+ * keep if alive (sticky) | claim affinity node by index-ordered prefix | water-fill | NONE.
+ *   rio_gp_solve   computes the new assignment column and `used`, does not publish it;
+ *   rio_gp_commit  publishes the last solve (pointer swap);
+ *   rio_gp_tick    = solve + commit. */
+int rio_gp_solve(rio_gp_t* h, rio_gp_stats* stats);
+int rio_gp_commit(rio_gp_t* h);
+int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats);
+/* Enqueue one solve on the handle's stream without waiting.  rio_gp_solve_wait drains the
+ * stream, runs the cut/spill fix-up for the LAST enqueued solve if it needed one, and
+ * returns its stats.  *n_slow = how many of the solves enqueued since the last wait took
+ * the fix-up path on the device. */
+int rio_gp_solve_async(rio_gp_t* h);
+int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow);
+/* Device pointer of the column the last solve produced (before commit). */
+const uint32_t* rio_gp_solved_dev(rio_gp_t* h);
+int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out_assign);
+
+/* ---- measurement hooks (HIP events on the handle's own stream) -------------------------- */
+int rio_gp_timer_begin(rio_gp_t* h);
+int rio_gp_timer_end(rio_gp_t* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIO_GPU_PLACEMENT_H */
