@@ -192,6 +192,11 @@ int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out_assign);
 /* ---- measurement hooks (HIP events on the handle's own stream) -------------------------- */
 int rio_gp_timer_begin(rio_gp_t* h);
 int rio_gp_timer_end(rio_gp_t* h, float* ms);
+/* One fast-path solve with a HIP-event pair around EACH kernel launch (so the durations are
+ * per-launch, not host-paired): scan_ms = the streaming kernel k_scan (16 algorithmic B/row),
+ * resolve_ms = k_resolve.  Does not publish; fails with RIO_GP_EINVAL if the solve needs the
+ * cut/spill fix-up (use rio_gp_solve then). */
+int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,113 @@
+// placement_kernels.h — launch interface between the C ABI (rio_gp_capi.hip) and the gfx950
+// kernels (placement_kernels.hip).  Internal; the public boundary is include/rio_gpu_placement.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace riogp {
+
+typedef uint32_t u32;
+typedef unsigned long long u64;
+
+constexpr u32 kNone = 0xFFFFFFFFu;       // unplaced (RIO_GP_NONE)
+constexpr u32 kSpillMark = 0xFFFFFFFEu;  // pending, waiting for the water-fill (never survives a solve)
+constexpr u32 kSkipMark = 0xFFFFFFFDu;   // virtual-table row that is a duplicate request (place_pending)
+constexpr u32 kNoCut = 0xFFFFFFFFu;
+
+constexpr int kWaves = 16;           // waves per workgroup of the streaming kernels
+constexpr int kBlock = kWaves * 64;  // 1024 threads: ONE workgroup per CU owns one LDS histogram
+constexpr int kTile = 256;           // objects per wave-iteration: 64 lanes x dwordx4
+constexpr u32 kMaxBlocks = 256;      // = CUs; rows of the per-block histogram table
+constexpr u32 kMaxSubs = 256;        // sub-chunks per block for the exact-cut refinement
+
+// Work decomposition of a table of n rows.  Index order is the only order that matters:
+// wave `gw` owns the contiguous rows [gw*wchunk, (gw+1)*wchunk), block b owns kWaves consecutive
+// wave ranges, sub-chunk t of block b is [b*chunk + t*sub, +sub).
+struct Plan {
+    u64 n;       // rows
+    u64 wchunk;  // rows per wave range (multiple of kTile)
+    u64 chunk;   // rows per block = kWaves * wchunk
+    u32 G;       // blocks (<= kMaxBlocks)
+    u32 sub;     // rows per sub-chunk (multiple of kTile), chunk/sub <= kMaxSubs
+    u32 subs;    // sub-chunks per block
+    u32 m;       // nodes
+    u32 mwords;  // ceil(m/32)
+};
+Plan make_plan(u64 n, u32 m, u32 max_blocks);
+
+// Accumulators of one solve, device resident (all 64-bit so they can be atomically added).
+struct DevStats {
+    u64 kept, evicted, claimants, spillcand;            // k_scan   (rows)
+    u64 load_kept, load_claim_tot, n_cut;               // k_resolve
+    u64 rejected, load_rejected;                        // k_apply_cut
+    u64 spilled, load_spilled, unplaced, load_unplaced; // k_spill_apply
+    u64 rounds_run;                                     // k_spill_prepare
+    u64 evicted_clean;                                  // k_clean
+    u64 err;                                            // invalid entries seen by batch kernels
+};
+
+// Scratch of one solve over one table (real table or the virtual table of place_pending).
+struct SolveBufs {
+    u64* H;          // [G][2m]  per-block load histograms: kept-by-cur | claim-by-aff
+    u64* blkstat;    // [G][4]   kept, evicted, claimants rows per block
+    u64* wsp_sum[2]; // [G*kWaves] spill-candidate load per wave range (ping-pong over rounds)
+    u32* wsp_cnt[2]; // [G*kWaves]
+    u64* wsp_base;   // [G*kWaves] exclusive prefix of wsp_sum
+    u64* used_kept;  // [m] load of kept rows (+ used_base for the virtual table)
+    u64* used_cur;   // [m] used_kept + admitted claims + admitted spills
+    u64* claim_tot;  // [m]
+    u32* cutblk;     // [m] block containing the cut or kNoCut
+    u64* budget;     // [m] free capacity left at the start of the cut block
+    u64* admpre;     // [m] claim load admitted before the cut block
+    u32* cutidx;     // [m] row index of the first rejected claimant or kNoCut
+    u64* T;          // [m][kMaxSubs] claim load per sub-chunk of the node's cut block
+    u64* wfC;        // [m+1] cumulative free capacity in water-fill order (saturating)
+    u32* wfOrder;    // [m]
+    u32* wfCnt;      // [1]
+    DevStats* stats;
+};
+
+// table columns; for the real table cur/next are the ping-pong assignment columns
+struct Table {
+    const u32* cur;
+    const u32* load;
+    const u32* aff;
+    u32* next;
+};
+
+struct NodeTab {
+    const u64* cap;         // [m]
+    const u32* alive_bits;  // [mwords]
+    const u64* used_base;   // [m] or nullptr (virtual table: the committed `used`)
+};
+
+// --- solve pipeline ---
+void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s);
+void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, hipStream_t s);
+void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s);
+void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
+                        hipStream_t s);
+
+// --- CRUD over the assignment column ---
+void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s);
+void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos_scratch,
+                   DevStats* st, hipStream_t s);
+void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
+                   DevStats* st, hipStream_t s);
+void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s);
+void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s);
+void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s);
+void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipStream_t s);
+
+// --- place_pending glue (virtual table) ---
+void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
+                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s);
+void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const u32* req, u64 n, u32* pos_scratch,
+                      u32* vcur, u32* vload, u32* vaff, hipStream_t s);
+void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
+                       u32* pos_scratch, const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node,
+                       u32* out_flag, hipStream_t s);
+
+size_t scan_lds_bytes(u32 m);
+
+}  // namespace riogp

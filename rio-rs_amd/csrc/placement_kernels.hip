@@ -1,0 +1,1033 @@
+// placement_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the batched object-placement solver.
+//
+// What is replaced (paths relative to /root/reference):
+//   LocalObjectPlacement::{lookup,update,remove,clean_server}  rio-rs/src/object_placement/local.rs:22-68
+//   Service::get_or_create_placement / check_address_mismatch  rio-rs/src/service.rs:193-298
+// by kernels over a dense table in HBM (object: cur/load/aff u32 columns; node: cap/alive/used).
+//
+// Everything here is integer/index work bounded by HBM bandwidth — no MFMA.  Design rules used
+// (guides: cdna_hip_programming.md §2, §6 G2/G11/G12/G13; MI355X_MICROARCH.md §LDS, §price list):
+//   * 64-wide waves, every column access is a coalesced dwordx4 (16 B/lane, 1 KiB per wave-instr);
+//   * each wave owns a CONTIGUOUS row range, so "index order" = (block, wave, iteration, lane,
+//     element) order and ordered prefix sums never need a block-wide barrier in the streaming loop;
+//   * one 1024-thread workgroup per CU (256 workgroups = 256 CUs = 8 XCDs x 32) so a solve has
+//     only 256 per-node histograms to reduce; per-node counters live in LDS (ds_add_u64), never
+//     in global atomics on the streaming path;
+//   * inter-workgroup dependencies are cut at kernel boundaries (per-XCD L2s are not coherent),
+//     never hand-rolled grid barriers;
+//   * all cross-row decisions are integer sums and index-ordered prefixes: results do not depend
+//     on dispatch order, so the output is bit-identical to the sequential oracle.
+#include "placement_kernels.h"
+
+namespace riogp {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
+    u32 lo = __shfl_up((u32)v, d, 64), hi = __shfl_up((u32)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int d) {
+    u32 lo = __shfl_xor((u32)v, d, 64), hi = __shfl_xor((u32)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+    u32 lo = __shfl((u32)v, src, 64), hi = __shfl((u32)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ u64 wave_incl_scan(u64 v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 t = shfl_up64(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 sat_add(u64 a, u64 b) {
+    u64 s = a + b;
+    return s < a ? ~0ull : s;
+}
+__device__ __forceinline__ u64 wave_incl_scan_sat(u64 v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 t = shfl_up64(v, d);
+        if (lane >= d) v = sat_add(v, t);
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_xor64(v, d);
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum32(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+constexpr int kSmall = 128;  // bytes of small per-block scratch at the head of the dynamic LDS region
+__device__ __forceinline__ bool bit_of(const u32* bits, u32 j) { return (bits[j >> 5] >> (j & 31)) & 1u; }
+
+Plan make_plan(u64 n, u32 m, u32 max_blocks) {
+    Plan p;
+    p.n = n;
+    p.m = m;
+    p.mwords = (m + 31) / 32;
+    if (max_blocks == 0 || max_blocks > kMaxBlocks) max_blocks = kMaxBlocks;
+    u64 tiles = (n + kTile - 1) / kTile;
+    if (tiles == 0) tiles = 1;
+    u64 g = (tiles + kWaves - 1) / kWaves;
+    if (g > max_blocks) g = max_blocks;
+    u64 wtiles = (tiles + g * kWaves - 1) / (g * kWaves);
+    p.wchunk = wtiles * kTile;
+    p.chunk = p.wchunk * kWaves;
+    p.G = (u32)((n + p.chunk - 1) / p.chunk);
+    if (p.G == 0) p.G = 1;
+    u64 tpb = wtiles * kWaves;  // tiles per block
+    u64 sub_tiles = (tpb + kMaxSubs - 1) / kMaxSubs;
+    p.sub = (u32)(sub_tiles * kTile);
+    p.subs = (u32)((p.chunk + p.sub - 1) / p.sub);
+    return p;
+}
+
+size_t scan_lds_bytes(u32 m) {
+    u32 mwords = (m + 31) / 32;
+    size_t b = kSmall + (size_t)2 * m * sizeof(u64) + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 64;
+    return (b + 15) & ~(size_t)15;
+}
+
+// Row classification shared by every streaming kernel (must be identical everywhere):
+//   kept      placed on a live node            -> sticky               (service.rs:241-242)
+//   claimant  pending, affinity node is live   -> first touch          (service.rs:244-252)
+//   else      pending, goes to the water-fill
+// VIRT (virtual table of place_pending): rows are requests; "kept" = already placed (dead nodes
+// were evicted beforehand), kSkipMark rows are duplicate requests and take no part.
+template <bool VIRT>
+__device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv) {
+    if (VIRT) {
+        if (c == kSkipMark) return 3;
+        if (c < m) return 0;
+    } else {
+        if (c < m && bit_of(alv, c)) return 0;
+    }
+    if (a < m && bit_of(alv, a)) return 1;
+    return 2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  k_scan — THE streaming kernel: one pass over cur/load/aff (12 B/row read), optimistic
+//     write of the new assignment (4 B/row), per-block per-node load histograms in LDS.
+//     Algorithmic traffic 16 B/row; everything else is <3 % overhead:
+//     H rows 2*m*8 B per block, 3 words per wave.
+// ------------------------------------------------------------------------------------------------
+template <bool VIRT>
+__global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                 const u32* __restrict__ aff, u32* __restrict__ next,
+                                                 const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
+                                                 u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
+                                                 u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m;
+    u32* bst = reinterpret_cast<u32*>(smem);                 // [4] (first 128 B: small scratch, G17)
+    u64* hist = reinterpret_cast<u64*>(smem + kSmall);       // [2m] kept-by-cur | claim-by-aff
+    u32* alv = reinterpret_cast<u32*>(hist + 2 * m);         // [mwords]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 k = tid; k < 2 * m; k += kBlock) hist[k] = 0;
+    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    if (tid < 4) bst[tid] = 0;
+    if (blockIdx.x == 0 && tid == 0) {  // accumulators later kernels add into
+        stats->load_kept = 0; stats->load_claim_tot = 0; stats->n_cut = 0;
+        stats->rejected = 0; stats->load_rejected = 0;
+        stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
+        stats->rounds_run = 0;
+    }
+    __syncthreads();
+
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    const u64 wstart = gw * p.wchunk;
+    u64 wend = wstart + p.wchunk;
+    if (wend > p.n) wend = p.n;
+
+    u64 sp_sum = 0;
+    u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;
+
+    u64 it = wstart;
+    uint4 cv, av, lv;
+    if (it < wend) {
+        const u64 i = it + (u64)lane * 4;
+        cv = *reinterpret_cast<const uint4*>(cur + i);
+        av = *reinterpret_cast<const uint4*>(aff + i);
+        lv = *reinterpret_cast<const uint4*>(load + i);
+    }
+    while (it < wend) {
+        const u64 nit = it + kTile;
+        uint4 cn, an, ln;
+        if (nit < wend) {  // software prefetch of the next tile (wave-uniform branch)
+            const u64 i = nit + (u64)lane * 4;
+            cn = *reinterpret_cast<const uint4*>(cur + i);
+            an = *reinterpret_cast<const uint4*>(aff + i);
+            ln = *reinterpret_cast<const uint4*>(load + i);
+        }
+        const u64 i0 = it + (u64)lane * 4;
+        uint4 ov;
+#define RIOGP_ROW(C, A, L, O, E)                                          \
+        if (i0 + E < wend) {                                              \
+            const int cls = classify<VIRT>(C, A, m, alv);                 \
+            if (cls == 0) {                                               \
+                O = C;                                                    \
+                if (!VIRT) { atomicAdd(&hist[C], (u64)L); ++kept_cnt; }   \
+            } else if (cls == 1) {                                        \
+                O = A;                                                    \
+                atomicAdd(&hist[m + A], (u64)L);                          \
+                ++claim_cnt;                                              \
+                if (!VIRT && C != kNone) ++evict_cnt;                     \
+            } else if (cls == 2) {                                        \
+                O = kSpillMark;                                           \
+                sp_sum += L; ++sp_cnt;                                    \
+                if (!VIRT && C != kNone) ++evict_cnt;                     \
+            } else {                                                      \
+                O = kSkipMark;                                            \
+            }                                                             \
+        } else { O = kNone; }
+        RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
+        RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
+        RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
+        RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
+#undef RIOGP_ROW
+        if (i0 + 3 < wend) {
+            *reinterpret_cast<uint4*>(next + i0) = ov;
+        } else {
+            if (i0 + 0 < wend) next[i0 + 0] = ov.x;
+            if (i0 + 1 < wend) next[i0 + 1] = ov.y;
+            if (i0 + 2 < wend) next[i0 + 2] = ov.z;
+        }
+        it = nit;
+        cv = cn; av = an; lv = ln;
+    }
+
+    // per-wave spill-candidate totals (index-ordered prefix over wave ranges comes later)
+    sp_sum = wave_sum(sp_sum);
+    sp_cnt = wave_sum32(sp_cnt);
+    kept_cnt = wave_sum32(kept_cnt);
+    evict_cnt = wave_sum32(evict_cnt);
+    claim_cnt = wave_sum32(claim_cnt);
+    if (lane == 0) {
+        wsp_sum[gw] = sp_sum;
+        wsp_cnt[gw] = sp_cnt;
+        atomicAdd(&bst[0], kept_cnt);
+        atomicAdd(&bst[1], evict_cnt);
+        atomicAdd(&bst[2], claim_cnt);
+    }
+    __syncthreads();
+    u64* Hrow = H + (size_t)blockIdx.x * 2 * m;
+    for (u32 k = tid; k < 2 * m; k += kBlock) Hrow[k] = hist[k];
+    if (tid < 3) blkstat[(size_t)blockIdx.x * 4 + tid] = bst[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  k_resolve — per node: used = sum over blocks, free, claim total, and the block in which the
+//     index-ordered claim prefix first exceeds free ("cut block").  16 nodes per workgroup,
+//     16 row-groups x 16 nodes: every H load of a thread is issued before the first wait.
+// ------------------------------------------------------------------------------------------------
+constexpr int kResNodes = 16, kResGroups = 16, kResRows = kMaxBlocks / kResGroups;  // 16 rows/thread
+
+__global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, const u64* __restrict__ blkstat,
+                                                 const u32* __restrict__ wsp_cnt, Plan p,
+                                                 const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
+                                                 const u64* __restrict__ used_base, u64* __restrict__ used_kept,
+                                                 u64* __restrict__ used_cur, u64* __restrict__ claim_tot,
+                                                 u32* __restrict__ cutblk, u64* __restrict__ budget,
+                                                 u64* __restrict__ admpre, u32* __restrict__ cutidx,
+                                                 DevStats* __restrict__ stats) {
+    __shared__ u64 su[kResGroups][kResNodes], sc[kResGroups][kResNodes];
+    __shared__ u64 red[8];
+    const int tid = threadIdx.x, nd = tid & (kResNodes - 1), grp = tid >> 4;
+    const u32 m = p.m, G = p.G;
+    const u32 j = blockIdx.x * kResNodes + nd;
+    const bool valid = j < m;
+    const u32 rows = (G + kResGroups - 1) / kResGroups;  // <= kResRows
+    u64 cu[kResRows], cc[kResRows];
+    u64 tu = 0, tc = 0;
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) {
+        const u32 row = grp * rows + r;
+        const bool ok = valid && (u32)r < rows && row < G;
+        cu[r] = ok ? H[(size_t)row * 2 * m + j] : 0;
+        cc[r] = ok ? H[(size_t)row * 2 * m + m + j] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) { tu += cu[r]; tc += cc[r]; }
+    su[grp][nd] = tu;
+    sc[grp][nd] = tc;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    u64 used = 0, ctot = 0, pre = 0;
+#pragma unroll
+    for (int g = 0; g < kResGroups; ++g) {
+        used += su[g][nd];
+        ctot += sc[g][nd];
+        if (g < grp) pre += sc[g][nd];
+    }
+    if (valid) {
+        const u64 kept_load = used;
+        if (used_base) used += used_base[j];
+        const bool alive = bit_of(alive_bits, j);
+        const u64 c = cap[j];
+        const u64 fre = (alive && c > used) ? c - used : 0;
+        if (ctot <= fre) {
+            if (grp == 0) {
+                used_kept[j] = used;
+                used_cur[j] = used + ctot;
+                claim_tot[j] = ctot;
+                cutblk[j] = kNoCut;
+                cutidx[j] = kNoCut;
+                budget[j] = fre;
+                admpre[j] = ctot;
+                atomicAdd(&red[0], kept_load);
+                atomicAdd(&red[1], ctot);
+            }
+        } else {
+            if (grp == 0) {
+                used_kept[j] = used;
+                claim_tot[j] = ctot;
+                atomicAdd(&red[0], kept_load);
+                atomicAdd(&red[1], ctot);
+                atomicAdd(&red[2], 1ull);
+            }
+            if (pre <= fre && pre + tc > fre) {  // the cut is inside this thread's row group
+                u64 cum = pre;
+#pragma unroll
+                for (int r = 0; r < kResRows; ++r) {
+                    if (cum <= fre && cum + cc[r] > fre) {
+                        cutblk[j] = grp * rows + r;
+                        budget[j] = fre - cum;
+                        admpre[j] = cum;
+                    }
+                    cum += cc[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (red[0]) atomicAdd(&stats->load_kept, red[0]);
+        if (red[1]) atomicAdd(&stats->load_claim_tot, red[1]);
+        if (red[2]) atomicAdd(&stats->n_cut, red[2]);
+    }
+    if (blockIdx.x == 0) {  // row counters of the scan: plain reduction, no atomics across launches
+        u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (u32 b = tid; b < G; b += 256) {
+            a0 += blkstat[(size_t)b * 4 + 0];
+            a1 += blkstat[(size_t)b * 4 + 1];
+            a2 += blkstat[(size_t)b * 4 + 2];
+        }
+        for (u32 w = tid; w < G * kWaves; w += 256) a3 += wsp_cnt[w];
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+        __shared__ u64 part[4][4];
+        if ((tid & 63) == 0) { part[tid >> 6][0] = a0; part[tid >> 6][1] = a1; part[tid >> 6][2] = a2; part[tid >> 6][3] = a3; }
+        __syncthreads();
+        if (tid == 0) {
+            stats->kept = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+            stats->evicted = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+            stats->claimants = part[0][2] + part[1][2] + part[2][2] + part[3][2];
+            stats->spillcand = part[0][3] + part[1][3] + part[2][3] + part[3][3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3a k_cut_subhist — only when some node has a cut: per-(node, sub-chunk) claim load inside the
+//     node's cut block.  One more pass over the blocks that contain a cut.
+// ------------------------------------------------------------------------------------------------
+template <bool VIRT>
+__global__ __launch_bounds__(kBlock) void k_cut_subhist(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                        const u32* __restrict__ aff,
+                                                        const u32* __restrict__ alive_bits, Plan p,
+                                                        const u32* __restrict__ cutblk, u64* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m;
+    u32& any = *reinterpret_cast<u32*>(smem);
+    u32* cb = reinterpret_cast<u32*>(smem + kSmall);  // [m]
+    u32* alv = cb + m;                                 // [mwords]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) any = 0;
+    __syncthreads();
+    u32 mine = 0;
+    for (u32 k = tid; k < m; k += kBlock) {
+        const u32 v = cutblk[k];
+        cb[k] = v;
+        mine |= (v == blockIdx.x);
+    }
+    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    if (mine) any = 1;
+    __syncthreads();
+    if (!any) return;
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    const u64 bstart = (u64)blockIdx.x * p.chunk;
+    const u64 wstart = gw * p.wchunk;
+    u64 wend = wstart + p.wchunk;
+    if (wend > p.n) wend = p.n;
+    for (u64 it = wstart; it < wend; it += kTile) {
+        const u64 i0 = it + (u64)lane * 4;
+        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
+        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
+        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+        const u32 t = (u32)((i0 - bstart) / p.sub);  // 4 consecutive rows share a sub-chunk (sub % 256 == 0)
+#define RIOGP_ROW(C, A, L, E)                                                                   \
+        if (i0 + E < wend && classify<VIRT>(C, A, m, alv) == 1 && cb[A] == blockIdx.x)           \
+            atomicAdd(&T[(size_t)A * kMaxSubs + t], (u64)L);
+        RIOGP_ROW(cv.x, av.x, lv.x, 0)
+        RIOGP_ROW(cv.y, av.y, lv.y, 1)
+        RIOGP_ROW(cv.z, av.z, lv.z, 2)
+        RIOGP_ROW(cv.w, av.w, lv.w, 3)
+#undef RIOGP_ROW
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b k_cut_exact — one wave per node with a cut: find the sub-chunk, then the exact row at which
+//     the inclusive claim prefix first exceeds the node's free capacity.
+// ------------------------------------------------------------------------------------------------
+template <bool VIRT>
+__global__ __launch_bounds__(256) void k_cut_exact(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                   const u32* __restrict__ aff, const u32* __restrict__ alive_bits,
+                                                   Plan p, const u32* __restrict__ cutblk,
+                                                   const u64* __restrict__ budget, const u64* __restrict__ admpre,
+                                                   const u64* __restrict__ T, const u64* __restrict__ used_kept,
+                                                   u32* __restrict__ cutidx, u64* __restrict__ used_cur) {
+    const int lane = threadIdx.x & 63;
+    const u32 j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= p.m) return;
+    const u32 b = cutblk[j];
+    if (b == kNoCut) return;
+    const u64 bud = budget[j];
+    // (1) sub-chunk: first t with prefix(T[j][0..t]) > bud
+    u64 acc = 0, pre_sub = 0;
+    u32 tstar = 0;
+    bool found = false;
+    for (u32 g = 0; g < p.subs && !found; g += 64) {
+        const u32 t = g + lane;
+        const u64 v = t < p.subs ? T[(size_t)j * kMaxSubs + t] : 0;
+        const u64 inc = wave_incl_scan(v, lane);
+        const u64 mask = __ballot(acc + inc > bud);
+        if (mask) {
+            const int fl = __ffsll((long long)mask) - 1;
+            tstar = g + fl;
+            pre_sub = acc + shfl64(inc - v, fl);
+            found = true;
+        } else {
+            acc += shfl64(inc, 63);
+        }
+    }
+    // (2) exact row inside the sub-chunk
+    const u64 bud2 = bud - pre_sub;
+    const u64 start = (u64)b * p.chunk + (u64)tstar * p.sub;
+    u64 end = start + p.sub;
+    if (end > (u64)(b + 1) * p.chunk) end = (u64)(b + 1) * p.chunk;
+    if (end > p.n) end = p.n;
+    u64 acc2 = 0, cut_row = kNoCut, adm_in = 0;
+    found = false;
+    for (u64 i0 = start; i0 < end && !found; i0 += 64) {
+        const u64 i = i0 + lane;
+        u64 v = 0;
+        if (i < end) {
+            const u32 c = cur[i], a = aff[i];
+            if (a == j && classify<VIRT>(c, a, p.m, alive_bits) == 1) v = load[i];
+            else v = ~0ull;  // marker: not a claimant of j
+        } else {
+            v = ~0ull;
+        }
+        const bool is_cl = v != ~0ull;
+        const u64 l = is_cl ? v : 0;
+        const u64 inc = wave_incl_scan(l, lane);
+        const u64 mask = __ballot(is_cl && acc2 + inc > bud2);
+        if (mask) {
+            const int fl = __ffsll((long long)mask) - 1;
+            cut_row = i0 + fl;
+            adm_in = acc2 + shfl64(inc - l, fl);
+            found = true;
+        } else {
+            acc2 += shfl64(inc, 63);
+        }
+    }
+    if (lane == 0) {
+        cutidx[j] = (u32)cut_row;
+        used_cur[j] = used_kept[j] + admpre[j] + pre_sub + adm_in;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  k_apply_cut — claimants at or beyond their node's cut row lose the optimistic assignment and
+//     join the spill set; per-wave spill totals are rebuilt (candidates + rejected).
+// ------------------------------------------------------------------------------------------------
+template <bool VIRT>
+__global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                      const u32* __restrict__ aff, u32* __restrict__ next,
+                                                      const u32* __restrict__ alive_bits, Plan p,
+                                                      const u32* __restrict__ cutidx, u64* __restrict__ wsp_sum,
+                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m;
+    u64* red = reinterpret_cast<u64*>(smem);           // [2]
+    u32* ci = reinterpret_cast<u32*>(smem + kSmall);   // [m]
+    u32* alv = ci + m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 k = tid; k < m; k += kBlock) ci[k] = cutidx[k];
+    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    if (tid < 2) red[tid] = 0;
+    __syncthreads();
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    const u64 wstart = gw * p.wchunk;
+    u64 wend = wstart + p.wchunk;
+    if (wend > p.n) wend = p.n;
+    u64 sp_sum = 0, rej_sum = 0;
+    u32 sp_cnt = 0, rej_cnt = 0;
+    for (u64 it = wstart; it < wend; it += kTile) {
+        const u64 i0 = it + (u64)lane * 4;
+        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
+        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
+        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+#define RIOGP_ROW(C, A, L, E)                                                    \
+        if (i0 + E < wend) {                                                     \
+            const int cls = classify<VIRT>(C, A, m, alv);                        \
+            if (cls == 2) { sp_sum += L; ++sp_cnt; }                             \
+            else if (cls == 1 && (u32)(i0 + E) >= ci[A]) {                       \
+                next[i0 + E] = kSpillMark;                                       \
+                sp_sum += L; ++sp_cnt; rej_sum += L; ++rej_cnt;                  \
+            }                                                                    \
+        }
+        RIOGP_ROW(cv.x, av.x, lv.x, 0)
+        RIOGP_ROW(cv.y, av.y, lv.y, 1)
+        RIOGP_ROW(cv.z, av.z, lv.z, 2)
+        RIOGP_ROW(cv.w, av.w, lv.w, 3)
+#undef RIOGP_ROW
+    }
+    sp_sum = wave_sum(sp_sum);
+    sp_cnt = wave_sum32(sp_cnt);
+    rej_sum = wave_sum(rej_sum);
+    rej_cnt = wave_sum32(rej_cnt);
+    if (lane == 0) {
+        wsp_sum[gw] = sp_sum;
+        wsp_cnt[gw] = sp_cnt;
+        if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
+    }
+    __syncthreads();
+    if (tid == 0 && red[0]) {
+        atomicAdd(&stats->rejected, red[0]);
+        atomicAdd(&stats->load_rejected, red[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// KS  k_spill_prepare — one workgroup: free capacity per node, rank nodes by (free desc, index asc),
+//     saturating cumulative free C[], and the exclusive prefix of the per-wave spill totals.
+// ------------------------------------------------------------------------------------------------
+__device__ u64 block_excl_scan_1024(u64 v, bool saturating, u64* lds_part /*[16]*/, u64* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 inc = saturating ? wave_incl_scan_sat(v, lane) : wave_incl_scan(v, lane);
+    if (lane == 63) lds_part[wave] = inc;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+    for (int w = 0; w < kWaves; ++w) {
+        const u64 x = lds_part[w];
+        if (w < wave) base = saturating ? sat_add(base, x) : base + x;
+        tot = saturating ? sat_add(tot, x) : tot + x;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    // exclusive = base + (inc - v); with saturation inc-v is wrong once saturated, recompute:
+    u64 excl;
+    if (saturating) {
+        u64 prev = shfl_up64(inc, 1);
+        if (lane == 0) prev = 0;
+        excl = sat_add(base, prev);
+    } else {
+        excl = base + (inc - v);
+    }
+    return excl;
+}
+
+__global__ __launch_bounds__(kBlock) void k_spill_prepare(Plan p, const u64* __restrict__ cap,
+                                                          const u32* __restrict__ alive_bits,
+                                                          const u64* __restrict__ used_cur,
+                                                          const u64* __restrict__ wsp_sum,
+                                                          const u32* __restrict__ wsp_cnt,
+                                                          u64* __restrict__ wsp_base, u64* __restrict__ wfC,
+                                                          u32* __restrict__ wfOrder, u32* __restrict__ wfCnt,
+                                                          DevStats* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m;
+    const u32 mp = (m + kBlock - 1) / kBlock * kBlock;  // padded
+    u64* part = reinterpret_cast<u64*>(smem);                  // [16]
+    u32& nz_total = *reinterpret_cast<u32*>(smem + 128);
+    u32& cnt_total = *reinterpret_cast<u32*>(smem + 132);
+    u64* fre = reinterpret_cast<u64*>(smem + 2 * kSmall);      // [mp] free by node
+    u64* sfr = fre + mp;                                        // [mp] free by rank
+    const int tid = threadIdx.x;
+    if (tid == 0) { nz_total = 0; cnt_total = 0; }
+    for (u32 j = tid; j < mp; j += kBlock) {
+        u64 f = 0;
+        if (j < m) {
+            const u64 c = cap[j], u = used_cur[j];
+            f = (bit_of(alive_bits, j) && c > u) ? c - u : 0;
+        }
+        fre[j] = f;
+        sfr[j] = 0;
+    }
+    __syncthreads();
+    // rank by counting: unique total order (free desc, index asc)
+    u32 nz = 0;
+    for (u32 j = tid; j < m; j += kBlock) {
+        const u64 f = fre[j];
+        if (f == 0) continue;
+        u32 rank = 0;
+        for (u32 k = 0; k < m; ++k) {
+            const u64 g = fre[k];
+            rank += (g > f) || (g == f && k < j);
+        }
+        sfr[rank] = f;
+        wfOrder[rank] = j;
+        ++nz;
+    }
+    nz = wave_sum32(nz);
+    if ((tid & 63) == 0 && nz) atomicAdd(&nz_total, nz);
+    __syncthreads();
+    // saturating inclusive scan over ranks: each thread owns mp/1024 consecutive ranks
+    const u32 per = mp / kBlock;
+    u64 loc = 0;
+    for (u32 q = 0; q < per; ++q) loc = sat_add(loc, sfr[tid * per + q]);
+    u64 excl = block_excl_scan_1024(loc, true, part, nullptr);
+    if (tid == 0) { wfC[0] = 0; *wfCnt = nz_total; }
+    for (u32 q = 0; q < per; ++q) {
+        const u32 rk = tid * per + q;
+        excl = sat_add(excl, sfr[rk]);
+        if (rk < m) wfC[rk + 1] = excl;
+    }
+    // exclusive prefix of spill load over wave ranges (index order) + remaining row count
+    const u32 nw = p.G * kWaves;  // <= 4096 = 4 per thread
+    u64 v[4], s = 0;
+    u32 cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 w = tid * 4 + q;
+        v[q] = w < nw ? wsp_sum[w] : 0;
+        cnt += w < nw ? wsp_cnt[w] : 0;
+        s += v[q];
+    }
+    u64 ex = block_excl_scan_1024(s, false, part, nullptr);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 w = tid * 4 + q;
+        if (w < nw) wsp_base[w] = ex;
+        ex += v[q];
+    }
+    cnt = wave_sum32(cnt);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&cnt_total, cnt);
+    __syncthreads();
+    if (tid == 0 && cnt_total) stats->rounds_run += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  k_spill_apply — water-fill: the spill set in index order has exclusive load prefix Q; the
+//     node whose cumulative-free interval [C[k], C[k+1]) contains Q takes the row iff it fits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ load, u32* __restrict__ next, Plan p,
+                                                        const u64* __restrict__ wsp_base,
+                                                        const u64* __restrict__ wfC, const u32* __restrict__ wfOrder,
+                                                        const u32* __restrict__ wfCnt, u64* __restrict__ used_cur,
+                                                        u64* __restrict__ wsp_sum_out, u32* __restrict__ wsp_cnt_out,
+                                                        int last, DevStats* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m;
+    u64* red = reinterpret_cast<u64*>(smem);           // [4]
+    u64* C = reinterpret_cast<u64*>(smem + kSmall);    // [m+1]
+    u64* adm = C + (m + 1);                            // [m] admitted load by node (this block)
+    u32* ord = reinterpret_cast<u32*>(adm + m);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 cnt = *wfCnt;
+    for (u32 k = tid; k <= m; k += kBlock) C[k] = k <= cnt ? wfC[k] : ~0ull;
+    for (u32 k = tid; k < m; k += kBlock) { adm[k] = 0; ord[k] = k < cnt ? wfOrder[k] : kNone; }
+    if (tid < 4) red[tid] = 0;
+    __syncthreads();
+    const u64 F = C[cnt];
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    const u64 wstart = gw * p.wchunk;
+    u64 wend = wstart + p.wchunk;
+    if (wend > p.n) wend = p.n;
+    u64 run = wsp_base[gw];
+    u64 rem_sum = 0, pl_sum = 0;
+    u32 rem_cnt = 0, pl_cnt = 0;
+    for (u64 it = wstart; it < wend; it += kTile) {
+        const u64 i0 = it + (u64)lane * 4;
+        const uint4 nv = *reinterpret_cast<const uint4*>(next + i0);
+        const bool mk0 = i0 + 0 < wend && nv.x == kSpillMark, mk1 = i0 + 1 < wend && nv.y == kSpillMark;
+        const bool mk2 = i0 + 2 < wend && nv.z == kSpillMark, mk3 = i0 + 3 < wend && nv.w == kSpillMark;
+        if (!__ballot(mk0 | mk1 | mk2 | mk3)) continue;  // wave-uniform: nothing to spill in this tile
+        const u64 l0 = mk0 ? load[i0 + 0] : 0, l1 = mk1 ? load[i0 + 1] : 0;
+        const u64 l2 = mk2 ? load[i0 + 2] : 0, l3 = mk3 ? load[i0 + 3] : 0;
+        const u64 lsum = l0 + l1 + l2 + l3;
+        const u64 inc = wave_incl_scan(lsum, lane);
+        u64 Q = run + (inc - lsum);
+        run += shfl64(inc, 63);
+#define RIOGP_ROW(MK, L, E)                                                       \
+        if (MK) {                                                                 \
+            u32 nd = kNone;                                                       \
+            if (cnt && Q < F) {                                                   \
+                u32 lo = 0, hi = cnt;                                             \
+                while (hi - lo > 1) {                                             \
+                    const u32 mid = lo + ((hi - lo) >> 1);                        \
+                    if (C[mid] <= Q) lo = mid; else hi = mid;                     \
+                }                                                                 \
+                if (Q + L <= C[lo + 1]) nd = ord[lo];                             \
+            }                                                                     \
+            if (nd != kNone) {                                                    \
+                next[i0 + E] = nd;                                                \
+                atomicAdd(&adm[nd], (u64)L);                                      \
+                pl_sum += L; ++pl_cnt;                                            \
+            } else {                                                              \
+                if (last) next[i0 + E] = kNone;                                   \
+                rem_sum += L; ++rem_cnt;                                          \
+            }                                                                     \
+            Q += L;                                                               \
+        }
+        RIOGP_ROW(mk0, l0, 0)
+        RIOGP_ROW(mk1, l1, 1)
+        RIOGP_ROW(mk2, l2, 2)
+        RIOGP_ROW(mk3, l3, 3)
+#undef RIOGP_ROW
+    }
+    rem_sum = wave_sum(rem_sum);
+    rem_cnt = wave_sum32(rem_cnt);
+    pl_sum = wave_sum(pl_sum);
+    pl_cnt = wave_sum32(pl_cnt);
+    if (lane == 0) {
+        wsp_sum_out[gw] = rem_sum;
+        wsp_cnt_out[gw] = rem_cnt;
+        if (pl_cnt) { atomicAdd(&red[0], (u64)pl_cnt); atomicAdd(&red[1], pl_sum); }
+        if (last && rem_cnt) { atomicAdd(&red[2], (u64)rem_cnt); atomicAdd(&red[3], rem_sum); }
+    }
+    __syncthreads();
+    for (u32 k = tid; k < m; k += kBlock)
+        if (adm[k]) atomicAdd(&used_cur[k], adm[k]);  // integer sums: order-independent
+    if (tid == 0) {
+        if (red[0]) { atomicAdd(&stats->spilled, red[0]); atomicAdd(&stats->load_spilled, red[1]); }
+        if (red[2]) { atomicAdd(&stats->unplaced, red[2]); atomicAdd(&stats->load_unplaced, red[3]); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CRUD kernels over the assignment column (local.rs:22-68)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_u32(u32* p, u64 n, u32 v) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_pack_alive(const uint8_t* alive, u32 m, u32* bits) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (m + 31) / 32) return;
+    u32 v = 0;
+    for (u32 b = 0; b < 32; ++b) {
+        const u32 j = w * 32 + b;
+        if (j < m && alive[j]) v |= 1u << b;
+    }
+    bits[w] = v;
+}
+
+// lookup (local.rs:42-49): 12 B/lookup — idx read, assign gather, out write
+__global__ void k_lookup(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u64 n,
+                         u32* __restrict__ out, DevStats* st) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k];
+        if (i < n_obj) out[k] = assign[i];
+        else { out[k] = kNone; atomicAdd(&st->err, 1ull); }
+    }
+}
+
+// update (local.rs:22-40), sequential last-writer-wins: phase 1 elects, per row, the highest
+// batch position (atomicMin of the reversed position in a row-sized scratch), phase 2 lets the
+// winner write and resets the scratch.
+__global__ void k_update_elect(u64 n_obj, u32 m, const u32* __restrict__ idx, const u32* __restrict__ node, u64 n,
+                               u32* __restrict__ pos, DevStats* st) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k], nd = node[k];
+        if (i < n_obj && (nd == kNone || nd < m)) atomicMin(&pos[i], (u32)(n - 1 - k));
+        else atomicAdd(&st->err, 1ull);
+    }
+}
+__global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ idx,
+                               const u32* __restrict__ node, u64 n, const u32* __restrict__ pos) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k], nd = node[k];
+        if (i < n_obj && (nd == kNone || nd < m) && pos[i] == (u32)(n - 1 - k)) assign[i] = nd;
+    }
+}
+__global__ void k_pos_reset(const u32* __restrict__ idx, u64 n, u64 n_obj, u32* __restrict__ pos) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k];
+        if (i < n_obj) pos[i] = kNone;
+    }
+}
+
+// remove (local.rs:60-68): exchange makes duplicate removals of one row decrement `used` once
+__global__ void k_remove(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ load,
+                         const u32* __restrict__ idx, u64 n, u64* __restrict__ used, DevStats* st) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k];
+        if (i >= n_obj) { atomicAdd(&st->err, 1ull); continue; }
+        const u32 old = atomicExch(&assign[i], kNone);
+        if (used && old < m) atomicAdd(&used[old], (u64)0 - (u64)load[i]);
+    }
+}
+
+// clean_server(s) (local.rs:51-58): one coalesced pass, 4 B read per row, 4 B written per evicted row
+__global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_obj, u32 m,
+                                               const u32* __restrict__ dead_bits, u64* __restrict__ used,
+                                               DevStats* st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32* db = reinterpret_cast<u32*>(smem);
+    __shared__ u32 any;
+    __shared__ u32 ev_total;
+    const u32 mwords = (m + 31) / 32;
+    const int tid = threadIdx.x;
+    if (tid == 0) { any = 0; ev_total = 0; }
+    __syncthreads();
+    u32 mine = 0;
+    for (u32 k = tid; k < mwords; k += blockDim.x) { const u32 v = dead_bits[k]; db[k] = v; mine |= v; }
+    if (mine) any = 1;
+    __syncthreads();
+    if (!any) return;
+    if (blockIdx.x == 0 && used)
+        for (u32 j = tid; j < m; j += blockDim.x)
+            if (bit_of(db, j)) used[j] = 0;
+    u32 ev = 0;
+    const u64 nvec = (n_obj + 3) / 4;
+    for (u64 v = (u64)blockIdx.x * blockDim.x + tid; v < nvec; v += (u64)gridDim.x * blockDim.x) {
+        const u64 i0 = v * 4;
+        uint4 c = *reinterpret_cast<const uint4*>(assign + i0);
+        const bool e0 = i0 + 0 < n_obj && c.x < m && bit_of(db, c.x), e1 = i0 + 1 < n_obj && c.y < m && bit_of(db, c.y);
+        const bool e2 = i0 + 2 < n_obj && c.z < m && bit_of(db, c.z), e3 = i0 + 3 < n_obj && c.w < m && bit_of(db, c.w);
+        if (e0 | e1 | e2 | e3) {
+            if (e0) assign[i0 + 0] = kNone;
+            if (e1) assign[i0 + 1] = kNone;
+            if (e2) assign[i0 + 2] = kNone;
+            if (e3) assign[i0 + 3] = kNone;
+            ev += e0 + e1 + e2 + e3;
+        }
+    }
+    ev = wave_sum32(ev);
+    if ((tid & 63) == 0 && ev) atomicAdd(&ev_total, ev);
+    __syncthreads();
+    if (tid == 0 && ev_total) atomicAdd(&st->evicted_clean, (u64)ev_total);
+}
+
+// used[j] = sum of load over rows assigned to j (8 B/row)
+__global__ __launch_bounds__(kBlock) void k_used(const u32* __restrict__ assign, const u32* __restrict__ load,
+                                                 u64 n_obj, u32 m, u64* __restrict__ used) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* hist = reinterpret_cast<u64*>(smem);
+    const int tid = threadIdx.x;
+    for (u32 k = tid; k < m; k += kBlock) hist[k] = 0;
+    __syncthreads();
+    const u64 nvec = (n_obj + 3) / 4;
+    for (u64 v = (u64)blockIdx.x * kBlock + tid; v < nvec; v += (u64)gridDim.x * kBlock) {
+        const u64 i0 = v * 4;
+        const uint4 c = *reinterpret_cast<const uint4*>(assign + i0);
+        const uint4 l = *reinterpret_cast<const uint4*>(load + i0);
+        if (i0 + 0 < n_obj && c.x < m) atomicAdd(&hist[c.x], (u64)l.x);
+        if (i0 + 1 < n_obj && c.y < m) atomicAdd(&hist[c.y], (u64)l.y);
+        if (i0 + 2 < n_obj && c.z < m) atomicAdd(&hist[c.z], (u64)l.z);
+        if (i0 + 3 < n_obj && c.w < m) atomicAdd(&hist[c.w], (u64)l.w);
+    }
+    __syncthreads();
+    for (u32 k = tid; k < m; k += kBlock)
+        if (hist[k]) atomicAdd(&used[k], hist[k]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// place_pending glue: requests -> virtual table -> solve -> scatter
+// ------------------------------------------------------------------------------------------------
+// (1) service.rs:227-237: a requested row placed on a dead node marks that node for clean_server
+__global__ void k_pp_mark_dead(const u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ alive_bits,
+                               const u32* __restrict__ idx, const u32* __restrict__ req, u64 n,
+                               u32* __restrict__ dead_bits, DevStats* st) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k];
+        if (i >= n_obj || req[k] >= m) { atomicAdd(&st->err, 1ull); continue; }
+        const u32 c = assign[i];
+        if (c < m && !bit_of(alive_bits, c)) atomicOr(&dead_bits[c >> 5], 1u << (c & 31));
+    }
+}
+// (2) first request of a row decides (atomicMin of position), (3) gather the virtual table
+__global__ void k_pp_elect(const u32* __restrict__ idx, u64 n, u64 n_obj, u32* __restrict__ pos) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k];
+        if (i < n_obj) atomicMin(&pos[i], (u32)k);
+    }
+}
+__global__ void k_pp_gather(const u32* __restrict__ assign, const u32* __restrict__ load,
+                            const u32* __restrict__ idx, const u32* __restrict__ req, u64 n,
+                            const u32* __restrict__ pos, u32* __restrict__ vcur, u32* __restrict__ vload,
+                            u32* __restrict__ vaff) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k];
+        const bool first = pos[i] == (u32)k;
+        vcur[k] = first ? assign[i] : kSkipMark;
+        vload[k] = load[i];
+        vaff[k] = req[k];
+    }
+}
+// (4) winners publish their new node
+__global__ void k_pp_scatter(u32* __restrict__ assign, const u32* __restrict__ idx, u64 n,
+                             const u32* __restrict__ vcur, const u32* __restrict__ vnext) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        if (vcur[k] == kNone) {
+            const u32 nd = vnext[k];
+            if (nd < kSkipMark) assign[idx[k]] = nd;
+        }
+    }
+}
+// (5) outputs + scratch reset
+__global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restrict__ idx,
+                            const u32* __restrict__ req, u64 n, const u32* __restrict__ vcur,
+                            u32* __restrict__ pos, const u32* __restrict__ alive_bits,
+                            const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
+                            u32* __restrict__ out_flag) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k], r = req[k];
+        const u32 nd = assign[i];
+        u32 fl;
+        if (nd == kNone) fl = 4u;                                  // UNPLACED
+        else if (vcur[k] == kNone) {                               // this request placed the row
+            const bool claimed = bit_of(alive_bits, r) && (cutidx == nullptr || (u32)k < cutidx[r]);
+            fl = claimed ? 2u : 3u;                                // PLACED | SPILLED
+        } else fl = (nd == r) ? 0u : 1u;                           // LOCAL | REDIRECT
+        out_node[k] = nd;
+        if (out_flag) out_flag[k] = fl;
+        pos[i] = kNone;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
+    u64 g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s) {
+    const size_t lds = scan_lds_bytes(p.m);
+    if (virt)
+        hipLaunchKernelGGL(k_scan<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next, nt.alive_bits,
+                           p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+    else
+        hipLaunchKernelGGL(k_scan<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next, nt.alive_bits,
+                           p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+}
+
+void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, hipStream_t s) {
+    const unsigned grid = (p.m + kResNodes - 1) / kResNodes;
+    hipLaunchKernelGGL(k_resolve, dim3(grid ? grid : 1), dim3(256), 0, s, b.H, b.blkstat, b.wsp_cnt[0], p, nt.cap,
+                       nt.alive_bits, nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.budget,
+                       b.admpre, b.cutidx, b.stats);
+}
+
+void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
+                      hipStream_t s) {
+    (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
+    const size_t lds = kSmall + ((size_t)p.m + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16;
+    const unsigned g4 = (p.m + 3) / 4;
+    if (virt) {
+        hipLaunchKernelGGL(k_cut_subhist<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                           b.cutblk, b.T);
+        hipLaunchKernelGGL(k_cut_exact<true>, dim3(g4), dim3(256), 0, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                           b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
+        hipLaunchKernelGGL(k_apply_cut<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
+                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+    } else {
+        hipLaunchKernelGGL(k_cut_subhist<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, nt.alive_bits,
+                           p, b.cutblk, b.T);
+        hipLaunchKernelGGL(k_cut_exact<false>, dim3(g4), dim3(256), 0, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                           b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
+        hipLaunchKernelGGL(k_apply_cut<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
+                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+    }
+}
+
+void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
+                        hipStream_t s) {
+    const int in = round & 1, out = in ^ 1;
+    const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
+    const size_t lds_prep = 2 * kSmall + (size_t)2 * mp * sizeof(u64);
+    hipLaunchKernelGGL(k_spill_prepare, dim3(1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
+                       b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.stats);
+    const size_t lds_apply = kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + (size_t)p.m * sizeof(u32) + 16;
+    hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_base, b.wfC,
+                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats);
+}
+
+void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, idx, n, out, st);
+}
+void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos, DevStats* st,
+                   hipStream_t s) {
+    if (!n) return;
+    const unsigned g = grid_for(n, 256, 4096);
+    hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
+    hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos);
+    hipLaunchKernelGGL(k_pos_reset, dim3(g), dim3(256), 0, s, idx, n, n_obj, pos);
+}
+void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
+                   hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_remove, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, load, idx, n, used,
+                       st);
+}
+void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s) {
+    const size_t lds = (size_t)((m + 31) / 32 + 4) * sizeof(u32);
+    hipLaunchKernelGGL(k_clean, dim3(grid_for((n_obj + 3) / 4, 256, 2048)), dim3(256), lds, s, assign, n_obj, m,
+                       dead_bits, used, st);
+}
+void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s) {
+    (void)hipMemsetAsync(used, 0, (size_t)m * sizeof(u64), s);
+    if (!n_obj) return;
+    hipLaunchKernelGGL(k_used, dim3(grid_for((n_obj + 3) / 4, kBlock, 256)), dim3(kBlock), (size_t)m * sizeof(u64), s,
+                       assign, load, n_obj, m, used);
+}
+void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, p, n, v);
+}
+void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipStream_t s) {
+    const u32 w = (m + 31) / 32;
+    hipLaunchKernelGGL(k_pack_alive, dim3((w + 63) / 64), dim3(64), 0, s, alive_bytes, m, alive_bits);
+}
+void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
+                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s) {
+    (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
+    hipLaunchKernelGGL(k_pp_mark_dead, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, alive_bits, idx,
+                       req, n, dead_bits, st);
+}
+void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const u32* req, u64 n, u32* pos, u32* vcur,
+                      u32* vload, u32* vaff, hipStream_t s) {
+    const unsigned g = grid_for(n, 256, 4096);
+    hipLaunchKernelGGL(k_pp_elect, dim3(g), dim3(256), 0, s, idx, n, (u64)~0ull, pos);
+    hipLaunchKernelGGL(k_pp_gather, dim3(g), dim3(256), 0, s, assign, load, idx, req, n, pos, vcur, vload, vaff);
+}
+void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext, u32* pos,
+                       const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node, u32* out_flag,
+                       hipStream_t s) {
+    const unsigned g = grid_for(n, 256, 4096);
+    hipLaunchKernelGGL(k_pp_scatter, dim3(g), dim3(256), 0, s, assign, idx, n, vcur, vnext);
+    hipLaunchKernelGGL(k_pp_output, dim3(g), dim3(256), 0, s, assign, idx, req, n, vcur, pos, alive_bits,
+                       cutidx_or_null, m, out_node, out_flag);
+}
+
+}  // namespace riogp

@@ -1,0 +1,717 @@
+// rio_gp_capi.hip — host side of the C ABI (include/rio_gpu_placement.h): handle, HBM tables,
+// stream, and the kernel sequences behind every entry point.  No torch, no CPU fallback.
+//
+// Reference interfaces replaced (relative to /root/reference):
+//   trait ObjectPlacement            rio-rs/src/object_placement/mod.rs:38-56
+//   LocalObjectPlacement             rio-rs/src/object_placement/local.rs:22-68
+//   Service::get_or_create_placement rio-rs/src/service.rs:193-254 (+ check_address_mismatch :261-298)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rio_gpu_placement.h"
+#include "placement_kernels.h"
+
+using namespace riogp;
+
+namespace {
+
+thread_local std::string g_create_error;
+constexpr int kRing = 64;  // in-flight async solves whose verdicts we keep
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct rio_gp {
+    std::mutex mu;
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    u64 cap_obj = 0, cap_rows = 0;
+    u32 cap_nodes = 0, rounds = 2;
+    u64 n = 0;
+    u32 m = 0;
+    // object table (HBM): two assignment columns (ping-pong), load, affinity, position scratch
+    u32* assign[2] = {nullptr, nullptr};
+    int cur = 0;
+    u32 *load = nullptr, *aff = nullptr, *pos = nullptr;
+    // node table
+    u64 *cap = nullptr, *used = nullptr;
+    u32 *alive_bits = nullptr, *dead_bits = nullptr;
+    uint8_t* alive_bytes = nullptr;
+    std::vector<uint8_t> h_alive;
+    bool used_valid = true;
+    // solve scratch
+    SolveBufs sb{};
+    DevStats* dstats = nullptr;
+    DevStats* h_stats = nullptr;  // pinned, kRing slots
+    Plan plan{};
+    bool have_solved = false;
+    u32 ring_n = 0;
+    // virtual table (place_pending) and staging for host-pointer calls
+    DevBuf vt[4], stage[4];
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                     \
+            return RIO_GP_EUPSTREAM;                                                          \
+        }                                                                                     \
+    } while (0)
+
+int fail(rio_gp* h, int rc, const std::string& msg) {
+    h->err = msg;
+    return rc;
+}
+
+template <typename T>
+int dalloc(rio_gp* h, T** out, size_t count) {
+    void* p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) {
+        h->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? RIO_GP_ENOMEM : RIO_GP_EUPSTREAM;
+    }
+    h->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return RIO_GP_OK;
+}
+
+int ensure(rio_gp* h, DevBuf& b, size_t bytes) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    bytes += 4096;  // vector loads may read one tile past n
+    if (b.bytes >= bytes) return RIO_GP_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(h, e == hipErrorOutOfMemory ? RIO_GP_ENOMEM : RIO_GP_EUPSTREAM,
+                                      std::string("hipMalloc(staging): ") + hipGetErrorString(e));
+    b.bytes = bytes;
+    return RIO_GP_OK;
+}
+
+void fill_stats(const DevStats& d, u64 n, rio_gp_stats* s) {
+    if (!s) return;
+    memset(s, 0, sizeof *s);
+    s->n_objects = n;
+    s->kept = d.kept;
+    s->evicted = d.evicted;
+    s->claimed = d.claimants - d.rejected;
+    s->spilled = d.spilled;
+    s->unplaced = d.unplaced;
+    s->load_kept = d.load_kept;
+    s->load_claimed = d.load_claim_tot - d.load_rejected;
+    s->load_spilled = d.load_spilled;
+    s->load_unplaced = d.load_unplaced;
+    s->cut_nodes = (uint32_t)d.n_cut;
+    s->slow_path = (d.n_cut > 0 || d.spillcand > 0) ? 1u : 0u;
+    s->rounds_run = (uint32_t)d.rounds_run;
+}
+
+Table real_table(rio_gp* h) { return Table{h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1]}; }
+NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; }
+
+// the cut / spill fix-up of a solve whose fast path said it needs one
+void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, const DevStats& verdict) {
+    if (verdict.n_cut > 0) launch_cut_fixup(p, t, nt, h->sb, virt, h->stream);
+    for (u32 r = 0; r < h->rounds; ++r) launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream);
+}
+
+int solve_locked(rio_gp* h, rio_gp_stats* stats) {
+    h->plan = make_plan(h->n, h->m, 0);
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    launch_scan(h->plan, t, nt, h->sb, false, h->stream);
+    launch_resolve(h->plan, nt, h->sb, h->stream);
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_stats[0].n_cut > 0 || h->h_stats[0].spillcand > 0) {
+        enqueue_slow(h, h->plan, t, nt, false, h->h_stats[0]);
+        HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, hipGetLastError());
+    fill_stats(h->h_stats[0], h->n, stats);
+    h->have_solved = true;
+    h->ring_n = 0;
+    return RIO_GP_OK;
+}
+
+int commit_locked(rio_gp* h) {
+    if (!h->have_solved) return fail(h, RIO_GP_EINVAL, "rio_gp_commit: no solve to commit");
+    h->cur ^= 1;
+    HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
+                             hipMemcpyDeviceToDevice, h->stream));
+    h->used_valid = true;
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
+int ensure_used(rio_gp* h) {
+    if (h->used_valid) return RIO_GP_OK;
+    launch_recompute_used(h->assign[h->cur], h->load, h->n, h->m, h->used, h->stream);
+    h->used_valid = true;
+    return RIO_GP_OK;
+}
+
+int zero_stats(rio_gp* h) {
+    HIPCHK(h, hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream));
+    return RIO_GP_OK;
+}
+
+int read_stats(rio_gp* h) {
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return RIO_GP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rio_gp_abi_version(void) { return RIO_GP_ABI_VERSION; }
+
+const char* rio_gp_last_error(rio_gp_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+const char* rio_gp_backend(rio_gp_t*) { return "hip:gfx950"; }
+
+int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out || cfg->struct_size != sizeof(rio_gp_cfg)) {
+        g_create_error = "rio_gp_create: bad cfg (struct_size mismatch)";
+        return RIO_GP_EINVAL;
+    }
+    if (cfg->max_objects > RIO_GP_MAX_OBJECTS || cfg->max_nodes > RIO_GP_MAX_NODES) {
+        g_create_error = "rio_gp_create: max_objects/max_nodes above the solver limits";
+        return RIO_GP_EINVAL;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_error = std::string("rio_gp_create: no usable HIP device (") +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device ordinal out of range") +
+                         "); there is no CPU fallback";
+        return RIO_GP_ENODEV;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("rio_gp_create: device is not gfx950 (MI355X): ") + prop.gcnArchName;
+        return RIO_GP_ENODEV;
+    }
+    rio_gp* h = new rio_gp();
+    h->device = cfg->device;
+    h->cap_obj = cfg->max_objects;
+    h->cap_rows = ((cfg->max_objects + kTile - 1) / kTile) * kTile + 2 * kTile;
+    h->cap_nodes = cfg->max_nodes ? cfg->max_nodes : 1;
+    h->rounds = cfg->spill_rounds ? cfg->spill_rounds : 2;
+    int rc = RIO_GP_OK;
+    auto bail = [&](int code) {
+        g_create_error = h->err;
+        rio_gp_destroy(h);
+        return code;
+    };
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(RIO_GP_EUPSTREAM); }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        h->err = "stream/event creation failed";
+        return bail(RIO_GP_EUPSTREAM);
+    }
+    const size_t R = h->cap_rows, M = h->cap_nodes, W = (size_t)kMaxBlocks * kWaves;
+#define A(ptr, cnt) if ((rc = dalloc(h, &(ptr), (cnt))) != RIO_GP_OK) return bail(rc)
+    A(h->assign[0], R); A(h->assign[1], R); A(h->load, R); A(h->aff, R); A(h->pos, R);
+    A(h->cap, M); A(h->used, M); A(h->alive_bits, (M + 31) / 32 + 4); A(h->dead_bits, (M + 31) / 32 + 4);
+    A(h->alive_bytes, M);
+    A(h->sb.H, (size_t)kMaxBlocks * 2 * M); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
+    A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
+    A(h->sb.wsp_base, W);
+    A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
+    A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
+    A(h->sb.wfCnt, 4); A(h->dstats, 1);
+#undef A
+    h->sb.stats = h->dstats;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stats), sizeof(DevStats) * kRing, hipHostMallocDefault) !=
+        hipSuccess) {
+        h->err = "hipHostMalloc failed";
+        return bail(RIO_GP_ENOMEM);
+    }
+    // every row starts unplaced; the position scratch is all-ones between calls
+    launch_fill_u32(h->assign[0], R, kNone, h->stream);
+    launch_fill_u32(h->assign[1], R, kNone, h->stream);
+    launch_fill_u32(h->pos, R, kNone, h->stream);
+    launch_fill_u32(h->load, R, 0, h->stream);
+    launch_fill_u32(h->aff, R, kNone, h->stream);
+    (void)hipMemsetAsync(h->used, 0, M * sizeof(u64), h->stream);
+    (void)hipMemsetAsync(h->alive_bits, 0, ((M + 31) / 32 + 4) * sizeof(u32), h->stream);
+    (void)hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream);
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        h->err = "initial fill failed (no gfx950 code object loaded?)";
+        return bail(RIO_GP_EUPSTREAM);
+    }
+    *out = h;
+    return RIO_GP_OK;
+}
+
+void rio_gp_destroy(rio_gp_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& b : h->vt) if (b.p) (void)hipFree(b.p);
+    for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
+    if (h->h_stats) (void)hipHostFree(h->h_stats);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int rio_gp_sync(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RIO_GP_OK;
+}
+
+uint64_t rio_gp_num_objects(rio_gp_t* h) { return h ? h->n : 0; }
+uint32_t rio_gp_num_nodes(rio_gp_t* h) { return h ? h->m : 0; }
+
+// ---- node table ---------------------------------------------------------------------------
+
+int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t* alive) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (m > h->cap_nodes) return fail(h, RIO_GP_EINVAL, "rio_gp_set_nodes: m exceeds max_nodes");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<u64> c(m ? m : 1, RIO_GP_CAP_INF);
+    if (cap) memcpy(c.data(), cap, (size_t)m * sizeof(u64));
+    h->h_alive.assign(m, 1);
+    if (alive) for (uint32_t j = 0; j < m; ++j) h->h_alive[j] = alive[j] ? 1 : 0;
+    if (m) {
+        HIPCHK(h, hipMemcpyAsync(h->cap, c.data(), (size_t)m * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->alive_bytes, h->h_alive.data(), m, hipMemcpyHostToDevice, h->stream));
+    }
+    launch_pack_alive(h->alive_bytes, m, h->alive_bits, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (m != h->m) h->used_valid = false;
+    h->m = m;
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
+int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive) {
+    if (!h || !alive) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (m != h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive_all: m differs from the node table");
+    HIPCHK(h, hipSetDevice(h->device));
+    for (uint32_t j = 0; j < m; ++j) h->h_alive[j] = alive[j] ? 1 : 0;
+    if (m) HIPCHK(h, hipMemcpyAsync(h->alive_bytes, h->h_alive.data(), m, hipMemcpyHostToDevice, h->stream));
+    launch_pack_alive(h->alive_bytes, m, h->alive_bits, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
+int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (node >= h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive: node out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->h_alive[node] = alive ? 1 : 0;
+    HIPCHK(h, hipMemcpyAsync(h->alive_bytes, h->h_alive.data(), h->m, hipMemcpyHostToDevice, h->stream));
+    launch_pack_alive(h->alive_bytes, h->m, h->alive_bits, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
+int rio_gp_get_nodes(rio_gp_t* h, uint32_t m, uint64_t* cap, uint8_t* alive, uint64_t* used) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (m != h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_get_nodes: m differs from the node table");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (used) { int rc = ensure_used(h); if (rc) return rc; }
+    if (cap && m) HIPCHK(h, hipMemcpyAsync(cap, h->cap, (size_t)m * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    if (used && m) HIPCHK(h, hipMemcpyAsync(used, h->used, (size_t)m * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (alive) memcpy(alive, h->h_alive.data(), m);
+    return RIO_GP_OK;
+}
+
+// ---- object table -------------------------------------------------------------------------
+
+static int set_objects_impl(rio_gp_t* h, uint64_t n, const uint32_t* load, const uint32_t* aff, hipMemcpyKind kind) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n > h->cap_obj) return fail(h, RIO_GP_EINVAL, "rio_gp_set_objects: n exceeds max_objects");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (load) { if (n) HIPCHK(h, hipMemcpyAsync(h->load, load, n * sizeof(u32), kind, h->stream)); }
+    else launch_fill_u32(h->load, n, 1u, h->stream);
+    if (aff) { if (n) HIPCHK(h, hipMemcpyAsync(h->aff, aff, n * sizeof(u32), kind, h->stream)); }
+    else launch_fill_u32(h->aff, n, kNone, h->stream);
+    launch_fill_u32(h->assign[h->cur], h->cap_rows, kNone, h->stream);
+    HIPCHK(h, hipMemsetAsync(h->used, 0, (size_t)h->cap_nodes * sizeof(u64), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->n = n;
+    h->used_valid = true;
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+int rio_gp_set_objects(rio_gp_t* h, uint64_t n, const uint32_t* load, const uint32_t* aff) {
+    return set_objects_impl(h, n, load, aff, hipMemcpyHostToDevice);
+}
+int rio_gp_set_objects_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_load, const uint32_t* d_aff) {
+    return set_objects_impl(h, n, d_load, d_aff, hipMemcpyDeviceToDevice);
+}
+
+static int set_assign_impl(rio_gp_t* h, uint64_t n, const uint32_t* assign, hipMemcpyKind kind) {
+    if (!h || !assign) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n != h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_set_assign: n differs from the object table");
+    if (kind == hipMemcpyHostToDevice)
+        for (uint64_t i = 0; i < n; ++i)
+            if (assign[i] != RIO_GP_NONE && assign[i] >= h->m)
+                return fail(h, RIO_GP_EINVAL, "rio_gp_set_assign: node id out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) HIPCHK(h, hipMemcpyAsync(h->assign[h->cur], assign, n * sizeof(u32), kind, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->used_valid = false;
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+int rio_gp_set_assign(rio_gp_t* h, uint64_t n, const uint32_t* a) { return set_assign_impl(h, n, a, hipMemcpyHostToDevice); }
+int rio_gp_set_assign_dev(rio_gp_t* h, uint64_t n, const uint32_t* a) { return set_assign_impl(h, n, a, hipMemcpyDeviceToDevice); }
+
+int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out) {
+    if (!h || !out) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n != h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_get_assign: n differs from the object table");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) HIPCHK(h, hipMemcpyAsync(out, h->assign[h->cur], n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RIO_GP_OK;
+}
+int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out) {
+    if (!h || !out) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n != h->n || !h->have_solved) return fail(h, RIO_GP_EINVAL, "rio_gp_get_solved: no solve / size mismatch");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) HIPCHK(h, hipMemcpyAsync(out, h->assign[h->cur ^ 1], n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RIO_GP_OK;
+}
+const uint32_t* rio_gp_assign_dev(rio_gp_t* h) { return h ? h->assign[h->cur] : nullptr; }
+const uint32_t* rio_gp_solved_dev(rio_gp_t* h) { return h ? h->assign[h->cur ^ 1] : nullptr; }
+
+// ---- CRUD ---------------------------------------------------------------------------------
+
+int rio_gp_lookup_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, uint32_t* d_out) {
+    if (!h || (n && (!d_idx || !d_out))) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = zero_stats(h);
+    if (rc) return rc;
+    launch_lookup(h->assign[h->cur], h->n, d_idx, n, d_out, h->dstats, h->stream);
+    if ((rc = read_stats(h))) return rc;
+    if (h->h_stats[0].err) return fail(h, RIO_GP_EINVAL, "rio_gp_lookup_batch: object index out of range");
+    return RIO_GP_OK;
+}
+
+int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* out_node) {
+    if (!h || (n && (!idx || !out_node))) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_lookup_batch: object index out of range");
+    if (!n) return RIO_GP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;
+    u32 *d_idx = (u32*)h->stage[0].p, *d_out = (u32*)h->stage[1].p;
+    HIPCHK(h, hipMemcpyAsync(d_idx, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    launch_lookup(h->assign[h->cur], h->n, d_idx, n, d_out, h->dstats, h->stream);
+    HIPCHK(h, hipMemcpyAsync(out_node, d_out, n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return RIO_GP_OK;
+}
+
+static int update_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node) {
+    int rc = zero_stats(h);
+    if (rc) return rc;
+    launch_update(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, h->pos, h->dstats, h->stream);
+    h->used_valid = false;
+    h->have_solved = false;
+    if ((rc = read_stats(h))) return rc;
+    if (h->h_stats[0].err) return fail(h, RIO_GP_EINVAL, "rio_gp_update_batch: invalid entries were skipped");
+    return RIO_GP_OK;
+}
+
+int rio_gp_update_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node) {
+    if (!h || (n && (!d_idx || !d_node))) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    return update_dev_locked(h, n, d_idx, d_node);
+}
+
+int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* node) {
+    if (!h || (n && (!idx || !node))) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n || (node[k] != RIO_GP_NONE && node[k] >= h->m))
+            return fail(h, RIO_GP_EINVAL, "rio_gp_update_batch: index or node out of range");
+    if (!n) return RIO_GP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->stage[1].p, node, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    return update_dev_locked(h, n, (const u32*)h->stage[0].p, (const u32*)h->stage[1].p);
+}
+
+static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
+    int rc = zero_stats(h);
+    if (rc) return rc;
+    launch_remove(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, h->used_valid ? h->used : nullptr, h->dstats,
+                  h->stream);
+    h->have_solved = false;
+    if ((rc = read_stats(h))) return rc;
+    if (h->h_stats[0].err) return fail(h, RIO_GP_EINVAL, "rio_gp_remove_batch: invalid entries were skipped");
+    return RIO_GP_OK;
+}
+
+int rio_gp_remove_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx) {
+    if (!h || (n && !d_idx)) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    return remove_dev_locked(h, n, d_idx);
+}
+
+int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
+    if (!h || (n && !idx)) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_remove_batch: object index out of range");
+    if (!n) return RIO_GP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->stage[0], n * sizeof(u32)))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    return remove_dev_locked(h, n, (const u32*)h->stage[0].p);
+}
+
+int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evicted) {
+    if (!h || !dead_bitmap) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    const u32 words32 = (h->m + 31) / 32;
+    std::vector<u32> bits(words32 + 1, 0);
+    for (u32 j = 0; j < h->m; ++j)
+        if ((dead_bitmap[j >> 6] >> (j & 63)) & 1ull) bits[j >> 5] |= 1u << (j & 31);
+    int rc = zero_stats(h);
+    if (rc) return rc;
+    if (words32)
+        HIPCHK(h, hipMemcpyAsync(h->dead_bits, bits.data(), words32 * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    if (words32)
+        launch_clean(h->assign[h->cur], h->n, h->m, h->dead_bits, h->used_valid ? h->used : nullptr, h->dstats,
+                     h->stream);
+    h->have_solved = false;
+    if ((rc = read_stats(h))) return rc;
+    if (evicted) *evicted = h->h_stats[0].evicted_clean;
+    return RIO_GP_OK;
+}
+
+int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
+    if (!h) return RIO_GP_EINVAL;
+    u32 m;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        m = h->m;
+        if (node >= m) {  // an address nothing was ever placed on: retain() removes nothing (local.rs:56)
+            if (evicted) *evicted = 0;
+            return RIO_GP_OK;
+        }
+    }
+    std::vector<uint64_t> bm((m + 63) / 64 + 1, 0);
+    bm[node >> 6] |= 1ull << (node & 63);
+    return rio_gp_clean_servers(h, bm.data(), evicted);
+}
+
+// ---- policy -------------------------------------------------------------------------------
+
+int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* requester,
+                         uint32_t* out_node, uint32_t* out_flag) {
+    if (!h || (n && (!idx || !requester || !out_node))) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n || requester[k] >= h->m)
+            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: object index or requester out of range");
+    if (!n) return RIO_GP_OK;
+    if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: batch too large");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t bytes = n * sizeof(u32);
+    for (int q = 0; q < 4; ++q) {
+        if ((rc = ensure(h, h->stage[q], bytes))) return rc;
+        if ((rc = ensure(h, h->vt[q], bytes))) return rc;
+    }
+    u32 *d_idx = (u32*)h->stage[0].p, *d_req = (u32*)h->stage[1].p, *d_out = (u32*)h->stage[2].p,
+        *d_flag = (u32*)h->stage[3].p;
+    u32 *vcur = (u32*)h->vt[0].p, *vload = (u32*)h->vt[1].p, *vaff = (u32*)h->vt[2].p, *vnext = (u32*)h->vt[3].p;
+    u32* assign = h->assign[h->cur];
+    if ((rc = ensure_used(h))) return rc;
+    HIPCHK(h, hipMemcpyAsync(d_idx, idx, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_req, requester, bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = zero_stats(h))) return rc;
+    // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
+    launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream);
+    launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream);
+    // (2)(3) first request per row decides; gather the virtual table (rows = requests)
+    launch_pp_gather(assign, h->load, d_idx, d_req, n, h->pos, vcur, vload, vaff, h->stream);
+    // (4) solve the virtual table against the committed `used`
+    const Plan vp = make_plan(n, h->m, 0);
+    const Table vtab{vcur, vload, vaff, vnext};
+    const NodeTab vnt{h->cap, h->alive_bits, h->used};
+    launch_scan(vp, vtab, vnt, h->sb, true, h->stream);
+    launch_resolve(vp, vnt, h->sb, h->stream);
+    if ((rc = read_stats(h))) return rc;
+    if (h->h_stats[0].n_cut > 0 || h->h_stats[0].spillcand > 0) enqueue_slow(h, vp, vtab, vnt, true, h->h_stats[0]);
+    // (5) publish, outputs, new `used`
+    launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
+                      h->stream);
+    HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
+                             hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out_node, d_out, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out_flag) HIPCHK(h, hipMemcpyAsync(out_flag, d_flag, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
+int rio_gp_solve(rio_gp_t* h, rio_gp_stats* stats) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    return solve_locked(h, stats);
+}
+
+int rio_gp_commit(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = commit_locked(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RIO_GP_OK;
+}
+
+int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = solve_locked(h, stats);
+    if (rc) return rc;
+    if ((rc = commit_locked(h))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RIO_GP_OK;
+}
+
+int rio_gp_solve_async(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->plan = make_plan(h->n, h->m, 0);
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    launch_scan(h->plan, t, nt, h->sb, false, h->stream);
+    launch_resolve(h->plan, nt, h->sb, h->stream);
+    HIPCHK(h, hipMemcpyAsync(&h->h_stats[h->ring_n % kRing], h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost,
+                             h->stream));
+    h->ring_n++;
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
+int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (h->ring_n == 0) return fail(h, RIO_GP_EINVAL, "rio_gp_solve_wait: nothing enqueued");
+    uint32_t slow = 0;
+    const u32 lo = h->ring_n > (u32)kRing ? h->ring_n - kRing : 0;
+    for (u32 k = lo; k < h->ring_n; ++k) {
+        const DevStats& d = h->h_stats[k % kRing];
+        slow += (d.n_cut > 0 || d.spillcand > 0);
+    }
+    const DevStats last = h->h_stats[(h->ring_n - 1) % kRing];
+    h->h_stats[0] = last;
+    if (last.n_cut > 0 || last.spillcand > 0) {
+        enqueue_slow(h, h->plan, real_table(h), real_nodes(h), false, last);
+        int rc = read_stats(h);
+        if (rc) return rc;
+    }
+    fill_stats(h->h_stats[0], h->n, stats);
+    if (n_slow) *n_slow = slow;
+    h->ring_n = 0;
+    h->have_solved = true;
+    return RIO_GP_OK;
+}
+
+int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
+    if (!h || !scan_ms || !resolve_ms) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->ev2) { HIPCHK(h, hipEventCreate(&h->ev2)); }
+    h->plan = make_plan(h->n, h->m, 0);
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    launch_scan(h->plan, t, nt, h->sb, false, h->stream);
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    launch_resolve(h->plan, nt, h->sb, h->stream);
+    HIPCHK(h, hipEventRecord(h->ev2, h->stream));
+    int rc = read_stats(h);
+    if (rc) return rc;
+    HIPCHK(h, hipEventElapsedTime(scan_ms, h->ev0, h->ev1));
+    HIPCHK(h, hipEventElapsedTime(resolve_ms, h->ev1, h->ev2));
+    h->have_solved = false;
+    if (h->h_stats[0].n_cut > 0 || h->h_stats[0].spillcand > 0)
+        return fail(h, RIO_GP_EINVAL, "rio_gp_solve_profiled: this table needs the cut/spill fix-up");
+    return RIO_GP_OK;
+}
+
+int rio_gp_timer_begin(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    return RIO_GP_OK;
+}
+
+int rio_gp_timer_end(rio_gp_t* h, float* ms) {
+    if (!h || !ms) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return RIO_GP_OK;
+}
+
+}  // extern "C"

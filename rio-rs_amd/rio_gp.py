@@ -1,0 +1,283 @@
+"""ctypes binding of the C ABI (include/rio_gpu_placement.h) — the stub a maintainer of a
+Python host would write; the Rust equivalent is in rio-rs_amd/rust/ and INTEGRATION.md.
+
+This module never computes anything itself and has no CPU fallback: if librio_gp.so is missing
+or there is no gfx950 device, it raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "librio_gp.so")
+NONE = 0xFFFFFFFF
+CAP_INF = 0xFFFFFFFFFFFFFFFF
+FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
+OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM = range(5)
+
+SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "gpu_object_placement.cpp")]
+HEADERS = [os.path.join(_DIR, "csrc", "placement_kernels.h"),
+           os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_placement.h"),
+           os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_object_placement.h")]
+
+
+class ObjectPlacementError(Exception):
+    """errors.rs:135-142: Upstream(String) | Unknown(String)"""
+
+    def __init__(self, kind, text, rc):
+        super().__init__("%s(%s)" % (kind, text))
+        self.kind, self.text, self.rc = kind, text, rc
+
+
+class Cfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_objects", C.c_uint64),
+                ("max_nodes", C.c_uint32), ("spill_rounds", C.c_uint32), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "n_objects", "kept", "evicted", "claimed", "spilled", "unplaced",
+        "load_kept", "load_claimed", "load_spilled", "load_unplaced")] + [
+        (k, C.c_uint32) for k in ("cut_nodes", "slow_path", "rounds_run", "reserved")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> rio-rs_amd/librio_gp.so (in-tree, travels with gpurun)."""
+    srcs = [s for s in SOURCES if os.path.exists(s)]
+    deps = srcs + [x for x in HEADERS if os.path.exists(x)]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps):
+        return LIB_PATH
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+           "-I", os.path.join(os.path.dirname(_DIR), "include"), "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+_vp = C.c_void_p
+_u32p = C.POINTER(C.c_uint32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("librio_gp.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.rio_gp_create.argtypes = [C.POINTER(Cfg), C.POINTER(_vp)]
+        L.rio_gp_destroy.argtypes = [_vp]
+        L.rio_gp_destroy.restype = None
+        L.rio_gp_last_error.argtypes = [_vp]
+        L.rio_gp_last_error.restype = C.c_char_p
+        L.rio_gp_backend.argtypes = [_vp]
+        L.rio_gp_backend.restype = C.c_char_p
+        L.rio_gp_abi_version.restype = C.c_uint32
+        L.rio_gp_sync.argtypes = [_vp]
+        L.rio_gp_set_nodes.argtypes = [_vp, C.c_uint32, _vp, _vp]
+        L.rio_gp_set_alive.argtypes = [_vp, C.c_uint32, C.c_uint8]
+        L.rio_gp_set_alive_all.argtypes = [_vp, C.c_uint32, _vp]
+        L.rio_gp_get_nodes.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp]
+        for nm in ("rio_gp_set_objects", "rio_gp_set_objects_dev"):
+            getattr(L, nm).argtypes = [_vp, C.c_uint64, _vp, _vp]
+        for nm in ("rio_gp_set_assign", "rio_gp_set_assign_dev", "rio_gp_get_assign", "rio_gp_get_solved"):
+            getattr(L, nm).argtypes = [_vp, C.c_uint64, _vp]
+        for nm in ("rio_gp_assign_dev", "rio_gp_solved_dev"):
+            getattr(L, nm).argtypes = [_vp]
+            getattr(L, nm).restype = _vp
+        L.rio_gp_num_objects.argtypes = [_vp]
+        L.rio_gp_num_objects.restype = C.c_uint64
+        L.rio_gp_num_nodes.argtypes = [_vp]
+        L.rio_gp_num_nodes.restype = C.c_uint32
+        for nm in ("rio_gp_lookup_batch", "rio_gp_lookup_batch_dev", "rio_gp_update_batch", "rio_gp_update_batch_dev"):
+            getattr(L, nm).argtypes = [_vp, C.c_uint64, _vp, _vp]
+        for nm in ("rio_gp_remove_batch", "rio_gp_remove_batch_dev"):
+            getattr(L, nm).argtypes = [_vp, C.c_uint64, _vp]
+        L.rio_gp_clean_server.argtypes = [_vp, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.rio_gp_clean_servers.argtypes = [_vp, _vp, C.POINTER(C.c_uint64)]
+        L.rio_gp_place_pending.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp]
+        L.rio_gp_solve.argtypes = [_vp, C.POINTER(Stats)]
+        L.rio_gp_commit.argtypes = [_vp]
+        L.rio_gp_tick.argtypes = [_vp, C.POINTER(Stats)]
+        L.rio_gp_solve_async.argtypes = [_vp]
+        L.rio_gp_solve_wait.argtypes = [_vp, C.POINTER(Stats), C.POINTER(C.c_uint32)]
+        L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rio_gp_timer_begin.argtypes = [_vp]
+        L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _u32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class GpuPlacement:
+    """Dense-index layer: thin, 1:1 over rio_gp_*.  Arrays are numpy uint32/uint64."""
+
+    def __init__(self, max_objects, max_nodes, device=0, spill_rounds=2):
+        self._h = _vp()
+        cfg = Cfg(C.sizeof(Cfg), device, max_objects, max_nodes, spill_rounds, 0, 0)
+        rc = lib().rio_gp_create(C.byref(cfg), C.byref(self._h))
+        if rc != OK:
+            text = (lib().rio_gp_last_error(None) or b"").decode()
+            self._h = None
+            raise ObjectPlacementError("Upstream" if rc in (EUPSTREAM, ENODEV, ENOMEM) else "Unknown", text, rc)
+
+    # -- error convention (errors.rs:135-142) --
+    def _chk(self, rc):
+        if rc != OK:
+            text = (lib().rio_gp_last_error(self._h) or b"").decode()
+            raise ObjectPlacementError("Unknown" if rc == EINVAL else "Upstream", text, rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rio_gp_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    def backend(self):
+        return lib().rio_gp_backend(self._h).decode()
+
+    def sync(self):
+        self._chk(lib().rio_gp_sync(self._h))
+
+    # -- tables --
+    def set_nodes(self, cap=None, alive=None, m=None):
+        if m is None:
+            m = len(cap) if cap is not None else len(alive)
+        cap = None if cap is None else np.ascontiguousarray(cap, dtype=np.uint64)
+        alive = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint8)
+        self._chk(lib().rio_gp_set_nodes(self._h, m, _ptr(cap), _ptr(alive)))
+
+    def set_alive(self, node, alive):
+        self._chk(lib().rio_gp_set_alive(self._h, node, int(bool(alive))))
+
+    def set_alive_all(self, alive):
+        alive = np.ascontiguousarray(alive, dtype=np.uint8)
+        self._chk(lib().rio_gp_set_alive_all(self._h, len(alive), _ptr(alive)))
+
+    def get_nodes(self):
+        m = self.num_nodes
+        cap, alive, used = np.empty(m, np.uint64), np.empty(m, np.uint8), np.empty(m, np.uint64)
+        self._chk(lib().rio_gp_get_nodes(self._h, m, _ptr(cap), _ptr(alive), _ptr(used)))
+        return cap, alive, used
+
+    def set_objects(self, n, load=None, aff=None):
+        load, aff = _u32(load), _u32(aff)
+        self._chk(lib().rio_gp_set_objects(self._h, n, _ptr(load), _ptr(aff)))
+
+    def set_objects_dev(self, n, d_load, d_aff):
+        self._chk(lib().rio_gp_set_objects_dev(self._h, n, _vp(d_load), _vp(d_aff)))
+
+    def set_assign(self, assign):
+        assign = _u32(assign)
+        self._chk(lib().rio_gp_set_assign(self._h, len(assign), _ptr(assign)))
+
+    def set_assign_dev(self, n, d_assign):
+        self._chk(lib().rio_gp_set_assign_dev(self._h, n, _vp(d_assign)))
+
+    def get_assign(self):
+        out = np.empty(self.num_objects, np.uint32)
+        self._chk(lib().rio_gp_get_assign(self._h, len(out), _ptr(out)))
+        return out
+
+    def get_solved(self):
+        out = np.empty(self.num_objects, np.uint32)
+        self._chk(lib().rio_gp_get_solved(self._h, len(out), _ptr(out)))
+        return out
+
+    @property
+    def num_objects(self):
+        return int(lib().rio_gp_num_objects(self._h))
+
+    @property
+    def num_nodes(self):
+        return int(lib().rio_gp_num_nodes(self._h))
+
+    # -- ObjectPlacement CRUD, batched --
+    def lookup_batch(self, idx):
+        idx = _u32(idx)
+        out = np.empty(len(idx), np.uint32)
+        self._chk(lib().rio_gp_lookup_batch(self._h, len(idx), _ptr(idx), _ptr(out)))
+        return out
+
+    def update_batch(self, idx, node):
+        idx, node = _u32(idx), _u32(node)
+        self._chk(lib().rio_gp_update_batch(self._h, len(idx), _ptr(idx), _ptr(node)))
+
+    def remove_batch(self, idx):
+        idx = _u32(idx)
+        self._chk(lib().rio_gp_remove_batch(self._h, len(idx), _ptr(idx)))
+
+    def clean_server(self, node):
+        ev = C.c_uint64(0)
+        self._chk(lib().rio_gp_clean_server(self._h, node, C.byref(ev)))
+        return int(ev.value)
+
+    def clean_servers(self, dead_nodes):
+        m = self.num_nodes
+        bm = np.zeros((m + 63) // 64 + 1, np.uint64)
+        for j in dead_nodes:
+            bm[int(j) >> 6] |= np.uint64(1) << np.uint64(int(j) & 63)
+        ev = C.c_uint64(0)
+        self._chk(lib().rio_gp_clean_servers(self._h, _ptr(bm), C.byref(ev)))
+        return int(ev.value)
+
+    # -- policy --
+    def place_pending(self, idx, requester):
+        idx, requester = _u32(idx), _u32(requester)
+        node, flag = np.empty(len(idx), np.uint32), np.empty(len(idx), np.uint32)
+        self._chk(lib().rio_gp_place_pending(self._h, len(idx), _ptr(idx), _ptr(requester), _ptr(node), _ptr(flag)))
+        return node, flag
+
+    def solve(self):
+        st = Stats()
+        self._chk(lib().rio_gp_solve(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def commit(self):
+        self._chk(lib().rio_gp_commit(self._h))
+
+    def tick(self):
+        st = Stats()
+        self._chk(lib().rio_gp_tick(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def solve_async(self):
+        self._chk(lib().rio_gp_solve_async(self._h))
+
+    def solve_wait(self):
+        st, ns = Stats(), C.c_uint32(0)
+        self._chk(lib().rio_gp_solve_wait(self._h, C.byref(st), C.byref(ns)))
+        return st.as_dict(), int(ns.value)
+
+    def solve_profiled(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._chk(lib().rio_gp_solve_profiled(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def timer_begin(self):
+        self._chk(lib().rio_gp_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        self._chk(lib().rio_gp_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)

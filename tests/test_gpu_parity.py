@@ -1,0 +1,388 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs — bit-exact (integer/index work).  Run on the GPU box: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+NONE = 0xFFFFFFFF
+INF = 0xFFFFFFFFFFFFFFFF
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sql_backend_golden.json")
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import rio_gp
+    rio_gp.build()
+    return rio_gp
+
+
+def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
+    g = gp.GpuPlacement(max(n, 1), max(m, 1), spill_rounds=rounds)
+    g.set_nodes(cap, alive, m=m)
+    g.set_objects(n, load, aff)
+    if cur is not None and n:
+        g.set_assign(cur)
+    return g
+
+
+def _check_tick(gp, oracle, cur, load, aff, cap, alive, rounds=2):
+    n, m = len(cur), len(cap)
+    g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds)
+    st = g.solve()
+    got = g.get_solved()
+    want, used, ost = oracle.tick(cur, load, aff, cap, alive, rounds)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert st == ost
+    assert np.array_equal(g.get_assign(), cur)  # solve does not publish
+    g.commit()
+    assert np.array_equal(g.get_assign(), want)
+    assert np.array_equal(g.get_nodes()[2], used)
+    g.close()
+    return ost
+
+
+def test_backend_is_hip(gp):
+    g = gp.GpuPlacement(16, 2)
+    assert g.backend() == "hip:gfx950"
+    g.close()
+
+
+# ---- reference known-answer tests, through the GPU (object_placement_backend.rs:11-34 etc.) ----
+
+def test_backend_save_and_load_dense(gp):
+    g = gp.GpuPlacement(8, 2)
+    g.set_nodes(m=2, cap=None, alive=np.ones(2, np.uint8))
+    g.set_objects(8)
+    assert g.lookup_batch([1])[0] == NONE                 # no_placement
+    g.update_batch([1], [0])                              # save
+    assert g.lookup_batch([1])[0] == 0                    # load
+    g.update_batch([1], [1])                              # upsert overwrites (sqlite.rs:149-193)
+    assert g.lookup_batch([1])[0] == 1
+    assert g.clean_server(1) == 1                         # clean_server
+    assert g.lookup_batch([1])[0] == NONE
+    g.update_batch([1], [0])
+    g.update_batch([1], [NONE])                           # update(None) deletes (local.rs:36-37)
+    assert g.lookup_batch([1])[0] == NONE
+    g.remove_batch([1, 2, 2])                             # remove absent: no-op (local.rs:60-68)
+    g.close()
+
+
+def test_sql_golden_through_gpu(gp):
+    """The reference's SQL semantics (golden file) replayed op by op through the HIP CRUD kernels."""
+    doc = json.load(open(GOLD))
+    for case in doc["cases"][:4]:
+        keys, addrs = {}, {}
+        for op in case["ops"]:
+            if op[0] in ("update", "lookup", "remove"):
+                keys.setdefault(op[1] + "." + op[2], len(keys))
+            if op[0] == "update":
+                addrs.setdefault(op[3], len(addrs))
+            if op[0] == "clean_server":
+                addrs.setdefault(op[1], len(addrs))
+        names = {v: k for k, v in addrs.items()}
+        g = gp.GpuPlacement(len(keys), len(addrs))
+        g.set_nodes(m=len(addrs), alive=np.ones(len(addrs), np.uint8))
+        g.set_objects(len(keys))
+        got = []
+        for op in case["ops"]:
+            if op[0] == "lookup":
+                v = int(g.lookup_batch([keys[op[1] + "." + op[2]]])[0])
+                got.append(None if v == NONE else names[v])
+            elif op[0] == "update":
+                g.update_batch([keys[op[1] + "." + op[2]]], [addrs[op[3]]])
+            elif op[0] == "remove":
+                g.remove_batch([keys[op[1] + "." + op[2]]])
+            else:
+                g.clean_server(addrs[op[1]])
+        assert got == case["expected_lookups"]
+        g.close()
+
+
+# ---- CRUD batches vs oracle ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_crud_batches_random(gp, oracle, seed):
+    rng = np.random.default_rng(seed)
+    n, m = int(rng.integers(100, 70000)), int(rng.integers(1, 300))
+    load = rng.integers(0, 100, n).astype(np.uint32)
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    for step in range(12):
+        k = int(rng.integers(1, 30000))
+        idx = rng.integers(0, n, k).astype(np.uint32)          # many duplicates: last writer wins
+        node = rng.integers(0, m, k).astype(np.uint32)
+        node[rng.random(k) < 0.1] = NONE
+        g.update_batch(idx, node)
+        assert oracle.update_batch(ref, m, idx, node) == 0
+        q = rng.integers(0, n, 5000).astype(np.uint32)
+        assert np.array_equal(g.lookup_batch(q), oracle.lookup_batch(ref, q))
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))
+        rm = rng.integers(0, n, int(rng.integers(1, 3000))).astype(np.uint32)
+        g.remove_batch(rm)
+        oracle.remove_batch(ref, rm)
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))  # incremental == scratch
+        dead = rng.choice(m, size=min(m, int(rng.integers(1, 4))), replace=False)
+        ev = g.clean_servers(dead)
+        assert ev == oracle.clean_servers(ref, m, dead)
+        assert np.array_equal(g.get_assign(), ref)
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))
+    g.close()
+
+
+def test_invalid_arguments_are_unknown_errors(gp):
+    g = gp.GpuPlacement(10, 2)
+    g.set_nodes(m=2, alive=np.ones(2, np.uint8))
+    g.set_objects(10)
+    for call in (lambda: g.lookup_batch([10]), lambda: g.update_batch([0], [2]), lambda: g.remove_batch([99]),
+                 lambda: g.place_pending([0], [2]), lambda: g.set_alive(5, 1)):
+        with pytest.raises(gp.ObjectPlacementError) as e:
+            call()
+        assert e.value.kind == "Unknown" and e.value.rc == gp.EINVAL
+    assert np.all(g.get_assign() == NONE)       # nothing was mutated
+    assert g.clean_server(7) == 0               # unknown address: retain() removes nothing
+    g.close()
+
+
+# ---- whole-table solve ---------------------------------------------------------------------------
+
+def test_tick_known_answers(gp, oracle):
+    # the hand-computed cases of tests/test_oracle_solver.py, through the kernels
+    st = _check_tick(gp, oracle, np.full(4, NONE, np.uint32), np.array([60, 50, 10, 10], np.uint32),
+                     np.zeros(4, np.uint32), np.array([100, 1000], np.uint64), np.ones(2, np.uint8), rounds=1)
+    assert st["claimed"] == 1 and st["spilled"] == 3
+    cur = np.full(5, NONE, np.uint32)
+    _check_tick(gp, oracle, cur, np.array([6, 4, 3, 5, 9], np.uint32), np.zeros(5, np.uint32),
+                np.array([100, 5, 8, 8], np.uint64), np.array([0, 1, 1, 1], np.uint8), rounds=2)
+    _check_tick(gp, oracle, np.array([0, 0, 1, NONE], np.uint32), np.array([10, 10, 5, 1], np.uint32),
+                np.array([1, 1, 0, 0], np.uint32), np.array([5, 100], np.uint64), np.array([1, 0], np.uint8))
+
+
+def _rand_case(rng, n, m, p_none=0.5, cap_scale=1.0, p_alive=0.85, skew=False, max_load=50):
+    cur = rng.integers(0, m, n).astype(np.uint32)
+    cur[rng.random(n) < p_none] = NONE
+    load = rng.integers(0, max_load, n).astype(np.uint32)
+    if skew:
+        aff = np.minimum((rng.pareto(1.2, n)).astype(np.int64), m - 1).astype(np.uint32)
+    else:
+        aff = rng.integers(0, m, n).astype(np.uint32)
+    aff[rng.random(n) < 0.03] = NONE
+    alive = (rng.random(m) < p_alive).astype(np.uint8)
+    cap = rng.integers(0, int(load.sum() * cap_scale / max(m, 1)) + 2, m).astype(np.uint64)
+    return cur, load, aff, cap, alive
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_tick_random_small(gp, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n, m = int(rng.integers(1, 5000)), int(rng.integers(1, 64))
+    _check_tick(gp, oracle, *_rand_case(rng, n, m, cap_scale=float(rng.choice([0.3, 1.0, 2.5]))),
+                rounds=int(rng.integers(1, 4)))
+
+
+@pytest.mark.parametrize("seed,n,m,skew", [(1, 300_000, 1024, False), (2, 1_000_003, 256, False),
+                                           (3, 777_777, 4096, True), (4, 65_536, 7, True), (5, 2_000_000, 8192, False)])
+def test_tick_random_large(gp, oracle, seed, n, m, skew):
+    rng = np.random.default_rng(2000 + seed)
+    st = _check_tick(gp, oracle, *_rand_case(rng, n, m, cap_scale=1.2, skew=skew, max_load=70000))
+    assert st["slow_path"] == 1
+
+
+def test_tick_fast_path_no_contention(gp, oracle):
+    cfg = synth.config("c3", n_override=500_000)
+    st = _check_tick(gp, oracle, cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
+    assert st["slow_path"] == 0 and st["claimed"] == cfg["n"] and st["unplaced"] == 0
+
+
+def test_tick_all_one_node_worst_case(gp, oracle):
+    """Every object claims node 0: one cut, one block holds it, everything else spills."""
+    n, m = 400_000, 16
+    rng = np.random.default_rng(5)
+    load = rng.integers(1, 20, n).astype(np.uint32)
+    cap = np.full(m, int(load.sum()) // 10, np.uint64)
+    _check_tick(gp, oracle, np.full(n, NONE, np.uint32), load, np.zeros(n, np.uint32), cap, np.ones(m, np.uint8),
+                rounds=3)
+
+
+def test_tick_tiny_capacity_cuts_in_first_block(gp, oracle):
+    """Free capacity ~0 everywhere: all M cuts fall into the first sub-chunks."""
+    n, m = 300_000, 1024
+    rng = np.random.default_rng(6)
+    load = rng.integers(1, 9, n).astype(np.uint32)
+    _check_tick(gp, oracle, np.full(n, NONE, np.uint32), load, rng.integers(0, m, n).astype(np.uint32),
+                rng.integers(0, 40, m).astype(np.uint64), np.ones(m, np.uint8))
+
+
+def test_tick_edge_shapes(gp, oracle):
+    one = np.ones(1, np.uint8)
+    _check_tick(gp, oracle, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32),
+                np.array([5], np.uint64), one)                                           # empty table
+    _check_tick(gp, oracle, np.array([NONE], np.uint32), np.array([0], np.uint32), np.array([0], np.uint32),
+                np.array([0], np.uint64), one)                                           # zero load fits zero cap
+    _check_tick(gp, oracle, np.full(257, NONE, np.uint32), np.full(257, 0xFFFFFFFF, np.uint32),
+                np.zeros(257, np.uint32), np.array([INF, 7], np.uint64), np.ones(2, np.uint8))  # max loads, inf cap
+    _check_tick(gp, oracle, np.full(1000, NONE, np.uint32), np.ones(1000, np.uint32), np.zeros(1000, np.uint32),
+                np.full(3, 10, np.uint64), np.zeros(3, np.uint8))                        # no live node at all
+
+
+def test_tick_equals_reference_policy_capacity_infinite(gp, oracle):
+    """cap = inf: the kernels reproduce service.rs:193-254 run object by object (string oracle)."""
+    rng = np.random.default_rng(11)
+    n, m = 3000, 12
+    alive = np.ones(m, np.uint8)
+    alive[[3, 7]] = 0
+    cur = rng.integers(0, m, n).astype(np.uint32)
+    cur[rng.random(n) < 0.5] = NONE
+    live = np.flatnonzero(alive)
+    aff = live[rng.integers(0, len(live), n)].astype(np.uint32)
+    g = _mk(gp, n, m, np.ones(n, np.uint32), aff, np.full(m, INF, np.uint64), alive, cur)
+    g.tick()
+    got = g.get_assign()
+    g.close()
+    provider = oracle.LocalObjectPlacement()
+    storage = oracle.LocalStorage()
+    for j in range(m):
+        ip, port = synth.node_address(j).split(":")
+        storage.push(ip, port, bool(alive[j]))
+    for i in range(n):
+        if cur[i] != NONE:
+            provider.update("Obj", str(i), synth.node_address(int(cur[i])))
+    for i in range(n):
+        want = oracle.get_or_create_placement(provider, storage, synth.node_address(int(aff[i])), "Obj", str(i))
+        assert want == synth.node_address(int(got[i]))
+
+
+def test_solve_is_deterministic_and_idempotent(gp, oracle):
+    rng = np.random.default_rng(21)
+    cur, load, aff, cap, alive = _rand_case(rng, 600_000, 512, cap_scale=1.1, max_load=1000)
+    g = _mk(gp, len(cur), len(cap), load, aff, cap, alive, cur)
+    g.solve()
+    a = g.get_solved()
+    for _ in range(3):
+        g.solve()
+        assert np.array_equal(g.get_solved(), a)           # same bytes run after run
+    g.commit()
+    g.tick()
+    b = g.get_assign()
+    placed = a != NONE
+    assert np.array_equal(b[placed], a[placed])              # a second tick moves nothing that was placed
+    g.close()
+
+
+def test_async_solves_match_sync(gp, oracle):
+    cfg = synth.config("c3", n_override=300_000)
+    g = _mk(gp, cfg["n"], cfg["m"], cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
+    for _ in range(5):
+        g.solve_async()
+    st, n_slow = g.solve_wait()
+    want, used, ost = oracle.tick(cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
+    assert n_slow == 0 and st == ost and np.array_equal(g.get_solved(), want)
+    # and a contended one through the async path
+    cap = cfg["cap"] // np.uint64(2)
+    g.set_nodes(cap, cfg["alive"])
+    g.solve_async()
+    st, n_slow = g.solve_wait()
+    want, used, ost = oracle.tick(cfg["cur"], cfg["load"], cfg["aff"], cap, cfg["alive"])
+    assert n_slow == 1 and st == ost and np.array_equal(g.get_solved(), want)
+    g.close()
+
+
+# ---- place_pending ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed,cap_inf", [(0, True), (1, False), (2, False), (3, True)])
+def test_place_pending_random(gp, oracle, seed, cap_inf):
+    rng = np.random.default_rng(3000 + seed)
+    n, m = int(rng.integers(200, 50000)), int(rng.integers(2, 200))
+    load = rng.integers(0, 30, n).astype(np.uint32)
+    cap = np.full(m, INF, np.uint64) if cap_inf else rng.integers(0, int(load.sum() / m) + 5, m).astype(np.uint64)
+    alive = np.ones(m, np.uint8)
+    g = gp.GpuPlacement(n, m, spill_rounds=2)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step in range(10):
+        if step % 3 == 1:
+            j = int(rng.integers(m))
+            alive[j] ^= 1
+            g.set_alive(j, alive[j])
+        k = int(rng.integers(1, 20000))
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        req = rng.integers(0, m, k).astype(np.uint32)
+        node, flag = g.place_pending(idx, req)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(node, wnode) and np.array_equal(flag, wflag), step
+        assert np.array_equal(g.get_assign(), ref)
+        assert np.array_equal(g.get_nodes()[2], used)
+    g.close()
+
+
+def test_config1_ping_pong_plumbing(gp, oracle):
+    """BASELINE config 1: 1 000 objects x 4 nodes: 1 000 misses -> first touch -> 1 000 hits ->
+    clean_server(node 2) -> re-place, against the string-level reference policy."""
+    cfg = synth.config("c1")
+    n, m = cfg["n"], cfg["m"]
+    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
+    provider, storage = oracle.LocalObjectPlacement(), oracle.LocalStorage()
+    for j in range(m):
+        ip, port = synth.node_address(j).split(":")
+        storage.push(ip, port, True)
+    idx = np.arange(n, dtype=np.uint32)
+    assert np.all(g.lookup_batch(idx) == NONE)
+    node, flag = g.place_pending(idx, cfg["aff"])
+    assert np.all(flag == gp.FLAG_PLACED) and np.array_equal(node, cfg["aff"])
+    for i in range(n):
+        assert oracle.get_or_create_placement(provider, storage, synth.node_address(int(cfg["aff"][i])), "Room",
+                                              str(i)) == synth.node_address(int(node[i]))
+    node2, flag2 = g.place_pending(idx, np.full(n, 1, np.uint32))        # every request lands on server 1
+    assert np.array_equal(node2, node) and np.all(flag2 == np.where(node == 1, gp.FLAG_LOCAL, gp.FLAG_REDIRECT))
+    ev = g.clean_server(2)
+    provider.clean_server(synth.node_address(2))
+    assert ev == int((cfg["aff"] == 2).sum())
+    g.set_alive(2, 0)
+    storage.set_is_active(*synth.node_address(2).split(":"), False)
+    node3, flag3 = g.place_pending(idx, np.full(n, 3, np.uint32))
+    for i in range(n):
+        assert oracle.get_or_create_placement(provider, storage, synth.node_address(3), "Room", str(i)) == \
+            synth.node_address(int(node3[i]))
+    assert np.all(node3[cfg["aff"] == 2] == 3)
+    g.close()
+
+
+# ---- full-size properties (BASELINE sizes; size-independent checks, no oracle run) -------------------
+
+def test_full_size_config3_properties(gp):
+    cfg = synth.config("c3")
+    n, m = cfg["n"], cfg["m"]
+    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
+    st = g.tick()
+    a = g.get_assign()
+    assert st["slow_path"] == 0 and st["claimed"] == n and np.array_equal(a, cfg["aff"])  # no node overflows
+    used = g.get_nodes()[2]
+    assert int(used.sum()) == int(cfg["load"].astype(np.uint64).sum())                   # checksum of checksums
+    assert np.array_equal(used, np.bincount(a, weights=cfg["load"].astype(np.float64), minlength=m).astype(np.uint64))
+    assert np.all(used <= cfg["cap"])
+    # churn: 10 % of the nodes die -> evict + re-place, nothing lands on a dead node, capacity holds
+    alive = synth.churn_mask(m, 1)
+    g.set_alive_all(alive)
+    st2 = g.tick()
+    b = g.get_assign()
+    moved = a != b
+    assert st2["evicted"] == int((alive[a] == 0).sum()) == int(moved.sum())
+    assert np.all(alive[b[b != NONE]] == 1)
+    used2 = g.get_nodes()[2]
+    assert np.all(used2[alive == 1] <= cfg["cap"][alive == 1]) and np.all(used2[alive == 0] == 0)
+    assert st2["kept"] + st2["claimed"] + st2["spilled"] + st2["unplaced"] == n
+    st3 = g.tick()                                                                         # idempotent
+    assert st3["evicted"] == 0 and np.array_equal(g.get_assign()[b != NONE], b[b != NONE])
+    # clean_server == evict-by-scan
+    ev = g.clean_server(int(b[0]))
+    assert ev == int((b == b[0]).sum())
+    g.close()
