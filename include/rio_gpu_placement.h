@@ -197,6 +197,11 @@ int rio_gp_timer_end(rio_gp_t* h, float* ms);
  * resolve_ms = k_resolve.  Does not publish; fails with RIO_GP_EINVAL if the solve needs the
  * cut/spill fix-up (use rio_gp_solve then). */
 int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms);
+/* A/B knob for tools/sweep_scan.py: tiles per wave-iteration of k_scan (1 | 2 | 4); process-wide. */
+void rio_gp_debug_set_scan_tpi(int tpi);
+/* Measurement aid: pure streaming kernels with k_scan's traffic mix (3 columns in, 1 out) over the handle's
+ * own columns; mode 0 grid-stride | 1 block-tiled | 2 wave-contiguous | 3 read-only | 4 1:1 copy.  ms per launch. */
+int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms);
 
 #ifdef __cplusplus
 }

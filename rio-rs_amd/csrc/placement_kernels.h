@@ -21,15 +21,16 @@ constexpr u32 kMaxBlocks = 256;      // = CUs; rows of the per-block histogram t
 constexpr u32 kMaxSubs = 256;        // sub-chunks per block for the exact-cut refinement
 
 // Work decomposition of a table of n rows.  Index order is the only order that matters:
-// wave `gw` owns the contiguous rows [gw*wchunk, (gw+1)*wchunk), block b owns kWaves consecutive
-// wave ranges, sub-chunk t of block b is [b*chunk + t*sub, +sub).
+// the table is `tiles` tiles of kTile rows; wave `gw` (of nw = G*kWaves) owns the contiguous tiles
+// [gw*tiles/nw, (gw+1)*tiles/nw) (balanced to +-1 tile), block b owns kWaves consecutive wave
+// ranges, sub-chunk t of block b is [block_row_lo(b) + t*sub, +sub).
 struct Plan {
     u64 n;       // rows
-    u64 wchunk;  // rows per wave range (multiple of kTile)
-    u64 chunk;   // rows per block = kWaves * wchunk
+    u64 tiles;   // ceil(n / kTile)
+    u32 nw;      // wave ranges = G * kWaves
     u32 G;       // blocks (<= kMaxBlocks)
-    u32 sub;     // rows per sub-chunk (multiple of kTile), chunk/sub <= kMaxSubs
-    u32 subs;    // sub-chunks per block
+    u32 sub;     // rows per sub-chunk (multiple of kTile)
+    u32 subs;    // sub-chunks per block (<= kMaxSubs)
     u32 m;       // nodes
     u32 mwords;  // ceil(m/32)
 };
@@ -49,6 +50,7 @@ struct DevStats {
 // Scratch of one solve over one table (real table or the virtual table of place_pending).
 struct SolveBufs {
     u64* H;          // [G][2m]  per-block load histograms: kept-by-cur | claim-by-aff
+    u64* partial;    // [ceil(m/4)][8] k_resolve per-workgroup partial counters (device copy)
     u64* blkstat;    // [G][4]   kept, evicted, claimants rows per block
     u64* wsp_sum[2]; // [G*kWaves] spill-candidate load per wave range (ping-pong over rounds)
     u32* wsp_cnt[2]; // [G*kWaves]
@@ -82,8 +84,16 @@ struct NodeTab {
 };
 
 // --- solve pipeline ---
-void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s);
-void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, hipStream_t s);
+void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
+                 hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// host_partial: pinned host rows [resolve_blocks(m)][8] = load_kept, load_claim_tot, n_cut, kept, evicted,
+// claimants, spillcand, present — the caller adds the rows up (no atomics / copy kernel on the stream)
+void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
+                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+unsigned resolve_blocks(u32 m);
+void set_scan_tpi(int tpi);
+float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
+                   hipEvent_t e0, hipEvent_t e1);
 void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s);
 void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
                         hipStream_t s);

@@ -19,6 +19,8 @@
 //     on dispatch order, so the output is bit-identical to the sequential oracle.
 #include "placement_kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace riogp {
 
 // ------------------------------------------------------------------------------------------------
@@ -68,6 +70,15 @@ __device__ __forceinline__ u32 wave_sum32(u32 v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
+// Balanced, index-ordered split of the table: wave gw owns tiles [gw*tiles/nw, (gw+1)*tiles/nw).
+__host__ __device__ __forceinline__ u64 wave_row_lo(const Plan& p, u64 gw) { return (gw * p.tiles / p.nw) * kTile; }
+__device__ __forceinline__ void wave_range(const Plan& p, u64 gw, u64& wstart, u64& wend) {
+    wstart = wave_row_lo(p, gw);
+    wend = wave_row_lo(p, gw + 1);
+    if (wend > p.n) wend = p.n;
+    if (wstart > wend) wstart = wend;
+}
+__device__ __forceinline__ u64 block_row_lo(const Plan& p, u32 b) { return wave_row_lo(p, (u64)b * kWaves); }
 constexpr int kSmall = 128;  // bytes of small per-block scratch at the head of the dynamic LDS region
 __device__ __forceinline__ bool bit_of(const u32* bits, u32 j) { return (bits[j >> 5] >> (j & 31)) & 1u; }
 
@@ -81,21 +92,21 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     if (tiles == 0) tiles = 1;
     u64 g = (tiles + kWaves - 1) / kWaves;
     if (g > max_blocks) g = max_blocks;
-    u64 wtiles = (tiles + g * kWaves - 1) / (g * kWaves);
-    p.wchunk = wtiles * kTile;
-    p.chunk = p.wchunk * kWaves;
-    p.G = (u32)((n + p.chunk - 1) / p.chunk);
-    if (p.G == 0) p.G = 1;
-    u64 tpb = wtiles * kWaves;  // tiles per block
-    u64 sub_tiles = (tpb + kMaxSubs - 1) / kMaxSubs;
+    p.tiles = tiles;
+    p.G = (u32)g;
+    p.nw = p.G * kWaves;
+    // rows of the largest block: ceil(tiles*16/nw) tiles (+1 for the floor/ceil jitter of the split)
+    const u64 max_block_tiles = (tiles * kWaves + p.nw - 1) / p.nw + 1;
+    const u64 sub_tiles = (max_block_tiles + kMaxSubs - 1) / kMaxSubs;
     p.sub = (u32)(sub_tiles * kTile);
-    p.subs = (u32)((p.chunk + p.sub - 1) / p.sub);
+    p.subs = (u32)((max_block_tiles * kTile + p.sub - 1) / p.sub);
+    if (p.subs > kMaxSubs) p.subs = kMaxSubs;
     return p;
 }
 
 size_t scan_lds_bytes(u32 m) {
     u32 mwords = (m + 31) / 32;
-    size_t b = kSmall + (size_t)2 * m * sizeof(u64) + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 64;
+    size_t b = kSmall + ((size_t)2 * m + 2) * sizeof(u64) + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 64;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -121,9 +132,78 @@ __device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv) {
 // K1  k_scan — THE streaming kernel: one pass over cur/load/aff (12 B/row read), optimistic
 //     write of the new assignment (4 B/row), per-block per-node load histograms in LDS.
 //     Algorithmic traffic 16 B/row; everything else is <3 % overhead:
-//     H rows 2*m*8 B per block, 3 words per wave.
+//     H row 2*m*8 B per block, 3 words per wave.
+//     The row body is branch-free (one ds_add_u64 per row, trash bin for rows that add nothing;
+//     counters are wave-uniform popcounts of ballots) so the next tile's three dwordx4 loads stay
+//     in flight under a counted vmcnt while the current tile is processed.
 // ------------------------------------------------------------------------------------------------
-template <bool VIRT>
+template <bool VIRT, bool ALLALIVE, bool CHECK, int HMODE = 0>
+__device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const uint4 lv, const u64 i0, const u64 wend,
+                                          const u32 m, const u32* alv, u64* hist, u32* __restrict__ next,
+                                          u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt) {
+    uint4 ov;
+    u64 sp_local = 0;
+    u32 any_sp = 0;
+#define RIOGP_ROW(C, A, L, O, E)                                                                       \
+    {                                                                                                  \
+        const bool inr = !CHECK || (i0 + E < wend);                                                    \
+        const bool cin = C < m, ain = A < m;                                                           \
+        const u32 cc = cin ? C : 0, aa = ain ? A : 0;                                                  \
+        const bool skip = VIRT && C == kSkipMark;                                                      \
+        const bool kept = inr && cin && (VIRT || ALLALIVE || bit_of(alv, cc));                         \
+        const bool cl = inr && !kept && !skip && ain && (ALLALIVE || bit_of(alv, aa));                 \
+        const bool sp = inr && !kept && !cl && !skip;                                                  \
+        const u32 bin = (kept && !VIRT) ? cc : (cl ? m + aa : 2 * m);                                  \
+        if (HMODE == 0) atomicAdd(&hist[bin], (u64)L);                                                 \
+        else if (HMODE == 2) atomicAdd(reinterpret_cast<u32*>(hist) + bin, (u32)L);                    \
+        O = kept ? C : (cl ? A : (skip ? kSkipMark : kSpillMark));                                     \
+        kept_cnt += (u32)__popcll(__ballot(kept));                                                     \
+        claim_cnt += (u32)__popcll(__ballot(cl));                                                      \
+        if (!VIRT) evict_cnt += (u32)__popcll(__ballot(inr && !kept && C != kNone));                   \
+        sp_local += sp ? (u64)L : 0;                                                                   \
+        any_sp |= sp;                                                                                  \
+    }
+    RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
+    RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
+    RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
+    RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
+#undef RIOGP_ROW
+    const u64 spmask = __ballot(any_sp);
+    if (spmask) {  // wave-uniform, never taken on the fast path
+        sp_sum += sp_local;
+        // exact row count of spill candidates in this tile
+        u32 c = 0;
+        c += (!CHECK || i0 + 0 < wend) && ov.x == kSpillMark;
+        c += (!CHECK || i0 + 1 < wend) && ov.y == kSpillMark;
+        c += (!CHECK || i0 + 2 < wend) && ov.z == kSpillMark;
+        c += (!CHECK || i0 + 3 < wend) && ov.w == kSpillMark;
+        sp_cnt += c;
+    }
+    if (!CHECK || i0 + 3 < wend) {
+        *reinterpret_cast<uint4*>(next + i0) = ov;
+    } else {
+        if (i0 + 0 < wend) next[i0 + 0] = ov.x;
+        if (i0 + 1 < wend) next[i0 + 1] = ov.y;
+        if (i0 + 2 < wend) next[i0 + 2] = ov.z;
+    }
+}
+
+template <bool NT>
+__device__ __forceinline__ uint4 ld4(const u32* p) {
+    if (NT) {
+        uint4 r;
+        r.x = __builtin_nontemporal_load(p + 0);
+        r.y = __builtin_nontemporal_load(p + 1);
+        r.z = __builtin_nontemporal_load(p + 2);
+        r.w = __builtin_nontemporal_load(p + 3);
+        return r;
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
+
+// TPI = tiles (of 256 rows) a wave processes per loop iteration; the next TPI tiles are always in
+// flight while the current ones are processed.
+template <bool VIRT, bool ALLALIVE, int TPI, int HMODE = 0>
 __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                  const u32* __restrict__ aff, u32* __restrict__ next,
                                                  const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
@@ -132,209 +212,216 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u32* bst = reinterpret_cast<u32*>(smem);                 // [4] (first 128 B: small scratch, G17)
-    u64* hist = reinterpret_cast<u64*>(smem + kSmall);       // [2m] kept-by-cur | claim-by-aff
-    u32* alv = reinterpret_cast<u32*>(hist + 2 * m);         // [mwords]
+    u64* hist = reinterpret_cast<u64*>(smem + kSmall);       // [2m + 2] kept-by-cur | claim-by-aff | trash
+    u32* alv = reinterpret_cast<u32*>(hist + 2 * m + 2);     // [mwords]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (u32 k = tid; k < 2 * m; k += kBlock) hist[k] = 0;
-    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+    const u64 span = wend > wstart ? wend - wstart : 0;
+    const u64 wfull = wstart + (span / kTile) * kTile;                  // end of the full tiles
+    const u64 wgrp = wstart + (span / (kTile * TPI)) * (kTile * TPI);   // end of the full TPI-tile groups
+
+    // first group of loads goes out BEFORE the LDS set-up and its barrier: HBM latency overlaps both
+    u64 it = wstart;
+    uint4 cv[TPI], av[TPI], lv[TPI];
+    if (it < wgrp) {
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const u64 i = it + (u64)q * kTile + (u64)lane * 4;
+            cv[q] = *reinterpret_cast<const uint4*>(cur + i);
+            av[q] = *reinterpret_cast<const uint4*>(aff + i);
+            lv[q] = *reinterpret_cast<const uint4*>(load + i);
+        }
+    }
+
+    for (u32 k = tid; k < 2 * m + 2; k += kBlock) hist[k] = 0;
+    if (!ALLALIVE)
+        for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
     if (tid < 4) bst[tid] = 0;
-    if (blockIdx.x == 0 && tid == 0) {  // accumulators later kernels add into
-        stats->load_kept = 0; stats->load_claim_tot = 0; stats->n_cut = 0;
+    if (blockIdx.x == 0 && tid == 0) {  // accumulators the fix-up kernels add into
         stats->rejected = 0; stats->load_rejected = 0;
         stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
         stats->rounds_run = 0;
     }
     __syncthreads();
 
-    const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    const u64 wstart = gw * p.wchunk;
-    u64 wend = wstart + p.wchunk;
-    if (wend > p.n) wend = p.n;
-
     u64 sp_sum = 0;
-    u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;
+    u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;  // kept/evict/claim are wave-uniform
 
-    u64 it = wstart;
-    uint4 cv, av, lv;
-    if (it < wend) {
-        const u64 i = it + (u64)lane * 4;
-        cv = *reinterpret_cast<const uint4*>(cur + i);
-        av = *reinterpret_cast<const uint4*>(aff + i);
-        lv = *reinterpret_cast<const uint4*>(load + i);
-    }
-    while (it < wend) {
-        const u64 nit = it + kTile;
-        uint4 cn, an, ln;
-        if (nit < wend) {  // software prefetch of the next tile (wave-uniform branch)
-            const u64 i = nit + (u64)lane * 4;
-            cn = *reinterpret_cast<const uint4*>(cur + i);
-            an = *reinterpret_cast<const uint4*>(aff + i);
-            ln = *reinterpret_cast<const uint4*>(load + i);
+    while (it < wgrp) {
+        const u64 nit = it + (u64)kTile * TPI;
+        // Software prefetch of the next group — UNCONDITIONAL (the columns are padded by >= 4 tiles) so the
+        // loop body is straight-line and these loads stay in flight while the current group is processed.
+        uint4 cn[TPI], an[TPI], ln[TPI];
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const u64 i = nit + (u64)q * kTile + (u64)lane * 4;
+            cn[q] = *reinterpret_cast<const uint4*>(cur + i);
+            an[q] = *reinterpret_cast<const uint4*>(aff + i);
+            ln[q] = *reinterpret_cast<const uint4*>(load + i);
         }
-        const u64 i0 = it + (u64)lane * 4;
-        uint4 ov;
-#define RIOGP_ROW(C, A, L, O, E)                                          \
-        if (i0 + E < wend) {                                              \
-            const int cls = classify<VIRT>(C, A, m, alv);                 \
-            if (cls == 0) {                                               \
-                O = C;                                                    \
-                if (!VIRT) { atomicAdd(&hist[C], (u64)L); ++kept_cnt; }   \
-            } else if (cls == 1) {                                        \
-                O = A;                                                    \
-                atomicAdd(&hist[m + A], (u64)L);                          \
-                ++claim_cnt;                                              \
-                if (!VIRT && C != kNone) ++evict_cnt;                     \
-            } else if (cls == 2) {                                        \
-                O = kSpillMark;                                           \
-                sp_sum += L; ++sp_cnt;                                    \
-                if (!VIRT && C != kNone) ++evict_cnt;                     \
-            } else {                                                      \
-                O = kSkipMark;                                            \
-            }                                                             \
-        } else { O = kNone; }
-        RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
-        RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
-        RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
-        RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
-#undef RIOGP_ROW
-        if (i0 + 3 < wend) {
-            *reinterpret_cast<uint4*>(next + i0) = ov;
-        } else {
-            if (i0 + 0 < wend) next[i0 + 0] = ov.x;
-            if (i0 + 1 < wend) next[i0 + 1] = ov.y;
-            if (i0 + 2 < wend) next[i0 + 2] = ov.z;
-        }
+#pragma unroll
+        for (int q = 0; q < TPI; ++q)
+            scan_tile<VIRT, ALLALIVE, false, HMODE>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend, m,
+                                                    alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt, claim_cnt);
         it = nit;
-        cv = cn; av = an; lv = ln;
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
+    }
+    for (; it < wend; it += kTile) {  // leftover full tiles (< TPI) and the ragged last tile of the table
+        const u64 i = it + (u64)lane * 4;
+        const uint4 c1 = *reinterpret_cast<const uint4*>(cur + i);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(aff + i);
+        const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
+        if (it < wfull)
+            scan_tile<VIRT, ALLALIVE, false>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                             evict_cnt, claim_cnt);
+        else
+            scan_tile<VIRT, ALLALIVE, true>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                            evict_cnt, claim_cnt);
     }
 
     // per-wave spill-candidate totals (index-ordered prefix over wave ranges comes later)
     sp_sum = wave_sum(sp_sum);
     sp_cnt = wave_sum32(sp_cnt);
-    kept_cnt = wave_sum32(kept_cnt);
-    evict_cnt = wave_sum32(evict_cnt);
-    claim_cnt = wave_sum32(claim_cnt);
     if (lane == 0) {
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
         atomicAdd(&bst[0], kept_cnt);
         atomicAdd(&bst[1], evict_cnt);
         atomicAdd(&bst[2], claim_cnt);
+        atomicAdd(&bst[3], sp_cnt);
     }
     __syncthreads();
     u64* Hrow = H + (size_t)blockIdx.x * 2 * m;
     for (u32 k = tid; k < 2 * m; k += kBlock) Hrow[k] = hist[k];
-    if (tid < 3) blkstat[(size_t)blockIdx.x * 4 + tid] = bst[tid];
+    if (tid < 4) blkstat[(size_t)blockIdx.x * 4 + tid] = bst[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2  k_resolve — per node: used = sum over blocks, free, claim total, and the block in which the
-//     index-ordered claim prefix first exceeds free ("cut block").  16 nodes per workgroup,
-//     16 row-groups x 16 nodes: every H load of a thread is issued before the first wait.
+// K2  k_resolve — per node: used = sum over blocks of the kept histogram, claim total, free, and
+//     the verdict "claims fit" (fast path) or "cut" (fix-up needed).  Column sums of the row-major
+//     [G][2m] table, spread over m/4 workgroups (all CUs, ~16 KiB each): thread = (row group, column),
+//     8 columns per workgroup = 4 nodes x {kept, claim}; every load is issued before the first wait.
+//     Per-workgroup partial counters go straight into the caller's pinned host slot (plain stores,
+//     no atomics, no fences, no copy kernel); the host adds the rows up.
 // ------------------------------------------------------------------------------------------------
-constexpr int kResNodes = 16, kResGroups = 16, kResRows = kMaxBlocks / kResGroups;  // 16 rows/thread
+constexpr int kResNodes = 4;
+constexpr int kResRowGroups = 32;                          // 256 threads = 32 row groups x 8 columns
+constexpr int kResRows = kMaxBlocks / kResRowGroups;       // 8 loads per thread
 
-__global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, const u64* __restrict__ blkstat,
-                                                 const u32* __restrict__ wsp_cnt, Plan p,
+__global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, const u64* __restrict__ blkstat, Plan p,
                                                  const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
                                                  const u64* __restrict__ used_base, u64* __restrict__ used_kept,
                                                  u64* __restrict__ used_cur, u64* __restrict__ claim_tot,
-                                                 u32* __restrict__ cutblk, u64* __restrict__ budget,
-                                                 u64* __restrict__ admpre, u32* __restrict__ cutidx,
-                                                 DevStats* __restrict__ stats) {
-    __shared__ u64 su[kResGroups][kResNodes], sc[kResGroups][kResNodes];
+                                                 u32* __restrict__ cutblk, u32* __restrict__ cutidx,
+                                                 u64* __restrict__ partial, u64* __restrict__ host_partial) {
+    __shared__ u64 part[kResRowGroups][8];
+    __shared__ u64 tot[8];
     __shared__ u64 red[8];
-    const int tid = threadIdx.x, nd = tid & (kResNodes - 1), grp = tid >> 4;
-    const u32 m = p.m, G = p.G;
-    const u32 j = blockIdx.x * kResNodes + nd;
+    const int tid = threadIdx.x, lane = tid & 63, col = tid & 7, rg = tid >> 3;
+    const u32 m = p.m, G = p.G, nb = gridDim.x;
+    const u32 j = blockIdx.x * kResNodes + (col & 3);
     const bool valid = j < m;
-    const u32 rows = (G + kResGroups - 1) / kResGroups;  // <= kResRows
-    u64 cu[kResRows], cc[kResRows];
-    u64 tu = 0, tc = 0;
+    const size_t c = (col < 4) ? (size_t)j : (size_t)m + j;
+    u64 v[kResRows];
 #pragma unroll
     for (int r = 0; r < kResRows; ++r) {
-        const u32 row = grp * rows + r;
-        const bool ok = valid && (u32)r < rows && row < G;
-        cu[r] = ok ? H[(size_t)row * 2 * m + j] : 0;
-        cc[r] = ok ? H[(size_t)row * 2 * m + m + j] : 0;
+        const u32 row = rg + r * kResRowGroups;
+        v[r] = (valid && row < G) ? H[(size_t)row * 2 * m + c] : 0;
     }
+    u64 sacc = 0;
 #pragma unroll
-    for (int r = 0; r < kResRows; ++r) { tu += cu[r]; tc += cc[r]; }
-    su[grp][nd] = tu;
-    sc[grp][nd] = tc;
+    for (int r = 0; r < kResRows; ++r) sacc += v[r];
+    part[rg][col] = sacc;
     if (tid < 8) red[tid] = 0;
     __syncthreads();
-    u64 used = 0, ctot = 0, pre = 0;
+    if (tid < 8) {
+        u64 t = 0;
 #pragma unroll
-    for (int g = 0; g < kResGroups; ++g) {
-        used += su[g][nd];
-        ctot += sc[g][nd];
-        if (g < grp) pre += sc[g][nd];
-    }
-    if (valid) {
-        const u64 kept_load = used;
-        if (used_base) used += used_base[j];
-        const bool alive = bit_of(alive_bits, j);
-        const u64 c = cap[j];
-        const u64 fre = (alive && c > used) ? c - used : 0;
-        if (ctot <= fre) {
-            if (grp == 0) {
-                used_kept[j] = used;
-                used_cur[j] = used + ctot;
-                claim_tot[j] = ctot;
-                cutblk[j] = kNoCut;
-                cutidx[j] = kNoCut;
-                budget[j] = fre;
-                admpre[j] = ctot;
-                atomicAdd(&red[0], kept_load);
-                atomicAdd(&red[1], ctot);
-            }
-        } else {
-            if (grp == 0) {
-                used_kept[j] = used;
-                claim_tot[j] = ctot;
-                atomicAdd(&red[0], kept_load);
-                atomicAdd(&red[1], ctot);
-                atomicAdd(&red[2], 1ull);
-            }
-            if (pre <= fre && pre + tc > fre) {  // the cut is inside this thread's row group
-                u64 cum = pre;
-#pragma unroll
-                for (int r = 0; r < kResRows; ++r) {
-                    if (cum <= fre && cum + cc[r] > fre) {
-                        cutblk[j] = grp * rows + r;
-                        budget[j] = fre - cum;
-                        admpre[j] = cum;
-                    }
-                    cum += cc[r];
-                }
-            }
-        }
+        for (int g = 0; g < kResRowGroups; ++g) t += part[g][tid];
+        tot[tid] = t;
     }
     __syncthreads();
-    if (tid == 0) {
-        if (red[0]) atomicAdd(&stats->load_kept, red[0]);
-        if (red[1]) atomicAdd(&stats->load_claim_tot, red[1]);
-        if (red[2]) atomicAdd(&stats->n_cut, red[2]);
+    if (tid < 4 && valid) {
+        const u64 kept_load = tot[tid], ctot = tot[tid + 4];
+        u64 used = kept_load;
+        if (used_base) used += used_base[j];
+        const u64 cj = cap[j];
+        const u64 fre = (bit_of(alive_bits, j) && cj > used) ? cj - used : 0;
+        used_kept[j] = used;
+        claim_tot[j] = ctot;
+        cutblk[j] = kNoCut;
+        cutidx[j] = kNoCut;
+        used_cur[j] = used + ctot;  // final unless the node has a cut (k_cut_exact rewrites it)
+        atomicAdd(&red[0], kept_load);
+        atomicAdd(&red[1], ctot);
+        if (ctot > fre) atomicAdd(&red[2], 1ull);
     }
-    if (blockIdx.x == 0) {  // row counters of the scan: plain reduction, no atomics across launches
-        u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (u32 b = tid; b < G; b += 256) {
-            a0 += blkstat[(size_t)b * 4 + 0];
-            a1 += blkstat[(size_t)b * 4 + 1];
-            a2 += blkstat[(size_t)b * 4 + 2];
-        }
-        for (u32 w = tid; w < G * kWaves; w += 256) a3 += wsp_cnt[w];
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-        __shared__ u64 part[4][4];
-        if ((tid & 63) == 0) { part[tid >> 6][0] = a0; part[tid >> 6][1] = a1; part[tid >> 6][2] = a2; part[tid >> 6][3] = a3; }
-        __syncthreads();
-        if (tid == 0) {
-            stats->kept = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-            stats->evicted = part[0][1] + part[1][1] + part[2][1] + part[3][1];
-            stats->claimants = part[0][2] + part[1][2] + part[2][2] + part[3][2];
-            stats->spillcand = part[0][3] + part[1][3] + part[2][3] + part[3][3];
+    if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
+        u64 acc = 0;
+        for (u32 r = blockIdx.x + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
+        acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
+        if (lane < 4) red[3 + lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        const u64 x = (tid < 7) ? red[tid] : 1ull;  // column 7 = "row present" marker
+        partial[(size_t)blockIdx.x * 8 + tid] = x;
+        if (host_partial) host_partial[(size_t)blockIdx.x * 8 + tid] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2c k_cutblk — fix-up path only: for nodes whose claims exceed their free capacity, the block in
+//     which the index-ordered claim prefix first exceeds free ("cut block"), the budget left at its
+//     start and the load admitted before it.  16 nodes x 16 row-groups per workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCbNodes = 16, kCbGroups = 16, kCbRows = kMaxBlocks / kCbGroups;  // 16 rows/thread
+
+__global__ __launch_bounds__(256) void k_cutblk(const u64* __restrict__ H, Plan p, const u64* __restrict__ cap,
+                                                const u32* __restrict__ alive_bits,
+                                                const u64* __restrict__ used_kept,
+                                                const u64* __restrict__ claim_tot, u32* __restrict__ cutblk,
+                                                u64* __restrict__ budget, u64* __restrict__ admpre) {
+    __shared__ u64 sc[kCbGroups][kCbNodes];
+    const int tid = threadIdx.x, nd = tid & (kCbNodes - 1), grp = tid >> 4;
+    const u32 m = p.m, G = p.G;
+    const u32 j = blockIdx.x * kCbNodes + nd;
+    const bool valid = j < m;
+    const u32 rows = (G + kCbGroups - 1) / kCbGroups;  // <= kCbRows
+    u64 fre = 0, ctot = 0;
+    if (valid) {
+        const u64 c = cap[j], used = used_kept[j];
+        fre = (bit_of(alive_bits, j) && c > used) ? c - used : 0;
+        ctot = claim_tot[j];
+    }
+    const bool has_cut = valid && ctot > fre;
+    u64 cc[kCbRows];
+    u64 tc = 0;
+#pragma unroll
+    for (int r = 0; r < kCbRows; ++r) {
+        const u32 row = grp * rows + r;
+        cc[r] = (has_cut && (u32)r < rows && row < G) ? H[(size_t)row * 2 * m + m + j] : 0;
+        tc += cc[r];
+    }
+    sc[grp][nd] = tc;
+    __syncthreads();
+    if (!has_cut) return;
+    u64 pre = 0;
+    for (int g = 0; g < grp; ++g) pre += sc[g][nd];
+    if (pre <= fre && pre + tc > fre) {  // the cut is inside this thread's row group
+        u64 cum = pre;
+#pragma unroll
+        for (int r = 0; r < kCbRows; ++r) {
+            if (cum <= fre && cum + cc[r] > fre) {
+                cutblk[j] = grp * rows + r;
+                budget[j] = fre - cum;
+                admpre[j] = cum;
+            }
+            cum += cc[r];
         }
     }
 }
@@ -367,10 +454,9 @@ __global__ __launch_bounds__(kBlock) void k_cut_subhist(const u32* __restrict__ 
     __syncthreads();
     if (!any) return;
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    const u64 bstart = (u64)blockIdx.x * p.chunk;
-    const u64 wstart = gw * p.wchunk;
-    u64 wend = wstart + p.wchunk;
-    if (wend > p.n) wend = p.n;
+    const u64 bstart = block_row_lo(p, blockIdx.x);
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
     for (u64 it = wstart; it < wend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
         const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
@@ -425,9 +511,9 @@ __global__ __launch_bounds__(256) void k_cut_exact(const u32* __restrict__ cur, 
     }
     // (2) exact row inside the sub-chunk
     const u64 bud2 = bud - pre_sub;
-    const u64 start = (u64)b * p.chunk + (u64)tstar * p.sub;
+    const u64 start = block_row_lo(p, b) + (u64)tstar * p.sub;
     u64 end = start + p.sub;
-    if (end > (u64)(b + 1) * p.chunk) end = (u64)(b + 1) * p.chunk;
+    if (end > block_row_lo(p, b + 1)) end = block_row_lo(p, b + 1);
     if (end > p.n) end = p.n;
     u64 acc2 = 0, cut_row = kNoCut, adm_in = 0;
     found = false;
@@ -481,9 +567,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
     if (tid < 2) red[tid] = 0;
     __syncthreads();
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    const u64 wstart = gw * p.wchunk;
-    u64 wend = wstart + p.wchunk;
-    if (wend > p.n) wend = p.n;
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
     u64 sp_sum = 0, rej_sum = 0;
     u32 sp_cnt = 0, rej_cnt = 0;
     for (u64 it = wstart; it < wend; it += kTile) {
@@ -646,18 +731,16 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     u64* red = reinterpret_cast<u64*>(smem);           // [4]
     u64* C = reinterpret_cast<u64*>(smem + kSmall);    // [m+1]
     u64* adm = C + (m + 1);                            // [m] admitted load by node (this block)
-    u32* ord = reinterpret_cast<u32*>(adm + m);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 cnt = *wfCnt;
     for (u32 k = tid; k <= m; k += kBlock) C[k] = k <= cnt ? wfC[k] : ~0ull;
-    for (u32 k = tid; k < m; k += kBlock) { adm[k] = 0; ord[k] = k < cnt ? wfOrder[k] : kNone; }
+    for (u32 k = tid; k < m; k += kBlock) adm[k] = 0;
     if (tid < 4) red[tid] = 0;
     __syncthreads();
     const u64 F = C[cnt];
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    const u64 wstart = gw * p.wchunk;
-    u64 wend = wstart + p.wchunk;
-    if (wend > p.n) wend = p.n;
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
     u64 run = wsp_base[gw];
     u64 rem_sum = 0, pl_sum = 0;
     u32 rem_cnt = 0, pl_cnt = 0;
@@ -682,7 +765,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                     const u32 mid = lo + ((hi - lo) >> 1);                        \
                     if (C[mid] <= Q) lo = mid; else hi = mid;                     \
                 }                                                                 \
-                if (Q + L <= C[lo + 1]) nd = ord[lo];                             \
+                if (Q + L <= C[lo + 1]) nd = wfOrder[lo];                             \
             }                                                                     \
             if (nd != kNone) {                                                    \
                 next[i0 + E] = nd;                                                \
@@ -921,26 +1004,65 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
     return (unsigned)g;
 }
 
-void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s) {
+int g_scan_tpi = 1;  // tiles per wave-iteration of k_scan (1 | 2 | 4); set through set_scan_tpi() for A/B runs
+void set_scan_tpi(int tpi) { g_scan_tpi = tpi; }
+
+template <bool VIRT, bool AA, int TPI, int HMODE = 0>
+static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
+                          hipEvent_t e0, hipEvent_t e1) {
     const size_t lds = scan_lds_bytes(p.m);
-    if (virt)
-        hipLaunchKernelGGL(k_scan<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next, nt.alive_bits,
-                           p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+    if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
+        hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0, t.cur,
+                              t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
+                              b.stats);
     else
-        hipLaunchKernelGGL(k_scan<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next, nt.alive_bits,
-                           p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+        hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
+                           nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
 }
 
-void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, hipStream_t s) {
-    const unsigned grid = (p.m + kResNodes - 1) / kResNodes;
-    hipLaunchKernelGGL(k_resolve, dim3(grid ? grid : 1), dim3(256), 0, s, b.H, b.blkstat, b.wsp_cnt[0], p, nt.cap,
-                       nt.alive_bits, nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.budget,
-                       b.admpre, b.cutidx, b.stats);
+void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
+                 hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (virt) {
+        if (all_alive) launch_scan_t<true, true, 1>(p, t, nt, b, s, e0, e1);
+        else launch_scan_t<true, false, 1>(p, t, nt, b, s, e0, e1);
+        return;
+    }
+#define RIOGP_DISPATCH(TPI)                                                     \
+    if (all_alive) launch_scan_t<false, true, TPI>(p, t, nt, b, s, e0, e1);     \
+    else launch_scan_t<false, false, TPI>(p, t, nt, b, s, e0, e1);
+    if (g_scan_tpi == 11) { launch_scan_t<false, true, 1, 1>(p, t, nt, b, s, e0, e1); return; }  // experiment: no atomics
+    if (g_scan_tpi == 12) { launch_scan_t<false, true, 1, 2>(p, t, nt, b, s, e0, e1); return; }  // experiment: u32 atomics
+    if (g_scan_tpi == 1) { RIOGP_DISPATCH(1) }
+    else if (g_scan_tpi == 4) { RIOGP_DISPATCH(4) }
+    else if (g_scan_tpi == 2) { RIOGP_DISPATCH(2) }
+    else { RIOGP_DISPATCH(1) }
+#undef RIOGP_DISPATCH
+}
+
+unsigned resolve_blocks(u32 m) {
+    unsigned g = (m + kResNodes - 1) / kResNodes;
+    return g ? g : 1;
+}
+
+void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
+                    hipEvent_t e0, hipEvent_t e1) {
+    const unsigned grid = resolve_blocks(p.m);
+    if (e0 && e1)
+        hipExtLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, s, e0, e1, 0, b.H, b.blkstat, p, nt.cap,
+                              nt.alive_bits, nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx,
+                              b.partial, host_partial);
+    else
+        hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, s, b.H, b.blkstat, p, nt.cap, nt.alive_bits,
+                           nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, b.partial,
+                           host_partial);
 }
 
 void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
                       hipStream_t s) {
     (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
+    const unsigned gcb = (p.m + kCbNodes - 1) / kCbNodes;
+    hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
+                       b.claim_tot, b.cutblk, b.budget, b.admpre);
     const size_t lds = kSmall + ((size_t)p.m + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16;
     const unsigned g4 = (p.m + 3) / 4;
     if (virt) {
@@ -967,7 +1089,7 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
     const size_t lds_prep = 2 * kSmall + (size_t)2 * mp * sizeof(u64);
     hipLaunchKernelGGL(k_spill_prepare, dim3(1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
                        b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.stats);
-    const size_t lds_apply = kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + (size_t)p.m * sizeof(u32) + 16;
+    const size_t lds_apply = kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + 16;
     hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_base, b.wfC,
                        b.wfOrder, b.wfCnt, b.used_cur, b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats);
 }

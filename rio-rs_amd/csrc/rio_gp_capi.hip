@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -35,7 +36,7 @@ struct rio_gp {
     std::string err;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     u64 cap_obj = 0, cap_rows = 0;
     u32 cap_nodes = 0, rounds = 2;
     u64 n = 0;
@@ -53,7 +54,11 @@ struct rio_gp {
     // solve scratch
     SolveBufs sb{};
     DevStats* dstats = nullptr;
-    DevStats* h_stats = nullptr;  // pinned, kRing slots
+    DevStats* h_stats = nullptr;  // pinned scratch for D2H copies of the device accumulators ([0]) + verdicts
+    u64* h_slots = nullptr;       // pinned+mapped, kRing slots x slot_rows x 8: k_resolve partial counters
+    u64* d_slots = nullptr;       // the same memory as the device sees it
+    size_t slot_rows = 0;
+    bool all_alive = true;
     Plan plan{};
     bool have_solved = false;
     u32 ring_n = 0;
@@ -94,7 +99,7 @@ int dalloc(rio_gp* h, T** out, size_t count) {
 
 int ensure(rio_gp* h, DevBuf& b, size_t bytes) {
     bytes = (bytes + 4095) & ~(size_t)4095;
-    bytes += 4096;  // vector loads may read one tile past n
+    bytes += 8 * kTile * sizeof(u32);  // k_scan prefetches up to 4 tiles past n
     if (b.bytes >= bytes) return RIO_GP_OK;
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
@@ -133,21 +138,49 @@ void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, b
     for (u32 r = 0; r < h->rounds; ++r) launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream);
 }
 
+u64* slot_dev(rio_gp* h, u32 k) { return h->d_slots + (size_t)(k % kRing) * h->slot_rows * 8; }
+
+// host-side fold of the per-workgroup partial rows k_resolve stored into a pinned slot
+DevStats reduce_slot(rio_gp* h, u32 k, u32 m) {
+    DevStats d;
+    memset(&d, 0, sizeof d);
+    const u64* rows = h->h_slots + (size_t)(k % kRing) * h->slot_rows * 8;
+    const unsigned nb = resolve_blocks(m);
+    for (unsigned r = 0; r < nb; ++r) {
+        const u64* x = rows + (size_t)r * 8;
+        d.load_kept += x[0]; d.load_claim_tot += x[1]; d.n_cut += x[2];
+        d.kept += x[3]; d.evicted += x[4]; d.claimants += x[5]; d.spillcand += x[6];
+    }
+    return d;
+}
+
+// fold the fix-up kernels' device accumulators into a fast-path verdict
+int merge_slow(rio_gp* h, DevStats* v) {
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const DevStats& d = h->h_stats[0];
+    v->rejected = d.rejected; v->load_rejected = d.load_rejected;
+    v->spilled = d.spilled; v->load_spilled = d.load_spilled;
+    v->unplaced = d.unplaced; v->load_unplaced = d.load_unplaced;
+    v->rounds_run = d.rounds_run;
+    return RIO_GP_OK;
+}
+
 int solve_locked(rio_gp* h, rio_gp_stats* stats) {
     h->plan = make_plan(h->n, h->m, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
-    launch_scan(h->plan, t, nt, h->sb, false, h->stream);
-    launch_resolve(h->plan, nt, h->sb, h->stream);
-    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+    launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->h_stats[0].n_cut > 0 || h->h_stats[0].spillcand > 0) {
-        enqueue_slow(h, h->plan, t, nt, false, h->h_stats[0]);
-        HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+    DevStats v = reduce_slot(h, 0, h->m);
+    if (v.n_cut > 0 || v.spillcand > 0) {
+        enqueue_slow(h, h->plan, t, nt, false, v);
+        int rc = merge_slow(h, &v);
+        if (rc) return rc;
     }
     HIPCHK(h, hipGetLastError());
-    fill_stats(h->h_stats[0], h->n, stats);
+    fill_stats(v, h->n, stats);
     h->have_solved = true;
     h->ring_n = 0;
     return RIO_GP_OK;
@@ -217,8 +250,9 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     }
     rio_gp* h = new rio_gp();
     h->device = cfg->device;
+    if (const char* e = getenv("RIO_GP_SCAN_TPI")) set_scan_tpi(atoi(e));  // A/B knob for bench runs
     h->cap_obj = cfg->max_objects;
-    h->cap_rows = ((cfg->max_objects + kTile - 1) / kTile) * kTile + 2 * kTile;
+    h->cap_rows = ((cfg->max_objects + kTile - 1) / kTile) * kTile + 8 * kTile;  // k_scan prefetches past the end
     h->cap_nodes = cfg->max_nodes ? cfg->max_nodes : 1;
     h->rounds = cfg->spill_rounds ? cfg->spill_rounds : 2;
     int rc = RIO_GP_OK;
@@ -239,6 +273,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->cap, M); A(h->used, M); A(h->alive_bits, (M + 31) / 32 + 4); A(h->dead_bits, (M + 31) / 32 + 4);
     A(h->alive_bytes, M);
     A(h->sb.H, (size_t)kMaxBlocks * 2 * M); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
+    A(h->sb.partial, (size_t)resolve_blocks((u32)M) * 8 + 8);
     A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
     A(h->sb.wsp_base, W);
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
@@ -246,11 +281,19 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.wfCnt, 4); A(h->dstats, 1);
 #undef A
     h->sb.stats = h->dstats;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stats), sizeof(DevStats) * kRing, hipHostMallocDefault) !=
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stats), sizeof(DevStats) * kRing, hipHostMallocMapped) !=
         hipSuccess) {
         h->err = "hipHostMalloc failed";
         return bail(RIO_GP_ENOMEM);
     }
+    h->slot_rows = resolve_blocks(h->cap_nodes);
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_slots), (size_t)kRing * h->slot_rows * 8 * sizeof(u64),
+                      hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_slots), h->h_slots, 0) != hipSuccess) {
+        h->err = "hipHostMalloc(mapped verdict slots) failed";
+        return bail(RIO_GP_ENOMEM);
+    }
+    memset(h->h_slots, 0, (size_t)kRing * h->slot_rows * 8 * sizeof(u64));
     // every row starts unplaced; the position scratch is all-ones between calls
     launch_fill_u32(h->assign[0], R, kNone, h->stream);
     launch_fill_u32(h->assign[1], R, kNone, h->stream);
@@ -276,9 +319,11 @@ void rio_gp_destroy(rio_gp_t* h) {
     for (auto& b : h->vt) if (b.p) (void)hipFree(b.p);
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
+    if (h->h_slots) (void)hipHostFree(h->h_slots);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->ev3) (void)hipEventDestroy(h->ev3);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -310,6 +355,8 @@ int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t
     }
     launch_pack_alive(h->alive_bytes, m, h->alive_bits, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->all_alive = true;
+    for (uint32_t j = 0; j < m; ++j) h->all_alive = h->all_alive && h->h_alive[j];
     if (m != h->m) h->used_valid = false;
     h->m = m;
     h->have_solved = false;
@@ -321,7 +368,8 @@ int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive) {
     std::lock_guard<std::mutex> g(h->mu);
     if (m != h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive_all: m differs from the node table");
     HIPCHK(h, hipSetDevice(h->device));
-    for (uint32_t j = 0; j < m; ++j) h->h_alive[j] = alive[j] ? 1 : 0;
+    h->all_alive = true;
+    for (uint32_t j = 0; j < m; ++j) { h->h_alive[j] = alive[j] ? 1 : 0; h->all_alive = h->all_alive && alive[j]; }
     if (m) HIPCHK(h, hipMemcpyAsync(h->alive_bytes, h->h_alive.data(), m, hipMemcpyHostToDevice, h->stream));
     launch_pack_alive(h->alive_bytes, m, h->alive_bits, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -335,6 +383,8 @@ int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive) {
     if (node >= h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive: node out of range");
     HIPCHK(h, hipSetDevice(h->device));
     h->h_alive[node] = alive ? 1 : 0;
+    h->all_alive = true;
+    for (uint32_t j = 0; j < h->m; ++j) h->all_alive = h->all_alive && h->h_alive[j];
     HIPCHK(h, hipMemcpyAsync(h->alive_bytes, h->h_alive.data(), h->m, hipMemcpyHostToDevice, h->stream));
     launch_pack_alive(h->alive_bytes, h->m, h->alive_bits, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -588,10 +638,14 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
     const Plan vp = make_plan(n, h->m, 0);
     const Table vtab{vcur, vload, vaff, vnext};
     const NodeTab vnt{h->cap, h->alive_bits, h->used};
-    launch_scan(vp, vtab, vnt, h->sb, true, h->stream);
-    launch_resolve(vp, vnt, h->sb, h->stream);
-    if ((rc = read_stats(h))) return rc;
-    if (h->h_stats[0].n_cut > 0 || h->h_stats[0].spillcand > 0) enqueue_slow(h, vp, vtab, vnt, true, h->h_stats[0]);
+    launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
+    launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    {
+        const DevStats v = reduce_slot(h, 0, h->m);
+        if (v.n_cut > 0 || v.spillcand > 0) enqueue_slow(h, vp, vtab, vnt, true, v);
+    }
     // (5) publish, outputs, new `used`
     launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
                       h->stream);
@@ -639,10 +693,8 @@ int rio_gp_solve_async(rio_gp_t* h) {
     h->plan = make_plan(h->n, h->m, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
-    launch_scan(h->plan, t, nt, h->sb, false, h->stream);
-    launch_resolve(h->plan, nt, h->sb, h->stream);
-    HIPCHK(h, hipMemcpyAsync(&h->h_stats[h->ring_n % kRing], h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost,
-                             h->stream));
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+    launch_resolve(h->plan, nt, h->sb, slot_dev(h, h->ring_n), h->stream);
     h->ring_n++;
     h->have_solved = false;
     return RIO_GP_OK;
@@ -657,18 +709,19 @@ int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow) {
     if (h->ring_n == 0) return fail(h, RIO_GP_EINVAL, "rio_gp_solve_wait: nothing enqueued");
     uint32_t slow = 0;
     const u32 lo = h->ring_n > (u32)kRing ? h->ring_n - kRing : 0;
+    DevStats last;
+    memset(&last, 0, sizeof last);
     for (u32 k = lo; k < h->ring_n; ++k) {
-        const DevStats& d = h->h_stats[k % kRing];
-        slow += (d.n_cut > 0 || d.spillcand > 0);
+        last = reduce_slot(h, k, h->m);
+        slow += (last.n_cut > 0 || last.spillcand > 0);
     }
-    const DevStats last = h->h_stats[(h->ring_n - 1) % kRing];
-    h->h_stats[0] = last;
     if (last.n_cut > 0 || last.spillcand > 0) {
         enqueue_slow(h, h->plan, real_table(h), real_nodes(h), false, last);
-        int rc = read_stats(h);
+        int rc = merge_slow(h, &last);
         if (rc) return rc;
+        HIPCHK(h, hipGetLastError());
     }
-    fill_stats(h->h_stats[0], h->n, stats);
+    fill_stats(last, h->n, stats);
     if (n_slow) *n_slow = slow;
     h->ring_n = 0;
     h->have_solved = true;
@@ -679,22 +732,36 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     if (!h || !scan_ms || !resolve_ms) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    if (!h->ev2) { HIPCHK(h, hipEventCreate(&h->ev2)); }
+    if (!h->ev2) { HIPCHK(h, hipEventCreate(&h->ev2)); HIPCHK(h, hipEventCreate(&h->ev3)); }
     h->plan = make_plan(h->n, h->m, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    launch_scan(h->plan, t, nt, h->sb, false, h->stream);
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    launch_resolve(h->plan, nt, h->sb, h->stream);
-    HIPCHK(h, hipEventRecord(h->ev2, h->stream));
-    int rc = read_stats(h);
-    if (rc) return rc;
+    // hipExtLaunchKernelGGL start/stop events = the dispatch's own begin/end timestamps
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, h->ev0, h->ev1);
+    launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream, h->ev2, h->ev3);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventElapsedTime(scan_ms, h->ev0, h->ev1));
-    HIPCHK(h, hipEventElapsedTime(resolve_ms, h->ev1, h->ev2));
+    HIPCHK(h, hipEventElapsedTime(resolve_ms, h->ev2, h->ev3));
     h->have_solved = false;
-    if (h->h_stats[0].n_cut > 0 || h->h_stats[0].spillcand > 0)
+    h->ring_n = 0;
+    const DevStats v = reduce_slot(h, 0, h->m);
+    if (v.n_cut > 0 || v.spillcand > 0)
         return fail(h, RIO_GP_EINVAL, "rio_gp_solve_profiled: this table needs the cut/spill fix-up");
+    return RIO_GP_OK;
+}
+
+void rio_gp_debug_set_scan_tpi(int tpi) { set_scan_tpi(tpi); }
+
+int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms) {
+    if (!h || !ms || reps < 1) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    // same columns the solve streams: cur/load/aff in, the ping-pong column out (an uncommitted solve is lost)
+    *ms = stream_probe(mode, h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1], h->n, reps, h->stream, h->ev0,
+                       h->ev1);
+    h->have_solved = false;
+    if (*ms < 0) return fail(h, RIO_GP_EUPSTREAM, "stream probe failed");
     return RIO_GP_OK;
 }
 

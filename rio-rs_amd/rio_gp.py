@@ -17,7 +17,8 @@ CAP_INF = 0xFFFFFFFFFFFFFFFF
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM = range(5)
 
-SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "gpu_object_placement.cpp")]
+SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "stream_probe.hip",
+                                                     "gpu_object_placement.cpp")]
 HEADERS = [os.path.join(_DIR, "csrc", "placement_kernels.h"),
            os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_placement.h"),
            os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_object_placement.h")]
@@ -110,6 +111,7 @@ def lib():
         L.rio_gp_solve_async.argtypes = [_vp]
         L.rio_gp_solve_wait.argtypes = [_vp, C.POINTER(Stats), C.POINTER(C.c_uint32)]
         L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rio_gp_timer_begin.argtypes = [_vp]
         L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
         _lib = L
@@ -273,6 +275,11 @@ class GpuPlacement:
         a, b = C.c_float(0), C.c_float(0)
         self._chk(lib().rio_gp_solve_profiled(self._h, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
+
+    def stream_probe(self, mode, reps=20):
+        ms = C.c_float(0)
+        self._chk(lib().rio_gp_debug_stream_probe(self._h, mode, reps, C.byref(ms)))
+        return float(ms.value)
 
     def timer_begin(self):
         self._chk(lib().rio_gp_timer_begin(self._h))
