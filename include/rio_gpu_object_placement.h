@@ -1,0 +1,101 @@
+/*
+ * rio_gpu_object_placement.h — string layer of the C ABI: the ObjectPlacement trait itself.
+ *
+ * What a Rust `GpuObjectPlacement: ObjectPlacement` binds (rio-rs_amd/rust/).
+ * Keys and values are the reference's own types (paths relative to /root/reference):
+ *
+ *   ObjectId(struct_name, object_id)        rio-rs/src/service_object.rs:19-26
+ *   ObjectPlacementItem{.., Option<String>} rio-rs/src/object_placement/mod.rs:20-34
+ *   trait ObjectPlacement                   rio-rs/src/object_placement/mod.rs:38-56
+ *   LocalObjectPlacement (parity target)    rio-rs/src/object_placement/local.rs:22-68
+ *   Service::get_or_create_placement        rio-rs/src/service.rs:193-254
+ *
+ * Strings are interned to dense rows / node ids on the host and every call lands in the
+ * rio_gp_* layer (rio_gpu_placement.h); the assignment lives in HBM only.  The object key is
+ * "{struct_name}.{object_id}" exactly as local.rs:26-29 builds it — including its quirk that
+ * ("a.b","c") and ("a","b.c") are the same object.
+ *
+ * Same conventions as rio_gpu_placement.h: int rc (RIO_GP_OK / EINVAL -> Unknown / EUPSTREAM ->
+ * Upstream), nothing thrown across the ABI, handle internally synchronized, no CPU fallback.
+ */
+#ifndef RIO_GPU_OBJECT_PLACEMENT_H
+#define RIO_GPU_OBJECT_PLACEMENT_H
+
+#include "rio_gpu_placement.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rio_op rio_op_t;
+
+typedef struct rio_op_cfg {
+    uint32_t struct_size;  /* = sizeof(rio_op_cfg) */
+    int32_t device;
+    uint64_t max_objects;  /* distinct object keys the table can hold */
+    uint32_t max_nodes;    /* distinct server addresses */
+    uint32_t spill_rounds; /* 0 -> 2 */
+    uint32_t flags;        /* reserved */
+    uint32_t reserved;
+} rio_op_cfg;
+
+/* LocalObjectPlacement::default() + ObjectPlacement::prepare (local.rs:15-18, mod.rs:42-44). */
+int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out);
+/* #[derive(Clone)]: the clone SHARES the map (Arc inside, local.rs:12-18; pinned by
+ * local.rs:71-123).  Returns the same state with one more reference. */
+rio_op_t* rio_op_clone(rio_op_t* p);
+/* Drop: releases one reference; the HBM tables go with the last one. */
+void rio_op_release(rio_op_t* p);
+/* mod.rs:42-44 (default no-op; kept so the adapter can forward it). */
+int rio_op_prepare(rio_op_t* p);
+const char* rio_op_last_error(rio_op_t* p);
+
+/* ObjectPlacement::update (mod.rs:46-49, local.rs:22-40): upsert; server_address == NULL is
+ * Option::None and deletes the entry (local.rs:36-37). */
+int rio_op_update(rio_op_t* p, const char* struct_name, const char* object_id, const char* server_address);
+/* ObjectPlacement::lookup (mod.rs:50, local.rs:42-49): *found = 1 and the address copied into
+ * out (NUL-terminated, truncated to out_cap) or *found = 0 (Ok(None)). */
+int rio_op_lookup(rio_op_t* p, const char* struct_name, const char* object_id, char* out, size_t out_cap,
+                  int* found);
+/* ObjectPlacement::clean_server (mod.rs:52, local.rs:51-58). */
+int rio_op_clean_server(rio_op_t* p, const char* address);
+/* ObjectPlacement::remove (mod.rs:55, local.rs:60-68). */
+int rio_op_remove(rio_op_t* p, const char* struct_name, const char* object_id);
+/* number of placed objects (HashMap::len of local.rs:12) */
+int rio_op_len(rio_op_t* p, uint64_t* out);
+
+/* Batched forms of the same calls: n keys at once, one kernel launch per call. */
+int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* struct_names, const char* const* object_ids,
+                        const char* const* server_addresses);
+/* out_node_ids[k] = node id or RIO_GP_NONE; resolve ids with rio_op_node_address. */
+int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* struct_names, const char* const* object_ids,
+                        uint32_t* out_node_ids);
+const char* rio_op_node_address(rio_op_t* p, uint32_t node_id);
+
+/* Membership feed: MembershipStorage::push / set_is_active (cluster/storage/mod.rs:74-80) pushed
+ * into the node table instead of being polled per request (is_active, mod.rs:102-110).  An address
+ * only ever seen through `update` is not a member, i.e. not active, as in the reference.
+ * capacity: load units, RIO_GP_CAP_INF = unbounded (the reference has no capacity). */
+int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t capacity);
+/* per-object load (default 1; new behaviour, the reference has none) */
+int rio_op_set_object_load(rio_op_t* p, const char* struct_name, const char* object_id, uint32_t load);
+
+/* Service::get_or_create_placement (service.rs:193-254) + check_address_mismatch (service.rs:261-298)
+ * for one request arriving at server `self_address`: returns the address the object lives on now and
+ * *flag = RIO_GP_FLAG_{LOCAL,REDIRECT,PLACED,SPILLED,UNPLACED} (UNPLACED: out is ""). */
+int rio_op_get_or_create_placement(rio_op_t* p, const char* struct_name, const char* object_id,
+                                   const char* self_address, char* out, size_t out_cap, uint32_t* flag);
+/* The same for n requests at once, processed as if sequentially in array order. */
+int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* const* struct_names,
+                                         const char* const* object_ids, const char* const* self_addresses,
+                                         uint32_t* out_node_ids, uint32_t* out_flags);
+
+/* Whole-table re-solve over the interned tables (rio_gp_tick). */
+int rio_op_tick(rio_op_t* p, rio_gp_stats* stats);
+/* The dense handle underneath (borrowed). */
+rio_gp_t* rio_op_dense(rio_op_t* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIO_GPU_OBJECT_PLACEMENT_H */

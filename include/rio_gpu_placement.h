@@ -129,6 +129,11 @@ int rio_gp_set_objects_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_load, cons
 int rio_gp_set_assign(rio_gp_t* h, uint64_t n, const uint32_t* assign);
 int rio_gp_set_assign_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_assign);
 int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out_assign);
+/* Change load and/or affinity of individual rows (either array may be NULL = leave as is). */
+int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* load,
+                            const uint32_t* aff);
+/* Number of placed rows (HashMap::len of local.rs:12): one 4 B/row pass. */
+int rio_gp_count_placed(rio_gp_t* h, uint64_t* out);
 /* Device pointer of the live assignment column (valid until the next tick/commit). */
 const uint32_t* rio_gp_assign_dev(rio_gp_t* h);
 uint64_t rio_gp_num_objects(rio_gp_t* h);

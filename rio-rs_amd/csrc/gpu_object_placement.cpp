@@ -1,0 +1,356 @@
+// gpu_object_placement.cpp — host-side mirror of the reference's ObjectPlacement interface
+// (include/rio_gpu_object_placement.h) on top of the dense C ABI.  Pure host C++: interning of
+// (struct_name, object_id) and "ip:port" strings, the malformed-record rule of the policy, reference
+// counting for Clone.  Every placement fact lives in HBM; this file never mirrors the assignment.
+//
+// Mirrors (relative to /root/reference):
+//   LocalObjectPlacement              rio-rs/src/object_placement/local.rs:12-68
+//   Service::get_or_create_placement  rio-rs/src/service.rs:193-254
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rio_gpu_object_placement.h"
+
+namespace {
+
+struct State {
+    std::mutex mu;
+    std::string err;
+    rio_gp_t* gp = nullptr;
+    uint64_t max_objects = 0;
+    uint32_t max_nodes = 0;
+    std::unordered_map<std::string, uint32_t> rows;   // "{type}.{id}" -> dense row (local.rs:26-29)
+    std::unordered_map<std::string, uint32_t> nodes;  // address -> node id
+    std::vector<std::string> node_addr;
+    std::vector<uint8_t> node_alive, node_malformed;
+    std::vector<uint64_t> node_cap;
+    uint32_t n_malformed = 0;
+    std::atomic<int> refs{1};
+};
+
+std::string key_of(const char* ty, const char* id) {  // local.rs:26-29,43,61
+    std::string k(ty ? ty : "");
+    k += '.';
+    k += id ? id : "";
+    return k;
+}
+
+// service.rs:204-213: splitn(2, ":"), a record is bad when ip or port is empty
+bool malformed(const std::string& a) {
+    const size_t c = a.find(':');
+    return c == std::string::npos || c == 0 || c + 1 >= a.size();
+}
+
+int fail(State* s, int rc, const std::string& m) {
+    s->err = m;
+    return rc;
+}
+int gp_fail(State* s, int rc) {
+    s->err = rio_gp_last_error(s->gp);
+    return rc;
+}
+
+int push_nodes(State* s) {
+    const uint32_t m = (uint32_t)s->node_addr.size();
+    int rc = rio_gp_set_nodes(s->gp, m, s->node_cap.data(), s->node_alive.data());
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+// find or create the node id of an address; *created tells the caller to push the node table
+int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, bool* created) {
+    auto it = s->nodes.find(addr);
+    if (it != s->nodes.end()) {
+        *out = it->second;
+        return RIO_GP_OK;
+    }
+    if (!create) {
+        *out = RIO_GP_NONE;
+        return RIO_GP_OK;
+    }
+    if (s->node_addr.size() >= s->max_nodes) return fail(s, RIO_GP_EINVAL, "node table full (max_nodes)");
+    const uint32_t id = (uint32_t)s->node_addr.size();
+    s->nodes.emplace(addr, id);
+    s->node_addr.push_back(addr);
+    s->node_alive.push_back(0);  // not a member until rio_op_set_member says so (is_active == false)
+    s->node_cap.push_back(RIO_GP_CAP_INF);
+    const bool bad = malformed(addr);
+    s->node_malformed.push_back(bad ? 1 : 0);
+    s->n_malformed += bad;
+    *out = id;
+    if (created) *created = true;
+    return RIO_GP_OK;
+}
+
+int intern_row(State* s, const std::string& key, bool create, uint32_t* out) {
+    auto it = s->rows.find(key);
+    if (it != s->rows.end()) {
+        *out = it->second;
+        return RIO_GP_OK;
+    }
+    if (!create) {
+        *out = RIO_GP_NONE;
+        return RIO_GP_OK;
+    }
+    if (s->rows.size() >= s->max_objects) return fail(s, RIO_GP_EINVAL, "object table full (max_objects)");
+    const uint32_t id = (uint32_t)s->rows.size();
+    s->rows.emplace(key, id);
+    *out = id;
+    return RIO_GP_OK;
+}
+
+void copy_out(const std::string& v, char* out, size_t cap) {
+    if (!out || !cap) return;
+    const size_t n = v.size() < cap - 1 ? v.size() : cap - 1;
+    memcpy(out, v.data(), n);
+    out[n] = 0;
+}
+
+// the whole policy for a batch of (row, requester) pairs; rows/reqs are dense ids
+int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& reqs, uint32_t* out_node,
+                 uint32_t* out_flag) {
+    const uint64_t n = rows.size();
+    if (s->n_malformed) {
+        // service.rs:213-223: a record whose address has no ip or no port is removed (only that record)
+        std::vector<uint32_t> cur(n), bad;
+        int rc = rio_gp_lookup_batch(s->gp, n, rows.data(), cur.data());
+        if (rc) return gp_fail(s, rc);
+        for (uint64_t k = 0; k < n; ++k)
+            if (cur[k] != RIO_GP_NONE && s->node_malformed[cur[k]]) bad.push_back(rows[k]);
+        if (!bad.empty() && (rc = rio_gp_remove_batch(s->gp, bad.size(), bad.data()))) return gp_fail(s, rc);
+    }
+    int rc = rio_gp_place_pending(s->gp, n, rows.data(), reqs.data(), out_node, out_flag);
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+}  // namespace
+
+struct rio_op {
+    State* s;
+};
+
+extern "C" {
+
+int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out || cfg->struct_size != sizeof(rio_op_cfg) || cfg->max_objects == 0 || cfg->max_nodes == 0)
+        return RIO_GP_EINVAL;
+    rio_gp_cfg g;
+    memset(&g, 0, sizeof g);
+    g.struct_size = sizeof g;
+    g.device = cfg->device;
+    g.max_objects = cfg->max_objects;
+    g.max_nodes = cfg->max_nodes;
+    g.spill_rounds = cfg->spill_rounds;
+    rio_gp_t* gp = nullptr;
+    int rc = rio_gp_create(&g, &gp);
+    if (rc) return rc;  // text in rio_gp_last_error(NULL)
+    // every potential row exists from the start, unplaced, load 1, no affinity
+    if ((rc = rio_gp_set_objects(gp, cfg->max_objects, nullptr, nullptr)) || (rc = rio_gp_set_nodes(gp, 0, nullptr, nullptr))) {
+        rio_gp_destroy(gp);
+        return rc;
+    }
+    State* s = new State();
+    s->gp = gp;
+    s->max_objects = cfg->max_objects;
+    s->max_nodes = cfg->max_nodes;
+    *out = new rio_op{s};
+    return RIO_GP_OK;
+}
+
+rio_op_t* rio_op_clone(rio_op_t* p) {
+    if (!p) return nullptr;
+    p->s->refs.fetch_add(1);
+    return new rio_op{p->s};
+}
+
+void rio_op_release(rio_op_t* p) {
+    if (!p) return;
+    State* s = p->s;
+    delete p;
+    if (s->refs.fetch_sub(1) == 1) {
+        rio_gp_destroy(s->gp);
+        delete s;
+    }
+}
+
+int rio_op_prepare(rio_op_t* p) { return p ? RIO_GP_OK : RIO_GP_EINVAL; }
+
+const char* rio_op_last_error(rio_op_t* p) { return p ? p->s->err.c_str() : rio_gp_last_error(nullptr); }
+
+rio_gp_t* rio_op_dense(rio_op_t* p) { return p ? p->s->gp : nullptr; }
+
+const char* rio_op_node_address(rio_op_t* p, uint32_t node_id) {
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> g(p->s->mu);
+    return node_id < p->s->node_addr.size() ? p->s->node_addr[node_id].c_str() : nullptr;
+}
+
+int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids,
+                        const char* const* addrs) {
+    if (!p || (n && (!tys || !ids || !addrs))) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    std::vector<uint32_t> rows, nodes;
+    rows.reserve(n);
+    nodes.reserve(n);
+    bool created = false;
+    for (uint64_t k = 0; k < n; ++k) {
+        uint32_t row = RIO_GP_NONE, node = RIO_GP_NONE;
+        int rc;
+        if (addrs[k]) {  // Some(address): entry(key) = address
+            if ((rc = intern_row(s, key_of(tys[k], ids[k]), true, &row))) return rc;
+            if ((rc = intern_node(s, addrs[k], true, &node, &created))) return rc;
+        } else {         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
+            if ((rc = intern_row(s, key_of(tys[k], ids[k]), false, &row))) return rc;
+            if (row == RIO_GP_NONE) continue;
+        }
+        rows.push_back(row);
+        nodes.push_back(node);
+    }
+    int rc;
+    if (created && (rc = push_nodes(s))) return rc;
+    if (rows.empty()) return RIO_GP_OK;
+    rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), nodes.data());
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr) {
+    return rio_op_update_batch(p, 1, &ty, &id, &addr);
+}
+
+int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids, uint32_t* out) {
+    if (!p || (n && (!tys || !ids || !out))) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    std::vector<uint32_t> rows, where;
+    for (uint64_t k = 0; k < n; ++k) {
+        uint32_t row;
+        int rc = intern_row(s, key_of(tys[k], ids[k]), false, &row);
+        if (rc) return rc;
+        out[k] = RIO_GP_NONE;  // unknown key: Ok(None)
+        if (row != RIO_GP_NONE) {
+            rows.push_back(row);
+            where.push_back((uint32_t)k);
+        }
+    }
+    if (rows.empty()) return RIO_GP_OK;
+    std::vector<uint32_t> res(rows.size());
+    int rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res.data());
+    if (rc) return gp_fail(s, rc);
+    for (size_t q = 0; q < rows.size(); ++q) out[where[q]] = res[q];
+    return RIO_GP_OK;
+}
+
+int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t cap, int* found) {
+    if (!p || !found) return RIO_GP_EINVAL;
+    uint32_t node = RIO_GP_NONE;
+    int rc = rio_op_lookup_batch(p, 1, &ty, &id, &node);
+    if (rc) return rc;
+    *found = node != RIO_GP_NONE;
+    if (*found) {
+        std::lock_guard<std::mutex> g(p->s->mu);
+        copy_out(p->s->node_addr[node], out, cap);
+    }
+    return RIO_GP_OK;
+}
+
+int rio_op_clean_server(rio_op_t* p, const char* address) {
+    if (!p || !address) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    uint32_t node;
+    int rc = intern_node(s, address, false, &node, nullptr);
+    if (rc) return rc;
+    if (node == RIO_GP_NONE) return RIO_GP_OK;  // nothing was ever placed there: retain() removes nothing
+    rc = rio_gp_clean_server(s->gp, node, nullptr);
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
+    if (!p) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    uint32_t row;
+    int rc = intern_row(s, key_of(ty, id), false, &row);
+    if (rc) return rc;
+    if (row == RIO_GP_NONE) return RIO_GP_OK;  // absent: no-op (local.rs:60-68)
+    rc = rio_gp_remove_batch(s->gp, 1, &row);
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+int rio_op_len(rio_op_t* p, uint64_t* out) {
+    if (!p || !out) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    int rc = rio_gp_count_placed(s->gp, out);
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t capacity) {
+    if (!p || !address) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    uint32_t node;
+    bool created = false;
+    int rc = intern_node(s, address, true, &node, &created);
+    if (rc) return rc;
+    s->node_alive[node] = active ? 1 : 0;
+    s->node_cap[node] = capacity;
+    return push_nodes(s);
+}
+
+int rio_op_set_object_load(rio_op_t* p, const char* ty, const char* id, uint32_t load) {
+    if (!p) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    uint32_t row;
+    int rc = intern_row(s, key_of(ty, id), true, &row);
+    if (rc) return rc;
+    rc = rio_gp_set_object_attrs(s->gp, 1, &row, &load, nullptr);
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids,
+                                         const char* const* selfs, uint32_t* out_node, uint32_t* out_flag) {
+    if (!p || (n && (!tys || !ids || !selfs || !out_node))) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    std::vector<uint32_t> rows(n), reqs(n);
+    bool created = false;
+    for (uint64_t k = 0; k < n; ++k) {
+        int rc;
+        if ((rc = intern_row(s, key_of(tys[k], ids[k]), true, &rows[k]))) return rc;
+        const size_t before = s->node_addr.size();
+        if ((rc = intern_node(s, selfs[k], true, &reqs[k], &created))) return rc;
+        if (s->node_addr.size() != before) s->node_alive[reqs[k]] = 1;  // a server answering requests is up
+    }
+    int rc;
+    if (created && (rc = push_nodes(s))) return rc;
+    return policy_batch(s, rows, reqs, out_node, out_flag);
+}
+
+int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, const char* self_address, char* out,
+                                   size_t cap, uint32_t* flag) {
+    if (!p || !self_address) return RIO_GP_EINVAL;
+    uint32_t node = RIO_GP_NONE, fl = 0;
+    int rc = rio_op_get_or_create_placement_batch(p, 1, &ty, &id, &self_address, &node, &fl);
+    if (rc) return rc;
+    if (flag) *flag = fl;
+    std::lock_guard<std::mutex> g(p->s->mu);
+    copy_out(node == RIO_GP_NONE ? std::string() : p->s->node_addr[node], out, cap);
+    return RIO_GP_OK;
+}
+
+int rio_op_tick(rio_op_t* p, rio_gp_stats* stats) {
+    if (!p) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    int rc = rio_gp_tick(s->gp, stats);
+    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+}  // extern "C"

@@ -107,6 +107,9 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s);
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s);
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s);
+void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32* nload, const u32* naff, u64 n,
+                      DevStats* st, hipStream_t s);
+void launch_count_placed(const u32* assign, u64 n_obj, DevStats* st, hipStream_t s);
 void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipStream_t s);
 
 // --- place_pending glue (virtual table) ---

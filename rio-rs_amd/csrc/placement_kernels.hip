@@ -252,12 +252,14 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 
     while (it < wgrp) {
         const u64 nit = it + (u64)kTile * TPI;
-        // Software prefetch of the next group — UNCONDITIONAL (the columns are padded by >= 4 tiles) so the
-        // loop body is straight-line and these loads stay in flight while the current group is processed.
+        // Software prefetch of the next group — UNCONDITIONAL so the loop body is straight-line and these
+        // loads stay in flight while the current group is processed; on the wave's last iteration the
+        // address is clamped to the group being processed (an L1/L2 hit, no HBM traffic, no over-read).
+        const u64 pit = nit < wgrp ? nit : it;
         uint4 cn[TPI], an[TPI], ln[TPI];
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
-            const u64 i = nit + (u64)q * kTile + (u64)lane * 4;
+            const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
             cn[q] = *reinterpret_cast<const uint4*>(cur + i);
             an[q] = *reinterpret_cast<const uint4*>(aff + i);
             ln[q] = *reinterpret_cast<const uint4*>(load + i);
@@ -326,6 +328,14 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     const u32 j = blockIdx.x * kResNodes + (col & 3);
     const bool valid = j < m;
     const size_t c = (col < 4) ? (size_t)j : (size_t)m + j;
+    // node-table operands of the verdict are requested up front so their latency overlaps the H loads
+    u64 cj = 0, ub = 0;
+    bool alive_j = false;
+    if (tid < 4 && valid) {
+        cj = cap[j];
+        alive_j = bit_of(alive_bits, j);
+        if (used_base) ub = used_base[j];
+    }
     u64 v[kResRows];
 #pragma unroll
     for (int r = 0; r < kResRows; ++r) {
@@ -347,10 +357,8 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     __syncthreads();
     if (tid < 4 && valid) {
         const u64 kept_load = tot[tid], ctot = tot[tid + 4];
-        u64 used = kept_load;
-        if (used_base) used += used_base[j];
-        const u64 cj = cap[j];
-        const u64 fre = (bit_of(alive_bits, j) && cj > used) ? cj - used : 0;
+        const u64 used = kept_load + ub;
+        const u64 fre = (alive_j && cj > used) ? cj - used : 0;
         used_kept[j] = used;
         claim_tot[j] = ctot;
         cutblk[j] = kNoCut;
@@ -907,6 +915,31 @@ __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_o
     if (tid == 0 && ev_total) atomicAdd(&st->evicted_clean, (u64)ev_total);
 }
 
+// scatter new load / affinity values into individual rows
+__global__ void k_set_attrs(u32* __restrict__ load, u32* __restrict__ aff, u64 n_obj, const u32* __restrict__ idx,
+                            const u32* __restrict__ nload, const u32* __restrict__ naff, u64 n, DevStats* st) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
+        const u32 i = idx[k];
+        if (i >= n_obj) { atomicAdd(&st->err, 1ull); continue; }
+        if (nload) load[i] = nload[k];
+        if (naff) aff[i] = naff[k];
+    }
+}
+
+// number of placed rows: 4 B/row
+__global__ __launch_bounds__(256) void k_count_placed(const u32* __restrict__ assign, u64 n_obj, DevStats* st) {
+    u32 c = 0;
+    const u64 nvec = (n_obj + 3) / 4;
+    for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (u64)gridDim.x * 256) {
+        const u64 i0 = v * 4;
+        const uint4 a = *reinterpret_cast<const uint4*>(assign + i0);
+        c += (i0 + 0 < n_obj && a.x != kNone) + (i0 + 1 < n_obj && a.y != kNone) + (i0 + 2 < n_obj && a.z != kNone) +
+             (i0 + 3 < n_obj && a.w != kNone);
+    }
+    c = wave_sum32(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&st->evicted_clean, (u64)c);  // reuses a scratch accumulator
+}
+
 // used[j] = sum of load over rows assigned to j (8 B/row)
 __global__ __launch_bounds__(kBlock) void k_used(const u32* __restrict__ assign, const u32* __restrict__ load,
                                                  u64 n_obj, u32 m, u64* __restrict__ used) {
@@ -1123,12 +1156,22 @@ void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m,
     hipLaunchKernelGGL(k_used, dim3(grid_for((n_obj + 3) / 4, kBlock, 256)), dim3(kBlock), (size_t)m * sizeof(u64), s,
                        assign, load, n_obj, m, used);
 }
+void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32* nload, const u32* naff, u64 n,
+                      DevStats* st, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_set_attrs, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, load, aff, n_obj, idx, nload, naff, n,
+                       st);
+}
+void launch_count_placed(const u32* assign, u64 n_obj, DevStats* st, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_placed, dim3(grid_for((n_obj + 3) / 4, 256, 2048)), dim3(256), 0, s, assign, n_obj, st);
+}
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, p, n, v);
 }
 void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipStream_t s) {
     const u32 w = (m + 31) / 32;
+    if (!w) return;
     hipLaunchKernelGGL(k_pack_alive, dim3((w + 63) / 64), dim3(64), 0, s, alive_bytes, m, alive_bits);
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,

@@ -467,6 +467,39 @@ int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RIO_GP_OK;
 }
+int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* load, const uint32_t* aff) {
+    if (!h || (n && !idx)) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_set_object_attrs: object index out of range");
+    if (!n || (!load && !aff)) return RIO_GP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    for (int q = 0; q < 3; ++q)
+        if ((rc = ensure(h, h->stage[q], n * sizeof(u32)))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    if (load) HIPCHK(h, hipMemcpyAsync(h->stage[1].p, load, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    if (aff) HIPCHK(h, hipMemcpyAsync(h->stage[2].p, aff, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    if ((rc = zero_stats(h))) return rc;
+    launch_set_attrs(h->load, h->aff, h->n, (const u32*)h->stage[0].p, load ? (const u32*)h->stage[1].p : nullptr,
+                     aff ? (const u32*)h->stage[2].p : nullptr, n, h->dstats, h->stream);
+    if (load) h->used_valid = false;
+    h->have_solved = false;
+    return read_stats(h);
+}
+
+int rio_gp_count_placed(rio_gp_t* h, uint64_t* out) {
+    if (!h || !out) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = zero_stats(h);
+    if (rc) return rc;
+    launch_count_placed(h->assign[h->cur], h->n, h->dstats, h->stream);
+    if ((rc = read_stats(h))) return rc;
+    *out = h->h_stats[0].evicted_clean;
+    return RIO_GP_OK;
+}
+
 const uint32_t* rio_gp_assign_dev(rio_gp_t* h) { return h ? h->assign[h->cur] : nullptr; }
 const uint32_t* rio_gp_solved_dev(rio_gp_t* h) { return h ? h->assign[h->cur ^ 1] : nullptr; }
 

@@ -288,3 +288,149 @@ class GpuPlacement:
         ms = C.c_float(0)
         self._chk(lib().rio_gp_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+# ---- string layer: the ObjectPlacement trait itself (include/rio_gpu_object_placement.h) ----------
+
+class OpCfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_objects", C.c_uint64),
+                ("max_nodes", C.c_uint32), ("spill_rounds", C.c_uint32), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+_op_ready = False
+
+
+def _oplib():
+    global _op_ready
+    L = lib()
+    if not _op_ready:
+        L.rio_op_create.argtypes = [C.POINTER(OpCfg), C.POINTER(_vp)]
+        L.rio_op_clone.argtypes = [_vp]
+        L.rio_op_clone.restype = _vp
+        L.rio_op_release.argtypes = [_vp]
+        L.rio_op_release.restype = None
+        L.rio_op_prepare.argtypes = [_vp]
+        L.rio_op_last_error.argtypes = [_vp]
+        L.rio_op_last_error.restype = C.c_char_p
+        L.rio_op_update.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.rio_op_lookup.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.rio_op_clean_server.argtypes = [_vp, C.c_char_p]
+        L.rio_op_remove.argtypes = [_vp, C.c_char_p, C.c_char_p]
+        L.rio_op_len.argtypes = [_vp, C.POINTER(C.c_uint64)]
+        L.rio_op_update_batch.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp]
+        L.rio_op_lookup_batch.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp]
+        L.rio_op_node_address.argtypes = [_vp, C.c_uint32]
+        L.rio_op_node_address.restype = C.c_char_p
+        L.rio_op_set_member.argtypes = [_vp, C.c_char_p, C.c_int, C.c_uint64]
+        L.rio_op_set_object_load.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_uint32]
+        L.rio_op_get_or_create_placement.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,
+                                                     C.POINTER(C.c_uint32)]
+        L.rio_op_get_or_create_placement_batch.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
+        L.rio_op_tick.argtypes = [_vp, C.POINTER(Stats)]
+        L.rio_op_dense.argtypes = [_vp]
+        L.rio_op_dense.restype = _vp
+        _op_ready = True
+    return L
+
+
+def _cstrs(items):
+    arr = (C.c_char_p * len(items))()
+    for k, v in enumerate(items):
+        arr[k] = None if v is None else v.encode()
+    return arr
+
+
+class GpuObjectPlacement:
+    """Drop-in for LocalObjectPlacement (object_placement/local.rs): same five methods, same
+    Option/None conventions; `clone()` shares the map like the Arc does."""
+
+    def __init__(self, max_objects=1 << 16, max_nodes=256, device=0, spill_rounds=2, _h=None):
+        if _h is not None:
+            self._h = _h
+            return
+        self._h = _vp()
+        cfg = OpCfg(C.sizeof(OpCfg), device, max_objects, max_nodes, spill_rounds, 0, 0)
+        rc = _oplib().rio_op_create(C.byref(cfg), C.byref(self._h))
+        if rc != OK:
+            text = (_oplib().rio_op_last_error(None) or b"").decode()
+            self._h = None
+            raise ObjectPlacementError("Unknown" if rc == EINVAL else "Upstream", text, rc)
+
+    def _chk(self, rc):
+        if rc != OK:
+            text = (_oplib().rio_op_last_error(self._h) or b"").decode()
+            raise ObjectPlacementError("Unknown" if rc == EINVAL else "Upstream", text, rc)
+
+    def clone(self):
+        return GpuObjectPlacement(_h=_vp(_oplib().rio_op_clone(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _oplib().rio_op_release(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- the trait (mod.rs:38-56) --
+    def prepare(self):
+        self._chk(_oplib().rio_op_prepare(self._h))
+
+    def update(self, struct_name, object_id, server_address):
+        a = None if server_address is None else server_address.encode()
+        self._chk(_oplib().rio_op_update(self._h, struct_name.encode(), object_id.encode(), a))
+
+    def lookup(self, struct_name, object_id):
+        buf, found = C.create_string_buffer(512), C.c_int(0)
+        self._chk(_oplib().rio_op_lookup(self._h, struct_name.encode(), object_id.encode(), buf, 512, C.byref(found)))
+        return buf.value.decode() if found.value else None
+
+    def clean_server(self, address):
+        self._chk(_oplib().rio_op_clean_server(self._h, address.encode()))
+
+    def remove(self, struct_name, object_id):
+        self._chk(_oplib().rio_op_remove(self._h, struct_name.encode(), object_id.encode()))
+
+    def __len__(self):
+        out = C.c_uint64(0)
+        self._chk(_oplib().rio_op_len(self._h, C.byref(out)))
+        return int(out.value)
+
+    # -- batched / membership / policy --
+    def update_batch(self, keys, addresses):
+        tys, ids = _cstrs([k[0] for k in keys]), _cstrs([k[1] for k in keys])
+        self._chk(_oplib().rio_op_update_batch(self._h, len(keys), tys, ids, _cstrs(addresses)))
+
+    def lookup_batch(self, keys):
+        tys, ids = _cstrs([k[0] for k in keys]), _cstrs([k[1] for k in keys])
+        out = np.empty(len(keys), np.uint32)
+        self._chk(_oplib().rio_op_lookup_batch(self._h, len(keys), tys, ids, _ptr(out)))
+        return [None if v == NONE else self.node_address(int(v)) for v in out]
+
+    def node_address(self, node_id):
+        v = _oplib().rio_op_node_address(self._h, node_id)
+        return None if v is None else v.decode()
+
+    def set_member(self, address, active=True, capacity=CAP_INF):
+        self._chk(_oplib().rio_op_set_member(self._h, address.encode(), int(bool(active)), capacity))
+
+    def set_object_load(self, struct_name, object_id, load):
+        self._chk(_oplib().rio_op_set_object_load(self._h, struct_name.encode(), object_id.encode(), load))
+
+    def get_or_create_placement(self, struct_name, object_id, self_address):
+        buf, flag = C.create_string_buffer(512), C.c_uint32(0)
+        self._chk(_oplib().rio_op_get_or_create_placement(self._h, struct_name.encode(), object_id.encode(),
+                                                          self_address.encode(), buf, 512, C.byref(flag)))
+        return (buf.value.decode() or None), int(flag.value)
+
+    def get_or_create_placement_batch(self, keys, self_addresses):
+        tys, ids = _cstrs([k[0] for k in keys]), _cstrs([k[1] for k in keys])
+        node, flag = np.empty(len(keys), np.uint32), np.empty(len(keys), np.uint32)
+        self._chk(_oplib().rio_op_get_or_create_placement_batch(self._h, len(keys), tys, ids, _cstrs(self_addresses),
+                                                                _ptr(node), _ptr(flag)))
+        return [None if v == NONE else self.node_address(int(v)) for v in node], flag
+
+    def tick(self):
+        st = Stats()
+        self._chk(_oplib().rio_op_tick(self._h, C.byref(st)))
+        return st.as_dict()

@@ -1,0 +1,172 @@
+"""The reference's own ObjectPlacement tests, re-run against the GPU-backed provider through the
+string-level C ABI (include/rio_gpu_object_placement.h).  Each test names the reference test it
+transcribes.  Run on the GPU box: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sql_backend_golden.json")
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import rio_gp
+    rio_gp.build()
+    return rio_gp
+
+
+# rio-rs/tests/object_placement_backend.rs:11-16  no_placement
+def test_no_placement(gp):
+    provider = gp.GpuObjectPlacement()
+    provider.prepare()
+    assert provider.lookup("obj", "1") is None
+
+
+# rio-rs/tests/object_placement_backend.rs:18-34  save_and_load
+def test_save_and_load(gp):
+    provider = gp.GpuObjectPlacement()
+    provider.prepare()
+    provider.update("obj", "1", "0.0.0.0:8888")
+    assert provider.lookup("obj", "1") == "0.0.0.0:8888"
+    provider.clean_server("0.0.0.0:8888")
+    assert provider.lookup("obj", "1") is None
+
+
+# rio-rs/src/object_placement/local.rs:71-123  local_object_placement_provider_is_clonable
+def test_provider_is_clonable(gp):
+    provider = gp.GpuObjectPlacement()
+    cloned = provider.clone()
+    provider.update("test", "1", "0.0.0.0:80")
+    assert provider.lookup("test", "1") is not None
+    assert cloned.lookup("test", "1") is not None
+    cloned.clean_server("0.0.0.0:80")
+    assert provider.lookup("test", "1") is None
+    assert cloned.lookup("test", "1") is None
+    provider.close()                      # dropping one clone keeps the shared state alive
+    cloned.update("test", "2", "0.0.0.0:80")
+    assert cloned.lookup("test", "2") == "0.0.0.0:80"
+
+
+# rio-rs/src/object_placement/sqlite.rs:149-193  test_sanity
+def test_sanity_upsert_overwrites(gp):
+    p = gp.GpuObjectPlacement()
+    assert p.lookup("Test", "1") is None
+    p.update("Test", "1", "0.0.0.0:5000")
+    assert p.lookup("Test", "1") == "0.0.0.0:5000"
+    p.update("Test", "1", "0.0.0.0:5001")
+    assert p.lookup("Test", "1") == "0.0.0.0:5001"
+    p.clean_server("0.0.0.0:5001")
+    assert p.lookup("Test", "1") is None
+
+
+# local.rs:36-37 update(None) deletes; local.rs:60-68 remove of an absent key; local.rs:26-29 key join quirk
+def test_none_remove_and_key_quirk(gp):
+    p = gp.GpuObjectPlacement()
+    p.remove("a", "1")
+    p.update("a", "1", None)
+    p.update("a", "1", "h:1")
+    assert len(p) == 1
+    p.update("a", "1", None)
+    assert p.lookup("a", "1") is None and len(p) == 0
+    p.update("a.b", "c", "h:1")
+    assert p.lookup("a", "b.c") == "h:1"
+    p.clean_server("never-seen:1")      # retain() on an address nothing lives on
+
+
+# the reference's SQL semantics (golden file) replayed through the string layer
+def test_sql_golden_through_string_layer(gp):
+    doc = json.load(open(GOLD))
+    for case in doc["cases"][:3]:
+        p = gp.GpuObjectPlacement(max_objects=4096, max_nodes=64)
+        got = []
+        for op in case["ops"]:
+            if op[0] == "lookup":
+                got.append(p.lookup(op[1], op[2]))
+            else:
+                getattr(p, op[0])(*op[1:])
+        assert got == case["expected_lookups"]
+        p.close()
+
+
+# rio-rs/tests/object_allocation.rs:75-137  move_object_on_server_failure (policy service.rs:193-254)
+def test_move_object_on_server_failure(gp):
+    p = gp.GpuObjectPlacement()
+    p.set_member("0.0.0.0:7001", True)
+    p.set_member("0.0.0.0:7002", True)
+    assert p.lookup("MockService", "1") is None                       # starts not allocated
+    first, flag = p.get_or_create_placement("MockService", "1", "0.0.0.0:7001")
+    assert first == "0.0.0.0:7001" and flag == gp.FLAG_PLACED          # first message allocates it
+    assert p.lookup("MockService", "1") == first
+    again, flag = p.get_or_create_placement("MockService", "1", "0.0.0.0:7002")
+    assert again == first and flag == gp.FLAG_REDIRECT                 # ResponseError::Redirect
+    p.set_member("0.0.0.0:7001", False)                                # the host dies
+    second, flag = p.get_or_create_placement("MockService", "1", "0.0.0.0:7002")
+    assert second == "0.0.0.0:7002" and flag == gp.FLAG_PLACED
+    assert first != second                                             # assert_ne!(first_server, second_server)
+
+
+# service.rs:213-223: a malformed record is removed (only that record) and the object re-placed
+def test_policy_bad_record_removed(gp, oracle):
+    p, o = gp.GpuObjectPlacement(), oracle.LocalObjectPlacement()
+    st = oracle.LocalStorage()
+    st.push("h", 1)
+    p.set_member("h:1", True)
+    for prov in (p, o):
+        prov.update("T", "x", "nocolon")
+        prov.update("T", "y", "nocolon")
+    got, _ = p.get_or_create_placement("T", "x", "h:1")
+    assert got == oracle.get_or_create_placement(o, st, "h:1", "T", "x") == "h:1"
+    assert p.lookup("T", "y") == o.lookup("T", "y") == "nocolon"       # the other bad record is untouched
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_differential_vs_reference_restatement(gp, oracle, seed):
+    """Random trait calls + policy requests: the GPU provider and the C++ restatement of
+    LocalObjectPlacement + service.rs policy must agree on every observable."""
+    rng = np.random.default_rng(seed)
+    addrs = ["10.0.0.%d:%d" % (k, 5000 + k) for k in range(6)]
+    p, o, st = gp.GpuObjectPlacement(max_objects=2048, max_nodes=32), oracle.LocalObjectPlacement(), oracle.LocalStorage()
+    alive = [True] * len(addrs)
+    for a in addrs:
+        ip, port = a.split(":")
+        st.push(ip, port, True)
+        p.set_member(a, True)
+    keys = [("T%d" % (k % 3), str(k)) for k in range(120)]
+    for step in range(400):
+        r = rng.random()
+        ty, oid = keys[int(rng.integers(len(keys)))]
+        if r < 0.15:
+            a = addrs[int(rng.integers(len(addrs)))]
+            p.update(ty, oid, a)
+            o.update(ty, oid, a)
+        elif r < 0.25:
+            p.remove(ty, oid)
+            o.remove(ty, oid)
+        elif r < 0.30:
+            a = addrs[int(rng.integers(len(addrs)))]
+            p.clean_server(a)
+            o.clean_server(a)
+        elif r < 0.36:
+            k = int(rng.integers(len(addrs)))
+            alive[k] = not alive[k]
+            if not any(alive):
+                alive[k] = True
+            ip, port = addrs[k].split(":")
+            st.set_is_active(ip, port, alive[k])
+            p.set_member(addrs[k], alive[k])
+        elif r < 0.75:
+            me = addrs[int(rng.choice([k for k in range(len(addrs)) if alive[k]]))]
+            got, flag = p.get_or_create_placement(ty, oid, me)
+            want = oracle.get_or_create_placement(o, st, me, ty, oid)
+            assert got == want, (step, ty, oid)
+            verdict = oracle.check_address_mismatch(o, st, me, want)
+            assert verdict == ("ok" if flag in (gp.FLAG_LOCAL, gp.FLAG_PLACED) else "redirect")
+        else:
+            assert p.lookup(ty, oid) == o.lookup(ty, oid), step
+    for ty, oid in keys:
+        assert p.lookup(ty, oid) == o.lookup(ty, oid)
+    assert len(p) == len(o)
+    assert p.lookup_batch(keys) == [o.lookup(*k) for k in keys]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): parity tests, smoke, bench, rocprofv3 kernel stats.
 # Usage: tools/gpu_check.sh <tag> [quick]
-TAG=${1:-r1}
+TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
