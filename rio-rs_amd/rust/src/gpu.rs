@@ -1,0 +1,198 @@
+//! `GpuObjectPlacement` — drop-in `ObjectPlacement` provider backed by the MI355X solver.
+//!
+//! Goes into the reference tree as `rio-rs/src/object_placement/gpu.rs` behind a cargo feature
+//! `gpu` (next to `local`, `sqlite`, `postgres`, `redis`, rio-rs/src/object_placement/mod.rs:10-17).
+//! It is a thin FFI wrapper over `librio_gp.so` (include/rio_gpu_object_placement.h); all string
+//! interning, batching and the HBM tables live behind the C ABI.
+//!
+//! NOT COMPILED IN THIS REPOSITORY: the build image has no cargo/rustc.  The C ABI it binds is
+//! exercised by tests/test_gpu_object_placement.py through the ctypes twin of this file
+//! (rio-rs_amd/rio_gp.py::GpuObjectPlacement), which re-runs the reference's own tests.
+
+use std::ffi::{c_char, c_int, c_void, CStr, CString};
+use std::fmt;
+use std::sync::Arc;
+
+use async_trait::async_trait;
+
+use crate::errors::ObjectPlacementError;
+use crate::object_placement::{ObjectPlacement, ObjectPlacementItem};
+use crate::ObjectId;
+
+#[repr(C)]
+struct RioOpCfg {
+    struct_size: u32,
+    device: i32,
+    max_objects: u64,
+    max_nodes: u32,
+    spill_rounds: u32,
+    flags: u32,
+    reserved: u32,
+}
+
+const RIO_GP_OK: c_int = 0;
+const RIO_GP_EINVAL: c_int = 1;
+pub const FLAG_LOCAL: u32 = 0;
+pub const FLAG_REDIRECT: u32 = 1;
+pub const FLAG_PLACED: u32 = 2;
+pub const FLAG_SPILLED: u32 = 3;
+pub const FLAG_UNPLACED: u32 = 4;
+
+#[link(name = "rio_gp")]
+extern "C" {
+    fn rio_op_create(cfg: *const RioOpCfg, out: *mut *mut c_void) -> c_int;
+    fn rio_op_clone(p: *mut c_void) -> *mut c_void;
+    fn rio_op_release(p: *mut c_void);
+    fn rio_op_last_error(p: *mut c_void) -> *const c_char;
+    fn rio_op_update(p: *mut c_void, ty: *const c_char, id: *const c_char, addr: *const c_char) -> c_int;
+    fn rio_op_lookup(p: *mut c_void, ty: *const c_char, id: *const c_char, out: *mut c_char, cap: usize,
+                     found: *mut c_int) -> c_int;
+    fn rio_op_clean_server(p: *mut c_void, addr: *const c_char) -> c_int;
+    fn rio_op_remove(p: *mut c_void, ty: *const c_char, id: *const c_char) -> c_int;
+    fn rio_op_set_member(p: *mut c_void, addr: *const c_char, active: c_int, capacity: u64) -> c_int;
+    fn rio_op_get_or_create_placement(p: *mut c_void, ty: *const c_char, id: *const c_char,
+                                      self_addr: *const c_char, out: *mut c_char, cap: usize,
+                                      flag: *mut u32) -> c_int;
+}
+
+/// One reference on the shared native state; `Drop` releases it (the HBM tables go with the last).
+struct Handle(*mut c_void);
+// The native handle is internally synchronized (one mutex + one HIP stream per state).
+unsafe impl Send for Handle {}
+unsafe impl Sync for Handle {}
+impl Drop for Handle {
+    fn drop(&mut self) {
+        unsafe { rio_op_release(self.0) }
+    }
+}
+
+/// `Clone` shares the placement table, exactly like `LocalObjectPlacement`'s inner `Arc`
+/// (rio-rs/src/object_placement/local.rs:12-18); servers in one process can share one clone
+/// (rio-rs/tests/server_utils.rs:62-73).
+#[derive(Clone)]
+pub struct GpuObjectPlacement {
+    inner: Arc<Handle>,
+}
+
+impl fmt::Debug for GpuObjectPlacement {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        f.debug_struct("GpuObjectPlacement").finish()
+    }
+}
+
+#[bon::bon]
+impl GpuObjectPlacement {
+    #[builder]
+    pub fn new(
+        #[builder(default = 0)] device: i32,
+        #[builder(default = 1 << 24)] max_objects: u64,
+        #[builder(default = 4096)] max_nodes: u32,
+        #[builder(default = 2)] spill_rounds: u32,
+    ) -> Result<Self, ObjectPlacementError> {
+        let cfg = RioOpCfg {
+            struct_size: std::mem::size_of::<RioOpCfg>() as u32,
+            device, max_objects, max_nodes, spill_rounds, flags: 0, reserved: 0,
+        };
+        let mut h: *mut c_void = std::ptr::null_mut();
+        let rc = unsafe { rio_op_create(&cfg, &mut h) };
+        if rc != RIO_GP_OK {
+            return Err(to_err(rc, std::ptr::null_mut()));
+        }
+        Ok(Self { inner: Arc::new(Handle(h)) })
+    }
+
+    /// Liveness/capacity feed: call from wherever `MembershipStorage::set_is_active` is called
+    /// (rio-rs/src/cluster/storage/mod.rs:80; the gossip loop, peer_to_peer.rs:170-191).
+    pub fn set_member(&self, address: &str, active: bool, capacity: Option<u64>) -> Result<(), ObjectPlacementError> {
+        let a = cstr(address)?;
+        check(unsafe { rio_op_set_member(self.inner.0, a.as_ptr(), active as c_int, capacity.unwrap_or(u64::MAX)) }, self)
+    }
+
+    /// Batched replacement of `Service::get_or_create_placement` + `check_address_mismatch`
+    /// (rio-rs/src/service.rs:193-298) for callers that want one call instead of
+    /// lookup + is_active + clean_server + update.
+    pub fn get_or_create_placement(&self, object_id: &ObjectId, self_address: &str)
+        -> Result<(Option<String>, u32), ObjectPlacementError> {
+        let (ty, id, me) = (cstr(&object_id.0)?, cstr(&object_id.1)?, cstr(self_address)?);
+        let mut buf = vec![0 as c_char; 512];
+        let mut flag = 0u32;
+        check(unsafe { rio_op_get_or_create_placement(self.inner.0, ty.as_ptr(), id.as_ptr(), me.as_ptr(),
+                                                      buf.as_mut_ptr(), buf.len(), &mut flag) }, self)?;
+        let s = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
+        Ok((if flag == FLAG_UNPLACED { None } else { Some(s) }, flag))
+    }
+}
+
+fn cstr(s: &str) -> Result<CString, ObjectPlacementError> {
+    CString::new(s).map_err(|e| ObjectPlacementError::Unknown(e.to_string()))
+}
+
+/// errors.rs:135-142: bad argument -> Unknown, anything from HIP -> Upstream.
+fn to_err(rc: c_int, h: *mut c_void) -> ObjectPlacementError {
+    let text = unsafe { CStr::from_ptr(rio_op_last_error(h)) }.to_string_lossy().into_owned();
+    if rc == RIO_GP_EINVAL { ObjectPlacementError::Unknown(text) } else { ObjectPlacementError::Upstream(text) }
+}
+fn check(rc: c_int, p: &GpuObjectPlacement) -> Result<(), ObjectPlacementError> {
+    if rc == RIO_GP_OK { Ok(()) } else { Err(to_err(rc, p.inner.0)) }
+}
+
+#[async_trait]
+impl ObjectPlacement for GpuObjectPlacement {
+    // mod.rs:46-49 / local.rs:22-40
+    async fn update(&self, object_placement: ObjectPlacementItem) -> Result<(), ObjectPlacementError> {
+        let ty = cstr(&object_placement.object_id.0)?;
+        let id = cstr(&object_placement.object_id.1)?;
+        let addr = match &object_placement.server_address {
+            Some(a) => Some(cstr(a)?),
+            None => None, // None deletes (local.rs:36-37)
+        };
+        let ap = addr.as_ref().map_or(std::ptr::null(), |a| a.as_ptr());
+        check(unsafe { rio_op_update(self.inner.0, ty.as_ptr(), id.as_ptr(), ap) }, self)
+    }
+
+    // mod.rs:50 / local.rs:42-49: a miss is Ok(None)
+    async fn lookup(&self, object_id: &ObjectId) -> Result<Option<String>, ObjectPlacementError> {
+        let (ty, id) = (cstr(&object_id.0)?, cstr(&object_id.1)?);
+        let mut buf = vec![0 as c_char; 512];
+        let mut found: c_int = 0;
+        check(unsafe { rio_op_lookup(self.inner.0, ty.as_ptr(), id.as_ptr(), buf.as_mut_ptr(), buf.len(), &mut found) }, self)?;
+        Ok(if found != 0 {
+            Some(unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned())
+        } else {
+            None
+        })
+    }
+
+    // mod.rs:52 / local.rs:51-58
+    async fn clean_server(&self, address: String) -> Result<(), ObjectPlacementError> {
+        let a = cstr(&address)?;
+        check(unsafe { rio_op_clean_server(self.inner.0, a.as_ptr()) }, self)
+    }
+
+    // mod.rs:55 / local.rs:60-68
+    async fn remove(&self, object_id: &ObjectId) -> Result<(), ObjectPlacementError> {
+        let (ty, id) = (cstr(&object_id.0)?, cstr(&object_id.1)?);
+        check(unsafe { rio_op_remove(self.inner.0, ty.as_ptr(), id.as_ptr()) }, self)
+    }
+}
+
+#[cfg(test)]
+mod test {
+    use super::*;
+
+    // the same assertions as local.rs:71-123, against the GPU provider
+    #[tokio::test]
+    async fn gpu_object_placement_provider_is_clonable() {
+        let provider = GpuObjectPlacement::builder().build().unwrap();
+        let cloned_provider = provider.clone();
+        provider
+            .update(ObjectPlacementItem::new(ObjectId("test".to_string(), "1".to_string()), Some("0.0.0.0:80".to_string())))
+            .await
+            .unwrap();
+        assert!(provider.lookup(&ObjectId("test".to_string(), "1".to_string())).await.unwrap().is_some());
+        assert!(cloned_provider.lookup(&ObjectId("test".to_string(), "1".to_string())).await.unwrap().is_some());
+        cloned_provider.clean_server("0.0.0.0:80".to_string()).await.unwrap();
+        assert!(provider.lookup(&ObjectId("test".to_string(), "1".to_string())).await.unwrap().is_none());
+        assert!(cloned_provider.lookup(&ObjectId("test".to_string(), "1".to_string())).await.unwrap().is_none());
+    }
+}
