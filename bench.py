@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--workload", default="c3", help="c3 (headline) | c3w | c2 | c4shard")
     ap.add_argument("--objects", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="N=1 only: run the row-sharded path (RCCL group of one rank) to price its extra kernels and launches")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
                     help="PMC-derived HBM bytes per k_scan launch (tools/pmc_traffic.py); null if absent")
@@ -91,21 +93,38 @@ def main():
     rio_gp.build()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n_over = a.objects or None
     per_rank = synth.config(a.workload, n_override=n_over, start=0)  # shapes only
     n_local = per_rank["n"]
+    # weak scaling: every rank owns n_local consecutive rows of ONE table of world*n_local rows (rank order =
+    # index order); capacities are set from the GLOBAL load, exactly as the unsharded config would
     cfg = synth.config(a.workload, n_override=n_local, start=rank * n_local) if world > 1 else per_rank
     n, m = cfg["n"], cfg["m"]
+    if dist is not None and a.workload != "c2":
+        tot = torch.tensor([int(cfg["load"].astype(np.uint64).sum())], device="cuda", dtype=torch.int64)
+        dist.all_reduce(tot)  # set-up only, not the data path
+        cfg["cap"] = np.full(m, -((-int(tot.item()) * 1250) // (1000 * m)), dtype=np.uint64)
 
     g = rio_gp.GpuPlacement(n, m, device=local_rank)
     g.set_nodes(cfg["cap"], cfg["alive"])
     g.set_objects(n, cfg["load"], cfg["aff"])
     if a.workload == "c3w":
         g.set_assign(cfg["cur"])
+
+    if dist is None:
+        step, wait = g.solve_async, g.solve_wait
+    else:
+        # row-sharded solve: k_scan + local sums -> RCCL all-gather of the (2m+8)-word record -> global resolve,
+        # all ordered on one stream; the verdicts are read once at the end, as at N=1
+        import sharded
+        sol = sharded.ShardedSolver([sharded.HipShardEngine(g, local_rank)], sharded.DistExchange(), spill_rounds=2)
+        step, wait = sol.solve_async, sol.solve_wait
 
     def barrier():
         if dist is not None:
@@ -114,23 +133,23 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        g.solve_async()
+        step()
     if a.warmup:
-        st, n_slow = g.solve_wait()
+        st, n_slow = wait()
     barrier()
     t0 = time.perf_counter()
     g.timer_begin()
     for _ in range(a.steps):
-        g.solve_async()
+        step()
     gpu_ms = g.timer_end()
-    st, n_slow = g.solve_wait()
+    st, n_slow = wait()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n
+    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n * world
     total_decisions = n * world * a.steps
 
     # per-launch duration of the dominant kernel, HIP events on the library's own stream
@@ -148,6 +167,9 @@ def main():
                      "ms": ms, "GBps": ALGO_BYTES_PER_DECISION * n / ms / 1e6}
         except Exception as e:  # measurement aid only
             probe = {"error": str(e)}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     scan_avg = float(np.mean(scan_ms)) if scan_ms else None
@@ -163,7 +185,9 @@ def main():
         "config": {"workload": "config 3: %d objects x %d nodes per GPU, Zipf(1.1) load, cap 1.25x, cold start "
                                "(all pending)" % (n, m) if a.workload == "c3" else a.workload,
                    "objects_per_gpu": n, "nodes": m, "parallelism": "rows sharded x%d" % world,
-                   "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end",
+                   "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end" if world == 1
+                           else "row-sharded solve: k_scan + k_resolve + pack -> RCCL all-gather of %d B/rank -> k_shard_import, "
+                                "one stream; verdicts read at the end" % (8 * (2 * m + 8)),
                    "slow_path_steps": n_slow},
         "gpu_ms_per_step_events": gpu_ms / a.steps,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -194,6 +194,52 @@ int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow);
 const uint32_t* rio_gp_solved_dev(rio_gp_t* h);
 int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out_assign);
 
+/* ---- row-sharded solve across the GPUs of one node ----------------------- */
+/*
+ * Rank r (one process, one GPU, one handle) owns the contiguous rows [off_r, off_r + n_r) of the
+ * object table; shard order = index order; the node table is replicated.  Rows couple only through
+ * the per-node load vectors, so the only cross-rank data are two small records, all-gathered by
+ * the CALLER between the calls below (RCCL over xGMI from the Rust/Python host; the library itself
+ * never talks to another rank):
+ *   X (rio_gp_shard_words1 = 2m+8 u64): local kept load[m] | local claim load[m] | 8 counters
+ *   Y (rio_gp_shard_words2 =  m+2 u64): locally admitted load[m] | pending spill load | pending rows
+ * Every cross-rank reduction is an integer sum taken in rank order, so the sharded solve equals the
+ * unsharded rio_gp_solve of the concatenated table bit for bit.
+ *
+ *   fast path (nothing cut, nothing spills):   scan -> [all-gather X] -> resolve -> verdict -> finish
+ *   fix-up:   ... verdict -> cut -> [all-gather Y] -> merge
+ *                 -> { spill(round) -> [all-gather Y] -> merge } while rows are pending -> finish
+ * then rio_gp_commit publishes as usual.  d_* are DEVICE pointers owned by the caller.
+ */
+typedef struct rio_gp_shard_info {
+    uint64_t cut_nodes;    /* nodes whose global claim load exceeds their free capacity */
+    uint64_t spill_rows;   /* rows (all ranks) whose affinity node is unusable: go to the water-fill */
+    uint64_t local_fixup;  /* != 0: THIS rank has claimants to re-mark (pass it to rio_gp_shard_cut) */
+    uint64_t kept, evicted, claimants, load_kept, load_claim; /* global row/load counters */
+} rio_gp_shard_info;
+/* Enqueue every later call of this handle on the caller's HIP stream (hipStream_t as void*; NULL = back
+ * to the handle's own stream), e.g. the stream the host's RCCL all-gather is ordered against. */
+int rio_gp_set_stream(rio_gp_t* h, void* hip_stream);
+uint32_t rio_gp_shard_words1(rio_gp_t* h);
+uint32_t rio_gp_shard_words2(rio_gp_t* h);
+/* k_scan + local column sums; d_x[words1] = this rank's X record.  Asynchronous. */
+int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x);
+/* d_xg[n_ranks][words1] = the all-gathered X records.  Asynchronous. */
+int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uint64_t* d_xg);
+/* Waits for the stream; global verdict of the LAST resolve; *n_slow = how many of the resolves enqueued
+ * since the last verdict need the fix-up. */
+int rio_gp_shard_verdict(rio_gp_t* h, rio_gp_shard_info* out, uint32_t* n_slow);
+/* Fix-up step 1 (only if cut_nodes or spill_rows): exact cut on this rank, d_y[words2] = Y record. */
+int rio_gp_shard_cut(rio_gp_t* h, int run_local_fixup, uint64_t* d_y);
+/* d_yg[n_ranks][words2] = all-gathered Y records -> global `used`, this rank's spill base.  Synchronous;
+ * returns the rows / load still waiting for the water-fill on all ranks. */
+int rio_gp_shard_merge(rio_gp_t* h, const uint64_t* d_yg, uint64_t* pending_rows, uint64_t* pending_load);
+/* One water-fill round over this rank's pending rows; d_y[words2] = Y record of the round. */
+int rio_gp_shard_spill(rio_gp_t* h, uint32_t round, int last, uint64_t* d_y);
+/* Local counters of this rank's rows (sum them over ranks; cut_nodes/slow_path/rounds_run are global
+ * quantities the caller already holds).  After this, rio_gp_commit / rio_gp_get_solved work as usual. */
+int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats);
+
 /* ---- measurement hooks (HIP events on the handle's own stream) -------------------------- */
 int rio_gp_timer_begin(rio_gp_t* h);
 int rio_gp_timer_end(rio_gp_t* h, float* ms);

@@ -66,6 +66,10 @@ struct SolveBufs {
     u64* wfC;        // [m+1] cumulative free capacity in water-fill order (saturating)
     u32* wfOrder;    // [m]
     u32* wfCnt;      // [1]
+    // row-sharded solve only (nullptr otherwise): nodes whose claim prefix overflowed on a lower rank, and the
+    // spill load pending on lower ranks
+    u32* forced_bits;        // [mwords]
+    u64* rank_base;          // [1]
     DevStats* stats;
 };
 
@@ -122,5 +126,15 @@ void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const
                        u32* out_flag, hipStream_t s);
 
 size_t scan_lds_bytes(u32 m);
+
+// --- row-sharded solve: records exchanged between ranks ---
+inline size_t shard_words1(u32 m) { return 2 * (size_t)m + 8; }  // X = [kept_local[m] | claim_local[m] | 8 counters]
+inline size_t shard_words2(u32 m) { return (size_t)m + 2; }      // Y = [delta[m] | spill load | spill rows]
+void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s);
+void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, const u64* Xg, u32 rank, u32 R,
+                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s);
+void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s);
+void launch_shard_import_delta(const Plan& p, const SolveBufs& b, const u64* Yg, u32 rank, u32 R, u64* gprev,
+                               u64* verdict_dev, u64* verdict_host, hipStream_t s);
 
 }  // namespace riogp

@@ -651,6 +651,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_prepare(Plan p, const u64* __r
                                                           const u32* __restrict__ wsp_cnt,
                                                           u64* __restrict__ wsp_base, u64* __restrict__ wfC,
                                                           u32* __restrict__ wfOrder, u32* __restrict__ wfCnt,
+                                                          const u64* __restrict__ rank_base,
                                                           DevStats* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_prepare(Plan p, const u64* __r
         s += v[q];
     }
     u64 ex = block_excl_scan_1024(s, false, part, nullptr);
+    if (rank_base) ex += *rank_base;  // row-sharded solve: spill load of every lower rank comes first
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const u32 w = tid * 4 + q;
@@ -1027,6 +1029,163 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row-sharded solve: rank r owns the contiguous rows [off_r, off_r + n_r); shard order
+// = index order, node tables are replicated.  The only cross-rank data are M-vectors:
+//   exchange #1  X_r = [kept_local[m] | claim_local[m] | 8 counters]          (every solve)
+//   exchange #2+ Y_r = [admitted-load delta[m] | spill load | spill rows]     (fix-up path only)
+// all-gathered by the caller (RCCL over xGMI; ≤ 64 KiB per rank, latency-bound).  These kernels turn
+// the gathered records into the local solver's view; every reduction is an integer sum in rank
+// order, so the composed result is bit-identical to the unsharded solve.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_shard_pack1(const u64* __restrict__ used_kept,
+                                                        const u64* __restrict__ claim_tot,
+                                                        const u64* __restrict__ partial, u32 nb, u32 m,
+                                                        u64* __restrict__ X) {
+    __shared__ u64 red[8];
+    const int tid = threadIdx.x;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    for (u32 j = tid; j < m; j += kBlock) {
+        X[j] = used_kept[j];
+        X[m + j] = claim_tot[j];
+    }
+    const u32 c = tid & 7;
+    u64 acc = 0;
+    for (u32 r = tid >> 3; r < nb; r += kBlock / 8) acc += partial[(size_t)r * 8 + c];
+    acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
+    if ((tid & 63) < 8) atomicAdd(&red[c], acc);
+    __syncthreads();
+    if (tid < 8) X[2 * (size_t)m + tid] = red[tid];
+}
+
+// verdict words: 0 cut nodes (global) | 1 spill-candidate rows (global) | 2 this rank has rows to re-mark |
+//                3 kept rows | 4 evicted rows | 5 claimant rows | 6 kept load | 7 claim load (all global)
+__global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__ Xg, u32 rank, u32 R, u32 m,
+                                                         const u64* __restrict__ cap,
+                                                         const u32* __restrict__ alive_bits,
+                                                         u64* __restrict__ used_kept, u64* __restrict__ used_cur,
+                                                         u64* __restrict__ claim_tot, u32* __restrict__ cutblk,
+                                                         u32* __restrict__ cutidx, u64* __restrict__ gprev,
+                                                         u64* __restrict__ gfinal, u32* __restrict__ forced_bits,
+                                                         u64* __restrict__ rank_base, u64* __restrict__ verdict_dev,
+                                                         u64* __restrict__ verdict_host) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32* fb = reinterpret_cast<u32*>(smem);  // [mwords]
+    __shared__ u64 red[8];
+    const int tid = threadIdx.x;
+    const u32 mwords = (m + 31) / 32;
+    const size_t W = 2 * (size_t)m + 8;
+    for (u32 k = tid; k < mwords; k += kBlock) fb[k] = 0;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    u32 ncut = 0, need = 0;
+    for (u32 j = tid; j < m; j += kBlock) {
+        u64 kept_glob = 0, claim_pre = 0, claim_glob = 0, claim_local = 0;
+        for (u32 r = 0; r < R; ++r) {
+            const u64 kx = Xg[r * W + j], cx = Xg[r * W + m + j];
+            kept_glob += kx;
+            if (r < rank) claim_pre += cx;
+            if (r == rank) claim_local = cx;
+            claim_glob += cx;
+        }
+        const u64 cj = cap[j];
+        const u64 fre = (bit_of(alive_bits, j) && cj > kept_glob) ? cj - kept_glob : 0;
+        const bool forced = claim_pre > fre;  // the node's prefix overflowed on a lower rank: everyone here is rejected
+        const u64 ukp = kept_glob + (forced ? fre : claim_pre);
+        used_kept[j] = ukp;  // local view: free = cap - ukp = what is left for THIS rank's claimants
+        claim_tot[j] = claim_local;
+        used_cur[j] = ukp + claim_local;
+        cutblk[j] = kNoCut;
+        cutidx[j] = kNoCut;
+        gprev[j] = kept_glob;
+        gfinal[j] = kept_glob + claim_glob;  // the committed `used` when nothing is cut and nothing spills
+        if (forced) atomicOr(&fb[j >> 5], 1u << (j & 31));
+        ncut += claim_glob > fre;
+        need += forced || claim_local > fre - claim_pre;
+    }
+    ncut = wave_sum32(ncut);
+    need = wave_sum32(need);
+    if ((tid & 63) == 0) {
+        if (ncut) atomicAdd(&red[0], (u64)ncut);
+        if (need) atomicAdd(&red[2], (u64)need);
+    }
+    if (tid < 8) {  // global counters: column tid of every rank's record
+        u64 s = 0;
+        for (u32 r = 0; r < R; ++r) s += Xg[r * W + 2 * (size_t)m + tid];
+        // k_resolve's partial columns: 0 load_kept 1 load_claim 2 (local n_cut, unused) 3 kept 4 evicted 5 claimants 6 spillcand
+        const int dst = tid == 0 ? 6 : tid == 1 ? 7 : tid == 3 ? 3 : tid == 4 ? 4 : tid == 5 ? 5 : tid == 6 ? 1 : -1;
+        if (dst >= 0) atomicAdd(&red[dst], s);
+    }
+    __syncthreads();
+    for (u32 k = tid; k < mwords; k += kBlock) forced_bits[k] = fb[k];
+    if (tid == 0) *rank_base = 0;
+    if (tid < 8) {
+        verdict_dev[tid] = red[tid];
+        if (verdict_host) verdict_host[tid] = red[tid];
+    }
+}
+
+// forced nodes: every local claimant is rejected, load-0 ones included (the strict prefix cut already fired)
+__global__ __launch_bounds__(kBlock) void k_shard_force(u32 m, const u32* __restrict__ forced_bits,
+                                                        const u64* __restrict__ used_kept, u32* __restrict__ cutidx,
+                                                        u64* __restrict__ used_cur) {
+    for (u32 j = threadIdx.x; j < m; j += kBlock)
+        if (bit_of(forced_bits, j)) {
+            cutidx[j] = 0;
+            used_cur[j] = used_kept[j];
+        }
+}
+
+// Y = [used_cur - base | spill load still pending on this rank | its row count]
+__global__ __launch_bounds__(kBlock) void k_shard_export_delta(const u64* __restrict__ used_cur,
+                                                               const u64* __restrict__ base,
+                                                               const u64* __restrict__ wsp_sum,
+                                                               const u32* __restrict__ wsp_cnt, u32 nw, u32 m,
+                                                               u64* __restrict__ Y) {
+    __shared__ u64 red[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) red[tid] = 0;
+    __syncthreads();
+    for (u32 j = tid; j < m; j += kBlock) Y[j] = used_cur[j] - base[j];
+    u64 s = 0, c = 0;
+    for (u32 w = tid; w < nw; w += kBlock) { s += wsp_sum[w]; c += wsp_cnt[w]; }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((tid & 63) == 0) { atomicAdd(&red[0], s); atomicAdd(&red[1], c); }
+    __syncthreads();
+    if (tid < 2) Y[m + tid] = red[tid];
+}
+
+// used_cur = global used so far; rank_base = spill load pending on lower ranks; verdict = [rows, load] pending globally
+__global__ __launch_bounds__(kBlock) void k_shard_import_delta(const u64* __restrict__ Yg, u32 rank, u32 R, u32 m,
+                                                               u64* __restrict__ gprev, u64* __restrict__ used_cur,
+                                                               u64* __restrict__ rank_base,
+                                                               u64* __restrict__ verdict_dev,
+                                                               u64* __restrict__ verdict_host) {
+    const int tid = threadIdx.x;
+    const size_t W = (size_t)m + 2;
+    for (u32 j = tid; j < m; j += kBlock) {
+        u64 g = gprev[j];
+        for (u32 r = 0; r < R; ++r) g += Yg[r * W + j];
+        gprev[j] = g;
+        used_cur[j] = g;
+    }
+    if (tid == 0) {
+        u64 base = 0, load = 0, rows = 0;
+        for (u32 r = 0; r < R; ++r) {
+            const u64 l = Yg[r * W + m];
+            if (r < rank) base += l;
+            load += l;
+            rows += Yg[r * W + m + 1];
+        }
+        *rank_base = base;
+        verdict_dev[0] = rows; verdict_dev[1] = load;
+        if (verdict_host) { verdict_host[0] = rows; verdict_host[1] = load; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
@@ -1103,6 +1262,7 @@ void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                            b.cutblk, b.T);
         hipLaunchKernelGGL(k_cut_exact<true>, dim3(g4), dim3(256), 0, s, t.cur, t.load, t.aff, nt.alive_bits, p,
                            b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
+        if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
         hipLaunchKernelGGL(k_apply_cut<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
                            nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
     } else {
@@ -1110,6 +1270,7 @@ void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                            p, b.cutblk, b.T);
         hipLaunchKernelGGL(k_cut_exact<false>, dim3(g4), dim3(256), 0, s, t.cur, t.load, t.aff, nt.alive_bits, p,
                            b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
+        if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
         hipLaunchKernelGGL(k_apply_cut<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
                            nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
     }
@@ -1121,7 +1282,7 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
     const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
     const size_t lds_prep = 2 * kSmall + (size_t)2 * mp * sizeof(u64);
     hipLaunchKernelGGL(k_spill_prepare, dim3(1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
-                       b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.stats);
+                       b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.rank_base, b.stats);
     const size_t lds_apply = kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + 16;
     hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_base, b.wfC,
                        b.wfOrder, b.wfCnt, b.used_cur, b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats);
@@ -1193,6 +1354,27 @@ void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const
     hipLaunchKernelGGL(k_pp_scatter, dim3(g), dim3(256), 0, s, assign, idx, n, vcur, vnext);
     hipLaunchKernelGGL(k_pp_output, dim3(g), dim3(256), 0, s, assign, idx, req, n, vcur, pos, alive_bits,
                        cutidx_or_null, m, out_node, out_flag);
+}
+
+void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s) {
+    hipLaunchKernelGGL(k_shard_pack1, dim3(1), dim3(kBlock), 0, s, b.used_kept, b.claim_tot, b.partial,
+                       resolve_blocks(p.m), p.m, X);
+}
+void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, const u64* Xg, u32 rank, u32 R,
+                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s) {
+    const size_t lds = (size_t)(p.mwords + 4) * sizeof(u32);
+    hipLaunchKernelGGL(k_shard_import, dim3(1), dim3(kBlock), lds, s, Xg, rank, R, p.m, nt.cap, nt.alive_bits,
+                       b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits,
+                       b.rank_base, verdict_dev, verdict_host);
+}
+void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s) {
+    hipLaunchKernelGGL(k_shard_export_delta, dim3(1), dim3(kBlock), 0, s, b.used_cur, base, b.wsp_sum[wsp_sel],
+                       b.wsp_cnt[wsp_sel], p.nw, p.m, Y);
+}
+void launch_shard_import_delta(const Plan& p, const SolveBufs& b, const u64* Yg, u32 rank, u32 R, u64* gprev,
+                               u64* verdict_dev, u64* verdict_host, hipStream_t s) {
+    hipLaunchKernelGGL(k_shard_import_delta, dim3(1), dim3(kBlock), 0, s, Yg, rank, R, p.m, gprev, b.used_cur,
+                       b.rank_base, verdict_dev, verdict_host);
 }
 
 }  // namespace riogp

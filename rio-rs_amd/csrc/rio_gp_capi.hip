@@ -35,7 +35,8 @@ struct rio_gp {
     std::mutex mu;
     std::string err;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every call of this handle is enqueued on
+    hipStream_t own_stream = nullptr;  // created by rio_gp_create (rio_gp_set_stream may point `stream` elsewhere)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     u64 cap_obj = 0, cap_rows = 0;
     u32 cap_nodes = 0, rounds = 2;
@@ -62,6 +63,13 @@ struct rio_gp {
     Plan plan{};
     bool have_solved = false;
     u32 ring_n = 0;
+    // row-sharded solve (rio_gp_shard_*): global `used` snapshots, forced-node bitmap, spill base, verdict words
+    u64 *sh_gprev = nullptr, *sh_gfinal = nullptr, *sh_rank_base = nullptr, *sh_verdict = nullptr;
+    u32* sh_forced = nullptr;
+    u32 sh_rank = 0, sh_R = 1;
+    int sh_state = 0;       // 0 idle | 1 scanned | 2 resolved | 3 cut exported | 4 merged | 5 spill exported
+    bool sh_slow = false;   // the solve in flight took the fix-up path
+    u32 sh_slot = 0;        // verdict slot of the last rio_gp_shard_resolve
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
     std::vector<void*> allocs;
@@ -262,7 +270,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return code;
     };
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(RIO_GP_EUPSTREAM); }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess || !(h->stream = h->own_stream) ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         h->err = "stream/event creation failed";
         return bail(RIO_GP_EUPSTREAM);
@@ -279,6 +287,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
     A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
     A(h->sb.wfCnt, 4); A(h->dstats, 1);
+    A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
 #undef A
     h->sb.stats = h->dstats;
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stats), sizeof(DevStats) * kRing, hipHostMallocMapped) !=
@@ -315,6 +324,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& b : h->vt) if (b.p) (void)hipFree(b.p);
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
@@ -324,7 +334,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -781,6 +791,152 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     const DevStats v = reduce_slot(h, 0, h->m);
     if (v.n_cut > 0 || v.spillcand > 0)
         return fail(h, RIO_GP_EINVAL, "rio_gp_solve_profiled: this table needs the cut/spill fix-up");
+    return RIO_GP_OK;
+}
+
+// ---- row-sharded solve across GPUs ------------------------------------------
+
+int rio_gp_set_stream(rio_gp_t* h, void* hip_stream) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return RIO_GP_OK;
+}
+
+uint32_t rio_gp_shard_words1(rio_gp_t* h) { return h ? (uint32_t)shard_words1(h->m) : 0; }
+uint32_t rio_gp_shard_words2(rio_gp_t* h) { return h ? (uint32_t)shard_words2(h->m) : 0; }
+
+static SolveBufs shard_bufs(rio_gp* h) {
+    SolveBufs b = h->sb;
+    b.forced_bits = h->sh_forced;
+    b.rank_base = h->sh_rank_base;
+    return b;
+}
+
+int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
+    if (!h || !d_x) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->plan = make_plan(h->n, h->m, 0);
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+    launch_resolve(h->plan, nt, h->sb, nullptr, h->stream);  // used_base = nullptr: purely local sums
+    launch_shard_pack1(h->plan, h->sb, reinterpret_cast<u64*>(d_x), h->stream);
+    h->have_solved = false;
+    h->sh_state = 1;
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uint64_t* d_xg) {
+    if (!h || !d_xg || n_ranks == 0 || rank >= n_ranks) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->sh_state != 1) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_resolve: call rio_gp_shard_scan first");
+    h->sh_rank = rank;
+    h->sh_R = n_ranks;
+    h->sh_slot = h->ring_n;
+    launch_shard_import(h->plan, real_nodes(h), shard_bufs(h), reinterpret_cast<const u64*>(d_xg), rank, n_ranks,
+                        h->sh_gprev, h->sh_gfinal, h->sh_verdict, slot_dev(h, h->ring_n), h->stream);
+    h->ring_n++;
+    h->sh_state = 2;
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_verdict(rio_gp_t* h, rio_gp_shard_info* out, uint32_t* n_slow) {
+    if (!h || !out) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->sh_state != 2) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_verdict: call rio_gp_shard_resolve first");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    uint32_t slow = 0;
+    const u32 lo = h->ring_n > (u32)kRing ? h->ring_n - kRing : 0;
+    for (u32 k = lo; k < h->ring_n; ++k) {
+        const u64* x = h->h_slots + (size_t)(k % kRing) * h->slot_rows * 8;
+        slow += (x[0] > 0 || x[1] > 0);
+    }
+    const u64* x = h->h_slots + (size_t)(h->sh_slot % kRing) * h->slot_rows * 8;
+    out->cut_nodes = x[0]; out->spill_rows = x[1]; out->local_fixup = x[2]; out->kept = x[3];
+    out->evicted = x[4]; out->claimants = x[5]; out->load_kept = x[6]; out->load_claim = x[7];
+    if (n_slow) *n_slow = slow;
+    h->sh_slow = (x[0] > 0 || x[1] > 0);
+    h->ring_n = 0;
+    if (!h->sh_slow)  // fast path: the committed `used` is the global kept + claimed load
+        HIPCHK(h, hipMemcpyAsync(h->sb.used_cur, h->sh_gfinal, (size_t)(h->m ? h->m : 1) * sizeof(u64),
+                                 hipMemcpyDeviceToDevice, h->stream));
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_cut(rio_gp_t* h, int run_local_fixup, uint64_t* d_y) {
+    if (!h || !d_y) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->sh_state != 2 || !h->sh_slow) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_cut: no fix-up pending");
+    HIPCHK(h, hipSetDevice(h->device));
+    const SolveBufs b = shard_bufs(h);
+    if (run_local_fixup) launch_cut_fixup(h->plan, real_table(h), real_nodes(h), b, false, h->stream);
+    launch_shard_export_delta(h->plan, b, h->sb.used_kept, 0, reinterpret_cast<u64*>(d_y), h->stream);
+    h->sh_state = 3;
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_merge(rio_gp_t* h, const uint64_t* d_yg, uint64_t* pending_rows, uint64_t* pending_load) {
+    if (!h || !d_yg) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->sh_state != 3 && h->sh_state != 5) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_merge: nothing exported");
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_shard_import_delta(h->plan, shard_bufs(h), reinterpret_cast<const u64*>(d_yg), h->sh_rank, h->sh_R,
+                              h->sh_gprev, h->sh_verdict, slot_dev(h, 0), h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    const u64* x = h->h_slots;
+    if (pending_rows) *pending_rows = x[0];
+    if (pending_load) *pending_load = x[1];
+    h->sh_state = 4;
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_spill(rio_gp_t* h, uint32_t round, int last, uint64_t* d_y) {
+    if (!h || !d_y) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->sh_state != 4) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_spill: call rio_gp_shard_merge first");
+    HIPCHK(h, hipSetDevice(h->device));
+    const SolveBufs b = shard_bufs(h);
+    launch_spill_round(h->plan, real_table(h), real_nodes(h), b, (int)round, last != 0, h->stream);
+    launch_shard_export_delta(h->plan, b, h->sh_gprev, (int)((round & 1) ^ 1), reinterpret_cast<u64*>(d_y), h->stream);
+    h->sh_state = 5;
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->sh_state != 2 && h->sh_state != 4)
+        return fail(h, RIO_GP_EINVAL, "rio_gp_shard_finish: solve not resolved / last exchange not merged");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+    // local row counters of this shard: fold k_resolve's per-workgroup partial rows on the host
+    std::vector<u64> part((size_t)resolve_blocks(h->m) * 8);
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->sb.partial, part.size() * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    DevStats v;
+    memset(&v, 0, sizeof v);
+    for (size_t r = 0; r < part.size() / 8; ++r) {
+        const u64* x = part.data() + r * 8;
+        v.load_kept += x[0]; v.load_claim_tot += x[1];
+        v.kept += x[3]; v.evicted += x[4]; v.claimants += x[5]; v.spillcand += x[6];
+    }
+    if (h->sh_slow) {
+        const DevStats& d = h->h_stats[0];
+        v.rejected = d.rejected; v.load_rejected = d.load_rejected;
+        v.spilled = d.spilled; v.load_spilled = d.load_spilled;
+        v.unplaced = d.unplaced; v.load_unplaced = d.load_unplaced;
+    }
+    fill_stats(v, h->n, local_stats);  // cut_nodes / slow_path / rounds_run are global: the caller has them
+    h->have_solved = true;
+    h->ring_n = 0;
+    h->sh_state = 0;
     return RIO_GP_OK;
 }
 

@@ -1,0 +1,258 @@
+"""Row-sharded whole-table solve across the GPUs of one node.
+
+One process per GPU; rank r owns the contiguous rows [off_r, off_r + n_r) of the object table
+(shard order = index order), the node table is replicated.  Rows couple only through per-node
+load vectors, so the data path has exactly one kind of exchange: an all-gather of a small u64
+record per rank (X = 2m+8 words on every solve; Y = m+2 words per fix-up step) — RCCL over xGMI
+through torch.distributed (backend "nccl" IS RCCL on ROCm), <= 64 KiB per rank, latency-bound.
+Every cross-rank reduction is an integer sum taken in rank order inside the shard kernels, so
+the composed result equals the unsharded solve (and the CPU oracle) bit for bit.
+
+This module only sequences the C-ABI phases (rio_gp_shard_*, include/rio_gpu_placement.h) and
+the collectives; it computes nothing itself and has no CPU fallback.  The engine interface is
+small on purpose: tests drive the same `ShardedSolver` with a numpy engine over gloo
+(tests/shard_engine_cpu.py) to check the protocol itself on machines without a GPU.
+
+Reference anchor: the coupling being sharded is the per-server "where do new objects go"
+decision of Service::get_or_create_placement (rio-rs/src/service.rs:193-254); the reference
+has no multi-device form of it.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import rio_gp
+
+STAT_KEYS = ("n_objects", "kept", "evicted", "claimed", "spilled", "unplaced",
+             "load_kept", "load_claimed", "load_spilled", "load_unplaced")
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("cut_nodes", "spill_rows", "local_fixup", "kept", "evicted",
+                                          "claimants", "load_kept", "load_claim")]
+
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    L = rio_gp.lib()
+    if not _ready:
+        vp = C.c_void_p
+        L.rio_gp_set_stream.argtypes = [vp, vp]
+        L.rio_gp_shard_words1.argtypes = [vp]
+        L.rio_gp_shard_words1.restype = C.c_uint32
+        L.rio_gp_shard_words2.argtypes = [vp]
+        L.rio_gp_shard_words2.restype = C.c_uint32
+        L.rio_gp_shard_scan.argtypes = [vp, vp]
+        L.rio_gp_shard_resolve.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+        L.rio_gp_shard_verdict.argtypes = [vp, C.POINTER(ShardInfo), C.POINTER(C.c_uint32)]
+        L.rio_gp_shard_cut.argtypes = [vp, C.c_int, vp]
+        L.rio_gp_shard_merge.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.rio_gp_shard_spill.argtypes = [vp, C.c_uint32, C.c_int, vp]
+        L.rio_gp_shard_finish.argtypes = [vp, C.POINTER(rio_gp.Stats)]
+        _ready = True
+    return L
+
+
+class HipShardEngine:
+    """One rank's shard: a rio_gp handle whose calls are enqueued on a torch stream, so that the
+    RCCL all-gather torch.distributed issues is ordered against the kernels on the device (no host
+    synchronisation on the fast path)."""
+
+    def __init__(self, placement, device=0, stream=None):
+        self.g = placement
+        self.device = torch.device("cuda", device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
+        self.g._chk(_lib().rio_gp_set_stream(self.g.handle, C.c_void_p(self.stream.cuda_stream)))
+        self.m = self.g.num_nodes
+        self.words1 = int(_lib().rio_gp_shard_words1(self.g.handle))
+        self.words2 = int(_lib().rio_gp_shard_words2(self.g.handle))
+
+    def ctx(self):
+        return torch.cuda.stream(self.stream)
+
+    def new_buffer(self, words):
+        with self.ctx():
+            return torch.zeros(int(words), dtype=torch.int64, device=self.device)
+
+    def scan(self, x):
+        self.g._chk(_lib().rio_gp_shard_scan(self.g.handle, C.c_void_p(x.data_ptr())))
+
+    def resolve(self, rank, n_ranks, xg):
+        self.g._chk(_lib().rio_gp_shard_resolve(self.g.handle, rank, n_ranks, C.c_void_p(xg.data_ptr())))
+
+    def verdict(self):
+        info, ns = ShardInfo(), C.c_uint32(0)
+        self.g._chk(_lib().rio_gp_shard_verdict(self.g.handle, C.byref(info), C.byref(ns)))
+        d = {k: int(getattr(info, k)) for k, _ in ShardInfo._fields_}
+        d["n_slow"] = int(ns.value)
+        return d
+
+    def cut(self, run_local_fixup, y):
+        self.g._chk(_lib().rio_gp_shard_cut(self.g.handle, int(bool(run_local_fixup)), C.c_void_p(y.data_ptr())))
+
+    def merge(self, yg):
+        rows, load = C.c_uint64(0), C.c_uint64(0)
+        self.g._chk(_lib().rio_gp_shard_merge(self.g.handle, C.c_void_p(yg.data_ptr()), C.byref(rows), C.byref(load)))
+        return int(rows.value), int(load.value)
+
+    def spill(self, rnd, last, y):
+        self.g._chk(_lib().rio_gp_shard_spill(self.g.handle, rnd, int(bool(last)), C.c_void_p(y.data_ptr())))
+
+    def finish(self):
+        st = rio_gp.Stats()
+        self.g._chk(_lib().rio_gp_shard_finish(self.g.handle, C.byref(st)))
+        return st.as_dict()
+
+    def commit(self):
+        self.g.commit()
+
+    def sync(self):
+        self.g.sync()
+
+
+class DistExchange:
+    """The data path's only collective: all-gather of one small record per rank through
+    torch.distributed ("nccl" = RCCL over xGMI on GPUs; "gloo" in the CPU tests)."""
+
+    def __init__(self, group=None, stage_through_host=False):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        # gloo cannot all-gather device tensors: tests that run several HIP shards as separate processes on ONE
+        # GPU bounce the record through host memory (never the bench path)
+        self.stage = stage_through_host
+
+    def ranks(self, n_local):
+        if n_local != 1:
+            raise ValueError("one shard per process")
+        return [self.rank]
+
+    def all_gather(self, parts):
+        inp = parts[0]
+        out = torch.empty(self.world * inp.numel(), dtype=inp.dtype, device=inp.device)
+        return self.all_gather_into(out, parts)
+
+    def all_gather_into(self, out, parts):
+        if self.stage and out.is_cuda:
+            h_in = parts[0].cpu()  # synchronises with the producing stream
+            h_out = torch.empty(out.numel(), dtype=out.dtype)
+            self.dist.all_gather_into_tensor(h_out, h_in, group=self.group)
+            out.copy_(h_out)
+            return out
+        self.dist.all_gather_into_tensor(out, parts[0], group=self.group)
+        return out
+
+
+class LocalExchange:
+    """G shards driven by ONE process on one device (tests, single-GPU what-if runs): the "all-gather" is
+    a concatenation in rank order — the same records, the same reduction order."""
+
+    def __init__(self, n_shards):
+        self.world = n_shards
+        self.rank = 0
+
+    def ranks(self, n_local):
+        if n_local != self.world:
+            raise ValueError("LocalExchange drives all shards")
+        return list(range(self.world))
+
+    def all_gather(self, parts):
+        return torch.cat(list(parts))
+
+    def all_gather_into(self, out, parts):
+        torch.cat(list(parts), out=out)
+        return out
+
+
+class ShardedSolver:
+    """Sequences the phases of one row-sharded solve over this process's engines (normally one)."""
+
+    def __init__(self, engines, exchange, spill_rounds=2):
+        self.engines = list(engines)
+        self.ex = exchange
+        self.ranks = exchange.ranks(len(self.engines))
+        self.R = exchange.world
+        self.rounds = spill_rounds
+        e0 = self.engines[0]
+        self.X = [e.new_buffer(e.words1) for e in self.engines]
+        self.Y = [e.new_buffer(e.words2) for e in self.engines]
+        self.S = [e.new_buffer(len(STAT_KEYS)) for e in self.engines]
+        self._ctx = getattr(e0, "ctx", None)
+        # ring of gathered-X buffers for back-to-back asynchronous solves (bench)
+        self.XG = [e0.new_buffer(self.R * e0.words1) for _ in range(4)]
+        self._k = 0
+
+    def _gather(self, parts, out=None):
+        if self._ctx is not None:
+            with self._ctx():
+                return self.ex.all_gather(parts) if out is None else self.ex.all_gather_into(out, parts)
+        return self.ex.all_gather(parts) if out is None else self.ex.all_gather_into(out, parts)
+
+    def _copy_in(self, dst, src):
+        if self._ctx is not None:
+            with self._ctx():
+                dst.copy_(src)
+        else:
+            dst.copy_(src)
+
+    # -- fast path, asynchronous: scan -> all-gather X -> resolve; nothing waits on the host --
+    def solve_async(self):
+        xg = self.XG[self._k % len(self.XG)]
+        self._k += 1
+        for e, x in zip(self.engines, self.X):
+            e.scan(x)
+        self._gather(self.X, out=xg)
+        for e, r in zip(self.engines, self.ranks):
+            e.resolve(r, self.R, xg)
+
+    # -- finish the LAST enqueued solve: verdict, fix-up exchanges if it needs them, global stats --
+    def solve_wait(self):
+        vs = [e.verdict() for e in self.engines]
+        v = vs[0]
+        slow = v["cut_nodes"] > 0 or v["spill_rows"] > 0
+        rounds_run = 0
+        if slow:
+            for e, y, ve in zip(self.engines, self.Y, vs):
+                e.cut(ve["local_fixup"] > 0 and v["cut_nodes"] > 0, y)
+            yg = self._gather(self.Y)
+            pend = [e.merge(yg) for e in self.engines][0]
+            for r in range(self.rounds):
+                if pend[0] == 0:
+                    break
+                rounds_run += 1
+                for e, y in zip(self.engines, self.Y):
+                    e.spill(r, r + 1 == self.rounds, y)
+                yg = self._gather(self.Y)
+                pend = [e.merge(yg) for e in self.engines][0]
+        local = [e.finish() for e in self.engines]
+        for s_t, st in zip(self.S, local):
+            self._copy_in(s_t, torch.tensor([st[k] for k in STAT_KEYS], dtype=torch.int64))
+        sg = self._gather(self.S).cpu().numpy().reshape(self.R, len(STAT_KEYS))
+        tot = sg.astype(np.uint64).sum(axis=0)
+        stats = {k: int(tot[i]) for i, k in enumerate(STAT_KEYS)}
+        stats.update(cut_nodes=v["cut_nodes"], slow_path=int(slow), rounds_run=rounds_run)
+        return stats, v["n_slow"]
+
+    def solve(self):
+        self.solve_async()
+        return self.solve_wait()[0]
+
+    def commit(self):
+        for e in self.engines:
+            e.commit()
+
+    def tick(self):
+        st = self.solve()
+        self.commit()
+        return st
+
+
+def shard_bounds(n, n_ranks):
+    """Contiguous, balanced row blocks: rank r owns [b[r], b[r+1])."""
+    return [(r * n) // n_ranks for r in range(n_ranks + 1)]

@@ -1,0 +1,170 @@
+"""Row-sharded solve on the GPU: the HIP shard phases (rio_gp_shard_*), sequenced by the same
+ShardedSolver the multi-GPU bench uses, against the whole-table CPU oracle — bit-exact.  One MI355X is
+enough: G shards = G handles on the device (LocalExchange), a world_size-1 RCCL group (DistExchange,
+"nccl"), and two PROCESSES sharing the GPU over gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NONE = 0xFFFFFFFF
+INF = 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def gp():
+    import rio_gp
+    rio_gp.build()
+    return rio_gp
+
+
+def make_engines(gp, case, bounds, rounds=2, stream=None):
+    import torch
+    import sharded
+    cur, load, aff, cap, alive = case
+    stream = stream or torch.cuda.Stream(torch.device("cuda", 0))
+    engines = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        n = hi - lo
+        g = gp.GpuPlacement(max(n, 1), max(len(cap), 1), spill_rounds=rounds)
+        g.set_nodes(cap, alive, m=len(cap))
+        g.set_objects(n, load[lo:hi], aff[lo:hi])
+        if n:
+            g.set_assign(cur[lo:hi])
+        engines.append(sharded.HipShardEngine(g, 0, stream))
+    return engines
+
+
+def check(gp, oracle, case, bounds, rounds=2):
+    import sharded
+    engines = make_engines(gp, case, bounds, rounds)
+    sol = sharded.ShardedSolver(engines, sharded.LocalExchange(len(engines)), spill_rounds=rounds)
+    st = sol.solve()
+    got = np.concatenate([e.g.get_solved() if e.g.num_objects else np.zeros(0, np.uint32) for e in engines])
+    want, used, ost = oracle.tick(*case, rounds)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert st == ost
+    sol.commit()
+    for e in engines:
+        assert np.array_equal(e.g.get_nodes()[2], used)  # every rank holds the GLOBAL used vector
+        e.g.close()
+    return ost
+
+
+def cases():
+    from test_sharded_protocol import CASES, random_case
+    return [random_case(100 + i, **kw) for i, kw in enumerate(CASES)]
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_hip_shards_equal_whole_table_oracle(gp, oracle, G):
+    import sharded
+    for case in cases():
+        check(gp, oracle, case, sharded.shard_bounds(len(case[0]), G))
+
+
+def test_hip_ragged_and_empty_shards(gp, oracle):
+    from test_sharded_protocol import random_case
+    case = random_case(7, n=3000, m=12, cap_scale=0.85, dead_frac=0.1, zero_load=0.1)
+    for bounds in ([0, 0, 1, 1, 2999, 3000, 3000], [0, 1500, 1500, 3000], [0, 7, 2000, 2001, 3000]):
+        check(gp, oracle, case, bounds)
+
+
+@pytest.mark.parametrize("rounds", [1, 4])
+def test_hip_shard_spill_rounds(gp, oracle, rounds):
+    from test_sharded_protocol import random_case
+    import sharded
+    case = random_case(11, n=50_000, m=20, cap_scale=0.95, dead_frac=0.15)
+    check(gp, oracle, case, sharded.shard_bounds(50_000, 4), rounds)
+
+
+def test_hip_shards_config3_shape(gp, oracle):
+    import sharded
+    cfg = synth.config("c3", n_override=2_000_000)
+    case = (cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
+    st = check(gp, oracle, case, sharded.shard_bounds(cfg["n"], 8))
+    assert st["slow_path"] == 0
+    # the same table squeezed: hundreds of cut nodes, forced nodes on the upper ranks, spill, unplaced rows
+    cap = (cfg["cap"] * np.uint64(9)) // np.uint64(10)
+    alive = cfg["alive"].copy()
+    alive[3::17] = 0
+    st = check(gp, oracle, (synth.warm_assign(cfg["n"], cfg["m"]), cfg["load"], cfg["aff"], cap, alive),
+               sharded.shard_bounds(cfg["n"], 8))
+    assert st["cut_nodes"] > 0 and st["evicted"] > 0
+
+
+def test_hip_shard_rccl_world1_async(gp, oracle):
+    """The bench's path: DistExchange over "nccl" (= RCCL), kernels and collective ordered on one torch stream,
+    several solves in flight, one verdict read at the end."""
+    import torch
+    import torch.distributed as dist
+    import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = synth.config("c3", n_override=1_000_000)
+        case = (cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"] * np.uint64(2), cfg["alive"])
+        engines = make_engines(gp, case, [0, cfg["n"]])
+        sol = sharded.ShardedSolver(engines, sharded.DistExchange())
+        for _ in range(6):
+            sol.solve_async()
+        st, n_slow = sol.solve_wait()
+        want, used, ost = oracle.tick(*case, 2)
+        assert n_slow == 0 and st == ost
+        assert np.array_equal(engines[0].g.get_solved(), want)
+        sol.commit()
+        assert np.array_equal(engines[0].g.get_nodes()[2], used)
+        engines[0].g.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _proc(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import rio_gp
+    import sharded
+    from test_sharded_protocol import random_case
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        case = random_case(31, n=200_000, m=48, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
+        b = sharded.shard_bounds(len(case[0]), world)
+        eng = make_engines(rio_gp, case, [b[rank], b[rank + 1]])[0]
+        sol = sharded.ShardedSolver([eng], sharded.DistExchange(stage_through_host=True))
+        st = sol.tick()
+        np.savez(os.path.join(out_dir, "g%d.npz" % rank), a=eng.g.get_assign(), used=eng.g.get_nodes()[2],
+                 st=np.array([st[k] for k in sorted(st)], np.uint64))
+        eng.g.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hip_shards_two_processes_one_gpu(gp, oracle, tmp_path):
+    import torch.multiprocessing as mp
+    from test_sharded_protocol import random_case
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_proc, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    case = random_case(31, n=200_000, m=48, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
+    want, used, ost = oracle.tick(*case, 2)
+    parts = [np.load(os.path.join(str(tmp_path), "g%d.npz" % r)) for r in range(2)]
+    assert np.array_equal(np.concatenate([z["a"] for z in parts]), want)
+    for z in parts:
+        assert np.array_equal(z["used"], used)
+        assert [int(v) for v in z["st"]] == [ost[k] for k in sorted(ost)]
