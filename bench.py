@@ -35,6 +35,12 @@ def parse():
     ap.add_argument("--workload", default="c3", help="c3 (headline) | c3w | c2 | c4shard")
     ap.add_argument("--objects", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="p2p", choices=("p2p", "native", "torch"),
+                    help="sharded runs: how the per-rank load records travel — p2p: stores into the peers' HBM windows over "
+                         "xGMI, no collective call; native: ncclAllGather issued by the library; torch: torch.distributed "
+                         "all_gather.  Falls back p2p -> native -> torch if a path cannot be set up")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="sharded runs: keep the all-gather on the scan stream (no overlap with the next solve's scan)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 only: run the row-sharded path (RCCL group of one rank) to price its extra kernels and launches")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
@@ -80,6 +86,11 @@ def cpu_baseline(cfg, sample):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON: libraries that write to C stdout (RCCL prints a version banner from
+    # every rank) are pointed at stderr for the whole run; fd 1 is restored only for rank 0's final print
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,25 +128,51 @@ def main():
     if a.workload == "c3w":
         g.set_assign(cfg["cur"])
 
-    if dist is None:
-        step, wait = g.solve_async, g.solve_wait
-    else:
-        # row-sharded solve: k_scan + local sums -> RCCL all-gather of the (2m+8)-word record -> global resolve,
-        # all ordered on one stream; the verdicts are read once at the end, as at N=1
-        import sharded
-        sol = sharded.ShardedSolver([sharded.HipShardEngine(g, local_rank)], sharded.DistExchange(), spill_rounds=2)
-        step, wait = sol.solve_async, sol.solve_wait
-
     def barrier():
         if dist is not None:
             dist.barrier()
         g.sync()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    if a.warmup:
-        st, n_slow = wait()
+    if dist is None:
+        step, wait = g.solve_async, g.solve_wait
+        for _ in range(a.warmup):
+            step()
+        if a.warmup:
+            st, n_slow = wait()
+    else:
+        # row-sharded solve: k_scan -> exchange of the (2m+8)-word record -> global resolve; the verdicts are read once
+        # at the end, as at N=1.  Exchange ladder p2p -> native -> torch: a path that cannot be set up, or whose warm-up
+        # fails on ANY rank (agreed through an all-reduce), is dropped for the next one on EVERY rank.
+        import sharded
+        eng = sharded.HipShardEngine(g, local_rank)
+        ladder = ["p2p", "native", "torch"]
+        ladder = ladder[ladder.index(a.exchange):]
+        sol = None
+        for kind in ladder:
+            ok, ex, why = 1, None, ""
+            try:
+                ex = {"p2p": sharded.P2PExchange, "native": sharded.NativeRcclExchange}[kind](eng) if kind != "torch" \
+                    else sharded.DistExchange()
+                sol = sharded.ShardedSolver([eng], ex, spill_rounds=2, pipeline=(kind == "torch" and not a.no_pipeline))
+                for _ in range(max(a.warmup, 2)):
+                    sol.solve_async()
+                st, n_slow = sol.solve_wait()
+            except Exception as e:  # set-up failure raises on every rank; a warm-up failure may be local
+                ok, why = 0, str(e)
+            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                a.exchange = kind
+                break
+            print("rank %d: exchange '%s' dropped (%s)" % (rank, kind, why or "failed on another rank"), file=sys.stderr)
+            if kind == "p2p" and ex is not None:
+                ex.close()
+            sol = None
+        if sol is None:
+            raise SystemExit("no exchange path could be set up")
+        step, wait = sol.solve_async, sol.solve_wait
+
     barrier()
     t0 = time.perf_counter()
     g.timer_begin()
@@ -185,9 +222,13 @@ def main():
         "config": {"workload": "config 3: %d objects x %d nodes per GPU, Zipf(1.1) load, cap 1.25x, cold start "
                                "(all pending)" % (n, m) if a.workload == "c3" else a.workload,
                    "objects_per_gpu": n, "nodes": m, "parallelism": "rows sharded x%d" % world,
-                   "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end" if world == 1
+                   "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end" if dist is None
                            else "row-sharded solve: k_scan + k_resolve + pack -> RCCL all-gather of %d B/rank -> k_shard_import, "
-                                "one stream; verdicts read at the end" % (8 * (2 * m + 8)),
+                                "%s; verdicts read at the end; collective issued by %s" % (
+                                    8 * (2 * m + 8), "one stream" if (a.no_pipeline and a.exchange == "torch") else
+                                    "exchange + import on a second stream, overlapping the next solve's scan",
+                                    {"p2p": "nobody: peer-to-peer stores into the peers' windows + sequence flags, one stream",
+                                     "native": "the library (ncclAllGather)", "torch": "torch.distributed"}[a.exchange]),
                    "slow_path_steps": n_slow},
         "gpu_ms_per_step_events": gpu_ms / a.steps,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -203,7 +244,14 @@ def main():
     }
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -224,8 +224,10 @@ uint32_t rio_gp_shard_words1(rio_gp_t* h);
 uint32_t rio_gp_shard_words2(rio_gp_t* h);
 /* k_scan + local column sums; d_x[words1] = this rank's X record.  Asynchronous. */
 int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x);
-/* d_xg[n_ranks][words1] = the all-gathered X records.  Asynchronous. */
-int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uint64_t* d_xg);
+/* d_xg[n_ranks][words1] = the all-gathered X records.  Asynchronous.  on_stream (hipStream_t, may be NULL = the
+ * handle's stream): a host that pipelines independent solves runs the exchange and this step on a second stream,
+ * ordered after rio_gp_shard_scan by its own event, so the all-gather overlaps the next solve's scan. */
+int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uint64_t* d_xg, void* on_stream);
 /* Waits for the stream; global verdict of the LAST resolve; *n_slow = how many of the resolves enqueued
  * since the last verdict need the fix-up. */
 int rio_gp_shard_verdict(rio_gp_t* h, rio_gp_shard_info* out, uint32_t* n_slow);
@@ -239,6 +241,32 @@ int rio_gp_shard_spill(rio_gp_t* h, uint32_t round, int last, uint64_t* d_y);
 /* Local counters of this rank's rows (sum them over ranks; cut_nodes/slow_path/rounds_run are global
  * quantities the caller already holds).  After this, rio_gp_commit / rio_gp_get_solved work as usual. */
 int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats);
+
+/* Preferred on one node: peer-to-peer exchange over xGMI with no collective call at all.  Every rank exports an
+ * uncached window (rio_gp_shard_p2p_export -> 64-byte hipIpcMemHandle_t), the host all-gathers the handles over its
+ * control channel, every rank maps its peers' windows (rio_gp_shard_p2p_connect; ends with a handshake and fails
+ * with RIO_GP_EUPSTREAM if a peer's store does not become visible within 3 s — fall back to RCCL then).  After that
+ * rio_gp_shard_solve_async and rio_gp_shard_exchange store each record straight into the peers' HBM and the
+ * consuming kernel waits on sequence flags: one stream, five launches, no host involvement.  All ranks must call
+ * export/connect/solve/exchange collectively and in the same order. */
+int rio_gp_shard_p2p_export(rio_gp_t* h, uint32_t n_ranks, void* out_handle64);
+int rio_gp_shard_p2p_connect(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const void* handles /* [n_ranks][64] */);
+int rio_gp_shard_p2p_ready(rio_gp_t* h);
+/* Unmap the peers' windows and free ours (e.g. to fall back to RCCL after a time-out). */
+int rio_gp_shard_p2p_close(rio_gp_t* h);
+
+/* Optional: let the library issue the all-gathers itself through RCCL (resolved at run time with dlopen — the
+ * copy already in the process, else librccl.so.1; `rccl_path` may name one, NULL = default search).  The host only
+ * moves the 128-byte ncclUniqueId from rank 0 to the other ranks over its own control channel:
+ *   rank 0: rio_gp_shard_comm_unique_id(id);  all ranks: rio_gp_shard_comm_init(h, rank, n_ranks, id).
+ * rio_gp_shard_solve_async = scan -> all-gather X -> resolve in ONE call, the exchange on a second stream so that
+ * back-to-back independent solves overlap it with the next scan; follow with rio_gp_shard_verdict / _finish (or the
+ * fix-up calls, using rio_gp_shard_exchange for the Y records) exactly as above. */
+int rio_gp_shard_comm_unique_id(void* out128, const char* rccl_path);
+int rio_gp_shard_comm_init(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const void* id128, const char* rccl_path);
+uint32_t rio_gp_shard_comm_ranks(rio_gp_t* h);
+int rio_gp_shard_solve_async(rio_gp_t* h);
+int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, uint64_t words_per_rank);
 
 /* ---- measurement hooks (HIP events on the handle's own stream) -------------------------- */
 int rio_gp_timer_begin(rio_gp_t* h);

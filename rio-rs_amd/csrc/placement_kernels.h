@@ -42,7 +42,7 @@ struct DevStats {
     u64 load_kept, load_claim_tot, n_cut;               // k_resolve
     u64 rejected, load_rejected;                        // k_apply_cut
     u64 spilled, load_spilled, unplaced, load_unplaced; // k_spill_apply
-    u64 rounds_run;                                     // k_spill_prepare
+    u64 rounds_run;                                     // k_spill_rank
     u64 evicted_clean;                                  // k_clean
     u64 err;                                            // invalid entries seen by batch kernels
 };
@@ -63,13 +63,14 @@ struct SolveBufs {
     u64* admpre;     // [m] claim load admitted before the cut block
     u32* cutidx;     // [m] row index of the first rejected claimant or kNoCut
     u64* T;          // [m][kMaxSubs] claim load per sub-chunk of the node's cut block
-    u64* wfC;        // [m+1] cumulative free capacity in water-fill order (saturating)
+    u64* wfC;        // [m+1] free capacity by water-fill rank (k_spill_apply rebuilds the saturating cumulative)
     u32* wfOrder;    // [m]
-    u32* wfCnt;      // [1]
+    u32* wfCnt;      // [2] ranked nodes | round has work
     // row-sharded solve only (nullptr otherwise): nodes whose claim prefix overflowed on a lower rank, and the
     // spill load pending on lower ranks
     u32* forced_bits;        // [mwords]
     u64* rank_base;          // [1]
+    const u64* pending_global;  // [1] rows still pending on ALL ranks (k_shard_import_delta), nullptr = local count
     DevStats* stats;
 };
 
@@ -131,8 +132,19 @@ size_t scan_lds_bytes(u32 m);
 inline size_t shard_words1(u32 m) { return 2 * (size_t)m + 8; }  // X = [kept_local[m] | claim_local[m] | 8 counters]
 inline size_t shard_words2(u32 m) { return (size_t)m + 2; }      // Y = [delta[m] | spill load | spill rows]
 void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s);
+// row_stride: u64 words between two ranks' records in Xg (0 = packed, shard_words1(m)); wait_flags != nullptr: Xg is
+// this rank's peer-to-peer window and the kernel first waits for every rank's flag == seq (p2p_err set on time-out)
 void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, const u64* Xg, u32 rank, u32 R,
-                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s);
+                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s,
+                         size_t row_stride = 0, const u64* wait_flags = nullptr, u64 seq = 0, u64* p2p_err = nullptr);
+// peer-to-peer all-gather over xGMI: store `words` of src + the flag `seq` into every peer's window; wait + copy out
+// k_resolve + pack + put in one kernel (peer-to-peer windows, R <= 32): local sums into every peer's window, flag last
+void launch_resolve_put(const Plan& p, const SolveBufs& b, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off,
+                        u64 seq, unsigned int* counter, hipStream_t s);
+void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off, u64 seq,
+                    hipStream_t s);
+void launch_p2p_wait_copy(const u64* win_slot, size_t W, u32 R, u32 words, const u64* flags, u64 seq, u64* err, u64* out,
+                          hipStream_t s);
 void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s);
 void launch_shard_import_delta(const Plan& p, const SolveBufs& b, const u64* Yg, u32 rank, u32 R, u64* gprev,
                                u64* verdict_dev, u64* verdict_host, hipStream_t s);

@@ -470,10 +470,26 @@ __global__ __launch_bounds__(kBlock) void k_cut_subhist(const u32* __restrict__ 
         const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
         const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
         const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
-        const u32 t = (u32)((i0 - bstart) / p.sub);  // 4 consecutive rows share a sub-chunk (sub % 256 == 0)
-#define RIOGP_ROW(C, A, L, E)                                                                   \
-        if (i0 + E < wend && classify<VIRT>(C, A, m, alv) == 1 && cb[A] == blockIdx.x)           \
-            atomicAdd(&T[(size_t)A * kMaxSubs + t], (u64)L);
+        // a tile (256 rows) lies inside ONE sub-chunk (sub % 256 == 0): aggregate per node across the wave
+        // before touching T, so a hot node costs one global atomic per tile instead of one per row
+        const u32 t = (u32)((it - bstart) / p.sub);
+#define RIOGP_ROW(C, A, L, E)                                                                              \
+        {                                                                                                  \
+            const bool hit = i0 + E < wend && classify<VIRT>(C, A, m, alv) == 1 && cb[A] == blockIdx.x;     \
+            u64 todo = __ballot(hit);                                                                      \
+            if (__popcll(todo) <= 8) {                                                                     \
+                if (hit) atomicAdd(&T[(size_t)A * kMaxSubs + t], (u64)L);                                  \
+                todo = 0;                                                                                  \
+            }                                                                                              \
+            while (todo) {                                                                                 \
+                const int ld = __ffsll((long long)todo) - 1;                                               \
+                const u32 nd = (u32)__shfl((int)A, ld, 64);                                                \
+                const bool same = hit && A == nd;                                                          \
+                const u64 sum = wave_sum(same ? (u64)L : 0ull);                                            \
+                if (lane == ld) atomicAdd(&T[(size_t)nd * kMaxSubs + t], sum);                             \
+                todo &= ~__ballot(same);                                                                   \
+            }                                                                                              \
+        }
         RIOGP_ROW(cv.x, av.x, lv.x, 0)
         RIOGP_ROW(cv.y, av.y, lv.y, 1)
         RIOGP_ROW(cv.z, av.z, lv.z, 2)
@@ -616,8 +632,12 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
 }
 
 // ------------------------------------------------------------------------------------------------
-// KS  k_spill_prepare — one workgroup: free capacity per node, rank nodes by (free desc, index asc),
-//     saturating cumulative free C[], and the exclusive prefix of the per-wave spill totals.
+// KS  k_spill_rank — per round: free capacity per node, rank of every node in the total order
+//     (free desc, index asc) by counting, and the exclusive prefix of the per-wave spill totals.
+//     Ranking is m^2 wave-uniform LDS reads: ONE workgroup is bound by a single CU's LDS port
+//     (measured 48 us at m = 1024), so it is spread over m/64 workgroups: each recomputes free[] in
+//     its LDS (m loads) and ranks 64 nodes, thread = (node, 1/16 of the k range).  The saturating
+//     cumulative C[] is rebuilt from the ranked free values in k_spill_apply's prologue.
 // ------------------------------------------------------------------------------------------------
 __device__ u64 block_excl_scan_1024(u64 v, bool saturating, u64* lds_part /*[16]*/, u64* total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -644,25 +664,30 @@ __device__ u64 block_excl_scan_1024(u64 v, bool saturating, u64* lds_part /*[16]
     return excl;
 }
 
-__global__ __launch_bounds__(kBlock) void k_spill_prepare(Plan p, const u64* __restrict__ cap,
-                                                          const u32* __restrict__ alive_bits,
-                                                          const u64* __restrict__ used_cur,
-                                                          const u64* __restrict__ wsp_sum,
-                                                          const u32* __restrict__ wsp_cnt,
-                                                          u64* __restrict__ wsp_base, u64* __restrict__ wfC,
-                                                          u32* __restrict__ wfOrder, u32* __restrict__ wfCnt,
-                                                          const u64* __restrict__ rank_base,
-                                                          DevStats* __restrict__ stats) {
+constexpr int kRankNodes = 64;
+
+__global__ __launch_bounds__(kBlock) void k_spill_rank(Plan p, const u64* __restrict__ cap,
+                                                       const u32* __restrict__ alive_bits,
+                                                       const u64* __restrict__ used_cur,
+                                                       const u64* __restrict__ wsp_sum,
+                                                       const u32* __restrict__ wsp_cnt,
+                                                       u64* __restrict__ wsp_base, u64* __restrict__ wfFree,
+                                                       u32* __restrict__ wfOrder, u32* __restrict__ wfCnt,
+                                                       const u64* __restrict__ rank_base,
+                                                       const u64* __restrict__ pending_global,
+                                                       DevStats* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     const u32 mp = (m + kBlock - 1) / kBlock * kBlock;  // padded
     u64* part = reinterpret_cast<u64*>(smem);                  // [16]
     u32& nz_total = *reinterpret_cast<u32*>(smem + 128);
     u32& cnt_total = *reinterpret_cast<u32*>(smem + 132);
-    u64* fre = reinterpret_cast<u64*>(smem + 2 * kSmall);      // [mp] free by node
-    u64* sfr = fre + mp;                                        // [mp] free by rank
-    const int tid = threadIdx.x;
+    u32* rk = reinterpret_cast<u32*>(smem + 2 * kSmall);       // [64] rank accumulators of this block's nodes
+    u64* fre = reinterpret_cast<u64*>(smem + 2 * kSmall + 256);  // [mp] free by node
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { nz_total = 0; cnt_total = 0; }
+    if (tid < kRankNodes) rk[tid] = 0;
+    u32 nz = 0;
     for (u32 j = tid; j < mp; j += kBlock) {
         u64 f = 0;
         if (j < m) {
@@ -670,60 +695,62 @@ __global__ __launch_bounds__(kBlock) void k_spill_prepare(Plan p, const u64* __r
             f = (bit_of(alive_bits, j) && c > u) ? c - u : 0;
         }
         fre[j] = f;
-        sfr[j] = 0;
+        nz += f != 0;
     }
-    __syncthreads();
-    // rank by counting: unique total order (free desc, index asc)
-    u32 nz = 0;
-    for (u32 j = tid; j < m; j += kBlock) {
-        const u64 f = fre[j];
-        if (f == 0) continue;
-        u32 rank = 0;
-        for (u32 k = 0; k < m; ++k) {
-            const u64 g = fre[k];
-            rank += (g > f) || (g == f && k < j);
-        }
-        sfr[rank] = f;
-        wfOrder[rank] = j;
-        ++nz;
-    }
-    nz = wave_sum32(nz);
-    if ((tid & 63) == 0 && nz) atomicAdd(&nz_total, nz);
-    __syncthreads();
-    // saturating inclusive scan over ranks: each thread owns mp/1024 consecutive ranks
-    const u32 per = mp / kBlock;
-    u64 loc = 0;
-    for (u32 q = 0; q < per; ++q) loc = sat_add(loc, sfr[tid * per + q]);
-    u64 excl = block_excl_scan_1024(loc, true, part, nullptr);
-    if (tid == 0) { wfC[0] = 0; *wfCnt = nz_total; }
-    for (u32 q = 0; q < per; ++q) {
-        const u32 rk = tid * per + q;
-        excl = sat_add(excl, sfr[rk]);
-        if (rk < m) wfC[rk + 1] = excl;
-    }
-    // exclusive prefix of spill load over wave ranges (index order) + remaining row count
+    // rows still pending: sum of the per-wave counts (every block needs the verdict; block 0 also the prefix)
     const u32 nw = p.G * kWaves;  // <= 4096 = 4 per thread
     u64 v[4], s = 0;
     u32 cnt = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const u32 w = tid * 4 + q;
-        v[q] = w < nw ? wsp_sum[w] : 0;
+        v[q] = (w < nw && blockIdx.x == 0) ? wsp_sum[w] : 0;
         cnt += w < nw ? wsp_cnt[w] : 0;
         s += v[q];
     }
-    u64 ex = block_excl_scan_1024(s, false, part, nullptr);
-    if (rank_base) ex += *rank_base;  // row-sharded solve: spill load of every lower rank comes first
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32 w = tid * 4 + q;
-        if (w < nw) wsp_base[w] = ex;
-        ex += v[q];
-    }
+    u64 ex = block_excl_scan_1024(s, false, part, nullptr);  // its barriers also publish fre[] / the zeroed counters
     cnt = wave_sum32(cnt);
-    if ((tid & 63) == 0 && cnt) atomicAdd(&cnt_total, cnt);
+    nz = wave_sum32(nz);
+    if (lane == 0) {
+        if (cnt) atomicAdd(&cnt_total, cnt);
+        if (nz) atomicAdd(&nz_total, nz);
+    }
     __syncthreads();
-    if (tid == 0 && cnt_total) stats->rounds_run += 1;
+    // row-sharded solve: "pending" is a global fact (k_shard_import_delta), else the local count
+    const bool pending = pending_global ? (*pending_global != 0) : (cnt_total != 0);
+    if (blockIdx.x == 0) {
+        if (rank_base) ex += *rank_base;  // spill load of every lower rank comes first
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 w = tid * 4 + q;
+            if (w < nw) wsp_base[w] = ex;
+            ex += v[q];
+        }
+        if (tid == 0) {
+            wfCnt[0] = pending ? nz_total : 0;
+            wfCnt[1] = pending ? 1 : 0;  // 0: k_spill_apply returns at once
+            if (pending) stats->rounds_run += 1;
+        }
+    }
+    if (!pending) return;
+    // rank of node j = #{k : free[k] > free[j] or (free[k] == free[j] and k < j)}; lane = node, wave = k range
+    const u32 j = blockIdx.x * kRankNodes + lane;
+    const u64 f = j < m ? fre[j] : 0;
+    const u32 per = mp / kWaves;  // multiple of 64
+    u32 r = 0;
+    for (u32 k0 = wave * per; k0 < (wave + 1) * per; k0 += 8) {
+        u64 g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[q] = fre[k0 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r += (g[q] > f) || (g[q] == f && k0 + q < j);
+    }
+    if (f != 0) atomicAdd(&rk[lane], r);
+    __syncthreads();
+    if (tid < kRankNodes && f != 0) {
+        wfFree[rk[tid]] = f;
+        wfOrder[rk[tid]] = j;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -732,18 +759,42 @@ __global__ __launch_bounds__(kBlock) void k_spill_prepare(Plan p, const u64* __r
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ load, u32* __restrict__ next, Plan p,
                                                         const u64* __restrict__ wsp_base,
-                                                        const u64* __restrict__ wfC, const u32* __restrict__ wfOrder,
+                                                        const u64* __restrict__ wfC /* free by rank */, const u32* __restrict__ wfOrder,
                                                         const u32* __restrict__ wfCnt, u64* __restrict__ used_cur,
+                                                        const u32* __restrict__ wsp_cnt_in,
                                                         u64* __restrict__ wsp_sum_out, u32* __restrict__ wsp_cnt_out,
                                                         int last, DevStats* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
-    u64* red = reinterpret_cast<u64*>(smem);           // [4]
-    u64* C = reinterpret_cast<u64*>(smem + kSmall);    // [m+1]
-    u64* adm = C + (m + 1);                            // [m] admitted load by node (this block)
+    u64* red = reinterpret_cast<u64*>(smem);               // [4]
+    u64* part = reinterpret_cast<u64*>(smem + kSmall);     // [16] block-scan partials
+    u64* C = reinterpret_cast<u64*>(smem + 2 * kSmall);    // [m+1]
+    u64* adm = C + (m + 1);                                // [m] admitted load by node (this block)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wfCnt[1] == 0) {  // nothing pending anywhere (k_spill_prepare): the round is a no-op
+        if (lane == 0) {
+            const u64 gw0 = (u64)blockIdx.x * kWaves + wave;
+            wsp_sum_out[gw0] = 0;
+            wsp_cnt_out[gw0] = 0;
+        }
+        return;
+    }
     const u32 cnt = *wfCnt;
-    for (u32 k = tid; k <= m; k += kBlock) C[k] = k <= cnt ? wfC[k] : ~0ull;
+    {   // C[0] = 0, C[k+1] = sat(C[k] + free of rank k): saturating block scan of the ranked free values
+        const u32 mp = (m + kBlock - 1) / kBlock * kBlock, per = mp / kBlock;
+        u64 loc = 0;
+        for (u32 q = 0; q < per; ++q) {
+            const u32 k = tid * per + q;
+            loc = sat_add(loc, k < cnt ? wfC[k] : 0);
+        }
+        u64 excl = block_excl_scan_1024(loc, true, part, nullptr);
+        if (tid == 0) C[0] = 0;
+        for (u32 q = 0; q < per; ++q) {
+            const u32 k = tid * per + q;
+            excl = sat_add(excl, k < cnt ? wfC[k] : 0);
+            if (k < m) C[k + 1] = k < cnt ? excl : ~0ull;
+        }
+    }
     for (u32 k = tid; k < m; k += kBlock) adm[k] = 0;
     if (tid < 4) red[tid] = 0;
     __syncthreads();
@@ -754,28 +805,62 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     u64 run = wsp_base[gw];
     u64 rem_sum = 0, pl_sum = 0;
     u32 rem_cnt = 0, pl_cnt = 0;
+    // Q only grows along a wave's rows, so the position in C[] is carried from tile to tile:
+    // lo_run = largest k < cnt with C[k] <= run (wave-uniform; one binary search per wave, then a short gallop per tile)
+    u32 lo_run = 0;
+    if (cnt) {
+        u32 lo = 0, hi = cnt;
+        while (hi - lo > 1) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (C[mid] <= run) lo = mid; else hi = mid;
+        }
+        lo_run = lo;
+    }
+    if (wsp_cnt_in[gw] == 0) wend = wstart;  // no pending row in this wave's range (later rounds: most waves)
+    uint4 nvn = make_uint4(0, 0, 0, 0), lvn = make_uint4(0, 0, 0, 0);
+    if (wstart < wend) {
+        nvn = *reinterpret_cast<const uint4*>(next + wstart + (u64)lane * 4);
+        lvn = *reinterpret_cast<const uint4*>(load + wstart + (u64)lane * 4);
+    }
     for (u64 it = wstart; it < wend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
-        const uint4 nv = *reinterpret_cast<const uint4*>(next + i0);
+        const uint4 nv = nvn, lv = lvn;
+        // next tile's marks and loads in flight while this one is processed (clamped: the last iteration re-reads
+        // its own tile).  Loads are fetched unconditionally: pending rows are spread over every 64 B segment anyway,
+        // and a dependent load after the mark test costs a full HBM latency per tile.
+        const u64 pit = it + kTile < wend ? it + kTile : it;
+        nvn = *reinterpret_cast<const uint4*>(next + pit + (u64)lane * 4);
+        lvn = *reinterpret_cast<const uint4*>(load + pit + (u64)lane * 4);
         const bool mk0 = i0 + 0 < wend && nv.x == kSpillMark, mk1 = i0 + 1 < wend && nv.y == kSpillMark;
         const bool mk2 = i0 + 2 < wend && nv.z == kSpillMark, mk3 = i0 + 3 < wend && nv.w == kSpillMark;
         if (!__ballot(mk0 | mk1 | mk2 | mk3)) continue;  // wave-uniform: nothing to spill in this tile
-        const u64 l0 = mk0 ? load[i0 + 0] : 0, l1 = mk1 ? load[i0 + 1] : 0;
-        const u64 l2 = mk2 ? load[i0 + 2] : 0, l3 = mk3 ? load[i0 + 3] : 0;
+        const u64 l0 = mk0 ? lv.x : 0, l1 = mk1 ? lv.y : 0;
+        const u64 l2 = mk2 ? lv.z : 0, l3 = mk3 ? lv.w : 0;
         const u64 lsum = l0 + l1 + l2 + l3;
         const u64 inc = wave_incl_scan(lsum, lane);
         u64 Q = run + (inc - lsum);
-        run += shfl64(inc, 63);
+        const u64 run_end = run + shfl64(inc, 63);
+        // wave-uniform bracket [lo_run, hi_run] of this tile's Q range: gallop from the carried position
+        u32 hi_run = lo_run;
+        if (cnt) {
+            u32 step = 1;
+            while (hi_run + step < cnt && C[hi_run + step] <= run_end) { hi_run += step; step <<= 1; }
+            u32 top = hi_run + step < cnt ? hi_run + step : cnt;  // C[top] > run_end or top == cnt
+            while (top - hi_run > 1) {
+                const u32 mid = hi_run + ((top - hi_run) >> 1);
+                if (C[mid] <= run_end) hi_run = mid; else top = mid;
+            }
+        }
 #define RIOGP_ROW(MK, L, E)                                                       \
         if (MK) {                                                                 \
             u32 nd = kNone;                                                       \
             if (cnt && Q < F) {                                                   \
-                u32 lo = 0, hi = cnt;                                             \
+                u32 lo = lo_run, hi = hi_run + 1;                                 \
                 while (hi - lo > 1) {                                             \
                     const u32 mid = lo + ((hi - lo) >> 1);                        \
                     if (C[mid] <= Q) lo = mid; else hi = mid;                     \
                 }                                                                 \
-                if (Q + L <= C[lo + 1]) nd = wfOrder[lo];                             \
+                if (Q + L <= C[lo + 1]) nd = wfOrder[lo];                         \
             }                                                                     \
             if (nd != kNone) {                                                    \
                 next[i0 + E] = nd;                                                \
@@ -792,6 +877,8 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         RIOGP_ROW(mk2, l2, 2)
         RIOGP_ROW(mk3, l3, 3)
 #undef RIOGP_ROW
+        run = run_end;
+        lo_run = hi_run;
     }
     rem_sum = wave_sum(rem_sum);
     rem_cnt = wave_sum32(rem_cnt);
@@ -1062,7 +1149,138 @@ __global__ __launch_bounds__(kBlock) void k_shard_pack1(const u64* __restrict__ 
 
 // verdict words: 0 cut nodes (global) | 1 spill-candidate rows (global) | 2 this rank has rows to re-mark |
 //                3 kept rows | 4 evicted rows | 5 claimant rows | 6 kept load | 7 claim load (all global)
-__global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__ Xg, u32 rank, u32 R, u32 m,
+// --- peer-to-peer exchange over xGMI: payload + sequence flag stored straight into every peer's window ---
+// Window memory is uncached / fine-grained (hipExtMallocWithFlags) and IPC-mapped by the peers; every access is a
+// system-scope 8-byte atomic, the flag is published after a system-scope release, and consumed with ONE relaxed poll
+// loop + ONE system-scope acquire (cdna_hip_programming.md Guideline 16, lifted from agent to system scope).
+#define RIOGP_SYS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define RIOGP_SYS_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+constexpr u64 kP2PTimeoutTicks = 300000000ull;  // wall_clock64 runs at 100 MHz: 3 s, then the error word is set
+
+// all threads of the block call this; thread r < R waits for peer r's flag of this step
+__device__ __forceinline__ void p2p_wait(const u64* flags, u32 R, u64 seq, u64* err) {
+    if (threadIdx.x < R) {
+        const u64* f = flags + (size_t)threadIdx.x * 8;
+        const u64 t0 = wall_clock64();
+        while (RIOGP_SYS_LOAD(f) != seq) {
+            if (wall_clock64() - t0 > kP2PTimeoutTicks) {
+                RIOGP_SYS_STORE(err, 1ull);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+}
+
+// block b delivers this rank's record to peer b: words of payload, then the flag
+__global__ __launch_bounds__(256) void k_p2p_put(const u64* __restrict__ src, u32 words, u64* const* __restrict__ peers,
+                                                 size_t data_off, size_t flag_off, u64 seq) {
+    u64* base = peers[blockIdx.x];
+    u64* dst = base + data_off;
+    for (u32 i = threadIdx.x; i < words; i += 256) RIOGP_SYS_STORE(dst + i, src[i]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) RIOGP_SYS_STORE(base + flag_off, seq);
+}
+
+// wait for every rank's record of this step, then copy them out of the window: out[r][words]
+__global__ __launch_bounds__(kBlock) void k_p2p_wait_copy(const u64* __restrict__ win_slot, size_t W, u32 R, u32 words,
+                                                          const u64* __restrict__ flags, u64 seq, u64* __restrict__ err,
+                                                          u64* __restrict__ out) {
+    p2p_wait(flags, R, seq, err);
+    for (u32 r = 0; r < R; ++r)
+        for (u32 i = threadIdx.x; i < words; i += kBlock)
+            if (out) out[(size_t)r * words + i] = RIOGP_SYS_LOAD(win_slot + (size_t)r * W + i);
+}
+
+// K2p k_resolve_put — row-sharded solve with peer-to-peer windows: the local column sums of H (as k_resolve) are
+//     stored straight into EVERY peer's window; the last workgroup to finish (agent-scope counter) folds the row
+//     counters, stores them too, and only then publishes this rank's flag to every peer.  Replaces
+//     k_resolve + pack + put (three launches) on that path.  R <= 32.
+__global__ __launch_bounds__(256) void k_resolve_put(const u64* __restrict__ H, const u64* __restrict__ blkstat, Plan p,
+                                                     u64* __restrict__ partial, u64* const* __restrict__ peers, u32 R,
+                                                     size_t data_off, size_t flag_off, u64 seq,
+                                                     unsigned int* __restrict__ counter) {
+    __shared__ u64 part[kResRowGroups][8];
+    __shared__ u64 tot[8];
+    __shared__ u64 red[8];
+    __shared__ u32 is_last;
+    const int tid = threadIdx.x, lane = tid & 63, col = tid & 7, rg = tid >> 3;
+    const u32 m = p.m, G = p.G, nb = gridDim.x;
+    const u32 j = blockIdx.x * kResNodes + (col & 3);
+    const bool valid = j < m;
+    const size_t c = (col < 4) ? (size_t)j : (size_t)m + j;
+    u64 v[kResRows];
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) {
+        const u32 row = rg + r * kResRowGroups;
+        v[r] = (valid && row < G) ? H[(size_t)row * 2 * m + c] : 0;
+    }
+    u64 sacc = 0;
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) sacc += v[r];
+    part[rg][col] = sacc;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    if (tid < 8) {
+        u64 t = 0;
+#pragma unroll
+        for (int g = 0; g < kResRowGroups; ++g) t += part[g][tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 8 * (int)R && valid) {  // thread = (peer, column): this workgroup's 8 sums into every window
+        u64* dst = peers[tid >> 3] + data_off;
+        RIOGP_SYS_STORE(dst + c, tot[col]);
+    }
+    if (tid == 0) {
+        u64 a = 0, b = 0;
+        for (int q = 0; q < 4; ++q)
+            if (blockIdx.x * kResNodes + q < m) { a += tot[q]; b += tot[q + 4]; }
+        red[0] = a;
+        red[1] = b;
+    }
+    if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
+        u64 acc = 0;
+        for (u32 r = blockIdx.x + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
+        acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
+        if (lane < 4) red[3 + lane] = acc;
+    }
+    __syncthreads();
+    // No release FENCE here: a system-scope release is buffer_wbl2 = write back every dirty L2 line, and k_scan has just
+    // dirtied megabytes of them (measured 17.6 us for this kernel with one fence per workgroup, against 4.5 us).  Every
+    // store that another agent or workgroup consumes is instead an sc0/sc1 write-through atomic, and s_waitcnt vmcnt(0)
+    // is their completion (MI355X_MICROARCH.md, "valid forms": 8-B atomics on both sides need no fence).
+    if (tid < 8)
+        __hip_atomic_store(partial + (size_t)blockIdx.x * 8 + tid, (tid < 7) ? red[tid] : 1ull, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) is_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+    __syncthreads();
+    if (!is_last) return;
+    if (tid < 8) red[tid] = 0;
+    __syncthreads();
+    {
+        u64 acc = 0;
+        for (u32 r = rg; r < nb; r += kResRowGroups)
+            acc += __hip_atomic_load(partial + (size_t)r * 8 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(&red[col], acc);
+    }
+    __syncthreads();
+    if (tid < 8 * (int)R) RIOGP_SYS_STORE(peers[tid >> 3] + data_off + 2 * (size_t)m + col, red[col]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < (int)R) RIOGP_SYS_STORE(peers[tid] + flag_off, seq);
+    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool P2P>
+__global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__ Xg, size_t W, const u64* __restrict__ wait_flags,
+                                                         u64 seq, u64* __restrict__ p2p_err, u32 rank, u32 R, u32 m,
                                                          const u64* __restrict__ cap,
                                                          const u32* __restrict__ alive_bits,
                                                          u64* __restrict__ used_kept, u64* __restrict__ used_cur,
@@ -1076,7 +1294,8 @@ __global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__
     __shared__ u64 red[8];
     const int tid = threadIdx.x;
     const u32 mwords = (m + 31) / 32;
-    const size_t W = 2 * (size_t)m + 8;
+    if (P2P) p2p_wait(wait_flags, R, seq, p2p_err);  // the records arrive while this kernel is already resident
+    auto ldx = [&](size_t k) -> u64 { return P2P ? RIOGP_SYS_LOAD(Xg + k) : Xg[k]; };
     for (u32 k = tid; k < mwords; k += kBlock) fb[k] = 0;
     if (tid < 8) red[tid] = 0;
     __syncthreads();
@@ -1084,7 +1303,7 @@ __global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__
     for (u32 j = tid; j < m; j += kBlock) {
         u64 kept_glob = 0, claim_pre = 0, claim_glob = 0, claim_local = 0;
         for (u32 r = 0; r < R; ++r) {
-            const u64 kx = Xg[r * W + j], cx = Xg[r * W + m + j];
+            const u64 kx = ldx(r * W + j), cx = ldx(r * W + m + j);
             kept_glob += kx;
             if (r < rank) claim_pre += cx;
             if (r == rank) claim_local = cx;
@@ -1113,7 +1332,7 @@ __global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__
     }
     if (tid < 8) {  // global counters: column tid of every rank's record
         u64 s = 0;
-        for (u32 r = 0; r < R; ++r) s += Xg[r * W + 2 * (size_t)m + tid];
+        for (u32 r = 0; r < R; ++r) s += ldx(r * W + 2 * (size_t)m + tid);
         // k_resolve's partial columns: 0 load_kept 1 load_claim 2 (local n_cut, unused) 3 kept 4 evicted 5 claimants 6 spillcand
         const int dst = tid == 0 ? 6 : tid == 1 ? 7 : tid == 3 ? 3 : tid == 4 ? 4 : tid == 5 ? 5 : tid == 6 ? 1 : -1;
         if (dst >= 0) atomicAdd(&red[dst], s);
@@ -1280,12 +1499,13 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
                         hipStream_t s) {
     const int in = round & 1, out = in ^ 1;
     const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
-    const size_t lds_prep = 2 * kSmall + (size_t)2 * mp * sizeof(u64);
-    hipLaunchKernelGGL(k_spill_prepare, dim3(1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
-                       b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.rank_base, b.stats);
-    const size_t lds_apply = kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + 16;
+    const size_t lds_prep = 2 * kSmall + 256 + (size_t)mp * sizeof(u64);
+    const unsigned grank = (p.m + kRankNodes - 1) / kRankNodes;
+    hipLaunchKernelGGL(k_spill_rank, dim3(grank ? grank : 1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
+                       b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.rank_base, b.pending_global, b.stats);
+    const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + 16;
     hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_base, b.wfC,
-                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats);
+                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats);
 }
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {
@@ -1361,11 +1581,31 @@ void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s
                        resolve_blocks(p.m), p.m, X);
 }
 void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, const u64* Xg, u32 rank, u32 R,
-                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s) {
+                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s,
+                         size_t row_stride, const u64* wait_flags, u64 seq, u64* p2p_err) {
     const size_t lds = (size_t)(p.mwords + 4) * sizeof(u32);
-    hipLaunchKernelGGL(k_shard_import, dim3(1), dim3(kBlock), lds, s, Xg, rank, R, p.m, nt.cap, nt.alive_bits,
-                       b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits,
-                       b.rank_base, verdict_dev, verdict_host);
+    const size_t W = row_stride ? row_stride : shard_words1(p.m);
+    if (wait_flags)
+        hipLaunchKernelGGL(k_shard_import<true>, dim3(1), dim3(kBlock), lds, s, Xg, W, wait_flags, seq, p2p_err, rank, R,
+                           p.m, nt.cap, nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, gprev,
+                           gfinal, b.forced_bits, b.rank_base, verdict_dev, verdict_host);
+    else
+        hipLaunchKernelGGL(k_shard_import<false>, dim3(1), dim3(kBlock), lds, s, Xg, W, (const u64*)nullptr, 0ull,
+                           (u64*)nullptr, rank, R, p.m, nt.cap, nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot,
+                           b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits, b.rank_base, verdict_dev, verdict_host);
+}
+void launch_resolve_put(const Plan& p, const SolveBufs& b, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off,
+                        u64 seq, unsigned int* counter, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve_put, dim3(resolve_blocks(p.m)), dim3(256), 0, s, b.H, b.blkstat, p, b.partial, d_peers, R,
+                       data_off, flag_off, seq, counter);
+}
+void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off, u64 seq,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_p2p_put, dim3(R), dim3(256), 0, s, src, words, d_peers, data_off, flag_off, seq);
+}
+void launch_p2p_wait_copy(const u64* win_slot, size_t W, u32 R, u32 words, const u64* flags, u64 seq, u64* err, u64* out,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_p2p_wait_copy, dim3(1), dim3(kBlock), 0, s, win_slot, W, R, words, flags, seq, err, out);
 }
 void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s) {
     hipLaunchKernelGGL(k_shard_export_delta, dim3(1), dim3(kBlock), 0, s, b.used_cur, base, b.wsp_sum[wsp_sel],

@@ -6,6 +6,7 @@
 //   LocalObjectPlacement             rio-rs/src/object_placement/local.rs:22-68
 //   Service::get_or_create_placement rio-rs/src/service.rs:193-254 (+ check_address_mismatch :261-298)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@ using namespace riogp;
 namespace {
 
 thread_local std::string g_create_error;
+struct RioGpNcclId { char internal[128]; };  // ncclUniqueId, passed BY VALUE to ncclCommInitRank
 constexpr int kRing = 64;  // in-flight async solves whose verdicts we keep
 
 struct DevBuf {
@@ -31,7 +33,56 @@ struct DevBuf {
 
 }  // namespace
 
+// RCCL, resolved at run time (dlopen of the copy already in the process, else librccl.so.1): the library has
+// no link-time dependency on it, and a host that never shards never loads it.  Only the four entry points
+// the data path needs; types restated from rccl.h (ncclUniqueId = 128 opaque bytes, ncclUint64 = 5).
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, RioGpNcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclUint64 = 5;
+constexpr int kShardRing = 4;
+
+struct ShardComm {
+    RcclApi api;
+    void* comm = nullptr;
+    u32 rank = 0, R = 1;
+    hipStream_t side = nullptr;  // exchange + global resolve of solve k run here, overlapping solve k+1's scan
+    hipEvent_t ready[kShardRing] = {}, done[kShardRing] = {};
+    bool done_valid[kShardRing] = {};
+    u64* X[kShardRing] = {};
+    u64* XG[kShardRing] = {};
+    u32 k = 0;
+};
+
+// Peer-to-peer exchange windows (rio_gp_shard_p2p_*): one uncached window per rank, IPC-mapped by every peer.
+//   data  [kP2PSlots][R][W]   record of rank r for the step using that slot
+//   flags [kP2PSlots][R][8]   sequence number of the step whose record is complete (one 64 B line each)
+//   hello [R][8]              set-up handshake
+constexpr int kP2PSlots = 4;
+struct P2P {
+    u32 rank = 0, R = 1;
+    size_t W = 0;                 // u64 words per record row
+    u64* win = nullptr;           // this rank's window
+    std::vector<void*> opened;    // peers' windows as mapped here (nullptr for our own)
+    u64** d_peers = nullptr;      // device array [R] of window bases (ours included)
+    u64* d_err = nullptr;         // set by a waiting kernel that timed out
+    u64* scratch = nullptr;       // [W] staging of the local record
+    u64 seq = 0;
+    unsigned int* d_counter = nullptr;  // k_resolve_put's "last workgroup" counter (self-resetting)
+    size_t data_off(u32 slot, u32 r) const { return ((size_t)slot * R + r) * W; }
+    size_t flag_off(u32 slot, u32 r) const { return (size_t)kP2PSlots * R * W + ((size_t)slot * R + r) * 8; }
+    size_t hello_off(u32 r) const { return (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)r * 8; }
+    size_t total_words() const { return (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)R * 8; }
+};
+
 struct rio_gp {
+    ShardComm* sc = nullptr;
+    P2P* p2p = nullptr;
     std::mutex mu;
     std::string err;
     int device = 0;
@@ -66,10 +117,15 @@ struct rio_gp {
     // row-sharded solve (rio_gp_shard_*): global `used` snapshots, forced-node bitmap, spill base, verdict words
     u64 *sh_gprev = nullptr, *sh_gfinal = nullptr, *sh_rank_base = nullptr, *sh_verdict = nullptr;
     u32* sh_forced = nullptr;
+    // outputs of the LOCAL column sums (k_resolve in shard mode): kept apart from the solver's arrays, which the
+    // global resolve of the PREVIOUS solve may still be writing on the exchange stream
+    u64 *sh_lkept = nullptr, *sh_lclaim = nullptr, *sh_lcur = nullptr;
+    u32 *sh_lcutblk = nullptr, *sh_lcutidx = nullptr;
     u32 sh_rank = 0, sh_R = 1;
     int sh_state = 0;       // 0 idle | 1 scanned | 2 resolved | 3 cut exported | 4 merged | 5 spill exported
     bool sh_slow = false;   // the solve in flight took the fix-up path
     u32 sh_slot = 0;        // verdict slot of the last rio_gp_shard_resolve
+    hipStream_t sh_side = nullptr;  // stream the last rio_gp_shard_resolve ran on, when not the handle's
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
     std::vector<void*> allocs;
@@ -85,6 +141,36 @@ namespace {
             return RIO_GP_EUPSTREAM;                                                          \
         }                                                                                     \
     } while (0)
+
+void p2p_free(rio_gp* h) {
+    P2P* q = h->p2p;
+    if (!q) return;
+    if (q->d_counter) (void)hipFree(q->d_counter);
+    for (void* o : q->opened) if (o) (void)hipIpcCloseMemHandle(o);
+    if (q->d_peers) (void)hipFree(q->d_peers);
+    if (q->d_err) (void)hipFree(q->d_err);
+    if (q->scratch) (void)hipFree(q->scratch);
+    if (q->win) (void)hipFree(q->win);
+    delete q;
+    h->p2p = nullptr;
+}
+
+void shard_comm_free(rio_gp* h) {
+    p2p_free(h);
+    ShardComm* sc = h->sc;
+    if (!sc) return;
+    if (sc->side) (void)hipStreamSynchronize(sc->side);
+    if (sc->comm && sc->api.CommDestroy) (void)sc->api.CommDestroy(sc->comm);
+    for (int q = 0; q < kShardRing; ++q) {
+        if (sc->ready[q]) (void)hipEventDestroy(sc->ready[q]);
+        if (sc->done[q]) (void)hipEventDestroy(sc->done[q]);
+        if (sc->X[q]) (void)hipFree(sc->X[q]);
+        if (sc->XG[q]) (void)hipFree(sc->XG[q]);
+    }
+    if (sc->side) (void)hipStreamDestroy(sc->side);
+    delete sc;
+    h->sc = nullptr;
+}
 
 int fail(rio_gp* h, int rc, const std::string& msg) {
     h->err = msg;
@@ -174,27 +260,7 @@ int merge_slow(rio_gp* h, DevStats* v) {
     return RIO_GP_OK;
 }
 
-int solve_locked(rio_gp* h, rio_gp_stats* stats) {
-    h->plan = make_plan(h->n, h->m, 0);
-    const Table t = real_table(h);
-    const NodeTab nt = real_nodes(h);
-    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
-    launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    DevStats v = reduce_slot(h, 0, h->m);
-    if (v.n_cut > 0 || v.spillcand > 0) {
-        enqueue_slow(h, h->plan, t, nt, false, v);
-        int rc = merge_slow(h, &v);
-        if (rc) return rc;
-    }
-    HIPCHK(h, hipGetLastError());
-    fill_stats(v, h->n, stats);
-    h->have_solved = true;
-    h->ring_n = 0;
-    return RIO_GP_OK;
-}
-
-int commit_locked(rio_gp* h) {
+int commit_enqueue(rio_gp* h) {
     if (!h->have_solved) return fail(h, RIO_GP_EINVAL, "rio_gp_commit: no solve to commit");
     h->cur ^= 1;
     HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
@@ -203,6 +269,37 @@ int commit_locked(rio_gp* h) {
     h->have_solved = false;
     return RIO_GP_OK;
 }
+
+// One whole-table solve; with `commit` the publication (pointer swap + `used` copy) is enqueued before the last
+// wait, so a tick costs two host waits (verdict, completion) on either path.
+int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
+    h->plan = make_plan(h->n, h->m, 0);
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+    launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    DevStats v = reduce_slot(h, 0, h->m);
+    const bool slow = v.n_cut > 0 || v.spillcand > 0;
+    if (slow) enqueue_slow(h, h->plan, t, nt, false, v);
+    h->have_solved = true;
+    h->ring_n = 0;
+    if (commit) {
+        int rc = commit_enqueue(h);
+        if (rc) return rc;
+    }
+    if (slow) {
+        int rc = merge_slow(h, &v);  // waits for the stream
+        if (rc) return rc;
+    } else if (commit) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, hipGetLastError());
+    fill_stats(v, h->n, stats);
+    return RIO_GP_OK;
+}
+
+int commit_locked(rio_gp* h) { return commit_enqueue(h); }
 
 int ensure_used(rio_gp* h) {
     if (h->used_valid) return RIO_GP_OK;
@@ -287,6 +384,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
     A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
     A(h->sb.wfCnt, 4); A(h->dstats, 1);
+    A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
 #undef A
     h->sb.stats = h->dstats;
@@ -325,6 +423,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
+    shard_comm_free(h);
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& b : h->vt) if (b.p) (void)hipFree(b.p);
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
@@ -723,11 +822,7 @@ int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = solve_locked(h, stats);
-    if (rc) return rc;
-    if ((rc = commit_locked(h))) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return RIO_GP_OK;
+    return solve_locked(h, stats, true);
 }
 
 int rio_gp_solve_async(rio_gp_t* h) {
@@ -796,6 +891,8 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
 
 // ---- row-sharded solve across GPUs ------------------------------------------
 
+static int p2p_check(rio_gp* h);
+
 int rio_gp_set_stream(rio_gp_t* h, void* hip_stream) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
@@ -808,10 +905,21 @@ int rio_gp_set_stream(rio_gp_t* h, void* hip_stream) {
 uint32_t rio_gp_shard_words1(rio_gp_t* h) { return h ? (uint32_t)shard_words1(h->m) : 0; }
 uint32_t rio_gp_shard_words2(rio_gp_t* h) { return h ? (uint32_t)shard_words2(h->m) : 0; }
 
+static SolveBufs local_bufs(rio_gp* h) {  // where the local sums of a shard scan go
+    SolveBufs b = h->sb;
+    b.used_kept = h->sh_lkept;
+    b.claim_tot = h->sh_lclaim;
+    b.used_cur = h->sh_lcur;
+    b.cutblk = h->sh_lcutblk;
+    b.cutidx = h->sh_lcutidx;
+    return b;
+}
+
 static SolveBufs shard_bufs(rio_gp* h) {
     SolveBufs b = h->sb;
     b.forced_bits = h->sh_forced;
     b.rank_base = h->sh_rank_base;
+    b.pending_global = h->sh_verdict;  // [0] = rows pending on all ranks, written by k_shard_import_delta
     return b;
 }
 
@@ -822,22 +930,25 @@ int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
-    launch_resolve(h->plan, nt, h->sb, nullptr, h->stream);  // used_base = nullptr: purely local sums
-    launch_shard_pack1(h->plan, h->sb, reinterpret_cast<u64*>(d_x), h->stream);
+    const SolveBufs lb = local_bufs(h);
+    launch_resolve(h->plan, nt, lb, nullptr, h->stream);  // used_base = nullptr: purely local sums
+    launch_shard_pack1(h->plan, lb, reinterpret_cast<u64*>(d_x), h->stream);
     h->have_solved = false;
     h->sh_state = 1;
     return RIO_GP_OK;
 }
 
-int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uint64_t* d_xg) {
+int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uint64_t* d_xg, void* on_stream) {
     if (!h || !d_xg || n_ranks == 0 || rank >= n_ranks) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     if (h->sh_state != 1) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_resolve: call rio_gp_shard_scan first");
     h->sh_rank = rank;
     h->sh_R = n_ranks;
     h->sh_slot = h->ring_n;
+    hipStream_t st = on_stream ? static_cast<hipStream_t>(on_stream) : h->stream;
+    h->sh_side = on_stream ? st : nullptr;
     launch_shard_import(h->plan, real_nodes(h), shard_bufs(h), reinterpret_cast<const u64*>(d_xg), rank, n_ranks,
-                        h->sh_gprev, h->sh_gfinal, h->sh_verdict, slot_dev(h, h->ring_n), h->stream);
+                        h->sh_gprev, h->sh_gfinal, h->sh_verdict, slot_dev(h, h->ring_n), st);
     h->ring_n++;
     h->sh_state = 2;
     return RIO_GP_OK;
@@ -848,7 +959,10 @@ int rio_gp_shard_verdict(rio_gp_t* h, rio_gp_shard_info* out, uint32_t* n_slow) 
     std::lock_guard<std::mutex> g(h->mu);
     if (h->sh_state != 2) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_verdict: call rio_gp_shard_resolve first");
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->sh_side) HIPCHK(h, hipStreamSynchronize(h->sh_side));  // the exchange stream of a pipelined caller
+    h->sh_side = nullptr;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->p2p && h->p2p->d_peers) { int rc = p2p_check(h); if (rc) return rc; }
     HIPCHK(h, hipGetLastError());
     uint32_t slow = 0;
     const u32 lo = h->ring_n > (u32)kRing ? h->ring_n - kRing : 0;
@@ -937,6 +1051,251 @@ int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats) {
     h->have_solved = true;
     h->ring_n = 0;
     h->sh_state = 0;
+    return RIO_GP_OK;
+}
+
+// ---- peer-to-peer exchange over xGMI (preferred): no collective call on the data path at all ----
+
+int rio_gp_shard_p2p_export(rio_gp_t* h, uint32_t n_ranks, void* out_handle64) {
+    if (!h || !out_handle64 || n_ranks == 0 || n_ranks > 32) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->p2p) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_p2p_export: window already exported");
+    HIPCHK(h, hipSetDevice(h->device));
+    P2P* q = new P2P();
+    q->R = n_ranks;
+    q->W = (shard_words1(h->cap_nodes) + 7) & ~(size_t)7;
+    const size_t bytes = q->total_words() * sizeof(u64);
+    void* w = nullptr;
+    // uncached first (what RCCL uses for its own flag/LL buffers on gfx94x/95x), fine-grained second; ordinary cached
+    // device memory is NOT acceptable: a peer's store would sit behind this GPU's stale L2 lines
+    if (hipExtMallocWithFlags(&w, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        w = nullptr;
+        if (hipExtMallocWithFlags(&w, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            delete q;
+            return fail(h, RIO_GP_EUPSTREAM, "rio_gp_shard_p2p_export: no uncached / fine-grained device memory");
+        }
+    }
+    q->win = static_cast<u64*>(w);
+    h->p2p = q;
+    HIPCHK(h, hipMemsetAsync(q->win, 0, bytes, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipIpcMemHandle_t ih;
+    HIPCHK(h, hipIpcGetMemHandle(&ih, q->win));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    memcpy(out_handle64, &ih, 64);
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_p2p_connect(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const void* handles) {
+    if (!h || !handles || n_ranks == 0 || rank >= n_ranks) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    P2P* q = h->p2p;
+    if (!q || q->R != n_ranks || q->d_peers) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_p2p_connect: export first / rank count differs");
+    HIPCHK(h, hipSetDevice(h->device));
+    q->rank = rank;
+    q->opened.assign(n_ranks, nullptr);
+    std::vector<u64*> bases(n_ranks, nullptr);
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        if (r == rank) { bases[r] = q->win; continue; }
+        hipIpcMemHandle_t ih;
+        memcpy(&ih, static_cast<const char*>(handles) + (size_t)r * 64, 64);
+        void* o = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&o, ih, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, RIO_GP_EUPSTREAM, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        }
+        q->opened[r] = o;
+        bases[r] = static_cast<u64*>(o);
+    }
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&q->d_peers), n_ranks * sizeof(u64*)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&q->d_err), sizeof(u64)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&q->scratch), q->W * sizeof(u64)));
+    HIPCHK(h, hipMemcpy(q->d_peers, bases.data(), n_ranks * sizeof(u64*), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(q->d_err, 0, sizeof(u64)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&q->d_counter), sizeof(unsigned int)));
+    HIPCHK(h, hipMemset(q->d_counter, 0, sizeof(unsigned int)));
+    // handshake: every rank stores a token into every peer's hello line and waits for all of theirs (3 s limit)
+    const u64 token = 0xC0FFEE0000000001ull;
+    launch_p2p_put(q->scratch, 0, q->d_peers, n_ranks, 0, q->hello_off(rank), token, h->stream);
+    launch_p2p_wait_copy(q->win, q->W, n_ranks, 0, q->win + q->hello_off(0), token, q->d_err, nullptr, h->stream);
+    u64 err = 0;
+    HIPCHK(h, hipMemcpyAsync(&err, q->d_err, sizeof err, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (err) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_shard_p2p_connect: a peer's handshake store never became visible");
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_p2p_ready(rio_gp_t* h) { return h && h->p2p && h->p2p->d_peers ? 1 : 0; }
+
+int rio_gp_shard_p2p_close(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipGetLastError();
+    p2p_free(h);
+    h->sh_state = 0;
+    h->ring_n = 0;
+    return RIO_GP_OK;
+}
+
+static int p2p_check(rio_gp* h) {  // after a wait on the stream: did any in-kernel wait time out?
+    u64 err = 0;
+    HIPCHK(h, hipMemcpyAsync(&err, h->p2p->d_err, sizeof err, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (err) return fail(h, RIO_GP_EUPSTREAM, "peer-to-peer exchange timed out waiting for a rank's record");
+    return RIO_GP_OK;
+}
+
+// ---- native RCCL exchange (optional): the library issues the all-gathers itself --------------
+
+static bool rccl_load(RcclApi* a, const char* path, std::string* err) {
+    const char* cands[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int pass = 0; pass < 2 && !a->lib; ++pass)      // pass 0: a copy already in the process (torch's), pass 1: load
+        for (const char* c : cands)
+            if (c && *c && (a->lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0)))) break;
+    if (!a->lib) { *err = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?"); return false; }
+    a->GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(a->lib, "ncclGetUniqueId"));
+    a->CommInitRank = reinterpret_cast<int (*)(void**, int, RioGpNcclId, int)>(dlsym(a->lib, "ncclCommInitRank"));
+    a->CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(a->lib, "ncclCommDestroy"));
+    a->AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(a->lib, "ncclAllGather"));
+    a->GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(a->lib, "ncclGetErrorString"));
+    if (!a->GetUniqueId || !a->CommInitRank || !a->CommDestroy || !a->AllGather) { *err = "librccl lacks a required symbol"; return false; }
+    return true;
+}
+
+int rio_gp_shard_comm_unique_id(void* out128, const char* rccl_path) {
+    if (!out128) return RIO_GP_EINVAL;
+    RcclApi a;
+    std::string err;
+    if (!rccl_load(&a, rccl_path, &err)) { g_create_error = err; return RIO_GP_EUPSTREAM; }
+    RioGpNcclId id;
+    memset(&id, 0, sizeof id);
+    const int rc = a.GetUniqueId(&id);
+    if (rc != 0) { g_create_error = "ncclGetUniqueId failed"; return RIO_GP_EUPSTREAM; }
+    memcpy(out128, &id, sizeof id);
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_comm_init(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const void* id128, const char* rccl_path) {
+    if (!h || !id128 || n_ranks == 0 || rank >= n_ranks) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->sc) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_comm_init: communicator already set up");
+    HIPCHK(h, hipSetDevice(h->device));
+    ShardComm* sc = new ShardComm();
+    std::string err;
+    if (!rccl_load(&sc->api, rccl_path, &err)) { delete sc; return fail(h, RIO_GP_EUPSTREAM, err); }
+    RioGpNcclId id;
+    memcpy(&id, id128, sizeof id);
+    const int rc = sc->api.CommInitRank(&sc->comm, (int)n_ranks, id, (int)rank);
+    if (rc != 0) {
+        const std::string m = std::string("ncclCommInitRank: ") + (sc->api.GetErrorString ? sc->api.GetErrorString(rc) : "failed");
+        delete sc;
+        return fail(h, RIO_GP_EUPSTREAM, m);
+    }
+    sc->rank = rank;
+    sc->R = n_ranks;
+    h->sc = sc;  // from here on rio_gp_destroy releases whatever was created
+    HIPCHK(h, hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking));
+    const size_t w1 = shard_words1(h->cap_nodes);
+    for (int q = 0; q < kShardRing; ++q) {
+        HIPCHK(h, hipEventCreateWithFlags(&sc->ready[q], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sc->done[q], hipEventDisableTiming));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&sc->X[q]), w1 * sizeof(u64)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&sc->XG[q]), w1 * n_ranks * sizeof(u64)));
+    }
+    return RIO_GP_OK;
+}
+
+uint32_t rio_gp_shard_comm_ranks(rio_gp_t* h) { return h && h->sc ? h->sc->R : 0; }
+
+// One whole fast-path step of the row-sharded solve, nothing waits on the host:
+//   stream:      k_scan, k_resolve (local sums), pack X      -> event
+//   side stream: ncclAllGather(X) over xGMI, k_shard_import  -> event (frees the ring slot)
+// Back-to-back calls overlap solve k's exchange with solve k+1's scan.
+int rio_gp_shard_solve_async(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->p2p && h->p2p->d_peers) {
+        // peer-to-peer, ONE stream, three launches, no collective call and no host wait:
+        //   k_scan -> k_resolve_put (local sums stored straight into every peer's window over xGMI, flag last)
+        //          -> k_shard_import (waits in-kernel for every rank's flag of this solve, then the global resolve)
+        // Stream order is the flow control: a rank's record j+1 leaves only after it consumed everyone's record j,
+        // so none of the 4 window slots is overwritten while its owner still reads it.  (Running the import on a
+        // second stream under the next scan was measured SLOWER on gfx950: two event records + two stream waits per
+        // solve cost more than the 5 us they hide.)
+        P2P* q = h->p2p;
+        const u64 seq = ++q->seq;
+        const u32 slot = (u32)(seq % kP2PSlots);
+        h->plan = make_plan(h->n, h->m, 0);
+        const Table t = real_table(h);
+        const NodeTab nt = real_nodes(h);
+        launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+        launch_resolve_put(h->plan, h->sb, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq,
+                           q->d_counter, h->stream);
+        h->sh_rank = q->rank;
+        h->sh_R = q->R;
+        h->sh_slot = h->ring_n;
+        h->sh_side = nullptr;
+        launch_shard_import(h->plan, nt, shard_bufs(h), q->win + q->data_off(slot, 0), q->rank, q->R, h->sh_gprev,
+                            h->sh_gfinal, h->sh_verdict, slot_dev(h, h->ring_n), h->stream, q->W,
+                            q->win + q->flag_off(slot, 0), seq, q->d_err);
+        h->ring_n++;
+        h->have_solved = false;
+        h->sh_state = 2;
+        return RIO_GP_OK;
+    }
+    ShardComm* sc = h->sc;
+    if (!sc) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_solve_async: set up rio_gp_shard_p2p_connect or rio_gp_shard_comm_init first");
+    const int q = (int)(sc->k++ % kShardRing);
+    if (sc->done_valid[q]) HIPCHK(h, hipStreamWaitEvent(h->stream, sc->done[q], 0));
+    h->plan = make_plan(h->n, h->m, 0);
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+    const SolveBufs lb = local_bufs(h);
+    launch_resolve(h->plan, nt, lb, nullptr, h->stream);
+    launch_shard_pack1(h->plan, lb, sc->X[q], h->stream);
+    HIPCHK(h, hipEventRecord(sc->ready[q], h->stream));
+    HIPCHK(h, hipStreamWaitEvent(sc->side, sc->ready[q], 0));
+    const int rc = sc->api.AllGather(sc->X[q], sc->XG[q], shard_words1(h->m), kNcclUint64, sc->comm, sc->side);
+    if (rc != 0) return fail(h, RIO_GP_EUPSTREAM, std::string("ncclAllGather: ") + (sc->api.GetErrorString ? sc->api.GetErrorString(rc) : "failed"));
+    h->sh_rank = sc->rank;
+    h->sh_R = sc->R;
+    h->sh_slot = h->ring_n;
+    h->sh_side = sc->side;
+    launch_shard_import(h->plan, nt, shard_bufs(h), sc->XG[q], sc->rank, sc->R, h->sh_gprev, h->sh_gfinal, h->sh_verdict,
+                        slot_dev(h, h->ring_n), sc->side);
+    HIPCHK(h, hipEventRecord(sc->done[q], sc->side));
+    sc->done_valid[q] = true;
+    h->ring_n++;
+    h->have_solved = false;
+    h->sh_state = 2;
+    return RIO_GP_OK;
+}
+
+// all-gather of `words` u64 per rank on the handle's stream (the Y records of the fix-up path, counters)
+int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, uint64_t words) {
+    if (!h || !d_in || !d_out) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->p2p && h->p2p->d_peers) {
+        P2P* q = h->p2p;
+        if (words > q->W) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_exchange: record larger than the window row");
+        const u64 seq = ++q->seq;
+        const u32 slot = (u32)(seq % kP2PSlots);
+        launch_p2p_put(reinterpret_cast<const u64*>(d_in), (u32)words, q->d_peers, q->R, q->data_off(slot, q->rank),
+                       q->flag_off(slot, q->rank), seq, h->stream);
+        launch_p2p_wait_copy(q->win + q->data_off(slot, 0), q->W, q->R, (u32)words, q->win + q->flag_off(slot, 0), seq,
+                             q->d_err, reinterpret_cast<u64*>(d_out), h->stream);
+        return p2p_check(h);
+    }
+    if (!h->sc) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_exchange: call rio_gp_shard_comm_init first");
+    const int rc = h->sc->api.AllGather(d_in, d_out, (size_t)words, kNcclUint64, h->sc->comm, h->stream);
+    if (rc != 0) return fail(h, RIO_GP_EUPSTREAM, "ncclAllGather failed");
     return RIO_GP_OK;
 }
 

@@ -47,12 +47,20 @@ def _lib():
         L.rio_gp_shard_words2.argtypes = [vp]
         L.rio_gp_shard_words2.restype = C.c_uint32
         L.rio_gp_shard_scan.argtypes = [vp, vp]
-        L.rio_gp_shard_resolve.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+        L.rio_gp_shard_resolve.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
         L.rio_gp_shard_verdict.argtypes = [vp, C.POINTER(ShardInfo), C.POINTER(C.c_uint32)]
         L.rio_gp_shard_cut.argtypes = [vp, C.c_int, vp]
         L.rio_gp_shard_merge.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.rio_gp_shard_spill.argtypes = [vp, C.c_uint32, C.c_int, vp]
         L.rio_gp_shard_finish.argtypes = [vp, C.POINTER(rio_gp.Stats)]
+        L.rio_gp_shard_comm_unique_id.argtypes = [vp, C.c_char_p]
+        L.rio_gp_shard_comm_init.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_char_p]
+        L.rio_gp_shard_solve_async.argtypes = [vp]
+        L.rio_gp_shard_exchange.argtypes = [vp, vp, vp, C.c_uint64]
+        L.rio_gp_shard_p2p_export.argtypes = [vp, C.c_uint32, vp]
+        L.rio_gp_shard_p2p_connect.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+        L.rio_gp_shard_p2p_ready.argtypes = [vp]
+        L.rio_gp_shard_p2p_close.argtypes = [vp]
         _ready = True
     return L
 
@@ -81,8 +89,9 @@ class HipShardEngine:
     def scan(self, x):
         self.g._chk(_lib().rio_gp_shard_scan(self.g.handle, C.c_void_p(x.data_ptr())))
 
-    def resolve(self, rank, n_ranks, xg):
-        self.g._chk(_lib().rio_gp_shard_resolve(self.g.handle, rank, n_ranks, C.c_void_p(xg.data_ptr())))
+    def resolve(self, rank, n_ranks, xg, on_stream=None):
+        st = C.c_void_p(on_stream.cuda_stream) if on_stream is not None else None
+        self.g._chk(_lib().rio_gp_shard_resolve(self.g.handle, rank, n_ranks, C.c_void_p(xg.data_ptr()), st))
 
     def verdict(self):
         info, ns = ShardInfo(), C.c_uint32(0)
@@ -149,6 +158,81 @@ class DistExchange:
         return out
 
 
+class NativeRcclExchange:
+    """The library issues the RCCL all-gathers itself (rio_gp_shard_comm_init / _solve_async / _exchange): one C call
+    per fast-path solve, the exchange on the library's second stream.  torch.distributed is used once, to move the
+    128-byte ncclUniqueId from rank 0 to the other ranks — a host in another language would use its own control
+    channel for that."""
+
+    def __init__(self, engine, group=None):
+        import os
+        import torch.distributed as dist
+        self.e = engine
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.path = path.encode() if os.path.exists(path) else None
+        uid = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            rc = _lib().rio_gp_shard_comm_unique_id(uid, self.path)
+            if rc:
+                raise rio_gp.ObjectPlacementError("Upstream", (_lib().rio_gp_last_error(None) or b"").decode(), rc)
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        buf = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        engine.g._chk(_lib().rio_gp_shard_comm_init(engine.g.handle, self.rank, self.world, buf, self.path))
+
+    def ranks(self, n_local):
+        if n_local != 1:
+            raise ValueError("one shard per process")
+        return [self.rank]
+
+    def native_solve_async(self):
+        self.e.g._chk(_lib().rio_gp_shard_solve_async(self.e.g.handle))
+
+    def all_gather(self, parts):
+        inp = parts[0]
+        out = torch.empty(self.world * inp.numel(), dtype=inp.dtype, device=inp.device)
+        return self.all_gather_into(out, parts)
+
+    def all_gather_into(self, out, parts):
+        inp = parts[0]
+        self.e.g._chk(_lib().rio_gp_shard_exchange(self.e.g.handle, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                  inp.numel()))
+        return out
+
+
+class P2PExchange(NativeRcclExchange):
+    """Peer-to-peer windows over xGMI (rio_gp_shard_p2p_*): each record is stored straight into the peers' HBM and
+    consumed behind sequence flags — no collective call on the data path.  torch.distributed only carries the
+    64-byte IPC handles at set-up.  Raises if any rank cannot map its peers or the handshake fails, on EVERY rank
+    (the outcome is agreed through the control channel), so that the caller can fall back consistently."""
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+        self.e = engine
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        h = engine.g.handle
+        mine = (C.c_uint8 * 64)()
+        rc = _lib().rio_gp_shard_p2p_export(h, self.world, mine)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(mine) if rc == 0 else None, group=group)
+        ok = rc == 0 and all(x is not None for x in handles)
+        if ok:
+            blob = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(handles))
+            ok = _lib().rio_gp_shard_p2p_connect(h, self.rank, self.world, blob) == 0
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(ok), group=group)
+        if not all(flags):
+            _lib().rio_gp_shard_p2p_close(h)
+            raise rio_gp.ObjectPlacementError("Upstream", "peer-to-peer windows unavailable on ranks %s: %s" % (
+                [r for r, f in enumerate(flags) if not f], (_lib().rio_gp_last_error(h) or b"").decode()), 2)
+
+    def close(self):
+        _lib().rio_gp_shard_p2p_close(self.e.g.handle)
+
+
 class LocalExchange:
     """G shards driven by ONE process on one device (tests, single-GPU what-if runs): the "all-gather" is
     a concatenation in rank order — the same records, the same reduction order."""
@@ -173,7 +257,10 @@ class LocalExchange:
 class ShardedSolver:
     """Sequences the phases of one row-sharded solve over this process's engines (normally one)."""
 
-    def __init__(self, engines, exchange, spill_rounds=2):
+    def __init__(self, engines, exchange, spill_rounds=2, pipeline=False):
+        """pipeline=True (one HIP engine per process): the all-gather and the global resolve of solve k run on a
+        second stream and overlap the scan of solve k+1 — for back-to-back INDEPENDENT solves (bench.py); a tick
+        that consumes the previous tick's commit cannot overlap and pays the exchange latency in full."""
         self.engines = list(engines)
         self.ex = exchange
         self.ranks = exchange.ranks(len(self.engines))
@@ -187,6 +274,11 @@ class ShardedSolver:
         # ring of gathered-X buffers for back-to-back asynchronous solves (bench)
         self.XG = [e0.new_buffer(self.R * e0.words1) for _ in range(4)]
         self._k = 0
+        self.pipeline = bool(pipeline) and self._ctx is not None and len(self.engines) == 1
+        if self.pipeline:
+            self.side = torch.cuda.Stream(e0.device)
+            self.XR = [e0.new_buffer(e0.words1) for _ in range(4)]   # ring of X records
+            self.done = [None] * 4                                   # side-stream event of the solve that used slot q
 
     def _gather(self, parts, out=None):
         if self._ctx is not None:
@@ -203,6 +295,10 @@ class ShardedSolver:
 
     # -- fast path, asynchronous: scan -> all-gather X -> resolve; nothing waits on the host --
     def solve_async(self):
+        if hasattr(self.ex, "native_solve_async"):
+            return self.ex.native_solve_async()
+        if self.pipeline:
+            return self._solve_async_pipelined()
         xg = self.XG[self._k % len(self.XG)]
         self._k += 1
         for e, x in zip(self.engines, self.X):
@@ -210,6 +306,20 @@ class ShardedSolver:
         self._gather(self.X, out=xg)
         for e, r in zip(self.engines, self.ranks):
             e.resolve(r, self.R, xg)
+
+    def _solve_async_pipelined(self):
+        e, q = self.engines[0], self._k % 4
+        self._k += 1
+        x, xg = self.XR[q], self.XG[q]
+        if self.done[q] is not None:          # slot q's previous exchange must have consumed x / produced xg
+            e.stream.wait_event(self.done[q])
+        e.scan(x)                             # k_scan + k_resolve + pack on the engine's stream
+        ready = e.stream.record_event()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            self.ex.all_gather_into(xg, [x])  # RCCL, ordered against the side stream
+            e.resolve(self.ranks[0], self.R, xg, on_stream=self.side)
+            self.done[q] = self.side.record_event()
 
     # -- finish the LAST enqueued solve: verdict, fix-up exchanges if it needs them, global stats --
     def solve_wait(self):

@@ -116,16 +116,93 @@ def test_hip_shard_rccl_world1_async(gp, oracle):
         cfg = synth.config("c3", n_override=1_000_000)
         case = (cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"] * np.uint64(2), cfg["alive"])
         engines = make_engines(gp, case, [0, cfg["n"]])
-        sol = sharded.ShardedSolver(engines, sharded.DistExchange())
-        for _ in range(6):
-            sol.solve_async()
-        st, n_slow = sol.solve_wait()
         want, used, ost = oracle.tick(*case, 2)
+        for pipeline in (False, True):  # True: exchange + global resolve on a second stream (the bench's default)
+            sol = sharded.ShardedSolver(engines, sharded.DistExchange(), pipeline=pipeline)
+            for _ in range(9):
+                sol.solve_async()
+            st, n_slow = sol.solve_wait()
+            assert n_slow == 0 and st == ost
+            assert np.array_equal(engines[0].g.get_solved(), want)
+        # a pipelined solve that needs the fix-up: same answer as the whole-table oracle
+        tight = (case[0], case[1], case[2], case[3] // np.uint64(3), case[4])
+        engines[0].g.set_nodes(tight[3], tight[4])
+        sol.solve_async()
+        sol.solve_async()
+        st, n_slow = sol.solve_wait()
+        w2, u2, o2 = oracle.tick(*tight, 2)
+        assert n_slow == 2 and st == o2 and np.array_equal(engines[0].g.get_solved(), w2)
+        engines[0].g.set_nodes(case[3], case[4])
+        sol.solve_async()
+        st, n_slow = sol.solve_wait()
         assert n_slow == 0 and st == ost
-        assert np.array_equal(engines[0].g.get_solved(), want)
         sol.commit()
         assert np.array_equal(engines[0].g.get_nodes()[2], used)
         engines[0].g.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hip_shard_native_rccl_world1(gp, oracle):
+    """rio_gp_shard_comm_init + rio_gp_shard_solve_async: the library issues ncclAllGather itself."""
+    import torch
+    import torch.distributed as dist
+    import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)  # control channel only (moves the ncclUniqueId)
+    try:
+        cfg = synth.config("c3", n_override=1_000_000)
+        case = (cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"] * np.uint64(2), cfg["alive"])
+        eng = make_engines(gp, case, [0, cfg["n"]])[0]
+        sol = sharded.ShardedSolver([eng], sharded.NativeRcclExchange(eng))
+        want, used, ost = oracle.tick(*case, 2)
+        for _ in range(9):
+            sol.solve_async()
+        st, n_slow = sol.solve_wait()
+        assert n_slow == 0 and st == ost and np.array_equal(eng.g.get_solved(), want)
+        tight = (case[0], case[1], case[2], case[3] // np.uint64(3), case[4])
+        eng.g.set_nodes(tight[3], tight[4])
+        sol.solve_async()
+        st, n_slow = sol.solve_wait()
+        w2, u2, o2 = oracle.tick(*tight, 2)
+        assert n_slow == 1 and st == o2 and np.array_equal(eng.g.get_solved(), w2)
+        sol.commit()
+        assert np.array_equal(eng.g.get_nodes()[2], u2)
+        eng.g.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hip_shard_p2p_world1(gp, oracle):
+    """Peer-to-peer window path with a single rank: export/connect/handshake, flag-gated import, Y exchanges."""
+    import torch
+    import torch.distributed as dist
+    import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        cfg = synth.config("c3", n_override=1_000_000)
+        case = (cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"] * np.uint64(2), cfg["alive"])
+        eng = make_engines(gp, case, [0, cfg["n"]])[0]
+        sol = sharded.ShardedSolver([eng], sharded.P2PExchange(eng))
+        want, used, ost = oracle.tick(*case, 2)
+        for _ in range(11):
+            sol.solve_async()
+        st, n_slow = sol.solve_wait()
+        assert n_slow == 0 and st == ost and np.array_equal(eng.g.get_solved(), want)
+        tight = (case[0], case[1], case[2], case[3] // np.uint64(3), case[4])
+        eng.g.set_nodes(tight[3], tight[4])
+        sol.solve_async()
+        st, n_slow = sol.solve_wait()
+        w2, u2, o2 = oracle.tick(*tight, 2)
+        assert n_slow == 1 and st == o2 and np.array_equal(eng.g.get_solved(), w2)
+        eng.g.close()
     finally:
         dist.destroy_process_group()
 
@@ -147,7 +224,13 @@ def _proc(rank, world, port, out_dir):
         case = random_case(31, n=200_000, m=48, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
         b = sharded.shard_bounds(len(case[0]), world)
         eng = make_engines(rio_gp, case, [b[rank], b[rank + 1]])[0]
-        sol = sharded.ShardedSolver([eng], sharded.DistExchange(stage_through_host=True))
+        if os.environ.get("RIO_TEST_EXCHANGE") == "p2p":   # IPC-mapped windows between the two processes
+            sol = sharded.ShardedSolver([eng], sharded.P2PExchange(eng))
+            for _ in range(5):
+                sol.solve_async()   # back-to-back steps: slot reuse and sequence flags across processes
+            sol.solve_wait()
+        else:
+            sol = sharded.ShardedSolver([eng], sharded.DistExchange(stage_through_host=True))
         st = sol.tick()
         np.savez(os.path.join(out_dir, "g%d.npz" % rank), a=eng.g.get_assign(), used=eng.g.get_nodes()[2],
                  st=np.array([st[k] for k in sorted(st)], np.uint64))
@@ -156,9 +239,11 @@ def _proc(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_hip_shards_two_processes_one_gpu(gp, oracle, tmp_path):
+@pytest.mark.parametrize("exchange", ["gloo", "p2p"])
+def test_hip_shards_two_processes_one_gpu(gp, oracle, tmp_path, exchange):
     import torch.multiprocessing as mp
     from test_sharded_protocol import random_case
+    os.environ["RIO_TEST_EXCHANGE"] = exchange
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_proc, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     case = random_case(31, n=200_000, m=48, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
