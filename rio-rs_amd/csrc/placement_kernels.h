@@ -18,7 +18,8 @@ constexpr int kWaves = 16;           // waves per workgroup of the streaming ker
 constexpr int kBlock = kWaves * 64;  // 1024 threads: ONE workgroup per CU owns one LDS histogram
 constexpr int kTile = 256;           // objects per wave-iteration: 64 lanes x dwordx4
 constexpr u32 kMaxBlocks = 256;      // = CUs; rows of the per-block histogram table
-constexpr u32 kMaxSubs = 256;        // sub-chunks per block for the exact-cut refinement
+constexpr u32 kMaxSubs = 256;
+constexpr int kSmallBatch = 256;     // place_pending / lookup micro-batches served by one workgroup and one launch        // sub-chunks per block for the exact-cut refinement
 
 // Work decomposition of a table of n rows.  Index order is the only order that matters:
 // the table is `tiles` tiles of kTile rows; wave `gw` (of nw = G*kWaves) owns the contiguous tiles
@@ -117,6 +118,10 @@ void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32*
 void launch_count_placed(const u32* assign, u64 n_obj, DevStats* st, hipStream_t s);
 void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipStream_t s);
 
+// --- place_pending, micro-batch (n <= kSmallBatch): one launch; idx/req/out_* may be mapped host memory; *status = 1
+//     means "needs the general path", nothing was changed ---
+void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
+                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s);

@@ -1118,6 +1118,83 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
 
 
 // ------------------------------------------------------------------------------------------------
+// place_pending, small batches (n <= kSmallBatch): the whole policy of service.rs:193-298 for a
+// micro-batch in ONE workgroup and ONE launch — request and result arrays are pinned host memory
+// mapped into the device (no staging copies), so a call is a launch and a wait.
+// Handles the common case completely: sticky hits (LOCAL / REDIRECT), first touch on a live
+// requester with room (PLACED), duplicates of one object in the batch.  Anything that needs the
+// heavy machinery — a requested object sitting on a dead node (clean_server of that node), a dead
+// requester, a full requester (water-fill) — makes it return status 1 having changed NOTHING, and
+// the caller runs the general path.  Results are identical either way (same ordered-prefix rule).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assign, const u32* __restrict__ load,
+                                                          u32 m, const u64* __restrict__ cap,
+                                                          const u32* __restrict__ alive_bits, u64* __restrict__ used,
+                                                          u32* __restrict__ pos, const u32* __restrict__ idx,
+                                                          const u32* __restrict__ req, u32 n,
+                                                          u32* __restrict__ out_node, u32* __restrict__ out_flag,
+                                                          u32* __restrict__ status) {
+    __shared__ u32 s_req[kSmallBatch], s_load[kSmallBatch], s_res[kSmallBatch];
+    __shared__ u32 s_general;
+    const u32 k = threadIdx.x;
+    const bool valid = k < n;
+    if (k == 0) s_general = 0;
+    u32 i = 0, r = 0, c = kNone, l = 0;
+    if (valid) {
+        i = idx[k];
+        r = req[k];
+        c = assign[i];
+        l = load[i];
+        atomicMin(&pos[i], k);  // the first request of an object decides (batch order)
+    }
+    __syncthreads();
+    bool first = false, claim = false;
+    u32 winner = k;
+    if (valid) {
+        winner = __hip_atomic_load(&pos[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        first = winner == k;
+        const bool dead_cur = c < m && !bit_of(alive_bits, c);   // service.rs:227-237 -> clean_server: general path
+        const bool pending = first && c == kNone;
+        claim = pending && bit_of(alive_bits, r);
+        if (dead_cur || (pending && !claim)) s_general = 1;
+    }
+    s_req[k] = claim ? r : kNone;
+    s_load[k] = claim ? l : 0;
+    __syncthreads();
+    u32 nd = c;
+    if (claim) {  // index-ordered inclusive prefix of the loads claiming requester r
+        u64 pre = 0;
+        for (u32 q = 0; q <= k; ++q) pre += (s_req[q] == r) ? (u64)s_load[q] : 0ull;
+        const u64 cj = cap[r], uj = used[r];
+        const u64 fre = cj > uj ? cj - uj : 0;
+        if (pre <= fre) nd = r;
+        else s_general = 1;  // requester full: water-fill needed
+    }
+    s_res[k] = nd;
+    __syncthreads();
+    if (s_general) {  // hand over untouched
+        if (valid) pos[i] = kNone;
+        if (k == 0) *status = 1;
+        return;
+    }
+    if (valid) {
+        u32 fl;
+        if (claim) {  // first touch (service.rs:244-252)
+            assign[i] = r;
+            atomicAdd(&used[r], (u64)l);
+            fl = 2u;  // PLACED
+        } else {
+            nd = first ? c : s_res[winner];  // later duplicates observe what the first request decided
+            fl = (nd == kNone) ? 4u : (nd == r ? 0u : 1u);
+        }
+        out_node[k] = nd;
+        out_flag[k] = fl;
+        pos[i] = kNone;
+    }
+    if (k == 0) *status = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-sharded solve: rank r owns the contiguous rows [off_r, off_r + n_r); shard order
 // = index order, node tables are replicated.  The only cross-rank data are M-vectors:
 //   exchange #1  X_r = [kept_local[m] | claim_local[m] | 8 counters]          (every solve)
@@ -1554,6 +1631,11 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
     const u32 w = (m + 31) / 32;
     if (!w) return;
     hipLaunchKernelGGL(k_pack_alive, dim3((w + 63) / 64), dim3(64), 0, s, alive_bytes, m, alive_bits);
+}
+void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
+                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_pp_small, dim3(1), dim3(kSmallBatch), 0, s, assign, load, m, cap, alive_bits, used, pos, idx, req, n,
+                       out_node, out_flag, status);
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s) {

@@ -126,6 +126,9 @@ struct rio_gp {
     bool sh_slow = false;   // the solve in flight took the fix-up path
     u32 sh_slot = 0;        // verdict slot of the last rio_gp_shard_resolve
     hipStream_t sh_side = nullptr;  // stream the last rio_gp_shard_resolve ran on, when not the handle's
+    // micro-batch staging: pinned host memory mapped into the device, [5][kSmallBatch] u32 = idx | req | node | flag | status
+    u32* h_small = nullptr;
+    u32* d_small = nullptr;
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
     std::vector<void*> allocs;
@@ -401,6 +404,12 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     memset(h->h_slots, 0, (size_t)kRing * h->slot_rows * 8 * sizeof(u64));
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_small), (size_t)5 * kSmallBatch * sizeof(u32), hipHostMallocMapped) !=
+            hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_small), h->h_small, 0) != hipSuccess) {
+        h->err = "hipHostMalloc(mapped micro-batch staging) failed";
+        return bail(RIO_GP_ENOMEM);
+    }
     // every row starts unplaced; the position scratch is all-ones between calls
     launch_fill_u32(h->assign[0], R, kNone, h->stream);
     launch_fill_u32(h->assign[1], R, kNone, h->stream);
@@ -429,6 +438,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_slots) (void)hipHostFree(h->h_slots);
+    if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -634,6 +644,14 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
     if (!n) return RIO_GP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
+    if (n <= (uint64_t)kSmallBatch) {  // micro-batch: the gather reads and writes mapped pinned memory, one launch + wait
+        memcpy(h->h_small, idx, n * sizeof(u32));
+        launch_lookup(h->assign[h->cur], h->n, h->d_small, n, h->d_small + 2 * kSmallBatch, h->dstats, h->stream);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        memcpy(out_node, h->h_small + 2 * kSmallBatch, n * sizeof(u32));
+        return RIO_GP_OK;
+    }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;
     u32 *d_idx = (u32*)h->stage[0].p, *d_out = (u32*)h->stage[1].p;
     HIPCHK(h, hipMemcpyAsync(d_idx, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
@@ -758,6 +776,27 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
     if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: batch too large");
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
+    if (n <= (uint64_t)kSmallBatch) {
+        // micro-batch: one workgroup, one launch, request/result arrays in mapped pinned memory (no staging copies)
+        if ((rc = ensure_used(h))) return rc;
+        u32 *hs = h->h_small, *ds = h->d_small;
+        memcpy(hs, idx, n * sizeof(u32));
+        memcpy(hs + kSmallBatch, requester, n * sizeof(u32));
+        hs[4 * kSmallBatch] = 2;  // neither 0 nor 1: the kernel must write it
+        launch_pp_small(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, h->pos, ds, ds + kSmallBatch,
+                        (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        const u32 status = hs[4 * kSmallBatch];
+        if (status == 0) {
+            memcpy(out_node, hs + 2 * kSmallBatch, n * sizeof(u32));
+            if (out_flag) memcpy(out_flag, hs + 3 * kSmallBatch, n * sizeof(u32));
+            h->have_solved = false;
+            return RIO_GP_OK;
+        }
+        if (status != 1) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_place_pending: micro-batch kernel left no status");
+        // status 1: a dead node / dead or full requester is involved — nothing was changed, take the general path
+    }
     const size_t bytes = n * sizeof(u32);
     for (int q = 0; q < 4; ++q) {
         if ((rc = ensure(h, h->stage[q], bytes))) return rc;

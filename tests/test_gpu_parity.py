@@ -326,6 +326,48 @@ def test_place_pending_random(gp, oracle, seed, cap_inf):
     g.close()
 
 
+@pytest.mark.parametrize("seed,cap_mode", [(0, "inf"), (1, "tight"), (2, "roomy"), (3, "tight")])
+def test_place_pending_micro_batches(gp, oracle, seed, cap_mode):
+    """Batches of 1..256 requests take the one-launch micro-batch kernel (k_pp_small) when nothing heavy is
+    involved and the general path otherwise; the request stream below mixes both (duplicates inside a batch, dead
+    current nodes, dead and full requesters, zero-load objects) and every call must equal the sequential oracle."""
+    rng = np.random.default_rng(4000 + seed)
+    n, m = 3000, int(rng.integers(2, 40))
+    load = rng.integers(0, 9, n).astype(np.uint32)
+    cap = {"inf": np.full(m, INF, np.uint64),
+           "tight": rng.integers(0, 40, m).astype(np.uint64),
+           "roomy": np.full(m, int(load.sum()), np.uint64)}[cap_mode]
+    alive = np.ones(m, np.uint8)
+    g = gp.GpuPlacement(n, m, spill_rounds=2)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step in range(120):
+        if step % 17 == 5:
+            j = int(rng.integers(m))
+            alive[j] ^= 1
+            g.set_alive(j, alive[j])
+        if step % 29 == 7:   # raw CRUD in between: `used` has to be rebuilt before the next micro-batch
+            ii = rng.integers(0, n, 20).astype(np.uint32)
+            g.remove_batch(ii)
+            oracle.remove_batch(ref, ii)
+            used[:] = oracle.recompute_used(ref, load, m)
+        k = int(rng.choice([1, 1, 2, 3, 7, 32, 64, 200, 256]))
+        idx = rng.integers(0, min(n, 40 + 30 * step), k).astype(np.uint32)   # small id range: plenty of duplicates
+        req = rng.integers(0, m, k).astype(np.uint32)
+        node, flag = g.place_pending(idx, req)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(node, wnode) and np.array_equal(flag, wflag), (step, k)
+        assert np.array_equal(g.lookup_batch(idx), ref[idx])
+        if step % 10 == 0:
+            assert np.array_equal(g.get_assign(), ref)
+            assert np.array_equal(g.get_nodes()[2], used)
+    assert np.array_equal(g.get_assign(), ref)
+    assert np.array_equal(g.get_nodes()[2], used)
+    g.close()
+
+
 def test_config1_ping_pong_plumbing(gp, oracle):
     """BASELINE config 1: 1 000 objects x 4 nodes: 1 000 misses -> first touch -> 1 000 hits ->
     clean_server(node 2) -> re-place, against the string-level reference policy."""
