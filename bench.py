@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 only: run the row-sharded path (RCCL group of one rank) to price its extra kernels and launches")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_traffic.json"),
                     help="PMC-derived HBM bytes per k_scan launch (tools/pmc_traffic.py); null if absent")
     return ap.parse_args()
 
