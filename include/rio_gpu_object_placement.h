@@ -90,6 +90,14 @@ int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* co
                                          const char* const* object_ids, const char* const* self_addresses,
                                          uint32_t* out_node_ids, uint32_t* out_flags);
 
+/* Durable twin of the table: every placed entry as (struct_name, object_id, server_address) —
+ * the columns of the reference's object_placement table (migrations/0001-sqlite-init.sql:1-9; written by
+ * sqlite.rs:68-85).  The arrays belong to the handle and stay valid until its next call.  Loading a snapshot is
+ * rio_op_update_batch.  rio-rs_amd/snapshot.py moves them to and from a SQLite file in that schema, so a GPU-backed
+ * server can warm-start from, or write back to, the placement DB of a SqliteObjectPlacement deployment. */
+int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_names, const char* const** object_ids,
+                    const char* const** server_addresses);
+
 /* Whole-table re-solve over the interned tables (rio_gp_tick). */
 int rio_op_tick(rio_op_t* p, rio_gp_stats* stats);
 /* The dense handle underneath (borrowed). */

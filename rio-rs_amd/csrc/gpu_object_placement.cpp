@@ -24,6 +24,8 @@ struct State {
     uint64_t max_objects = 0;
     uint32_t max_nodes = 0;
     std::unordered_map<std::string, uint32_t> rows;   // "{type}.{id}" -> dense row (local.rs:26-29)
+    std::vector<std::pair<std::string, std::string>> row_key;  // row -> the (struct_name, object_id) it was first interned as
+    std::vector<const char*> snap_ty, snap_id, snap_addr;      // last rio_op_snapshot (pointers into row_key / node_addr)
     std::unordered_map<std::string, uint32_t> nodes;  // address -> node id
     std::vector<std::string> node_addr;
     std::vector<uint8_t> node_alive, node_malformed;
@@ -85,7 +87,8 @@ int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, b
     return RIO_GP_OK;
 }
 
-int intern_row(State* s, const std::string& key, bool create, uint32_t* out) {
+int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* out) {
+    const std::string key = key_of(ty, id);
     auto it = s->rows.find(key);
     if (it != s->rows.end()) {
         *out = it->second;
@@ -96,9 +99,10 @@ int intern_row(State* s, const std::string& key, bool create, uint32_t* out) {
         return RIO_GP_OK;
     }
     if (s->rows.size() >= s->max_objects) return fail(s, RIO_GP_EINVAL, "object table full (max_objects)");
-    const uint32_t id = (uint32_t)s->rows.size();
-    s->rows.emplace(key, id);
-    *out = id;
+    const uint32_t row = (uint32_t)s->rows.size();
+    s->rows.emplace(key, row);
+    s->row_key.emplace_back(ty ? ty : "", id ? id : "");
+    *out = row;
     return RIO_GP_OK;
 }
 
@@ -202,10 +206,10 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
         uint32_t row = RIO_GP_NONE, node = RIO_GP_NONE;
         int rc;
         if (addrs[k]) {  // Some(address): entry(key) = address
-            if ((rc = intern_row(s, key_of(tys[k], ids[k]), true, &row))) return rc;
+            if ((rc = intern_row(s, tys[k], ids[k], true, &row))) return rc;
             if ((rc = intern_node(s, addrs[k], true, &node, &created))) return rc;
         } else {         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
-            if ((rc = intern_row(s, key_of(tys[k], ids[k]), false, &row))) return rc;
+            if ((rc = intern_row(s, tys[k], ids[k], false, &row))) return rc;
             if (row == RIO_GP_NONE) continue;
         }
         rows.push_back(row);
@@ -229,7 +233,7 @@ int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
     std::vector<uint32_t> rows, where;
     for (uint64_t k = 0; k < n; ++k) {
         uint32_t row;
-        int rc = intern_row(s, key_of(tys[k], ids[k]), false, &row);
+        int rc = intern_row(s, tys[k], ids[k], false, &row);
         if (rc) return rc;
         out[k] = RIO_GP_NONE;  // unknown key: Ok(None)
         if (row != RIO_GP_NONE) {
@@ -275,7 +279,7 @@ int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
     uint32_t row;
-    int rc = intern_row(s, key_of(ty, id), false, &row);
+    int rc = intern_row(s, ty, id, false, &row);
     if (rc) return rc;
     if (row == RIO_GP_NONE) return RIO_GP_OK;  // absent: no-op (local.rs:60-68)
     rc = rio_gp_remove_batch(s->gp, 1, &row);
@@ -308,7 +312,7 @@ int rio_op_set_object_load(rio_op_t* p, const char* ty, const char* id, uint32_t
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
     uint32_t row;
-    int rc = intern_row(s, key_of(ty, id), true, &row);
+    int rc = intern_row(s, ty, id, true, &row);
     if (rc) return rc;
     rc = rio_gp_set_object_attrs(s->gp, 1, &row, &load, nullptr);
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
@@ -323,7 +327,7 @@ int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* co
     bool created = false;
     for (uint64_t k = 0; k < n; ++k) {
         int rc;
-        if ((rc = intern_row(s, key_of(tys[k], ids[k]), true, &rows[k]))) return rc;
+        if ((rc = intern_row(s, tys[k], ids[k], true, &rows[k]))) return rc;
         const size_t before = s->node_addr.size();
         if ((rc = intern_node(s, selfs[k], true, &reqs[k], &created))) return rc;
         if (s->node_addr.size() != before) s->node_alive[reqs[k]] = 1;  // a server answering requests is up
@@ -342,6 +346,29 @@ int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, 
     if (flag) *flag = fl;
     std::lock_guard<std::mutex> g(p->s->mu);
     copy_out(node == RIO_GP_NONE ? std::string() : p->s->node_addr[node], out, cap);
+    return RIO_GP_OK;
+}
+
+int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_names, const char* const** object_ids,
+                    const char* const** server_addresses) {
+    if (!p || !n_out || !struct_names || !object_ids || !server_addresses) return RIO_GP_EINVAL;
+    State* s = p->s;
+    std::lock_guard<std::mutex> g(s->mu);
+    std::vector<uint32_t> assign(s->max_objects);
+    int rc = rio_gp_get_assign(s->gp, s->max_objects, assign.data());
+    if (rc) return gp_fail(s, rc);
+    s->snap_ty.clear(); s->snap_id.clear(); s->snap_addr.clear();
+    for (size_t row = 0; row < s->row_key.size(); ++row) {
+        const uint32_t nd = assign[row];
+        if (nd == RIO_GP_NONE || nd >= s->node_addr.size()) continue;
+        s->snap_ty.push_back(s->row_key[row].first.c_str());
+        s->snap_id.push_back(s->row_key[row].second.c_str());
+        s->snap_addr.push_back(s->node_addr[nd].c_str());
+    }
+    *n_out = s->snap_ty.size();
+    *struct_names = s->snap_ty.data();
+    *object_ids = s->snap_id.data();
+    *server_addresses = s->snap_addr.data();
     return RIO_GP_OK;
 }
 

@@ -328,6 +328,8 @@ def _oplib():
                                                      C.POINTER(C.c_uint32)]
         L.rio_op_get_or_create_placement_batch.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
         L.rio_op_tick.argtypes = [_vp, C.POINTER(Stats)]
+        L.rio_op_snapshot.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_char_p)),
+                                      C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_char_p))]
         L.rio_op_dense.argtypes = [_vp]
         L.rio_op_dense.restype = _vp
         _op_ready = True
@@ -434,3 +436,10 @@ class GpuObjectPlacement:
         st = Stats()
         self._chk(_oplib().rio_op_tick(self._h, C.byref(st)))
         return st.as_dict()
+
+    def snapshot(self):
+        """Every placed entry as (struct_name, object_id, server_address) — the reference's table columns."""
+        n = C.c_uint64(0)
+        ty, oid, addr = C.POINTER(C.c_char_p)(), C.POINTER(C.c_char_p)(), C.POINTER(C.c_char_p)()
+        self._chk(_oplib().rio_op_snapshot(self._h, C.byref(n), C.byref(ty), C.byref(oid), C.byref(addr)))
+        return [(ty[k].decode(), oid[k].decode(), addr[k].decode()) for k in range(n.value)]

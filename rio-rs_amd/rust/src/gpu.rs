@@ -32,6 +32,15 @@ struct RioOpCfg {
 
 const RIO_GP_OK: c_int = 0;
 const RIO_GP_EINVAL: c_int = 1;
+/// `rio_gp_stats` (include/rio_gpu_placement.h): counters of one whole-table solve.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct RioGpStats {
+    pub n_objects: u64, pub kept: u64, pub evicted: u64, pub claimed: u64, pub spilled: u64, pub unplaced: u64,
+    pub load_kept: u64, pub load_claimed: u64, pub load_spilled: u64, pub load_unplaced: u64,
+    pub cut_nodes: u32, pub slow_path: u32, pub rounds_run: u32, pub reserved: u32,
+}
+
 pub const FLAG_LOCAL: u32 = 0;
 pub const FLAG_REDIRECT: u32 = 1;
 pub const FLAG_PLACED: u32 = 2;
@@ -50,6 +59,9 @@ extern "C" {
     fn rio_op_clean_server(p: *mut c_void, addr: *const c_char) -> c_int;
     fn rio_op_remove(p: *mut c_void, ty: *const c_char, id: *const c_char) -> c_int;
     fn rio_op_set_member(p: *mut c_void, addr: *const c_char, active: c_int, capacity: u64) -> c_int;
+    fn rio_op_tick(p: *mut c_void, stats: *mut RioGpStats) -> c_int;
+    fn rio_op_snapshot(p: *mut c_void, n_out: *mut u64, tys: *mut *const *const c_char, ids: *mut *const *const c_char,
+                       addrs: *mut *const *const c_char) -> c_int;
     fn rio_op_get_or_create_placement(p: *mut c_void, ty: *const c_char, id: *const c_char,
                                       self_addr: *const c_char, out: *mut c_char, cap: usize,
                                       flag: *mut u32) -> c_int;
@@ -120,6 +132,25 @@ impl GpuObjectPlacement {
                                                       buf.as_mut_ptr(), buf.len(), &mut flag) }, self)?;
         let s = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
         Ok((if flag == FLAG_UNPLACED { None } else { Some(s) }, flag))
+    }
+}
+
+impl GpuObjectPlacement {
+    /// Eager rebalance (the batched form of the lazy `clean_server` + first-touch path):
+    /// every object gets a decision in one call; evicted objects are re-placed at once.
+    pub fn tick(&self) -> Result<RioGpStats, ObjectPlacementError> {
+        let mut st = RioGpStats::default();
+        check(unsafe { rio_op_tick(self.inner.0, &mut st) }, self)?;
+        Ok(st)
+    }
+
+    /// Every placed entry as `(struct_name, object_id, server_address)` — the columns of the reference's
+    /// `object_placement` table, e.g. to write back through `SqliteObjectPlacement::update`.
+    pub fn snapshot(&self) -> Result<Vec<(String, String, String)>, ObjectPlacementError> {
+        let (mut n, mut ty, mut id, mut ad) = (0u64, std::ptr::null(), std::ptr::null(), std::ptr::null());
+        check(unsafe { rio_op_snapshot(self.inner.0, &mut n, &mut ty, &mut id, &mut ad) }, self)?;
+        let s = |p: *const *const c_char, k: usize| unsafe { CStr::from_ptr(*p.add(k)).to_string_lossy().into_owned() };
+        Ok((0..n as usize).map(|k| (s(ty, k), s(id, k), s(ad, k))).collect())
     }
 }
 

@@ -170,3 +170,46 @@ def test_random_differential_vs_reference_restatement(gp, oracle, seed):
         assert p.lookup(ty, oid) == o.lookup(ty, oid)
     assert len(p) == len(o)
     assert p.lookup_batch(keys) == [o.lookup(*k) for k in keys]
+
+
+def test_snapshot_round_trip_in_the_reference_schema(gp, tmp_path):
+    """dump -> a SQLite file in the reference's layout -> readable by the REFERENCE's own SELECT
+    (sqlite.rs:87-93, text carried by the golden fixture) -> load into a fresh table; and the other way round:
+    a DB built with the reference's DDL + upsert text warm-starts the GPU table."""
+    import json
+    import re
+    import sqlite3
+    import snapshot
+    sql = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sql_backend_golden.json")))["sql"]
+    bind = lambda stmt: re.sub(r"\$(\d)", r"?\1", stmt)
+    a = gp.GpuObjectPlacement(max_objects=4096, max_nodes=16)
+    keys = [("Room", str(i)) for i in range(300)] + [("a.b", "c"), ("Metric", "x:y")]
+    addrs = ["10.0.0.%d:5000" % (i % 7) for i in range(len(keys))]
+    a.update_batch(keys, addrs)
+    a.remove("Room", "7")
+    a.clean_server("10.0.0.3:5000")
+    want = {k: a.lookup(*k) for k in keys}
+    path = str(tmp_path / "placement.sqlite3")
+    n = snapshot.dump_sqlite(a, path)
+    assert n == sum(v is not None for v in want.values()) == len(a)
+    db = sqlite3.connect(path)
+    for k, v in want.items():   # the reference's lookup statement against OUR file
+        row = db.execute(bind(sql["select"]), k).fetchone()
+        assert (row[0] if row else None) == v
+    db.close()
+    b = gp.GpuObjectPlacement(max_objects=4096, max_nodes=16)
+    assert snapshot.load_sqlite(b, path) == n
+    assert {k: b.lookup(*k) for k in keys} == want
+    # a database written by the reference's own DDL + upsert text
+    path2 = str(tmp_path / "reference.sqlite3")
+    db = sqlite3.connect(path2)
+    db.executescript(sql["ddl"])
+    for k, v in zip(keys, addrs):
+        db.execute(bind(sql["upsert"]), (k[0], k[1], v))
+    db.execute(bind(sql["upsert"]), ("Room", "1", "10.9.9.9:1"))   # upsert overwrites (sqlite.rs:149-193)
+    db.commit(); db.close()
+    c = gp.GpuObjectPlacement(max_objects=4096, max_nodes=16)
+    assert snapshot.load_sqlite(c, path2) == len(keys)
+    assert c.lookup("Room", "1") == "10.9.9.9:1" and c.lookup("a.b", "c") == addrs[300] and len(c) == len(keys)
+    for x in (a, b, c):
+        x.close()
