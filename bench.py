@@ -39,6 +39,10 @@ def parse():
                     help="sharded runs: how the per-rank load records travel — p2p: stores into the peers' HBM windows over "
                          "xGMI, no collective call; native: ncclAllGather issued by the library; torch: torch.distributed "
                          "all_gather.  Falls back p2p -> native -> torch if a path cannot be set up")
+    ap.add_argument("--backend", default="nccl", help="control-plane backend; 'gloo' only for --same-device flow tests")
+    ap.add_argument("--same-device", action="store_true",
+                    help="flow test on a 1-GPU box: every rank uses device 0 (RCCL refuses that, so use --backend gloo; "
+                         "the peer-to-peer windows work between processes on one device); numbers are meaningless")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded runs: keep the all-gather on the scan stream (no overlap with the next solve's scan)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -102,13 +106,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     rio_gp.build()
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or a.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     n_over = a.objects or None
     per_rank = synth.config(a.workload, n_override=n_over, start=0)  # shapes only
@@ -117,7 +126,7 @@ def main():
     # index order); capacities are set from the GLOBAL load, exactly as the unsharded config would
     cfg = synth.config(a.workload, n_override=n_local, start=rank * n_local) if world > 1 else per_rank
     n, m = cfg["n"], cfg["m"]
-    if dist is not None and a.workload != "c2":
+    if dist is not None:
         tot = torch.tensor([int(cfg["load"].astype(np.uint64).sum())], device="cuda", dtype=torch.int64)
         dist.all_reduce(tot)  # set-up only, not the data path
         cfg["cap"] = np.full(m, -((-int(tot.item()) * 1250) // (1000 * m)), dtype=np.uint64)
@@ -213,7 +222,8 @@ def main():
     achieved = (ALGO_BYTES_PER_DECISION * n / (scan_avg * 1e-3) / 1e9) if scan_avg else None
     traffic = None
     if a.traffic_json and os.path.exists(a.traffic_json):
-        traffic = json.load(open(a.traffic_json)).get("hbm_bytes_per_launch")
+        tj = json.load(open(a.traffic_json))
+        traffic = tj.get("hbm_bytes_per_launch") if tj.get("n_rows") == n else None  # measured for this row count only
     out = {
         "metric": "placement decisions/sec + achieved HBM GB/s, 10M objects x 1 024 nodes",
         "value": total_decisions / dt, "unit": "decisions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -223,12 +233,14 @@ def main():
                                "(all pending)" % (n, m) if a.workload == "c3" else a.workload,
                    "objects_per_gpu": n, "nodes": m, "parallelism": "rows sharded x%d" % world,
                    "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end" if dist is None
-                           else "row-sharded solve: k_scan + k_resolve + pack -> RCCL all-gather of %d B/rank -> k_shard_import, "
-                                "%s; verdicts read at the end; collective issued by %s" % (
-                                    8 * (2 * m + 8), "one stream" if (a.no_pipeline and a.exchange == "torch") else
-                                    "exchange + import on a second stream, overlapping the next solve's scan",
-                                    {"p2p": "nobody: peer-to-peer stores into the peers' windows + sequence flags, one stream",
-                                     "native": "the library (ncclAllGather)", "torch": "torch.distributed"}[a.exchange]),
+                           else {"p2p": "row-sharded solve: k_scan -> k_resolve_put (local sums stored straight into every peer's HBM "
+                                        "window over xGMI, %d B/rank, sequence flag last) -> k_shard_import (waits in-kernel for all "
+                                        "flags); one stream, three launches, no collective call; verdicts read at the end",
+                                 "native": "row-sharded solve: k_scan + k_resolve + pack -> ncclAllGather of %d B/rank issued by the "
+                                           "library on a second stream -> k_shard_import; verdicts read at the end",
+                                 "torch": "row-sharded solve: k_scan + k_resolve + pack -> torch.distributed all_gather (RCCL) of %d "
+                                          "B/rank -> k_shard_import; verdicts read at the end"}[a.exchange] % (8 * (2 * m + 8)),
+                   "exchange": None if dist is None else a.exchange,
                    "slow_path_steps": n_slow},
         "gpu_ms_per_step_events": gpu_ms / a.steps,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -1,0 +1,46 @@
+"""bench.py's launch contract, exercised on the GPU box: the N=1 line, and the N=2 flow exactly as the driver
+starts it (python -m torch.distributed.run ... bench.py --gpus 2) — with both ranks on the one GPU a gpurun box
+has (gloo control plane, peer-to-peer windows between the two processes).  stdout must be ONE JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _one_json_line(out):
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]
+    return json.loads(lines[0])
+
+
+def test_bench_line_n1():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--workload", "c2",
+                        "--cpu-sample", "20000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["unit"] == "decisions/s" and d["value"] > 1e9
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["stats_last_step"]["claimed"] + d["stats_last_step"]["spilled"] + d["stats_last_step"]["unplaced"] == 1000000
+
+
+@pytest.mark.parametrize("exchange", ["p2p", "torch"])
+def test_bench_two_ranks_as_the_driver_launches_it(exchange):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+           "--workload", "c2", "--objects", "500000", "--no-cpu-baseline", "--backend", "gloo", "--same-device", "--exchange", exchange]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["objects_per_gpu"] == 500000
+    assert d["stats_last_step"]["n_objects"] == 1000000      # global counters: both shards
+    assert d["config"]["slow_path_steps"] == 0
+    # gloo cannot all-gather device tensors, so the torch path is expected to drop... to nothing: it IS the last rung
+    assert d["config"]["exchange"] in ("p2p", "torch")
