@@ -276,6 +276,9 @@ int rio_gp_timer_end(rio_gp_t* h, float* ms);
  * resolve_ms = k_resolve.  Does not publish; fails with RIO_GP_EINVAL if the solve needs the
  * cut/spill fix-up (use rio_gp_solve then). */
 int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms);
+/* A/B and test knob: packed fix-up (fix-up passes over the pending rows only) 0 = adaptive (default: used when the
+ * previous solve left <= 25 % of the rows pending), 1 = always, 2 = never.  Results are identical in every mode. */
+int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 /* A/B knob for tools/sweep_scan.py: tiles per wave-iteration of k_scan (1 | 2 | 4); process-wide. */
 void rio_gp_debug_set_scan_tpi(int tpi);
 /* Measurement aid: pure streaming kernels with k_scan's traffic mix (3 columns in, 1 out) over the handle's

@@ -34,6 +34,8 @@ struct Plan {
     u32 subs;    // sub-chunks per block (<= kMaxSubs)
     u32 m;       // nodes
     u32 mwords;  // ceil(m/32)
+    // packed fix-up (see PackOut): when set, wave gw's rows are only the first wcnt[gw] positions of its range
+    const u32* wcnt;
 };
 Plan make_plan(u64 n, u32 m, u32 max_blocks);
 
@@ -75,6 +77,18 @@ struct SolveBufs {
     DevStats* stats;
 };
 
+// Packed pending rows (k_scan<COMPACT>): wave gw copies its PENDING rows, in index order, to the front of its own
+// row range in these scratch columns and records how many (wcnt[gw]).  The fix-up kernels then run unchanged over
+// {cur = an all-NONE column, load, aff, next} with Plan::wcnt set, so their passes cost O(pending rows) instead of
+// O(rows); k_pk_scatter writes the decisions back through `idx`.  Index order is preserved: (wave, packed position).
+struct PackOut {
+    u32* idx;
+    u32* load;
+    u32* aff;
+    u32* next;
+    u32* wcnt;  // [G*kWaves]
+};
+
 // table columns; for the real table cur/next are the ping-pong assignment columns
 struct Table {
     const u32* cur;
@@ -91,7 +105,9 @@ struct NodeTab {
 
 // --- solve pipeline ---
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
-                 hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                 hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const PackOut* pack = nullptr);
+// next[idx[pos]] = pk_next[pos] over every wave's packed rows (p.wcnt set)
+void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t s);
 // host_partial: pinned host rows [resolve_blocks(m)][8] = load_kept, load_claim_tot, n_cut, kept, evicted,
 // claimants, spillcand, present — the caller adds the rows up (no atomics / copy kernel on the stream)
 void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,

@@ -77,6 +77,17 @@ __device__ __forceinline__ void wave_range(const Plan& p, u64 gw, u64& wstart, u
     wend = wave_row_lo(p, gw + 1);
     if (wend > p.n) wend = p.n;
     if (wstart > wend) wstart = wend;
+    if (p.wcnt) {  // packed fix-up: only the first wcnt[gw] positions of the range hold rows
+        const u64 e = wstart + p.wcnt[gw];
+        if (e < wend) wend = e;
+    }
+}
+// the wave whose range contains row position i (inverse of wave_row_lo), and whether i is a live packed position
+__device__ __forceinline__ bool packed_live(const Plan& p, u64 i) {
+    if (!p.wcnt) return true;
+    const u64 tile = i / kTile;
+    const u64 gw = ((tile + 1) * p.nw - 1) / p.tiles;
+    return i - wave_row_lo(p, gw) < p.wcnt[gw];
 }
 __device__ __forceinline__ u64 block_row_lo(const Plan& p, u32 b) { return wave_row_lo(p, (u64)b * kWaves); }
 constexpr int kSmall = 128;  // bytes of small per-block scratch at the head of the dynamic LDS region
@@ -87,6 +98,7 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     p.n = n;
     p.m = m;
     p.mwords = (m + 31) / 32;
+    p.wcnt = nullptr;
     if (max_blocks == 0 || max_blocks > kMaxBlocks) max_blocks = kMaxBlocks;
     u64 tiles = (n + kTile - 1) / kTile;
     if (tiles == 0) tiles = 1;
@@ -137,13 +149,14 @@ __device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv) {
 //     counters are wave-uniform popcounts of ballots) so the next tile's three dwordx4 loads stay
 //     in flight under a counted vmcnt while the current tile is processed.
 // ------------------------------------------------------------------------------------------------
-template <bool VIRT, bool ALLALIVE, bool CHECK, int HMODE = 0>
+template <bool VIRT, bool ALLALIVE, bool CHECK, int HMODE = 0, bool COMPACT = false>
 __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const uint4 lv, const u64 i0, const u64 wend,
                                           const u32 m, const u32* alv, u64* hist, u32* __restrict__ next,
-                                          u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt) {
+                                          u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt,
+                                          const PackOut* pk = nullptr, u64* pk_pos = nullptr) {
     uint4 ov;
     u64 sp_local = 0;
-    u32 any_sp = 0;
+    u32 any_sp = 0, pm = 0;
 #define RIOGP_ROW(C, A, L, O, E)                                                                       \
     {                                                                                                  \
         const bool inr = !CHECK || (i0 + E < wend);                                                    \
@@ -162,12 +175,28 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         if (!VIRT) evict_cnt += (u32)__popcll(__ballot(inr && !kept && C != kNone));                   \
         sp_local += sp ? (u64)L : 0;                                                                   \
         any_sp |= sp;                                                                                  \
+        if (COMPACT) pm |= (u32)(cl | sp) << E;                                                        \
     }
     RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
     RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
     RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
     RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
 #undef RIOGP_ROW
+    if (COMPACT) {  // pending rows of this tile, in index order (lane-major, then element), to the wave's packed cursor
+        const u64 b0 = __ballot(pm & 1u), b1 = __ballot(pm & 2u), b2 = __ballot(pm & 4u), b3 = __ballot(pm & 8u);
+        if (b0 | b1 | b2 | b3) {
+            const u64 lt = (1ull << (threadIdx.x & 63)) - 1ull;
+            u64 pos = *pk_pos + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+#define RIOGP_PK(E, A, L, O)                                                                     \
+            if (pm & (1u << E)) { pk->idx[pos] = (u32)(i0 + E); pk->load[pos] = L; pk->aff[pos] = A; pk->next[pos] = O; ++pos; }
+            RIOGP_PK(0, av.x, lv.x, ov.x)
+            RIOGP_PK(1, av.y, lv.y, ov.y)
+            RIOGP_PK(2, av.z, lv.z, ov.z)
+            RIOGP_PK(3, av.w, lv.w, ov.w)
+#undef RIOGP_PK
+            *pk_pos += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+        }
+    }
     const u64 spmask = __ballot(any_sp);
     if (spmask) {  // wave-uniform, never taken on the fast path
         sp_sum += sp_local;
@@ -203,12 +232,12 @@ __device__ __forceinline__ uint4 ld4(const u32* p) {
 
 // TPI = tiles (of 256 rows) a wave processes per loop iteration; the next TPI tiles are always in
 // flight while the current ones are processed.
-template <bool VIRT, bool ALLALIVE, int TPI, int HMODE = 0>
+template <bool VIRT, bool ALLALIVE, int TPI, int HMODE = 0, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                  const u32* __restrict__ aff, u32* __restrict__ next,
                                                  const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
                                                  u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
-                                                 u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats) {
+                                                 u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u32* bst = reinterpret_cast<u32*>(smem);                 // [4] (first 128 B: small scratch, G17)
@@ -249,6 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 
     u64 sp_sum = 0;
     u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;  // kept/evict/claim are wave-uniform
+    u64 pk_pos = wstart;  // COMPACT: this wave's packed write cursor (wave-uniform)
 
     while (it < wgrp) {
         const u64 nit = it + (u64)kTile * TPI;
@@ -266,8 +296,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         }
 #pragma unroll
         for (int q = 0; q < TPI; ++q)
-            scan_tile<VIRT, ALLALIVE, false, HMODE>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend, m,
-                                                    alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt, claim_cnt);
+            scan_tile<VIRT, ALLALIVE, false, HMODE, COMPACT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
+                                                             m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
+                                                             claim_cnt, &pko, &pk_pos);
         it = nit;
 #pragma unroll
         for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
@@ -278,11 +309,11 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         const uint4 a1 = *reinterpret_cast<const uint4*>(aff + i);
         const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
         if (it < wfull)
-            scan_tile<VIRT, ALLALIVE, false>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                             evict_cnt, claim_cnt);
+            scan_tile<VIRT, ALLALIVE, false, 0, COMPACT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                                         evict_cnt, claim_cnt, &pko, &pk_pos);
         else
-            scan_tile<VIRT, ALLALIVE, true>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                            evict_cnt, claim_cnt);
+            scan_tile<VIRT, ALLALIVE, true, 0, COMPACT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                                        evict_cnt, claim_cnt, &pko, &pk_pos);
     }
 
     // per-wave spill-candidate totals (index-ordered prefix over wave ranges comes later)
@@ -291,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     if (lane == 0) {
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
+        if (COMPACT) pko.wcnt[gw] = (u32)(pk_pos - wstart);
         atomicAdd(&bst[0], kept_cnt);
         atomicAdd(&bst[1], evict_cnt);
         atomicAdd(&bst[2], claim_cnt);
@@ -544,7 +576,7 @@ __global__ __launch_bounds__(256) void k_cut_exact(const u32* __restrict__ cur, 
     for (u64 i0 = start; i0 < end && !found; i0 += 64) {
         const u64 i = i0 + lane;
         u64 v = 0;
-        if (i < end) {
+        if (i < end && packed_live(p, i)) {
             const u32 c = cur[i], a = aff[i];
             if (a == j && classify<VIRT>(c, a, p.m, alive_bits) == 1) v = load[i];
             else v = ~0ull;  // marker: not a claimant of j
@@ -897,6 +929,16 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         if (red[0]) { atomicAdd(&stats->spilled, red[0]); atomicAdd(&stats->load_spilled, red[1]); }
         if (red[2]) { atomicAdd(&stats->unplaced, red[2]); atomicAdd(&stats->load_unplaced, red[3]); }
     }
+}
+
+// packed fix-up: decisions of the packed rows back into the real assignment column
+__global__ __launch_bounds__(kBlock) void k_pk_scatter(Plan p, const u32* __restrict__ idx, const u32* __restrict__ pk_next,
+                                                       u32* __restrict__ next) {
+    const int lane = threadIdx.x & 63;
+    const u64 gw = (u64)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+    for (u64 i = wstart + lane; i < wend; i += 64) next[idx[i]] = pk_next[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1495,21 +1537,31 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
 int g_scan_tpi = 1;  // tiles per wave-iteration of k_scan (1 | 2 | 4); set through set_scan_tpi() for A/B runs
 void set_scan_tpi(int tpi) { g_scan_tpi = tpi; }
 
-template <bool VIRT, bool AA, int TPI, int HMODE = 0>
+template <bool VIRT, bool AA, int TPI, int HMODE = 0, bool COMPACT = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
-                          hipEvent_t e0, hipEvent_t e1) {
+                          hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr) {
     const size_t lds = scan_lds_bytes(p.m);
+    const PackOut pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
-        hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0, t.cur,
-                              t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
-                              b.stats);
+        hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE, COMPACT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
+                              t.cur, t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
+                              b.stats, pko);
     else
-        hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+        hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE, COMPACT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
+                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko);
+}
+
+void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t s) {
+    hipLaunchKernelGGL(k_pk_scatter, dim3(p.G), dim3(kBlock), 0, s, p, pk.idx, pk.next, next);
 }
 
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
-                 hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                 hipStream_t s, hipEvent_t e0, hipEvent_t e1, const PackOut* pack) {
+    if (pack && !virt) {  // k_scan that also packs the pending rows of every wave (adaptive fix-up, rio_gp_capi.hip)
+        if (all_alive) launch_scan_t<false, true, 1, 0, true>(p, t, nt, b, s, e0, e1, pack);
+        else launch_scan_t<false, false, 1, 0, true>(p, t, nt, b, s, e0, e1, pack);
+        return;
+    }
     if (virt) {
         if (all_alive) launch_scan_t<true, true, 1>(p, t, nt, b, s, e0, e1);
         else launch_scan_t<true, false, 1>(p, t, nt, b, s, e0, e1);

@@ -126,6 +126,11 @@ struct rio_gp {
     bool sh_slow = false;   // the solve in flight took the fix-up path
     u32 sh_slot = 0;        // verdict slot of the last rio_gp_shard_resolve
     hipStream_t sh_side = nullptr;  // stream the last rio_gp_shard_resolve ran on, when not the handle's
+    // packed fix-up (PackOut, placement_kernels.h): scratch columns + per-wave counts; chosen adaptively per tick
+    PackOut pk{};
+    bool last_pending_valid = false;
+    u64 last_pending = 0;
+    int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
     // micro-batch staging: pinned host memory mapped into the device, [5][kSmallBatch] u32 = idx | req | node | flag | status
     u32* h_small = nullptr;
     u32* d_small = nullptr;
@@ -279,12 +284,29 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     h->plan = make_plan(h->n, h->m, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
-    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+    // Adaptive packed fix-up: when the previous solve left few rows pending (a churn stream: most rows are kept),
+    // k_scan also packs this solve's pending rows per wave, and — if the verdict then asks for the fix-up — the cut
+    // and water-fill kernels run over the packed rows only (O(pending) passes instead of O(rows)); results identical.
+    const bool compact = h->compact_mode == 1 ||
+                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending * 4 <= h->n && h->n >= 65536);
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
     launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     DevStats v = reduce_slot(h, 0, h->m);
     const bool slow = v.n_cut > 0 || v.spillcand > 0;
-    if (slow) enqueue_slow(h, h->plan, t, nt, false, v);
+    h->last_pending = v.claimants + v.spillcand;
+    h->last_pending_valid = true;
+    if (slow) {
+        if (compact) {
+            Plan pp = h->plan;
+            pp.wcnt = h->pk.wcnt;
+            const Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
+            enqueue_slow(h, pp, vt, nt, true, v);
+            launch_pk_scatter(pp, h->pk, t.next, h->stream);
+        } else {
+            enqueue_slow(h, h->plan, t, nt, false, v);
+        }
+    }
     h->have_solved = true;
     h->ring_n = 0;
     if (commit) {
@@ -387,6 +409,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
     A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
     A(h->sb.wfCnt, 4); A(h->dstats, 1);
+    A(h->pk.idx, R); A(h->pk.load, R); A(h->pk.aff, R); A(h->pk.next, R); A(h->pk.wcnt, W);
     A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
 #undef A
@@ -1339,6 +1362,13 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
 }
 
 void rio_gp_debug_set_scan_tpi(int tpi) { set_scan_tpi(tpi); }
+
+int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
+    if (!h || mode < 0 || mode > 2) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->compact_mode = mode;
+    return RIO_GP_OK;
+}
 
 int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms) {
     if (!h || !ms || reps < 1) return RIO_GP_EINVAL;

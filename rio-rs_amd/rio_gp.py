@@ -112,6 +112,7 @@ def lib():
         L.rio_gp_solve_wait.argtypes = [_vp, C.POINTER(Stats), C.POINTER(C.c_uint32)]
         L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
         L.rio_gp_timer_begin.argtypes = [_vp]
         L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
         _lib = L
@@ -280,6 +281,10 @@ class GpuPlacement:
         ms = C.c_float(0)
         self._chk(lib().rio_gp_debug_stream_probe(self._h, mode, reps, C.byref(ms)))
         return float(ms.value)
+
+    def set_compact(self, mode):
+        """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode)."""
+        self._chk(lib().rio_gp_debug_set_compact(self._h, {"auto": 0, "always": 1, "never": 2}.get(mode, mode)))
 
     def timer_begin(self):
         self._chk(lib().rio_gp_timer_begin(self._h))

@@ -33,17 +33,19 @@ def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
 
 def _check_tick(gp, oracle, cur, load, aff, cap, alive, rounds=2):
     n, m = len(cur), len(cap)
-    g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds)
-    st = g.solve()
-    got = g.get_solved()
     want, used, ost = oracle.tick(cur, load, aff, cap, alive, rounds)
-    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
-    assert st == ost
-    assert np.array_equal(g.get_assign(), cur)  # solve does not publish
-    g.commit()
-    assert np.array_equal(g.get_assign(), want)
-    assert np.array_equal(g.get_nodes()[2], used)
-    g.close()
+    for mode in ("never", "always"):   # fix-up over the whole table | over the packed pending rows: same answer
+        g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds)
+        g.set_compact(mode)
+        st = g.solve()
+        got = g.get_solved()
+        assert np.array_equal(got, want), (mode, np.flatnonzero(got != want)[:10])
+        assert st == ost, mode
+        assert np.array_equal(g.get_assign(), cur)  # solve does not publish
+        g.commit()
+        assert np.array_equal(g.get_assign(), want)
+        assert np.array_equal(g.get_nodes()[2], used)
+        g.close()
     return ost
 
 
@@ -293,6 +295,25 @@ def test_async_solves_match_sync(gp, oracle):
     st, n_slow = g.solve_wait()
     want, used, ost = oracle.tick(cfg["cur"], cfg["load"], cfg["aff"], cap, cfg["alive"])
     assert n_slow == 1 and st == ost and np.array_equal(g.get_solved(), want)
+    g.close()
+
+
+def test_churn_stream_adaptive_packed_fixup(gp, oracle):
+    """Config-5 shape: committed ticks while a different 10 % of the nodes is down each tick.  From the second tick
+    on the adaptive rule switches to the packed fix-up (few rows pending); every tick must equal the oracle chain."""
+    cfg = synth.config("c3", n_override=1_500_000)
+    n, m = cfg["n"], cfg["m"]
+    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"], synth.warm_assign(n, m))
+    ref = synth.warm_assign(n, m)
+    for tick in range(6):
+        alive = synth.churn_mask(m, 2 + tick)
+        g.set_alive_all(alive)
+        st = g.tick()
+        ref, used, ost = oracle.tick(ref, cfg["load"], cfg["aff"], cfg["cap"], alive, 2)
+        assert st == ost, tick
+        assert np.array_equal(g.get_assign(), ref), tick
+        assert np.array_equal(g.get_nodes()[2], used), tick
+        assert tick == 0 or (ost["slow_path"] == 1 and ost["evicted"] > 0)
     g.close()
 
 

@@ -12,7 +12,9 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = synth.config("c3")
 n, m = cfg["n"], cfg["m"]
 g = rio_gp.GpuPlacement(n, m)
-res = {"which": which, "reps": reps, "n": n, "m": m}
+if len(sys.argv) > 3:
+    g.set_compact(sys.argv[3])   # auto | always | never
+res = {"which": which, "reps": reps, "n": n, "m": m, "compact": sys.argv[3] if len(sys.argv) > 3 else "auto"}
 if which == "churn":
     g.set_nodes(cfg["cap"], cfg["alive"])
     g.set_objects(n, cfg["load"], cfg["aff"])
