@@ -126,7 +126,10 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
                    DevStats* st, hipStream_t s);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
                    DevStats* st, hipStream_t s);
-void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s);
+// counter == nullptr: accumulate into st->evicted_clean.  ticket/host_out: self-resetting counter + total written to
+// mapped host memory by the last workgroup (dead_bits may itself be mapped host memory).
+void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s,
+                  u64* counter = nullptr, unsigned int* ticket = nullptr, u64* host_out = nullptr);
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s);
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s);
 void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32* nload, const u32* naff, u64 n,

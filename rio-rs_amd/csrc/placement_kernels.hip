@@ -971,7 +971,7 @@ __global__ void k_lookup(const u32* __restrict__ assign, u64 n_obj, const u32* _
 
 // update (local.rs:22-40), sequential last-writer-wins: phase 1 elects, per row, the highest
 // batch position (atomicMin of the reversed position in a row-sized scratch), phase 2 lets the
-// winner write and resets the scratch.
+// winner write and put its scratch slot back to all-ones.
 __global__ void k_update_elect(u64 n_obj, u32 m, const u32* __restrict__ idx, const u32* __restrict__ node, u64 n,
                                u32* __restrict__ pos, DevStats* st) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
@@ -980,20 +980,18 @@ __global__ void k_update_elect(u64 n_obj, u32 m, const u32* __restrict__ idx, co
         else atomicAdd(&st->err, 1ull);
     }
 }
+// the elected writer publishes and puts the scratch slot back to all-ones itself (a loser that reads the slot after
+// that sees NONE != its own position and does nothing) — no third pass
 __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ idx,
-                               const u32* __restrict__ node, u64 n, const u32* __restrict__ pos) {
+                               const u32* __restrict__ node, u64 n, u32* __restrict__ pos) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k], nd = node[k];
-        if (i < n_obj && (nd == kNone || nd < m) && pos[i] == (u32)(n - 1 - k)) assign[i] = nd;
+        if (i < n_obj && (nd == kNone || nd < m) && pos[i] == (u32)(n - 1 - k)) {
+            assign[i] = nd;
+            pos[i] = kNone;
+        }
     }
 }
-__global__ void k_pos_reset(const u32* __restrict__ idx, u64 n, u64 n_obj, u32* __restrict__ pos) {
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
-        const u32 i = idx[k];
-        if (i < n_obj) pos[i] = kNone;
-    }
-}
-
 // remove (local.rs:60-68): exchange makes duplicate removals of one row decrement `used` once
 __global__ void k_remove(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ load,
                          const u32* __restrict__ idx, u64 n, u64* __restrict__ used, DevStats* st) {
@@ -1006,9 +1004,12 @@ __global__ void k_remove(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* 
 }
 
 // clean_server(s) (local.rs:51-58): one coalesced pass, 4 B read per row, 4 B written per evicted row
+// counter: device accumulator of evicted rows.  ticket/host_out (optional): the last workgroup to finish copies the
+// total into mapped host memory and resets counter and ticket, so a synchronous call needs no memset / copy-back.
 __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                const u32* __restrict__ dead_bits, u64* __restrict__ used,
-                                               DevStats* st) {
+                                               u64* __restrict__ counter, unsigned int* __restrict__ ticket,
+                                               u64* __restrict__ host_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32* db = reinterpret_cast<u32*>(smem);
     __shared__ u32 any;
@@ -1043,7 +1044,19 @@ __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_o
     ev = wave_sum32(ev);
     if ((tid & 63) == 0 && ev) atomicAdd(&ev_total, ev);
     __syncthreads();
-    if (tid == 0 && ev_total) atomicAdd(&st->evicted_clean, (u64)ev_total);
+    if (tid == 0) {
+        // returning atomic: its value is back (the add is performed at L2) before the ticket below depends on it
+        const u64 before = __hip_atomic_fetch_add(counter, (u64)ev_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket) {
+            const unsigned int t = __hip_atomic_fetch_add(ticket, 1u + (unsigned int)(before & 0ull), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                *host_out = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // scatter new load / affinity values into individual rows
@@ -1647,7 +1660,6 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
     hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos);
-    hipLaunchKernelGGL(k_pos_reset, dim3(g), dim3(256), 0, s, idx, n, n_obj, pos);
 }
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
                    hipStream_t s) {
@@ -1655,10 +1667,11 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
     hipLaunchKernelGGL(k_remove, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, load, idx, n, used,
                        st);
 }
-void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s) {
+void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
+                  u64* counter, unsigned int* ticket, u64* host_out) {
     const size_t lds = (size_t)((m + 31) / 32 + 4) * sizeof(u32);
     hipLaunchKernelGGL(k_clean, dim3(grid_for((n_obj + 3) / 4, 256, 2048)), dim3(256), lds, s, assign, n_obj, m,
-                       dead_bits, used, st);
+                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out);
 }
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s) {
     (void)hipMemsetAsync(used, 0, (size_t)m * sizeof(u64), s);

@@ -131,6 +131,12 @@ struct rio_gp {
     bool last_pending_valid = false;
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
+    // clean_server(s): dead bitmap + evicted count in mapped pinned memory, self-resetting device counter + ticket
+    u32* h_cs = nullptr;
+    u32* d_cs = nullptr;
+    size_t cs_words = 0;
+    u64* cs_cnt = nullptr;
+    unsigned int* cs_ticket = nullptr;
     // micro-batch staging: pinned host memory mapped into the device, [5][kSmallBatch] u32 = idx | req | node | flag | status
     u32* h_small = nullptr;
     u32* d_small = nullptr;
@@ -427,6 +433,17 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     memset(h->h_slots, 0, (size_t)kRing * h->slot_rows * 8 * sizeof(u64));
+    h->cs_words = (((size_t)h->cap_nodes + 31) / 32 + 8 + 1) & ~(size_t)1;  // bitmap words, then the u64 count (8 B aligned)
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cs), (h->cs_words + 2) * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_cs), h->h_cs, 0) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->cs_cnt), sizeof(u64)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->cs_ticket), sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(h->cs_cnt, 0, sizeof(u64)) != hipSuccess || hipMemset(h->cs_ticket, 0, sizeof(unsigned int)) != hipSuccess) {
+        h->err = "clean_server staging allocation failed";
+        return bail(RIO_GP_ENOMEM);
+    }
+    h->allocs.push_back(h->cs_cnt);
+    h->allocs.push_back(h->cs_ticket);
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_small), (size_t)5 * kSmallBatch * sizeof(u32), hipHostMallocMapped) !=
             hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_small), h->h_small, 0) != hipSuccess) {
@@ -462,6 +479,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_slots) (void)hipHostFree(h->h_slots);
     if (h->h_small) (void)hipHostFree(h->h_small);
+    if (h->h_cs) (void)hipHostFree(h->h_cs);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -753,20 +771,24 @@ int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evi
     if (!h || !dead_bitmap) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
+    // one launch + one wait: the kernel reads the bitmap from mapped pinned memory and its last workgroup writes the
+    // evicted count back into it (no staging copy, no counter memset, no copy-back)
     const u32 words32 = (h->m + 31) / 32;
-    std::vector<u32> bits(words32 + 1, 0);
+    u64* h_count = reinterpret_cast<u64*>(h->h_cs + h->cs_words);
+    *h_count = 0;
+    if (evicted) *evicted = 0;
+    if (!words32) return RIO_GP_OK;
+    bool any = false;
+    for (u32 w = 0; w < words32; ++w) h->h_cs[w] = 0;
     for (u32 j = 0; j < h->m; ++j)
-        if ((dead_bitmap[j >> 6] >> (j & 63)) & 1ull) bits[j >> 5] |= 1u << (j & 31);
-    int rc = zero_stats(h);
-    if (rc) return rc;
-    if (words32)
-        HIPCHK(h, hipMemcpyAsync(h->dead_bits, bits.data(), words32 * sizeof(u32), hipMemcpyHostToDevice, h->stream));
-    if (words32)
-        launch_clean(h->assign[h->cur], h->n, h->m, h->dead_bits, h->used_valid ? h->used : nullptr, h->dstats,
-                     h->stream);
+        if ((dead_bitmap[j >> 6] >> (j & 63)) & 1ull) { h->h_cs[j >> 5] |= 1u << (j & 31); any = true; }
     h->have_solved = false;
-    if ((rc = read_stats(h))) return rc;
-    if (evicted) *evicted = h->h_stats[0].evicted_clean;
+    if (!any) return RIO_GP_OK;  // retain() with a predicate nothing matches
+    launch_clean(h->assign[h->cur], h->n, h->m, h->d_cs, h->used_valid ? h->used : nullptr, h->dstats, h->stream,
+                 h->cs_cnt, h->cs_ticket, reinterpret_cast<u64*>(h->d_cs + h->cs_words));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (evicted) *evicted = *h_count;
     return RIO_GP_OK;
 }
 
