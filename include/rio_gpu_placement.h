@@ -279,6 +279,11 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms);
 /* A/B and test knob: packed fix-up (fix-up passes over the pending rows only) 0 = adaptive (default: used when the
  * previous solve left <= 25 % of the rows pending), 1 = always, 2 = never.  Results are identical in every mode. */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
+/* A/B and test knob for the cut / water-fill fix-up.  fused: 1 (default) = k_cutblk + k_cut_fused, packed decisions
+ * written through by the water-fill | 0 = the unfused launch chain.  speculate: 0 (default) = enqueue the fix-up behind
+ * k_resolve without waiting for the verdict when the previous solve needed it | 1 = always | 2 = never.  Results are
+ * identical in every combination. */
+int rio_gp_debug_set_fixup(rio_gp_t* h, int fused, int speculate);
 /* A/B knob for tools/sweep_scan.py: tiles per wave-iteration of k_scan (1 | 2 | 4); process-wide. */
 void rio_gp_debug_set_scan_tpi(int tpi);
 /* Measurement aid: pure streaming kernels with k_scan's traffic mix (3 columns in, 1 out) over the handle's

@@ -95,6 +95,10 @@ struct Table {
     const u32* load;
     const u32* aff;
     u32* next;
+    // packed fix-up only (else nullptr): the water-fill also writes each decision to real_next[pk_idx[position]],
+    // which makes the separate k_pk_scatter launch unnecessary when at least one spill round runs
+    const u32* pk_idx = nullptr;
+    u32* real_next = nullptr;
 };
 
 struct NodeTab {
@@ -116,7 +120,8 @@ unsigned resolve_blocks(u32 m);
 void set_scan_tpi(int tpi);
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1);
-void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s);
+void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
+                      bool fused = true);
 void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
                         hipStream_t s);
 
@@ -136,6 +141,8 @@ void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32*
                       DevStats* st, hipStream_t s);
 void launch_count_placed(const u32* assign, u64 n_obj, DevStats* st, hipStream_t s);
 void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipStream_t s);
+struct WordPack { u32 w[256]; };  // 8 192 bits = RIO_GP_MAX_NODES, passed by value as a kernel argument
+void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t s);
 
 // --- place_pending, micro-batch (n <= kSmallBatch): one launch; idx/req/out_* may be mapped host memory; *status = 1
 //     means "needs the general path", nothing was changed ---

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         stats->rejected = 0; stats->load_rejected = 0;
         stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
         stats->rounds_run = 0;
+        stats->n_cut = 0;  // device-side "a node has a cut" flag (k_cutblk)
     }
     __syncthreads();
 
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(256) void k_cutblk(const u64* __restrict__ H, Plan 
                                                 const u32* __restrict__ alive_bits,
                                                 const u64* __restrict__ used_kept,
                                                 const u64* __restrict__ claim_tot, u32* __restrict__ cutblk,
-                                                u64* __restrict__ budget, u64* __restrict__ admpre) {
+                                                u64* __restrict__ budget, u64* __restrict__ admpre,
+                                                DevStats* __restrict__ stats) {
     __shared__ u64 sc[kCbGroups][kCbNodes];
     const int tid = threadIdx.x, nd = tid & (kCbNodes - 1), grp = tid >> 4;
     const u32 m = p.m, G = p.G;
@@ -448,7 +450,10 @@ __global__ __launch_bounds__(256) void k_cutblk(const u64* __restrict__ H, Plan 
         tc += cc[r];
     }
     sc[grp][nd] = tc;
-    __syncthreads();
+    // stats->n_cut (zeroed by k_scan) > 0 iff some node has a cut: k_cut_fused returns at once otherwise, which is what
+    // makes it cheap to enqueue the fix-up speculatively behind a solve whose verdict the host has not read yet
+    const int any_cut = __syncthreads_or(has_cut && grp == 0);
+    if (tid == 0 && any_cut) atomicAdd(&stats->n_cut, 1ull);
     if (!has_cut) return;
     u64 pre = 0;
     for (int g = 0; g < grp; ++g) pre += sc[g][nd];
@@ -664,6 +669,205 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
 }
 
 // ------------------------------------------------------------------------------------------------
+// K34 k_cut_fused — the whole cut fix-up behind k_cutblk in ONE launch (replaces the T memset,
+//     k_cut_subhist, k_cut_exact, k_shard_force and k_apply_cut: five dependent launches whose
+//     floor was latency, not bytes).  What makes the fusion legal: the exact cut row of node j is a
+//     fact about ONE workgroup's rows (block cutblk[j]), and whether a claimant row i of block b
+//     is rejected depends only on cutblk[A] (known before the launch) and — when cutblk[A] == b —
+//     on the exact cut this very workgroup computes.  So per workgroup b:
+//       P0  thr[j] = 0 (cutblk[j] < b, or forced: every claimant here is rejected) | NOCUT
+//           (cutblk[j] > b / no cut) | "local" (cutblk[j] == b: gets a slot);
+//       P1  per group of K local nodes: T[slot][sub-chunk] claim load of the block's rows, LDS
+//           atomics (the 2 MB global T of the unfused path is gone);
+//       P2  one wave per local node: sub-chunk by prefix over its T row, then the exact row;
+//           thr[j] = cutidx[j] = that row, used_cur[j] = kept + admitted;
+//       P3  claimants with i >= thr[aff] lose the optimistic assignment (k_apply_cut's pass).
+//     Rows are streamed twice (P1, P3: the second pass hits L2/MALL) only in blocks that own a cut.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kSlotNone = 0xFFFFu;
+
+template <bool VIRT>
+__global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                      const u32* __restrict__ aff, u32* __restrict__ next,
+                                                      const u32* __restrict__ alive_bits, Plan p,
+                                                      const u32* __restrict__ cutblk, const u64* __restrict__ budget,
+                                                      const u64* __restrict__ admpre,
+                                                      const u64* __restrict__ used_kept,
+                                                      const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
+                                                      u64* __restrict__ used_cur, u64* __restrict__ wsp_sum,
+                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m, mr = (m + 7) & ~7u, subs = p.subs;
+    u32& nlocal = *reinterpret_cast<u32*>(smem);
+    u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
+    u32* thr = reinterpret_cast<u32*>(smem + kSmall);                        // [mr] reject threshold by node
+    unsigned short* slot = reinterpret_cast<unsigned short*>(thr + mr);      // [mr] local slot of a node or kSlotNone
+    unsigned short* node_of = slot + mr;                                     // [mr] node of a local slot
+    u32* alv = reinterpret_cast<u32*>(node_of + mr);                         // [(mwords+3)&~3]
+    u64* T = reinterpret_cast<u64*>(alv + ((p.mwords + 3) & ~3u));           // [K][subs]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 b = blockIdx.x;
+    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
+    if (tid == 0) { nlocal = 0; red[0] = 0; red[1] = 0; }
+    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    __syncthreads();
+    for (u32 j = tid; j < m; j += kBlock) {
+        const u32 cbv = cutblk[j];
+        u32 t = kNoCut;
+        u32 s = kSlotNone;
+        if (forced_bits && bit_of(forced_bits, j)) {  // row-sharded solve: the prefix overflowed on a lower rank
+            t = 0;
+            if (b == 0) { cutidx[j] = 0; used_cur[j] = used_kept[j]; }
+        } else if (cbv < b) {
+            t = 0;
+        } else if (cbv == b) {
+            s = atomicAdd(&nlocal, 1u);
+            node_of[s] = (unsigned short)j;
+        }
+        thr[j] = t;
+        slot[j] = (unsigned short)s;
+    }
+    __syncthreads();
+    const u32 nloc = nlocal;
+    const u64 gw = (u64)b * kWaves + wave;
+    const u64 bstart = block_row_lo(p, b);
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+
+    for (u32 g0 = 0; g0 < nloc; g0 += K) {
+        const u32 kn = nloc - g0 < K ? nloc - g0 : K;
+        for (u32 k = tid; k < kn * subs; k += kBlock) T[k] = 0;
+        __syncthreads();
+        // P1: claim load per (local node, sub-chunk); a tile (256 rows) lies inside ONE sub-chunk (sub % 256 == 0)
+        for (u64 it = wstart; it < wend; it += kTile) {
+            const u64 i0 = it + (u64)lane * 4;
+            const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
+            const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
+            const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+            const u32 t = (u32)((it - bstart) / p.sub);
+#define RIOGP_ROW(C, A, L, E)                                                                              \
+            {                                                                                              \
+                bool hit = i0 + E < wend && classify<VIRT>(C, A, m, alv) == 1;                             \
+                u32 ls = 0;                                                                                \
+                if (hit) { ls = (u32)slot[A] - g0; hit = ls < kn; }  /* kSlotNone - g0 >= kn: K <= 64 */   \
+                u64 todo = __ballot(hit);                                                                  \
+                if (__popcll(todo) <= 8) {                                                                 \
+                    if (hit) atomicAdd(&T[ls * subs + t], (u64)L);                                         \
+                    todo = 0;                                                                              \
+                }                                                                                          \
+                while (todo) { /* hot node: one LDS atomic per (node, tile) instead of one per row */      \
+                    const int ld = __ffsll((long long)todo) - 1;                                           \
+                    const u32 s0 = (u32)__shfl((int)ls, ld, 64);                                           \
+                    const bool same = hit && ls == s0;                                                     \
+                    const u64 sum = wave_sum(same ? (u64)L : 0ull);                                        \
+                    if (lane == ld) atomicAdd(&T[s0 * subs + t], sum);                                     \
+                    todo &= ~__ballot(same);                                                               \
+                }                                                                                          \
+            }
+            RIOGP_ROW(cv.x, av.x, lv.x, 0)
+            RIOGP_ROW(cv.y, av.y, lv.y, 1)
+            RIOGP_ROW(cv.z, av.z, lv.z, 2)
+            RIOGP_ROW(cv.w, av.w, lv.w, 3)
+#undef RIOGP_ROW
+        }
+        __syncthreads();
+        // P2: one wave per local node — sub-chunk, then exact row (k_cut_exact's search, T row in LDS)
+        for (u32 ls = wave; ls < kn; ls += kWaves) {
+            const u32 j = node_of[g0 + ls];
+            const u64 bud = budget[j];
+            const u64* Tj = T + (size_t)ls * subs;
+            u64 acc = 0, pre_sub = 0;
+            u32 tstar = 0;
+            bool found = false;
+            for (u32 g = 0; g < subs && !found; g += 64) {
+                const u32 t = g + lane;
+                const u64 v = t < subs ? Tj[t] : 0;
+                const u64 inc = wave_incl_scan(v, lane);
+                const u64 mask = __ballot(acc + inc > bud);
+                if (mask) {
+                    const int fl = __ffsll((long long)mask) - 1;
+                    tstar = g + fl;
+                    pre_sub = acc + shfl64(inc - v, fl);
+                    found = true;
+                } else {
+                    acc += shfl64(inc, 63);
+                }
+            }
+            const u64 bud2 = bud - pre_sub;
+            const u64 start = bstart + (u64)tstar * p.sub;
+            u64 end = start + p.sub;
+            if (end > block_row_lo(p, b + 1)) end = block_row_lo(p, b + 1);
+            if (end > p.n) end = p.n;
+            u64 acc2 = 0, cut_row = kNoCut, adm_in = 0;
+            found = false;
+            for (u64 i0 = start; i0 < end && !found; i0 += 64) {
+                const u64 i = i0 + lane;
+                bool is_cl = false;
+                u64 l = 0;
+                if (i < end && packed_live(p, i)) {
+                    const u32 c = cur[i], a = aff[i];
+                    if (a == j && classify<VIRT>(c, a, m, alv) == 1) { is_cl = true; l = load[i]; }
+                }
+                const u64 inc = wave_incl_scan(l, lane);
+                const u64 mask = __ballot(is_cl && acc2 + inc > bud2);
+                if (mask) {
+                    const int fl = __ffsll((long long)mask) - 1;
+                    cut_row = i0 + fl;
+                    adm_in = acc2 + shfl64(inc - l, fl);
+                    found = true;
+                } else {
+                    acc2 += shfl64(inc, 63);
+                }
+            }
+            if (lane == 0) {
+                thr[j] = (u32)cut_row;
+                cutidx[j] = (u32)cut_row;
+                used_cur[j] = used_kept[j] + admpre[j] + pre_sub + adm_in;
+            }
+        }
+        __syncthreads();
+    }
+
+    // P3: re-mark the rejected claimants, rebuild the per-wave spill totals (candidates + rejected)
+    u64 sp_sum = 0, rej_sum = 0;
+    u32 sp_cnt = 0, rej_cnt = 0;
+    for (u64 it = wstart; it < wend; it += kTile) {
+        const u64 i0 = it + (u64)lane * 4;
+        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
+        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
+        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+#define RIOGP_ROW(C, A, L, E)                                                    \
+        if (i0 + E < wend) {                                                     \
+            const int cls = classify<VIRT>(C, A, m, alv);                        \
+            if (cls == 2) { sp_sum += L; ++sp_cnt; }                             \
+            else if (cls == 1 && (u32)(i0 + E) >= thr[A]) {                      \
+                next[i0 + E] = kSpillMark;                                       \
+                sp_sum += L; ++sp_cnt; rej_sum += L; ++rej_cnt;                  \
+            }                                                                    \
+        }
+        RIOGP_ROW(cv.x, av.x, lv.x, 0)
+        RIOGP_ROW(cv.y, av.y, lv.y, 1)
+        RIOGP_ROW(cv.z, av.z, lv.z, 2)
+        RIOGP_ROW(cv.w, av.w, lv.w, 3)
+#undef RIOGP_ROW
+    }
+    sp_sum = wave_sum(sp_sum);
+    sp_cnt = wave_sum32(sp_cnt);
+    rej_sum = wave_sum(rej_sum);
+    rej_cnt = wave_sum32(rej_cnt);
+    if (lane == 0) {
+        wsp_sum[gw] = sp_sum;
+        wsp_cnt[gw] = sp_cnt;
+        if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
+    }
+    __syncthreads();
+    if (tid == 0 && red[0]) {
+        atomicAdd(&stats->rejected, red[0]);
+        atomicAdd(&stats->load_rejected, red[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // KS  k_spill_rank — per round: free capacity per node, rank of every node in the total order
 //     (free desc, index asc) by counting, and the exclusive prefix of the per-wave spill totals.
 //     Ranking is m^2 wave-uniform LDS reads: ONE workgroup is bound by a single CU's LDS port
@@ -795,7 +999,8 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                                                         const u32* __restrict__ wfCnt, u64* __restrict__ used_cur,
                                                         const u32* __restrict__ wsp_cnt_in,
                                                         u64* __restrict__ wsp_sum_out, u32* __restrict__ wsp_cnt_out,
-                                                        int last, DevStats* __restrict__ stats) {
+                                                        int last, DevStats* __restrict__ stats,
+                                                        const u32* __restrict__ pk_idx, u32* __restrict__ real_next) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u64* red = reinterpret_cast<u64*>(smem);               // [4]
@@ -849,20 +1054,26 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         lo_run = lo;
     }
     if (wsp_cnt_in[gw] == 0) wend = wstart;  // no pending row in this wave's range (later rounds: most waves)
-    uint4 nvn = make_uint4(0, 0, 0, 0), lvn = make_uint4(0, 0, 0, 0);
+    // packed fix-up: `next` is the packed decision column; every decision is also written straight into the real
+    // assignment column through pk_idx (k_pk_scatter's job, without its launch).  Every pending row gets its final
+    // value here: placed rows in the round that places them, the rest (NONE) in the last round.
+    const bool scat = pk_idx != nullptr;
+    uint4 nvn = make_uint4(0, 0, 0, 0), lvn = make_uint4(0, 0, 0, 0), ivn = make_uint4(0, 0, 0, 0);
     if (wstart < wend) {
         nvn = *reinterpret_cast<const uint4*>(next + wstart + (u64)lane * 4);
         lvn = *reinterpret_cast<const uint4*>(load + wstart + (u64)lane * 4);
+        if (scat) ivn = *reinterpret_cast<const uint4*>(pk_idx + wstart + (u64)lane * 4);
     }
     for (u64 it = wstart; it < wend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
-        const uint4 nv = nvn, lv = lvn;
+        const uint4 nv = nvn, lv = lvn, iv = ivn;
         // next tile's marks and loads in flight while this one is processed (clamped: the last iteration re-reads
         // its own tile).  Loads are fetched unconditionally: pending rows are spread over every 64 B segment anyway,
         // and a dependent load after the mark test costs a full HBM latency per tile.
         const u64 pit = it + kTile < wend ? it + kTile : it;
         nvn = *reinterpret_cast<const uint4*>(next + pit + (u64)lane * 4);
         lvn = *reinterpret_cast<const uint4*>(load + pit + (u64)lane * 4);
+        if (scat) ivn = *reinterpret_cast<const uint4*>(pk_idx + pit + (u64)lane * 4);
         const bool mk0 = i0 + 0 < wend && nv.x == kSpillMark, mk1 = i0 + 1 < wend && nv.y == kSpillMark;
         const bool mk2 = i0 + 2 < wend && nv.z == kSpillMark, mk3 = i0 + 3 < wend && nv.w == kSpillMark;
         if (!__ballot(mk0 | mk1 | mk2 | mk3)) continue;  // wave-uniform: nothing to spill in this tile
@@ -883,7 +1094,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                 if (C[mid] <= run_end) hi_run = mid; else top = mid;
             }
         }
-#define RIOGP_ROW(MK, L, E)                                                       \
+#define RIOGP_ROW(MK, L, E, IDX)                                                  \
         if (MK) {                                                                 \
             u32 nd = kNone;                                                       \
             if (cnt && Q < F) {                                                   \
@@ -896,18 +1107,22 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
             }                                                                     \
             if (nd != kNone) {                                                    \
                 next[i0 + E] = nd;                                                \
+                if (scat) real_next[IDX] = nd;                                    \
                 atomicAdd(&adm[nd], (u64)L);                                      \
                 pl_sum += L; ++pl_cnt;                                            \
             } else {                                                              \
-                if (last) next[i0 + E] = kNone;                                   \
+                if (last) {                                                       \
+                    next[i0 + E] = kNone;                                         \
+                    if (scat) real_next[IDX] = kNone;                             \
+                }                                                                 \
                 rem_sum += L; ++rem_cnt;                                          \
             }                                                                     \
             Q += L;                                                               \
         }
-        RIOGP_ROW(mk0, l0, 0)
-        RIOGP_ROW(mk1, l1, 1)
-        RIOGP_ROW(mk2, l2, 2)
-        RIOGP_ROW(mk3, l3, 3)
+        RIOGP_ROW(mk0, l0, 0, iv.x)
+        RIOGP_ROW(mk1, l1, 1, iv.y)
+        RIOGP_ROW(mk2, l2, 2, iv.z)
+        RIOGP_ROW(mk3, l3, 3, iv.w)
 #undef RIOGP_ROW
         run = run_end;
         lo_run = hi_run;
@@ -946,6 +1161,14 @@ __global__ __launch_bounds__(kBlock) void k_pk_scatter(Plan p, const u32* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ void k_fill_u32(u32* p, u64 n, u32 v) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// liveness push (rio_gp_set_alive*): the host packs the bitmap and hands it over BY VALUE in the kernel arguments
+// (<= 1 KiB at 8 192 nodes) — no staging buffer whose lifetime would need a wait, no copy engine hand-off; the update
+// is ordered on the handle's stream like any kernel and the call returns without synchronising.
+__global__ void k_store_words(WordPack pack, u32 nwords, u32* __restrict__ dst) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) dst[w] = pack.w[w];
 }
 
 __global__ void k_pack_alive(const uint8_t* alive, u32 m, u32* bits) {
@@ -1610,12 +1833,40 @@ void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* h
                            host_partial);
 }
 
+size_t cut_fused_lds(const Plan& p, u32* K_out) {
+    const u32 mr = (p.m + 7) & ~7u;
+    const size_t fixed = kSmall + (size_t)mr * 8 + (size_t)((p.mwords + 3) & ~3u) * sizeof(u32);
+    const size_t row = (size_t)p.subs * sizeof(u64);
+    size_t K = (150 * 1024 - fixed) / row;
+    if (K > 48) K = 48;
+    if (K < 1) K = 1;
+    *K_out = (u32)K;
+    return fixed + K * row;
+}
+
+// fused: k_cutblk + k_cut_fused (default) | else the unfused chain: T memset, k_cutblk, k_cut_subhist, k_cut_exact,
+// (k_shard_force,) k_apply_cut — kept for A/B runs and as a second implementation the parity tests compare against
 void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
-                      hipStream_t s) {
-    (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
+                      hipStream_t s, bool fused) {
     const unsigned gcb = (p.m + kCbNodes - 1) / kCbNodes;
+    if (fused) {
+        hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
+                           b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
+        u32 K = 1;
+        const size_t ldsf = cut_fused_lds(p, &K);
+        if (virt)
+            hipLaunchKernelGGL(k_cut_fused<true>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
+                               nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, K);
+        else
+            hipLaunchKernelGGL(k_cut_fused<false>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
+                               nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, K);
+        return;
+    }
+    (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
     hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
-                       b.claim_tot, b.cutblk, b.budget, b.admpre);
+                       b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
     const size_t lds = kSmall + ((size_t)p.m + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16;
     const unsigned g4 = (p.m + 3) / 4;
     if (virt) {
@@ -1647,7 +1898,8 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
                        b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.rank_base, b.pending_global, b.stats);
     const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + 16;
     hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_base, b.wfC,
-                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats);
+                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats,
+                       t.pk_idx, t.real_next);
 }
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {
@@ -1691,6 +1943,10 @@ void launch_count_placed(const u32* assign, u64 n_obj, DevStats* st, hipStream_t
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, p, n, v);
+}
+void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t s) {
+    if (!nwords) return;
+    hipLaunchKernelGGL(k_store_words, dim3((nwords + 63) / 64), dim3(64), 0, s, pack, nwords, dst);
 }
 void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipStream_t s) {
     const u32 w = (m + 31) / 32;

@@ -131,6 +131,9 @@ struct rio_gp {
     bool last_pending_valid = false;
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
+    int fixup_mode = 1;    // 1 fused cut fix-up + scatter folded into the water-fill | 0 the unfused chain (rio_gp_debug_set_fixup)
+    int spec_mode = 0;     // speculative fix-up enqueue: 0 auto (after a solve that needed it) | 1 always | 2 never
+    bool last_slow = false;
     // clean_server(s): dead bitmap + evicted count in mapped pinned memory, self-resetting device counter + ticket
     u32* h_cs = nullptr;
     u32* d_cs = nullptr;
@@ -242,7 +245,7 @@ NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; 
 
 // the cut / spill fix-up of a solve whose fast path said it needs one
 void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, const DevStats& verdict) {
-    if (verdict.n_cut > 0) launch_cut_fixup(p, t, nt, h->sb, virt, h->stream);
+    if (verdict.n_cut > 0) launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode == 1);
     for (u32 r = 0; r < h->rounds; ++r) launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream);
 }
 
@@ -277,15 +280,15 @@ int merge_slow(rio_gp* h, DevStats* v) {
 int commit_enqueue(rio_gp* h) {
     if (!h->have_solved) return fail(h, RIO_GP_EINVAL, "rio_gp_commit: no solve to commit");
     h->cur ^= 1;
-    HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
-                             hipMemcpyDeviceToDevice, h->stream));
+    std::swap(h->used, h->sb.used_cur);  // publication = two pointer swaps: the solve's `used` vector becomes the committed one
     h->used_valid = true;
     h->have_solved = false;
     return RIO_GP_OK;
 }
 
-// One whole-table solve; with `commit` the publication (pointer swap + `used` copy) is enqueued before the last
-// wait, so a tick costs two host waits (verdict, completion) on either path.
+// One whole-table solve; with `commit` the publication (two pointer swaps) happens before the last wait.
+// Host waits: verdict + completion when the fix-up is needed, verdict only on the fast path — and ONE wait when the
+// fix-up was enqueued speculatively (below).
 int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     h->plan = make_plan(h->n, h->m, 0);
     const Table t = real_table(h);
@@ -295,22 +298,35 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     // and water-fill kernels run over the packed rows only (O(pending) passes instead of O(rows)); results identical.
     const bool compact = h->compact_mode == 1 ||
                          (h->compact_mode == 0 && h->last_pending_valid && h->last_pending * 4 <= h->n && h->n >= 65536);
+    // Speculative fix-up: when the previous solve needed the fix-up (a churn stream needs it every tick), its kernels
+    // are enqueued right behind k_resolve instead of after a host round trip for the verdict.  Every fix-up kernel
+    // guards itself on device (k_cut_fused: stats->n_cut; the water-fill rounds: pending-row count), so a solve that
+    // turns out not to need them pays a few no-op launches and gets the same result.
+    const bool spec = h->fixup_mode == 1 && h->spec_mode != 2 && (h->spec_mode == 1 || h->last_slow);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
     launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    DevStats v = reduce_slot(h, 0, h->m);
-    const bool slow = v.n_cut > 0 || v.spillcand > 0;
-    h->last_pending = v.claimants + v.spillcand;
-    h->last_pending_valid = true;
-    if (slow) {
+    DevStats v;
+    bool slow = false;
+    if (!spec) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        v = reduce_slot(h, 0, h->m);
+        slow = v.n_cut > 0 || v.spillcand > 0;
+    }
+    if (spec || slow) {
+        DevStats all;  // speculative: run both halves, they guard themselves
+        memset(&all, 0, sizeof all);
+        all.n_cut = 1;
+        const DevStats& what = spec ? all : v;
         if (compact) {
             Plan pp = h->plan;
             pp.wcnt = h->pk.wcnt;
-            const Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
-            enqueue_slow(h, pp, vt, nt, true, v);
-            launch_pk_scatter(pp, h->pk, t.next, h->stream);
+            Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
+            const bool fused_scatter = h->fixup_mode == 1 && h->rounds >= 1;  // the water-fill writes through pk.idx itself
+            if (fused_scatter) { vt.pk_idx = h->pk.idx; vt.real_next = t.next; }
+            enqueue_slow(h, pp, vt, nt, true, what);
+            if (!fused_scatter) launch_pk_scatter(pp, h->pk, t.next, h->stream);
         } else {
-            enqueue_slow(h, h->plan, t, nt, false, v);
+            enqueue_slow(h, h->plan, t, nt, false, what);
         }
     }
     h->have_solved = true;
@@ -319,13 +335,28 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
         int rc = commit_enqueue(h);
         if (rc) return rc;
     }
-    if (slow) {
+    if (spec) {
+        HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        v = reduce_slot(h, 0, h->m);
+        slow = v.n_cut > 0 || v.spillcand > 0;
+        if (slow) {
+            const DevStats& d = h->h_stats[0];
+            v.rejected = d.rejected; v.load_rejected = d.load_rejected;
+            v.spilled = d.spilled; v.load_spilled = d.load_spilled;
+            v.unplaced = d.unplaced; v.load_unplaced = d.load_unplaced;
+            v.rounds_run = d.rounds_run;
+        }
+    } else if (slow) {
         int rc = merge_slow(h, &v);  // waits for the stream
         if (rc) return rc;
     } else if (commit) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     HIPCHK(h, hipGetLastError());
+    h->last_pending = v.claimants + v.spillcand;
+    h->last_pending_valid = true;
+    h->last_slow = slow;
     fill_stats(v, h->n, stats);
     return RIO_GP_OK;
 }
@@ -523,18 +554,30 @@ int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t
     return RIO_GP_OK;
 }
 
+// Liveness push without a host wait: bitmap packed here, delivered in the arguments of one tiny kernel.
+static int push_alive_bits(rio_gp* h) {
+    static_assert(RIO_GP_MAX_NODES <= 256 * 32, "WordPack holds RIO_GP_MAX_NODES bits");
+    WordPack pk;
+    const u32 words = (h->m + 31) / 32;
+    memset(pk.w, 0, sizeof(u32) * (words ? words : 1));
+    h->all_alive = true;
+    for (uint32_t j = 0; j < h->m; ++j) {
+        if (h->h_alive[j]) pk.w[j >> 5] |= 1u << (j & 31);
+        else h->all_alive = false;
+    }
+    launch_store_words(pk, words, h->alive_bits, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
 int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive) {
     if (!h || !alive) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     if (m != h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive_all: m differs from the node table");
     HIPCHK(h, hipSetDevice(h->device));
-    h->all_alive = true;
-    for (uint32_t j = 0; j < m; ++j) { h->h_alive[j] = alive[j] ? 1 : 0; h->all_alive = h->all_alive && alive[j]; }
-    if (m) HIPCHK(h, hipMemcpyAsync(h->alive_bytes, h->h_alive.data(), m, hipMemcpyHostToDevice, h->stream));
-    launch_pack_alive(h->alive_bytes, m, h->alive_bits, h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->have_solved = false;
-    return RIO_GP_OK;
+    for (uint32_t j = 0; j < m; ++j) h->h_alive[j] = alive[j] ? 1 : 0;
+    return push_alive_bits(h);
 }
 
 int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive) {
@@ -543,13 +586,7 @@ int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive) {
     if (node >= h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive: node out of range");
     HIPCHK(h, hipSetDevice(h->device));
     h->h_alive[node] = alive ? 1 : 0;
-    h->all_alive = true;
-    for (uint32_t j = 0; j < h->m; ++j) h->all_alive = h->all_alive && h->h_alive[j];
-    HIPCHK(h, hipMemcpyAsync(h->alive_bytes, h->h_alive.data(), h->m, hipMemcpyHostToDevice, h->stream));
-    launch_pack_alive(h->alive_bytes, h->m, h->alive_bits, h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->have_solved = false;
-    return RIO_GP_OK;
+    return push_alive_bits(h);
 }
 
 int rio_gp_get_nodes(rio_gp_t* h, uint32_t m, uint64_t* cap, uint8_t* alive, uint64_t* used) {
@@ -1072,7 +1109,7 @@ int rio_gp_shard_cut(rio_gp_t* h, int run_local_fixup, uint64_t* d_y) {
     if (h->sh_state != 2 || !h->sh_slow) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_cut: no fix-up pending");
     HIPCHK(h, hipSetDevice(h->device));
     const SolveBufs b = shard_bufs(h);
-    if (run_local_fixup) launch_cut_fixup(h->plan, real_table(h), real_nodes(h), b, false, h->stream);
+    if (run_local_fixup) launch_cut_fixup(h->plan, real_table(h), real_nodes(h), b, false, h->stream, h->fixup_mode == 1);
     launch_shard_export_delta(h->plan, b, h->sb.used_kept, 0, reinterpret_cast<u64*>(d_y), h->stream);
     h->sh_state = 3;
     return RIO_GP_OK;
@@ -1389,6 +1426,14 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     if (!h || mode < 0 || mode > 2) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     h->compact_mode = mode;
+    return RIO_GP_OK;
+}
+
+int rio_gp_debug_set_fixup(rio_gp_t* h, int fused, int speculate) {
+    if (!h || fused < 0 || fused > 1 || speculate < 0 || speculate > 2) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->fixup_mode = fused;
+    h->spec_mode = speculate;
     return RIO_GP_OK;
 }
 

@@ -113,6 +113,7 @@ def lib():
         L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
+        L.rio_gp_debug_set_fixup.argtypes = [_vp, C.c_int, C.c_int]
         L.rio_gp_timer_begin.argtypes = [_vp]
         L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
         _lib = L
@@ -285,6 +286,11 @@ class GpuPlacement:
     def set_compact(self, mode):
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode)."""
         self._chk(lib().rio_gp_debug_set_compact(self._h, {"auto": 0, "always": 1, "never": 2}.get(mode, mode)))
+
+    def set_fixup(self, fused=True, speculate="auto"):
+        """fused cut fix-up on/off; speculative enqueue auto | always | never (results identical in every mode)."""
+        self._chk(lib().rio_gp_debug_set_fixup(self._h, 1 if fused else 0,
+                                               {"auto": 0, "always": 1, "never": 2}.get(speculate, speculate)))
 
     def timer_begin(self):
         self._chk(lib().rio_gp_timer_begin(self._h))

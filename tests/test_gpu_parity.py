@@ -22,6 +22,10 @@ def gp():
     return rio_gp
 
 
+FIXUP_VARIANTS = (("never", False, "never"), ("always", False, "never"),
+                  ("never", True, "always"), ("always", True, "always"), ("always", True, "never"))
+
+
 def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
     g = gp.GpuPlacement(max(n, 1), max(m, 1), spill_rounds=rounds)
     g.set_nodes(cap, alive, m=m)
@@ -34,9 +38,13 @@ def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
 def _check_tick(gp, oracle, cur, load, aff, cap, alive, rounds=2):
     n, m = len(cur), len(cap)
     want, used, ost = oracle.tick(cur, load, aff, cap, alive, rounds)
-    for mode in ("never", "always"):   # fix-up over the whole table | over the packed pending rows: same answer
+    # Every implementation of the fix-up must give the same bytes: over the whole table | over the packed pending rows;
+    # unfused launch chain | k_cut_fused with the scatter folded into the water-fill; enqueued after the host has read
+    # the verdict | speculatively behind k_resolve (device-side guards).
+    for mode in FIXUP_VARIANTS:
         g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds)
-        g.set_compact(mode)
+        g.set_compact(mode[0])
+        g.set_fixup(fused=mode[1], speculate=mode[2])
         st = g.solve()
         got = g.get_solved()
         assert np.array_equal(got, want), (mode, np.flatnonzero(got != want)[:10])
@@ -298,12 +306,15 @@ def test_async_solves_match_sync(gp, oracle):
     g.close()
 
 
-def test_churn_stream_adaptive_packed_fixup(gp, oracle):
+@pytest.mark.parametrize("fused,spec", [(True, "auto"), (False, "never"), (True, "always")])
+def test_churn_stream_adaptive_packed_fixup(gp, oracle, fused, spec):
     """Config-5 shape: committed ticks while a different 10 % of the nodes is down each tick.  From the second tick
-    on the adaptive rule switches to the packed fix-up (few rows pending); every tick must equal the oracle chain."""
+    on the adaptive rule switches to the packed fix-up (few rows pending) and — fused fix-up — enqueues it
+    speculatively, without reading the verdict first; every tick must equal the oracle chain."""
     cfg = synth.config("c3", n_override=1_500_000)
     n, m = cfg["n"], cfg["m"]
     g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"], synth.warm_assign(n, m))
+    g.set_fixup(fused=fused, speculate=spec)
     ref = synth.warm_assign(n, m)
     for tick in range(6):
         alive = synth.churn_mask(m, 2 + tick)
