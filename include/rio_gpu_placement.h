@@ -286,6 +286,8 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 int rio_gp_debug_set_fixup(rio_gp_t* h, int fused, int speculate);
 /* A/B knob for tools/sweep_scan.py: tiles per wave-iteration of k_scan (1 | 2 | 4); process-wide. */
 void rio_gp_debug_set_scan_tpi(int tpi);
+/* measurement aid: read (out2048 != NULL: 256 workgroups x 8 words) and switch the phase trace of k_cut_fused */
+int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048);
 /* Measurement aid: pure streaming kernels with k_scan's traffic mix (3 columns in, 1 out) over the handle's
  * own columns; mode 0 grid-stride | 1 block-tiled | 2 wave-contiguous | 3 read-only | 4 1:1 copy.  ms per launch. */
 int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms);

@@ -118,6 +118,8 @@ void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* h
                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 unsigned resolve_blocks(u32 m);
 void set_scan_tpi(int tpi);
+int cut_trace_enable(int on);  // k_cut_fused phase trace (measurement aid)
+int cut_trace_read(u64* out /*[kMaxBlocks*8]*/);
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1);
 void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,

@@ -27,7 +27,20 @@ namespace riogp {
 // helpers
 // ------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ u64 shfl_up64(u64 v, int d) {
+// Cross-lane helpers.  Scans and sums run on DPP (row_shr within a row of 16 lanes, row_bcast:15 / :31 across rows —
+// gfx9 wave64 only): VALU moves of a few cycles each instead of ds_bpermute round trips through the LDS crossbar
+// (12 dependent bpermutes per u64 scan were the latency floor of every ordered-prefix search).
+template <int CTRL>
+__device__ __forceinline__ u64 dpp64(u64 v) {  // lanes without a valid source read 0
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, CTRL, 0xf, 0xf, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((u64)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ u32 dpp32(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64 shfl_up64(u64 v, int d) {  // general shuffles (ds_bpermute): off the hot loops
     u32 lo = __shfl_up((u32)v, d, 64), hi = __shfl_up((u32)(v >> 32), d, 64);
     return ((u64)hi << 32) | lo;
 }
@@ -35,17 +48,22 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int d) {
     u32 lo = __shfl_xor((u32)v, d, 64), hi = __shfl_xor((u32)(v >> 32), d, 64);
     return ((u64)hi << 32) | lo;
 }
+// value of a WAVE-UNIFORM lane (src must be the same in every lane: a constant or derived from a ballot)
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
-    u32 lo = __shfl((u32)v, src, 64), hi = __shfl((u32)(v >> 32), src, 64);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, src);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), src);
     return ((u64)hi << 32) | lo;
 }
 // inclusive prefix sum over the 64 lanes of a wave
 __device__ __forceinline__ u64 wave_incl_scan(u64 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u64 t = shfl_up64(v, d);
-        if (lane >= d) v += t;
-    }
+    const int rl = lane & 15;
+    u64 t;
+    t = dpp64<0x111>(v); if (rl >= 1) v += t;               // row_shr:1
+    t = dpp64<0x112>(v); if (rl >= 2) v += t;               // row_shr:2
+    t = dpp64<0x114>(v); if (rl >= 4) v += t;               // row_shr:4
+    t = dpp64<0x118>(v); if (rl >= 8) v += t;               // row_shr:8
+    t = dpp64<0x142>(v); if ((lane & 31) >= 16) v += t;     // row_bcast:15
+    t = dpp64<0x143>(v); if (lane >= 32) v += t;            // row_bcast:31
     return v;
 }
 __device__ __forceinline__ u64 sat_add(u64 a, u64 b) {
@@ -53,22 +71,30 @@ __device__ __forceinline__ u64 sat_add(u64 a, u64 b) {
     return s < a ? ~0ull : s;
 }
 __device__ __forceinline__ u64 wave_incl_scan_sat(u64 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u64 t = shfl_up64(v, d);
-        if (lane >= d) v = sat_add(v, t);
-    }
+    const int rl = lane & 15;
+    u64 t;
+    t = dpp64<0x111>(v); if (rl >= 1) v = sat_add(v, t);
+    t = dpp64<0x112>(v); if (rl >= 2) v = sat_add(v, t);
+    t = dpp64<0x114>(v); if (rl >= 4) v = sat_add(v, t);
+    t = dpp64<0x118>(v); if (rl >= 8) v = sat_add(v, t);
+    t = dpp64<0x142>(v); if ((lane & 31) >= 16) v = sat_add(v, t);
+    t = dpp64<0x143>(v); if (lane >= 32) v = sat_add(v, t);
     return v;
 }
+// sum over the wave, the same value in every lane (readlane 63 of the scan)
 __device__ __forceinline__ u64 wave_sum(u64 v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += shfl_xor64(v, d);
-    return v;
+    return shfl64(wave_incl_scan(v, (int)(threadIdx.x & 63)), 63);
 }
 __device__ __forceinline__ u32 wave_sum32(u32 v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    const int lane = (int)(threadIdx.x & 63), rl = lane & 15;
+    u32 t;
+    t = dpp32<0x111>(v); if (rl >= 1) v += t;
+    t = dpp32<0x112>(v); if (rl >= 2) v += t;
+    t = dpp32<0x114>(v); if (rl >= 4) v += t;
+    t = dpp32<0x118>(v); if (rl >= 8) v += t;
+    t = dpp32<0x142>(v); if ((lane & 31) >= 16) v += t;
+    t = dpp32<0x143>(v); if (lane >= 32) v += t;
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 // Balanced, index-ordered split of the table: wave gw owns tiles [gw*tiles/nw, (gw+1)*tiles/nw).
 __host__ __device__ __forceinline__ u64 wave_row_lo(const Plan& p, u64 gw) { return (gw * p.tiles / p.nw) * kTile; }
@@ -684,7 +710,20 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
 //       P3  claimants with i >= thr[aff] lose the optimistic assignment (k_apply_cut's pass).
 //     Rows are streamed twice (P1, P3: the second pass hits L2/MALL) only in blocks that own a cut.
 // ------------------------------------------------------------------------------------------------
+// Phase trace of k_cut_fused (measurement aid, off by default): workgroup b stores wall_clock64() (100 MHz) at its phase
+// boundaries into g_cut_trace[b][0..7] = start, P0 end, P1 time, P2 time, P3 time, nloc, S, P2a time.
+__device__ int g_cut_trace_on = 0;
+__device__ u64 g_cut_trace[kMaxBlocks * 8];
+#define RIOGP_TRACE(slot, val) do { if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + (slot)] = (val); } while (0)
+
 constexpr u32 kSlotNone = 0xFFFFu;
+constexpr int kCutMinSubs = 16;  // coarsest sub-chunking of a block (= one sub-chunk per wave range on average)
+
+// fixed LDS of k_cut_fused in front of the T region (keep in step with cut_fused_lds)
+__host__ __device__ __forceinline__ size_t cut_fused_fixed(u32 m, u32 mwords) {
+    const u32 mr = (m + 7) & ~7u;
+    return kSmall + (size_t)mr * 8 + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 2 * kWaves * sizeof(u64);
+}
 
 template <bool VIRT>
 __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cur, const u32* __restrict__ load,
@@ -695,21 +734,30 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
                                                       const u64* __restrict__ used_kept,
                                                       const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
                                                       u64* __restrict__ used_cur, u64* __restrict__ wsp_sum,
-                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 K) {
+                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 tcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 m = p.m, mr = (m + 7) & ~7u, subs = p.subs;
+    const u32 m = p.m, mr = (m + 7) & ~7u;
     u32& nlocal = *reinterpret_cast<u32*>(smem);
     u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
     u32* thr = reinterpret_cast<u32*>(smem + kSmall);                        // [mr] reject threshold by node
     unsigned short* slot = reinterpret_cast<unsigned short*>(thr + mr);      // [mr] local slot of a node or kSlotNone
     unsigned short* node_of = slot + mr;                                     // [mr] node of a local slot
     u32* alv = reinterpret_cast<u32*>(node_of + mr);                         // [(mwords+3)&~3]
-    u64* T = reinterpret_cast<u64*>(alv + ((p.mwords + 3) & ~3u));           // [K][subs]
+    u64* rlo = reinterpret_cast<u64*>(alv + ((p.mwords + 3) & ~3u));         // [16] first row position of wave range w
+    u64* whi = rlo + kWaves;                                                 // [16] end of its LIVE rows (n / packed count)
+    u64* T = whi + kWaves;                                                   // [tcap]: T[K][S] from the front,
+                                                                             //         budget of slot s at T[tcap-1-s]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x;
     if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
+    RIOGP_TRACE(0, wall_clock64());
     if (tid == 0) { nlocal = 0; red[0] = 0; red[1] = 0; }
     for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    const u64 gw = (u64)b * kWaves + wave;
+    const u64 bstart = block_row_lo(p, b);
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+    if (lane == 0) { rlo[wave] = wave_row_lo(p, gw); whi[wave] = wend; }
     __syncthreads();
     for (u32 j = tid; j < m; j += kBlock) {
         const u32 cbv = cutblk[j];
@@ -723,45 +771,68 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
         } else if (cbv == b) {
             s = atomicAdd(&nlocal, 1u);
             node_of[s] = (unsigned short)j;
+            T[tcap - 1 - s] = budget[j];  // s < m <= tcap - kCutMinSubs (cut_fused_lds)
         }
         thr[j] = t;
         slot[j] = (unsigned short)s;
     }
     __syncthreads();
     const u32 nloc = nlocal;
-    const u64 gw = (u64)b * kWaves + wave;
-    const u64 bstart = block_row_lo(p, b);
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
+    // Sub-chunking of THIS block, chosen so that all its local nodes share one pass when they fit: cuts are not spread
+    // evenly over blocks (a nearly full cluster cuts every node within its first claimants, i.e. in block 0), and
+    // a pass per 48 nodes with a serial row search per node is what made such a block take >100 us.  mult finest
+    // sub-chunks (p.sub rows each) form one sub-chunk; S of them cover the block; K nodes share a pass.
+    const u32 tfree = tcap - nloc;
+    u32 mult = 1;
+    if (nloc) {
+        const u32 smax = tfree / nloc;  // T words per node that fit if every local node is in ONE group
+        if (smax < (p.subs | 1u)) {
+            const u32 want = smax <= (u32)kCutMinSubs ? (u32)kCutMinSubs : smax - 1;
+            mult = (p.subs + want - 1) / want;
+        }
+    }
+    const u32 S = (p.subs + mult - 1) / mult;
+    const u32 Sp = (S | 1u) < 3u ? 3u : (S | 1u);    // T row stride: odd (lane-per-node walks are bank-conflict free),
+                                                     // >= 3 (the row is reused for the node's search record)
+    const u32 stiles = (p.sub / kTile) * mult;       // tiles per sub-chunk
+    const u64 srows = (u64)stiles * kTile;
+    u32 K = tfree / Sp;
+    if (K < 1) K = 1;
+    u64 bend = block_row_lo(p, b + 1);
+    if (bend > p.n) bend = p.n;
+    RIOGP_TRACE(1, wall_clock64());
+    RIOGP_TRACE(5, (u64)nloc);
+    RIOGP_TRACE(6, (u64)S);
+    u64 tr_p1 = 0, tr_p2 = 0, tr_p2a = 0;
 
     for (u32 g0 = 0; g0 < nloc; g0 += K) {
         const u32 kn = nloc - g0 < K ? nloc - g0 : K;
-        for (u32 k = tid; k < kn * subs; k += kBlock) T[k] = 0;
+        const u64 tr_a = g_cut_trace_on ? wall_clock64() : 0;
+        for (u32 k = tid; k < kn * Sp; k += kBlock) T[k] = 0;
         __syncthreads();
-        // P1: claim load per (local node, sub-chunk); a tile (256 rows) lies inside ONE sub-chunk (sub % 256 == 0)
+        // P1: claim load per (local node, sub-chunk); a tile (256 rows) lies inside ONE sub-chunk
         for (u64 it = wstart; it < wend; it += kTile) {
             const u64 i0 = it + (u64)lane * 4;
             const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
             const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
             const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
-            const u32 t = (u32)((it - bstart) / p.sub);
+            const u32 t = (u32)((it - bstart) / kTile) / stiles;
 #define RIOGP_ROW(C, A, L, E)                                                                              \
             {                                                                                              \
                 bool hit = i0 + E < wend && classify<VIRT>(C, A, m, alv) == 1;                             \
                 u32 ls = 0;                                                                                \
-                if (hit) { ls = (u32)slot[A] - g0; hit = ls < kn; }  /* kSlotNone - g0 >= kn: K <= 64 */   \
-                u64 todo = __ballot(hit);                                                                  \
-                if (__popcll(todo) <= 8) {                                                                 \
-                    if (hit) atomicAdd(&T[ls * subs + t], (u64)L);                                         \
-                    todo = 0;                                                                              \
-                }                                                                                          \
-                while (todo) { /* hot node: one LDS atomic per (node, tile) instead of one per row */      \
+                if (hit) { ls = (u32)slot[A] - g0; hit = ls < kn; }  /* kSlotNone - g0 >= kn always */     \
+                const u64 todo = __ballot(hit);                                                            \
+                if (todo) { /* a HOT node (>= 16 rows of this wave-element) costs one LDS atomic, not 16+ */ \
                     const int ld = __ffsll((long long)todo) - 1;                                           \
                     const u32 s0 = (u32)__shfl((int)ls, ld, 64);                                           \
                     const bool same = hit && ls == s0;                                                     \
-                    const u64 sum = wave_sum(same ? (u64)L : 0ull);                                        \
-                    if (lane == ld) atomicAdd(&T[s0 * subs + t], sum);                                     \
-                    todo &= ~__ballot(same);                                                               \
+                    if (__popcll(__ballot(same)) >= 16) {                                                  \
+                        const u64 sum = wave_sum(same ? (u64)L : 0ull);                                    \
+                        if (lane == ld) atomicAdd(&T[s0 * Sp + t], sum);                                    \
+                        hit = hit && !same;                                                                \
+                    }                                                                                      \
+                    if (hit) atomicAdd(&T[ls * Sp + t], (u64)L);                                            \
                 }                                                                                          \
             }
             RIOGP_ROW(cv.x, av.x, lv.x, 0)
@@ -771,62 +842,183 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
 #undef RIOGP_ROW
         }
         __syncthreads();
-        // P2: one wave per local node — sub-chunk, then exact row (k_cut_exact's search, T row in LDS)
-        for (u32 ls = wave; ls < kn; ls += kWaves) {
-            const u32 j = node_of[g0 + ls];
-            const u64 bud = budget[j];
-            const u64* Tj = T + (size_t)ls * subs;
-            u64 acc = 0, pre_sub = 0;
-            u32 tstar = 0;
-            bool found = false;
-            for (u32 g = 0; g < subs && !found; g += 64) {
-                const u32 t = g + lane;
-                const u64 v = t < subs ? Tj[t] : 0;
-                const u64 inc = wave_incl_scan(v, lane);
-                const u64 mask = __ballot(acc + inc > bud);
-                if (mask) {
-                    const int fl = __ffsll((long long)mask) - 1;
-                    tstar = g + fl;
-                    pre_sub = acc + shfl64(inc - v, fl);
-                    found = true;
-                } else {
-                    acc += shfl64(inc, 63);
+        const u64 tr_b = g_cut_trace_on ? wall_clock64() : 0;
+        // P2a: per local node, the sub-chunk that holds the cut (ordered walk over its T row), then the first tile of it
+        //      with live rows (packed fix-up: most positions of a range are dead); the search record {start | end<<32,
+        //      budget inside the sub-chunk, load admitted before it} goes into the first three words of the node's own
+        //      T row.  LDS only.  Two forms, picked by estimated instruction count: one LANE per node (many nodes, short
+        //      rows: row stride odd, so no bank conflicts) or one WAVE per node with a DPP scan (few nodes, long rows).
+        auto first_live = [&](u64 st, u64 en) -> u64 {  // uniform or per-lane: only LDS broadcast reads
+            while (st + kTile < en) {
+                int w = 0;
+                for (int q = 1; q < kWaves; ++q) w += rlo[q] <= st;
+                if (whi[w] > st) break;
+                st += kTile;
+            }
+            return st;
+        };
+        const u32 cost_lane = ((S + 7) / 8) * 100u;
+        const u32 cost_wave = ((kn + kWaves - 1) / kWaves) * (((S + 63) / 64) * 80u + 120u);
+        if (cost_lane <= cost_wave) {
+            for (u32 ls = tid; ls < kn; ls += kBlock) {
+                u64* Tj = T + (size_t)ls * Sp;
+                const u64 bud = T[tcap - 1 - (g0 + ls)];
+                u64 acc = 0;
+                u32 tstar = S;
+                for (u32 t0 = 0; t0 < S && tstar == S; t0 += 8) {  // 8 independent LDS reads, then a branch-free ordered walk
+                    u64 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = t0 + q < S ? Tj[t0 + q] : 0ull;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const u64 nv = acc + v[q];
+                        const bool open = tstar == S;
+                        const bool over = nv > bud;  // padding words are 0: never over
+                        tstar = (open && over) ? t0 + q : tstar;
+                        acc = (open && !over) ? nv : acc;
+                    }
+                }
+                if (tstar == S) { tstar = 0; acc = 0; }  // no overflow anywhere (k_cutblk says there is one): block start
+                const u64 st0 = bstart + (u64)tstar * srows;
+                u64 en = st0 + srows;
+                if (en > bend) en = bend;
+                const u64 st = first_live(st0, en);
+                Tj[0] = st | (en << 32);  // rows are u32-indexed
+                Tj[1] = bud - acc;
+                Tj[2] = acc;
+            }
+        } else {
+            for (u32 ls = wave; ls < kn; ls += kWaves) {
+                u64* Tj = T + (size_t)ls * Sp;
+                const u64 bud = T[tcap - 1 - (g0 + ls)];
+                u64 acc = 0, pre = 0;
+                u32 tstar = 0;
+                bool found = false;
+                for (u32 g = 0; g < S && !found; g += 64) {
+                    const u32 t = g + lane;
+                    const u64 v = t < S ? Tj[t] : 0;
+                    const u64 inc = wave_incl_scan(v, lane);
+                    const u64 mask = __ballot(acc + inc > bud);
+                    if (mask) {
+                        const int fl = __ffsll((long long)mask) - 1;
+                        tstar = g + fl;
+                        pre = acc + shfl64(inc - v, fl);
+                        found = true;
+                    } else {
+                        acc += shfl64(inc, 63);
+                    }
+                }
+                const u64 st0 = bstart + (u64)tstar * srows;
+                u64 en = st0 + srows;
+                if (en > bend) en = bend;
+                const u64 st = first_live(st0, en);
+                if (lane == 0) {  // every lane has read its words of the row (the scan consumed them) before this store
+                    Tj[0] = st | (en << 32);
+                    Tj[1] = bud - pre;
+                    Tj[2] = pre;
                 }
             }
-            const u64 bud2 = bud - pre_sub;
-            const u64 start = bstart + (u64)tstar * p.sub;
-            u64 end = start + p.sub;
-            if (end > block_row_lo(p, b + 1)) end = block_row_lo(p, b + 1);
-            if (end > p.n) end = p.n;
+        }
+        __syncthreads();
+        if (g_cut_trace_on) tr_p2a += wall_clock64() - tr_b;
+        // P2b: one wave per node, three nodes per wave in flight — the exact row inside the sub-chunk, tile by tile
+        //      (dwordx4 columns, in-tile order = lane, element).  The tiles and node words of three nodes are requested
+        //      before the first is searched: a workgroup that owns hundreds of cuts is bound by the round trips of its
+        //      16 waves, so each trip has to carry several nodes.
+        struct Job { u32 ls; uint4 c, a, l; u64 uk, ad; };  // only what is in flight; the record is re-read from LDS
+        auto fetch = [&](Job& q, u32 ls) {
+            const u64 start = T[(size_t)ls * Sp] & 0xFFFFFFFFull;
+            const u32 j = node_of[g0 + ls];
+            q.ls = ls;
+            q.c = *reinterpret_cast<const uint4*>(cur + start + (u64)lane * 4);
+            q.a = *reinterpret_cast<const uint4*>(aff + start + (u64)lane * 4);
+            q.l = *reinterpret_cast<const uint4*>(load + start + (u64)lane * 4);
+            q.uk = used_kept[j];
+            q.ad = admpre[j];
+        };
+        auto run = [&](const Job& q) {
+            const u64* Tj = T + (size_t)q.ls * Sp;
+            const u64 se = Tj[0];
+            const u64 q_start = se & 0xFFFFFFFFull, q_end = se >> 32;
+            const u64 bud2 = Tj[1], q_pre_sub = Tj[2];
+            const u32 j = node_of[g0 + q.ls];
             u64 acc2 = 0, cut_row = kNoCut, adm_in = 0;
-            found = false;
-            for (u64 i0 = start; i0 < end && !found; i0 += 64) {
-                const u64 i = i0 + lane;
-                bool is_cl = false;
-                u64 l = 0;
-                if (i < end && packed_live(p, i)) {
-                    const u32 c = cur[i], a = aff[i];
-                    if (a == j && classify<VIRT>(c, a, m, alv) == 1) { is_cl = true; l = load[i]; }
+            // one tile of the search: rows of node j's claimants in (lane, element) order against bud2
+            auto scan1 = [&](const uint4& xc, const uint4& xa, const uint4& xl, u64 t0) -> bool {
+                // the wave range this tile lies in (ranges are whole tiles) and where its live rows end
+                const int w = __popcll(__ballot(lane < kWaves && rlo[lane & (kWaves - 1)] <= t0)) - 1;
+                const u64 lim = whi[w < 0 ? 0 : w];
+                const u64 i0 = t0 + (u64)lane * 4;
+                u64 l0, l1, l2, l3;
+                bool k0, k1, k2, k3;
+                // branch-free: j is a live node, so "claimant of j" = aff == j and the row is pending (not kept, not a
+                // duplicate request); short-circuit && here costs an exec-mask branch per term and element
+#define RIOGP_EL(C, A, L, E, KO, LO)                                                        \
+                {                                                                            \
+                    const u32 cx = C < m ? C : 0u;                                           \
+                    const bool keptx = VIRT ? (C < m) : ((C < m) & bit_of(alv, cx));         \
+                    KO = (i0 + E < lim) & (A == j) & !keptx & !(VIRT && C == kSkipMark);     \
+                    LO = KO ? (u64)L : 0ull;                                                 \
                 }
-                const u64 inc = wave_incl_scan(l, lane);
-                const u64 mask = __ballot(is_cl && acc2 + inc > bud2);
+                RIOGP_EL(xc.x, xa.x, xl.x, 0, k0, l0)
+                RIOGP_EL(xc.y, xa.y, xl.y, 1, k1, l1)
+                RIOGP_EL(xc.z, xa.z, xl.z, 2, k2, l2)
+                RIOGP_EL(xc.w, xa.w, xl.w, 3, k3, l3)
+#undef RIOGP_EL
+                const u64 s1 = l0 + l1, s2 = s1 + l2, s3 = s2 + l3;
+                const u64 inc = wave_incl_scan(s3, lane);
+                const u64 ex = acc2 + inc - s3;  // load of this node's claimants before this lane's rows
+                int e = 4;
+                if (k3 && ex + s3 > bud2) e = 3;
+                if (k2 && ex + s2 > bud2) e = 2;
+                if (k1 && ex + s1 > bud2) e = 1;
+                if (k0 && ex + l0 > bud2) e = 0;
+                const u64 mask = __ballot(e < 4);
                 if (mask) {
                     const int fl = __ffsll((long long)mask) - 1;
-                    cut_row = i0 + fl;
-                    adm_in = acc2 + shfl64(inc - l, fl);
-                    found = true;
-                } else {
-                    acc2 += shfl64(inc, 63);
+                    const int ef = __builtin_amdgcn_readlane(e, fl);
+                    const u64 before = ef == 0 ? 0ull : (ef == 1 ? l0 : (ef == 2 ? s1 : s2));
+                    cut_row = t0 + (u64)fl * 4 + (u64)ef;
+                    adm_in = shfl64(ex + before, fl);
+                    return true;
                 }
+                acc2 += shfl64(inc, 63);
+                return false;
+            };
+            bool found = scan1(q.c, q.a, q.l, q_start);
+            for (u64 t0 = q_start + kTile; t0 < q_end && !found; t0 += kTile) {  // rare: cut deeper in the sub-chunk
+                const int w = __popcll(__ballot(lane < kWaves && rlo[lane & (kWaves - 1)] <= t0)) - 1;
+                if (whi[w < 0 ? 0 : w] <= t0) continue;  // no live row in this tile: nothing to load
+                const uint4 xc = *reinterpret_cast<const uint4*>(cur + t0 + (u64)lane * 4);
+                const uint4 xa = *reinterpret_cast<const uint4*>(aff + t0 + (u64)lane * 4);
+                const uint4 xl = *reinterpret_cast<const uint4*>(load + t0 + (u64)lane * 4);
+                found = scan1(xc, xa, xl, t0);
             }
             if (lane == 0) {
                 thr[j] = (u32)cut_row;
                 cutidx[j] = (u32)cut_row;
-                used_cur[j] = used_kept[j] + admpre[j] + pre_sub + adm_in;
+                used_cur[j] = q.uk + q.ad + q_pre_sub + adm_in;
             }
+        };
+        constexpr int kInFlight = 3;
+        for (u32 base = wave; base < kn; base += kInFlight * kWaves) {
+            Job q[kInFlight];
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {  // clamped past the last node: the requests stay unconditional
+                const u32 ls = base + (u32)u * kWaves;
+                fetch(q[u], ls < kn ? ls : base);
+            }
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u)
+                if (base + (u32)u * kWaves < kn) run(q[u]);
         }
         __syncthreads();
+        if (g_cut_trace_on) { const u64 tr_c = wall_clock64(); tr_p1 += tr_b - tr_a; tr_p2 += tr_c - tr_b; }
     }
+    RIOGP_TRACE(2, tr_p1);
+    RIOGP_TRACE(3, tr_p2);
+    RIOGP_TRACE(7, tr_p2a);
+    RIOGP_TRACE(4, wall_clock64());
 
     // P3: re-mark the rejected claimants, rebuild the per-wave spill totals (candidates + rejected)
     u64 sp_sum = 0, rej_sum = 0;
@@ -865,6 +1057,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
         atomicAdd(&stats->rejected, red[0]);
         atomicAdd(&stats->load_rejected, red[1]);
     }
+    if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64() - g_cut_trace[(size_t)blockIdx.x * 8 + 4];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1772,6 +1965,8 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
 
 int g_scan_tpi = 1;  // tiles per wave-iteration of k_scan (1 | 2 | 4); set through set_scan_tpi() for A/B runs
 void set_scan_tpi(int tpi) { g_scan_tpi = tpi; }
+int cut_trace_enable(int on) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_trace_on), &on, sizeof on); }
+int cut_trace_read(u64* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cut_trace), sizeof(u64) * kMaxBlocks * 8); }
 
 template <bool VIRT, bool AA, int TPI, int HMODE = 0, bool COMPACT = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
@@ -1833,15 +2028,16 @@ void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* h
                            host_partial);
 }
 
-size_t cut_fused_lds(const Plan& p, u32* K_out) {
-    const u32 mr = (p.m + 7) & ~7u;
-    const size_t fixed = kSmall + (size_t)mr * 8 + (size_t)((p.mwords + 3) & ~3u) * sizeof(u32);
-    const size_t row = (size_t)p.subs * sizeof(u64);
-    size_t K = (150 * 1024 - fixed) / row;
-    if (K > 48) K = 48;
-    if (K < 1) K = 1;
-    *K_out = (u32)K;
-    return fixed + K * row;
+// dynamic LDS of k_cut_fused: the fixed tables + as many u64 slots of T as fit (a budget word per local node lives at
+// the end of T, so at least m + kCutMinSubs)
+size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
+    const size_t fixed = cut_fused_fixed(p.m, p.mwords);
+    size_t slots = (150 * 1024 - fixed) / sizeof(u64);
+    const size_t most = (size_t)p.m * ((p.subs | 1u) + 3);  // every node local to one block, finest sub-chunking
+    if (slots > most) slots = most;
+    if (slots < (size_t)p.m + 2 * kCutMinSubs) slots = (size_t)p.m + 2 * kCutMinSubs;  // m <= 8 192: never binds below 160 KiB
+    *tcap_out = (u32)slots;
+    return fixed + slots * sizeof(u64);
 }
 
 // fused: k_cutblk + k_cut_fused (default) | else the unfused chain: T memset, k_cutblk, k_cut_subhist, k_cut_exact,
@@ -1852,16 +2048,16 @@ void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
     if (fused) {
         hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
                            b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
-        u32 K = 1;
-        const size_t ldsf = cut_fused_lds(p, &K);
+        u32 tcap = 0;
+        const size_t ldsf = cut_fused_lds(p, &tcap);
         if (virt)
             hipLaunchKernelGGL(k_cut_fused<true>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, K);
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap);
         else
             hipLaunchKernelGGL(k_cut_fused<false>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, K);
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap);
         return;
     }
     (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);

@@ -1422,6 +1422,16 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
 
 void rio_gp_debug_set_scan_tpi(int tpi) { set_scan_tpi(tpi); }
 
+int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out2048 && cut_trace_read(reinterpret_cast<u64*>(out2048)) != 0) return fail(h, RIO_GP_EUPSTREAM, "cut trace read failed");
+    if (cut_trace_enable(enable) != 0) return fail(h, RIO_GP_EUPSTREAM, "cut trace enable failed");
+    return RIO_GP_OK;
+}
+
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     if (!h || mode < 0 || mode > 2) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);

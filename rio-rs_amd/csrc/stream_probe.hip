@@ -63,6 +63,21 @@ __global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ a,
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nv; i += (u64)gridDim.x * 256) o[i] = a[i];
 }
 
+// modes 7/8/9: grid-stride with non-temporal loads / stores / both (does the streaming hint help past the MALL?)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_probe_nt(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                  const u32x4* __restrict__ c, u32x4* __restrict__ o, u64 nv) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nv; i += (u64)gridDim.x * 256) {
+        const u32x4 x = NTL ? __builtin_nontemporal_load(a + i) : a[i];
+        const u32x4 y = NTL ? __builtin_nontemporal_load(b + i) : b[i];
+        const u32x4 z = NTL ? __builtin_nontemporal_load(c + i) : c[i];
+        const u32x4 r = x ^ y ^ z;
+        if (NTS) __builtin_nontemporal_store(r, o + i);
+        else o[i] = r;
+    }
+}
+
 // returns per-launch ms (dispatch timestamps) averaged over reps; bytes moved = see bench.py
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1) {
@@ -77,6 +92,9 @@ float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u
             case 2: hipExtLaunchKernelGGL(k_probe_wavecontig, dim3(256), dim3(1024), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             case 3: hipExtLaunchKernelGGL(k_probe_readonly, dim3(2048), dim3(256), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             case 5: hipExtLaunchKernelGGL(k_probe_gridstride, dim3(8192), dim3(256), 0, s, e0, e1, 0, A, B, C, O, nv); break;
+            case 7: hipExtLaunchKernelGGL((k_probe_nt<true, false>), dim3(2048), dim3(256), 0, s, e0, e1, 0, (const u32x4*)a, (const u32x4*)b, (const u32x4*)c, (u32x4*)o, nv); break;
+            case 8: hipExtLaunchKernelGGL((k_probe_nt<false, true>), dim3(2048), dim3(256), 0, s, e0, e1, 0, (const u32x4*)a, (const u32x4*)b, (const u32x4*)c, (u32x4*)o, nv); break;
+            case 9: hipExtLaunchKernelGGL((k_probe_nt<true, true>), dim3(2048), dim3(256), 0, s, e0, e1, 0, (const u32x4*)a, (const u32x4*)b, (const u32x4*)c, (u32x4*)o, nv); break;
             case 6: hipExtLaunchKernelGGL(k_probe_gridstride, dim3(1024), dim3(256), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             default: hipExtLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, s, e0, e1, 0, A, O, nv); break;
         }

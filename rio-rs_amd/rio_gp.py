@@ -113,6 +113,7 @@ def lib():
         L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
+        L.rio_gp_debug_cut_trace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
         L.rio_gp_debug_set_fixup.argtypes = [_vp, C.c_int, C.c_int]
         L.rio_gp_timer_begin.argtypes = [_vp]
         L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
@@ -282,6 +283,13 @@ class GpuPlacement:
         ms = C.c_float(0)
         self._chk(lib().rio_gp_debug_stream_probe(self._h, mode, reps, C.byref(ms)))
         return float(ms.value)
+
+    def cut_trace(self, enable=True, read=False):
+        """k_cut_fused phase trace (measurement aid): returns [256][8] u64 = start, P0 end, P1 total, P2 total, P3 time,
+        nloc, S, groups (100 MHz ticks) of the last launch when read=True."""
+        out = (C.c_uint64 * 2048)() if read else None
+        self._chk(lib().rio_gp_debug_cut_trace(self._h, 1 if enable else 0, out))
+        return np.ctypeslib.as_array(out).reshape(256, 8).copy() if read else None
 
     def set_compact(self, mode):
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode)."""

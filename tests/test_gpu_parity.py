@@ -231,6 +231,21 @@ def test_tick_tiny_capacity_cuts_in_first_block(gp, oracle):
                 rng.integers(0, 40, m).astype(np.uint64), np.ones(m, np.uint8))
 
 
+@pytest.mark.parametrize("n,m,maxcap,zero_loads", [(600_000, 4096, 60, False), (1_200_000, 8192, 30, True),
+                                                      (3_000_000, 2048, 2000, True)])
+def test_tick_cuts_concentrated_in_few_blocks(gp, oracle, n, m, maxcap, zero_loads):
+    """A nearly full cluster: every node's cut lies within its first claimants, so ONE workgroup owns hundreds or
+    thousands of cuts (k_cut_fused: coarser sub-chunks so they share a pass, several groups when even that does not
+    fit, pipelined per-node row search).  Zero-load claimants ride along until the first overflow."""
+    rng = np.random.default_rng(60 + m)
+    load = rng.integers(0 if zero_loads else 1, 12, n).astype(np.uint32)
+    cap = rng.integers(0, maxcap, m).astype(np.uint64)
+    cap[rng.integers(0, m, m // 16)] = 0
+    alive = np.ones(m, np.uint8)
+    alive[rng.integers(0, m, m // 50)] = 0
+    _check_tick(gp, oracle, np.full(n, NONE, np.uint32), load, rng.integers(0, m, n).astype(np.uint32), cap, alive)
+
+
 def test_tick_edge_shapes(gp, oracle):
     one = np.ones(1, np.uint8)
     _check_tick(gp, oracle, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32),
