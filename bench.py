@@ -169,6 +169,11 @@ def main():
                 for _ in range(max(a.warmup, 2)):
                     sol.solve_async()
                 st, n_slow = sol.solve_wait()
+                # an exchange that delivers wrong records must not survive the warm-up: every row decided exactly
+                # once and every unit of load accounted for, on the GLOBAL table
+                if st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] != n * world or \
+                        st["load_kept"] + st["load_claimed"] + st["load_spilled"] + st["load_unplaced"] != int(tot.item()):
+                    raise RuntimeError("exchange '%s' produced inconsistent global stats: %r" % (kind, st))
             except Exception as e:  # set-up failure raises on every rank; a warm-up failure may be local
                 ok, why = 0, str(e)
             flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
