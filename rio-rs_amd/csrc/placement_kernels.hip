@@ -1744,6 +1744,156 @@ __global__ __launch_bounds__(kBlock) void k_p2p_wait_copy(const u64* __restrict_
             if (out) out[(size_t)r * words + i] = RIOGP_SYS_LOAD(win_slot + (size_t)r * W + i);
 }
 
+// K2x k_resolve_xchg — the whole fast-path exchange of the row-sharded solve in ONE launch over peer-to-peer windows
+//     (replaces k_resolve_put + k_shard_import<P2P>: two launches, a "last workgroup" fold, a flag per rank and a
+//     single-workgroup import).  Node tables couple the ranks only node by node, so every workgroup exchanges and
+//     resolves ITS OWN four nodes: local column sums of H for 4 nodes x {kept, claim} + its slice of the row counters
+//     go straight into every peer's window row of this rank as DATA-TAGGED granules — each u64 travels as two 8-byte
+//     words {low half | tag}, {high half | tag}, tag = the step's sequence number — so there is no flag, no store
+//     drain and no release fence on the path: a consumer polls the very words it needs until both carry this step's
+//     tag (an 8-byte store is delivered whole; a stale word carries the tag of four steps ago).  Then the four nodes are
+//     resolved against the global sums (k_shard_import's per-node maths) and one partial verdict row goes to the host
+//     slot (the host adds the rows up, as after k_resolve).  No workgroup waits for another one of its own rank.
+//     Row layout (u64 words, row stride W >= shard_xchg_words(m)): value v of {kept[m] | claim[m] | nb x 8 counters}
+//     at words 2v, 2v+1.
+__device__ __forceinline__ void xchg_put(u64* row, size_t v, u64 x, u32 tag) {
+    RIOGP_SYS_STORE(row + 2 * v, (x & 0xFFFFFFFFull) | ((u64)tag << 32));
+    RIOGP_SYS_STORE(row + 2 * v + 1, (x >> 32) | ((u64)tag << 32));
+}
+__device__ __forceinline__ u64 xchg_get(const u64* row, size_t v, u32 tag, u64* err) {
+    const u64 t0 = wall_clock64();
+    for (;;) {
+        const u64 g0 = RIOGP_SYS_LOAD(row + 2 * v), g1 = RIOGP_SYS_LOAD(row + 2 * v + 1);
+        if ((u32)(g0 >> 32) == tag && (u32)(g1 >> 32) == tag) return (g0 & 0xFFFFFFFFull) | (g1 << 32);
+        if (wall_clock64() - t0 > kP2PTimeoutTicks) {
+            RIOGP_SYS_STORE(err, 1ull);
+            return 0;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H, const u64* __restrict__ blkstat, Plan p,
+                                                      u64* const* __restrict__ peers, u32 R, u32 rank,
+                                                      size_t my_row_off /* of THIS rank's row, in every window */,
+                                                      const u64* __restrict__ win_rows /* row 0 of the slot, own window */,
+                                                      size_t W, u64 seq, u64* __restrict__ p2p_err,
+                                                      const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
+                                                      u64* __restrict__ used_kept, u64* __restrict__ used_cur,
+                                                      u64* __restrict__ claim_tot, u32* __restrict__ cutblk,
+                                                      u32* __restrict__ cutidx, u64* __restrict__ gprev,
+                                                      u64* __restrict__ gfinal, u32* __restrict__ forced_bits,
+                                                      u64* __restrict__ rank_base, u64* __restrict__ partial,
+                                                      u64* __restrict__ host_partial) {
+    __shared__ u64 part[kResRowGroups][8];
+    __shared__ u64 vals[16];      // what this workgroup sends: 8 column sums | 8 counters
+    __shared__ u64 got[32][16];   // the same 16 values of every rank (R <= 32)
+    __shared__ u64 outc[8];       // partial verdict row
+    __shared__ u32 nib;
+    const int tid = threadIdx.x, lane = tid & 63, col = tid & 7, rg = tid >> 3;
+    const u32 m = p.m, G = p.G, nb = gridDim.x, b = blockIdx.x;
+    const u32 tag = (u32)seq;
+    const u32 j = b * kResNodes + (col & 3);
+    const bool valid = j < m;
+    const size_t c = (col < 4) ? (size_t)j : (size_t)m + j;
+    // value index of word w (0..15) of this workgroup in a row
+    auto vidx = [&](u32 w) -> size_t {
+        return w < 4 ? (size_t)b * kResNodes + w : w < 8 ? (size_t)m + (size_t)b * kResNodes + (w - 4)
+                                                         : 2 * (size_t)m + (size_t)b * 8 + (w - 8);
+    };
+    auto wvalid = [&](u32 w) -> bool { return w >= 8 || b * kResNodes + (w & 3) < m; };
+    u64 v[kResRows];
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) {
+        const u32 row = rg + r * kResRowGroups;
+        v[r] = (valid && row < G) ? H[(size_t)row * 2 * m + c] : 0;
+    }
+    u64 sacc = 0;
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) sacc += v[r];
+    part[rg][col] = sacc;
+    if (tid < 8) outc[tid] = 0;
+    if (tid >= 8 && tid < 16) vals[tid] = tid == 15 ? 1ull : 0ull;
+    if (tid == 0) nib = 0;
+    __syncthreads();
+    if (tid < 8) {
+        u64 t = 0;
+#pragma unroll
+        for (int g = 0; g < kResRowGroups; ++g) t += part[g][tid];
+        vals[tid] = t;
+    }
+    if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
+        u64 acc = 0;
+        for (u32 r = b + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
+        acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
+        if (lane < 4) vals[8 + 3 + lane] = acc;  // 3 kept  4 evicted  5 claimants  6 spill candidates (rows)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u64 a = 0, bb = 0;
+        for (int q = 0; q < 4; ++q)
+            if (b * kResNodes + q < m) { a += vals[q]; bb += vals[q + 4]; }
+        vals[8 + 0] = a;   // load kept
+        vals[8 + 1] = bb;  // load claimed
+    }
+    __syncthreads();
+    if (tid < 8) partial[(size_t)b * 8 + tid] = vals[8 + tid];  // this shard's own counters (rio_gp_shard_finish)
+    // send: this workgroup's 16 values into this rank's row of EVERY window
+    for (u32 i = tid; i < 16 * R; i += 256) {
+        const u32 w = i & 15;
+        if (wvalid(w)) xchg_put(peers[i >> 4] + my_row_off, vidx(w), vals[w], tag);
+    }
+    // receive: the same 16 values of every rank, polled word by word
+    for (u32 i = tid; i < 16 * R; i += 256) {
+        const u32 w = i & 15, r = i >> 4;
+        got[r][w] = wvalid(w) ? xchg_get(win_rows + (size_t)r * W, vidx(w), tag, p2p_err) : 0ull;
+    }
+    __syncthreads();
+    // resolve this workgroup's nodes against the global sums (k_shard_import's maths, node by node)
+    if (tid < kResNodes) {
+        const u32 jn = b * kResNodes + tid;
+        if (jn < m) {
+            u64 kept_glob = 0, claim_pre = 0, claim_glob = 0, claim_local = 0;
+            for (u32 r = 0; r < R; ++r) {
+                const u64 kx = got[r][tid], cx = got[r][4 + tid];
+                kept_glob += kx;
+                if (r < rank) claim_pre += cx;
+                if (r == rank) claim_local = cx;
+                claim_glob += cx;
+            }
+            const u64 cj = cap[jn];
+            const u64 fre = (bit_of(alive_bits, jn) && cj > kept_glob) ? cj - kept_glob : 0;
+            const bool forced = claim_pre > fre;  // the node's prefix overflowed on a lower rank: everyone here is rejected
+            const u64 ukp = kept_glob + (forced ? fre : claim_pre);
+            used_kept[jn] = ukp;
+            claim_tot[jn] = claim_local;
+            used_cur[jn] = ukp + claim_local;
+            cutblk[jn] = kNoCut;
+            cutidx[jn] = kNoCut;
+            gprev[jn] = kept_glob;
+            gfinal[jn] = kept_glob + claim_glob;
+            if (forced) atomicOr(&nib, 1u << tid);
+            if (claim_glob > fre) atomicAdd(&outc[0], 1ull);                          // cut nodes (global)
+            if (forced || claim_local > fre - claim_pre) atomicAdd(&outc[2], 1ull);   // this rank has a local fix-up
+        }
+    } else if (tid >= 8 && tid < 16) {  // global counters: word tid of this workgroup's slice, summed over the ranks
+        const int k = tid - 8;
+        u64 sum = 0;
+        for (u32 r = 0; r < R; ++r) sum += got[r][tid];
+        // verdict row: 0 cut nodes 1 spill rows 2 local fix-up 3 kept 4 evicted 5 claimants 6 load kept 7 load claimed
+        const int dst = k == 0 ? 6 : k == 1 ? 7 : k == 3 ? 3 : k == 4 ? 4 : k == 5 ? 5 : k == 6 ? 1 : -1;
+        if (dst >= 0) atomicAdd(&outc[dst], sum);
+    }
+    __syncthreads();
+    if (tid == 0) {  // four bits of the forced bitmap belong to this workgroup alone (4 | 32)
+        const u32 w = (b * kResNodes) >> 5, sh = (b * kResNodes) & 31;
+        atomicAnd(&forced_bits[w], ~(0xFu << sh));
+        if (nib) atomicOr(&forced_bits[w], nib << sh);
+        if (b == 0) *rank_base = 0;
+    }
+    if (tid < 8) host_partial[(size_t)b * 8 + tid] = outc[tid];
+}
+
 // K2p k_resolve_put — row-sharded solve with peer-to-peer windows: the local column sums of H (as k_resolve) are
 //     stored straight into EVERY peer's window; the last workgroup to finish (agent-scope counter) folds the row
 //     counters, stores them too, and only then publishes this rank's flag to every peer.  Replaces
@@ -2197,6 +2347,13 @@ void launch_resolve_put(const Plan& p, const SolveBufs& b, u64* const* d_peers, 
                         u64 seq, unsigned int* counter, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_put, dim3(resolve_blocks(p.m)), dim3(256), 0, s, b.H, b.blkstat, p, b.partial, d_peers, R,
                        data_off, flag_off, seq, counter);
+}
+void launch_resolve_xchg(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* const* d_peers, u32 R, u32 rank,
+                         size_t my_row_off, const u64* win_rows, size_t W, u64 seq, u64* p2p_err, u64* gprev, u64* gfinal,
+                         u64* host_partial, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve_xchg, dim3(resolve_blocks(p.m)), dim3(256), 0, s, b.H, b.blkstat, p, d_peers, R, rank,
+                       my_row_off, win_rows, W, seq, p2p_err, nt.cap, nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot,
+                       b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits, b.rank_base, b.partial, host_partial);
 }
 void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off, u64 seq,
                     hipStream_t s) {

@@ -60,13 +60,16 @@ struct ShardComm {
 };
 
 // Peer-to-peer exchange windows (rio_gp_shard_p2p_*): one uncached window per rank, IPC-mapped by every peer.
-//   data  [kP2PSlots][R][W]   record of rank r for the step using that slot
-//   flags [kP2PSlots][R][8]   sequence number of the step whose record is complete (one 64 B line each)
+//   xdata [kP2PSlots][R][Wx]  k_resolve_xchg's data-tagged words of rank r (a region of its own: a raw record word whose
+//                             upper half happened to equal a step's tag would be taken for that step's data)
+//   data  [kP2PSlots][R][W]   raw record of rank r for the step using that slot (fix-up exchanges, legacy fast path)
+//   flags [kP2PSlots][R][8]   sequence number of the step whose raw record is complete (one 64 B line each)
 //   hello [R][8]              set-up handshake
 constexpr int kP2PSlots = 4;
 struct P2P {
     u32 rank = 0, R = 1;
-    size_t W = 0;                 // u64 words per record row
+    size_t W = 0;                 // u64 words per raw record row
+    size_t Wx = 0;                // u64 words per tagged row (shard_xchg_words)
     u64* win = nullptr;           // this rank's window
     std::vector<void*> opened;    // peers' windows as mapped here (nullptr for our own)
     u64** d_peers = nullptr;      // device array [R] of window bases (ours included)
@@ -74,10 +77,12 @@ struct P2P {
     u64* scratch = nullptr;       // [W] staging of the local record
     u64 seq = 0;
     unsigned int* d_counter = nullptr;  // k_resolve_put's "last workgroup" counter (self-resetting)
-    size_t data_off(u32 slot, u32 r) const { return ((size_t)slot * R + r) * W; }
-    size_t flag_off(u32 slot, u32 r) const { return (size_t)kP2PSlots * R * W + ((size_t)slot * R + r) * 8; }
-    size_t hello_off(u32 r) const { return (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)r * 8; }
-    size_t total_words() const { return (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)R * 8; }
+    size_t xdata_off(u32 slot, u32 r) const { return ((size_t)slot * R + r) * Wx; }
+    size_t xwords() const { return (size_t)kP2PSlots * R * Wx; }
+    size_t data_off(u32 slot, u32 r) const { return xwords() + ((size_t)slot * R + r) * W; }
+    size_t flag_off(u32 slot, u32 r) const { return xwords() + (size_t)kP2PSlots * R * W + ((size_t)slot * R + r) * 8; }
+    size_t hello_off(u32 r) const { return xwords() + (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)r * 8; }
+    size_t total_words() const { return xwords() + (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)R * 8; }
 };
 
 struct rio_gp {
@@ -121,6 +126,8 @@ struct rio_gp {
     // global resolve of the PREVIOUS solve may still be writing on the exchange stream
     u64 *sh_lkept = nullptr, *sh_lclaim = nullptr, *sh_lcur = nullptr;
     u32 *sh_lcutblk = nullptr, *sh_lcutidx = nullptr;
+    u32 sh_rows = 1;        // verdict rows of the last shard resolve in its pinned slot (1 | resolve_blocks(m))
+    bool p2p_fused = true;  // peer-to-peer fast path as ONE launch (k_resolve_xchg); RIO_GP_P2P_LEGACY=1: put + import
     u32 sh_rank = 0, sh_R = 1;
     int sh_state = 0;       // 0 idle | 1 scanned | 2 resolved | 3 cut exported | 4 merged | 5 spill exported
     bool sh_slow = false;   // the solve in flight took the fix-up path
@@ -418,6 +425,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     rio_gp* h = new rio_gp();
     h->device = cfg->device;
     if (const char* e = getenv("RIO_GP_SCAN_TPI")) set_scan_tpi(atoi(e));  // A/B knob for bench runs
+    if (const char* e = getenv("RIO_GP_P2P_LEGACY")) h->p2p_fused = atoi(e) == 0;
     h->cap_obj = cfg->max_objects;
     h->cap_rows = ((cfg->max_objects + kTile - 1) / kTile) * kTile + 8 * kTile;  // k_scan prefetches past the end
     h->cap_nodes = cfg->max_nodes ? cfg->max_nodes : 1;
@@ -1066,6 +1074,7 @@ int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uin
     h->sh_rank = rank;
     h->sh_R = n_ranks;
     h->sh_slot = h->ring_n;
+    h->sh_rows = 1;
     hipStream_t st = on_stream ? static_cast<hipStream_t>(on_stream) : h->stream;
     h->sh_side = on_stream ? st : nullptr;
     launch_shard_import(h->plan, real_nodes(h), shard_bufs(h), reinterpret_cast<const u64*>(d_xg), rank, n_ranks,
@@ -1087,11 +1096,18 @@ int rio_gp_shard_verdict(rio_gp_t* h, rio_gp_shard_info* out, uint32_t* n_slow) 
     HIPCHK(h, hipGetLastError());
     uint32_t slow = 0;
     const u32 lo = h->ring_n > (u32)kRing ? h->ring_n - kRing : 0;
+    auto fold = [&](u32 k, u64* x) {  // one verdict row (k_shard_import) or one partial row per workgroup (k_resolve_xchg)
+        const u64* rows = h->h_slots + (size_t)(k % kRing) * h->slot_rows * 8;
+        for (int c = 0; c < 8; ++c) x[c] = 0;
+        for (u32 r = 0; r < h->sh_rows; ++r)
+            for (int c = 0; c < 8; ++c) x[c] += rows[(size_t)r * 8 + c];
+    };
+    u64 x[8];
     for (u32 k = lo; k < h->ring_n; ++k) {
-        const u64* x = h->h_slots + (size_t)(k % kRing) * h->slot_rows * 8;
+        fold(k, x);
         slow += (x[0] > 0 || x[1] > 0);
     }
-    const u64* x = h->h_slots + (size_t)(h->sh_slot % kRing) * h->slot_rows * 8;
+    fold(h->sh_slot, x);
     out->cut_nodes = x[0]; out->spill_rows = x[1]; out->local_fixup = x[2]; out->kept = x[3];
     out->evicted = x[4]; out->claimants = x[5]; out->load_kept = x[6]; out->load_claim = x[7];
     if (n_slow) *n_slow = slow;
@@ -1185,6 +1201,7 @@ int rio_gp_shard_p2p_export(rio_gp_t* h, uint32_t n_ranks, void* out_handle64) {
     P2P* q = new P2P();
     q->R = n_ranks;
     q->W = (shard_words1(h->cap_nodes) + 7) & ~(size_t)7;
+    q->Wx = (shard_xchg_words(h->cap_nodes) + 7) & ~(size_t)7;
     const size_t bytes = q->total_words() * sizeof(u64);
     void* w = nullptr;
     // uncached first (what RCCL uses for its own flag/LL buffers on gfx94x/95x), fine-grained second; ordinary cached
@@ -1356,15 +1373,28 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         const Table t = real_table(h);
         const NodeTab nt = real_nodes(h);
         launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
-        launch_resolve_put(h->plan, h->sb, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq,
-                           q->d_counter, h->stream);
         h->sh_rank = q->rank;
         h->sh_R = q->R;
         h->sh_slot = h->ring_n;
         h->sh_side = nullptr;
-        launch_shard_import(h->plan, nt, shard_bufs(h), q->win + q->data_off(slot, 0), q->rank, q->R, h->sh_gprev,
-                            h->sh_gfinal, h->sh_verdict, slot_dev(h, h->ring_n), h->stream, q->W,
-                            q->win + q->flag_off(slot, 0), seq, q->d_err);
+        if (h->p2p_fused) {
+            // ONE launch behind the scan: every workgroup exchanges and resolves its own four nodes (k_resolve_xchg);
+            // the verdict arrives as resolve_blocks(m) partial rows in the pinned slot
+            SolveBufs xb = shard_bufs(h);
+            xb.H = h->sb.H;
+            xb.blkstat = h->sb.blkstat;
+            launch_resolve_xchg(h->plan, nt, xb, q->d_peers, q->R, q->rank, q->xdata_off(slot, q->rank),
+                                q->win + q->xdata_off(slot, 0), q->Wx, seq, q->d_err, h->sh_gprev, h->sh_gfinal,
+                                slot_dev(h, h->ring_n), h->stream);
+            h->sh_rows = resolve_blocks(h->m);
+        } else {
+            launch_resolve_put(h->plan, h->sb, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq,
+                               q->d_counter, h->stream);
+            launch_shard_import(h->plan, nt, shard_bufs(h), q->win + q->data_off(slot, 0), q->rank, q->R, h->sh_gprev,
+                                h->sh_gfinal, h->sh_verdict, slot_dev(h, h->ring_n), h->stream, q->W,
+                                q->win + q->flag_off(slot, 0), seq, q->d_err);
+            h->sh_rows = 1;
+        }
         h->ring_n++;
         h->have_solved = false;
         h->sh_state = 2;
@@ -1388,6 +1418,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     h->sh_rank = sc->rank;
     h->sh_R = sc->R;
     h->sh_slot = h->ring_n;
+    h->sh_rows = 1;
     h->sh_side = sc->side;
     launch_shard_import(h->plan, nt, shard_bufs(h), sc->XG[q], sc->rank, sc->R, h->sh_gprev, h->sh_gfinal, h->sh_verdict,
                         slot_dev(h, h->ring_n), sc->side);
