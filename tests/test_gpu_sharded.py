@@ -176,8 +176,11 @@ def test_hip_shard_native_rccl_world1(gp, oracle):
         dist.destroy_process_group()
 
 
-def test_hip_shard_p2p_world1(gp, oracle):
-    """Peer-to-peer window path with a single rank: export/connect/handshake, flag-gated import, Y exchanges."""
+@pytest.mark.parametrize("legacy", [False, True])
+def test_hip_shard_p2p_world1(gp, oracle, legacy, monkeypatch):
+    """Peer-to-peer window path with a single rank: export/connect/handshake, the one-launch tagged exchange
+    (k_resolve_xchg) or the legacy put + flag-gated import (RIO_GP_P2P_LEGACY=1, read at handle creation), Y exchanges."""
+    monkeypatch.setenv("RIO_GP_P2P_LEGACY", "1" if legacy else "0")
     import torch
     import torch.distributed as dist
     import sharded
@@ -221,7 +224,7 @@ def _proc(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        case = random_case(31, n=200_000, m=48, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
+        case = random_case(31, n=200_000, m=50, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
         b = sharded.shard_bounds(len(case[0]), world)
         eng = make_engines(rio_gp, case, [b[rank], b[rank + 1]])[0]
         if os.environ.get("RIO_TEST_EXCHANGE") == "p2p":   # IPC-mapped windows between the two processes
@@ -239,14 +242,15 @@ def _proc(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["gloo", "p2p"])
-def test_hip_shards_two_processes_one_gpu(gp, oracle, tmp_path, exchange):
+@pytest.mark.parametrize("exchange", ["gloo", "p2p", "p2p-legacy"])
+def test_hip_shards_two_processes_one_gpu(gp, oracle, tmp_path, exchange, monkeypatch):
     import torch.multiprocessing as mp
     from test_sharded_protocol import random_case
-    os.environ["RIO_TEST_EXCHANGE"] = exchange
+    monkeypatch.setenv("RIO_TEST_EXCHANGE", exchange.split("-")[0])
+    monkeypatch.setenv("RIO_GP_P2P_LEGACY", "1" if exchange.endswith("legacy") else "0")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_proc, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    case = random_case(31, n=200_000, m=48, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
+    case = random_case(31, n=200_000, m=50, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
     want, used, ost = oracle.tick(*case, 2)
     parts = [np.load(os.path.join(str(tmp_path), "g%d.npz" % r)) for r in range(2)]
     assert np.array_equal(np.concatenate([z["a"] for z in parts]), want)
