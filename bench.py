@@ -264,9 +264,10 @@ def main():
                                "(all pending)" % (n, m) if a.workload == "c3" else a.workload,
                    "objects_per_gpu": n, "nodes": m, "parallelism": "rows sharded x%d" % world,
                    "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end" if dist is None
-                           else {"p2p": "row-sharded solve: k_scan -> k_resolve_put (local sums stored straight into every peer's HBM "
-                                        "window over xGMI, %d B/rank, sequence flag last) -> k_shard_import (waits in-kernel for all "
-                                        "flags); one stream, three launches, no collective call; verdicts read at the end",
+                           else {"p2p": "row-sharded solve: k_scan -> k_resolve_xchg (every workgroup stores its four nodes' local sums straight into "
+                                        "every peer's HBM window over xGMI as data-tagged 8-byte words, %d B/rank, polls the same words of "
+                                        "every rank and resolves its nodes); one stream, two launches, no collective call, no flag; "
+                                        "verdicts read at the end",
                                  "native": "row-sharded solve: k_scan + k_resolve + pack -> ncclAllGather of %d B/rank issued by the "
                                            "library on a second stream -> k_shard_import; verdicts read at the end",
                                  "torch": "row-sharded solve: k_scan + k_resolve + pack -> torch.distributed all_gather (RCCL) of %d "
