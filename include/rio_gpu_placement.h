@@ -246,9 +246,11 @@ int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats);
  * uncached window (rio_gp_shard_p2p_export -> 64-byte hipIpcMemHandle_t), the host all-gathers the handles over its
  * control channel, every rank maps its peers' windows (rio_gp_shard_p2p_connect; ends with a handshake and fails
  * with RIO_GP_EUPSTREAM if a peer's store does not become visible within 3 s — fall back to RCCL then).  After that
- * rio_gp_shard_solve_async and rio_gp_shard_exchange store each record straight into the peers' HBM and the
- * consuming kernel waits on sequence flags: one stream, five launches, no host involvement.  All ranks must call
- * export/connect/solve/exchange collectively and in the same order. */
+ * rio_gp_shard_solve_async is two launches on one stream, no host involvement: the scan, then one kernel in which every
+ * workgroup stores its four nodes' sums straight into the peers' HBM as data-tagged 8-byte words, polls the same words of
+ * every rank and resolves its nodes (no flag, no collective).  rio_gp_shard_exchange (fix-up records) stores the raw
+ * record and a sequence flag; the consuming kernel waits on the flags.  All ranks must call export/connect/solve/exchange
+ * collectively and in the same order. */
 int rio_gp_shard_p2p_export(rio_gp_t* h, uint32_t n_ranks, void* out_handle64);
 int rio_gp_shard_p2p_connect(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const void* handles /* [n_ranks][64] */);
 int rio_gp_shard_p2p_ready(rio_gp_t* h);
