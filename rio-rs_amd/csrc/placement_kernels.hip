@@ -711,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
 //     Rows are streamed twice (P1, P3: the second pass hits L2/MALL) only in blocks that own a cut.
 // ------------------------------------------------------------------------------------------------
 // Phase trace of k_cut_fused (measurement aid, off by default): workgroup b stores wall_clock64() (100 MHz) at its phase
-// boundaries into g_cut_trace[b][0..7] = start, P0 end, P1 time, P2 time, P3 time, nloc, S, P2a time.
+// boundaries into g_cut_trace[b][0..7] = start, P0 end, passes (all levels), row searches, P3 time, nloc, S, walks (all levels).
 __device__ int g_cut_trace_on = 0;
 __device__ u64 g_cut_trace[kMaxBlocks * 8];
 #define RIOGP_TRACE(slot, val) do { if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + (slot)] = (val); } while (0)
@@ -771,35 +771,46 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
         } else if (cbv == b) {
             s = atomicAdd(&nlocal, 1u);
             node_of[s] = (unsigned short)j;
-            T[tcap - 1 - s] = budget[j];  // s < m <= tcap - kCutMinSubs (cut_fused_lds)
         }
         thr[j] = t;
         slot[j] = (unsigned short)s;
     }
     __syncthreads();
     const u32 nloc = nlocal;
-    // Sub-chunking of THIS block, chosen so that all its local nodes share one pass when they fit: cuts are not spread
-    // evenly over blocks (a nearly full cluster cuts every node within its first claimants, i.e. in block 0), and
-    // a pass per 48 nodes with a serial row search per node is what made such a block take >100 us.  mult finest
-    // sub-chunks (p.sub rows each) form one sub-chunk; S of them cover the block; K nodes share a pass.
-    const u32 tfree = tcap - nloc;
-    u32 mult = 1;
+    // Where is each local node's cut row?  Refinement by S-way histograms over the workgroup's rows, level by level:
+    // level 0 splits the block's tiles into S pieces, a pass over the rows adds every claimant's load to T[node][piece],
+    // an ordered walk over the node's T row finds the piece that holds the cut and shrinks the node's range to it;
+    // the next level splits THAT range, and so on.  A level costs one pass over the block's rows; it is taken while
+    // letting every node scan its remaining range row by row would cost more (cuts are not spread evenly over blocks:
+    // a nearly full cluster cuts every node within its first claimants, i.e. all in block 0 — and on a 1.5e9-row table
+    // one workgroup owning 964 cuts with 16 pieces of 1 400 tiles each spent 38 ms re-reading its rows per node).
+    // S is chosen so that all local nodes share the passes when they fit (K nodes per group otherwise).
+    // LDS: T rows [K][Sp] from the front of the T region, node state (budget left, load admitted before the range,
+    // first tile of the range) in 3 x [K] words at its end.
+    const u32 F = p.sub / kTile;
+    const u32 BT = p.subs * F;                       // tiles per block (plan bound, the same for every block)
+    u32 S = BT < 255u ? BT : 255u;                   // fan-out per level
     if (nloc) {
-        const u32 smax = tfree / nloc;  // T words per node that fit if every local node is in ONE group
-        if (smax < (p.subs | 1u)) {
-            const u32 want = smax <= (u32)kCutMinSubs ? (u32)kCutMinSubs : smax - 1;
-            mult = (p.subs + want - 1) / want;
-        }
+        const u32 per = tcap / nloc;                 // words per node if every local node is in ONE group
+        const u32 sfit = per > 4 ? per - 4 : 0;      // T words of them (3 state words, 1 for the odd stride)
+        if (sfit < S) S = sfit < (u32)kCutMinSubs ? (u32)kCutMinSubs : sfit;
+        if (S > BT) S = BT;
     }
-    const u32 S = (p.subs + mult - 1) / mult;
+    if (S < 1) S = 1;
     const u32 Sp = (S | 1u) < 3u ? 3u : (S | 1u);    // T row stride: odd (lane-per-node walks are bank-conflict free),
-                                                     // >= 3 (the row is reused for the node's search record)
-    const u32 stiles = (p.sub / kTile) * mult;       // tiles per sub-chunk
-    const u64 srows = (u64)stiles * kTile;
-    u32 K = tfree / Sp;
+                                                     // >= 3 (the T region is reused for two words per node below)
+    u32 K = tcap / (Sp + 3);
     if (K < 1) K = 1;
     u64 bend = block_row_lo(p, b + 1);
     if (bend > p.n) bend = p.n;
+    // tiles of this block that hold live rows (packed fix-up: a fraction of BT), for the "is another level worth a pass" test
+    u32 live_tiles;
+    {
+        const u32 mine = lane < kWaves ? (u32)((whi[lane & (kWaves - 1)] > rlo[lane & (kWaves - 1)]
+                                                     ? whi[lane & (kWaves - 1)] - rlo[lane & (kWaves - 1)] + kTile - 1 : 0) / kTile) : 0u;
+        live_tiles = wave_sum32(mine);
+        if (live_tiles < 1) live_tiles = 1;
+    }
     RIOGP_TRACE(1, wall_clock64());
     RIOGP_TRACE(5, (u64)nloc);
     RIOGP_TRACE(6, (u64)S);
@@ -807,127 +818,167 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
 
     for (u32 g0 = 0; g0 < nloc; g0 += K) {
         const u32 kn = nloc - g0 < K ? nloc - g0 : K;
-        const u64 tr_a = g_cut_trace_on ? wall_clock64() : 0;
-        for (u32 k = tid; k < kn * Sp; k += kBlock) T[k] = 0;
-        __syncthreads();
-        // P1: claim load per (local node, sub-chunk); a tile (256 rows) lies inside ONE sub-chunk
-        for (u64 it = wstart; it < wend; it += kTile) {
-            const u64 i0 = it + (u64)lane * 4;
-            const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
-            const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
-            const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
-            const u32 t = (u32)((it - bstart) / kTile) / stiles;
-#define RIOGP_ROW(C, A, L, E)                                                                              \
-            {                                                                                              \
-                bool hit = i0 + E < wend && classify<VIRT>(C, A, m, alv) == 1;                             \
-                u32 ls = 0;                                                                                \
-                if (hit) { ls = (u32)slot[A] - g0; hit = ls < kn; }  /* kSlotNone - g0 >= kn always */     \
-                const u64 todo = __ballot(hit);                                                            \
-                if (todo) { /* a HOT node (>= 16 rows of this wave-element) costs one LDS atomic, not 16+ */ \
-                    const int ld = __ffsll((long long)todo) - 1;                                           \
-                    const u32 s0 = (u32)__shfl((int)ls, ld, 64);                                           \
-                    const bool same = hit && ls == s0;                                                     \
-                    if (__popcll(__ballot(same)) >= 16) {                                                  \
-                        const u64 sum = wave_sum(same ? (u64)L : 0ull);                                    \
-                        if (lane == ld) atomicAdd(&T[s0 * Sp + t], sum);                                    \
-                        hit = hit && !same;                                                                \
-                    }                                                                                      \
-                    if (hit) atomicAdd(&T[ls * Sp + t], (u64)L);                                            \
-                }                                                                                          \
-            }
-            RIOGP_ROW(cv.x, av.x, lv.x, 0)
-            RIOGP_ROW(cv.y, av.y, lv.y, 1)
-            RIOGP_ROW(cv.z, av.z, lv.z, 2)
-            RIOGP_ROW(cv.w, av.w, lv.w, 3)
-#undef RIOGP_ROW
+        u64* st_bud = T + tcap - 3 * (size_t)K;      // [K] budget left inside the node's current range
+        u64* st_pre = st_bud + K;                    // [K] claim load admitted before the range (inside this block)
+        u64* st_rs = st_pre + K;                     // [K] first tile of the range (tile offset inside the block)
+        for (u32 ls = tid; ls < kn; ls += kBlock) {
+            st_bud[ls] = budget[node_of[g0 + ls]];
+            st_pre[ls] = 0;
+            st_rs[ls] = 0;
         }
-        __syncthreads();
-        const u64 tr_b = g_cut_trace_on ? wall_clock64() : 0;
-        // P2a: per local node, the sub-chunk that holds the cut (ordered walk over its T row), then the first tile of it
-        //      with live rows (packed fix-up: most positions of a range are dead); the search record {start | end<<32,
-        //      budget inside the sub-chunk, load admitted before it} goes into the first three words of the node's own
-        //      T row.  LDS only.  Two forms, picked by estimated instruction count: one LANE per node (many nodes, short
-        //      rows: row stride odd, so no bank conflicts) or one WAVE per node with a DPP scan (few nodes, long rows).
-        auto first_live = [&](u64 st, u64 en) -> u64 {  // uniform or per-lane: only LDS broadcast reads
-            while (st + kTile < en) {
+        u32 rlen = BT;                               // tiles in every node's current range (uniform per level)
+        for (u32 level = 0;; ++level) {
+            const u32 ptiles = (rlen + S - 1) / S;   // tiles per piece at this level
+            const u32 np = (rlen + ptiles - 1) / ptiles;  // pieces actually used (<= S)
+            const u64 tr_a = g_cut_trace_on ? wall_clock64() : 0;
+            for (u32 k = tid; k < kn * Sp; k += kBlock) T[k] = 0;
+            __syncthreads();
+            // pass: claim load per (local node, piece of its range); a tile (256 rows) lies inside ONE piece
+            for (u64 it = wstart; it < wend; it += kTile) {
+                const u64 i0 = it + (u64)lane * 4;
+                const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
+                const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
+                const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+                const u32 tb = (u32)((it - bstart) / kTile);
+                const u32 t_lvl0 = tb / ptiles;
+#define RIOGP_ROW(C, A, L, E)                                                                              \
+                {                                                                                          \
+                    /* branch-free class test (as P3): claimant = in range, not kept, not a duplicate, affinity live */ \
+                    const bool cin = C < m, ain = A < m;                                                   \
+                    const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                        \
+                    const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                \
+                    const u32 ls = (u32)slot[ax] - g0;  /* kSlotNone - g0 >= kn always */                  \
+                    bool hit = (i0 + E < wend) & !kept & !(VIRT && C == kSkipMark) & ain & bit_of(alv, ax) & (ls < kn); \
+                    u32 t = 0;                                                                             \
+                    if (level == 0) {                                                                      \
+                        t = t_lvl0;  /* every range is the whole block: the piece is a property of the tile */ \
+                    } else if (hit) {                                                                      \
+                        const u32 off = tb - (u32)st_rs[ls];  /* below the range wraps to a huge value */  \
+                        hit = off < rlen;                                                                  \
+                        t = off / ptiles;                                                                  \
+                    }                                                                                      \
+                    const u64 todo = __ballot(hit);                                                        \
+                    if (__popcll(todo) >= 16) { /* a HOT node (>= 16 rows of this wave-element): one LDS atomic, not 16+ */ \
+                        const int ld = __ffsll((long long)todo) - 1;                                       \
+                        const u32 s0 = (u32)__shfl((int)(ls * Sp + t), ld, 64);                            \
+                        const bool same = hit && ls * Sp + t == s0;                                        \
+                        if (__popcll(__ballot(same)) >= 16) {                                              \
+                            const u64 sum = wave_sum(same ? (u64)L : 0ull);                                \
+                            if (lane == ld) atomicAdd(&T[s0], sum);                                        \
+                            hit = hit && !same;                                                            \
+                        }                                                                                  \
+                    }                                                                                      \
+                    if (hit) atomicAdd(&T[ls * Sp + t], (u64)L);                                           \
+                }
+                RIOGP_ROW(cv.x, av.x, lv.x, 0)
+                RIOGP_ROW(cv.y, av.y, lv.y, 1)
+                RIOGP_ROW(cv.z, av.z, lv.z, 2)
+                RIOGP_ROW(cv.w, av.w, lv.w, 3)
+#undef RIOGP_ROW
+            }
+            __syncthreads();
+            const u64 tr_b = g_cut_trace_on ? wall_clock64() : 0;
+            // ordered walk over each node's T row: the piece that holds the cut becomes the node's range.  Two forms,
+            // picked by estimated instruction count: one LANE per node (many nodes, short rows: row stride odd, so no
+            // bank conflicts) or one WAVE per node with a DPP scan (few nodes, long rows).  LDS only.
+            const u32 cost_lane = ((np + 7) / 8) * 100u;
+            const u32 cost_wave = ((kn + kWaves - 1) / kWaves) * (((np + 63) / 64) * 80u + 120u);
+            if (cost_lane <= cost_wave) {
+                for (u32 ls = tid; ls < kn; ls += kBlock) {
+                    const u64* Tj = T + (size_t)ls * Sp;
+                    const u64 bud = st_bud[ls];
+                    u64 acc = 0;
+                    u32 tstar = np;
+                    for (u32 t0 = 0; t0 < np && tstar == np; t0 += 8) {  // 8 independent LDS reads, then a branch-free walk
+                        u64 v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = t0 + q < np ? Tj[t0 + q] : 0ull;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const u64 nv = acc + v[q];
+                            const bool open = tstar == np;
+                            const bool over = nv > bud;  // padding words are 0: never over
+                            tstar = (open && over) ? t0 + q : tstar;
+                            acc = (open && !over) ? nv : acc;
+                        }
+                    }
+                    if (tstar == np) { tstar = 0; acc = 0; }  // no overflow anywhere (k_cutblk says there is one): range start
+                    st_bud[ls] = bud - acc;
+                    st_pre[ls] += acc;
+                    st_rs[ls] += (u64)tstar * ptiles;
+                }
+            } else {
+                for (u32 ls = wave; ls < kn; ls += kWaves) {
+                    const u64* Tj = T + (size_t)ls * Sp;
+                    const u64 bud = st_bud[ls];
+                    u64 acc = 0, pre = 0;
+                    u32 tstar = 0;
+                    bool found = false;
+                    for (u32 g = 0; g < np && !found; g += 64) {
+                        const u32 t = g + lane;
+                        const u64 v = t < np ? Tj[t] : 0;
+                        const u64 inc = wave_incl_scan(v, lane);
+                        const u64 mask = __ballot(acc + inc > bud);
+                        if (mask) {
+                            const int fl = __ffsll((long long)mask) - 1;
+                            tstar = g + fl;
+                            pre = acc + shfl64(inc - v, fl);
+                            found = true;
+                        } else {
+                            acc += shfl64(inc, 63);
+                        }
+                    }
+                    if (lane == 0) {
+                        st_bud[ls] = bud - pre;
+                        st_pre[ls] += pre;
+                        st_rs[ls] += (u64)tstar * ptiles;
+                    }
+                }
+            }
+            __syncthreads();
+            if (g_cut_trace_on) { const u64 tr_c = wall_clock64(); tr_p1 += tr_b - tr_a; tr_p2a += tr_c - tr_b; }
+            rlen = ptiles;
+            // another level?  In tile-steps shared by 16 waves: row-by-row searches of the remaining ranges cost about
+            // kn x rlen x (live share) ordered scans; one more level costs a pass over the live tiles (a third of a scan
+            // each) plus a fixed part (zeroing, barriers, walks ~ 100 scans).  Taken only when it clearly pays (2x).
+            if (rlen <= 1 || (u64)kn * rlen * live_tiles <= (u64)BT * (2ull * (live_tiles / 3 + 100))) break;
+        }
+        const u64 tr_b2 = g_cut_trace_on ? wall_clock64() : 0;
+        // the rows each node's search covers: from the first tile of its range that holds live rows (packed fix-up: most
+        // positions of a wave range are dead) to the end of the range — one lane per node, LDS only, into the T region
+        // (free now): T[ls] = first row, T[kn + ls] = end.  Done here so that the searches below start with their loads.
+        for (u32 ls = tid; ls < kn; ls += kBlock) {
+            u64 rs = bstart + st_rs[ls] * kTile;
+            u64 re = rs + (u64)rlen * kTile;
+            if (re > bend) re = bend;
+            if (rs > re) rs = re;
+            u64 st = rs;
+            while (st + kTile < re) {
                 int w = 0;
                 for (int q = 1; q < kWaves; ++q) w += rlo[q] <= st;
                 if (whi[w] > st) break;
                 st += kTile;
             }
-            return st;
-        };
-        const u32 cost_lane = ((S + 7) / 8) * 100u;
-        const u32 cost_wave = ((kn + kWaves - 1) / kWaves) * (((S + 63) / 64) * 80u + 120u);
-        if (cost_lane <= cost_wave) {
-            for (u32 ls = tid; ls < kn; ls += kBlock) {
-                u64* Tj = T + (size_t)ls * Sp;
-                const u64 bud = T[tcap - 1 - (g0 + ls)];
-                u64 acc = 0;
-                u32 tstar = S;
-                for (u32 t0 = 0; t0 < S && tstar == S; t0 += 8) {  // 8 independent LDS reads, then a branch-free ordered walk
-                    u64 v[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = t0 + q < S ? Tj[t0 + q] : 0ull;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const u64 nv = acc + v[q];
-                        const bool open = tstar == S;
-                        const bool over = nv > bud;  // padding words are 0: never over
-                        tstar = (open && over) ? t0 + q : tstar;
-                        acc = (open && !over) ? nv : acc;
-                    }
-                }
-                if (tstar == S) { tstar = 0; acc = 0; }  // no overflow anywhere (k_cutblk says there is one): block start
-                const u64 st0 = bstart + (u64)tstar * srows;
-                u64 en = st0 + srows;
-                if (en > bend) en = bend;
-                const u64 st = first_live(st0, en);
-                Tj[0] = st | (en << 32);  // rows are u32-indexed
-                Tj[1] = bud - acc;
-                Tj[2] = acc;
-            }
-        } else {
-            for (u32 ls = wave; ls < kn; ls += kWaves) {
-                u64* Tj = T + (size_t)ls * Sp;
-                const u64 bud = T[tcap - 1 - (g0 + ls)];
-                u64 acc = 0, pre = 0;
-                u32 tstar = 0;
-                bool found = false;
-                for (u32 g = 0; g < S && !found; g += 64) {
-                    const u32 t = g + lane;
-                    const u64 v = t < S ? Tj[t] : 0;
-                    const u64 inc = wave_incl_scan(v, lane);
-                    const u64 mask = __ballot(acc + inc > bud);
-                    if (mask) {
-                        const int fl = __ffsll((long long)mask) - 1;
-                        tstar = g + fl;
-                        pre = acc + shfl64(inc - v, fl);
-                        found = true;
-                    } else {
-                        acc += shfl64(inc, 63);
-                    }
-                }
-                const u64 st0 = bstart + (u64)tstar * srows;
-                u64 en = st0 + srows;
-                if (en > bend) en = bend;
-                const u64 st = first_live(st0, en);
-                if (lane == 0) {  // every lane has read its words of the row (the scan consumed them) before this store
-                    Tj[0] = st | (en << 32);
-                    Tj[1] = bud - pre;
-                    Tj[2] = pre;
-                }
-            }
+            T[ls] = st;
+            T[kn + ls] = re;
         }
         __syncthreads();
-        if (g_cut_trace_on) tr_p2a += wall_clock64() - tr_b;
-        // P2b: one wave per node, three nodes per wave in flight — the exact row inside the sub-chunk, tile by tile
+        // P2b: one wave per node, three nodes per wave in flight — the exact row inside the range, tile by tile
         //      (dwordx4 columns, in-tile order = lane, element).  The tiles and node words of three nodes are requested
         //      before the first is searched: a workgroup that owns hundreds of cuts is bound by the round trips of its
         //      16 waves, so each trip has to carry several nodes.
-        struct Job { u32 ls; uint4 c, a, l; u64 uk, ad; };  // only what is in flight; the record is re-read from LDS
+        struct Job { u32 ls; uint4 c, a, l; u64 uk, ad; };  // only what is in flight; the rest is re-read from LDS
+        // first live tile at or after t, below lim (LDS tables only; wave-uniform)
+        auto next_live = [&](u64 t, u64 lim) -> u64 {
+            while (t < lim) {
+                const int w = __popcll(__ballot(lane < kWaves && rlo[lane & (kWaves - 1)] <= t)) - 1;
+                if (whi[w < 0 ? 0 : w] > t) break;
+                t += kTile;
+            }
+            return t;
+        };
         auto fetch = [&](Job& q, u32 ls) {
-            const u64 start = T[(size_t)ls * Sp] & 0xFFFFFFFFull;
+            const u64 start = T[ls];
             const u32 j = node_of[g0 + ls];
             q.ls = ls;
             q.c = *reinterpret_cast<const uint4*>(cur + start + (u64)lane * 4);
@@ -937,10 +988,8 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
             q.ad = admpre[j];
         };
         auto run = [&](const Job& q) {
-            const u64* Tj = T + (size_t)q.ls * Sp;
-            const u64 se = Tj[0];
-            const u64 q_start = se & 0xFFFFFFFFull, q_end = se >> 32;
-            const u64 bud2 = Tj[1], q_pre_sub = Tj[2];
+            const u64 q_start = T[q.ls], q_end = T[kn + q.ls];
+            const u64 bud2 = st_bud[q.ls], q_pre_sub = st_pre[q.ls];
             const u32 j = node_of[g0 + q.ls];
             u64 acc2 = 0, cut_row = kNoCut, adm_in = 0;
             // one tile of the search: rows of node j's claimants in (lane, element) order against bud2
@@ -985,10 +1034,10 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
                 acc2 += shfl64(inc, 63);
                 return false;
             };
+            // the first tile is the one this job prefetched; deeper tiles of the range are rare and short (the refinement
+            // levels above keep kn x range small), so they are read one at a time, tiles without live rows skipped
             bool found = scan1(q.c, q.a, q.l, q_start);
-            for (u64 t0 = q_start + kTile; t0 < q_end && !found; t0 += kTile) {  // rare: cut deeper in the sub-chunk
-                const int w = __popcll(__ballot(lane < kWaves && rlo[lane & (kWaves - 1)] <= t0)) - 1;
-                if (whi[w < 0 ? 0 : w] <= t0) continue;  // no live row in this tile: nothing to load
+            for (u64 t0 = next_live(q_start + kTile, q_end); t0 < q_end && !found; t0 = next_live(t0 + kTile, q_end)) {
                 const uint4 xc = *reinterpret_cast<const uint4*>(cur + t0 + (u64)lane * 4);
                 const uint4 xa = *reinterpret_cast<const uint4*>(aff + t0 + (u64)lane * 4);
                 const uint4 xl = *reinterpret_cast<const uint4*>(load + t0 + (u64)lane * 4);
@@ -1013,29 +1062,38 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
                 if (base + (u32)u * kWaves < kn) run(q[u]);
         }
         __syncthreads();
-        if (g_cut_trace_on) { const u64 tr_c = wall_clock64(); tr_p1 += tr_b - tr_a; tr_p2 += tr_c - tr_b; }
+        if (g_cut_trace_on) tr_p2 += wall_clock64() - tr_b2;
     }
     RIOGP_TRACE(2, tr_p1);
     RIOGP_TRACE(3, tr_p2);
     RIOGP_TRACE(7, tr_p2a);
     RIOGP_TRACE(4, wall_clock64());
 
-    // P3: re-mark the rejected claimants, rebuild the per-wave spill totals (candidates + rejected)
+    // P3: re-mark the rejected claimants, rebuild the per-wave spill totals (candidates + rejected).  Every workgroup
+    //     runs this over all its rows, so the row body is branch-free except for the (rare) store: the class of a row is
+    //     computed with bit operations, counts are popcounts of ballots (wave-uniform), loads are summed under selects.
     u64 sp_sum = 0, rej_sum = 0;
-    u32 sp_cnt = 0, rej_cnt = 0;
+    u32 sp_cnt = 0, rej_cnt = 0;  // wave-uniform
     for (u64 it = wstart; it < wend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
         const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
         const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
         const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
-#define RIOGP_ROW(C, A, L, E)                                                    \
-        if (i0 + E < wend) {                                                     \
-            const int cls = classify<VIRT>(C, A, m, alv);                        \
-            if (cls == 2) { sp_sum += L; ++sp_cnt; }                             \
-            else if (cls == 1 && (u32)(i0 + E) >= thr[A]) {                      \
-                next[i0 + E] = kSpillMark;                                       \
-                sp_sum += L; ++sp_cnt; rej_sum += L; ++rej_cnt;                  \
-            }                                                                    \
+#define RIOGP_ROW(C, A, L, E)                                                                        \
+        {                                                                                            \
+            const bool inr = i0 + E < wend;                                                          \
+            const bool cin = C < m, ain = A < m;                                                     \
+            const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                          \
+            const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                  \
+            const bool skip = VIRT && C == kSkipMark;                                                \
+            const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                             \
+            const bool sp = inr & !kept & !skip & !cl;                                               \
+            const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                        \
+            if (rej) next[i0 + E] = kSpillMark;                                                      \
+            sp_sum += (sp | rej) ? (u64)L : 0ull;                                                    \
+            rej_sum += rej ? (u64)L : 0ull;                                                          \
+            sp_cnt += (u32)__popcll(__ballot(sp | rej));                                             \
+            rej_cnt += (u32)__popcll(__ballot(rej));                                                 \
         }
         RIOGP_ROW(cv.x, av.x, lv.x, 0)
         RIOGP_ROW(cv.y, av.y, lv.y, 1)
@@ -1044,9 +1102,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
 #undef RIOGP_ROW
     }
     sp_sum = wave_sum(sp_sum);
-    sp_cnt = wave_sum32(sp_cnt);
     rej_sum = wave_sum(rej_sum);
-    rej_cnt = wave_sum32(rej_cnt);
     if (lane == 0) {
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
@@ -2194,14 +2250,14 @@ void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* h
                            host_partial);
 }
 
-// dynamic LDS of k_cut_fused: the fixed tables + as many u64 slots of T as fit (a budget word per local node lives at
-// the end of T, so at least m + kCutMinSubs)
+// dynamic LDS of k_cut_fused: the fixed tables + as many u64 words of T region as fit (T rows [K][S|1] + 3 state words
+// per node of a group; every local node in one group at the finest fan-out needs m * ((255|1) + 3) words)
 size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
     const size_t fixed = cut_fused_fixed(p.m, p.mwords);
     size_t slots = (150 * 1024 - fixed) / sizeof(u64);
-    const size_t most = (size_t)p.m * ((p.subs | 1u) + 3);  // every node local to one block, finest sub-chunking
+    const size_t most = (size_t)p.m * 259;
     if (slots > most) slots = most;
-    if (slots < (size_t)p.m + 2 * kCutMinSubs) slots = (size_t)p.m + 2 * kCutMinSubs;  // m <= 8 192: never binds below 160 KiB
+    if (slots < 64) slots = 64;
     *tcap_out = (u32)slots;
     return fixed + slots * sizeof(u64);
 }

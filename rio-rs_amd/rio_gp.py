@@ -71,9 +71,10 @@ _u32p = C.POINTER(C.c_uint32)
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("RIO_GP_LIB", LIB_PATH)  # A/B runs of another build of the same sources (measurement aid)
+        if not os.path.exists(path):
             raise RuntimeError("librio_gp.so is not built (run __graft_entry__.build()); there is no CPU fallback")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.rio_gp_create.argtypes = [C.POINTER(Cfg), C.POINTER(_vp)]
         L.rio_gp_destroy.argtypes = [_vp]
         L.rio_gp_destroy.restype = None

@@ -232,11 +232,12 @@ def test_tick_tiny_capacity_cuts_in_first_block(gp, oracle):
 
 
 @pytest.mark.parametrize("n,m,maxcap,zero_loads", [(600_000, 4096, 60, False), (1_200_000, 8192, 30, True),
-                                                      (3_000_000, 2048, 2000, True)])
+                                                      (3_000_000, 2048, 2000, True), (40_000_000, 2048, 30000, True)])
 def test_tick_cuts_concentrated_in_few_blocks(gp, oracle, n, m, maxcap, zero_loads):
     """A nearly full cluster: every node's cut lies within its first claimants, so ONE workgroup owns hundreds or
     thousands of cuts (k_cut_fused: coarser sub-chunks so they share a pass, several groups when even that does not
-    fit, pipelined per-node row search).  Zero-load claimants ride along until the first overflow."""
+    fit, pipelined per-node row search; at 40 M rows a sub-chunk is ~40 tiles, which takes the coarse group search first).
+    Zero-load claimants ride along until the first overflow."""
     rng = np.random.default_rng(60 + m)
     load = rng.integers(0 if zero_loads else 1, 12, n).astype(np.uint32)
     cap = rng.integers(0, maxcap, m).astype(np.uint64)
