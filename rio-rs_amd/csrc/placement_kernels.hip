@@ -703,9 +703,11 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
 //     on the exact cut this very workgroup computes.  So per workgroup b:
 //       P0  thr[j] = 0 (cutblk[j] < b, or forced: every claimant here is rejected) | NOCUT
 //           (cutblk[j] > b / no cut) | "local" (cutblk[j] == b: gets a slot);
-//       P1  per group of K local nodes: T[slot][sub-chunk] claim load of the block's rows, LDS
-//           atomics (the 2 MB global T of the unfused path is gone);
-//       P2  one wave per local node: sub-chunk by prefix over its T row, then the exact row;
+//       P1  per group of K local nodes, level by level: T[slot][piece of the node's current range] claim
+//           load of the block's rows (LDS atomics; the 2 MB global T of the unfused path is gone), then
+//           an ordered walk over each node's T row shrinks its range to the piece that holds the cut;
+//           another level only while row-by-row searches would cost more than one more pass;
+//       P2  one wave per local node: the exact row inside the remaining range (whole tiles, dwordx4);
 //           thr[j] = cutidx[j] = that row, used_cur[j] = kept + admitted;
 //       P3  claimants with i >= thr[aff] lose the optimistic assignment (k_apply_cut's pass).
 //     Rows are streamed twice (P1, P3: the second pass hits L2/MALL) only in blocks that own a cut.
@@ -717,7 +719,7 @@ __device__ u64 g_cut_trace[kMaxBlocks * 8];
 #define RIOGP_TRACE(slot, val) do { if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + (slot)] = (val); } while (0)
 
 constexpr u32 kSlotNone = 0xFFFFu;
-constexpr int kCutMinSubs = 16;  // coarsest sub-chunking of a block (= one sub-chunk per wave range on average)
+constexpr int kCutMinSubs = 16;  // smallest fan-out of a refinement level
 
 // fixed LDS of k_cut_fused in front of the T region (keep in step with cut_fused_lds)
 __host__ __device__ __forceinline__ size_t cut_fused_fixed(u32 m, u32 mwords) {
