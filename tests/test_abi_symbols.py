@@ -58,3 +58,49 @@ def test_bad_cfg_rejected(built):
     cfg = built.Cfg(4, 0, 10, 2, 0, 0, 0)  # wrong struct_size
     assert built.lib().rio_gp_create(ctypes.byref(cfg), ctypes.byref(h)) == built.EINVAL
     assert not h.value
+
+
+C_HOST = r"""
+#include <stdio.h>
+#include <string.h>
+#include "rio_gpu_placement.h"
+#include "rio_gpu_object_placement.h"
+/* what a cgo / bindgen consumer sees: plain C99, no C++ types anywhere in the boundary */
+int main(void) {
+    rio_gp_cfg cfg;
+    rio_gp_t* h = 0;
+    int rc;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (uint32_t)sizeof cfg;
+    cfg.max_objects = 1000;
+    cfg.max_nodes = 4;
+    rc = rio_gp_create(&cfg, &h);
+    printf("abi=%u rc=%d err=%s\n", rio_gp_abi_version(), rc, rio_gp_last_error(0));
+    if (rc == RIO_GP_OK) { printf("backend=%s\n", rio_gp_backend(h)); rio_gp_destroy(h); }
+    cfg.struct_size = 4;
+    return rio_gp_create(&cfg, &h) == RIO_GP_EINVAL && h == 0 ? 0 : 1;
+}
+"""
+
+
+def test_headers_are_plain_c99_and_a_c_host_links(built, tmp_path):
+    """The boundary is a C ABI: both headers compile as strict C99 and as C++11, and a C program linked against the
+    library drives rio_gp_create through it (no device here -> RIO_GP_ENODEV with a message, never a CPU fallback)."""
+    import subprocess
+    import torch
+    src = tmp_path / "host.c"
+    src.write_text(C_HOST)
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(built.LIB_PATH)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)],
+                   check=True)
+    exe = tmp_path / "host"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe),
+                    "-L", libdir, "-lrio_gp", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi=1" in r.stdout
+    if torch.cuda.is_available():
+        assert "rc=0" in r.stdout and "backend=hip:gfx950" in r.stdout
+    else:
+        assert "rc=%d" % built.ENODEV in r.stdout and "no CPU fallback" in r.stdout
