@@ -242,17 +242,19 @@ def _proc(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["gloo", "p2p", "p2p-legacy"])
-def test_hip_shards_two_processes_one_gpu(gp, oracle, tmp_path, exchange, monkeypatch):
+@pytest.mark.parametrize("exchange,world", [("gloo", 2), ("p2p", 2), ("p2p-legacy", 2), ("p2p", 3), ("p2p", 5)])
+def test_hip_shards_several_processes_one_gpu(gp, oracle, tmp_path, exchange, world, monkeypatch):
+    """One process per rank, all on the one GPU of the box: real cross-process windows, every rank's claim prefix over
+    the lower ranks, forced nodes, back-to-back steps (slot reuse), then a committed tick with the fix-up exchanges."""
     import torch.multiprocessing as mp
     from test_sharded_protocol import random_case
     monkeypatch.setenv("RIO_TEST_EXCHANGE", exchange.split("-")[0])
     monkeypatch.setenv("RIO_GP_P2P_LEGACY", "1" if exchange.endswith("legacy") else "0")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_proc, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_proc, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     case = random_case(31, n=200_000, m=50, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
     want, used, ost = oracle.tick(*case, 2)
-    parts = [np.load(os.path.join(str(tmp_path), "g%d.npz" % r)) for r in range(2)]
+    parts = [np.load(os.path.join(str(tmp_path), "g%d.npz" % r)) for r in range(world)]
     assert np.array_equal(np.concatenate([z["a"] for z in parts]), want)
     for z in parts:
         assert np.array_equal(z["used"], used)
