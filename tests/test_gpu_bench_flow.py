@@ -44,3 +44,19 @@ def test_bench_two_ranks_as_the_driver_launches_it(exchange):
     assert d["config"]["slow_path_steps"] == 0
     # gloo cannot all-gather device tensors, so the torch path is expected to drop... to nothing: it IS the last rung
     assert d["config"]["exchange"] in ("p2p", "torch")
+
+
+def test_bench_eight_ranks_headline_workload_on_one_gpu():
+    """The driver's N=8 command line with the headline workload (c3: Zipf loads, 1 024 nodes), all eight ranks on the one
+    GPU of the box: eight processes exchanging through each other's IPC-mapped windows, global capacities, one JSON line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "3",
+           "--objects", "1000000", "--no-cpu-baseline", "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["exchange"] == "p2p", d["config"]
+    st = d["stats_last_step"]
+    assert st["n_objects"] == 8_000_000 and st["claimed"] == 8_000_000 and d["config"]["slow_path_steps"] == 0
+
