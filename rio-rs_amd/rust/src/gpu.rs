@@ -52,6 +52,7 @@ extern "C" {
     fn rio_op_create(cfg: *const RioOpCfg, out: *mut *mut c_void) -> c_int;
     fn rio_op_clone(p: *mut c_void) -> *mut c_void;
     fn rio_op_release(p: *mut c_void);
+    fn rio_op_prepare(p: *mut c_void) -> c_int;
     fn rio_op_last_error(p: *mut c_void) -> *const c_char;
     fn rio_op_update(p: *mut c_void, ty: *const c_char, id: *const c_char, addr: *const c_char) -> c_int;
     fn rio_op_lookup(p: *mut c_void, ty: *const c_char, id: *const c_char, out: *mut c_char, cap: usize,
@@ -169,6 +170,12 @@ fn check(rc: c_int, p: &GpuObjectPlacement) -> Result<(), ObjectPlacementError> 
 
 #[async_trait]
 impl ObjectPlacement for GpuObjectPlacement {
+    // mod.rs:42-44: the tables were allocated by `builder()`; forwarded so that a failed device shows up at start-up
+    // (Server::prepare, server.rs:122-123) and not on the first request
+    async fn prepare(&self) -> Result<(), ObjectPlacementError> {
+        check(unsafe { rio_op_prepare(self.inner.0) }, self)
+    }
+
     // mod.rs:46-49 / local.rs:22-40
     async fn update(&self, object_placement: ObjectPlacementItem) -> Result<(), ObjectPlacementError> {
         let ty = cstr(&object_placement.object_id.0)?;

@@ -104,3 +104,33 @@ def test_headers_are_plain_c99_and_a_c_host_links(built, tmp_path):
         assert "rc=0" in r.stdout and "backend=hip:gfx950" in r.stdout
     else:
         assert "rc=%d" % built.ENODEV in r.stdout and "no CPU fallback" in r.stdout
+
+
+def _c_prototypes():
+    """name -> number of parameters, for every function the headers declare."""
+    protos = {}
+    for hdr in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+        for m in re.finditer(r"\b(rio_(?:gp|op)_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+            args = m.group(2).strip()
+            protos[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return protos
+
+
+def test_rust_adapter_declares_the_same_signatures():
+    """The Rust adapter cannot be compiled here (no cargo/rustc): at least its extern "C" block must name functions the
+    headers declare, with the same number of parameters, and cover the whole trait (mod.rs:38-56)."""
+    rs = open(os.path.join(ROOT, "rio-rs_amd", "rust", "src", "gpu.rs")).read()
+    block = re.search(r'extern\s+"C"\s*\{(.*?)\n\}', rs, flags=re.S).group(1)
+    decls = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+             for m in re.finditer(r"fn\s+(rio_[a-z0-9_]+)\s*\(([^)]*)\)", block, flags=re.S)}
+    protos = _c_prototypes()
+    assert len(decls) >= 10
+    for name, nargs in decls.items():
+        assert name in protos, "gpu.rs binds %s, which no header declares" % name
+        assert protos[name] == nargs, "%s: header has %d parameters, gpu.rs %d" % (name, protos[name], nargs)
+    for needed in ("rio_op_update", "rio_op_lookup", "rio_op_clean_server", "rio_op_remove", "rio_op_clone"):
+        assert needed in decls, needed
+    # the trait impl itself: the five methods of ObjectPlacement
+    for method in ("fn prepare", "fn update", "fn lookup", "fn clean_server", "fn remove"):
+        assert method in rs, method
