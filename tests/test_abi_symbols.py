@@ -134,3 +134,17 @@ def test_rust_adapter_declares_the_same_signatures():
     # the trait impl itself: the five methods of ObjectPlacement
     for method in ("fn prepare", "fn update", "fn lookup", "fn clean_server", "fn remove"):
         assert method in rs, method
+
+
+def test_rust_structs_mirror_the_c_layout():
+    """#[repr(C)] structs of gpu.rs: same field names, in the same order, as the header's typedefs."""
+    rs = open(os.path.join(ROOT, "rio-rs_amd", "rust", "src", "gpu.rs")).read()
+    hdrs = "".join(re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+                   for h in glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for rust_name, c_name in (("RioGpStats", "rio_gp_stats"), ("RioOpCfg", "rio_op_cfg")):
+        m = re.search(r"#\[repr\(C\)\][^{]*struct\s+%s\s*\{(.*?)\}" % rust_name, rs, flags=re.S)
+        assert m, "%s must be #[repr(C)]" % rust_name
+        rust_fields = re.findall(r"(?:pub\s+)?([a-z_0-9]+)\s*:\s*[ui](?:8|16|32|64)", m.group(1))
+        c = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}" % c_name, hdrs, flags=re.S).group(1)
+        c_fields = [f.strip() for decl in re.findall(r"u?int(?:8|16|32|64)_t\s+([^;]+);", c) for f in decl.split(",")]
+        assert rust_fields == c_fields, (rust_name, rust_fields, c_fields)
