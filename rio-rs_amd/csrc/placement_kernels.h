@@ -122,8 +122,9 @@ int cut_trace_enable(int on);  // k_cut_fused phase trace (measurement aid)
 int cut_trace_read(u64* out /*[kMaxBlocks*8]*/);
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1);
+// have_cutblk: launch_resolve of the same solve (same bufs) has already written cutblk / budget / admpre
 void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
-                      bool fused = true);
+                      bool fused = true, bool have_cutblk = false);
 void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
                         hipStream_t s);
 

@@ -378,10 +378,15 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
                                                  const u64* __restrict__ used_base, u64* __restrict__ used_kept,
                                                  u64* __restrict__ used_cur, u64* __restrict__ claim_tot,
                                                  u32* __restrict__ cutblk, u32* __restrict__ cutidx,
-                                                 u64* __restrict__ partial, u64* __restrict__ host_partial) {
+                                                 u64* __restrict__ partial, u64* __restrict__ host_partial,
+                                                 u64* __restrict__ budget, u64* __restrict__ admpre,
+                                                 DevStats* __restrict__ stats) {
     __shared__ u64 part[kResRowGroups][8];
     __shared__ u64 tot[8];
     __shared__ u64 red[8];
+    __shared__ u64 cutfre[kResNodes];               // free capacity of a node of this workgroup that has a cut
+    __shared__ u32 cutmask;                         // which of the four nodes have one
+    __shared__ u64 colbuf[kResNodes][kMaxBlocks];   // their claim columns, row order (only filled when cutmask != 0)
     const int tid = threadIdx.x, lane = tid & 63, col = tid & 7, rg = tid >> 3;
     const u32 m = p.m, G = p.G, nb = gridDim.x;
     const u32 j = blockIdx.x * kResNodes + (col & 3);
@@ -406,6 +411,7 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     for (int r = 0; r < kResRows; ++r) sacc += v[r];
     part[rg][col] = sacc;
     if (tid < 8) red[tid] = 0;
+    if (tid == 0) cutmask = 0;
     __syncthreads();
     if (tid < 8) {
         u64 t = 0;
@@ -425,7 +431,11 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
         used_cur[j] = used + ctot;  // final unless the node has a cut (k_cut_exact rewrites it)
         atomicAdd(&red[0], kept_load);
         atomicAdd(&red[1], ctot);
-        if (ctot > fre) atomicAdd(&red[2], 1ull);
+        if (ctot > fre) {
+            atomicAdd(&red[2], 1ull);
+            cutfre[tid] = fre;
+            atomicOr(&cutmask, 1u << tid);
+        }
     }
     if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
         u64 acc = 0;
@@ -439,6 +449,41 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
         partial[(size_t)blockIdx.x * 8 + tid] = x;
         if (host_partial) host_partial[(size_t)blockIdx.x * 8 + tid] = x;
     }
+    // A node whose claims exceed its free capacity: in which block (row of H) does the ordered prefix cross it?  The
+    // column is still in this workgroup's registers, so the answer costs no extra launch (k_cutblk's job on this path):
+    // claim columns to LDS in row order, one wave per cut node, four rows per lane, ordered scan.
+    if (!budget || cutmask == 0) return;  // block-uniform
+    if (col >= 4) {
+#pragma unroll
+        for (int r = 0; r < kResRows; ++r) colbuf[col - 4][rg + r * kResRowGroups] = v[r];
+    }
+    __syncthreads();
+    const int q = tid >> 6;  // wave = node of this workgroup
+    if (q < kResNodes && ((cutmask >> q) & 1u)) {
+        const u64 fre = cutfre[q];
+        const u64 x0 = colbuf[q][lane * 4 + 0], x1 = colbuf[q][lane * 4 + 1], x2 = colbuf[q][lane * 4 + 2],
+                  x3 = colbuf[q][lane * 4 + 3];
+        const u64 s1 = x0 + x1, s2 = s1 + x2, s3 = s2 + x3;
+        const u64 inc = wave_incl_scan(s3, lane);
+        const u64 ex = inc - s3;
+        int e = 4;  // first row of this lane whose inclusive prefix exceeds the free capacity
+        if (ex + s3 > fre) e = 3;
+        if (ex + s2 > fre) e = 2;
+        if (ex + s1 > fre) e = 1;
+        if (ex + x0 > fre) e = 0;
+        const u64 mask = __ballot(e < 4);
+        if (mask) {
+            const int fl = __ffsll((long long)mask) - 1;
+            if (lane == fl) {
+                const u64 cum = ex + (e == 0 ? 0ull : e == 1 ? x0 : e == 2 ? s1 : s2);
+                const u32 jq = blockIdx.x * kResNodes + q;
+                cutblk[jq] = (u32)(lane * 4 + e);
+                budget[jq] = fre - cum;
+                admpre[jq] = cum;
+            }
+        }
+    }
+    if (tid == 0) atomicAdd(&stats->n_cut, 1ull);  // device-side "some node has a cut" flag (k_cut_fused's guard)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2245,11 +2290,11 @@ void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* h
     if (e0 && e1)
         hipExtLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, s, e0, e1, 0, b.H, b.blkstat, p, nt.cap,
                               nt.alive_bits, nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx,
-                              b.partial, host_partial);
+                              b.partial, host_partial, b.budget, b.admpre, b.stats);
     else
         hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, s, b.H, b.blkstat, p, nt.cap, nt.alive_bits,
                            nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, b.partial,
-                           host_partial);
+                           host_partial, b.budget, b.admpre, b.stats);
 }
 
 // dynamic LDS of k_cut_fused: the fixed tables + as many u64 words of T region as fit (T rows [K][S|1] + 3 state words
@@ -2267,11 +2312,12 @@ size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
 // fused: k_cutblk + k_cut_fused (default) | else the unfused chain: T memset, k_cutblk, k_cut_subhist, k_cut_exact,
 // (k_shard_force,) k_apply_cut — kept for A/B runs and as a second implementation the parity tests compare against
 void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
-                      hipStream_t s, bool fused) {
+                      hipStream_t s, bool fused, bool have_cutblk) {
     const unsigned gcb = (p.m + kCbNodes - 1) / kCbNodes;
     if (fused) {
-        hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
-                           b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
+        if (!have_cutblk)  // k_resolve of this solve has already located the cut blocks (not on the row-sharded path)
+            hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
+                               b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
         u32 tcap = 0;
         const size_t ldsf = cut_fused_lds(p, &tcap);
         if (virt)

@@ -252,7 +252,8 @@ NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; 
 
 // the cut / spill fix-up of a solve whose fast path said it needs one
 void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, const DevStats& verdict) {
-    if (verdict.n_cut > 0) launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode == 1);
+    // every caller ran launch_resolve over h->sb for this solve: the cut blocks are already located
+    if (verdict.n_cut > 0) launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode == 1, true);
     for (u32 r = 0; r < h->rounds; ++r) launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream);
 }
 
