@@ -90,6 +90,8 @@ float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u
             case 0: hipExtLaunchKernelGGL(k_probe_gridstride, dim3(2048), dim3(256), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             case 1: hipExtLaunchKernelGGL(k_probe_blocktile, dim3(256), dim3(1024), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             case 2: hipExtLaunchKernelGGL(k_probe_wavecontig, dim3(256), dim3(1024), 0, s, e0, e1, 0, A, B, C, O, nv); break;
+            case 10: hipExtLaunchKernelGGL(k_probe_wavecontig, dim3(512), dim3(1024), 0, s, e0, e1, 0, A, B, C, O, nv); break;  // 2 workgroups per CU
+            case 11: hipExtLaunchKernelGGL(k_probe_blocktile, dim3(512), dim3(1024), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             case 3: hipExtLaunchKernelGGL(k_probe_readonly, dim3(2048), dim3(256), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             case 5: hipExtLaunchKernelGGL(k_probe_gridstride, dim3(8192), dim3(256), 0, s, e0, e1, 0, A, B, C, O, nv); break;
             case 7: hipExtLaunchKernelGGL((k_probe_nt<true, false>), dim3(2048), dim3(256), 0, s, e0, e1, 0, (const u32x4*)a, (const u32x4*)b, (const u32x4*)c, (u32x4*)o, nv); break;
