@@ -1,12 +1,17 @@
 // gpu_object_placement.cpp — host-side mirror of the reference's ObjectPlacement interface
 // (include/rio_gpu_object_placement.h) on top of the dense C ABI.  Pure host C++: interning of
 // (struct_name, object_id) and "ip:port" strings, the malformed-record rule of the policy, reference
-// counting for Clone.  Every placement fact lives in HBM; this file never mirrors the assignment.
+// counting for Clone, and a combining front-end for the single-object calls (concurrent callers share one device
+// round trip).  Every placement fact lives in HBM; this file never mirrors the assignment.
 //
 // Mirrors (relative to /root/reference):
 //   LocalObjectPlacement              rio-rs/src/object_placement/local.rs:12-68
 //   Service::get_or_create_placement  rio-rs/src/service.rs:193-254
+#include <sched.h>
+
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -17,8 +22,24 @@
 
 namespace {
 
+// One single-object call waiting for its device round trip (see run_combined).
+struct Req {
+    int kind;                 // 0 lookup | 1 get_or_create_placement
+    uint32_t row, req;        // dense ids (req: requester node, kind 1)
+    uint32_t node = RIO_GP_NONE, flag = 0;
+    int rc = RIO_GP_OK;
+    std::atomic<int> done{0};  // set LAST by the serving thread: the request lives on its caller's stack
+};
+
 struct State {
-    std::mutex mu;
+    std::mutex mu;    // compound operations and their device call sequences (taken first)
+    std::mutex imu;   // the interning tables below (taken second, or alone by the combined single-object calls, which
+                      // must be able to intern and queue while the serving thread waits for the device)
+    std::mutex qmu;                    // combiner: queue of single-object calls + who is serving it
+    std::condition_variable qcv;
+    std::vector<Req*> queue;
+    bool serving = false;
+    int sleepers = 0;                  // waiters that gave up spinning and sleep on qcv
     std::string err;
     rio_gp_t* gp = nullptr;
     uint64_t max_objects = 0;
@@ -115,19 +136,110 @@ void copy_out(const std::string& v, char* out, size_t cap) {
 
 // the whole policy for a batch of (row, requester) pairs; rows/reqs are dense ids
 int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& reqs, uint32_t* out_node,
-                 uint32_t* out_flag) {
+                 uint32_t* out_flag, bool tables_locked = true) {
     const uint64_t n = rows.size();
-    if (s->n_malformed) {
+    bool any_malformed;
+    {
+        std::unique_lock<std::mutex> li(s->imu, std::defer_lock);
+        if (!tables_locked) li.lock();
+        any_malformed = s->n_malformed != 0;
+    }
+    if (any_malformed) {
         // service.rs:213-223: a record whose address has no ip or no port is removed (only that record)
         std::vector<uint32_t> cur(n), bad;
         int rc = rio_gp_lookup_batch(s->gp, n, rows.data(), cur.data());
         if (rc) return gp_fail(s, rc);
-        for (uint64_t k = 0; k < n; ++k)
-            if (cur[k] != RIO_GP_NONE && s->node_malformed[cur[k]]) bad.push_back(rows[k]);
+        {
+            std::unique_lock<std::mutex> li(s->imu, std::defer_lock);
+            if (!tables_locked) li.lock();
+            for (uint64_t k = 0; k < n; ++k)
+                if (cur[k] != RIO_GP_NONE && s->node_malformed[cur[k]]) bad.push_back(rows[k]);
+        }
         if (!bad.empty() && (rc = rio_gp_remove_batch(s->gp, bad.size(), bad.data()))) return gp_fail(s, rc);
     }
     int rc = rio_gp_place_pending(s->gp, n, rows.data(), reqs.data(), out_node, out_flag);
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+// Combining front-end for the single-object calls (ObjectPlacement::lookup, get_or_create_placement): the reference is
+// called from one tokio task per connection (server.rs:292-304), and one device round trip per call (16-22 us behind a
+// mutex) would cap a provider at ~5e4 calls/s however many tasks call it.  Callers queue their request; whoever finds
+// nobody serving becomes the server: it takes up to kCombine queued requests, runs ONE batched device call per kind (the
+// micro-batch kernels: one launch + one wait for <= 256 requests), publishes the results and repeats until the queue
+// is empty.  A lone caller pays exactly what it paid before; N concurrent callers share a round trip.  Requests of one
+// batch keep their arrival order (the first request for an object decides, as in rio_gp_place_pending).
+constexpr size_t kCombine = 256;
+
+void serve(State* s, std::vector<Req*>& batch) {
+    std::lock_guard<std::mutex> g(s->mu);  // NOT imu: callers keep interning and queueing during the device round trip
+    std::vector<uint32_t> rows, reqs, res, fl;
+    std::vector<Req*> who;
+    for (int kind = 0; kind < 2; ++kind) {
+        rows.clear(); reqs.clear(); who.clear();
+        for (Req* r : batch)
+            if (r->kind == kind) { rows.push_back(r->row); reqs.push_back(r->req); who.push_back(r); }
+        if (who.empty()) continue;
+        res.assign(who.size(), RIO_GP_NONE);
+        fl.assign(who.size(), 0);
+        int rc;
+        if (kind == 0) {
+            rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res.data());
+            if (rc) gp_fail(s, rc);
+        } else {
+            rc = policy_batch(s, rows, reqs, res.data(), fl.data(), false);
+        }
+        for (size_t k = 0; k < who.size(); ++k) { who[k]->rc = rc; who[k]->node = res[k]; who[k]->flag = fl[k]; }
+    }
+}
+
+int run_combined(State* s, Req* mine) {
+    std::unique_lock<std::mutex> lk(s->qmu);
+    s->queue.push_back(mine);
+    if (s->serving) {
+        // a device round trip is 15-25 us: spin on the own flag first (a futex sleep + wake costs more than the wait and,
+        // with hundreds of waiters, serialises them), sleep only when it takes much longer
+        lk.unlock();
+        for (int spin = 0; spin < 400; ++spin) {  // ~10 us of pure spinning
+            if (mine->done.load(std::memory_order_acquire)) return mine->rc;
+            __builtin_ia32_pause();
+        }
+        for (int y = 0; y < 200; ++y) {           // then give the core away between looks (more threads than cores)
+            if (mine->done.load(std::memory_order_acquire)) return mine->rc;
+            sched_yield();
+        }
+        lk.lock();
+        ++s->sleepers;
+        s->qcv.wait(lk, [&] { return mine->done.load(std::memory_order_acquire) != 0; });
+        --s->sleepers;
+        return mine->rc;
+    }
+    s->serving = true;
+    std::vector<Req*> batch;
+    size_t last_batch = 1;
+    while (!s->queue.empty()) {
+        if (last_batch > 1 && s->queue.size() < last_batch) {
+            // other callers are active and on their way back with their next request: a few microseconds of collecting
+            // turn "one, then everyone else" into "everyone" per device round trip
+            lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(4)) __builtin_ia32_pause();
+            lk.lock();
+        }
+        const size_t take = s->queue.size() < kCombine ? s->queue.size() : kCombine;
+        batch.assign(s->queue.begin(), s->queue.begin() + take);
+        s->queue.erase(s->queue.begin(), s->queue.begin() + take);
+        lk.unlock();
+        serve(s, batch);
+        const int my_rc = mine->rc;  // `mine` may be in this batch: read before anything is released
+        (void)my_rc;
+        for (Req* r : batch)
+            if (r != mine) r->done.store(1, std::memory_order_release);  // last touch of *r
+        last_batch = batch.size();
+        lk.lock();
+        if (s->sleepers) s->qcv.notify_all();
+    }
+    s->serving = false;
+    return mine->rc;
 }
 
 }  // namespace
@@ -190,6 +302,7 @@ rio_gp_t* rio_op_dense(rio_op_t* p) { return p ? p->s->gp : nullptr; }
 const char* rio_op_node_address(rio_op_t* p, uint32_t node_id) {
     if (!p) return nullptr;
     std::lock_guard<std::mutex> g(p->s->mu);
+    std::lock_guard<std::mutex> gi(p->s->imu);
     return node_id < p->s->node_addr.size() ? p->s->node_addr[node_id].c_str() : nullptr;
 }
 
@@ -198,6 +311,7 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
     if (!p || (n && (!tys || !ids || !addrs))) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     std::vector<uint32_t> rows, nodes;
     rows.reserve(n);
     nodes.reserve(n);
@@ -230,6 +344,7 @@ int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
     if (!p || (n && (!tys || !ids || !out))) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     std::vector<uint32_t> rows, where;
     for (uint64_t k = 0; k < n; ++k) {
         uint32_t row;
@@ -251,13 +366,23 @@ int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
 
 int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t cap, int* found) {
     if (!p || !found) return RIO_GP_EINVAL;
-    uint32_t node = RIO_GP_NONE;
-    int rc = rio_op_lookup_batch(p, 1, &ty, &id, &node);
+    State* s = p->s;
+    Req r;
+    r.kind = 0;
+    r.req = RIO_GP_NONE;
+    {
+        std::lock_guard<std::mutex> gi(s->imu);
+        int rc = intern_row(s, ty, id, false, &r.row);
+        if (rc) return rc;
+    }
+    *found = 0;
+    if (r.row == RIO_GP_NONE) return RIO_GP_OK;  // unknown key: Ok(None), no device work
+    int rc = run_combined(s, &r);
     if (rc) return rc;
-    *found = node != RIO_GP_NONE;
+    *found = r.node != RIO_GP_NONE;
     if (*found) {
-        std::lock_guard<std::mutex> g(p->s->mu);
-        copy_out(p->s->node_addr[node], out, cap);
+        std::lock_guard<std::mutex> gi(s->imu);
+        copy_out(s->node_addr[r.node], out, cap);
     }
     return RIO_GP_OK;
 }
@@ -266,6 +391,7 @@ int rio_op_clean_server(rio_op_t* p, const char* address) {
     if (!p || !address) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     uint32_t node;
     int rc = intern_node(s, address, false, &node, nullptr);
     if (rc) return rc;
@@ -278,6 +404,7 @@ int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     uint32_t row;
     int rc = intern_row(s, ty, id, false, &row);
     if (rc) return rc;
@@ -290,6 +417,7 @@ int rio_op_len(rio_op_t* p, uint64_t* out) {
     if (!p || !out) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     int rc = rio_gp_count_placed(s->gp, out);
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
 }
@@ -298,6 +426,7 @@ int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t cap
     if (!p || !address) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     uint32_t node;
     bool created = false;
     int rc = intern_node(s, address, true, &node, &created);
@@ -311,6 +440,7 @@ int rio_op_set_object_load(rio_op_t* p, const char* ty, const char* id, uint32_t
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     uint32_t row;
     int rc = intern_row(s, ty, id, true, &row);
     if (rc) return rc;
@@ -323,6 +453,7 @@ int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* co
     if (!p || (n && (!tys || !ids || !selfs || !out_node))) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     std::vector<uint32_t> rows(n), reqs(n);
     bool created = false;
     for (uint64_t k = 0; k < n; ++k) {
@@ -340,12 +471,29 @@ int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* co
 int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, const char* self_address, char* out,
                                    size_t cap, uint32_t* flag) {
     if (!p || !self_address) return RIO_GP_EINVAL;
-    uint32_t node = RIO_GP_NONE, fl = 0;
-    int rc = rio_op_get_or_create_placement_batch(p, 1, &ty, &id, &self_address, &node, &fl);
+    State* s = p->s;
+    Req r;
+    r.kind = 1;
+    bool created = false;
+    {
+        std::lock_guard<std::mutex> gi(s->imu);
+        int rc;
+        if ((rc = intern_row(s, ty, id, true, &r.row))) return rc;
+        const size_t before = s->node_addr.size();
+        if ((rc = intern_node(s, self_address, true, &r.req, &created))) return rc;
+        if (s->node_addr.size() != before) s->node_alive[r.req] = 1;  // a server answering requests is up
+    }
+    if (created) {  // rare: a requester never seen before — the node table goes to the device before the request does
+        std::lock_guard<std::mutex> g(s->mu);
+        std::lock_guard<std::mutex> gi(s->imu);
+        int rc = push_nodes(s);
+        if (rc) return rc;
+    }
+    int rc = run_combined(s, &r);
     if (rc) return rc;
-    if (flag) *flag = fl;
-    std::lock_guard<std::mutex> g(p->s->mu);
-    copy_out(node == RIO_GP_NONE ? std::string() : p->s->node_addr[node], out, cap);
+    if (flag) *flag = r.flag;
+    std::lock_guard<std::mutex> gi(s->imu);
+    copy_out(r.node == RIO_GP_NONE ? std::string() : s->node_addr[r.node], out, cap);
     return RIO_GP_OK;
 }
 
@@ -354,6 +502,7 @@ int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_nam
     if (!p || !n_out || !struct_names || !object_ids || !server_addresses) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     std::vector<uint32_t> assign(s->max_objects);
     int rc = rio_gp_get_assign(s->gp, s->max_objects, assign.data());
     if (rc) return gp_fail(s, rc);
@@ -376,6 +525,7 @@ int rio_op_tick(rio_op_t* p, rio_gp_stats* stats) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> gi(s->imu);
     int rc = rio_gp_tick(s->gp, stats);
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
 }

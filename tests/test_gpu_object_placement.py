@@ -213,3 +213,28 @@ def test_snapshot_round_trip_in_the_reference_schema(gp, tmp_path):
     assert c.lookup("Room", "1") == "10.9.9.9:1" and c.lookup("a.b", "c") == addrs[300] and len(c) == len(keys)
     for x in (a, b, c):
         x.close()
+
+
+def test_concurrent_single_object_calls_share_round_trips(gp, tmp_path):
+    """The trait is called from one task per connection (server.rs:292-304): T threads issue single-object lookups and
+    get_or_create_placement calls against ONE provider through the C ABI (examples/c_host_threads.c, plain C + pthreads).
+    Every answer must be right, and concurrent callers must not be slower than a lone one (the combining front-end lets
+    them share a device round trip)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_host_threads"
+    libdir = os.path.dirname(gp.LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-std=c99", "-pthread", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_host_threads.c"), "-o", str(exe), "-L", libdir, "-lrio_gp",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), "5000", "400", "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 4 and all(x["wrong"] == 0 for x in rows)          # 2 calls x threads {1, 4}; 8 is not in the ladder
+    for call in ("lookup", "get_or_create_placement"):
+        one = [x for x in rows if x["call"] == call and x["threads"] == 1][0]["calls_per_s"]
+        four = [x for x in rows if x["call"] == call and x["threads"] == 4][0]["calls_per_s"]
+        assert four > 0.9 * one, (call, one, four)
+
