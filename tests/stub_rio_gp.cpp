@@ -1,0 +1,101 @@
+// stub_rio_gp.cpp — TEST INFRASTRUCTURE ONLY: a host-memory stand-in for the dense C ABI (include/rio_gpu_placement.h),
+// just enough of it for the string layer (rio-rs_amd/csrc/gpu_object_placement.cpp) to run under ThreadSanitizer on a
+// machine without a GPU (tests/test_host_layer_races.py).  It is linked into that one test binary and nowhere else; the
+// product library has no CPU path.  Policy = the capacity-free reference policy (service.rs:193-254): sticky if the node
+// is alive, else first touch on the requester.
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../include/rio_gpu_placement.h"
+
+struct rio_gp {
+    std::mutex mu;
+    std::vector<uint32_t> assign;
+    std::vector<uint8_t> alive;
+    std::string err;
+};
+
+extern "C" {
+uint32_t rio_gp_abi_version(void) { return RIO_GP_ABI_VERSION; }
+const char* rio_gp_last_error(rio_gp_t* h) { return h ? h->err.c_str() : "stub"; }
+const char* rio_gp_backend(rio_gp_t*) { return "stub:host (tests only)"; }
+int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
+    if (!cfg || !out) return RIO_GP_EINVAL;
+    rio_gp* h = new rio_gp();
+    h->assign.assign(cfg->max_objects, RIO_GP_NONE);
+    *out = h;
+    return RIO_GP_OK;
+}
+void rio_gp_destroy(rio_gp_t* h) { delete h; }
+int rio_gp_set_objects(rio_gp_t* h, uint64_t n, const uint32_t*, const uint32_t*) {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n > h->assign.size()) return RIO_GP_EINVAL;
+    return RIO_GP_OK;
+}
+int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t*, const uint8_t* alive) {
+    std::lock_guard<std::mutex> g(h->mu);
+    h->alive.assign(m, 1);
+    if (alive) memcpy(h->alive.data(), alive, m);
+    return RIO_GP_OK;
+}
+int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* out) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k) {
+        if (idx[k] >= h->assign.size()) return RIO_GP_EINVAL;
+        out[k] = h->assign[idx[k]];
+    }
+    return RIO_GP_OK;
+}
+int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* node) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k) h->assign[idx[k]] = node[k];
+    return RIO_GP_OK;
+}
+int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k) h->assign[idx[k]] = RIO_GP_NONE;
+    return RIO_GP_OK;
+}
+int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
+    std::lock_guard<std::mutex> g(h->mu);
+    uint64_t ev = 0;
+    for (auto& a : h->assign)
+        if (a == node) { a = RIO_GP_NONE; ++ev; }
+    if (evicted) *evicted = ev;
+    return RIO_GP_OK;
+}
+int rio_gp_count_placed(rio_gp_t* h, uint64_t* out) {
+    std::lock_guard<std::mutex> g(h->mu);
+    uint64_t c = 0;
+    for (auto a : h->assign) c += a != RIO_GP_NONE;
+    *out = c;
+    return RIO_GP_OK;
+}
+int rio_gp_set_object_attrs(rio_gp_t*, uint64_t, const uint32_t*, const uint32_t*, const uint32_t*) { return RIO_GP_OK; }
+int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out) {
+    std::lock_guard<std::mutex> g(h->mu);
+    memcpy(out, h->assign.data(), n * sizeof(uint32_t));
+    return RIO_GP_OK;
+}
+int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* req, uint32_t* out_node, uint32_t* out_flag) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k) {
+        uint32_t& a = h->assign[idx[k]];
+        const bool up = a != RIO_GP_NONE && a < h->alive.size() && h->alive[a];
+        uint32_t fl;
+        if (up) fl = a == req[k] ? RIO_GP_FLAG_LOCAL : RIO_GP_FLAG_REDIRECT;
+        else if (req[k] < h->alive.size() && h->alive[req[k]]) { a = req[k]; fl = RIO_GP_FLAG_PLACED; }
+        else { a = RIO_GP_NONE; fl = RIO_GP_FLAG_UNPLACED; }
+        out_node[k] = a;
+        if (out_flag) out_flag[k] = fl;
+    }
+    return RIO_GP_OK;
+}
+int rio_gp_tick(rio_gp_t* h, rio_gp_stats* st) {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (st) memset(st, 0, sizeof *st);
+    return RIO_GP_OK;
+}
+}  // extern "C"
