@@ -24,8 +24,8 @@ namespace {
 
 // One single-object call waiting for its device round trip (see run_combined).
 struct Req {
-    int kind;                 // 0 lookup | 1 get_or_create_placement
-    uint32_t row, req;        // dense ids (req: requester node, kind 1)
+    int kind;                 // 0 lookup | 1 get_or_create_placement | 2 update | 3 remove
+    uint32_t row, req;        // dense ids (req: requester node for kind 1, new node or NONE for kind 2)
     uint32_t node = RIO_GP_NONE, flag = 0;
     int rc = RIO_GP_OK;
     std::atomic<int> done{0};  // set LAST by the serving thread: the request lives on its caller's stack
@@ -174,7 +174,9 @@ void serve(State* s, std::vector<Req*>& batch) {
     std::lock_guard<std::mutex> g(s->mu);  // NOT imu: callers keep interning and queueing during the device round trip
     std::vector<uint32_t> rows, reqs, res, fl;
     std::vector<Req*> who;
-    for (int kind = 0; kind < 2; ++kind) {
+    // writes first, in arrival order (sequential last-writer-wins, local.rs:22-40), then the reads and the policy calls:
+    // a caller only returns after the batch, so any order inside it is a valid linearisation of concurrent calls
+    for (int kind : {2, 3, 0, 1}) {
         rows.clear(); reqs.clear(); who.clear();
         for (Req* r : batch)
             if (r->kind == kind) { rows.push_back(r->row); reqs.push_back(r->req); who.push_back(r); }
@@ -185,8 +187,14 @@ void serve(State* s, std::vector<Req*>& batch) {
         if (kind == 0) {
             rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res.data());
             if (rc) gp_fail(s, rc);
-        } else {
+        } else if (kind == 1) {
             rc = policy_batch(s, rows, reqs, res.data(), fl.data(), false);
+        } else if (kind == 2) {
+            rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), reqs.data());
+            if (rc) gp_fail(s, rc);
+        } else {
+            rc = rio_gp_remove_batch(s->gp, rows.size(), rows.data());
+            if (rc) gp_fail(s, rc);
         }
         for (size_t k = 0; k < who.size(); ++k) { who[k]->rc = rc; who[k]->node = res[k]; who[k]->flag = fl[k]; }
     }
@@ -337,7 +345,30 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
 }
 
 int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr) {
-    return rio_op_update_batch(p, 1, &ty, &id, &addr);
+    if (!p) return RIO_GP_EINVAL;
+    State* s = p->s;
+    Req r;
+    r.kind = 2;
+    r.req = RIO_GP_NONE;
+    bool created = false;
+    {
+        std::lock_guard<std::mutex> gi(s->imu);
+        int rc;
+        if (addr) {  // Some(address): entry(key) = address
+            if ((rc = intern_row(s, ty, id, true, &r.row))) return rc;
+            if ((rc = intern_node(s, addr, true, &r.req, &created))) return rc;
+        } else {     // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
+            if ((rc = intern_row(s, ty, id, false, &r.row))) return rc;
+            if (r.row == RIO_GP_NONE) return RIO_GP_OK;
+        }
+    }
+    if (created) {  // a server address never seen before: the node table goes to the device first
+        std::lock_guard<std::mutex> g(s->mu);
+        std::lock_guard<std::mutex> gi(s->imu);
+        int rc = push_nodes(s);
+        if (rc) return rc;
+    }
+    return run_combined(s, &r);
 }
 
 int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids, uint32_t* out) {
@@ -403,14 +434,16 @@ int rio_op_clean_server(rio_op_t* p, const char* address) {
 int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
-    uint32_t row;
-    int rc = intern_row(s, ty, id, false, &row);
-    if (rc) return rc;
-    if (row == RIO_GP_NONE) return RIO_GP_OK;  // absent: no-op (local.rs:60-68)
-    rc = rio_gp_remove_batch(s->gp, 1, &row);
-    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+    Req r;
+    r.kind = 3;
+    r.req = RIO_GP_NONE;
+    {
+        std::lock_guard<std::mutex> gi(s->imu);
+        int rc = intern_row(s, ty, id, false, &r.row);
+        if (rc) return rc;
+    }
+    if (r.row == RIO_GP_NONE) return RIO_GP_OK;  // absent: no-op (local.rs:60-68)
+    return run_combined(s, &r);
 }
 
 int rio_op_len(rio_op_t* p, uint64_t* out) {

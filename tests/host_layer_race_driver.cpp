@@ -35,6 +35,14 @@ int main() {
                 rio_op_clean_server(mine, "10.9.9.9:1");
                 rio_op_set_member(mine, self.c_str(), 1, RIO_GP_CAP_INF);
             }
+            if (k % 13 == 0) {  // single-object writes go through the same combining queue as the reads
+                const std::string key = "w" + std::to_string(tid) + "_" + std::to_string(k);
+                if (rio_op_update(mine, "Own", key.c_str(), self.c_str()) != RIO_GP_OK) ++bad;
+                if (rio_op_lookup(mine, "Own", key.c_str(), out, sizeof out, &found) != RIO_GP_OK || !found || self != out) ++bad;
+                if (rio_op_remove(mine, "Own", key.c_str()) != RIO_GP_OK) ++bad;
+                if (rio_op_lookup(mine, "Own", key.c_str(), out, sizeof out, &found) != RIO_GP_OK || found) ++bad;
+                if (rio_op_update(mine, "Own", key.c_str(), nullptr) != RIO_GP_OK) ++bad;  // None deletes (local.rs:36-37)
+            }
             if (k % 97 == 0) {
                 const char* ty = "Other";
                 const char* oid = id.c_str();
