@@ -132,6 +132,8 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s);
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos_scratch,
                    DevStats* st, hipStream_t s);
+// n <= kSmallBatch validated entries (may be mapped host memory): last writer wins inside the batch, one launch
+void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
                    DevStats* st, hipStream_t s);
 // counter == nullptr: accumulate into st->evicted_clean.  ticket/host_out: self-resetting counter + total written to

@@ -1511,6 +1511,22 @@ __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const
         }
     }
 }
+// update, micro-batch (n <= kSmallBatch): one workgroup, one launch; entries were validated by the host and may sit in
+// mapped host memory.  Sequential last-writer-wins inside the batch: an entry loses to any LATER entry for the same row.
+__global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
+                                                              const u32* __restrict__ node, u32 n) {
+    __shared__ u32 li[kSmallBatch];
+    const u32 k = threadIdx.x;
+    u32 i = kNone, nd = kNone;
+    if (k < n) { i = idx[k]; nd = node[k]; }
+    li[k] = i;
+    __syncthreads();
+    if (k >= n) return;
+    bool wins = true;
+    for (u32 q = k + 1; q < n; ++q) wins &= li[q] != i;
+    if (wins) assign[i] = nd;
+}
+
 // remove (local.rs:60-68): exchange makes duplicate removals of one row decrement `used` once.  The load released per
 // node is gathered in an LDS histogram and flushed once per workgroup: a per-row global atomic on `used` serialises a
 // million removals on at most m addresses (measured 55 us per million rows).
@@ -2378,6 +2394,10 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
     hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos);
+}
+void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n);
 }
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
                    hipStream_t s) {

@@ -776,6 +776,18 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
     if (!n) return RIO_GP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
+    if (n <= (uint64_t)kSmallBatch) {
+        // micro-batch (one first-touch update per activation in the reference flow, service.rs:244-252): the entries were
+        // validated above, so the kernels read them from mapped pinned memory and nothing is copied, zeroed or read back
+        memcpy(h->h_small, idx, n * sizeof(u32));
+        memcpy(h->h_small + kSmallBatch, node, n * sizeof(u32));
+        launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream);
+        h->used_valid = false;
+        h->have_solved = false;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        return RIO_GP_OK;
+    }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->stage[1].p, node, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
@@ -808,6 +820,15 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     if (!n) return RIO_GP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
+    if (n <= (uint64_t)kSmallBatch) {  // micro-batch: validated above, read from mapped pinned memory, one launch + one wait
+        memcpy(h->h_small, idx, n * sizeof(u32));
+        launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_small, n, h->used_valid ? h->used : nullptr, h->dstats,
+                      h->stream);
+        h->have_solved = false;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        return RIO_GP_OK;
+    }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
     return remove_dev_locked(h, n, (const u32*)h->stage[0].p);

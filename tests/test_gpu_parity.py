@@ -147,6 +147,35 @@ def test_crud_batches_random(gp, oracle, seed):
     g.close()
 
 
+@pytest.mark.parametrize("seed", [10, 11])
+def test_crud_micro_batches(gp, oracle, seed):
+    """Batches of <= 256 entries take the one-launch paths over mapped pinned memory (k_update_small: last writer wins
+    INSIDE the batch; remove with the incremental `used`; lookup): same bytes as the oracle, duplicates included."""
+    rng = np.random.default_rng(seed)
+    n, m = 3000, 17
+    load = rng.integers(0, 100, n).astype(np.uint32)
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    for step in range(60):
+        k = int(rng.choice([1, 2, 7, 64, 255, 256]))
+        idx = rng.integers(0, 40 if step % 3 == 0 else n, k).astype(np.uint32)   # every third step: heavy duplication
+        node = rng.integers(0, m, k).astype(np.uint32)
+        node[rng.random(k) < 0.15] = NONE
+        g.update_batch(idx, node)
+        assert oracle.update_batch(ref, m, idx, node) == 0
+        q = rng.integers(0, n, int(rng.integers(1, 257))).astype(np.uint32)
+        assert np.array_equal(g.lookup_batch(q), oracle.lookup_batch(ref, q))
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))
+        rm = rng.integers(0, 60 if step % 4 == 0 else n, int(rng.integers(1, 257))).astype(np.uint32)
+        g.remove_batch(rm)
+        oracle.remove_batch(ref, rm)
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))  # incremental == scratch
+        assert np.array_equal(g.get_assign(), ref)
+    g.close()
+
+
 def test_invalid_arguments_are_unknown_errors(gp):
     g = gp.GpuPlacement(10, 2)
     g.set_nodes(m=2, alive=np.ones(2, np.uint8))
