@@ -112,6 +112,7 @@ def lib():
         L.rio_gp_solve_async.argtypes = [_vp]
         L.rio_gp_solve_wait.argtypes = [_vp, C.POINTER(Stats), C.POINTER(C.c_uint32)]
         L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.rio_gp_set_object_attrs.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp]
         L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
         L.rio_gp_debug_cut_trace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
@@ -189,6 +190,11 @@ class GpuPlacement:
     def set_objects(self, n, load=None, aff=None):
         load, aff = _u32(load), _u32(aff)
         self._chk(lib().rio_gp_set_objects(self._h, n, _ptr(load), _ptr(aff)))
+
+    def set_object_attrs(self, idx, load=None, aff=None):
+        """Change load and/or affinity of individual rows (either may be None = leave as is)."""
+        idx, load, aff = _u32(idx), _u32(load), _u32(aff)
+        self._chk(lib().rio_gp_set_object_attrs(self._h, len(idx), _ptr(idx), _ptr(load), _ptr(aff)))
 
     def set_objects_dev(self, n, d_load, d_aff):
         self._chk(lib().rio_gp_set_objects_dev(self._h, n, _vp(d_load), _vp(d_aff)))

@@ -507,3 +507,16 @@ def test_full_size_config3_properties(gp):
     ev = g.clean_server(int(b[0]))
     assert ev == int((b == b[0]).sum())
     g.close()
+
+
+def test_soak_churn_stream_against_the_oracle():
+    """120 ticks of membership churn with load / affinity edits, removals and request micro-batches in between, every
+    tick and every batch compared with the oracle (tools/soak_churn.py; profiles/r03_soak.json holds 4 900 such ticks)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_churn.py"), "120", "200000", "512", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["all_ticks_equal_oracle"] is True
+
