@@ -1897,14 +1897,17 @@ __device__ __forceinline__ void xchg_put(u64* row, size_t v, u64 x, u32 tag) {
 }
 __device__ __forceinline__ u64 xchg_get(const u64* row, size_t v, u32 tag, u64* err) {
     const u64 t0 = wall_clock64();
-    for (;;) {
+    for (int tries = 0;; ++tries) {
         const u64 g0 = RIOGP_SYS_LOAD(row + 2 * v), g1 = RIOGP_SYS_LOAD(row + 2 * v + 1);
         if ((u32)(g0 >> 32) == tag && (u32)(g1 >> 32) == tag) return (g0 & 0xFFFFFFFFull) | (g1 << 32);
         if (wall_clock64() - t0 > kP2PTimeoutTicks) {
             RIOGP_SYS_STORE(err, 1ull);
             return 0;
         }
-        __builtin_amdgcn_s_sleep(2);
+        // back off: tens of thousands of lanes polling uncached memory compete with the very stores they wait for
+        if (tries < 8) __builtin_amdgcn_s_sleep(2);
+        else if (tries < 32) __builtin_amdgcn_s_sleep(8);
+        else __builtin_amdgcn_s_sleep(32);
     }
 }
 
