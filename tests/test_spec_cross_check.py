@@ -1,0 +1,37 @@
+"""The C oracle against an independent plain-Python restatement of DESIGN.md section 2 (tests/spec_tick.py)."""
+import numpy as np
+import pytest
+
+import spec_tick
+
+NONE = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import pyoracle
+    pyoracle.build()
+    return pyoracle
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_c_oracle_equals_the_written_specification(oracle, seed):
+    rng = np.random.default_rng(9000 + seed)
+    n, m = int(rng.integers(0, 400)), int(rng.integers(1, 24))
+    cur = rng.integers(0, m + 2, n).astype(np.uint32)           # m, m+1: invalid node ids
+    cur[rng.random(n) < 0.5] = NONE
+    load = rng.integers(0, int(rng.choice([3, 50, 4000])), n).astype(np.uint32)   # zero loads included
+    aff = rng.integers(0, m + 1, n).astype(np.uint32)
+    aff[rng.random(n) < 0.05] = NONE
+    alive = (rng.random(m) < 0.8).astype(np.uint8)
+    scale = float(rng.choice([0.0, 0.4, 1.0, 3.0]))
+    cap = rng.integers(0, int(load.sum() * scale / m) + 2, m).astype(np.uint64)
+    if seed % 7 == 0:
+        cap[rng.integers(0, m)] = np.uint64(0xFFFFFFFFFFFFFFFF)   # an unbounded node: saturating cumulative capacity
+    rounds = int(rng.integers(1, 4))
+    want, used, st = oracle.tick(cur, load, aff, cap, alive, rounds)
+    got, gused = spec_tick.tick(cur.tolist(), load.tolist(), aff.tolist(), cap.tolist(), alive.tolist(), rounds)
+    assert got == want.tolist()
+    assert gused == used.tolist()
+    placed = [g != NONE for g in got]
+    assert st["kept"] + st["claimed"] + st["spilled"] == sum(placed) and st["unplaced"] == n - sum(placed)
