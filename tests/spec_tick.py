@@ -61,3 +61,85 @@ def tick(cur, load, aff, cap, alive, rounds=2):
             q += l
         rest = left
     return nxt, used
+
+
+def _waterfill(rest, load_of, cap, alive, used, rounds, place):
+    """The water-fill rounds of section 2 step 3 over `rest` (ids in order); place(id, node) records a decision."""
+    m = len(cap)
+    for _ in range(rounds):
+        if not rest:
+            break
+        fr = [max(int(cap[j]) - used[j], 0) if alive[j] else 0 for j in range(m)]
+        order = sorted((j for j in range(m) if fr[j] > 0), key=lambda j: (-fr[j], j))
+        C = [0]
+        for j in order:
+            C.append(min(C[-1] + fr[j], SAT))
+        q, left = 0, []
+        for i in rest:
+            l = load_of(i)
+            ok = False
+            if order and q < C[-1]:
+                k = max(t for t in range(len(order)) if C[t] <= q)
+                if q + l <= C[k + 1]:
+                    place(i, order[k])
+                    used[order[k]] += l
+                    ok = True
+            if not ok:
+                left.append(i)
+            q += l
+        rest = left
+    return rest
+
+
+def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2):
+    """The batched policy as include/rio_gpu_placement.h words it (service.rs:193-298 with capacity): in place on
+    `assign` and `used` (python lists); returns (out_node, out_flag)."""
+    m = len(cap)
+    # a requested object on a node that is not alive: clean_server(that node) — ALL of its objects are un-placed
+    dead = {assign[i] for i in idx if assign[i] != NONE and assign[i] < m and not alive[assign[i]]}
+    if dead:
+        for r in range(len(assign)):
+            if assign[r] in dead:
+                assign[r] = NONE
+        for d in dead:
+            used[d] = 0
+    free = [max(int(cap[j]) - used[j], 0) if alive[j] else 0 for j in range(m)]
+    run = [0] * m
+    decided, how, rest = {}, {}, []
+    for k, (i, r) in enumerate(zip(idx, requester)):
+        if i in decided:
+            continue                           # the first request for an object decides, later ones observe
+        decided[i] = k
+        if assign[i] != NONE:
+            how[k] = "sticky"
+            continue
+        if alive[r]:
+            run[r] += int(load[i])             # strict prefix: an overflow stays an overflow for everyone after it
+            if run[r] <= free[r]:
+                how[k] = ("placed", r)
+                continue
+        rest.append(k)
+    for k, h in how.items():
+        if h != "sticky":
+            used[h[1]] += int(load[idx[k]])
+    spilled = {}
+    _waterfill(rest, lambda k: int(load[idx[k]]), cap, alive, used, rounds, lambda k, node: spilled.__setitem__(k, node))
+    for k, h in how.items():
+        if h != "sticky":
+            assign[idx[k]] = h[1]
+    for k, node in spilled.items():
+        assign[idx[k]] = node
+    out_node, out_flag = [], []
+    for k, (i, r) in enumerate(zip(idx, requester)):
+        nd = assign[i]
+        if decided[i] == k and how.get(k, None) not in (None, "sticky"):
+            fl = 2                             # PLACED: first touch on the requester
+        elif decided[i] == k and k in spilled:
+            fl = 3                             # SPILLED
+        elif nd == NONE:
+            fl = 4                             # UNPLACED
+        else:
+            fl = 0 if nd == r else 1           # LOCAL / REDIRECT
+        out_node.append(nd)
+        out_flag.append(fl)
+    return out_node, out_flag

@@ -35,3 +35,33 @@ def test_c_oracle_equals_the_written_specification(oracle, seed):
     assert gused == used.tolist()
     placed = [g != NONE for g in got]
     assert st["kept"] + st["claimed"] + st["spilled"] == sum(placed) and st["unplaced"] == n - sum(placed)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_c_oracle_place_pending_equals_the_written_contract(oracle, seed):
+    rng = np.random.default_rng(7000 + seed)
+    n, m = int(rng.integers(1, 300)), int(rng.integers(1, 16))
+    load = rng.integers(0, int(rng.choice([3, 60, 3000])), n).astype(np.uint32)
+    alive = (rng.random(m) < 0.75).astype(np.uint8)
+    if not alive.any():
+        alive[0] = 1
+    assign = rng.integers(0, m, n).astype(np.uint32)            # some rows sit on dead nodes
+    assign[rng.random(n) < 0.5] = NONE
+    scale = float(rng.choice([0.3, 1.0, 2.5]))
+    cap = rng.integers(0, int(load.sum() * scale / m) + 2, m).astype(np.uint64)
+    if seed % 5 == 0:
+        cap[:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    used = np.zeros(m, np.uint64)
+    for i in range(n):
+        if assign[i] != NONE:
+            used[assign[i]] += np.uint64(load[i])
+    q = int(rng.integers(1, 120))
+    idx = rng.integers(0, n, q).astype(np.uint32)               # duplicates on purpose
+    req = rng.integers(0, m, q).astype(np.uint32)               # requesters may be inactive members
+    rounds = int(rng.integers(1, 4))
+    a2, u2 = assign.tolist(), [int(x) for x in used]
+    snode, sflag = spec_tick.place_pending(a2, load.tolist(), cap.tolist(), alive.tolist(), u2, idx.tolist(), req.tolist(), rounds)
+    a1, u1 = assign.copy(), used.copy()
+    onode, oflag = oracle.place_pending(a1, load, cap, alive, u1, idx, req, rounds)
+    assert onode.tolist() == snode and oflag.tolist() == sflag
+    assert a1.tolist() == a2 and [int(x) for x in u1] == u2
