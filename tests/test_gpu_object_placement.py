@@ -236,5 +236,5 @@ def test_concurrent_single_object_calls_share_round_trips(gp, tmp_path):
     for call in ("lookup", "get_or_create_placement"):
         one = [x for x in rows if x["call"] == call and x["threads"] == 1][0]["calls_per_s"]
         four = [x for x in rows if x["call"] == call and x["threads"] == 4][0]["calls_per_s"]
-        assert four > 0.9 * one, (call, one, four)
+        assert four > 0.5 * one, (call, one, four)   # shares round trips (measured 1.6x); the bound only guards against a convoy
 
