@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", help="c3 (headline) | c3w | c2 | c4shard")
+    ap.add_argument("--workload", default="c3", help="c3 (headline) | c3w | c2 | c4shard | c5 (config 5: churn ticks, N=1 only)")
     ap.add_argument("--objects", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="p2p", choices=("p2p", "native", "torch"),
@@ -90,6 +90,44 @@ def cpu_baseline(cfg, sample):
     }
 
 
+def bench_churn(a, g, cfg, saved_stdout):
+    """BASELINE.json config 5: the config-3 table, warm; every step = one liveness push (10 % of the nodes down, the
+    previous casualties back) + one committed whole-table tick (evict + re-place through the fix-up path)."""
+    import synth
+    n, m = cfg["n"], cfg["m"]
+    g.set_assign(synth.warm_assign(n, m))
+    g.tick()
+    masks = [synth.churn_mask(m, 2 + k) for k in range(a.warmup + a.steps)]
+    for k in range(a.warmup):
+        g.set_alive_all(masks[k])
+        g.tick()
+    g.sync()
+    moved = slow = 0
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        g.set_alive_all(masks[a.warmup + k])
+        st = g.tick()
+        moved += st["claimed"] + st["spilled"]
+        slow += st["slow_path"]
+    dt = time.perf_counter() - t0
+    out = {
+        "metric": "placement decisions/sec, 10M objects x 1 024 nodes with 10 % node-failure churn per tick", "value": n * a.steps / dt,
+        "unit": "decisions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "config 5: %d objects x %d nodes, Zipf(1.1) load, cap 1.25x, warm; per step 10 %% of the nodes "
+                               "flip and one committed tick evicts and re-places their objects" % (n, m),
+                   "step": "rio_gp_set_alive_all + rio_gp_tick (synchronous: the host reads every tick's counters)",
+                   "slow_path_steps": slow},
+        "objects_moved_per_s": moved / dt, "stats_last_step": st,
+        "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_DECISION * n * a.steps / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ALGO_BYTES_PER_DECISION * n * a.steps / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "whole tick (8 dependent launches + host turn-around; latency-bound, DESIGN.md section 5)"},
+    }
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     # stdout carries exactly ONE line, the JSON: libraries that write to C stdout (RCCL prints a version banner from
@@ -122,7 +160,9 @@ def main():
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     n_over = a.objects or None
-    per_rank = synth.config(a.workload, n_override=n_over, start=0)  # shapes only
+    if a.workload == "c5" and world > 1:
+        raise SystemExit("--workload c5 is a single-GPU line (the row-sharded churn tick is covered by tools/soak_sharded.py)")
+    per_rank = synth.config("c3" if a.workload == "c5" else a.workload, n_override=n_over, start=0)  # shapes only
     n_local = per_rank["n"]
     # weak scaling: every rank owns n_local consecutive rows of ONE table of world*n_local rows (rank order =
     # index order); capacities are set from the GLOBAL load, exactly as the unsharded config would
@@ -138,6 +178,8 @@ def main():
     g.set_objects(n, cfg["load"], cfg["aff"])
     if a.workload == "c3w":
         g.set_assign(cfg["cur"])
+    if a.workload == "c5":
+        return bench_churn(a, g, cfg, saved_stdout)
 
     def barrier():
         if dist is not None:

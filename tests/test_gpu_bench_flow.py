@@ -61,3 +61,13 @@ def test_bench_eight_ranks_on_one_gpu():
     st = d["stats_last_step"]
     assert st["n_objects"] == 8_000_000 and st["claimed"] == 8_000_000 and d["config"]["slow_path_steps"] == 0
 
+
+def test_bench_config5_churn_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--steps", "12", "--warmup", "3",
+                        "--objects", "1000000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 1e8 and d["objects_moved_per_s"] > 0
+    st = d["stats_last_step"]
+    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == 1000000 and st["evicted"] > 0
+
