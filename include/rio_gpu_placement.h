@@ -50,6 +50,18 @@ extern "C" {
 #define RIO_GP_MAX_OBJECTS 0x7FFFF000ull
 /* capacity value meaning "unbounded" (the reference has no capacity at all) */
 #define RIO_GP_CAP_INF 0xFFFFFFFFFFFFFFFFull
+/* Affinity value of a row that is NOT an object: the dense twin of "no entry in the map" (a key that was never
+ * inserted, or was removed: local.rs:36-37,60-68, or dropped by clean_server: local.rs:51-58).  A whole-table solve
+ * keeps such a row where it is if it happens to be placed on a live node and never places it otherwise; it is not
+ * counted in rio_gp_stats.n_objects.  Any other affinity >= the node count (RIO_GP_NONE included) means "an object
+ * without a preferred node": it goes to the water-fill. */
+#define RIO_GP_AFF_INACTIVE 0xFFFFFFFEu
+/* rio_gp_cfg.flags */
+/* Row lifecycle (what the string layer uses): rows start as non-objects (affinity RIO_GP_AFF_INACTIVE) and the CRUD
+ * calls maintain that column — update(i, node) and the first place_pending request of a pending row make row i an
+ * object (affinity = the node / the requester), update(i, NONE), remove and clean_server make it a non-object again.
+ * Without the flag the affinity column is only ever written by rio_gp_set_objects / rio_gp_set_object_attrs. */
+#define RIO_GP_CFG_ROW_LIFECYCLE 1u
 
 /* return codes */
 #define RIO_GP_OK 0
@@ -73,13 +85,13 @@ typedef struct rio_gp_cfg {
     uint64_t max_objects;  /* row capacity of the object table (<= RIO_GP_MAX_OBJECTS) */
     uint32_t max_nodes;    /* row capacity of the node table (<= RIO_GP_MAX_NODES) */
     uint32_t spill_rounds; /* water-fill rounds for objects their affinity node rejects; 0 -> default 2 */
-    uint32_t flags;        /* reserved, 0 */
+    uint32_t flags;        /* RIO_GP_CFG_* bits, 0 = none */
     uint32_t reserved;
 } rio_gp_cfg;
 
 /* Counters of one whole-table solve (rio_gp_tick / rio_gp_solve). */
 typedef struct rio_gp_stats {
-    uint64_t n_objects;
+    uint64_t n_objects; /* rows that are objects = kept + claimed + spilled + unplaced */
     uint64_t kept;      /* sticky: placed on a live node (service.rs:241-242) */
     uint64_t evicted;   /* were placed on a dead node (clean_server, service.rs:227-237) */
     uint64_t claimed;   /* pending, admitted on their affinity node (first touch, service.rs:244-252) */
@@ -121,7 +133,8 @@ int rio_gp_get_nodes(rio_gp_t* h, uint32_t m, uint64_t* cap, uint8_t* alive, uin
 /* ---- object table ---------------------------------------------------------------------- */
 
 /* Define rows 0..n-1: per-object load and affinity (= the requesting server `self.address`
- * of service.rs:244).  All rows start unplaced.  load == NULL -> 1; aff == NULL -> RIO_GP_NONE. */
+ * of service.rs:244).  All rows start unplaced.  load == NULL -> 1; aff == NULL -> RIO_GP_NONE
+ * (RIO_GP_AFF_INACTIVE under RIO_GP_CFG_ROW_LIFECYCLE). */
 int rio_gp_set_objects(rio_gp_t* h, uint64_t n, const uint32_t* load, const uint32_t* aff);
 int rio_gp_set_objects_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_load, const uint32_t* d_aff);
 /* Bulk-load / dump the whole assignment column (warm start, snapshot; the on-disk twin is
@@ -129,9 +142,15 @@ int rio_gp_set_objects_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_load, cons
 int rio_gp_set_assign(rio_gp_t* h, uint64_t n, const uint32_t* assign);
 int rio_gp_set_assign_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_assign);
 int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out_assign);
+/* Read the load and/or affinity columns back (either may be NULL). */
+int rio_gp_get_objects(rio_gp_t* h, uint64_t n, uint32_t* out_load, uint32_t* out_aff);
 /* Change load and/or affinity of individual rows (either array may be NULL = leave as is). */
 int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* load,
                             const uint32_t* aff);
+/* Change how many rows take part (0 <= n <= max_objects) WITHOUT touching their contents: rows >= n are neither
+ * solved nor valid indices until n grows again.  A host that hands out rows one by one (the string layer's interning)
+ * keeps n at its high-water mark so that a solve streams the rows in use, not the table's capacity. */
+int rio_gp_set_num_objects(rio_gp_t* h, uint64_t n);
 /* Number of placed rows (HashMap::len of local.rs:12): one 4 B/row pass. */
 int rio_gp_count_placed(rio_gp_t* h, uint64_t* out);
 /* Device pointer of the live assignment column (valid until the next tick/commit). */
@@ -174,6 +193,11 @@ int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evi
  * be NULL. */
 int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* requester,
                          uint32_t* out_node, uint32_t* out_flag);
+/* The same with request and result arrays already resident in HBM (device pointers; d_out_flag may be NULL).  The
+ * entries are checked on the device BEFORE anything is changed: an out-of-range index or requester fails the whole call
+ * with RIO_GP_EINVAL and leaves the table as it was. */
+int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_requester,
+                             uint32_t* d_out_node, uint32_t* d_out_flag);
 
 /* Whole-table solve: every row gets a decision in one call (the eager form of the lazy
  * per-request path of service.rs:193-254 + the clean_server stream of SURVEY §3.2):
@@ -247,7 +271,7 @@ int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats);
  * control channel, every rank maps its peers' windows (rio_gp_shard_p2p_connect; ends with a handshake and fails
  * with RIO_GP_EUPSTREAM if a peer's store does not become visible within 3 s — fall back to RCCL then).  After that
  * rio_gp_shard_solve_async is two launches on one stream, no host involvement: the scan, then one kernel in which every
- * workgroup stores its four nodes' sums straight into the peers' HBM as data-tagged 8-byte words, polls the same words of
+ * workgroup stores its eight nodes' sums straight into the peers' HBM as data-tagged 8-byte words, polls the same words of
  * every rank and resolves its nodes (no flag, no collective).  rio_gp_shard_exchange (fix-up records) stores the raw
  * record and a sequence flag; the consuming kernel waits on the flags.  All ranks must call export/connect/solve/exchange
  * collectively and in the same order. */
@@ -278,21 +302,7 @@ int rio_gp_timer_end(rio_gp_t* h, float* ms);
  * resolve_ms = k_resolve.  Does not publish; fails with RIO_GP_EINVAL if the solve needs the
  * cut/spill fix-up (use rio_gp_solve then). */
 int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms);
-/* A/B and test knob: packed fix-up (fix-up passes over the pending rows only) 0 = adaptive (default: used when the
- * previous solve left <= 25 % of the rows pending), 1 = always, 2 = never.  Results are identical in every mode. */
-int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
-/* A/B and test knob for the cut / water-fill fix-up.  fused: 1 (default) = k_cutblk + k_cut_fused, packed decisions
- * written through by the water-fill | 0 = the unfused launch chain.  speculate: 0 (default) = enqueue the fix-up behind
- * k_resolve without waiting for the verdict when the previous solve needed it | 1 = always | 2 = never.  Results are
- * identical in every combination. */
-int rio_gp_debug_set_fixup(rio_gp_t* h, int fused, int speculate);
-/* A/B knob for tools/sweep_scan.py: tiles per wave-iteration of k_scan (1 | 2 | 4); process-wide. */
-void rio_gp_debug_set_scan_tpi(int tpi);
-/* measurement aid: read (out2048 != NULL: 256 workgroups x 8 words) and switch the phase trace of k_cut_fused */
-int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048);
-/* Measurement aid: pure streaming kernels with k_scan's traffic mix (3 columns in, 1 out) over the handle's
- * own columns; mode 0 grid-stride | 1 block-tiled | 2 wave-contiguous | 3 read-only | 4 1:1 copy.  ms per launch. */
-int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms);
+/* A/B knobs, phase traces and the streaming probes are not part of the boundary: rio_gpu_placement_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -199,6 +199,7 @@ int orc_tick(const uint32_t* cur, const uint32_t* load, const uint32_t* aff, uin
     for (uint64_t i = 0; i < n_obj; ++i) {
         if (kept[i]) continue;
         uint32_t a = aff[i];
+        if (a == ORC_AFF_INACTIVE) { --s.n_objects; continue; } /* not an object (row lifecycle): never placed */
         if (a != ORC_NONE && a < m && alive[a]) {
             run[a] += load[i];
             if (run[a] <= fre[a]) {

@@ -25,6 +25,9 @@ extern "C" {
 
 #define ORC_NONE 0xFFFFFFFFu
 #define ORC_CAP_INF 0xFFFFFFFFFFFFFFFFull
+/* affinity value of a row that is not an object (RIO_GP_AFF_INACTIVE): a solve keeps it where it is if it is
+ * placed on a live node, and never places it otherwise; it is not counted in n_objects */
+#define ORC_AFF_INACTIVE 0xFFFFFFFEu
 
 /* identical layout to rio_gp_stats (include/rio_gpu_placement.h) */
 typedef struct orc_stats {

@@ -7,12 +7,24 @@
 // Mirrors (relative to /root/reference):
 //   LocalObjectPlacement              rio-rs/src/object_placement/local.rs:12-68
 //   Service::get_or_create_placement  rio-rs/src/service.rs:193-254
+//
+// Which rows are objects is a DEVICE fact too (RIO_GP_CFG_ROW_LIFECYCLE): a key that was never inserted, was removed
+// (local.rs:36-37,60-68) or was dropped by clean_server (local.rs:51-58) has no entry in the reference's map; here its
+// row carries the affinity RIO_GP_AFF_INACTIVE, which keeps it out of every whole-table solve (rio_op_tick), and the
+// table's row count on the device is the high-water mark of the rows handed out, not max_objects.  Keys of such rows
+// are reclaimed lazily, when the table runs full (reclaim()).
+//
+// Locks (always taken in this order): mu — compound operations and every device call sequence; imu — the interning
+// tables; qmu — the combiner's queue.  What the device knows of the host tables (node table, row count) is brought
+// up to date under mu by sync_device() BEFORE any device call that may carry a new id, by whichever thread issues
+// that call: an id can therefore never reach the device ahead of the table entry it refers to, whoever interned it.
 #include <sched.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -22,12 +34,22 @@
 
 namespace {
 
+constexpr int kFull = -1000;  // internal: the object table has no free row (reclaim, then retry)
+
+// Text of the calling thread's last failed call (rio_op_last_error): a failure is reported to the thread that made
+// the call, so its text is that thread's too — no lock, no race with other callers' failures.
+thread_local std::string t_err;
+// rio_op_snapshot's arrays: copies, owned by the calling thread until its next snapshot
+thread_local std::vector<std::string> t_snap_store;
+thread_local std::vector<const char*> t_snap_ty, t_snap_id, t_snap_addr;
+
 // One single-object call waiting for its device round trip (see run_combined).
 struct Req {
     int kind;                 // 0 lookup | 1 get_or_create_placement | 2 update | 3 remove
     uint32_t row, req;        // dense ids (req: requester node for kind 1, new node or NONE for kind 2)
     uint32_t node = RIO_GP_NONE, flag = 0;
     int rc = RIO_GP_OK;
+    std::string err;          // text of ITS failure (a request that fails does not fail its batch-mates)
     std::atomic<int> done{0};  // set LAST by the serving thread: the request lives on its caller's stack
 };
 
@@ -40,18 +62,31 @@ struct State {
     std::vector<Req*> queue;
     bool serving = false;
     int sleepers = 0;                  // waiters that gave up spinning and sleep on qcv
-    std::string err;
     rio_gp_t* gp = nullptr;
     uint64_t max_objects = 0;
     uint32_t max_nodes = 0;
+    // --- under imu ---
     std::unordered_map<std::string, uint32_t> rows;   // "{type}.{id}" -> dense row (local.rs:26-29)
-    std::vector<std::pair<std::string, std::string>> row_key;  // row -> the (struct_name, object_id) it was first interned as
-    std::vector<const char*> snap_ty, snap_id, snap_addr;      // last rio_op_snapshot (pointers into row_key / node_addr)
+    std::deque<std::pair<std::string, std::string>> row_key;  // row -> the (struct_name, object_id) it is interned as
+    std::vector<uint8_t> row_live;                    // row currently has a key
+    std::vector<uint32_t> free_rows;                  // reclaimed rows, ready for new keys
+    uint64_t hi_rows = 0;                             // rows ever handed out: every row id is < hi_rows
     std::unordered_map<std::string, uint32_t> nodes;  // address -> node id
-    std::vector<std::string> node_addr;
+    std::deque<std::string> node_addr;                // deque: element addresses are stable (rio_op_node_address)
     std::vector<uint8_t> node_alive, node_malformed;
     std::vector<uint64_t> node_cap;
     uint32_t n_malformed = 0;
+    uint64_t node_version = 1;                        // bumped on every change of the node table
+    uint64_t shape_version = 1;                       // bumped when a node is added or a capacity changes (not on liveness flips)
+    bool reclaiming = false;                          // single-object calls wait (rcv) while keys are being reclaimed
+    std::condition_variable rcv;
+    // --- under mu ---
+    uint64_t pushed_version = 0;                      // node_version the device holds
+    uint64_t pushed_shape = 0;
+    uint32_t pushed_nodes = 0;
+    uint64_t pushed_rows = 0;                         // row count the device holds (rio_gp_set_num_objects)
+    // ---
+    std::atomic<int> inflight{0};                     // single-object calls between their intern and their return
     std::atomic<int> refs{1};
 };
 
@@ -68,23 +103,56 @@ bool malformed(const std::string& a) {
     return c == std::string::npos || c == 0 || c + 1 >= a.size();
 }
 
-int fail(State* s, int rc, const std::string& m) {
-    s->err = m;
+int fail(int rc, const std::string& m) {
+    t_err = m;
     return rc;
 }
-int gp_fail(State* s, int rc) {
-    s->err = rio_gp_last_error(s->gp);
+int gp_fail(State* s, int rc) {  // only directly after the failing rio_gp_* call, under mu (nobody else calls the handle)
+    const char* e = rio_gp_last_error(s->gp);
+    t_err = e ? e : "";
     return rc;
 }
 
-int push_nodes(State* s) {
-    const uint32_t m = (uint32_t)s->node_addr.size();
-    int rc = rio_gp_set_nodes(s->gp, m, s->node_cap.data(), s->node_alive.data());
-    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+// Bring the device's copy of the host tables up to date: the node table (any new address, liveness or capacity change)
+// and the row count.  Requires mu; imu is taken here unless the caller already holds it.
+int sync_device(State* s, bool imu_held) {
+    std::vector<uint64_t> cap;
+    std::vector<uint8_t> alive;
+    uint64_t version, shape, nrows;
+    uint32_t m;
+    {
+        std::unique_lock<std::mutex> li(s->imu, std::defer_lock);
+        if (!imu_held) li.lock();
+        version = s->node_version;
+        shape = s->shape_version;
+        m = (uint32_t)s->node_addr.size();
+        nrows = s->hi_rows;
+        if (version != s->pushed_version) {
+            cap = s->node_cap;
+            alive = s->node_alive;
+        }
+    }
+    if (version != s->pushed_version) {
+        // a liveness flip alone is one small asynchronous kernel (MembershipStorage::set_is_active pushed, not polled);
+        // a new address or a capacity change replaces the node table
+        const int rc = (shape == s->pushed_shape && m == s->pushed_nodes && m > 0)
+                           ? rio_gp_set_alive_all(s->gp, m, alive.data())
+                           : rio_gp_set_nodes(s->gp, m, cap.data(), alive.data());
+        if (rc) return gp_fail(s, rc);
+        s->pushed_version = version;
+        s->pushed_shape = shape;
+        s->pushed_nodes = m;
+    }
+    if (nrows != s->pushed_rows) {
+        const int rc = rio_gp_set_num_objects(s->gp, nrows);
+        if (rc) return gp_fail(s, rc);
+        s->pushed_rows = nrows;
+    }
+    return RIO_GP_OK;
 }
 
-// find or create the node id of an address; *created tells the caller to push the node table
-int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, bool* created) {
+// find or create the node id of an address (imu held)
+int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, bool mark_up = false) {
     auto it = s->nodes.find(addr);
     if (it != s->nodes.end()) {
         *out = it->second;
@@ -94,20 +162,23 @@ int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, b
         *out = RIO_GP_NONE;
         return RIO_GP_OK;
     }
-    if (s->node_addr.size() >= s->max_nodes) return fail(s, RIO_GP_EINVAL, "node table full (max_nodes)");
+    if (s->node_addr.size() >= s->max_nodes) return fail(RIO_GP_EINVAL, "node table full (max_nodes)");
     const uint32_t id = (uint32_t)s->node_addr.size();
     s->nodes.emplace(addr, id);
     s->node_addr.push_back(addr);
-    s->node_alive.push_back(0);  // not a member until rio_op_set_member says so (is_active == false)
+    // not a member until rio_op_set_member says so (is_active == false) — except a server that answers requests itself
+    s->node_alive.push_back(mark_up ? 1 : 0);
     s->node_cap.push_back(RIO_GP_CAP_INF);
     const bool bad = malformed(addr);
     s->node_malformed.push_back(bad ? 1 : 0);
     s->n_malformed += bad;
+    ++s->node_version;
+    ++s->shape_version;
     *out = id;
-    if (created) *created = true;
     return RIO_GP_OK;
 }
 
+// find or create the row of a key (imu held).  kFull: no free row — the caller releases its locks, runs reclaim() and retries.
 int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* out) {
     const std::string key = key_of(ty, id);
     auto it = s->rows.find(key);
@@ -119,11 +190,68 @@ int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* 
         *out = RIO_GP_NONE;
         return RIO_GP_OK;
     }
-    if (s->rows.size() >= s->max_objects) return fail(s, RIO_GP_EINVAL, "object table full (max_objects)");
-    const uint32_t row = (uint32_t)s->rows.size();
+    uint32_t row;
+    if (!s->free_rows.empty()) {
+        row = s->free_rows.back();
+        s->free_rows.pop_back();
+    } else if (s->hi_rows < s->max_objects) {
+        row = (uint32_t)s->hi_rows++;
+        s->row_key.emplace_back();
+        s->row_live.push_back(0);
+    } else {
+        return kFull;
+    }
     s->rows.emplace(key, row);
-    s->row_key.emplace_back(ty ? ty : "", id ? id : "");
+    s->row_key[row] = std::make_pair(std::string(ty ? ty : ""), std::string(id ? id : ""));
+    s->row_live[row] = 1;
     *out = row;
+    return RIO_GP_OK;
+}
+
+// The table is full: give the rows of keys that are no longer objects (unplaced AND affinity RIO_GP_AFF_INACTIVE on the
+// device: removed, deleted, dropped by clean_server and not touched since) back to the free list and forget their keys —
+// what HashMap::remove / retain do at once in the reference (local.rs:36-37,51-68).  Row ids live in single-object calls
+// between their intern and their return, so those are drained first and held off meanwhile; compound calls are excluded
+// by mu.  EINVAL when every row belongs to a live object.
+int reclaim(State* s) {
+    {
+        std::unique_lock<std::mutex> li(s->imu);
+        while (s->reclaiming) s->rcv.wait(li);  // someone else is at it: wait, then let the caller retry
+        if (!s->free_rows.empty() || s->hi_rows < s->max_objects) return RIO_GP_OK;
+        s->reclaiming = true;
+    }
+    while (s->inflight.load(std::memory_order_acquire) != 0) sched_yield();
+    int rc = RIO_GP_OK;
+    size_t got = 0;
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        std::lock_guard<std::mutex> gi(s->imu);
+        const uint64_t n = s->hi_rows;
+        std::vector<uint32_t> assign(n ? n : 1), aff(n ? n : 1), gone, ones;
+        if ((rc = sync_device(s, true)) == RIO_GP_OK) {
+            if ((rc = rio_gp_get_assign(s->gp, n, assign.data())) || (rc = rio_gp_get_objects(s->gp, n, nullptr, aff.data())))
+                rc = gp_fail(s, rc);
+        }
+        if (rc == RIO_GP_OK) {
+            for (uint64_t r = 0; r < n; ++r)
+                if (s->row_live[r] && assign[r] == RIO_GP_NONE && aff[r] == RIO_GP_AFF_INACTIVE) {
+                    s->rows.erase(key_of(s->row_key[r].first.c_str(), s->row_key[r].second.c_str()));
+                    s->row_key[r] = std::pair<std::string, std::string>();
+                    s->row_live[r] = 0;
+                    s->free_rows.push_back((uint32_t)r);
+                    gone.push_back((uint32_t)r);
+                }
+            got = gone.size();
+            if (got) {  // a recycled row starts like a fresh one: load 1
+                ones.assign(got, 1u);
+                if ((rc = rio_gp_set_object_attrs(s->gp, got, gone.data(), ones.data(), nullptr))) rc = gp_fail(s, rc);
+            }
+        }
+        s->reclaiming = false;
+    }
+    s->rcv.notify_all();
+    if (rc) return rc;
+    if (!got) return fail(RIO_GP_EINVAL, "object table full (max_objects live objects)");
     return RIO_GP_OK;
 }
 
@@ -134,7 +262,7 @@ void copy_out(const std::string& v, char* out, size_t cap) {
     out[n] = 0;
 }
 
-// the whole policy for a batch of (row, requester) pairs; rows/reqs are dense ids
+// the whole policy for a batch of (row, requester) pairs; rows/reqs are dense ids (mu held, device tables in sync)
 int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& reqs, uint32_t* out_node,
                  uint32_t* out_flag, bool tables_locked = true) {
     const uint64_t n = rows.size();
@@ -170,8 +298,31 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
 // batch keep their arrival order (the first request for an object decides, as in rio_gp_place_pending).
 constexpr size_t kCombine = 256;
 
+// one batched device call for the requests `who` of one kind; t_err holds the text when it fails
+int run_kind(State* s, int kind, std::vector<uint32_t>& rows, std::vector<uint32_t>& reqs, uint32_t* res, uint32_t* fl) {
+    int rc;
+    if (kind == 0) {
+        if ((rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res))) gp_fail(s, rc);
+    } else if (kind == 1) {
+        rc = policy_batch(s, rows, reqs, res, fl, false);
+    } else if (kind == 2) {
+        if ((rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), reqs.data()))) gp_fail(s, rc);
+    } else {
+        if ((rc = rio_gp_remove_batch(s->gp, rows.size(), rows.data()))) gp_fail(s, rc);
+    }
+    return rc;
+}
+
 void serve(State* s, std::vector<Req*>& batch) {
     std::lock_guard<std::mutex> g(s->mu);  // NOT imu: callers keep interning and queueing during the device round trip
+    // every id in this batch was interned before its request was queued: whatever the device does not know yet of the
+    // node table or the row count goes there now, ahead of the requests (the serving thread may not be the one that
+    // interned the new address)
+    const int src = sync_device(s, false);
+    if (src) {
+        for (Req* r : batch) { r->rc = src; r->err = t_err; }
+        return;
+    }
     std::vector<uint32_t> rows, reqs, res, fl;
     std::vector<Req*> who;
     // writes first, in arrival order (sequential last-writer-wins, local.rs:22-40), then the reads and the policy calls:
@@ -183,20 +334,24 @@ void serve(State* s, std::vector<Req*>& batch) {
         if (who.empty()) continue;
         res.assign(who.size(), RIO_GP_NONE);
         fl.assign(who.size(), 0);
-        int rc;
-        if (kind == 0) {
-            rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res.data());
-            if (rc) gp_fail(s, rc);
-        } else if (kind == 1) {
-            rc = policy_batch(s, rows, reqs, res.data(), fl.data(), false);
-        } else if (kind == 2) {
-            rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), reqs.data());
-            if (rc) gp_fail(s, rc);
-        } else {
-            rc = rio_gp_remove_batch(s->gp, rows.size(), rows.data());
-            if (rc) gp_fail(s, rc);
+        int rc = run_kind(s, kind, rows, reqs, res.data(), fl.data());
+        if (rc == RIO_GP_OK || who.size() == 1) {
+            for (size_t k = 0; k < who.size(); ++k) {
+                who[k]->rc = rc; who[k]->node = res[k]; who[k]->flag = fl[k];
+                if (rc) who[k]->err = t_err;
+            }
+            continue;
         }
-        for (size_t k = 0; k < who.size(); ++k) { who[k]->rc = rc; who[k]->node = res[k]; who[k]->flag = fl[k]; }
+        // The batched call was refused (the dense layer validates before it mutates): run the requests one by one, in
+        // order, so that only the offender sees the error — its batch-mates are other callers' requests.
+        std::vector<uint32_t> r1(1), q1(1);
+        for (size_t k = 0; k < who.size(); ++k) {
+            r1[0] = rows[k]; q1[0] = reqs[k];
+            uint32_t nd = RIO_GP_NONE, f = 0;
+            rc = run_kind(s, kind, r1, q1, &nd, &f);
+            who[k]->rc = rc; who[k]->node = nd; who[k]->flag = f;
+            if (rc) who[k]->err = t_err;
+        }
     }
 }
 
@@ -238,8 +393,6 @@ int run_combined(State* s, Req* mine) {
         s->queue.erase(s->queue.begin(), s->queue.begin() + take);
         lk.unlock();
         serve(s, batch);
-        const int my_rc = mine->rc;  // `mine` may be in this batch: read before anything is released
-        (void)my_rc;
         for (Req* r : batch)
             if (r != mine) r->done.store(1, std::memory_order_release);  // last touch of *r
         last_batch = batch.size();
@@ -248,6 +401,51 @@ int run_combined(State* s, Req* mine) {
     }
     s->serving = false;
     return mine->rc;
+}
+
+// A single-object call: intern under imu (held off while keys are being reclaimed), count as in flight while its row id
+// is on its way to the device (reclaim() waits for that count to drain before it forgets any key).
+// `intern` fills the request and returns RIO_GP_OK, kFull, an error, or 1 = "nothing to do" (e.g. lookup of an unknown key).
+template <typename F>
+int single_call(State* s, Req* r, F intern) {
+    for (int attempt = 0;; ++attempt) {
+        int rc;
+        {
+            std::unique_lock<std::mutex> li(s->imu);
+            while (s->reclaiming) s->rcv.wait(li);
+            rc = intern();
+            if (rc == RIO_GP_OK) s->inflight.fetch_add(1, std::memory_order_acq_rel);
+        }
+        if (rc == kFull && attempt == 0) {
+            if ((rc = reclaim(s))) return rc;
+            continue;
+        }
+        if (rc == kFull) return fail(RIO_GP_EINVAL, "object table full (max_objects live objects)");
+        if (rc != RIO_GP_OK) return rc;
+        rc = run_combined(s, r);
+        s->inflight.fetch_sub(1, std::memory_order_acq_rel);  // what the caller still holds are node ids: never reclaimed
+        if (rc) t_err = r->err;
+        return rc;
+    }
+}
+
+// compound (mu + imu for the whole call) operations: run `body`, reclaim and retry once when the table is full
+template <typename F>
+int compound_call(State* s, F body) {
+    for (int attempt = 0;; ++attempt) {
+        int rc;
+        {
+            std::lock_guard<std::mutex> g(s->mu);
+            std::lock_guard<std::mutex> gi(s->imu);
+            rc = body();
+        }
+        if (rc == kFull && attempt == 0) {
+            if ((rc = reclaim(s))) return rc;
+            continue;
+        }
+        if (rc == kFull) return fail(RIO_GP_EINVAL, "object table full (max_objects live objects)");
+        return rc;
+    }
 }
 
 }  // namespace
@@ -261,7 +459,7 @@ extern "C" {
 int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     if (out) *out = nullptr;
     if (!cfg || !out || cfg->struct_size != sizeof(rio_op_cfg) || cfg->max_objects == 0 || cfg->max_nodes == 0)
-        return RIO_GP_EINVAL;
+        return fail(RIO_GP_EINVAL, "rio_op_create: bad cfg");
     rio_gp_cfg g;
     memset(&g, 0, sizeof g);
     g.struct_size = sizeof g;
@@ -269,11 +467,18 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     g.max_objects = cfg->max_objects;
     g.max_nodes = cfg->max_nodes;
     g.spill_rounds = cfg->spill_rounds;
+    g.flags = RIO_GP_CFG_ROW_LIFECYCLE;
     rio_gp_t* gp = nullptr;
     int rc = rio_gp_create(&g, &gp);
-    if (rc) return rc;  // text in rio_gp_last_error(NULL)
-    // every potential row exists from the start, unplaced, load 1, no affinity
-    if ((rc = rio_gp_set_objects(gp, cfg->max_objects, nullptr, nullptr)) || (rc = rio_gp_set_nodes(gp, 0, nullptr, nullptr))) {
+    if (rc) {
+        const char* e = rio_gp_last_error(nullptr);
+        return fail(rc, e ? e : "");
+    }
+    // every potential row is initialised (unplaced, load 1, not an object); none takes part until it is handed out
+    if ((rc = rio_gp_set_objects(gp, cfg->max_objects, nullptr, nullptr)) || (rc = rio_gp_set_num_objects(gp, 0)) ||
+        (rc = rio_gp_set_nodes(gp, 0, nullptr, nullptr))) {
+        const char* e = rio_gp_last_error(gp);
+        t_err = e ? e : "";
         rio_gp_destroy(gp);
         return rc;
     }
@@ -281,6 +486,8 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     s->gp = gp;
     s->max_objects = cfg->max_objects;
     s->max_nodes = cfg->max_nodes;
+    s->pushed_version = s->node_version;  // the empty node table is on the device
+    s->pushed_shape = s->shape_version;
     *out = new rio_op{s};
     return RIO_GP_OK;
 }
@@ -303,14 +510,14 @@ void rio_op_release(rio_op_t* p) {
 
 int rio_op_prepare(rio_op_t* p) { return p ? RIO_GP_OK : RIO_GP_EINVAL; }
 
-const char* rio_op_last_error(rio_op_t* p) { return p ? p->s->err.c_str() : rio_gp_last_error(nullptr); }
+const char* rio_op_last_error(rio_op_t*) { return t_err.c_str(); }
 
 rio_gp_t* rio_op_dense(rio_op_t* p) { return p ? p->s->gp : nullptr; }
 
 const char* rio_op_node_address(rio_op_t* p, uint32_t node_id) {
     if (!p) return nullptr;
-    std::lock_guard<std::mutex> g(p->s->mu);
     std::lock_guard<std::mutex> gi(p->s->imu);
+    // node_addr is a deque of strings that are never modified: the pointer stays valid for the life of the provider
     return node_id < p->s->node_addr.size() ? p->s->node_addr[node_id].c_str() : nullptr;
 }
 
@@ -318,30 +525,29 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
                         const char* const* addrs) {
     if (!p || (n && (!tys || !ids || !addrs))) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
-    std::vector<uint32_t> rows, nodes;
-    rows.reserve(n);
-    nodes.reserve(n);
-    bool created = false;
-    for (uint64_t k = 0; k < n; ++k) {
-        uint32_t row = RIO_GP_NONE, node = RIO_GP_NONE;
-        int rc;
-        if (addrs[k]) {  // Some(address): entry(key) = address
-            if ((rc = intern_row(s, tys[k], ids[k], true, &row))) return rc;
-            if ((rc = intern_node(s, addrs[k], true, &node, &created))) return rc;
-        } else {         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
-            if ((rc = intern_row(s, tys[k], ids[k], false, &row))) return rc;
-            if (row == RIO_GP_NONE) continue;
+    return compound_call(s, [&]() -> int {
+        std::vector<uint32_t> rows, nodes;
+        rows.reserve(n);
+        nodes.reserve(n);
+        for (uint64_t k = 0; k < n; ++k) {
+            uint32_t row = RIO_GP_NONE, node = RIO_GP_NONE;
+            int rc;
+            if (addrs[k]) {  // Some(address): entry(key) = address
+                if ((rc = intern_row(s, tys[k], ids[k], true, &row))) return rc;
+                if ((rc = intern_node(s, addrs[k], true, &node))) return rc;
+            } else {         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
+                if ((rc = intern_row(s, tys[k], ids[k], false, &row))) return rc;
+                if (row == RIO_GP_NONE) continue;
+            }
+            rows.push_back(row);
+            nodes.push_back(node);
         }
-        rows.push_back(row);
-        nodes.push_back(node);
-    }
-    int rc;
-    if (created && (rc = push_nodes(s))) return rc;
-    if (rows.empty()) return RIO_GP_OK;
-    rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), nodes.data());
-    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+        int rc;
+        if ((rc = sync_device(s, true))) return rc;
+        if (rows.empty()) return RIO_GP_OK;
+        rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), nodes.data());
+        return rc ? gp_fail(s, rc) : RIO_GP_OK;
+    });
 }
 
 int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr) {
@@ -350,25 +556,17 @@ int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr)
     Req r;
     r.kind = 2;
     r.req = RIO_GP_NONE;
-    bool created = false;
-    {
-        std::lock_guard<std::mutex> gi(s->imu);
+    const int rc = single_call(s, &r, [&]() -> int {
         int rc;
         if (addr) {  // Some(address): entry(key) = address
             if ((rc = intern_row(s, ty, id, true, &r.row))) return rc;
-            if ((rc = intern_node(s, addr, true, &r.req, &created))) return rc;
-        } else {     // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
-            if ((rc = intern_row(s, ty, id, false, &r.row))) return rc;
-            if (r.row == RIO_GP_NONE) return RIO_GP_OK;
+            return intern_node(s, addr, true, &r.req);
         }
-    }
-    if (created) {  // a server address never seen before: the node table goes to the device first
-        std::lock_guard<std::mutex> g(s->mu);
-        std::lock_guard<std::mutex> gi(s->imu);
-        int rc = push_nodes(s);
-        if (rc) return rc;
-    }
-    return run_combined(s, &r);
+        // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
+        if ((rc = intern_row(s, ty, id, false, &r.row))) return rc;
+        return r.row == RIO_GP_NONE ? 1 : RIO_GP_OK;
+    });
+    return rc == 1 ? RIO_GP_OK : rc;
 }
 
 int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids, uint32_t* out) {
@@ -388,8 +586,10 @@ int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
         }
     }
     if (rows.empty()) return RIO_GP_OK;
+    int rc;
+    if ((rc = sync_device(s, true))) return rc;
     std::vector<uint32_t> res(rows.size());
-    int rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res.data());
+    rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res.data());
     if (rc) return gp_fail(s, rc);
     for (size_t q = 0; q < rows.size(); ++q) out[where[q]] = res[q];
     return RIO_GP_OK;
@@ -401,14 +601,13 @@ int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t
     Req r;
     r.kind = 0;
     r.req = RIO_GP_NONE;
-    {
-        std::lock_guard<std::mutex> gi(s->imu);
-        int rc = intern_row(s, ty, id, false, &r.row);
-        if (rc) return rc;
-    }
     *found = 0;
-    if (r.row == RIO_GP_NONE) return RIO_GP_OK;  // unknown key: Ok(None), no device work
-    int rc = run_combined(s, &r);
+    const int rc = single_call(s, &r, [&]() -> int {
+        const int rc = intern_row(s, ty, id, false, &r.row);
+        if (rc) return rc;
+        return r.row == RIO_GP_NONE ? 1 : RIO_GP_OK;  // unknown key: Ok(None), no device work
+    });
+    if (rc == 1) return RIO_GP_OK;
     if (rc) return rc;
     *found = r.node != RIO_GP_NONE;
     if (*found) {
@@ -424,9 +623,10 @@ int rio_op_clean_server(rio_op_t* p, const char* address) {
     std::lock_guard<std::mutex> g(s->mu);
     std::lock_guard<std::mutex> gi(s->imu);
     uint32_t node;
-    int rc = intern_node(s, address, false, &node, nullptr);
+    int rc = intern_node(s, address, false, &node);
     if (rc) return rc;
     if (node == RIO_GP_NONE) return RIO_GP_OK;  // nothing was ever placed there: retain() removes nothing
+    if ((rc = sync_device(s, true))) return rc;
     rc = rio_gp_clean_server(s->gp, node, nullptr);
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
 }
@@ -437,21 +637,21 @@ int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
     Req r;
     r.kind = 3;
     r.req = RIO_GP_NONE;
-    {
-        std::lock_guard<std::mutex> gi(s->imu);
-        int rc = intern_row(s, ty, id, false, &r.row);
+    const int rc = single_call(s, &r, [&]() -> int {
+        const int rc = intern_row(s, ty, id, false, &r.row);
         if (rc) return rc;
-    }
-    if (r.row == RIO_GP_NONE) return RIO_GP_OK;  // absent: no-op (local.rs:60-68)
-    return run_combined(s, &r);
+        return r.row == RIO_GP_NONE ? 1 : RIO_GP_OK;  // absent: no-op (local.rs:60-68)
+    });
+    return rc == 1 ? RIO_GP_OK : rc;
 }
 
 int rio_op_len(rio_op_t* p, uint64_t* out) {
     if (!p || !out) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
-    int rc = rio_gp_count_placed(s->gp, out);
+    int rc;
+    if ((rc = sync_device(s, false))) return rc;
+    rc = rio_gp_count_placed(s->gp, out);
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
 }
 
@@ -461,44 +661,46 @@ int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t cap
     std::lock_guard<std::mutex> g(s->mu);
     std::lock_guard<std::mutex> gi(s->imu);
     uint32_t node;
-    bool created = false;
-    int rc = intern_node(s, address, true, &node, &created);
+    int rc = intern_node(s, address, true, &node);
     if (rc) return rc;
     s->node_alive[node] = active ? 1 : 0;
-    s->node_cap[node] = capacity;
-    return push_nodes(s);
+    if (s->node_cap[node] != capacity) {
+        s->node_cap[node] = capacity;
+        ++s->shape_version;
+    }
+    ++s->node_version;
+    return sync_device(s, true);
 }
 
 int rio_op_set_object_load(rio_op_t* p, const char* ty, const char* id, uint32_t load) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
-    uint32_t row;
-    int rc = intern_row(s, ty, id, true, &row);
-    if (rc) return rc;
-    rc = rio_gp_set_object_attrs(s->gp, 1, &row, &load, nullptr);
-    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+    return compound_call(s, [&]() -> int {
+        uint32_t row;
+        int rc = intern_row(s, ty, id, true, &row);
+        if (rc) return rc;
+        if ((rc = sync_device(s, true))) return rc;
+        // the load only: the key does not become an object before its first update / request
+        rc = rio_gp_set_object_attrs(s->gp, 1, &row, &load, nullptr);
+        return rc ? gp_fail(s, rc) : RIO_GP_OK;
+    });
 }
 
 int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids,
                                          const char* const* selfs, uint32_t* out_node, uint32_t* out_flag) {
     if (!p || (n && (!tys || !ids || !selfs || !out_node))) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
-    std::vector<uint32_t> rows(n), reqs(n);
-    bool created = false;
-    for (uint64_t k = 0; k < n; ++k) {
+    return compound_call(s, [&]() -> int {
+        std::vector<uint32_t> rows(n), reqs(n);
+        for (uint64_t k = 0; k < n; ++k) {
+            int rc;
+            if ((rc = intern_row(s, tys[k], ids[k], true, &rows[k]))) return rc;
+            if ((rc = intern_node(s, selfs[k], true, &reqs[k], true))) return rc;  // a server answering requests is up
+        }
         int rc;
-        if ((rc = intern_row(s, tys[k], ids[k], true, &rows[k]))) return rc;
-        const size_t before = s->node_addr.size();
-        if ((rc = intern_node(s, selfs[k], true, &reqs[k], &created))) return rc;
-        if (s->node_addr.size() != before) s->node_alive[reqs[k]] = 1;  // a server answering requests is up
-    }
-    int rc;
-    if (created && (rc = push_nodes(s))) return rc;
-    return policy_batch(s, rows, reqs, out_node, out_flag);
+        if ((rc = sync_device(s, true))) return rc;
+        return policy_batch(s, rows, reqs, out_node, out_flag);
+    });
 }
 
 int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, const char* self_address, char* out,
@@ -507,22 +709,11 @@ int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, 
     State* s = p->s;
     Req r;
     r.kind = 1;
-    bool created = false;
-    {
-        std::lock_guard<std::mutex> gi(s->imu);
+    const int rc = single_call(s, &r, [&]() -> int {
         int rc;
         if ((rc = intern_row(s, ty, id, true, &r.row))) return rc;
-        const size_t before = s->node_addr.size();
-        if ((rc = intern_node(s, self_address, true, &r.req, &created))) return rc;
-        if (s->node_addr.size() != before) s->node_alive[r.req] = 1;  // a server answering requests is up
-    }
-    if (created) {  // rare: a requester never seen before — the node table goes to the device before the request does
-        std::lock_guard<std::mutex> g(s->mu);
-        std::lock_guard<std::mutex> gi(s->imu);
-        int rc = push_nodes(s);
-        if (rc) return rc;
-    }
-    int rc = run_combined(s, &r);
+        return intern_node(s, self_address, true, &r.req, true);  // a server answering requests is up
+    });
     if (rc) return rc;
     if (flag) *flag = r.flag;
     std::lock_guard<std::mutex> gi(s->imu);
@@ -534,23 +725,34 @@ int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_nam
                     const char* const** server_addresses) {
     if (!p || !n_out || !struct_names || !object_ids || !server_addresses) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
-    std::vector<uint32_t> assign(s->max_objects);
-    int rc = rio_gp_get_assign(s->gp, s->max_objects, assign.data());
-    if (rc) return gp_fail(s, rc);
-    s->snap_ty.clear(); s->snap_id.clear(); s->snap_addr.clear();
-    for (size_t row = 0; row < s->row_key.size(); ++row) {
-        const uint32_t nd = assign[row];
-        if (nd == RIO_GP_NONE || nd >= s->node_addr.size()) continue;
-        s->snap_ty.push_back(s->row_key[row].first.c_str());
-        s->snap_id.push_back(s->row_key[row].second.c_str());
-        s->snap_addr.push_back(s->node_addr[nd].c_str());
+    t_snap_store.clear();
+    t_snap_ty.clear(); t_snap_id.clear(); t_snap_addr.clear();
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        std::lock_guard<std::mutex> gi(s->imu);
+        int rc;
+        if ((rc = sync_device(s, true))) return rc;
+        const uint64_t n = s->hi_rows;
+        std::vector<uint32_t> assign(n ? n : 1);
+        if ((rc = rio_gp_get_assign(s->gp, n, assign.data()))) return gp_fail(s, rc);
+        // copies: keys can be reclaimed and the tables can grow as soon as the locks are released
+        for (uint64_t row = 0; row < n; ++row) {
+            const uint32_t nd = assign[row];
+            if (!s->row_live[row] || nd == RIO_GP_NONE || nd >= s->node_addr.size()) continue;
+            t_snap_store.push_back(s->row_key[row].first);
+            t_snap_store.push_back(s->row_key[row].second);
+            t_snap_store.push_back(s->node_addr[nd]);
+        }
     }
-    *n_out = s->snap_ty.size();
-    *struct_names = s->snap_ty.data();
-    *object_ids = s->snap_id.data();
-    *server_addresses = s->snap_addr.data();
+    for (size_t k = 0; k + 2 < t_snap_store.size(); k += 3) {
+        t_snap_ty.push_back(t_snap_store[k].c_str());
+        t_snap_id.push_back(t_snap_store[k + 1].c_str());
+        t_snap_addr.push_back(t_snap_store[k + 2].c_str());
+    }
+    *n_out = t_snap_ty.size();
+    *struct_names = t_snap_ty.data();
+    *object_ids = t_snap_id.data();
+    *server_addresses = t_snap_addr.data();
     return RIO_GP_OK;
 }
 
@@ -558,8 +760,9 @@ int rio_op_tick(rio_op_t* p, rio_gp_stats* stats) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
-    int rc = rio_gp_tick(s->gp, stats);
+    int rc;
+    if ((rc = sync_device(s, false))) return rc;
+    rc = rio_gp_tick(s->gp, stats);
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
 }
 

@@ -12,6 +12,7 @@ typedef unsigned long long u64;
 constexpr u32 kNone = 0xFFFFFFFFu;       // unplaced (RIO_GP_NONE)
 constexpr u32 kSpillMark = 0xFFFFFFFEu;  // pending, waiting for the water-fill (never survives a solve)
 constexpr u32 kSkipMark = 0xFFFFFFFDu;   // virtual-table row that is a duplicate request (place_pending)
+constexpr u32 kAffInactive = 0xFFFFFFFEu;  // AFFINITY of a row that is not an object (RIO_GP_AFF_INACTIVE): never placed
 constexpr u32 kNoCut = 0xFFFFFFFFu;
 
 constexpr int kWaves = 16;           // waves per workgroup of the streaming kernels
@@ -52,8 +53,9 @@ struct DevStats {
 
 // Scratch of one solve over one table (real table or the virtual table of place_pending).
 struct SolveBufs {
-    u64* H;          // [G][2m]  per-block load histograms: kept-by-cur | claim-by-aff
-    u64* partial;    // [ceil(m/4)][8] k_resolve per-workgroup partial counters (device copy)
+    u64* H;          // [ceil(m/8)][G][16] per-block load histograms, node-group major: kept-by-cur x8 | claim-by-aff x8
+                     //   (one 128-byte line per (group of 8 nodes, block): k_resolve reads G contiguous lines per workgroup)
+    u64* partial;    // [ceil(m/8)][8] k_resolve per-workgroup partial counters (device copy)
     u64* blkstat;    // [G][4]   kept, evicted, claimants rows per block
     u64* wsp_sum[2]; // [G*kWaves] spill-candidate load per wave range (ping-pong over rounds)
     u32* wsp_cnt[2]; // [G*kWaves]
@@ -117,7 +119,7 @@ void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t 
 void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 unsigned resolve_blocks(u32 m);
-void set_scan_tpi(int tpi);
+void set_scan_nt(int mode);  // 0 by table size | 1 always | 2 never: non-temporal column streams in k_scan
 int cut_trace_enable(int on);  // k_cut_fused phase trace (measurement aid)
 int cut_trace_read(u64* out /*[kMaxBlocks*8]*/);
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
@@ -130,16 +132,18 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
 
 // --- CRUD over the assignment column ---
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s);
+// aff_life (every CRUD launcher below): the affinity column when the handle tracks the row lifecycle (rows that are
+// written become objects, rows that are removed / deleted / dropped by clean_server stop being objects), else nullptr
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos_scratch,
-                   DevStats* st, hipStream_t s);
+                   DevStats* st, hipStream_t s, u32* aff_life = nullptr);
 // n <= kSmallBatch validated entries (may be mapped host memory): last writer wins inside the batch, one launch
-void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s);
+void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
-                   DevStats* st, hipStream_t s);
+                   DevStats* st, hipStream_t s, u32* aff_life = nullptr);
 // counter == nullptr: accumulate into st->evicted_clean.  ticket/host_out: self-resetting counter + total written to
 // mapped host memory by the last workgroup (dead_bits may itself be mapped host memory).
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s,
-                  u64* counter = nullptr, unsigned int* ticket = nullptr, u64* host_out = nullptr);
+                  u64* counter = nullptr, unsigned int* ticket = nullptr, u64* host_out = nullptr, u32* aff_life = nullptr);
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s);
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s);
 void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32* nload, const u32* naff, u64 n,
@@ -152,7 +156,8 @@ void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t 
 // --- place_pending, micro-batch (n <= kSmallBatch): one launch; idx/req/out_* may be mapped host memory; *status = 1
 //     means "needs the general path", nothing was changed ---
 void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
-                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s);
+                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
+                     u32* aff_life = nullptr);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s);
@@ -160,7 +165,7 @@ void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const 
                       u32* vcur, u32* vload, u32* vaff, hipStream_t s);
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
                        u32* pos_scratch, const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node,
-                       u32* out_flag, hipStream_t s);
+                       u32* out_flag, hipStream_t s, u32* aff_life = nullptr);
 
 size_t scan_lds_bytes(u32 m);
 
@@ -168,18 +173,13 @@ size_t scan_lds_bytes(u32 m);
 inline size_t shard_words1(u32 m) { return 2 * (size_t)m + 8; }  // X = [kept_local[m] | claim_local[m] | 8 counters]
 inline size_t shard_words2(u32 m) { return (size_t)m + 2; }      // Y = [delta[m] | spill load | spill rows]
 void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s);
-// row_stride: u64 words between two ranks' records in Xg (0 = packed, shard_words1(m)); wait_flags != nullptr: Xg is
-// this rank's peer-to-peer window and the kernel first waits for every rank's flag == seq (p2p_err set on time-out)
+// Xg[R][shard_words1(m)] = the all-gathered X records (RCCL paths)
 void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, const u64* Xg, u32 rank, u32 R,
-                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s,
-                         size_t row_stride = 0, const u64* wait_flags = nullptr, u64 seq = 0, u64* p2p_err = nullptr);
-// peer-to-peer all-gather over xGMI: store `words` of src + the flag `seq` into every peer's window; wait + copy out
-// k_resolve + pack + put in one kernel (peer-to-peer windows, R <= 32): local sums into every peer's window, flag last
-void launch_resolve_put(const Plan& p, const SolveBufs& b, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off,
-                        u64 seq, unsigned int* counter, hipStream_t s);
+                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s);
+// peer-to-peer exchange over xGMI (windows IPC-mapped by every rank, R <= 32)
 // the whole fast-path exchange in one launch (k_resolve_xchg): window rows of shard_xchg_words(m) words; host_partial =
 // pinned rows [resolve_blocks(m)][8] of partial verdicts (the caller adds them up)
-inline size_t shard_xchg_words(u32 m) { return 2 * (2 * (size_t)m + 8 * (size_t)((m + 3) / 4)); }  // two tagged words per value
+inline size_t shard_xchg_words(u32 m) { return 2 * (2 * (size_t)m + 8 * (size_t)((m + 7) / 8)); }  // two tagged words per value
 void launch_resolve_xchg(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* const* d_peers, u32 R, u32 rank,
                          size_t my_row_off, const u64* win_rows, size_t W, u64 seq, u64* p2p_err, u64* gprev, u64* gfinal,
                          u64* host_partial, hipStream_t s);

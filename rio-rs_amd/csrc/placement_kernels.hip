@@ -151,7 +151,7 @@ size_t scan_lds_bytes(u32 m) {
 // Row classification shared by every streaming kernel (must be identical everywhere):
 //   kept      placed on a live node            -> sticky               (service.rs:241-242)
 //   claimant  pending, affinity node is live   -> first touch          (service.rs:244-252)
-//   else      pending, goes to the water-fill
+//   else      pending, goes to the water-fill — unless its affinity is kAffInactive (not an object: class 3, ignored)
 // VIRT (virtual table of place_pending): rows are requests; "kept" = already placed (dead nodes
 // were evicted beforehand), kSkipMark rows are duplicate requests and take no part.
 template <bool VIRT>
@@ -163,6 +163,7 @@ __device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv) {
         if (c < m && bit_of(alv, c)) return 0;
     }
     if (a < m && bit_of(alv, a)) return 1;
+    if (!VIRT && a == kAffInactive) return 3;  // not an object: takes no part
     return 2;
 }
 
@@ -170,12 +171,38 @@ __device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv) {
 // K1  k_scan — THE streaming kernel: one pass over cur/load/aff (12 B/row read), optimistic
 //     write of the new assignment (4 B/row), per-block per-node load histograms in LDS.
 //     Algorithmic traffic 16 B/row; everything else is <3 % overhead:
-//     H row 2*m*8 B per block, 3 words per wave.
+//     H lines 2*m*8 B per block, 3 words per wave.
 //     The row body is branch-free (one ds_add_u64 per row, trash bin for rows that add nothing;
 //     counters are wave-uniform popcounts of ballots) so the next tile's three dwordx4 loads stay
 //     in flight under a counted vmcnt while the current tile is processed.
+//     A row whose affinity is kAffInactive is not an object (row lifecycle of the string layer:
+//     never interned, removed, or dropped by clean_server): it is kept if it happens to be placed
+//     on a live node and takes no part otherwise — neither claimant nor spill candidate.
 // ------------------------------------------------------------------------------------------------
-template <bool VIRT, bool ALLALIVE, bool CHECK, int HMODE = 0, bool COMPACT = false>
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+// NT: non-temporal column streams for tables beyond the 256 MiB Infinity Cache (measured +1-2 % at 40-100 M rows and
+// -25 % at 10 M rows, where the cache serves part of every pass: launch_scan picks by table size)
+template <bool NT>
+__device__ __forceinline__ uint4 ld4(const u32* p) {
+    if (NT) {
+        const u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return make_uint4(r.x, r.y, r.z, r.w);
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(u32* p, const uint4 v) {
+    if (NT) {
+        u32x4 r;
+        r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+        __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(p));
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+
+template <bool VIRT, bool ALLALIVE, bool CHECK, bool COMPACT = false, bool NT = false>
 __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const uint4 lv, const u64 i0, const u64 wend,
                                           const u32 m, const u32* alv, u64* hist, u32* __restrict__ next,
                                           u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt,
@@ -189,13 +216,13 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         const bool cin = C < m, ain = A < m;                                                           \
         const u32 cc = cin ? C : 0, aa = ain ? A : 0;                                                  \
         const bool skip = VIRT && C == kSkipMark;                                                      \
+        const bool dead = !VIRT && A == kAffInactive;                                                  \
         const bool kept = inr && cin && (VIRT || ALLALIVE || bit_of(alv, cc));                         \
         const bool cl = inr && !kept && !skip && ain && (ALLALIVE || bit_of(alv, aa));                 \
-        const bool sp = inr && !kept && !cl && !skip;                                                  \
+        const bool sp = inr && !kept && !cl && !skip && !dead;                                         \
         const u32 bin = (kept && !VIRT) ? cc : (cl ? m + aa : 2 * m);                                  \
-        if (HMODE == 0) atomicAdd(&hist[bin], (u64)L);                                                 \
-        else if (HMODE == 2) atomicAdd(reinterpret_cast<u32*>(hist) + bin, (u32)L);                    \
-        O = kept ? C : (cl ? A : (skip ? kSkipMark : kSpillMark));                                     \
+        atomicAdd(&hist[bin], (u64)L);                                                                 \
+        O = kept ? C : (cl ? A : (skip ? kSkipMark : (dead ? kNone : kSpillMark)));                    \
         kept_cnt += (u32)__popcll(__ballot(kept));                                                     \
         claim_cnt += (u32)__popcll(__ballot(cl));                                                      \
         if (!VIRT) evict_cnt += (u32)__popcll(__ballot(inr && !kept && C != kNone));                   \
@@ -235,7 +262,7 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         sp_cnt += c;
     }
     if (!CHECK || i0 + 3 < wend) {
-        *reinterpret_cast<uint4*>(next + i0) = ov;
+        st4<NT>(next + i0, ov);
     } else {
         if (i0 + 0 < wend) next[i0 + 0] = ov.x;
         if (i0 + 1 < wend) next[i0 + 1] = ov.y;
@@ -243,22 +270,12 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
     }
 }
 
-template <bool NT>
-__device__ __forceinline__ uint4 ld4(const u32* p) {
-    if (NT) {
-        uint4 r;
-        r.x = __builtin_nontemporal_load(p + 0);
-        r.y = __builtin_nontemporal_load(p + 1);
-        r.z = __builtin_nontemporal_load(p + 2);
-        r.w = __builtin_nontemporal_load(p + 3);
-        return r;
-    }
-    return *reinterpret_cast<const uint4*>(p);
-}
+// Where workgroup b's sums for node group g (8 nodes) live in H: one 128-byte line {kept x8 | claim x8}.
+__host__ __device__ __forceinline__ size_t h_line(u32 g, u32 b, u32 G) { return ((size_t)g * G + b) * 16; }
 
 // TPI = tiles (of 256 rows) a wave processes per loop iteration; the next TPI tiles are always in
 // flight while the current ones are processed.
-template <bool VIRT, bool ALLALIVE, int TPI, int HMODE = 0, bool COMPACT = false>
+template <bool VIRT, bool ALLALIVE, int TPI, bool COMPACT = false, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                  const u32* __restrict__ aff, u32* __restrict__ next,
                                                  const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
@@ -285,9 +302,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u64 i = it + (u64)q * kTile + (u64)lane * 4;
-            cv[q] = *reinterpret_cast<const uint4*>(cur + i);
-            av[q] = *reinterpret_cast<const uint4*>(aff + i);
-            lv[q] = *reinterpret_cast<const uint4*>(load + i);
+            cv[q] = ld4<NT>(cur + i);
+            av[q] = ld4<NT>(aff + i);
+            lv[q] = ld4<NT>(load + i);
         }
     }
 
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         stats->rejected = 0; stats->load_rejected = 0;
         stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
         stats->rounds_run = 0;
-        stats->n_cut = 0;  // device-side "a node has a cut" flag (k_cutblk)
+        stats->n_cut = 0;  // device-side "a node has a cut" flag (k_resolve / k_cutblk)
     }
     __syncthreads();
 
@@ -317,15 +334,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
-            cn[q] = *reinterpret_cast<const uint4*>(cur + i);
-            an[q] = *reinterpret_cast<const uint4*>(aff + i);
-            ln[q] = *reinterpret_cast<const uint4*>(load + i);
+            cn[q] = ld4<NT>(cur + i);
+            an[q] = ld4<NT>(aff + i);
+            ln[q] = ld4<NT>(load + i);
         }
 #pragma unroll
         for (int q = 0; q < TPI; ++q)
-            scan_tile<VIRT, ALLALIVE, false, HMODE, COMPACT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
-                                                             m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
-                                                             claim_cnt, &pko, &pk_pos);
+            scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
+                                                          m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
+                                                          claim_cnt, &pko, &pk_pos);
         it = nit;
 #pragma unroll
         for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
@@ -336,11 +353,11 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         const uint4 a1 = *reinterpret_cast<const uint4*>(aff + i);
         const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
         if (it < wfull)
-            scan_tile<VIRT, ALLALIVE, false, 0, COMPACT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                         evict_cnt, claim_cnt, &pko, &pk_pos);
+            scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                                          evict_cnt, claim_cnt, &pko, &pk_pos);
         else
-            scan_tile<VIRT, ALLALIVE, true, 0, COMPACT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                        evict_cnt, claim_cnt, &pko, &pk_pos);
+            scan_tile<VIRT, ALLALIVE, true, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                                         evict_cnt, claim_cnt, &pko, &pk_pos);
     }
 
     // per-wave spill-candidate totals (index-ordered prefix over wave ranges comes later)
@@ -356,22 +373,61 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         atomicAdd(&bst[3], sp_cnt);
     }
     __syncthreads();
-    u64* Hrow = H + (size_t)blockIdx.x * 2 * m;
-    for (u32 k = tid; k < 2 * m; k += kBlock) Hrow[k] = hist[k];
+    // this block's sums, node-group major: line (g, b) = {kept of nodes 8g..8g+7 | their claim loads} — 16 consecutive
+    // threads store one 128-byte line, so k_resolve's workgroup g reads G contiguous lines and nothing else
+    const u32 ng = (m + 7) >> 3;
+    for (u32 k = tid; k < ng * 16; k += kBlock) {
+        const u32 g = k >> 4, c = k & 15, j = g * 8 + (c & 7);
+        H[h_line(g, blockIdx.x, p.G) + c] = j < m ? hist[(c >> 3) * m + j] : 0ull;
+    }
     if (tid < 4) blkstat[(size_t)blockIdx.x * 4 + tid] = bst[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2  k_resolve — per node: used = sum over blocks of the kept histogram, claim total, free, and
-//     the verdict "claims fit" (fast path) or "cut" (fix-up needed).  Column sums of the row-major
-//     [G][2m] table, spread over m/4 workgroups (all CUs, ~16 KiB each): thread = (row group, column),
-//     8 columns per workgroup = 4 nodes x {kept, claim}; every load is issued before the first wait.
+//     the verdict "claims fit" (fast path) or "cut" (fix-up needed).  Workgroup g owns node group g
+//     (8 nodes) and reads exactly its G contiguous 128-byte lines of H ({kept x8 | claim x8} per
+//     block, written that way by k_scan): algorithmic = fetched bytes (the row-major [G][2m] table of
+//     the first version cost 4.1x: two 32-byte slices per 16 KiB row and workgroup).  Thread =
+//     (row group, column pair): one dwordx4 per line and thread, every load issued before the first wait.
 //     Per-workgroup partial counters go straight into the caller's pinned host slot (plain stores,
 //     no atomics, no fences, no copy kernel); the host adds the rows up.
 // ------------------------------------------------------------------------------------------------
-constexpr int kResNodes = 4;
-constexpr int kResRowGroups = 32;                          // 256 threads = 32 row groups x 8 columns
-constexpr int kResRows = kMaxBlocks / kResRowGroups;       // 8 loads per thread
+constexpr int kResNodes = 8;
+constexpr int kResRowGroups = 32;                          // 256 threads = 32 row groups x 8 column pairs
+constexpr int kResRows = kMaxBlocks / kResRowGroups;       // 8 lines (16 B of each) per thread
+
+// sums of this workgroup's 16 columns over the G blocks -> tot[16] (kept x8 | claim x8); v[r][0..1] keep the thread's
+// own addends (columns 2*cp, 2*cp+1 of rows rg + 32 r) for the cut-block search
+__device__ __forceinline__ void resolve_column_sums(const u64* __restrict__ H, u32 g, u32 G, u64 (&v)[kResRows][2],
+                                                    u64 (*part)[16], u64* tot) {
+    const int tid = threadIdx.x, cp = tid & 7, rg = tid >> 3;
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) {
+        const u32 row = rg + r * kResRowGroups;
+        if (row < G) {
+            const uint4 x = *reinterpret_cast<const uint4*>(H + h_line(g, row, G) + 2 * cp);
+            v[r][0] = ((u64)x.y << 32) | x.x;
+            v[r][1] = ((u64)x.w << 32) | x.z;
+        } else {
+            v[r][0] = 0;
+            v[r][1] = 0;
+        }
+    }
+    u64 s0 = 0, s1 = 0;
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) { s0 += v[r][0]; s1 += v[r][1]; }
+    part[rg][2 * cp] = s0;
+    part[rg][2 * cp + 1] = s1;
+    __syncthreads();
+    if (tid < 16) {
+        u64 t = 0;
+#pragma unroll
+        for (int q = 0; q < kResRowGroups; ++q) t += part[q][tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, const u64* __restrict__ blkstat, Plan p,
                                                  const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
@@ -381,54 +437,37 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
                                                  u64* __restrict__ partial, u64* __restrict__ host_partial,
                                                  u64* __restrict__ budget, u64* __restrict__ admpre,
                                                  DevStats* __restrict__ stats) {
-    __shared__ u64 part[kResRowGroups][8];
-    __shared__ u64 tot[8];
+    __shared__ u64 part[kResRowGroups][16];
+    __shared__ u64 tot[16];
     __shared__ u64 red[8];
     __shared__ u64 cutfre[kResNodes];               // free capacity of a node of this workgroup that has a cut
-    __shared__ u32 cutmask;                         // which of the four nodes have one
+    __shared__ u32 cutmask;                         // which of the eight nodes have one
     __shared__ u64 colbuf[kResNodes][kMaxBlocks];   // their claim columns, row order (only filled when cutmask != 0)
-    const int tid = threadIdx.x, lane = tid & 63, col = tid & 7, rg = tid >> 3;
-    const u32 m = p.m, G = p.G, nb = gridDim.x;
-    const u32 j = blockIdx.x * kResNodes + (col & 3);
-    const bool valid = j < m;
-    const size_t c = (col < 4) ? (size_t)j : (size_t)m + j;
+    const int tid = threadIdx.x, lane = tid & 63, cp = tid & 7, rg = tid >> 3;
+    const u32 m = p.m, G = p.G, nb = gridDim.x, g = blockIdx.x;
+    const u32 j = g * kResNodes + (u32)tid;          // node of thread tid < 8
+    const bool valid = tid < kResNodes && j < m;
     // node-table operands of the verdict are requested up front so their latency overlaps the H loads
     u64 cj = 0, ub = 0;
     bool alive_j = false;
-    if (tid < 4 && valid) {
+    if (valid) {
         cj = cap[j];
         alive_j = bit_of(alive_bits, j);
         if (used_base) ub = used_base[j];
     }
-    u64 v[kResRows];
-#pragma unroll
-    for (int r = 0; r < kResRows; ++r) {
-        const u32 row = rg + r * kResRowGroups;
-        v[r] = (valid && row < G) ? H[(size_t)row * 2 * m + c] : 0;
-    }
-    u64 sacc = 0;
-#pragma unroll
-    for (int r = 0; r < kResRows; ++r) sacc += v[r];
-    part[rg][col] = sacc;
     if (tid < 8) red[tid] = 0;
     if (tid == 0) cutmask = 0;
-    __syncthreads();
-    if (tid < 8) {
-        u64 t = 0;
-#pragma unroll
-        for (int g = 0; g < kResRowGroups; ++g) t += part[g][tid];
-        tot[tid] = t;
-    }
-    __syncthreads();
-    if (tid < 4 && valid) {
-        const u64 kept_load = tot[tid], ctot = tot[tid + 4];
+    u64 v[kResRows][2];
+    resolve_column_sums(H, g, G, v, part, tot);      // two barriers inside: red / cutmask are published
+    if (valid) {
+        const u64 kept_load = tot[tid], ctot = tot[tid + kResNodes];
         const u64 used = kept_load + ub;
         const u64 fre = (alive_j && cj > used) ? cj - used : 0;
         used_kept[j] = used;
         claim_tot[j] = ctot;
         cutblk[j] = kNoCut;
         cutidx[j] = kNoCut;
-        used_cur[j] = used + ctot;  // final unless the node has a cut (k_cut_exact rewrites it)
+        used_cur[j] = used + ctot;  // final unless the node has a cut (the cut kernels rewrite it)
         atomicAdd(&red[0], kept_load);
         atomicAdd(&red[1], ctot);
         if (ctot > fre) {
@@ -437,29 +476,32 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
             atomicOr(&cutmask, 1u << tid);
         }
     }
-    if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
+    if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows g, g+nb, ... of blkstat
         u64 acc = 0;
-        for (u32 r = blockIdx.x + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
+        for (u32 r = g + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
         acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
         if (lane < 4) red[3 + lane] = acc;
     }
     __syncthreads();
     if (tid < 8) {
         const u64 x = (tid < 7) ? red[tid] : 1ull;  // column 7 = "row present" marker
-        partial[(size_t)blockIdx.x * 8 + tid] = x;
-        if (host_partial) host_partial[(size_t)blockIdx.x * 8 + tid] = x;
+        partial[(size_t)g * 8 + tid] = x;
+        if (host_partial) host_partial[(size_t)g * 8 + tid] = x;
     }
-    // A node whose claims exceed its free capacity: in which block (row of H) does the ordered prefix cross it?  The
-    // column is still in this workgroup's registers, so the answer costs no extra launch (k_cutblk's job on this path):
-    // claim columns to LDS in row order, one wave per cut node, four rows per lane, ordered scan.
+    // A node whose claims exceed its free capacity: in which block (line of H) does the ordered prefix cross it?  The
+    // column is still in this workgroup's registers, so the answer costs no extra launch (k_cutblk's job on the row-sharded
+    // path): claim columns to LDS in row order, one wave per pair of nodes, four rows per lane, ordered scan.
     if (!budget || cutmask == 0) return;  // block-uniform
-    if (col >= 4) {
+    if (cp >= 4) {
 #pragma unroll
-        for (int r = 0; r < kResRows; ++r) colbuf[col - 4][rg + r * kResRowGroups] = v[r];
+        for (int r = 0; r < kResRows; ++r) {
+            colbuf[2 * cp - kResNodes][rg + r * kResRowGroups] = v[r][0];
+            colbuf[2 * cp - kResNodes + 1][rg + r * kResRowGroups] = v[r][1];
+        }
     }
     __syncthreads();
-    const int q = tid >> 6;  // wave = node of this workgroup
-    if (q < kResNodes && ((cutmask >> q) & 1u)) {
+    for (int q = tid >> 6; q < kResNodes; q += 4) {  // wave -> nodes q, q + 4
+        if (!((cutmask >> q) & 1u)) continue;
         const u64 fre = cutfre[q];
         const u64 x0 = colbuf[q][lane * 4 + 0], x1 = colbuf[q][lane * 4 + 1], x2 = colbuf[q][lane * 4 + 2],
                   x3 = colbuf[q][lane * 4 + 3];
@@ -476,14 +518,14 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
             const int fl = __ffsll((long long)mask) - 1;
             if (lane == fl) {
                 const u64 cum = ex + (e == 0 ? 0ull : e == 1 ? x0 : e == 2 ? s1 : s2);
-                const u32 jq = blockIdx.x * kResNodes + q;
+                const u32 jq = g * kResNodes + q;
                 cutblk[jq] = (u32)(lane * 4 + e);
                 budget[jq] = fre - cum;
                 admpre[jq] = cum;
             }
         }
     }
-    if (tid == 0) atomicAdd(&stats->n_cut, 1ull);  // device-side "some node has a cut" flag (k_cut_fused's guard)
+    if (tid == 0) atomicAdd(&stats->n_cut, 1ull);  // device-side "some node has a cut" flag (the cut kernels' guard)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,7 +559,7 @@ __global__ __launch_bounds__(256) void k_cutblk(const u64* __restrict__ H, Plan 
 #pragma unroll
     for (int r = 0; r < kCbRows; ++r) {
         const u32 row = grp * rows + r;
-        cc[r] = (has_cut && (u32)r < rows && row < G) ? H[(size_t)row * 2 * m + m + j] : 0;
+        cc[r] = (has_cut && (u32)r < rows && row < G) ? H[h_line(j >> 3, row, G) + 8 + (j & 7)] : 0;
         tc += cc[r];
     }
     sc[grp][nd] = tc;
@@ -1134,7 +1176,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
             const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                  \
             const bool skip = VIRT && C == kSkipMark;                                                \
             const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                             \
-            const bool sp = inr & !kept & !skip & !cl;                                               \
+            const bool sp = inr & !kept & !skip & !cl & (VIRT | (A != kAffInactive));                \
             const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                        \
             if (rej) next[i0 + E] = kSpillMark;                                                      \
             sp_sum += (sp | rej) ? (u64)L : 0ull;                                                    \
@@ -1478,7 +1520,43 @@ __global__ void k_pack_alive(const uint8_t* alive, u32 m, u32* bits) {
     bits[w] = v;
 }
 
-// lookup (local.rs:42-49): 12 B/lookup — idx read, assign gather, out write
+// lookup (local.rs:42-49): 12 B/lookup — idx read, assign gather, out write.  A lane takes FOUR consecutive lookups: one
+// dwordx4 index read, four independent gathers in flight before the first is used, one dwordx4 store (the scalar form —
+// one dependent 4-byte gather per lane and iteration — reached 40 % of the roofline on sequential indices and 7.7 % on
+// random ones, where every gather pulls a whole 128-byte line through the fabric for 4 useful bytes).
+__global__ __launch_bounds__(256) void k_lookup4(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u64 n,
+                                                 u32* __restrict__ out, DevStats* st) {
+    const u64 nvec = n >> 2;
+    u32 bad = 0;
+    const u64 stride = (u64)gridDim.x * 256;
+    u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    for (; v + stride < nvec; v += 2 * stride) {  // two vectors per trip: eight gathers in flight per lane
+        const uint4 ia = *reinterpret_cast<const uint4*>(idx + 4 * v);
+        const uint4 ib = *reinterpret_cast<const uint4*>(idx + 4 * (v + stride));
+        uint4 ra, rb;
+#define RIOGP_G(I, R) { const bool ok = I < n_obj; R = assign[ok ? I : 0]; R = ok ? R : kNone; bad += !ok; }
+        RIOGP_G(ia.x, ra.x) RIOGP_G(ia.y, ra.y) RIOGP_G(ia.z, ra.z) RIOGP_G(ia.w, ra.w)
+        RIOGP_G(ib.x, rb.x) RIOGP_G(ib.y, rb.y) RIOGP_G(ib.z, rb.z) RIOGP_G(ib.w, rb.w)
+        *reinterpret_cast<uint4*>(out + 4 * v) = ra;
+        *reinterpret_cast<uint4*>(out + 4 * (v + stride)) = rb;
+    }
+    for (; v < nvec; v += stride) {
+        const uint4 ia = *reinterpret_cast<const uint4*>(idx + 4 * v);
+        uint4 ra;
+        RIOGP_G(ia.x, ra.x) RIOGP_G(ia.y, ra.y) RIOGP_G(ia.z, ra.z) RIOGP_G(ia.w, ra.w)
+        *reinterpret_cast<uint4*>(out + 4 * v) = ra;
+    }
+    const u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x;  // ragged tail (< 4 entries)
+    if (k < n) {
+        const u32 i = idx[k];
+        u32 r;
+        RIOGP_G(i, r)
+        out[k] = r;
+    }
+#undef RIOGP_G
+    if (bad) atomicAdd(&st->err, (u64)bad);
+}
+// the same for index / result arrays that are not 16-byte aligned
 __global__ void k_lookup(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u64 n,
                          u32* __restrict__ out, DevStats* st) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
@@ -1501,20 +1579,24 @@ __global__ void k_update_elect(u64 n_obj, u32 m, const u32* __restrict__ idx, co
 }
 // the elected writer publishes and puts the scratch slot back to all-ones itself (a loser that reads the slot after
 // that sees NONE != its own position and does nothing) — no third pass
+// aff_life (row lifecycle, nullptr otherwise): the written row becomes an object whose affinity is its node, a deleted
+// one (node NONE, local.rs:36-37) stops being one
 __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ idx,
-                               const u32* __restrict__ node, u64 n, u32* __restrict__ pos) {
+                               const u32* __restrict__ node, u64 n, u32* __restrict__ pos, u32* __restrict__ aff_life) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k], nd = node[k];
         if (i < n_obj && (nd == kNone || nd < m) && pos[i] == (u32)(n - 1 - k)) {
             assign[i] = nd;
             pos[i] = kNone;
+            if (aff_life) aff_life[i] = nd == kNone ? kAffInactive : nd;
         }
     }
 }
 // update, micro-batch (n <= kSmallBatch): one workgroup, one launch; entries were validated by the host and may sit in
 // mapped host memory.  Sequential last-writer-wins inside the batch: an entry loses to any LATER entry for the same row.
 __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
-                                                              const u32* __restrict__ node, u32 n) {
+                                                              const u32* __restrict__ node, u32 n,
+                                                              u32* __restrict__ aff_life) {
     __shared__ u32 li[kSmallBatch];
     const u32 k = threadIdx.x;
     u32 i = kNone, nd = kNone;
@@ -1524,7 +1606,10 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
     if (k >= n) return;
     bool wins = true;
     for (u32 q = k + 1; q < n; ++q) wins &= li[q] != i;
-    if (wins) assign[i] = nd;
+    if (wins) {
+        assign[i] = nd;
+        if (aff_life) aff_life[i] = nd == kNone ? kAffInactive : nd;
+    }
 }
 
 // remove (local.rs:60-68): exchange makes duplicate removals of one row decrement `used` once.  The load released per
@@ -1532,7 +1617,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
 // million removals on at most m addresses (measured 55 us per million rows).
 __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                    const u32* __restrict__ load, const u32* __restrict__ idx, u64 n,
-                                                   u64* __restrict__ used, DevStats* st) {
+                                                   u64* __restrict__ used, DevStats* st, u32* __restrict__ aff_life) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* rel = reinterpret_cast<u64*>(smem);  // [m] load released per node (only when `used` is maintained)
     if (used) {
@@ -1545,6 +1630,7 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
         if (i >= n_obj) { ++bad; continue; }
         const u32 old = atomicExch(&assign[i], kNone);
         if (used && old < m) atomicAdd(&rel[old], (u64)load[i]);
+        if (aff_life) aff_life[i] = kAffInactive;  // row lifecycle: a removed key is no longer an object
     }
     if (bad) atomicAdd(&st->err, (u64)bad);
     if (used) {
@@ -1560,7 +1646,7 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
 __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                const u32* __restrict__ dead_bits, u64* __restrict__ used,
                                                u64* __restrict__ counter, unsigned int* __restrict__ ticket,
-                                               u64* __restrict__ host_out) {
+                                               u64* __restrict__ host_out, u32* __restrict__ aff_life) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32* db = reinterpret_cast<u32*>(smem);
     __shared__ u32 any;
@@ -1589,6 +1675,12 @@ __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_o
             if (e1) assign[i0 + 1] = kNone;
             if (e2) assign[i0 + 2] = kNone;
             if (e3) assign[i0 + 3] = kNone;
+            if (aff_life) {  // row lifecycle: retain() drops the entries (local.rs:51-58); they come back on their next request
+                if (e0) aff_life[i0 + 0] = kAffInactive;
+                if (e1) aff_life[i0 + 1] = kAffInactive;
+                if (e2) aff_life[i0 + 2] = kAffInactive;
+                if (e3) aff_life[i0 + 3] = kAffInactive;
+            }
             ev += e0 + e1 + e2 + e3;
         }
     }
@@ -1706,10 +1798,12 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
                             const u32* __restrict__ req, u64 n, const u32* __restrict__ vcur,
                             u32* __restrict__ pos, const u32* __restrict__ alive_bits,
                             const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
-                            u32* __restrict__ out_flag) {
+                            u32* __restrict__ out_flag, u32* __restrict__ aff_life) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k], r = req[k];
         const u32 nd = assign[i];
+        // row lifecycle: the first request of a pending row makes it an object (placed or not), home = the requester
+        if (aff_life && vcur[k] == kNone) aff_life[i] = r;
         u32 fl;
         if (nd == kNone) fl = 4u;                                  // UNPLACED
         else if (vcur[k] == kNone) {                               // this request placed the row
@@ -1739,7 +1833,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
                                                           u32* __restrict__ pos, const u32* __restrict__ idx,
                                                           const u32* __restrict__ req, u32 n,
                                                           u32* __restrict__ out_node, u32* __restrict__ out_flag,
-                                                          u32* __restrict__ status) {
+                                                          u32* __restrict__ status, u32* __restrict__ aff_life) {
     __shared__ u32 s_req[kSmallBatch], s_load[kSmallBatch], s_res[kSmallBatch];
     __shared__ u32 s_general;
     const u32 k = threadIdx.x;
@@ -1788,6 +1882,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
         if (claim) {  // first touch (service.rs:244-252)
             assign[i] = r;
             atomicAdd(&used[r], (u64)l);
+            if (aff_life) aff_life[i] = r;  // row lifecycle: the object exists from its first touch, its home is the requester
             fl = 2u;  // PLACED
         } else {
             nd = first ? c : s_res[winner];  // later duplicates observe what the first request decided
@@ -1879,14 +1974,13 @@ __global__ __launch_bounds__(kBlock) void k_p2p_wait_copy(const u64* __restrict_
             if (out) out[(size_t)r * words + i] = RIOGP_SYS_LOAD(win_slot + (size_t)r * W + i);
 }
 
-// K2x k_resolve_xchg — the whole fast-path exchange of the row-sharded solve in ONE launch over peer-to-peer windows
-//     (replaces k_resolve_put + k_shard_import<P2P>: two launches, a "last workgroup" fold, a flag per rank and a
-//     single-workgroup import).  Node tables couple the ranks only node by node, so every workgroup exchanges and
-//     resolves ITS OWN four nodes: local column sums of H for 4 nodes x {kept, claim} + its slice of the row counters
-//     go straight into every peer's window row of this rank as DATA-TAGGED granules — each u64 travels as two 8-byte
+// K2x k_resolve_xchg — the whole fast-path exchange of the row-sharded solve in ONE launch over peer-to-peer windows.
+//     Node tables couple the ranks only node by node, so every workgroup exchanges and resolves ITS OWN node group
+//     (k_resolve's 8 nodes): local column sums of H for 8 nodes x {kept, claim} + its slice of the row counters go
+//     straight into every peer's window row of this rank as DATA-TAGGED granules — each u64 travels as two 8-byte
 //     words {low half | tag}, {high half | tag}, tag = the step's sequence number — so there is no flag, no store
 //     drain and no release fence on the path: a consumer polls the very words it needs until both carry this step's
-//     tag (an 8-byte store is delivered whole; a stale word carries the tag of four steps ago).  Then the four nodes are
+//     tag (an 8-byte store is delivered whole; a stale word carries the tag of four steps ago).  Then the nodes are
 //     resolved against the global sums (k_shard_import's per-node maths) and one partial verdict row goes to the host
 //     slot (the host adds the rows up, as after k_resolve).  No workgroup waits for another one of its own rank.
 //     Row layout (u64 words, row stride W >= shard_xchg_words(m)): value v of {kept[m] | claim[m] | nb x 8 counters}
@@ -1911,6 +2005,8 @@ __device__ __forceinline__ u64 xchg_get(const u64* row, size_t v, u32 tag, u64* 
     }
 }
 
+constexpr int kXchgVals = 3 * kResNodes;  // per workgroup: 8 kept sums | 8 claim sums | 8 counters
+
 __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H, const u64* __restrict__ blkstat, Plan p,
                                                       u64* const* __restrict__ peers, u32 R, u32 rank,
                                                       size_t my_row_off /* of THIS rank's row, in every window */,
@@ -1923,67 +2019,48 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
                                                       u64* __restrict__ gfinal, u32* __restrict__ forced_bits,
                                                       u64* __restrict__ rank_base, u64* __restrict__ partial,
                                                       u64* __restrict__ host_partial) {
-    __shared__ u64 part[kResRowGroups][8];
-    __shared__ u64 vals[16];      // what this workgroup sends: 8 column sums | 8 counters
-    __shared__ u64 got[32][16];   // the same 16 values of every rank (R <= 32)
-    __shared__ u64 outc[8];       // partial verdict row
+    __shared__ u64 part[kResRowGroups][16];
+    __shared__ u64 vals[kXchgVals];      // what this workgroup sends (the first 16 are resolve_column_sums' tot[])
+    __shared__ u64 got[32][kXchgVals];   // the same values of every rank (R <= 32)
+    __shared__ u64 outc[8];              // partial verdict row
     __shared__ u32 nib;
-    const int tid = threadIdx.x, lane = tid & 63, col = tid & 7, rg = tid >> 3;
+    const int tid = threadIdx.x, lane = tid & 63;
     const u32 m = p.m, G = p.G, nb = gridDim.x, b = blockIdx.x;
     const u32 tag = (u32)seq;
-    const u32 j = b * kResNodes + (col & 3);
-    const bool valid = j < m;
-    const size_t c = (col < 4) ? (size_t)j : (size_t)m + j;
-    // value index of word w (0..15) of this workgroup in a row
+    // value index of word w (0..23) of this workgroup in a row
     auto vidx = [&](u32 w) -> size_t {
-        return w < 4 ? (size_t)b * kResNodes + w : w < 8 ? (size_t)m + (size_t)b * kResNodes + (w - 4)
-                                                         : 2 * (size_t)m + (size_t)b * 8 + (w - 8);
+        return w < 8 ? (size_t)b * kResNodes + w : w < 16 ? (size_t)m + (size_t)b * kResNodes + (w - 8)
+                                                          : 2 * (size_t)m + (size_t)b * 8 + (w - 16);
     };
-    auto wvalid = [&](u32 w) -> bool { return w >= 8 || b * kResNodes + (w & 3) < m; };
-    u64 v[kResRows];
-#pragma unroll
-    for (int r = 0; r < kResRows; ++r) {
-        const u32 row = rg + r * kResRowGroups;
-        v[r] = (valid && row < G) ? H[(size_t)row * 2 * m + c] : 0;
-    }
-    u64 sacc = 0;
-#pragma unroll
-    for (int r = 0; r < kResRows; ++r) sacc += v[r];
-    part[rg][col] = sacc;
+    auto wvalid = [&](u32 w) -> bool { return w >= 16 || b * kResNodes + (w & 7) < m; };
     if (tid < 8) outc[tid] = 0;
-    if (tid >= 8 && tid < 16) vals[tid] = tid == 15 ? 1ull : 0ull;
+    if (tid >= 16 && tid < kXchgVals) vals[tid] = tid == kXchgVals - 1 ? 1ull : 0ull;
     if (tid == 0) nib = 0;
-    __syncthreads();
-    if (tid < 8) {
-        u64 t = 0;
-#pragma unroll
-        for (int g = 0; g < kResRowGroups; ++g) t += part[g][tid];
-        vals[tid] = t;
-    }
+    u64 v[kResRows][2];
+    resolve_column_sums(H, b, G, v, part, vals);   // vals[0..7] kept sums, vals[8..15] claim sums
     if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
         u64 acc = 0;
         for (u32 r = b + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
         acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
-        if (lane < 4) vals[8 + 3 + lane] = acc;  // 3 kept  4 evicted  5 claimants  6 spill candidates (rows)
+        if (lane < 4) vals[16 + 3 + lane] = acc;  // 3 kept  4 evicted  5 claimants  6 spill candidates (rows)
     }
-    __syncthreads();
     if (tid == 0) {
         u64 a = 0, bb = 0;
-        for (int q = 0; q < 4; ++q)
-            if (b * kResNodes + q < m) { a += vals[q]; bb += vals[q + 4]; }
-        vals[8 + 0] = a;   // load kept
-        vals[8 + 1] = bb;  // load claimed
+        for (int q = 0; q < kResNodes; ++q)
+            if (b * kResNodes + q < m) { a += vals[q]; bb += vals[q + kResNodes]; }
+        vals[16 + 0] = a;   // load kept
+        vals[16 + 1] = bb;  // load claimed
     }
     __syncthreads();
-    if (tid < 8) partial[(size_t)b * 8 + tid] = vals[8 + tid];  // this shard's own counters (rio_gp_shard_finish)
-    // send: this workgroup's 16 values into this rank's row of EVERY window
-    for (u32 i = tid; i < 16 * R; i += 256) {
-        const u32 w = i & 15;
-        if (wvalid(w)) xchg_put(peers[i >> 4] + my_row_off, vidx(w), vals[w], tag);
+    if (tid < 8) partial[(size_t)b * 8 + tid] = vals[16 + tid];  // this shard's own counters (rio_gp_shard_finish)
+    // send: this workgroup's values into this rank's row of EVERY window
+    for (u32 i = tid; i < (u32)kXchgVals * R; i += 256) {
+        const u32 w = i % kXchgVals;
+        if (wvalid(w)) xchg_put(peers[i / kXchgVals] + my_row_off, vidx(w), vals[w], tag);
     }
-    // receive: the same 16 values of every rank, polled word by word
-    for (u32 i = tid; i < 16 * R; i += 256) {
-        const u32 w = i & 15, r = i >> 4;
+    // receive: the same values of every rank, polled word by word
+    for (u32 i = tid; i < (u32)kXchgVals * R; i += 256) {
+        const u32 w = i % kXchgVals, r = i / kXchgVals;
         got[r][w] = wvalid(w) ? xchg_get(win_rows + (size_t)r * W, vidx(w), tag, p2p_err) : 0ull;
     }
     __syncthreads();
@@ -1993,7 +2070,7 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
         if (jn < m) {
             u64 kept_glob = 0, claim_pre = 0, claim_glob = 0, claim_local = 0;
             for (u32 r = 0; r < R; ++r) {
-                const u64 kx = got[r][tid], cx = got[r][4 + tid];
+                const u64 kx = got[r][tid], cx = got[r][kResNodes + tid];
                 kept_glob += kx;
                 if (r < rank) claim_pre += cx;
                 if (r == rank) claim_local = cx;
@@ -2014,8 +2091,8 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
             if (claim_glob > fre) atomicAdd(&outc[0], 1ull);                          // cut nodes (global)
             if (forced || claim_local > fre - claim_pre) atomicAdd(&outc[2], 1ull);   // this rank has a local fix-up
         }
-    } else if (tid >= 8 && tid < 16) {  // global counters: word tid of this workgroup's slice, summed over the ranks
-        const int k = tid - 8;
+    } else if (tid >= 16 && tid < kXchgVals) {  // global counters: word tid of this workgroup's slice, summed over the ranks
+        const int k = tid - 16;
         u64 sum = 0;
         for (u32 r = 0; r < R; ++r) sum += got[r][tid];
         // verdict row: 0 cut nodes 1 spill rows 2 local fix-up 3 kept 4 evicted 5 claimants 6 load kept 7 load claimed
@@ -2023,100 +2100,17 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
         if (dst >= 0) atomicAdd(&outc[dst], sum);
     }
     __syncthreads();
-    if (tid == 0) {  // four bits of the forced bitmap belong to this workgroup alone (4 | 32)
+    if (tid == 0) {  // eight bits of the forced bitmap belong to this workgroup alone (8 | 32)
         const u32 w = (b * kResNodes) >> 5, sh = (b * kResNodes) & 31;
-        atomicAnd(&forced_bits[w], ~(0xFu << sh));
+        atomicAnd(&forced_bits[w], ~(0xFFu << sh));
         if (nib) atomicOr(&forced_bits[w], nib << sh);
         if (b == 0) *rank_base = 0;
     }
     if (tid < 8) host_partial[(size_t)b * 8 + tid] = outc[tid];
 }
 
-// K2p k_resolve_put — row-sharded solve with peer-to-peer windows: the local column sums of H (as k_resolve) are
-//     stored straight into EVERY peer's window; the last workgroup to finish (agent-scope counter) folds the row
-//     counters, stores them too, and only then publishes this rank's flag to every peer.  Replaces
-//     k_resolve + pack + put (three launches) on that path.  R <= 32.
-__global__ __launch_bounds__(256) void k_resolve_put(const u64* __restrict__ H, const u64* __restrict__ blkstat, Plan p,
-                                                     u64* __restrict__ partial, u64* const* __restrict__ peers, u32 R,
-                                                     size_t data_off, size_t flag_off, u64 seq,
-                                                     unsigned int* __restrict__ counter) {
-    __shared__ u64 part[kResRowGroups][8];
-    __shared__ u64 tot[8];
-    __shared__ u64 red[8];
-    __shared__ u32 is_last;
-    const int tid = threadIdx.x, lane = tid & 63, col = tid & 7, rg = tid >> 3;
-    const u32 m = p.m, G = p.G, nb = gridDim.x;
-    const u32 j = blockIdx.x * kResNodes + (col & 3);
-    const bool valid = j < m;
-    const size_t c = (col < 4) ? (size_t)j : (size_t)m + j;
-    u64 v[kResRows];
-#pragma unroll
-    for (int r = 0; r < kResRows; ++r) {
-        const u32 row = rg + r * kResRowGroups;
-        v[r] = (valid && row < G) ? H[(size_t)row * 2 * m + c] : 0;
-    }
-    u64 sacc = 0;
-#pragma unroll
-    for (int r = 0; r < kResRows; ++r) sacc += v[r];
-    part[rg][col] = sacc;
-    if (tid < 8) red[tid] = 0;
-    __syncthreads();
-    if (tid < 8) {
-        u64 t = 0;
-#pragma unroll
-        for (int g = 0; g < kResRowGroups; ++g) t += part[g][tid];
-        tot[tid] = t;
-    }
-    __syncthreads();
-    if (tid < 8 * (int)R && valid) {  // thread = (peer, column): this workgroup's 8 sums into every window
-        u64* dst = peers[tid >> 3] + data_off;
-        RIOGP_SYS_STORE(dst + c, tot[col]);
-    }
-    if (tid == 0) {
-        u64 a = 0, b = 0;
-        for (int q = 0; q < 4; ++q)
-            if (blockIdx.x * kResNodes + q < m) { a += tot[q]; b += tot[q + 4]; }
-        red[0] = a;
-        red[1] = b;
-    }
-    if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
-        u64 acc = 0;
-        for (u32 r = blockIdx.x + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
-        acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
-        if (lane < 4) red[3 + lane] = acc;
-    }
-    __syncthreads();
-    // No release FENCE here: a system-scope release is buffer_wbl2 = write back every dirty L2 line, and k_scan has just
-    // dirtied megabytes of them (measured 17.6 us for this kernel with one fence per workgroup, against 4.5 us).  Every
-    // store that another agent or workgroup consumes is instead an sc0/sc1 write-through atomic, and s_waitcnt vmcnt(0)
-    // is their completion (MI355X_MICROARCH.md, "valid forms": 8-B atomics on both sides need no fence).
-    if (tid < 8)
-        __hip_atomic_store(partial + (size_t)blockIdx.x * 8 + tid, (tid < 7) ? red[tid] : 1ull, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) is_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
-    __syncthreads();
-    if (!is_last) return;
-    if (tid < 8) red[tid] = 0;
-    __syncthreads();
-    {
-        u64 acc = 0;
-        for (u32 r = rg; r < nb; r += kResRowGroups)
-            acc += __hip_atomic_load(partial + (size_t)r * 8 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(&red[col], acc);
-    }
-    __syncthreads();
-    if (tid < 8 * (int)R) RIOGP_SYS_STORE(peers[tid >> 3] + data_off + 2 * (size_t)m + col, red[col]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < (int)R) RIOGP_SYS_STORE(peers[tid] + flag_off, seq);
-    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <bool P2P>
-__global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__ Xg, size_t W, const u64* __restrict__ wait_flags,
-                                                         u64 seq, u64* __restrict__ p2p_err, u32 rank, u32 R, u32 m,
+// global resolve of the all-gathered X records (RCCL paths): one workgroup, every node
+__global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__ Xg, size_t W, u32 rank, u32 R, u32 m,
                                                          const u64* __restrict__ cap,
                                                          const u32* __restrict__ alive_bits,
                                                          u64* __restrict__ used_kept, u64* __restrict__ used_cur,
@@ -2130,8 +2124,6 @@ __global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__
     __shared__ u64 red[8];
     const int tid = threadIdx.x;
     const u32 mwords = (m + 31) / 32;
-    if (P2P) p2p_wait(wait_flags, R, seq, p2p_err);  // the records arrive while this kernel is already resident
-    auto ldx = [&](size_t k) -> u64 { return P2P ? RIOGP_SYS_LOAD(Xg + k) : Xg[k]; };
     for (u32 k = tid; k < mwords; k += kBlock) fb[k] = 0;
     if (tid < 8) red[tid] = 0;
     __syncthreads();
@@ -2139,7 +2131,7 @@ __global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__
     for (u32 j = tid; j < m; j += kBlock) {
         u64 kept_glob = 0, claim_pre = 0, claim_glob = 0, claim_local = 0;
         for (u32 r = 0; r < R; ++r) {
-            const u64 kx = ldx(r * W + j), cx = ldx(r * W + m + j);
+            const u64 kx = Xg[r * W + j], cx = Xg[r * W + m + j];
             kept_glob += kx;
             if (r < rank) claim_pre += cx;
             if (r == rank) claim_local = cx;
@@ -2168,7 +2160,7 @@ __global__ __launch_bounds__(kBlock) void k_shard_import(const u64* __restrict__
     }
     if (tid < 8) {  // global counters: column tid of every rank's record
         u64 s = 0;
-        for (u32 r = 0; r < R; ++r) s += ldx(r * W + 2 * (size_t)m + tid);
+        for (u32 r = 0; r < R; ++r) s += Xg[r * W + 2 * (size_t)m + tid];
         // k_resolve's partial columns: 0 load_kept 1 load_claim 2 (local n_cut, unused) 3 kept 4 evicted 5 claimants 6 spillcand
         const int dst = tid == 0 ? 6 : tid == 1 ? 7 : tid == 3 ? 3 : tid == 4 ? 4 : tid == 5 ? 5 : tid == 6 ? 1 : -1;
         if (dst >= 0) atomicAdd(&red[dst], s);
@@ -2251,22 +2243,20 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
     return (unsigned)g;
 }
 
-int g_scan_tpi = 2;  // tiles per wave-iteration of k_scan (1 | 2 | 4): 2 measured +2.5 % over 1, 4 loses to its unpipelined tail; set_scan_tpi() for A/B runs
-void set_scan_tpi(int tpi) { g_scan_tpi = tpi; }
 int cut_trace_enable(int on) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_trace_on), &on, sizeof on); }
 int cut_trace_read(u64* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cut_trace), sizeof(u64) * kMaxBlocks * 8); }
 
-template <bool VIRT, bool AA, int TPI, int HMODE = 0, bool COMPACT = false>
+template <bool VIRT, bool AA, int TPI, bool COMPACT = false, bool NT = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
                           hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr) {
     const size_t lds = scan_lds_bytes(p.m);
     const PackOut pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
-        hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE, COMPACT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
+        hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
                               t.cur, t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
                               b.stats, pko);
     else
-        hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, HMODE, COMPACT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
+        hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
                            t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko);
 }
 
@@ -2274,11 +2264,18 @@ void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t 
     hipLaunchKernelGGL(k_pk_scatter, dim3(p.G), dim3(kBlock), 0, s, p, pk.idx, pk.next, next);
 }
 
+// Tiles per wave-iteration: 2 on the plain whole-table scan (measured +2.5 % over 1; 4 loses to its unpipelined tail),
+// 1 where the row body is heavier (packing) or the table is small (virtual table of place_pending).
+// Non-temporal streams once the four columns no longer fit the 256 MiB Infinity Cache.
+constexpr u64 kScanNtRows = (u64)20 << 20;  // 16 B/row * 20 Mi rows = 320 MiB of columns
+int g_scan_nt_mode = 0;  // 0 by size | 1 always | 2 never (rio_gp_debug_set_scan_nt, A/B runs)
+void set_scan_nt(int mode) { g_scan_nt_mode = mode; }
+
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
                  hipStream_t s, hipEvent_t e0, hipEvent_t e1, const PackOut* pack) {
     if (pack && !virt) {  // k_scan that also packs the pending rows of every wave (adaptive fix-up, rio_gp_capi.hip)
-        if (all_alive) launch_scan_t<false, true, 1, 0, true>(p, t, nt, b, s, e0, e1, pack);
-        else launch_scan_t<false, false, 1, 0, true>(p, t, nt, b, s, e0, e1, pack);
+        if (all_alive) launch_scan_t<false, true, 1, true>(p, t, nt, b, s, e0, e1, pack);
+        else launch_scan_t<false, false, 1, true>(p, t, nt, b, s, e0, e1, pack);
         return;
     }
     if (virt) {
@@ -2286,16 +2283,13 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
         else launch_scan_t<true, false, 1>(p, t, nt, b, s, e0, e1);
         return;
     }
-#define RIOGP_DISPATCH(TPI)                                                     \
-    if (all_alive) launch_scan_t<false, true, TPI>(p, t, nt, b, s, e0, e1);     \
-    else launch_scan_t<false, false, TPI>(p, t, nt, b, s, e0, e1);
-    if (g_scan_tpi == 11) { launch_scan_t<false, true, 1, 1>(p, t, nt, b, s, e0, e1); return; }  // experiment: no atomics
-    if (g_scan_tpi == 12) { launch_scan_t<false, true, 1, 2>(p, t, nt, b, s, e0, e1); return; }  // experiment: u32 atomics
-    if (g_scan_tpi == 1) { RIOGP_DISPATCH(1) }
-    else if (g_scan_tpi == 4) { RIOGP_DISPATCH(4) }
-    else if (g_scan_tpi == 2) { RIOGP_DISPATCH(2) }
-    else { RIOGP_DISPATCH(1) }
-#undef RIOGP_DISPATCH
+    if (g_scan_nt_mode == 1 || (g_scan_nt_mode == 0 && p.n >= kScanNtRows)) {
+        if (all_alive) launch_scan_t<false, true, 2, false, true>(p, t, nt, b, s, e0, e1);
+        else launch_scan_t<false, false, 2, false, true>(p, t, nt, b, s, e0, e1);
+        return;
+    }
+    if (all_alive) launch_scan_t<false, true, 2>(p, t, nt, b, s, e0, e1);
+    else launch_scan_t<false, false, 2>(p, t, nt, b, s, e0, e1);
 }
 
 unsigned resolve_blocks(u32 m) {
@@ -2389,30 +2383,33 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_lookup, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, idx, n, out, st);
+    if ((((uintptr_t)idx | (uintptr_t)out) & 15u) == 0)
+        hipLaunchKernelGGL(k_lookup4, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, s, assign, n_obj, idx, n, out, st);
+    else
+        hipLaunchKernelGGL(k_lookup, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, idx, n, out, st);
 }
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos, DevStats* st,
-                   hipStream_t s) {
+                   hipStream_t s, u32* aff_life) {
     if (!n) return;
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
-    hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos);
+    hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos, aff_life);
 }
-void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s) {
+void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life) {
     if (!n) return;
-    hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n);
+    hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n, aff_life);
 }
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
-                   hipStream_t s) {
+                   hipStream_t s, u32* aff_life) {
     if (!n) return;
     hipLaunchKernelGGL(k_remove, dim3(grid_for(n, kBlock * 4, 256)), dim3(kBlock), used ? (size_t)m * sizeof(u64) : 0, s, assign,
-                       n_obj, m, load, idx, n, used, st);
+                       n_obj, m, load, idx, n, used, st, aff_life);
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
-                  u64* counter, unsigned int* ticket, u64* host_out) {
+                  u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life) {
     const size_t lds = (size_t)((m + 31) / 32 + 4) * sizeof(u32);
     hipLaunchKernelGGL(k_clean, dim3(grid_for((n_obj + 3) / 4, 256, 2048)), dim3(256), lds, s, assign, n_obj, m,
-                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out);
+                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out, aff_life);
 }
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s) {
     (void)hipMemsetAsync(used, 0, (size_t)m * sizeof(u64), s);
@@ -2443,9 +2440,10 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
     hipLaunchKernelGGL(k_pack_alive, dim3((w + 63) / 64), dim3(64), 0, s, alive_bytes, m, alive_bits);
 }
 void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
-                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s) {
+                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
+                     u32* aff_life) {
     hipLaunchKernelGGL(k_pp_small, dim3(1), dim3(kSmallBatch), 0, s, assign, load, m, cap, alive_bits, used, pos, idx, req, n,
-                       out_node, out_flag, status);
+                       out_node, out_flag, status, aff_life);
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s) {
@@ -2461,11 +2459,11 @@ void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const 
 }
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext, u32* pos,
                        const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node, u32* out_flag,
-                       hipStream_t s) {
+                       hipStream_t s, u32* aff_life) {
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_pp_scatter, dim3(g), dim3(256), 0, s, assign, idx, n, vcur, vnext);
     hipLaunchKernelGGL(k_pp_output, dim3(g), dim3(256), 0, s, assign, idx, req, n, vcur, pos, alive_bits,
-                       cutidx_or_null, m, out_node, out_flag);
+                       cutidx_or_null, m, out_node, out_flag, aff_life);
 }
 
 void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s) {
@@ -2473,23 +2471,11 @@ void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s
                        resolve_blocks(p.m), p.m, X);
 }
 void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, const u64* Xg, u32 rank, u32 R,
-                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s,
-                         size_t row_stride, const u64* wait_flags, u64 seq, u64* p2p_err) {
+                         u64* gprev, u64* gfinal, u64* verdict_dev, u64* verdict_host, hipStream_t s) {
     const size_t lds = (size_t)(p.mwords + 4) * sizeof(u32);
-    const size_t W = row_stride ? row_stride : shard_words1(p.m);
-    if (wait_flags)
-        hipLaunchKernelGGL(k_shard_import<true>, dim3(1), dim3(kBlock), lds, s, Xg, W, wait_flags, seq, p2p_err, rank, R,
-                           p.m, nt.cap, nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, gprev,
-                           gfinal, b.forced_bits, b.rank_base, verdict_dev, verdict_host);
-    else
-        hipLaunchKernelGGL(k_shard_import<false>, dim3(1), dim3(kBlock), lds, s, Xg, W, (const u64*)nullptr, 0ull,
-                           (u64*)nullptr, rank, R, p.m, nt.cap, nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot,
-                           b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits, b.rank_base, verdict_dev, verdict_host);
-}
-void launch_resolve_put(const Plan& p, const SolveBufs& b, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off,
-                        u64 seq, unsigned int* counter, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve_put, dim3(resolve_blocks(p.m)), dim3(256), 0, s, b.H, b.blkstat, p, b.partial, d_peers, R,
-                       data_off, flag_off, seq, counter);
+    hipLaunchKernelGGL(k_shard_import, dim3(1), dim3(kBlock), lds, s, Xg, shard_words1(p.m), rank, R, p.m, nt.cap,
+                       nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits,
+                       b.rank_base, verdict_dev, verdict_host);
 }
 void launch_resolve_xchg(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* const* d_peers, u32 R, u32 rank,
                          size_t my_row_off, const u64* win_rows, size_t W, u64 seq, u64* p2p_err, u64* gprev, u64* gfinal,

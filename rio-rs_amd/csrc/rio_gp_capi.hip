@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/rio_gpu_placement.h"
+#include "../../include/rio_gpu_placement_debug.h"
 #include "placement_kernels.h"
 
 using namespace riogp;
@@ -62,7 +63,7 @@ struct ShardComm {
 // Peer-to-peer exchange windows (rio_gp_shard_p2p_*): one uncached window per rank, IPC-mapped by every peer.
 //   xdata [kP2PSlots][R][Wx]  k_resolve_xchg's data-tagged words of rank r (a region of its own: a raw record word whose
 //                             upper half happened to equal a step's tag would be taken for that step's data)
-//   data  [kP2PSlots][R][W]   raw record of rank r for the step using that slot (fix-up exchanges, legacy fast path)
+//   data  [kP2PSlots][R][W]   raw record of rank r for the step using that slot (fix-up exchanges)
 //   flags [kP2PSlots][R][8]   sequence number of the step whose raw record is complete (one 64 B line each)
 //   hello [R][8]              set-up handshake
 constexpr int kP2PSlots = 4;
@@ -76,7 +77,6 @@ struct P2P {
     u64* d_err = nullptr;         // set by a waiting kernel that timed out
     u64* scratch = nullptr;       // [W] staging of the local record
     u64 seq = 0;
-    unsigned int* d_counter = nullptr;  // k_resolve_put's "last workgroup" counter (self-resetting)
     size_t xdata_off(u32 slot, u32 r) const { return ((size_t)slot * R + r) * Wx; }
     size_t xwords() const { return (size_t)kP2PSlots * R * Wx; }
     size_t data_off(u32 slot, u32 r) const { return xwords() + ((size_t)slot * R + r) * W; }
@@ -91,6 +91,7 @@ struct rio_gp {
     std::mutex mu;
     std::string err;
     int device = 0;
+    bool lifecycle = false;            // RIO_GP_CFG_ROW_LIFECYCLE: the affinity column also says which rows are objects
     hipStream_t stream = nullptr;      // the stream every call of this handle is enqueued on
     hipStream_t own_stream = nullptr;  // created by rio_gp_create (rio_gp_set_stream may point `stream` elsewhere)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -127,7 +128,6 @@ struct rio_gp {
     u64 *sh_lkept = nullptr, *sh_lclaim = nullptr, *sh_lcur = nullptr;
     u32 *sh_lcutblk = nullptr, *sh_lcutidx = nullptr;
     u32 sh_rows = 1;        // verdict rows of the last shard resolve in its pinned slot (1 | resolve_blocks(m))
-    bool p2p_fused = true;  // peer-to-peer fast path as ONE launch (k_resolve_xchg); RIO_GP_P2P_LEGACY=1: put + import
     u32 sh_rank = 0, sh_R = 1;
     int sh_state = 0;       // 0 idle | 1 scanned | 2 resolved | 3 cut exported | 4 merged | 5 spill exported
     bool sh_slow = false;   // the solve in flight took the fix-up path
@@ -169,7 +169,6 @@ namespace {
 void p2p_free(rio_gp* h) {
     P2P* q = h->p2p;
     if (!q) return;
-    if (q->d_counter) (void)hipFree(q->d_counter);
     for (void* o : q->opened) if (o) (void)hipIpcCloseMemHandle(o);
     if (q->d_peers) (void)hipFree(q->d_peers);
     if (q->d_err) (void)hipFree(q->d_err);
@@ -232,7 +231,8 @@ int ensure(rio_gp* h, DevBuf& b, size_t bytes) {
 void fill_stats(const DevStats& d, u64 n, rio_gp_stats* s) {
     if (!s) return;
     memset(s, 0, sizeof *s);
-    s->n_objects = n;
+    (void)n;
+    s->n_objects = d.kept + d.claimants + d.spillcand;  // = rows, minus the rows that are not objects (RIO_GP_AFF_INACTIVE)
     s->kept = d.kept;
     s->evicted = d.evicted;
     s->claimed = d.claimants - d.rejected;
@@ -247,6 +247,7 @@ void fill_stats(const DevStats& d, u64 n, rio_gp_stats* s) {
     s->rounds_run = (uint32_t)d.rounds_run;
 }
 
+u32* aff_life(rio_gp* h) { return h->lifecycle ? h->aff : nullptr; }
 Table real_table(rio_gp* h) { return Table{h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1]}; }
 NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; }
 
@@ -425,8 +426,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     }
     rio_gp* h = new rio_gp();
     h->device = cfg->device;
-    if (const char* e = getenv("RIO_GP_SCAN_TPI")) set_scan_tpi(atoi(e));  // A/B knob for bench runs
-    if (const char* e = getenv("RIO_GP_P2P_LEGACY")) h->p2p_fused = atoi(e) == 0;
+    h->lifecycle = (cfg->flags & RIO_GP_CFG_ROW_LIFECYCLE) != 0;
     h->cap_obj = cfg->max_objects;
     h->cap_rows = ((cfg->max_objects + kTile - 1) / kTile) * kTile + 8 * kTile;  // k_scan prefetches past the end
     h->cap_nodes = cfg->max_nodes ? cfg->max_nodes : 1;
@@ -448,7 +448,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->assign[0], R); A(h->assign[1], R); A(h->load, R); A(h->aff, R); A(h->pos, R);
     A(h->cap, M); A(h->used, M); A(h->alive_bits, (M + 31) / 32 + 4); A(h->dead_bits, (M + 31) / 32 + 4);
     A(h->alive_bytes, M);
-    A(h->sb.H, (size_t)kMaxBlocks * 2 * M); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
+    A(h->sb.H, (size_t)((M + 7) / 8) * kMaxBlocks * 16); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
     A(h->sb.partial, (size_t)resolve_blocks((u32)M) * 8 + 8);
     A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
     A(h->sb.wsp_base, W);
@@ -621,7 +621,7 @@ static int set_objects_impl(rio_gp_t* h, uint64_t n, const uint32_t* load, const
     if (load) { if (n) HIPCHK(h, hipMemcpyAsync(h->load, load, n * sizeof(u32), kind, h->stream)); }
     else launch_fill_u32(h->load, n, 1u, h->stream);
     if (aff) { if (n) HIPCHK(h, hipMemcpyAsync(h->aff, aff, n * sizeof(u32), kind, h->stream)); }
-    else launch_fill_u32(h->aff, n, kNone, h->stream);
+    else launch_fill_u32(h->aff, n, h->lifecycle ? kAffInactive : kNone, h->stream);
     launch_fill_u32(h->assign[h->cur], h->cap_rows, kNone, h->stream);
     HIPCHK(h, hipMemsetAsync(h->used, 0, (size_t)h->cap_nodes * sizeof(u64), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -673,6 +673,16 @@ int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RIO_GP_OK;
 }
+int rio_gp_get_objects(rio_gp_t* h, uint64_t n, uint32_t* out_load, uint32_t* out_aff) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n != h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_get_objects: n differs from the object table");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n && out_load) HIPCHK(h, hipMemcpyAsync(out_load, h->load, n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    if (n && out_aff) HIPCHK(h, hipMemcpyAsync(out_aff, h->aff, n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RIO_GP_OK;
+}
 int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* load, const uint32_t* aff) {
     if (!h || (n && !idx)) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
@@ -703,6 +713,16 @@ int rio_gp_count_placed(rio_gp_t* h, uint64_t* out) {
     launch_count_placed(h->assign[h->cur], h->n, h->dstats, h->stream);
     if ((rc = read_stats(h))) return rc;
     *out = h->h_stats[0].evicted_clean;
+    return RIO_GP_OK;
+}
+
+int rio_gp_set_num_objects(rio_gp_t* h, uint64_t n) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n > h->cap_obj) return fail(h, RIO_GP_EINVAL, "rio_gp_set_num_objects: n exceeds max_objects");
+    h->n = n;  // rows keep their contents: rows >= n simply take no part (and are rejected as indices) until n grows again
+    h->have_solved = false;
+    h->last_pending_valid = false;
     return RIO_GP_OK;
 }
 
@@ -752,7 +772,7 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
 static int update_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node) {
     int rc = zero_stats(h);
     if (rc) return rc;
-    launch_update(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, h->pos, h->dstats, h->stream);
+    launch_update(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, h->pos, h->dstats, h->stream, aff_life(h));
     h->used_valid = false;
     h->have_solved = false;
     if ((rc = read_stats(h))) return rc;
@@ -781,7 +801,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         // validated above, so the kernels read them from mapped pinned memory and nothing is copied, zeroed or read back
         memcpy(h->h_small, idx, n * sizeof(u32));
         memcpy(h->h_small + kSmallBatch, node, n * sizeof(u32));
-        launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream);
+        launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream, aff_life(h));
         h->used_valid = false;
         h->have_solved = false;
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -798,7 +818,7 @@ static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
     int rc = zero_stats(h);
     if (rc) return rc;
     launch_remove(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, h->used_valid ? h->used : nullptr, h->dstats,
-                  h->stream);
+                  h->stream, aff_life(h));
     h->have_solved = false;
     if ((rc = read_stats(h))) return rc;
     if (h->h_stats[0].err) return fail(h, RIO_GP_EINVAL, "rio_gp_remove_batch: invalid entries were skipped");
@@ -823,7 +843,7 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     if (n <= (uint64_t)kSmallBatch) {  // micro-batch: validated above, read from mapped pinned memory, one launch + one wait
         memcpy(h->h_small, idx, n * sizeof(u32));
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_small, n, h->used_valid ? h->used : nullptr, h->dstats,
-                      h->stream);
+                      h->stream, aff_life(h));
         h->have_solved = false;
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
@@ -852,7 +872,7 @@ int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evi
     h->have_solved = false;
     if (!any) return RIO_GP_OK;  // retain() with a predicate nothing matches
     launch_clean(h->assign[h->cur], h->n, h->m, h->d_cs, h->used_valid ? h->used : nullptr, h->dstats, h->stream,
-                 h->cs_cnt, h->cs_ticket, reinterpret_cast<u64*>(h->d_cs + h->cs_words));
+                 h->cs_cnt, h->cs_ticket, reinterpret_cast<u64*>(h->d_cs + h->cs_words), aff_life(h));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     if (evicted) *evicted = *h_count;
@@ -877,6 +897,51 @@ int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
 
 // ---- policy -------------------------------------------------------------------------------
 
+// The general path of place_pending over DEVICE-resident request / result arrays (the host-pointer call stages into
+// these, the _dev call hands its own): mark dead -> clean -> elect first request -> gather the virtual table -> solve it
+// against the committed `used` (same kernels, VIRT) -> scatter + outputs.  check_entries: the entries were not
+// validated on the host, so k_pp_mark_dead's count of bad ones is read BEFORE anything is changed.
+static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const u32* d_req, u32* d_out, u32* d_flag,
+                                 bool check_entries) {
+    int rc;
+    const size_t bytes = n * sizeof(u32);
+    for (int q = 0; q < 4; ++q)
+        if ((rc = ensure(h, h->vt[q], bytes))) return rc;
+    u32 *vcur = (u32*)h->vt[0].p, *vload = (u32*)h->vt[1].p, *vaff = (u32*)h->vt[2].p, *vnext = (u32*)h->vt[3].p;
+    u32* assign = h->assign[h->cur];
+    if ((rc = ensure_used(h))) return rc;
+    if ((rc = zero_stats(h))) return rc;
+    // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
+    launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream);
+    if (check_entries) {
+        if ((rc = read_stats(h))) return rc;
+        if (h->h_stats[0].err)
+            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
+    }
+    launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
+    // (2)(3) first request per row decides; gather the virtual table (rows = requests)
+    launch_pp_gather(assign, h->load, d_idx, d_req, n, h->pos, vcur, vload, vaff, h->stream);
+    // (4) solve the virtual table against the committed `used`
+    const Plan vp = make_plan(n, h->m, 0);
+    const Table vtab{vcur, vload, vaff, vnext};
+    const NodeTab vnt{h->cap, h->alive_bits, h->used};
+    launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
+    launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    {
+        const DevStats v = reduce_slot(h, 0, h->m);
+        if (v.n_cut > 0 || v.spillcand > 0) enqueue_slow(h, vp, vtab, vnt, true, v);
+    }
+    // (5) publish, outputs, new `used`
+    launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
+                      h->stream, aff_life(h));
+    HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
+                             hipMemcpyDeviceToDevice, h->stream));
+    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
 int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* requester,
                          uint32_t* out_node, uint32_t* out_flag) {
     if (!h || (n && (!idx || !requester || !out_node))) return RIO_GP_EINVAL;
@@ -896,7 +961,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         memcpy(hs + kSmallBatch, requester, n * sizeof(u32));
         hs[4 * kSmallBatch] = 2;  // neither 0 nor 1: the kernel must write it
         launch_pp_small(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, h->pos, ds, ds + kSmallBatch,
-                        (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream);
+                        (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         const u32 status = hs[4 * kSmallBatch];
@@ -910,45 +975,31 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         // status 1: a dead node / dead or full requester is involved — nothing was changed, take the general path
     }
     const size_t bytes = n * sizeof(u32);
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q)
         if ((rc = ensure(h, h->stage[q], bytes))) return rc;
-        if ((rc = ensure(h, h->vt[q], bytes))) return rc;
-    }
     u32 *d_idx = (u32*)h->stage[0].p, *d_req = (u32*)h->stage[1].p, *d_out = (u32*)h->stage[2].p,
         *d_flag = (u32*)h->stage[3].p;
-    u32 *vcur = (u32*)h->vt[0].p, *vload = (u32*)h->vt[1].p, *vaff = (u32*)h->vt[2].p, *vnext = (u32*)h->vt[3].p;
-    u32* assign = h->assign[h->cur];
-    if ((rc = ensure_used(h))) return rc;
     HIPCHK(h, hipMemcpyAsync(d_idx, idx, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_req, requester, bytes, hipMemcpyHostToDevice, h->stream));
-    if ((rc = zero_stats(h))) return rc;
-    // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
-    launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream);
-    launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream);
-    // (2)(3) first request per row decides; gather the virtual table (rows = requests)
-    launch_pp_gather(assign, h->load, d_idx, d_req, n, h->pos, vcur, vload, vaff, h->stream);
-    // (4) solve the virtual table against the committed `used`
-    const Plan vp = make_plan(n, h->m, 0);
-    const Table vtab{vcur, vload, vaff, vnext};
-    const NodeTab vnt{h->cap, h->alive_bits, h->used};
-    launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
-    launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
-    {
-        const DevStats v = reduce_slot(h, 0, h->m);
-        if (v.n_cut > 0 || v.spillcand > 0) enqueue_slow(h, vp, vtab, vnt, true, v);
-    }
-    // (5) publish, outputs, new `used`
-    launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
-                      h->stream);
-    HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
-                             hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = place_pending_general(h, n, d_idx, d_req, d_out, d_flag, false))) return rc;
     HIPCHK(h, hipMemcpyAsync(out_node, d_out, bytes, hipMemcpyDeviceToHost, h->stream));
     if (out_flag) HIPCHK(h, hipMemcpyAsync(out_flag, d_flag, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
-    h->have_solved = false;
+    return RIO_GP_OK;
+}
+
+int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_requester,
+                             uint32_t* d_out_node, uint32_t* d_out_flag) {
+    if (!h || (n && (!d_idx || !d_requester || !d_out_node))) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!n) return RIO_GP_OK;
+    if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: batch too large");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = place_pending_general(h, n, d_idx, d_requester, d_out_node, d_out_flag, true);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
     return RIO_GP_OK;
 }
 
@@ -1275,8 +1326,6 @@ int rio_gp_shard_p2p_connect(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&q->scratch), q->W * sizeof(u64)));
     HIPCHK(h, hipMemcpy(q->d_peers, bases.data(), n_ranks * sizeof(u64*), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(q->d_err, 0, sizeof(u64)));
-    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&q->d_counter), sizeof(unsigned int)));
-    HIPCHK(h, hipMemset(q->d_counter, 0, sizeof(unsigned int)));
     // handshake: every rank stores a token into every peer's hello line and waits for all of theirs (3 s limit)
     const u64 token = 0xC0FFEE0000000001ull;
     launch_p2p_put(q->scratch, 0, q->d_peers, n_ranks, 0, q->hello_off(rank), token, h->stream);
@@ -1381,11 +1430,9 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     if (h->p2p && h->p2p->d_peers) {
-        // peer-to-peer, ONE stream, three launches, no collective call and no host wait:
-        //   k_scan -> k_resolve_put (local sums stored straight into every peer's window over xGMI, flag last)
-        //          -> k_shard_import (waits in-kernel for every rank's flag of this solve, then the global resolve)
+        // peer-to-peer, ONE stream, two launches, no collective call and no host wait: k_scan -> k_resolve_xchg.
         // Stream order is the flow control: a rank's record j+1 leaves only after it consumed everyone's record j,
-        // so none of the 4 window slots is overwritten while its owner still reads it.  (Running the import on a
+        // so none of the 4 window slots is overwritten while its owner still reads it.  (Running the exchange on a
         // second stream under the next scan was measured SLOWER on gfx950: two event records + two stream waits per
         // solve cost more than the 5 us they hide.)
         P2P* q = h->p2p;
@@ -1399,24 +1446,15 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         h->sh_R = q->R;
         h->sh_slot = h->ring_n;
         h->sh_side = nullptr;
-        if (h->p2p_fused) {
-            // ONE launch behind the scan: every workgroup exchanges and resolves its own four nodes (k_resolve_xchg);
-            // the verdict arrives as resolve_blocks(m) partial rows in the pinned slot
-            SolveBufs xb = shard_bufs(h);
-            xb.H = h->sb.H;
-            xb.blkstat = h->sb.blkstat;
-            launch_resolve_xchg(h->plan, nt, xb, q->d_peers, q->R, q->rank, q->xdata_off(slot, q->rank),
-                                q->win + q->xdata_off(slot, 0), q->Wx, seq, q->d_err, h->sh_gprev, h->sh_gfinal,
-                                slot_dev(h, h->ring_n), h->stream);
-            h->sh_rows = resolve_blocks(h->m);
-        } else {
-            launch_resolve_put(h->plan, h->sb, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq,
-                               q->d_counter, h->stream);
-            launch_shard_import(h->plan, nt, shard_bufs(h), q->win + q->data_off(slot, 0), q->rank, q->R, h->sh_gprev,
-                                h->sh_gfinal, h->sh_verdict, slot_dev(h, h->ring_n), h->stream, q->W,
-                                q->win + q->flag_off(slot, 0), seq, q->d_err);
-            h->sh_rows = 1;
-        }
+        // ONE launch behind the scan: every workgroup exchanges and resolves its own node group (k_resolve_xchg);
+        // the verdict arrives as resolve_blocks(m) partial rows in the pinned slot
+        SolveBufs xb = shard_bufs(h);
+        xb.H = h->sb.H;
+        xb.blkstat = h->sb.blkstat;
+        launch_resolve_xchg(h->plan, nt, xb, q->d_peers, q->R, q->rank, q->xdata_off(slot, q->rank),
+                            q->win + q->xdata_off(slot, 0), q->Wx, seq, q->d_err, h->sh_gprev, h->sh_gfinal,
+                            slot_dev(h, h->ring_n), h->stream);
+        h->sh_rows = resolve_blocks(h->m);
         h->ring_n++;
         h->have_solved = false;
         h->sh_state = 2;
@@ -1473,7 +1511,7 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
     return RIO_GP_OK;
 }
 
-void rio_gp_debug_set_scan_tpi(int tpi) { set_scan_tpi(tpi); }
+void rio_gp_debug_set_scan_nt(int mode) { set_scan_nt(mode); }
 
 int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048) {
     if (!h) return RIO_GP_EINVAL;

@@ -14,12 +14,15 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "librio_gp.so")
 NONE = 0xFFFFFFFF
 CAP_INF = 0xFFFFFFFFFFFFFFFF
+AFF_INACTIVE = 0xFFFFFFFE       # RIO_GP_AFF_INACTIVE: affinity of a row that is not an object
+CFG_ROW_LIFECYCLE = 1           # RIO_GP_CFG_ROW_LIFECYCLE
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM = range(5)
 
 SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "stream_probe.hip",
                                                      "gpu_object_placement.cpp")]
 HEADERS = [os.path.join(_DIR, "csrc", "placement_kernels.h"),
+           os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_placement_debug.h"),
            os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_placement.h"),
            os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_object_placement.h")]
 
@@ -113,6 +116,11 @@ def lib():
         L.rio_gp_solve_wait.argtypes = [_vp, C.POINTER(Stats), C.POINTER(C.c_uint32)]
         L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rio_gp_set_object_attrs.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp]
+        L.rio_gp_get_objects.argtypes = [_vp, C.c_uint64, _vp, _vp]
+        L.rio_gp_set_num_objects.argtypes = [_vp, C.c_uint64]
+        L.rio_gp_place_pending_dev.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp]
+        L.rio_gp_debug_set_scan_nt.argtypes = [C.c_int]
+        L.rio_gp_debug_set_scan_nt.restype = None
         L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
         L.rio_gp_debug_cut_trace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
@@ -134,9 +142,9 @@ def _u32(a):
 class GpuPlacement:
     """Dense-index layer: thin, 1:1 over rio_gp_*.  Arrays are numpy uint32/uint64."""
 
-    def __init__(self, max_objects, max_nodes, device=0, spill_rounds=2):
+    def __init__(self, max_objects, max_nodes, device=0, spill_rounds=2, flags=0):
         self._h = _vp()
-        cfg = Cfg(C.sizeof(Cfg), device, max_objects, max_nodes, spill_rounds, 0, 0)
+        cfg = Cfg(C.sizeof(Cfg), device, max_objects, max_nodes, spill_rounds, flags, 0)
         rc = lib().rio_gp_create(C.byref(cfg), C.byref(self._h))
         if rc != OK:
             text = (lib().rio_gp_last_error(None) or b"").decode()
@@ -195,6 +203,15 @@ class GpuPlacement:
         """Change load and/or affinity of individual rows (either may be None = leave as is)."""
         idx, load, aff = _u32(idx), _u32(load), _u32(aff)
         self._chk(lib().rio_gp_set_object_attrs(self._h, len(idx), _ptr(idx), _ptr(load), _ptr(aff)))
+
+    def get_objects(self):
+        n = self.num_objects
+        load, aff = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        self._chk(lib().rio_gp_get_objects(self._h, n, _ptr(load), _ptr(aff)))
+        return load, aff
+
+    def set_num_objects(self, n):
+        self._chk(lib().rio_gp_set_num_objects(self._h, n))
 
     def set_objects_dev(self, n, d_load, d_aff):
         self._chk(lib().rio_gp_set_objects_dev(self._h, n, _vp(d_load), _vp(d_aff)))
@@ -260,6 +277,11 @@ class GpuPlacement:
         self._chk(lib().rio_gp_place_pending(self._h, len(idx), _ptr(idx), _ptr(requester), _ptr(node), _ptr(flag)))
         return node, flag
 
+    def place_pending_dev(self, n, d_idx, d_requester, d_out_node, d_out_flag=None):
+        """Device pointers (ints): request and result arrays already resident in HBM."""
+        self._chk(lib().rio_gp_place_pending_dev(self._h, n, _vp(d_idx), _vp(d_requester), _vp(d_out_node),
+                                                 _vp(d_out_flag) if d_out_flag else None))
+
     def solve(self):
         st = Stats()
         self._chk(lib().rio_gp_solve(self._h, C.byref(st)))
@@ -303,8 +325,10 @@ class GpuPlacement:
         self._chk(lib().rio_gp_debug_set_compact(self._h, {"auto": 0, "always": 1, "never": 2}.get(mode, mode)))
 
     def set_fixup(self, fused=True, speculate="auto"):
-        """fused cut fix-up on/off; speculative enqueue auto | always | never (results identical in every mode)."""
-        self._chk(lib().rio_gp_debug_set_fixup(self._h, 1 if fused else 0,
+        """cut fix-up implementation: "split" / 2 (default: k_cut_find + k_cut_apply), True / 1 (one fused launch),
+        False / 0 (the unfused chain); speculative enqueue auto | always | never (results identical in every mode)."""
+        impl = {"split": 2, True: 1, False: 0}.get(fused, fused)
+        self._chk(lib().rio_gp_debug_set_fixup(self._h, int(impl),
                                                {"auto": 0, "always": 1, "never": 2}.get(speculate, speculate)))
 
     def timer_begin(self):

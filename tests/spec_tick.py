@@ -2,6 +2,7 @@
 Python for small tables.  TEST INFRASTRUCTURE: it exists so that the C oracle (oracle/placement_oracle.c) — which *is* the
 definition the GPU is held to — is itself checked against the written rules by something that shares no code with it."""
 NONE = 0xFFFFFFFF
+INACTIVE = 0xFFFFFFFE   # affinity of a row that is not an object: kept if placed on a live node, never placed otherwise
 SAT = (1 << 64) - 1
 
 
@@ -25,6 +26,8 @@ def tick(cur, load, aff, cap, alive, rounds=2):
     rest = []
     for i in pending:
         a = int(aff[i])
+        if a == INACTIVE:
+            continue                  # not an object: takes no part, stays NONE
         if not up(a):
             rest.append(i)
             continue

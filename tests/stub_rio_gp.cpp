@@ -2,7 +2,9 @@
 // just enough of it for the string layer (rio-rs_amd/csrc/gpu_object_placement.cpp) to run under ThreadSanitizer on a
 // machine without a GPU (tests/test_host_layer_races.py).  It is linked into that one test binary and nowhere else; the
 // product library has no CPU path.  Policy = the capacity-free reference policy (service.rs:193-254): sticky if the node
-// is alive, else first touch on the requester.
+// is alive, else first touch on the requester.  Like the real library it VALIDATES every index against the row count
+// and the node table it was given (RIO_GP_EINVAL, nothing mutated) — which is what exposes an id that reaches the
+// "device" ahead of the table entry it refers to — and it keeps the row-lifecycle column (RIO_GP_CFG_ROW_LIFECYCLE).
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -12,9 +14,11 @@
 
 struct rio_gp {
     std::mutex mu;
-    std::vector<uint32_t> assign;
+    std::vector<uint32_t> assign, aff, load;
     std::vector<uint8_t> alive;
+    uint64_t n = 0;
     std::string err;
+    int fail(const char* m) { err = m; return RIO_GP_EINVAL; }
 };
 
 extern "C" {
@@ -25,69 +29,113 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     if (!cfg || !out) return RIO_GP_EINVAL;
     rio_gp* h = new rio_gp();
     h->assign.assign(cfg->max_objects, RIO_GP_NONE);
+    h->aff.assign(cfg->max_objects, RIO_GP_AFF_INACTIVE);
+    h->load.assign(cfg->max_objects, 1);
     *out = h;
     return RIO_GP_OK;
 }
 void rio_gp_destroy(rio_gp_t* h) { delete h; }
 int rio_gp_set_objects(rio_gp_t* h, uint64_t n, const uint32_t*, const uint32_t*) {
     std::lock_guard<std::mutex> g(h->mu);
-    if (n > h->assign.size()) return RIO_GP_EINVAL;
+    if (n > h->assign.size()) return h->fail("stub: n exceeds max_objects");
+    h->n = n;
+    return RIO_GP_OK;
+}
+int rio_gp_set_num_objects(rio_gp_t* h, uint64_t n) {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n > h->assign.size()) return h->fail("stub: n exceeds max_objects");
+    h->n = n;
+    return RIO_GP_OK;
+}
+int rio_gp_get_objects(rio_gp_t* h, uint64_t n, uint32_t* load, uint32_t* aff) {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n != h->n) return h->fail("stub: n differs");
+    if (load) memcpy(load, h->load.data(), n * sizeof(uint32_t));
+    if (aff) memcpy(aff, h->aff.data(), n * sizeof(uint32_t));
     return RIO_GP_OK;
 }
 int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t*, const uint8_t* alive) {
     std::lock_guard<std::mutex> g(h->mu);
     h->alive.assign(m, 1);
-    if (alive) memcpy(h->alive.data(), alive, m);
+    if (alive && m) memcpy(h->alive.data(), alive, m);
+    return RIO_GP_OK;
+}
+int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive) {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (m != h->alive.size()) return h->fail("stub: m differs from the node table");
+    memcpy(h->alive.data(), alive, m);
     return RIO_GP_OK;
 }
 int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* out) {
     std::lock_guard<std::mutex> g(h->mu);
-    for (uint64_t k = 0; k < n; ++k) {
-        if (idx[k] >= h->assign.size()) return RIO_GP_EINVAL;
-        out[k] = h->assign[idx[k]];
-    }
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n) return h->fail("stub: object index out of range");
+    for (uint64_t k = 0; k < n; ++k) out[k] = h->assign[idx[k]];
     return RIO_GP_OK;
 }
 int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* node) {
     std::lock_guard<std::mutex> g(h->mu);
-    for (uint64_t k = 0; k < n; ++k) h->assign[idx[k]] = node[k];
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n || (node[k] != RIO_GP_NONE && node[k] >= h->alive.size()))
+            return h->fail("stub: index or node out of range");
+    for (uint64_t k = 0; k < n; ++k) {
+        h->assign[idx[k]] = node[k];
+        h->aff[idx[k]] = node[k] == RIO_GP_NONE ? RIO_GP_AFF_INACTIVE : node[k];
+    }
     return RIO_GP_OK;
 }
 int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     std::lock_guard<std::mutex> g(h->mu);
-    for (uint64_t k = 0; k < n; ++k) h->assign[idx[k]] = RIO_GP_NONE;
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n) return h->fail("stub: object index out of range");
+    for (uint64_t k = 0; k < n; ++k) { h->assign[idx[k]] = RIO_GP_NONE; h->aff[idx[k]] = RIO_GP_AFF_INACTIVE; }
     return RIO_GP_OK;
 }
 int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
     std::lock_guard<std::mutex> g(h->mu);
     uint64_t ev = 0;
-    for (auto& a : h->assign)
-        if (a == node) { a = RIO_GP_NONE; ++ev; }
+    for (uint64_t i = 0; i < h->n; ++i)
+        if (h->assign[i] == node) { h->assign[i] = RIO_GP_NONE; h->aff[i] = RIO_GP_AFF_INACTIVE; ++ev; }
     if (evicted) *evicted = ev;
     return RIO_GP_OK;
 }
 int rio_gp_count_placed(rio_gp_t* h, uint64_t* out) {
     std::lock_guard<std::mutex> g(h->mu);
     uint64_t c = 0;
-    for (auto a : h->assign) c += a != RIO_GP_NONE;
+    for (uint64_t i = 0; i < h->n; ++i) c += h->assign[i] != RIO_GP_NONE;
     *out = c;
     return RIO_GP_OK;
 }
-int rio_gp_set_object_attrs(rio_gp_t*, uint64_t, const uint32_t*, const uint32_t*, const uint32_t*) { return RIO_GP_OK; }
+int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* load, const uint32_t* aff) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n) return h->fail("stub: object index out of range");
+    for (uint64_t k = 0; k < n; ++k) {
+        if (load) h->load[idx[k]] = load[k];
+        if (aff) h->aff[idx[k]] = aff[k];
+    }
+    return RIO_GP_OK;
+}
 int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out) {
     std::lock_guard<std::mutex> g(h->mu);
+    if (n != h->n) return h->fail("stub: n differs");
     memcpy(out, h->assign.data(), n * sizeof(uint32_t));
     return RIO_GP_OK;
 }
 int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* req, uint32_t* out_node, uint32_t* out_flag) {
     std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n || req[k] >= h->alive.size()) return h->fail("stub: object index or requester out of range");
     for (uint64_t k = 0; k < n; ++k) {
         uint32_t& a = h->assign[idx[k]];
         const bool up = a != RIO_GP_NONE && a < h->alive.size() && h->alive[a];
         uint32_t fl;
         if (up) fl = a == req[k] ? RIO_GP_FLAG_LOCAL : RIO_GP_FLAG_REDIRECT;
-        else if (req[k] < h->alive.size() && h->alive[req[k]]) { a = req[k]; fl = RIO_GP_FLAG_PLACED; }
-        else { a = RIO_GP_NONE; fl = RIO_GP_FLAG_UNPLACED; }
+        else {
+            h->aff[idx[k]] = req[k];
+            if (h->alive[req[k]]) { a = req[k]; fl = RIO_GP_FLAG_PLACED; }
+            else { a = RIO_GP_NONE; fl = RIO_GP_FLAG_UNPLACED; }
+        }
         out_node[k] = a;
         if (out_flag) out_flag[k] = fl;
     }
@@ -96,6 +144,17 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
 int rio_gp_tick(rio_gp_t* h, rio_gp_stats* st) {
     std::lock_guard<std::mutex> g(h->mu);
     if (st) memset(st, 0, sizeof *st);
+    for (uint64_t i = 0; i < h->n; ++i) {
+        uint32_t& a = h->assign[i];
+        if (a != RIO_GP_NONE && a < h->alive.size() && h->alive[a]) { if (st) ++st->kept; continue; }
+        if (a != RIO_GP_NONE && st) ++st->evicted;
+        a = RIO_GP_NONE;
+        if (h->aff[i] == RIO_GP_AFF_INACTIVE) continue;                     // not an object
+        for (uint32_t j = 0; j < h->alive.size(); ++j)
+            if (h->alive[j]) { a = j; break; }
+        if (st) { if (a != RIO_GP_NONE) ++st->spilled; else ++st->unplaced; }
+    }
+    if (st) st->n_objects = st->kept + st->spilled + st->unplaced;
     return RIO_GP_OK;
 }
 }  // extern "C"

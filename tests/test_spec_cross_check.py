@@ -23,6 +23,8 @@ def test_c_oracle_equals_the_written_specification(oracle, seed):
     load = rng.integers(0, int(rng.choice([3, 50, 4000])), n).astype(np.uint32)   # zero loads included
     aff = rng.integers(0, m + 1, n).astype(np.uint32)
     aff[rng.random(n) < 0.05] = NONE
+    if seed % 3 == 0:
+        aff[rng.random(n) < 0.15] = spec_tick.INACTIVE            # rows that are not objects (row lifecycle)
     alive = (rng.random(m) < 0.8).astype(np.uint8)
     scale = float(rng.choice([0.0, 0.4, 1.0, 3.0]))
     cap = rng.integers(0, int(load.sum() * scale / m) + 2, m).astype(np.uint64)
@@ -34,7 +36,9 @@ def test_c_oracle_equals_the_written_specification(oracle, seed):
     assert got == want.tolist()
     assert gused == used.tolist()
     placed = [g != NONE for g in got]
-    assert st["kept"] + st["claimed"] + st["spilled"] == sum(placed) and st["unplaced"] == n - sum(placed)
+    inactive = sum(1 for i in range(n) if aff[i] == spec_tick.INACTIVE and got[i] == NONE)
+    assert st["n_objects"] == n - inactive
+    assert st["kept"] + st["claimed"] + st["spilled"] == sum(placed) and st["unplaced"] == st["n_objects"] - sum(placed)
 
 
 @pytest.mark.parametrize("seed", range(40))
