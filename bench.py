@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — placement decisions/sec + achieved HBM GB/s of the whole-table solve.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on
-rank 0.  A "step" is one whole-table solve (rio_gp_solve_async: every row of the table gets a
-placement decision) over the synthetic table of BASELINE.json config 3 — 10 M objects x 1 024
-nodes, Zipf(1.1) loads, cold start (every object pending) — already resident in HBM.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+A "step" is one whole-table solve (every row of the table gets a placement decision), inputs resident in HBM.
+
+  N = 1   BASELINE.json config 3 (the configuration the metric is quoted on): 10 M objects x 1 024 nodes, Zipf(1.1)
+          loads, cold start (every object pending); step = rio_gp_solve_async (k_scan + k_resolve).
+  N > 1   BASELINE.json config 4 as north_star states it: ONE table of 100 M objects x 4 096 nodes, rows sharded over
+          the N ranks (12.5 M rows per GPU at N = 8), "scaling": "strong"; the weak-scaled config 3 (10 M rows per
+          GPU of one N x 10 M-row table) is measured in the same run and reported under "weak_config3".
+
   value        = decisions of all ranks / max-over-ranks wall time of the K steps
-  roofline     = k_scan (the streaming kernel, >90 % of a step): algorithmic 16 B/decision
-                 (read cur+load+aff, write assign) / its per-launch HIP-event time
+  parity       = the solved assignment column, the per-node `used` vector and the counters compared bit for bit with
+                 the CPU oracle's solve of the same table, in this very run (exit code 3 on a mismatch)
+  roofline     = k_scan (the streaming kernel, >90 % of a step): algorithmic 16 B/decision (read
+                 cur+load+aff, write assign) / its per-launch HIP-event time; `traffic` = HBM bytes per launch from
+                 rocprofv3 PMC passes run by this script (traffic_source says how they were obtained)
   cpu_baseline = the CPU oracle port of the reference's per-object path, on a bounded sample
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -25,6 +35,7 @@ import numpy as np  # noqa: E402
 
 ALGO_BYTES_PER_DECISION = 16
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+C4_ROWS, C4_NODES = 100_000_000, 4096
 
 
 def parse():
@@ -32,8 +43,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", help="c3 (headline) | c3w | c2 | c4shard | c5 (config 5: churn ticks, N=1 only)")
-    ap.add_argument("--objects", type=int, default=0, help="override rows per GPU")
+    ap.add_argument("--workload", default=None,
+                    help="default: c3 at N=1, c4 (ONE 100 M x 4 096 table split over the ranks) at N>1 | c3 | c3w | c2 | "
+                         "c4 | c5 (config 5: churn ticks, N=1 only)")
+    ap.add_argument("--objects", type=int, default=0, help="override rows per GPU (weak-scaled workloads)")
+    ap.add_argument("--total-objects", type=int, default=0, help="override the TOTAL row count of the strong-scaled c4 table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="p2p", choices=("p2p", "native", "torch"),
                     help="sharded runs: how the per-rank load records travel — p2p: stores into the peers' HBM windows over "
@@ -46,16 +60,22 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded runs: keep the all-gather on the scan stream (no overlap with the next solve's scan)")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="N=1 only: run the row-sharded path (RCCL group of one rank) to price its extra kernels and launches")
+                    help="N=1 only: run the row-sharded path (group of one rank) to price its extra kernels and launches")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--no-cold", action="store_true",
                     help="skip the beyond-the-Infinity-Cache data point (the same kernel over a 4x table, 640 MB of columns)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_traffic.json"),
-                    help="PMC-derived HBM bytes per k_scan launch (tools/pmc_traffic.py); null if absent")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run comparison with the CPU oracle")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline.traffic falls back to profiles/)")
+    ap.add_argument("--no-c4", action="store_true", help="N=1: skip the config-4-on-one-GPU data point (100 M x 4 096)")
+    ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaled config-3 second measurement")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "round2_traffic.json"),
+                    help="fallback for roofline.traffic when the in-run PMC passes are skipped or fail")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sample):
+# ------------------------------------------------------------------------------------------------ CPU baseline
+
+def cpu_baseline(cfg, sample, array_oracle_seconds=None):
     """Time the oracle port of the reference's per-object path on this box's host cores (bounded)."""
     import pyoracle
     n = min(sample, cfg["n"])
@@ -68,10 +88,10 @@ def cpu_baseline(cfg, sample):
     tW, _ = pyoracle.bench_policy(nW, cfg["m"], aff[:nW], threads=1, warm=True)      # warm: sticky hit + O(M) is_active
     v1, vT = n / t1, nT / tT
     best_v, best_c = (v1, 1) if v1 >= vT else (vT, cores)
-    # "best reasonable CPU": the array solver (same algorithm as the GPU), one thread, full table
-    t0 = time.perf_counter()
-    pyoracle.tick(cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
-    t_arr = time.perf_counter() - t0
+    if array_oracle_seconds is None:  # "best reasonable CPU": the array solver (same algorithm as the GPU), one thread
+        t0 = time.perf_counter()
+        pyoracle.tick(cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"])
+        array_oracle_seconds = time.perf_counter() - t0
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
@@ -85,19 +105,133 @@ def cpu_baseline(cfg, sample):
         "value_1thread": v1, "value_allcores": vT, "host_cores": cores, "cpu_model": model,
         "warm_sticky_hits_1thread": {"value": nW / tW, "unit": "decisions/s", "rows": nW,
                                      "note": "every call hits and pays the O(M) is_active member scan (cluster/storage/mod.rs:95-110)"},
-        "array_oracle_1thread": {"value": cfg["n"] / t_arr, "unit": "decisions/s", "rows": cfg["n"],
-                                 "note": "oracle/placement_oracle.c orc_tick: the GPU algorithm run sequentially on dense arrays"},
+        "array_oracle_1thread": {"value": cfg["n"] / array_oracle_seconds, "unit": "decisions/s", "rows": cfg["n"],
+                                 "note": "oracle/placement_oracle.c orc_tick: the GPU algorithm run sequentially on dense arrays "
+                                         "(the same run the parity check compares against)"},
     }
 
 
+# ------------------------------------------------------------------------------------------------ parity (in-run)
+
+def parity_single(g, cfg, rounds=2):
+    """One more solve of the benchmark table, compared with the CPU oracle bit for bit: assignment column, counters,
+    and (after the commit) the per-node `used` vector.  Returns (record, oracle_seconds)."""
+    import pyoracle
+    t0 = time.perf_counter()
+    want, used, ost = pyoracle.tick(cfg["cur"], cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"], rounds)
+    t_orc = time.perf_counter() - t0
+    st = g.solve()
+    got = g.get_solved()
+    eq_a = bool(np.array_equal(got, want))
+    g.commit()
+    eq_u = bool(np.array_equal(g.get_nodes()[2], used))
+    eq_s = st == ost
+    rec = {"checked_rows": int(cfg["n"]), "equal": eq_a and eq_u and eq_s, "assign_equal": eq_a, "used_equal": eq_u,
+           "stats_equal": eq_s, "against": "oracle/placement_oracle.c orc_tick on the same table, same run",
+           "oracle_seconds": t_orc}
+    if not eq_a:
+        bad = np.flatnonzero(got != want)
+        rec["first_mismatches"] = [[int(i), int(got[i]), int(want[i])] for i in bad[:5]]
+    if not eq_s:
+        rec["stats_gpu"], rec["stats_oracle"] = st, ost
+    return rec, t_orc
+
+
+def parity_sharded(dist, backend, g, sol, workload, n_total, m, bounds, rank, world, cap):
+    """Every rank's solved rows and its (global) `used` vector against the oracle's solve of the WHOLE table, computed
+    on rank 0 from the same generator."""
+    import torch
+    import synth
+    st = sol.solve()
+    mine = g.get_solved()
+    sol.commit()
+    used = g.get_nodes()[2]
+    nmax = max(bounds[r + 1] - bounds[r] for r in range(world))
+    dev = "cuda" if backend == "nccl" else "cpu"
+    pad = np.full(nmax, 0xFFFFFFFF, np.uint32)
+    pad[:len(mine)] = mine
+    t_rows = torch.from_numpy(pad.astype(np.int64)).to(dev)
+    t_used = torch.from_numpy(used.astype(np.int64)).to(dev)
+    rows_all = [torch.empty_like(t_rows) for _ in range(world)]
+    used_all = [torch.empty_like(t_used) for _ in range(world)]
+    dist.all_gather(rows_all, t_rows)
+    dist.all_gather(used_all, t_used)
+    if rank != 0:
+        return None
+    import pyoracle
+    glob = synth.config(workload, n_override=n_total, start=0)
+    t0 = time.perf_counter()
+    want, wused, ost = pyoracle.tick(glob["cur"], glob["load"], glob["aff"], cap, glob["alive"], 2)
+    t_orc = time.perf_counter() - t0
+    got = np.concatenate([rows_all[r].cpu().numpy().astype(np.uint32)[:bounds[r + 1] - bounds[r]] for r in range(world)])
+    eq_a = bool(np.array_equal(got, want))
+    eq_u = all(bool(np.array_equal(used_all[r].cpu().numpy().astype(np.uint64), wused)) for r in range(world))
+    keys = ("n_objects", "kept", "evicted", "claimed", "spilled", "unplaced", "load_kept", "load_claimed", "load_spilled",
+            "load_unplaced", "cut_nodes", "slow_path", "rounds_run")
+    eq_s = all(st[k] == ost[k] for k in keys)
+    rec = {"checked_rows": int(n_total), "equal": eq_a and eq_u and eq_s, "assign_equal": eq_a, "used_equal_on_every_rank": eq_u,
+           "stats_equal": eq_s, "against": "oracle/placement_oracle.c orc_tick on the WHOLE %d-row table (rank 0), every rank's "
+                                            "shard gathered" % n_total, "oracle_seconds": t_orc}
+    if not eq_s:
+        rec["stats_gpu"], rec["stats_oracle"] = st, ost
+    return rec
+
+
+# ------------------------------------------------------------------------------------------------ PMC traffic (in-run)
+
+def pmc_traffic_in_run(n_rows, timeout=240):
+    """HBM bytes per k_scan launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they do not fit one pass,
+    MI355X_MICROARCH.md §rocprofv3) over tools/pmc_workload.py, calibrated on the stream probes of the same passes
+    (tools/pmc_traffic.py).  Runs as child processes next to this one; returns (doc, source) or (None, reason)."""
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    import pmc_traffic
+    work = tempfile.mkdtemp(prefix="rio_pmc_")
+    env = dict(os.environ, TMPDIR=work)
+    dirs = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter.lower())
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "pmc_workload.py"), "c3", str(n_rows)]
+            r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-300:])
+            dirs[counter] = d
+        doc = pmc_traffic.compute(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], n_rows)
+        if "hbm_bytes_per_launch" not in doc:
+            return None, "PMC passes produced no k_scan / probe counters"
+        return doc, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate --kernel-trace "
+                     "passes over tools/pmc_workload.py: 30 solves of the same table + stream probes of known traffic that "
+                     "calibrate both counters; MI355X_MICROARCH.md §HBM)")
+    except Exception as e:  # measurement aid: never fails the bench
+        return None, "PMC passes failed: %r" % (e,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------ config 5 (churn)
+
 def bench_churn(a, g, cfg, saved_stdout):
     """BASELINE.json config 5: the config-3 table, warm; every step = one liveness push (10 % of the nodes down, the
-    previous casualties back) + one committed whole-table tick (evict + re-place through the fix-up path)."""
+    previous casualties back) + one committed whole-table tick (evict + re-place through the fix-up path).  Two timed
+    streams over the same masks: synchronous ticks (the host reads every tick's counters before the next push) and, when
+    the library offers it, pipelined ticks (rio_gp_tick_async: the counters are read back later; results identical)."""
+    import pyoracle
     import synth
     n, m = cfg["n"], cfg["m"]
-    g.set_assign(synth.warm_assign(n, m))
-    g.tick()
-    masks = [synth.churn_mask(m, 2 + k) for k in range(a.warmup + a.steps)]
+    warm = synth.warm_assign(n, m)
+    total = a.warmup + a.steps
+    masks = [synth.churn_mask(m, 2 + k) for k in range(total)]
+
+    def reset():
+        g.set_alive_all(np.ones(m, np.uint8))
+        g.set_assign(warm)
+        g.tick()
+
+    reset()
     for k in range(a.warmup):
         g.set_alive_all(masks[k])
         g.tick()
@@ -110,6 +244,41 @@ def bench_churn(a, g, cfg, saved_stdout):
         moved += st["claimed"] + st["spilled"]
         slow += st["slow_path"]
     dt = time.perf_counter() - t0
+    final_sync = g.get_assign()
+    used_sync = g.get_nodes()[2]
+    # parity of the WHOLE committed stream, at full size: the oracle replays the same masks from the same warm table
+    parity = None
+    if not a.no_parity:
+        ref = warm.copy()
+        t1 = time.perf_counter()
+        ref, used, ost = pyoracle.tick(ref, cfg["load"], cfg["aff"], cfg["cap"], np.ones(m, np.uint8), 2)
+        for k in range(total):
+            ref, used, ost = pyoracle.tick(ref, cfg["load"], cfg["aff"], cfg["cap"], masks[k], 2)
+        parity = {"checked_rows": int(n), "ticks_replayed": total + 1, "equal": bool(np.array_equal(final_sync, ref)) and
+                  bool(np.array_equal(used_sync, used)) and st == ost,
+                  "against": "oracle/placement_oracle.c orc_tick chained over the same %d liveness masks; assignment column, "
+                             "`used` and the last tick's counters after the final tick" % total,
+                  "oracle_seconds": time.perf_counter() - t1}
+    piped = None
+    if hasattr(g, "tick_async"):
+        reset()
+        for k in range(a.warmup):
+            g.set_alive_all(masks[k])
+            g.tick_async()
+        g.tick_wait()
+        g.sync()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            g.set_alive_all(masks[a.warmup + k])
+            g.tick_async()
+        sts = g.tick_wait()
+        dtp = time.perf_counter() - t0
+        piped = {"ms_per_step": dtp / a.steps * 1e3, "value": n * a.steps / dtp, "unit": "decisions/s",
+                 "frac_of_roofline": ALGO_BYTES_PER_DECISION * n * a.steps / dtp / 1e9 / HBM_PEAK_GBPS,
+                 "equal_to_synchronous_stream": bool(np.array_equal(g.get_assign(), final_sync)) and
+                 bool(np.array_equal(g.get_nodes()[2], used_sync)) and sts[-1] == st,
+                 "step": "rio_gp_set_alive_all + rio_gp_tick_async: nothing waits on the host between ticks, every tick's "
+                         "counters are read afterwards (rio_gp_tick_wait)"}
     out = {
         "metric": "placement decisions/sec, 10M objects x 1 024 nodes with 10 % node-failure churn per tick", "value": n * a.steps / dt,
         "unit": "decisions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -118,15 +287,135 @@ def bench_churn(a, g, cfg, saved_stdout):
                                "flip and one committed tick evicts and re-places their objects" % (n, m),
                    "step": "rio_gp_set_alive_all + rio_gp_tick (synchronous: the host reads every tick's counters)",
                    "slow_path_steps": slow},
-        "objects_moved_per_s": moved / dt, "stats_last_step": st,
+        "objects_moved_per_s": moved / dt, "stats_last_step": st, "parity": parity, "pipelined": piped,
         "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_DECISION * n * a.steps / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": ALGO_BYTES_PER_DECISION * n * a.steps / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "whole tick (8 dependent launches + host turn-around; latency-bound, DESIGN.md section 5)"},
+                     "traffic_source": "not measured for this workload (profiles/ holds the per-kernel PMC summaries of the fix-up path)",
+                     "kernel": "whole tick (dependent launches + host turn-around; latency-bound, DESIGN.md section 5)"},
     }
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+    if parity is not None and not parity["equal"]:
+        sys.exit(3)
 
+
+# ------------------------------------------------------------------------------------------------ sharded set-up
+
+def make_sharded_solver(a, dist, g, local_rank, rank, n_global, load_total):
+    """Exchange ladder p2p -> native -> torch: a path that cannot be set up, or whose warm-up fails on ANY rank (agreed
+    through an all-reduce), is dropped for the next one on EVERY rank."""
+    import torch
+    import sharded
+    eng = sharded.HipShardEngine(g, local_rank)
+    ladder = ["p2p", "native", "torch"]
+    ladder = ladder[ladder.index(a.exchange):]
+    tried = []
+    for kind in ladder:
+        ok, ex, why, sol = 1, None, "", None
+        try:
+            ex = {"p2p": sharded.P2PExchange, "native": sharded.NativeRcclExchange}[kind](eng) if kind != "torch" \
+                else sharded.DistExchange()
+            sol = sharded.ShardedSolver([eng], ex, spill_rounds=2, pipeline=(kind == "torch" and not a.no_pipeline))
+            for _ in range(max(a.warmup, 2)):
+                sol.solve_async()
+            st, n_slow = sol.solve_wait()
+            # an exchange that delivers wrong records must not survive the warm-up: every row decided exactly once and
+            # every unit of load accounted for, on the GLOBAL table
+            if st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] != n_global or \
+                    st["load_kept"] + st["load_claimed"] + st["load_spilled"] + st["load_unplaced"] != load_total:
+                raise RuntimeError("exchange '%s' produced inconsistent global stats: %r" % (kind, st))
+        except Exception as e:  # set-up failure raises on every rank; a warm-up failure may be local
+            ok, why = 0, str(e)
+        dev = "cuda" if a.backend == "nccl" else "cpu"
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        tried.append({"path": kind, "ok": bool(int(flag.item())), "why": why[:200]})
+        if int(flag.item()) == 1:
+            return sol, kind, tried
+        print("rank %d: exchange '%s' dropped (%s)" % (rank, kind, why or "failed on another rank"), file=sys.stderr)
+        if kind == "p2p" and ex is not None and hasattr(ex, "close"):
+            ex.close()
+    raise SystemExit("no exchange path could be set up")
+
+
+def timed_steps(a, g, dist, torch, step, wait):
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        g.sync()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    g.timer_begin()
+    for _ in range(a.steps):
+        step()
+    gpu_ms = g.timer_end()
+    st, n_slow = wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dev = "cuda" if a.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, gpu_ms, st, n_slow
+
+
+def global_cap(dist, torch, a, load, m):
+    """cap[j] = ceil(1.25 * sum of the GLOBAL load / m), the same on every rank (set-up only, not the data path)."""
+    dev = "cuda" if a.backend == "nccl" else "cpu"
+    tot = torch.tensor([int(load.astype(np.uint64).sum())], device=dev, dtype=torch.int64)
+    dist.all_reduce(tot)
+    total = int(tot.item())
+    return np.full(m, -((-total * 1250) // (1000 * m)), dtype=np.uint64), total
+
+
+def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank):
+    """One sharded measurement: build this rank's shard, pick the exchange, time K steps, check parity."""
+    strong = workload == "c4"
+    if strong:
+        n_total = a.total_objects or C4_ROWS
+        import sharded
+        bounds = sharded.shard_bounds(n_total, world)
+        start, n_local = bounds[rank], bounds[rank + 1] - bounds[rank]
+    else:
+        n_local = a.objects or synth.DEFAULT_ROWS[workload]
+        n_total = n_local * world
+        bounds = [r * n_local for r in range(world + 1)]
+        start = rank * n_local
+    cfg = synth.config(workload, n_override=n_local, start=start)
+    n, m = cfg["n"], cfg["m"]
+    cfg["cap"], load_total = global_cap(dist, torch, a, cfg["load"], m)
+    g = rio_gp.GpuPlacement(max(n, 1), m, device=local_rank)
+    g.set_nodes(cfg["cap"], cfg["alive"])
+    g.set_objects(n, cfg["load"], cfg["aff"])
+    sol, kind, tried = make_sharded_solver(a, dist, g, local_rank, rank, n_total, load_total)
+    dt, gpu_ms, st, n_slow = timed_steps(a, g, dist, torch, sol.solve_async, sol.solve_wait)
+    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n_total
+    parity = None
+    if not a.no_parity:
+        parity = parity_sharded(dist, a.backend, g, sol, workload, n_total, m, bounds, rank, world, cfg["cap"])
+    rec = {"value": n_total * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "gpu_ms_per_step_events": gpu_ms / a.steps,
+           "rows_total": n_total, "rows_this_rank": n, "nodes": m, "exchange": kind, "exchange_ladder": tried,
+           "slow_path_steps": n_slow, "stats_last_step": st, "parity": parity,
+           "whole_step_achieved_GBps": ALGO_BYTES_PER_DECISION * n / (gpu_ms / a.steps * 1e-3) / 1e9}
+    g.close()
+    return rec
+
+
+def peer_matrix(torch, world, same_device):
+    """hipDeviceCanAccessPeer for every pair of the ranks' devices (what the peer-to-peer windows need)."""
+    try:
+        if same_device:
+            return "all ranks on device 0 (--same-device flow test)"
+        nd = torch.cuda.device_count()
+        return [[int(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(min(nd, world))] for i in range(min(nd, world))]
+    except Exception as e:
+        return "unavailable: %r" % (e,)
+
+
+# ------------------------------------------------------------------------------------------------ main
 
 def main():
     a = parse()
@@ -149,6 +438,7 @@ def main():
     if a.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    workload = a.workload or ("c3" if world == 1 else "c4")
     dist = None
     if world > 1 or a.force_sharded:
         import torch.distributed as dist
@@ -158,94 +448,83 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
-
-    n_over = a.objects or None
-    if a.workload == "c5" and world > 1:
+    if workload == "c5" and world > 1:
         raise SystemExit("--workload c5 is a single-GPU line (the row-sharded churn tick is covered by tools/soak_sharded.py)")
-    per_rank = synth.config("c3" if a.workload == "c5" else a.workload, n_override=n_over, start=0)  # shapes only
-    n_local = per_rank["n"]
-    # weak scaling: every rank owns n_local consecutive rows of ONE table of world*n_local rows (rank order =
-    # index order); capacities are set from the GLOBAL load, exactly as the unsharded config would
-    cfg = synth.config(a.workload, n_override=n_local, start=rank * n_local) if world > 1 else per_rank
-    n, m = cfg["n"], cfg["m"]
-    if dist is not None:
-        tot = torch.tensor([int(cfg["load"].astype(np.uint64).sum())], device="cuda", dtype=torch.int64)
-        dist.all_reduce(tot)  # set-up only, not the data path
-        cfg["cap"] = np.full(m, -((-int(tot.item()) * 1250) // (1000 * m)), dtype=np.uint64)
 
+    if dist is not None:
+        # ---- row-sharded runs: the primary measurement, then (N>1, c4) the weak-scaled config 3 in the same run
+        prim = run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank)
+        weak = None
+        if workload == "c4" and world > 1 and not a.no_weak:
+            weak = run_sharded(a, dist, torch, rio_gp, synth, "c3", rank, world, local_rank)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+        strong = workload == "c4"
+        m = prim["nodes"]
+        out = {
+            "metric": "placement decisions/sec + achieved HBM GB/s, 10M objects x 1 024 nodes" if not strong else
+                      "placement decisions/sec + achieved HBM GB/s, 100M objects x 4 096 nodes row-sharded across the GPUs",
+            "value": prim["value"], "unit": "decisions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": ("config 4: %d objects x %d nodes, %d per GPU (ONE table, rows sharded over %d ranks), Zipf(1.1) "
+                                    "load, cap 1.25x of the global load, cold start" % (prim["rows_total"], m, prim["rows_this_rank"], world))
+                       if strong else ("%s: %d objects x %d nodes per GPU of one %d-row table, cap from the global load, cold start"
+                                       % (workload, prim["rows_this_rank"], m, prim["rows_total"])),
+                       "objects_per_gpu": prim["rows_this_rank"], "objects_total": prim["rows_total"], "nodes": m,
+                       "parallelism": "rows sharded x%d" % world,
+                       "step": {"p2p": "row-sharded solve: k_scan -> k_resolve_xchg (every workgroup stores its eight nodes' local sums "
+                                       "straight into every peer's HBM window over xGMI as data-tagged 8-byte words, polls the same "
+                                       "words of every rank and resolves its nodes); one stream, two launches, no collective call, "
+                                       "no flag; verdicts read at the end",
+                                "native": "row-sharded solve: k_scan + k_resolve + pack -> ncclAllGather of %d B/rank issued by the "
+                                          "library on a second stream -> k_shard_import; verdicts read at the end" % (8 * (2 * m + 8)),
+                                "torch": "row-sharded solve: k_scan + k_resolve + pack -> torch.distributed all_gather (RCCL) of %d "
+                                         "B/rank -> k_shard_import; verdicts read at the end" % (8 * (2 * m + 8))}[prim["exchange"]],
+                       "exchange": prim["exchange"], "exchange_ladder": prim["exchange_ladder"],
+                       "peer_access": peer_matrix(torch, world, a.same_device), "slow_path_steps": prim["slow_path_steps"]},
+            "gpu_ms_per_step_events": prim["gpu_ms_per_step_events"],
+            "parity": prim["parity"],
+            "roofline": {"bound": "hbm", "achieved": prim["whole_step_achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": prim["whole_step_achieved_GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                         "traffic_source": "not measured in sharded runs (PMC passes are single-process)",
+                         "kernel": "whole sharded step on rank 0 (k_scan + exchange/resolve), HIP events on the library's stream",
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DECISION * prim["rows_this_rank"]},
+            "stats_last_step": prim["stats_last_step"],
+        }
+        if weak is not None:
+            out["weak_config3"] = {"metric": "placement decisions/sec, 10M objects x 1 024 nodes per GPU (weak scaling)",
+                                   "value": weak["value"], "unit": "decisions/s", "scaling": "weak", "ms_per_step": weak["ms_per_step"],
+                                   "objects_per_gpu": weak["rows_this_rank"], "objects_total": weak["rows_total"], "nodes": weak["nodes"],
+                                   "exchange": weak["exchange"], "slow_path_steps": weak["slow_path_steps"], "parity": weak["parity"]}
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        bad = [p for p in (prim["parity"], weak["parity"] if weak else None) if p is not None and not p["equal"]]
+        if bad:
+            sys.exit(3)
+        return
+
+    # ---- N = 1 -----------------------------------------------------------------------------------------------
+    cfg = synth.config("c3" if workload == "c5" else workload, n_override=(a.objects or None))
+    n, m = cfg["n"], cfg["m"]
     g = rio_gp.GpuPlacement(n, m, device=local_rank)
     g.set_nodes(cfg["cap"], cfg["alive"])
     g.set_objects(n, cfg["load"], cfg["aff"])
-    if a.workload == "c3w":
+    if workload == "c3w":
         g.set_assign(cfg["cur"])
-    if a.workload == "c5":
+    if workload == "c5":
         return bench_churn(a, g, cfg, saved_stdout)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        g.sync()
-        torch.cuda.synchronize()
-
-    if dist is None:
-        step, wait = g.solve_async, g.solve_wait
-        for _ in range(a.warmup):
-            step()
-        if a.warmup:
-            st, n_slow = wait()
-    else:
-        # row-sharded solve: k_scan -> exchange of the (2m+8)-word record -> global resolve; the verdicts are read once
-        # at the end, as at N=1.  Exchange ladder p2p -> native -> torch: a path that cannot be set up, or whose warm-up
-        # fails on ANY rank (agreed through an all-reduce), is dropped for the next one on EVERY rank.
-        import sharded
-        eng = sharded.HipShardEngine(g, local_rank)
-        ladder = ["p2p", "native", "torch"]
-        ladder = ladder[ladder.index(a.exchange):]
-        sol = None
-        for kind in ladder:
-            ok, ex, why = 1, None, ""
-            try:
-                ex = {"p2p": sharded.P2PExchange, "native": sharded.NativeRcclExchange}[kind](eng) if kind != "torch" \
-                    else sharded.DistExchange()
-                sol = sharded.ShardedSolver([eng], ex, spill_rounds=2, pipeline=(kind == "torch" and not a.no_pipeline))
-                for _ in range(max(a.warmup, 2)):
-                    sol.solve_async()
-                st, n_slow = sol.solve_wait()
-                # an exchange that delivers wrong records must not survive the warm-up: every row decided exactly
-                # once and every unit of load accounted for, on the GLOBAL table
-                if st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] != n * world or \
-                        st["load_kept"] + st["load_claimed"] + st["load_spilled"] + st["load_unplaced"] != int(tot.item()):
-                    raise RuntimeError("exchange '%s' produced inconsistent global stats: %r" % (kind, st))
-            except Exception as e:  # set-up failure raises on every rank; a warm-up failure may be local
-                ok, why = 0, str(e)
-            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                a.exchange = kind
-                break
-            print("rank %d: exchange '%s' dropped (%s)" % (rank, kind, why or "failed on another rank"), file=sys.stderr)
-            if kind == "p2p" and ex is not None:
-                ex.close()
-            sol = None
-        if sol is None:
-            raise SystemExit("no exchange path could be set up")
-        step, wait = sol.solve_async, sol.solve_wait
-
-    barrier()
-    t0 = time.perf_counter()
-    g.timer_begin()
-    for _ in range(a.steps):
-        step()
-    gpu_ms = g.timer_end()
-    st, n_slow = wait()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n * world
-    total_decisions = n * world * a.steps
+    for _ in range(a.warmup):
+        g.solve_async()
+    if a.warmup:
+        g.solve_wait()
+    dt, gpu_ms, st, n_slow = timed_steps(a, g, None, torch, g.solve_async, g.solve_wait)
+    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n
+    total_decisions = n * a.steps
 
     # per-launch duration of the dominant kernel, HIP events on the library's own stream
     scan_ms, res_ms = [], []
@@ -255,7 +534,7 @@ def main():
             scan_ms.append(s_ms)
             res_ms.append(r_ms)
     probe = None
-    if rank == 0 and n_slow == 0:
+    if n_slow == 0:
         try:  # what this chip's memory system gives a plain grid-stride kernel with the same 3-in/1-out mix
             ms = g.stream_probe(0, 20)
             probe = {"pattern": "grid-stride 2048x256, read cur/load/aff + write one column, no other work",
@@ -263,10 +542,10 @@ def main():
         except Exception as e:  # measurement aid only
             probe = {"error": str(e)}
     cold = None
-    if rank == 0 and world == 1 and n_slow == 0 and not a.no_cold and a.workload == "c3":
+    if n_slow == 0 and not a.no_cold and workload == "c3":
         # The headline table (160 MB of columns) fits the 256 MiB Infinity Cache, so repeated solves are partly served
         # by it.  Same kernel, same per-row inputs tiled 4x (640 MB of columns, capacities scaled): every launch streams
-        # from HBM.  Reported next to the headline, never instead of it.
+        # from HBM.  Reported next to the headline, never instead of it: kernel-only AND whole-step (k_scan + k_resolve).
         try:
             k = 4
             loadk, affk = np.tile(cfg["load"], k), np.tile(cfg["aff"], k)
@@ -277,59 +556,119 @@ def main():
                 gb.solve_profiled()
             cs = [gb.solve_profiled()[0] for _ in range(30)]
             pm = gb.stream_probe(0, 10)
+            for _ in range(3):
+                gb.solve_async()
+            gb.solve_wait()
+            gb.sync()
+            gb.timer_begin()
+            for _ in range(30):
+                gb.solve_async()
+            wms = gb.timer_end() / 30
+            gb.solve_wait()
             gb.close()
             cms = float(np.mean(cs))
             cold = {"rows": k * n, "column_bytes": 16 * k * n, "kernel_ms": cms,
                     "achieved": ALGO_BYTES_PER_DECISION * k * n / (cms * 1e-3) / 1e9, "unit": "GB/s",
                     "frac": ALGO_BYTES_PER_DECISION * k * n / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "whole_step_ms": wms, "whole_step_achieved": ALGO_BYTES_PER_DECISION * k * n / (wms * 1e-3) / 1e9,
+                    "whole_step_frac": ALGO_BYTES_PER_DECISION * k * n / (wms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "stream_probe_GBps": ALGO_BYTES_PER_DECISION * k * n / pm / 1e6,
-                    "note": "k_scan over the headline rows tiled 4x: beyond the 256 MiB Infinity Cache"}
+                    "note": "the headline rows tiled 4x: beyond the 256 MiB Infinity Cache; kernel = k_scan alone (dispatch events), "
+                            "whole step = k_scan + k_resolve back to back (30 pipelined steps between two events)"}
         except Exception as e:  # measurement aid only
             cold = {"error": str(e)}
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank != 0:
-        return
+    c4one = None
+    if not a.no_c4 and workload == "c3" and not a.objects:
+        # BASELINE config 4 on ONE GPU (the N=1 point of the strong-scaling curve): 100 M x 4 096, parity at size
+        try:
+            c4 = synth.config("c4")
+            g4 = rio_gp.GpuPlacement(c4["n"], c4["m"], device=local_rank)
+            g4.set_nodes(c4["cap"], c4["alive"])
+            g4.set_objects(c4["n"], c4["load"], c4["aff"])
+            for _ in range(3):
+                g4.solve_async()
+            g4.solve_wait()
+            g4.sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g4.solve_async()
+            st4, slow4 = g4.solve_wait()
+            t4 = (time.perf_counter() - t0) / 20
+            sc4 = [g4.solve_profiled()[0] for _ in range(10)] if slow4 == 0 else []
+            par4 = None if a.no_parity else parity_single(g4, c4)[0]
+            g4.close()
+            c4one = {"workload": "config 4 on one GPU: %d objects x %d nodes, Zipf(1.1), cap 1.25x, cold" % (c4["n"], c4["m"]),
+                     "value": c4["n"] / t4, "unit": "decisions/s", "ms_per_step": t4 * 1e3, "slow_path_steps": slow4,
+                     "k_scan_ms": float(np.mean(sc4)) if sc4 else None,
+                     "k_scan_frac": (ALGO_BYTES_PER_DECISION * c4["n"] / (float(np.mean(sc4)) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if sc4 else None,
+                     "whole_step_frac": ALGO_BYTES_PER_DECISION * c4["n"] / t4 / 1e9 / HBM_PEAK_GBPS, "parity": par4}
+            del c4
+        except Exception as e:  # measurement aid only
+            c4one = {"error": repr(e)}
+    # a dependent stream of COMMITTED ticks over the same table (each tick consumes the previous tick's commit and the
+    # host reads its counters): the un-pipelined price of a step
+    dep = None
+    parity = None
+    t_orc = None
+    if not a.no_parity:
+        parity, t_orc = parity_single(g, cfg)   # leaves the table committed (warm)
+    try:
+        g.tick()
+        g.sync()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            g.tick()
+        dep = (time.perf_counter() - t0) / 100 * 1e3
+    except Exception:
+        dep = None
+
     scan_avg = float(np.mean(scan_ms)) if scan_ms else None
     achieved = (ALGO_BYTES_PER_DECISION * n / (scan_avg * 1e-3) / 1e9) if scan_avg else None
-    traffic = None
-    if a.traffic_json and os.path.exists(a.traffic_json):
+    traffic, traffic_source, traffic_detail = None, "not measured", None
+    if not a.no_pmc and n_slow == 0:
+        doc, src = pmc_traffic_in_run(n)
+        if doc is not None:
+            traffic, traffic_source = doc["hbm_bytes_per_launch"], src
+            traffic_detail = {k: doc.get(k) for k in ("k_scan", "k_resolve", "calibration")}
+        else:
+            traffic_source = "in-run PMC passes unavailable (%s)" % src
+    if traffic is None and a.traffic_json and os.path.exists(a.traffic_json):
         tj = json.load(open(a.traffic_json))
-        traffic = tj.get("hbm_bytes_per_launch") if tj.get("n_rows") == n else None  # measured for this row count only
+        if tj.get("n_rows") == n:  # measured for this row count only
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source += "; value replayed from %s (rocprofv3 PMC passes of an earlier run of this build, tools/gpu_round.sh)" % \
+                os.path.relpath(a.traffic_json, ROOT)
+    whole = ALGO_BYTES_PER_DECISION * n / (gpu_ms / a.steps * 1e-3) / 1e9
     out = {
         "metric": "placement decisions/sec + achieved HBM GB/s, 10M objects x 1 024 nodes",
-        "value": total_decisions / dt, "unit": "decisions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": total_decisions / dt, "unit": "decisions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "config 3: %d objects x %d nodes per GPU, Zipf(1.1) load, cap 1.25x, cold start "
-                               "(all pending)" % (n, m) if a.workload == "c3" else a.workload,
-                   "objects_per_gpu": n, "nodes": m, "parallelism": "rows sharded x%d" % world,
-                   "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end" if dist is None
-                           else {"p2p": "row-sharded solve: k_scan -> k_resolve_xchg (every workgroup stores its four nodes' local sums straight into "
-                                        "every peer's HBM window over xGMI as data-tagged 8-byte words, %d B/rank, polls the same words of "
-                                        "every rank and resolves its nodes); one stream, two launches, no collective call, no flag; "
-                                        "verdicts read at the end",
-                                 "native": "row-sharded solve: k_scan + k_resolve + pack -> ncclAllGather of %d B/rank issued by the "
-                                           "library on a second stream -> k_shard_import; verdicts read at the end",
-                                 "torch": "row-sharded solve: k_scan + k_resolve + pack -> torch.distributed all_gather (RCCL) of %d "
-                                          "B/rank -> k_shard_import; verdicts read at the end"}[a.exchange] % (8 * (2 * m + 8)),
-                   "exchange": None if dist is None else a.exchange,
-                   "slow_path_steps": n_slow},
+        "config": {"workload": "config 3: %d objects x %d nodes, Zipf(1.1) load, cap 1.25x, cold start "
+                               "(all pending)" % (n, m) if workload == "c3" else workload,
+                   "objects_per_gpu": n, "nodes": m, "parallelism": "rows sharded x1",
+                   "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end",
+                   "exchange": None, "slow_path_steps": n_slow},
         "gpu_ms_per_step_events": gpu_ms / a.steps,
+        "dependent_tick_ms": dep,
+        "dependent_tick_frac": (ALGO_BYTES_PER_DECISION * n / (dep * 1e-3) / 1e9 / HBM_PEAK_GBPS) if dep else None,
+        "parity": parity,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                     "traffic_source": traffic_source, "traffic_detail": traffic_detail,
                      "kernel": "k_scan", "kernel_ms": scan_avg,
                      "kernel_ms_p10_p90": [float(np.percentile(scan_ms, 10)), float(np.percentile(scan_ms, 90))] if scan_ms else None,
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DECISION * n,
                      "resolve_kernel_ms": float(np.mean(res_ms)) if res_ms else None,
                      "frac_of_measured_copy_peak_6290": (achieved / 6290.0) if achieved else None,
-                     "whole_step_achieved_GBps": ALGO_BYTES_PER_DECISION * n / (gpu_ms / a.steps * 1e-3) / 1e9,
+                     "whole_step_achieved_GBps": whole, "whole_step_frac": whole / HBM_PEAK_GBPS,
                      "stream_probe": probe, "beyond_infinity_cache": cold},
+        "config4_single_gpu": c4one,
         "stats_last_step": st,
     }
     if not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample, t_orc)
+    g.close()
     sys.stdout.flush()
     try:
         import ctypes
@@ -338,6 +677,9 @@ def main():
         pass
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+    bad = [p for p in (parity, (c4one or {}).get("parity")) if p is not None and not p["equal"]]
+    if bad:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

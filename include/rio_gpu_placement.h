@@ -208,6 +208,14 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
 int rio_gp_solve(rio_gp_t* h, rio_gp_stats* stats);
 int rio_gp_commit(rio_gp_t* h);
 int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats);
+/* The committed tick without a host wait: rio_gp_tick_async enqueues solve + fix-up + commit of one tick on the handle's
+ * stream and returns; ticks enqueued back to back each consume the previous one's commit on the device (and any
+ * rio_gp_set_alive* pushed in between, in stream order).  rio_gp_tick_wait waits for all of them and hands out their
+ * counters, oldest first: *n_out = ticks completed since the last wait, out[0..min(cap, *n_out)) = the most recent ones.
+ * The tables are exactly what the same sequence of rio_gp_tick calls produces; only the counters arrive later.  (A
+ * server that pushes a membership change and rebalances has no use for the counters before the next push.) */
+int rio_gp_tick_async(rio_gp_t* h);
+int rio_gp_tick_wait(rio_gp_t* h, rio_gp_stats* out, uint32_t cap, uint32_t* n_out);
 /* Enqueue one solve on the handle's stream without waiting.  rio_gp_solve_wait drains the
  * stream, runs the cut/spill fix-up for the LAST enqueued solve if it needed one, and
  * returns its stats.  *n_slow = how many of the solves enqueued since the last wait took

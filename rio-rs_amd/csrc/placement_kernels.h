@@ -59,7 +59,6 @@ struct SolveBufs {
     u64* blkstat;    // [G][4]   kept, evicted, claimants rows per block
     u64* wsp_sum[2]; // [G*kWaves] spill-candidate load per wave range (ping-pong over rounds)
     u32* wsp_cnt[2]; // [G*kWaves]
-    u64* wsp_base;   // [G*kWaves] exclusive prefix of wsp_sum
     u64* used_kept;  // [m] load of kept rows (+ used_base for the virtual table)
     u64* used_cur;   // [m] used_kept + admitted claims + admitted spills
     u64* claim_tot;  // [m]
@@ -124,11 +123,14 @@ int cut_trace_enable(int on);  // k_cut_fused phase trace (measurement aid)
 int cut_trace_read(u64* out /*[kMaxBlocks*8]*/);
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1);
-// have_cutblk: launch_resolve of the same solve (same bufs) has already written cutblk / budget / admpre
-void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
-                      bool fused = true, bool have_cutblk = false);
+// impl: 2 = k_cut_find + k_cut_apply_rank | 1 = k_cut_fused | 0 = the unfused chain.  have_cutblk: launch_resolve of the
+// same solve (same bufs) has already written cutblk / budget / admpre.  with_rank (impl 2): the ranking of water-fill
+// round 0 rides in the second launch — only when nothing changes used_cur between the cut and that round (not on the
+// row-sharded path, where the Y exchange does).  Returns true when that ranking was enqueued.
+bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
+                      int impl = 2, bool have_cutblk = false, bool with_rank = false);
 void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
-                        hipStream_t s);
+                        hipStream_t s, bool rank_done = false);
 
 // --- CRUD over the assignment column ---
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s);

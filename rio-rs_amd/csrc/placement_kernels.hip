@@ -814,17 +814,19 @@ __host__ __device__ __forceinline__ size_t cut_fused_fixed(u32 m, u32 mwords) {
     return kSmall + (size_t)mr * 8 + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 2 * kWaves * sizeof(u64);
 }
 
+// The search half of the cut fix-up for ONE block b of rows: which nodes have their cut in b (all of them, or the slice
+// j % sel_mod == sel_rem of them when the block's cuts are spread over several workgroups), and for each the exact row —
+// P0..P2 of the description above.  Every thread of the workgroup calls it; on return thr[] (LDS) holds the reject
+// threshold of every node as seen from block b, and cutidx[] / used_cur[] (global) are final for the nodes searched.
 template <bool VIRT>
-__global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cur, const u32* __restrict__ load,
-                                                      const u32* __restrict__ aff, u32* __restrict__ next,
-                                                      const u32* __restrict__ alive_bits, Plan p,
-                                                      const u32* __restrict__ cutblk, const u64* __restrict__ budget,
-                                                      const u64* __restrict__ admpre,
-                                                      const u64* __restrict__ used_kept,
-                                                      const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
-                                                      u64* __restrict__ used_cur, u64* __restrict__ wsp_sum,
-                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 tcap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 b, const u32 sel_mod, const u32 sel_rem,
+                                                 const bool write_forced, const u32* __restrict__ cur,
+                                                 const u32* __restrict__ load, const u32* __restrict__ aff,
+                                                 const u32* __restrict__ alive_bits, const Plan& p,
+                                                 const u32* __restrict__ cutblk, const u64* __restrict__ budget,
+                                                 const u64* __restrict__ admpre, const u64* __restrict__ used_kept,
+                                                 const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
+                                                 u64* __restrict__ used_cur, const u32 tcap) {
     const u32 m = p.m, mr = (m + 7) & ~7u;
     u32& nlocal = *reinterpret_cast<u32*>(smem);
     u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
@@ -837,8 +839,6 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
     u64* T = whi + kWaves;                                                   // [tcap]: T[K][S] from the front,
                                                                              //         budget of slot s at T[tcap-1-s]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 b = blockIdx.x;
-    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
     RIOGP_TRACE(0, wall_clock64());
     if (tid == 0) { nlocal = 0; red[0] = 0; red[1] = 0; }
     for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
@@ -854,10 +854,10 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
         u32 s = kSlotNone;
         if (forced_bits && bit_of(forced_bits, j)) {  // row-sharded solve: the prefix overflowed on a lower rank
             t = 0;
-            if (b == 0) { cutidx[j] = 0; used_cur[j] = used_kept[j]; }
+            if (write_forced && b == 0) { cutidx[j] = 0; used_cur[j] = used_kept[j]; }
         } else if (cbv < b) {
             t = 0;
-        } else if (cbv == b) {
+        } else if (cbv == b && (sel_mod <= 1 || j % sel_mod == sel_rem)) {  // this work item's slice of the block's cuts
             s = atomicAdd(&nlocal, 1u);
             node_of[s] = (unsigned short)j;
         }
@@ -1158,6 +1158,32 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
     RIOGP_TRACE(7, tr_p2a);
     RIOGP_TRACE(4, wall_clock64());
 
+}
+
+template <bool VIRT>
+__global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                      const u32* __restrict__ aff, u32* __restrict__ next,
+                                                      const u32* __restrict__ alive_bits, Plan p,
+                                                      const u32* __restrict__ cutblk, const u64* __restrict__ budget,
+                                                      const u64* __restrict__ admpre,
+                                                      const u64* __restrict__ used_kept,
+                                                      const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
+                                                      u64* __restrict__ used_cur, u64* __restrict__ wsp_sum,
+                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 tcap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m, mr = (m + 7) & ~7u;
+    u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
+    u32* thr = reinterpret_cast<u32*>(smem + kSmall);                        // [mr] reject threshold by node
+    u32* alv = reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(thr + mr) + 2 * mr);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 b = blockIdx.x;
+    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
+    cut_search_block<VIRT>(smem, b, 1, 0, true, cur, load, aff, alive_bits, p, cutblk, budget, admpre, used_kept, forced_bits,
+                           cutidx, used_cur, tcap);
+    const u64 gw = (u64)b * kWaves + wave;
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+
     // P3: re-mark the rejected claimants, rebuild the per-wave spill totals (candidates + rejected).  Every workgroup
     //     runs this over all its rows, so the row body is branch-free except for the (rare) store: the class of a row is
     //     computed with bit operations, counts are popcounts of ballots (wave-uniform), loads are summed under selects.
@@ -1206,8 +1232,83 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
 }
 
 // ------------------------------------------------------------------------------------------------
-// KS  k_spill_rank — per round: free capacity per node, rank of every node in the total order
-//     (free desc, index asc) by counting, and the exclusive prefix of the per-wave spill totals.
+// K3f k_cut_find — the search half of the cut fix-up, spread over the chip.  In k_cut_fused the workgroup that owns
+//     block b of rows also owns every cut that falls into b, and in a nearly full cluster most nodes reject within
+//     their first claimants: one workgroup searched 200-400 nodes (31 us) while ~250 CUs idled.  The search for node j
+//     needs only block cutblk[j]'s rows, so it is a work ITEM (block b, slice s of the nodes cut in b): every
+//     workgroup derives the same item list from cutblk[] (a histogram over blocks, ceil(count / 16) slices per block,
+//     at most 64; slice = j mod slices), takes the items blockIdx.x, +gridDim.x, ... and runs the block search on each.
+//     The re-marking pass that needs EVERY node's result is the next launch (k_cut_apply_rank).
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kCutPerItem = 16;    // cut nodes per work item (one per wave of the workgroup that searches them)
+constexpr u32 kCutMaxSlices = 64;  // slices of one block's cuts
+constexpr u32 kCutFindGrid = 256;  // one workgroup per CU (the search needs ~150 KiB of LDS)
+
+template <bool VIRT>
+__global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                     const u32* __restrict__ aff, const u32* __restrict__ alive_bits,
+                                                     Plan p, const u32* __restrict__ cutblk,
+                                                     const u64* __restrict__ budget, const u64* __restrict__ admpre,
+                                                     const u64* __restrict__ used_kept,
+                                                     const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
+                                                     u64* __restrict__ used_cur, DevStats* __restrict__ stats, u32 tcap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 cnt[kMaxBlocks];                 // nodes whose cut falls into block b
+    __shared__ unsigned short istart[kMaxBlocks + 1];  // first item of block b; [kMaxBlocks] = number of items
+    __shared__ unsigned char nsl[kMaxBlocks];       // slices (= items) of block b
+    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 m = p.m, G = p.G;
+    if (forced_bits && blockIdx.x == 0)  // row-sharded solve: the prefix overflowed on a lower rank — nothing is admitted here
+        for (u32 j = tid; j < m; j += kBlock)
+            if (bit_of(forced_bits, j)) { cutidx[j] = 0; used_cur[j] = used_kept[j]; }
+    for (u32 k = tid; k < kMaxBlocks; k += kBlock) cnt[k] = 0;
+    __syncthreads();
+    for (u32 j = tid; j < m; j += kBlock) {
+        const u32 cb = cutblk[j];
+        if (cb < G && !(forced_bits && bit_of(forced_bits, j))) atomicAdd(&cnt[cb], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // slices per block and their exclusive prefix: one wave, four blocks per lane
+        u32 c[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 bq = (u32)tid * 4 + q;
+            const u32 nn = bq < G ? cnt[bq] : 0;
+            u32 sl = (nn + kCutPerItem - 1) / kCutPerItem;
+            if (sl > kCutMaxSlices) sl = kCutMaxSlices;
+            c[q] = sl;
+            tot += sl;
+        }
+        const u64 inc = wave_incl_scan((u64)tot, lane);
+        u32 ex = (u32)inc - tot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            istart[tid * 4 + q] = (unsigned short)ex;
+            nsl[tid * 4 + q] = (unsigned char)c[q];
+            ex += c[q];
+        }
+        if (tid == 63) istart[kMaxBlocks] = (unsigned short)inc;
+    }
+    __syncthreads();
+    const u32 items = istart[kMaxBlocks];
+    for (u32 item = blockIdx.x; item < items; item += gridDim.x) {
+        u32 lo = 0, hi = kMaxBlocks;  // the last block whose first item is <= item (blocks without cuts share their successor's start)
+        while (hi - lo > 1) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (istart[mid] <= item) lo = mid; else hi = mid;
+        }
+        __syncthreads();  // the previous item's LDS tables are dead from here on
+        cut_search_block<VIRT>(smem, lo, nsl[lo], item - istart[lo], false, cur, load, aff, alive_bits, p, cutblk, budget,
+                               admpre, used_kept, forced_bits, cutidx, used_cur, tcap);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// KS  k_spill_rank — per round: free capacity per node and the rank of every node in the total order
+//     (free desc, index asc) by counting.  (The exclusive prefix of the per-wave spill totals and the "is anything
+//     pending" verdict are computed by k_spill_apply's own prologue — 48 KiB of L2 reads per workgroup — so that the
+//     ranking of round 0 depends on the cut search only and can share a launch with k_cut_apply.)
 //     Ranking is m^2 wave-uniform LDS reads: ONE workgroup is bound by a single CU's LDS port
 //     (measured 48 us at m = 1024), so it is spread over m/64 workgroups: each recomputes free[] in
 //     its LDS (m loads) and ranks 64 nodes, thread = (node, 1/16 of the k range).  The saturating
@@ -1240,26 +1341,18 @@ __device__ u64 block_excl_scan_1024(u64 v, bool saturating, u64* lds_part /*[16]
 
 constexpr int kRankNodes = 64;
 
-__global__ __launch_bounds__(kBlock) void k_spill_rank(Plan p, const u64* __restrict__ cap,
-                                                       const u32* __restrict__ alive_bits,
-                                                       const u64* __restrict__ used_cur,
-                                                       const u64* __restrict__ wsp_sum,
-                                                       const u32* __restrict__ wsp_cnt,
-                                                       u64* __restrict__ wsp_base, u64* __restrict__ wfFree,
-                                                       u32* __restrict__ wfOrder, u32* __restrict__ wfCnt,
-                                                       const u64* __restrict__ rank_base,
-                                                       const u64* __restrict__ pending_global,
-                                                       DevStats* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Body of one ranking workgroup (64 nodes).  LDS: [2*kSmall + 256 + mp*8] bytes at smem.
+__device__ __forceinline__ void spill_rank_body(unsigned char* smem, const u32 rb /* ranking block */, const Plan& p,
+                                                const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
+                                                const u64* __restrict__ used_cur, u64* __restrict__ wfFree,
+                                                u32* __restrict__ wfOrder, u32* __restrict__ wfCnt) {
     const u32 m = p.m;
     const u32 mp = (m + kBlock - 1) / kBlock * kBlock;  // padded
-    u64* part = reinterpret_cast<u64*>(smem);                  // [16]
     u32& nz_total = *reinterpret_cast<u32*>(smem + 128);
-    u32& cnt_total = *reinterpret_cast<u32*>(smem + 132);
-    u32* rk = reinterpret_cast<u32*>(smem + 2 * kSmall);       // [64] rank accumulators of this block's nodes
+    u32* rk = reinterpret_cast<u32*>(smem + 2 * kSmall);         // [64] rank accumulators of this block's nodes
     u64* fre = reinterpret_cast<u64*>(smem + 2 * kSmall + 256);  // [mp] free by node
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { nz_total = 0; cnt_total = 0; }
+    if (tid == 0) nz_total = 0;
     if (tid < kRankNodes) rk[tid] = 0;
     u32 nz = 0;
     for (u32 j = tid; j < mp; j += kBlock) {
@@ -1271,44 +1364,13 @@ __global__ __launch_bounds__(kBlock) void k_spill_rank(Plan p, const u64* __rest
         fre[j] = f;
         nz += f != 0;
     }
-    // rows still pending: sum of the per-wave counts (every block needs the verdict; block 0 also the prefix)
-    const u32 nw = p.G * kWaves;  // <= 4096 = 4 per thread
-    u64 v[4], s = 0;
-    u32 cnt = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32 w = tid * 4 + q;
-        v[q] = (w < nw && blockIdx.x == 0) ? wsp_sum[w] : 0;
-        cnt += w < nw ? wsp_cnt[w] : 0;
-        s += v[q];
-    }
-    u64 ex = block_excl_scan_1024(s, false, part, nullptr);  // its barriers also publish fre[] / the zeroed counters
-    cnt = wave_sum32(cnt);
-    nz = wave_sum32(nz);
-    if (lane == 0) {
-        if (cnt) atomicAdd(&cnt_total, cnt);
-        if (nz) atomicAdd(&nz_total, nz);
-    }
     __syncthreads();
-    // row-sharded solve: "pending" is a global fact (k_shard_import_delta), else the local count
-    const bool pending = pending_global ? (*pending_global != 0) : (cnt_total != 0);
-    if (blockIdx.x == 0) {
-        if (rank_base) ex += *rank_base;  // spill load of every lower rank comes first
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32 w = tid * 4 + q;
-            if (w < nw) wsp_base[w] = ex;
-            ex += v[q];
-        }
-        if (tid == 0) {
-            wfCnt[0] = pending ? nz_total : 0;
-            wfCnt[1] = pending ? 1 : 0;  // 0: k_spill_apply returns at once
-            if (pending) stats->rounds_run += 1;
-        }
-    }
-    if (!pending) return;
+    nz = wave_sum32(nz);
+    if (lane == 0 && nz) atomicAdd(&nz_total, nz);
+    __syncthreads();
+    if (rb == 0 && tid == 0) wfCnt[0] = nz_total;  // number of ranked nodes (free > 0)
     // rank of node j = #{k : free[k] > free[j] or (free[k] == free[j] and k < j)}; lane = node, wave = k range
-    const u32 j = blockIdx.x * kRankNodes + lane;
+    const u32 j = rb * kRankNodes + lane;
     const u64 f = j < m ? fre[j] : 0;
     const u32 per = mp / kWaves;  // multiple of 64
     u32 r = 0;
@@ -1327,18 +1389,106 @@ __global__ __launch_bounds__(kBlock) void k_spill_rank(Plan p, const u64* __rest
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_spill_rank(Plan p, const u64* __restrict__ cap,
+                                                       const u32* __restrict__ alive_bits,
+                                                       const u64* __restrict__ used_cur, u64* __restrict__ wfFree,
+                                                       u32* __restrict__ wfOrder, u32* __restrict__ wfCnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    spill_rank_body(smem, blockIdx.x, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4r k_cut_apply_rank — behind k_cut_find: blocks [0, G) re-mark the rejected claimants (row i of a claimant of node a
+//     is rejected iff i >= cutidx[a]; every claimant of a forced node is) and rebuild the per-wave spill totals — the
+//     branch-free pass P3 of k_cut_fused; blocks [G, G + m/64) rank the nodes for water-fill round 0 (k_spill_rank's
+//     body): that ranking needs used_cur[], final since k_cut_find, and nothing this launch's other blocks produce, so it
+//     rides along instead of costing a dependent launch of its own.
+// ------------------------------------------------------------------------------------------------
+template <bool VIRT>
+__global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict__ cur, const u32* __restrict__ load,
+                                                           const u32* __restrict__ aff, u32* __restrict__ next,
+                                                           const u32* __restrict__ alive_bits, Plan p,
+                                                           const u32* __restrict__ cutidx,
+                                                           const u32* __restrict__ forced_bits, u64* __restrict__ wsp_sum,
+                                                           u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats,
+                                                           const u64* __restrict__ cap, const u64* __restrict__ used_cur,
+                                                           u64* __restrict__ wfFree, u32* __restrict__ wfOrder,
+                                                           u32* __restrict__ wfCnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x >= p.G) {
+        spill_rank_body(smem, blockIdx.x - p.G, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
+        return;
+    }
+    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // no cut anywhere: k_scan's spill totals stand
+    const u32 m = p.m;
+    u64* red = reinterpret_cast<u64*>(smem + 16);      // [2]
+    u32* thr = reinterpret_cast<u32*>(smem + kSmall);  // [m] first rejected row of a node's claimants (kNoCut: none)
+    u32* alv = thr + ((m + 3) & ~3u);                  // [mwords]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 j = tid; j < m; j += kBlock) thr[j] = (forced_bits && bit_of(forced_bits, j)) ? 0u : cutidx[j];
+    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    if (tid < 2) red[tid] = 0;
+    __syncthreads();
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+    u64 sp_sum = 0, rej_sum = 0;
+    u32 sp_cnt = 0, rej_cnt = 0;  // wave-uniform
+    for (u64 it = wstart; it < wend; it += kTile) {
+        const u64 i0 = it + (u64)lane * 4;
+        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
+        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
+        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+#define RIOGP_ROW(C, A, L, E)                                                                        \
+        {                                                                                            \
+            const bool inr = i0 + E < wend;                                                          \
+            const bool cin = C < m, ain = A < m;                                                     \
+            const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                          \
+            const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                  \
+            const bool skip = VIRT && C == kSkipMark;                                                \
+            const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                             \
+            const bool sp = inr & !kept & !skip & !cl & (VIRT | (A != kAffInactive));                \
+            const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                        \
+            if (rej) next[i0 + E] = kSpillMark;                                                      \
+            sp_sum += (sp | rej) ? (u64)L : 0ull;                                                    \
+            rej_sum += rej ? (u64)L : 0ull;                                                          \
+            sp_cnt += (u32)__popcll(__ballot(sp | rej));                                             \
+            rej_cnt += (u32)__popcll(__ballot(rej));                                                 \
+        }
+        RIOGP_ROW(cv.x, av.x, lv.x, 0)
+        RIOGP_ROW(cv.y, av.y, lv.y, 1)
+        RIOGP_ROW(cv.z, av.z, lv.z, 2)
+        RIOGP_ROW(cv.w, av.w, lv.w, 3)
+#undef RIOGP_ROW
+    }
+    sp_sum = wave_sum(sp_sum);
+    rej_sum = wave_sum(rej_sum);
+    if (lane == 0) {
+        wsp_sum[gw] = sp_sum;
+        wsp_cnt[gw] = sp_cnt;
+        if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
+    }
+    __syncthreads();
+    if (tid == 0 && red[0]) {
+        atomicAdd(&stats->rejected, red[0]);
+        atomicAdd(&stats->load_rejected, red[1]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5  k_spill_apply — water-fill: the spill set in index order has exclusive load prefix Q; the
 //     node whose cumulative-free interval [C[k], C[k+1]) contains Q takes the row iff it fits.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ load, u32* __restrict__ next, Plan p,
-                                                        const u64* __restrict__ wsp_base,
+                                                        const u64* __restrict__ wsp_sum_in,
                                                         const u64* __restrict__ wfC /* free by rank */, const u32* __restrict__ wfOrder,
                                                         const u32* __restrict__ wfCnt, u64* __restrict__ used_cur,
                                                         const u32* __restrict__ wsp_cnt_in,
                                                         u64* __restrict__ wsp_sum_out, u32* __restrict__ wsp_cnt_out,
                                                         int last, DevStats* __restrict__ stats,
-                                                        const u32* __restrict__ pk_idx, u32* __restrict__ real_next) {
+                                                        const u32* __restrict__ pk_idx, u32* __restrict__ real_next,
+                                                        const u64* __restrict__ rank_base,
+                                                        const u64* __restrict__ pending_global) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u64* red = reinterpret_cast<u64*>(smem);               // [4]
@@ -1346,13 +1496,44 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     u64* C = reinterpret_cast<u64*>(smem + 2 * kSmall);    // [m+1]
     u64* adm = C + (m + 1);                                // [m] admitted load by node (this block)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (wfCnt[1] == 0) {  // nothing pending anywhere (k_spill_prepare): the round is a no-op
-        if (lane == 0) {
-            const u64 gw0 = (u64)blockIdx.x * kWaves + wave;
-            wsp_sum_out[gw0] = 0;
-            wsp_cnt_out[gw0] = 0;
+    // Prologue: what is pending, and where does this workgroup's first wave start in the index-ordered spill prefix?
+    // Every workgroup folds the per-wave totals of the previous step itself (nw <= 4 096 words of each: L2 reads).
+    u64 my_base;
+    {
+        const u32 nw = p.G * kWaves, w0 = blockIdx.x * kWaves;
+        u64 sb = 0;
+        u32 c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 w = tid * 4 + q;
+            if (w < nw) {
+                c += wsp_cnt_in[w];
+                if (w < w0 + (u32)kWaves) {  // the waves before this workgroup, and its own for the in-block prefix
+                    const u64 v = wsp_sum_in[w];
+                    if (w < w0) sb += v;
+                    else part[w - w0] = v;   // staged for the in-block prefix below (16 words)
+                }
+            }
         }
-        return;
+        sb = wave_sum(sb);
+        c = wave_sum32(c);
+        if (tid < 4) red[tid] = 0;
+        __syncthreads();
+        if (lane == 0) { atomicAdd(&red[0], sb); atomicAdd(&red[1], (u64)c); }
+        __syncthreads();
+        const bool pending = pending_global ? (*pending_global != 0) : (red[1] != 0);
+        if (!pending) {  // nothing pending anywhere: the round is a no-op
+            if (lane == 0) {
+                const u64 gw0 = (u64)blockIdx.x * kWaves + wave;
+                wsp_sum_out[gw0] = 0;
+                wsp_cnt_out[gw0] = 0;
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && tid == 0) stats->rounds_run += 1;
+        my_base = red[0] + (rank_base ? *rank_base : 0ull);  // row-sharded solve: the spill load of every lower rank comes first
+        for (int w = 0; w < wave; ++w) my_base += part[w];
+        __syncthreads();  // red / part are reused below
     }
     const u32 cnt = *wfCnt;
     {   // C[0] = 0, C[k+1] = sat(C[k] + free of rank k): saturating block scan of the ranked free values
@@ -1377,7 +1558,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
-    u64 run = wsp_base[gw];
+    u64 run = my_base;
     u64 rem_sum = 0, pl_sum = 0;
     u32 rem_cnt = 0, pl_cnt = 0;
     // Q only grows along a wave's rows, so the position in C[] is carried from tile to tile:
@@ -2322,17 +2503,41 @@ size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
     return fixed + slots * sizeof(u64);
 }
 
-// fused: k_cutblk + k_cut_fused (default) | else the unfused chain: T memset, k_cutblk, k_cut_subhist, k_cut_exact,
-// (k_shard_force,) k_apply_cut — kept for A/B runs and as a second implementation the parity tests compare against
-void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
-                      hipStream_t s, bool fused, bool have_cutblk) {
+// impl 2 (default): k_cut_find (the searches, spread over the chip) + k_cut_apply_rank (re-marking + the ranking of
+// water-fill round 0 when with_rank) | 1: one fused launch per solve, k_cut_fused | 0: the first, unfused chain — T memset,
+// k_cutblk, k_cut_subhist, k_cut_exact, (k_shard_force,) k_apply_cut.  All three are kept: the parity tests drive the same
+// inputs through each and compare bytes.  Returns true when the ranking of round 0 was part of these launches.
+bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
+                      hipStream_t s, int impl, bool have_cutblk, bool with_rank) {
     const unsigned gcb = (p.m + kCbNodes - 1) / kCbNodes;
-    if (fused) {
+    if (impl >= 1) {
         if (!have_cutblk)  // k_resolve of this solve has already located the cut blocks (not on the row-sharded path)
             hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
                                b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
         u32 tcap = 0;
         const size_t ldsf = cut_fused_lds(p, &tcap);
+        if (impl == 2) {
+            const unsigned gfind = kCutFindGrid;
+            const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
+            const size_t lds_rank = 2 * kSmall + 256 + (size_t)mp * sizeof(u64);
+            const size_t lds_apply = kSmall + ((size_t)((p.m + 3) & ~3u) + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16;
+            const unsigned grank = with_rank ? ((p.m + kRankNodes - 1) / kRankNodes ? (p.m + kRankNodes - 1) / kRankNodes : 1) : 0;
+            const size_t lds2 = (with_rank && lds_rank > lds_apply) ? lds_rank : lds_apply;
+            if (virt) {
+                hipLaunchKernelGGL(k_cut_find<true>, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                                   b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
+                hipLaunchKernelGGL(k_cut_apply_rank<true>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
+                                   nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt);
+            } else {
+                hipLaunchKernelGGL(k_cut_find<false>, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                                   b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
+                hipLaunchKernelGGL(k_cut_apply_rank<false>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
+                                   nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt);
+            }
+            return with_rank;
+        }
         if (virt)
             hipLaunchKernelGGL(k_cut_fused<true>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
@@ -2341,7 +2546,7 @@ void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
             hipLaunchKernelGGL(k_cut_fused<false>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
                                b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap);
-        return;
+        return false;
     }
     (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
     hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
@@ -2365,20 +2570,23 @@ void launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
         hipLaunchKernelGGL(k_apply_cut<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
                            nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
     }
+    return false;
 }
 
+// rank_done: the ranking of this round has already been enqueued (k_cut_apply_rank)
 void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
-                        hipStream_t s) {
+                        hipStream_t s, bool rank_done) {
     const int in = round & 1, out = in ^ 1;
     const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
     const size_t lds_prep = 2 * kSmall + 256 + (size_t)mp * sizeof(u64);
     const unsigned grank = (p.m + kRankNodes - 1) / kRankNodes;
-    hipLaunchKernelGGL(k_spill_rank, dim3(grank ? grank : 1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
-                       b.wsp_sum[in], b.wsp_cnt[in], b.wsp_base, b.wfC, b.wfOrder, b.wfCnt, b.rank_base, b.pending_global, b.stats);
+    if (!rank_done)
+        hipLaunchKernelGGL(k_spill_rank, dim3(grank ? grank : 1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
+                           b.wfC, b.wfOrder, b.wfCnt);
     const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + 16;
-    hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_base, b.wfC,
+    hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_sum[in], b.wfC,
                        b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats,
-                       t.pk_idx, t.real_next);
+                       t.pk_idx, t.real_next, b.rank_base, b.pending_global);
 }
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {

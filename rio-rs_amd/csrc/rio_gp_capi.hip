@@ -120,6 +120,11 @@ struct rio_gp {
     Plan plan{};
     bool have_solved = false;
     u32 ring_n = 0;
+    // asynchronous committed ticks (rio_gp_tick_async): verdict slots [kRing, 2 kRing) and their own ring of device-stats
+    // copies, so that synchronous calls made while ticks are in flight do not touch what has not been harvested yet
+    u32 tick_n = 0;
+    DevStats* h_tick_stats = nullptr;
+    std::vector<rio_gp_stats> tick_done;
     // row-sharded solve (rio_gp_shard_*): global `used` snapshots, forced-node bitmap, spill base, verdict words
     u64 *sh_gprev = nullptr, *sh_gfinal = nullptr, *sh_rank_base = nullptr, *sh_verdict = nullptr;
     u32* sh_forced = nullptr;
@@ -138,7 +143,8 @@ struct rio_gp {
     bool last_pending_valid = false;
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
-    int fixup_mode = 1;    // 1 fused cut fix-up + scatter folded into the water-fill | 0 the unfused chain (rio_gp_debug_set_fixup)
+    int fixup_mode = 2;    // cut fix-up: 2 split launches (k_cut_find + k_cut_apply_rank) | 1 one fused launch | 0 the unfused
+                           // chain; >= 1 also folds the packed scatter into the water-fill (rio_gp_debug_set_fixup)
     int spec_mode = 0;     // speculative fix-up enqueue: 0 auto (after a solve that needed it) | 1 always | 2 never
     bool last_slow = false;
     // clean_server(s): dead bitmap + evicted count in mapped pinned memory, self-resetting device counter + ticket
@@ -254,17 +260,20 @@ NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; 
 // the cut / spill fix-up of a solve whose fast path said it needs one
 void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, const DevStats& verdict) {
     // every caller ran launch_resolve over h->sb for this solve: the cut blocks are already located
-    if (verdict.n_cut > 0) launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode == 1, true);
-    for (u32 r = 0; r < h->rounds; ++r) launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream);
+    bool rank0 = false;
+    if (verdict.n_cut > 0) rank0 = launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode, true, h->rounds >= 1);
+    for (u32 r = 0; r < h->rounds; ++r)
+        launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream, r == 0 && rank0);
 }
 
 u64* slot_dev(rio_gp* h, u32 k) { return h->d_slots + (size_t)(k % kRing) * h->slot_rows * 8; }
+constexpr u32 kTickSlot0 = (u32)kRing;  // slot index k >= kRing: the asynchronous ticks' half of the slot table
 
 // host-side fold of the per-workgroup partial rows k_resolve stored into a pinned slot
 DevStats reduce_slot(rio_gp* h, u32 k, u32 m) {
     DevStats d;
     memset(&d, 0, sizeof d);
-    const u64* rows = h->h_slots + (size_t)(k % kRing) * h->slot_rows * 8;
+    const u64* rows = h->h_slots + (size_t)(k >= kTickSlot0 ? kTickSlot0 + (k - kTickSlot0) % kRing : k % kRing) * h->slot_rows * 8;
     const unsigned nb = resolve_blocks(m);
     for (unsigned r = 0; r < nb; ++r) {
         const u64* x = rows + (size_t)r * 8;
@@ -300,6 +309,7 @@ int commit_enqueue(rio_gp* h) {
 // fix-up was enqueued speculatively (below).
 int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     h->plan = make_plan(h->n, h->m, 0);
+    h->ring_n = 0;
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     // Adaptive packed fix-up: when the previous solve left few rows pending (a churn stream: most rows are kept),
@@ -311,7 +321,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     // are enqueued right behind k_resolve instead of after a host round trip for the verdict.  Every fix-up kernel
     // guards itself on device (k_cut_fused: stats->n_cut; the water-fill rounds: pending-row count), so a solve that
     // turns out not to need them pays a few no-op launches and gets the same result.
-    const bool spec = h->fixup_mode == 1 && h->spec_mode != 2 && (h->spec_mode == 1 || h->last_slow);
+    const bool spec = h->fixup_mode >= 1 && h->spec_mode != 2 && (h->spec_mode == 1 || h->last_slow);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
     launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
     DevStats v;
@@ -330,7 +340,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
             Plan pp = h->plan;
             pp.wcnt = h->pk.wcnt;
             Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
-            const bool fused_scatter = h->fixup_mode == 1 && h->rounds >= 1;  // the water-fill writes through pk.idx itself
+            const bool fused_scatter = h->fixup_mode >= 1 && h->rounds >= 1;  // the water-fill writes through pk.idx itself
             if (fused_scatter) { vt.pk_idx = h->pk.idx; vt.real_next = t.next; }
             enqueue_slow(h, pp, vt, nt, true, what);
             if (!fused_scatter) launch_pk_scatter(pp, h->pk, t.next, h->stream);
@@ -371,6 +381,74 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
 }
 
 int commit_locked(rio_gp* h) { return commit_enqueue(h); }
+
+// wait for the asynchronous ticks in flight and turn their verdict slots + device-stats copies into rio_gp_stats
+int harvest_ticks(rio_gp* h) {
+    if (!h->tick_n) return RIO_GP_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    for (u32 k = 0; k < h->tick_n; ++k) {
+        DevStats v = reduce_slot(h, kTickSlot0 + k, h->m);
+        const bool slow = v.n_cut > 0 || v.spillcand > 0;
+        if (slow) {
+            const DevStats& d = h->h_tick_stats[k];
+            v.rejected = d.rejected; v.load_rejected = d.load_rejected;
+            v.spilled = d.spilled; v.load_spilled = d.load_spilled;
+            v.unplaced = d.unplaced; v.load_unplaced = d.load_unplaced;
+            v.rounds_run = d.rounds_run;
+        }
+        rio_gp_stats st;
+        fill_stats(v, h->n, &st);
+        h->tick_done.push_back(st);
+        h->last_pending = v.claimants + v.spillcand;
+        h->last_pending_valid = true;
+        h->last_slow = slow;
+    }
+    h->tick_n = 0;
+    return RIO_GP_OK;
+}
+
+// One committed tick, nothing waits on the host: k_scan (packing when the last known solve left few rows pending),
+// k_resolve into this tick's verdict slot, the whole fix-up behind it (every fix-up kernel guards itself on the device),
+// the publication (two pointer swaps, host side) and an asynchronous copy of the device accumulators into this tick's
+// pinned record.  The result is the one rio_gp_tick computes; only the counters arrive later (rio_gp_tick_wait).
+int tick_async_locked(rio_gp* h) {
+    if (h->ring_n) return fail(h, RIO_GP_EINVAL, "rio_gp_tick_async: rio_gp_solve_async solves are in flight (call rio_gp_solve_wait)");
+    if (h->tick_n == (u32)kRing) { int rc = harvest_ticks(h); if (rc) return rc; }
+    h->plan = make_plan(h->n, h->m, 0);
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    const bool compact = h->compact_mode == 1 ||
+                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending * 4 <= h->n && h->n >= 65536);
+    const u32 k = h->tick_n;
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
+    launch_resolve(h->plan, nt, h->sb, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, h->stream);
+    DevStats all;
+    memset(&all, 0, sizeof all);
+    all.n_cut = 1;
+    const int impl = h->fixup_mode >= 1 ? h->fixup_mode : 2;  // the unfused chain has no device-side guards: not speculative
+    const int saved = h->fixup_mode;
+    h->fixup_mode = impl;
+    if (compact) {
+        Plan pp = h->plan;
+        pp.wcnt = h->pk.wcnt;
+        Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
+        const bool fused_scatter = h->rounds >= 1;
+        if (fused_scatter) { vt.pk_idx = h->pk.idx; vt.real_next = t.next; }
+        enqueue_slow(h, pp, vt, nt, true, all);
+        if (!fused_scatter) launch_pk_scatter(pp, h->pk, t.next, h->stream);
+    } else {
+        enqueue_slow(h, h->plan, t, nt, false, all);
+    }
+    h->fixup_mode = saved;
+    h->have_solved = true;
+    int rc = commit_enqueue(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(&h->h_tick_stats[k], h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->tick_n = k + 1;
+    return RIO_GP_OK;
+}
 
 int ensure_used(rio_gp* h) {
     if (h->used_valid) return RIO_GP_OK;
@@ -451,7 +529,6 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.H, (size_t)((M + 7) / 8) * kMaxBlocks * 16); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
     A(h->sb.partial, (size_t)resolve_blocks((u32)M) * 8 + 8);
     A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
-    A(h->sb.wsp_base, W);
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
     A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
     A(h->sb.wfCnt, 4); A(h->dstats, 1);
@@ -466,13 +543,14 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     h->slot_rows = resolve_blocks(h->cap_nodes);
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_slots), (size_t)kRing * h->slot_rows * 8 * sizeof(u64),
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_slots), (size_t)2 * kRing * h->slot_rows * 8 * sizeof(u64),
                       hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->h_tick_stats), sizeof(DevStats) * kRing, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_slots), h->h_slots, 0) != hipSuccess) {
         h->err = "hipHostMalloc(mapped verdict slots) failed";
         return bail(RIO_GP_ENOMEM);
     }
-    memset(h->h_slots, 0, (size_t)kRing * h->slot_rows * 8 * sizeof(u64));
+    memset(h->h_slots, 0, (size_t)2 * kRing * h->slot_rows * 8 * sizeof(u64));
     h->cs_words = (((size_t)h->cap_nodes + 31) / 32 + 8 + 1) & ~(size_t)1;  // bitmap words, then the u64 count (8 B aligned)
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cs), (h->cs_words + 2) * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_cs), h->h_cs, 0) != hipSuccess ||
@@ -518,6 +596,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_slots) (void)hipHostFree(h->h_slots);
+    if (h->h_tick_stats) (void)hipHostFree(h->h_tick_stats);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_cs) (void)hipHostFree(h->h_cs);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1027,6 +1106,27 @@ int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats) {
     return solve_locked(h, stats, true);
 }
 
+int rio_gp_tick_async(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    return tick_async_locked(h);
+}
+
+int rio_gp_tick_wait(rio_gp_t* h, rio_gp_stats* out, uint32_t cap, uint32_t* n_out) {
+    if (!h || !n_out || (cap && !out)) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = harvest_ticks(h);
+    if (rc) return rc;
+    const size_t n = h->tick_done.size();
+    const size_t take = n < cap ? n : cap;
+    for (size_t k = 0; k < take; ++k) out[k] = h->tick_done[n - take + k];  // the most recent `take`, oldest first
+    *n_out = (uint32_t)n;
+    h->tick_done.clear();
+    return RIO_GP_OK;
+}
+
 int rio_gp_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
@@ -1198,7 +1298,7 @@ int rio_gp_shard_cut(rio_gp_t* h, int run_local_fixup, uint64_t* d_y) {
     if (h->sh_state != 2 || !h->sh_slow) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_cut: no fix-up pending");
     HIPCHK(h, hipSetDevice(h->device));
     const SolveBufs b = shard_bufs(h);
-    if (run_local_fixup) launch_cut_fixup(h->plan, real_table(h), real_nodes(h), b, false, h->stream, h->fixup_mode == 1);
+    if (run_local_fixup) launch_cut_fixup(h->plan, real_table(h), real_nodes(h), b, false, h->stream, h->fixup_mode, false, false);
     launch_shard_export_delta(h->plan, b, h->sb.used_kept, 0, reinterpret_cast<u64*>(d_y), h->stream);
     h->sh_state = 3;
     return RIO_GP_OK;
@@ -1531,7 +1631,7 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
 }
 
 int rio_gp_debug_set_fixup(rio_gp_t* h, int fused, int speculate) {
-    if (!h || fused < 0 || fused > 1 || speculate < 0 || speculate > 2) return RIO_GP_EINVAL;
+    if (!h || fused < 0 || fused > 2 || speculate < 0 || speculate > 2) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     h->fixup_mode = fused;
     h->spec_mode = speculate;

@@ -113,6 +113,8 @@ def lib():
         L.rio_gp_commit.argtypes = [_vp]
         L.rio_gp_tick.argtypes = [_vp, C.POINTER(Stats)]
         L.rio_gp_solve_async.argtypes = [_vp]
+        L.rio_gp_tick_async.argtypes = [_vp]
+        L.rio_gp_tick_wait.argtypes = [_vp, C.POINTER(Stats), C.c_uint32, C.POINTER(C.c_uint32)]
         L.rio_gp_solve_wait.argtypes = [_vp, C.POINTER(Stats), C.POINTER(C.c_uint32)]
         L.rio_gp_solve_profiled.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.rio_gp_set_object_attrs.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp]
@@ -294,6 +296,15 @@ class GpuPlacement:
         st = Stats()
         self._chk(lib().rio_gp_tick(self._h, C.byref(st)))
         return st.as_dict()
+
+    def tick_async(self):
+        self._chk(lib().rio_gp_tick_async(self._h))
+
+    def tick_wait(self, cap=4096):
+        """Counters of the asynchronous ticks completed since the last wait (the most recent `cap`), oldest first."""
+        arr, n = (Stats * cap)(), C.c_uint32(0)
+        self._chk(lib().rio_gp_tick_wait(self._h, arr, cap, C.byref(n)))
+        return [arr[k].as_dict() for k in range(min(cap, int(n.value)))]
 
     def solve_async(self):
         self._chk(lib().rio_gp_solve_async(self._h))

@@ -37,6 +37,7 @@ def object_id(i, struct_name="Obj"):
     return (struct_name, str(int(i)))
 
 
+DEFAULT_ROWS = {"c1": 1000, "c2": 1_000_000, "c3": 10_000_000, "c3w": 10_000_000, "c4": 100_000_000, "c4shard": 12_500_000}
 _zipf_cdf_cache = {}
 
 
@@ -74,7 +75,8 @@ def config(name, scale=1.0, seed=SEED, start=0, n_override=None):
     """Return dict(n, m, load, aff, cur, cap, alive) for a BASELINE.json config.
 
     name: "c1" 1 000 x 4 (plumbing) | "c2" 1M x 256 uniform | "c3" 10M x 1 024 Zipf (cold) |
-          "c3w" warm variant | "c4shard" one 12.5M x 4 096 row shard of config 4.
+          "c3w" warm variant | "c4" 100M x 4 096 Zipf (cold; a row shard of it = n_override + start) |
+          "c4shard" one 12.5M x 4 096 row shard of config 4.
     `scale` shrinks n (tests); `start` offsets the object counter (row shards).
     """
     if name == "c1":
@@ -83,6 +85,8 @@ def config(name, scale=1.0, seed=SEED, start=0, n_override=None):
         n, m = 1_000_000, 256
     elif name in ("c3", "c3w"):
         n, m = 10_000_000, 1024
+    elif name == "c4":
+        n, m = 100_000_000, 4096
     elif name == "c4shard":
         n, m = 12_500_000, 4096
     else:

@@ -238,3 +238,154 @@ def test_concurrent_single_object_calls_share_round_trips(gp, tmp_path):
         four = [x for x in rows if x["call"] == call and x["threads"] == 4][0]["calls_per_s"]
         assert four > 0.5 * one, (call, one, four)   # shares round trips (measured 1.6x); the bound only guards against a convoy
 
+
+
+# ---- rows that are not objects (rio_op_tick must not resurrect removed / never-inserted keys) -------
+
+def test_tick_does_not_resurrect_removed_or_unknown_rows(gp):
+    p = gp.GpuObjectPlacement(max_objects=1 << 12, max_nodes=8)
+    p.set_member("10.0.0.1:1", True)
+    p.set_member("10.0.0.2:1", True)
+    for k in range(40):
+        p.update("T", str(k), "10.0.0.%d:1" % (1 + k % 2))
+    for k in range(0, 40, 4):
+        p.remove("T", str(k))                                   # 10 removed
+    p.update("T", "1", None)                                    # deleted through update(None) (local.rs:36-37)
+    p.set_object_load("T", "load-only", 7)                      # a key with a load but never placed: not an object
+    assert len(p) == 29
+    st = p.tick()
+    assert st["n_objects"] == 29 and st["kept"] == 29 and st["spilled"] == 0 and st["unplaced"] == 0
+    assert len(p) == 29                                         # NOT max_objects
+    for k in range(0, 40, 4):
+        assert p.lookup("T", str(k)) is None                    # removed stays removed
+    assert p.lookup("T", "1") is None and p.lookup("T", "load-only") is None
+    assert sorted(x[1] for x in p.snapshot()) == sorted(str(k) for k in range(40) if k % 4 and k != 1)
+    # a server dies: its objects are evicted AND re-placed by the tick (eager form of service.rs:227-252); the removed
+    # rows still do not take part
+    p.set_member("10.0.0.1:1", False)
+    on1 = [k for k in range(40) if k % 4 and k != 1 and k % 2 == 0]
+    st = p.tick()
+    assert st["evicted"] == len(on1) and st["n_objects"] == 29 and st["unplaced"] == 0
+    for k in on1:
+        assert p.lookup("T", str(k)) == "10.0.0.2:1"
+    assert len(p) == 29
+    # explicit clean_server drops the entries (local.rs:51-58): they are not re-placed by a tick, they come back lazily
+    p.clean_server("10.0.0.2:1")
+    assert len(p) == 0
+    st = p.tick()
+    assert st["n_objects"] == 0 and len(p) == 0
+    got, flag = p.get_or_create_placement("T", "2", "10.0.0.2:1")
+    assert got == "10.0.0.2:1" and flag == gp.FLAG_PLACED and len(p) == 1
+    p.close()
+
+
+def test_row_lifecycle_column_on_the_dense_layer(gp, oracle):
+    """RIO_GP_CFG_ROW_LIFECYCLE: the CRUD calls maintain which rows are objects (affinity column), and a tick over such a
+    table equals the oracle's tick over the same columns — inactive rows included."""
+    rng = np.random.default_rng(5)
+    n, m = 50_000, 24
+    g = gp.GpuPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
+    cap = np.full(m, 0xFFFFFFFFFFFFFFFF, np.uint64)
+    g.set_nodes(cap, np.ones(m, np.uint8))
+    g.set_objects(n)                                             # load 1, every row a non-object
+    load, aff = g.get_objects()
+    assert np.all(aff == gp.AFF_INACTIVE) and np.all(load == 1)
+    idx = rng.choice(n, 20_000, replace=False).astype(np.uint32)
+    node = rng.integers(0, m, len(idx)).astype(np.uint32)
+    g.update_batch(idx, node)                                    # objects now, affinity = their node
+    g.update_batch(idx[:10], node[:10])                          # micro-batch path
+    g.remove_batch(idx[:3000])                                   # not objects any more
+    g.update_batch(idx[3000:4000], np.full(1000, gp.NONE, np.uint32))   # update(None) deletes
+    ev = g.clean_servers([0, 1])                                 # dropped by clean_server
+    req_rows = np.setdiff1d(np.arange(n, dtype=np.uint32), idx)[:5000]
+    reqs = rng.integers(2, m, len(req_rows)).astype(np.uint32)
+    g.place_pending(req_rows, reqs)                              # first touch: objects, home = the requester
+    g.place_pending(req_rows[:100], reqs[:100])                  # micro-batch: sticky hits, nothing changes
+    assign = g.get_assign()
+    load, aff = g.get_objects()
+    live = np.zeros(n, bool)
+    live[idx[4000:]] = True
+    live[idx[4000:][np.isin(node[4000:], [0, 1])]] = False
+    live[req_rows] = True
+    assert ev == int(np.isin(node[4000:], [0, 1]).sum())
+    assert np.array_equal(aff != gp.AFF_INACTIVE, live)
+    assert np.array_equal(assign != gp.NONE, live)
+    assert np.array_equal(aff[req_rows], reqs) and np.array_equal(aff[idx[4000:]][live[idx[4000:]]], node[4000:][live[idx[4000:]]])
+    alive = np.ones(m, np.uint8)
+    alive[[5, 9]] = 0
+    g.set_alive_all(alive)
+    want, used, ost = oracle.tick(assign, load, aff, cap, alive, 2)
+    st = g.tick()
+    assert st == ost and st["n_objects"] == int(live.sum())
+    assert np.array_equal(g.get_assign(), want) and np.array_equal(g.get_nodes()[2], used)
+    g.close()
+
+
+# ---- VERDICT r1 weak #6: first requests after a server joins, from many threads at once ------------------------------
+
+def test_concurrent_calls_introducing_new_addresses(gp):
+    """16 threads, every call introduces or reuses a server address nobody has pushed to the device yet (ctypes releases
+    the GIL in the C call, so the calls really overlap): zero non-OK returns, every answer right.  Before the fix the
+    thread that interned a new address released the table lock before the node table went to the device, another
+    thread's request carrying the new id could get there first, and the WHOLE combined batch failed with EINVAL."""
+    import threading
+    p = gp.GpuObjectPlacement(max_objects=1 << 16, max_nodes=4096)
+    errors, wrong = [], []
+
+    def worker(t):
+        mine = p.clone()
+        try:
+            for k in range(120):
+                a = "10.1.%d.%d:7000" % ((t + k) % 200, k % 7)
+                b = "10.2.%d.1:7000" % ((t * 3 + k) % 250)
+                key = "n%d_%d" % (t, k)
+                got, flag = mine.get_or_create_placement("New", key, a)
+                if got != a or flag != gp.FLAG_PLACED:
+                    wrong.append((key, a, got, flag))
+                mine.update("Upd", key, b)
+                if mine.lookup("Upd", key) != b:
+                    wrong.append((key, b))
+        except Exception as e:  # any ObjectPlacementError is a failure of the test
+            errors.append(repr(e))
+        finally:
+            mine.close()
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:3]
+    assert not wrong, wrong[:3]
+    assert len(p) == 2 * 16 * 120
+    p.close()
+
+
+def test_keys_are_reclaimed_when_the_table_runs_full(gp):
+    """interned rows were never reclaimed — under object-id churn a long-running server hit 'object table full'
+    for good.  Now removed / deleted / cleaned keys give their rows back when the table runs full, and a table full of
+    LIVE objects fails with its own message while everything else keeps working."""
+    p = gp.GpuObjectPlacement(max_objects=256, max_nodes=8)
+    p.set_member("h:1", True)
+    for k in range(2000):                                      # 2 000 distinct keys through 256 rows
+        key = "c%d" % k
+        assert p.get_or_create_placement("Churn", key, "h:1")[0] == "h:1"
+        if k % 3 == 0:
+            p.remove("Churn", key)
+        elif k % 3 == 1:
+            p.update("Churn", key, None)
+        else:
+            p.clean_server("h:1")
+        assert p.lookup("Churn", key) is None
+    assert len(p) == 0
+    for k in range(256):
+        p.update("Live", str(k), "h:1")
+    assert len(p) == 256
+    with pytest.raises(gp.ObjectPlacementError) as e:
+        p.update("Live", "one-too-many", "h:1")
+    assert e.value.kind == "Unknown" and "object table full" in e.value.text
+    assert p.lookup("Live", "17") == "h:1"                      # the table still answers
+    p.remove("Live", "17")
+    p.update("Live", "one-too-many", "h:1")                     # and a freed row is found again
+    assert p.lookup("Live", "one-too-many") == "h:1" and len(p) == 256
+    p.close()

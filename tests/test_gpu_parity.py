@@ -22,8 +22,12 @@ def gp():
     return rio_gp
 
 
+# (packed fix-up, cut implementation, speculative enqueue): False = the unfused launch chain, True = one fused launch
+# (k_cut_fused), "split" = k_cut_find + k_cut_apply_rank (the default)
 FIXUP_VARIANTS = (("never", False, "never"), ("always", False, "never"),
-                  ("never", True, "always"), ("always", True, "always"), ("always", True, "never"))
+                  ("never", True, "always"), ("always", True, "always"), ("always", True, "never"),
+                  ("never", "split", "never"), ("always", "split", "always"), ("never", "split", "always"),
+                  ("always", "split", "never"))
 
 
 def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
@@ -234,6 +238,17 @@ def test_tick_random_large(gp, oracle, seed, n, m, skew):
     assert st["slow_path"] == 1
 
 
+@pytest.mark.parametrize("seed,n,m", [(1, 4000, 9), (2, 300_000, 1024), (3, 1_000_000, 64)])
+def test_tick_rows_that_are_not_objects(gp, oracle, seed, n, m):
+    """Affinity RIO_GP_AFF_INACTIVE (row lifecycle): such a row is kept if it sits on a live node and takes no part
+    otherwise — never claimed, never water-filled, not counted — in every implementation of the fix-up."""
+    rng = np.random.default_rng(2500 + seed)
+    cur, load, aff, cap, alive = _rand_case(rng, n, m, cap_scale=1.1, max_load=300)
+    aff[rng.random(n) < 0.3] = 0xFFFFFFFE
+    st = _check_tick(gp, oracle, cur, load, aff, cap, alive)
+    assert st["n_objects"] < n and st["n_objects"] == st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"]
+
+
 def test_tick_fast_path_no_contention(gp, oracle):
     cfg = synth.config("c3", n_override=500_000)
     cfg["cap"] = synth.uniform_cap(cfg["load"], cfg["m"], headroom=2.5)  # few rows per node: keep every node under cap
@@ -351,7 +366,7 @@ def test_async_solves_match_sync(gp, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("fused,spec", [(True, "auto"), (False, "never"), (True, "always")])
+@pytest.mark.parametrize("fused,spec", [("split", "auto"), (True, "auto"), (False, "never"), (True, "always"), ("split", "always")])
 def test_churn_stream_adaptive_packed_fixup(gp, oracle, fused, spec):
     """Config-5 shape: committed ticks while a different 10 % of the nodes is down each tick.  From the second tick
     on the adaptive rule switches to the packed fix-up (few rows pending) and — fused fix-up — enqueues it
@@ -370,6 +385,38 @@ def test_churn_stream_adaptive_packed_fixup(gp, oracle, fused, spec):
         assert np.array_equal(g.get_assign(), ref), tick
         assert np.array_equal(g.get_nodes()[2], used), tick
         assert tick == 0 or (ost["slow_path"] == 1 and ost["evicted"] > 0)
+    g.close()
+
+
+def test_async_ticks_equal_the_synchronous_stream(gp, oracle):
+    """rio_gp_tick_async: committed ticks enqueued back to back with liveness pushes in between, nothing waits on the host;
+    tables and counters must be exactly those of the same sequence of rio_gp_tick calls (= the oracle chain), including
+    more ticks in flight than the verdict ring holds (64) and synchronous calls in the middle of the stream."""
+    cfg = synth.config("c3", n_override=600_000)
+    n, m = cfg["n"], cfg["m"]
+    ref = synth.warm_assign(n, m)
+    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"], ref)
+    want = []
+    ticks = 70
+    for tick in range(ticks):
+        alive = synth.churn_mask(m, 2 + tick) if tick % 5 else np.ones(m, np.uint8)   # every fifth tick: nothing to fix
+        g.set_alive_all(alive)
+        g.tick_async()
+        ref, used, ost = oracle.tick(ref, cfg["load"], cfg["aff"], cfg["cap"], alive, 2)
+        want.append(ost)
+        if tick == 30:   # a synchronous lookup in the middle of the stream: ordered behind the ticks enqueued so far
+            q = np.arange(0, n, 977, dtype=np.uint32)
+            assert np.array_equal(g.lookup_batch(q), ref[q])
+    got = g.tick_wait()
+    assert len(got) == ticks
+    for k in range(ticks):
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert np.array_equal(g.get_assign(), ref)
+    assert np.array_equal(g.get_nodes()[2], used)
+    assert g.tick_wait() == []
+    st = g.tick()                                            # and the synchronous call still works afterwards
+    ref, used, ost = oracle.tick(ref, cfg["load"], cfg["aff"], cfg["cap"], alive, 2)
+    assert st == ost and np.array_equal(g.get_assign(), ref)
     g.close()
 
 
@@ -442,6 +489,47 @@ def test_place_pending_micro_batches(gp, oracle, seed, cap_mode):
             assert np.array_equal(g.get_nodes()[2], used)
     assert np.array_equal(g.get_assign(), ref)
     assert np.array_equal(g.get_nodes()[2], used)
+    g.close()
+
+
+def test_place_pending_dev_equals_host_call(gp, oracle):
+    """rio_gp_place_pending_dev: request / result arrays resident in HBM (torch tensors), same answers as the oracle;
+    a bad entry fails the call before anything changes."""
+    import torch
+    rng = np.random.default_rng(77)
+    n, m = 400_000, 300
+    load = rng.integers(0, 40, n).astype(np.uint32)
+    cap = rng.integers(0, int(load.sum() / m) + 5, m).astype(np.uint64)
+    alive = np.ones(m, np.uint8)
+    alive[[7, 100]] = 0
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step in range(4):
+        k = int(rng.integers(1000, 300_000))
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        req = rng.integers(0, m, k).astype(np.uint32)
+        d_idx = torch.from_numpy(idx.astype(np.int64)).to(torch.int32).cuda()
+        d_req = torch.from_numpy(req.astype(np.int64)).to(torch.int32).cuda()
+        d_node = torch.empty(k, dtype=torch.int32, device="cuda")
+        d_flag = torch.empty(k, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g.place_pending_dev(k, d_idx.data_ptr(), d_req.data_ptr(), d_node.data_ptr(), d_flag.data_ptr())
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(d_node.cpu().numpy().view(np.uint32), wnode), step
+        assert np.array_equal(d_flag.cpu().numpy().view(np.uint32), wflag), step
+        assert np.array_equal(g.get_assign(), ref)
+        assert np.array_equal(g.get_nodes()[2], used)
+    bad = torch.tensor([1, 2, n, 3], dtype=torch.int64).to(torch.int32).cuda()      # index n is out of range
+    rq = torch.zeros(4, dtype=torch.int32, device="cuda")
+    out = torch.empty(4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(gp.ObjectPlacementError) as e:
+        g.place_pending_dev(4, bad.data_ptr(), rq.data_ptr(), out.data_ptr())
+    assert e.value.rc == gp.EINVAL
+    assert np.array_equal(g.get_assign(), ref)                                       # nothing was changed
     g.close()
 
 

@@ -176,11 +176,9 @@ def test_hip_shard_native_rccl_world1(gp, oracle):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("legacy", [False, True])
-def test_hip_shard_p2p_world1(gp, oracle, legacy, monkeypatch):
+def test_hip_shard_p2p_world1(gp, oracle):
     """Peer-to-peer window path with a single rank: export/connect/handshake, the one-launch tagged exchange
-    (k_resolve_xchg) or the legacy put + flag-gated import (RIO_GP_P2P_LEGACY=1, read at handle creation), Y exchanges."""
-    monkeypatch.setenv("RIO_GP_P2P_LEGACY", "1" if legacy else "0")
+    (k_resolve_xchg), Y exchanges."""
     import torch
     import torch.distributed as dist
     import sharded
@@ -242,14 +240,13 @@ def _proc(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,world", [("gloo", 2), ("p2p", 2), ("p2p-legacy", 2), ("p2p", 3), ("p2p", 5)])
+@pytest.mark.parametrize("exchange,world", [("gloo", 2), ("p2p", 2), ("p2p", 3), ("p2p", 5)])
 def test_hip_shards_several_processes_one_gpu(gp, oracle, tmp_path, exchange, world, monkeypatch):
     """One process per rank, all on the one GPU of the box: real cross-process windows, every rank's claim prefix over
     the lower ranks, forced nodes, back-to-back steps (slot reuse), then a committed tick with the fix-up exchanges."""
     import torch.multiprocessing as mp
     from test_sharded_protocol import random_case
-    monkeypatch.setenv("RIO_TEST_EXCHANGE", exchange.split("-")[0])
-    monkeypatch.setenv("RIO_GP_P2P_LEGACY", "1" if exchange.endswith("legacy") else "0")
+    monkeypatch.setenv("RIO_TEST_EXCHANGE", exchange)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_proc, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     case = random_case(31, n=200_000, m=50, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)

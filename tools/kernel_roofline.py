@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""rocprofv3 outputs of tools/kernel_roofline.sh -> one record per kernel: average duration, algorithmic bytes per launch,
+HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, calibrated on the stream probes of the same session),
+achieved algorithmic GB/s, fraction of the 8 TB/s roofline and traffic / algorithmic.  Usage:
+  kernel_roofline.py <dir with <phase>_{trace,fetch,write} sub-directories> <out.json>"""
+import csv, glob, json, os, re, sys
+
+N, M = 10_000_000, 1024
+PEAK = 8000.0
+
+
+def trace_avg(d):
+    """kernel name -> (avg duration us, launches, [durations])"""
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"]
+            acc.setdefault(k, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    return {k: (sum(v) / len(v), len(v), v) for k, v in acc.items()}
+
+
+def pmc_avg(d, counter):
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("riogp::", "")
+
+
+# (phase, kernel-name regex) -> (label, algorithmic bytes per launch, what the bytes are)
+def specs(pending_rows):
+    pk = pending_rows   # packed rows of a churn tick
+    return [
+        ("fast", r"k_scan<false, true, 2, false", "k_scan (fast path, TPI 2)", 16 * N, "12 B read + 4 B written per row"),
+        ("fast", r"k_resolve", "k_resolve", 2 * M * 8 * 256, "H: 2m u64 per block x 256 blocks"),
+        ("churn", r"k_scan<false, false, 1, true", "k_scan<COMPACT> (churn tick)", 16 * N + 16 * pk, "16 B/row + 16 B per packed pending row"),
+        ("churn", r"k_cut_find<true>", "k_cut_find (packed rows)", 12 * pk, "one pass over the packed pending rows of the blocks that own cuts (upper bound: all)"),
+        ("churn", r"k_cut_apply_rank<true>", "k_cut_apply_rank (packed rows)", 12 * pk, "12 B per packed pending row (+4 B per rejected)"),
+        ("churn", r"k_spill_rank", "k_spill_rank (round 1)", M * 24, "cap/used/alive of every node per workgroup"),
+        ("churn", r"k_spill_apply", "k_spill_apply (packed rows, both rounds)", 12 * pk, "next + load + idx of the packed rows (+8 B per placed)"),
+        ("churn_unpacked", r"k_cut_find<false>", "k_cut_find (whole table, churn)", 12 * N, "upper bound: every block owns a cut"),
+        ("churn_unpacked", r"k_cut_apply_rank<false>", "k_cut_apply_rank (whole table, churn)", 12 * N, "12 B/row"),
+        ("churn_unpacked", r"k_spill_apply", "k_spill_apply (whole table, churn)", 8 * N, "next + load per row"),
+        ("contended", r"k_cut_find<false>", "k_cut_find (whole table, contended)", 12 * N, "one pass over the blocks that own cuts (all)"),
+        ("contended", r"k_cut_apply_rank<false>", "k_cut_apply_rank (whole table, contended)", 12 * N, "12 B/row"),
+        ("contended", r"k_spill_apply", "k_spill_apply (whole table, contended)", 8 * N, "next + load per row"),
+        ("crud", r"k_lookup4", "k_lookup4 (10 M random / 5 M sequential mixed)", 12 * N, "idx + gather + out per lookup"),
+        ("crud", r"k_update_elect", "k_update_elect (10 M random)", 8 * N, "idx + node per entry (update = elect + apply: 8 B/op over both)"),
+        ("crud", r"k_update_apply", "k_update_apply (10 M random)", 8 * N, "see k_update_elect"),
+        ("crud", r"k_remove", "k_remove (10 M random)", 8 * N, "idx + row per removal"),
+        ("crud", r"k_clean", "k_clean (10 % of the nodes)", 4 * N, "4 B/row read (+4 B per evicted row)"),
+        ("pp", r"k_pp_mark_dead", "k_pp_mark_dead (1 M requests)", 12 * 1_000_000, "idx + req + row per request"),
+        ("pp", r"k_pp_elect", "k_pp_elect", 8 * 1_000_000, "idx + scratch slot"),
+        ("pp", r"k_pp_gather", "k_pp_gather", 32 * 1_000_000, "idx, req, pos, assign, load in; 3 virtual columns out"),
+        ("pp", r"k_scan<true", "k_scan<VIRT> (1 M virtual rows)", 16 * 1_000_000, "16 B per virtual row"),
+        ("pp", r"k_pp_scatter", "k_pp_scatter", 16 * 1_000_000, "vcur, vnext, idx, assign"),
+        ("pp", r"k_pp_output", "k_pp_output", 24 * 1_000_000, "idx, req, assign, vcur in; node, flag out; scratch reset"),
+    ]
+
+
+def main():
+    base, out = sys.argv[1], sys.argv[2]
+    # calibration from the probes phase
+    pf, pw = pmc_avg(os.path.join(base, "probes_fetch"), "FETCH_SIZE"), pmc_avg(os.path.join(base, "probes_write"), "WRITE_SIZE")
+    col = 4.0 * N
+    def pick(d, needle):
+        for k, v in d.items():
+            if needle in k:
+                return v
+        return None
+    fs = [x for x in (col / pick(pf, "k_probe_copy") / 1024 if pick(pf, "k_probe_copy") else None,
+                      3 * col / pick(pf, "k_probe_readonly") / 1024 if pick(pf, "k_probe_readonly") else None,
+                      3 * col / pick(pf, "k_probe_gridstride") / 1024 if pick(pf, "k_probe_gridstride") else None) if x]
+    ws = [x for x in (col / pick(pw, "k_probe_copy") / 1024 if pick(pw, "k_probe_copy") else None,
+                      col / pick(pw, "k_probe_gridstride") / 1024 if pick(pw, "k_probe_gridstride") else None) if x]
+    fscale = sum(fs) / len(fs) if fs else 2.0
+    wscale = sum(ws) / len(ws) if ws else 1.0
+    pending = None
+    try:
+        pending = json.load(open(os.path.join(base, "churn_stats.json")))["pending_rows"]
+    except Exception:
+        pending = 1_000_000
+    doc = {"n_rows": N, "n_nodes": M, "peak_GBps": PEAK,
+           "calibration": {"fetch_bytes_per_reported_byte": fscale, "write_bytes_per_reported_byte": wscale,
+                           "note": "FETCH_SIZE / WRITE_SIZE (KiB) scaled by known-traffic stream probes of the same session "
+                                   "(MI355X_MICROARCH.md section HBM: gfx950 FETCH_SIZE reports half of a wide coalesced read); "
+                                   "narrow / scattered accesses are NOT covered by that calibration: their counter bytes are a lower bound"},
+           "churn_pending_rows": pending, "kernels": []}
+    cache = {}
+    for phase, pat, label, alg, what in specs(pending):
+        if phase not in cache:
+            cache[phase] = (trace_avg(os.path.join(base, phase + "_trace")), pmc_avg(os.path.join(base, phase + "_fetch"), "FETCH_SIZE"),
+                            pmc_avg(os.path.join(base, phase + "_write"), "WRITE_SIZE"))
+        tr, pf_, pw_ = cache[phase]
+        names = [k for k in tr if re.search(pat, short(k))]
+        if not names:
+            doc["kernels"].append({"kernel": label, "phase": phase, "missing": True})
+            continue
+        durs = [d for k in names for d in tr[k][2]]
+        dur = sum(durs) / len(durs)
+        f = [pf_[k] for k in names if k in pf_]
+        w = [pw_[k] for k in names if k in pw_]
+        traffic = None
+        if f and w:
+            traffic = (sum(f) / len(f)) * 1024 * fscale + (sum(w) / len(w)) * 1024 * wscale
+        rec = {"kernel": label, "phase": phase, "launches": len(durs), "avg_us": dur, "algorithmic_bytes": alg, "bytes_are": what,
+               "achieved_GBps": alg / dur / 1e3, "frac_of_8TBps": alg / dur / 1e3 / PEAK,
+               "counter_bytes": traffic, "traffic_over_algorithmic": (traffic / alg) if traffic else None}
+        doc["kernels"].append(rec)
+    json.dump(doc, open(out, "w"), indent=1)
+    for r in doc["kernels"]:
+        if r.get("missing"):
+            print("%-46s MISSING" % r["kernel"])
+        else:
+            print("%-46s %9.1f us  %8.1f GB/s  %5.1f %%  traffic/alg %s" % (r["kernel"], r["avg_us"], r["achieved_GBps"], 100 * r["frac_of_8TBps"],
+                  ("%.2f" % r["traffic_over_algorithmic"]) if r["traffic_over_algorithmic"] else "-"))
+
+
+if __name__ == "__main__":
+    main()

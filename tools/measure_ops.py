@@ -131,4 +131,24 @@ for k in (1, 1000, 100_000, 1_000_000):
     t0 = time.perf_counter(); g.place_pending(ii, rq); t = time.perf_counter() - t0
     rec("place_pending batch=%d (host buffers)" % k, k, t, 28, "PCIe-inclusive, cold rows")
 g.close()
+# --- place_pending_dev: request / result arrays resident in HBM, kernel-side time (HIP events on the library stream) ---
+g = mk()
+onode = torch.empty(n, dtype=torch.int32, device="cuda")
+oflag = torch.empty(n, dtype=torch.int32, device="cuda")
+req = torch.from_numpy(cfg["aff"].astype(np.int64)).to(torch.int32).cuda()
+perm = torch.from_numpy((synth.r(np.arange(n, dtype=np.uint64), 9) % np.uint64(n)).astype(np.int64)).to(torch.int32).cuda()
+reqp = req[perm.long()].contiguous()
+torch.cuda.synchronize()
+for k in (1000, 100_000, 1_000_000, 10_000_000):
+    ts = []
+    for rep in range(4):
+        g.set_assign(np.full(n, 0xFFFFFFFF, np.uint32))
+        g.get_nodes()
+        g.sync()
+        g.timer_begin()
+        L.rio_gp_place_pending_dev(h2 := g.handle, k, vp(perm.data_ptr()), vp(reqp.data_ptr()), vp(onode.data_ptr()), vp(oflag.data_ptr()))
+        ts.append(g.timer_end() * 1e-3)
+    rec("place_pending_dev batch=%d (cold rows)" % k, k, float(np.mean(ts[1:])), 28,
+        "device-resident requests; includes the validation read-back and the verdict wait (2 host waits)")
+g.close()
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", tag + "_ops.json"), "w"), indent=1)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Streaming-probe sweep inside and beyond the 256 MiB Infinity Cache: what the chip gives the solve's 3-read/1-write
-mix, a read-only pass and a 1:1 copy, with and without non-temporal hints, next to k_scan (TPI 1 and 2).
+mix, a read-only pass and a 1:1 copy, with and without non-temporal hints, next to k_scan with plain and with non-temporal
+column streams (launch_scan switches to the latter at 20 Mi rows; rio_gp_debug_set_scan_nt forces either).
 Usage: nt_probe.py [rows,rows,...]"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,13 +22,13 @@ for n in rows:
     g.set_nodes(synth.uniform_cap(load, m), np.ones(m, np.uint8))
     g.set_objects(n, load, aff)
     rec = {"rows": n}
-    for code, name in ((1, "tpi1"), (2, "tpi2")):
-        rio_gp.lib().rio_gp_debug_set_scan_tpi(code)
+    for code, name in ((2, "plain"), (1, "nt")):
+        rio_gp.lib().rio_gp_debug_set_scan_nt(code)
         for _ in range(5):
             g.solve_profiled()
         sc = [g.solve_profiled()[0] for _ in range(30)]
         rec["k_scan_%s_GBps" % name] = 16 * n / float(np.median(sc)) / 1e6
-    rio_gp.lib().rio_gp_debug_set_scan_tpi(2)
+    rio_gp.lib().rio_gp_debug_set_scan_nt(0)
     for mode, name, nb in ((0, "3r1w", 16), (5, "3r1w_8192wg", 16), (7, "3r1w_ntload", 16), (8, "3r1w_ntstore", 16),
                            (9, "3r1w_ntboth", 16), (3, "read3", 12), (4, "copy", 8), (2, "3r1w_wavecontig", 16)):
         ms = g.stream_probe(mode, 10)

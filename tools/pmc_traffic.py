@@ -27,8 +27,8 @@ def pick(d, needle):
     return None
 
 
-def main():
-    fdir, wdir, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+def compute(fdir, wdir, n):
+    """Counters of the two passes -> dict (see the module docstring); bench.py calls this for its in-run passes."""
     F, W = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
     col = 4.0 * n  # bytes of one u32 column
     f_copy, f_ro, f_gs = pick(F, "k_probe_copy"), pick(F, "k_probe_readonly"), pick(F, "k_probe_gridstride")
@@ -55,6 +55,12 @@ def main():
         doc["hbm_bytes_per_launch"] = rd + wr
     if f_res and w_res and fs and ws:
         doc["k_resolve"] = {"hbm_bytes_per_launch": f_res * 1024 * fs + w_res * 1024 * ws}
+    return doc
+
+
+def main():
+    fdir, wdir, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    doc = compute(fdir, wdir, n)
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps({k: doc[k] for k in doc if k not in ("raw_KiB",)}))
 

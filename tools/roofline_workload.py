@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""One PHASE of the hot path per process, for the rocprofv3 passes of tools/kernel_roofline.sh (kernel trace + the two PMC
+passes): every kernel DESIGN.md section 4 names runs in exactly one phase with known algorithmic bytes, so that its
+duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round2_kernel_roofline.json).
+Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|crud|pp|probes> [reps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np
+import rio_gp, synth
+
+phase = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+cfg = synth.config("c3")
+n, m = cfg["n"], cfg["m"]
+g = rio_gp.GpuPlacement(n, m)
+g.set_nodes(cfg["cap"], cfg["alive"])
+g.set_objects(n, cfg["load"], cfg["aff"])
+if phase == "fast":                      # k_scan<.., TPI 2>, k_resolve
+    for _ in range(reps * 3):
+        g.solve_async()
+    g.solve_wait()
+elif phase in ("churn", "churn_unpacked"):   # k_scan<COMPACT>, k_cut_find, k_cut_apply_rank, k_spill_rank, k_spill_apply (packed rows)
+    if phase == "churn_unpacked":
+        g.set_compact("never")
+    g.set_assign(synth.warm_assign(n, m))
+    g.tick()
+    for k in range(reps + 2):
+        g.set_alive_all(synth.churn_mask(m, 2 + k))
+        st = g.tick()
+    if os.environ.get("RIO_KROOF_DIR"):
+        import json
+        json.dump({"pending_rows": st["claimed"] + st["spilled"] + st["unplaced"], "last_tick": st},
+                  open(os.path.join(os.environ["RIO_KROOF_DIR"], "churn_stats.json"), "w"))
+elif phase == "contended":               # the same fix-up kernels over ALL rows (cold table, capacity 0.9 x load)
+    g.set_nodes((cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64), cfg["alive"])
+    for _ in range(reps):
+        g.solve()
+elif phase in ("crud", "pp"):
+    import ctypes as C
+    import torch
+    L, h, vp = rio_gp.lib(), g.handle, C.c_void_p
+    idx = torch.from_numpy((synth.r(np.arange(n, dtype=np.uint64), 7) % np.uint64(n)).astype(np.int64)).to(torch.int32).cuda()
+    node = torch.from_numpy(synth.warm_assign(n, m, stream=8).astype(np.int64)).to(torch.int32).cuda()
+    outb = torch.empty(n, dtype=torch.int32, device="cuda")
+    flg = torch.empty(n, dtype=torch.int32, device="cuda")
+    seq = torch.arange(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    if phase == "crud":                  # k_lookup4 (random, then sequential), k_update_*, k_remove, k_clean
+        g.set_assign(synth.warm_assign(n, m))
+        for _ in range(3):
+            L.rio_gp_lookup_batch_dev(h, n, vp(idx.data_ptr()), vp(outb.data_ptr()))
+        for _ in range(3):
+            L.rio_gp_update_batch_dev(h, n, vp(idx.data_ptr()), vp(node.data_ptr()))
+        for _ in range(3):
+            L.rio_gp_remove_batch_dev(h, n, vp(idx.data_ptr()))
+            g.set_assign(synth.warm_assign(n, m))
+        for k in range(3):
+            g.clean_servers(list(np.flatnonzero(synth.churn_mask(m, 1 + k) == 0)))
+            g.set_assign(synth.warm_assign(n, m))
+        L.rio_gp_lookup_batch_dev(h, n // 2, vp(seq.data_ptr()), vp(outb.data_ptr()))   # n/2 sequential: a different launch size -> told apart in the trace
+    else:                                # k_pp_* + the virtual-table solve, 1 M requests on a cold table
+        k = 1_000_000
+        for _ in range(3):
+            g.set_assign(np.full(n, 0xFFFFFFFF, np.uint32))
+            g.get_nodes()
+            L.rio_gp_place_pending_dev(h, k, vp(idx.data_ptr()), vp(node.data_ptr()), vp(outb.data_ptr()), vp(flg.data_ptr()))
+elif phase == "probes":                  # known traffic: calibration of FETCH_SIZE / WRITE_SIZE
+    for mode in (4, 0, 3):
+        g.stream_probe(mode, 10)
+g.close()

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Workload for profiling the fix-up path (cut + water-fill): config-5 churn ticks, the contended cold solve
-and the skewed cold solve.  Usage: slowpath_workload.py [churn|contended|skew] [reps] [auto|always|never (packed)] [default|legacy|fused|spec]
-  default = fused cut fix-up, speculative enqueue after a solve that needed the fix-up (what the library does)
-  legacy  = the unfused launch chain, no speculation;  fused = fused, never speculative;  spec = fused, always"""
+and the skewed cold solve.  Usage: slowpath_workload.py [churn|contended|skew] [reps] [auto|always|never (packed)] [default|legacy|fusedk|fused|spec]
+  default = split cut fix-up (k_cut_find + k_cut_apply_rank), speculative enqueue after a solve that needed the fix-up (what the library does)
+  legacy  = the unfused launch chain, no speculation;  fusedk = ONE fused cut launch (k_cut_fused), speculation as default;
+  fused = k_cut_fused, never speculative;  spec = k_cut_fused, always speculative"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -18,7 +19,7 @@ if len(sys.argv) > 3:
     g.set_compact(sys.argv[3])   # auto | always | never
 fx = sys.argv[4] if len(sys.argv) > 4 else "default"
 if fx != "default":
-    g.set_fixup(fused=(fx != "legacy"), speculate={"legacy": "never", "fused": "never", "spec": "always"}[fx])
+    g.set_fixup(fused=(fx != "legacy"), speculate={"legacy": "never", "fusedk": "auto", "fused": "never", "spec": "always"}[fx])
 res = {"which": which, "reps": reps, "n": n, "m": m, "compact": sys.argv[3] if len(sys.argv) > 3 else "auto", "fixup": fx}
 if which == "churn":
     g.set_nodes(cfg["cap"], cfg["alive"])
