@@ -28,6 +28,9 @@ int rio_gp_debug_set_fixup(rio_gp_t* h, int impl, int speculate);
 void rio_gp_debug_set_scan_nt(int mode);
 /* read (out2048 != NULL: 256 workgroups x 8 words) and switch the phase trace of the cut kernels */
 int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048);
+/* phase traces of the other fix-up kernels (switched by rio_gp_debug_cut_trace's enable): table 0 / 1 = k_spill_apply
+ * first / last round, 2 = k_cut_apply_rank, 3 = k_cut_find; 256 workgroups x 8 words of wall_clock64 (100 MHz) */
+int rio_gp_debug_ktrace(rio_gp_t* h, int table, uint64_t* out2048);
 /* pure streaming kernels with k_scan's traffic mix (3 columns in, 1 out) over the handle's own columns; mode
  * 0 grid-stride | 1 block-tiled | 2 wave-contiguous | 3 read-only | 4 1:1 copy.  ms per launch. */
 int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms);

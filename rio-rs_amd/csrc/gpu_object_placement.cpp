@@ -35,6 +35,7 @@
 namespace {
 
 constexpr int kFull = -1000;  // internal: the object table has no free row (reclaim, then retry)
+constexpr int kNoop = -1001;  // internal: nothing to do on the device (an unknown key looked up / removed / deleted)
 
 // Text of the calling thread's last failed call (rio_op_last_error): a failure is reported to the thread that made
 // the call, so its text is that thread's too — no lock, no race with other callers' failures.
@@ -405,7 +406,7 @@ int run_combined(State* s, Req* mine) {
 
 // A single-object call: intern under imu (held off while keys are being reclaimed), count as in flight while its row id
 // is on its way to the device (reclaim() waits for that count to drain before it forgets any key).
-// `intern` fills the request and returns RIO_GP_OK, kFull, an error, or 1 = "nothing to do" (e.g. lookup of an unknown key).
+// `intern` fills the request and returns RIO_GP_OK, kFull, an error, or kNoop = "nothing to do" (e.g. lookup of an unknown key).
 template <typename F>
 int single_call(State* s, Req* r, F intern) {
     for (int attempt = 0;; ++attempt) {
@@ -564,9 +565,9 @@ int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr)
         }
         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
         if ((rc = intern_row(s, ty, id, false, &r.row))) return rc;
-        return r.row == RIO_GP_NONE ? 1 : RIO_GP_OK;
+        return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;
     });
-    return rc == 1 ? RIO_GP_OK : rc;
+    return rc == kNoop ? RIO_GP_OK : rc;
 }
 
 int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids, uint32_t* out) {
@@ -605,9 +606,9 @@ int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t
     const int rc = single_call(s, &r, [&]() -> int {
         const int rc = intern_row(s, ty, id, false, &r.row);
         if (rc) return rc;
-        return r.row == RIO_GP_NONE ? 1 : RIO_GP_OK;  // unknown key: Ok(None), no device work
+        return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;  // unknown key: Ok(None), no device work
     });
-    if (rc == 1) return RIO_GP_OK;
+    if (rc == kNoop) return RIO_GP_OK;
     if (rc) return rc;
     *found = r.node != RIO_GP_NONE;
     if (*found) {
@@ -640,9 +641,9 @@ int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
     const int rc = single_call(s, &r, [&]() -> int {
         const int rc = intern_row(s, ty, id, false, &r.row);
         if (rc) return rc;
-        return r.row == RIO_GP_NONE ? 1 : RIO_GP_OK;  // absent: no-op (local.rs:60-68)
+        return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;  // absent: no-op (local.rs:60-68)
     });
-    return rc == 1 ? RIO_GP_OK : rc;
+    return rc == kNoop ? RIO_GP_OK : rc;
 }
 
 int rio_op_len(rio_op_t* p, uint64_t* out) {

@@ -121,6 +121,7 @@ unsigned resolve_blocks(u32 m);
 void set_scan_nt(int mode);  // 0 by table size | 1 always | 2 never: non-temporal column streams in k_scan
 int cut_trace_enable(int on);  // k_cut_fused phase trace (measurement aid)
 int cut_trace_read(u64* out /*[kMaxBlocks*8]*/);
+int ktrace_read(int table, u64* out /*[kMaxBlocks*8]*/);  // 0/1 k_spill_apply first/last round, 2 k_cut_apply_rank, 3 k_cut_find
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1);
 // impl: 2 = k_cut_find + k_cut_apply_rank | 1 = k_cut_fused | 0 = the unfused chain.  have_cutblk: launch_resolve of the

@@ -804,6 +804,11 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
 __device__ int g_cut_trace_on = 0;
 __device__ u64 g_cut_trace[kMaxBlocks * 8];
 #define RIOGP_TRACE(slot, val) do { if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + (slot)] = (val); } while (0)
+// the same for the other fix-up kernels: table 0 = k_spill_apply (first round), 1 = k_spill_apply (last round),
+// 2 = k_cut_apply_rank, 3 = k_cut_find (item table / first item / end); workgroup b, phase boundary `slot`
+constexpr int kKtTables = 4;
+__device__ u64 g_kt[kKtTables][kMaxBlocks * 8];
+#define RIOGP_KT(table, slot) do { if (threadIdx.x == 0 && g_cut_trace_on && blockIdx.x < kMaxBlocks) g_kt[table][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
 
 constexpr u32 kSlotNone = 0xFFFFu;
 constexpr int kCutMinSubs = 16;  // smallest fan-out of a refinement level
@@ -1259,6 +1264,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
     if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 m = p.m, G = p.G;
+    RIOGP_KT(3, 0);
     if (forced_bits && blockIdx.x == 0)  // row-sharded solve: the prefix overflowed on a lower rank — nothing is admitted here
         for (u32 j = tid; j < m; j += kBlock)
             if (bit_of(forced_bits, j)) { cutidx[j] = 0; used_cur[j] = used_kept[j]; }
@@ -1292,6 +1298,8 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
     }
     __syncthreads();
     const u32 items = istart[kMaxBlocks];
+    RIOGP_KT(3, 1);
+    if (threadIdx.x == 0 && g_cut_trace_on && blockIdx.x < kMaxBlocks) g_kt[3][(size_t)blockIdx.x * 8 + 3] = items;
     for (u32 item = blockIdx.x; item < items; item += gridDim.x) {
         u32 lo = 0, hi = kMaxBlocks;  // the last block whose first item is <= item (blocks without cuts share their successor's start)
         while (hi - lo > 1) {
@@ -1302,6 +1310,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
         cut_search_block<VIRT>(smem, lo, nsl[lo], item - istart[lo], false, cur, load, aff, alive_bits, p, cutblk, budget,
                                admpre, used_kept, forced_bits, cutidx, used_cur, tcap);
     }
+    RIOGP_KT(3, 2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1425,10 +1434,12 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
     u32* thr = reinterpret_cast<u32*>(smem + kSmall);  // [m] first rejected row of a node's claimants (kNoCut: none)
     u32* alv = thr + ((m + 3) & ~3u);                  // [mwords]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RIOGP_KT(2, 0);
     for (u32 j = tid; j < m; j += kBlock) thr[j] = (forced_bits && bit_of(forced_bits, j)) ? 0u : cutidx[j];
     for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
     if (tid < 2) red[tid] = 0;
     __syncthreads();
+    RIOGP_KT(2, 1);
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
@@ -1461,6 +1472,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
         RIOGP_ROW(cv.w, av.w, lv.w, 3)
 #undef RIOGP_ROW
     }
+    RIOGP_KT(2, 2);
     sp_sum = wave_sum(sp_sum);
     rej_sum = wave_sum(rej_sum);
     if (lane == 0) {
@@ -1473,6 +1485,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
         atomicAdd(&stats->rejected, red[0]);
         atomicAdd(&stats->load_rejected, red[1]);
     }
+    RIOGP_KT(2, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1496,6 +1509,8 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     u64* C = reinterpret_cast<u64*>(smem + 2 * kSmall);    // [m+1]
     u64* adm = C + (m + 1);                                // [m] admitted load by node (this block)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ktab = last ? 1 : 0;
+    RIOGP_KT(ktab, 0);
     // Prologue: what is pending, and where does this workgroup's first wave start in the index-ordered spill prefix?
     // Every workgroup folds the per-wave totals of the previous step itself (nw <= 4 096 words of each: L2 reads).
     u64 my_base;
@@ -1535,6 +1550,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         for (int w = 0; w < wave; ++w) my_base += part[w];
         __syncthreads();  // red / part are reused below
     }
+    RIOGP_KT(ktab, 1);
     const u32 cnt = *wfCnt;
     {   // C[0] = 0, C[k+1] = sat(C[k] + free of rank k): saturating block scan of the ranked free values
         const u32 mp = (m + kBlock - 1) / kBlock * kBlock, per = mp / kBlock;
@@ -1554,6 +1570,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     for (u32 k = tid; k < m; k += kBlock) adm[k] = 0;
     if (tid < 4) red[tid] = 0;
     __syncthreads();
+    RIOGP_KT(ktab, 2);
     const u64 F = C[cnt];
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
@@ -1646,6 +1663,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         run = run_end;
         lo_run = hi_run;
     }
+    RIOGP_KT(ktab, 3);
     rem_sum = wave_sum(rem_sum);
     rem_cnt = wave_sum32(rem_cnt);
     pl_sum = wave_sum(pl_sum);
@@ -1657,12 +1675,14 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         if (last && rem_cnt) { atomicAdd(&red[2], (u64)rem_cnt); atomicAdd(&red[3], rem_sum); }
     }
     __syncthreads();
+    RIOGP_KT(ktab, 4);
     for (u32 k = tid; k < m; k += kBlock)
         if (adm[k]) atomicAdd(&used_cur[k], adm[k]);  // integer sums: order-independent
     if (tid == 0) {
         if (red[0]) { atomicAdd(&stats->spilled, red[0]); atomicAdd(&stats->load_spilled, red[1]); }
         if (red[2]) { atomicAdd(&stats->unplaced, red[2]); atomicAdd(&stats->load_unplaced, red[3]); }
     }
+    RIOGP_KT(ktab, 5);
 }
 
 // packed fix-up: decisions of the packed rows back into the real assignment column
@@ -2426,6 +2446,10 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
 
 int cut_trace_enable(int on) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_trace_on), &on, sizeof on); }
 int cut_trace_read(u64* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cut_trace), sizeof(u64) * kMaxBlocks * 8); }
+int ktrace_read(int table, u64* out) {
+    if (table < 0 || table >= kKtTables) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kt), sizeof(u64) * kMaxBlocks * 8, sizeof(u64) * kMaxBlocks * 8 * (size_t)table);
+}
 
 template <bool VIRT, bool AA, int TPI, bool COMPACT = false, bool NT = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,

@@ -270,10 +270,13 @@ u64* slot_dev(rio_gp* h, u32 k) { return h->d_slots + (size_t)(k % kRing) * h->s
 constexpr u32 kTickSlot0 = (u32)kRing;  // slot index k >= kRing: the asynchronous ticks' half of the slot table
 
 // host-side fold of the per-workgroup partial rows k_resolve stored into a pinned slot
-DevStats reduce_slot(rio_gp* h, u32 k, u32 m) {
+DevStats reduce_rows(rio_gp* h, size_t slot, u32 m);
+DevStats reduce_slot(rio_gp* h, u32 k, u32 m) { return reduce_rows(h, k % kRing, m); }                    // solve ring
+DevStats reduce_tick_slot(rio_gp* h, u32 k, u32 m) { return reduce_rows(h, kTickSlot0 + k % kRing, m); }  // tick ring
+DevStats reduce_rows(rio_gp* h, size_t slot, u32 m) {
     DevStats d;
     memset(&d, 0, sizeof d);
-    const u64* rows = h->h_slots + (size_t)(k >= kTickSlot0 ? kTickSlot0 + (k - kTickSlot0) % kRing : k % kRing) * h->slot_rows * 8;
+    const u64* rows = h->h_slots + slot * h->slot_rows * 8;
     const unsigned nb = resolve_blocks(m);
     for (unsigned r = 0; r < nb; ++r) {
         const u64* x = rows + (size_t)r * 8;
@@ -388,7 +391,7 @@ int harvest_ticks(rio_gp* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     for (u32 k = 0; k < h->tick_n; ++k) {
-        DevStats v = reduce_slot(h, kTickSlot0 + k, h->m);
+        DevStats v = reduce_tick_slot(h, k, h->m);
         const bool slow = v.n_cut > 0 || v.spillcand > 0;
         if (slow) {
             const DevStats& d = h->h_tick_stats[k];
@@ -1620,6 +1623,15 @@ int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (out2048 && cut_trace_read(reinterpret_cast<u64*>(out2048)) != 0) return fail(h, RIO_GP_EUPSTREAM, "cut trace read failed");
     if (cut_trace_enable(enable) != 0) return fail(h, RIO_GP_EUPSTREAM, "cut trace enable failed");
+    return RIO_GP_OK;
+}
+
+int rio_gp_debug_ktrace(rio_gp_t* h, int table, uint64_t* out2048) {
+    if (!h || !out2048) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ktrace_read(table, reinterpret_cast<u64*>(out2048)) != 0) return fail(h, RIO_GP_EUPSTREAM, "ktrace read failed");
     return RIO_GP_OK;
 }
 

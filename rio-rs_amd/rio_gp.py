@@ -126,6 +126,7 @@ def lib():
         L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
         L.rio_gp_debug_cut_trace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
+        L.rio_gp_debug_ktrace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
         L.rio_gp_debug_set_fixup.argtypes = [_vp, C.c_int, C.c_int]
         L.rio_gp_timer_begin.argtypes = [_vp]
         L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
@@ -330,6 +331,13 @@ class GpuPlacement:
         out = (C.c_uint64 * 2048)() if read else None
         self._chk(lib().rio_gp_debug_cut_trace(self._h, 1 if enable else 0, out))
         return np.ctypeslib.as_array(out).reshape(256, 8).copy() if read else None
+
+    def ktrace(self, table):
+        """Phase trace of a fix-up kernel's last launch: [256][8] u64 of wall_clock64 (100 MHz); table 0 / 1 k_spill_apply
+        first / last round, 2 k_cut_apply_rank, 3 k_cut_find.  Enable with cut_trace(True)."""
+        out = (C.c_uint64 * 2048)()
+        self._chk(lib().rio_gp_debug_ktrace(self._h, table, out))
+        return np.ctypeslib.as_array(out).reshape(256, 8).copy()
 
     def set_compact(self, mode):
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode)."""

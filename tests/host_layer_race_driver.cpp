@@ -154,6 +154,12 @@ int main() {
         int found = 0;
         if (rio_op_lookup(p, "Live", "live0", out, sizeof out, &found) != RIO_GP_OK || !found) ++bad;
         if (full_errors != 8) ++bad;   // 520 keys, 512 rows
+        // the other entry points must report the full table too (update interns a key as well), and "nothing to do" calls
+        // (unknown keys) must stay RIO_GP_OK — the two used to share a return value inside the layer
+        if (rio_op_update(p, "Live", "one-too-many", "10.3.0.1:1") != RIO_GP_EINVAL) ++bad;
+        if (rio_op_update(p, "Nobody", "x", nullptr) != RIO_GP_OK) ++bad;
+        if (rio_op_remove(p, "Nobody", "x") != RIO_GP_OK) ++bad;
+        if (rio_op_lookup(p, "Nobody", "x", out, sizeof out, &found) != RIO_GP_OK || found) ++bad;
         // a failing request next to good ones: threads looking up good keys while others run into the full table
         std::vector<std::thread> th;
         for (int t = 0; t < 6; ++t)

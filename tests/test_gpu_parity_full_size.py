@@ -164,7 +164,7 @@ def test_config4_as_8_row_shards(gp, oracle):
     for e in engines:
         assert np.array_equal(e.g.get_nodes()[2], used)
     # squeeze the capacities: cuts on every rank, forced nodes on the upper ranks, water-fill across shards
-    cap = (cfg["cap"] * np.uint64(9)) // np.uint64(10)
+    cap = (cfg["cap"] * np.uint64(72)) // np.uint64(100)   # 0.9 x the load
     for e in engines:
         e.g.set_nodes(cap, cfg["alive"])
         e.g.set_assign(np.full(e.g.num_objects, NONE, np.uint32))

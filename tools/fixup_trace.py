@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Where the fix-up kernels of a config-5 churn tick spend their time: phase traces written by the kernels themselves
+(wall_clock64, 100 MHz) for k_cut_find (+ the block search inside it), k_cut_apply_rank and both k_spill_apply rounds.
+Usage: fixup_trace.py [ticks] [auto|never]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np
+import rio_gp, synth
+ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+cfg = synth.config("c3")
+n, m = cfg["n"], cfg["m"]
+g = rio_gp.GpuPlacement(n, m)
+if len(sys.argv) > 2:
+    g.set_compact(sys.argv[2])
+g.set_nodes(cfg["cap"], cfg["alive"])
+g.set_objects(n, cfg["load"], cfg["aff"])
+g.set_assign(synth.warm_assign(n, m))
+g.tick()
+g.cut_trace(True)
+for k in range(ticks):
+    g.set_alive_all(synth.churn_mask(m, 2 + k))
+    st = g.tick()
+us = lambda x: float(x) / 100.0
+def table(t, names):
+    tr = g.ktrace(t).astype(np.int64)
+    live = tr[:, 0] > 0
+    if not live.any():
+        return None
+    t0 = tr[live, 0].min()
+    rec = {"workgroups": int(live.sum())}
+    for i, nm in enumerate(names):
+        if i == 0:
+            rec["start_spread_us"] = us(tr[live, 0].max() - t0)
+            continue
+        d = tr[live, i] - tr[live, i - 1]
+        rec[nm + "_us_median_max"] = [us(np.median(d)), us(d.max())]
+    rec["end_minus_first_start_us_max"] = us(tr[live, len(names) - 1].max() - t0)
+    return rec
+out = {"last_tick": st,
+       "k_spill_apply_round0": table(0, ["start", "prefix+pending", "C[] build", "rows", "block sync", "used_cur atomics"]),
+       "k_spill_apply_last": table(1, ["start", "prefix+pending", "C[] build", "rows", "block sync", "used_cur atomics"]),
+       "k_cut_apply_rank": table(2, ["start", "thr+alive load", "rows", "reduce"])}
+tr = g.ktrace(3).astype(np.int64)
+live = tr[:, 0] > 0
+if live.any():
+    out["k_cut_find"] = {"workgroups": int(live.sum()), "items": int(tr[live, 3].max()),
+                         "item_table_us_median": us(np.median(tr[live, 1] - tr[live, 0])),
+                         "items_us_median_max": [us(np.median(tr[live, 2] - tr[live, 1])), us((tr[live, 2] - tr[live, 1]).max())],
+                         "end_minus_first_start_us_max": us(tr[live, 2].max() - tr[live, 0].min())}
+ct = g.cut_trace(False, read=True).astype(np.int64)
+busy = ct[:, 5] > 0
+if busy.any():
+    out["block_search_last_item_per_wg"] = {"workgroups_with_nodes": int(busy.sum()), "nodes_median_max": [float(np.median(ct[busy, 5])), int(ct[busy, 5].max())],
+                                            "P0_us_median": us(np.median(ct[busy, 1] - ct[busy, 0])), "passes_us_median": us(np.median(ct[busy, 2])),
+                                            "walks_us_median": us(np.median(ct[busy, 7])), "row_search_us_median": us(np.median(ct[busy, 3])), "S_median": float(np.median(ct[busy, 6]))}
+print(json.dumps(out, indent=1))
+g.close()

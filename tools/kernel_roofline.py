@@ -52,7 +52,8 @@ def specs(pending_rows):
         ("contended", r"k_cut_find<false>", "k_cut_find (whole table, contended)", 12 * N, "one pass over the blocks that own cuts (all)"),
         ("contended", r"k_cut_apply_rank<false>", "k_cut_apply_rank (whole table, contended)", 12 * N, "12 B/row"),
         ("contended", r"k_spill_apply", "k_spill_apply (whole table, contended)", 8 * N, "next + load per row"),
-        ("crud", r"k_lookup4", "k_lookup4 (10 M random / 5 M sequential mixed)", 12 * N, "idx + gather + out per lookup"),
+        ("crud", r"k_lookup4", "k_lookup4 (10 M random indices)", 12 * N, "idx + gather + out per lookup"),
+        ("lookup_seq", r"k_lookup4", "k_lookup4 (10 M sequential indices)", 12 * N, "idx + gather + out per lookup"),
         ("crud", r"k_update_elect", "k_update_elect (10 M random)", 8 * N, "idx + node per entry (update = elect + apply: 8 B/op over both)"),
         ("crud", r"k_update_apply", "k_update_apply (10 M random)", 8 * N, "see k_update_elect"),
         ("crud", r"k_remove", "k_remove (10 M random)", 8 * N, "idx + row per removal"),

@@ -2,7 +2,7 @@
 """One PHASE of the hot path per process, for the rocprofv3 passes of tools/kernel_roofline.sh (kernel trace + the two PMC
 passes): every kernel DESIGN.md section 4 names runs in exactly one phase with known algorithmic bytes, so that its
 duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round2_kernel_roofline.json).
-Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|crud|pp|probes> [reps]"""
+Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|crud|lookup_seq|pp|probes> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -37,35 +37,37 @@ elif phase == "contended":               # the same fix-up kernels over ALL rows
     g.set_nodes((cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64), cfg["alive"])
     for _ in range(reps):
         g.solve()
-elif phase in ("crud", "pp"):
+elif phase in ("crud", "pp", "lookup_seq"):
     import ctypes as C
-    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from hipbuf import DevBuf
     L, h, vp = rio_gp.lib(), g.handle, C.c_void_p
-    idx = torch.from_numpy((synth.r(np.arange(n, dtype=np.uint64), 7) % np.uint64(n)).astype(np.int64)).to(torch.int32).cuda()
-    node = torch.from_numpy(synth.warm_assign(n, m, stream=8).astype(np.int64)).to(torch.int32).cuda()
-    outb = torch.empty(n, dtype=torch.int32, device="cuda")
-    flg = torch.empty(n, dtype=torch.int32, device="cuda")
-    seq = torch.arange(n, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+    idx = DevBuf((synth.r(np.arange(n, dtype=np.uint64), 7) % np.uint64(n)).astype(np.uint32))
+    node = DevBuf(synth.warm_assign(n, m, stream=8))
+    outb, flg = DevBuf(nbytes=4 * n), DevBuf(nbytes=4 * n)
+    seq = DevBuf(np.arange(n, dtype=np.uint32))
     if phase == "crud":                  # k_lookup4 (random, then sequential), k_update_*, k_remove, k_clean
         g.set_assign(synth.warm_assign(n, m))
         for _ in range(3):
-            L.rio_gp_lookup_batch_dev(h, n, vp(idx.data_ptr()), vp(outb.data_ptr()))
+            L.rio_gp_lookup_batch_dev(h, n, vp(idx.ptr), vp(outb.ptr))
         for _ in range(3):
-            L.rio_gp_update_batch_dev(h, n, vp(idx.data_ptr()), vp(node.data_ptr()))
+            L.rio_gp_update_batch_dev(h, n, vp(idx.ptr), vp(node.ptr))
         for _ in range(3):
-            L.rio_gp_remove_batch_dev(h, n, vp(idx.data_ptr()))
+            L.rio_gp_remove_batch_dev(h, n, vp(idx.ptr))
             g.set_assign(synth.warm_assign(n, m))
         for k in range(3):
             g.clean_servers(list(np.flatnonzero(synth.churn_mask(m, 1 + k) == 0)))
             g.set_assign(synth.warm_assign(n, m))
-        L.rio_gp_lookup_batch_dev(h, n // 2, vp(seq.data_ptr()), vp(outb.data_ptr()))   # n/2 sequential: a different launch size -> told apart in the trace
+    elif phase == "lookup_seq":          # k_lookup4 over sequential indices: the coalesced ceiling of the same kernel
+        g.set_assign(synth.warm_assign(n, m))
+        for _ in range(5):
+            L.rio_gp_lookup_batch_dev(h, n, vp(seq.ptr), vp(outb.ptr))
     else:                                # k_pp_* + the virtual-table solve, 1 M requests on a cold table
         k = 1_000_000
         for _ in range(3):
             g.set_assign(np.full(n, 0xFFFFFFFF, np.uint32))
             g.get_nodes()
-            L.rio_gp_place_pending_dev(h, k, vp(idx.data_ptr()), vp(node.data_ptr()), vp(outb.data_ptr()), vp(flg.data_ptr()))
+            L.rio_gp_place_pending_dev(h, k, vp(idx.ptr), vp(node.ptr), vp(outb.ptr), vp(flg.ptr))
 elif phase == "probes":                  # known traffic: calibration of FETCH_SIZE / WRITE_SIZE
     for mode in (4, 0, 3):
         g.stream_probe(mode, 10)

@@ -21,6 +21,7 @@ if [ -z "$QUICK" ]; then
   bash tools/prof_churn.sh ${TAG} > /dev/null 2>&1
   bash tools/kernel_roofline.sh ${TAG} > $OUT/${TAG}_kroof.log 2>&1
   timeout 600 python tools/measure_ops.py ${TAG} > $OUT/${TAG}_ops.log 2>&1
+  timeout 300 python tools/fixup_trace.py 6 > $OUT/${TAG}_fixup_trace.json 2> $OUT/${TAG}_fixup_trace.err
   for w in churn contended skew; do
     timeout 300 python tools/slowpath_workload.py $w 40 > $OUT/${TAG}_slowpath_$w.json 2> $OUT/${TAG}_slowpath_$w.err
   done
@@ -38,4 +39,5 @@ if [ -z "$QUICK" ]; then
   echo "---- ops"; tail -25 $OUT/${TAG}_ops.log
   echo "---- slow path"; for w in churn contended skew churn_fusedk; do cut -c1-260 $OUT/${TAG}_slowpath_$w.json; done
   tail -14 $OUT/${TAG}_churn_timeline.txt
+  echo "---- fix-up phase traces"; cat $OUT/${TAG}_fixup_trace.json; tail -3 $OUT/${TAG}_fixup_trace.err
 fi
