@@ -51,6 +51,18 @@ struct DevStats {
     u64 err;                                            // invalid entries seen by batch kernels
 };
 
+// Per-workgroup rows of the fix-up counters (a whole-table solve whose counters the host wants): workgroup b of the
+// streaming grid owns row b of `dev` across the kernels of one solve — k_scan zeroes it, the cut pass and every water-fill
+// round add to it with plain stores, and each round also stores the row into `host` (pinned, mapped): the host folds the
+// rows when it reads the verdict.  No contended atomics on eight global words (a 255-to-1 fan-in is ~3 us at the tail of
+// three kernels per tick) and no copy kernel for the totals.  Both nullptr: the kernels add into DevStats atomically
+// (row-sharded solve, place_pending).
+// row = { rejected rows, rejected load, spilled rows, spilled load, unplaced rows, unplaced load, rounds run (row 0), - }
+struct FxRows {
+    u64* dev = nullptr;   // [kMaxBlocks][8]
+    u64* host = nullptr;  // [kMaxBlocks][8], device address of pinned host memory
+};
+
 // Scratch of one solve over one table (real table or the virtual table of place_pending).
 struct SolveBufs {
     u64* H;          // [ceil(m/8)][G][16] per-block load histograms, node-group major: kept-by-cur x8 | claim-by-aff x8
@@ -76,6 +88,7 @@ struct SolveBufs {
     u64* rank_base;          // [1]
     const u64* pending_global;  // [1] rows still pending on ALL ranks (k_shard_import_delta), nullptr = local count
     DevStats* stats;
+    FxRows fx;
 };
 
 // Packed pending rows (k_scan<COMPACT>): wave gw copies its PENDING rows, in index order, to the front of its own

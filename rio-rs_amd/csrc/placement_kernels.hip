@@ -142,12 +142,12 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     return p;
 }
 
-size_t scan_lds_bytes(u32 m) {
-    u32 mwords = (m + 31) / 32;
-    size_t b = kSmall + ((size_t)2 * m + 2) * sizeof(u64) + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 64;
+__host__ __device__ __forceinline__ size_t scan_lds_bytes_dev(u32 m) {
+    const u32 mwords = (m + 31) / 32;
+    const size_t b = kSmall + ((size_t)2 * m + 2) * sizeof(u64) + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 64;
     return (b + 15) & ~(size_t)15;
 }
-
+size_t scan_lds_bytes(u32 m) { return scan_lds_bytes_dev(m); }
 // Row classification shared by every streaming kernel (must be identical everywhere):
 //   kept      placed on a live node            -> sticky               (service.rs:241-242)
 //   claimant  pending, affinity node is live   -> first touch          (service.rs:244-252)
@@ -180,6 +180,7 @@ __device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv) {
 //     on a live node and takes no part otherwise — neither claimant nor spill candidate.
 // ------------------------------------------------------------------------------------------------
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+constexpr u32 kStageCap = 320;  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
 
 // NT: non-temporal column streams for tables beyond the 256 MiB Infinity Cache (measured +1-2 % at 40-100 M rows and
 // -25 % at 10 M rows, where the cache serves part of every pass: launch_scan picks by table size)
@@ -202,11 +203,12 @@ __device__ __forceinline__ void st4(u32* p, const uint4 v) {
     }
 }
 
-template <bool VIRT, bool ALLALIVE, bool CHECK, bool COMPACT = false, bool NT = false>
+template <bool VIRT, bool ALLALIVE, bool CHECK, int COMPACT = 0, bool NT = false>
 __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const uint4 lv, const u64 i0, const u64 wend,
                                           const u32 m, const u32* alv, u64* hist, u32* __restrict__ next,
                                           u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt,
-                                          const PackOut* pk = nullptr, u64* pk_pos = nullptr) {
+                                          const PackOut* pk = nullptr, u64* pk_pos = nullptr, u32* stage = nullptr,
+                                          u32* st_head = nullptr, u32* st_fill = nullptr) {
     uint4 ov;
     u64 sp_local = 0;
     u32 any_sp = 0, pm = 0;
@@ -239,15 +241,49 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         const u64 b0 = __ballot(pm & 1u), b1 = __ballot(pm & 2u), b2 = __ballot(pm & 4u), b3 = __ballot(pm & 8u);
         if (b0 | b1 | b2 | b3) {
             const u64 lt = (1ull << (threadIdx.x & 63)) - 1ull;
-            u64 pos = *pk_pos + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
-#define RIOGP_PK(E, A, L, O)                                                                     \
-            if (pm & (1u << E)) { pk->idx[pos] = (u32)(i0 + E); pk->load[pos] = L; pk->aff[pos] = A; pk->next[pos] = O; ++pos; }
-            RIOGP_PK(0, av.x, lv.x, ov.x)
-            RIOGP_PK(1, av.y, lv.y, ov.y)
-            RIOGP_PK(2, av.z, lv.z, ov.z)
-            RIOGP_PK(3, av.w, lv.w, ov.w)
+            const u32 rank = (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+            const u32 cnt = (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            if (COMPACT == 2) {
+                // Staged: the records go to this wave's LDS ring (four columns of kStageCap words) first; whenever 64 are
+                // waiting they leave as four fully coalesced 256-byte stores.  The direct form below issues up to sixteen
+                // masked store instructions per tile with a handful of scattered lanes each: measured 37-40 us for the
+                // churn-tick scan against 26 us for the plain scan.
+                u32 e = *st_head + *st_fill + rank;
+#define RIOGP_PK(E, A, L, O)                                                                              \
+                if (pm & (1u << E)) {                                                                     \
+                    const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
+                    stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; stage[2 * kStageCap + x] = A;     \
+                    stage[3 * kStageCap + x] = O; ++e;                                                    \
+                }
+                RIOGP_PK(0, av.x, lv.x, ov.x)
+                RIOGP_PK(1, av.y, lv.y, ov.y)
+                RIOGP_PK(2, av.z, lv.z, ov.z)
+                RIOGP_PK(3, av.w, lv.w, ov.w)
 #undef RIOGP_PK
-            *pk_pos += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+                *st_fill += cnt;
+                __builtin_amdgcn_wave_barrier();
+                while (*st_fill >= 64u) {  // wave-uniform
+                    u32 x = *st_head + (threadIdx.x & 63);
+                    x = x >= kStageCap ? x - kStageCap : x;
+                    const u32 v0 = stage[x], v1 = stage[kStageCap + x], v2 = stage[2 * kStageCap + x], v3 = stage[3 * kStageCap + x];
+                    const u64 o = *pk_pos + (threadIdx.x & 63);
+                    pk->idx[o] = v0; pk->load[o] = v1; pk->aff[o] = v2; pk->next[o] = v3;
+                    *st_head = *st_head + 64u >= kStageCap ? *st_head + 64u - kStageCap : *st_head + 64u;
+                    *st_fill -= 64u;
+                    *pk_pos += 64u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                u64 pos = *pk_pos + rank;
+#define RIOGP_PK(E, A, L, O)                                                                     \
+                if (pm & (1u << E)) { pk->idx[pos] = (u32)(i0 + E); pk->load[pos] = L; pk->aff[pos] = A; pk->next[pos] = O; ++pos; }
+                RIOGP_PK(0, av.x, lv.x, ov.x)
+                RIOGP_PK(1, av.y, lv.y, ov.y)
+                RIOGP_PK(2, av.z, lv.z, ov.z)
+                RIOGP_PK(3, av.w, lv.w, ov.w)
+#undef RIOGP_PK
+                *pk_pos += cnt;
+            }
         }
     }
     const u64 spmask = __ballot(any_sp);
@@ -275,12 +311,13 @@ __host__ __device__ __forceinline__ size_t h_line(u32 g, u32 b, u32 G) { return 
 
 // TPI = tiles (of 256 rows) a wave processes per loop iteration; the next TPI tiles are always in
 // flight while the current ones are processed.
-template <bool VIRT, bool ALLALIVE, int TPI, bool COMPACT = false, bool NT = false>
+template <bool VIRT, bool ALLALIVE, int TPI, int COMPACT = 0, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                  const u32* __restrict__ aff, u32* __restrict__ next,
                                                  const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
                                                  u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
-                                                 u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko) {
+                                                 u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko,
+                                                 FxRows fx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u32* bst = reinterpret_cast<u32*>(smem);                 // [4] (first 128 B: small scratch, G17)
@@ -312,6 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     if (!ALLALIVE)
         for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
     if (tid < 4) bst[tid] = 0;
+    if (fx.dev && tid < 8) fx.dev[(size_t)blockIdx.x * 8 + tid] = 0;  // this workgroup's row of the fix-up counters
     if (blockIdx.x == 0 && tid == 0) {  // accumulators the fix-up kernels add into
         stats->rejected = 0; stats->load_rejected = 0;
         stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
@@ -323,6 +361,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     u64 sp_sum = 0;
     u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;  // kept/evict/claim are wave-uniform
     u64 pk_pos = wstart;  // COMPACT: this wave's packed write cursor (wave-uniform)
+    // COMPACT == 2: this wave's packing ring sits behind the histogram region (launch_scan sizes the dynamic LDS for it)
+    u32* stage = COMPACT == 2 ? reinterpret_cast<u32*>(smem + scan_lds_bytes_dev(p.m)) + (size_t)wave * 4 * kStageCap : nullptr;
+    u32 st_head = 0, st_fill = 0;
 
     while (it < wgrp) {
         const u64 nit = it + (u64)kTile * TPI;
@@ -342,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         for (int q = 0; q < TPI; ++q)
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
                                                           m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
-                                                          claim_cnt, &pko, &pk_pos);
+                                                          claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill);
         it = nit;
 #pragma unroll
         for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
@@ -354,10 +395,20 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
         if (it < wfull)
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                          evict_cnt, claim_cnt, &pko, &pk_pos);
+                                                          evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill);
         else
             scan_tile<VIRT, ALLALIVE, true, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                         evict_cnt, claim_cnt, &pko, &pk_pos);
+                                                         evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill);
+    }
+    if (COMPACT == 2 && st_fill) {  // what is left in the ring (< 64 records)
+        u32 x = st_head + (u32)lane;
+        x = x >= kStageCap ? x - kStageCap : x;
+        if ((u32)lane < st_fill) {
+            const u64 o = pk_pos + (u32)lane;
+            pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
+            pko.next[o] = stage[3 * kStageCap + x];
+        }
+        pk_pos += st_fill;
     }
 
     // per-wave spill-candidate totals (index-ordered prefix over wave ranges comes later)
@@ -584,6 +635,18 @@ __global__ __launch_bounds__(256) void k_cutblk(const u64* __restrict__ H, Plan 
     }
 }
 
+// rejected claimants of one workgroup: into its row of the fix-up counters, or atomically into DevStats
+__device__ __forceinline__ void fx_add_rejected(const FxRows& fx, DevStats* stats, u64 cnt, u64 load) {
+    if (fx.dev) {
+        u64* r = fx.dev + (size_t)blockIdx.x * 8;
+        r[0] += cnt;
+        r[1] += load;
+    } else if (cnt) {
+        atomicAdd(&stats->rejected, cnt);
+        atomicAdd(&stats->load_rejected, load);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3a k_cut_subhist — only when some node has a cut: per-(node, sub-chunk) claim load inside the
 //     node's cut block.  One more pass over the blocks that contain a cut.
@@ -729,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
                                                       const u32* __restrict__ aff, u32* __restrict__ next,
                                                       const u32* __restrict__ alive_bits, Plan p,
                                                       const u32* __restrict__ cutidx, u64* __restrict__ wsp_sum,
-                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats) {
+                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, FxRows fx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u64* red = reinterpret_cast<u64*>(smem);           // [2]
@@ -775,10 +838,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
         if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
     }
     __syncthreads();
-    if (tid == 0 && red[0]) {
-        atomicAdd(&stats->rejected, red[0]);
-        atomicAdd(&stats->load_rejected, red[1]);
-    }
+    if (tid == 0) fx_add_rejected(fx, stats, red[0], red[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1174,7 +1234,8 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
                                                       const u64* __restrict__ used_kept,
                                                       const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
                                                       u64* __restrict__ used_cur, u64* __restrict__ wsp_sum,
-                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 tcap) {
+                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 tcap,
+                                                      FxRows fx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m, mr = (m + 7) & ~7u;
     u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
@@ -1229,10 +1290,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
         if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
     }
     __syncthreads();
-    if (tid == 0 && red[0]) {
-        atomicAdd(&stats->rejected, red[0]);
-        atomicAdd(&stats->load_rejected, red[1]);
-    }
+    if (tid == 0) fx_add_rejected(fx, stats, red[0], red[1]);
     if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64() - g_cut_trace[(size_t)blockIdx.x * 8 + 4];
 }
 
@@ -1422,7 +1480,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
                                                            u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats,
                                                            const u64* __restrict__ cap, const u64* __restrict__ used_cur,
                                                            u64* __restrict__ wfFree, u32* __restrict__ wfOrder,
-                                                           u32* __restrict__ wfCnt) {
+                                                           u32* __restrict__ wfCnt, FxRows fx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x >= p.G) {
         spill_rank_body(smem, blockIdx.x - p.G, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
@@ -1481,10 +1539,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
         if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
     }
     __syncthreads();
-    if (tid == 0 && red[0]) {
-        atomicAdd(&stats->rejected, red[0]);
-        atomicAdd(&stats->load_rejected, red[1]);
-    }
+    if (tid == 0) fx_add_rejected(fx, stats, red[0], red[1]);
     RIOGP_KT(2, 3);
 }
 
@@ -1501,13 +1556,15 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                                                         int last, DevStats* __restrict__ stats,
                                                         const u32* __restrict__ pk_idx, u32* __restrict__ real_next,
                                                         const u64* __restrict__ rank_base,
-                                                        const u64* __restrict__ pending_global) {
+                                                        const u64* __restrict__ pending_global, FxRows fx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u64* red = reinterpret_cast<u64*>(smem);               // [4]
     u64* part = reinterpret_cast<u64*>(smem + kSmall);     // [16] block-scan partials
     u64* C = reinterpret_cast<u64*>(smem + 2 * kSmall);    // [m+1]
     u64* adm = C + (m + 1);                                // [m] admitted load by node (this block)
+    unsigned short* ord = reinterpret_cast<unsigned short*>(adm + m);  // [m] node of rank k (a global read per placed row otherwise:
+                                                           //     four dependent ~1 us round trips per lane and tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ktab = last ? 1 : 0;
     RIOGP_KT(ktab, 0);
@@ -1545,7 +1602,10 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
             }
             return;
         }
-        if (blockIdx.x == 0 && tid == 0) stats->rounds_run += 1;
+        if (blockIdx.x == 0 && tid == 0) {
+            if (fx.dev) fx.dev[6] += 1;
+            else stats->rounds_run += 1;
+        }
         my_base = red[0] + (rank_base ? *rank_base : 0ull);  // row-sharded solve: the spill load of every lower rank comes first
         for (int w = 0; w < wave; ++w) my_base += part[w];
         __syncthreads();  // red / part are reused below
@@ -1567,7 +1627,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
             if (k < m) C[k + 1] = k < cnt ? excl : ~0ull;
         }
     }
-    for (u32 k = tid; k < m; k += kBlock) adm[k] = 0;
+    for (u32 k = tid; k < m; k += kBlock) { adm[k] = 0; ord[k] = (unsigned short)(k < cnt ? wfOrder[k] : 0u); }
     if (tid < 4) red[tid] = 0;
     __syncthreads();
     RIOGP_KT(ktab, 2);
@@ -1639,7 +1699,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                     const u32 mid = lo + ((hi - lo) >> 1);                        \
                     if (C[mid] <= Q) lo = mid; else hi = mid;                     \
                 }                                                                 \
-                if (Q + L <= C[lo + 1]) nd = wfOrder[lo];                         \
+                if (Q + L <= C[lo + 1]) nd = (u32)ord[lo];                        \
             }                                                                     \
             if (nd != kNone) {                                                    \
                 next[i0 + E] = nd;                                                \
@@ -1678,7 +1738,12 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     RIOGP_KT(ktab, 4);
     for (u32 k = tid; k < m; k += kBlock)
         if (adm[k]) atomicAdd(&used_cur[k], adm[k]);  // integer sums: order-independent
-    if (tid == 0) {
+    if (fx.dev) {  // this workgroup's row of the fix-up counters, and its copy in the host's pinned slot
+        u64* r = fx.dev + (size_t)blockIdx.x * 8;
+        if (tid == 0) { r[2] += red[0]; r[3] += red[1]; r[4] += red[2]; r[5] += red[3]; }
+        __syncthreads();
+        if (tid < 8) fx.host[(size_t)blockIdx.x * 8 + tid] = r[tid];
+    } else if (tid == 0) {
         if (red[0]) { atomicAdd(&stats->spilled, red[0]); atomicAdd(&stats->load_spilled, red[1]); }
         if (red[2]) { atomicAdd(&stats->unplaced, red[2]); atomicAdd(&stats->load_unplaced, red[3]); }
     }
@@ -2451,18 +2516,18 @@ int ktrace_read(int table, u64* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kt), sizeof(u64) * kMaxBlocks * 8, sizeof(u64) * kMaxBlocks * 8 * (size_t)table);
 }
 
-template <bool VIRT, bool AA, int TPI, bool COMPACT = false, bool NT = false>
+template <bool VIRT, bool AA, int TPI, int COMPACT = 0, bool NT = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
                           hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr) {
-    const size_t lds = scan_lds_bytes(p.m);
+    const size_t lds = scan_lds_bytes(p.m) + (COMPACT == 2 ? (size_t)kWaves * 4 * kStageCap * sizeof(u32) : 0);
     const PackOut pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
         hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
                               t.cur, t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
-                              b.stats, pko);
+                              b.stats, pko, b.fx);
     else
         hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
-                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko);
+                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx);
 }
 
 void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t s) {
@@ -2474,13 +2539,21 @@ void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t 
 // Non-temporal streams once the four columns no longer fit the 256 MiB Infinity Cache.
 constexpr u64 kScanNtRows = (u64)20 << 20;  // 16 B/row * 20 Mi rows = 320 MiB of columns
 int g_scan_nt_mode = 0;  // 0 by size | 1 always | 2 never (rio_gp_debug_set_scan_nt, A/B runs)
-void set_scan_nt(int mode) { g_scan_nt_mode = mode; }
+int g_scan_stage = 1;    // packing through LDS rings (0: straight from registers; rio_gp_debug_set_scan_nt bit 4, A/B runs)
+void set_scan_nt(int mode) { g_scan_nt_mode = mode & 3; g_scan_stage = (mode & 16) ? 0 : 1; }
 
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
                  hipStream_t s, hipEvent_t e0, hipEvent_t e1, const PackOut* pack) {
     if (pack && !virt) {  // k_scan that also packs the pending rows of every wave (adaptive fix-up, rio_gp_capi.hip)
-        if (all_alive) launch_scan_t<false, true, 1, true>(p, t, nt, b, s, e0, e1, pack);
-        else launch_scan_t<false, false, 1, true>(p, t, nt, b, s, e0, e1, pack);
+        // through per-wave LDS rings when they fit next to the histograms (m up to ~4 800), straight from registers else
+        const bool staged = g_scan_stage && scan_lds_bytes(p.m) + (size_t)kWaves * 4 * kStageCap * sizeof(u32) <= (size_t)160 * 1024;
+        if (staged) {
+            if (all_alive) launch_scan_t<false, true, 1, 2>(p, t, nt, b, s, e0, e1, pack);
+            else launch_scan_t<false, false, 1, 2>(p, t, nt, b, s, e0, e1, pack);
+        } else {
+            if (all_alive) launch_scan_t<false, true, 1, 1>(p, t, nt, b, s, e0, e1, pack);
+            else launch_scan_t<false, false, 1, 1>(p, t, nt, b, s, e0, e1, pack);
+        }
         return;
     }
     if (virt) {
@@ -2552,24 +2625,24 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
                 hipLaunchKernelGGL(k_cut_apply_rank<true>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt);
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx);
             } else {
                 hipLaunchKernelGGL(k_cut_find<false>, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
                 hipLaunchKernelGGL(k_cut_apply_rank<false>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt);
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx);
             }
             return with_rank;
         }
         if (virt)
             hipLaunchKernelGGL(k_cut_fused<true>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap);
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx);
         else
             hipLaunchKernelGGL(k_cut_fused<false>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap);
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx);
         return false;
     }
     (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
@@ -2584,7 +2657,7 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                            b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
         if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
         hipLaunchKernelGGL(k_apply_cut<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx);
     } else {
         hipLaunchKernelGGL(k_cut_subhist<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, nt.alive_bits,
                            p, b.cutblk, b.T);
@@ -2592,7 +2665,7 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                            b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
         if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
         hipLaunchKernelGGL(k_apply_cut<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats);
+                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx);
     }
     return false;
 }
@@ -2607,10 +2680,10 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
     if (!rank_done)
         hipLaunchKernelGGL(k_spill_rank, dim3(grank ? grank : 1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
                            b.wfC, b.wfOrder, b.wfCnt);
-    const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + 16;
+    const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + (size_t)p.m * sizeof(unsigned short) + 16;
     hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_sum[in], b.wfC,
                        b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats,
-                       t.pk_idx, t.real_next, b.rank_base, b.pending_global);
+                       t.pk_idx, t.real_next, b.rank_base, b.pending_global, b.fx);
 }
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {

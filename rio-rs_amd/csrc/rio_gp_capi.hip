@@ -123,8 +123,13 @@ struct rio_gp {
     // asynchronous committed ticks (rio_gp_tick_async): verdict slots [kRing, 2 kRing) and their own ring of device-stats
     // copies, so that synchronous calls made while ticks are in flight do not touch what has not been harvested yet
     u32 tick_n = 0;
-    DevStats* h_tick_stats = nullptr;
+    u32 tick_G[kRing] = {};  // workgroups of the streaming grid of asynchronous tick k (how many counter rows to fold)
     std::vector<rio_gp_stats> tick_done;
+    // fix-up counters as per-workgroup rows (FxRows, placement_kernels.h): device rows + pinned slots [1 + kRing][kMaxBlocks][8]
+    // (slot 0: synchronous solves, slots 1..kRing: asynchronous ticks)
+    u64* fx_dev = nullptr;
+    u64* h_fx = nullptr;
+    u64* d_fx = nullptr;
     // row-sharded solve (rio_gp_shard_*): global `used` snapshots, forced-node bitmap, spill base, verdict words
     u64 *sh_gprev = nullptr, *sh_gfinal = nullptr, *sh_rank_base = nullptr, *sh_verdict = nullptr;
     u32* sh_forced = nullptr;
@@ -286,15 +291,26 @@ DevStats reduce_rows(rio_gp* h, size_t slot, u32 m) {
     return d;
 }
 
-// fold the fix-up kernels' device accumulators into a fast-path verdict
+// the fix-up kernels of the next solve write their per-workgroup counter rows into pinned slot `slot` (0: synchronous
+// solves, 1 + k: asynchronous tick k)
+void use_fx_slot(rio_gp* h, u32 slot) {
+    h->sb.fx.dev = h->fx_dev;
+    h->sb.fx.host = h->d_fx + (size_t)slot * kMaxBlocks * 8;
+}
+// fold those rows into a fast-path verdict (after the stream has been waited for)
+void fold_fx(rio_gp* h, u32 slot, u32 G, DevStats* v) {
+    const u64* rows = h->h_fx + (size_t)slot * kMaxBlocks * 8;
+    u64 x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (u32 b = 0; b < G; ++b)
+        for (int c = 0; c < 8; ++c) x[c] += rows[(size_t)b * 8 + c];
+    v->rejected = x[0]; v->load_rejected = x[1];
+    v->spilled = x[2]; v->load_spilled = x[3];
+    v->unplaced = x[4]; v->load_unplaced = x[5];
+    v->rounds_run = x[6];
+}
 int merge_slow(rio_gp* h, DevStats* v) {
-    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const DevStats& d = h->h_stats[0];
-    v->rejected = d.rejected; v->load_rejected = d.load_rejected;
-    v->spilled = d.spilled; v->load_spilled = d.load_spilled;
-    v->unplaced = d.unplaced; v->load_unplaced = d.load_unplaced;
-    v->rounds_run = d.rounds_run;
+    fold_fx(h, 0, h->plan.G, v);
     return RIO_GP_OK;
 }
 
@@ -313,6 +329,7 @@ int commit_enqueue(rio_gp* h) {
 int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     h->plan = make_plan(h->n, h->m, 0);
     h->ring_n = 0;
+    use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     // Adaptive packed fix-up: when the previous solve left few rows pending (a churn stream: most rows are kept),
@@ -358,17 +375,10 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
         if (rc) return rc;
     }
     if (spec) {
-        HIPCHK(h, hipMemcpyAsync(h->h_stats, h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         v = reduce_slot(h, 0, h->m);
         slow = v.n_cut > 0 || v.spillcand > 0;
-        if (slow) {
-            const DevStats& d = h->h_stats[0];
-            v.rejected = d.rejected; v.load_rejected = d.load_rejected;
-            v.spilled = d.spilled; v.load_spilled = d.load_spilled;
-            v.unplaced = d.unplaced; v.load_unplaced = d.load_unplaced;
-            v.rounds_run = d.rounds_run;
-        }
+        if (slow) fold_fx(h, 0, h->plan.G, &v);  // the water-fill rounds stored every workgroup's row into the pinned slot
     } else if (slow) {
         int rc = merge_slow(h, &v);  // waits for the stream
         if (rc) return rc;
@@ -393,13 +403,7 @@ int harvest_ticks(rio_gp* h) {
     for (u32 k = 0; k < h->tick_n; ++k) {
         DevStats v = reduce_tick_slot(h, k, h->m);
         const bool slow = v.n_cut > 0 || v.spillcand > 0;
-        if (slow) {
-            const DevStats& d = h->h_tick_stats[k];
-            v.rejected = d.rejected; v.load_rejected = d.load_rejected;
-            v.spilled = d.spilled; v.load_spilled = d.load_spilled;
-            v.unplaced = d.unplaced; v.load_unplaced = d.load_unplaced;
-            v.rounds_run = d.rounds_run;
-        }
+        if (slow) fold_fx(h, 1 + k, h->tick_G[k], &v);
         rio_gp_stats st;
         fill_stats(v, h->n, &st);
         h->tick_done.push_back(st);
@@ -424,6 +428,8 @@ int tick_async_locked(rio_gp* h) {
     const bool compact = h->compact_mode == 1 ||
                          (h->compact_mode == 0 && h->last_pending_valid && h->last_pending * 4 <= h->n && h->n >= 65536);
     const u32 k = h->tick_n;
+    use_fx_slot(h, 1 + k);
+    h->tick_G[k] = h->plan.G;
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
     launch_resolve(h->plan, nt, h->sb, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, h->stream);
     DevStats all;
@@ -447,7 +453,6 @@ int tick_async_locked(rio_gp* h) {
     h->have_solved = true;
     int rc = commit_enqueue(h);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(&h->h_tick_stats[k], h->dstats, sizeof(DevStats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipGetLastError());
     h->tick_n = k + 1;
     return RIO_GP_OK;
@@ -534,7 +539,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
     A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
-    A(h->sb.wfCnt, 4); A(h->dstats, 1);
+    A(h->sb.wfCnt, 4); A(h->dstats, 1); A(h->fx_dev, (size_t)kMaxBlocks * 8);
     A(h->pk.idx, R); A(h->pk.load, R); A(h->pk.aff, R); A(h->pk.next, R); A(h->pk.wcnt, W);
     A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
@@ -548,12 +553,14 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     h->slot_rows = resolve_blocks(h->cap_nodes);
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_slots), (size_t)2 * kRing * h->slot_rows * 8 * sizeof(u64),
                       hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&h->h_tick_stats), sizeof(DevStats) * kRing, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->h_fx), (size_t)(1 + kRing) * kMaxBlocks * 8 * sizeof(u64), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_fx), h->h_fx, 0) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_slots), h->h_slots, 0) != hipSuccess) {
         h->err = "hipHostMalloc(mapped verdict slots) failed";
         return bail(RIO_GP_ENOMEM);
     }
     memset(h->h_slots, 0, (size_t)2 * kRing * h->slot_rows * 8 * sizeof(u64));
+    memset(h->h_fx, 0, (size_t)(1 + kRing) * kMaxBlocks * 8 * sizeof(u64));
     h->cs_words = (((size_t)h->cap_nodes + 31) / 32 + 8 + 1) & ~(size_t)1;  // bitmap words, then the u64 count (8 B aligned)
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cs), (h->cs_words + 2) * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_cs), h->h_cs, 0) != hipSuccess ||
@@ -599,7 +606,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_slots) (void)hipHostFree(h->h_slots);
-    if (h->h_tick_stats) (void)hipHostFree(h->h_tick_stats);
+    if (h->h_fx) (void)hipHostFree(h->h_fx);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_cs) (void)hipHostFree(h->h_cs);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -991,6 +998,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         if ((rc = ensure(h, h->vt[q], bytes))) return rc;
     u32 *vcur = (u32*)h->vt[0].p, *vload = (u32*)h->vt[1].p, *vaff = (u32*)h->vt[2].p, *vnext = (u32*)h->vt[3].p;
     u32* assign = h->assign[h->cur];
+    h->sb.fx = FxRows{};  // nobody reads the fix-up counters of the virtual-table solve: plain DevStats atomics, no pinned slot touched
     if ((rc = ensure_used(h))) return rc;
     if ((rc = zero_stats(h))) return rc;
     // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
@@ -1134,6 +1142,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     h->plan = make_plan(h->n, h->m, 0);
+    use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
@@ -1177,6 +1186,7 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->ev2) { HIPCHK(h, hipEventCreate(&h->ev2)); HIPCHK(h, hipEventCreate(&h->ev3)); }
     h->plan = make_plan(h->n, h->m, 0);
+    use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     // hipExtLaunchKernelGGL start/stop events = the dispatch's own begin/end timestamps
@@ -1232,6 +1242,7 @@ int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
     if (!h || !d_x) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     h->plan = make_plan(h->n, h->m, 0);
+    h->sb.fx = FxRows{};  // row-sharded solve: the fix-up counters are summed in DevStats (rio_gp_shard_finish reads them)
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
@@ -1542,6 +1553,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         const u64 seq = ++q->seq;
         const u32 slot = (u32)(seq % kP2PSlots);
         h->plan = make_plan(h->n, h->m, 0);
+        h->sb.fx = FxRows{};
         const Table t = real_table(h);
         const NodeTab nt = real_nodes(h);
         launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
@@ -1568,6 +1580,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     const int q = (int)(sc->k++ % kShardRing);
     if (sc->done_valid[q]) HIPCHK(h, hipStreamWaitEvent(h->stream, sc->done[q], 0));
     h->plan = make_plan(h->n, h->m, 0);
+    h->sb.fx = FxRows{};
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
