@@ -71,6 +71,8 @@ struct SolveBufs {
     u64* blkstat;    // [G][4]   kept, evicted, claimants rows per block
     u64* wsp_sum[2]; // [G*kWaves] spill-candidate load per wave range (ping-pong over rounds)
     u32* wsp_cnt[2]; // [G*kWaves]
+    u64* bsp_sum[2]; // [G] the same per workgroup (what k_spill_apply's prologue folds: G words instead of G*kWaves)
+    u32* bsp_cnt[2]; // [G]
     u64* used_kept;  // [m] load of kept rows (+ used_base for the virtual table)
     u64* used_cur;   // [m] used_kept + admitted claims + admitted spills
     u64* claim_tot;  // [m]

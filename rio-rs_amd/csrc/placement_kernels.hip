@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
                                                  const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
                                                  u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
                                                  u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko,
-                                                 FxRows fx) {
+                                                 FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u32* bst = reinterpret_cast<u32*>(smem);                 // [4] (first 128 B: small scratch, G17)
@@ -349,6 +349,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     if (!ALLALIVE)
         for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
     if (tid < 4) bst[tid] = 0;
+    u64& bsum = *reinterpret_cast<u64*>(smem + 32);          // spill-candidate load of the whole block
+    if (tid == 0) bsum = 0;
     if (fx.dev && tid < 8) fx.dev[(size_t)blockIdx.x * 8 + tid] = 0;  // this workgroup's row of the fix-up counters
     if (blockIdx.x == 0 && tid == 0) {  // accumulators the fix-up kernels add into
         stats->rejected = 0; stats->load_rejected = 0;
@@ -422,8 +424,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         atomicAdd(&bst[1], evict_cnt);
         atomicAdd(&bst[2], claim_cnt);
         atomicAdd(&bst[3], sp_cnt);
+        if (sp_sum) atomicAdd(&bsum, sp_sum);
     }
     __syncthreads();
+    if (tid == 0) { bsp_sum[blockIdx.x] = bsum; bsp_cnt[blockIdx.x] = bst[3]; }
     // this block's sums, node-group major: line (g, b) = {kept of nodes 8g..8g+7 | their claim loads} — 16 consecutive
     // threads store one 128-byte line, so k_resolve's workgroup g reads G contiguous lines and nothing else
     const u32 ng = (m + 7) >> 3;
@@ -792,16 +796,17 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
                                                       const u32* __restrict__ aff, u32* __restrict__ next,
                                                       const u32* __restrict__ alive_bits, Plan p,
                                                       const u32* __restrict__ cutidx, u64* __restrict__ wsp_sum,
-                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, FxRows fx) {
+                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, FxRows fx,
+                                                      u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
-    u64* red = reinterpret_cast<u64*>(smem);           // [2]
+    u64* red = reinterpret_cast<u64*>(smem);           // [4]
     u32* ci = reinterpret_cast<u32*>(smem + kSmall);   // [m]
     u32* alv = ci + m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (u32 k = tid; k < m; k += kBlock) ci[k] = cutidx[k];
     for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
-    if (tid < 2) red[tid] = 0;
+    if (tid < 4) red[tid] = 0;
     __syncthreads();
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
@@ -836,9 +841,14 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
         if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
+        if (sp_cnt) { atomicAdd(&red[2], sp_sum); atomicAdd(&red[3], (u64)sp_cnt); }
     }
     __syncthreads();
-    if (tid == 0) fx_add_rejected(fx, stats, red[0], red[1]);
+    if (tid == 0) {
+        fx_add_rejected(fx, stats, red[0], red[1]);
+        bsp_sum[blockIdx.x] = red[2];
+        bsp_cnt[blockIdx.x] = (u32)red[3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -905,7 +915,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                                                                              //         budget of slot s at T[tcap-1-s]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     RIOGP_TRACE(0, wall_clock64());
-    if (tid == 0) { nlocal = 0; red[0] = 0; red[1] = 0; }
+    if (tid == 0) { nlocal = 0; red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0; }
     for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
     const u64 gw = (u64)b * kWaves + wave;
     const u64 bstart = block_row_lo(p, b);
@@ -1235,7 +1245,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
                                                       const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
                                                       u64* __restrict__ used_cur, u64* __restrict__ wsp_sum,
                                                       u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 tcap,
-                                                      FxRows fx) {
+                                                      FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m, mr = (m + 7) & ~7u;
     u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
@@ -1288,9 +1298,14 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
         if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
+        if (sp_cnt) { atomicAdd(&red[2], sp_sum); atomicAdd(&red[3], (u64)sp_cnt); }
     }
     __syncthreads();
-    if (tid == 0) fx_add_rejected(fx, stats, red[0], red[1]);
+    if (tid == 0) {
+        fx_add_rejected(fx, stats, red[0], red[1]);
+        bsp_sum[blockIdx.x] = red[2];
+        bsp_cnt[blockIdx.x] = (u32)red[3];
+    }
     if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64() - g_cut_trace[(size_t)blockIdx.x * 8 + 4];
 }
 
@@ -1480,7 +1495,8 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
                                                            u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats,
                                                            const u64* __restrict__ cap, const u64* __restrict__ used_cur,
                                                            u64* __restrict__ wfFree, u32* __restrict__ wfOrder,
-                                                           u32* __restrict__ wfCnt, FxRows fx) {
+                                                           u32* __restrict__ wfCnt, FxRows fx, u64* __restrict__ bsp_sum,
+                                                           u32* __restrict__ bsp_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x >= p.G) {
         spill_rank_body(smem, blockIdx.x - p.G, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
@@ -1495,7 +1511,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
     RIOGP_KT(2, 0);
     for (u32 j = tid; j < m; j += kBlock) thr[j] = (forced_bits && bit_of(forced_bits, j)) ? 0u : cutidx[j];
     for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
-    if (tid < 2) red[tid] = 0;
+    if (tid < 4) red[tid] = 0;
     __syncthreads();
     RIOGP_KT(2, 1);
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
@@ -1537,9 +1553,14 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
         if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
+        if (sp_cnt) { atomicAdd(&red[2], sp_sum); atomicAdd(&red[3], (u64)sp_cnt); }
     }
     __syncthreads();
-    if (tid == 0) fx_add_rejected(fx, stats, red[0], red[1]);
+    if (tid == 0) {
+        fx_add_rejected(fx, stats, red[0], red[1]);
+        bsp_sum[blockIdx.x] = red[2];
+        bsp_cnt[blockIdx.x] = (u32)red[3];
+    }
     RIOGP_KT(2, 3);
 }
 
@@ -1556,7 +1577,9 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                                                         int last, DevStats* __restrict__ stats,
                                                         const u32* __restrict__ pk_idx, u32* __restrict__ real_next,
                                                         const u64* __restrict__ rank_base,
-                                                        const u64* __restrict__ pending_global, FxRows fx) {
+                                                        const u64* __restrict__ pending_global, FxRows fx,
+                                                        const u64* __restrict__ bsp_sum_in, const u32* __restrict__ bsp_cnt_in,
+                                                        u64* __restrict__ bsp_sum_out, u32* __restrict__ bsp_cnt_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u64* red = reinterpret_cast<u64*>(smem);               // [4]
@@ -1569,29 +1592,36 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     const int ktab = last ? 1 : 0;
     RIOGP_KT(ktab, 0);
     // Prologue: what is pending, and where does this workgroup's first wave start in the index-ordered spill prefix?
-    // Every workgroup folds the per-wave totals of the previous step itself (nw <= 4 096 words of each: L2 reads).
+    // Every global operand of the prologue is requested before the first one is used (one round trip, not three): the
+    // per-workgroup spill totals of the previous step (G words: k_scan / the cut pass / the previous round wrote them next
+    // to the per-wave ones), this workgroup's own 16 per-wave totals, the ranked free capacities and the rank order.
+    const u32 mpad = (m + kBlock - 1) / kBlock * kBlock, per = mpad / kBlock;  // per <= 8 (m <= 8 192)
+    const u32 cnt = *wfCnt;
+    u64 fr[8];
+    u32 od[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+        const u32 k = tid * per + q;
+        const bool in = q < per && k < cnt;
+        fr[q] = in ? wfC[k] : 0ull;
+        od[q] = in ? wfOrder[k] : 0u;
+    }
     u64 my_base;
     {
-        const u32 nw = p.G * kWaves, w0 = blockIdx.x * kWaves;
+        const u32 G = p.G, w0 = blockIdx.x * kWaves;
         u64 sb = 0;
         u32 c = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32 w = tid * 4 + q;
-            if (w < nw) {
-                c += wsp_cnt_in[w];
-                if (w < w0 + (u32)kWaves) {  // the waves before this workgroup, and its own for the in-block prefix
-                    const u64 v = wsp_sum_in[w];
-                    if (w < w0) sb += v;
-                    else part[w - w0] = v;   // staged for the in-block prefix below (16 words)
-                }
-            }
+        if ((u32)tid < G) {
+            const u64 v = bsp_sum_in[tid];
+            c = bsp_cnt_in[tid];
+            if ((u32)tid < blockIdx.x) sb = v;
         }
+        if (tid < kWaves) part[tid] = wsp_sum_in[w0 + tid];  // staged for the in-block prefix below
         sb = wave_sum(sb);
         c = wave_sum32(c);
-        if (tid < 4) red[tid] = 0;
+        if (tid < 6) red[tid] = 0;
         __syncthreads();
-        if (lane == 0) { atomicAdd(&red[0], sb); atomicAdd(&red[1], (u64)c); }
+        if (lane == 0 && (sb | c)) { atomicAdd(&red[0], sb); atomicAdd(&red[1], (u64)c); }
         __syncthreads();
         const bool pending = pending_global ? (*pending_global != 0) : (red[1] != 0);
         if (!pending) {  // nothing pending anywhere: the round is a no-op
@@ -1600,6 +1630,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                 wsp_sum_out[gw0] = 0;
                 wsp_cnt_out[gw0] = 0;
             }
+            if (tid == 0) { bsp_sum_out[blockIdx.x] = 0; bsp_cnt_out[blockIdx.x] = 0; }
             return;
         }
         if (blockIdx.x == 0 && tid == 0) {
@@ -1611,24 +1642,21 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         __syncthreads();  // red / part are reused below
     }
     RIOGP_KT(ktab, 1);
-    const u32 cnt = *wfCnt;
     {   // C[0] = 0, C[k+1] = sat(C[k] + free of rank k): saturating block scan of the ranked free values
-        const u32 mp = (m + kBlock - 1) / kBlock * kBlock, per = mp / kBlock;
         u64 loc = 0;
-        for (u32 q = 0; q < per; ++q) {
-            const u32 k = tid * per + q;
-            loc = sat_add(loc, k < cnt ? wfC[k] : 0);
-        }
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) loc = sat_add(loc, fr[q]);
         u64 excl = block_excl_scan_1024(loc, true, part, nullptr);
         if (tid == 0) C[0] = 0;
-        for (u32 q = 0; q < per; ++q) {
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
             const u32 k = tid * per + q;
-            excl = sat_add(excl, k < cnt ? wfC[k] : 0);
-            if (k < m) C[k + 1] = k < cnt ? excl : ~0ull;
+            excl = sat_add(excl, fr[q]);
+            if (q < per && k < m) { C[k + 1] = k < cnt ? excl : ~0ull; ord[k] = (unsigned short)od[q]; }
         }
     }
-    for (u32 k = tid; k < m; k += kBlock) { adm[k] = 0; ord[k] = (unsigned short)(k < cnt ? wfOrder[k] : 0u); }
-    if (tid < 4) red[tid] = 0;
+    for (u32 k = tid; k < m; k += kBlock) adm[k] = 0;
+    if (tid < 6) red[tid] = 0;
     __syncthreads();
     RIOGP_KT(ktab, 2);
     const u64 F = C[cnt];
@@ -1733,9 +1761,11 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         wsp_cnt_out[gw] = rem_cnt;
         if (pl_cnt) { atomicAdd(&red[0], (u64)pl_cnt); atomicAdd(&red[1], pl_sum); }
         if (last && rem_cnt) { atomicAdd(&red[2], (u64)rem_cnt); atomicAdd(&red[3], rem_sum); }
+        if (rem_cnt) { atomicAdd(&red[4], rem_sum); atomicAdd(&red[5], (u64)rem_cnt); }
     }
     __syncthreads();
     RIOGP_KT(ktab, 4);
+    if (tid == 0) { bsp_sum_out[blockIdx.x] = red[4]; bsp_cnt_out[blockIdx.x] = (u32)red[5]; }
     for (u32 k = tid; k < m; k += kBlock)
         if (adm[k]) atomicAdd(&used_cur[k], adm[k]);  // integer sums: order-independent
     if (fx.dev) {  // this workgroup's row of the fix-up counters, and its copy in the host's pinned slot
@@ -2524,10 +2554,10 @@ static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, cons
     if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
         hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
                               t.cur, t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
-                              b.stats, pko, b.fx);
+                              b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
     else
         hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
-                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx);
+                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
 }
 
 void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t s) {
@@ -2625,24 +2655,24 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
                 hipLaunchKernelGGL(k_cut_apply_rank<true>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx);
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
             } else {
                 hipLaunchKernelGGL(k_cut_find<false>, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
                 hipLaunchKernelGGL(k_cut_apply_rank<false>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx);
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
             }
             return with_rank;
         }
         if (virt)
             hipLaunchKernelGGL(k_cut_fused<true>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx);
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
         else
             hipLaunchKernelGGL(k_cut_fused<false>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
                                nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx);
+                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
         return false;
     }
     (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
@@ -2657,7 +2687,7 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                            b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
         if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
         hipLaunchKernelGGL(k_apply_cut<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx);
+                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
     } else {
         hipLaunchKernelGGL(k_cut_subhist<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, nt.alive_bits,
                            p, b.cutblk, b.T);
@@ -2665,7 +2695,7 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
                            b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
         if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
         hipLaunchKernelGGL(k_apply_cut<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx);
+                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
     }
     return false;
 }
@@ -2683,7 +2713,7 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
     const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + (size_t)p.m * sizeof(unsigned short) + 16;
     hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_sum[in], b.wfC,
                        b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats,
-                       t.pk_idx, t.real_next, b.rank_base, b.pending_global, b.fx);
+                       t.pk_idx, t.real_next, b.rank_base, b.pending_global, b.fx, b.bsp_sum[in], b.bsp_cnt[in], b.bsp_sum[out], b.bsp_cnt[out]);
 }
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {

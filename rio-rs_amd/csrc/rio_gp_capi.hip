@@ -537,6 +537,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.H, (size_t)((M + 7) / 8) * kMaxBlocks * 16); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
     A(h->sb.partial, (size_t)resolve_blocks((u32)M) * 8 + 8);
     A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
+    A(h->sb.bsp_sum[0], (size_t)kMaxBlocks); A(h->sb.bsp_sum[1], (size_t)kMaxBlocks); A(h->sb.bsp_cnt[0], (size_t)kMaxBlocks); A(h->sb.bsp_cnt[1], (size_t)kMaxBlocks);
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
     A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
     A(h->sb.wfCnt, 4); A(h->dstats, 1); A(h->fx_dev, (size_t)kMaxBlocks * 8);
