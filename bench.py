@@ -625,7 +625,7 @@ def main():
     scan_avg = float(np.mean(scan_ms)) if scan_ms else None
     achieved = (ALGO_BYTES_PER_DECISION * n / (scan_avg * 1e-3) / 1e9) if scan_avg else None
     traffic, traffic_source, traffic_detail = None, "not measured", None
-    if not a.no_pmc and n_slow == 0:
+    if not a.no_pmc and n_slow == 0 and workload == "c3":
         doc, src = pmc_traffic_in_run(n)
         if doc is not None:
             traffic, traffic_source = doc["hbm_bytes_per_launch"], src

@@ -158,6 +158,14 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
 void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
                    DevStats* st, hipStream_t s, u32* aff_life = nullptr);
+// big random batches, partitioned by row window first (k_part_bin ...): part_applicable says whether a batch qualifies,
+// scratch = part_scratch_words(n_obj, n) u32 words of device memory
+bool part_applicable(u64 n_obj, u64 n);
+size_t part_scratch_words(u64 n_obj, u64 n);
+void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
+                        hipStream_t s, u32* aff_life = nullptr);
+void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u32* scratch,
+                        u64* used_or_null, DevStats* st, hipStream_t s, u32* aff_life = nullptr);
 // counter == nullptr: accumulate into st->evicted_clean.  ticket/host_out: self-resetting counter + total written to
 // mapped host memory by the last workgroup (dead_bits may itself be mapped host memory).
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s,

@@ -1936,6 +1936,174 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Big random CRUD batches, partitioned by row window (update_batch / remove_batch of >= 2^18 entries).
+//   A random entry of the plain kernels above touches three or four 128-byte lines of row-sized arrays (election word,
+//   re-read, assignment, scratch reset) for 8 useful bytes: counters show 5x (elect) and 21x (apply) the algorithmic
+//   bytes, 1.4 % of the HBM roofline on 10 M entries.  Here the batch is first BINNED by row window, one pass:
+//     k_part_bin    256 workgroups, each over one contiguous slice of the batch: LDS histogram of its entries over the
+//                   windows (W = 16 384 rows), exclusive scan, then the entries are written back reordered by window
+//                   INSIDE the slice's own region of a scratch array (no global allocation, no global atomics), as
+//                   4-byte records {row in window | node code} (+ the batch position for updates), together with the
+//                   (window, slice) fragment table;
+//     k_part_update one workgroup per window: every fragment of the window streams through an LDS table of W u64 words —
+//                   last-writer-wins is an ds_max_u64 on {position + 1 | node code} — and the window's rows are then
+//                   written DENSELY, coalesced, once;
+//     k_part_remove the same with a flag per row; the released load goes through an LDS histogram per node.
+//   Traffic: the batch twice (the second read comes from L2 / Infinity Cache), the records twice, the window once.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kPartGrid = 256;        // slices of the batch = workgroups of k_part_bin
+constexpr u32 kPartShift = 14;        // rows per window = 16 384: W u64 election words = 128 KiB of LDS
+constexpr u32 kPartWin = 1u << kPartShift;
+constexpr u32 kPartMaxBins = 8192;    // 134 M rows
+constexpr u32 kNodeNoneCode = 0x3FFFu;  // 14-bit code of RIO_GP_NONE (node ids are < 8 192)
+
+template <bool UPDATE>
+__global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32* __restrict__ idx,
+                                                     const u32* __restrict__ node, u64 n, u32 nbins,
+                                                     u32* __restrict__ rec, u32* __restrict__ kk,
+                                                     u32* __restrict__ frag_off, u32* __restrict__ frag_cnt,
+                                                     DevStats* st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* part = reinterpret_cast<u64*>(smem);                 // [16] block-scan partials
+    u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins]
+    u32* cur = hist + nbins;                                  // [nbins] write cursor of a window inside this slice
+    const int tid = threadIdx.x;
+    const u64 per = (n + kPartGrid - 1) / kPartGrid;
+    const u64 lo = (u64)blockIdx.x * per;
+    u64 hi = lo + per;
+    if (hi > n) hi = n;
+    for (u32 b = tid; b < nbins; b += kBlock) hist[b] = 0;
+    __syncthreads();
+    u32 bad = 0;
+    for (u64 k = lo + tid; k < hi; k += kBlock) {
+        const u32 i = idx[k];
+        bool ok = i < n_obj;
+        if (UPDATE) { const u32 nd = node[k]; ok = ok && (nd == kNone || nd < m); }
+        if (ok) atomicAdd(&hist[i >> kPartShift], 1u);
+        else ++bad;
+    }
+    if (bad) atomicAdd(&st->err, (u64)bad);
+    __syncthreads();
+    {   // exclusive scan over the windows: up to 8 per thread
+        const u32 per_t = (nbins + kBlock - 1) / kBlock;
+        u32 v[8];
+        u64 loc = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+            const u32 b = tid * per_t + q;
+            v[q] = (q < per_t && b < nbins) ? hist[b] : 0u;
+            loc += v[q];
+        }
+        u64 ex = block_excl_scan_1024(loc, false, part, nullptr);
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+            const u32 b = tid * per_t + q;
+            if (q < per_t && b < nbins) {
+                cur[b] = (u32)ex;
+                frag_off[(size_t)b * kPartGrid + blockIdx.x] = (u32)(lo + ex);
+                frag_cnt[(size_t)b * kPartGrid + blockIdx.x] = v[q];
+            }
+            ex += v[q];
+        }
+    }
+    __syncthreads();
+    for (u64 k = lo + tid; k < hi; k += kBlock) {
+        const u32 i = idx[k];
+        bool ok = i < n_obj;
+        u32 code = 0;
+        if (UPDATE) {
+            const u32 nd = node[k];
+            ok = ok && (nd == kNone || nd < m);
+            code = nd == kNone ? kNodeNoneCode : nd;
+        }
+        if (ok) {
+            const u32 pos = atomicAdd(&cur[i >> kPartShift], 1u);  // any order inside a fragment: the position decides later
+            rec[lo + pos] = (i & (kPartWin - 1)) | (code << kPartShift);
+            if (UPDATE) kk[lo + pos] = (u32)k;
+        }
+    }
+}
+
+// one workgroup per window; wave w streams the fragments w, w + 16, ... of its window
+__global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ rec,
+                                                        const u32* __restrict__ kk, const u32* __restrict__ frag_off,
+                                                        const u32* __restrict__ frag_cnt, u32* __restrict__ aff_life) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* win = reinterpret_cast<u64*>(smem);  // [kPartWin] {batch position + 1 | node code} of the last writer, 0 = untouched
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 b = blockIdx.x;
+    // this wave's fragment descriptors first (their latency overlaps the table clear)
+    u32 fo[kPartGrid / kWaves], fc[kPartGrid / kWaves];
+#pragma unroll
+    for (u32 q = 0; q < kPartGrid / kWaves; ++q) {
+        const u32 f = wave + q * kWaves;
+        fo[q] = frag_off[(size_t)b * kPartGrid + f];
+        fc[q] = frag_cnt[(size_t)b * kPartGrid + f];
+    }
+    for (u32 r = tid; r < kPartWin; r += kBlock) win[r] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (u32 q = 0; q < kPartGrid / kWaves; ++q)
+        for (u32 e = lane; e < fc[q]; e += 64) {
+            const u32 r = rec[fo[q] + e], k = kk[fo[q] + e];
+            atomicMax(&win[r & (kPartWin - 1)], ((u64)(k + 1u) << 16) | (u64)(r >> kPartShift));
+        }
+    __syncthreads();
+    const u64 base = (u64)b << kPartShift;
+    for (u32 r = tid; r < kPartWin; r += kBlock) {
+        const u64 v = win[r];
+        if (v && base + r < n_obj) {
+            const u32 code = (u32)v & 0xFFFFu;
+            const u32 nd = code == kNodeNoneCode ? kNone : code;
+            assign[base + r] = nd;
+            if (aff_life) aff_life[base + r] = nd == kNone ? kAffInactive : nd;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
+                                                        const u32* __restrict__ load, const u32* __restrict__ rec,
+                                                        const u32* __restrict__ frag_off, const u32* __restrict__ frag_cnt,
+                                                        u64* __restrict__ used, u32* __restrict__ aff_life) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32* flag = reinterpret_cast<u32*>(smem);                       // [kPartWin] row of this window is in the batch
+    u64* rel = reinterpret_cast<u64*>(smem + (size_t)kPartWin * 4);  // [m] load released per node (when `used` is maintained)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 b = blockIdx.x;
+    u32 fo[kPartGrid / kWaves], fc[kPartGrid / kWaves];
+#pragma unroll
+    for (u32 q = 0; q < kPartGrid / kWaves; ++q) {
+        const u32 f = wave + q * kWaves;
+        fo[q] = frag_off[(size_t)b * kPartGrid + f];
+        fc[q] = frag_cnt[(size_t)b * kPartGrid + f];
+    }
+    for (u32 r = tid; r < kPartWin; r += kBlock) flag[r] = 0;
+    if (used)
+        for (u32 j = tid; j < m; j += kBlock) rel[j] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (u32 q = 0; q < kPartGrid / kWaves; ++q)
+        for (u32 e = lane; e < fc[q]; e += 64) flag[rec[fo[q] + e] & (kPartWin - 1)] = 1u;  // duplicates: the same store
+    __syncthreads();
+    const u64 base = (u64)b << kPartShift;
+    for (u32 r = tid; r < kPartWin; r += kBlock) {
+        if (flag[r] && base + r < n_obj) {
+            const u32 old = assign[base + r];
+            if (old != kNone) {
+                assign[base + r] = kNone;
+                if (used && old < m) atomicAdd(&rel[old], (u64)load[base + r]);
+            }
+            if (aff_life) aff_life[base + r] = kAffInactive;  // row lifecycle: a removed key is no longer an object
+        }
+    }
+    if (used) {
+        __syncthreads();
+        for (u32 j = tid; j < m; j += kBlock)
+            if (rel[j]) atomicAdd(&used[j], (u64)0 - rel[j]);
+    }
+}
+
 // clean_server(s) (local.rs:51-58): one coalesced pass, 4 B read per row, 4 B written per evicted row
 // counter: device accumulator of evicted rows.  ticket/host_out (optional): the last workgroup to finish copies the
 // total into mapped host memory and resets counter and ticket, so a synchronous call needs no memset / copy-back.
@@ -2739,6 +2907,35 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
     if (!n) return;
     hipLaunchKernelGGL(k_remove, dim3(grid_for(n, kBlock * 4, 256)), dim3(kBlock), used ? (size_t)m * sizeof(u64) : 0, s, assign,
                        n_obj, m, load, idx, n, used, st, aff_life);
+}
+// The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
+// provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
+bool part_applicable(u64 n_obj, u64 n) {
+    const u64 nbins = (n_obj + kPartWin - 1) >> kPartShift;
+    return n >= ((u64)1 << 18) && n <= 0x7FFFFFFFull && nbins >= 32 && nbins <= kPartMaxBins;
+}
+size_t part_scratch_words(u64 n_obj, u64 n) {
+    const u64 nbins = (n_obj + kPartWin - 1) >> kPartShift;
+    return (size_t)(2 * n + 2 * nbins * kPartGrid + 64);
+}
+void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
+                        hipStream_t s, u32* aff_life) {
+    const u32 nbins = (u32)((n_obj + kPartWin - 1) >> kPartShift);
+    u32 *rec = scratch, *kk = scratch + n, *fo = scratch + 2 * n, *fc = fo + (size_t)nbins * kPartGrid;
+    const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
+    hipLaunchKernelGGL(k_part_bin<true>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, node, n, nbins, rec, kk, fo, fc, st);
+    hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), (size_t)kPartWin * sizeof(u64), s, assign, n_obj, rec, kk, fo, fc,
+                       aff_life);
+}
+void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u32* scratch, u64* used,
+                        DevStats* st, hipStream_t s, u32* aff_life) {
+    const u32 nbins = (u32)((n_obj + kPartWin - 1) >> kPartShift);
+    u32 *rec = scratch, *fo = scratch + 2 * n, *fc = fo + (size_t)nbins * kPartGrid;
+    const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
+    hipLaunchKernelGGL(k_part_bin<false>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, (const u32*)nullptr, n, nbins, rec,
+                       (u32*)nullptr, fo, fc, st);
+    hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), (size_t)kPartWin * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0), s,
+                       assign, n_obj, m, load, rec, fo, fc, used, aff_life);
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
                   u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life) {

@@ -151,6 +151,7 @@ struct rio_gp {
     int fixup_mode = 2;    // cut fix-up: 2 split launches (k_cut_find + k_cut_apply_rank) | 1 one fused launch | 0 the unfused
                            // chain; >= 1 also folds the packed scatter into the water-fill (rio_gp_debug_set_fixup)
     int spec_mode = 0;     // speculative fix-up enqueue: 0 auto (after a solve that needed it) | 1 always | 2 never
+    int part_mode = 0;     // partitioned CRUD batches: 0 when the batch qualifies | 2 never (rio_gp_debug_set_compact bit 4)
     bool last_slow = false;
     // clean_server(s): dead bitmap + evicted count in mapped pinned memory, self-resetting device counter + ticket
     u32* h_cs = nullptr;
@@ -163,6 +164,7 @@ struct rio_gp {
     u32* d_small = nullptr;
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
+    DevBuf part;  // scratch of the partitioned update / remove batches (records + fragment tables)
     std::vector<void*> allocs;
 };
 
@@ -605,6 +607,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& b : h->vt) if (b.p) (void)hipFree(b.p);
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
+    if (h->part.p) (void)hipFree(h->part.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_slots) (void)hipHostFree(h->h_slots);
     if (h->h_fx) (void)hipHostFree(h->h_fx);
@@ -862,7 +865,12 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
 static int update_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node) {
     int rc = zero_stats(h);
     if (rc) return rc;
-    launch_update(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, h->pos, h->dstats, h->stream, aff_life(h));
+    if (h->part_mode != 2 && part_applicable(h->n, n)) {  // big batch: binned by row window, elected in LDS, written densely
+        if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32)))) return rc;
+        launch_update_part(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, (u32*)h->part.p, h->dstats, h->stream, aff_life(h));
+    } else {
+        launch_update(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, h->pos, h->dstats, h->stream, aff_life(h));
+    }
     h->used_valid = false;
     h->have_solved = false;
     if ((rc = read_stats(h))) return rc;
@@ -907,8 +915,14 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
 static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
     int rc = zero_stats(h);
     if (rc) return rc;
-    launch_remove(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, h->used_valid ? h->used : nullptr, h->dstats,
-                  h->stream, aff_life(h));
+    if (h->part_mode != 2 && part_applicable(h->n, n)) {
+        if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32)))) return rc;
+        launch_remove_part(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, (u32*)h->part.p, h->used_valid ? h->used : nullptr,
+                           h->dstats, h->stream, aff_life(h));
+    } else {
+        launch_remove(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, h->used_valid ? h->used : nullptr, h->dstats,
+                      h->stream, aff_life(h));
+    }
     h->have_solved = false;
     if ((rc = read_stats(h))) return rc;
     if (h->h_stats[0].err) return fail(h, RIO_GP_EINVAL, "rio_gp_remove_batch: invalid entries were skipped");
@@ -1650,8 +1664,10 @@ int rio_gp_debug_ktrace(rio_gp_t* h, int table, uint64_t* out2048) {
 }
 
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
-    if (!h || mode < 0 || mode > 2) return RIO_GP_EINVAL;
+    if (!h || mode < 0 || (mode & 15) > 2) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
+    h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
+    mode &= 15;
     h->compact_mode = mode;
     return RIO_GP_OK;
 }

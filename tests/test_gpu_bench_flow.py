@@ -28,6 +28,28 @@ def test_bench_line_n1():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["stats_last_step"]["claimed"] + d["stats_last_step"]["spilled"] + d["stats_last_step"]["unplaced"] == 1000000
+    # the run checks itself against the oracle (and would have exited with rc 3 on a mismatch)
+    assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 1000000
+    assert d["dependent_tick_ms"] > 0 and "traffic_source" in d["roofline"]
+
+
+def test_bench_headline_line_has_parity_traffic_and_config4():
+    """The default command line of the driver at N=1, shortened: config 3 at full size with the in-run parity check, the
+    in-run PMC passes and the config-4-on-one-GPU data point (100 M x 4 096, parity at size)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--cpu-sample", "200000"],
+                       capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_json_line(r.stdout)
+    assert d["config"]["objects_per_gpu"] == 10_000_000 and d["config"]["nodes"] == 1024
+    assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 10_000_000
+    assert d["roofline"]["frac"] > 0.5 and d["roofline"]["whole_step_frac"] > 0.4
+    if d["roofline"]["traffic"] is not None:   # rocprofv3 present: measured in this run, not replayed
+        assert d["roofline"]["traffic_source"].startswith("measured in this run")
+        assert 0.9 < d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] < 1.3
+    c4 = d["config4_single_gpu"]
+    assert c4["parity"]["equal"] is True and c4["parity"]["checked_rows"] == 100_000_000 and c4["slow_path_steps"] == 0
+    cold = d["roofline"]["beyond_infinity_cache"]
+    assert cold["rows"] == 40_000_000 and cold["whole_step_frac"] > 0.4
 
 
 @pytest.mark.parametrize("exchange", ["p2p", "torch"])
@@ -44,6 +66,28 @@ def test_bench_two_ranks_as_the_driver_launches_it(exchange):
     assert d["config"]["slow_path_steps"] == 0
     # gloo cannot all-gather device tensors, so the torch path is expected to drop... to nothing: it IS the last rung
     assert d["config"]["exchange"] in ("p2p", "torch")
+
+
+def test_bench_config4_strong_scaling_two_ranks():
+    """north_star's config 4 is what `bench.py --gpus N` measures for N > 1: ONE table split over the ranks (strong
+    scaling), here 2 M x 4 096 over two ranks that share the one GPU.  Two exchange kernels of 4 096 nodes cannot be
+    co-resident on one device, so this flow test runs the collective path (torch / gloo); on a real
+    node every rank has its own GPU and the ladder starts at the peer-to-peer windows.  The weak-scaled config 3 is the
+    second measurement of the same run, and both check themselves against the whole-table oracle."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+           "--total-objects", "2000000", "--objects", "300000", "--backend", "gloo", "--same-device", "--exchange", "torch"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["objects_total"] == 2_000_000 and d["config"]["objects_per_gpu"] == 1_000_000 and d["config"]["nodes"] == 4096
+    assert d["config"]["workload"].startswith("config 4:")
+    assert d["config"]["exchange"] == "torch" and d["config"]["exchange_ladder"][0]["ok"] is True
+    assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 2_000_000
+    w = d["weak_config3"]
+    assert w["scaling"] == "weak" and w["objects_per_gpu"] == 300000 and w["nodes"] == 1024 and w["parity"]["equal"] is True
 
 
 def test_bench_eight_ranks_on_one_gpu():

@@ -180,6 +180,78 @@ def test_crud_micro_batches(gp, oracle, seed):
     g.close()
 
 
+@pytest.mark.parametrize("seed,n,m,k", [(0, 2_000_003, 300, 3_000_000), (1, 600_000, 7, 262_144), (2, 10_000_000, 1024, 10_000_000)])
+def test_crud_big_batches_partitioned_by_row_window(gp, oracle, seed, n, m, k):
+    """update_batch / remove_batch of >= 2^18 entries take the window-partitioned kernels (k_part_bin, k_part_update,
+    k_part_remove): sequential last-writer-wins among heavy duplicates, deletes (node NONE), the incremental `used`
+    vector of remove, the row-lifecycle column — same bytes as the oracle and as the plain per-entry kernels."""
+    rng = np.random.default_rng(4400 + seed)
+    load = rng.integers(0, 100, n).astype(np.uint32)
+    g = gp.GpuPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
+    g.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    g.set_objects(n, load, None)
+    plain = gp.GpuPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
+    plain.set_compact("auto", partitioned_crud=False)
+    plain.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    plain.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    life = np.zeros(n, bool)
+    for step in range(2):
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        idx[: k // 4] = rng.integers(0, 5000, k // 4).astype(np.uint32)       # a quarter of the batch fights over 5 000 rows
+        node = rng.integers(0, m, k).astype(np.uint32)
+        node[rng.random(k) < 0.1] = NONE
+        for h in (g, plain):
+            h.update_batch(idx, node)
+        assert oracle.update_batch(ref, m, idx, node) == 0
+        got = g.get_assign()
+        assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:10]
+        assert np.array_equal(plain.get_assign(), ref)
+        life[idx] = ref[idx] != NONE
+        assert np.array_equal(g.get_objects()[1] != gp.AFF_INACTIVE, life)
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))   # rebuilt from scratch after raw updates
+        rm = rng.integers(0, n, max(k // 2, 262_144)).astype(np.uint32)        # duplicates and absent rows included
+        for h in (g, plain):
+            h.remove_batch(rm)
+        oracle.remove_batch(ref, rm)
+        life[rm] = False
+        assert np.array_equal(g.get_assign(), ref) and np.array_equal(plain.get_assign(), ref)
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))   # incremental == scratch
+        assert np.array_equal(g.get_objects()[1] != gp.AFF_INACTIVE, life)
+    g.close()
+    plain.close()
+
+
+def test_crud_big_batch_dev_skips_invalid_entries(gp, oracle):
+    """Device-resident batch with out-of-range entries: they are skipped and reported (RIO_GP_EINVAL), the valid ones applied —
+    the partitioned kernels keep the contract of the plain ones."""
+    import torch
+    n, m, k = 1_000_000, 40, 400_000
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, n, k).astype(np.uint32)
+    node = rng.integers(0, m, k).astype(np.uint32)
+    idx[[5, 77777]] = n + 3
+    node[[9, 12345]] = m
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    g.set_objects(n)
+    d_idx = torch.from_numpy(idx.astype(np.int64)).to(torch.int32).cuda()
+    d_node = torch.from_numpy(node.astype(np.int64)).to(torch.int32).cuda()
+    torch.cuda.synchronize()
+    import ctypes as C
+    rc = gp.lib().rio_gp_update_batch_dev(g.handle, k, C.c_void_p(d_idx.data_ptr()), C.c_void_p(d_node.data_ptr()))
+    assert rc == gp.EINVAL
+    ok = (idx < n) & (node < m)
+    ref = np.full(n, NONE, np.uint32)
+    assert oracle.update_batch(ref, m, idx[ok], node[ok]) == 0
+    assert np.array_equal(g.get_assign(), ref)
+    rc = gp.lib().rio_gp_remove_batch_dev(g.handle, k, C.c_void_p(d_idx.data_ptr()))
+    assert rc == gp.EINVAL
+    oracle.remove_batch(ref, idx[idx < n])
+    assert np.array_equal(g.get_assign(), ref)
+    g.close()
+
+
 def test_invalid_arguments_are_unknown_errors(gp):
     g = gp.GpuPlacement(10, 2)
     g.set_nodes(m=2, alive=np.ones(2, np.uint8))
