@@ -1958,10 +1958,12 @@ constexpr u32 kPartWin = 1u << kPartShift;
 constexpr u32 kPartMaxBins = 8192;    // 134 M rows
 constexpr u32 kNodeNoneCode = 0x3FFFu;  // 14-bit code of RIO_GP_NONE (node ids are < 8 192)
 
+// records: updates {row in window | node code << 14, batch position} as ONE 8-byte word (one scattered store per entry,
+// not two), removals the 4-byte row-in-window alone
 template <bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32* __restrict__ idx,
                                                      const u32* __restrict__ node, u64 n, u32 nbins,
-                                                     u32* __restrict__ rec, u32* __restrict__ kk,
+                                                     u32* __restrict__ rec, uint2* __restrict__ rec2,
                                                      u32* __restrict__ frag_off, u32* __restrict__ frag_cnt,
                                                      DevStats* st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1969,19 +1971,34 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins]
     u32* cur = hist + nbins;                                  // [nbins] write cursor of a window inside this slice
     const int tid = threadIdx.x;
-    const u64 per = (n + kPartGrid - 1) / kPartGrid;
+    // slices are whole groups of 4 entries (dwordx4 reads); a lane takes 4 consecutive entries, 2 groups per trip:
+    // one 4-byte read per lane and trip left the loop latency-bound at ~1 TB/s
+    const u64 per = (((n + kPartGrid - 1) / kPartGrid) + 3) & ~(u64)3;
     const u64 lo = (u64)blockIdx.x * per;
     u64 hi = lo + per;
     if (hi > n) hi = n;
+    if (lo > hi) hi = lo;
     for (u32 b = tid; b < nbins; b += kBlock) hist[b] = 0;
     __syncthreads();
     u32 bad = 0;
-    for (u64 k = lo + tid; k < hi; k += kBlock) {
-        const u32 i = idx[k];
-        bool ok = i < n_obj;
-        if (UPDATE) { const u32 nd = node[k]; ok = ok && (nd == kNone || nd < m); }
-        if (ok) atomicAdd(&hist[i >> kPartShift], 1u);
-        else ++bad;
+    auto valid = [&](u32 i, u32 nd) -> bool { return i < n_obj && (!UPDATE || nd == kNone || nd < m); };
+    auto load4 = [&](const u32* p, u64 k) -> uint4 {  // entries k..k+3 of a column, zero past hi (k is a multiple of 4)
+        if (k + 4 <= hi) return *reinterpret_cast<const uint4*>(p + k);
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (k + 0 < hi) r.x = p[k + 0];
+        if (k + 1 < hi) r.y = p[k + 1];
+        if (k + 2 < hi) r.z = p[k + 2];
+        return r;
+    };
+    for (u64 k0 = lo + (u64)tid * 4; k0 < hi; k0 += (u64)kBlock * 8) {
+        const u64 k1 = k0 + (u64)kBlock * 4;
+        const uint4 ia = load4(idx, k0), ib = k1 < hi ? load4(idx, k1) : make_uint4(0, 0, 0, 0);
+        uint4 na = make_uint4(0, 0, 0, 0), nb = na;
+        if (UPDATE) { na = load4(node, k0); if (k1 < hi) nb = load4(node, k1); }
+#define RIOGP_H(K, I, N) if ((K) < hi) { if (valid(I, N)) atomicAdd(&hist[(I) >> kPartShift], 1u); else ++bad; }
+        RIOGP_H(k0 + 0, ia.x, na.x) RIOGP_H(k0 + 1, ia.y, na.y) RIOGP_H(k0 + 2, ia.z, na.z) RIOGP_H(k0 + 3, ia.w, na.w)
+        RIOGP_H(k1 + 0, ib.x, nb.x) RIOGP_H(k1 + 1, ib.y, nb.y) RIOGP_H(k1 + 2, ib.z, nb.z) RIOGP_H(k1 + 3, ib.w, nb.w)
+#undef RIOGP_H
     }
     if (bad) atomicAdd(&st->err, (u64)bad);
     __syncthreads();
@@ -2008,46 +2025,56 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
         }
     }
     __syncthreads();
-    for (u64 k = lo + tid; k < hi; k += kBlock) {
-        const u32 i = idx[k];
-        bool ok = i < n_obj;
-        u32 code = 0;
-        if (UPDATE) {
-            const u32 nd = node[k];
-            ok = ok && (nd == kNone || nd < m);
-            code = nd == kNone ? kNodeNoneCode : nd;
+    for (u64 k0 = lo + (u64)tid * 4; k0 < hi; k0 += (u64)kBlock * 8) {
+        const u64 k1 = k0 + (u64)kBlock * 4;
+        const uint4 ia = load4(idx, k0), ib = k1 < hi ? load4(idx, k1) : make_uint4(0, 0, 0, 0);
+        uint4 na = make_uint4(0, 0, 0, 0), nb = na;
+        if (UPDATE) { na = load4(node, k0); if (k1 < hi) nb = load4(node, k1); }
+#define RIOGP_S(K, I, N)                                                                                   \
+        if ((K) < hi && valid(I, N)) {                                                                     \
+            const u32 pos = atomicAdd(&cur[(I) >> kPartShift], 1u); /* any order inside a fragment */        \
+            const u32 r = ((I) & (kPartWin - 1)) | ((UPDATE ? ((N) == kNone ? kNodeNoneCode : (N)) : 0u) << kPartShift); \
+            if (UPDATE) rec2[lo + pos] = make_uint2(r, (u32)(K));                                          \
+            else rec[lo + pos] = r;                                                                        \
         }
-        if (ok) {
-            const u32 pos = atomicAdd(&cur[i >> kPartShift], 1u);  // any order inside a fragment: the position decides later
-            rec[lo + pos] = (i & (kPartWin - 1)) | (code << kPartShift);
-            if (UPDATE) kk[lo + pos] = (u32)k;
-        }
+        RIOGP_S(k0 + 0, ia.x, na.x) RIOGP_S(k0 + 1, ia.y, na.y) RIOGP_S(k0 + 2, ia.z, na.z) RIOGP_S(k0 + 3, ia.w, na.w)
+        RIOGP_S(k1 + 0, ib.x, nb.x) RIOGP_S(k1 + 1, ib.y, nb.y) RIOGP_S(k1 + 2, ib.z, nb.z) RIOGP_S(k1 + 3, ib.w, nb.w)
+#undef RIOGP_S
     }
 }
 
-// one workgroup per window; wave w streams the fragments w, w + 16, ... of its window
-__global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ rec,
-                                                        const u32* __restrict__ kk, const u32* __restrict__ frag_off,
-                                                        const u32* __restrict__ frag_cnt, u32* __restrict__ aff_life) {
+// one workgroup per window; wave w streams the fragments w, w + 16, ... of its window: the first 64 records of all its
+// 16 fragments are requested before the first is used (a fragment is ~64 records on a 10 M batch: one request each)
+constexpr u32 kPartFragsPerWave = kPartGrid / kWaves;
+
+__global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign, u64 n_obj, const uint2* __restrict__ rec2,
+                                                        const u32* __restrict__ frag_off, const u32* __restrict__ frag_cnt,
+                                                        u32* __restrict__ aff_life) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* win = reinterpret_cast<u64*>(smem);  // [kPartWin] {batch position + 1 | node code} of the last writer, 0 = untouched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x;
-    // this wave's fragment descriptors first (their latency overlaps the table clear)
-    u32 fo[kPartGrid / kWaves], fc[kPartGrid / kWaves];
+    u32 fo[kPartFragsPerWave], fc[kPartFragsPerWave];
 #pragma unroll
-    for (u32 q = 0; q < kPartGrid / kWaves; ++q) {
+    for (u32 q = 0; q < kPartFragsPerWave; ++q) {
         const u32 f = wave + q * kWaves;
         fo[q] = frag_off[(size_t)b * kPartGrid + f];
         fc[q] = frag_cnt[(size_t)b * kPartGrid + f];
     }
+    uint2 first[kPartFragsPerWave];
+#pragma unroll
+    for (u32 q = 0; q < kPartFragsPerWave; ++q) first[q] = (u32)lane < fc[q] ? rec2[fo[q] + lane] : make_uint2(0, 0);
     for (u32 r = tid; r < kPartWin; r += kBlock) win[r] = 0;
     __syncthreads();
+#pragma unroll
+    for (u32 q = 0; q < kPartFragsPerWave; ++q)
+        if ((u32)lane < fc[q])
+            atomicMax(&win[first[q].x & (kPartWin - 1)], ((u64)(first[q].y + 1u) << 16) | (u64)(first[q].x >> kPartShift));
 #pragma unroll 1
-    for (u32 q = 0; q < kPartGrid / kWaves; ++q)
-        for (u32 e = lane; e < fc[q]; e += 64) {
-            const u32 r = rec[fo[q] + e], k = kk[fo[q] + e];
-            atomicMax(&win[r & (kPartWin - 1)], ((u64)(k + 1u) << 16) | (u64)(r >> kPartShift));
+    for (u32 q = 0; q < kPartFragsPerWave; ++q)
+        for (u32 e = 64 + lane; e < fc[q]; e += 64) {
+            const uint2 x = rec2[fo[q] + e];
+            atomicMax(&win[x.x & (kPartWin - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShift));
         }
     __syncthreads();
     const u64 base = (u64)b << kPartShift;
@@ -2071,20 +2098,26 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
     u64* rel = reinterpret_cast<u64*>(smem + (size_t)kPartWin * 4);  // [m] load released per node (when `used` is maintained)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x;
-    u32 fo[kPartGrid / kWaves], fc[kPartGrid / kWaves];
+    u32 fo[kPartFragsPerWave], fc[kPartFragsPerWave];
 #pragma unroll
-    for (u32 q = 0; q < kPartGrid / kWaves; ++q) {
+    for (u32 q = 0; q < kPartFragsPerWave; ++q) {
         const u32 f = wave + q * kWaves;
         fo[q] = frag_off[(size_t)b * kPartGrid + f];
         fc[q] = frag_cnt[(size_t)b * kPartGrid + f];
     }
+    u32 first[kPartFragsPerWave];
+#pragma unroll
+    for (u32 q = 0; q < kPartFragsPerWave; ++q) first[q] = (u32)lane < fc[q] ? rec[fo[q] + lane] : 0u;
     for (u32 r = tid; r < kPartWin; r += kBlock) flag[r] = 0;
     if (used)
         for (u32 j = tid; j < m; j += kBlock) rel[j] = 0;
     __syncthreads();
+#pragma unroll
+    for (u32 q = 0; q < kPartFragsPerWave; ++q)
+        if ((u32)lane < fc[q]) flag[first[q] & (kPartWin - 1)] = 1u;  // duplicates: the same store
 #pragma unroll 1
-    for (u32 q = 0; q < kPartGrid / kWaves; ++q)
-        for (u32 e = lane; e < fc[q]; e += 64) flag[rec[fo[q] + e] & (kPartWin - 1)] = 1u;  // duplicates: the same store
+    for (u32 q = 0; q < kPartFragsPerWave; ++q)
+        for (u32 e = 64 + lane; e < fc[q]; e += 64) flag[rec[fo[q] + e] & (kPartWin - 1)] = 1u;
     __syncthreads();
     const u64 base = (u64)b << kPartShift;
     for (u32 r = tid; r < kPartWin; r += kBlock) {
@@ -2910,30 +2943,35 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
 }
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
-bool part_applicable(u64 n_obj, u64 n) {
+bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node) {
     const u64 nbins = (n_obj + kPartWin - 1) >> kPartShift;
-    return n >= ((u64)1 << 18) && n <= 0x7FFFFFFFull && nbins >= 32 && nbins <= kPartMaxBins;
+    // dense enough that rewriting whole windows pays (a sparse batch touches few rows of each), columns 16-byte aligned
+    return n >= ((u64)1 << 18) && n <= 0x7FFFFFFFull && n * 8 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
+           (((uintptr_t)idx | (uintptr_t)node) & 15u) == 0;
 }
 size_t part_scratch_words(u64 n_obj, u64 n) {
     const u64 nbins = (n_obj + kPartWin - 1) >> kPartShift;
-    return (size_t)(2 * n + 2 * nbins * kPartGrid + 64);
+    return (size_t)(2 * (n + 4 * kPartGrid) + 2 * nbins * kPartGrid + 64);  // slices are rounded up to groups of 4 entries
 }
 void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
                         hipStream_t s, u32* aff_life) {
     const u32 nbins = (u32)((n_obj + kPartWin - 1) >> kPartShift);
-    u32 *rec = scratch, *kk = scratch + n, *fo = scratch + 2 * n, *fc = fo + (size_t)nbins * kPartGrid;
+    const size_t nrec = (size_t)(n + 4 * kPartGrid);
+    uint2* rec2 = reinterpret_cast<uint2*>(scratch);
+    u32 *fo = scratch + 2 * nrec, *fc = fo + (size_t)nbins * kPartGrid;
     const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
-    hipLaunchKernelGGL(k_part_bin<true>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, node, n, nbins, rec, kk, fo, fc, st);
-    hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), (size_t)kPartWin * sizeof(u64), s, assign, n_obj, rec, kk, fo, fc,
-                       aff_life);
+    hipLaunchKernelGGL(k_part_bin<true>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, node, n, nbins, (u32*)nullptr, rec2,
+                       fo, fc, st);
+    hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), (size_t)kPartWin * sizeof(u64), s, assign, n_obj, rec2, fo, fc, aff_life);
 }
 void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u32* scratch, u64* used,
                         DevStats* st, hipStream_t s, u32* aff_life) {
     const u32 nbins = (u32)((n_obj + kPartWin - 1) >> kPartShift);
-    u32 *rec = scratch, *fo = scratch + 2 * n, *fc = fo + (size_t)nbins * kPartGrid;
+    const size_t nrec = (size_t)(n + 4 * kPartGrid);
+    u32 *rec = scratch, *fo = scratch + 2 * nrec, *fc = fo + (size_t)nbins * kPartGrid;
     const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
     hipLaunchKernelGGL(k_part_bin<false>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, (const u32*)nullptr, n, nbins, rec,
-                       (u32*)nullptr, fo, fc, st);
+                       (uint2*)nullptr, fo, fc, st);
     hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), (size_t)kPartWin * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0), s,
                        assign, n_obj, m, load, rec, fo, fc, used, aff_life);
 }

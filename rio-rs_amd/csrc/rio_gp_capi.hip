@@ -865,7 +865,7 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
 static int update_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node) {
     int rc = zero_stats(h);
     if (rc) return rc;
-    if (h->part_mode != 2 && part_applicable(h->n, n)) {  // big batch: binned by row window, elected in LDS, written densely
+    if (h->part_mode != 2 && part_applicable(h->n, n, d_idx, d_node)) {  // big batch: binned by row window, elected in LDS, written densely
         if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32)))) return rc;
         launch_update_part(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, (u32*)h->part.p, h->dstats, h->stream, aff_life(h));
     } else {
@@ -915,7 +915,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
 static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
     int rc = zero_stats(h);
     if (rc) return rc;
-    if (h->part_mode != 2 && part_applicable(h->n, n)) {
+    if (h->part_mode != 2 && part_applicable(h->n, n, d_idx, nullptr)) {
         if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32)))) return rc;
         launch_remove_part(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, (u32*)h->part.p, h->used_valid ? h->used : nullptr,
                            h->dstats, h->stream, aff_life(h));
