@@ -27,6 +27,8 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 int rio_gp_debug_set_fixup(rio_gp_t* h, int impl, int speculate);
 /* non-temporal column streams in k_scan: 0 = by table size (default) | 1 = always | 2 = never; process-wide. */
 void rio_gp_debug_set_scan_nt(int mode);
+/* window of the partitioned update / remove batches: 1 << shift rows, shift 12..14 (default 14); process-wide. */
+void rio_gp_debug_set_part_shift(int shift);
 /* read (out2048 != NULL: 256 workgroups x 8 words) and switch the phase trace of the cut kernels */
 int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048);
 /* phase traces of the other fix-up kernels (switched by rio_gp_debug_cut_trace's enable): table 0 / 1 = k_spill_apply

@@ -1953,16 +1953,15 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
 //   Traffic: the batch twice (the second read comes from L2 / Infinity Cache), the records twice, the window once.
 // ------------------------------------------------------------------------------------------------
 constexpr u32 kPartGrid = 256;        // slices of the batch = workgroups of k_part_bin
-constexpr u32 kPartShift = 14;        // rows per window = 16 384: W u64 election words = 128 KiB of LDS
-constexpr u32 kPartWin = 1u << kPartShift;
-constexpr u32 kPartMaxBins = 8192;    // 134 M rows
+constexpr u32 kPartShiftMax = 14;     // rows per window <= 16 384: W u64 election words = 128 KiB of LDS
+constexpr u32 kPartMaxBins = 8192;    // 134 M rows at the largest window
 constexpr u32 kNodeNoneCode = 0x3FFFu;  // 14-bit code of RIO_GP_NONE (node ids are < 8 192)
 
 // records: updates {row in window | node code << 14, batch position} as ONE 8-byte word (one scattered store per entry,
 // not two), removals the 4-byte row-in-window alone
 template <bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32* __restrict__ idx,
-                                                     const u32* __restrict__ node, u64 n, u32 nbins,
+                                                     const u32* __restrict__ node, u64 n, u32 nbins, const u32 wshift,
                                                      u32* __restrict__ rec, uint2* __restrict__ rec2,
                                                      u32* __restrict__ frag_off, u32* __restrict__ frag_cnt,
                                                      DevStats* st) {
@@ -1971,6 +1970,7 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins]
     u32* cur = hist + nbins;                                  // [nbins] write cursor of a window inside this slice
     const int tid = threadIdx.x;
+    const u32 wmask = (1u << wshift) - 1u;
     // slices are whole groups of 4 entries (dwordx4 reads); a lane takes 4 consecutive entries, 2 groups per trip:
     // one 4-byte read per lane and trip left the loop latency-bound at ~1 TB/s
     const u64 per = (((n + kPartGrid - 1) / kPartGrid) + 3) & ~(u64)3;
@@ -1995,7 +1995,7 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
         const uint4 ia = load4(idx, k0), ib = k1 < hi ? load4(idx, k1) : make_uint4(0, 0, 0, 0);
         uint4 na = make_uint4(0, 0, 0, 0), nb = na;
         if (UPDATE) { na = load4(node, k0); if (k1 < hi) nb = load4(node, k1); }
-#define RIOGP_H(K, I, N) if ((K) < hi) { if (valid(I, N)) atomicAdd(&hist[(I) >> kPartShift], 1u); else ++bad; }
+#define RIOGP_H(K, I, N) if ((K) < hi) { if (valid(I, N)) atomicAdd(&hist[(I) >> wshift], 1u); else ++bad; }
         RIOGP_H(k0 + 0, ia.x, na.x) RIOGP_H(k0 + 1, ia.y, na.y) RIOGP_H(k0 + 2, ia.z, na.z) RIOGP_H(k0 + 3, ia.w, na.w)
         RIOGP_H(k1 + 0, ib.x, nb.x) RIOGP_H(k1 + 1, ib.y, nb.y) RIOGP_H(k1 + 2, ib.z, nb.z) RIOGP_H(k1 + 3, ib.w, nb.w)
 #undef RIOGP_H
@@ -2032,8 +2032,8 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
         if (UPDATE) { na = load4(node, k0); if (k1 < hi) nb = load4(node, k1); }
 #define RIOGP_S(K, I, N)                                                                                   \
         if ((K) < hi && valid(I, N)) {                                                                     \
-            const u32 pos = atomicAdd(&cur[(I) >> kPartShift], 1u); /* any order inside a fragment */        \
-            const u32 r = ((I) & (kPartWin - 1)) | ((UPDATE ? ((N) == kNone ? kNodeNoneCode : (N)) : 0u) << kPartShift); \
+            const u32 pos = atomicAdd(&cur[(I) >> wshift], 1u); /* any order inside a fragment */        \
+            const u32 r = ((I) & wmask) | ((UPDATE ? ((N) == kNone ? kNodeNoneCode : (N)) : 0u) << kPartShiftMax); \
             if (UPDATE) rec2[lo + pos] = make_uint2(r, (u32)(K));                                          \
             else rec[lo + pos] = r;                                                                        \
         }
@@ -2049,10 +2049,11 @@ constexpr u32 kPartFragsPerWave = kPartGrid / kWaves;
 
 __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign, u64 n_obj, const uint2* __restrict__ rec2,
                                                         const u32* __restrict__ frag_off, const u32* __restrict__ frag_cnt,
-                                                        u32* __restrict__ aff_life) {
+                                                        u32* __restrict__ aff_life, const u32 wshift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* win = reinterpret_cast<u64*>(smem);  // [kPartWin] {batch position + 1 | node code} of the last writer, 0 = untouched
+    u64* win = reinterpret_cast<u64*>(smem);  // [W] {batch position + 1 | node code} of the last writer, 0 = untouched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 kPartWin = 1u << wshift;
     const u32 b = blockIdx.x;
     u32 fo[kPartFragsPerWave], fc[kPartFragsPerWave];
 #pragma unroll
@@ -2069,15 +2070,15 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
 #pragma unroll
     for (u32 q = 0; q < kPartFragsPerWave; ++q)
         if ((u32)lane < fc[q])
-            atomicMax(&win[first[q].x & (kPartWin - 1)], ((u64)(first[q].y + 1u) << 16) | (u64)(first[q].x >> kPartShift));
+            atomicMax(&win[first[q].x & (kPartWin - 1)], ((u64)(first[q].y + 1u) << 16) | (u64)(first[q].x >> kPartShiftMax));
 #pragma unroll 1
     for (u32 q = 0; q < kPartFragsPerWave; ++q)
         for (u32 e = 64 + lane; e < fc[q]; e += 64) {
             const uint2 x = rec2[fo[q] + e];
-            atomicMax(&win[x.x & (kPartWin - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShift));
+            atomicMax(&win[x.x & (kPartWin - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShiftMax));
         }
     __syncthreads();
-    const u64 base = (u64)b << kPartShift;
+    const u64 base = (u64)b << wshift;
     for (u32 r = tid; r < kPartWin; r += kBlock) {
         const u64 v = win[r];
         if (v && base + r < n_obj) {
@@ -2092,9 +2093,10 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
 __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                         const u32* __restrict__ load, const u32* __restrict__ rec,
                                                         const u32* __restrict__ frag_off, const u32* __restrict__ frag_cnt,
-                                                        u64* __restrict__ used, u32* __restrict__ aff_life) {
+                                                        u64* __restrict__ used, u32* __restrict__ aff_life, const u32 wshift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32* flag = reinterpret_cast<u32*>(smem);                       // [kPartWin] row of this window is in the batch
+    const u32 kPartWin = 1u << wshift;
+    u32* flag = reinterpret_cast<u32*>(smem);                       // [W] row of this window is in the batch
     u64* rel = reinterpret_cast<u64*>(smem + (size_t)kPartWin * 4);  // [m] load released per node (when `used` is maintained)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x;
@@ -2119,7 +2121,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
     for (u32 q = 0; q < kPartFragsPerWave; ++q)
         for (u32 e = 64 + lane; e < fc[q]; e += 64) flag[rec[fo[q] + e] & (kPartWin - 1)] = 1u;
     __syncthreads();
-    const u64 base = (u64)b << kPartShift;
+    const u64 base = (u64)b << wshift;
     for (u32 r = tid; r < kPartWin; r += kBlock) {
         if (flag[r] && base + r < n_obj) {
             const u32 old = assign[base + r];
@@ -2168,10 +2170,10 @@ __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_o
         const bool e0 = i0 + 0 < n_obj && c.x < m && bit_of(db, c.x), e1 = i0 + 1 < n_obj && c.y < m && bit_of(db, c.y);
         const bool e2 = i0 + 2 < n_obj && c.z < m && bit_of(db, c.z), e3 = i0 + 3 < n_obj && c.w < m && bit_of(db, c.w);
         if (e0 | e1 | e2 | e3) {
-            if (e0) assign[i0 + 0] = kNone;
-            if (e1) assign[i0 + 1] = kNone;
-            if (e2) assign[i0 + 2] = kNone;
-            if (e3) assign[i0 + 3] = kNone;
+            // the lane's four rows go back as ONE 16-byte store (up to four masked 4-byte stores cost 40 us per pass over
+            // 10 M rows with 10 % of them evicted, against 8 us of reading); the column is padded past n_obj
+            c.x = e0 ? kNone : c.x; c.y = e1 ? kNone : c.y; c.z = e2 ? kNone : c.z; c.w = e3 ? kNone : c.w;
+            *reinterpret_cast<uint4*>(assign + i0) = c;
             if (aff_life) {  // row lifecycle: retain() drops the entries (local.rs:51-58); they come back on their next request
                 if (e0) aff_life[i0 + 0] = kAffInactive;
                 if (e1) aff_life[i0 + 1] = kAffInactive;
@@ -2943,37 +2945,40 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
 }
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
+int g_part_shift = 14;  // rows per window = 1 << shift (rio_gp_debug_set_part_shift: 12..14)
+void set_part_shift(int shift) { g_part_shift = shift < 12 ? 12 : shift > (int)kPartShiftMax ? (int)kPartShiftMax : shift; }
+static inline u64 part_bins(u64 n_obj) { return (n_obj + ((u64)1 << g_part_shift) - 1) >> g_part_shift; }
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node) {
-    const u64 nbins = (n_obj + kPartWin - 1) >> kPartShift;
+    const u64 nbins = part_bins(n_obj);
     // dense enough that rewriting whole windows pays (a sparse batch touches few rows of each), columns 16-byte aligned
     return n >= ((u64)1 << 18) && n <= 0x7FFFFFFFull && n * 8 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
            (((uintptr_t)idx | (uintptr_t)node) & 15u) == 0;
 }
 size_t part_scratch_words(u64 n_obj, u64 n) {
-    const u64 nbins = (n_obj + kPartWin - 1) >> kPartShift;
-    return (size_t)(2 * (n + 4 * kPartGrid) + 2 * nbins * kPartGrid + 64);  // slices are rounded up to groups of 4 entries
+    return (size_t)(2 * (n + 4 * kPartGrid) + 2 * part_bins(n_obj) * kPartGrid + 64);  // slices are rounded up to groups of 4 entries
 }
 void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
                         hipStream_t s, u32* aff_life) {
-    const u32 nbins = (u32)((n_obj + kPartWin - 1) >> kPartShift);
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const size_t nrec = (size_t)(n + 4 * kPartGrid);
     uint2* rec2 = reinterpret_cast<uint2*>(scratch);
     u32 *fo = scratch + 2 * nrec, *fc = fo + (size_t)nbins * kPartGrid;
     const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
-    hipLaunchKernelGGL(k_part_bin<true>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, node, n, nbins, (u32*)nullptr, rec2,
-                       fo, fc, st);
-    hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), (size_t)kPartWin * sizeof(u64), s, assign, n_obj, rec2, fo, fc, aff_life);
+    hipLaunchKernelGGL(k_part_bin<true>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, node, n, nbins, wshift,
+                       (u32*)nullptr, rec2, fo, fc, st);
+    hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), ((size_t)1 << wshift) * sizeof(u64), s, assign, n_obj, rec2, fo, fc,
+                       aff_life, wshift);
 }
 void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u32* scratch, u64* used,
                         DevStats* st, hipStream_t s, u32* aff_life) {
-    const u32 nbins = (u32)((n_obj + kPartWin - 1) >> kPartShift);
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const size_t nrec = (size_t)(n + 4 * kPartGrid);
     u32 *rec = scratch, *fo = scratch + 2 * nrec, *fc = fo + (size_t)nbins * kPartGrid;
     const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
-    hipLaunchKernelGGL(k_part_bin<false>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, (const u32*)nullptr, n, nbins, rec,
-                       (uint2*)nullptr, fo, fc, st);
-    hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), (size_t)kPartWin * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0), s,
-                       assign, n_obj, m, load, rec, fo, fc, used, aff_life);
+    hipLaunchKernelGGL(k_part_bin<false>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, (const u32*)nullptr, n, nbins, wshift,
+                       rec, (uint2*)nullptr, fo, fc, st);
+    hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), ((size_t)1 << wshift) * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0),
+                       s, assign, n_obj, m, load, rec, fo, fc, used, aff_life, wshift);
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
                   u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life) {

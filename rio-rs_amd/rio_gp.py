@@ -123,6 +123,8 @@ def lib():
         L.rio_gp_place_pending_dev.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp]
         L.rio_gp_debug_set_scan_nt.argtypes = [C.c_int]
         L.rio_gp_debug_set_scan_nt.restype = None
+        L.rio_gp_debug_set_part_shift.argtypes = [C.c_int]
+        L.rio_gp_debug_set_part_shift.restype = None
         L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
         L.rio_gp_debug_cut_trace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
