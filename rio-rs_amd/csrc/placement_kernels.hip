@@ -1940,48 +1940,41 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
 // Big random CRUD batches, partitioned by row window (update_batch / remove_batch of >= 2^18 entries).
 //   A random entry of the plain kernels above touches three or four 128-byte lines of row-sized arrays (election word,
 //   re-read, assignment, scratch reset) for 8 useful bytes: counters show 5x (elect) and 21x (apply) the algorithmic
-//   bytes, 1.4 % of the HBM roofline on 10 M entries.  Here the batch is first BINNED by row window, one pass:
-//     k_part_bin    256 workgroups, each over one contiguous slice of the batch: LDS histogram of its entries over the
-//                   windows (W = 16 384 rows), exclusive scan, then the entries are written back reordered by window
-//                   INSIDE the slice's own region of a scratch array (no global allocation, no global atomics), as
-//                   4-byte records {row in window | node code} (+ the batch position for updates), together with the
-//                   (window, slice) fragment table;
-//     k_part_update one workgroup per window: every fragment of the window streams through an LDS table of W u64 words —
-//                   last-writer-wins is an ds_max_u64 on {position + 1 | node code} — and the window's rows are then
-//                   written DENSELY, coalesced, once;
+//   bytes, 1.4 % of the HBM roofline on 10 M entries.  Here the batch is first SORTED BY ROW WINDOW in chunks:
+//     k_part_bin    one workgroup per chunk of 8 192 consecutive entries (8 per lane, two dwordx4 per column): LDS
+//                   histogram over the windows (W = 16 384 rows) with the returned count as the entry's rank, exclusive
+//                   scan, the records {row in window | node code, batch position} go to their sorted place in an LDS
+//                   staging buffer and leave as ONE coalesced copy — a first version scattered them straight to global
+//                   memory, 611 write streams per workgroup: 88 us of partial-line writes for 10 M entries; the chunk's
+//                   window boundaries go to a u16 table [window][chunk];
+//     k_part_update one workgroup per window: the window's piece of every chunk (~13 records each on a 10 M batch) is
+//                   addressed through a prefix over the chunk table, one lane per record, and streams through an LDS
+//                   table of W u64 words — last-writer-wins is a ds_max_u64 on {position + 1 | node code}; the window's rows
+//                   are then written DENSELY, coalesced, once;
 //     k_part_remove the same with a flag per row; the released load goes through an LDS histogram per node.
-//   Traffic: the batch twice (the second read comes from L2 / Infinity Cache), the records twice, the window once.
+//   Batches of more than 2 048 chunks are applied slice by slice, in order.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 kPartGrid = 256;        // slices of the batch = workgroups of k_part_bin
+constexpr u32 kPartSub = 8192;        // entries per chunk = workgroup of k_part_bin (8 per lane)
+constexpr u32 kPartMaxChunks = 2048;  // chunks per slice of the batch (16.7 M entries): the apply kernels' LDS tables
 constexpr u32 kPartShiftMax = 14;     // rows per window <= 16 384: W u64 election words = 128 KiB of LDS
 constexpr u32 kPartMaxBins = 8192;    // 134 M rows at the largest window
 constexpr u32 kNodeNoneCode = 0x3FFFu;  // 14-bit code of RIO_GP_NONE (node ids are < 8 192)
 
-// records: updates {row in window | node code << 14, batch position} as ONE 8-byte word (one scattered store per entry,
-// not two), removals the 4-byte row-in-window alone
+// records: updates {row in window | node code << 14, position in the slice} (8 bytes), removals the row in window (4 bytes)
 template <bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32* __restrict__ idx,
                                                      const u32* __restrict__ node, u64 n, u32 nbins, const u32 wshift,
                                                      u32* __restrict__ rec, uint2* __restrict__ rec2,
-                                                     u32* __restrict__ frag_off, u32* __restrict__ frag_cnt,
-                                                     DevStats* st) {
+                                                     unsigned short* __restrict__ start16, DevStats* st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* part = reinterpret_cast<u64*>(smem);                 // [16] block-scan partials
-    u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins]
-    u32* cur = hist + nbins;                                  // [nbins] write cursor of a window inside this slice
+    u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins] entries of this chunk per window
+    u32* off = hist + nbins;                                  // [nbins + 1] where a window's records start in the sorted chunk
+    unsigned char* stage = smem + kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16;  // [kPartSub] records
     const int tid = threadIdx.x;
-    const u32 wmask = (1u << wshift) - 1u;
-    // slices are whole groups of 4 entries (dwordx4 reads); a lane takes 4 consecutive entries, 2 groups per trip:
-    // one 4-byte read per lane and trip left the loop latency-bound at ~1 TB/s
-    const u64 per = (((n + kPartGrid - 1) / kPartGrid) + 3) & ~(u64)3;
-    const u64 lo = (u64)blockIdx.x * per;
-    u64 hi = lo + per;
-    if (hi > n) hi = n;
-    if (lo > hi) hi = lo;
-    for (u32 b = tid; b < nbins; b += kBlock) hist[b] = 0;
-    __syncthreads();
-    u32 bad = 0;
-    auto valid = [&](u32 i, u32 nd) -> bool { return i < n_obj && (!UPDATE || nd == kNone || nd < m); };
+    const u32 wmask = (1u << wshift) - 1u, nchunks = gridDim.x, c = blockIdx.x;
+    const u64 lo = (u64)c * kPartSub;
+    const u64 hi = lo + kPartSub < n ? lo + kPartSub : n;
     auto load4 = [&](const u32* p, u64 k) -> uint4 {  // entries k..k+3 of a column, zero past hi (k is a multiple of 4)
         if (k + 4 <= hi) return *reinterpret_cast<const uint4*>(p + k);
         uint4 r = make_uint4(0, 0, 0, 0);
@@ -1990,15 +1983,23 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
         if (k + 2 < hi) r.z = p[k + 2];
         return r;
     };
-    for (u64 k0 = lo + (u64)tid * 4; k0 < hi; k0 += (u64)kBlock * 8) {
-        const u64 k1 = k0 + (u64)kBlock * 4;
-        const uint4 ia = load4(idx, k0), ib = k1 < hi ? load4(idx, k1) : make_uint4(0, 0, 0, 0);
-        uint4 na = make_uint4(0, 0, 0, 0), nb = na;
-        if (UPDATE) { na = load4(node, k0); if (k1 < hi) nb = load4(node, k1); }
-#define RIOGP_H(K, I, N) if ((K) < hi) { if (valid(I, N)) atomicAdd(&hist[(I) >> wshift], 1u); else ++bad; }
-        RIOGP_H(k0 + 0, ia.x, na.x) RIOGP_H(k0 + 1, ia.y, na.y) RIOGP_H(k0 + 2, ia.z, na.z) RIOGP_H(k0 + 3, ia.w, na.w)
-        RIOGP_H(k1 + 0, ib.x, nb.x) RIOGP_H(k1 + 1, ib.y, nb.y) RIOGP_H(k1 + 2, ib.z, nb.z) RIOGP_H(k1 + 3, ib.w, nb.w)
-#undef RIOGP_H
+    const u64 k0 = lo + (u64)tid * 4, k1 = k0 + (u64)kBlock * 4;
+    const uint4 ia = load4(idx, k0), ib = load4(idx, k1);
+    uint4 na = make_uint4(0, 0, 0, 0), nb = na;
+    if (UPDATE) { na = load4(node, k0); nb = load4(node, k1); }
+    for (u32 b = tid; b < nbins; b += kBlock) hist[b] = 0;
+    __syncthreads();
+    const u32 I[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+    const u32 N[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+    u32 rk[8];
+    u32 bad = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 k = (j < 4 ? k0 : k1) + (u64)(j & 3);
+        const bool in = k < hi;
+        const bool ok = in && I[j] < n_obj && (!UPDATE || N[j] == kNone || N[j] < m);
+        rk[j] = ok ? atomicAdd(&hist[I[j] >> wshift], 1u) : 0xFFFFFFFFu;  // the returned count = the entry's rank in its window
+        bad += in && !ok;
     }
     if (bad) atomicAdd(&st->err, (u64)bad);
     __syncthreads();
@@ -2012,74 +2013,85 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
             v[q] = (q < per_t && b < nbins) ? hist[b] : 0u;
             loc += v[q];
         }
-        u64 ex = block_excl_scan_1024(loc, false, part, nullptr);
+        u64 total = 0;
+        u64 ex = block_excl_scan_1024(loc, false, part, &total);
 #pragma unroll
         for (u32 q = 0; q < 8; ++q) {
             const u32 b = tid * per_t + q;
             if (q < per_t && b < nbins) {
-                cur[b] = (u32)ex;
-                frag_off[(size_t)b * kPartGrid + blockIdx.x] = (u32)(lo + ex);
-                frag_cnt[(size_t)b * kPartGrid + blockIdx.x] = v[q];
+                off[b] = (u32)ex;
+                start16[(size_t)b * nchunks + c] = (unsigned short)ex;
             }
             ex += v[q];
         }
+        if (tid == 0) {
+            off[nbins] = (u32)total;
+            start16[(size_t)nbins * nchunks + c] = (unsigned short)total;
+        }
     }
     __syncthreads();
-    for (u64 k0 = lo + (u64)tid * 4; k0 < hi; k0 += (u64)kBlock * 8) {
-        const u64 k1 = k0 + (u64)kBlock * 4;
-        const uint4 ia = load4(idx, k0), ib = k1 < hi ? load4(idx, k1) : make_uint4(0, 0, 0, 0);
-        uint4 na = make_uint4(0, 0, 0, 0), nb = na;
-        if (UPDATE) { na = load4(node, k0); if (k1 < hi) nb = load4(node, k1); }
-#define RIOGP_S(K, I, N)                                                                                   \
-        if ((K) < hi && valid(I, N)) {                                                                     \
-            const u32 pos = atomicAdd(&cur[(I) >> wshift], 1u); /* any order inside a fragment */        \
-            const u32 r = ((I) & wmask) | ((UPDATE ? ((N) == kNone ? kNodeNoneCode : (N)) : 0u) << kPartShiftMax); \
-            if (UPDATE) rec2[lo + pos] = make_uint2(r, (u32)(K));                                          \
-            else rec[lo + pos] = r;                                                                        \
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (rk[j] != 0xFFFFFFFFu) {
+            const u32 pos = off[I[j] >> wshift] + rk[j];
+            const u32 r = (I[j] & wmask) | ((UPDATE ? (N[j] == kNone ? kNodeNoneCode : N[j]) : 0u) << kPartShiftMax);
+            const u32 k = (u32)((j < 4 ? k0 : k1) + (u64)(j & 3));
+            if (UPDATE) reinterpret_cast<uint2*>(stage)[pos] = make_uint2(r, k);
+            else reinterpret_cast<u32*>(stage)[pos] = r;
         }
-        RIOGP_S(k0 + 0, ia.x, na.x) RIOGP_S(k0 + 1, ia.y, na.y) RIOGP_S(k0 + 2, ia.z, na.z) RIOGP_S(k0 + 3, ia.w, na.w)
-        RIOGP_S(k1 + 0, ib.x, nb.x) RIOGP_S(k1 + 1, ib.y, nb.y) RIOGP_S(k1 + 2, ib.z, nb.z) RIOGP_S(k1 + 3, ib.w, nb.w)
-#undef RIOGP_S
+    __syncthreads();
+    const u32 total = off[nbins];
+    for (u32 t = tid; t < total; t += kBlock) {  // the sorted chunk leaves in one coalesced copy
+        if (UPDATE) rec2[lo + t] = reinterpret_cast<const uint2*>(stage)[t];
+        else rec[lo + t] = reinterpret_cast<const u32*>(stage)[t];
     }
 }
 
-// one workgroup per window; wave w streams the fragments w, w + 16, ... of its window: the first 64 records of all its
-// 16 fragments are requested before the first is used (a fragment is ~64 records on a 10 M batch: one request each)
-constexpr u32 kPartFragsPerWave = kPartGrid / kWaves;
+// The apply kernels walk the window's piece of every chunk (~13 records on a 10 M batch): a QUARTER wave (16 lanes) per
+// piece, so a wave instruction covers four pieces; quarter-wave g of wave w takes the chunks 64 i + 4 w + g.  Every
+// descriptor (two u16 reads) is requested before the first record, records go out four pieces per lane at a time.
+constexpr int kPartIters = kPartMaxChunks / 64;  // 32 pieces per quarter wave at most
+
+#define RIOGP_PART_DESCRIPTORS()                                                                          \
+    u32 pbase[kPartIters], pcnt[kPartIters];                                                              \
+    _Pragma("unroll") for (int i = 0; i < kPartIters; ++i) {                                              \
+        const u32 f = (u32)i * 64u + (u32)wave * 4u + (u32)(lane >> 4);                                   \
+        const bool in = f < nchunks;                                                                      \
+        const u32 s0 = in ? start16[(size_t)b * nchunks + f] : 0u;                                        \
+        const u32 s1 = in ? start16[(size_t)(b + 1) * nchunks + f] : 0u;                                  \
+        pbase[i] = f * kPartSub + s0;                                                                     \
+        pcnt[i] = s1 - s0;                                                                                \
+    }
 
 __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign, u64 n_obj, const uint2* __restrict__ rec2,
-                                                        const u32* __restrict__ frag_off, const u32* __restrict__ frag_cnt,
+                                                        const unsigned short* __restrict__ start16, u32 nchunks,
                                                         u32* __restrict__ aff_life, const u32 wshift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* win = reinterpret_cast<u64*>(smem);  // [W] {batch position + 1 | node code} of the last writer, 0 = untouched
+    const u32 W = 1u << wshift;
+    u64* win = reinterpret_cast<u64*>(smem);  // [W] {position + 1 | node code} of the last writer, 0 = untouched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 kPartWin = 1u << wshift;
-    const u32 b = blockIdx.x;
-    u32 fo[kPartFragsPerWave], fc[kPartFragsPerWave];
-#pragma unroll
-    for (u32 q = 0; q < kPartFragsPerWave; ++q) {
-        const u32 f = wave + q * kWaves;
-        fo[q] = frag_off[(size_t)b * kPartGrid + f];
-        fc[q] = frag_cnt[(size_t)b * kPartGrid + f];
-    }
-    uint2 first[kPartFragsPerWave];
-#pragma unroll
-    for (u32 q = 0; q < kPartFragsPerWave; ++q) first[q] = (u32)lane < fc[q] ? rec2[fo[q] + lane] : make_uint2(0, 0);
-    for (u32 r = tid; r < kPartWin; r += kBlock) win[r] = 0;
+    const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
+    RIOGP_PART_DESCRIPTORS()
+    for (u32 r = tid; r < W; r += kBlock) win[r] = 0;
     __syncthreads();
 #pragma unroll
-    for (u32 q = 0; q < kPartFragsPerWave; ++q)
-        if ((u32)lane < fc[q])
-            atomicMax(&win[first[q].x & (kPartWin - 1)], ((u64)(first[q].y + 1u) << 16) | (u64)(first[q].x >> kPartShiftMax));
+    for (int i = 0; i < kPartIters; i += 4) {
+        uint2 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = o16 < pcnt[i + q] ? rec2[pbase[i + q] + o16] : make_uint2(0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (o16 < pcnt[i + q]) atomicMax(&win[x[q].x & (W - 1)], ((u64)(x[q].y + 1u) << 16) | (u64)(x[q].x >> kPartShiftMax));
+    }
 #pragma unroll 1
-    for (u32 q = 0; q < kPartFragsPerWave; ++q)
-        for (u32 e = 64 + lane; e < fc[q]; e += 64) {
-            const uint2 x = rec2[fo[q] + e];
-            atomicMax(&win[x.x & (kPartWin - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShiftMax));
+    for (int i = 0; i < kPartIters; ++i)  // pieces of more than 16 records
+        for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) {
+            const uint2 x = rec2[pbase[i] + o];
+            atomicMax(&win[x.x & (W - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShiftMax));
         }
     __syncthreads();
     const u64 base = (u64)b << wshift;
-    for (u32 r = tid; r < kPartWin; r += kBlock) {
+    for (u32 r = tid; r < W; r += kBlock) {
         const u64 v = win[r];
         if (v && base + r < n_obj) {
             const u32 code = (u32)v & 0xFFFFu;
@@ -2092,37 +2104,34 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
 
 __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                         const u32* __restrict__ load, const u32* __restrict__ rec,
-                                                        const u32* __restrict__ frag_off, const u32* __restrict__ frag_cnt,
+                                                        const unsigned short* __restrict__ start16, u32 nchunks,
                                                         u64* __restrict__ used, u32* __restrict__ aff_life, const u32 wshift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 kPartWin = 1u << wshift;
-    u32* flag = reinterpret_cast<u32*>(smem);                       // [W] row of this window is in the batch
-    u64* rel = reinterpret_cast<u64*>(smem + (size_t)kPartWin * 4);  // [m] load released per node (when `used` is maintained)
+    const u32 W = 1u << wshift;
+    u32* flag = reinterpret_cast<u32*>(smem);               // [W] row of this window is in the batch
+    u64* rel = reinterpret_cast<u64*>(flag + W);            // [m] load released per node (when `used` is maintained)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 b = blockIdx.x;
-    u32 fo[kPartFragsPerWave], fc[kPartFragsPerWave];
-#pragma unroll
-    for (u32 q = 0; q < kPartFragsPerWave; ++q) {
-        const u32 f = wave + q * kWaves;
-        fo[q] = frag_off[(size_t)b * kPartGrid + f];
-        fc[q] = frag_cnt[(size_t)b * kPartGrid + f];
-    }
-    u32 first[kPartFragsPerWave];
-#pragma unroll
-    for (u32 q = 0; q < kPartFragsPerWave; ++q) first[q] = (u32)lane < fc[q] ? rec[fo[q] + lane] : 0u;
-    for (u32 r = tid; r < kPartWin; r += kBlock) flag[r] = 0;
+    const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
+    RIOGP_PART_DESCRIPTORS()
+    for (u32 r = tid; r < W; r += kBlock) flag[r] = 0;
     if (used)
         for (u32 j = tid; j < m; j += kBlock) rel[j] = 0;
     __syncthreads();
 #pragma unroll
-    for (u32 q = 0; q < kPartFragsPerWave; ++q)
-        if ((u32)lane < fc[q]) flag[first[q] & (kPartWin - 1)] = 1u;  // duplicates: the same store
+    for (int i = 0; i < kPartIters; i += 4) {
+        u32 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = o16 < pcnt[i + q] ? rec[pbase[i + q] + o16] : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (o16 < pcnt[i + q]) flag[x[q] & (W - 1)] = 1u;  // duplicates: the same store
+    }
 #pragma unroll 1
-    for (u32 q = 0; q < kPartFragsPerWave; ++q)
-        for (u32 e = 64 + lane; e < fc[q]; e += 64) flag[rec[fo[q] + e] & (kPartWin - 1)] = 1u;
+    for (int i = 0; i < kPartIters; ++i)
+        for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) flag[rec[pbase[i] + o] & (W - 1)] = 1u;
     __syncthreads();
     const u64 base = (u64)b << wshift;
-    for (u32 r = tid; r < kPartWin; r += kBlock) {
+    for (u32 r = tid; r < W; r += kBlock) {
         if (flag[r] && base + r < n_obj) {
             const u32 old = assign[base + r];
             if (old != kNone) {
@@ -2138,6 +2147,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
             if (rel[j]) atomicAdd(&used[j], (u64)0 - rel[j]);
     }
 }
+#undef RIOGP_PART_DESCRIPTORS
 
 // clean_server(s) (local.rs:51-58): one coalesced pass, 4 B read per row, 4 B written per evicted row
 // counter: device accumulator of evicted rows.  ticket/host_out (optional): the last workgroup to finish copies the
@@ -2954,31 +2964,45 @@ bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node) {
     return n >= ((u64)1 << 18) && n <= 0x7FFFFFFFull && n * 8 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
            (((uintptr_t)idx | (uintptr_t)node) & 15u) == 0;
 }
+// one slice of the batch at a time: records (8 B each) + the u16 chunk table [nbins + 1][chunks]
 size_t part_scratch_words(u64 n_obj, u64 n) {
-    return (size_t)(2 * (n + 4 * kPartGrid) + 2 * part_bins(n_obj) * kPartGrid + 64);  // slices are rounded up to groups of 4 entries
+    const u64 slice = n < (u64)kPartMaxChunks * kPartSub ? n : (u64)kPartMaxChunks * kPartSub;
+    const u64 chunks = (slice + kPartSub - 1) / kPartSub;
+    return (size_t)(2 * chunks * kPartSub + ((part_bins(n_obj) + 1) * chunks + 1) / 2 + 64);
+}
+static size_t part_bin_lds(u32 nbins, size_t rec_bytes) {
+    return kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16 + (size_t)kPartSub * rec_bytes;
 }
 void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
                         hipStream_t s, u32* aff_life) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
-    const size_t nrec = (size_t)(n + 4 * kPartGrid);
-    uint2* rec2 = reinterpret_cast<uint2*>(scratch);
-    u32 *fo = scratch + 2 * nrec, *fc = fo + (size_t)nbins * kPartGrid;
-    const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
-    hipLaunchKernelGGL(k_part_bin<true>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, node, n, nbins, wshift,
-                       (u32*)nullptr, rec2, fo, fc, st);
-    hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), ((size_t)1 << wshift) * sizeof(u64), s, assign, n_obj, rec2, fo, fc,
-                       aff_life, wshift);
+    const u64 slice_max = (u64)kPartMaxChunks * kPartSub;
+    for (u64 at = 0; at < n; at += slice_max) {  // slices in batch order: a later slice overwrites an earlier one's rows
+        const u64 ns = n - at < slice_max ? n - at : slice_max;
+        const u32 chunks = (u32)((ns + kPartSub - 1) / kPartSub);
+        uint2* rec2 = reinterpret_cast<uint2*>(scratch);
+        unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
+        hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx + at,
+                           node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st);
+        const size_t lds = ((size_t)1 << wshift) * sizeof(u64);
+        hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, wshift);
+    }
 }
 void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u32* scratch, u64* used,
                         DevStats* st, hipStream_t s, u32* aff_life) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
-    const size_t nrec = (size_t)(n + 4 * kPartGrid);
-    u32 *rec = scratch, *fo = scratch + 2 * nrec, *fc = fo + (size_t)nbins * kPartGrid;
-    const size_t lds_bin = kSmall + (size_t)2 * nbins * sizeof(u32);
-    hipLaunchKernelGGL(k_part_bin<false>, dim3(kPartGrid), dim3(kBlock), lds_bin, s, n_obj, m, idx, (const u32*)nullptr, n, nbins, wshift,
-                       rec, (uint2*)nullptr, fo, fc, st);
-    hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), ((size_t)1 << wshift) * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0),
-                       s, assign, n_obj, m, load, rec, fo, fc, used, aff_life, wshift);
+    const u64 slice_max = (u64)kPartMaxChunks * kPartSub;
+    for (u64 at = 0; at < n; at += slice_max) {
+        const u64 ns = n - at < slice_max ? n - at : slice_max;
+        const u32 chunks = (u32)((ns + kPartSub - 1) / kPartSub);
+        u32* rec = scratch;
+        unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
+        hipLaunchKernelGGL(k_part_bin<false>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(u32)), s, n_obj, m, idx + at,
+                           (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st);
+        const size_t lds = ((size_t)1 << wshift) * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0) + 16;
+        hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, m, load, rec, start16, chunks, used, aff_life,
+                           wshift);
+    }
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
                   u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life) {

@@ -225,7 +225,7 @@ def test_crud_big_batches_partitioned_by_row_window(gp, oracle, seed, n, m, k):
 def test_crud_big_batch_dev_skips_invalid_entries(gp, oracle):
     """Device-resident batch with out-of-range entries: they are skipped and reported (RIO_GP_EINVAL), the valid ones applied —
     the partitioned kernels keep the contract of the plain ones."""
-    import torch
+    from hipbuf import DevBuf   # device arrays through hipMalloc / hipMemcpy (tools/hipbuf.py): no torch in the loop
     n, m, k = 1_000_000, 40, 400_000
     rng = np.random.default_rng(9)
     idx = rng.integers(0, n, k).astype(np.uint32)
@@ -235,21 +235,21 @@ def test_crud_big_batch_dev_skips_invalid_entries(gp, oracle):
     g = gp.GpuPlacement(n, m)
     g.set_nodes(m=m, alive=np.ones(m, np.uint8))
     g.set_objects(n)
-    d_idx = torch.from_numpy(idx.astype(np.int64)).to(torch.int32).cuda()
-    d_node = torch.from_numpy(node.astype(np.int64)).to(torch.int32).cuda()
-    torch.cuda.synchronize()
+    d_idx, d_node = DevBuf(idx), DevBuf(node)
     import ctypes as C
-    rc = gp.lib().rio_gp_update_batch_dev(g.handle, k, C.c_void_p(d_idx.data_ptr()), C.c_void_p(d_node.data_ptr()))
+    rc = gp.lib().rio_gp_update_batch_dev(g.handle, k, C.c_void_p(d_idx.ptr), C.c_void_p(d_node.ptr))
     assert rc == gp.EINVAL
     ok = (idx < n) & (node < m)
     ref = np.full(n, NONE, np.uint32)
     assert oracle.update_batch(ref, m, idx[ok], node[ok]) == 0
     assert np.array_equal(g.get_assign(), ref)
-    rc = gp.lib().rio_gp_remove_batch_dev(g.handle, k, C.c_void_p(d_idx.data_ptr()))
+    rc = gp.lib().rio_gp_remove_batch_dev(g.handle, k, C.c_void_p(d_idx.ptr))
     assert rc == gp.EINVAL
     oracle.remove_batch(ref, idx[idx < n])
     assert np.array_equal(g.get_assign(), ref)
     g.close()
+    d_idx.free()
+    d_node.free()
 
 
 def test_invalid_arguments_are_unknown_errors(gp):
@@ -567,7 +567,7 @@ def test_place_pending_micro_batches(gp, oracle, seed, cap_mode):
 def test_place_pending_dev_equals_host_call(gp, oracle):
     """rio_gp_place_pending_dev: request / result arrays resident in HBM (torch tensors), same answers as the oracle;
     a bad entry fails the call before anything changes."""
-    import torch
+    from hipbuf import DevBuf   # device arrays through hipMalloc / hipMemcpy (tools/hipbuf.py): no torch in the loop
     rng = np.random.default_rng(77)
     n, m = 400_000, 300
     load = rng.integers(0, 40, n).astype(np.uint32)
@@ -583,23 +583,20 @@ def test_place_pending_dev_equals_host_call(gp, oracle):
         k = int(rng.integers(1000, 300_000))
         idx = rng.integers(0, n, k).astype(np.uint32)
         req = rng.integers(0, m, k).astype(np.uint32)
-        d_idx = torch.from_numpy(idx.astype(np.int64)).to(torch.int32).cuda()
-        d_req = torch.from_numpy(req.astype(np.int64)).to(torch.int32).cuda()
-        d_node = torch.empty(k, dtype=torch.int32, device="cuda")
-        d_flag = torch.empty(k, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-        g.place_pending_dev(k, d_idx.data_ptr(), d_req.data_ptr(), d_node.data_ptr(), d_flag.data_ptr())
+        d_idx, d_req = DevBuf(idx), DevBuf(req)
+        d_node, d_flag = DevBuf(nbytes=4 * k), DevBuf(nbytes=4 * k)
+        g.place_pending_dev(k, d_idx.ptr, d_req.ptr, d_node.ptr, d_flag.ptr)
         wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
-        assert np.array_equal(d_node.cpu().numpy().view(np.uint32), wnode), step
-        assert np.array_equal(d_flag.cpu().numpy().view(np.uint32), wflag), step
+        assert np.array_equal(d_node.to_host(), wnode), step
+        assert np.array_equal(d_flag.to_host(), wflag), step
         assert np.array_equal(g.get_assign(), ref)
         assert np.array_equal(g.get_nodes()[2], used)
-    bad = torch.tensor([1, 2, n, 3], dtype=torch.int64).to(torch.int32).cuda()      # index n is out of range
-    rq = torch.zeros(4, dtype=torch.int32, device="cuda")
-    out = torch.empty(4, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+        for x in (d_idx, d_req, d_node, d_flag):
+            x.free()
+    bad = DevBuf(np.array([1, 2, n, 3], np.uint32))      # index n is out of range
+    rq, out = DevBuf(np.zeros(4, np.uint32)), DevBuf(nbytes=16)
     with pytest.raises(gp.ObjectPlacementError) as e:
-        g.place_pending_dev(4, bad.data_ptr(), rq.data_ptr(), out.data_ptr())
+        g.place_pending_dev(4, bad.ptr, rq.ptr, out.ptr)
     assert e.value.rc == gp.EINVAL
     assert np.array_equal(g.get_assign(), ref)                                       # nothing was changed
     g.close()

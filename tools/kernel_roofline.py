@@ -54,9 +54,13 @@ def specs(pending_rows):
         ("contended", r"k_spill_apply", "k_spill_apply (whole table, contended)", 8 * N, "next + load per row"),
         ("crud", r"k_lookup4", "k_lookup4 (10 M random indices)", 12 * N, "idx + gather + out per lookup"),
         ("lookup_seq", r"k_lookup4", "k_lookup4 (10 M sequential indices)", 12 * N, "idx + gather + out per lookup"),
-        ("crud", r"k_update_elect", "k_update_elect (10 M random)", 8 * N, "idx + node per entry (update = elect + apply: 8 B/op over both)"),
-        ("crud", r"k_update_apply", "k_update_apply (10 M random)", 8 * N, "see k_update_elect"),
-        ("crud", r"k_remove", "k_remove (10 M random)", 8 * N, "idx + row per removal"),
+        ("crud", r"k_part_bin<true>", "k_part_bin<update> (10 M random)", 8 * N, "idx + node per entry (update = bin + apply: 8 B/op over both)"),
+        ("crud", r"k_part_update", "k_part_update (10 M random)", 8 * N, "see k_part_bin"),
+        ("crud", r"k_part_bin<false>", "k_part_bin<remove> (10 M random)", 8 * N, "idx + row per removal (remove = bin + apply)"),
+        ("crud", r"k_part_remove", "k_part_remove (10 M random)", 8 * N, "see k_part_bin"),
+        ("crud_plain", r"k_update_elect", "k_update_elect (plain kernels, 10 M random)", 8 * N, "idx + node per entry (update = elect + apply)"),
+        ("crud_plain", r"k_update_apply", "k_update_apply (plain kernels, 10 M random)", 8 * N, "see k_update_elect"),
+        ("crud_plain", r"k_remove", "k_remove (plain kernel, 10 M random)", 8 * N, "idx + row per removal"),
         ("crud", r"k_clean", "k_clean (10 % of the nodes)", 4 * N, "4 B/row read (+4 B per evicted row)"),
         ("pp", r"k_pp_mark_dead", "k_pp_mark_dead (1 M requests)", 12 * 1_000_000, "idx + req + row per request"),
         ("pp", r"k_pp_elect", "k_pp_elect", 8 * 1_000_000, "idx + scratch slot"),

@@ -2,7 +2,7 @@
 """One PHASE of the hot path per process, for the rocprofv3 passes of tools/kernel_roofline.sh (kernel trace + the two PMC
 passes): every kernel DESIGN.md section 4 names runs in exactly one phase with known algorithmic bytes, so that its
 duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round2_kernel_roofline.json).
-Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|crud|lookup_seq|pp|probes> [reps]"""
+Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|crud|crud_plain|lookup_seq|pp|probes> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -37,7 +37,7 @@ elif phase == "contended":               # the same fix-up kernels over ALL rows
     g.set_nodes((cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64), cfg["alive"])
     for _ in range(reps):
         g.solve()
-elif phase in ("crud", "pp", "lookup_seq"):
+elif phase in ("crud", "crud_plain", "pp", "lookup_seq"):
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from hipbuf import DevBuf
@@ -46,7 +46,9 @@ elif phase in ("crud", "pp", "lookup_seq"):
     node = DevBuf(synth.warm_assign(n, m, stream=8))
     outb, flg = DevBuf(nbytes=4 * n), DevBuf(nbytes=4 * n)
     seq = DevBuf(np.arange(n, dtype=np.uint32))
-    if phase == "crud":                  # k_lookup4 (random, then sequential), k_update_*, k_remove, k_clean
+    if phase in ("crud", "crud_plain"):  # k_lookup4 (random), update / remove (window-partitioned, or the plain per-entry kernels), k_clean
+        if phase == "crud_plain":
+            g.set_compact("auto", partitioned_crud=False)
         g.set_assign(synth.warm_assign(n, m))
         for _ in range(3):
             L.rio_gp_lookup_batch_dev(h, n, vp(idx.ptr), vp(outb.ptr))

@@ -22,6 +22,7 @@ if [ -z "$QUICK" ]; then
   bash tools/kernel_roofline.sh ${TAG} > $OUT/${TAG}_kroof.log 2>&1
   timeout 600 python tools/measure_ops.py ${TAG} > $OUT/${TAG}_ops.log 2>&1
   timeout 300 python tools/fixup_trace.py 6 > $OUT/${TAG}_fixup_trace.json 2> $OUT/${TAG}_fixup_trace.err
+  timeout 300 python tools/crud_ab.py 5 > $OUT/${TAG}_crud_ab.log 2>&1
   for w in churn contended skew; do
     timeout 300 python tools/slowpath_workload.py $w 40 > $OUT/${TAG}_slowpath_$w.json 2> $OUT/${TAG}_slowpath_$w.err
   done
