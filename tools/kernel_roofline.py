@@ -39,9 +39,9 @@ def short(name):
 def specs(pending_rows):
     pk = pending_rows   # packed rows of a churn tick
     return [
-        ("fast", r"k_scan<false, true, 2, false", "k_scan (fast path, TPI 2)", 16 * N, "12 B read + 4 B written per row"),
+        ("fast", r"k_scan<false, true, 2, 0", "k_scan (fast path, TPI 2)", 16 * N, "12 B read + 4 B written per row"),
         ("fast", r"k_resolve", "k_resolve", 2 * M * 8 * 256, "H: 2m u64 per block x 256 blocks"),
-        ("churn", r"k_scan<false, false, 1, true", "k_scan<COMPACT> (churn tick)", 16 * N + 16 * pk, "16 B/row + 16 B per packed pending row"),
+        ("churn", r"k_scan<false, false, 1, 2", "k_scan<COMPACT> (churn tick)", 16 * N + 16 * pk, "16 B/row + 16 B per packed pending row"),
         ("churn", r"k_cut_find<true>", "k_cut_find (packed rows)", 12 * pk, "one pass over the packed pending rows of the blocks that own cuts (upper bound: all)"),
         ("churn", r"k_cut_apply_rank<true>", "k_cut_apply_rank (packed rows)", 12 * pk, "12 B per packed pending row (+4 B per rejected)"),
         ("churn", r"k_spill_rank", "k_spill_rank (round 1)", M * 24, "cap/used/alive of every node per workgroup"),
