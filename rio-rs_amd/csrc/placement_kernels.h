@@ -29,12 +29,18 @@ constexpr int kSmallBatch = 256;     // place_pending / lookup micro-batches ser
 struct Plan {
     u64 n;       // rows
     u64 tiles;   // ceil(n / kTile)
+    u64 tq;      // tiles / nw   } the balanced split without a division on the device
+    u64 div_magic;  // ceil(2^38 / nw)
+    u32 tr;      // tiles % nw
     u32 nw;      // wave ranges = G * kWaves
     u32 G;       // blocks (<= kMaxBlocks)
     u32 sub;     // rows per sub-chunk (multiple of kTile)
     u32 subs;    // sub-chunks per block (<= kMaxSubs)
     u32 m;       // nodes
     u32 mwords;  // ceil(m/32)
+    u32 trace;   // phase tracing of the fix-up kernels (measurement aid; set by the launchers, 0 = off)
+    u64 mark;    // what k_resolve stores in column 7 of its partial rows ("row present"): 1, or the sequence number the
+                 // host spins on instead of waiting for the stream
     // packed fix-up (see PackOut): when set, wave gw's rows are only the first wcnt[gw] positions of its range
     const u32* wcnt;
 };
@@ -61,6 +67,8 @@ struct DevStats {
 struct FxRows {
     u64* dev = nullptr;   // [kMaxBlocks][8]
     u64* host = nullptr;  // [kMaxBlocks][8], device address of pinned host memory
+    u64 seq = 0;          // != 0: the LAST water-fill round stores it in word 7 of every row (also when the round is a
+                          // no-op): the host spins on the pinned rows instead of waiting for the stream
 };
 
 // Scratch of one solve over one table (real table or the virtual table of place_pending).
@@ -137,6 +145,7 @@ void set_scan_nt(int mode);  // 0 by table size | 1 always | 2 never: non-tempor
 int cut_trace_enable(int on);  // k_cut_fused phase trace (measurement aid)
 int cut_trace_read(u64* out /*[kMaxBlocks*8]*/);
 int ktrace_read(int table, u64* out /*[kMaxBlocks*8]*/);  // 0/1 k_spill_apply first/last round, 2 k_cut_apply_rank, 3 k_cut_find
+float sync_probe(int mode, int reps, hipStream_t s);  // host round-trip probes (stream_probe.hip)
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1);
 // impl: 2 = k_cut_find + k_cut_apply_rank | 1 = k_cut_fused | 0 = the unfused chain.  have_cutblk: launch_resolve of the
@@ -149,15 +158,19 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
                         hipStream_t s, bool rank_done = false);
 
 // --- CRUD over the assignment column ---
-void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s);
+// done / seq (lookup, update_small, remove, pp_small): when the call is ONE workgroup, its last act is to store seq into
+// *done (mapped pinned memory) — the host spins on the word instead of waiting for the stream; nullptr = no word
+void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s,
+                   u32* done = nullptr, u32 seq = 0);
 // aff_life (every CRUD launcher below): the affinity column when the handle tracks the row lifecycle (rows that are
 // written become objects, rows that are removed / deleted / dropped by clean_server stop being objects), else nullptr
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos_scratch,
                    DevStats* st, hipStream_t s, u32* aff_life = nullptr);
 // n <= kSmallBatch validated entries (may be mapped host memory): last writer wins inside the batch, one launch
-void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr);
+void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr,
+                         u32* done = nullptr, u32 seq = 0);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
-                   DevStats* st, hipStream_t s, u32* aff_life = nullptr);
+                   DevStats* st, hipStream_t s, u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0);
 // big random batches, partitioned by row window first (k_part_bin ...): part_applicable says whether a batch qualifies,
 // scratch = part_scratch_words(n_obj, n) u32 words of device memory
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node_or_null);
@@ -184,7 +197,7 @@ void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t 
 //     means "needs the general path", nothing was changed ---
 void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
                      const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                     u32* aff_life = nullptr);
+                     u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s);

@@ -97,7 +97,13 @@ __device__ __forceinline__ u32 wave_sum32(u32 v) {
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 // Balanced, index-ordered split of the table: wave gw owns tiles [gw*tiles/nw, (gw+1)*tiles/nw).
-__host__ __device__ __forceinline__ u64 wave_row_lo(const Plan& p, u64 gw) { return (gw * p.tiles / p.nw) * kTile; }
+// Division-free: tiles = tq * nw + tr, so gw * tiles / nw = gw * tq + floor(gw * tr / nw); gw <= nw <= 4 096 keeps gw * tr
+// below 2^24, where the multiply-shift by div_magic = ceil(2^38 / nw) is exact (error < 2^-14 < 1 / nw).  A 64-bit
+// division is ~100 instructions, twice per wave in every kernel's prologue (measured: ~1 us of a 10 us fix-up kernel).
+__host__ __device__ __forceinline__ u64 wave_row_lo(const Plan& p, u64 gw) {
+    const u64 x = gw * p.tr;
+    return (gw * p.tq + ((x * p.div_magic) >> 38)) * kTile;
+}
 __device__ __forceinline__ void wave_range(const Plan& p, u64 gw, u64& wstart, u64& wend) {
     wstart = wave_row_lo(p, gw);
     wend = wave_row_lo(p, gw + 1);
@@ -112,7 +118,7 @@ __device__ __forceinline__ void wave_range(const Plan& p, u64 gw, u64& wstart, u
 __device__ __forceinline__ bool packed_live(const Plan& p, u64 i) {
     if (!p.wcnt) return true;
     const u64 tile = i / kTile;
-    const u64 gw = ((tile + 1) * p.nw - 1) / p.tiles;
+    u64 gw = ((tile + 1) * p.nw - 1) / p.tiles;  // (off the hot paths: the unfused cut search only)
     return i - wave_row_lo(p, gw) < p.wcnt[gw];
 }
 __device__ __forceinline__ u64 block_row_lo(const Plan& p, u32 b) { return wave_row_lo(p, (u64)b * kWaves); }
@@ -125,6 +131,8 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     p.m = m;
     p.mwords = (m + 31) / 32;
     p.wcnt = nullptr;
+    p.trace = 0;
+    p.mark = 1;
     if (max_blocks == 0 || max_blocks > kMaxBlocks) max_blocks = kMaxBlocks;
     u64 tiles = (n + kTile - 1) / kTile;
     if (tiles == 0) tiles = 1;
@@ -133,6 +141,9 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     p.tiles = tiles;
     p.G = (u32)g;
     p.nw = p.G * kWaves;
+    p.tq = tiles / p.nw;
+    p.tr = (u32)(tiles % p.nw);
+    p.div_magic = ((1ull << 38) + p.nw - 1) / p.nw;
     // rows of the largest block: ceil(tiles*16/nw) tiles (+1 for the floor/ceil jitter of the split)
     const u64 max_block_tiles = (tiles * kWaves + p.nw - 1) / p.nw + 1;
     const u64 sub_tiles = (max_block_tiles + kMaxSubs - 1) / kMaxSubs;
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     u64* hist = reinterpret_cast<u64*>(smem + kSmall);       // [2m + 2] kept-by-cur | claim-by-aff | trash
     u32* alv = reinterpret_cast<u32*>(hist + 2 * m + 2);     // [mwords]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     }
     __syncthreads();
     if (tid < 8) {
-        const u64 x = (tid < 7) ? red[tid] : 1ull;  // column 7 = "row present" marker
+        const u64 x = (tid < 7) ? red[tid] : p.mark;  // column 7 = "row present" marker (1, or the host's sequence number)
         partial[(size_t)g * 8 + tid] = x;
         if (host_partial) host_partial[(size_t)g * 8 + tid] = x;
     }
@@ -871,14 +882,17 @@ __global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cu
 // ------------------------------------------------------------------------------------------------
 // Phase trace of k_cut_fused (measurement aid, off by default): workgroup b stores wall_clock64() (100 MHz) at its phase
 // boundaries into g_cut_trace[b][0..7] = start, P0 end, passes (all levels), row searches, P3 time, nloc, S, walks (all levels).
-__device__ int g_cut_trace_on = 0;
+// the switch travels in the Plan (a kernel argument): a flag in device memory would cost the first wave of every workgroup
+// a load round trip at every trace point even when tracing is off
+static int g_trace_host = 0;
+#define KT_ON (p.trace != 0)
 __device__ u64 g_cut_trace[kMaxBlocks * 8];
-#define RIOGP_TRACE(slot, val) do { if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + (slot)] = (val); } while (0)
+#define RIOGP_TRACE(slot, val) do { if (tid == 0 && KT_ON) g_cut_trace[(size_t)blockIdx.x * 8 + (slot)] = (val); } while (0)
 // the same for the other fix-up kernels: table 0 = k_spill_apply (first round), 1 = k_spill_apply (last round),
 // 2 = k_cut_apply_rank, 3 = k_cut_find (item table / first item / end); workgroup b, phase boundary `slot`
 constexpr int kKtTables = 4;
 __device__ u64 g_kt[kKtTables][kMaxBlocks * 8];
-#define RIOGP_KT(table, slot) do { if (threadIdx.x == 0 && g_cut_trace_on && blockIdx.x < kMaxBlocks) g_kt[table][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#define RIOGP_KT(table, slot) do { if (threadIdx.x == 0 && KT_ON && blockIdx.x < kMaxBlocks) g_kt[table][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
 
 constexpr u32 kSlotNone = 0xFFFFu;
 constexpr int kCutMinSubs = 16;  // smallest fan-out of a refinement level
@@ -889,11 +903,15 @@ __host__ __device__ __forceinline__ size_t cut_fused_fixed(u32 m, u32 mwords) {
     return kSmall + (size_t)mr * 8 + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 2 * kWaves * sizeof(u64);
 }
 
+// The block search is at the register limit (128 VGPRs at 1 024 threads): its phase timers are compiled in only in the
+// TRACE instantiation, which the launchers pick while tracing is switched on.
+#undef KT_ON
+#define KT_ON (TRACE && p.trace != 0)
 // The search half of the cut fix-up for ONE block b of rows: which nodes have their cut in b (all of them, or the slice
 // j % sel_mod == sel_rem of them when the block's cuts are spread over several workgroups), and for each the exact row —
 // P0..P2 of the description above.  Every thread of the workgroup calls it; on return thr[] (LDS) holds the reject
 // threshold of every node as seen from block b, and cutidx[] / used_cur[] (global) are final for the nodes searched.
-template <bool VIRT>
+template <bool VIRT, bool TRACE>
 __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 b, const u32 sel_mod, const u32 sel_rem,
                                                  const bool write_forced, const u32* __restrict__ cur,
                                                  const u32* __restrict__ load, const u32* __restrict__ aff,
@@ -913,26 +931,33 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
     u64* whi = rlo + kWaves;                                                 // [16] end of its LIVE rows (n / packed count)
     u64* T = whi + kWaves;                                                   // [tcap]: T[K][S] from the front,
                                                                              //         budget of slot s at T[tcap-1-s]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
     RIOGP_TRACE(0, wall_clock64());
     if (tid == 0) { nlocal = 0; red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0; }
-    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    // one round trip for the liveness words, the packed row count of this wave and the thread's first cutblk[] word
     const u64 gw = (u64)b * kWaves + wave;
+    const u32 cb0 = cutblk[(u32)tid < m ? (u32)tid : m - 1];
+    const u32 ak = (u32)tid < p.mwords ? (u32)tid : p.mwords - 1;  // mwords <= 256 < kBlock
+    const u32 aw = alive_bits[ak];
+    const u32 wc = *(p.wcnt ? p.wcnt + gw : cutblk);
     const u64 bstart = block_row_lo(p, b);
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
+    u64 wstart = wave_row_lo(p, gw), wend = wave_row_lo(p, gw + 1);
+    if (wend > p.n) wend = p.n;
+    if (wstart > wend) wstart = wend;
+    if (p.wcnt && wstart + wc < wend) wend = wstart + wc;
+    alv[ak] = aw;  // threads past mwords rewrite the last word with its own value
     if (lane == 0) { rlo[wave] = wave_row_lo(p, gw); whi[wave] = wend; }
     __syncthreads();
     for (u32 j = tid; j < m; j += kBlock) {
-        const u32 cbv = cutblk[j];
+        const u32 cbq = j == (u32)tid ? cb0 : cutblk[j];  // (m > 1 024: the later words are fetched here)
         u32 t = kNoCut;
         u32 s = kSlotNone;
         if (forced_bits && bit_of(forced_bits, j)) {  // row-sharded solve: the prefix overflowed on a lower rank
             t = 0;
             if (write_forced && b == 0) { cutidx[j] = 0; used_cur[j] = used_kept[j]; }
-        } else if (cbv < b) {
+        } else if (cbq < b) {
             t = 0;
-        } else if (cbv == b && (sel_mod <= 1 || j % sel_mod == sel_rem)) {  // this work item's slice of the block's cuts
+        } else if (cbq == b && (sel_mod <= 1 || j % sel_mod == sel_rem)) {  // this work item's slice of the block's cuts
             s = atomicAdd(&nlocal, 1u);
             node_of[s] = (unsigned short)j;
         }
@@ -994,7 +1019,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
         for (u32 level = 0;; ++level) {
             const u32 ptiles = (rlen + S - 1) / S;   // tiles per piece at this level
             const u32 np = (rlen + ptiles - 1) / ptiles;  // pieces actually used (<= S)
-            const u64 tr_a = g_cut_trace_on ? wall_clock64() : 0;
+            const u64 tr_a = KT_ON ? wall_clock64() : 0;
             for (u32 k = tid; k < kn * Sp; k += kBlock) T[k] = 0;
             __syncthreads();
             // pass: claim load per (local node, piece of its range); a tile (256 rows) lies inside ONE piece
@@ -1041,7 +1066,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
 #undef RIOGP_ROW
             }
             __syncthreads();
-            const u64 tr_b = g_cut_trace_on ? wall_clock64() : 0;
+            const u64 tr_b = KT_ON ? wall_clock64() : 0;
             // ordered walk over each node's T row: the piece that holds the cut becomes the node's range.  Two forms,
             // picked by estimated instruction count: one LANE per node (many nodes, short rows: row stride odd, so no
             // bank conflicts) or one WAVE per node with a DPP scan (few nodes, long rows).  LDS only.
@@ -1100,14 +1125,14 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                 }
             }
             __syncthreads();
-            if (g_cut_trace_on) { const u64 tr_c = wall_clock64(); tr_p1 += tr_b - tr_a; tr_p2a += tr_c - tr_b; }
+            if (KT_ON) { const u64 tr_c = wall_clock64(); tr_p1 += tr_b - tr_a; tr_p2a += tr_c - tr_b; }
             rlen = ptiles;
             // another level?  In tile-steps shared by 16 waves: row-by-row searches of the remaining ranges cost about
             // kn x rlen x (live share) ordered scans; one more level costs a pass over the live tiles (a third of a scan
             // each) plus a fixed part (zeroing, barriers, walks ~ 100 scans).  Taken only when it clearly pays (2x).
             if (rlen <= 1 || (u64)kn * rlen * live_tiles <= (u64)BT * (2ull * (live_tiles / 3 + 100))) break;
         }
-        const u64 tr_b2 = g_cut_trace_on ? wall_clock64() : 0;
+        const u64 tr_b2 = KT_ON ? wall_clock64() : 0;
         // the rows each node's search covers: from the first tile of its range that holds live rows (packed fix-up: most
         // positions of a wave range are dead) to the end of the range — one lane per node, LDS only, into the T region
         // (free now): T[ls] = first row, T[kn + ls] = end.  Done here so that the searches below start with their loads.
@@ -1226,7 +1251,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                 if (base + (u32)u * kWaves < kn) run(q[u]);
         }
         __syncthreads();
-        if (g_cut_trace_on) tr_p2 += wall_clock64() - tr_b2;
+        if (KT_ON) tr_p2 += wall_clock64() - tr_b2;
     }
     RIOGP_TRACE(2, tr_p1);
     RIOGP_TRACE(3, tr_p2);
@@ -1235,7 +1260,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
 
 }
 
-template <bool VIRT>
+template <bool VIRT, bool TRACE>
 __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                       const u32* __restrict__ aff, u32* __restrict__ next,
                                                       const u32* __restrict__ alive_bits, Plan p,
@@ -1251,10 +1276,10 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
     u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
     u32* thr = reinterpret_cast<u32*>(smem + kSmall);                        // [mr] reject threshold by node
     u32* alv = reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(thr + mr) + 2 * mr);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
     const u32 b = blockIdx.x;
     if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
-    cut_search_block<VIRT>(smem, b, 1, 0, true, cur, load, aff, alive_bits, p, cutblk, budget, admpre, used_kept, forced_bits,
+    cut_search_block<VIRT, TRACE>(smem, b, 1, 0, true, cur, load, aff, alive_bits, p, cutblk, budget, admpre, used_kept, forced_bits,
                            cutidx, used_cur, tcap);
     const u64 gw = (u64)b * kWaves + wave;
     u64 wstart, wend;
@@ -1306,7 +1331,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cu
         bsp_sum[blockIdx.x] = red[2];
         bsp_cnt[blockIdx.x] = (u32)red[3];
     }
-    if (tid == 0 && g_cut_trace_on) g_cut_trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64() - g_cut_trace[(size_t)blockIdx.x * 8 + 4];
+    if (tid == 0 && KT_ON) g_cut_trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64() - g_cut_trace[(size_t)blockIdx.x * 8 + 4];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1322,7 +1347,7 @@ constexpr u32 kCutPerItem = 16;    // cut nodes per work item (one per wave of t
 constexpr u32 kCutMaxSlices = 64;  // slices of one block's cuts
 constexpr u32 kCutFindGrid = 256;  // one workgroup per CU (the search needs ~150 KiB of LDS)
 
-template <bool VIRT>
+template <bool VIRT, bool TRACE>
 __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                      const u32* __restrict__ aff, const u32* __restrict__ alive_bits,
                                                      Plan p, const u32* __restrict__ cutblk,
@@ -1334,9 +1359,11 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
     __shared__ u32 cnt[kMaxBlocks];                 // nodes whose cut falls into block b
     __shared__ unsigned short istart[kMaxBlocks + 1];  // first item of block b; [kMaxBlocks] = number of items
     __shared__ unsigned char nsl[kMaxBlocks];       // slices (= items) of block b
-    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 m = p.m, G = p.G;
+    const u64 ncut = stats->n_cut;  // one round trip for the verdict and the thread's first cutblk[] word
+    const u32 cb0 = cutblk[(u32)tid < m ? (u32)tid : m - 1];
+    if (ncut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
     RIOGP_KT(3, 0);
     if (forced_bits && blockIdx.x == 0)  // row-sharded solve: the prefix overflowed on a lower rank — nothing is admitted here
         for (u32 j = tid; j < m; j += kBlock)
@@ -1344,7 +1371,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
     for (u32 k = tid; k < kMaxBlocks; k += kBlock) cnt[k] = 0;
     __syncthreads();
     for (u32 j = tid; j < m; j += kBlock) {
-        const u32 cb = cutblk[j];
+        const u32 cb = j == (u32)tid ? cb0 : cutblk[j];
         if (cb < G && !(forced_bits && bit_of(forced_bits, j))) atomicAdd(&cnt[cb], 1u);
     }
     __syncthreads();
@@ -1372,7 +1399,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
     __syncthreads();
     const u32 items = istart[kMaxBlocks];
     RIOGP_KT(3, 1);
-    if (threadIdx.x == 0 && g_cut_trace_on && blockIdx.x < kMaxBlocks) g_kt[3][(size_t)blockIdx.x * 8 + 3] = items;
+    if (threadIdx.x == 0 && KT_ON && blockIdx.x < kMaxBlocks) g_kt[3][(size_t)blockIdx.x * 8 + 3] = items;
     for (u32 item = blockIdx.x; item < items; item += gridDim.x) {
         u32 lo = 0, hi = kMaxBlocks;  // the last block whose first item is <= item (blocks without cuts share their successor's start)
         while (hi - lo > 1) {
@@ -1380,12 +1407,14 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
             if (istart[mid] <= item) lo = mid; else hi = mid;
         }
         __syncthreads();  // the previous item's LDS tables are dead from here on
-        cut_search_block<VIRT>(smem, lo, nsl[lo], item - istart[lo], false, cur, load, aff, alive_bits, p, cutblk, budget,
+        cut_search_block<VIRT, TRACE>(smem, lo, nsl[lo], item - istart[lo], false, cur, load, aff, alive_bits, p, cutblk, budget,
                                admpre, used_kept, forced_bits, cutidx, used_cur, tcap);
     }
     RIOGP_KT(3, 2);
 }
 
+#undef KT_ON
+#define KT_ON (p.trace != 0)
 // ------------------------------------------------------------------------------------------------
 // KS  k_spill_rank — per round: free capacity per node and the rank of every node in the total order
 //     (free desc, index asc) by counting.  (The exclusive prefix of the per-wave spill totals and the "is anything
@@ -1502,28 +1531,59 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
         spill_rank_body(smem, blockIdx.x - p.G, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
         return;
     }
-    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // no cut anywhere: k_scan's spill totals stand
     const u32 m = p.m;
     u64* red = reinterpret_cast<u64*>(smem + 16);      // [2]
     u32* thr = reinterpret_cast<u32*>(smem + kSmall);  // [m] first rejected row of a node's claimants (kNoCut: none)
     u32* alv = thr + ((m + 3) & ~3u);                  // [mwords]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
     RIOGP_KT(2, 0);
-    for (u32 j = tid; j < m; j += kBlock) thr[j] = (forced_bits && bit_of(forced_bits, j)) ? 0u : cutidx[j];
-    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    // Every global operand is requested up front, in the order it is needed and without predicates (clamped addresses):
+    // the packed row count of this wave, the cut rows and the liveness words, then the wave's first tile of rows — whose
+    // round trip then runs under the LDS fill and the barrier instead of after them.
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    const u32 wc = *(p.wcnt ? p.wcnt + gw : cutidx);
+    const u64 ncut = stats->n_cut;
+    const u32 per = (m + kBlock - 1) / kBlock;  // <= 8
+    u32 tv[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) tv[q] = 0;
+    tv[0] = cutidx[(u32)tid < m ? (u32)tid : m - 1];
+    if (per > 1) {  // m > 1 024
+#pragma unroll
+        for (u32 q = 1; q < 8; ++q) {
+            const u32 j = tid + (q < per ? q : per - 1) * kBlock;
+            tv[q] = cutidx[j < m ? j : m - 1];
+        }
+    }
+    const u32 ak = (u32)tid < p.mwords ? (u32)tid : p.mwords - 1;  // mwords <= 256 < kBlock
+    const u32 aw = alive_bits[ak];
+    u64 wstart = wave_row_lo(p, gw), wend = wave_row_lo(p, gw + 1);
+    if (wend > p.n) wend = p.n;
+    if (wstart > wend) wstart = wend;
+    if (p.wcnt && wstart + wc < wend) wend = wstart + wc;
+    const u64 rs = (wstart < wend ? wstart : 0ull) + (u64)lane * 4;
+    uint4 cvn = *reinterpret_cast<const uint4*>(cur + rs);
+    uint4 avn = *reinterpret_cast<const uint4*>(aff + rs);
+    uint4 lvn = *reinterpret_cast<const uint4*>(load + rs);
+    if (ncut == 0 && forced_bits == nullptr) return;  // no cut anywhere: k_scan's spill totals stand
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+        const u32 j = tid + q * kBlock;
+        if (q < per && j < m) thr[j] = (forced_bits && bit_of(forced_bits, j)) ? 0u : tv[q];
+    }
+    alv[ak] = aw;  // threads past mwords rewrite the last word with its own value
     if (tid < 4) red[tid] = 0;
     __syncthreads();
     RIOGP_KT(2, 1);
-    const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
     u64 sp_sum = 0, rej_sum = 0;
     u32 sp_cnt = 0, rej_cnt = 0;  // wave-uniform
     for (u64 it = wstart; it < wend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
-        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
-        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
-        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+        const uint4 cv = cvn, av = avn, lv = lvn;
+        const u64 pit = (it + kTile < wend ? it + kTile : it) + (u64)lane * 4;  // next tile in flight (the last re-reads its own)
+        cvn = *reinterpret_cast<const uint4*>(cur + pit);
+        avn = *reinterpret_cast<const uint4*>(aff + pit);
+        lvn = *reinterpret_cast<const uint4*>(load + pit);
 #define RIOGP_ROW(C, A, L, E)                                                                        \
         {                                                                                            \
             const bool inr = i0 + E < wend;                                                          \
@@ -1588,7 +1648,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     u64* adm = C + (m + 1);                                // [m] admitted load by node (this block)
     unsigned short* ord = reinterpret_cast<unsigned short*>(adm + m);  // [m] node of rank k (a global read per placed row otherwise:
                                                            //     four dependent ~1 us round trips per lane and tile)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
     const int ktab = last ? 1 : 0;
     RIOGP_KT(ktab, 0);
     // Prologue: what is pending, and where does this workgroup's first wave start in the index-ordered spill prefix?
@@ -1596,34 +1656,69 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     // per-workgroup spill totals of the previous step (G words: k_scan / the cut pass / the previous round wrote them next
     // to the per-wave ones), this workgroup's own 16 per-wave totals, the ranked free capacities and the rank order.
     const u32 mpad = (m + kBlock - 1) / kBlock * kBlock, per = mpad / kBlock;  // per <= 8 (m <= 8 192)
+    // Loads retire in issue order, so the two words the ROW loads depend on go first (this wave's packed row count and its
+    // pending count), then the prologue's operands — all with clamped addresses instead of predicates, so that nothing
+    // waits on `cnt` or on a branch before it is requested — and then the wave's first tile of rows, whose round trip
+    // runs under the prologue instead of after it.
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    const u32 G = p.G, w0 = blockIdx.x * kWaves;
+    const u32 wc = *(p.wcnt ? p.wcnt + gw : wsp_cnt_in + gw);
+    const u32 pc = wsp_cnt_in[gw];
     const u32 cnt = *wfCnt;
+    const u64 pgv = pending_global ? *pending_global : 0ull;  // row-sharded solve: the exchange's verdict / the lower ranks' spill load
+    const u64 rbv = rank_base ? *rank_base : 0ull;
     u64 fr[8];
     u32 od[8];
 #pragma unroll
+    for (u32 q = 0; q < 8; ++q) { fr[q] = 0; od[q] = 0; }
+    {
+        const u32 k = tid * per, kk = k < m ? k : m - 1;
+        fr[0] = wfC[kk];
+        od[0] = wfOrder[kk];
+    }
+    if (per > 1) {  // m > 1 024: q >= per re-reads the thread's last word (a hit in the vector cache): no per-word branch
+#pragma unroll
+        for (u32 q = 1; q < 8; ++q) {
+            const u32 k = tid * per + (q < per ? q : per - 1), kk = k < m ? k : m - 1;
+            fr[q] = wfC[kk];
+            od[q] = wfOrder[kk];
+        }
+    }
+    const u32 bt = (u32)tid < G ? (u32)tid : G - 1;
+    const u64 bv = bsp_sum_in[bt];
+    const u32 bc = bsp_cnt_in[bt];
+    const u64 pw = wsp_sum_in[w0 + (tid & (kWaves - 1))];
+    u64 wstart = wave_row_lo(p, gw), wend = wave_row_lo(p, gw + 1);
+    if (wend > p.n) wend = p.n;
+    if (wstart > wend) wstart = wend;
+    if (p.wcnt && wstart + wc < wend) wend = wstart + wc;  // packed fix-up: only the first wcnt[gw] positions hold rows
+    if (pc == 0) wend = wstart;  // no pending row in this wave's range (later rounds: most waves)
+    const bool scat = pk_idx != nullptr;
+    // unconditional (a wave without rows reads tile 0 and ignores it): a load behind a branch would make every later
+    // wait a wait for ALL loads, the prologue's included
+    const u64 rs = (wstart < wend ? wstart : 0ull) + (u64)lane * 4;
+    uint4 nvn = *reinterpret_cast<const uint4*>(next + rs);
+    uint4 lvn = *reinterpret_cast<const uint4*>(load + rs);
+    uint4 ivn = *reinterpret_cast<const uint4*>((scat ? pk_idx : load) + rs);
+#pragma unroll
     for (u32 q = 0; q < 8; ++q) {
-        const u32 k = tid * per + q;
-        const bool in = q < per && k < cnt;
-        fr[q] = in ? wfC[k] : 0ull;
-        od[q] = in ? wfOrder[k] : 0u;
+        const bool in = q < per && tid * per + q < cnt;
+        fr[q] = in ? fr[q] : 0ull;
+        od[q] = in ? od[q] : 0u;
     }
     u64 my_base;
     {
-        const u32 G = p.G, w0 = blockIdx.x * kWaves;
-        u64 sb = 0;
-        u32 c = 0;
-        if ((u32)tid < G) {
-            const u64 v = bsp_sum_in[tid];
-            c = bsp_cnt_in[tid];
-            if ((u32)tid < blockIdx.x) sb = v;
-        }
-        if (tid < kWaves) part[tid] = wsp_sum_in[w0 + tid];  // staged for the in-block prefix below
+        u64 sb = ((u32)tid < G && (u32)tid < blockIdx.x) ? bv : 0ull;
+        u32 c = (u32)tid < G ? bc : 0u;
+        part[tid & (kWaves - 1)] = pw;  // staged for the in-block prefix below (every thread stores: a store behind a
+                                        // branch would pull the load in after it, and its wait with it)
         sb = wave_sum(sb);
         c = wave_sum32(c);
         if (tid < 6) red[tid] = 0;
         __syncthreads();
         if (lane == 0 && (sb | c)) { atomicAdd(&red[0], sb); atomicAdd(&red[1], (u64)c); }
         __syncthreads();
-        const bool pending = pending_global ? (*pending_global != 0) : (red[1] != 0);
+        const bool pending = pending_global ? (pgv != 0) : (red[1] != 0);
         if (!pending) {  // nothing pending anywhere: the round is a no-op
             if (lane == 0) {
                 const u64 gw0 = (u64)blockIdx.x * kWaves + wave;
@@ -1631,13 +1726,12 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                 wsp_cnt_out[gw0] = 0;
             }
             if (tid == 0) { bsp_sum_out[blockIdx.x] = 0; bsp_cnt_out[blockIdx.x] = 0; }
+            if (last && fx.dev && fx.seq && tid < 8)  // the host may be spinning on this row
+                fx.host[(size_t)blockIdx.x * 8 + tid] = tid == 7 ? fx.seq : fx.dev[(size_t)blockIdx.x * 8 + tid];
             return;
         }
-        if (blockIdx.x == 0 && tid == 0) {
-            if (fx.dev) fx.dev[6] += 1;
-            else stats->rounds_run += 1;
-        }
-        my_base = red[0] + (rank_base ? *rank_base : 0ull);  // row-sharded solve: the spill load of every lower rank comes first
+        if (!fx.dev && blockIdx.x == 0 && tid == 0) atomicAdd(&stats->rounds_run, 1ull);  // (fx rows: counted in the epilogue)
+        my_base = red[0] + rbv;  // row-sharded solve: the spill load of every lower rank comes first
         for (int w = 0; w < wave; ++w) my_base += part[w];
         __syncthreads();  // red / part are reused below
     }
@@ -1660,9 +1754,6 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     __syncthreads();
     RIOGP_KT(ktab, 2);
     const u64 F = C[cnt];
-    const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
     u64 run = my_base;
     u64 rem_sum = 0, pl_sum = 0;
     u32 rem_cnt = 0, pl_cnt = 0;
@@ -1677,17 +1768,9 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         }
         lo_run = lo;
     }
-    if (wsp_cnt_in[gw] == 0) wend = wstart;  // no pending row in this wave's range (later rounds: most waves)
     // packed fix-up: `next` is the packed decision column; every decision is also written straight into the real
     // assignment column through pk_idx (k_pk_scatter's job, without its launch).  Every pending row gets its final
     // value here: placed rows in the round that places them, the rest (NONE) in the last round.
-    const bool scat = pk_idx != nullptr;
-    uint4 nvn = make_uint4(0, 0, 0, 0), lvn = make_uint4(0, 0, 0, 0), ivn = make_uint4(0, 0, 0, 0);
-    if (wstart < wend) {
-        nvn = *reinterpret_cast<const uint4*>(next + wstart + (u64)lane * 4);
-        lvn = *reinterpret_cast<const uint4*>(load + wstart + (u64)lane * 4);
-        if (scat) ivn = *reinterpret_cast<const uint4*>(pk_idx + wstart + (u64)lane * 4);
-    }
     for (u64 it = wstart; it < wend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
         const uint4 nv = nvn, lv = lvn, iv = ivn;
@@ -1718,6 +1801,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                 if (C[mid] <= run_end) hi_run = mid; else top = mid;
             }
         }
+        if (it == wstart) RIOGP_KT(ktab, 6);
 #define RIOGP_ROW(MK, L, E, IDX)                                                  \
         if (MK) {                                                                 \
             u32 nd = kNone;                                                       \
@@ -1748,6 +1832,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         RIOGP_ROW(mk2, l2, 2, iv.z)
         RIOGP_ROW(mk3, l3, 3, iv.w)
 #undef RIOGP_ROW
+        if (it == wstart) RIOGP_KT(ktab, 7);
         run = run_end;
         lo_run = hi_run;
     }
@@ -1768,11 +1853,15 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
     if (tid == 0) { bsp_sum_out[blockIdx.x] = red[4]; bsp_cnt_out[blockIdx.x] = (u32)red[5]; }
     for (u32 k = tid; k < m; k += kBlock)
         if (adm[k]) atomicAdd(&used_cur[k], adm[k]);  // integer sums: order-independent
-    if (fx.dev) {  // this workgroup's row of the fix-up counters, and its copy in the host's pinned slot
-        u64* r = fx.dev + (size_t)blockIdx.x * 8;
-        if (tid == 0) { r[2] += red[0]; r[3] += red[1]; r[4] += red[2]; r[5] += red[3]; }
-        __syncthreads();
-        if (tid < 8) fx.host[(size_t)blockIdx.x * 8 + tid] = r[tid];
+    if (fx.dev) {  // this workgroup's row of the fix-up counters, and its copy in the host's pinned slot: one round trip
+        if (tid < 8) {
+            u64* r = fx.dev + (size_t)blockIdx.x * 8;
+            const u64 add = tid == 2 ? red[0] : tid == 3 ? red[1] : tid == 4 ? red[2] : tid == 5 ? red[3]
+                          : (tid == 6 && blockIdx.x == 0) ? 1ull : 0ull;  // [6] of row 0 = rounds run
+            const u64 v = (tid == 7 && last && fx.seq) ? fx.seq : r[tid] + add;  // [7] = the host's sequence number
+            r[tid] = v;
+            fx.host[(size_t)blockIdx.x * 8 + tid] = v;
+        }
     } else if (tid == 0) {
         if (red[0]) { atomicAdd(&stats->spilled, red[0]); atomicAdd(&stats->load_spilled, red[1]); }
         if (red[2]) { atomicAdd(&stats->unplaced, red[2]); atomicAdd(&stats->load_unplaced, red[3]); }
@@ -1816,12 +1905,22 @@ __global__ void k_pack_alive(const uint8_t* alive, u32 m, u32* bits) {
     bits[w] = v;
 }
 
+// Completion word of a single-workgroup call (micro-batches): every thread calls it after its last result store; the
+// host spins on the mapped pinned word instead of going through hipStreamSynchronize (measured: 7.3 us instead of 12.6 us
+// for launch + wait, tools/sync_probe.py).  done == nullptr: the caller waits for the stream.
+__device__ __forceinline__ void signal_done(u32* done, u32 seq) {
+    if (!done) return;
+    __threadfence_system();  // this thread's result stores are on their way to host memory before ...
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // ... the word is
+}
+
 // lookup (local.rs:42-49): 12 B/lookup — idx read, assign gather, out write.  A lane takes FOUR consecutive lookups: one
 // dwordx4 index read, four independent gathers in flight before the first is used, one dwordx4 store (the scalar form —
 // one dependent 4-byte gather per lane and iteration — reached 40 % of the roofline on sequential indices and 7.7 % on
 // random ones, where every gather pulls a whole 128-byte line through the fabric for 4 useful bytes).
 __global__ __launch_bounds__(256) void k_lookup4(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u64 n,
-                                                 u32* __restrict__ out, DevStats* st) {
+                                                 u32* __restrict__ out, DevStats* st, u32* done, u32 seq) {
     const u64 nvec = n >> 2;
     u32 bad = 0;
     const u64 stride = (u64)gridDim.x * 256;
@@ -1851,15 +1950,17 @@ __global__ __launch_bounds__(256) void k_lookup4(const u32* __restrict__ assign,
     }
 #undef RIOGP_G
     if (bad) atomicAdd(&st->err, (u64)bad);
+    signal_done(done, seq);
 }
 // the same for index / result arrays that are not 16-byte aligned
 __global__ void k_lookup(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u64 n,
-                         u32* __restrict__ out, DevStats* st) {
+                         u32* __restrict__ out, DevStats* st, u32* done, u32 seq) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k];
         if (i < n_obj) out[k] = assign[i];
         else { out[k] = kNone; atomicAdd(&st->err, 1ull); }
     }
+    signal_done(done, seq);
 }
 
 // update (local.rs:22-40), sequential last-writer-wins: phase 1 elects, per row, the highest
@@ -1892,20 +1993,22 @@ __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const
 // mapped host memory.  Sequential last-writer-wins inside the batch: an entry loses to any LATER entry for the same row.
 __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
                                                               const u32* __restrict__ node, u32 n,
-                                                              u32* __restrict__ aff_life) {
+                                                              u32* __restrict__ aff_life, u32* done, u32 seq) {
     __shared__ u32 li[kSmallBatch];
     const u32 k = threadIdx.x;
     u32 i = kNone, nd = kNone;
     if (k < n) { i = idx[k]; nd = node[k]; }
     li[k] = i;
     __syncthreads();
-    if (k >= n) return;
-    bool wins = true;
-    for (u32 q = k + 1; q < n; ++q) wins &= li[q] != i;
-    if (wins) {
-        assign[i] = nd;
-        if (aff_life) aff_life[i] = nd == kNone ? kAffInactive : nd;
+    if (k < n) {
+        bool wins = true;
+        for (u32 q = k + 1; q < n; ++q) wins &= li[q] != i;
+        if (wins) {
+            assign[i] = nd;
+            if (aff_life) aff_life[i] = nd == kNone ? kAffInactive : nd;
+        }
     }
+    signal_done(done, seq);  // the host may reuse the staging rows once the word is there
 }
 
 // remove (local.rs:60-68): exchange makes duplicate removals of one row decrement `used` once.  The load released per
@@ -1913,7 +2016,8 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
 // million removals on at most m addresses (measured 55 us per million rows).
 __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                    const u32* __restrict__ load, const u32* __restrict__ idx, u64 n,
-                                                   u64* __restrict__ used, DevStats* st, u32* __restrict__ aff_life) {
+                                                   u64* __restrict__ used, DevStats* st, u32* __restrict__ aff_life,
+                                                   u32* done, u32 seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* rel = reinterpret_cast<u64*>(smem);  // [m] load released per node (only when `used` is maintained)
     if (used) {
@@ -1934,6 +2038,7 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
         for (u32 j = threadIdx.x; j < m; j += kBlock)
             if (rel[j]) atomicAdd(&used[j], (u64)0 - rel[j]);
     }
+    signal_done(done, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2342,7 +2447,8 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
                                                           u32* __restrict__ pos, const u32* __restrict__ idx,
                                                           const u32* __restrict__ req, u32 n,
                                                           u32* __restrict__ out_node, u32* __restrict__ out_flag,
-                                                          u32* __restrict__ status, u32* __restrict__ aff_life) {
+                                                          u32* __restrict__ status, u32* __restrict__ aff_life,
+                                                          u32* done, u32 seq) {
     __shared__ u32 s_req[kSmallBatch], s_load[kSmallBatch], s_res[kSmallBatch];
     __shared__ u32 s_general;
     const u32 k = threadIdx.x;
@@ -2384,6 +2490,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
     if (s_general) {  // hand over untouched
         if (valid) pos[i] = kNone;
         if (k == 0) *status = 1;
+        signal_done(done, seq);
         return;
     }
     if (valid) {
@@ -2402,6 +2509,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
         pos[i] = kNone;
     }
     if (k == 0) *status = 0;
+    signal_done(done, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2752,7 +2860,7 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
     return (unsigned)g;
 }
 
-int cut_trace_enable(int on) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cut_trace_on), &on, sizeof on); }
+int cut_trace_enable(int on) { g_trace_host = on; return 0; }
 int cut_trace_read(u64* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cut_trace), sizeof(u64) * kMaxBlocks * 8); }
 int ktrace_read(int table, u64* out) {
     if (table < 0 || table >= kKtTables) return -1;
@@ -2847,8 +2955,10 @@ size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
 // water-fill round 0 when with_rank) | 1: one fused launch per solve, k_cut_fused | 0: the first, unfused chain — T memset,
 // k_cutblk, k_cut_subhist, k_cut_exact, (k_shard_force,) k_apply_cut.  All three are kept: the parity tests drive the same
 // inputs through each and compare bytes.  Returns true when the ranking of round 0 was part of these launches.
-bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
+bool launch_cut_fixup(const Plan& p_in, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
                       hipStream_t s, int impl, bool have_cutblk, bool with_rank) {
+    Plan p = p_in;
+    p.trace = (u32)g_trace_host;
     const unsigned gcb = (p.m + kCbNodes - 1) / kCbNodes;
     if (impl >= 1) {
         if (!have_cutblk)  // k_resolve of this solve has already located the cut blocks (not on the row-sharded path)
@@ -2864,13 +2974,15 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
             const unsigned grank = with_rank ? ((p.m + kRankNodes - 1) / kRankNodes ? (p.m + kRankNodes - 1) / kRankNodes : 1) : 0;
             const size_t lds2 = (with_rank && lds_rank > lds_apply) ? lds_rank : lds_apply;
             if (virt) {
-                hipLaunchKernelGGL(k_cut_find<true>, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                auto kfn = p.trace ? k_cut_find<true, true> : k_cut_find<true, false>;
+                hipLaunchKernelGGL(kfn, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
                 hipLaunchKernelGGL(k_cut_apply_rank<true>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
                                    b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
             } else {
-                hipLaunchKernelGGL(k_cut_find<false>, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                auto kfn = p.trace ? k_cut_find<false, true> : k_cut_find<false, false>;
+                hipLaunchKernelGGL(kfn, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
                 hipLaunchKernelGGL(k_cut_apply_rank<false>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
@@ -2878,14 +2990,11 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
             }
             return with_rank;
         }
-        if (virt)
-            hipLaunchKernelGGL(k_cut_fused<true>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
-                               nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
-        else
-            hipLaunchKernelGGL(k_cut_fused<false>, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
-                               nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                               b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
+        auto kfn = virt ? (p.trace ? k_cut_fused<true, true> : k_cut_fused<true, false>)
+                        : (p.trace ? k_cut_fused<false, true> : k_cut_fused<false, false>);
+        hipLaunchKernelGGL(kfn, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
+                           nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
+                           b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
         return false;
     }
     (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
@@ -2914,8 +3023,10 @@ bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const So
 }
 
 // rank_done: the ranking of this round has already been enqueued (k_cut_apply_rank)
-void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
+void launch_spill_round(const Plan& p_in, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
                         hipStream_t s, bool rank_done) {
+    Plan p = p_in;
+    p.trace = (u32)g_trace_host;
     const int in = round & 1, out = in ^ 1;
     const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
     const size_t lds_prep = 2 * kSmall + 256 + (size_t)mp * sizeof(u64);
@@ -2929,12 +3040,14 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
                        t.pk_idx, t.real_next, b.rank_base, b.pending_global, b.fx, b.bsp_sum[in], b.bsp_cnt[in], b.bsp_sum[out], b.bsp_cnt[out]);
 }
 
-void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s) {
+void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s, u32* done,
+                   u32 seq) {
     if (!n) return;
-    if ((((uintptr_t)idx | (uintptr_t)out) & 15u) == 0)
-        hipLaunchKernelGGL(k_lookup4, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, s, assign, n_obj, idx, n, out, st);
-    else
-        hipLaunchKernelGGL(k_lookup, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, idx, n, out, st);
+    const bool vec = (((uintptr_t)idx | (uintptr_t)out) & 15u) == 0;
+    const unsigned g = vec ? grid_for((n + 3) / 4, 256, 2048) : grid_for(n, 256, 4096);
+    if (g != 1) done = nullptr;  // the completion word is a single-workgroup protocol (callers pass it for micro-batches only)
+    if (vec) hipLaunchKernelGGL(k_lookup4, dim3(g), dim3(256), 0, s, assign, n_obj, idx, n, out, st, done, seq);
+    else hipLaunchKernelGGL(k_lookup, dim3(g), dim3(256), 0, s, assign, n_obj, idx, n, out, st, done, seq);
 }
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos, DevStats* st,
                    hipStream_t s, u32* aff_life) {
@@ -2943,15 +3056,18 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
     hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
     hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos, aff_life);
 }
-void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life) {
+void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life, u32* done,
+                         u32 seq) {
     if (!n) return;
-    hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n, aff_life);
+    hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n, aff_life, done, seq);
 }
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
-                   hipStream_t s, u32* aff_life) {
+                   hipStream_t s, u32* aff_life, u32* done, u32 seq) {
     if (!n) return;
-    hipLaunchKernelGGL(k_remove, dim3(grid_for(n, kBlock * 4, 256)), dim3(kBlock), used ? (size_t)m * sizeof(u64) : 0, s, assign,
-                       n_obj, m, load, idx, n, used, st, aff_life);
+    const unsigned g = grid_for(n, kBlock * 4, 256);
+    if (g != 1) done = nullptr;  // (single-workgroup protocol)
+    hipLaunchKernelGGL(k_remove, dim3(g), dim3(kBlock), used ? (size_t)m * sizeof(u64) : 0, s, assign,
+                       n_obj, m, load, idx, n, used, st, aff_life, done, seq);
 }
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
@@ -3040,9 +3156,9 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
 }
 void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
                      const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                     u32* aff_life) {
+                     u32* aff_life, u32* done, u32 seq) {
     hipLaunchKernelGGL(k_pp_small, dim3(1), dim3(kSmallBatch), 0, s, assign, load, m, cap, alive_bits, used, pos, idx, req, n,
-                       out_node, out_flag, status, aff_life);
+                       out_node, out_flag, status, aff_life, done, seq);
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s) {

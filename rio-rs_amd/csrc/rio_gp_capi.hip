@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -159,9 +161,11 @@ struct rio_gp {
     size_t cs_words = 0;
     u64* cs_cnt = nullptr;
     unsigned int* cs_ticket = nullptr;
-    // micro-batch staging: pinned host memory mapped into the device, [5][kSmallBatch] u32 = idx | req | node | flag | status
+    // micro-batch staging: pinned host memory mapped into the device, [6][kSmallBatch] u32 = idx | req | node | flag | status | completion word
     u32* h_small = nullptr;
     u32* d_small = nullptr;
+    u64 wait_seq = 1;       // sequence numbers of the synchronous solves (spin_rows): never 0 or 1
+    u32 small_seq = 0;      // sequence number of the last micro-batch call; its completion word is row 5, word 0
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
     DevBuf part;  // scratch of the partitioned update / remove batches (records + fragment tables)
@@ -298,6 +302,23 @@ DevStats reduce_rows(rio_gp* h, size_t slot, u32 m) {
 void use_fx_slot(rio_gp* h, u32 slot) {
     h->sb.fx.dev = h->fx_dev;
     h->sb.fx.host = h->d_fx + (size_t)slot * kMaxBlocks * 8;
+    h->sb.fx.seq = 0;
+}
+// Waiting without the runtime: the kernels of a synchronous solve store the solve's sequence number into word 7 of every
+// row they write into mapped pinned memory (k_resolve's partial rows, the last water-fill round's counter rows); the host
+// spins until every row carries it.  launch + hipStreamSynchronize costs 12.6 us, launch + spin 7.3 us
+// (tools/sync_probe.py).  false: not there after 50 ms — the caller asks the stream (a dead kernel shows up there).
+bool spin_rows(const u64* rows, u32 nrows, u64 seq) {
+    const volatile u64* r = rows;
+    const auto t0 = std::chrono::steady_clock::now();
+    u32 spins = 0;
+    for (u32 i = 0; i < nrows;) {
+        if (r[(size_t)i * 8 + 7] == seq) { ++i; continue; }
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return false;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
 }
 // fold those rows into a fast-path verdict (after the stream has been waited for)
 void fold_fx(rio_gp* h, u32 slot, u32 G, DevStats* v) {
@@ -311,7 +332,7 @@ void fold_fx(rio_gp* h, u32 slot, u32 G, DevStats* v) {
     v->rounds_run = x[6];
 }
 int merge_slow(rio_gp* h, DevStats* v) {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!(h->sb.fx.seq && spin_rows(h->h_fx, h->plan.G, h->sb.fx.seq))) HIPCHK(h, hipStreamSynchronize(h->stream));
     fold_fx(h, 0, h->plan.G, v);
     return RIO_GP_OK;
 }
@@ -332,6 +353,11 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     h->plan = make_plan(h->n, h->m, 0);
     h->ring_n = 0;
     use_fx_slot(h, 0);
+    const u64 seq = ++h->wait_seq;
+    h->plan.mark = seq;  // k_resolve's partial rows carry it ...
+    // ... and so do the counter rows of the last water-fill round, when that round is the solve's last kernel
+    const bool fx_last = h->fixup_mode >= 1 && h->rounds >= 1;
+    if (fx_last) h->sb.fx.seq = seq;
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     // Adaptive packed fix-up: when the previous solve left few rows pending (a churn stream: most rows are kept),
@@ -348,8 +374,9 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
     DevStats v;
     bool slow = false;
+    const u64* vrows = h->h_slots;  // slot 0 of the solve ring
     if (!spec) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!spin_rows(vrows, resolve_blocks(h->m), seq)) HIPCHK(h, hipStreamSynchronize(h->stream));
         v = reduce_slot(h, 0, h->m);
         slow = v.n_cut > 0 || v.spillcand > 0;
     }
@@ -377,16 +404,14 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
         if (rc) return rc;
     }
     if (spec) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!(fx_last && spin_rows(h->h_fx, h->plan.G, seq))) HIPCHK(h, hipStreamSynchronize(h->stream));
         v = reduce_slot(h, 0, h->m);
         slow = v.n_cut > 0 || v.spillcand > 0;
         if (slow) fold_fx(h, 0, h->plan.G, &v);  // the water-fill rounds stored every workgroup's row into the pinned slot
     } else if (slow) {
-        int rc = merge_slow(h, &v);  // waits for the stream
+        int rc = merge_slow(h, &v);  // waits for the last round's rows (or the stream)
         if (rc) return rc;
-    } else if (commit) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
+    }  // (fast path: k_resolve was the last kernel and its rows are here; the publication is two host-side swaps)
     HIPCHK(h, hipGetLastError());
     h->last_pending = v.claimants + v.spillcand;
     h->last_pending_valid = true;
@@ -457,6 +482,31 @@ int tick_async_locked(rio_gp* h) {
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     h->tick_n = k + 1;
+    return RIO_GP_OK;
+}
+
+// Micro-batch calls (one workgroup) end by storing their sequence number into a word of mapped pinned memory
+// (signal_done, placement_kernels.hip); the host spins on it — launch + hipStreamSynchronize measured 12.6 us, launch +
+// spin 7.3 us (tools/sync_probe.py).  A kernel that dies never writes the word: after ~50 ms the stream is asked.
+u32 small_begin(rio_gp* h) {
+    if (++h->small_seq == 0) h->small_seq = 1;
+    return h->small_seq;
+}
+u32* small_done_dev(rio_gp* h) { return h->d_small + 5 * kSmallBatch; }
+int small_wait(rio_gp* h, u32 seq) {
+    volatile u32* w = h->h_small + 5 * kSmallBatch;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (u32 spins = 1; *w != seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
+    if (*w == seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return RIO_GP_OK;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (*w != seq) return fail(h, RIO_GP_EUPSTREAM, "micro-batch kernel left no completion word");
     return RIO_GP_OK;
 }
 
@@ -575,12 +625,13 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     }
     h->allocs.push_back(h->cs_cnt);
     h->allocs.push_back(h->cs_ticket);
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_small), (size_t)5 * kSmallBatch * sizeof(u32), hipHostMallocMapped) !=
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_small), (size_t)6 * kSmallBatch * sizeof(u32), hipHostMallocMapped) !=
             hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_small), h->h_small, 0) != hipSuccess) {
         h->err = "hipHostMalloc(mapped micro-batch staging) failed";
         return bail(RIO_GP_ENOMEM);
     }
+    memset(h->h_small, 0, (size_t)6 * kSmallBatch * sizeof(u32));  // completion word: 0 = no call yet (sequence numbers start at 1)
     // every row starts unplaced; the position scratch is all-ones between calls
     launch_fill_u32(h->assign[0], R, kNone, h->stream);
     launch_fill_u32(h->assign[1], R, kNone, h->stream);
@@ -846,9 +897,10 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
     int rc;
     if (n <= (uint64_t)kSmallBatch) {  // micro-batch: the gather reads and writes mapped pinned memory, one launch + wait
         memcpy(h->h_small, idx, n * sizeof(u32));
-        launch_lookup(h->assign[h->cur], h->n, h->d_small, n, h->d_small + 2 * kSmallBatch, h->dstats, h->stream);
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
+        const u32 seq = small_begin(h);
+        launch_lookup(h->assign[h->cur], h->n, h->d_small, n, h->d_small + 2 * kSmallBatch, h->dstats, h->stream,
+                      small_done_dev(h), seq);
+        if ((rc = small_wait(h, seq))) return rc;
         memcpy(out_node, h->h_small + 2 * kSmallBatch, n * sizeof(u32));
         return RIO_GP_OK;
     }
@@ -899,12 +951,12 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         // validated above, so the kernels read them from mapped pinned memory and nothing is copied, zeroed or read back
         memcpy(h->h_small, idx, n * sizeof(u32));
         memcpy(h->h_small + kSmallBatch, node, n * sizeof(u32));
-        launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream, aff_life(h));
+        const u32 seq = small_begin(h);
+        launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream, aff_life(h),
+                            small_done_dev(h), seq);
         h->used_valid = false;
         h->have_solved = false;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
-        return RIO_GP_OK;
+        return small_wait(h, seq);
     }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
@@ -946,12 +998,11 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     int rc;
     if (n <= (uint64_t)kSmallBatch) {  // micro-batch: validated above, read from mapped pinned memory, one launch + one wait
         memcpy(h->h_small, idx, n * sizeof(u32));
+        const u32 seq = small_begin(h);
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_small, n, h->used_valid ? h->used : nullptr, h->dstats,
-                      h->stream, aff_life(h));
+                      h->stream, aff_life(h), small_done_dev(h), seq);
         h->have_solved = false;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
-        return RIO_GP_OK;
+        return small_wait(h, seq);
     }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
@@ -1065,10 +1116,11 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         memcpy(hs, idx, n * sizeof(u32));
         memcpy(hs + kSmallBatch, requester, n * sizeof(u32));
         hs[4 * kSmallBatch] = 2;  // neither 0 nor 1: the kernel must write it
+        const u32 seq = small_begin(h);
         launch_pp_small(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, h->pos, ds, ds + kSmallBatch,
-                        (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
+                        (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h),
+                        small_done_dev(h), seq);
+        if ((rc = small_wait(h, seq))) return rc;
         const u32 status = hs[4 * kSmallBatch];
         if (status == 0) {
             memcpy(out_node, hs + 2 * kSmallBatch, n * sizeof(u32));
@@ -1685,6 +1737,11 @@ int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms) {
     if (!h || !ms || reps < 1) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
+    if (mode >= 20 && mode <= 23) {  // host round-trip probes: microseconds per call / 1000
+        *ms = sync_probe(mode, reps, h->stream);
+        if (*ms < 0) return fail(h, RIO_GP_EUPSTREAM, "sync probe failed");
+        return RIO_GP_OK;
+    }
     // same columns the solve streams: cur/load/aff in, the ping-pong column out (an uncommitted solve is lost)
     *ms = stream_probe(mode, h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1], h->n, reps, h->stream, h->ev0,
                        h->ev1);

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <chrono>
+
 #include "placement_kernels.h"
 
 namespace riogp {
@@ -76,6 +78,43 @@ __global__ __launch_bounds__(256) void k_probe_nt(const u32x4* __restrict__ a, c
         if (NTS) __builtin_nontemporal_store(r, o + i);
         else o[i] = r;
     }
+}
+
+// ---- host round-trip probes (modes 20..23): what does ONE synchronous call cost besides its kernel?  A one-thread kernel
+// stores a sequence number into mapped pinned memory; the host either waits for the stream (what every synchronous entry
+// point did up to round 2) or spins on the word.  `from_host`: the kernel first reads a word of mapped pinned memory (a
+// request staged by the host) instead of taking it from its arguments.  Returns microseconds per call, as ms / 1000.
+__global__ void k_probe_flag(const u32* __restrict__ req, u32* flag, u32 seq, int from_host) {
+    u32 v = seq;
+    if (from_host) v = __builtin_nontemporal_load(req);
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+float sync_probe(int mode, int reps, hipStream_t s) {
+    u32* hbuf = nullptr;
+    u32* dbuf = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&hbuf), 256, hipHostMallocMapped) != hipSuccess) return -1.f;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dbuf), hbuf, 0) != hipSuccess) { (void)hipHostFree(hbuf); return -1.f; }
+    volatile u32* flag = hbuf + 32;
+    const bool spin = mode == 21 || mode == 22;
+    const int from_host = mode == 22 || mode == 23;
+    double best = 1e30;
+    for (int pass = 0; pass < 3; ++pass) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; ++r) {
+            const u32 seq = (u32)(pass * reps + r + 1);
+            hbuf[0] = seq;
+            hipLaunchKernelGGL(k_probe_flag, dim3(1), dim3(1), 0, s, dbuf, dbuf + 32, seq, from_host);
+            if (spin) {
+                u64 guard = 0;
+                while (*flag != seq && ++guard < (1ull << 31)) __builtin_ia32_pause();
+            } else if (hipStreamSynchronize(s) != hipSuccess) { (void)hipHostFree(hbuf); return -1.f; }
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipHostFree(hbuf); return -1.f; }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        if (us < best) best = us;
+    }
+    (void)hipHostFree(hbuf);
+    return (float)(best / 1000.0);
 }
 
 // returns per-launch ms (dispatch timestamps) averaged over reps; bytes moved = see bench.py

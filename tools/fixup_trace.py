@@ -23,7 +23,7 @@ for k in range(ticks):
     g.set_alive_all(synth.churn_mask(m, 2 + k))
     st = g.tick()
 us = lambda x: float(x) / 100.0
-def table(t, names):
+def table(t, names, first_tile=False):
     tr = g.ktrace(t).astype(np.int64)
     live = tr[:, 0] > 0
     if not live.any():
@@ -37,10 +37,17 @@ def table(t, names):
         d = tr[live, i] - tr[live, i - 1]
         rec[nm + "_us_median_max"] = [us(np.median(d)), us(d.max())]
     rec["end_minus_first_start_us_max"] = us(tr[live, len(names) - 1].max() - t0)
+    if first_tile:   # slots 6 / 7: wave 0's first tile — scan + bracket done, rows done (0 when the wave had no tile)
+        has = live & (tr[:, 6] > tr[:, 2]) & (tr[:, 7] >= tr[:, 6])
+        if has.any():
+            rec["wave0_first_tile_us_median"] = {"lo_run search + load wait + scan + bracket": us(np.median(tr[has, 6] - tr[has, 2])),
+                                                 "its rows": us(np.median(tr[has, 7] - tr[has, 6])),
+                                                 "rest of the wave's tiles": us(np.median(tr[has, 3] - tr[has, 7])),
+                                                 "waves_with_a_tile": int(has.sum())}
     return rec
 out = {"last_tick": st,
-       "k_spill_apply_round0": table(0, ["start", "prefix+pending", "C[] build", "rows", "block sync", "used_cur atomics"]),
-       "k_spill_apply_last": table(1, ["start", "prefix+pending", "C[] build", "rows", "block sync", "used_cur atomics"]),
+       "k_spill_apply_round0": table(0, ["start", "prefix+pending", "C[] build", "rows", "block sync", "used_cur atomics"], True),
+       "k_spill_apply_last": table(1, ["start", "prefix+pending", "C[] build", "rows", "block sync", "used_cur atomics"], True),
        "k_cut_apply_rank": table(2, ["start", "thr+alive load", "rows", "reduce"])}
 tr = g.ktrace(3).astype(np.int64)
 live = tr[:, 0] > 0
