@@ -158,6 +158,10 @@ void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const 
                         hipStream_t s, bool rank_done = false);
 
 // --- CRUD over the assignment column ---
+// the requests of a call of at most 4 entries, passed in the kernel arguments (a = object indices, b = nodes / requesters)
+struct SmallInline { u32 a[4]; u32 b[4]; };
+void launch_lookup_small(const u32* assign, u64 n_obj, const u32* idx, u32 n, u32* out, DevStats* st, hipStream_t s,
+                         u32* done, u32 seq, const SmallInline* inl = nullptr);
 // done / seq (lookup, update_small, remove, pp_small): when the call is ONE workgroup, its last act is to store seq into
 // *done (mapped pinned memory) — the host spins on the word instead of waiting for the stream; nullptr = no word
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s,
@@ -168,9 +172,10 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
                    DevStats* st, hipStream_t s, u32* aff_life = nullptr);
 // n <= kSmallBatch validated entries (may be mapped host memory): last writer wins inside the batch, one launch
 void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr,
-                         u32* done = nullptr, u32 seq = 0);
+                         u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
-                   DevStats* st, hipStream_t s, u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0);
+                   DevStats* st, hipStream_t s, u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0,
+                   const SmallInline* inl = nullptr);
 // big random batches, partitioned by row window first (k_part_bin ...): part_applicable says whether a batch qualifies,
 // scratch = part_scratch_words(n_obj, n) u32 words of device memory
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node_or_null);
@@ -197,7 +202,7 @@ void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t 
 //     means "needs the general path", nothing was changed ---
 void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
                      const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                     u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0);
+                     u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s);

@@ -1915,6 +1915,24 @@ __device__ __forceinline__ void signal_done(u32* done, u32 seq) {
     if (threadIdx.x == 0) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // ... the word is
 }
 
+// Requests of the smallest calls (n <= 4: the reference's one-object-per-request flow) travel in the kernel arguments
+// instead of mapped pinned memory: the kernel saves a PCIe read round trip (1.3 us of a 7-9 us call, tools/sync_probe.py).
+__device__ __forceinline__ u32 inl_sel(const uint4 v, u32 k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+
+// lookup, micro-batch (n <= kSmallBatch): one workgroup; requests inline (ninl = n <= 4) or in mapped pinned memory,
+// results into mapped pinned memory, then the completion word
+__global__ __launch_bounds__(kSmallBatch) void k_lookup_small(const u32* __restrict__ assign, u64 n_obj,
+                                                              const u32* __restrict__ idx, u32 n, u32* __restrict__ out,
+                                                              DevStats* st, u32* done, u32 seq, u32 ninl, uint4 ia) {
+    const u32 k = threadIdx.x;
+    if (k < n) {
+        const u32 i = ninl ? inl_sel(ia, k) : idx[k];
+        if (i < n_obj) out[k] = assign[i];
+        else { out[k] = kNone; atomicAdd(&st->err, 1ull); }
+    }
+    signal_done(done, seq);
+}
+
 // lookup (local.rs:42-49): 12 B/lookup — idx read, assign gather, out write.  A lane takes FOUR consecutive lookups: one
 // dwordx4 index read, four independent gathers in flight before the first is used, one dwordx4 store (the scalar form —
 // one dependent 4-byte gather per lane and iteration — reached 40 % of the roofline on sequential indices and 7.7 % on
@@ -1993,11 +2011,15 @@ __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const
 // mapped host memory.  Sequential last-writer-wins inside the batch: an entry loses to any LATER entry for the same row.
 __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
                                                               const u32* __restrict__ node, u32 n,
-                                                              u32* __restrict__ aff_life, u32* done, u32 seq) {
+                                                              u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl,
+                                                              uint4 ia, uint4 ib) {
     __shared__ u32 li[kSmallBatch];
     const u32 k = threadIdx.x;
     u32 i = kNone, nd = kNone;
-    if (k < n) { i = idx[k]; nd = node[k]; }
+    if (k < n) {
+        i = ninl ? inl_sel(ia, k) : idx[k];
+        nd = ninl ? inl_sel(ib, k) : node[k];
+    }
     li[k] = i;
     __syncthreads();
     if (k < n) {
@@ -2017,7 +2039,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
 __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                    const u32* __restrict__ load, const u32* __restrict__ idx, u64 n,
                                                    u64* __restrict__ used, DevStats* st, u32* __restrict__ aff_life,
-                                                   u32* done, u32 seq) {
+                                                   u32* done, u32 seq, u32 ninl, uint4 ia) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* rel = reinterpret_cast<u64*>(smem);  // [m] load released per node (only when `used` is maintained)
     if (used) {
@@ -2026,10 +2048,11 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
     }
     u32 bad = 0;
     for (u64 k = (u64)blockIdx.x * kBlock + threadIdx.x; k < n; k += (u64)gridDim.x * kBlock) {
-        const u32 i = idx[k];
+        const u32 i = ninl ? inl_sel(ia, (u32)k) : idx[k];
         if (i >= n_obj) { ++bad; continue; }
+        const u32 li = used ? load[i] : 0u;  // requested with the exchange, not after it (one round trip, not two)
         const u32 old = atomicExch(&assign[i], kNone);
-        if (used && old < m) atomicAdd(&rel[old], (u64)load[i]);
+        if (used && old < m) atomicAdd(&rel[old], (u64)li);
         if (aff_life) aff_life[i] = kAffInactive;  // row lifecycle: a removed key is no longer an object
     }
     if (bad) atomicAdd(&st->err, (u64)bad);
@@ -2448,29 +2471,36 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
                                                           const u32* __restrict__ req, u32 n,
                                                           u32* __restrict__ out_node, u32* __restrict__ out_flag,
                                                           u32* __restrict__ status, u32* __restrict__ aff_life,
-                                                          u32* done, u32 seq) {
+                                                          u32* done, u32 seq, u32 ninl, uint4 ia, uint4 ib) {
     __shared__ u32 s_req[kSmallBatch], s_load[kSmallBatch], s_res[kSmallBatch];
     __shared__ u32 s_general;
     const u32 k = threadIdx.x;
     const bool valid = k < n;
     if (k == 0) s_general = 0;
     u32 i = 0, r = 0, c = kNone, l = 0;
+    u64 cj = 0, uj = 0;
+    bool r_alive = false;
+    const bool election = n > 1;  // a single request is its object's first request: no scratch round trips
     if (valid) {
-        i = idx[k];
-        r = req[k];
+        i = ninl ? inl_sel(ia, k) : idx[k];
+        r = ninl ? inl_sel(ib, k) : req[k];
+        // everything a request may need is requested at once: the call is a chain of device round trips, not bandwidth
         c = assign[i];
         l = load[i];
-        atomicMin(&pos[i], k);  // the first request of an object decides (batch order)
+        cj = cap[r];
+        uj = used[r];
+        r_alive = bit_of(alive_bits, r);
+        if (election) atomicMin(&pos[i], k);  // the first request of an object decides (batch order)
     }
     __syncthreads();
     bool first = false, claim = false;
     u32 winner = k;
     if (valid) {
-        winner = __hip_atomic_load(&pos[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (election) winner = __hip_atomic_load(&pos[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         first = winner == k;
         const bool dead_cur = c < m && !bit_of(alive_bits, c);   // service.rs:227-237 -> clean_server: general path
         const bool pending = first && c == kNone;
-        claim = pending && bit_of(alive_bits, r);
+        claim = pending && r_alive;
         if (dead_cur || (pending && !claim)) s_general = 1;
     }
     s_req[k] = claim ? r : kNone;
@@ -2480,7 +2510,6 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
     if (claim) {  // index-ordered inclusive prefix of the loads claiming requester r
         u64 pre = 0;
         for (u32 q = 0; q <= k; ++q) pre += (s_req[q] == r) ? (u64)s_load[q] : 0ull;
-        const u64 cj = cap[r], uj = used[r];
         const u64 fre = cj > uj ? cj - uj : 0;
         if (pre <= fre) nd = r;
         else s_general = 1;  // requester full: water-fill needed
@@ -2488,7 +2517,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
     s_res[k] = nd;
     __syncthreads();
     if (s_general) {  // hand over untouched
-        if (valid) pos[i] = kNone;
+        if (valid && election) pos[i] = kNone;
         if (k == 0) *status = 1;
         signal_done(done, seq);
         return;
@@ -2506,7 +2535,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
         }
         out_node[k] = nd;
         out_flag[k] = fl;
-        pos[i] = kNone;
+        if (election) pos[i] = kNone;
     }
     if (k == 0) *status = 0;
     signal_done(done, seq);
@@ -3056,18 +3085,28 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
     hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
     hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos, aff_life);
 }
-void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life, u32* done,
-                         u32 seq) {
+// inl (every micro-batch launcher): the n <= 4 requests themselves (a = indices, b = nodes / requesters), or nullptr
+static inline uint4 inl_a(const SmallInline* inl) { return inl ? make_uint4(inl->a[0], inl->a[1], inl->a[2], inl->a[3]) : make_uint4(0, 0, 0, 0); }
+static inline uint4 inl_b(const SmallInline* inl) { return inl ? make_uint4(inl->b[0], inl->b[1], inl->b[2], inl->b[3]) : make_uint4(0, 0, 0, 0); }
+void launch_lookup_small(const u32* assign, u64 n_obj, const u32* idx, u32 n, u32* out, DevStats* st, hipStream_t s,
+                         u32* done, u32 seq, const SmallInline* inl) {
     if (!n) return;
-    hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n, aff_life, done, seq);
+    hipLaunchKernelGGL(k_lookup_small, dim3(1), dim3(kSmallBatch), 0, s, assign, n_obj, idx, n, out, st, done, seq,
+                       inl ? n : 0u, inl_a(inl));
+}
+void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life, u32* done,
+                         u32 seq, const SmallInline* inl) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n, aff_life, done, seq,
+                       inl ? n : 0u, inl_a(inl), inl_b(inl));
 }
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
-                   hipStream_t s, u32* aff_life, u32* done, u32 seq) {
+                   hipStream_t s, u32* aff_life, u32* done, u32 seq, const SmallInline* inl) {
     if (!n) return;
     const unsigned g = grid_for(n, kBlock * 4, 256);
     if (g != 1) done = nullptr;  // (single-workgroup protocol)
     hipLaunchKernelGGL(k_remove, dim3(g), dim3(kBlock), used ? (size_t)m * sizeof(u64) : 0, s, assign,
-                       n_obj, m, load, idx, n, used, st, aff_life, done, seq);
+                       n_obj, m, load, idx, n, used, st, aff_life, done, seq, (inl && n <= 4) ? (u32)n : 0u, inl_a(inl));
 }
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
@@ -3156,9 +3195,9 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
 }
 void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
                      const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                     u32* aff_life, u32* done, u32 seq) {
+                     u32* aff_life, u32* done, u32 seq, const SmallInline* inl) {
     hipLaunchKernelGGL(k_pp_small, dim3(1), dim3(kSmallBatch), 0, s, assign, load, m, cap, alive_bits, used, pos, idx, req, n,
-                       out_node, out_flag, status, aff_life, done, seq);
+                       out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl));
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s) {

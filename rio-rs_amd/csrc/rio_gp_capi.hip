@@ -493,6 +493,14 @@ u32 small_begin(rio_gp* h) {
     return h->small_seq;
 }
 u32* small_done_dev(rio_gp* h) { return h->d_small + 5 * kSmallBatch; }
+bool small_inline(SmallInline* inl, uint64_t n, const uint32_t* a, const uint32_t* b) {
+    if (n > 4) return false;
+    for (uint64_t k = 0; k < 4; ++k) {
+        inl->a[k] = k < n ? a[k] : 0u;
+        inl->b[k] = (k < n && b) ? b[k] : 0u;
+    }
+    return true;
+}
 int small_wait(rio_gp* h, u32 seq) {
     volatile u32* w = h->h_small + 5 * kSmallBatch;
     const auto t0 = std::chrono::steady_clock::now();
@@ -896,10 +904,12 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (n <= (uint64_t)kSmallBatch) {  // micro-batch: the gather reads and writes mapped pinned memory, one launch + wait
-        memcpy(h->h_small, idx, n * sizeof(u32));
+        SmallInline inl;
+        const bool in_args = small_inline(&inl, n, idx, nullptr);  // n <= 4: the requests ride in the kernel arguments
+        if (!in_args) memcpy(h->h_small, idx, n * sizeof(u32));
         const u32 seq = small_begin(h);
-        launch_lookup(h->assign[h->cur], h->n, h->d_small, n, h->d_small + 2 * kSmallBatch, h->dstats, h->stream,
-                      small_done_dev(h), seq);
+        launch_lookup_small(h->assign[h->cur], h->n, h->d_small, (u32)n, h->d_small + 2 * kSmallBatch, h->dstats, h->stream,
+                            small_done_dev(h), seq, in_args ? &inl : nullptr);
         if ((rc = small_wait(h, seq))) return rc;
         memcpy(out_node, h->h_small + 2 * kSmallBatch, n * sizeof(u32));
         return RIO_GP_OK;
@@ -949,11 +959,15 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
     if (n <= (uint64_t)kSmallBatch) {
         // micro-batch (one first-touch update per activation in the reference flow, service.rs:244-252): the entries were
         // validated above, so the kernels read them from mapped pinned memory and nothing is copied, zeroed or read back
-        memcpy(h->h_small, idx, n * sizeof(u32));
-        memcpy(h->h_small + kSmallBatch, node, n * sizeof(u32));
+        SmallInline inl;
+        const bool in_args = small_inline(&inl, n, idx, node);
+        if (!in_args) {
+            memcpy(h->h_small, idx, n * sizeof(u32));
+            memcpy(h->h_small + kSmallBatch, node, n * sizeof(u32));
+        }
         const u32 seq = small_begin(h);
         launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream, aff_life(h),
-                            small_done_dev(h), seq);
+                            small_done_dev(h), seq, in_args ? &inl : nullptr);
         h->used_valid = false;
         h->have_solved = false;
         return small_wait(h, seq);
@@ -997,10 +1011,12 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     if (n <= (uint64_t)kSmallBatch) {  // micro-batch: validated above, read from mapped pinned memory, one launch + one wait
-        memcpy(h->h_small, idx, n * sizeof(u32));
+        SmallInline inl;
+        const bool in_args = small_inline(&inl, n, idx, nullptr);
+        if (!in_args) memcpy(h->h_small, idx, n * sizeof(u32));
         const u32 seq = small_begin(h);
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_small, n, h->used_valid ? h->used : nullptr, h->dstats,
-                      h->stream, aff_life(h), small_done_dev(h), seq);
+                      h->stream, aff_life(h), small_done_dev(h), seq, in_args ? &inl : nullptr);
         h->have_solved = false;
         return small_wait(h, seq);
     }
@@ -1113,13 +1129,17 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         // micro-batch: one workgroup, one launch, request/result arrays in mapped pinned memory (no staging copies)
         if ((rc = ensure_used(h))) return rc;
         u32 *hs = h->h_small, *ds = h->d_small;
-        memcpy(hs, idx, n * sizeof(u32));
-        memcpy(hs + kSmallBatch, requester, n * sizeof(u32));
+        SmallInline inl;
+        const bool in_args = small_inline(&inl, n, idx, requester);
+        if (!in_args) {
+            memcpy(hs, idx, n * sizeof(u32));
+            memcpy(hs + kSmallBatch, requester, n * sizeof(u32));
+        }
         hs[4 * kSmallBatch] = 2;  // neither 0 nor 1: the kernel must write it
         const u32 seq = small_begin(h);
         launch_pp_small(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, h->pos, ds, ds + kSmallBatch,
                         (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h),
-                        small_done_dev(h), seq);
+                        small_done_dev(h), seq, in_args ? &inl : nullptr);
         if ((rc = small_wait(h, seq))) return rc;
         const u32 status = hs[4 * kSmallBatch];
         if (status == 0) {

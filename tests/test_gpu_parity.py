@@ -163,16 +163,16 @@ def test_crud_micro_batches(gp, oracle, seed):
     g.set_objects(n, load, None)
     ref = np.full(n, NONE, np.uint32)
     for step in range(60):
-        k = int(rng.choice([1, 2, 7, 64, 255, 256]))
+        k = int(rng.choice([1, 2, 3, 4, 5, 7, 64, 255, 256]))   # <= 4: requests in the kernel arguments
         idx = rng.integers(0, 40 if step % 3 == 0 else n, k).astype(np.uint32)   # every third step: heavy duplication
         node = rng.integers(0, m, k).astype(np.uint32)
         node[rng.random(k) < 0.15] = NONE
         g.update_batch(idx, node)
         assert oracle.update_batch(ref, m, idx, node) == 0
-        q = rng.integers(0, n, int(rng.integers(1, 257))).astype(np.uint32)
+        q = rng.integers(0, n, int(rng.choice([1, 2, 3, 4, 5, int(rng.integers(1, 257))]))).astype(np.uint32)
         assert np.array_equal(g.lookup_batch(q), oracle.lookup_batch(ref, q))
         assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))
-        rm = rng.integers(0, 60 if step % 4 == 0 else n, int(rng.integers(1, 257))).astype(np.uint32)
+        rm = rng.integers(0, 60 if step % 4 == 0 else n, int(rng.choice([1, 3, 4, 5, int(rng.integers(1, 257))]))).astype(np.uint32)
         g.remove_batch(rm)
         oracle.remove_batch(ref, rm)
         assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))  # incremental == scratch
@@ -549,7 +549,7 @@ def test_place_pending_micro_batches(gp, oracle, seed, cap_mode):
             g.remove_batch(ii)
             oracle.remove_batch(ref, ii)
             used[:] = oracle.recompute_used(ref, load, m)
-        k = int(rng.choice([1, 1, 2, 3, 7, 32, 64, 200, 256]))
+        k = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 32, 64, 200, 256]))
         idx = rng.integers(0, min(n, 40 + 30 * step), k).astype(np.uint32)   # small id range: plenty of duplicates
         req = rng.integers(0, m, k).astype(np.uint32)
         node, flag = g.place_pending(idx, req)

@@ -13,7 +13,7 @@ def cp(a, b):
         print("profiles/" + b)
 for name in ("bench_n1.json", "bench_c5.json", "kernel_roofline.json", "kernel_roofline.txt", "churn_timeline.txt", "fixup_trace.json",
              "ops.json", "pytest_gpu.log", "smoke.log", "slowpath_churn.json", "slowpath_contended.json", "slowpath_skew.json",
-             "slowpath_churn_fusedk.json"):
+             "slowpath_churn_fusedk.json", "latency.txt"):
     cp("%s_%s" % (tag, name), "%s_%s" % (pre, name))
 cp("crud_ab.json", pre + "_crud_ab.json")
 for f in glob.glob(os.path.join(src, tag + "_prof", "*kernel_stats.csv")):

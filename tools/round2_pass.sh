@@ -23,6 +23,7 @@ if [ -z "$QUICK" ]; then
   timeout 600 python tools/measure_ops.py ${TAG} > $OUT/${TAG}_ops.log 2>&1
   timeout 300 python tools/fixup_trace.py 6 > $OUT/${TAG}_fixup_trace.json 2> $OUT/${TAG}_fixup_trace.err
   timeout 300 python tools/crud_ab.py 5 > $OUT/${TAG}_crud_ab.log 2>&1
+  ( timeout 200 python tools/sync_probe.py; timeout 200 python tools/latency_probe.py | tail -1; timeout 200 python tools/latency_small_ops.py | tail -1 ) > $OUT/${TAG}_latency.txt 2>&1
   for w in churn contended skew; do
     timeout 300 python tools/slowpath_workload.py $w 40 > $OUT/${TAG}_slowpath_$w.json 2> $OUT/${TAG}_slowpath_$w.err
   done
@@ -40,5 +41,6 @@ if [ -z "$QUICK" ]; then
   echo "---- ops"; tail -25 $OUT/${TAG}_ops.log
   echo "---- slow path"; for w in churn contended skew churn_fusedk; do cut -c1-260 $OUT/${TAG}_slowpath_$w.json; done
   tail -14 $OUT/${TAG}_churn_timeline.txt
+  echo "---- latencies"; cat $OUT/${TAG}_latency.txt
   echo "---- fix-up phase traces"; cat $OUT/${TAG}_fixup_trace.json; tail -3 $OUT/${TAG}_fixup_trace.err
 fi
