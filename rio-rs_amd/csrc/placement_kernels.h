@@ -188,7 +188,8 @@ void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u3
 // counter == nullptr: accumulate into st->evicted_clean.  ticket/host_out: self-resetting counter + total written to
 // mapped host memory by the last workgroup (dead_bits may itself be mapped host memory).
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s,
-                  u64* counter = nullptr, unsigned int* ticket = nullptr, u64* host_out = nullptr, u32* aff_life = nullptr);
+                  u64* counter = nullptr, unsigned int* ticket = nullptr, u64* host_out = nullptr, u32* aff_life = nullptr,
+                  u32 seq = 0 /* != 0: *host_out = total | seq << 40, the word the host spins on */);
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s);
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s);
 void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32* nload, const u32* naff, u64 n,

@@ -523,6 +523,14 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     }
     if (tid < 8) red[tid] = 0;
     if (tid == 0) cutmask = 0;
+    // this wave-1 lane's first word of the k_scan row counters (rows g, g + nb, ... of blkstat) is requested here, ahead of
+    // the H loads, instead of after the two barriers below: one dependent round trip less in a 4 us kernel
+    u64 bs_acc = 0;
+    u32 bs_r = G;
+    if (tid >= 64 && tid < 128) {
+        bs_r = g + nb * (lane >> 2);
+        if (bs_r < G) bs_acc = blkstat[(size_t)bs_r * 4 + (lane & 3)];
+    }
     u64 v[kResRows][2];
     resolve_column_sums(H, g, G, v, part, tot);      // two barriers inside: red / cutmask are published
     if (valid) {
@@ -543,8 +551,9 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
         }
     }
     if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows g, g+nb, ... of blkstat
-        u64 acc = 0;
-        for (u32 r = g + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
+        u64 acc = bs_acc;
+        if (bs_r < G)  // (more than one row per lane only for m < 128)
+            for (u32 r = bs_r + nb * 16; r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
         acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
         if (lane < 4) red[3 + lane] = acc;
     }
@@ -1650,6 +1659,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                                                            //     four dependent ~1 us round trips per lane and tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
     const int ktab = last ? 1 : 0;
+    constexpr u32 kKeepVal = 0xFFFFFFF0u;  // "this row is not written" in the staged decisions (no node id, not NONE)
     RIOGP_KT(ktab, 0);
     // Prologue: what is pending, and where does this workgroup's first wave start in the index-ordered spill prefix?
     // Every global operand of the prologue is requested before the first one is used (one round trip, not three): the
@@ -1802,7 +1812,9 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
             }
         }
         if (it == wstart) RIOGP_KT(ktab, 6);
-#define RIOGP_ROW(MK, L, E, IDX)                                                  \
+        uint4 ov = nv;  // the lane's four decisions leave as ONE 16-byte store (rows that stay pending keep their mark)
+        uint4 wv = make_uint4(kKeepVal, kKeepVal, kKeepVal, kKeepVal);  // what goes into the real assignment column
+#define RIOGP_ROW(MK, L, E, IDX, OUT, WOUT)                                       \
         if (MK) {                                                                 \
             u32 nd = kNone;                                                       \
             if (cnt && Q < F) {                                                   \
@@ -1814,24 +1826,33 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                 if (Q + L <= C[lo + 1]) nd = (u32)ord[lo];                        \
             }                                                                     \
             if (nd != kNone) {                                                    \
-                next[i0 + E] = nd;                                                \
-                if (scat) real_next[IDX] = nd;                                    \
+                OUT = nd;                                                         \
+                WOUT = nd;                                                        \
                 atomicAdd(&adm[nd], (u64)L);                                      \
                 pl_sum += L; ++pl_cnt;                                            \
             } else {                                                              \
                 if (last) {                                                       \
-                    next[i0 + E] = kNone;                                         \
-                    if (scat) real_next[IDX] = kNone;                             \
+                    OUT = kNone;                                                  \
+                    WOUT = kNone;                                                 \
                 }                                                                 \
                 rem_sum += L; ++rem_cnt;                                          \
             }                                                                     \
             Q += L;                                                               \
         }
-        RIOGP_ROW(mk0, l0, 0, iv.x)
-        RIOGP_ROW(mk1, l1, 1, iv.y)
-        RIOGP_ROW(mk2, l2, 2, iv.z)
-        RIOGP_ROW(mk3, l3, 3, iv.w)
+        RIOGP_ROW(mk0, l0, 0, iv.x, ov.x, wv.x)
+        RIOGP_ROW(mk1, l1, 1, iv.y, ov.y, wv.y)
+        RIOGP_ROW(mk2, l2, 2, iv.z, ov.z, wv.z)
+        RIOGP_ROW(mk3, l3, 3, iv.w, ov.w, wv.w)
 #undef RIOGP_ROW
+        if ((ov.x != nv.x) | (ov.y != nv.y) | (ov.z != nv.z) | (ov.w != nv.w)) *reinterpret_cast<uint4*>(next + i0) = ov;
+        if (scat) {  // the decisions of the packed rows go to their REAL rows: scattered 4-byte stores (~1 M per churn tick; transposing
+                     // them through LDS so that neighbouring lanes write neighbouring rows was measured: no gain, the cost
+                     // is the ~300 k distinct lines at the memory side, not the number of requests)
+            if (wv.x != kKeepVal) real_next[iv.x] = wv.x;
+            if (wv.y != kKeepVal) real_next[iv.y] = wv.y;
+            if (wv.z != kKeepVal) real_next[iv.z] = wv.z;
+            if (wv.w != kKeepVal) real_next[iv.w] = wv.w;
+        }
         if (it == wstart) RIOGP_KT(ktab, 7);
         run = run_end;
         lo_run = hi_run;
@@ -2280,38 +2301,49 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
 // clean_server(s) (local.rs:51-58): one coalesced pass, 4 B read per row, 4 B written per evicted row
 // counter: device accumulator of evicted rows.  ticket/host_out (optional): the last workgroup to finish copies the
 // total into mapped host memory and resets counter and ticket, so a synchronous call needs no memset / copy-back.
-__global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_obj, u32 m,
+__global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                const u32* __restrict__ dead_bits, u64* __restrict__ used,
                                                u64* __restrict__ counter, unsigned int* __restrict__ ticket,
-                                               u64* __restrict__ host_out, u32* __restrict__ aff_life) {
+                                               u64* __restrict__ host_out, u32* __restrict__ aff_life, u32 seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32* db = reinterpret_cast<u32*>(smem);
     __shared__ u32 any;
     __shared__ u32 ev_total;
     const u32 mwords = (m + 31) / 32;
     const int tid = threadIdx.x;
+    // At most 256 workgroups of 1 024 threads, a grid-stride loop with the next vector in flight: the kernel ends with two
+    // returning atomics per workgroup on ONE address (count, ticket), and those serialise at ~10 ns each — 2 048 workgroups
+    // of 256 threads spent 40 us there, five times the 8 us of streaming the column.
+    const u64 nvec = (n_obj + 3) / 4, stride = (u64)gridDim.x * kBlock;
+    u64 v = (u64)blockIdx.x * kBlock + tid;
+    uint4 c = make_uint4(kNone, kNone, kNone, kNone);
+    if (v < nvec) c = *reinterpret_cast<const uint4*>(assign + v * 4);  // requested before the bitmap set-up below
     if (tid == 0) { any = 0; ev_total = 0; }
     __syncthreads();
     u32 mine = 0;
-    for (u32 k = tid; k < mwords; k += blockDim.x) { const u32 v = dead_bits[k]; db[k] = v; mine |= v; }
+    for (u32 k = tid; k < mwords; k += kBlock) { const u32 w = dead_bits[k]; db[k] = w; mine |= w; }
     if (mine) any = 1;
     __syncthreads();
     if (!any) return;
     if (blockIdx.x == 0 && used)
-        for (u32 j = tid; j < m; j += blockDim.x)
+        for (u32 j = tid; j < m; j += kBlock)
             if (bit_of(db, j)) used[j] = 0;
     u32 ev = 0;
-    const u64 nvec = (n_obj + 3) / 4;
-    for (u64 v = (u64)blockIdx.x * blockDim.x + tid; v < nvec; v += (u64)gridDim.x * blockDim.x) {
-        const u64 i0 = v * 4;
-        uint4 c = *reinterpret_cast<const uint4*>(assign + i0);
+    for (; v < nvec; v += stride) {
+        const u64 i0 = v * 4, vn = v + stride;
+        uint4 cn = make_uint4(kNone, kNone, kNone, kNone);
+        if (vn < nvec) cn = *reinterpret_cast<const uint4*>(assign + vn * 4);
         const bool e0 = i0 + 0 < n_obj && c.x < m && bit_of(db, c.x), e1 = i0 + 1 < n_obj && c.y < m && bit_of(db, c.y);
         const bool e2 = i0 + 2 < n_obj && c.z < m && bit_of(db, c.z), e3 = i0 + 3 < n_obj && c.w < m && bit_of(db, c.w);
-        if (e0 | e1 | e2 | e3) {
-            // the lane's four rows go back as ONE 16-byte store (up to four masked 4-byte stores cost 40 us per pass over
-            // 10 M rows with 10 % of them evicted, against 8 us of reading); the column is padded past n_obj
+        const bool mine_ev = e0 | e1 | e2 | e3;
+        // A wave that evicts anything writes its whole kilobyte back, every lane its 16 bytes (unchanged rows keep their
+        // value; nothing else writes the column while this runs): full 128-byte lines instead of scattered 16-byte pieces
+        // of them.  The column is padded past n_obj.
+        if (__ballot(mine_ev)) {
             c.x = e0 ? kNone : c.x; c.y = e1 ? kNone : c.y; c.z = e2 ? kNone : c.z; c.w = e3 ? kNone : c.w;
             *reinterpret_cast<uint4*>(assign + i0) = c;
+        }
+        if (mine_ev) {
             if (aff_life) {  // row lifecycle: retain() drops the entries (local.rs:51-58); they come back on their next request
                 if (e0) aff_life[i0 + 0] = kAffInactive;
                 if (e1) aff_life[i0 + 1] = kAffInactive;
@@ -2320,6 +2352,7 @@ __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_o
             }
             ev += e0 + e1 + e2 + e3;
         }
+        c = cn;
     }
     ev = wave_sum32(ev);
     if ((tid & 63) == 0 && ev) atomicAdd(&ev_total, ev);
@@ -2331,7 +2364,8 @@ __global__ __launch_bounds__(256) void k_clean(u32* __restrict__ assign, u64 n_o
             const unsigned int t = __hip_atomic_fetch_add(ticket, 1u + (unsigned int)(before & 0ull), __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT);
             if (t == gridDim.x - 1) {
-                *host_out = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the total, tagged with the caller's sequence number in bits 40..63: the host spins on the tag (one 8-byte store)
+                *host_out = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | ((u64)seq << 40);
                 __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -3160,10 +3194,10 @@ void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u3
     }
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
-                  u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life) {
+                  u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life, u32 seq) {
     const size_t lds = (size_t)((m + 31) / 32 + 4) * sizeof(u32);
-    hipLaunchKernelGGL(k_clean, dim3(grid_for((n_obj + 3) / 4, 256, 2048)), dim3(256), lds, s, assign, n_obj, m,
-                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out, aff_life);
+    hipLaunchKernelGGL(k_clean, dim3(grid_for((n_obj + 3) / 4, kBlock, 256)), dim3(kBlock), lds, s, assign, n_obj, m,
+                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out, aff_life, seq);
 }
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s) {
     (void)hipMemsetAsync(used, 0, (size_t)m * sizeof(u64), s);

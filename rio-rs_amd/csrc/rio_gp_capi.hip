@@ -1042,11 +1042,25 @@ int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evi
         if ((dead_bitmap[j >> 6] >> (j & 63)) & 1ull) { h->h_cs[j >> 5] |= 1u << (j & 31); any = true; }
     h->have_solved = false;
     if (!any) return RIO_GP_OK;  // retain() with a predicate nothing matches
+    const u32 seq = (small_begin(h) & 0xFFFFFFu) | 0x800000u;  // 24 bits, never 0
     launch_clean(h->assign[h->cur], h->n, h->m, h->d_cs, h->used_valid ? h->used : nullptr, h->dstats, h->stream,
-                 h->cs_cnt, h->cs_ticket, reinterpret_cast<u64*>(h->d_cs + h->cs_words), aff_life(h));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
-    if (evicted) *evicted = *h_count;
+                 h->cs_cnt, h->cs_ticket, reinterpret_cast<u64*>(h->d_cs + h->cs_words), aff_life(h), seq);
+    {   // the last workgroup stores total | seq << 40 into mapped pinned memory: spin on the tag, ask the stream after 50 ms
+        volatile u64* w = h_count;
+        const auto t0 = std::chrono::steady_clock::now();
+        u32 spins = 0;
+        while ((*w >> 40) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+        }
+        if ((*w >> 40) != seq) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipGetLastError());
+            if ((*w >> 40) != seq) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_clean_servers: the kernel left no total");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (evicted) *evicted = *h_count & ((1ull << 40) - 1);
     return RIO_GP_OK;
 }
 

@@ -37,6 +37,14 @@ def table(t, names, first_tile=False):
         d = tr[live, i] - tr[live, i - 1]
         rec[nm + "_us_median_max"] = [us(np.median(d)), us(d.max())]
     rec["end_minus_first_start_us_max"] = us(tr[live, len(names) - 1].max() - t0)
+    if first_tile:   # where along the index-ordered prefix are the slow workgroups?  mean of 16 consecutive workgroups each
+        idx = np.flatnonzero(live)
+        rows_d = (tr[:, 3] - tr[:, 2])[live]
+        sync_d = (tr[:, 4] - tr[:, 3])[live]
+        nb = max(1, len(idx) // 16)
+        rec["rows_us_mean_by_16th_of_the_grid"] = [round(us(rows_d[k * nb:(k + 1) * nb].mean()), 2) for k in range(16) if len(rows_d[k * nb:(k + 1) * nb])]
+        rec["rows+sync_us_mean_by_16th_of_the_grid"] = [round(us((rows_d + sync_d)[k * nb:(k + 1) * nb].mean()), 2) for k in range(16) if len(rows_d[k * nb:(k + 1) * nb])]
+        rec["rows_us_deciles"] = [round(us(x), 2) for x in np.percentile(rows_d, [10, 30, 50, 70, 90, 100])]
     if first_tile:   # slots 6 / 7: wave 0's first tile — scan + bracket done, rows done (0 when the wave had no tile)
         has = live & (tr[:, 6] > tr[:, 2]) & (tr[:, 7] >= tr[:, 6])
         if has.any():
