@@ -67,6 +67,56 @@ def test_backend_is_hip(gp):
     g.close()
 
 
+def test_host_waits_without_the_runtime(gp, oracle):
+    """Synchronous calls spin on a word their last kernel stores into mapped pinned memory (completion word of the
+    single-workgroup calls, sequence number in the pinned rows of k_resolve / the last water-fill round, the tagged total
+    of k_clean) instead of hipStreamSynchronize.  Thousands of back-to-back calls of every kind, results checked: a word
+    that arrives before the data it guards, or a stale sequence number, shows up as a wrong answer here."""
+    rng = np.random.default_rng(77)
+    n, m = 50_000, 64
+    load = rng.integers(1, 50, n).astype(np.uint32)
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(np.full(m, 1 << 40, np.uint64), np.ones(m, np.uint8))
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    for step in range(1500):
+        k = int(rng.integers(1, 7))
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        node = rng.integers(0, m, k).astype(np.uint32)
+        g.update_batch(idx, node)
+        oracle.update_batch(ref, m, idx, node)
+        q = rng.integers(0, n, int(rng.integers(1, 6))).astype(np.uint32)
+        assert np.array_equal(g.lookup_batch(q), ref[q]), step
+        if step % 7 == 0:
+            rm = rng.integers(0, n, 3).astype(np.uint32)
+            g.remove_batch(rm)
+            oracle.remove_batch(ref, rm)
+        if step % 50 == 0:
+            j = int(rng.integers(m))
+            assert g.clean_server(j) == int((ref == j).sum()), step
+            ref[ref == j] = NONE
+    assert np.array_equal(g.get_assign(), ref)
+    # the probe kernels behind tools/sync_probe.py: both ways of waiting complete and take microseconds, not milliseconds
+    for mode in (20, 21, 22, 23):
+        assert 0 < g.stream_probe(mode, 200) * 1000.0 < 200.0, mode
+    g.close()
+    # synchronous ticks, alternating fast path and fix-up path: counters and tables of every tick against the oracle
+    n, m = 300_000, 100
+    cur, load, aff, cap, alive = _rand_case(np.random.default_rng(5), n, m, cap_scale=1.6, p_alive=1.0)
+    g = gp.GpuPlacement(n, m, spill_rounds=2)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, aff)
+    g.set_assign(cur)
+    for t in range(40):
+        if t % 3 == 0:
+            alive = (np.random.default_rng(100 + t).random(m) > 0.15).astype(np.uint8)
+            g.set_alive_all(alive)
+        cur, used, ost = oracle.tick(cur, load, aff, cap, alive, 2)
+        assert g.tick() == ost, t
+        assert np.array_equal(g.get_assign(), cur), t
+    g.close()
+
+
 # ---- reference known-answer tests, through the GPU (object_placement_backend.rs:11-34 etc.) ----
 
 def test_backend_save_and_load_dense(gp):
