@@ -29,6 +29,10 @@ int rio_gp_debug_set_fixup(rio_gp_t* h, int impl, int speculate);
 void rio_gp_debug_set_scan_nt(int mode);
 /* window of the partitioned update / remove batches: 1 << shift rows, shift 12..14 (default 14); process-wide. */
 void rio_gp_debug_set_part_shift(int shift);
+/* first row of wave range `wave` (0 .. *n_waves; the last value is the end of the table rounded up to a tile) of a table
+ * of n_objects rows, exactly as the kernels compute it (a multiply-shift instead of a 64-bit division); host-only, needs
+ * no GPU: tests/test_abi_symbols.py checks it against the plain division. */
+uint64_t rio_gp_debug_wave_row_lo(uint64_t n_objects, uint32_t n_nodes, uint32_t wave, uint32_t* n_waves);
 /* read (out2048 != NULL: 256 workgroups x 8 words) and switch the phase trace of the cut kernels */
 int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048);
 /* phase traces of the other fix-up kernels (switched by rio_gp_debug_cut_trace's enable): table 0 / 1 = k_spill_apply

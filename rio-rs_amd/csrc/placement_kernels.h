@@ -45,6 +45,7 @@ struct Plan {
     const u32* wcnt;
 };
 Plan make_plan(u64 n, u32 m, u32 max_blocks);
+u64 plan_wave_row_lo(u64 n, u32 m, u32 gw, u32* nw_out);  // first row of wave range gw, as the device computes it (debug / tests)
 
 // Accumulators of one solve, device resident (all 64-bit so they can be atomically added).
 struct DevStats {

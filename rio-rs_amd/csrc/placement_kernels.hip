@@ -153,6 +153,13 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     return p;
 }
 
+// the split as the kernels compute it, for the host-side check of the multiply-shift against the plain division
+u64 plan_wave_row_lo(u64 n, u32 m, u32 gw, u32* nw_out) {
+    const Plan p = make_plan(n, m, 0);
+    if (nw_out) *nw_out = p.nw;
+    return wave_row_lo(p, gw);
+}
+
 __host__ __device__ __forceinline__ size_t scan_lds_bytes_dev(u32 m) {
     const u32 mwords = (m + 31) / 32;
     const size_t b = kSmall + ((size_t)2 * m + 2) * sizeof(u64) + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 64;

@@ -1730,6 +1730,9 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
 
 void rio_gp_debug_set_scan_nt(int mode) { set_scan_nt(mode); }
 void rio_gp_debug_set_part_shift(int shift) { set_part_shift(shift); }
+uint64_t rio_gp_debug_wave_row_lo(uint64_t n_objects, uint32_t n_nodes, uint32_t wave, uint32_t* n_waves) {
+    return plan_wave_row_lo(n_objects, n_nodes, wave, n_waves);
+}
 
 int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048) {
     if (!h) return RIO_GP_EINVAL;

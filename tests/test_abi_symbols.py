@@ -222,3 +222,31 @@ def test_rust_structs_mirror_the_c_layout():
         c = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}" % c_name, hdrs, flags=re.S).group(1)
         c_fields = [f.strip() for decl in re.findall(r"u?int(?:8|16|32|64)_t\s+([^;]+);", c) for f in decl.split(",")]
         assert rust_fields == c_fields, (rust_name, rust_fields, c_fields)
+
+
+def test_row_split_without_division_equals_the_division(built):
+    """Every kernel splits the table into wave ranges with wave_row_lo (placement_kernels.hip): a multiply-shift by a per-plan
+    constant instead of the 64-bit division gw * tiles / nw.  Host-side check over EVERY wave index of many table sizes,
+    among them the configured ones (10 M, 100 M), the largest (2^31 - 1 rows) and the sizes around every boundary."""
+    L = ctypes.CDLL(built.LIB_PATH)
+    f = L.rio_gp_debug_wave_row_lo
+    f.restype = ctypes.c_uint64
+    f.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    import random
+    rnd = random.Random(9)
+    sizes = [1, 2, 255, 256, 257, 4095, 4096, 4097, 65535, 65536, 1 << 20, (1 << 20) + 255, 10_000_000, 40_000_000,
+             100_000_000, 1_500_000_000, (1 << 31) - 1]
+    sizes += [256 * 16 * g + d for g in (1, 2, 255, 256, 257) for d in (-1, 0, 1)]
+    sizes += [rnd.randrange(1, 1 << 31) for _ in range(40)] + [rnd.randrange(1, 1 << 22) for _ in range(40)]
+    for n in sizes:
+        nw = ctypes.c_uint32(0)
+        f(n, 64, 0, ctypes.byref(nw))
+        tiles = max(1, (n + 255) // 256)
+        assert 16 <= nw.value <= 4096 and nw.value % 16 == 0
+        prev = 0
+        for gw in range(nw.value + 1):
+            got = f(n, 64, gw, None)
+            assert got == (gw * tiles // nw.value) * 256, (n, gw, got)
+            assert got >= prev
+            prev = got
+        assert prev == tiles * 256
