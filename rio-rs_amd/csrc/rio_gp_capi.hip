@@ -1108,12 +1108,14 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     // (2)(3) first request per row decides; gather the virtual table (rows = requests)
     launch_pp_gather(assign, h->load, d_idx, d_req, n, h->pos, vcur, vload, vaff, h->stream);
     // (4) solve the virtual table against the committed `used`
-    const Plan vp = make_plan(n, h->m, 0);
+    Plan vp = make_plan(n, h->m, 0);
+    const u64 seq = ++h->wait_seq;
+    vp.mark = seq;  // k_resolve's pinned partial rows carry it: the verdict is waited for without the runtime (spin_rows)
     const Table vtab{vcur, vload, vaff, vnext};
     const NodeTab vnt{h->cap, h->alive_bits, h->used};
     launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
     launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!spin_rows(h->h_slots, resolve_blocks(h->m), seq)) HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     {
         const DevStats v = reduce_slot(h, 0, h->m);
