@@ -82,7 +82,8 @@ int rio_op_set_object_load(rio_op_t* p, const char* struct_name, const char* obj
 
 /* Service::get_or_create_placement (service.rs:193-254) + check_address_mismatch (service.rs:261-298)
  * for one request arriving at server `self_address`: returns the address the object lives on now and
- * *flag = RIO_GP_FLAG_{LOCAL,REDIRECT,PLACED,SPILLED,UNPLACED} (UNPLACED: out is ""). */
+ * *flag = RIO_GP_FLAG_{LOCAL,REDIRECT,PLACED,SPILLED,UNPLACED} (UNPLACED: out is ""), with RIO_GP_FLAG_REPLACED OR-ed on
+ * when the object was found on a server that is not alive (that server was cleaned, the object re-placed). */
 int rio_op_get_or_create_placement(rio_op_t* p, const char* struct_name, const char* object_id,
                                    const char* self_address, char* out, size_t out_cap, uint32_t* flag);
 /* The same for n requests at once, processed as if sequentially in array order. */

@@ -76,6 +76,12 @@ extern "C" {
 #define RIO_GP_FLAG_PLACED 2u     /* was unplaced/evicted, now first-touch placed on the requester (service.rs:244-252) */
 #define RIO_GP_FLAG_SPILLED 3u    /* requester full: placed on another node (capacity extension; caller redirects) */
 #define RIO_GP_FLAG_UNPLACED 4u   /* no capacity anywhere: stays RIO_GP_NONE */
+/* OR-ed onto PLACED / SPILLED / UNPLACED of the request that found its object on a server that is not alive: that server
+ * was cleaned (clean_server, service.rs:227-237) and the object re-placed by this call — check_address_mismatch's
+ * "placed elsewhere, but there is dead" branch (service.rs:268-285).  Later requests for the same object in the same batch
+ * observe the new placement (LOCAL / REDIRECT). */
+#define RIO_GP_FLAG_REPLACED 0x10u
+#define RIO_GP_FLAG_MASK 0x0Fu    /* the five outcomes above */
 
 typedef struct rio_gp rio_gp_t;
 

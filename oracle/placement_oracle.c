@@ -257,9 +257,11 @@ int orc_place_pending(uint32_t* assign, const uint32_t* load, uint64_t n_obj, co
     /* (1) service.rs:227-237: a requested object placed on an inactive server triggers
      *     clean_server(that server) — ALL of its objects are un-placed. */
     int any_dead = 0;
+    uint8_t* wasdead = (uint8_t*)calloc((size_t)n + 1, 1);  /* the request found its object on a server that is not alive */
+    if (!wasdead) return 4;
     for (uint64_t k = 0; k < n; ++k) {
         uint32_t c = assign[idx[k]];
-        if (c != ORC_NONE && c < m && !alive[c]) { dead[c >> 6] |= 1ull << (c & 63); any_dead = 1; }
+        if (c != ORC_NONE && c < m && !alive[c]) { dead[c >> 6] |= 1ull << (c & 63); any_dead = 1; wasdead[k] = 1; }
     }
     if (any_dead) {
         orc_clean_servers(assign, n_obj, dead, m);
@@ -304,9 +306,12 @@ int orc_place_pending(uint32_t* assign, const uint32_t* load, uint64_t n_obj, co
         else if (first[k] && state[k] == 3) fl = 3;   /* SPILLED */
         else if (nd == ORC_NONE) fl = 4;              /* UNPLACED */
         else fl = (nd == requester[k]) ? 0u : 1u;     /* LOCAL / REDIRECT */
+        /* service.rs:268-285: placed elsewhere, there is dead -> cleaned and re-placed by this request (the first one
+         * for the object; later ones observe the new placement) */
+        if (first[k] && wasdead[k]) fl |= ORC_FLAG_REPLACED;
         out_node[k] = nd;
         if (out_flag) out_flag[k] = fl;
     }
-    free(dead); free(first); free(state); free(rem); free(slot_node); free(run); free(fre); free(seen);
+    free(dead); free(first); free(state); free(rem); free(slot_node); free(run); free(fre); free(seen); free(wasdead);
     return 0;
 }

@@ -28,6 +28,7 @@ extern "C" {
 /* affinity value of a row that is not an object (RIO_GP_AFF_INACTIVE): a solve keeps it where it is if it is
  * placed on a live node, and never places it otherwise; it is not counted in n_objects */
 #define ORC_AFF_INACTIVE 0xFFFFFFFEu
+#define ORC_FLAG_REPLACED 0x10u  /* OR-ed onto the outcome of a request that found its object on a dead server (service.rs:268-285) */
 
 /* identical layout to rio_gp_stats (include/rio_gpu_placement.h) */
 typedef struct orc_stats {

@@ -13,6 +13,7 @@ constexpr u32 kNone = 0xFFFFFFFFu;       // unplaced (RIO_GP_NONE)
 constexpr u32 kSpillMark = 0xFFFFFFFEu;  // pending, waiting for the water-fill (never survives a solve)
 constexpr u32 kSkipMark = 0xFFFFFFFDu;   // virtual-table row that is a duplicate request (place_pending)
 constexpr u32 kAffInactive = 0xFFFFFFFEu;  // AFFINITY of a row that is not an object (RIO_GP_AFF_INACTIVE): never placed
+constexpr u32 kFlagReplaced = 0x10u;  // RIO_GP_FLAG_REPLACED (rio_gpu_placement.h)
 constexpr u32 kNoCut = 0xFFFFFFFFu;
 
 constexpr int kWaves = 16;           // waves per workgroup of the streaming kernels
@@ -207,7 +208,7 @@ void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const 
                      u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
-                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s);
+                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead = nullptr);
 void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const u32* req, u64 n, u32* pos_scratch,
                       u32* vcur, u32* vload, u32* vaff, hipStream_t s);
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,

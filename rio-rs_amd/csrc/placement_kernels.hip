@@ -2434,12 +2434,16 @@ __global__ __launch_bounds__(kBlock) void k_used(const u32* __restrict__ assign,
 // (1) service.rs:227-237: a requested row placed on a dead node marks that node for clean_server
 __global__ void k_pp_mark_dead(const u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ alive_bits,
                                const u32* __restrict__ idx, const u32* __restrict__ req, u64 n,
-                               u32* __restrict__ dead_bits, DevStats* st) {
+                               u32* __restrict__ dead_bits, DevStats* st, u32* __restrict__ req_dead) {
+    // req_dead (optional, the call's flag column): RIO_GP_FLAG_REPLACED for a request that finds its object on a dead node,
+    // 0 otherwise — k_pp_output keeps the bit for the FIRST request of the object (service.rs:268-285)
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k];
-        if (i >= n_obj || req[k] >= m) { atomicAdd(&st->err, 1ull); continue; }
+        if (i >= n_obj || req[k] >= m) { atomicAdd(&st->err, 1ull); if (req_dead) req_dead[k] = 0; continue; }
         const u32 c = assign[i];
-        if (c < m && !bit_of(alive_bits, c)) atomicOr(&dead_bits[c >> 5], 1u << (c & 31));
+        const bool dead = c < m && !bit_of(alive_bits, c);
+        if (dead) atomicOr(&dead_bits[c >> 5], 1u << (c & 31));
+        if (req_dead) req_dead[k] = dead ? kFlagReplaced : 0u;
     }
 }
 // (2) first request of a row decides (atomicMin of position), (3) gather the virtual table
@@ -2489,7 +2493,8 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
             fl = claimed ? 2u : 3u;                                // PLACED | SPILLED
         } else fl = (nd == r) ? 0u : 1u;                           // LOCAL | REDIRECT
         out_node[k] = nd;
-        if (out_flag) out_flag[k] = fl;
+        // the column still holds k_pp_mark_dead's "found on a dead node" bits: the first request of the object keeps its own
+        if (out_flag) out_flag[k] = fl | (vcur[k] == kNone ? (out_flag[k] & kFlagReplaced) : 0u);
         pos[i] = kNone;
     }
 }
@@ -3241,10 +3246,10 @@ void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const 
                        out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl));
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
-                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s) {
+                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead) {
     (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
     hipLaunchKernelGGL(k_pp_mark_dead, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, alive_bits, idx,
-                       req, n, dead_bits, st);
+                       req, n, dead_bits, st, req_dead);
 }
 void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const u32* req, u64 n, u32* pos, u32* vcur,
                       u32* vload, u32* vaff, hipStream_t s) {

@@ -1098,7 +1098,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     if ((rc = ensure_used(h))) return rc;
     if ((rc = zero_stats(h))) return rc;
     // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
-    launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream);
+    launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream, d_flag);
     if (check_entries) {
         if ((rc = read_stats(h))) return rc;
         if (h->h_stats[0].err)

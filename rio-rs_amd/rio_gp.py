@@ -17,6 +17,8 @@ CAP_INF = 0xFFFFFFFFFFFFFFFF
 AFF_INACTIVE = 0xFFFFFFFE       # RIO_GP_AFF_INACTIVE: affinity of a row that is not an object
 CFG_ROW_LIFECYCLE = 1           # RIO_GP_CFG_ROW_LIFECYCLE
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
+FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleaned and re-placed by this request
+FLAG_MASK = 0x0F
 OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM = range(5)
 
 SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "stream_probe.hip",

@@ -56,6 +56,10 @@ pub const FLAG_REDIRECT: u32 = 1;
 pub const FLAG_PLACED: u32 = 2;
 pub const FLAG_SPILLED: u32 = 3;
 pub const FLAG_UNPLACED: u32 = 4;
+/// OR-ed onto PLACED / SPILLED / UNPLACED: the object was found on a server that is not alive; that server was cleaned
+/// and the object re-placed by this call (service.rs:268-285).
+pub const FLAG_REPLACED: u32 = 0x10;
+pub const FLAG_MASK: u32 = 0x0F;
 
 #[link(name = "rio_gp")]
 extern "C" {
@@ -142,7 +146,7 @@ impl GpuObjectPlacement {
         check(unsafe { rio_op_get_or_create_placement(self.inner.0, ty.as_ptr(), id.as_ptr(), me.as_ptr(),
                                                       buf.as_mut_ptr(), buf.len(), &mut flag) }, self)?;
         let s = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
-        Ok((if flag == FLAG_UNPLACED { None } else { Some(s) }, flag))
+        Ok((if flag & FLAG_MASK == FLAG_UNPLACED { None } else { Some(s) }, flag))
     }
 }
 

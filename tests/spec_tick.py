@@ -100,6 +100,7 @@ def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2):
     m = len(cap)
     # a requested object on a node that is not alive: clean_server(that node) — ALL of its objects are un-placed
     dead = {assign[i] for i in idx if assign[i] != NONE and assign[i] < m and not alive[assign[i]]}
+    found_dead = [assign[i] in dead for i in idx]   # this request found its object on a server that is not alive
     if dead:
         for r in range(len(assign)):
             if assign[r] in dead:
@@ -143,6 +144,8 @@ def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2):
             fl = 4                             # UNPLACED
         else:
             fl = 0 if nd == r else 1           # LOCAL / REDIRECT
+        if decided[i] == k and found_dead[k]:
+            fl |= 0x10                         # REPLACED: the server was cleaned, the object re-placed by this request
         out_node.append(nd)
         out_flag.append(fl)
     return out_node, out_flag

@@ -104,7 +104,7 @@ def test_move_object_on_server_failure(gp):
     assert again == first and flag == gp.FLAG_REDIRECT                 # ResponseError::Redirect
     p.set_member("0.0.0.0:7001", False)                                # the host dies
     second, flag = p.get_or_create_placement("MockService", "1", "0.0.0.0:7002")
-    assert second == "0.0.0.0:7002" and flag == gp.FLAG_PLACED
+    assert second == "0.0.0.0:7002" and flag == gp.FLAG_PLACED | gp.FLAG_REPLACED   # found on the dead host, re-placed
     assert first != second                                             # assert_ne!(first_server, second_server)
 
 
@@ -163,7 +163,7 @@ def test_random_differential_vs_reference_restatement(gp, oracle, seed):
             want = oracle.get_or_create_placement(o, st, me, ty, oid)
             assert got == want, (step, ty, oid)
             verdict = oracle.check_address_mismatch(o, st, me, want)
-            assert verdict == ("ok" if flag in (gp.FLAG_LOCAL, gp.FLAG_PLACED) else "redirect")
+            assert verdict == ("ok" if flag & gp.FLAG_MASK in (gp.FLAG_LOCAL, gp.FLAG_PLACED) else "redirect")
         else:
             assert p.lookup(ty, oid) == o.lookup(ty, oid), step
     for ty, oid in keys:

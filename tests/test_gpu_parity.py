@@ -572,6 +572,49 @@ def test_place_pending_random(gp, oracle, seed, cap_inf):
     g.close()
 
 
+def test_place_pending_replaced_flag(gp, oracle):
+    """RIO_GP_FLAG_REPLACED (service.rs:268-285): the known-answer case of the oracle test, and a
+    large batch in which a tenth of the nodes has just died."""
+    assign = np.array([0, 0, 1, NONE], np.uint32)
+    g = gp.GpuPlacement(4, 3)
+    g.set_nodes(np.full(3, INF, np.uint64), np.array([0, 1, 1], np.uint8))
+    g.set_objects(4, np.ones(4, np.uint32), None)
+    g.set_assign(assign)
+    node, flag = g.place_pending(np.array([0, 0, 2, 1, 3], np.uint32), np.array([1, 2, 1, 2, 2], np.uint32))
+    assert list(node) == [1, 1, 1, 2, 2]
+    assert list(flag) == [gp.FLAG_PLACED | gp.FLAG_REPLACED, gp.FLAG_REDIRECT, gp.FLAG_LOCAL,
+                          gp.FLAG_PLACED | gp.FLAG_REPLACED, gp.FLAG_PLACED]
+    assert list(g.get_assign()) == [1, 2, 1, 2]
+    g.close()
+    rng = np.random.default_rng(8)
+    n, m, k = 200_000, 300, 50_000
+    load = rng.integers(1, 20, n).astype(np.uint32)
+    ref = rng.integers(0, m, n).astype(np.uint32)
+    ref[rng.random(n) < 0.2] = NONE
+    alive = (rng.random(m) > 0.1).astype(np.uint8)
+    cap = np.full(m, int(load.sum()), np.uint64)
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    g.set_assign(ref)
+    used = oracle.recompute_used(ref, load, m)
+    idx = rng.integers(0, n, k).astype(np.uint32)
+    req = np.flatnonzero(alive)[rng.integers(0, int(alive.sum()), k)].astype(np.uint32)
+    start = ref.copy()
+    node, flag = g.place_pending(idx, req)
+    wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+    assert np.array_equal(node, wnode) and np.array_equal(flag, wflag)
+    rep = (flag & gp.FLAG_REPLACED) != 0
+    assert rep.sum() > 1000
+    on_dead = (start[idx] != NONE) & (alive[np.minimum(start[idx], m - 1)] == 0)
+    assert not (rep & ~on_dead).any()                      # only requests that found their object on a dead node ...
+    _, firsts = np.unique(idx, return_index=True)
+    is_first = np.zeros(k, bool); is_first[firsts] = True
+    assert np.array_equal(rep, on_dead & is_first)         # ... and only the first request of each such object
+    assert np.array_equal(g.get_assign(), ref)
+    g.close()
+
+
 @pytest.mark.parametrize("seed,cap_mode", [(0, "inf"), (1, "tight"), (2, "roomy"), (3, "tight")])
 def test_place_pending_micro_batches(gp, oracle, seed, cap_mode):
     """Batches of 1..256 requests take the one-launch micro-batch kernel (k_pp_small) when nothing heavy is

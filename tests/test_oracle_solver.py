@@ -46,15 +46,23 @@ def test_place_pending_equals_reference_policy_when_capacity_is_infinite(oracle,
         nreq = int(rng.integers(1, 60))
         idx = rng.integers(0, n_obj, nreq).astype(np.uint32)           # duplicates on purpose
         req = live[rng.integers(0, len(live), nreq)].astype(np.uint32)  # requesters are live servers
+        start = assign.copy()
         out_node, out_flag = oracle.place_pending(assign, load, cap, alive, used, idx, req)
+        seen = set()
         for k in range(nreq):
             before = provider.lookup("Obj", str(idx[k]))
             got = oracle.get_or_create_placement(provider, storage, _addr(int(req[k])), "Obj", str(idx[k]))
             assert got == _addr(int(out_node[k])), (step, k)
             verdict = oracle.check_address_mismatch(provider, storage, _addr(int(req[k])), got)
-            assert verdict == ("ok" if out_flag[k] in (0, 2) else "redirect")
-            if out_flag[k] == 2:
+            base = int(out_flag[k]) & 0x0F
+            assert verdict == ("ok" if base in (0, 2) else "redirect")
+            if base == 2:
                 assert before is None or before != got
+            # REPLACED (service.rs:268-285): the first request of an object that sat on a dead server when the batch arrived
+            first = int(idx[k]) not in seen
+            seen.add(int(idx[k]))
+            was_dead = start[idx[k]] != NONE and not alive[start[idx[k]]]
+            assert bool(int(out_flag[k]) & 0x10) == bool(first and was_dead), (step, k)
         for i in range(n_obj):  # whole table identical, including bulk evictions
             v = provider.lookup("Obj", str(i))
             assert (v is None and assign[i] == NONE) or v == _addr(int(assign[i]))
@@ -187,3 +195,20 @@ def test_invalid_arguments(oracle):
     with pytest.raises(ValueError):
         oracle.lookup_batch(assign, [4])
     assert np.all(assign == NONE)
+
+
+def test_place_pending_replaced_flag_known_answer(oracle):
+    """service.rs:268-285 folded into the flag: a request that finds its object on a server
+    that is not alive gets REPLACED OR-ed onto its outcome — that server is cleaned, the object re-placed; later requests
+    for the same object in the batch observe the new placement."""
+    assign = np.array([0, 0, 1, NONE], np.uint32)
+    load = np.ones(4, np.uint32)
+    cap = np.full(3, INF, np.uint64)
+    alive = np.array([0, 1, 1], np.uint8)
+    used = oracle.recompute_used(assign, load, 3)
+    idx = np.array([0, 0, 2, 1, 3], np.uint32)
+    req = np.array([1, 2, 1, 2, 2], np.uint32)
+    node, flag = oracle.place_pending(assign, load, cap, alive, used, idx, req)
+    assert list(node) == [1, 1, 1, 2, 2]
+    assert list(flag) == [0x12, 1, 0, 0x12, 2]   # PLACED|REPLACED, REDIRECT, LOCAL, PLACED|REPLACED, PLACED
+    assert list(assign) == [1, 2, 1, 2] and list(used) == [0, 2, 2]
