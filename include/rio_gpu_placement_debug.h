@@ -18,7 +18,8 @@ extern "C" {
 
 /* packed fix-up (fix-up passes over the pending rows only): 0 = adaptive (default: used when the previous solve left
  * <= 25 % of the rows pending), 1 = always, 2 = never.  + 16: big update / remove batches (>= 2^18 entries) go through the plain
- * per-entry kernels instead of the window-partitioned ones. */
+ * per-entry kernels instead of the window-partitioned ones.  + (mode << 5), mode 0 | 1 | 2 as above: packing at the cut pass
+ * of a whole-table solve (adaptive: when the previous solve sent <= 25 % of the rows to the water-fill). */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 /* cut / water-fill fix-up.  impl: 2 (default) = split launches (k_cut_find spread over the chip, then k_cut_apply) |
  * 1 = one fused launch per solve (k_cut_fused) | 0 = the first, unfused launch chain.  speculate: 0 (default) =

@@ -125,6 +125,9 @@ struct Table {
     // which makes the separate k_pk_scatter launch unnecessary when at least one spill round runs
     const u32* pk_idx = nullptr;
     u32* real_next = nullptr;
+    // the packing pass has already stored NONE into the real row of every packed row (k_cut_apply_rank<PACK>): the last
+    // round then writes only the rows it places, not one scattered NONE per row it could not place
+    bool none_prewritten = false;
 };
 
 struct NodeTab {
@@ -155,7 +158,9 @@ float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u
 // round 0 rides in the second launch — only when nothing changes used_cur between the cut and that round (not on the
 // row-sharded path, where the Y exchange does).  Returns true when that ranking was enqueued.
 bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
-                      int impl = 2, bool have_cutblk = false, bool with_rank = false);
+                      int impl = 2, bool have_cutblk = false, bool with_rank = false, const PackOut* pack = nullptr);
+// pack (impl 2, real table only): k_cut_apply_rank also copies every row that goes on to the water-fill into the pack
+// columns (PackOut, per-wave counts in pack->wcnt); the caller then runs the water-fill rounds over the packed rows.
 void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
                         hipStream_t s, bool rank_done = false);
 

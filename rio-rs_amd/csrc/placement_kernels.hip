@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_rank(Plan p, const u64* __rest
 //     body): that ranking needs used_cur[], final since k_cut_find, and nothing this launch's other blocks produce, so it
 //     rides along instead of costing a dependent launch of its own.
 // ------------------------------------------------------------------------------------------------
-template <bool VIRT>
+template <bool VIRT, bool PACK = false>
 __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                            const u32* __restrict__ aff, u32* __restrict__ next,
                                                            const u32* __restrict__ alive_bits, Plan p,
@@ -1541,7 +1541,11 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
                                                            const u64* __restrict__ cap, const u64* __restrict__ used_cur,
                                                            u64* __restrict__ wfFree, u32* __restrict__ wfOrder,
                                                            u32* __restrict__ wfCnt, FxRows fx, u64* __restrict__ bsp_sum,
-                                                           u32* __restrict__ bsp_cnt) {
+                                                           u32* __restrict__ bsp_cnt, PackOut pko) {
+    // PACK (whole-table solves whose previous solve left few rows for the water-fill): every row that goes on to the
+    // water-fill — spill candidates and the claimants rejected here — is ALSO copied, in index order, to the front of its
+    // wave's range in the pack columns (row, load, mark) and counted in pko.wcnt; the water-fill rounds then run over the
+    // packed rows only (k_spill_apply writes its decisions through pk_idx), not over the whole table twice.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x >= p.G) {
         spill_rank_body(smem, blockIdx.x - p.G, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
@@ -1581,7 +1585,12 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
     uint4 cvn = *reinterpret_cast<const uint4*>(cur + rs);
     uint4 avn = *reinterpret_cast<const uint4*>(aff + rs);
     uint4 lvn = *reinterpret_cast<const uint4*>(load + rs);
-    if (ncut == 0 && forced_bits == nullptr) return;  // no cut anywhere: k_scan's spill totals stand
+    if (!PACK && ncut == 0 && forced_bits == nullptr) return;  // no cut anywhere: k_scan's spill totals stand
+    if (PACK && ncut == 0 && forced_bits == nullptr && bsp_cnt[blockIdx.x] == 0) {
+        // no cut anywhere and k_scan saw no spill candidate in this block: nothing to pack, its totals (zero) stand
+        if (lane == 0) pko.wcnt[gw] = 0;
+        return;
+    }
 #pragma unroll
     for (u32 q = 0; q < 8; ++q) {
         const u32 j = tid + q * kBlock;
@@ -1593,39 +1602,95 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict
     RIOGP_KT(2, 1);
     u64 sp_sum = 0, rej_sum = 0;
     u32 sp_cnt = 0, rej_cnt = 0;  // wave-uniform
+    u64 pk_pos = wstart;          // PACK: this wave's packed write cursor (wave-uniform)
+    // PACK: this wave's packing ring (row | load, kStageCap words each) behind the thr / alive tables
+    u32* stage = PACK ? alv + ((p.mwords + 3) & ~3u) + (size_t)wave * 2 * kStageCap : nullptr;
+    u32 st_head = 0, st_fill = 0;
     for (u64 it = wstart; it < wend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
         const uint4 cv = cvn, av = avn, lv = lvn;
+        u32 pm = 0;  // PACK: which of the lane's four rows go on to the water-fill
         const u64 pit = (it + kTile < wend ? it + kTile : it) + (u64)lane * 4;  // next tile in flight (the last re-reads its own)
         cvn = *reinterpret_cast<const uint4*>(cur + pit);
         avn = *reinterpret_cast<const uint4*>(aff + pit);
         lvn = *reinterpret_cast<const uint4*>(load + pit);
-#define RIOGP_ROW(C, A, L, E)                                                                        \
+        // The rows' `next` values are rebuilt from the columns (what k_scan wrote: kept -> cur, claimant -> affinity,
+        // duplicate request -> skip mark, not an object -> NONE, the rest -> spill mark) with the rejected claimants turned
+        // into spill marks (PACK: every row that goes on to the water-fill into NONE, final unless a round places it
+        // through pk_idx), and a wave that changes anything writes its whole kilobyte back, every lane its 16 bytes:
+        // full 128-byte lines instead of masked 4-byte stores into them (positions past wend are padding / scratch).
+        uint4 ov;
+        bool chg = false;
+#define RIOGP_ROW(C, A, L, O, E)                                                                     \
         {                                                                                            \
             const bool inr = i0 + E < wend;                                                          \
             const bool cin = C < m, ain = A < m;                                                     \
             const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                          \
             const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                  \
             const bool skip = VIRT && C == kSkipMark;                                                \
+            const bool dead = !VIRT && A == kAffInactive;                                            \
             const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                             \
-            const bool sp = inr & !kept & !skip & !cl & (VIRT | (A != kAffInactive));                \
+            const bool sp = inr & !kept & !skip & !cl & !dead;                                       \
             const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                        \
-            if (rej) next[i0 + E] = kSpillMark;                                                      \
+            const u32 mark = PACK ? kNone : kSpillMark;                                              \
+            O = kept ? C : (cl ? (rej ? mark : A) : (skip ? kSkipMark : (dead ? kNone : mark)));     \
+            if (PACK) pm |= (u32)(sp | rej) << E;                                                    \
+            chg |= PACK ? (sp | rej) : rej;                                                          \
             sp_sum += (sp | rej) ? (u64)L : 0ull;                                                    \
             rej_sum += rej ? (u64)L : 0ull;                                                          \
             sp_cnt += (u32)__popcll(__ballot(sp | rej));                                             \
             rej_cnt += (u32)__popcll(__ballot(rej));                                                 \
         }
-        RIOGP_ROW(cv.x, av.x, lv.x, 0)
-        RIOGP_ROW(cv.y, av.y, lv.y, 1)
-        RIOGP_ROW(cv.z, av.z, lv.z, 2)
-        RIOGP_ROW(cv.w, av.w, lv.w, 3)
+        RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
+        RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
+        RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
+        RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
 #undef RIOGP_ROW
+        if (__ballot(chg)) *reinterpret_cast<uint4*>(next + i0) = ov;
+        if (PACK) {  // index order = lane-major, then element; through this wave's LDS ring, 64 records per flush (k_scan<COMPACT>)
+            const u64 b0 = __ballot(pm & 1u), b1 = __ballot(pm & 2u), b2 = __ballot(pm & 4u), b3 = __ballot(pm & 8u);
+            if (b0 | b1 | b2 | b3) {
+                const u64 lt = (1ull << lane) - 1ull;
+                u32 e = st_head + st_fill + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+#define RIOGP_PK(E, L)                                                                                     \
+                if (pm & (1u << E)) {                                                                      \
+                    const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
+                    stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; ++e;                               \
+                }
+                RIOGP_PK(0, lv.x)
+                RIOGP_PK(1, lv.y)
+                RIOGP_PK(2, lv.z)
+                RIOGP_PK(3, lv.w)
+#undef RIOGP_PK
+                st_fill += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+                __builtin_amdgcn_wave_barrier();
+                while (st_fill >= 64u) {  // wave-uniform
+                    u32 x = st_head + (u32)lane;
+                    x = x >= kStageCap ? x - kStageCap : x;
+                    const u64 o = pk_pos + (u32)lane;
+                    pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.next[o] = kSpillMark;
+                    st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
+                    st_fill -= 64u;
+                    pk_pos += 64u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+    if (PACK && st_fill) {  // what is left in the ring (< 64 records)
+        u32 x = st_head + (u32)lane;
+        x = x >= kStageCap ? x - kStageCap : x;
+        if ((u32)lane < st_fill) {
+            const u64 o = pk_pos + (u32)lane;
+            pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.next[o] = kSpillMark;
+        }
+        pk_pos += st_fill;
     }
     RIOGP_KT(2, 2);
     sp_sum = wave_sum(sp_sum);
     rej_sum = wave_sum(rej_sum);
     if (lane == 0) {
+        if (PACK) pko.wcnt[gw] = (u32)(pk_pos - wstart);
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
         if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
@@ -1840,7 +1905,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
             } else {                                                              \
                 if (last) {                                                       \
                     OUT = kNone;                                                  \
-                    WOUT = kNone;                                                 \
+                    if (last == 1) WOUT = kNone;  /* 2: the real rows already hold NONE */ \
                 }                                                                 \
                 rem_sum += L; ++rem_cnt;                                          \
             }                                                                     \
@@ -3031,7 +3096,7 @@ size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
 // k_cutblk, k_cut_subhist, k_cut_exact, (k_shard_force,) k_apply_cut.  All three are kept: the parity tests drive the same
 // inputs through each and compare bytes.  Returns true when the ranking of round 0 was part of these launches.
 bool launch_cut_fixup(const Plan& p_in, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
-                      hipStream_t s, int impl, bool have_cutblk, bool with_rank) {
+                      hipStream_t s, int impl, bool have_cutblk, bool with_rank, const PackOut* pack) {
     Plan p = p_in;
     p.trace = (u32)g_trace_host;
     const unsigned gcb = (p.m + kCbNodes - 1) / kCbNodes;
@@ -3045,7 +3110,8 @@ bool launch_cut_fixup(const Plan& p_in, const Table& t, const NodeTab& nt, const
             const unsigned gfind = kCutFindGrid;
             const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
             const size_t lds_rank = 2 * kSmall + 256 + (size_t)mp * sizeof(u64);
-            const size_t lds_apply = kSmall + ((size_t)((p.m + 3) & ~3u) + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16;
+            const size_t lds_apply = kSmall + ((size_t)((p.m + 3) & ~3u) + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16 +
+                                     (pack ? (size_t)kWaves * 2 * kStageCap * sizeof(u32) : 0);
             const unsigned grank = with_rank ? ((p.m + kRankNodes - 1) / kRankNodes ? (p.m + kRankNodes - 1) / kRankNodes : 1) : 0;
             const size_t lds2 = (with_rank && lds_rank > lds_apply) ? lds_rank : lds_apply;
             if (virt) {
@@ -3054,14 +3120,15 @@ bool launch_cut_fixup(const Plan& p_in, const Table& t, const NodeTab& nt, const
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
                 hipLaunchKernelGGL(k_cut_apply_rank<true>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0], PackOut{});
             } else {
                 auto kfn = p.trace ? k_cut_find<false, true> : k_cut_find<false, false>;
                 hipLaunchKernelGGL(kfn, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
                                    b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
-                hipLaunchKernelGGL(k_cut_apply_rank<false>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
+                auto kap = pack ? k_cut_apply_rank<false, true> : k_cut_apply_rank<false, false>;
+                hipLaunchKernelGGL(kap, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
                                    nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
+                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0], pack ? *pack : PackOut{});
             }
             return with_rank;
         }
@@ -3111,7 +3178,8 @@ void launch_spill_round(const Plan& p_in, const Table& t, const NodeTab& nt, con
                            b.wfC, b.wfOrder, b.wfCnt);
     const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + (size_t)p.m * sizeof(unsigned short) + 16;
     hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_sum[in], b.wfC,
-                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out], last ? 1 : 0, b.stats,
+                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out],
+                       last ? (t.none_prewritten ? 2 : 1) : 0, b.stats,
                        t.pk_idx, t.real_next, b.rank_base, b.pending_global, b.fx, b.bsp_sum[in], b.bsp_cnt[in], b.bsp_sum[out], b.bsp_cnt[out]);
 }
 

@@ -150,6 +150,9 @@ struct rio_gp {
     bool last_pending_valid = false;
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
+    int cutpack_mode = 0;  // the same for packing at the cut pass of whole-table solves (bits 5-6 of rio_gp_debug_set_compact)
+    u64 last_fix_rows = 0;  // rows the previous solve sent to the water-fill (spill candidates + rejected claimants)
+    bool last_fix_valid = false;
     int fixup_mode = 2;    // cut fix-up: 2 split launches (k_cut_find + k_cut_apply_rank) | 1 one fused launch | 0 the unfused
                            // chain; >= 1 also folds the packed scatter into the water-fill (rio_gp_debug_set_fixup)
     int spec_mode = 0;     // speculative fix-up enqueue: 0 auto (after a solve that needed it) | 1 always | 2 never
@@ -269,10 +272,26 @@ Table real_table(rio_gp* h) { return Table{h->assign[h->cur], h->load, h->aff, h
 NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; }
 
 // the cut / spill fix-up of a solve whose fast path said it needs one
-void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, const DevStats& verdict) {
+// cutpack (whole-table solves of the real table, split cut fix-up, >= 1 round, a cut to apply): the pass that re-marks the
+// rejected claimants also packs every row that goes on to the water-fill, and the rounds run over those rows only.
+void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, const DevStats& verdict,
+                  bool cutpack = false) {
     // every caller ran launch_resolve over h->sb for this solve: the cut blocks are already located
     bool rank0 = false;
-    if (verdict.n_cut > 0) rank0 = launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode, true, h->rounds >= 1);
+    cutpack = cutpack && !virt && verdict.n_cut > 0 && h->fixup_mode == 2 && h->rounds >= 1 && !p.wcnt;
+    if (verdict.n_cut > 0)
+        rank0 = launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode, true, h->rounds >= 1, cutpack ? &h->pk : nullptr);
+    if (cutpack) {
+        Plan pp = p;
+        pp.wcnt = h->pk.wcnt;
+        Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
+        vt.pk_idx = h->pk.idx;
+        vt.real_next = t.next;
+        vt.none_prewritten = true;
+        for (u32 r = 0; r < h->rounds; ++r)
+            launch_spill_round(pp, vt, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream, r == 0 && rank0);
+        return;
+    }
     for (u32 r = 0; r < h->rounds; ++r)
         launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream, r == 0 && rank0);
 }
@@ -370,6 +389,11 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     // guards itself on device (k_cut_fused: stats->n_cut; the water-fill rounds: pending-row count), so a solve that
     // turns out not to need them pays a few no-op launches and gets the same result.
     const bool spec = h->fixup_mode >= 1 && h->spec_mode != 2 && (h->spec_mode == 1 || h->last_slow);
+    // Packing at the cut pass: a whole-table solve (nothing known to be kept) whose previous solve sent few rows to the
+    // water-fill — a contended table re-solved: ~10 % of the rows — lets k_cut_apply_rank pack those rows, and both
+    // water-fill rounds run over them instead of streaming the table twice more.  Results identical.
+    const bool cutpack = !compact && (h->cutpack_mode == 1 ||
+                                      (h->cutpack_mode == 0 && h->last_fix_valid && h->last_fix_rows * 4 <= h->n && h->n >= 65536));
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
     launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
     DevStats v;
@@ -394,7 +418,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
             enqueue_slow(h, pp, vt, nt, true, what);
             if (!fused_scatter) launch_pk_scatter(pp, h->pk, t.next, h->stream);
         } else {
-            enqueue_slow(h, h->plan, t, nt, false, what);
+            enqueue_slow(h, h->plan, t, nt, false, what, cutpack);
         }
     }
     h->have_solved = true;
@@ -415,6 +439,8 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     HIPCHK(h, hipGetLastError());
     h->last_pending = v.claimants + v.spillcand;
     h->last_pending_valid = true;
+    h->last_fix_rows = v.spillcand + (slow ? v.rejected : 0);
+    h->last_fix_valid = true;
     h->last_slow = slow;
     fill_stats(v, h->n, stats);
     return RIO_GP_OK;
@@ -1759,6 +1785,8 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     if (!h || mode < 0 || (mode & 15) > 2) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
+    h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
+    if (h->cutpack_mode == 3) return RIO_GP_EINVAL;
     mode &= 15;
     h->compact_mode = mode;
     return RIO_GP_OK;

@@ -343,11 +343,13 @@ class GpuPlacement:
         self._chk(lib().rio_gp_debug_ktrace(self._h, table, out))
         return np.ctypeslib.as_array(out).reshape(256, 8).copy()
 
-    def set_compact(self, mode, partitioned_crud=True):
+    def set_compact(self, mode, partitioned_crud=True, cut_pack="auto"):
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode).  partitioned_crud=False: big
-        update / remove batches through the plain per-entry kernels (A/B runs, parity tests)."""
-        self._chk(lib().rio_gp_debug_set_compact(self._h, {"auto": 0, "always": 1, "never": 2}.get(mode, mode) |
-                                                 (0 if partitioned_crud else 16)))
+        update / remove batches through the plain per-entry kernels (A/B runs, parity tests).  cut_pack: the same three
+        modes for packing at the cut pass of whole-table solves (k_cut_apply_rank<PACK>)."""
+        modes = {"auto": 0, "always": 1, "never": 2}
+        self._chk(lib().rio_gp_debug_set_compact(self._h, modes.get(mode, mode) | (0 if partitioned_crud else 16) |
+                                                 (modes.get(cut_pack, cut_pack) << 5)))
 
     def set_fixup(self, fused=True, speculate="auto"):
         """cut fix-up implementation: "split" / 2 (default: k_cut_find + k_cut_apply), True / 1 (one fused launch),

@@ -27,7 +27,9 @@ def gp():
 FIXUP_VARIANTS = (("never", False, "never"), ("always", False, "never"),
                   ("never", True, "always"), ("always", True, "always"), ("always", True, "never"),
                   ("never", "split", "never"), ("always", "split", "always"), ("never", "split", "always"),
-                  ("always", "split", "never"))
+                  ("always", "split", "never"),
+                  # packing at the cut pass of the whole-table solve (k_cut_apply_rank<PACK>), host-ordered and speculative
+                  ("cutpack", "split", "never"), ("cutpack", "split", "always"))
 
 
 def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
@@ -47,7 +49,10 @@ def _check_tick(gp, oracle, cur, load, aff, cap, alive, rounds=2):
     # the verdict | speculatively behind k_resolve (device-side guards).
     for mode in FIXUP_VARIANTS:
         g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds)
-        g.set_compact(mode[0])
+        if mode[0] == "cutpack":
+            g.set_compact("never", cut_pack="always")
+        else:
+            g.set_compact(mode[0], cut_pack="never")
         g.set_fixup(fused=mode[1], speculate=mode[2])
         st = g.solve()
         got = g.get_solved()

@@ -66,9 +66,12 @@ def test_config2_exact_every_fixup_variant(gp, oracle):
     g.close()
     tight = dict(cfg, cap=np.full(256, 3000, np.uint64))
     for compact, impl, spec in (("never", 0, "never"), ("always", 0, "never"), ("never", 1, "always"), ("always", 1, "always"),
-                                ("always", 1, "never"), ("never", 2, "never"), ("always", 2, "always")):
+                                ("always", 1, "never"), ("never", 2, "never"), ("always", 2, "always"), ("cutpack", 2, "always")):
         g = _mk(gp, tight)
-        g.set_compact(compact)
+        if compact == "cutpack":
+            g.set_compact("never", cut_pack="always")
+        else:
+            g.set_compact(compact, cut_pack="never")
         try:
             g.set_fixup(fused=impl, speculate=spec)
         except gp.ObjectPlacementError:
@@ -100,8 +103,14 @@ def test_config3_contended_at_10m(gp, oracle):
     cfg = cfg_of("c3")
     tight = dict(cfg, cap=(cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64))
     g = _mk(gp, tight)
-    _, _, st = _same(g, oracle, tight["cur"], tight)
+    _, _, st = _same(g, oracle, tight["cur"], tight, commit=False)
     assert st["cut_nodes"] > 900 and st["unplaced"] > 0
+    # the same table again: the first solve sent ~10 % of the rows to the water-fill, so this one packs them at the cut pass
+    _, _, st2 = _same(g, oracle, tight["cur"], tight, commit=False)
+    assert st2 == st
+    g.set_compact("auto", cut_pack="never")
+    _, _, st3 = _same(g, oracle, tight["cur"], tight)
+    assert st3 == st
     g.close()
 
 
