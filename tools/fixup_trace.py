@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the fix-up kernels of a config-5 churn tick spend their time: phase traces written by the kernels themselves
 (wall_clock64, 100 MHz) for k_cut_find (+ the block search inside it), k_cut_apply_rank and both k_spill_apply rounds.
-Usage: fixup_trace.py [ticks] [auto|never]"""
+Usage: fixup_trace.py [ticks] [auto|never] [churn|contended]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -14,14 +14,24 @@ n, m = cfg["n"], cfg["m"]
 g = rio_gp.GpuPlacement(n, m)
 if len(sys.argv) > 2:
     g.set_compact(sys.argv[2])
-g.set_nodes(cfg["cap"], cfg["alive"])
-g.set_objects(n, cfg["load"], cfg["aff"])
-g.set_assign(synth.warm_assign(n, m))
-g.tick()
-g.cut_trace(True)
-for k in range(ticks):
-    g.set_alive_all(synth.churn_mask(m, 2 + k))
-    st = g.tick()
+workload = sys.argv[3] if len(sys.argv) > 3 else "churn"   # churn | contended (cold solves, capacity 0.9 x load)
+if workload == "contended":
+    g.set_nodes((cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64), cfg["alive"])
+    g.set_objects(n, cfg["load"], cfg["aff"])
+    g.solve()
+    g.solve()
+    g.cut_trace(True)
+    for k in range(ticks):
+        st = g.solve()
+else:
+    g.set_nodes(cfg["cap"], cfg["alive"])
+    g.set_objects(n, cfg["load"], cfg["aff"])
+    g.set_assign(synth.warm_assign(n, m))
+    g.tick()
+    g.cut_trace(True)
+    for k in range(ticks):
+        g.set_alive_all(synth.churn_mask(m, 2 + k))
+        st = g.tick()
 us = lambda x: float(x) / 100.0
 def table(t, names, first_tile=False):
     tr = g.ktrace(t).astype(np.int64)

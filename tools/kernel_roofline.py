@@ -43,15 +43,17 @@ def specs(pending_rows):
         ("fast", r"k_resolve", "k_resolve", 2 * M * 8 * 256, "H: 2m u64 per block x 256 blocks"),
         ("churn", r"k_scan<false, false, 1, 2", "k_scan<COMPACT> (churn tick)", 16 * N + 16 * pk, "16 B/row + 16 B per packed pending row"),
         ("churn", r"k_cut_find<true, false>", "k_cut_find (packed rows)", 12 * pk, "one pass over the packed pending rows of the blocks that own cuts (upper bound: all)"),
-        ("churn", r"k_cut_apply_rank<true>", "k_cut_apply_rank (packed rows)", 12 * pk, "12 B per packed pending row (+4 B per rejected)"),
+        ("churn", r"k_cut_apply_rank<true, false>", "k_cut_apply_rank (packed rows)", 12 * pk, "12 B per packed pending row (+4 B per rejected)"),
         ("churn", r"k_spill_rank", "k_spill_rank (round 1)", M * 24, "cap/used/alive of every node per workgroup"),
         ("churn", r"k_spill_apply", "k_spill_apply (packed rows, both rounds)", 12 * pk, "next + load + idx of the packed rows (+8 B per placed)"),
         ("churn_unpacked", r"k_cut_find<false, false>", "k_cut_find (whole table, churn)", 12 * N, "upper bound: every block owns a cut"),
-        ("churn_unpacked", r"k_cut_apply_rank<false>", "k_cut_apply_rank (whole table, churn)", 12 * N, "12 B/row"),
+        ("churn_unpacked", r"k_cut_apply_rank<false, false>", "k_cut_apply_rank (whole table, churn)", 12 * N, "12 B/row"),
         ("churn_unpacked", r"k_spill_apply", "k_spill_apply (whole table, churn)", 8 * N, "next + load per row"),
         ("contended", r"k_cut_find<false, false>", "k_cut_find (whole table, contended)", 12 * N, "one pass over the blocks that own cuts (all)"),
-        ("contended", r"k_cut_apply_rank<false>", "k_cut_apply_rank (whole table, contended)", 12 * N, "12 B/row"),
+        ("contended", r"k_cut_apply_rank<false, false>", "k_cut_apply_rank (whole table, contended)", 12 * N, "12 B/row"),
         ("contended", r"k_spill_apply", "k_spill_apply (whole table, contended)", 8 * N, "next + load per row"),
+        ("contended_packed", r"k_cut_apply_rank<false, true>", "k_cut_apply_rank<PACK> (whole table, contended: packs the water-fill rows)", 16 * N, "12 B read + 4 B written per row (+12 B per packed row)"),
+        ("contended_packed", r"k_spill_apply", "k_spill_apply (contended, rows packed at the cut pass; concentrated in the last workgroups)", 12 * N // 10, "next + load + idx of ~1 M packed rows"),
         ("crud", r"k_lookup4", "k_lookup4 (10 M random indices)", 12 * N, "idx + gather + out per lookup"),
         ("lookup_seq", r"k_lookup4", "k_lookup4 (10 M sequential indices)", 12 * N, "idx + gather + out per lookup"),
         ("crud", r"k_part_bin<true>", "k_part_bin<update> (10 M random)", 8 * N, "idx + node per entry (update = bin + apply: 8 B/op over both)"),

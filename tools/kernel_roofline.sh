@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/${TAG}_kroof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export RIO_KROOF_DIR=$OUT
-for ph in probes fast churn churn_unpacked contended crud crud_plain lookup_seq pp; do
+for ph in probes fast churn churn_unpacked contended contended_packed crud crud_plain lookup_seq pp; do
   timeout 240 rocprofv3 --kernel-trace --output-format csv -d $OUT/${ph}_trace -o t -- python $ROOT/tools/roofline_workload.py $ph > $OUT/${ph}_trace.log 2>&1
   timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${ph}_fetch -o f -- python $ROOT/tools/roofline_workload.py $ph 4 > $OUT/${ph}_fetch.log 2>&1
   timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${ph}_write -o w -- python $ROOT/tools/roofline_workload.py $ph 4 > $OUT/${ph}_write.log 2>&1

@@ -2,7 +2,7 @@
 """One PHASE of the hot path per process, for the rocprofv3 passes of tools/kernel_roofline.sh (kernel trace + the two PMC
 passes): every kernel DESIGN.md section 4 names runs in exactly one phase with known algorithmic bytes, so that its
 duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round2_kernel_roofline.json).
-Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|crud|crud_plain|lookup_seq|pp|probes> [reps]"""
+Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|contended_packed|crud|crud_plain|lookup_seq|pp|probes> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -23,7 +23,7 @@ if phase == "fast":                      # k_scan<.., TPI 2>, k_resolve
     g.solve_wait()
 elif phase in ("churn", "churn_unpacked"):   # k_scan<COMPACT>, k_cut_find, k_cut_apply_rank, k_spill_rank, k_spill_apply (packed rows)
     if phase == "churn_unpacked":
-        g.set_compact("never")
+        g.set_compact("never", cut_pack="never")
     g.set_assign(synth.warm_assign(n, m))
     g.tick()
     for k in range(reps + 2):
@@ -33,8 +33,10 @@ elif phase in ("churn", "churn_unpacked"):   # k_scan<COMPACT>, k_cut_find, k_cu
         import json
         json.dump({"pending_rows": st["claimed"] + st["spilled"] + st["unplaced"], "last_tick": st},
                   open(os.path.join(os.environ["RIO_KROOF_DIR"], "churn_stats.json"), "w"))
-elif phase == "contended":               # the same fix-up kernels over ALL rows (cold table, capacity 0.9 x load)
+elif phase in ("contended", "contended_packed"):   # the same fix-up kernels over ALL rows (cold table, capacity 0.9 x load);
+    # _packed: the cut pass packs the rows that go on to the water-fill (what the library does from the second such solve on)
     g.set_nodes((cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64), cfg["alive"])
+    g.set_compact("auto", cut_pack="always" if phase == "contended_packed" else "never")
     for _ in range(reps):
         g.solve()
 elif phase in ("crud", "crud_plain", "pp", "lookup_seq"):
