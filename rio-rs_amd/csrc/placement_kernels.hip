@@ -2272,6 +2272,7 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
 // piece, so a wave instruction covers four pieces; quarter-wave g of wave w takes the chunks 64 i + 4 w + g.  Every
 // descriptor (two u16 reads) is requested before the first record, records go out four pieces per lane at a time.
 constexpr int kPartIters = kPartMaxChunks / 64;  // 32 pieces per quarter wave at most
+constexpr int kPartRowVecs = (1 << kPartShiftMax) / (kBlock * 4);  // 16-byte vectors of the window's rows per thread (4)
 
 #define RIOGP_PART_DESCRIPTORS()                                                                          \
     u32 pbase[kPartIters], pcnt[kPartIters];                                                              \
@@ -2292,6 +2293,7 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
     u64* win = reinterpret_cast<u64*>(smem);  // [W] {position + 1 | node code} of the last writer, 0 = untouched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
+    const u64 base = (u64)b << wshift;
     RIOGP_PART_DESCRIPTORS()
     for (u32 r = tid; r < W; r += kBlock) win[r] = 0;
     __syncthreads();
@@ -2304,6 +2306,14 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
         for (int q = 0; q < 4; ++q)
             if (o16 < pcnt[i + q]) atomicMax(&win[x[q].x & (W - 1)], ((u64)(x[q].y + 1u) << 16) | (u64)(x[q].x >> kPartShiftMax));
     }
+    // this thread's rows of the window as they are now (the columns are padded to whole tiles): requested here, behind the
+    // main loop (its registers are free again) and ahead of the tail loop and the barrier
+    uint4 curv[kPartRowVecs];
+#pragma unroll
+    for (int q = 0; q < kPartRowVecs; ++q) {
+        const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
+        curv[q] = (r4 < W && base + r4 < n_obj) ? *reinterpret_cast<const uint4*>(assign + base + r4) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll 1
     for (int i = 0; i < kPartIters; ++i)  // pieces of more than 16 records
         for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) {
@@ -2311,14 +2321,25 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
             atomicMax(&win[x.x & (W - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShiftMax));
         }
     __syncthreads();
-    const u64 base = (u64)b << wshift;
-    for (u32 r = tid; r < W; r += kBlock) {
-        const u64 v = win[r];
-        if (v && base + r < n_obj) {
-            const u32 code = (u32)v & 0xFFFFu;
-            const u32 nd = code == kNodeNoneCode ? kNone : code;
-            assign[base + r] = nd;
-            if (aff_life) aff_life[base + r] = nd == kNone ? kAffInactive : nd;
+    // The window's rows leave as whole 16-byte vectors merged with their current values (requested at the top of the kernel),
+    // every lane of a wave that changes anything: full 128-byte lines.  Masked 4-byte stores — 63 % of the rows of a 10 M
+    // batch over 10 M rows — touch nearly every 32-byte sector without filling it, a read-modify-write at the memory side.
+#pragma unroll
+    for (int q = 0; q < kPartRowVecs; ++q) {
+        const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
+        if (r4 >= W || base + r4 >= n_obj) continue;
+        const u64 v0 = win[r4], v1 = win[r4 + 1], v2 = win[r4 + 2], v3 = win[r4 + 3];
+        uint4 o = curv[q];
+#define RIOGP_MERGE(V, O)                                                                   \
+        if (V) { const u32 code = (u32)V & 0xFFFFu; O = code == kNodeNoneCode ? kNone : code; }
+        RIOGP_MERGE(v0, o.x) RIOGP_MERGE(v1, o.y) RIOGP_MERGE(v2, o.z) RIOGP_MERGE(v3, o.w)
+#undef RIOGP_MERGE
+        if (__ballot((v0 | v1 | v2 | v3) != 0)) *reinterpret_cast<uint4*>(assign + base + r4) = o;
+        if (aff_life) {
+            if (v0) aff_life[base + r4 + 0] = o.x == kNone ? kAffInactive : o.x;
+            if (v1) aff_life[base + r4 + 1] = o.y == kNone ? kAffInactive : o.y;
+            if (v2) aff_life[base + r4 + 2] = o.z == kNone ? kAffInactive : o.z;
+            if (v3) aff_life[base + r4 + 3] = o.w == kNone ? kAffInactive : o.w;
         }
     }
 }
@@ -2347,20 +2368,35 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
         for (int q = 0; q < 4; ++q)
             if (o16 < pcnt[i + q]) flag[x[q] & (W - 1)] = 1u;  // duplicates: the same store
     }
+    const u64 base = (u64)b << wshift;
+    uint4 curv[kPartRowVecs];  // the window's rows as they are now (as in k_part_update: whole vectors go back)
+#pragma unroll
+    for (int q = 0; q < kPartRowVecs; ++q) {
+        const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
+        curv[q] = (r4 < W && base + r4 < n_obj) ? *reinterpret_cast<const uint4*>(assign + base + r4) : make_uint4(0, 0, 0, 0);
+    }
 #pragma unroll 1
     for (int i = 0; i < kPartIters; ++i)
         for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) flag[rec[pbase[i] + o] & (W - 1)] = 1u;
     __syncthreads();
-    const u64 base = (u64)b << wshift;
-    for (u32 r = tid; r < W; r += kBlock) {
-        if (flag[r] && base + r < n_obj) {
-            const u32 old = assign[base + r];
-            if (old != kNone) {
-                assign[base + r] = kNone;
-                if (used && old < m) atomicAdd(&rel[old], (u64)load[base + r]);
-            }
-            if (aff_life) aff_life[base + r] = kAffInactive;  // row lifecycle: a removed key is no longer an object
+#pragma unroll
+    for (int q = 0; q < kPartRowVecs; ++q) {
+        const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
+        if (r4 >= W || base + r4 >= n_obj) continue;
+        const uint4 f = *reinterpret_cast<const uint4*>(flag + r4);
+        uint4 o = curv[q];
+        // (rows past n_obj inside the vector are never flagged: the entries were validated)
+#define RIOGP_RM(F, O, E)                                                                                   \
+        if (F) {                                                                                            \
+            if (O != kNone) {                                                                               \
+                if (used && O < m) atomicAdd(&rel[O], (u64)load[base + r4 + E]);                            \
+                O = kNone;                                                                                  \
+            }                                                                                               \
+            if (aff_life) aff_life[base + r4 + E] = kAffInactive;  /* row lifecycle: no longer an object */ \
         }
+        RIOGP_RM(f.x, o.x, 0) RIOGP_RM(f.y, o.y, 1) RIOGP_RM(f.z, o.z, 2) RIOGP_RM(f.w, o.w, 3)
+#undef RIOGP_RM
+        if (__ballot((f.x | f.y | f.z | f.w) != 0)) *reinterpret_cast<uint4*>(assign + base + r4) = o;
     }
     if (used) {
         __syncthreads();
