@@ -2272,6 +2272,8 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
 // piece, so a wave instruction covers four pieces; quarter-wave g of wave w takes the chunks 64 i + 4 w + g.  Every
 // descriptor (two u16 reads) is requested before the first record, records go out four pieces per lane at a time.
 constexpr int kPartIters = kPartMaxChunks / 64;  // 32 pieces per quarter wave at most
+constexpr int kPartFlight = 4;   // pieces per lane requested before the first is used (8 was measured: no gain — the loop is bound by
+                                 // the partial-line reads of the ~13-record pieces, not by its round trips)
 constexpr int kPartRowVecs = (1 << kPartShiftMax) / (kBlock * 4);  // 16-byte vectors of the window's rows per thread (4)
 
 #define RIOGP_PART_DESCRIPTORS()                                                                          \
@@ -2298,12 +2300,12 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
     for (u32 r = tid; r < W; r += kBlock) win[r] = 0;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kPartIters; i += 4) {
-        uint2 x[4];
+    for (int i = 0; i < kPartIters; i += kPartFlight) {  // kPartFlight pieces per lane in flight: the loop is a chain of round trips
+        uint2 x[kPartFlight];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = o16 < pcnt[i + q] ? rec2[pbase[i + q] + o16] : make_uint2(0, 0);
+        for (int q = 0; q < kPartFlight; ++q) x[q] = o16 < pcnt[i + q] ? rec2[pbase[i + q] + o16] : make_uint2(0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < kPartFlight; ++q)
             if (o16 < pcnt[i + q]) atomicMax(&win[x[q].x & (W - 1)], ((u64)(x[q].y + 1u) << 16) | (u64)(x[q].x >> kPartShiftMax));
     }
     // this thread's rows of the window as they are now (the columns are padded to whole tiles): requested here, behind the
@@ -2360,12 +2362,12 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
         for (u32 j = tid; j < m; j += kBlock) rel[j] = 0;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kPartIters; i += 4) {
-        u32 x[4];
+    for (int i = 0; i < kPartIters; i += kPartFlight) {
+        u32 x[kPartFlight];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = o16 < pcnt[i + q] ? rec[pbase[i + q] + o16] : 0u;
+        for (int q = 0; q < kPartFlight; ++q) x[q] = o16 < pcnt[i + q] ? rec[pbase[i + q] + o16] : 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < kPartFlight; ++q)
             if (o16 < pcnt[i + q]) flag[x[q] & (W - 1)] = 1u;  // duplicates: the same store
     }
     const u64 base = (u64)b << wshift;
