@@ -1886,6 +1886,8 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         if (it == wstart) RIOGP_KT(ktab, 6);
         uint4 ov = nv;  // the lane's four decisions leave as ONE 16-byte store (rows that stay pending keep their mark)
         uint4 wv = make_uint4(kKeepVal, kKeepVal, kKeepVal, kKeepVal);  // what goes into the real assignment column
+        u32 pn[4] = {kNone, kNone, kNone, kNone};  // node of the lane's placed rows and their loads: admitted after the row loop
+        u64 pll[4] = {0, 0, 0, 0};
 #define RIOGP_ROW(MK, L, E, IDX, OUT, WOUT)                                       \
         if (MK) {                                                                 \
             u32 nd = kNone;                                                       \
@@ -1900,7 +1902,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
             if (nd != kNone) {                                                    \
                 OUT = nd;                                                         \
                 WOUT = nd;                                                        \
-                atomicAdd(&adm[nd], (u64)L);                                      \
+                pn[E] = nd; pll[E] = (u64)L;                                      \
                 pl_sum += L; ++pl_cnt;                                            \
             } else {                                                              \
                 if (last) {                                                       \
@@ -1916,6 +1918,26 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         RIOGP_ROW(mk2, l2, 2, iv.z, ov.z, wv.z)
         RIOGP_ROW(mk3, l3, 3, iv.w, ov.w, wv.w)
 #undef RIOGP_ROW
+        {   // Admitted load per node (adm[], LDS).  The rows of a tile mostly land on ONE node (a node's free capacity is
+            // thousands of rows wide): one ds_add_u64 per placed row is then 256 atomics on one address per tile, serialised
+            // in the one LDS pipe the 16 waves share — the water-fill of 9.4 M rows spent most of its 47 us there.  When
+            // every placed row of the tile has the same node the wave adds them up in registers (DPP) and issues ONE atomic.
+            const u32 n0 = pn[0] != kNone ? pn[0] : pn[1] != kNone ? pn[1] : pn[2] != kNone ? pn[2] : pn[3];
+            const u64 pmask = __ballot(n0 != kNone);
+            if (pmask) {
+                const u32 nd0 = (u32)__builtin_amdgcn_readlane((int)n0, __ffsll((long long)pmask) - 1);
+                const bool odd = (pn[0] != kNone && pn[0] != nd0) | (pn[1] != kNone && pn[1] != nd0) |
+                                 (pn[2] != kNone && pn[2] != nd0) | (pn[3] != kNone && pn[3] != nd0);
+                if (!__ballot(odd)) {
+                    const u64 tot = wave_sum(pll[0] + pll[1] + pll[2] + pll[3]);
+                    if (lane == 0) atomicAdd(&adm[nd0], tot);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (pn[e] != kNone) atomicAdd(&adm[pn[e]], pll[e]);
+                }
+            }
+        }
         if ((ov.x != nv.x) | (ov.y != nv.y) | (ov.z != nv.z) | (ov.w != nv.w)) *reinterpret_cast<uint4*>(next + i0) = ov;
         if (scat) {  // the decisions of the packed rows go to their REAL rows: scattered 4-byte stores (~1 M per churn tick; transposing
                      // them through LDS so that neighbouring lanes write neighbouring rows was measured: no gain, the cost
