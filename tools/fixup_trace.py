@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the fix-up kernels of a config-5 churn tick spend their time: phase traces written by the kernels themselves
 (wall_clock64, 100 MHz) for k_cut_find (+ the block search inside it), k_cut_apply_rank and both k_spill_apply rounds.
-Usage: fixup_trace.py [ticks] [auto|never] [churn|contended]"""
+Usage: fixup_trace.py [ticks] [auto|never] [churn|contended|skew]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -15,9 +15,13 @@ g = rio_gp.GpuPlacement(n, m)
 if len(sys.argv) > 2:
     g.set_compact(sys.argv[2])
 workload = sys.argv[3] if len(sys.argv) > 3 else "churn"   # churn | contended (cold solves, capacity 0.9 x load)
-if workload == "contended":
-    g.set_nodes((cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64), cfg["alive"])
-    g.set_objects(n, cfg["load"], cfg["aff"])
+if workload in ("contended", "skew"):
+    if workload == "contended":
+        g.set_nodes((cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64), cfg["alive"])
+        g.set_objects(n, cfg["load"], cfg["aff"])
+    else:   # Pareto-skewed affinity: a few hot nodes oversubscribed, 9.4 M rows go to the water-fill
+        g.set_nodes(cfg["cap"], cfg["alive"])
+        g.set_objects(n, cfg["load"], np.minimum((np.random.default_rng(1).pareto(1.1, n)).astype(np.int64), m - 1).astype(np.uint32))
     g.solve()
     g.solve()
     g.cut_trace(True)
