@@ -1744,7 +1744,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                                                            //     four dependent ~1 us round trips per lane and tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
     const int ktab = last ? 1 : 0;
-    constexpr u32 kKeepVal = 0xFFFFFFF0u;  // "this row is not written" in the staged decisions (no node id, not NONE)
+    constexpr u32 kKeepVal = 0xFFFFFFF0u;  // "no store for this row" among the values bound for the real column (no node id, not NONE)
     RIOGP_KT(ktab, 0);
     // Prologue: what is pending, and where does this workgroup's first wave start in the index-ordered spill prefix?
     // Every global operand of the prologue is requested before the first one is used (one round trip, not three): the
