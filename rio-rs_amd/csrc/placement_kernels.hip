@@ -1038,61 +1038,99 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
             const u64 tr_a = KT_ON ? wall_clock64() : 0;
             for (u32 k = tid; k < kn * Sp; k += kBlock) T[k] = 0;
             __syncthreads();
-            // pass: claim load per (local node, piece of its range); a tile (256 rows) lies inside ONE piece.  The next tile is
-            // in flight while this one is processed: ONE workgroup streams the block (470 KB of a 10 M-row table), and with a
-            // single tile per wave outstanding it ran at ~25 GB/s — 12 us per pass while most of the chip idles.
-            uint4 cvn = make_uint4(0, 0, 0, 0), avn = cvn, lvn = cvn;
-            if (wstart < wend) {
-                const u64 f0 = wstart + (u64)lane * 4;
-                cvn = *reinterpret_cast<const uint4*>(cur + f0);
-                avn = *reinterpret_cast<const uint4*>(aff + f0);
-                lvn = *reinterpret_cast<const uint4*>(load + f0);
-            }
-            for (u64 it = wstart; it < wend; it += kTile) {
-                const u64 i0 = it + (u64)lane * 4;
-                const uint4 cv = cvn, av = avn, lv = lvn;
-                {
-                    const u64 pn = (it + kTile < wend ? it + kTile : it) + (u64)lane * 4;  // (the last tile re-reads itself)
-                    cvn = *reinterpret_cast<const uint4*>(cur + pn);
-                    avn = *reinterpret_cast<const uint4*>(aff + pn);
-                    lvn = *reinterpret_cast<const uint4*>(load + pn);
-                }
-                const u32 tb = (u32)((it - bstart) / kTile);
-                const u32 t_lvl0 = tb / ptiles;
+            if (kn == 1) {
+                // ONE local node (a few hot nodes cut, each in a block of its own — skewed affinity): its claimants of a tile all
+                // add to the same piece, so the tile is summed in registers (one DPP reduction) and added once; no slot table,
+                // no per-row atomics, and tiles outside the node's current range are not even read.  The general pass below
+                // spends ~240 instructions per tile and wave on this, 12 us per pass on the one CU that owns the item.
+                const u32 nd0 = (u32)node_of[g0];
+                const bool live0 = bit_of(alv, nd0);
+                const u32 rs0 = (u32)st_rs[0];
+                for (u64 it = wstart; it < wend; it += kTile) {
+                    const u32 tb = (u32)((it - bstart) / kTile);
+                    u32 t = tb / ptiles;
+                    if (level != 0) {
+                        const u32 off = tb - rs0;  // below the range wraps to a huge value
+                        if (off >= rlen) continue;
+                        t = off / ptiles;
+                    }
+                    const u64 i0 = it + (u64)lane * 4;
+                    const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
+                    const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
+                    const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
+                    u64 sum = 0;
 #define RIOGP_ROW(C, A, L, E)                                                                              \
-                {                                                                                          \
-                    /* branch-free class test (as P3): claimant = in range, not kept, not a duplicate, affinity live */ \
-                    const bool cin = C < m, ain = A < m;                                                   \
-                    const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                        \
-                    const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                \
-                    const u32 ls = (u32)slot[ax] - g0;  /* kSlotNone - g0 >= kn always */                  \
-                    bool hit = (i0 + E < wend) & !kept & !(VIRT && C == kSkipMark) & ain & bit_of(alv, ax) & (ls < kn); \
-                    u32 t = 0;                                                                             \
-                    if (level == 0) {                                                                      \
-                        t = t_lvl0;  /* every range is the whole block: the piece is a property of the tile */ \
-                    } else if (hit) {                                                                      \
-                        const u32 off = tb - (u32)st_rs[ls];  /* below the range wraps to a huge value */  \
-                        hit = off < rlen;                                                                  \
-                        t = off / ptiles;                                                                  \
-                    }                                                                                      \
-                    const u64 todo = __ballot(hit);                                                        \
-                    if (__popcll(todo) >= 16) { /* a HOT node (>= 16 rows of this wave-element): one LDS atomic, not 16+ */ \
-                        const int ld = __ffsll((long long)todo) - 1;                                       \
-                        const u32 s0 = (u32)__shfl((int)(ls * Sp + t), ld, 64);                            \
-                        const bool same = hit && ls * Sp + t == s0;                                        \
-                        if (__popcll(__ballot(same)) >= 16) {                                              \
-                            const u64 sum = wave_sum(same ? (u64)L : 0ull);                                \
-                            if (lane == ld) atomicAdd(&T[s0], sum);                                        \
-                            hit = hit && !same;                                                            \
-                        }                                                                                  \
-                    }                                                                                      \
-                    if (hit) atomicAdd(&T[ls * Sp + t], (u64)L);                                           \
-                }
-                RIOGP_ROW(cv.x, av.x, lv.x, 0)
-                RIOGP_ROW(cv.y, av.y, lv.y, 1)
-                RIOGP_ROW(cv.z, av.z, lv.z, 2)
-                RIOGP_ROW(cv.w, av.w, lv.w, 3)
+                    {                                                                                      \
+                        const bool cin = C < m;                                                            \
+                        const bool kept = VIRT ? cin : (cin & bit_of(alv, cin ? C : 0u));                  \
+                        const bool hit = (i0 + E < wend) & !kept & !(VIRT && C == kSkipMark) & (A == nd0) & live0; \
+                        sum += hit ? (u64)L : 0ull;                                                        \
+                    }
+                    RIOGP_ROW(cv.x, av.x, lv.x, 0)
+                    RIOGP_ROW(cv.y, av.y, lv.y, 1)
+                    RIOGP_ROW(cv.z, av.z, lv.z, 2)
+                    RIOGP_ROW(cv.w, av.w, lv.w, 3)
 #undef RIOGP_ROW
+                    sum = wave_sum(sum);
+                    if (lane == 0 && sum) atomicAdd(&T[t], sum);
+                }
+            } else {
+                // pass: claim load per (local node, piece of its range); a tile (256 rows) lies inside ONE piece.  The next tile is
+                // in flight while this one is processed: ONE workgroup streams the block (470 KB of a 10 M-row table), and with a
+                // single tile per wave outstanding it ran at ~25 GB/s — 12 us per pass while most of the chip idles.
+                uint4 cvn = make_uint4(0, 0, 0, 0), avn = cvn, lvn = cvn;
+                if (wstart < wend) {
+                    const u64 f0 = wstart + (u64)lane * 4;
+                    cvn = *reinterpret_cast<const uint4*>(cur + f0);
+                    avn = *reinterpret_cast<const uint4*>(aff + f0);
+                    lvn = *reinterpret_cast<const uint4*>(load + f0);
+                }
+                for (u64 it = wstart; it < wend; it += kTile) {
+                    const u64 i0 = it + (u64)lane * 4;
+                    const uint4 cv = cvn, av = avn, lv = lvn;
+                    {
+                        const u64 pn = (it + kTile < wend ? it + kTile : it) + (u64)lane * 4;  // (the last tile re-reads itself)
+                        cvn = *reinterpret_cast<const uint4*>(cur + pn);
+                        avn = *reinterpret_cast<const uint4*>(aff + pn);
+                        lvn = *reinterpret_cast<const uint4*>(load + pn);
+                    }
+                    const u32 tb = (u32)((it - bstart) / kTile);
+                    const u32 t_lvl0 = tb / ptiles;
+    #define RIOGP_ROW(C, A, L, E)                                                                              \
+                    {                                                                                          \
+                        /* branch-free class test (as P3): claimant = in range, not kept, not a duplicate, affinity live */ \
+                        const bool cin = C < m, ain = A < m;                                                   \
+                        const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                        \
+                        const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                \
+                        const u32 ls = (u32)slot[ax] - g0;  /* kSlotNone - g0 >= kn always */                  \
+                        bool hit = (i0 + E < wend) & !kept & !(VIRT && C == kSkipMark) & ain & bit_of(alv, ax) & (ls < kn); \
+                        u32 t = 0;                                                                             \
+                        if (level == 0) {                                                                      \
+                            t = t_lvl0;  /* every range is the whole block: the piece is a property of the tile */ \
+                        } else if (hit) {                                                                      \
+                            const u32 off = tb - (u32)st_rs[ls];  /* below the range wraps to a huge value */  \
+                            hit = off < rlen;                                                                  \
+                            t = off / ptiles;                                                                  \
+                        }                                                                                      \
+                        const u64 todo = __ballot(hit);                                                        \
+                        if (__popcll(todo) >= 16) { /* a HOT node (>= 16 rows of this wave-element): one LDS atomic, not 16+ */ \
+                            const int ld = __ffsll((long long)todo) - 1;                                       \
+                            const u32 s0 = (u32)__shfl((int)(ls * Sp + t), ld, 64);                            \
+                            const bool same = hit && ls * Sp + t == s0;                                        \
+                            if (__popcll(__ballot(same)) >= 16) {                                              \
+                                const u64 sum = wave_sum(same ? (u64)L : 0ull);                                \
+                                if (lane == ld) atomicAdd(&T[s0], sum);                                        \
+                                hit = hit && !same;                                                            \
+                            }                                                                                  \
+                        }                                                                                      \
+                        if (hit) atomicAdd(&T[ls * Sp + t], (u64)L);                                           \
+                    }
+                    RIOGP_ROW(cv.x, av.x, lv.x, 0)
+                    RIOGP_ROW(cv.y, av.y, lv.y, 1)
+                    RIOGP_ROW(cv.z, av.z, lv.z, 2)
+                    RIOGP_ROW(cv.w, av.w, lv.w, 3)
+    #undef RIOGP_ROW
+                }
             }
             __syncthreads();
             const u64 tr_b = KT_ON ? wall_clock64() : 0;
