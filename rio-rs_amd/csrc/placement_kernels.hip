@@ -1920,6 +1920,26 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         const u64 l0 = mk0 ? lv.x : 0, l1 = mk1 ? lv.y : 0;
         const u64 l2 = mk2 ? lv.z : 0, l3 = mk3 ? lv.w : 0;
         const u64 lsum = l0 + l1 + l2 + l3;
+        if (cnt == 0 || run >= F) {
+            // Nothing from here on can be placed: the prefix Q of every remaining row of this wave is >= run >= F, the total
+            // free capacity of this round (wave-uniform, and it stays true for the wave's later tiles).  The rows are only
+            // counted — no prefix scan, no bracket, no searches: a contended table sends ~1 M rows through both rounds this
+            // way, and they sit in the last tenth of the workgroups.
+            rem_sum += lsum;
+            rem_cnt += (u32)mk0 + (u32)mk1 + (u32)mk2 + (u32)mk3;
+            if (last) {
+                uint4 ov = nv;
+                ov.x = mk0 ? kNone : ov.x; ov.y = mk1 ? kNone : ov.y; ov.z = mk2 ? kNone : ov.z; ov.w = mk3 ? kNone : ov.w;
+                *reinterpret_cast<uint4*>(next + i0) = ov;  // (every lane: whole lines; lanes without marks rewrite their values)
+                if (scat && last == 1) {
+                    if (mk0) real_next[iv.x] = kNone;
+                    if (mk1) real_next[iv.y] = kNone;
+                    if (mk2) real_next[iv.z] = kNone;
+                    if (mk3) real_next[iv.w] = kNone;
+                }
+            }
+            continue;
+        }
         const u64 inc = wave_incl_scan(lsum, lane);
         u64 Q = run + (inc - lsum);
         const u64 run_end = run + shfl64(inc, 63);
