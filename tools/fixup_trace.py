@@ -84,5 +84,11 @@ if busy.any():
     out["block_search_last_item_per_wg"] = {"workgroups_with_nodes": int(busy.sum()), "nodes_median_max": [float(np.median(ct[busy, 5])), int(ct[busy, 5].max())],
                                             "P0_us_median": us(np.median(ct[busy, 1] - ct[busy, 0])), "passes_us_median": us(np.median(ct[busy, 2])),
                                             "walks_us_median": us(np.median(ct[busy, 7])), "row_search_us_median": us(np.median(ct[busy, 3])), "S_median": float(np.median(ct[busy, 6]))}
+if busy.any():   # the three slowest block searches, phase by phase
+    tot = ct[:, 4] - ct[:, 0]
+    order = [int(b) for b in np.argsort(-tot * busy)[:3]]
+    out["slowest_block_searches"] = [{"workgroup": b, "nodes": int(ct[b, 5]), "S": int(ct[b, 6]), "total_us": us(tot[b]),
+                                      "P0_us": us(ct[b, 1] - ct[b, 0]), "passes_us": us(ct[b, 2]), "walks_us": us(ct[b, 7]),
+                                      "row_search_us": us(ct[b, 3])} for b in order]
 print(json.dumps(out, indent=1))
 g.close()
