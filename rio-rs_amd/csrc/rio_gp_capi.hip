@@ -1782,13 +1782,11 @@ int rio_gp_debug_ktrace(rio_gp_t* h, int table, uint64_t* out2048) {
 }
 
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
-    if (!h || mode < 0 || (mode & 15) > 2) return RIO_GP_EINVAL;
+    if (!h || mode < 0 || mode >= 128 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
     std::lock_guard<std::mutex> g(h->mu);
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
     h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
-    if (h->cutpack_mode == 3) return RIO_GP_EINVAL;
-    mode &= 15;
-    h->compact_mode = mode;
+    h->compact_mode = mode & 15;
     return RIO_GP_OK;
 }
 

@@ -318,6 +318,11 @@ def test_invalid_arguments_are_unknown_errors(gp):
         assert e.value.kind == "Unknown" and e.value.rc == gp.EINVAL
     assert np.all(g.get_assign() == NONE)       # nothing was mutated
     assert g.clean_server(7) == 0               # unknown address: retain() removes nothing
+    # the debug knobs reject what they do not know (modes are 0 | 1 | 2 in every field)
+    for bad in (3, 3 << 5, 7):
+        assert gp.lib().rio_gp_debug_set_compact(g.handle, bad) == gp.EINVAL
+    assert gp.lib().rio_gp_debug_set_fixup(g.handle, 3, 0) == gp.EINVAL
+    assert gp.lib().rio_gp_debug_set_compact(g.handle, 2 | 16 | (1 << 5)) == 0   # never | plain CRUD | cut-pass packing always
     g.close()
 
 
