@@ -21,6 +21,7 @@ constexpr int kBlock = kWaves * 64;  // 1024 threads: ONE workgroup per CU owns 
 constexpr int kTile = 256;           // objects per wave-iteration: 64 lanes x dwordx4
 constexpr u32 kMaxBlocks = 256;      // = CUs; rows of the per-block histogram table
 constexpr u32 kMaxSubs = 256;
+constexpr int kMidBatch = 16384;     // lookups of up to this many entries go through mapped pinned memory and a completion word
 constexpr int kSmallBatch = 256;     // place_pending / lookup micro-batches served by one workgroup and one launch        // sub-chunks per block for the exact-cut refinement
 
 // Work decomposition of a table of n rows.  Index order is the only order that matters:
@@ -172,7 +173,8 @@ void launch_lookup_small(const u32* assign, u64 n_obj, const u32* idx, u32 n, u3
 // done / seq (lookup, update_small, remove, pp_small): when the call is ONE workgroup, its last act is to store seq into
 // *done (mapped pinned memory) — the host spins on the word instead of waiting for the stream; nullptr = no word
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s,
-                   u32* done = nullptr, u32 seq = 0);
+                   u32* done = nullptr, u32 seq = 0, unsigned int* ticket = nullptr);  // ticket (device word, 0 between calls):
+                   // several workgroups may share the completion word — the last one to finish stores it
 // aff_life (every CRUD launcher below): the affinity column when the handle tracks the row lifecycle (rows that are
 // written become objects, rows that are removed / deleted / dropped by clean_server stop being objects), else nullptr
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos_scratch,

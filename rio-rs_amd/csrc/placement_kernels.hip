@@ -2101,6 +2101,20 @@ __device__ __forceinline__ void signal_done(u32* done, u32 seq) {
     if (threadIdx.x == 0) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // ... the word is
 }
 
+// The same for a call of several workgroups (medium batches): every workgroup fences its result stores and takes a ticket;
+// the last one resets the ticket and stores the completion word.
+__device__ __forceinline__ void signal_done_grid(unsigned int* ticket, u32* done, u32 seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Requests of the smallest calls (n <= 4: the reference's one-object-per-request flow) travel in the kernel arguments
 // instead of mapped pinned memory: the kernel saves a PCIe read round trip (1.3 us of a 7-9 us call, tools/sync_probe.py).
 __device__ __forceinline__ u32 inl_sel(const uint4 v, u32 k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
@@ -2124,7 +2138,8 @@ __global__ __launch_bounds__(kSmallBatch) void k_lookup_small(const u32* __restr
 // one dependent 4-byte gather per lane and iteration — reached 40 % of the roofline on sequential indices and 7.7 % on
 // random ones, where every gather pulls a whole 128-byte line through the fabric for 4 useful bytes).
 __global__ __launch_bounds__(256) void k_lookup4(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u64 n,
-                                                 u32* __restrict__ out, DevStats* st, u32* done, u32 seq) {
+                                                 u32* __restrict__ out, DevStats* st, u32* done, u32 seq,
+                                                 unsigned int* ticket) {
     const u64 nvec = n >> 2;
     u32 bad = 0;
     const u64 stride = (u64)gridDim.x * 256;
@@ -2154,7 +2169,8 @@ __global__ __launch_bounds__(256) void k_lookup4(const u32* __restrict__ assign,
     }
 #undef RIOGP_G
     if (bad) atomicAdd(&st->err, (u64)bad);
-    signal_done(done, seq);
+    if (ticket) signal_done_grid(ticket, done, seq);  // medium batches in mapped pinned memory: several workgroups
+    else signal_done(done, seq);
 }
 // the same for index / result arrays that are not 16-byte aligned
 __global__ void k_lookup(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u64 n,
@@ -3315,12 +3331,14 @@ void launch_spill_round(const Plan& p_in, const Table& t, const NodeTab& nt, con
 }
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s, u32* done,
-                   u32 seq) {
+                   u32 seq, unsigned int* ticket) {
     if (!n) return;
     const bool vec = (((uintptr_t)idx | (uintptr_t)out) & 15u) == 0;
     const unsigned g = vec ? grid_for((n + 3) / 4, 256, 2048) : grid_for(n, 256, 4096);
-    if (g != 1) done = nullptr;  // the completion word is a single-workgroup protocol (callers pass it for micro-batches only)
-    if (vec) hipLaunchKernelGGL(k_lookup4, dim3(g), dim3(256), 0, s, assign, n_obj, idx, n, out, st, done, seq);
+    if (!vec) ticket = nullptr;  // (the several-workgroup completion protocol is k_lookup4's)
+    if (g != 1 && !ticket) done = nullptr;  // without a ticket the completion word is a single-workgroup protocol
+    if (!done) ticket = nullptr;
+    if (vec) hipLaunchKernelGGL(k_lookup4, dim3(g), dim3(256), 0, s, assign, n_obj, idx, n, out, st, done, seq, ticket);
     else hipLaunchKernelGGL(k_lookup, dim3(g), dim3(256), 0, s, assign, n_obj, idx, n, out, st, done, seq);
 }
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos, DevStats* st,

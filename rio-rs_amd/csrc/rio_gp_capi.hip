@@ -168,6 +168,9 @@ struct rio_gp {
     u32* h_small = nullptr;
     u32* d_small = nullptr;
     u64 wait_seq = 1;       // sequence numbers of the synchronous solves (spin_rows): never 0 or 1
+    u32* h_mid = nullptr;   // medium lookup batches (<= kMidBatch): [2][kMidBatch] u32 = idx | out, mapped pinned memory
+    u32* d_mid = nullptr;
+    unsigned int* mid_ticket = nullptr;  // device word of the several-workgroup completion protocol
     u32 small_seq = 0;      // sequence number of the last micro-batch call; its completion word is row 5, word 0
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
@@ -666,6 +669,14 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     memset(h->h_small, 0, (size_t)6 * kSmallBatch * sizeof(u32));  // completion word: 0 = no call yet (sequence numbers start at 1)
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_mid), (size_t)2 * kMidBatch * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mid), h->h_mid, 0) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->mid_ticket), sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(h->mid_ticket, 0, sizeof(unsigned int)) != hipSuccess) {
+        h->err = "hipHostMalloc(mapped medium-batch staging) failed";
+        return bail(RIO_GP_ENOMEM);
+    }
+    h->allocs.push_back(h->mid_ticket);
     // every row starts unplaced; the position scratch is all-ones between calls
     launch_fill_u32(h->assign[0], R, kNone, h->stream);
     launch_fill_u32(h->assign[1], R, kNone, h->stream);
@@ -697,6 +708,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->h_slots) (void)hipHostFree(h->h_slots);
     if (h->h_fx) (void)hipHostFree(h->h_fx);
     if (h->h_small) (void)hipHostFree(h->h_small);
+    if (h->h_mid) (void)hipHostFree(h->h_mid);
     if (h->h_cs) (void)hipHostFree(h->h_cs);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -938,6 +950,17 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
                             small_done_dev(h), seq, in_args ? &inl : nullptr);
         if ((rc = small_wait(h, seq))) return rc;
         memcpy(out_node, h->h_small + 2 * kSmallBatch, n * sizeof(u32));
+        return RIO_GP_OK;
+    }
+    if (n <= (uint64_t)kMidBatch) {
+        // medium batch: indices and results in mapped pinned memory, a few workgroups, the last one stores the completion
+        // word — no staging copies through the runtime, no stream wait (1 000 lookups: 29.5 -> ~13 us per call)
+        memcpy(h->h_mid, idx, n * sizeof(u32));
+        const u32 seq = small_begin(h);
+        launch_lookup(h->assign[h->cur], h->n, h->d_mid, n, h->d_mid + kMidBatch, h->dstats, h->stream, small_done_dev(h), seq,
+                      h->mid_ticket);
+        if ((rc = small_wait(h, seq))) return rc;
+        memcpy(out_node, h->h_mid + kMidBatch, n * sizeof(u32));
         return RIO_GP_OK;
     }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;

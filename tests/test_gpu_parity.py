@@ -235,6 +235,26 @@ def test_crud_micro_batches(gp, oracle, seed):
     g.close()
 
 
+def test_lookup_batch_sizes_around_every_path_boundary(gp, oracle):
+    """lookup_batch takes the one-workgroup kernel up to 256 entries (requests in the kernel arguments up to 4), mapped pinned
+    memory with a several-workgroup completion word up to 16 384, staging copies beyond: the sizes on both sides of every
+    boundary, twice each (the completion protocol resets its ticket itself)."""
+    rng = np.random.default_rng(3)
+    n, m = 500_000, 77
+    ref = rng.integers(0, m, n).astype(np.uint32)
+    ref[rng.random(n) < 0.3] = NONE
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    g.set_objects(n)
+    g.set_assign(ref)
+    for k in (1, 4, 5, 255, 256, 257, 1000, 1023, 1024, 1025, 4097, 16383, 16384, 16385, 70_000) * 2:
+        q = rng.integers(0, n, k).astype(np.uint32)
+        assert np.array_equal(g.lookup_batch(q), ref[q]), k
+    with pytest.raises(gp.ObjectPlacementError):
+        g.lookup_batch(np.array([0] * 300 + [n], np.uint32))   # an index out of range in a medium batch: refused, nothing read
+    g.close()
+
+
 @pytest.mark.parametrize("seed,n,m,k", [(0, 2_000_003, 300, 3_000_000), (1, 600_000, 7, 262_144), (2, 10_000_000, 1024, 10_000_000)])
 def test_crud_big_batches_partitioned_by_row_window(gp, oracle, seed, n, m, k):
     """update_batch / remove_batch of >= 2^18 entries take the window-partitioned kernels (k_part_bin, k_part_update,
