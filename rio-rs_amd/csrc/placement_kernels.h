@@ -220,7 +220,8 @@ void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const 
                       u32* vcur, u32* vload, u32* vaff, hipStream_t s);
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
                        u32* pos_scratch, const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node,
-                       u32* out_flag, hipStream_t s, u32* aff_life = nullptr);
+                       u32* out_flag, hipStream_t s, u32* aff_life = nullptr, unsigned int* ticket = nullptr,
+                       u32* done = nullptr, u32 seq = 0);  // ticket/done/seq: the several-workgroup completion word (launch_lookup)
 
 size_t scan_lds_bytes(u32 m);
 

@@ -168,7 +168,7 @@ struct rio_gp {
     u32* h_small = nullptr;
     u32* d_small = nullptr;
     u64 wait_seq = 1;       // sequence numbers of the synchronous solves (spin_rows): never 0 or 1
-    u32* h_mid = nullptr;   // medium lookup batches (<= kMidBatch): [2][kMidBatch] u32 = idx | out, mapped pinned memory
+    u32* h_mid = nullptr;   // medium batches (<= kMidBatch), mapped pinned memory, [4][kMidBatch] u32: lookup idx | out; place_pending idx | req | out | flag
     u32* d_mid = nullptr;
     unsigned int* mid_ticket = nullptr;  // device word of the several-workgroup completion protocol
     u32 small_seq = 0;      // sequence number of the last micro-batch call; its completion word is row 5, word 0
@@ -669,7 +669,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     memset(h->h_small, 0, (size_t)6 * kSmallBatch * sizeof(u32));  // completion word: 0 = no call yet (sequence numbers start at 1)
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_mid), (size_t)2 * kMidBatch * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_mid), (size_t)4 * kMidBatch * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mid), h->h_mid, 0) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->mid_ticket), sizeof(unsigned int)) != hipSuccess ||
         hipMemset(h->mid_ticket, 0, sizeof(unsigned int)) != hipSuccess) {
@@ -1135,8 +1135,9 @@ int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
 // these, the _dev call hands its own): mark dead -> clean -> elect first request -> gather the virtual table -> solve it
 // against the committed `used` (same kernels, VIRT) -> scatter + outputs.  check_entries: the entries were not
 // validated on the host, so k_pp_mark_dead's count of bad ones is read BEFORE anything is changed.
+// done_seq != 0: the request / result arrays are mapped pinned memory and the last kernel stores the completion word
 static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const u32* d_req, u32* d_out, u32* d_flag,
-                                 bool check_entries) {
+                                 bool check_entries, u32 done_seq = 0) {
     int rc;
     const size_t bytes = n * sizeof(u32);
     for (int q = 0; q < 4; ++q)
@@ -1172,7 +1173,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     }
     // (5) publish, outputs, new `used`
     launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
-                      h->stream, aff_life(h));
+                      h->stream, aff_life(h), done_seq ? h->mid_ticket : nullptr, done_seq ? small_done_dev(h) : nullptr, done_seq);
     HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
                              hipMemcpyDeviceToDevice, h->stream));
     h->have_solved = false;
@@ -1217,6 +1218,21 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         // status 1: a dead node / dead or full requester is involved — nothing was changed, take the general path
     }
     const size_t bytes = n * sizeof(u32);
+    if (n <= (uint64_t)kMidBatch / 4) {
+        // medium batch (<= 4 096 requests): requests and results in mapped pinned memory (the kernels of the general path read
+        // and write them in place — five kernels re-read them over PCIe, which is why the bound is lower than for lookups),
+        // the output kernel's last workgroup stores the completion word: four staging copies and the stream wait less per call
+        u32* hm = h->h_mid;
+        u32* dm = h->d_mid;
+        memcpy(hm, idx, bytes);
+        memcpy(hm + kMidBatch, requester, bytes);
+        const u32 seq = small_begin(h);
+        if ((rc = place_pending_general(h, n, dm, dm + kMidBatch, dm + 2 * kMidBatch, dm + 3 * kMidBatch, false, seq))) return rc;
+        if ((rc = small_wait(h, seq))) return rc;
+        memcpy(out_node, hm + 2 * kMidBatch, bytes);
+        if (out_flag) memcpy(out_flag, hm + 3 * kMidBatch, bytes);
+        return RIO_GP_OK;
+    }
     for (int q = 0; q < 4; ++q)
         if ((rc = ensure(h, h->stage[q], bytes))) return rc;
     u32 *d_idx = (u32*)h->stage[0].p, *d_req = (u32*)h->stage[1].p, *d_out = (u32*)h->stage[2].p,

@@ -645,6 +645,35 @@ def test_place_pending_replaced_flag(gp, oracle):
     g.close()
 
 
+def test_place_pending_batch_sizes_around_every_path_boundary(gp, oracle):
+    """place_pending: one workgroup up to 256 requests, the general path over mapped pinned memory (completion word stored by
+    the output kernel's last workgroup) up to 4 096, staging copies beyond — the sizes on both sides of every boundary, with
+    nodes dying in between, every call against the sequential oracle (nodes, flags, table, `used`)."""
+    rng = np.random.default_rng(21)
+    n, m = 300_000, 50
+    load = rng.integers(1, 30, n).astype(np.uint32)
+    cap = np.full(m, int(load.sum()) // m + 5000, np.uint64)
+    alive = np.ones(m, np.uint8)
+    g = gp.GpuPlacement(n, m, spill_rounds=2)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step, k in enumerate((256, 257, 1000, 4095, 4096, 4097, 20_000, 300, 2048, 257)):
+        if step % 3 == 2:
+            j = int(rng.integers(m))
+            alive[j] ^= 1
+            g.set_alive(j, alive[j])
+        idx = rng.integers(0, n // 4, k).astype(np.uint32)
+        req = np.flatnonzero(alive)[rng.integers(0, int(alive.sum()), k)].astype(np.uint32)
+        node, flag = g.place_pending(idx, req)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(node, wnode) and np.array_equal(flag, wflag), (step, k)
+        assert np.array_equal(g.get_assign(), ref), (step, k)
+        assert np.array_equal(g.get_nodes()[2], used), (step, k)
+    g.close()
+
+
 @pytest.mark.parametrize("seed,cap_mode", [(0, "inf"), (1, "tight"), (2, "roomy"), (3, "tight")])
 def test_place_pending_micro_batches(gp, oracle, seed, cap_mode):
     """Batches of 1..256 requests take the one-launch micro-batch kernel (k_pp_small) when nothing heavy is
