@@ -178,13 +178,14 @@ void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out
 // aff_life (every CRUD launcher below): the affinity column when the handle tracks the row lifecycle (rows that are
 // written become objects, rows that are removed / deleted / dropped by clean_server stop being objects), else nullptr
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos_scratch,
-                   DevStats* st, hipStream_t s, u32* aff_life = nullptr);
+                   DevStats* st, hipStream_t s, u32* aff_life = nullptr, unsigned int* ticket = nullptr, u32* done = nullptr,
+                   u32 seq = 0);
 // n <= kSmallBatch validated entries (may be mapped host memory): last writer wins inside the batch, one launch
 void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr,
                          u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
                    DevStats* st, hipStream_t s, u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0,
-                   const SmallInline* inl = nullptr);
+                   const SmallInline* inl = nullptr, unsigned int* ticket = nullptr);
 // big random batches, partitioned by row window first (k_part_bin ...): part_applicable says whether a batch qualifies,
 // scratch = part_scratch_words(n_obj, n) u32 words of device memory
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node_or_null);

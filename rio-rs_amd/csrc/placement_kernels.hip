@@ -2199,7 +2199,8 @@ __global__ void k_update_elect(u64 n_obj, u32 m, const u32* __restrict__ idx, co
 // aff_life (row lifecycle, nullptr otherwise): the written row becomes an object whose affinity is its node, a deleted
 // one (node NONE, local.rs:36-37) stops being one
 __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ idx,
-                               const u32* __restrict__ node, u64 n, u32* __restrict__ pos, u32* __restrict__ aff_life) {
+                               const u32* __restrict__ node, u64 n, u32* __restrict__ pos, u32* __restrict__ aff_life,
+                               unsigned int* ticket, u32* done, u32 seq) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k], nd = node[k];
         if (i < n_obj && (nd == kNone || nd < m) && pos[i] == (u32)(n - 1 - k)) {
@@ -2208,6 +2209,7 @@ __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const
             if (aff_life) aff_life[i] = nd == kNone ? kAffInactive : nd;
         }
     }
+    if (done) signal_done_grid(ticket, done, seq);  // medium batches from mapped pinned memory: the host spins on the word
 }
 // update, micro-batch (n <= kSmallBatch): one workgroup, one launch; entries were validated by the host and may sit in
 // mapped host memory.  Sequential last-writer-wins inside the batch: an entry loses to any LATER entry for the same row.
@@ -2241,7 +2243,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
 __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                    const u32* __restrict__ load, const u32* __restrict__ idx, u64 n,
                                                    u64* __restrict__ used, DevStats* st, u32* __restrict__ aff_life,
-                                                   u32* done, u32 seq, u32 ninl, uint4 ia) {
+                                                   u32* done, u32 seq, u32 ninl, uint4 ia, unsigned int* ticket) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* rel = reinterpret_cast<u64*>(smem);  // [m] load released per node (only when `used` is maintained)
     if (used) {
@@ -2263,7 +2265,8 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
         for (u32 j = threadIdx.x; j < m; j += kBlock)
             if (rel[j]) atomicAdd(&used[j], (u64)0 - rel[j]);
     }
-    signal_done(done, seq);
+    if (ticket) signal_done_grid(ticket, done, seq);
+    else signal_done(done, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3344,11 +3347,12 @@ void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out
     else hipLaunchKernelGGL(k_lookup, dim3(g), dim3(256), 0, s, assign, n_obj, idx, n, out, st, done, seq);
 }
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos, DevStats* st,
-                   hipStream_t s, u32* aff_life) {
+                   hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq) {
     if (!n) return;
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
-    hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos, aff_life);
+    hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos, aff_life, ticket,
+                       ticket ? done : nullptr, seq);
 }
 // inl (every micro-batch launcher): the n <= 4 requests themselves (a = indices, b = nodes / requesters), or nullptr
 static inline uint4 inl_a(const SmallInline* inl) { return inl ? make_uint4(inl->a[0], inl->a[1], inl->a[2], inl->a[3]) : make_uint4(0, 0, 0, 0); }
@@ -3366,12 +3370,13 @@ void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hi
                        inl ? n : 0u, inl_a(inl), inl_b(inl));
 }
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
-                   hipStream_t s, u32* aff_life, u32* done, u32 seq, const SmallInline* inl) {
+                   hipStream_t s, u32* aff_life, u32* done, u32 seq, const SmallInline* inl, unsigned int* ticket) {
     if (!n) return;
     const unsigned g = grid_for(n, kBlock * 4, 256);
-    if (g != 1) done = nullptr;  // (single-workgroup protocol)
+    if (g != 1 && !ticket) done = nullptr;  // without a ticket the completion word is a single-workgroup protocol
+    if (!done) ticket = nullptr;
     hipLaunchKernelGGL(k_remove, dim3(g), dim3(kBlock), used ? (size_t)m * sizeof(u64) : 0, s, assign,
-                       n_obj, m, load, idx, n, used, st, aff_life, done, seq, (inl && n <= 4) ? (u32)n : 0u, inl_a(inl));
+                       n_obj, m, load, idx, n, used, st, aff_life, done, seq, (inl && n <= 4) ? (u32)n : 0u, inl_a(inl), ticket);
 }
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.

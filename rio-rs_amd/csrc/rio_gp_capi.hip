@@ -1021,6 +1021,18 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         h->have_solved = false;
         return small_wait(h, seq);
     }
+    if (n <= (uint64_t)kMidBatch) {
+        // medium batch, validated above: the election and the apply kernel read the entries from mapped pinned memory, the
+        // apply kernel's last workgroup stores the completion word — no staging copies, no counter read-back, no stream wait
+        memcpy(h->h_mid, idx, n * sizeof(u32));
+        memcpy(h->h_mid + kMidBatch, node, n * sizeof(u32));
+        const u32 seq = small_begin(h);
+        launch_update(h->assign[h->cur], h->n, h->m, h->d_mid, h->d_mid + kMidBatch, n, h->pos, h->dstats, h->stream, aff_life(h),
+                      h->mid_ticket, small_done_dev(h), seq);
+        h->used_valid = false;
+        h->have_solved = false;
+        return small_wait(h, seq);
+    }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->stage[0].p, idx, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->stage[1].p, node, n * sizeof(u32), hipMemcpyHostToDevice, h->stream));
@@ -1066,6 +1078,14 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
         const u32 seq = small_begin(h);
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_small, n, h->used_valid ? h->used : nullptr, h->dstats,
                       h->stream, aff_life(h), small_done_dev(h), seq, in_args ? &inl : nullptr);
+        h->have_solved = false;
+        return small_wait(h, seq);
+    }
+    if (n <= (uint64_t)kMidBatch) {  // medium batch, validated above: as update_batch
+        memcpy(h->h_mid, idx, n * sizeof(u32));
+        const u32 seq = small_begin(h);
+        launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_mid, n, h->used_valid ? h->used : nullptr, h->dstats,
+                      h->stream, aff_life(h), small_done_dev(h), seq, nullptr, h->mid_ticket);
         h->have_solved = false;
         return small_wait(h, seq);
     }

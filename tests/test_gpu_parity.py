@@ -235,6 +235,32 @@ def test_crud_micro_batches(gp, oracle, seed):
     g.close()
 
 
+def test_update_remove_batch_sizes_around_every_path_boundary(gp, oracle):
+    """update_batch / remove_batch from host buffers: one workgroup up to 256 entries, mapped pinned memory with a completion
+    word up to 16 384, staging copies beyond — with duplicates and deletions inside every batch, `used` maintained."""
+    rng = np.random.default_rng(12)
+    n, m = 200_000, 33
+    load = rng.integers(0, 50, n).astype(np.uint32)
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    for k in (256, 257, 1000, 4096, 16383, 16384, 16385, 50_000, 300, 257):
+        idx = rng.integers(0, n // 3, k).astype(np.uint32)          # plenty of duplicates: the last writer wins
+        node = rng.integers(0, m, k).astype(np.uint32)
+        node[rng.random(k) < 0.1] = NONE
+        g.update_batch(idx, node)
+        assert oracle.update_batch(ref, m, idx, node) == 0
+        assert np.array_equal(g.get_assign(), ref), k
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m)), k
+        rm = rng.integers(0, n // 3, max(1, k // 2)).astype(np.uint32)
+        g.remove_batch(rm)
+        oracle.remove_batch(ref, rm)
+        assert np.array_equal(g.get_assign(), ref), k
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m)), k
+    g.close()
+
+
 def test_lookup_batch_sizes_around_every_path_boundary(gp, oracle):
     """lookup_batch takes the one-workgroup kernel up to 256 entries (requests in the kernel arguments up to 4), mapped pinned
     memory with a several-workgroup completion word up to 16 384, staging copies beyond: the sizes on both sides of every
