@@ -222,7 +222,8 @@ void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const 
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
                        u32* pos_scratch, const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node,
                        u32* out_flag, hipStream_t s, u32* aff_life = nullptr, unsigned int* ticket = nullptr,
-                       u32* done = nullptr, u32 seq = 0);  // ticket/done/seq: the several-workgroup completion word (launch_lookup)
+                       u32* done = nullptr, u32 seq = 0, bool flag_bits = true);  // ticket/done/seq: the several-workgroup
+                       // completion word (launch_lookup); flag_bits: out_flag holds k_pp_mark_dead's REPLACED bits
 
 size_t scan_lds_bytes(u32 m);
 

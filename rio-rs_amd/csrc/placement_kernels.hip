@@ -2696,7 +2696,7 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
                             u32* __restrict__ pos, const u32* __restrict__ alive_bits,
                             const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
                             u32* __restrict__ out_flag, u32* __restrict__ aff_life, unsigned int* ticket, u32* done,
-                            u32 seq) {
+                            u32 seq, u32 keep_mask /* kFlagReplaced, or 0 when k_pp_mark_dead did not run (every node alive) */) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k], r = req[k];
         const u32 nd = assign[i];
@@ -2710,7 +2710,7 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
         } else fl = (nd == r) ? 0u : 1u;                           // LOCAL | REDIRECT
         out_node[k] = nd;
         // the column still holds k_pp_mark_dead's "found on a dead node" bits: the first request of the object keeps its own
-        if (out_flag) out_flag[k] = fl | (vcur[k] == kNone ? (out_flag[k] & kFlagReplaced) : 0u);
+        if (out_flag) out_flag[k] = fl | ((keep_mask && vcur[k] == kNone) ? (out_flag[k] & keep_mask) : 0u);
         pos[i] = kNone;
     }
     if (done) signal_done_grid(ticket, done, seq);  // medium batches: the outputs sit in mapped pinned memory, the host spins
@@ -3483,11 +3483,12 @@ void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const 
 }
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext, u32* pos,
                        const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node, u32* out_flag,
-                       hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq) {
+                       hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq, bool flag_bits) {
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_pp_scatter, dim3(g), dim3(256), 0, s, assign, idx, n, vcur, vnext);
     hipLaunchKernelGGL(k_pp_output, dim3(g), dim3(256), 0, s, assign, idx, req, n, vcur, pos, alive_bits,
-                       cutidx_or_null, m, out_node, out_flag, aff_life, ticket, (ticket ? done : nullptr), seq);
+                       cutidx_or_null, m, out_node, out_flag, aff_life, ticket, (ticket ? done : nullptr), seq,
+                       flag_bits ? kFlagReplaced : 0u);
 }
 
 void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s) {

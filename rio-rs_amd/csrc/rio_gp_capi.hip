@@ -1166,15 +1166,21 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     u32* assign = h->assign[h->cur];
     h->sb.fx = FxRows{};  // nobody reads the fix-up counters of the virtual-table solve: plain DevStats atomics, no pinned slot touched
     if ((rc = ensure_used(h))) return rc;
-    if ((rc = zero_stats(h))) return rc;
-    // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
-    launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream, d_flag);
-    if (check_entries) {
-        if ((rc = read_stats(h))) return rc;
-        if (h->h_stats[0].err)
-            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
+    // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes.  With every node alive and
+    //     the entries validated on the host there is nothing to mark, nothing to clean and no counter to read: four
+    //     enqueues less on a path whose cost is its launches.
+    const bool mark = check_entries || !h->all_alive;
+    if (mark) {
+        if ((rc = zero_stats(h))) return rc;
+        launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream, d_flag);
+        if (check_entries) {
+            if ((rc = read_stats(h))) return rc;
+            if (h->h_stats[0].err)
+                return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
+        }
+        if (!h->all_alive)
+            launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
     }
-    launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
     // (2)(3) first request per row decides; gather the virtual table (rows = requests)
     launch_pp_gather(assign, h->load, d_idx, d_req, n, h->pos, vcur, vload, vaff, h->stream);
     // (4) solve the virtual table against the committed `used`
@@ -1193,9 +1199,9 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     }
     // (5) publish, outputs, new `used`
     launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
-                      h->stream, aff_life(h), done_seq ? h->mid_ticket : nullptr, done_seq ? small_done_dev(h) : nullptr, done_seq);
-    HIPCHK(h, hipMemcpyAsync(h->used, h->sb.used_cur, (size_t)(h->m ? h->m : 1) * sizeof(u64),
-                             hipMemcpyDeviceToDevice, h->stream));
+                      h->stream, aff_life(h), done_seq ? h->mid_ticket : nullptr, done_seq ? small_done_dev(h) : nullptr, done_seq,
+                      mark);
+    std::swap(h->used, h->sb.used_cur);  // the solve's `used` vector becomes the committed one (as commit does): no copy
     h->have_solved = false;
     return RIO_GP_OK;
 }
