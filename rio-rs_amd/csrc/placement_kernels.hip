@@ -2727,6 +2727,7 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
 // requester, a full requester (water-fill) — makes it return status 1 having changed NOTHING, and
 // the caller runs the general path.  Results are identical either way (same ordered-prefix rule).
 // ------------------------------------------------------------------------------------------------
+constexpr u32 kPpTot = 2048;  // nodes up to which k_pp_small keeps a per-requester running total in LDS (16 KiB)
 __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assign, const u32* __restrict__ load,
                                                           u32 m, const u64* __restrict__ cap,
                                                           const u32* __restrict__ alive_bits, u64* __restrict__ used,
@@ -2736,6 +2737,8 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
                                                           u32* __restrict__ status, u32* __restrict__ aff_life,
                                                           u32* done, u32 seq, u32 ninl, uint4 ia, uint4 ib) {
     __shared__ u32 s_req[kSmallBatch], s_load[kSmallBatch], s_res[kSmallBatch];
+    __shared__ u64 s_tot[kPpTot];  // claim load per requester so far, in batch order (m <= kPpTot)
+    __shared__ unsigned char s_own[kPpTot];  // lane of a wave's (last) claimant per requester: duplicate detection
     __shared__ u32 s_general;
     const u32 k = threadIdx.x;
     const bool valid = k < n;
@@ -2770,9 +2773,49 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
     s_load[k] = claim ? l : 0;
     __syncthreads();
     u32 nd = c;
-    if (claim) {  // index-ordered inclusive prefix of the loads claiming requester r
-        u64 pre = 0;
+    // index-ordered inclusive prefix of the loads claiming requester r
+    u64 pre = 0;
+    if (m <= kPpTot) {
+        // Wave by wave, in batch order: the total of the earlier waves comes from a per-requester word in LDS that the last
+        // claimant of each requester in the wave advances; inside a wave a claimant whose requester nobody else of the wave
+        // claims (the usual case) has nothing to add up, otherwise the wave walks its 64 lanes with readlane.  The plain
+        // form below walks the LDS copy of the batch once per request: ~15 us for 256 requests, most of the call.
+        if (claim) s_tot[r] = 0;  // (every claimant of r stores the same zero)
+        __syncthreads();
+        const int lane = (int)(k & 63u), wave = (int)(k >> 6);
+        const u32 rkey = claim ? r : kNone;
+        const int nwaves = (int)((n + 63u) >> 6);
+        for (int w = 0; w < nwaves; ++w) {
+            if (wave == w && __ballot(claim)) {
+                // do two claimants of this wave share a requester?  each writes its lane into the requester's owner word
+                // and reads it back: a lane that reads another lane's number has company (LDS operations of one wave
+                // execute in order, so every lane sees the last writer)
+                if (claim) s_own[r] = (unsigned char)lane;
+                const bool shared = claim && s_own[r] != (unsigned char)lane;
+                u64 inw = claim ? (u64)l : 0ull;
+                bool later = false;
+                if (__ballot(shared)) {  // rare: the prefix over the lower lanes with the same requester, 64 readlane steps
+                    inw = 0;
+                    const int nsrc = (int)n - w * 64 < 64 ? (int)n - w * 64 : 64;  // requests of this wave
+                    for (int src = 0; src < nsrc; ++src) {
+                        const u32 rs = (u32)__builtin_amdgcn_readlane((int)rkey, src);
+                        const u32 ls = (u32)__builtin_amdgcn_readlane((int)l, src);
+                        const bool same = claim && rs == r;
+                        inw += (same && src <= lane) ? (u64)ls : 0ull;
+                        later |= same && src > lane;
+                    }
+                }
+                if (claim) {
+                    pre = s_tot[r] + inw;
+                    if (!later) s_tot[r] = pre;  // the requester's last claimant in this wave: total so far
+                }
+            }
+            __syncthreads();
+        }
+    } else if (claim) {
         for (u32 q = 0; q <= k; ++q) pre += (s_req[q] == r) ? (u64)s_load[q] : 0ull;
+    }
+    if (claim) {
         const u64 fre = cj > uj ? cj - uj : 0;
         if (pre <= fre) nd = r;
         else s_general = 1;  // requester full: water-fill needed
