@@ -183,6 +183,9 @@ void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* nod
 // n <= kSmallBatch validated entries (may be mapped host memory): last writer wins inside the batch, one launch
 void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr,
                          u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
+// n <= kSmallBatch validated entries (may be mapped host memory / kernel arguments): one small workgroup
+void launch_remove_small(u32* assign, u32 m, const u32* load, const u32* idx, u32 n, u64* used_or_null, hipStream_t s,
+                         u32* aff_life, u32* done, u32 seq, const SmallInline* inl);
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used_or_null,
                    DevStats* st, hipStream_t s, u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0,
                    const SmallInline* inl = nullptr, unsigned int* ticket = nullptr);

@@ -2248,6 +2248,23 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
     signal_done(done, seq);  // the host may reuse the staging rows once the word is there
 }
 
+// remove, micro-batch (n <= kSmallBatch): one small workgroup, the released load goes straight to `used` (a handful of atomics;
+// the big kernel's per-node LDS histogram — 1 024 threads, two passes over m words — was 12 us of a one-entry call)
+__global__ __launch_bounds__(kSmallBatch) void k_remove_small(u32* __restrict__ assign, u32 m, const u32* __restrict__ load,
+                                                              const u32* __restrict__ idx, u32 n, u64* __restrict__ used,
+                                                              u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl,
+                                                              uint4 ia) {
+    const u32 k = threadIdx.x;
+    if (k < n) {
+        const u32 i = ninl ? inl_sel(ia, k) : idx[k];
+        const u32 li = used ? load[i] : 0u;
+        const u32 old = atomicExch(&assign[i], kNone);  // duplicates inside the batch: only the first sees the node
+        if (used && old < m) atomicAdd(&used[old], (u64)0 - (u64)li);
+        if (aff_life) aff_life[i] = kAffInactive;  // row lifecycle: a removed key is no longer an object
+    }
+    signal_done(done, seq);
+}
+
 // remove (local.rs:60-68): exchange makes duplicate removals of one row decrement `used` once.  The load released per
 // node is gathered in an LDS histogram and flushed once per workgroup: a per-row global atomic on `used` serialises a
 // million removals on at most m addresses (measured 55 us per million rows).
@@ -3422,6 +3439,12 @@ void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hi
     if (!n) return;
     hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n, aff_life, done, seq,
                        inl ? n : 0u, inl_a(inl), inl_b(inl));
+}
+void launch_remove_small(u32* assign, u32 m, const u32* load, const u32* idx, u32 n, u64* used, hipStream_t s, u32* aff_life,
+                         u32* done, u32 seq, const SmallInline* inl) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_remove_small, dim3(1), dim3(kSmallBatch), 0, s, assign, m, load, idx, n, used, aff_life, done, seq,
+                       (inl && n <= 4) ? n : 0u, inl_a(inl));
 }
 void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u64* used, DevStats* st,
                    hipStream_t s, u32* aff_life, u32* done, u32 seq, const SmallInline* inl, unsigned int* ticket) {

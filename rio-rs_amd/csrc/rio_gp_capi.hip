@@ -1076,8 +1076,8 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
         const bool in_args = small_inline(&inl, n, idx, nullptr);
         if (!in_args) memcpy(h->h_small, idx, n * sizeof(u32));
         const u32 seq = small_begin(h);
-        launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_small, n, h->used_valid ? h->used : nullptr, h->dstats,
-                      h->stream, aff_life(h), small_done_dev(h), seq, in_args ? &inl : nullptr);
+        launch_remove_small(h->assign[h->cur], h->m, h->load, h->d_small, (u32)n, h->used_valid ? h->used : nullptr, h->stream,
+                            aff_life(h), small_done_dev(h), seq, in_args ? &inl : nullptr);
         h->have_solved = false;
         return small_wait(h, seq);
     }
