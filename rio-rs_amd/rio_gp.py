@@ -270,9 +270,9 @@ class GpuPlacement:
 
     def clean_servers(self, dead_nodes):
         m = self.num_nodes
-        bm = np.zeros((m + 63) // 64 + 1, np.uint64)
-        for j in dead_nodes:
-            bm[int(j) >> 6] |= np.uint64(1) << np.uint64(int(j) & 63)
+        bits = np.zeros(((m + 63) // 64 + 1) * 64, np.uint8)
+        bits[np.asarray(list(dead_nodes), np.int64)] = 1
+        bm = np.packbits(bits, bitorder="little").view(np.uint64)
         ev = C.c_uint64(0)
         self._chk(lib().rio_gp_clean_servers(self._h, _ptr(bm), C.byref(ev)))
         return int(ev.value)
