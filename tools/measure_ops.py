@@ -57,6 +57,11 @@ rec("lookup_batch_dev (random idx)", n, t, 12, "includes the per-call stats read
 seq = torch.arange(n, dtype=torch.int32, device="cuda")
 t = timed(g, lambda: L.rio_gp_lookup_batch_dev(h, n, vp(seq.data_ptr()), vp(outb.data_ptr())), 5)
 rec("lookup_batch_dev (sequential idx)", n, t, 12)
+# object popularity is not uniform in an actor system: Zipf(1.1) over a million hot objects scattered over the table
+zr = (synth.zipf_loads(n, s=1.1, kmax=1 << 20, stream=11).astype(np.uint64) - np.uint64(1)) * np.uint64(2654435761) % np.uint64(n)
+zidx = torch.from_numpy(zr.astype(np.int64)).to(torch.int32).cuda()
+t = timed(g, lambda: L.rio_gp_lookup_batch_dev(h, n, vp(zidx.data_ptr()), vp(outb.data_ptr())), 5)
+rec("lookup_batch_dev (Zipf(1.1) popularity)", n, t, 12, "indices drawn Zipf(1.1) over 2^20 hot objects scattered over the 10 M rows")
 t = timed(g, lambda: L.rio_gp_update_batch_dev(h, n, vp(idx.data_ptr()), vp(node.data_ptr())), 5)
 rec("update_batch_dev (random idx, dups)", n, t, 8, "2 kernels: elect, apply (the winner resets its scratch slot)")
 t = timed(g, lambda: L.rio_gp_remove_batch_dev(h, n // 10, vp(idx.data_ptr())), 5)
