@@ -38,7 +38,7 @@ for k in range(ticks):
     load[e] = rng.integers(0, 5000, 200).astype(np.uint32)
     aff[e] = rng.integers(0, m, 200).astype(np.uint32)
     g.set_object_attrs(e, load[e], aff[e])
-    rm = rng.integers(0, n, 100).astype(np.uint32)
+    rm = rng.integers(0, n, int(rng.choice([1, 3, 100, 400, 5000]))).astype(np.uint32)   # micro / medium batches
     g.remove_batch(rm)
     ref[rm] = 0xFFFFFFFF
     want, used, ost = pyoracle.tick(ref, load, aff, cap, alive)
@@ -52,7 +52,7 @@ for k in range(ticks):
     slow += st["slow_path"]
     moved += st["claimed"] + st["spilled"]
     # a micro-batch of requests between ticks (k_pp_small or the general path), against the oracle's place_pending
-    q = int(rng.choice([1, 8, 200, 300]))
+    q = int(rng.choice([1, 3, 8, 200, 300, 1500, 5000]))   # one workgroup | mapped pinned memory | staging copies
     idx = rng.integers(0, n, q).astype(np.uint32)
     live = np.flatnonzero(alive)
     req = live[rng.integers(0, len(live), q)].astype(np.uint32)
@@ -61,6 +61,10 @@ for k in range(ticks):
     if not (np.array_equal(node, wnode) and np.array_equal(flag, wflag) and np.array_equal(g.get_assign(), ref)):
         print(json.dumps({"tick": k, "place_pending_mismatch": True}))
         sys.exit(4)
+    lq = rng.integers(0, n, int(rng.choice([1, 4, 5, 256, 257, 3000, 20000]))).astype(np.uint32)
+    if not np.array_equal(g.lookup_batch(lq), ref[lq]):
+        print(json.dumps({"tick": k, "lookup_mismatch": True}))
+        sys.exit(5)
 print(json.dumps({"ticks": ticks, "rows": n, "nodes": m, "seed": seed, "slow_ticks": slow, "objects_moved": int(moved),
                   "all_ticks_equal_oracle": True, "wall_s": round(time.time() - t0, 1)}))
 g.close()
