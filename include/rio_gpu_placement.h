@@ -28,6 +28,11 @@
  *     rc 0, never an error (local.rs:48).  Nothing throws or aborts across the ABI.
  *   - A handle is internally synchronized (one mutex + one HIP stream per handle); calls
  *     are synchronous on return unless the name ends in `_async`.
+ *     "Synchronous" means the results are in the caller's buffers and every effect is
+ *     ordered before the handle's next call; the library waits on completion words its
+ *     kernels store into mapped pinned memory (the calling thread spins for the length of
+ *     the call — call from a blocking pool, not from an async executor thread) and asks
+ *     the HIP stream only when a word does not arrive (a device fault surfaces there).
  *   - There is NO CPU fallback: rio_gp_create fails with RIO_GP_ENODEV without a gfx950
  *     device.
  */
