@@ -54,9 +54,15 @@ const char* rio_op_last_error(rio_op_t* p);
  * Option::None and deletes the entry (local.rs:36-37). */
 int rio_op_update(rio_op_t* p, const char* struct_name, const char* object_id, const char* server_address);
 /* ObjectPlacement::lookup (mod.rs:50, local.rs:42-49): *found = 1 and the address copied into
- * out (NUL-terminated, truncated to out_cap) or *found = 0 (Ok(None)). */
+ * out (NUL-terminated) or *found = 0 (Ok(None)).  The reference returns an owned String of any
+ * length, so an address is NEVER truncated: when it does not fit out_cap the call returns
+ * RIO_GP_ERANGE with *found = 1 and out = "", and rio_op_last_address_len says how long the
+ * address is — the caller asks again with a buffer of that length + 1 (lookup is a pure read). */
 int rio_op_lookup(rio_op_t* p, const char* struct_name, const char* object_id, char* out, size_t out_cap,
                   int* found);
+/* Length in bytes (without the NUL) of the address the CALLING THREAD's last rio_op_lookup /
+ * rio_op_get_or_create_placement produced (0: Ok(None) / UNPLACED). */
+size_t rio_op_last_address_len(rio_op_t* p);
 /* ObjectPlacement::clean_server (mod.rs:52, local.rs:51-58). */
 int rio_op_clean_server(rio_op_t* p, const char* address);
 /* ObjectPlacement::remove (mod.rs:55, local.rs:60-68). */
@@ -77,13 +83,16 @@ const char* rio_op_node_address(rio_op_t* p, uint32_t node_id);
  * only ever seen through `update` is not a member, i.e. not active, as in the reference.
  * capacity: load units, RIO_GP_CAP_INF = unbounded (the reference has no capacity). */
 int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t capacity);
-/* per-object load (default 1; new behaviour, the reference has none) */
+/* per-object load (default 1; new behaviour, the reference has none).  A key first seen here keeps its row (and the
+ * load) until its first update / request makes it an object; from then on it is reclaimed like any other key. */
 int rio_op_set_object_load(rio_op_t* p, const char* struct_name, const char* object_id, uint32_t load);
 
 /* Service::get_or_create_placement (service.rs:193-254) + check_address_mismatch (service.rs:261-298)
  * for one request arriving at server `self_address`: returns the address the object lives on now and
  * *flag = RIO_GP_FLAG_{LOCAL,REDIRECT,PLACED,SPILLED,UNPLACED} (UNPLACED: out is ""), with RIO_GP_FLAG_REPLACED OR-ed on
- * when the object was found on a server that is not alive (that server was cleaned, the object re-placed). */
+ * when the object was found on a server that is not alive (that server was cleaned, the object re-placed).
+ * RIO_GP_ERANGE (address longer than out_cap - 1): the decision IS made and *flag is set, out = ""; fetch the
+ * address with rio_op_lookup into a buffer of rio_op_last_address_len() + 1 bytes. */
 int rio_op_get_or_create_placement(rio_op_t* p, const char* struct_name, const char* object_id,
                                    const char* self_address, char* out, size_t out_cap, uint32_t* flag);
 /* The same for n requests at once, processed as if sequentially in array order. */

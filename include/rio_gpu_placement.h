@@ -74,6 +74,7 @@ extern "C" {
 #define RIO_GP_EUPSTREAM 2 /* -> ObjectPlacementError::Upstream (errors.rs:137-138) */
 #define RIO_GP_ENODEV 3    /* no HIP device / not gfx950: the product path fails loudly */
 #define RIO_GP_ENOMEM 4
+#define RIO_GP_ERANGE 5    /* string layer: the caller's output buffer is too small (nothing is truncated) */
 
 /* per-request outcome of rio_gp_place_pending (service.rs:193-298 folded into one code) */
 #define RIO_GP_FLAG_LOCAL 0u      /* already placed on the requester (sticky hit, service.rs:241-242,262-264) */

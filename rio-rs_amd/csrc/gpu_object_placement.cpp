@@ -40,6 +40,9 @@ constexpr int kNoop = -1001;  // internal: nothing to do on the device (an unkno
 // Text of the calling thread's last failed call (rio_op_last_error): a failure is reported to the thread that made
 // the call, so its text is that thread's too — no lock, no race with other callers' failures.
 thread_local std::string t_err;
+// length of the address the calling thread's last rio_op_lookup / rio_op_get_or_create_placement produced
+// (rio_op_last_address_len): what a caller whose buffer was too small (RIO_GP_ERANGE) allocates before it asks again
+thread_local size_t t_addr_len = 0;
 // rio_op_snapshot's arrays: copies, owned by the calling thread until its next snapshot
 thread_local std::vector<std::string> t_snap_store;
 thread_local std::vector<const char*> t_snap_ty, t_snap_id, t_snap_addr;
@@ -61,7 +64,7 @@ struct State {
     std::mutex qmu;                    // combiner: queue of single-object calls + who is serving it
     std::condition_variable qcv;
     std::vector<Req*> queue;
-    bool serving = false;
+    std::atomic<bool> serving{false};   // written under qmu; waiters also read it while they spin
     int sleepers = 0;                  // waiters that gave up spinning and sleep on qcv
     rio_gp_t* gp = nullptr;
     uint64_t max_objects = 0;
@@ -70,6 +73,8 @@ struct State {
     std::unordered_map<std::string, uint32_t> rows;   // "{type}.{id}" -> dense row (local.rs:26-29)
     std::deque<std::pair<std::string, std::string>> row_key;  // row -> the (struct_name, object_id) it is interned as
     std::vector<uint8_t> row_live;                    // row currently has a key
+    std::vector<uint8_t> row_keep;                    // key created by rio_op_set_object_load and not used since: its load is
+                                                      // what the caller set, so reclaim() must not recycle (and reset) the row
     std::vector<uint32_t> free_rows;                  // reclaimed rows, ready for new keys
     uint64_t hi_rows = 0;                             // rows ever handed out: every row id is < hi_rows
     std::unordered_map<std::string, uint32_t> nodes;  // address -> node id
@@ -180,11 +185,14 @@ int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, b
 }
 
 // find or create the row of a key (imu held).  kFull: no free row — the caller releases its locks, runs reclaim() and retries.
-int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* out) {
+// use: the call makes (or unmakes) an object of the key — update, get_or_create_placement, remove; a key whose row is
+// held for a load set ahead of its first use (row_keep) is an ordinary key from then on
+int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* out, bool use = false) {
     const std::string key = key_of(ty, id);
     auto it = s->rows.find(key);
     if (it != s->rows.end()) {
         *out = it->second;
+        if (use) s->row_keep[it->second] = 0;
         return RIO_GP_OK;
     }
     if (!create) {
@@ -199,12 +207,14 @@ int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* 
         row = (uint32_t)s->hi_rows++;
         s->row_key.emplace_back();
         s->row_live.push_back(0);
+        s->row_keep.push_back(0);
     } else {
         return kFull;
     }
     s->rows.emplace(key, row);
     s->row_key[row] = std::make_pair(std::string(ty ? ty : ""), std::string(id ? id : ""));
     s->row_live[row] = 1;
+    s->row_keep[row] = use ? 0 : 1;  // created without a use: rio_op_set_object_load ahead of the first update / request
     *out = row;
     return RIO_GP_OK;
 }
@@ -235,7 +245,7 @@ int reclaim(State* s) {
         }
         if (rc == RIO_GP_OK) {
             for (uint64_t r = 0; r < n; ++r)
-                if (s->row_live[r] && assign[r] == RIO_GP_NONE && aff[r] == RIO_GP_AFF_INACTIVE) {
+                if (s->row_live[r] && !s->row_keep[r] && assign[r] == RIO_GP_NONE && aff[r] == RIO_GP_AFF_INACTIVE) {
                     s->rows.erase(key_of(s->row_key[r].first.c_str(), s->row_key[r].second.c_str()));
                     s->row_key[r] = std::pair<std::string, std::string>();
                     s->row_live[r] = 0;
@@ -256,11 +266,17 @@ int reclaim(State* s) {
     return RIO_GP_OK;
 }
 
-void copy_out(const std::string& v, char* out, size_t cap) {
-    if (!out || !cap) return;
-    const size_t n = v.size() < cap - 1 ? v.size() : cap - 1;
-    memcpy(out, v.data(), n);
-    out[n] = 0;
+// The address into the caller's buffer, whole or not at all: the reference returns an owned String of any length
+// (local.rs:42-49), so nothing is ever truncated.  RIO_GP_ERANGE: the buffer is too small — out holds "" and
+// rio_op_last_address_len() says how many bytes (without the NUL) the address has.
+int copy_out(const std::string& v, char* out, size_t cap) {
+    t_addr_len = v.size();
+    if (out && cap) out[0] = 0;
+    if (!out || cap < v.size() + 1)
+        return fail(RIO_GP_ERANGE, "address of " + std::to_string(v.size()) + " bytes does not fit the output buffer");
+    memcpy(out, v.data(), v.size());
+    out[v.size()] = 0;
+    return RIO_GP_OK;
 }
 
 // the whole policy for a batch of (row, requester) pairs; rows/reqs are dense ids (mu held, device tables in sync)
@@ -294,8 +310,9 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
 // called from one tokio task per connection (server.rs:292-304), and one device round trip per call (16-22 us behind a
 // mutex) would cap a provider at ~5e4 calls/s however many tasks call it.  Callers queue their request; whoever finds
 // nobody serving becomes the server: it takes up to kCombine queued requests, runs ONE batched device call per kind (the
-// micro-batch kernels: one launch + one wait for <= 256 requests), publishes the results and repeats until the queue
-// is empty.  A lone caller pays exactly what it paid before; N concurrent callers share a round trip.  Requests of one
+// micro-batch kernels: one launch + one wait for <= 256 requests), publishes the results, serves at most one more batch
+// after the one that held its own request and then hands the role to a queued waiter (bounded tenure: run_combined).
+// A lone caller pays exactly what it paid before; N concurrent callers share a round trip.  Requests of one
 // batch keep their arrival order (the first request for an object decides, as in rio_gp_place_pending).
 constexpr size_t kCombine = 256;
 
@@ -359,28 +376,43 @@ void serve(State* s, std::vector<Req*>& batch) {
 int run_combined(State* s, Req* mine) {
     std::unique_lock<std::mutex> lk(s->qmu);
     s->queue.push_back(mine);
-    if (s->serving) {
+    // Wait for the result, or for the server's role: a server hands the role over after its own batch plus one more
+    // (below), so a waiter also looks at `serving` and takes over when nobody serves a queue that still holds its request.
+    while (s->serving.load(std::memory_order_relaxed)) {
         // a device round trip is 15-25 us: spin on the own flag first (a futex sleep + wake costs more than the wait and,
         // with hundreds of waiters, serialises them), sleep only when it takes much longer
         lk.unlock();
-        for (int spin = 0; spin < 400; ++spin) {  // ~10 us of pure spinning
+        bool look = false;
+        for (int spin = 0; spin < 400 && !look; ++spin) {  // ~10 us of pure spinning
             if (mine->done.load(std::memory_order_acquire)) return mine->rc;
+            look = !s->serving.load(std::memory_order_acquire);
             __builtin_ia32_pause();
         }
-        for (int y = 0; y < 200; ++y) {           // then give the core away between looks (more threads than cores)
+        for (int y = 0; y < 200 && !look; ++y) {           // then give the core away between looks (more threads than cores)
             if (mine->done.load(std::memory_order_acquire)) return mine->rc;
+            look = !s->serving.load(std::memory_order_acquire);
             sched_yield();
         }
         lk.lock();
-        ++s->sleepers;
-        s->qcv.wait(lk, [&] { return mine->done.load(std::memory_order_acquire) != 0; });
-        --s->sleepers;
-        return mine->rc;
+        if (mine->done.load(std::memory_order_acquire)) return mine->rc;
+        if (!look && s->serving.load(std::memory_order_relaxed)) {
+            ++s->sleepers;
+            s->qcv.wait(lk, [&] { return mine->done.load(std::memory_order_acquire) != 0 || !s->serving.load(std::memory_order_relaxed); });
+            --s->sleepers;
+            if (mine->done.load(std::memory_order_acquire)) return mine->rc;
+        }
     }
-    s->serving = true;
+    // Nobody serves and this request is still queued: this thread is the server.  Its tenure is bounded — the batches up
+    // to the one that holds its own request, plus at most ONE more (the requests that arrived meanwhile) — and then the
+    // role is handed to a queued waiter: with closed-loop callers the queue never drains (each caller's next request
+    // arrives while the others' are served), and a server that loops "until empty" never returns to its own caller
+    // (round-2 advisor finding; in the Rust binding that pins a tokio blocking-pool thread).
+    s->serving.store(true, std::memory_order_relaxed);
     std::vector<Req*> batch;
     size_t last_batch = 1;
-    while (!s->queue.empty()) {
+    bool own_done = false;
+    int extra = 0;
+    while (!s->queue.empty() && !(own_done && extra >= 1)) {
         if (last_batch > 1 && s->queue.size() < last_batch) {
             // other callers are active and on their way back with their next request: a few microseconds of collecting
             // turn "one, then everyone else" into "everyone" per device round trip
@@ -394,13 +426,17 @@ int run_combined(State* s, Req* mine) {
         s->queue.erase(s->queue.begin(), s->queue.begin() + take);
         lk.unlock();
         serve(s, batch);
-        for (Req* r : batch)
+        if (own_done) ++extra;
+        for (Req* r : batch) {
             if (r != mine) r->done.store(1, std::memory_order_release);  // last touch of *r
+            else own_done = true;
+        }
         last_batch = batch.size();
         lk.lock();
         if (s->sleepers) s->qcv.notify_all();
     }
-    s->serving = false;
+    s->serving.store(false, std::memory_order_release);
+    if (!s->queue.empty() && s->sleepers) s->qcv.notify_all();  // spinning waiters see `serving`; sleeping ones are woken
     return mine->rc;
 }
 
@@ -534,10 +570,10 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
             uint32_t row = RIO_GP_NONE, node = RIO_GP_NONE;
             int rc;
             if (addrs[k]) {  // Some(address): entry(key) = address
-                if ((rc = intern_row(s, tys[k], ids[k], true, &row))) return rc;
+                if ((rc = intern_row(s, tys[k], ids[k], true, &row, true))) return rc;
                 if ((rc = intern_node(s, addrs[k], true, &node))) return rc;
             } else {         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
-                if ((rc = intern_row(s, tys[k], ids[k], false, &row))) return rc;
+                if ((rc = intern_row(s, tys[k], ids[k], false, &row, true))) return rc;
                 if (row == RIO_GP_NONE) continue;
             }
             rows.push_back(row);
@@ -560,11 +596,11 @@ int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr)
     const int rc = single_call(s, &r, [&]() -> int {
         int rc;
         if (addr) {  // Some(address): entry(key) = address
-            if ((rc = intern_row(s, ty, id, true, &r.row))) return rc;
+            if ((rc = intern_row(s, ty, id, true, &r.row, true))) return rc;
             return intern_node(s, addr, true, &r.req);
         }
         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
-        if ((rc = intern_row(s, ty, id, false, &r.row))) return rc;
+        if ((rc = intern_row(s, ty, id, false, &r.row, true))) return rc;
         return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;
     });
     return rc == kNoop ? RIO_GP_OK : rc;
@@ -611,12 +647,15 @@ int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t
     if (rc == kNoop) return RIO_GP_OK;
     if (rc) return rc;
     *found = r.node != RIO_GP_NONE;
+    t_addr_len = 0;
     if (*found) {
         std::lock_guard<std::mutex> gi(s->imu);
-        copy_out(s->node_addr[r.node], out, cap);
+        return copy_out(s->node_addr[r.node], out, cap);  // RIO_GP_ERANGE: *found is set, nothing was copied
     }
     return RIO_GP_OK;
 }
+
+size_t rio_op_last_address_len(rio_op_t*) { return t_addr_len; }
 
 int rio_op_clean_server(rio_op_t* p, const char* address) {
     if (!p || !address) return RIO_GP_EINVAL;
@@ -639,7 +678,7 @@ int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
     r.kind = 3;
     r.req = RIO_GP_NONE;
     const int rc = single_call(s, &r, [&]() -> int {
-        const int rc = intern_row(s, ty, id, false, &r.row);
+        const int rc = intern_row(s, ty, id, false, &r.row, true);
         if (rc) return rc;
         return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;  // absent: no-op (local.rs:60-68)
     });
@@ -695,7 +734,7 @@ int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* co
         std::vector<uint32_t> rows(n), reqs(n);
         for (uint64_t k = 0; k < n; ++k) {
             int rc;
-            if ((rc = intern_row(s, tys[k], ids[k], true, &rows[k]))) return rc;
+            if ((rc = intern_row(s, tys[k], ids[k], true, &rows[k], true))) return rc;
             if ((rc = intern_node(s, selfs[k], true, &reqs[k], true))) return rc;  // a server answering requests is up
         }
         int rc;
@@ -712,14 +751,14 @@ int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, 
     r.kind = 1;
     const int rc = single_call(s, &r, [&]() -> int {
         int rc;
-        if ((rc = intern_row(s, ty, id, true, &r.row))) return rc;
+        if ((rc = intern_row(s, ty, id, true, &r.row, true))) return rc;
         return intern_node(s, self_address, true, &r.req, true);  // a server answering requests is up
     });
     if (rc) return rc;
     if (flag) *flag = r.flag;
     std::lock_guard<std::mutex> gi(s->imu);
-    copy_out(r.node == RIO_GP_NONE ? std::string() : s->node_addr[r.node], out, cap);
-    return RIO_GP_OK;
+    // RIO_GP_ERANGE: the decision is made and *flag is set; the address is one rio_op_lookup away (a pure read)
+    return copy_out(r.node == RIO_GP_NONE ? std::string() : s->node_addr[r.node], out, cap);
 }
 
 int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_names, const char* const** object_ids,

@@ -177,12 +177,14 @@ void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out
                    // several workgroups may share the completion word — the last one to finish stores it
 // aff_life (every CRUD launcher below): the affinity column when the handle tracks the row lifecycle (rows that are
 // written become objects, rows that are removed / deleted / dropped by clean_server stop being objects), else nullptr
+// used / load != nullptr (medium batches): the per-node load vector follows the writes (a few global atomics)
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos_scratch,
                    DevStats* st, hipStream_t s, u32* aff_life = nullptr, unsigned int* ticket = nullptr, u32* done = nullptr,
-                   u32 seq = 0);
+                   u32 seq = 0, u64* used = nullptr, const u32* load = nullptr);
 // n <= kSmallBatch validated entries (may be mapped host memory): last writer wins inside the batch, one launch
 void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life = nullptr,
-                         u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
+                         u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr, u64* used = nullptr,
+                         const u32* load = nullptr, u32 m = 0);
 // n <= kSmallBatch validated entries (may be mapped host memory / kernel arguments): one small workgroup
 void launch_remove_small(u32* assign, u32 m, const u32* load, const u32* idx, u32 n, u64* used_or_null, hipStream_t s,
                          u32* aff_life, u32* done, u32 seq, const SmallInline* inl);

@@ -2198,12 +2198,22 @@ __global__ void k_update_elect(u64 n_obj, u32 m, const u32* __restrict__ idx, co
 // that sees NONE != its own position and does nothing) — no third pass
 // aff_life (row lifecycle, nullptr otherwise): the written row becomes an object whose affinity is its node, a deleted
 // one (node NONE, local.rs:36-37) stops being one
+// used / load (medium batches only, nullptr otherwise): the per-node load vector follows the write — the row's load leaves
+// its old node and arrives on the new one (a handful of global atomics; big batches invalidate `used` instead)
 __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ idx,
                                const u32* __restrict__ node, u64 n, u32* __restrict__ pos, u32* __restrict__ aff_life,
-                               unsigned int* ticket, u32* done, u32 seq) {
+                               unsigned int* ticket, u32* done, u32 seq, u64* __restrict__ used,
+                               const u32* __restrict__ load) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k], nd = node[k];
         if (i < n_obj && (nd == kNone || nd < m) && pos[i] == (u32)(n - 1 - k)) {
+            if (used) {  // (one winner per row: nobody else touches assign[i] in this launch)
+                const u32 old = assign[i], li = load[i];
+                if (old != nd && li) {
+                    if (old < m) atomicAdd(&used[old], (u64)0 - (u64)li);
+                    if (nd < m) atomicAdd(&used[nd], (u64)li);
+                }
+            }
             assign[i] = nd;
             pos[i] = kNone;
             if (aff_life) aff_life[i] = nd == kNone ? kAffInactive : nd;
@@ -2216,7 +2226,8 @@ __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const
 __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
                                                               const u32* __restrict__ node, u32 n,
                                                               u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl,
-                                                              uint4 ia, uint4 ib) {
+                                                              uint4 ia, uint4 ib, u64* __restrict__ used,
+                                                              const u32* __restrict__ load, u32 m) {
     // Last writer per row through a small open-addressing table in LDS (2 x kSmallBatch slots, linear probing): the row id
     // claims a slot with a compare-and-swap, the batch positions meet in an atomic max.  (Comparing every entry with every
     // later one, the first version, is 256 dependent LDS reads for the first entry of a full batch: 7.5 us of kernel time.)
@@ -2225,10 +2236,11 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
     __shared__ u32 hpos[kSlots];
     const u32 k = threadIdx.x;
     for (u32 q = k; q < kSlots; q += kSmallBatch) { hkey[q] = kNone; hpos[q] = 0; }
-    u32 i = kNone, nd = kNone;
+    u32 i = kNone, nd = kNone, old = kNone, li = 0;
     if (k < n) {
         i = ninl ? inl_sel(ia, k) : idx[k];
         nd = ninl ? inl_sel(ib, k) : node[k];
+        if (used) { old = assign[i]; li = load[i]; }  // requested with the election, not after it: one round trip
     }
     __syncthreads();
     u32 slot = (i * 2654435761u) >> 23 & (kSlots - 1);  // (row ids are < 2^31: kNone never is one)
@@ -2244,6 +2256,12 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
     if (k < n && hpos[slot] == k + 1) {  // this entry is the row's last one in the batch
         assign[i] = nd;
         if (aff_life) aff_life[i] = nd == kNone ? kAffInactive : nd;
+        // `used` follows the write (round-2 advisor finding: invalidating it made the next place_pending re-stream the
+        // whole table): every entry of the row read the same old node; the winner moves the row's load
+        if (used && old != nd && li) {
+            if (old < m) atomicAdd(&used[old], (u64)0 - (u64)li);
+            if (nd < m) atomicAdd(&used[nd], (u64)li);
+        }
     }
     signal_done(done, seq);  // the host may reuse the staging rows once the word is there
 }
@@ -2766,7 +2784,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
                                                           u32* done, u32 seq, u32 ninl, uint4 ia, uint4 ib) {
     __shared__ u32 s_req[kSmallBatch], s_load[kSmallBatch], s_res[kSmallBatch];
     __shared__ u64 s_tot[kPpTot];  // claim load per requester so far, in batch order (m <= kPpTot)
-    __shared__ unsigned char s_own[kPpTot];  // lane of a wave's (last) claimant per requester: duplicate detection
+    __shared__ u32 s_own[kPpTot];  // claimants of a requester inside the wave being processed: duplicate detection
     __shared__ u32 s_general;
     const u32 k = threadIdx.x;
     const bool valid = k < n;
@@ -2808,18 +2826,21 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
         // claimant of each requester in the wave advances; inside a wave a claimant whose requester nobody else of the wave
         // claims (the usual case) has nothing to add up, otherwise the wave walks its 64 lanes with readlane.  The plain
         // form below walks the LDS copy of the batch once per request: ~15 us for 256 requests, most of the call.
-        if (claim) s_tot[r] = 0;  // (every claimant of r stores the same zero)
+        if (claim) { s_tot[r] = 0; s_own[r] = 0; }  // (every claimant of r stores the same zeros)
         __syncthreads();
         const int lane = (int)(k & 63u), wave = (int)(k >> 6);
         const u32 rkey = claim ? r : kNone;
         const int nwaves = (int)((n + 63u) >> 6);
         for (int w = 0; w < nwaves; ++w) {
             if (wave == w && __ballot(claim)) {
-                // do two claimants of this wave share a requester?  each writes its lane into the requester's owner word
-                // and reads it back: a lane that reads another lane's number has company (LDS operations of one wave
-                // execute in order, so every lane sees the last writer)
-                if (claim) s_own[r] = (unsigned char)lane;
-                const bool shared = claim && s_own[r] != (unsigned char)lane;
+                // do two claimants of this wave share a requester?  each takes a ticket from the requester's counter with a
+                // RETURNING LDS atomic: the second claimant of a requester gets a non-zero ticket, and one such lane is
+                // enough (the walk below is a wave-uniform decision).  A plain store + load of the same word does not work:
+                // the compiler forwards the store to the load (round-2 advisor finding: `shared` was compiled away and
+                // same-requester claimants of one wave were admitted past the requester's capacity).
+                u32 ticket = 0;
+                if (claim) ticket = atomicAdd(&s_own[r], 1u);
+                const bool shared = claim && ticket != 0;
                 u64 inw = claim ? (u64)l : 0ull;
                 bool later = false;
                 if (__ballot(shared)) {  // rare: the prefix over the lower lanes with the same requester, 64 readlane steps
@@ -2836,6 +2857,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assi
                 if (claim) {
                     pre = s_tot[r] + inw;
                     if (!later) s_tot[r] = pre;  // the requester's last claimant in this wave: total so far
+                    __hip_atomic_store(&s_own[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // for the later waves
                 }
             }
             __syncthreads();
@@ -3418,12 +3440,12 @@ void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out
     else hipLaunchKernelGGL(k_lookup, dim3(g), dim3(256), 0, s, assign, n_obj, idx, n, out, st, done, seq);
 }
 void launch_update(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* pos, DevStats* st,
-                   hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq) {
+                   hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq, u64* used, const u32* load) {
     if (!n) return;
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_update_elect, dim3(g), dim3(256), 0, s, n_obj, m, idx, node, n, pos, st);
     hipLaunchKernelGGL(k_update_apply, dim3(g), dim3(256), 0, s, assign, n_obj, m, idx, node, n, pos, aff_life, ticket,
-                       ticket ? done : nullptr, seq);
+                       ticket ? done : nullptr, seq, used, load);
 }
 // inl (every micro-batch launcher): the n <= 4 requests themselves (a = indices, b = nodes / requesters), or nullptr
 static inline uint4 inl_a(const SmallInline* inl) { return inl ? make_uint4(inl->a[0], inl->a[1], inl->a[2], inl->a[3]) : make_uint4(0, 0, 0, 0); }
@@ -3435,10 +3457,10 @@ void launch_lookup_small(const u32* assign, u64 n_obj, const u32* idx, u32 n, u3
                        inl ? n : 0u, inl_a(inl));
 }
 void launch_update_small(u32* assign, const u32* idx, const u32* node, u32 n, hipStream_t s, u32* aff_life, u32* done,
-                         u32 seq, const SmallInline* inl) {
+                         u32 seq, const SmallInline* inl, u64* used, const u32* load, u32 m) {
     if (!n) return;
     hipLaunchKernelGGL(k_update_small, dim3(1), dim3(kSmallBatch), 0, s, assign, idx, node, n, aff_life, done, seq,
-                       inl ? n : 0u, inl_a(inl), inl_b(inl));
+                       inl ? n : 0u, inl_a(inl), inl_b(inl), used, load, m);
 }
 void launch_remove_small(u32* assign, u32 m, const u32* load, const u32* idx, u32 n, u64* used, hipStream_t s, u32* aff_life,
                          u32* done, u32 seq, const SmallInline* inl) {

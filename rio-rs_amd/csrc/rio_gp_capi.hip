@@ -122,6 +122,8 @@ struct rio_gp {
     Plan plan{};
     bool have_solved = false;
     u32 ring_n = 0;
+    u32 ring_slow = 0;     // fix-up verdicts among the rio_gp_solve_async solves whose ring slots were recycled
+    bool ring_any = false; // a rio_gp_solve_async solve has been enqueued since the last rio_gp_solve_wait
     // asynchronous committed ticks (rio_gp_tick_async): verdict slots [kRing, 2 kRing) and their own ring of device-stats
     // copies, so that synchronous calls made while ticks are in flight do not touch what has not been harvested yet
     u32 tick_n = 0;
@@ -373,7 +375,7 @@ int commit_enqueue(rio_gp* h) {
 // fix-up was enqueued speculatively (below).
 int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     h->plan = make_plan(h->n, h->m, 0);
-    h->ring_n = 0;
+    h->ring_n = 0; h->ring_slow = 0; h->ring_any = false;
     use_fx_slot(h, 0);
     const u64 seq = ++h->wait_seq;
     h->plan.mark = seq;  // k_resolve's partial rows carry it ...
@@ -425,7 +427,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
         }
     }
     h->have_solved = true;
-    h->ring_n = 0;
+    h->ring_n = 0; h->ring_slow = 0; h->ring_any = false;
     if (commit) {
         int rc = commit_enqueue(h);
         if (rc) return rc;
@@ -910,7 +912,10 @@ int rio_gp_set_num_objects(rio_gp_t* h, uint64_t n) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     if (n > h->cap_obj) return fail(h, RIO_GP_EINVAL, "rio_gp_set_num_objects: n exceeds max_objects");
-    h->n = n;  // rows keep their contents: rows >= n simply take no part (and are rejected as indices) until n grows again
+    // rows keep their contents: rows >= n simply take no part (and are rejected as indices) until n grows again — but a
+    // placed row that drops out (or comes back) changes what `used` must count, so the vector is rebuilt before its next use
+    if (n != h->n) h->used_valid = false;
+    h->n = n;
     h->have_solved = false;
     h->last_pending_valid = false;
     return RIO_GP_OK;
@@ -1015,9 +1020,10 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
             memcpy(h->h_small + kSmallBatch, node, n * sizeof(u32));
         }
         const u32 seq = small_begin(h);
+        // `used` follows the writes when it is valid (k_remove_small does the same): a server that mixes single updates with
+        // policy calls does not re-stream the whole table before every place_pending
         launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream, aff_life(h),
-                            small_done_dev(h), seq, in_args ? &inl : nullptr);
-        h->used_valid = false;
+                            small_done_dev(h), seq, in_args ? &inl : nullptr, h->used_valid ? h->used : nullptr, h->load, h->m);
         h->have_solved = false;
         return small_wait(h, seq);
     }
@@ -1028,8 +1034,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         memcpy(h->h_mid + kMidBatch, node, n * sizeof(u32));
         const u32 seq = small_begin(h);
         launch_update(h->assign[h->cur], h->n, h->m, h->d_mid, h->d_mid + kMidBatch, n, h->pos, h->dstats, h->stream, aff_life(h),
-                      h->mid_ticket, small_done_dev(h), seq);
-        h->used_valid = false;
+                      h->mid_ticket, small_done_dev(h), seq, h->used_valid ? h->used : nullptr, h->load);
         h->have_solved = false;
         return small_wait(h, seq);
     }
@@ -1335,13 +1340,26 @@ int rio_gp_tick_wait(rio_gp_t* h, rio_gp_stats* out, uint32_t cap, uint32_t* n_o
 int rio_gp_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));  // a host with several handles (one per GPU) calls from any thread
+    // the verdict ring holds kRing solves: fold the oldest slot's verdict into the running count before it is overwritten
+    // (rio_gp_solve_wait reports how many of ALL the solves since the last wait took the fix-up path)
+    if (h->ring_n >= (u32)kRing) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (u32 k = 0; k < h->ring_n; ++k) {
+            const DevStats v = reduce_slot(h, k, h->m);
+            h->ring_slow += (v.n_cut > 0 || v.spillcand > 0);
+        }
+        h->ring_n = 0;
+    }
     h->plan = make_plan(h->n, h->m, 0);
     use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
     launch_resolve(h->plan, nt, h->sb, slot_dev(h, h->ring_n), h->stream);
+    HIPCHK(h, hipGetLastError());
     h->ring_n++;
+    h->ring_any = true;
     h->have_solved = false;
     return RIO_GP_OK;
 }
@@ -1352,15 +1370,17 @@ int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
-    if (h->ring_n == 0) return fail(h, RIO_GP_EINVAL, "rio_gp_solve_wait: nothing enqueued");
-    uint32_t slow = 0;
-    const u32 lo = h->ring_n > (u32)kRing ? h->ring_n - kRing : 0;
+    if (!h->ring_any) return fail(h, RIO_GP_EINVAL, "rio_gp_solve_wait: nothing enqueued");
+    uint32_t slow = h->ring_slow;  // solves whose slots were recycled (rio_gp_solve_async folds them in)
     DevStats last;
     memset(&last, 0, sizeof last);
-    for (u32 k = lo; k < h->ring_n; ++k) {
+    if (h->ring_n == 0) last = reduce_slot(h, kRing - 1, h->m);  // exactly a multiple of kRing: the last solve sits in the last slot
+    for (u32 k = 0; k < h->ring_n; ++k) {
         last = reduce_slot(h, k, h->m);
         slow += (last.n_cut > 0 || last.spillcand > 0);
     }
+    h->ring_slow = 0;
+    h->ring_any = false;
     if (last.n_cut > 0 || last.spillcand > 0) {
         enqueue_slow(h, h->plan, real_table(h), real_nodes(h), false, last);
         int rc = merge_slow(h, &last);
@@ -1391,7 +1411,7 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     HIPCHK(h, hipEventElapsedTime(scan_ms, h->ev0, h->ev1));
     HIPCHK(h, hipEventElapsedTime(resolve_ms, h->ev2, h->ev3));
     h->have_solved = false;
-    h->ring_n = 0;
+    h->ring_n = 0; h->ring_slow = 0; h->ring_any = false;
     const DevStats v = reduce_slot(h, 0, h->m);
     if (v.n_cut > 0 || v.spillcand > 0)
         return fail(h, RIO_GP_EINVAL, "rio_gp_solve_profiled: this table needs the cut/spill fix-up");

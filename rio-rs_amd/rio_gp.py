@@ -19,7 +19,7 @@ CFG_ROW_LIFECYCLE = 1           # RIO_GP_CFG_ROW_LIFECYCLE
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleaned and re-placed by this request
 FLAG_MASK = 0x0F
-OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM = range(5)
+OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM, ERANGE = range(6)
 
 SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "stream_probe.hip",
                                                      "gpu_object_placement.cpp")]
@@ -392,6 +392,8 @@ def _oplib():
         L.rio_op_last_error.restype = C.c_char_p
         L.rio_op_update.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_char_p]
         L.rio_op_lookup.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.rio_op_last_address_len.argtypes = [_vp]
+        L.rio_op_last_address_len.restype = C.c_size_t
         L.rio_op_clean_server.argtypes = [_vp, C.c_char_p]
         L.rio_op_remove.argtypes = [_vp, C.c_char_p, C.c_char_p]
         L.rio_op_len.argtypes = [_vp, C.POINTER(C.c_uint64)]
@@ -459,10 +461,18 @@ class GpuObjectPlacement:
         a = None if server_address is None else server_address.encode()
         self._chk(_oplib().rio_op_update(self._h, struct_name.encode(), object_id.encode(), a))
 
-    def lookup(self, struct_name, object_id):
-        buf, found = C.create_string_buffer(512), C.c_int(0)
-        self._chk(_oplib().rio_op_lookup(self._h, struct_name.encode(), object_id.encode(), buf, 512, C.byref(found)))
-        return buf.value.decode() if found.value else None
+    def lookup(self, struct_name, object_id, _cap=512):
+        """Option<String> of any length (local.rs:42-49): a buffer that is too small is RIO_GP_ERANGE plus the length to
+        allocate — the address is never truncated."""
+        L, cap = _oplib(), _cap
+        while True:
+            buf, found = C.create_string_buffer(cap), C.c_int(0)
+            rc = L.rio_op_lookup(self._h, struct_name.encode(), object_id.encode(), buf, cap, C.byref(found))
+            if rc == ERANGE:
+                cap = int(L.rio_op_last_address_len(self._h)) + 1
+                continue
+            self._chk(rc)
+            return buf.value.decode() if found.value else None
 
     def clean_server(self, address):
         self._chk(_oplib().rio_op_clean_server(self._h, address.encode()))
@@ -496,10 +506,13 @@ class GpuObjectPlacement:
     def set_object_load(self, struct_name, object_id, load):
         self._chk(_oplib().rio_op_set_object_load(self._h, struct_name.encode(), object_id.encode(), load))
 
-    def get_or_create_placement(self, struct_name, object_id, self_address):
-        buf, flag = C.create_string_buffer(512), C.c_uint32(0)
-        self._chk(_oplib().rio_op_get_or_create_placement(self._h, struct_name.encode(), object_id.encode(),
-                                                          self_address.encode(), buf, 512, C.byref(flag)))
+    def get_or_create_placement(self, struct_name, object_id, self_address, _cap=512):
+        buf, flag = C.create_string_buffer(_cap), C.c_uint32(0)
+        rc = _oplib().rio_op_get_or_create_placement(self._h, struct_name.encode(), object_id.encode(),
+                                                     self_address.encode(), buf, _cap, C.byref(flag))
+        if rc == ERANGE:  # the decision is made, the flag is set: the (long) address is one lookup away
+            return self.lookup(struct_name, object_id), int(flag.value)
+        self._chk(rc)
         return (buf.value.decode() or None), int(flag.value)
 
     def get_or_create_placement_batch(self, keys, self_addresses):

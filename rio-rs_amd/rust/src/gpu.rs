@@ -42,6 +42,8 @@ struct RioOpCfg {
 
 const RIO_GP_OK: c_int = 0;
 const RIO_GP_EINVAL: c_int = 1;
+/// the output buffer was too small: nothing is truncated, `rio_op_last_address_len` says what is needed
+const RIO_GP_ERANGE: c_int = 5;
 /// `rio_gp_stats` (include/rio_gpu_placement.h): counters of one whole-table solve.
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -71,6 +73,7 @@ extern "C" {
     fn rio_op_update(p: *mut c_void, ty: *const c_char, id: *const c_char, addr: *const c_char) -> c_int;
     fn rio_op_lookup(p: *mut c_void, ty: *const c_char, id: *const c_char, out: *mut c_char, cap: usize,
                      found: *mut c_int) -> c_int;
+    fn rio_op_last_address_len(p: *mut c_void) -> usize;
     fn rio_op_clean_server(p: *mut c_void, addr: *const c_char) -> c_int;
     fn rio_op_remove(p: *mut c_void, ty: *const c_char, id: *const c_char) -> c_int;
     fn rio_op_set_member(p: *mut c_void, addr: *const c_char, active: c_int, capacity: u64) -> c_int;
@@ -143,8 +146,13 @@ impl GpuObjectPlacement {
         let (ty, id, me) = (cstr(&object_id.0)?, cstr(&object_id.1)?, cstr(self_address)?);
         let mut buf = vec![0 as c_char; 512];
         let mut flag = 0u32;
-        check(unsafe { rio_op_get_or_create_placement(self.inner.0, ty.as_ptr(), id.as_ptr(), me.as_ptr(),
-                                                      buf.as_mut_ptr(), buf.len(), &mut flag) }, self)?;
+        let rc = unsafe { rio_op_get_or_create_placement(self.inner.0, ty.as_ptr(), id.as_ptr(), me.as_ptr(),
+                                                         buf.as_mut_ptr(), buf.len(), &mut flag) };
+        if rc == RIO_GP_ERANGE {
+            // the decision is made and `flag` is set; an address longer than the buffer is one lookup (a pure read) away
+            return Ok((lookup_owned(self, &ty, &id)?, flag));
+        }
+        check(rc, self)?;
         let s = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
         Ok((if flag & FLAG_MASK == FLAG_UNPLACED { None } else { Some(s) }, flag))
     }
@@ -168,6 +176,24 @@ impl GpuObjectPlacement {
         check(unsafe { rio_op_snapshot(self.inner.0, &mut n, &mut ty, &mut id, &mut ad) }, self)?;
         let s = |p: *const *const c_char, k: usize| unsafe { CStr::from_ptr(*p.add(k)).to_string_lossy().into_owned() };
         Ok((0..n as usize).map(|k| (s(ty, k), s(id, k), s(ad, k))).collect())
+    }
+}
+
+/// `lookup` into an owned `String` of ANY length (local.rs:42-49 returns `Option<String>`): the native call never
+/// truncates — a buffer that is too small comes back as RIO_GP_ERANGE together with the length to allocate.
+/// Runs on the calling thread (`rio_op_last_address_len` is that thread's).
+fn lookup_owned(me: &GpuObjectPlacement, ty: &CString, id: &CString) -> Result<Option<String>, ObjectPlacementError> {
+    let mut buf = vec![0 as c_char; 512];
+    loop {
+        let mut found: c_int = 0;
+        let rc = unsafe { rio_op_lookup(me.inner.0, ty.as_ptr(), id.as_ptr(), buf.as_mut_ptr(), buf.len(), &mut found) };
+        if rc == RIO_GP_ERANGE {
+            // (another writer may have moved the object to an even longer address meanwhile: loop)
+            buf = vec![0 as c_char; unsafe { rio_op_last_address_len(me.inner.0) } + 1];
+            continue;
+        }
+        check(rc, me)?;
+        return Ok(if found != 0 { Some(unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()) } else { None });
     }
 }
 
@@ -225,17 +251,7 @@ impl ObjectPlacement for GpuObjectPlacement {
     async fn lookup(&self, object_id: &ObjectId) -> Result<Option<String>, ObjectPlacementError> {
         let (ty, id) = (cstr(&object_id.0)?, cstr(&object_id.1)?);
         let me = self.clone();
-        blocking(move || {
-            let mut buf = vec![0 as c_char; 512];
-            let mut found: c_int = 0;
-            check(unsafe { rio_op_lookup(me.inner.0, ty.as_ptr(), id.as_ptr(), buf.as_mut_ptr(), buf.len(), &mut found) }, &me)?;
-            Ok(if found != 0 {
-                Some(unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned())
-            } else {
-                None
-            })
-        })
-        .await
+        blocking(move || lookup_owned(&me, &ty, &id)).await
     }
 
     // mod.rs:52 / local.rs:51-58

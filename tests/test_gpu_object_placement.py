@@ -389,3 +389,57 @@ def test_keys_are_reclaimed_when_the_table_runs_full(gp):
     p.update("Live", "one-too-many", "h:1")                     # and a freed row is found again
     assert p.lookup("Live", "one-too-many") == "h:1" and len(p) == 256
     p.close()
+
+
+def test_addresses_of_any_length_are_never_truncated(gp):
+    """local.rs:42-49 returns Option<String> of any length (round-2 verdict: the C layer truncated to out_cap).  A 600-byte
+    address comes back whole through the adapter's retry, and the raw call reports RIO_GP_ERANGE plus the needed length."""
+    import ctypes as C
+    p = gp.GpuObjectPlacement(max_objects=64, max_nodes=8)
+    long_addr = "host-" + "x" * 590 + ":5000"
+    assert len(long_addr) == 600
+    p.update("Long", "1", long_addr)
+    assert p.lookup("Long", "1") == long_addr                                   # 512-byte first try, then the exact size
+    L = gp._oplib()
+    buf, found = C.create_string_buffer(64), C.c_int(0)
+    rc = L.rio_op_lookup(p._h, b"Long", b"1", buf, 64, C.byref(found))
+    assert rc == gp.ERANGE and found.value == 1 and buf.value == b""
+    assert L.rio_op_last_address_len(p._h) == 600
+    buf = C.create_string_buffer(601)
+    assert L.rio_op_lookup(p._h, b"Long", b"1", buf, 601, C.byref(found)) == gp.OK and buf.value.decode() == long_addr
+    # exactly fitting / one short
+    assert L.rio_op_lookup(p._h, b"Long", b"1", C.create_string_buffer(600), 600, C.byref(found)) == gp.ERANGE
+    # the policy call: the decision is made and flagged even when the address does not fit the caller's buffer
+    p.set_member(long_addr, True)
+    addr, flag = p.get_or_create_placement("Long", "2", long_addr, _cap=32)
+    assert addr == long_addr and flag == gp.FLAG_PLACED
+    addr, flag = p.get_or_create_placement("Long", "2", long_addr)
+    assert addr == long_addr and flag == gp.FLAG_LOCAL
+    assert p.lookup("Long", "nobody") is None and L.rio_op_last_address_len(p._h) == 0
+    p.close()
+
+
+def test_a_load_set_ahead_of_first_use_survives_key_reclaim(gp):
+    """Round-2 advisor finding: reclaim() recycled (and reset to load 1) the row of a key whose load had been set before its
+    first update / request.  Such a key keeps its row until it is used; afterwards it is reclaimed like any other key."""
+    p = gp.GpuObjectPlacement(max_objects=64, max_nodes=4)
+    p.set_member("a:1", True, capacity=10)
+    p.set_member("b:1", True, capacity=1000)
+    p.set_object_load("Heavy", "h", 7)                      # not an object yet
+    for k in range(300):                                    # key churn through the other 63 rows: several reclaims
+        key = "c%d" % k
+        assert p.get_or_create_placement("Churn", key, "b:1")[0] == "b:1"
+        p.remove("Churn", key)
+    assert p.get_or_create_placement("Heavy", "h", "a:1") == ("a:1", gp.FLAG_PLACED)
+    st = p.tick()                                           # the row still carries load 7
+    assert st["load_kept"] == 7
+    # 'a:1' holds 7 of 10: a second object of load 7 does not fit and is water-filled onto b:1
+    p.set_object_load("Heavy", "h2", 7)
+    assert p.get_or_create_placement("Heavy", "h2", "a:1") == ("b:1", gp.FLAG_SPILLED)
+    p.remove("Heavy", "h")                                  # used now: reclaimable like any other key
+    for k in range(300):
+        key = "d%d" % k
+        assert p.get_or_create_placement("Churn", key, "b:1")[0] == "b:1"
+        p.remove("Churn", key)
+    assert p.lookup("Heavy", "h") is None and p.lookup("Heavy", "h2") == "b:1"
+    p.close()

@@ -742,6 +742,46 @@ def test_place_pending_micro_batches(gp, oracle, seed, cap_mode):
     g.close()
 
 
+def test_place_pending_micro_batch_same_requester_capacity(gp, oracle):
+    """Round-2 advisor finding: first-touch requests of ONE wave of the micro-batch kernel that share a requester must be
+    admitted by the index-ordered prefix of their loads — a capacity that fits each row alone but not their sum.  This is
+    the normal shape of the rio_op combiner (every caller passes the same self_address)."""
+    g = gp.GpuPlacement(64, 3)
+    cap = np.array([2, 100, 100], np.uint64)
+    g.set_nodes(cap, np.ones(3, np.uint8))
+    load = np.ones(64, np.uint32)
+    g.set_objects(64, load, None)
+    ref, used = np.full(64, NONE, np.uint32), np.zeros(3, np.uint64)
+    idx, req = np.array([0, 1, 2], np.uint32), np.zeros(3, np.uint32)
+    node, flag = g.place_pending(idx, req)
+    wnode, wflag = oracle.place_pending(ref, load, cap, np.ones(3, np.uint8), used, idx, req)
+    assert np.array_equal(node, wnode) and np.array_equal(flag, wflag), (node, wnode, flag, wflag)
+    assert list(g.get_nodes()[2]) == list(used) and used[0] == 2
+    g.close()
+    rng = np.random.default_rng(91)
+    for trial in range(30):
+        m = int(rng.integers(1, 6))
+        n = 2000
+        load = rng.integers(0, 5, n).astype(np.uint32)
+        k = int(rng.choice([3, 17, 64, 65, 130, 256]))
+        alive = np.ones(m, np.uint8)
+        g = gp.GpuPlacement(n, m)
+        ref, used = np.full(n, NONE, np.uint32), np.zeros(m, np.uint64)
+        # capacities around the total a batch asks of its requesters: some batches fit (micro path), some overflow by a row
+        cap = rng.integers(max(1, k // m - 4), 2 * k // m + 6, m).astype(np.uint64)
+        g.set_nodes(cap, alive)
+        g.set_objects(n, load, None)
+        for step in range(3):
+            idx = rng.permutation(n)[:k].astype(np.uint32)   # distinct first-touch rows
+            req = rng.integers(0, m, k).astype(np.uint32)
+            node, flag = g.place_pending(idx, req)
+            wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+            assert np.array_equal(node, wnode) and np.array_equal(flag, wflag), (trial, step, k, m)
+            assert np.array_equal(g.get_nodes()[2], used), (trial, step)
+        assert np.array_equal(g.get_assign(), ref)
+        g.close()
+
+
 def test_place_pending_dev_equals_host_call(gp, oracle):
     """rio_gp_place_pending_dev: request / result arrays resident in HBM (torch tensors), same answers as the oracle;
     a bad entry fails the call before anything changes."""
