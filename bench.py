@@ -535,8 +535,11 @@ def main():
             res_ms.append(r_ms)
     probe = None
     if n_slow == 0:
-        try:  # what this chip's memory system gives a plain grid-stride kernel with the same 3-in/1-out mix
-            ms = g.stream_probe(0, 20)
+        try:  # what this chip's memory system gives a plain grid-stride kernel with the same 3-in/1-out mix (lab build)
+            gl = rio_gp.LabPlacement(n, m, device=local_rank)
+            gl.set_objects(n, cfg["load"], cfg["aff"])
+            ms = gl.stream_probe(0, 20)
+            gl.close()
             probe = {"pattern": "grid-stride 2048x256, read cur/load/aff + write one column, no other work",
                      "ms": ms, "GBps": ALGO_BYTES_PER_DECISION * n / ms / 1e6}
         except Exception as e:  # measurement aid only
@@ -555,7 +558,10 @@ def main():
             for _ in range(5):
                 gb.solve_profiled()
             cs = [gb.solve_profiled()[0] for _ in range(30)]
-            pm = gb.stream_probe(0, 10)
+            gl = rio_gp.LabPlacement(k * n, m, device=local_rank)
+            gl.set_objects(k * n, loadk, affk)
+            pm = gl.stream_probe(0, 10)
+            gl.close()
             for _ in range(3):
                 gb.solve_async()
             gb.solve_wait()

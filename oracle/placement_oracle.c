@@ -75,8 +75,19 @@ void orc_recompute_used(const uint32_t* assign, const uint32_t* load, uint64_t n
 
 /* ---- water-fill (spill) ------------------------------------------------------------------ */
 
+/* Order of the nodes in the water-fill: by CAPACITY CLASS descending, node index ascending inside a class.  The class of a
+ * free capacity f > 0 is f rounded down to three significant bits, as an ordinal: 4 * floor(log2 f) + the two bits below
+ * the leading one (256 classes, monotone in f).  Emptiest nodes first, to within a quarter octave — and a rank that a
+ * workgroup obtains by COUNTING (histogram over classes + position among the equals) instead of a comparison sort of m
+ * 64-bit keys, which costs ~1 400 vector instructions per key on one CU (measured: 10 us at m = 1 024).  DESIGN.md section 2. */
+static uint32_t wf_class(uint64_t f) {
+    uint32_t e = 63u - (uint32_t)__builtin_clzll(f); /* f > 0 */
+    uint32_t mant = e >= 2 ? (uint32_t)(f >> (e - 2)) & 3u : (uint32_t)(f << (2 - e)) & 3u;
+    return e * 4u + mant;
+}
+
 typedef struct wf {
-    uint32_t* order; /* nodes with free > 0, sorted by (free desc, index asc) */
+    uint32_t* order; /* nodes with free > 0, sorted by (capacity class desc, index asc) */
     uint64_t* C;     /* C[0] = 0, C[k+1] = sat(C[k] + free[order[k]]) */
     uint32_t cnt;
     uint64_t F;
@@ -85,7 +96,8 @@ typedef struct wf {
 static const uint64_t* g_sort_free;
 static int wf_cmp(const void* a, const void* b) {
     uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
-    if (g_sort_free[x] != g_sort_free[y]) return g_sort_free[x] > g_sort_free[y] ? -1 : 1;
+    const uint32_t cx = wf_class(g_sort_free[x]), cy = wf_class(g_sort_free[y]);
+    if (cx != cy) return cx > cy ? -1 : 1;
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 
@@ -220,7 +232,7 @@ int orc_tick(const uint32_t* cur, const uint32_t* load, const uint32_t* aff, uin
         if (!kept[i] && next[i] != ORC_NONE) run[next[i]] += load[i];
     for (uint32_t j = 0; j < m; ++j) used[j] += run[j];
 
-    /* pass 3 — spill: water-fill the rest, index order, onto nodes by (free desc, index asc). */
+    /* pass 3 — spill: water-fill the rest, index order, onto nodes by (capacity class desc, index asc). */
     uint64_t n_spill0 = n_rem;
     n_rem = spill_rounds(rem, n_rem, NULL, load, next, cap, alive, used, m, rounds, &s.rounds_run);
     for (uint64_t t = 0; t < n_rem; ++t) {

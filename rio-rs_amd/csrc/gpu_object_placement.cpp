@@ -639,6 +639,7 @@ int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t
     r.kind = 0;
     r.req = RIO_GP_NONE;
     *found = 0;
+    t_addr_len = 0;
     const int rc = single_call(s, &r, [&]() -> int {
         const int rc = intern_row(s, ty, id, false, &r.row);
         if (rc) return rc;
@@ -749,6 +750,7 @@ int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, 
     State* s = p->s;
     Req r;
     r.kind = 1;
+    t_addr_len = 0;
     const int rc = single_call(s, &r, [&]() -> int {
         int rc;
         if ((rc = intern_row(s, ty, id, true, &r.row, true))) return rc;

@@ -40,7 +40,7 @@ struct Plan {
     u32 subs;    // sub-chunks per block (<= kMaxSubs)
     u32 m;       // nodes
     u32 mwords;  // ceil(m/32)
-    u32 trace;   // phase tracing of the fix-up kernels (measurement aid; set by the launchers, 0 = off)
+    u32 trace;   // lab build: phase traces of the fix-up kernels (0 in the product)
     u64 mark;    // what k_resolve stores in column 7 of its partial rows ("row present"): 1, or the sequence number the
                  // host spins on instead of waiting for the stream
     // packed fix-up (see PackOut): when set, wave gw's rows are only the first wcnt[gw] positions of its range
@@ -91,18 +91,25 @@ struct SolveBufs {
     u64* budget;     // [m] free capacity left at the start of the cut block
     u64* admpre;     // [m] claim load admitted before the cut block
     u32* cutidx;     // [m] row index of the first rejected claimant or kNoCut
-    u64* T;          // [m][kMaxSubs] claim load per sub-chunk of the node's cut block
-    u64* wfC;        // [m+1] free capacity by water-fill rank (k_spill_apply rebuilds the saturating cumulative)
-    u32* wfOrder;    // [m]
-    u32* wfCnt;      // [2] ranked nodes | round has work
     // row-sharded solve only (nullptr otherwise): nodes whose claim prefix overflowed on a lower rank, and the
     // spill load pending on lower ranks
     u32* forced_bits;        // [mwords]
     u64* rank_base;          // [1]
     const u64* pending_global;  // [1] rows still pending on ALL ranks (k_shard_import_delta), nullptr = local count
+    // The claim load the cuts reject, for the ordered spill prefix of k_fill's round 0 (no pass over rows):
+    u64* RP;         // [node groups][G] by node group, in the blocks BEFORE block b: k_scan zeroes, a k_resolve workgroup that owns
+                     //   cut nodes stores its row (plain stores, whole lines); nullptr: not maintained
+    u64* R;          // [G] correction of the cut blocks themselves (what a cut block admits of its nodes), as a negative
+                     //   number: k_scan zeroes, k_cut_find adds (k_resolve<SEARCH> folds it into RP instead)
+    u64* D;          // [kFillRounds][m] load admitted per water-fill round, kept apart from used_cur so that no round reads
+                     //   and writes the same vector: k_resolve zeroes it, round r of k_fill orders the nodes by
+                     //   used_cur + D[0..r) and adds into D[r]; the committed `used` is used_cur + sum D (launch_used_fold).
+                     //   nullptr (row-sharded solve): the rounds read used_snap and add straight into used_cur
+    const u64* used_snap;  // row-sharded solve: the global `used` vector as the last exchange left it (nobody writes it during a round)
     DevStats* stats;
     FxRows fx;
 };
+constexpr u32 kFillRounds = 8;  // rows of SolveBufs::D = the largest number of water-fill rounds per solve
 
 // Packed pending rows (k_scan<COMPACT>): wave gw copies its PENDING rows, in index order, to the front of its own
 // row range in these scratch columns and records how many (wcnt[gw]).  The fix-up kernels then run unchanged over
@@ -140,30 +147,36 @@ struct NodeTab {
 // --- solve pipeline ---
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
                  hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const PackOut* pack = nullptr);
-// next[idx[pos]] = pk_next[pos] over every wave's packed rows (p.wcnt set)
-void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t s);
 // host_partial: pinned host rows [resolve_blocks(m)][8] = load_kept, load_claim_tot, n_cut, kept, evicted,
-// claimants, spillcand, present — the caller adds the rows up (no atomics / copy kernel on the stream)
+// claimants, spillcand, present — the caller adds the rows up (no atomics / copy kernel on the stream).
+// search (with p.wcnt set): the packed pending rows — k_resolve also finds the exact cut rows (no k_cut_find launch).
+// fold_into: the committed `used` vector still waiting for the D rows of the previous committed solve (folded in before
+// b.D is zeroed), fold_rounds = that solve's rounds.
 void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
-                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const PackOut* search = nullptr,
+                    u64* fold_into = nullptr, u32 fold_rounds = 0);
 unsigned resolve_blocks(u32 m);
 void set_scan_nt(int mode);  // 0 by table size | 1 always | 2 never: non-temporal column streams in k_scan
-int cut_trace_enable(int on);  // k_cut_fused phase trace (measurement aid)
-int cut_trace_read(u64* out /*[kMaxBlocks*8]*/);
-int ktrace_read(int table, u64* out /*[kMaxBlocks*8]*/);  // 0/1 k_spill_apply first/last round, 2 k_cut_apply_rank, 3 k_cut_find
+// The exact cut search as a launch of its own (k_cut_find; guards itself on the device).  have_cutblk: launch_resolve of
+// the same solve (same bufs) has already written cutblk / budget / admpre — else k_cutblk runs first (row-sharded path).
+void launch_cut_find(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
+                     bool have_cutblk);
+// One launch of k_fill: apply = re-mark the rejected claimants (+ pack: copy the rows that go on to the water-fill into the
+// pack columns, per-wave counts in pack->wcnt; real table only), fill = one water-fill round.  apply && fill is round 0
+// of a solve, fill alone a later round, apply alone the row-sharded solve's cut step.  The workgroups order the nodes
+// themselves (by capacity class, in LDS): there is no ranking launch.
+void launch_fill(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool apply, bool fill,
+                 int round, bool last, hipStream_t s, const PackOut* pack = nullptr);
+bool fill_can_pack(u32 m);
+// used[j] += D[0][j] + ... + D[rounds-1][j]
+void launch_used_fold(u64* used, const u64* D, u32 m, u32 rounds, hipStream_t s);
+#ifdef RIO_GP_LAB
+int ktrace_enable(int on);
+int ktrace_read(int table, u64* out /*[kMaxBlocks*8]*/);  // 0 k_resolve<search> | 1 k_fill round 0 | 2 k_fill later rounds
 float sync_probe(int mode, int reps, hipStream_t s);  // host round-trip probes (stream_probe.hip)
 float stream_probe(int mode, const u32* a, const u32* b, const u32* c, u32* o, u64 n, int reps, hipStream_t s,
                    hipEvent_t e0, hipEvent_t e1);
-// impl: 2 = k_cut_find + k_cut_apply_rank | 1 = k_cut_fused | 0 = the unfused chain.  have_cutblk: launch_resolve of the
-// same solve (same bufs) has already written cutblk / budget / admpre.  with_rank (impl 2): the ranking of water-fill
-// round 0 rides in the second launch — only when nothing changes used_cur between the cut and that round (not on the
-// row-sharded path, where the Y exchange does).  Returns true when that ranking was enqueued.
-bool launch_cut_fixup(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
-                      int impl = 2, bool have_cutblk = false, bool with_rank = false, const PackOut* pack = nullptr);
-// pack (impl 2, real table only): k_cut_apply_rank also copies every row that goes on to the water-fill into the pack
-// columns (PackOut, per-wave counts in pack->wcnt); the caller then runs the water-fill rounds over the packed rows.
-void launch_spill_round(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
-                        hipStream_t s, bool rank_done = false);
+#endif
 
 // --- CRUD over the assignment column ---
 // the requests of a call of at most 4 entries, passed in the kernel arguments (a = object indices, b = nodes / requesters)

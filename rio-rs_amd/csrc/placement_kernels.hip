@@ -125,13 +125,31 @@ __device__ __forceinline__ u64 block_row_lo(const Plan& p, u32 b) { return wave_
 constexpr int kSmall = 128;  // bytes of small per-block scratch at the head of the dynamic LDS region
 __device__ __forceinline__ bool bit_of(const u32* bits, u32 j) { return (bits[j >> 5] >> (j & 31)) & 1u; }
 
+// Phase traces (lab build only; compiled out of the product): workgroup b stores wall_clock64() (100 MHz) at phase
+// boundary `slot` of kernel table `tab` into g_kt[tab][b][slot] when the plan's trace flag is set.
+#ifdef RIO_GP_LAB
+constexpr int kKtTables = 5;
+__device__ u64 g_kt[kKtTables][kMaxBlocks * 8];
+static int g_trace_host = 0;
+#define RIOGP_KT(pl, tab, slot) do { if (threadIdx.x == 0 && (pl).trace && blockIdx.x < kMaxBlocks) g_kt[tab][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+int ktrace_enable(int on) { g_trace_host = on; return 0; }
+int ktrace_read(int table, u64* out) {
+    if (table < 0 || table >= kKtTables) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kt), sizeof(u64) * kMaxBlocks * 8, sizeof(u64) * kMaxBlocks * 8 * (size_t)table);
+}
+static inline u32 trace_flag() { return (u32)g_trace_host; }
+#else
+#define RIOGP_KT(pl, tab, slot) do { } while (0)
+static inline u32 trace_flag() { return 0; }
+#endif
+
 Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     Plan p;
     p.n = n;
     p.m = m;
     p.mwords = (m + 31) / 32;
     p.wcnt = nullptr;
-    p.trace = 0;
+    p.trace = trace_flag();
     p.mark = 1;
     if (max_blocks == 0 || max_blocks > kMaxBlocks) max_blocks = kMaxBlocks;
     u64 tiles = (n + kTile - 1) / kTile;
@@ -335,7 +353,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
                                                  const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
                                                  u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
                                                  u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko,
-                                                 FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt) {
+                                                 FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt,
+                                                 u64* __restrict__ R, u64* __restrict__ RP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u32* bst = reinterpret_cast<u32*>(smem);                 // [4] (first 128 B: small scratch, G17)
@@ -343,6 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     u32* alv = reinterpret_cast<u32*>(hist + 2 * m + 2);     // [mwords]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
+    RIOGP_KT(p, 3, 0);
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
@@ -370,6 +390,13 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     u64& bsum = *reinterpret_cast<u64*>(smem + 32);          // spill-candidate load of the whole block
     if (tid == 0) bsum = 0;
     if (fx.dev && tid < 8) fx.dev[(size_t)blockIdx.x * 8 + tid] = 0;  // this workgroup's row of the fix-up counters
+    // claim load the cuts reject, for k_fill's ordered spill prefix: row blockIdx.x of RP (by node group, written by k_resolve
+    // workgroups that own cut nodes) and the cut block's correction R[blockIdx.x] (k_cut_find) start at zero
+    if (R && tid == 0) R[blockIdx.x] = 0;
+    if (RP) {  // (this workgroup's share of the [node group][block] words: contiguous)
+        const u32 ngr = (m + 7) >> 3;
+        for (u32 k = tid; k < ngr; k += kBlock) RP[(size_t)blockIdx.x * ngr + k] = 0;
+    }
     if (blockIdx.x == 0 && tid == 0) {  // accumulators the fix-up kernels add into
         stats->rejected = 0; stats->load_rejected = 0;
         stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
@@ -454,31 +481,38 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         H[h_line(g, blockIdx.x, p.G) + c] = j < m ? hist[(c >> 3) * m + j] : 0ull;
     }
     if (tid < 4) blkstat[(size_t)blockIdx.x * 4 + tid] = bst[tid];
+    RIOGP_KT(p, 3, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2  k_resolve — per node: used = sum over blocks of the kept histogram, claim total, free, and
 //     the verdict "claims fit" (fast path) or "cut" (fix-up needed).  Workgroup g owns node group g
 //     (8 nodes) and reads exactly its G contiguous 128-byte lines of H ({kept x8 | claim x8} per
-//     block, written that way by k_scan): algorithmic = fetched bytes (the row-major [G][2m] table of
-//     the first version cost 4.1x: two 32-byte slices per 16 KiB row and workgroup).  Thread =
-//     (row group, column pair): one dwordx4 per line and thread, every load issued before the first wait.
-//     Per-workgroup partial counters go straight into the caller's pinned host slot (plain stores,
-//     no atomics, no fences, no copy kernel); the host adds the rows up.
+//     block, written that way by k_scan): algorithmic = fetched bytes.  Thread = (row group, column pair): one dwordx4
+//     per line and thread, every load issued before the first wait.  Per-workgroup partial counters go straight into the
+//     caller's pinned host slot (plain stores, no atomics, no fences, no copy kernel); the host adds the rows up.
+//     For a node whose claims exceed its free capacity the block in which the ordered claim prefix crosses it is found
+//     from the columns still in registers, and the claim load the cut rejects BEHIND that block goes into R[] (k_fill's
+//     ordered spill prefix needs it per block).
+//     SEARCH (packed fix-up: the pending rows of every wave sit at the front of its range, k_scan<COMPACT>): the exact cut
+//     row is found here as well — the cut block's pending rows are a few thousand, so a pair of waves per node reads them
+//     with every load in flight at once (one round trip) instead of a launch of its own (k_cut_find: 14 us per churn tick).
 // ------------------------------------------------------------------------------------------------
 constexpr int kResNodes = 8;
 constexpr int kResRowGroups = 32;                          // 256 threads = 32 row groups x 8 column pairs
 constexpr int kResRows = kMaxBlocks / kResRowGroups;       // 8 lines (16 B of each) per thread
+constexpr int kSrchSlots = 10;                             // tiles (256 rows) the in-resolve search holds in registers per batch
 
 // sums of this workgroup's 16 columns over the G blocks -> tot[16] (kept x8 | claim x8); v[r][0..1] keep the thread's
-// own addends (columns 2*cp, 2*cp+1 of rows rg + 32 r) for the cut-block search
+// own addends (columns 2*cp, 2*cp+1 of rows rg + 32 r) for the cut-block search.  Threads >= 256 only take the barriers.
 __device__ __forceinline__ void resolve_column_sums(const u64* __restrict__ H, u32 g, u32 G, u64 (&v)[kResRows][2],
                                                     u64 (*part)[16], u64* tot) {
-    const int tid = threadIdx.x, cp = tid & 7, rg = tid >> 3;
+    const int tid = threadIdx.x, cp = tid & 7, rg = (tid >> 3) & (kResRowGroups - 1);
+    const bool act = tid < 256;
 #pragma unroll
     for (int r = 0; r < kResRows; ++r) {
         const u32 row = rg + r * kResRowGroups;
-        if (row < G) {
+        if (act && row < G) {
             const uint4 x = *reinterpret_cast<const uint4*>(H + h_line(g, row, G) + 2 * cp);
             v[r][0] = ((u64)x.y << 32) | x.x;
             v[r][1] = ((u64)x.w << 32) | x.z;
@@ -490,8 +524,10 @@ __device__ __forceinline__ void resolve_column_sums(const u64* __restrict__ H, u
     u64 s0 = 0, s1 = 0;
 #pragma unroll
     for (int r = 0; r < kResRows; ++r) { s0 += v[r][0]; s1 += v[r][1]; }
-    part[rg][2 * cp] = s0;
-    part[rg][2 * cp + 1] = s1;
+    if (act) {
+        part[rg][2 * cp] = s0;
+        part[rg][2 * cp + 1] = s1;
+    }
     __syncthreads();
     if (tid < 16) {
         u64 t = 0;
@@ -502,21 +538,35 @@ __device__ __forceinline__ void resolve_column_sums(const u64* __restrict__ H, u
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, const u64* __restrict__ blkstat, Plan p,
-                                                 const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
-                                                 const u64* __restrict__ used_base, u64* __restrict__ used_kept,
-                                                 u64* __restrict__ used_cur, u64* __restrict__ claim_tot,
-                                                 u32* __restrict__ cutblk, u32* __restrict__ cutidx,
-                                                 u64* __restrict__ partial, u64* __restrict__ host_partial,
-                                                 u64* __restrict__ budget, u64* __restrict__ admpre,
-                                                 DevStats* __restrict__ stats) {
+struct ResolveArgs {
+    const u64* H; const u64* blkstat; Plan p;
+    const u64* cap; const u32* alive_bits; const u64* used_base;
+    u64* used_kept; u64* used_cur; u64* claim_tot; u32* cutblk; u32* cutidx;
+    u64* partial; u64* host_partial; u64* budget; u64* admpre; DevStats* stats;
+    u64* RP;           // [node groups][G] claim load the cuts of a node group reject in the blocks BEFORE block b (nullptr: not
+                       // wanted — row-sharded local sums): k_fill's round 0 sums column b.  Plain stores, one writer per row.
+    u64* D;            // [kFillRounds][m] per-round admitted loads of k_fill: zeroed here (nullptr: none)
+    u64* fold_into;    // committed `used` still waiting for the previous committed solve's D rows: folded in before they are zeroed
+    u32 fold_rounds;
+    // SEARCH: the packed pending rows (affinity, load) of every wave range
+    const u32* pk_aff; const u32* pk_load;
+};
+
+template <bool SEARCH>
+__global__ __launch_bounds__(SEARCH ? kBlock : 256) void k_resolve(const ResolveArgs a) {
     __shared__ u64 part[kResRowGroups][16];
     __shared__ u64 tot[16];
     __shared__ u64 red[8];
     __shared__ u64 cutfre[kResNodes];               // free capacity of a node of this workgroup that has a cut
     __shared__ u32 cutmask;                         // which of the eight nodes have one
     __shared__ u64 colbuf[kResNodes][kMaxBlocks];   // their claim columns, row order (only filled when cutmask != 0)
-    const int tid = threadIdx.x, lane = tid & 63, cp = tid & 7, rg = tid >> 3;
+    __shared__ u32 s_cb[kResNodes];                 // cut block
+    __shared__ u64 s_bud[kResNodes], s_adm[kResNodes], s_used[kResNodes];  // budget at its start | admitted before it | kept load
+    __shared__ u64 s_half[kResNodes];               // SEARCH: claim load of the node in the first half of its cut block
+    __shared__ u32 s_row[kResNodes];                // SEARCH: cut row found by the first half (kNoCut: not there)
+    __shared__ u64 s_in[kResNodes];                 // SEARCH: load admitted inside the cut block
+    const Plan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, cp = tid & 7, rg = (tid >> 3) & (kResRowGroups - 1);
     const u32 m = p.m, G = p.G, nb = gridDim.x, g = blockIdx.x;
     const u32 j = g * kResNodes + (u32)tid;          // node of thread tid < 8
     const bool valid = tid < kResNodes && j < m;
@@ -524,11 +574,20 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     u64 cj = 0, ub = 0;
     bool alive_j = false;
     if (valid) {
-        cj = cap[j];
-        alive_j = bit_of(alive_bits, j);
-        if (used_base) ub = used_base[j];
+        cj = a.cap[j];
+        alive_j = bit_of(a.alive_bits, j);
+        if (a.used_base) ub = a.used_base[j];
+        // the rounds' admitted-load vectors: what the previous committed solve left goes into the committed `used` first
+        if (a.D) {
+            if (a.fold_into) {
+                u64 f = a.fold_into[j];
+                for (u32 r = 0; r < a.fold_rounds; ++r) f += a.D[(size_t)r * m + j];
+                a.fold_into[j] = f;
+            }
+            for (u32 r = 0; r < kFillRounds; ++r) a.D[(size_t)r * m + j] = 0;
+        }
     }
-    if (tid < 8) red[tid] = 0;
+    if (tid < 8) { red[tid] = 0; s_row[tid] = kNoCut; s_half[tid] = 0; s_in[tid] = 0; }
     if (tid == 0) cutmask = 0;
     // this wave-1 lane's first word of the k_scan row counters (rows g, g + nb, ... of blkstat) is requested here, ahead of
     // the H loads, instead of after the two barriers below: one dependent round trip less in a 4 us kernel
@@ -536,19 +595,22 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     u32 bs_r = G;
     if (tid >= 64 && tid < 128) {
         bs_r = g + nb * (lane >> 2);
-        if (bs_r < G) bs_acc = blkstat[(size_t)bs_r * 4 + (lane & 3)];
+        if (bs_r < G) bs_acc = a.blkstat[(size_t)bs_r * 4 + (lane & 3)];
     }
+    if (SEARCH) RIOGP_KT(p, 0, 0);
     u64 v[kResRows][2];
-    resolve_column_sums(H, g, G, v, part, tot);      // two barriers inside: red / cutmask are published
+    resolve_column_sums(a.H, g, G, v, part, tot);      // two barriers inside: red / cutmask are published
+    if (SEARCH) RIOGP_KT(p, 0, 1);
     if (valid) {
         const u64 kept_load = tot[tid], ctot = tot[tid + kResNodes];
         const u64 used = kept_load + ub;
         const u64 fre = (alive_j && cj > used) ? cj - used : 0;
-        used_kept[j] = used;
-        claim_tot[j] = ctot;
-        cutblk[j] = kNoCut;
-        cutidx[j] = kNoCut;
-        used_cur[j] = used + ctot;  // final unless the node has a cut (the cut kernels rewrite it)
+        a.used_kept[j] = used;
+        a.claim_tot[j] = ctot;
+        a.cutblk[j] = kNoCut;
+        a.cutidx[j] = kNoCut;
+        a.used_cur[j] = used + ctot;  // final unless the node has a cut (the cut search rewrites it)
+        s_used[tid] = used;
         atomicAdd(&red[0], kept_load);
         atomicAdd(&red[1], ctot);
         if (ctot > fre) {
@@ -560,21 +622,21 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
     if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows g, g+nb, ... of blkstat
         u64 acc = bs_acc;
         if (bs_r < G)  // (more than one row per lane only for m < 128)
-            for (u32 r = bs_r + nb * 16; r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
+            for (u32 r = bs_r + nb * 16; r < G; r += nb * 16) acc += a.blkstat[(size_t)r * 4 + (lane & 3)];
         acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
         if (lane < 4) red[3 + lane] = acc;
     }
     __syncthreads();
     if (tid < 8) {
         const u64 x = (tid < 7) ? red[tid] : p.mark;  // column 7 = "row present" marker (1, or the host's sequence number)
-        partial[(size_t)g * 8 + tid] = x;
-        if (host_partial) host_partial[(size_t)g * 8 + tid] = x;
+        a.partial[(size_t)g * 8 + tid] = x;
+        if (a.host_partial) a.host_partial[(size_t)g * 8 + tid] = x;
     }
     // A node whose claims exceed its free capacity: in which block (line of H) does the ordered prefix cross it?  The
     // column is still in this workgroup's registers, so the answer costs no extra launch (k_cutblk's job on the row-sharded
     // path): claim columns to LDS in row order, one wave per pair of nodes, four rows per lane, ordered scan.
-    if (!budget || cutmask == 0) return;  // block-uniform
-    if (cp >= 4) {
+    if (!a.budget || cutmask == 0) return;  // block-uniform
+    if (tid < 256 && cp >= 4) {
 #pragma unroll
         for (int r = 0; r < kResRows; ++r) {
             colbuf[2 * cp - kResNodes][rg + r * kResRowGroups] = v[r][0];
@@ -582,32 +644,204 @@ __global__ __launch_bounds__(256) void k_resolve(const u64* __restrict__ H, cons
         }
     }
     __syncthreads();
-    for (int q = tid >> 6; q < kResNodes; q += 4) {  // wave -> nodes q, q + 4
-        if (!((cutmask >> q) & 1u)) continue;
-        const u64 fre = cutfre[q];
-        const u64 x0 = colbuf[q][lane * 4 + 0], x1 = colbuf[q][lane * 4 + 1], x2 = colbuf[q][lane * 4 + 2],
-                  x3 = colbuf[q][lane * 4 + 3];
-        const u64 s1 = x0 + x1, s2 = s1 + x2, s3 = s2 + x3;
-        const u64 inc = wave_incl_scan(s3, lane);
-        const u64 ex = inc - s3;
-        int e = 4;  // first row of this lane whose inclusive prefix exceeds the free capacity
-        if (ex + s3 > fre) e = 3;
-        if (ex + s2 > fre) e = 2;
-        if (ex + s1 > fre) e = 1;
-        if (ex + x0 > fre) e = 0;
-        const u64 mask = __ballot(e < 4);
-        if (mask) {
-            const int fl = __ffsll((long long)mask) - 1;
-            if (lane == fl) {
-                const u64 cum = ex + (e == 0 ? 0ull : e == 1 ? x0 : e == 2 ? s1 : s2);
-                const u32 jq = g * kResNodes + q;
-                cutblk[jq] = (u32)(lane * 4 + e);
-                budget[jq] = fre - cum;
-                admpre[jq] = cum;
+    if (tid < 256) {
+        for (int q = tid >> 6; q < kResNodes; q += 4) {  // wave -> nodes q, q + 4
+            if (!((cutmask >> q) & 1u)) continue;
+            const u64 fre = cutfre[q];
+            const u64 x0 = colbuf[q][lane * 4 + 0], x1 = colbuf[q][lane * 4 + 1], x2 = colbuf[q][lane * 4 + 2],
+                      x3 = colbuf[q][lane * 4 + 3];
+            const u64 s1 = x0 + x1, s2 = s1 + x2, s3 = s2 + x3;
+            const u64 inc = wave_incl_scan(s3, lane);
+            const u64 ex = inc - s3;
+            int e = 4;  // first row of this lane whose inclusive prefix exceeds the free capacity
+            if (ex + s3 > fre) e = 3;
+            if (ex + s2 > fre) e = 2;
+            if (ex + s1 > fre) e = 1;
+            if (ex + x0 > fre) e = 0;
+            const u64 mask = __ballot(e < 4);
+            if (mask) {
+                const int fl = __ffsll((long long)mask) - 1;
+                if (lane == fl) {
+                    const u64 cum = ex + (e == 0 ? 0ull : e == 1 ? x0 : e == 2 ? s1 : s2);
+                    const u32 jq = g * kResNodes + q;
+                    a.cutblk[jq] = (u32)(lane * 4 + e);
+                    a.budget[jq] = fre - cum;
+                    a.admpre[jq] = cum;
+                    s_cb[q] = (u32)(lane * 4 + e);
+                    s_bud[q] = fre - cum;
+                    s_adm[q] = cum;
+                }
+            } else if (lane == 0) {
+                s_cb[q] = kNoCut;  // (cannot happen: the column total exceeds the free capacity)
             }
         }
     }
-    if (tid == 0) atomicAdd(&stats->n_cut, 1ull);  // device-side "some node has a cut" flag (the cut kernels' guard)
+    if (tid == 0) atomicAdd(&a.stats->n_cut, 1ull);  // device-side "some node has a cut" flag (the cut kernels' guard)
+    __syncthreads();
+    // What this group's cuts reject, per block: behind a node's cut block its whole claim load, in the cut block what the exact
+    // search does not admit.  k_fill's round 0 needs the sum over the blocks BEFORE its own: the exclusive prefix over the
+    // blocks goes to RP[b][g] (plain stores; 32 k atomics on sixteen lines were 30 us of this kernel).  The in-block
+    // correction is known here only when this kernel searches (SEARCH); k_cut_find puts it into R[cut block] otherwise.
+    auto store_rejected = [&]() {
+        __shared__ u64 wtot[4];
+        u64 r = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int q = 0; q < kResNodes; ++q)
+                if (((cutmask >> q) & 1u) && s_cb[q] != kNoCut) {
+                    if ((u32)tid >= s_cb[q]) r += colbuf[q][tid];
+                    if (SEARCH && (u32)tid == s_cb[q]) r -= s_in[q];
+                }
+        }
+        const u64 inc = wave_incl_scan(r, lane);
+        if (tid < 256 && lane == 63) wtot[tid >> 6] = inc;
+        __syncthreads();
+        if (tid < (int)G) {
+            u64 ex = inc - r;
+            for (int w = 0; w < (tid >> 6); ++w) ex += wtot[w];
+            a.RP[(size_t)g * G + tid] = ex;  // row g: this workgroup's 2 KB, whole lines (a [block][group] layout made every
+                                             // word a partial-line store from another XCD: 32 k of them cost this kernel 20 us)
+        }
+    };
+    if (!SEARCH) {
+        if (a.RP) store_rejected();
+        return;
+    }
+    RIOGP_KT(p, 0, 2);
+    // ---- exact cut rows of this group's nodes: waves 2q, 2q+1 take node q; each reads eight wave ranges of the cut block.
+    //      The rows of the eight ranges are taken in "slots" of 64 (range-major, so slot order = index order); a batch of
+    //      kSrchSlots slots is requested at once — one round trip for ~2 500 rows, the usual half block of a churn tick —
+    //      and the second half's first batch is in flight while the first half searches.
+    {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = wave >> 1, half = wave & 1;
+        const bool mine = ((cutmask >> q) & 1u) && s_cb[q] != kNoCut;
+        const u32 jq = g * kResNodes + q;
+        const u32 cb = mine ? s_cb[q] : 0u;
+        const u64 gw0 = (u64)cb * kWaves + (u64)half * 8;
+        // the eight ranges: first position and number of packed rows (lane s < 8 fetches range s)
+        u64 lo_l = 0;
+        u32 cn_l = 0;
+        if (mine && lane < 8) {
+            const u64 gw = gw0 + lane;
+            u64 ws = wave_row_lo(p, gw), we = wave_row_lo(p, gw + 1);
+            if (we > p.n) we = p.n;
+            if (ws > we) ws = we;
+            const u64 c = p.wcnt[gw];
+            lo_l = ws;
+            cn_l = (u32)(c < we - ws ? c : we - ws);
+        }
+        u32 cnt_s[8], pre_s[9];  // rows of range s | slots before range s
+        u64 lo_s[8];
+        pre_s[0] = 0;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            cnt_s[s8] = (u32)__builtin_amdgcn_readlane((int)cn_l, s8);
+            lo_s[s8] = shfl64(lo_l, s8);
+            pre_s[s8 + 1] = pre_s[s8] + ((cnt_s[s8] + (u32)kTile - 1u) / (u32)kTile);
+        }
+        const u32 nslots = mine ? pre_s[8] : 0u;
+        // a slot = one tile (256 rows, dwordx4 per lane and column: the ranges start on tile boundaries); 64-row slots of
+        // single dwords were 4x the load instructions and cost this kernel 20 us
+        uint4 ra[kSrchSlots], rl[kSrchSlots];  // affinity | load of the batch's rows (rows = slot base + 4 lane ..)
+        u32 d_lo = 0, d_hi = 0, d_rem = 0;     // lane k: first position (two halves) and rows of slot t0 + k
+        // descriptors of the batch starting at slot t0 (lane k -> slot t0 + k), then every row of the batch is requested
+        auto fetch = [&](u32 t0) {
+            const u32 t = t0 + (u32)lane;
+            u32 sg = 0;
+#pragma unroll
+            for (int s8 = 1; s8 < 8; ++s8) sg += t >= pre_s[s8];
+            u64 lo = lo_s[0];
+            u32 cn = cnt_s[0], pr = pre_s[0];
+#pragma unroll
+            for (int s8 = 1; s8 < 8; ++s8) {
+                const bool pick = sg == (u32)s8;
+                lo = pick ? lo_s[s8] : lo;
+                cn = pick ? cnt_s[s8] : cn;
+                pr = pick ? pre_s[s8] : pr;
+            }
+            const u32 off = (t - pr) * (u32)kTile;
+            const bool ok = t < nslots && off < cn;
+            const u64 st = ok ? lo + off : lo_s[0];
+            const u32 rem = ok ? (cn - off < (u32)kTile ? cn - off : (u32)kTile) : 0u;
+            d_lo = (u32)st; d_hi = (u32)(st >> 32); d_rem = rem;
+#pragma unroll
+            for (int k = 0; k < kSrchSlots; ++k) {
+                const u64 base = ((u64)(u32)__builtin_amdgcn_readlane((int)d_hi, k) << 32) | (u32)__builtin_amdgcn_readlane((int)d_lo, k);
+                const u64 at = base + (u64)lane * 4;  // (a whole tile is always addressable: the columns are padded)
+                ra[k] = *reinterpret_cast<const uint4*>(a.pk_aff + at);
+                rl[k] = *reinterpret_cast<const uint4*>(a.pk_load + at);
+            }
+        };
+        // ordered walk over the batch in registers: claim load of node jq, and the first row whose inclusive prefix exceeds
+        // the budget.  Rows of a packed range are all pending, so "claimant of jq" = affinity == jq (and inside the slot).
+        u64 acc = 0, adm_in = 0;
+        u32 row = kNoCut;
+        bool found = false;
+        auto consume = [&](u64 bud) {
+#pragma unroll
+            for (int k = 0; k < kSrchSlots; ++k) {
+                const u32 rem_k = (u32)__builtin_amdgcn_readlane((int)d_rem, k);
+                const u32 e0 = (u32)lane * 4u;
+                const bool k0 = e0 + 0 < rem_k && ra[k].x == jq, k1 = e0 + 1 < rem_k && ra[k].y == jq;
+                const bool k2 = e0 + 2 < rem_k && ra[k].z == jq, k3 = e0 + 3 < rem_k && ra[k].w == jq;
+                if (!__ballot(k0 | k1 | k2 | k3)) continue;  // (wave-uniform: a node has a handful of claimants per block)
+                const u64 l0 = k0 ? (u64)rl[k].x : 0ull, l1 = k1 ? (u64)rl[k].y : 0ull;
+                const u64 l2 = k2 ? (u64)rl[k].z : 0ull, l3 = k3 ? (u64)rl[k].w : 0ull;
+                const u64 s1 = l0 + l1, s2 = s1 + l2, s3 = s2 + l3;
+                const u64 inc = wave_incl_scan(s3, lane);
+                if (!found) {
+                    const u64 ex = acc + inc - s3;  // claim load of jq before this lane's rows
+                    int e = 4;
+                    if (k3 && ex + s3 > bud) e = 3;
+                    if (k2 && ex + s2 > bud) e = 2;
+                    if (k1 && ex + s1 > bud) e = 1;
+                    if (k0 && ex + l0 > bud) e = 0;
+                    const u64 over = __ballot(e < 4);
+                    if (over) {
+                        const int fl = __ffsll((long long)over) - 1;
+                        const int ef = __builtin_amdgcn_readlane(e, fl);
+                        const u64 before = ef == 0 ? 0ull : (ef == 1 ? l0 : (ef == 2 ? s1 : s2));
+                        const u64 base = ((u64)(u32)__builtin_amdgcn_readlane((int)d_hi, k) << 32) | (u32)__builtin_amdgcn_readlane((int)d_lo, k);
+                        row = (u32)(base + (u64)fl * 4 + (u64)ef);
+                        adm_in = shfl64(ex + before, fl);
+                        found = true;
+                    }
+                }
+                acc += shfl64(inc, 63);
+            }
+        };
+        RIOGP_KT(p, 0, 3);
+        if (mine && nslots) fetch(0);
+        RIOGP_KT(p, 0, 4);
+        if (mine && half == 0) {
+            for (u32 t0 = 0; t0 < nslots; t0 += kSrchSlots) {
+                if (t0) fetch(t0);
+                consume(s_bud[q]);
+            }
+            if (lane == 0) { s_half[q] = acc; s_row[q] = row; s_in[q] = adm_in; }
+        }
+        RIOGP_KT(p, 0, 5);
+        __syncthreads();
+        if (mine && half == 1 && s_row[q] == kNoCut) {
+            acc = s_half[q];  // the first half's claimants come first, and all of them were admitted
+            for (u32 t0 = 0; t0 < nslots; t0 += kSrchSlots) {
+                if (t0) fetch(t0);
+                consume(s_bud[q]);
+            }
+            if (lane == 0) { s_row[q] = row; s_in[q] = adm_in; }
+        }
+        __syncthreads();
+        RIOGP_KT(p, 0, 6);
+        if (mine && half == 0 && lane == 0) {
+            const u64 in_blk = s_row[q] == kNoCut ? 0ull : s_in[q];  // (kNoCut cannot happen: the block prefix crosses the budget here)
+            a.cutidx[jq] = s_row[q];
+            a.used_cur[jq] = s_used[q] + s_adm[q] + in_blk;
+            s_in[q] = in_blk;
+        }
+        __syncthreads();
+        if (a.RP) store_rejected();
+        RIOGP_KT(p, 0, 7);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,255 +913,29 @@ __device__ __forceinline__ void fx_add_rejected(const FxRows& fx, DevStats* stat
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3a k_cut_subhist — only when some node has a cut: per-(node, sub-chunk) claim load inside the
-//     node's cut block.  One more pass over the blocks that contain a cut.
+// K3  the exact cut search for ONE block b of rows (cut_search_block) and the kernel that spreads the searches over the chip
+//     (k_cut_find).  The exact cut row of node j is a fact about ONE block's rows (block cutblk[j], located by k_resolve):
+//       P0  which nodes have their cut in b (a slice of them when the block's cuts are spread over several work items);
+//       P1  per group of K such nodes, level by level: T[slot][piece of the node's current range] claim load of the
+//           block's rows (LDS atomics), then an ordered walk over each node's T row shrinks its range to the piece
+//           that holds the cut; another level only while row-by-row searches would cost more than one more pass;
+//       P2  one wave per node: the exact row inside the remaining range (whole tiles, dwordx4);
+//           cutidx[j] = that row, used_cur[j] = kept + admitted, R[b] -= what the block admits of the node.
 // ------------------------------------------------------------------------------------------------
-template <bool VIRT>
-__global__ __launch_bounds__(kBlock) void k_cut_subhist(const u32* __restrict__ cur, const u32* __restrict__ load,
-                                                        const u32* __restrict__ aff,
-                                                        const u32* __restrict__ alive_bits, Plan p,
-                                                        const u32* __restrict__ cutblk, u64* __restrict__ T) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 m = p.m;
-    u32& any = *reinterpret_cast<u32*>(smem);
-    u32* cb = reinterpret_cast<u32*>(smem + kSmall);  // [m]
-    u32* alv = cb + m;                                 // [mwords]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) any = 0;
-    __syncthreads();
-    u32 mine = 0;
-    for (u32 k = tid; k < m; k += kBlock) {
-        const u32 v = cutblk[k];
-        cb[k] = v;
-        mine |= (v == blockIdx.x);
-    }
-    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
-    if (mine) any = 1;
-    __syncthreads();
-    if (!any) return;
-    const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    const u64 bstart = block_row_lo(p, blockIdx.x);
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
-    for (u64 it = wstart; it < wend; it += kTile) {
-        const u64 i0 = it + (u64)lane * 4;
-        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
-        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
-        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
-        // a tile (256 rows) lies inside ONE sub-chunk (sub % 256 == 0): aggregate per node across the wave
-        // before touching T, so a hot node costs one global atomic per tile instead of one per row
-        const u32 t = (u32)((it - bstart) / p.sub);
-#define RIOGP_ROW(C, A, L, E)                                                                              \
-        {                                                                                                  \
-            const bool hit = i0 + E < wend && classify<VIRT>(C, A, m, alv) == 1 && cb[A] == blockIdx.x;     \
-            u64 todo = __ballot(hit);                                                                      \
-            if (__popcll(todo) <= 8) {                                                                     \
-                if (hit) atomicAdd(&T[(size_t)A * kMaxSubs + t], (u64)L);                                  \
-                todo = 0;                                                                                  \
-            }                                                                                              \
-            while (todo) {                                                                                 \
-                const int ld = __ffsll((long long)todo) - 1;                                               \
-                const u32 nd = (u32)__shfl((int)A, ld, 64);                                                \
-                const bool same = hit && A == nd;                                                          \
-                const u64 sum = wave_sum(same ? (u64)L : 0ull);                                            \
-                if (lane == ld) atomicAdd(&T[(size_t)nd * kMaxSubs + t], sum);                             \
-                todo &= ~__ballot(same);                                                                   \
-            }                                                                                              \
-        }
-        RIOGP_ROW(cv.x, av.x, lv.x, 0)
-        RIOGP_ROW(cv.y, av.y, lv.y, 1)
-        RIOGP_ROW(cv.z, av.z, lv.z, 2)
-        RIOGP_ROW(cv.w, av.w, lv.w, 3)
-#undef RIOGP_ROW
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3b k_cut_exact — one wave per node with a cut: find the sub-chunk, then the exact row at which
-//     the inclusive claim prefix first exceeds the node's free capacity.
-// ------------------------------------------------------------------------------------------------
-template <bool VIRT>
-__global__ __launch_bounds__(256) void k_cut_exact(const u32* __restrict__ cur, const u32* __restrict__ load,
-                                                   const u32* __restrict__ aff, const u32* __restrict__ alive_bits,
-                                                   Plan p, const u32* __restrict__ cutblk,
-                                                   const u64* __restrict__ budget, const u64* __restrict__ admpre,
-                                                   const u64* __restrict__ T, const u64* __restrict__ used_kept,
-                                                   u32* __restrict__ cutidx, u64* __restrict__ used_cur) {
-    const int lane = threadIdx.x & 63;
-    const u32 j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= p.m) return;
-    const u32 b = cutblk[j];
-    if (b == kNoCut) return;
-    const u64 bud = budget[j];
-    // (1) sub-chunk: first t with prefix(T[j][0..t]) > bud
-    u64 acc = 0, pre_sub = 0;
-    u32 tstar = 0;
-    bool found = false;
-    for (u32 g = 0; g < p.subs && !found; g += 64) {
-        const u32 t = g + lane;
-        const u64 v = t < p.subs ? T[(size_t)j * kMaxSubs + t] : 0;
-        const u64 inc = wave_incl_scan(v, lane);
-        const u64 mask = __ballot(acc + inc > bud);
-        if (mask) {
-            const int fl = __ffsll((long long)mask) - 1;
-            tstar = g + fl;
-            pre_sub = acc + shfl64(inc - v, fl);
-            found = true;
-        } else {
-            acc += shfl64(inc, 63);
-        }
-    }
-    // (2) exact row inside the sub-chunk
-    const u64 bud2 = bud - pre_sub;
-    const u64 start = block_row_lo(p, b) + (u64)tstar * p.sub;
-    u64 end = start + p.sub;
-    if (end > block_row_lo(p, b + 1)) end = block_row_lo(p, b + 1);
-    if (end > p.n) end = p.n;
-    u64 acc2 = 0, cut_row = kNoCut, adm_in = 0;
-    found = false;
-    for (u64 i0 = start; i0 < end && !found; i0 += 64) {
-        const u64 i = i0 + lane;
-        u64 v = 0;
-        if (i < end && packed_live(p, i)) {
-            const u32 c = cur[i], a = aff[i];
-            if (a == j && classify<VIRT>(c, a, p.m, alive_bits) == 1) v = load[i];
-            else v = ~0ull;  // marker: not a claimant of j
-        } else {
-            v = ~0ull;
-        }
-        const bool is_cl = v != ~0ull;
-        const u64 l = is_cl ? v : 0;
-        const u64 inc = wave_incl_scan(l, lane);
-        const u64 mask = __ballot(is_cl && acc2 + inc > bud2);
-        if (mask) {
-            const int fl = __ffsll((long long)mask) - 1;
-            cut_row = i0 + fl;
-            adm_in = acc2 + shfl64(inc - l, fl);
-            found = true;
-        } else {
-            acc2 += shfl64(inc, 63);
-        }
-    }
-    if (lane == 0) {
-        cutidx[j] = (u32)cut_row;
-        used_cur[j] = used_kept[j] + admpre[j] + pre_sub + adm_in;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4  k_apply_cut — claimants at or beyond their node's cut row lose the optimistic assignment and
-//     join the spill set; per-wave spill totals are rebuilt (candidates + rejected).
-// ------------------------------------------------------------------------------------------------
-template <bool VIRT>
-__global__ __launch_bounds__(kBlock) void k_apply_cut(const u32* __restrict__ cur, const u32* __restrict__ load,
-                                                      const u32* __restrict__ aff, u32* __restrict__ next,
-                                                      const u32* __restrict__ alive_bits, Plan p,
-                                                      const u32* __restrict__ cutidx, u64* __restrict__ wsp_sum,
-                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, FxRows fx,
-                                                      u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 m = p.m;
-    u64* red = reinterpret_cast<u64*>(smem);           // [4]
-    u32* ci = reinterpret_cast<u32*>(smem + kSmall);   // [m]
-    u32* alv = ci + m;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (u32 k = tid; k < m; k += kBlock) ci[k] = cutidx[k];
-    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
-    if (tid < 4) red[tid] = 0;
-    __syncthreads();
-    const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
-    u64 sp_sum = 0, rej_sum = 0;
-    u32 sp_cnt = 0, rej_cnt = 0;
-    for (u64 it = wstart; it < wend; it += kTile) {
-        const u64 i0 = it + (u64)lane * 4;
-        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
-        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
-        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
-#define RIOGP_ROW(C, A, L, E)                                                    \
-        if (i0 + E < wend) {                                                     \
-            const int cls = classify<VIRT>(C, A, m, alv);                        \
-            if (cls == 2) { sp_sum += L; ++sp_cnt; }                             \
-            else if (cls == 1 && (u32)(i0 + E) >= ci[A]) {                       \
-                next[i0 + E] = kSpillMark;                                       \
-                sp_sum += L; ++sp_cnt; rej_sum += L; ++rej_cnt;                  \
-            }                                                                    \
-        }
-        RIOGP_ROW(cv.x, av.x, lv.x, 0)
-        RIOGP_ROW(cv.y, av.y, lv.y, 1)
-        RIOGP_ROW(cv.z, av.z, lv.z, 2)
-        RIOGP_ROW(cv.w, av.w, lv.w, 3)
-#undef RIOGP_ROW
-    }
-    sp_sum = wave_sum(sp_sum);
-    sp_cnt = wave_sum32(sp_cnt);
-    rej_sum = wave_sum(rej_sum);
-    rej_cnt = wave_sum32(rej_cnt);
-    if (lane == 0) {
-        wsp_sum[gw] = sp_sum;
-        wsp_cnt[gw] = sp_cnt;
-        if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
-        if (sp_cnt) { atomicAdd(&red[2], sp_sum); atomicAdd(&red[3], (u64)sp_cnt); }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        fx_add_rejected(fx, stats, red[0], red[1]);
-        bsp_sum[blockIdx.x] = red[2];
-        bsp_cnt[blockIdx.x] = (u32)red[3];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K34 k_cut_fused — the whole cut fix-up behind k_cutblk in ONE launch (replaces the T memset,
-//     k_cut_subhist, k_cut_exact, k_shard_force and k_apply_cut: five dependent launches whose
-//     floor was latency, not bytes).  What makes the fusion legal: the exact cut row of node j is a
-//     fact about ONE workgroup's rows (block cutblk[j]), and whether a claimant row i of block b
-//     is rejected depends only on cutblk[A] (known before the launch) and — when cutblk[A] == b —
-//     on the exact cut this very workgroup computes.  So per workgroup b:
-//       P0  thr[j] = 0 (cutblk[j] < b, or forced: every claimant here is rejected) | NOCUT
-//           (cutblk[j] > b / no cut) | "local" (cutblk[j] == b: gets a slot);
-//       P1  per group of K local nodes, level by level: T[slot][piece of the node's current range] claim
-//           load of the block's rows (LDS atomics; the 2 MB global T of the unfused path is gone), then
-//           an ordered walk over each node's T row shrinks its range to the piece that holds the cut;
-//           another level only while row-by-row searches would cost more than one more pass;
-//       P2  one wave per local node: the exact row inside the remaining range (whole tiles, dwordx4);
-//           thr[j] = cutidx[j] = that row, used_cur[j] = kept + admitted;
-//       P3  claimants with i >= thr[aff] lose the optimistic assignment (k_apply_cut's pass).
-//     Rows are streamed twice (P1, P3: the second pass hits L2/MALL) only in blocks that own a cut.
-// ------------------------------------------------------------------------------------------------
-// Phase trace of k_cut_fused (measurement aid, off by default): workgroup b stores wall_clock64() (100 MHz) at its phase
-// boundaries into g_cut_trace[b][0..7] = start, P0 end, passes (all levels), row searches, P3 time, nloc, S, walks (all levels).
-// the switch travels in the Plan (a kernel argument): a flag in device memory would cost the first wave of every workgroup
-// a load round trip at every trace point even when tracing is off
-static int g_trace_host = 0;
-#define KT_ON (p.trace != 0)
-__device__ u64 g_cut_trace[kMaxBlocks * 8];
-#define RIOGP_TRACE(slot, val) do { if (tid == 0 && KT_ON) g_cut_trace[(size_t)blockIdx.x * 8 + (slot)] = (val); } while (0)
-// the same for the other fix-up kernels: table 0 = k_spill_apply (first round), 1 = k_spill_apply (last round),
-// 2 = k_cut_apply_rank, 3 = k_cut_find (item table / first item / end); workgroup b, phase boundary `slot`
-constexpr int kKtTables = 4;
-__device__ u64 g_kt[kKtTables][kMaxBlocks * 8];
-#define RIOGP_KT(table, slot) do { if (threadIdx.x == 0 && KT_ON && blockIdx.x < kMaxBlocks) g_kt[table][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
-
 constexpr u32 kSlotNone = 0xFFFFu;
 constexpr int kCutMinSubs = 16;  // smallest fan-out of a refinement level
 
-// fixed LDS of k_cut_fused in front of the T region (keep in step with cut_fused_lds)
+// fixed LDS of the block search in front of the T region (keep in step with cut_find_lds)
 __host__ __device__ __forceinline__ size_t cut_fused_fixed(u32 m, u32 mwords) {
     const u32 mr = (m + 7) & ~7u;
     return kSmall + (size_t)mr * 8 + (size_t)((mwords + 3) & ~3u) * sizeof(u32) + 2 * kWaves * sizeof(u64);
 }
 
-// The block search is at the register limit (128 VGPRs at 1 024 threads): its phase timers are compiled in only in the
-// TRACE instantiation, which the launchers pick while tracing is switched on.
-#undef KT_ON
-#define KT_ON (TRACE && p.trace != 0)
 // The search half of the cut fix-up for ONE block b of rows: which nodes have their cut in b (all of them, or the slice
 // j % sel_mod == sel_rem of them when the block's cuts are spread over several workgroups), and for each the exact row —
 // P0..P2 of the description above.  Every thread of the workgroup calls it; on return thr[] (LDS) holds the reject
 // threshold of every node as seen from block b, and cutidx[] / used_cur[] (global) are final for the nodes searched.
-template <bool VIRT, bool TRACE>
+template <bool VIRT>
 __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 b, const u32 sel_mod, const u32 sel_rem,
                                                  const bool write_forced, const u32* __restrict__ cur,
                                                  const u32* __restrict__ load, const u32* __restrict__ aff,
@@ -935,7 +943,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                                                  const u32* __restrict__ cutblk, const u64* __restrict__ budget,
                                                  const u64* __restrict__ admpre, const u64* __restrict__ used_kept,
                                                  const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
-                                                 u64* __restrict__ used_cur, const u32 tcap) {
+                                                 u64* __restrict__ used_cur, const u32 tcap, u64* __restrict__ R) {
     const u32 m = p.m, mr = (m + 7) & ~7u;
     u32& nlocal = *reinterpret_cast<u32*>(smem);
     u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
@@ -948,7 +956,6 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
     u64* T = whi + kWaves;                                                   // [tcap]: T[K][S] from the front,
                                                                              //         budget of slot s at T[tcap-1-s]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
-    RIOGP_TRACE(0, wall_clock64());
     if (tid == 0) { nlocal = 0; red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0; }
     // one round trip for the liveness words, the packed row count of this wave and the thread's first cutblk[] word
     const u64 gw = (u64)b * kWaves + wave;
@@ -1016,10 +1023,6 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
         live_tiles = wave_sum32(mine);
         if (live_tiles < 1) live_tiles = 1;
     }
-    RIOGP_TRACE(1, wall_clock64());
-    RIOGP_TRACE(5, (u64)nloc);
-    RIOGP_TRACE(6, (u64)S);
-    u64 tr_p1 = 0, tr_p2 = 0, tr_p2a = 0;
 
     for (u32 g0 = 0; g0 < nloc; g0 += K) {
         const u32 kn = nloc - g0 < K ? nloc - g0 : K;
@@ -1035,7 +1038,6 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
         for (u32 level = 0;; ++level) {
             const u32 ptiles = (rlen + S - 1) / S;   // tiles per piece at this level
             const u32 np = (rlen + ptiles - 1) / ptiles;  // pieces actually used (<= S)
-            const u64 tr_a = KT_ON ? wall_clock64() : 0;
             for (u32 k = tid; k < kn * Sp; k += kBlock) T[k] = 0;
             __syncthreads();
             if (kn == 1) {
@@ -1133,7 +1135,6 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                 }
             }
             __syncthreads();
-            const u64 tr_b = KT_ON ? wall_clock64() : 0;
             // ordered walk over each node's T row: the piece that holds the cut becomes the node's range.  Two forms,
             // picked by estimated instruction count: one LANE per node (many nodes, short rows: row stride odd, so no
             // bank conflicts) or one WAVE per node with a DPP scan (few nodes, long rows).  LDS only.
@@ -1192,14 +1193,12 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                 }
             }
             __syncthreads();
-            if (KT_ON) { const u64 tr_c = wall_clock64(); tr_p1 += tr_b - tr_a; tr_p2a += tr_c - tr_b; }
             rlen = ptiles;
             // another level?  In tile-steps shared by 16 waves: row-by-row searches of the remaining ranges cost about
             // kn x rlen x (live share) ordered scans; one more level costs a pass over the live tiles (a third of a scan
             // each) plus a fixed part (zeroing, barriers, walks ~ 100 scans).  Taken only when it clearly pays (2x).
             if (rlen <= 1 || (u64)kn * rlen * live_tiles <= (u64)BT * (2ull * (live_tiles / 3 + 100))) break;
         }
-        const u64 tr_b2 = KT_ON ? wall_clock64() : 0;
         // the rows each node's search covers: from the first tile of its range that holds live rows (packed fix-up: most
         // positions of a wave range are dead) to the end of the range — one lane per node, LDS only, into the T region
         // (free now): T[ls] = first row, T[kn + ls] = end.  Done here so that the searches below start with their loads.
@@ -1303,6 +1302,9 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                 thr[j] = (u32)cut_row;
                 cutidx[j] = (u32)cut_row;
                 used_cur[j] = q.uk + q.ad + q_pre_sub + adm_in;
+                // k_resolve counted the node's whole claim load of this block as rejected (RP, k_fill's ordered spill prefix):
+                // what the block admits of it comes off again — summed over the item in LDS, one global atomic per item
+                if (R && q_pre_sub + adm_in) atomicAdd(&red[1], q_pre_sub + adm_in);
             }
         };
         constexpr int kInFlight = 3;
@@ -1318,110 +1320,33 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                 if (base + (u32)u * kWaves < kn) run(q[u]);
         }
         __syncthreads();
-        if (KT_ON) tr_p2 += wall_clock64() - tr_b2;
     }
-    RIOGP_TRACE(2, tr_p1);
-    RIOGP_TRACE(3, tr_p2);
-    RIOGP_TRACE(7, tr_p2a);
-    RIOGP_TRACE(4, wall_clock64());
-
-}
-
-template <bool VIRT, bool TRACE>
-__global__ __launch_bounds__(kBlock) void k_cut_fused(const u32* __restrict__ cur, const u32* __restrict__ load,
-                                                      const u32* __restrict__ aff, u32* __restrict__ next,
-                                                      const u32* __restrict__ alive_bits, Plan p,
-                                                      const u32* __restrict__ cutblk, const u64* __restrict__ budget,
-                                                      const u64* __restrict__ admpre,
-                                                      const u64* __restrict__ used_kept,
-                                                      const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
-                                                      u64* __restrict__ used_cur, u64* __restrict__ wsp_sum,
-                                                      u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, u32 tcap,
-                                                      FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 m = p.m, mr = (m + 7) & ~7u;
-    u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
-    u32* thr = reinterpret_cast<u32*>(smem + kSmall);                        // [mr] reject threshold by node
-    u32* alv = reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(thr + mr) + 2 * mr);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
-    const u32 b = blockIdx.x;
-    if (stats->n_cut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
-    cut_search_block<VIRT, TRACE>(smem, b, 1, 0, true, cur, load, aff, alive_bits, p, cutblk, budget, admpre, used_kept, forced_bits,
-                           cutidx, used_cur, tcap);
-    const u64 gw = (u64)b * kWaves + wave;
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
-
-    // P3: re-mark the rejected claimants, rebuild the per-wave spill totals (candidates + rejected).  Every workgroup
-    //     runs this over all its rows, so the row body is branch-free except for the (rare) store: the class of a row is
-    //     computed with bit operations, counts are popcounts of ballots (wave-uniform), loads are summed under selects.
-    u64 sp_sum = 0, rej_sum = 0;
-    u32 sp_cnt = 0, rej_cnt = 0;  // wave-uniform
-    for (u64 it = wstart; it < wend; it += kTile) {
-        const u64 i0 = it + (u64)lane * 4;
-        const uint4 cv = *reinterpret_cast<const uint4*>(cur + i0);
-        const uint4 av = *reinterpret_cast<const uint4*>(aff + i0);
-        const uint4 lv = *reinterpret_cast<const uint4*>(load + i0);
-#define RIOGP_ROW(C, A, L, E)                                                                        \
-        {                                                                                            \
-            const bool inr = i0 + E < wend;                                                          \
-            const bool cin = C < m, ain = A < m;                                                     \
-            const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                          \
-            const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                  \
-            const bool skip = VIRT && C == kSkipMark;                                                \
-            const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                             \
-            const bool sp = inr & !kept & !skip & !cl & (VIRT | (A != kAffInactive));                \
-            const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                        \
-            if (rej) next[i0 + E] = kSpillMark;                                                      \
-            sp_sum += (sp | rej) ? (u64)L : 0ull;                                                    \
-            rej_sum += rej ? (u64)L : 0ull;                                                          \
-            sp_cnt += (u32)__popcll(__ballot(sp | rej));                                             \
-            rej_cnt += (u32)__popcll(__ballot(rej));                                                 \
-        }
-        RIOGP_ROW(cv.x, av.x, lv.x, 0)
-        RIOGP_ROW(cv.y, av.y, lv.y, 1)
-        RIOGP_ROW(cv.z, av.z, lv.z, 2)
-        RIOGP_ROW(cv.w, av.w, lv.w, 3)
-#undef RIOGP_ROW
-    }
-    sp_sum = wave_sum(sp_sum);
-    rej_sum = wave_sum(rej_sum);
-    if (lane == 0) {
-        wsp_sum[gw] = sp_sum;
-        wsp_cnt[gw] = sp_cnt;
-        if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
-        if (sp_cnt) { atomicAdd(&red[2], sp_sum); atomicAdd(&red[3], (u64)sp_cnt); }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        fx_add_rejected(fx, stats, red[0], red[1]);
-        bsp_sum[blockIdx.x] = red[2];
-        bsp_cnt[blockIdx.x] = (u32)red[3];
-    }
-    if (tid == 0 && KT_ON) g_cut_trace[(size_t)blockIdx.x * 8 + 4] = wall_clock64() - g_cut_trace[(size_t)blockIdx.x * 8 + 4];
+    if (R && tid == 0 && red[1]) atomicAdd(&R[b], (u64)0 - red[1]);  // what this item's cuts admit inside block b
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3f k_cut_find — the search half of the cut fix-up, spread over the chip.  In k_cut_fused the workgroup that owns
-//     block b of rows also owns every cut that falls into b, and in a nearly full cluster most nodes reject within
-//     their first claimants: one workgroup searched 200-400 nodes (31 us) while ~250 CUs idled.  The search for node j
+// K3f k_cut_find — the exact cut search, spread over the chip (whole-table solves; the packed fix-up searches inside
+//     k_resolve).  If the workgroup that owns block b of rows also owned every cut that falls into b, a nearly full cluster —
+//     most nodes reject within their first claimants — would have one workgroup search 200-400 nodes (31 us measured)
+//     while ~250 CUs idle.  The search for node j
 //     needs only block cutblk[j]'s rows, so it is a work ITEM (block b, slice s of the nodes cut in b): every
 //     workgroup derives the same item list from cutblk[] (a histogram over blocks, ceil(count / 16) slices per block,
 //     at most 64; slice = j mod slices), takes the items blockIdx.x, +gridDim.x, ... and runs the block search on each.
-//     The re-marking pass that needs EVERY node's result is the next launch (k_cut_apply_rank).
+//     The re-marking pass that needs EVERY node's result is the next launch (k_fill).
 // ------------------------------------------------------------------------------------------------
 constexpr u32 kCutPerItem = 16;    // cut nodes per work item (one per wave of the workgroup that searches them)
 constexpr u32 kCutMaxSlices = 64;  // slices of one block's cuts
 constexpr u32 kCutFindGrid = 256;  // one workgroup per CU (the search needs ~150 KiB of LDS)
 
-template <bool VIRT, bool TRACE>
+template <bool VIRT>
 __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                      const u32* __restrict__ aff, const u32* __restrict__ alive_bits,
                                                      Plan p, const u32* __restrict__ cutblk,
                                                      const u64* __restrict__ budget, const u64* __restrict__ admpre,
                                                      const u64* __restrict__ used_kept,
                                                      const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
-                                                     u64* __restrict__ used_cur, DevStats* __restrict__ stats, u32 tcap) {
+                                                     u64* __restrict__ used_cur, DevStats* __restrict__ stats, u32 tcap,
+                                                     u64* __restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u32 cnt[kMaxBlocks];                 // nodes whose cut falls into block b
     __shared__ unsigned short istart[kMaxBlocks + 1];  // first item of block b; [kMaxBlocks] = number of items
@@ -1431,7 +1356,6 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
     const u64 ncut = stats->n_cut;  // one round trip for the verdict and the thread's first cutblk[] word
     const u32 cb0 = cutblk[(u32)tid < m ? (u32)tid : m - 1];
     if (ncut == 0 && forced_bits == nullptr) return;  // speculative launch behind a solve that had no cut
-    RIOGP_KT(3, 0);
     if (forced_bits && blockIdx.x == 0)  // row-sharded solve: the prefix overflowed on a lower rank — nothing is admitted here
         for (u32 j = tid; j < m; j += kBlock)
             if (bit_of(forced_bits, j)) { cutidx[j] = 0; used_cur[j] = used_kept[j]; }
@@ -1465,8 +1389,6 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
     }
     __syncthreads();
     const u32 items = istart[kMaxBlocks];
-    RIOGP_KT(3, 1);
-    if (threadIdx.x == 0 && KT_ON && blockIdx.x < kMaxBlocks) g_kt[3][(size_t)blockIdx.x * 8 + 3] = items;
     for (u32 item = blockIdx.x; item < items; item += gridDim.x) {
         u32 lo = 0, hi = kMaxBlocks;  // the last block whose first item is <= item (blocks without cuts share their successor's start)
         while (hi - lo > 1) {
@@ -1474,24 +1396,12 @@ __global__ __launch_bounds__(kBlock) void k_cut_find(const u32* __restrict__ cur
             if (istart[mid] <= item) lo = mid; else hi = mid;
         }
         __syncthreads();  // the previous item's LDS tables are dead from here on
-        cut_search_block<VIRT, TRACE>(smem, lo, nsl[lo], item - istart[lo], false, cur, load, aff, alive_bits, p, cutblk, budget,
-                               admpre, used_kept, forced_bits, cutidx, used_cur, tcap);
+        cut_search_block<VIRT>(smem, lo, nsl[lo], item - istart[lo], false, cur, load, aff, alive_bits, p, cutblk, budget,
+                               admpre, used_kept, forced_bits, cutidx, used_cur, tcap, R);
     }
-    RIOGP_KT(3, 2);
 }
 
-#undef KT_ON
-#define KT_ON (p.trace != 0)
-// ------------------------------------------------------------------------------------------------
-// KS  k_spill_rank — per round: free capacity per node and the rank of every node in the total order
-//     (free desc, index asc) by counting.  (The exclusive prefix of the per-wave spill totals and the "is anything
-//     pending" verdict are computed by k_spill_apply's own prologue — 48 KiB of L2 reads per workgroup — so that the
-//     ranking of round 0 depends on the cut search only and can share a launch with k_cut_apply.)
-//     Ranking is m^2 wave-uniform LDS reads: ONE workgroup is bound by a single CU's LDS port
-//     (measured 48 us at m = 1024), so it is spread over m/64 workgroups: each recomputes free[] in
-//     its LDS (m loads) and ranks 64 nodes, thread = (node, 1/16 of the k range).  The saturating
-//     cumulative C[] is rebuilt from the ranked free values in k_spill_apply's prologue.
-// ------------------------------------------------------------------------------------------------
+// block-wide exclusive prefix (1 024 threads), optionally saturating
 __device__ u64 block_excl_scan_1024(u64 v, bool saturating, u64* lds_part /*[16]*/, u64* total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 inc = saturating ? wave_incl_scan_sat(v, lane) : wave_incl_scan(v, lane);
@@ -1517,377 +1427,465 @@ __device__ u64 block_excl_scan_1024(u64 v, bool saturating, u64* lds_part /*[16]
     return excl;
 }
 
-constexpr int kRankNodes = 64;
-
-// Body of one ranking workgroup (64 nodes).  LDS: [2*kSmall + 256 + mp*8] bytes at smem.
-__device__ __forceinline__ void spill_rank_body(unsigned char* smem, const u32 rb /* ranking block */, const Plan& p,
-                                                const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
-                                                const u64* __restrict__ used_cur, u64* __restrict__ wfFree,
-                                                u32* __restrict__ wfOrder, u32* __restrict__ wfCnt) {
-    const u32 m = p.m;
-    const u32 mp = (m + kBlock - 1) / kBlock * kBlock;  // padded
-    u32& nz_total = *reinterpret_cast<u32*>(smem + 128);
-    u32* rk = reinterpret_cast<u32*>(smem + 2 * kSmall);         // [64] rank accumulators of this block's nodes
-    u64* fre = reinterpret_cast<u64*>(smem + 2 * kSmall + 256);  // [mp] free by node
+// ------------------------------------------------------------------------------------------------
+// Water-fill order inside the workgroup.  The water-fill takes the nodes by CAPACITY CLASS descending, node index ascending
+// inside a class; the class of a free capacity f > 0 is f rounded down to three significant bits, as an ordinal
+// (4 * floor(log2 f) + the two bits below the leading one: 256 classes, monotone in f — DESIGN.md section 2 step 3,
+// oracle/placement_oracle.c wf_class).  That order is a COUNTING problem: rank = nodes in higher classes + nodes of the same
+// class with a lower index.  Every workgroup of k_fill computes it itself, in LDS, while its first rows are on their way
+// from HBM (~100 vector instructions per node; the first version of this solver ranked by exact free capacity, which needs
+// a comparison sort: ~1 400 instructions per node on one CU = 10 us at m = 1 024, or a launch of its own per round).
+//   group = the 64 nodes one wave holds in one pass (node j = tid + 1024 q: group q * 16 + wave, in node order);
+//   tab[group][class] = nodes of the class in the group -> exclusive prefix over the groups (thread = class);
+//   rank(j) = nodes in higher classes + tab[group(j)][class] + position of j among the group's nodes of its class.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 wf_class(u64 f) {  // f > 0
+    const u32 e = 63u - (u32)__clzll((long long)f);
+    const u32 mant = e >= 2 ? (u32)(f >> (e - 2)) & 3u : (u32)(f << (2 - e)) & 3u;
+    return e * 4u + mant;
+}
+__host__ __device__ __forceinline__ size_t rank_tab_bytes(u32 m) {  // u16 [groups][256]
+    const u32 per = (m + kBlock - 1) / kBlock;
+    return ((size_t)(per ? per : 1) * kWaves + 2) * 256 * sizeof(unsigned short);  // + class totals / offsets (+ the total)
+}
+// fr[q] = free capacity of node tid + 1024 q (0: not ranked), q < per <= 8.  On return rk[q] = rank of that node (only
+// where fr[q] != 0) and the return value = number of ranked nodes.  tab: rank_tab_bytes(m) of LDS, ZEROED by the caller
+// before its last barrier.  Every thread of the workgroup calls it (three barriers inside).
+// tab layout: [class][pass q][wave] counts (the 16 waves of a pass = one 16-lane DPP row), then 256 class totals / offsets.
+__device__ __forceinline__ u32 rank_by_class(unsigned short* tab, const u32 per, const u64 (&fr)[8], u32 (&rk)[8], const Plan& p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) nz_total = 0;
-    if (tid < kRankNodes) rk[tid] = 0;
-    u32 nz = 0;
-    for (u32 j = tid; j < mp; j += kBlock) {
-        u64 f = 0;
-        if (j < m) {
-            const u64 c = cap[j], u = used_cur[j];
-            f = (bit_of(alive_bits, j) && c > u) ? c - u : 0;
-        }
-        fre[j] = f;
-        nz += f != 0;
-    }
-    __syncthreads();
-    nz = wave_sum32(nz);
-    if (lane == 0 && nz) atomicAdd(&nz_total, nz);
-    __syncthreads();
-    if (rb == 0 && tid == 0) wfCnt[0] = nz_total;  // number of ranked nodes (free > 0)
-    // rank of node j = #{k : free[k] > free[j] or (free[k] == free[j] and k < j)}; lane = node, wave = k range
-    const u32 j = rb * kRankNodes + lane;
-    const u64 f = j < m ? fre[j] : 0;
-    const u32 per = mp / kWaves;  // multiple of 64
-    u32 r = 0;
-    for (u32 k0 = wave * per; k0 < (wave + 1) * per; k0 += 8) {
-        u64 g[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) g[q] = fre[k0 + q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r += (g[q] > f) || (g[q] == f && k0 + q < j);
-    }
-    if (f != 0) atomicAdd(&rk[lane], r);
-    __syncthreads();
-    if (tid < kRankNodes && f != 0) {
-        wfFree[rk[tid]] = f;
-        wfOrder[rk[tid]] = j;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_spill_rank(Plan p, const u64* __restrict__ cap,
-                                                       const u32* __restrict__ alive_bits,
-                                                       const u64* __restrict__ used_cur, u64* __restrict__ wfFree,
-                                                       u32* __restrict__ wfOrder, u32* __restrict__ wfCnt) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    spill_rank_body(smem, blockIdx.x, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4r k_cut_apply_rank — behind k_cut_find: blocks [0, G) re-mark the rejected claimants (row i of a claimant of node a
-//     is rejected iff i >= cutidx[a]; every claimant of a forced node is) and rebuild the per-wave spill totals — the
-//     branch-free pass P3 of k_cut_fused; blocks [G, G + m/64) rank the nodes for water-fill round 0 (k_spill_rank's
-//     body): that ranking needs used_cur[], final since k_cut_find, and nothing this launch's other blocks produce, so it
-//     rides along instead of costing a dependent launch of its own.
-// ------------------------------------------------------------------------------------------------
-template <bool VIRT, bool PACK = false>
-__global__ __launch_bounds__(kBlock) void k_cut_apply_rank(const u32* __restrict__ cur, const u32* __restrict__ load,
-                                                           const u32* __restrict__ aff, u32* __restrict__ next,
-                                                           const u32* __restrict__ alive_bits, Plan p,
-                                                           const u32* __restrict__ cutidx,
-                                                           const u32* __restrict__ forced_bits, u64* __restrict__ wsp_sum,
-                                                           u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats,
-                                                           const u64* __restrict__ cap, const u64* __restrict__ used_cur,
-                                                           u64* __restrict__ wfFree, u32* __restrict__ wfOrder,
-                                                           u32* __restrict__ wfCnt, FxRows fx, u64* __restrict__ bsp_sum,
-                                                           u32* __restrict__ bsp_cnt, PackOut pko) {
-    // PACK (whole-table solves whose previous solve left few rows for the water-fill): every row that goes on to the
-    // water-fill — spill candidates and the claimants rejected here — is ALSO copied, in index order, to the front of its
-    // wave's range in the pack columns (row, load, mark) and counted in pko.wcnt; the water-fill rounds then run over the
-    // packed rows only (k_spill_apply writes its decisions through pk_idx), not over the whole table twice.
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (blockIdx.x >= p.G) {
-        spill_rank_body(smem, blockIdx.x - p.G, p, cap, alive_bits, used_cur, wfFree, wfOrder, wfCnt);
-        return;
-    }
-    const u32 m = p.m;
-    u64* red = reinterpret_cast<u64*>(smem + 16);      // [2]
-    u32* thr = reinterpret_cast<u32*>(smem + kSmall);  // [m] first rejected row of a node's claimants (kNoCut: none)
-    u32* alv = thr + ((m + 3) & ~3u);                  // [mwords]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
-    RIOGP_KT(2, 0);
-    // Every global operand is requested up front, in the order it is needed and without predicates (clamped addresses):
-    // the packed row count of this wave, the cut rows and the liveness words, then the wave's first tile of rows — whose
-    // round trip then runs under the LDS fill and the barrier instead of after them.
-    const u64 gw = (u64)blockIdx.x * kWaves + wave;
-    const u32 wc = *(p.wcnt ? p.wcnt + gw : cutidx);
-    const u64 ncut = stats->n_cut;
-    const u32 per = (m + kBlock - 1) / kBlock;  // <= 8
-    u32 tv[8];
-#pragma unroll
-    for (u32 q = 0; q < 8; ++q) tv[q] = 0;
-    tv[0] = cutidx[(u32)tid < m ? (u32)tid : m - 1];
-    if (per > 1) {  // m > 1 024
-#pragma unroll
-        for (u32 q = 1; q < 8; ++q) {
-            const u32 j = tid + (q < per ? q : per - 1) * kBlock;
-            tv[q] = cutidx[j < m ? j : m - 1];
-        }
-    }
-    const u32 ak = (u32)tid < p.mwords ? (u32)tid : p.mwords - 1;  // mwords <= 256 < kBlock
-    const u32 aw = alive_bits[ak];
-    u64 wstart = wave_row_lo(p, gw), wend = wave_row_lo(p, gw + 1);
-    if (wend > p.n) wend = p.n;
-    if (wstart > wend) wstart = wend;
-    if (p.wcnt && wstart + wc < wend) wend = wstart + wc;
-    const u64 rs = (wstart < wend ? wstart : 0ull) + (u64)lane * 4;
-    uint4 cvn = *reinterpret_cast<const uint4*>(cur + rs);
-    uint4 avn = *reinterpret_cast<const uint4*>(aff + rs);
-    uint4 lvn = *reinterpret_cast<const uint4*>(load + rs);
-    if (!PACK && ncut == 0 && forced_bits == nullptr) return;  // no cut anywhere: k_scan's spill totals stand
-    if (PACK && ncut == 0 && forced_bits == nullptr && bsp_cnt[blockIdx.x] == 0) {
-        // no cut anywhere and k_scan saw no spill candidate in this block: nothing to pack, its totals (zero) stand
-        if (lane == 0) pko.wcnt[gw] = 0;
-        return;
-    }
+    unsigned short* ctot = tab + (size_t)per * kWaves * 256;  // [256] nodes of the class, then: nodes in higher classes
+    u32 cls[8], pos[8];
+    const u64 below = (1ull << lane) - 1ull;
 #pragma unroll
     for (u32 q = 0; q < 8; ++q) {
-        const u32 j = tid + q * kBlock;
-        if (q < per && j < m) thr[j] = (forced_bits && bit_of(forced_bits, j)) ? 0u : tv[q];
-    }
-    alv[ak] = aw;  // threads past mwords rewrite the last word with its own value
-    if (tid < 4) red[tid] = 0;
-    __syncthreads();
-    RIOGP_KT(2, 1);
-    u64 sp_sum = 0, rej_sum = 0;
-    u32 sp_cnt = 0, rej_cnt = 0;  // wave-uniform
-    u64 pk_pos = wstart;          // PACK: this wave's packed write cursor (wave-uniform)
-    // PACK: this wave's packing ring (row | load, kStageCap words each) behind the thr / alive tables
-    u32* stage = PACK ? alv + ((p.mwords + 3) & ~3u) + (size_t)wave * 2 * kStageCap : nullptr;
-    u32 st_head = 0, st_fill = 0;
-    for (u64 it = wstart; it < wend; it += kTile) {
-        const u64 i0 = it + (u64)lane * 4;
-        const uint4 cv = cvn, av = avn, lv = lvn;
-        u32 pm = 0;  // PACK: which of the lane's four rows go on to the water-fill
-        const u64 pit = (it + kTile < wend ? it + kTile : it) + (u64)lane * 4;  // next tile in flight (the last re-reads its own)
-        cvn = *reinterpret_cast<const uint4*>(cur + pit);
-        avn = *reinterpret_cast<const uint4*>(aff + pit);
-        lvn = *reinterpret_cast<const uint4*>(load + pit);
-        // The rows' `next` values are rebuilt from the columns (what k_scan wrote: kept -> cur, claimant -> affinity,
-        // duplicate request -> skip mark, not an object -> NONE, the rest -> spill mark) with the rejected claimants turned
-        // into spill marks (PACK: every row that goes on to the water-fill into NONE, final unless a round places it
-        // through pk_idx), and a wave that changes anything writes its whole kilobyte back, every lane its 16 bytes:
-        // full 128-byte lines instead of masked 4-byte stores into them (positions past wend are padding / scratch).
-        uint4 ov;
-        bool chg = false;
-#define RIOGP_ROW(C, A, L, O, E)                                                                     \
-        {                                                                                            \
-            const bool inr = i0 + E < wend;                                                          \
-            const bool cin = C < m, ain = A < m;                                                     \
-            const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                          \
-            const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                  \
-            const bool skip = VIRT && C == kSkipMark;                                                \
-            const bool dead = !VIRT && A == kAffInactive;                                            \
-            const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                             \
-            const bool sp = inr & !kept & !skip & !cl & !dead;                                       \
-            const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                        \
-            const u32 mark = PACK ? kNone : kSpillMark;                                              \
-            O = kept ? C : (cl ? (rej ? mark : A) : (skip ? kSkipMark : (dead ? kNone : mark)));     \
-            if (PACK) pm |= (u32)(sp | rej) << E;                                                    \
-            chg |= PACK ? (sp | rej) : rej;                                                          \
-            sp_sum += (sp | rej) ? (u64)L : 0ull;                                                    \
-            rej_sum += rej ? (u64)L : 0ull;                                                          \
-            sp_cnt += (u32)__popcll(__ballot(sp | rej));                                             \
-            rej_cnt += (u32)__popcll(__ballot(rej));                                                 \
-        }
-        RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
-        RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
-        RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
-        RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
-#undef RIOGP_ROW
-        if (__ballot(chg)) *reinterpret_cast<uint4*>(next + i0) = ov;
-        if (PACK) {  // index order = lane-major, then element; through this wave's LDS ring, 64 records per flush (k_scan<COMPACT>)
-            const u64 b0 = __ballot(pm & 1u), b1 = __ballot(pm & 2u), b2 = __ballot(pm & 4u), b3 = __ballot(pm & 8u);
-            if (b0 | b1 | b2 | b3) {
-                const u64 lt = (1ull << lane) - 1ull;
-                u32 e = st_head + st_fill + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
-#define RIOGP_PK(E, L)                                                                                     \
-                if (pm & (1u << E)) {                                                                      \
-                    const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
-                    stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; ++e;                               \
-                }
-                RIOGP_PK(0, lv.x)
-                RIOGP_PK(1, lv.y)
-                RIOGP_PK(2, lv.z)
-                RIOGP_PK(3, lv.w)
-#undef RIOGP_PK
-                st_fill += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-                __builtin_amdgcn_wave_barrier();
-                while (st_fill >= 64u) {  // wave-uniform
-                    u32 x = st_head + (u32)lane;
-                    x = x >= kStageCap ? x - kStageCap : x;
-                    const u64 o = pk_pos + (u32)lane;
-                    pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.next[o] = kSpillMark;
-                    st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
-                    st_fill -= 64u;
-                    pk_pos += 64u;
-                    __builtin_amdgcn_wave_barrier();
-                }
+        cls[q] = 0; pos[q] = 0;
+        if (q < per) {  // (uniform)
+            const bool in = fr[q] != 0;
+            const u32 c = in ? wf_class(fr[q]) : 0x100u;
+            u64 same = ~0ull;  // lanes of this group with the same class (nine ballots: eight class bits + "ranked at all")
+#pragma unroll
+            for (int b = 0; b < 9; ++b) {
+                const u64 bal = __ballot((c >> b) & 1u);
+                same &= ((c >> b) & 1u) ? bal : ~bal;
             }
+            cls[q] = c;
+            pos[q] = (u32)__popcll(same & below);
+            if (in && pos[q] == 0) tab[((size_t)c * per + q) * kWaves + wave] = (unsigned short)__popcll(same);
         }
     }
-    if (PACK && st_fill) {  // what is left in the ring (< 64 records)
-        u32 x = st_head + (u32)lane;
-        x = x >= kStageCap ? x - kStageCap : x;
-        if ((u32)lane < st_fill) {
-            const u64 o = pk_pos + (u32)lane;
-            pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.next[o] = kSpillMark;
+    RIOGP_KT(p, 4, 0);
+    __syncthreads();
+    RIOGP_KT(p, 4, 1);
+    {   // exclusive prefix over the groups (pass-major, then wave = node order), one 16-lane row per class and pass
+        const u32 row = (u32)lane >> 4, l16 = (u32)lane & 15u;
+        for (u32 c = (u32)wave * 4u + row; c < 256u; c += kWaves * 4u) {
+            u32 carry = 0;
+            for (u32 q = 0; q < per; ++q) {
+                unsigned short* cell = tab + ((size_t)c * per + q) * kWaves + l16;
+                const u32 v = *cell;
+                u32 inc = v, t;
+                t = dpp32<0x111>(inc); if (l16 >= 1) inc += t;
+                t = dpp32<0x112>(inc); if (l16 >= 2) inc += t;
+                t = dpp32<0x114>(inc); if (l16 >= 4) inc += t;
+                t = dpp32<0x118>(inc); if (l16 >= 8) inc += t;
+                *cell = (unsigned short)(carry + inc - v);
+                carry += (u32)__shfl((int)inc, (lane | 15), 64);
+            }
+            if (l16 == 0) ctot[c] = (unsigned short)carry;
         }
-        pk_pos += st_fill;
     }
-    RIOGP_KT(2, 2);
-    sp_sum = wave_sum(sp_sum);
-    rej_sum = wave_sum(rej_sum);
-    if (lane == 0) {
-        if (PACK) pko.wcnt[gw] = (u32)(pk_pos - wstart);
-        wsp_sum[gw] = sp_sum;
-        wsp_cnt[gw] = sp_cnt;
-        if (rej_cnt) { atomicAdd(&red[0], (u64)rej_cnt); atomicAdd(&red[1], rej_sum); }
-        if (sp_cnt) { atomicAdd(&red[2], sp_sum); atomicAdd(&red[3], (u64)sp_cnt); }
+    RIOGP_KT(p, 4, 2);
+    __syncthreads();
+    u32 all = 0;
+    if (wave == 0) {  // nodes in higher classes: suffix sum over the 256 class totals, four classes per lane
+        const u32 c0 = ctot[4 * lane], c1 = ctot[4 * lane + 1], c2 = ctot[4 * lane + 2], c3 = ctot[4 * lane + 3];
+        const u32 s4 = c0 + c1 + c2 + c3;
+        const u32 inc = (u32)wave_incl_scan((u64)s4, lane);
+        all = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        const u32 above = all - inc;  // nodes in the classes of higher lanes
+        ctot[4 * lane + 3] = (unsigned short)above;
+        ctot[4 * lane + 2] = (unsigned short)(above + c3);
+        ctot[4 * lane + 1] = (unsigned short)(above + c3 + c2);
+        ctot[4 * lane] = (unsigned short)(above + c3 + c2 + c1);
+        if (lane == 0) ctot[256] = (unsigned short)all;
     }
     __syncthreads();
-    if (tid == 0) {
-        fx_add_rejected(fx, stats, red[0], red[1]);
-        bsp_sum[blockIdx.x] = red[2];
-        bsp_cnt[blockIdx.x] = (u32)red[3];
+    RIOGP_KT(p, 4, 3);
+    all = ctot[256];
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+        rk[q] = 0;
+        if (q < per && cls[q] < 0x100u)
+            rk[q] = (u32)ctot[cls[q]] + (u32)tab[((size_t)cls[q] * per + q) * kWaves + wave] + pos[q];
     }
-    RIOGP_KT(2, 3);
+    RIOGP_KT(p, 4, 4);
+    return all;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5  k_spill_apply — water-fill: the spill set in index order has exclusive load prefix Q; the
-//     node whose cumulative-free interval [C[k], C[k+1]) contains Q takes the row iff it fits.
+// K4  k_fill — everything behind the cut search in ONE launch per water-fill round:
+//       pass A (APPLY)  re-mark the rejected claimants (row i of a claimant of node a is rejected iff i >= cutidx[a];
+//                       every claimant of a forced node is), rebuild the per-wave spill totals, optionally (PACK) copy the
+//                       rows that go on to the water-fill to the front of the wave's range in the pack columns;
+//       order           the nodes by capacity class, in LDS (rank_by_class): no ranking launch, no comparison sort;
+//       pass B (FILL)   the water-fill round: the spill set in index order has exclusive load prefix Q, the node whose
+//                       cumulative-free interval [C[k], C[k+1]) contains Q takes the row iff it fits entirely.
+//     Round 0 of a solve is APPLY + FILL (this replaced three launches: re-marking, ranking, water-fill); later rounds are
+//     FILL only (two launches each before); the row-sharded solve, whose ranks exchange their admitted loads
+//     between the cut and the rounds, uses APPLY only and FILL only.
+//     What makes APPLY + FILL one launch: the ordered spill prefix at a workgroup's first row needs the spill load of every
+//     EARLIER block after the cut — the candidates k_scan counted (bsp_sum) plus the claim load the cut rejected there,
+//     R[b], which k_resolve (blocks behind a node's cut block: the whole claim load of the node) and the cut search (the cut
+//     block itself) accumulate without touching a row.  Inside the block the workgroup has its own rows.
+//     `used` is never read and written in the same round — a workgroup that starts late must order the nodes by the same free
+//     capacities as one that started early: round r reads Uread + D[0] + ... + D[r-1] and adds what it admits into Uadd.
+//     One GPU: Uread = the solve's used_cur, Uadd = D[r] (zeroed by k_resolve); the host folds used_cur + sum D into the
+//     committed vector when somebody needs it (k_used_fold).  Row-sharded solve: Uread = the snapshot of the global vector the
+//     exchange left (gprev), D = nullptr, Uadd = used_cur (what the next exchange exports).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ load, u32* __restrict__ next, Plan p,
-                                                        const u64* __restrict__ wsp_sum_in,
-                                                        const u64* __restrict__ wfC /* free by rank */, const u32* __restrict__ wfOrder,
-                                                        const u32* __restrict__ wfCnt, u64* __restrict__ used_cur,
-                                                        const u32* __restrict__ wsp_cnt_in,
-                                                        u64* __restrict__ wsp_sum_out, u32* __restrict__ wsp_cnt_out,
-                                                        int last, DevStats* __restrict__ stats,
-                                                        const u32* __restrict__ pk_idx, u32* __restrict__ real_next,
-                                                        const u64* __restrict__ rank_base,
-                                                        const u64* __restrict__ pending_global, FxRows fx,
-                                                        const u64* __restrict__ bsp_sum_in, const u32* __restrict__ bsp_cnt_in,
-                                                        u64* __restrict__ bsp_sum_out, u32* __restrict__ bsp_cnt_out) {
+
+struct FillArgs {
+    const u32* cur; const u32* load; const u32* aff; u32* next;   // the table (pass A; pass B too unless PACK)
+    const u32* alive_bits;
+    Plan p;
+    const u32* cutidx; const u32* forced_bits;                     // APPLY
+    const u64* cap; const u64* Uread; const u64* D; u64* Uadd; u32 round;   // FILL
+    const u64* wsp_sum_in; const u32* wsp_cnt_in; u64* wsp_sum_out; u32* wsp_cnt_out;
+    const u64* bsp_sum_in; const u32* bsp_cnt_in; u64* bsp_sum_out; u32* bsp_cnt_out;
+    const u64* R; const u64* RP; u32 ng;                           // APPLY && FILL: the cuts' rejected claim load (k_scan's comment)
+    int last;                                                      // 0 | 1 last round | 2 last round, NONE already in the real rows
+    DevStats* stats;
+    const u32* pk_idx; u32* real_next;                             // rows are packed: decisions also go to real_next[pk_idx[pos]]
+    const u64* rank_base; const u64* pending_global;               // row-sharded solve
+    FxRows fx;
+    PackOut pko;                                                   // PACK
+};
+
+// LDS layout of k_fill (bytes): [0,512) small | C[m+1] u64 | ord[m] u16 | X = max(adm[m] u64, thr[mr] u32 + alv + rings, class table)
+__host__ __device__ __forceinline__ size_t fill_lds_x(u32 m, u32 mwords, bool pack) {
+    const size_t a = (size_t)m * sizeof(u64);
+    const size_t b = (size_t)((m + 3) & ~3u) * sizeof(u32) + (size_t)((mwords + 3) & ~3u) * sizeof(u32) +
+                     (pack ? (size_t)kWaves * 2 * kStageCap * sizeof(u32) : 0);
+    const size_t c = rank_tab_bytes(m);
+    const size_t x = a > b ? a : b;
+    return ((x > c ? x : c) + 15) & ~(size_t)15;
+}
+__host__ __device__ __forceinline__ size_t fill_lds_off_ord(u32 m) { return 512 + (((size_t)(m + 1) * sizeof(u64) + 15) & ~(size_t)15); }
+__host__ __device__ __forceinline__ size_t fill_lds_off_x(u32 m) { return fill_lds_off_ord(m) + (((size_t)m * sizeof(unsigned short) + 15) & ~(size_t)15); }
+
+template <bool VIRT, bool APPLY, bool FILL, bool PACK>
+__global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Plan& p = a.p;
     const u32 m = p.m;
-    u64* red = reinterpret_cast<u64*>(smem);               // [4]
-    u64* part = reinterpret_cast<u64*>(smem + kSmall);     // [16] block-scan partials
-    u64* C = reinterpret_cast<u64*>(smem + 2 * kSmall);    // [m+1]
-    u64* adm = C + (m + 1);                                // [m] admitted load by node (this block)
-    unsigned short* ord = reinterpret_cast<unsigned short*>(adm + m);  // [m] node of rank k (a global read per placed row otherwise:
-                                                           //     four dependent ~1 us round trips per lane and tile)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row ranges in SGPRs
-    const int ktab = last ? 1 : 0;
-    constexpr u32 kKeepVal = 0xFFFFFFF0u;  // "no store for this row" among the values bound for the real column (no node id, not NONE)
-    RIOGP_KT(ktab, 0);
-    // Prologue: what is pending, and where does this workgroup's first wave start in the index-ordered spill prefix?
-    // Every global operand of the prologue is requested before the first one is used (one round trip, not three): the
-    // per-workgroup spill totals of the previous step (G words: k_scan / the cut pass / the previous round wrote them next
-    // to the per-wave ones), this workgroup's own 16 per-wave totals, the ranked free capacities and the rank order.
-    const u32 mpad = (m + kBlock - 1) / kBlock * kBlock, per = mpad / kBlock;  // per <= 8 (m <= 8 192)
-    // Loads retire in issue order, so the two words the ROW loads depend on go first (this wave's packed row count and its
-    // pending count), then the prologue's operands — all with clamped addresses instead of predicates, so that nothing
-    // waits on `cnt` or on a branch before it is requested — and then the wave's first tile of rows, whose round trip
-    // runs under the prologue instead of after it.
+    // red[16]: 0 spill load of the earlier blocks | 1 pending rows anywhere | 2 placed rows | 3 placed load | 4 remaining load |
+    //          5 remaining rows | 6 rejected rows | 7 rejected load | 8 nodes with room (u32)
+    u64* red = reinterpret_cast<u64*>(smem);                      // [16]
+    u64* part = reinterpret_cast<u64*>(smem + 128);               // [16] block-scan partials
+    u64* wsum = reinterpret_cast<u64*>(smem + 256);               // [16] spill load per wave of this block (after pass A)
+    u32* wcn = reinterpret_cast<u32*>(smem + 384);                // [16] pending rows per wave
+    u64* C = reinterpret_cast<u64*>(smem + 512);                  // [m+1]
+    unsigned short* ord = reinterpret_cast<unsigned short*>(smem + fill_lds_off_ord(m));  // [m] node of rank k
+    unsigned char* X = smem + fill_lds_off_x(m);
+    u64* adm = reinterpret_cast<u64*>(X);                         // [m] admitted load by node (pass B)
+    u32* thr = reinterpret_cast<u32*>(X);                         // [mr] first rejected row of a node's claimants (pass A)
+    u32* alv = thr + ((m + 3) & ~3u);                             // [mwords]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr u32 kKeepVal = 0xFFFFFFF0u;  // "no store for this row" among the values bound for the real column
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     const u32 G = p.G, w0 = blockIdx.x * kWaves;
-    const u32 wc = *(p.wcnt ? p.wcnt + gw : wsp_cnt_in + gw);
-    const u32 pc = wsp_cnt_in[gw];
-    const u32 cnt = *wfCnt;
-    const u64 pgv = pending_global ? *pending_global : 0ull;  // row-sharded solve: the exchange's verdict / the lower ranks' spill load
-    const u64 rbv = rank_base ? *rank_base : 0ull;
-    u64 fr[8];
-    u32 od[8];
+
+    constexpr int kt = APPLY ? 1 : 2;  // trace table (lab build)
+    RIOGP_KT(p, kt, 0);
+    // ---- prologue: every global operand is requested before the first one is used, with clamped addresses instead of
+    //      predicates (a load behind a branch turns every later wait into a wait for ALL loads)
+    const u32 wc = *(p.wcnt ? p.wcnt + gw : a.wsp_cnt_in + gw);
+    const u32 pc = a.wsp_cnt_in[gw];
+    const u64 ncut = a.stats->n_cut;
+    const u32 per = (m + kBlock - 1) / kBlock;  // <= 8
+    u32 tv[8];
+    u32 aw = 0;
+    const u32 ak = (u32)tid < p.mwords ? (u32)tid : p.mwords - 1;  // mwords <= 256 < kBlock
+    if (APPLY) {
 #pragma unroll
-    for (u32 q = 0; q < 8; ++q) { fr[q] = 0; od[q] = 0; }
-    {
-        const u32 k = tid * per, kk = k < m ? k : m - 1;
-        fr[0] = wfC[kk];
-        od[0] = wfOrder[kk];
+        for (u32 q = 0; q < 8; ++q) tv[q] = 0;
+        tv[0] = a.cutidx[(u32)tid < m ? (u32)tid : m - 1];
+        if (per > 1) {
+#pragma unroll
+            for (u32 q = 1; q < 8; ++q) {
+                const u32 j = tid + (q < per ? q : per - 1) * kBlock;
+                tv[q] = a.cutidx[j < m ? j : m - 1];
+            }
+        }
+        aw = a.alive_bits[ak];
     }
-    if (per > 1) {  // m > 1 024: q >= per re-reads the thread's last word (a hit in the vector cache): no per-word branch
+    // free capacity of this thread's nodes (tid, tid + 1024, ...): what the water-fill orders the nodes by
+    u64 fr[8];
+    u32 cnt = 0;
+    u64 pgv = 0, rbv = 0;
+    if (FILL) {
 #pragma unroll
-        for (u32 q = 1; q < 8; ++q) {
-            const u32 k = tid * per + (q < per ? q : per - 1), kk = k < m ? k : m - 1;
-            fr[q] = wfC[kk];
-            od[q] = wfOrder[kk];
+        for (u32 q = 0; q < 8; ++q) fr[q] = 0;
+        pgv = a.pending_global ? *a.pending_global : 0ull;
+        rbv = a.rank_base ? *a.rank_base : 0ull;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+            if (q < per) {  // (uniform)
+                const u32 j = tid + q * kBlock, jj = j < m ? j : m - 1;
+                u64 u = a.Uread[jj];
+                if (a.D)
+                    for (u32 r = 0; r < a.round; ++r) u += a.D[(size_t)r * m + jj];
+                const u64 c = a.cap[jj];
+                const bool al = bit_of(a.alive_bits, jj);
+                fr[q] = (j < m && al && c > u) ? c - u : 0ull;
+            }
         }
     }
     const u32 bt = (u32)tid < G ? (u32)tid : G - 1;
-    const u64 bv = bsp_sum_in[bt];
-    const u32 bc = bsp_cnt_in[bt];
-    const u64 pw = wsp_sum_in[w0 + (tid & (kWaves - 1))];
+    const u64 bv = a.bsp_sum_in[bt] + ((APPLY && FILL) ? a.R[bt] : 0ull);
+    // ... and, by node group, the claim load the cuts reject in the blocks before this one (column blockIdx.x of RP)
+    const u64 rpv = (APPLY && FILL) ? a.RP[(size_t)((u32)tid < a.ng ? (u32)tid : a.ng - 1) * G + blockIdx.x] : 0ull;
+    const u32 bc = a.bsp_cnt_in[bt];
+    const u64 pw = a.wsp_sum_in[w0 + (tid & (kWaves - 1))];
     u64 wstart = wave_row_lo(p, gw), wend = wave_row_lo(p, gw + 1);
     if (wend > p.n) wend = p.n;
     if (wstart > wend) wstart = wend;
-    if (p.wcnt && wstart + wc < wend) wend = wstart + wc;  // packed fix-up: only the first wcnt[gw] positions hold rows
-    if (pc == 0) wend = wstart;  // no pending row in this wave's range (later rounds: most waves)
-    const bool scat = pk_idx != nullptr;
-    // unconditional (a wave without rows reads tile 0 and ignores it): a load behind a branch would make every later
-    // wait a wait for ALL loads, the prologue's included
+    if (p.wcnt && wstart + wc < wend) wend = wstart + wc;  // packed rows: only the first wcnt[gw] positions hold rows
+    u64 bstart = wstart, bend = wend;                      // pass B's rows
+    if (FILL && !APPLY && pc == 0) bend = bstart;          // no pending row in this wave's range (later rounds: most waves)
+    // first tile of the wave's rows: pass A's columns (APPLY) or pass B's (FILL only)
     const u64 rs = (wstart < wend ? wstart : 0ull) + (u64)lane * 4;
-    uint4 nvn = *reinterpret_cast<const uint4*>(next + rs);
-    uint4 lvn = *reinterpret_cast<const uint4*>(load + rs);
-    uint4 ivn = *reinterpret_cast<const uint4*>((scat ? pk_idx : load) + rs);
-#pragma unroll
-    for (u32 q = 0; q < 8; ++q) {
-        const bool in = q < per && tid * per + q < cnt;
-        fr[q] = in ? fr[q] : 0ull;
-        od[q] = in ? od[q] : 0u;
+    uint4 cvn = make_uint4(0, 0, 0, 0), avn = cvn, lvn = cvn, nvn = cvn, ivn = cvn;
+    const bool scat = a.pk_idx != nullptr;
+    if (APPLY) {
+        cvn = *reinterpret_cast<const uint4*>(a.cur + rs);
+        avn = *reinterpret_cast<const uint4*>(a.aff + rs);
+        lvn = *reinterpret_cast<const uint4*>(a.load + rs);
+        // pass B's first tile of real-row indices (packed rows): a cold read, requested here instead of behind pass A
+        if (FILL && !PACK) ivn = *reinterpret_cast<const uint4*>((scat ? a.pk_idx : a.load) + rs);
+    } else {
+        const u64 rb = (bstart < bend ? bstart : 0ull) + (u64)lane * 4;
+        nvn = *reinterpret_cast<const uint4*>(a.next + rb);
+        lvn = *reinterpret_cast<const uint4*>(a.load + rb);
+        ivn = *reinterpret_cast<const uint4*>((scat ? a.pk_idx : a.load) + rb);
     }
-    u64 my_base;
-    {
-        u64 sb = ((u32)tid < G && (u32)tid < blockIdx.x) ? bv : 0ull;
-        u32 c = (u32)tid < G ? bc : 0u;
-        part[tid & (kWaves - 1)] = pw;  // staged for the in-block prefix below (every thread stores: a store behind a
-                                        // branch would pull the load in after it, and its wait with it)
-        sb = wave_sum(sb);
-        c = wave_sum32(c);
-        if (tid < 6) red[tid] = 0;
-        __syncthreads();
-        if (lane == 0 && (sb | c)) { atomicAdd(&red[0], sb); atomicAdd(&red[1], (u64)c); }
-        __syncthreads();
-        const bool pending = pending_global ? (pgv != 0) : (red[1] != 0);
-        if (!pending) {  // nothing pending anywhere: the round is a no-op
-            if (lane == 0) {
-                const u64 gw0 = (u64)blockIdx.x * kWaves + wave;
-                wsp_sum_out[gw0] = 0;
-                wsp_cnt_out[gw0] = 0;
-            }
-            if (tid == 0) { bsp_sum_out[blockIdx.x] = 0; bsp_cnt_out[blockIdx.x] = 0; }
-            if (last && fx.dev && fx.seq && tid < 8)  // the host may be spinning on this row
-                fx.host[(size_t)blockIdx.x * 8 + tid] = tid == 7 ? fx.seq : fx.dev[(size_t)blockIdx.x * 8 + tid];
+
+    // ---- is there anything to do?  (every fix-up launch may be speculative: enqueued behind a solve whose verdict
+    //      nobody has read yet)
+    if (APPLY && !FILL) {
+        if (!PACK && ncut == 0 && a.forced_bits == nullptr) return;  // no cut anywhere: k_scan's spill totals stand
+        if (PACK && ncut == 0 && a.forced_bits == nullptr && a.bsp_cnt_in[blockIdx.x] == 0) {
+            if (lane == 0) a.pko.wcnt[gw] = 0;
             return;
         }
-        if (!fx.dev && blockIdx.x == 0 && tid == 0) atomicAdd(&stats->rounds_run, 1ull);  // (fx rows: counted in the epilogue)
-        my_base = red[0] + rbv;  // row-sharded solve: the spill load of every lower rank comes first
-        for (int w = 0; w < wave; ++w) my_base += part[w];
-        __syncthreads();  // red / part are reused below
     }
-    RIOGP_KT(ktab, 1);
-    {   // C[0] = 0, C[k+1] = sat(C[k] + free of rank k): saturating block scan of the ranked free values
+    if (tid < 16) red[tid] = 0;
+    if (FILL)  // the class table of the node order (rank_by_class), zeroed ahead of a barrier that is needed anyway
+        for (u32 k = tid; k < (u32)(rank_tab_bytes(m) / 4); k += kBlock) reinterpret_cast<u32*>(X)[k] = 0;
+    __syncthreads();
+    u64 blk_base = 0;  // spill load of every earlier block
+    if (FILL) {
+        u64 sb = ((u32)tid < G && (u32)tid < blockIdx.x) ? bv : 0ull;
+        if (APPLY && (u32)tid < a.ng) sb += rpv;
+        u32 c = (u32)tid < G ? bc : 0u;
+        sb = wave_sum(sb);
+        c = wave_sum32(c);
+        if (lane == 0 && (sb | c)) { atomicAdd(&red[0], sb); atomicAdd(&red[1], (u64)c); }
+        __syncthreads();
+        const bool pending = a.pending_global ? (pgv != 0) : (red[1] != 0 || (APPLY && (ncut != 0 || a.forced_bits != nullptr)));
+        if (!pending) {  // nothing pending anywhere: the round is a no-op
+            if (lane == 0) {
+                a.wsp_sum_out[gw] = 0;
+                a.wsp_cnt_out[gw] = 0;
+                if (PACK) a.pko.wcnt[gw] = 0;
+            }
+            if (tid == 0) { a.bsp_sum_out[blockIdx.x] = 0; a.bsp_cnt_out[blockIdx.x] = 0; }
+            if (a.last && a.fx.dev && a.fx.seq && tid < 8)  // the host may be spinning on this row
+                a.fx.host[(size_t)blockIdx.x * 8 + tid] = tid == 7 ? a.fx.seq : a.fx.dev[(size_t)blockIdx.x * 8 + tid];
+            return;
+        }
+        if (!a.fx.dev && blockIdx.x == 0 && tid == 0) atomicAdd(&a.stats->rounds_run, 1ull);  // (fx rows: counted in the epilogue)
+        blk_base = red[0] + rbv;  // row-sharded solve: the spill load of every lower rank comes first
+        RIOGP_KT(p, kt, 1);
+    }
+
+    // ---- order of the nodes: C[0] = 0, C[k+1] = sat(C[k] + free of rank k), ord[k] = node of rank k
+    if (FILL) {
+        u32 rk[8];
+        cnt = rank_by_class(reinterpret_cast<unsigned short*>(X), per, fr, rk, p);
+        // free capacities to their ranks (C[k+1] holds the free capacity of rank k until the scan below), nodes to ord[]
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q)
+            if (q < per && fr[q] != 0) { C[rk[q] + 1] = fr[q]; ord[rk[q]] = (unsigned short)(tid + q * kBlock); }
+        __syncthreads();
+        RIOGP_KT(p, 4, 5);
+        u64 fk[8];
         u64 loc = 0;
 #pragma unroll
-        for (u32 q = 0; q < 8; ++q) loc = sat_add(loc, fr[q]);
-        u64 excl = block_excl_scan_1024(loc, true, part, nullptr);
+        for (u32 q = 0; q < 8; ++q) {
+            const u32 k = tid * per + q;
+            fk[q] = (q < per && k < cnt) ? C[k + 1] : 0ull;
+            loc = sat_add(loc, fk[q]);
+        }
+        u64 excl = block_excl_scan_1024(loc, true, part, nullptr);  // (barriers inside: every C[k+1] is read before it is rewritten)
+        RIOGP_KT(p, 4, 6);
         if (tid == 0) C[0] = 0;
 #pragma unroll
         for (u32 q = 0; q < 8; ++q) {
             const u32 k = tid * per + q;
-            excl = sat_add(excl, fr[q]);
-            if (q < per && k < m) { C[k + 1] = k < cnt ? excl : ~0ull; ord[k] = (unsigned short)od[q]; }
+            excl = sat_add(excl, fk[q]);
+            if (q < per && k < m) C[k + 1] = k < cnt ? excl : ~0ull;
         }
+        __syncthreads();  // C / ord complete; the class table in X is dead
+        RIOGP_KT(p, kt, 2);
+        RIOGP_KT(p, 4, 7);
     }
+
+    // ---- pass A: re-mark, spill totals, packing
+    if (APPLY) {
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+            const u32 j = tid + q * kBlock;
+            if (q < per && j < m) thr[j] = (a.forced_bits && bit_of(a.forced_bits, j)) ? 0u : tv[q];
+        }
+        alv[ak] = aw;  // threads past mwords rewrite the last word with its own value
+        __syncthreads();
+        u64 sp_sum = 0, rej_sum = 0;
+        u32 sp_cnt = 0, rej_cnt = 0;  // wave-uniform
+        u64 pk_pos = wstart;          // PACK: this wave's packed write cursor (wave-uniform)
+        u32* stage = PACK ? alv + ((p.mwords + 3) & ~3u) + (size_t)wave * 2 * kStageCap : nullptr;
+        u32 st_head = 0, st_fill = 0;
+        for (u64 it = wstart; it < wend; it += kTile) {
+            const u64 i0 = it + (u64)lane * 4;
+            const uint4 cv = cvn, av = avn, lv = lvn;
+            u32 pm = 0;  // PACK: which of the lane's four rows go on to the water-fill
+            const u64 pit = (it + kTile < wend ? it + kTile : it) + (u64)lane * 4;  // next tile in flight (the last re-reads its own)
+            cvn = *reinterpret_cast<const uint4*>(a.cur + pit);
+            avn = *reinterpret_cast<const uint4*>(a.aff + pit);
+            lvn = *reinterpret_cast<const uint4*>(a.load + pit);
+            // The rows' `next` values are rebuilt from the columns (what k_scan wrote: kept -> cur, claimant -> affinity,
+            // duplicate request -> skip mark, not an object -> NONE, the rest -> spill mark) with the rejected claimants turned
+            // into spill marks (PACK: every row that goes on to the water-fill into NONE, final unless a round places it
+            // through pk_idx), and a wave that changes anything writes its whole kilobyte back, every lane its 16 bytes.
+            uint4 ov;
+            bool chg = false;
+#define RIOGP_ROW(CC, A, L, O, E)                                                                    \
+            {                                                                                        \
+                const bool inr = i0 + E < wend;                                                      \
+                const bool cin = CC < m, ain = A < m;                                                \
+                const u32 cx = cin ? CC : 0u, ax = ain ? A : 0u;                                     \
+                const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                              \
+                const bool skip = VIRT && CC == kSkipMark;                                           \
+                const bool dead = !VIRT && A == kAffInactive;                                        \
+                const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                         \
+                const bool sp = inr & !kept & !skip & !cl & !dead;                                   \
+                const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                    \
+                const u32 mark = PACK ? kNone : kSpillMark;                                          \
+                O = kept ? CC : (cl ? (rej ? mark : A) : (skip ? kSkipMark : (dead ? kNone : mark))); \
+                if (PACK) pm |= (u32)(sp | rej) << E;                                                \
+                chg |= PACK ? (sp | rej) : rej;                                                      \
+                sp_sum += (sp | rej) ? (u64)L : 0ull;                                                \
+                rej_sum += rej ? (u64)L : 0ull;                                                      \
+                sp_cnt += (u32)__popcll(__ballot(sp | rej));                                         \
+                rej_cnt += (u32)__popcll(__ballot(rej));                                             \
+            }
+            RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
+            RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
+            RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
+            RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
+#undef RIOGP_ROW
+            if (__ballot(chg)) *reinterpret_cast<uint4*>(a.next + i0) = ov;
+            if (PACK) {  // index order = lane-major, then element; through this wave's LDS ring, 64 records per flush
+                const u64 b0 = __ballot(pm & 1u), b1 = __ballot(pm & 2u), b2 = __ballot(pm & 4u), b3 = __ballot(pm & 8u);
+                if (b0 | b1 | b2 | b3) {
+                    const u64 lt = (1ull << lane) - 1ull;
+                    u32 e = st_head + st_fill + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+#define RIOGP_PK(E, L)                                                                                     \
+                    if (pm & (1u << E)) {                                                                  \
+                        const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
+                        stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; ++e;                           \
+                    }
+                    RIOGP_PK(0, lv.x)
+                    RIOGP_PK(1, lv.y)
+                    RIOGP_PK(2, lv.z)
+                    RIOGP_PK(3, lv.w)
+#undef RIOGP_PK
+                    st_fill += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+                    __builtin_amdgcn_wave_barrier();
+                    while (st_fill >= 64u) {  // wave-uniform
+                        u32 x = st_head + (u32)lane;
+                        x = x >= kStageCap ? x - kStageCap : x;
+                        const u64 o = pk_pos + (u32)lane;
+                        a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = kSpillMark;
+                        st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
+                        st_fill -= 64u;
+                        pk_pos += 64u;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+        if (PACK && st_fill) {  // what is left in the ring (< 64 records)
+            u32 x = st_head + (u32)lane;
+            x = x >= kStageCap ? x - kStageCap : x;
+            if ((u32)lane < st_fill) {
+                const u64 o = pk_pos + (u32)lane;
+                a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = kSpillMark;
+            }
+            pk_pos += st_fill;
+        }
+        sp_sum = wave_sum(sp_sum);
+        rej_sum = wave_sum(rej_sum);
+        if (lane == 0) {
+            if (PACK) a.pko.wcnt[gw] = (u32)(pk_pos - wstart);
+            wsum[wave] = sp_sum;
+            wcn[wave] = sp_cnt;
+            if (rej_cnt) { atomicAdd(&red[6], (u64)rej_cnt); atomicAdd(&red[7], rej_sum); }
+        }
+        if (!FILL) {
+            if (lane == 0) {
+                a.wsp_sum_out[gw] = sp_sum;
+                a.wsp_cnt_out[gw] = sp_cnt;
+                if (sp_cnt) { atomicAdd(&red[4], sp_sum); atomicAdd(&red[5], (u64)sp_cnt); }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                fx_add_rejected(a.fx, a.stats, red[6], red[7]);
+                a.bsp_sum_out[blockIdx.x] = red[4];
+                a.bsp_cnt_out[blockIdx.x] = (u32)red[5];
+            }
+            return;
+        }
+        // pass B runs over what pass A left: the packed rows (PACK) or the same rows with their new marks
+        if (PACK) { bstart = wstart; bend = pk_pos; }
+        if (sp_cnt == 0) bend = bstart;
+        __syncthreads();  // wsum complete; thr / alv / rings are dead: the region becomes adm.  (Also orders this wave's
+                          // mark / pack stores before its own loads of the same rows below.)
+        const u64 rb = (bstart < bend ? bstart : 0ull) + (u64)lane * 4;
+        const u32* nsrc = PACK ? a.pko.next : a.next;
+        const u32* lsrc = PACK ? a.pko.load : a.load;
+        const u32* isrc = PACK ? a.pko.idx : (scat ? a.pk_idx : a.load);
+        nvn = *reinterpret_cast<const uint4*>(nsrc + rb);
+        lvn = *reinterpret_cast<const uint4*>(lsrc + rb);
+        if (PACK) ivn = *reinterpret_cast<const uint4*>(isrc + rb);  // (else: requested in the prologue, rb == rs)
+        RIOGP_KT(p, kt, 3);
+    } else if (FILL) {
+        if (tid < kWaves) wsum[tid] = pw;  // staged for the in-block prefix below
+    }
+    if (!FILL) return;
+
+    // ---- pass B: the water-fill round
+    const bool bscat = PACK || scat;
+    u32* const bnext = PACK ? a.pko.next : a.next;
+    const u32* const bload = PACK ? a.pko.load : a.load;
+    const u32* const bidx = PACK ? a.pko.idx : a.pk_idx;
     for (u32 k = tid; k < m; k += kBlock) adm[k] = 0;
-    if (tid < 6) red[tid] = 0;
     __syncthreads();
-    RIOGP_KT(ktab, 2);
+    RIOGP_KT(p, kt, 4);
+    u64 run = blk_base;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
     const u64 F = C[cnt];
-    u64 run = my_base;
     u64 rem_sum = 0, pl_sum = 0;
     u32 rem_cnt = 0, pl_cnt = 0;
     // Q only grows along a wave's rows, so the position in C[] is carried from tile to tile:
@@ -1901,41 +1899,34 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         }
         lo_run = lo;
     }
-    // packed fix-up: `next` is the packed decision column; every decision is also written straight into the real
-    // assignment column through pk_idx (k_pk_scatter's job, without its launch).  Every pending row gets its final
-    // value here: placed rows in the round that places them, the rest (NONE) in the last round.
-    for (u64 it = wstart; it < wend; it += kTile) {
+    const int last = a.last;
+    for (u64 it = bstart; it < bend; it += kTile) {
         const u64 i0 = it + (u64)lane * 4;
         const uint4 nv = nvn, lv = lvn, iv = ivn;
-        // next tile's marks and loads in flight while this one is processed (clamped: the last iteration re-reads
-        // its own tile).  Loads are fetched unconditionally: pending rows are spread over every 64 B segment anyway,
-        // and a dependent load after the mark test costs a full HBM latency per tile.
-        const u64 pit = it + kTile < wend ? it + kTile : it;
-        nvn = *reinterpret_cast<const uint4*>(next + pit + (u64)lane * 4);
-        lvn = *reinterpret_cast<const uint4*>(load + pit + (u64)lane * 4);
-        if (scat) ivn = *reinterpret_cast<const uint4*>(pk_idx + pit + (u64)lane * 4);
-        const bool mk0 = i0 + 0 < wend && nv.x == kSpillMark, mk1 = i0 + 1 < wend && nv.y == kSpillMark;
-        const bool mk2 = i0 + 2 < wend && nv.z == kSpillMark, mk3 = i0 + 3 < wend && nv.w == kSpillMark;
+        const u64 pit = it + kTile < bend ? it + kTile : it;  // next tile in flight (the last iteration re-reads its own)
+        nvn = *reinterpret_cast<const uint4*>(bnext + pit + (u64)lane * 4);
+        lvn = *reinterpret_cast<const uint4*>(bload + pit + (u64)lane * 4);
+        if (bscat) ivn = *reinterpret_cast<const uint4*>(bidx + pit + (u64)lane * 4);
+        const bool mk0 = i0 + 0 < bend && nv.x == kSpillMark, mk1 = i0 + 1 < bend && nv.y == kSpillMark;
+        const bool mk2 = i0 + 2 < bend && nv.z == kSpillMark, mk3 = i0 + 3 < bend && nv.w == kSpillMark;
         if (!__ballot(mk0 | mk1 | mk2 | mk3)) continue;  // wave-uniform: nothing to spill in this tile
         const u64 l0 = mk0 ? lv.x : 0, l1 = mk1 ? lv.y : 0;
         const u64 l2 = mk2 ? lv.z : 0, l3 = mk3 ? lv.w : 0;
         const u64 lsum = l0 + l1 + l2 + l3;
         if (cnt == 0 || run >= F) {
             // Nothing from here on can be placed: the prefix Q of every remaining row of this wave is >= run >= F, the total
-            // free capacity of this round (wave-uniform, and it stays true for the wave's later tiles).  The rows are only
-            // counted — no prefix scan, no bracket, no searches: a contended table sends ~1 M rows through both rounds this
-            // way, and they sit in the last tenth of the workgroups.
+            // free capacity of this round (wave-uniform, and it stays true for the wave's later tiles): the rows are only counted.
             rem_sum += lsum;
             rem_cnt += (u32)mk0 + (u32)mk1 + (u32)mk2 + (u32)mk3;
             if (last) {
                 uint4 ov = nv;
                 ov.x = mk0 ? kNone : ov.x; ov.y = mk1 ? kNone : ov.y; ov.z = mk2 ? kNone : ov.z; ov.w = mk3 ? kNone : ov.w;
-                *reinterpret_cast<uint4*>(next + i0) = ov;  // (every lane: whole lines; lanes without marks rewrite their values)
-                if (scat && last == 1) {
-                    if (mk0) real_next[iv.x] = kNone;
-                    if (mk1) real_next[iv.y] = kNone;
-                    if (mk2) real_next[iv.z] = kNone;
-                    if (mk3) real_next[iv.w] = kNone;
+                *reinterpret_cast<uint4*>(bnext + i0) = ov;  // (every lane: whole lines; lanes without marks rewrite their values)
+                if (bscat && last == 1) {
+                    if (mk0) a.real_next[iv.x] = kNone;
+                    if (mk1) a.real_next[iv.y] = kNone;
+                    if (mk2) a.real_next[iv.z] = kNone;
+                    if (mk3) a.real_next[iv.w] = kNone;
                 }
             }
             continue;
@@ -1945,7 +1936,7 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
         const u64 run_end = run + shfl64(inc, 63);
         // wave-uniform bracket [lo_run, hi_run] of this tile's Q range: gallop from the carried position
         u32 hi_run = lo_run;
-        if (cnt) {
+        {
             u32 step = 1;
             while (hi_run + step < cnt && C[hi_run + step] <= run_end) { hi_run += step; step <<= 1; }
             u32 top = hi_run + step < cnt ? hi_run + step : cnt;  // C[top] > run_end or top == cnt
@@ -1954,15 +1945,32 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                 if (C[mid] <= run_end) hi_run = mid; else top = mid;
             }
         }
-        if (it == wstart) RIOGP_KT(ktab, 6);
         uint4 ov = nv;  // the lane's four decisions leave as ONE 16-byte store (rows that stay pending keep their mark)
         uint4 wv = make_uint4(kKeepVal, kKeepVal, kKeepVal, kKeepVal);  // what goes into the real assignment column
+        if (hi_run == lo_run && run_end <= C[lo_run + 1]) {
+            // The whole tile lies inside ONE node's interval (a node's free capacity is thousands of rows wide: nearly every
+            // tile): every marked row fits entirely, no per-row search, one atomic for the tile's admitted load.
+            const u32 nd0 = (u32)ord[lo_run];
+            ov.x = mk0 ? nd0 : ov.x; ov.y = mk1 ? nd0 : ov.y; ov.z = mk2 ? nd0 : ov.z; ov.w = mk3 ? nd0 : ov.w;
+            pl_sum += lsum;
+            pl_cnt += (u32)mk0 + (u32)mk1 + (u32)mk2 + (u32)mk3;
+            if (lane == 0) atomicAdd(&adm[nd0], run_end - run);
+            *reinterpret_cast<uint4*>(bnext + i0) = ov;
+            if (bscat) {
+                if (mk0) a.real_next[iv.x] = nd0;
+                if (mk1) a.real_next[iv.y] = nd0;
+                if (mk2) a.real_next[iv.z] = nd0;
+                if (mk3) a.real_next[iv.w] = nd0;
+            }
+            run = run_end;
+            continue;
+        }
         u32 pn[4] = {kNone, kNone, kNone, kNone};  // node of the lane's placed rows and their loads: admitted after the row loop
         u64 pll[4] = {0, 0, 0, 0};
-#define RIOGP_ROW(MK, L, E, IDX, OUT, WOUT)                                       \
+#define RIOGP_ROW(MK, L, E, OUT, WOUT)                                            \
         if (MK) {                                                                 \
             u32 nd = kNone;                                                       \
-            if (cnt && Q < F) {                                                   \
+            if (Q < F) {                                                          \
                 u32 lo = lo_run, hi = hi_run + 1;                                 \
                 while (hi - lo > 1) {                                             \
                     const u32 mid = lo + ((hi - lo) >> 1);                        \
@@ -1984,15 +1992,14 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
             }                                                                     \
             Q += L;                                                               \
         }
-        RIOGP_ROW(mk0, l0, 0, iv.x, ov.x, wv.x)
-        RIOGP_ROW(mk1, l1, 1, iv.y, ov.y, wv.y)
-        RIOGP_ROW(mk2, l2, 2, iv.z, ov.z, wv.z)
-        RIOGP_ROW(mk3, l3, 3, iv.w, ov.w, wv.w)
+        RIOGP_ROW(mk0, l0, 0, ov.x, wv.x)
+        RIOGP_ROW(mk1, l1, 1, ov.y, wv.y)
+        RIOGP_ROW(mk2, l2, 2, ov.z, wv.z)
+        RIOGP_ROW(mk3, l3, 3, ov.w, wv.w)
 #undef RIOGP_ROW
         {   // Admitted load per node (adm[], LDS).  The rows of a tile mostly land on ONE node (a node's free capacity is
-            // thousands of rows wide): one ds_add_u64 per placed row is then 256 atomics on one address per tile, serialised
-            // in the one LDS pipe the 16 waves share — the water-fill of 9.4 M rows spent most of its 47 us there.  When
-            // every placed row of the tile has the same node the wave adds them up in registers (DPP) and issues ONE atomic.
+            // thousands of rows wide): when every placed row of the tile has the same node the wave adds them up in
+            // registers (DPP) and issues ONE atomic instead of up to 256 on one address.
             const u32 n0 = pn[0] != kNone ? pn[0] : pn[1] != kNone ? pn[1] : pn[2] != kNone ? pn[2] : pn[3];
             const u64 pmask = __ballot(n0 != kNone);
             if (pmask) {
@@ -2009,60 +2016,57 @@ __global__ __launch_bounds__(kBlock) void k_spill_apply(const u32* __restrict__ 
                 }
             }
         }
-        if ((ov.x != nv.x) | (ov.y != nv.y) | (ov.z != nv.z) | (ov.w != nv.w)) *reinterpret_cast<uint4*>(next + i0) = ov;
-        if (scat) {  // the decisions of the packed rows go to their REAL rows: scattered 4-byte stores (~1 M per churn tick; transposing
-                     // them through LDS so that neighbouring lanes write neighbouring rows was measured: no gain, the cost
-                     // is the ~300 k distinct lines at the memory side, not the number of requests)
-            if (wv.x != kKeepVal) real_next[iv.x] = wv.x;
-            if (wv.y != kKeepVal) real_next[iv.y] = wv.y;
-            if (wv.z != kKeepVal) real_next[iv.z] = wv.z;
-            if (wv.w != kKeepVal) real_next[iv.w] = wv.w;
+        if ((ov.x != nv.x) | (ov.y != nv.y) | (ov.z != nv.z) | (ov.w != nv.w)) *reinterpret_cast<uint4*>(bnext + i0) = ov;
+        if (bscat) {  // the decisions of the packed rows go to their REAL rows: scattered 4-byte stores
+            if (wv.x != kKeepVal) a.real_next[iv.x] = wv.x;
+            if (wv.y != kKeepVal) a.real_next[iv.y] = wv.y;
+            if (wv.z != kKeepVal) a.real_next[iv.z] = wv.z;
+            if (wv.w != kKeepVal) a.real_next[iv.w] = wv.w;
         }
-        if (it == wstart) RIOGP_KT(ktab, 7);
         run = run_end;
         lo_run = hi_run;
     }
-    RIOGP_KT(ktab, 3);
+    RIOGP_KT(p, kt, 5);
     rem_sum = wave_sum(rem_sum);
     rem_cnt = wave_sum32(rem_cnt);
     pl_sum = wave_sum(pl_sum);
     pl_cnt = wave_sum32(pl_cnt);
     if (lane == 0) {
-        wsp_sum_out[gw] = rem_sum;
-        wsp_cnt_out[gw] = rem_cnt;
-        if (pl_cnt) { atomicAdd(&red[0], (u64)pl_cnt); atomicAdd(&red[1], pl_sum); }
-        if (last && rem_cnt) { atomicAdd(&red[2], (u64)rem_cnt); atomicAdd(&red[3], rem_sum); }
+        a.wsp_sum_out[gw] = rem_sum;
+        a.wsp_cnt_out[gw] = rem_cnt;
+        if (pl_cnt) { atomicAdd(&red[2], (u64)pl_cnt); atomicAdd(&red[3], pl_sum); }
         if (rem_cnt) { atomicAdd(&red[4], rem_sum); atomicAdd(&red[5], (u64)rem_cnt); }
     }
     __syncthreads();
-    RIOGP_KT(ktab, 4);
-    if (tid == 0) { bsp_sum_out[blockIdx.x] = red[4]; bsp_cnt_out[blockIdx.x] = (u32)red[5]; }
+    RIOGP_KT(p, kt, 6);
+    if (tid == 0) { a.bsp_sum_out[blockIdx.x] = red[4]; a.bsp_cnt_out[blockIdx.x] = (u32)red[5]; }
     for (u32 k = tid; k < m; k += kBlock)
-        if (adm[k]) atomicAdd(&used_cur[k], adm[k]);  // integer sums: order-independent
-    if (fx.dev) {  // this workgroup's row of the fix-up counters, and its copy in the host's pinned slot: one round trip
+        if (adm[k]) atomicAdd(&a.Uadd[k], adm[k]);  // integer sums: order-independent
+    if (a.fx.dev) {  // this workgroup's row of the fix-up counters, and its copy in the host's pinned slot: one round trip
         if (tid < 8) {
-            u64* r = fx.dev + (size_t)blockIdx.x * 8;
-            const u64 add = tid == 2 ? red[0] : tid == 3 ? red[1] : tid == 4 ? red[2] : tid == 5 ? red[3]
+            u64* r = a.fx.dev + (size_t)blockIdx.x * 8;
+            const u64 add = tid == 0 ? red[6] : tid == 1 ? red[7] : tid == 2 ? red[2] : tid == 3 ? red[3]
+                          : (tid == 4 && last) ? red[5] : (tid == 5 && last) ? red[4]
                           : (tid == 6 && blockIdx.x == 0) ? 1ull : 0ull;  // [6] of row 0 = rounds run
-            const u64 v = (tid == 7 && last && fx.seq) ? fx.seq : r[tid] + add;  // [7] = the host's sequence number
+            const u64 v = (tid == 7 && last && a.fx.seq) ? a.fx.seq : r[tid] + add;  // [7] = the host's sequence number
             r[tid] = v;
-            fx.host[(size_t)blockIdx.x * 8 + tid] = v;
+            a.fx.host[(size_t)blockIdx.x * 8 + tid] = v;
         }
     } else if (tid == 0) {
-        if (red[0]) { atomicAdd(&stats->spilled, red[0]); atomicAdd(&stats->load_spilled, red[1]); }
-        if (red[2]) { atomicAdd(&stats->unplaced, red[2]); atomicAdd(&stats->load_unplaced, red[3]); }
+        if (APPLY && red[6]) { atomicAdd(&a.stats->rejected, red[6]); atomicAdd(&a.stats->load_rejected, red[7]); }
+        if (red[2]) { atomicAdd(&a.stats->spilled, red[2]); atomicAdd(&a.stats->load_spilled, red[3]); }
+        if (last && red[5]) { atomicAdd(&a.stats->unplaced, red[5]); atomicAdd(&a.stats->load_unplaced, red[4]); }
     }
-    RIOGP_KT(ktab, 5);
+    RIOGP_KT(p, kt, 7);
 }
 
-// packed fix-up: decisions of the packed rows back into the real assignment column
-__global__ __launch_bounds__(kBlock) void k_pk_scatter(Plan p, const u32* __restrict__ idx, const u32* __restrict__ pk_next,
-                                                       u32* __restrict__ next) {
-    const int lane = threadIdx.x & 63;
-    const u64 gw = (u64)blockIdx.x * kWaves + (threadIdx.x >> 6);
-    u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
-    for (u64 i = wstart + lane; i < wend; i += 64) next[idx[i]] = pk_next[i];
+// committed `used` = U0 + the rounds' admitted loads (see k_fill); D rows are left as they are (k_resolve zeroes them)
+__global__ void k_used_fold(u64* __restrict__ used, const u64* __restrict__ D, u32 m, u32 rounds) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    u64 u = used[j];
+    for (u32 r = 0; r < rounds; ++r) u += D[(size_t)r * m + j];
+    used[j] = u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3245,13 +3249,6 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
     return (unsigned)g;
 }
 
-int cut_trace_enable(int on) { g_trace_host = on; return 0; }
-int cut_trace_read(u64* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cut_trace), sizeof(u64) * kMaxBlocks * 8); }
-int ktrace_read(int table, u64* out) {
-    if (table < 0 || table >= kKtTables) return -1;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kt), sizeof(u64) * kMaxBlocks * 8, sizeof(u64) * kMaxBlocks * 8 * (size_t)table);
-}
-
 template <bool VIRT, bool AA, int TPI, int COMPACT = 0, bool NT = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
                           hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr) {
@@ -3260,22 +3257,19 @@ static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, cons
     if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
         hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
                               t.cur, t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
-                              b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
+                              b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);
     else
         hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
-                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
-}
-
-void launch_pk_scatter(const Plan& p, const PackOut& pk, u32* next, hipStream_t s) {
-    hipLaunchKernelGGL(k_pk_scatter, dim3(p.G), dim3(kBlock), 0, s, p, pk.idx, pk.next, next);
+                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx, b.bsp_sum[0],
+                           b.bsp_cnt[0], b.R, b.RP);
 }
 
 // Tiles per wave-iteration: 2 on the plain whole-table scan (measured +2.5 % over 1; 4 loses to its unpipelined tail),
 // 1 where the row body is heavier (packing) or the table is small (virtual table of place_pending).
 // Non-temporal streams once the four columns no longer fit the 256 MiB Infinity Cache.
 constexpr u64 kScanNtRows = (u64)20 << 20;  // 16 B/row * 20 Mi rows = 320 MiB of columns
-int g_scan_nt_mode = 0;  // 0 by size | 1 always | 2 never (rio_gp_debug_set_scan_nt, A/B runs)
-int g_scan_stage = 1;    // packing through LDS rings (0: straight from registers; rio_gp_debug_set_scan_nt bit 4, A/B runs)
+int g_scan_nt_mode = 0;  // 0 by size | 1 always | 2 never (lab builds: rio_gp_debug_set_scan_nt, A/B runs)
+int g_scan_stage = 1;    // packing through LDS rings (0: straight from registers; lab builds, A/B runs)
 void set_scan_nt(int mode) { g_scan_nt_mode = mode & 3; g_scan_stage = (mode & 16) ? 0 : 1; }
 
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
@@ -3312,21 +3306,28 @@ unsigned resolve_blocks(u32 m) {
 }
 
 void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
-                    hipEvent_t e0, hipEvent_t e1) {
+                    hipEvent_t e0, hipEvent_t e1, const PackOut* search, u64* fold_into, u32 fold_rounds) {
     const unsigned grid = resolve_blocks(p.m);
-    if (e0 && e1)
-        hipExtLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, s, e0, e1, 0, b.H, b.blkstat, p, nt.cap,
-                              nt.alive_bits, nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx,
-                              b.partial, host_partial, b.budget, b.admpre, b.stats);
-    else
-        hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, s, b.H, b.blkstat, p, nt.cap, nt.alive_bits,
-                           nt.used_base, b.used_kept, b.used_cur, b.claim_tot, b.cutblk, b.cutidx, b.partial,
-                           host_partial, b.budget, b.admpre, b.stats);
+    ResolveArgs a;
+    a.H = b.H; a.blkstat = b.blkstat; a.p = p;
+    a.cap = nt.cap; a.alive_bits = nt.alive_bits; a.used_base = nt.used_base;
+    a.used_kept = b.used_kept; a.used_cur = b.used_cur; a.claim_tot = b.claim_tot; a.cutblk = b.cutblk; a.cutidx = b.cutidx;
+    a.partial = b.partial; a.host_partial = host_partial; a.budget = b.budget; a.admpre = b.admpre; a.stats = b.stats;
+    a.RP = b.RP; a.D = b.D; a.fold_into = b.D ? fold_into : nullptr; a.fold_rounds = fold_rounds;
+    a.pk_aff = search ? search->aff : nullptr; a.pk_load = search ? search->load : nullptr;
+    const bool srch = search != nullptr && p.wcnt != nullptr;
+    if (e0 && e1) {
+        if (srch) hipExtLaunchKernelGGL(k_resolve<true>, dim3(grid), dim3(kBlock), 0, s, e0, e1, 0, a);
+        else hipExtLaunchKernelGGL(k_resolve<false>, dim3(grid), dim3(256), 0, s, e0, e1, 0, a);
+    } else {
+        if (srch) hipLaunchKernelGGL(k_resolve<true>, dim3(grid), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL(k_resolve<false>, dim3(grid), dim3(256), 0, s, a);
+    }
 }
 
-// dynamic LDS of k_cut_fused: the fixed tables + as many u64 words of T region as fit (T rows [K][S|1] + 3 state words
+// dynamic LDS of k_cut_find: the fixed tables + as many u64 words of T region as fit (T rows [K][S|1] + 3 state words
 // per node of a group; every local node in one group at the finest fan-out needs m * ((255|1) + 3) words)
-size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
+static size_t cut_find_lds(const Plan& p, u32* tcap_out) {
     const size_t fixed = cut_fused_fixed(p.m, p.mwords);
     size_t slots = (150 * 1024 - fixed) / sizeof(u64);
     const size_t most = (size_t)p.m * 259;
@@ -3336,96 +3337,73 @@ size_t cut_fused_lds(const Plan& p, u32* tcap_out) {
     return fixed + slots * sizeof(u64);
 }
 
-// impl 2 (default): k_cut_find (the searches, spread over the chip) + k_cut_apply_rank (re-marking + the ranking of
-// water-fill round 0 when with_rank) | 1: one fused launch per solve, k_cut_fused | 0: the first, unfused chain — T memset,
-// k_cutblk, k_cut_subhist, k_cut_exact, (k_shard_force,) k_apply_cut.  All three are kept: the parity tests drive the same
-// inputs through each and compare bytes.  Returns true when the ranking of round 0 was part of these launches.
-bool launch_cut_fixup(const Plan& p_in, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt,
-                      hipStream_t s, int impl, bool have_cutblk, bool with_rank, const PackOut* pack) {
-    Plan p = p_in;
-    p.trace = (u32)g_trace_host;
+// The exact cut search as a launch of its own: k_cut_find, spread over the chip (whole-table solves, the virtual table of
+// place_pending, the row-sharded solve; the packed fix-up searches inside k_resolve).  have_cutblk: launch_resolve of the
+// same solve (same bufs) has already located the cut blocks; else k_cutblk does (row-sharded path: the global resolve
+// changed the free capacities after the local sums).  Guards itself on the device (stats->n_cut): cheap to enqueue
+// speculatively behind a solve whose verdict the host has not read yet.
+void launch_cut_find(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, hipStream_t s,
+                     bool have_cutblk) {
     const unsigned gcb = (p.m + kCbNodes - 1) / kCbNodes;
-    if (impl >= 1) {
-        if (!have_cutblk)  // k_resolve of this solve has already located the cut blocks (not on the row-sharded path)
-            hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
-                               b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
-        u32 tcap = 0;
-        const size_t ldsf = cut_fused_lds(p, &tcap);
-        if (impl == 2) {
-            const unsigned gfind = kCutFindGrid;
-            const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
-            const size_t lds_rank = 2 * kSmall + 256 + (size_t)mp * sizeof(u64);
-            const size_t lds_apply = kSmall + ((size_t)((p.m + 3) & ~3u) + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16 +
-                                     (pack ? (size_t)kWaves * 2 * kStageCap * sizeof(u32) : 0);
-            const unsigned grank = with_rank ? ((p.m + kRankNodes - 1) / kRankNodes ? (p.m + kRankNodes - 1) / kRankNodes : 1) : 0;
-            const size_t lds2 = (with_rank && lds_rank > lds_apply) ? lds_rank : lds_apply;
-            if (virt) {
-                auto kfn = p.trace ? k_cut_find<true, true> : k_cut_find<true, false>;
-                hipLaunchKernelGGL(kfn, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
-                                   b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
-                hipLaunchKernelGGL(k_cut_apply_rank<true>, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
-                                   nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0], PackOut{});
-            } else {
-                auto kfn = p.trace ? k_cut_find<false, true> : k_cut_find<false, false>;
-                hipLaunchKernelGGL(kfn, dim3(gfind), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
-                                   b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap);
-                auto kap = pack ? k_cut_apply_rank<false, true> : k_cut_apply_rank<false, false>;
-                hipLaunchKernelGGL(kap, dim3(p.G + grank), dim3(kBlock), lds2, s, t.cur, t.load, t.aff, t.next,
-                                   nt.alive_bits, p, b.cutidx, b.forced_bits, b.wsp_sum[0], b.wsp_cnt[0], b.stats, nt.cap,
-                                   b.used_cur, b.wfC, b.wfOrder, b.wfCnt, b.fx, b.bsp_sum[0], b.bsp_cnt[0], pack ? *pack : PackOut{});
-            }
-            return with_rank;
-        }
-        auto kfn = virt ? (p.trace ? k_cut_fused<true, true> : k_cut_fused<true, false>)
-                        : (p.trace ? k_cut_fused<false, true> : k_cut_fused<false, false>);
-        hipLaunchKernelGGL(kfn, dim3(p.G), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx,
-                           b.used_cur, b.wsp_sum[0], b.wsp_cnt[0], b.stats, tcap, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
-        return false;
-    }
-    (void)hipMemsetAsync(b.T, 0, (size_t)p.m * kMaxSubs * sizeof(u64), s);
-    hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
-                       b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
-    const size_t lds = kSmall + ((size_t)p.m + ((p.mwords + 3) & ~3u)) * sizeof(u32) + 16;
-    const unsigned g4 = (p.m + 3) / 4;
-    if (virt) {
-        hipLaunchKernelGGL(k_cut_subhist<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, nt.alive_bits, p,
-                           b.cutblk, b.T);
-        hipLaunchKernelGGL(k_cut_exact<true>, dim3(g4), dim3(256), 0, s, t.cur, t.load, t.aff, nt.alive_bits, p,
-                           b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
-        if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
-        hipLaunchKernelGGL(k_apply_cut<true>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
-    } else {
-        hipLaunchKernelGGL(k_cut_subhist<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, nt.alive_bits,
-                           p, b.cutblk, b.T);
-        hipLaunchKernelGGL(k_cut_exact<false>, dim3(g4), dim3(256), 0, s, t.cur, t.load, t.aff, nt.alive_bits, p,
-                           b.cutblk, b.budget, b.admpre, b.T, b.used_kept, b.cutidx, b.used_cur);
-        if (b.forced_bits) hipLaunchKernelGGL(k_shard_force, dim3(1), dim3(kBlock), 0, s, p.m, b.forced_bits, b.used_kept, b.cutidx, b.used_cur);
-        hipLaunchKernelGGL(k_apply_cut<false>, dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff, t.next,
-                           nt.alive_bits, p, b.cutidx, b.wsp_sum[0], b.wsp_cnt[0], b.stats, b.fx, b.bsp_sum[0], b.bsp_cnt[0]);
-    }
-    return false;
+    if (!have_cutblk)
+        hipLaunchKernelGGL(k_cutblk, dim3(gcb ? gcb : 1), dim3(256), 0, s, b.H, p, nt.cap, nt.alive_bits, b.used_kept,
+                           b.claim_tot, b.cutblk, b.budget, b.admpre, b.stats);
+    u32 tcap = 0;
+    const size_t ldsf = cut_find_lds(p, &tcap);
+    u64* R = have_cutblk ? b.R : nullptr;  // (k_cutblk does not maintain R: the row-sharded path does not use it)
+    if (virt)
+        hipLaunchKernelGGL(k_cut_find<true>, dim3(kCutFindGrid), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                           b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap, R);
+    else
+        hipLaunchKernelGGL(k_cut_find<false>, dim3(kCutFindGrid), dim3(kBlock), ldsf, s, t.cur, t.load, t.aff, nt.alive_bits, p,
+                           b.cutblk, b.budget, b.admpre, b.used_kept, b.forced_bits, b.cutidx, b.used_cur, b.stats, tcap, R);
 }
 
-// rank_done: the ranking of this round has already been enqueued (k_cut_apply_rank)
-void launch_spill_round(const Plan& p_in, const Table& t, const NodeTab& nt, const SolveBufs& b, int round, bool last,
-                        hipStream_t s, bool rank_done) {
-    Plan p = p_in;
-    p.trace = (u32)g_trace_host;
-    const int in = round & 1, out = in ^ 1;
-    const u32 mp = (p.m + kBlock - 1) / kBlock * kBlock;
-    const size_t lds_prep = 2 * kSmall + 256 + (size_t)mp * sizeof(u64);
-    const unsigned grank = (p.m + kRankNodes - 1) / kRankNodes;
-    if (!rank_done)
-        hipLaunchKernelGGL(k_spill_rank, dim3(grank ? grank : 1), dim3(kBlock), lds_prep, s, p, nt.cap, nt.alive_bits, b.used_cur,
-                           b.wfC, b.wfOrder, b.wfCnt);
-    const size_t lds_apply = 2 * kSmall + ((size_t)(p.m + 1) + p.m) * sizeof(u64) + (size_t)p.m * sizeof(unsigned short) + 16;
-    hipLaunchKernelGGL(k_spill_apply, dim3(p.G), dim3(kBlock), lds_apply, s, t.load, t.next, p, b.wsp_sum[in], b.wfC,
-                       b.wfOrder, b.wfCnt, b.used_cur, b.wsp_cnt[in], b.wsp_sum[out], b.wsp_cnt[out],
-                       last ? (t.none_prewritten ? 2 : 1) : 0, b.stats,
-                       t.pk_idx, t.real_next, b.rank_base, b.pending_global, b.fx, b.bsp_sum[in], b.bsp_cnt[in], b.bsp_sum[out], b.bsp_cnt[out]);
+static size_t fill_lds_bytes(u32 m, u32 mwords, bool pack) { return fill_lds_off_x(m) + fill_lds_x(m, mwords, pack) + 16; }
+bool fill_can_pack(u32 m) { return fill_lds_bytes(m, (m + 31) / 32, true) <= (size_t)160 * 1024; }
+
+// One launch of k_fill:
+//   apply && fill   round 0 of a solve: re-mark + (pack) + water-fill
+//   fill            a later round
+//   apply           the row-sharded solve's cut step (the Y exchange sits between it and the rounds)
+// The round orders the nodes by used_cur + D[0..round) and adds what it admits into D[round] — or, row-sharded solve
+// (b.used_snap set, b.D == nullptr), orders them by the snapshot and adds into used_cur.
+void launch_fill(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool apply, bool fill,
+                 int round, bool last, hipStream_t s, const PackOut* pack) {
+    const int in = (apply ? 0 : (round & 1)), out = fill ? (in ^ 1) : 0;
+    FillArgs a;
+    a.cur = t.cur; a.load = t.load; a.aff = t.aff; a.next = t.next;
+    a.alive_bits = nt.alive_bits;
+    a.p = p;
+    a.cutidx = b.cutidx; a.forced_bits = b.forced_bits;
+    a.cap = nt.cap; a.round = (u32)round;
+    if (b.D) { a.Uread = b.used_cur; a.D = b.D; a.Uadd = b.D + (size_t)round * p.m; }
+    else { a.Uread = b.used_snap ? b.used_snap : b.used_cur; a.D = nullptr; a.Uadd = b.used_cur; }
+    a.wsp_sum_in = b.wsp_sum[in]; a.wsp_cnt_in = b.wsp_cnt[in]; a.wsp_sum_out = b.wsp_sum[out]; a.wsp_cnt_out = b.wsp_cnt[out];
+    a.bsp_sum_in = b.bsp_sum[in]; a.bsp_cnt_in = b.bsp_cnt[in]; a.bsp_sum_out = b.bsp_sum[out]; a.bsp_cnt_out = b.bsp_cnt[out];
+    a.R = b.R; a.RP = b.RP; a.ng = resolve_blocks(p.m);
+    a.last = last ? ((t.none_prewritten || pack) ? 2 : 1) : 0;
+    a.stats = b.stats;
+    a.pk_idx = t.pk_idx; a.real_next = pack ? t.next : t.real_next;
+    a.rank_base = b.rank_base; a.pending_global = b.pending_global;
+    a.fx = b.fx;
+    a.pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t lds = fill_lds_bytes(p.m, p.mwords, pack != nullptr);
+    if (apply && fill) {
+        if (virt) hipLaunchKernelGGL((k_fill<true, true, true, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+        else if (pack) hipLaunchKernelGGL((k_fill<false, true, true, true>), dim3(p.G), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_fill<false, true, true, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+    } else if (fill) {
+        hipLaunchKernelGGL((k_fill<false, false, true, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+    } else {
+        if (virt) hipLaunchKernelGGL((k_fill<true, true, false, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_fill<false, true, false, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+    }
+}
+
+void launch_used_fold(u64* used, const u64* D, u32 m, u32 rounds, hipStream_t s) {
+    if (!m) return;
+    hipLaunchKernelGGL(k_used_fold, dim3((m + 255) / 256), dim3(256), 0, s, used, D, m, rounds);
 }
 
 void launch_lookup(const u32* assign, u64 n_obj, const u32* idx, u64 n, u32* out, DevStats* st, hipStream_t s, u32* done,

@@ -18,7 +18,9 @@
 #include <vector>
 
 #include "../../include/rio_gpu_placement.h"
+#ifdef RIO_GP_LAB
 #include "../../include/rio_gpu_placement_debug.h"
+#endif
 #include "placement_kernels.h"
 
 using namespace riogp;
@@ -111,6 +113,12 @@ struct rio_gp {
     uint8_t* alive_bytes = nullptr;
     std::vector<uint8_t> h_alive;
     bool used_valid = true;
+    // water-fill rounds keep what they admit apart from the solve's `used` vector (SolveBufs::D): the committed vector is
+    // h->used + the first parts_rounds rows of D until somebody folds them in (the next solve's k_resolve, or fold_used)
+    u64* D = nullptr;
+    bool used_parts = false;
+    u32 parts_rounds = 0;
+    bool solve_used_D = false;  // the solve waiting for its commit ran with sb.D set
     // solve scratch
     SolveBufs sb{};
     DevStats* dstats = nullptr;
@@ -155,8 +163,6 @@ struct rio_gp {
     int cutpack_mode = 0;  // the same for packing at the cut pass of whole-table solves (bits 5-6 of rio_gp_debug_set_compact)
     u64 last_fix_rows = 0;  // rows the previous solve sent to the water-fill (spill candidates + rejected claimants)
     bool last_fix_valid = false;
-    int fixup_mode = 2;    // cut fix-up: 2 split launches (k_cut_find + k_cut_apply_rank) | 1 one fused launch | 0 the unfused
-                           // chain; >= 1 also folds the packed scatter into the water-fill (rio_gp_debug_set_fixup)
     int spec_mode = 0;     // speculative fix-up enqueue: 0 auto (after a solve that needed it) | 1 always | 2 never
     int part_mode = 0;     // partitioned CRUD batches: 0 when the batch qualifies | 2 never (rio_gp_debug_set_compact bit 4)
     bool last_slow = false;
@@ -276,16 +282,15 @@ u32* aff_life(rio_gp* h) { return h->lifecycle ? h->aff : nullptr; }
 Table real_table(rio_gp* h) { return Table{h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1]}; }
 NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; }
 
-// the cut / spill fix-up of a solve whose fast path said it needs one
-// cutpack (whole-table solves of the real table, split cut fix-up, >= 1 round, a cut to apply): the pass that re-marks the
-// rejected claimants also packs every row that goes on to the water-fill, and the rounds run over those rows only.
-void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, const DevStats& verdict,
-                  bool cutpack = false) {
-    // every caller ran launch_resolve over h->sb for this solve: the cut blocks are already located
-    bool rank0 = false;
-    cutpack = cutpack && !virt && verdict.n_cut > 0 && h->fixup_mode == 2 && h->rounds >= 1 && !p.wcnt;
-    if (verdict.n_cut > 0)
-        rank0 = launch_cut_fixup(p, t, nt, h->sb, virt, h->stream, h->fixup_mode, true, h->rounds >= 1, cutpack ? &h->pk : nullptr);
+// The fix-up of a solve whose fast path said it needs one (or may need one: every kernel here guards itself on the
+// device, so the sequence can be enqueued before the host has read the verdict):
+//   the exact cut search — k_cut_find, unless launch_resolve already searched (packed pending rows: `searched`);
+//   round 0 = k_fill<APPLY, FILL> (re-mark + water-fill; cutpack: it also packs the rows that go on to the water-fill, and
+//   the later rounds run over those rows only); rounds 1.. = k_fill<FILL>.
+void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, bool searched, bool cutpack = false) {
+    cutpack = cutpack && !virt && !p.wcnt && h->rounds >= 1 && fill_can_pack(p.m);
+    if (!searched) launch_cut_find(p, t, nt, h->sb, virt, h->stream, true);
+    launch_fill(p, t, nt, h->sb, virt, true, true, 0, h->rounds == 1, h->stream, cutpack ? &h->pk : nullptr);
     if (cutpack) {
         Plan pp = p;
         pp.wcnt = h->pk.wcnt;
@@ -293,12 +298,30 @@ void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, b
         vt.pk_idx = h->pk.idx;
         vt.real_next = t.next;
         vt.none_prewritten = true;
-        for (u32 r = 0; r < h->rounds; ++r)
-            launch_spill_round(pp, vt, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream, r == 0 && rank0);
+        for (u32 r = 1; r < h->rounds; ++r) launch_fill(pp, vt, nt, h->sb, true, false, true, (int)r, r + 1 == h->rounds, h->stream);
         return;
     }
-    for (u32 r = 0; r < h->rounds; ++r)
-        launch_spill_round(p, t, nt, h->sb, (int)r, r + 1 == h->rounds, h->stream, r == 0 && rank0);
+    for (u32 r = 1; r < h->rounds; ++r) launch_fill(p, t, nt, h->sb, virt, false, true, (int)r, r + 1 == h->rounds, h->stream);
+}
+
+// committed `used` = h->used + the D rows of the last committed solve, until they are folded in: by the next solve's
+// k_resolve (for free), or here when somebody needs the vector first
+void fold_used(rio_gp* h) {
+    if (!h->used_parts) return;
+    launch_used_fold(h->used, h->D, h->m, h->parts_rounds, h->stream);
+    h->used_parts = false;
+}
+// scan + resolve of one solve over the REAL table: the packed pending rows' cuts are searched inside k_resolve, the previous
+// committed solve's D rows are folded into the committed vector before k_resolve zeroes them
+void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool compact, u64* host_rows) {
+    h->sb.D = h->D;
+    h->solve_used_D = h->sb.D != nullptr;
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
+    Plan rp = h->plan;
+    if (compact) rp.wcnt = h->pk.wcnt;
+    launch_resolve(rp, nt, h->sb, host_rows, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr,
+                   h->used_parts ? h->used : nullptr, h->parts_rounds);
+    h->used_parts = false;
 }
 
 u64* slot_dev(rio_gp* h, u32 k) { return h->d_slots + (size_t)(k % kRing) * h->slot_rows * 8; }
@@ -366,6 +389,8 @@ int commit_enqueue(rio_gp* h) {
     h->cur ^= 1;
     std::swap(h->used, h->sb.used_cur);  // publication = two pointer swaps: the solve's `used` vector becomes the committed one
     h->used_valid = true;
+    h->used_parts = h->solve_used_D;     // ... plus what its water-fill rounds admitted (D rows), folded in later
+    h->parts_rounds = h->rounds;
     h->have_solved = false;
     return RIO_GP_OK;
 }
@@ -380,7 +405,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     const u64 seq = ++h->wait_seq;
     h->plan.mark = seq;  // k_resolve's partial rows carry it ...
     // ... and so do the counter rows of the last water-fill round, when that round is the solve's last kernel
-    const bool fx_last = h->fixup_mode >= 1 && h->rounds >= 1;
+    const bool fx_last = h->rounds >= 1;
     if (fx_last) h->sb.fx.seq = seq;
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
@@ -391,16 +416,15 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
                          (h->compact_mode == 0 && h->last_pending_valid && h->last_pending * 4 <= h->n && h->n >= 65536);
     // Speculative fix-up: when the previous solve needed the fix-up (a churn stream needs it every tick), its kernels
     // are enqueued right behind k_resolve instead of after a host round trip for the verdict.  Every fix-up kernel
-    // guards itself on device (k_cut_fused: stats->n_cut; the water-fill rounds: pending-row count), so a solve that
+    // guards itself on device (the cut search: stats->n_cut; the water-fill rounds: pending-row count), so a solve that
     // turns out not to need them pays a few no-op launches and gets the same result.
-    const bool spec = h->fixup_mode >= 1 && h->spec_mode != 2 && (h->spec_mode == 1 || h->last_slow);
+    const bool spec = h->spec_mode != 2 && (h->spec_mode == 1 || h->last_slow);
     // Packing at the cut pass: a whole-table solve (nothing known to be kept) whose previous solve sent few rows to the
-    // water-fill — a contended table re-solved: ~10 % of the rows — lets k_cut_apply_rank pack those rows, and both
-    // water-fill rounds run over them instead of streaming the table twice more.  Results identical.
+    // water-fill — a contended table re-solved: ~10 % of the rows — lets round 0 of k_fill pack those rows on its way, and
+    // the later rounds run over them instead of streaming the table again.  Results identical.
     const bool cutpack = !compact && (h->cutpack_mode == 1 ||
                                       (h->cutpack_mode == 0 && h->last_fix_valid && h->last_fix_rows * 4 <= h->n && h->n >= 65536));
-    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
-    launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream);
+    enqueue_scan_resolve(h, t, nt, compact, slot_dev(h, 0));
     DevStats v;
     bool slow = false;
     const u64* vrows = h->h_slots;  // slot 0 of the solve ring
@@ -410,20 +434,15 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
         slow = v.n_cut > 0 || v.spillcand > 0;
     }
     if (spec || slow) {
-        DevStats all;  // speculative: run both halves, they guard themselves
-        memset(&all, 0, sizeof all);
-        all.n_cut = 1;
-        const DevStats& what = spec ? all : v;
         if (compact) {
             Plan pp = h->plan;
             pp.wcnt = h->pk.wcnt;
             Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
-            const bool fused_scatter = h->fixup_mode >= 1 && h->rounds >= 1;  // the water-fill writes through pk.idx itself
-            if (fused_scatter) { vt.pk_idx = h->pk.idx; vt.real_next = t.next; }
-            enqueue_slow(h, pp, vt, nt, true, what);
-            if (!fused_scatter) launch_pk_scatter(pp, h->pk, t.next, h->stream);
+            vt.pk_idx = h->pk.idx;  // the water-fill writes every decision through pk.idx into the real column itself
+            vt.real_next = t.next;
+            enqueue_slow(h, pp, vt, nt, true, true);
         } else {
-            enqueue_slow(h, h->plan, t, nt, false, what, cutpack);
+            enqueue_slow(h, h->plan, t, nt, false, false, cutpack);
         }
     }
     h->have_solved = true;
@@ -488,26 +507,17 @@ int tick_async_locked(rio_gp* h) {
     const u32 k = h->tick_n;
     use_fx_slot(h, 1 + k);
     h->tick_G[k] = h->plan.G;
-    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
-    launch_resolve(h->plan, nt, h->sb, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, h->stream);
-    DevStats all;
-    memset(&all, 0, sizeof all);
-    all.n_cut = 1;
-    const int impl = h->fixup_mode >= 1 ? h->fixup_mode : 2;  // the unfused chain has no device-side guards: not speculative
-    const int saved = h->fixup_mode;
-    h->fixup_mode = impl;
+    enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8);
     if (compact) {
         Plan pp = h->plan;
         pp.wcnt = h->pk.wcnt;
         Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
-        const bool fused_scatter = h->rounds >= 1;
-        if (fused_scatter) { vt.pk_idx = h->pk.idx; vt.real_next = t.next; }
-        enqueue_slow(h, pp, vt, nt, true, all);
-        if (!fused_scatter) launch_pk_scatter(pp, h->pk, t.next, h->stream);
+        vt.pk_idx = h->pk.idx;
+        vt.real_next = t.next;
+        enqueue_slow(h, pp, vt, nt, true, true);
     } else {
-        enqueue_slow(h, h->plan, t, nt, false, all);
+        enqueue_slow(h, h->plan, t, nt, false, false);
     }
-    h->fixup_mode = saved;
     h->have_solved = true;
     int rc = commit_enqueue(h);
     if (rc) return rc;
@@ -550,7 +560,8 @@ int small_wait(rio_gp* h, u32 seq) {
 }
 
 int ensure_used(rio_gp* h) {
-    if (h->used_valid) return RIO_GP_OK;
+    if (h->used_valid) { fold_used(h); return RIO_GP_OK; }
+    h->used_parts = false;  // rebuilt from the assignment column: nothing to fold
     launch_recompute_used(h->assign[h->cur], h->load, h->n, h->m, h->used, h->stream);
     h->used_valid = true;
     return RIO_GP_OK;
@@ -608,6 +619,11 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     h->cap_rows = ((cfg->max_objects + kTile - 1) / kTile) * kTile + 8 * kTile;  // k_scan prefetches past the end
     h->cap_nodes = cfg->max_nodes ? cfg->max_nodes : 1;
     h->rounds = cfg->spill_rounds ? cfg->spill_rounds : 2;
+    if (h->rounds > kFillRounds) {
+        g_create_error = "rio_gp_create: spill_rounds above the solver limit (8)";
+        delete h;
+        return RIO_GP_EINVAL;
+    }
     int rc = RIO_GP_OK;
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -630,8 +646,8 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
     A(h->sb.bsp_sum[0], (size_t)kMaxBlocks); A(h->sb.bsp_sum[1], (size_t)kMaxBlocks); A(h->sb.bsp_cnt[0], (size_t)kMaxBlocks); A(h->sb.bsp_cnt[1], (size_t)kMaxBlocks);
     A(h->sb.used_kept, M); A(h->sb.used_cur, M); A(h->sb.claim_tot, M); A(h->sb.cutblk, M); A(h->sb.budget, M);
-    A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->sb.T, M * kMaxSubs); A(h->sb.wfC, M + 1); A(h->sb.wfOrder, M);
-    A(h->sb.wfCnt, 4); A(h->dstats, 1); A(h->fx_dev, (size_t)kMaxBlocks * 8);
+    A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->dstats, 1); A(h->fx_dev, (size_t)kMaxBlocks * 8);
+    A(h->sb.R, (size_t)kMaxBlocks); A(h->sb.RP, (size_t)kMaxBlocks * resolve_blocks((u32)M)); A(h->D, (size_t)kFillRounds * M);
     A(h->pk.idx, R); A(h->pk.load, R); A(h->pk.aff, R); A(h->pk.next, R); A(h->pk.wcnt, W);
     A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
@@ -688,6 +704,8 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     (void)hipMemsetAsync(h->used, 0, M * sizeof(u64), h->stream);
     (void)hipMemsetAsync(h->alive_bits, 0, ((M + 31) / 32 + 4) * sizeof(u32), h->stream);
     (void)hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream);
+    (void)hipMemsetAsync(h->D, 0, (size_t)kFillRounds * M * sizeof(u64), h->stream);
+    (void)hipMemsetAsync(h->sb.R, 0, (size_t)kMaxBlocks * sizeof(u64), h->stream);
     if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
         h->err = "initial fill failed (no gfx950 code object loaded?)";
         return bail(RIO_GP_EUPSTREAM);
@@ -749,7 +767,7 @@ int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->all_alive = true;
     for (uint32_t j = 0; j < m; ++j) h->all_alive = h->all_alive && h->h_alive[j];
-    if (m != h->m) h->used_valid = false;
+    if (m != h->m) { h->used_valid = false; h->used_parts = false; }
     h->m = m;
     h->have_solved = false;
     return RIO_GP_OK;
@@ -819,6 +837,7 @@ static int set_objects_impl(rio_gp_t* h, uint64_t n, const uint32_t* load, const
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n = n;
     h->used_valid = true;
+    h->used_parts = false;
     h->have_solved = false;
     return RIO_GP_OK;
 }
@@ -1022,6 +1041,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         const u32 seq = small_begin(h);
         // `used` follows the writes when it is valid (k_remove_small does the same): a server that mixes single updates with
         // policy calls does not re-stream the whole table before every place_pending
+        fold_used(h);
         launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream, aff_life(h),
                             small_done_dev(h), seq, in_args ? &inl : nullptr, h->used_valid ? h->used : nullptr, h->load, h->m);
         h->have_solved = false;
@@ -1033,6 +1053,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         memcpy(h->h_mid, idx, n * sizeof(u32));
         memcpy(h->h_mid + kMidBatch, node, n * sizeof(u32));
         const u32 seq = small_begin(h);
+        fold_used(h);
         launch_update(h->assign[h->cur], h->n, h->m, h->d_mid, h->d_mid + kMidBatch, n, h->pos, h->dstats, h->stream, aff_life(h),
                       h->mid_ticket, small_done_dev(h), seq, h->used_valid ? h->used : nullptr, h->load);
         h->have_solved = false;
@@ -1047,6 +1068,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
 static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
     int rc = zero_stats(h);
     if (rc) return rc;
+    fold_used(h);
     if (h->part_mode != 2 && part_applicable(h->n, n, d_idx, nullptr)) {
         if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32)))) return rc;
         launch_remove_part(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, (u32*)h->part.p, h->used_valid ? h->used : nullptr,
@@ -1081,6 +1103,7 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
         const bool in_args = small_inline(&inl, n, idx, nullptr);
         if (!in_args) memcpy(h->h_small, idx, n * sizeof(u32));
         const u32 seq = small_begin(h);
+        fold_used(h);
         launch_remove_small(h->assign[h->cur], h->m, h->load, h->d_small, (u32)n, h->used_valid ? h->used : nullptr, h->stream,
                             aff_life(h), small_done_dev(h), seq, in_args ? &inl : nullptr);
         h->have_solved = false;
@@ -1089,6 +1112,7 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     if (n <= (uint64_t)kMidBatch) {  // medium batch, validated above: as update_batch
         memcpy(h->h_mid, idx, n * sizeof(u32));
         const u32 seq = small_begin(h);
+        fold_used(h);
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_mid, n, h->used_valid ? h->used : nullptr, h->dstats,
                       h->stream, aff_life(h), small_done_dev(h), seq, nullptr, h->mid_ticket);
         h->have_solved = false;
@@ -1117,6 +1141,7 @@ int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evi
     h->have_solved = false;
     if (!any) return RIO_GP_OK;  // retain() with a predicate nothing matches
     const u32 seq = (small_begin(h) & 0xFFFFFFu) | 0x800000u;  // 24 bits, never 0
+    fold_used(h);  // (k_clean zeroes the dead nodes' entries: what the last solve's rounds admitted there must be in first)
     launch_clean(h->assign[h->cur], h->n, h->m, h->d_cs, h->used_valid ? h->used : nullptr, h->dstats, h->stream,
                  h->cs_cnt, h->cs_ticket, reinterpret_cast<u64*>(h->d_cs + h->cs_words), aff_life(h), seq);
     {   // the last workgroup stores total | seq << 40 into mapped pinned memory: spin on the tag, ask the stream after 50 ms
@@ -1193,20 +1218,25 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     const u64 seq = ++h->wait_seq;
     vp.mark = seq;  // k_resolve's pinned partial rows carry it: the verdict is waited for without the runtime (spin_rows)
     const Table vtab{vcur, vload, vaff, vnext};
-    const NodeTab vnt{h->cap, h->alive_bits, h->used};
+    const NodeTab vnt{h->cap, h->alive_bits, h->used};  // (ensure_used above folded whatever the last solve's rounds had left)
+    h->sb.D = h->D;
     launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
     launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
     if (!spin_rows(h->h_slots, resolve_blocks(h->m), seq)) HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    bool vslow = false;
     {
         const DevStats v = reduce_slot(h, 0, h->m);
-        if (v.n_cut > 0 || v.spillcand > 0) enqueue_slow(h, vp, vtab, vnt, true, v);
+        vslow = v.n_cut > 0 || v.spillcand > 0;
+        if (vslow) enqueue_slow(h, vp, vtab, vnt, true, false);
     }
     // (5) publish, outputs, new `used`
     launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
                       h->stream, aff_life(h), done_seq ? h->mid_ticket : nullptr, done_seq ? small_done_dev(h) : nullptr, done_seq,
                       mark);
     std::swap(h->used, h->sb.used_cur);  // the solve's `used` vector becomes the committed one (as commit does): no copy
+    h->used_parts = vslow && h->sb.D != nullptr;  // + what the water-fill rounds admitted (D rows), folded in later
+    h->parts_rounds = h->rounds;
     h->have_solved = false;
     return RIO_GP_OK;
 }
@@ -1355,8 +1385,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
     use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
-    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
-    launch_resolve(h->plan, nt, h->sb, slot_dev(h, h->ring_n), h->stream);
+    enqueue_scan_resolve(h, t, nt, false, slot_dev(h, h->ring_n));
     HIPCHK(h, hipGetLastError());
     h->ring_n++;
     h->ring_any = true;
@@ -1382,7 +1411,7 @@ int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow) {
     h->ring_slow = 0;
     h->ring_any = false;
     if (last.n_cut > 0 || last.spillcand > 0) {
-        enqueue_slow(h, h->plan, real_table(h), real_nodes(h), false, last);
+        enqueue_slow(h, h->plan, real_table(h), real_nodes(h), false, false);
         int rc = merge_slow(h, &last);
         if (rc) return rc;
         HIPCHK(h, hipGetLastError());
@@ -1404,6 +1433,9 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     // hipExtLaunchKernelGGL start/stop events = the dispatch's own begin/end timestamps
+    fold_used(h);
+    h->sb.D = h->D;
+    h->solve_used_D = h->sb.D != nullptr;
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, h->ev0, h->ev1);
     launch_resolve(h->plan, nt, h->sb, slot_dev(h, 0), h->stream, h->ev2, h->ev3);
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1436,6 +1468,9 @@ uint32_t rio_gp_shard_words2(rio_gp_t* h) { return h ? (uint32_t)shard_words2(h-
 
 static SolveBufs local_bufs(rio_gp* h) {  // where the local sums of a shard scan go
     SolveBufs b = h->sb;
+    b.RP = nullptr;
+    b.R = nullptr;  // the row-sharded solve keeps the cut step and the rounds apart (the Y exchange sits between them):
+    b.D = nullptr;  // no per-block rejected loads, admitted load straight into used_cur, a ranking launch per round
     b.used_kept = h->sh_lkept;
     b.claim_tot = h->sh_lclaim;
     b.used_cur = h->sh_lcur;
@@ -1446,6 +1481,10 @@ static SolveBufs local_bufs(rio_gp* h) {  // where the local sums of a shard sca
 
 static SolveBufs shard_bufs(rio_gp* h) {
     SolveBufs b = h->sb;
+    b.RP = nullptr;
+    b.R = nullptr;
+    b.D = nullptr;
+    b.used_snap = h->sh_gprev;  // the global `used` as the last exchange left it: what a round orders the nodes by
     b.forced_bits = h->sh_forced;
     b.rank_base = h->sh_rank_base;
     b.pending_global = h->sh_verdict;  // [0] = rows pending on all ranks, written by k_shard_import_delta
@@ -1457,6 +1496,8 @@ int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
     std::lock_guard<std::mutex> g(h->mu);
     h->plan = make_plan(h->n, h->m, 0);
     h->sb.fx = FxRows{};  // row-sharded solve: the fix-up counters are summed in DevStats (rio_gp_shard_finish reads them)
+    fold_used(h);
+    h->solve_used_D = false;
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
@@ -1526,7 +1567,10 @@ int rio_gp_shard_cut(rio_gp_t* h, int run_local_fixup, uint64_t* d_y) {
     if (h->sh_state != 2 || !h->sh_slow) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_cut: no fix-up pending");
     HIPCHK(h, hipSetDevice(h->device));
     const SolveBufs b = shard_bufs(h);
-    if (run_local_fixup) launch_cut_fixup(h->plan, real_table(h), real_nodes(h), b, false, h->stream, h->fixup_mode, false, false);
+    if (run_local_fixup) {
+        launch_cut_find(h->plan, real_table(h), real_nodes(h), b, false, h->stream, false);
+        launch_fill(h->plan, real_table(h), real_nodes(h), b, false, true, false, 0, false, h->stream);
+    }
     launch_shard_export_delta(h->plan, b, h->sb.used_kept, 0, reinterpret_cast<u64*>(d_y), h->stream);
     h->sh_state = 3;
     return RIO_GP_OK;
@@ -1554,7 +1598,7 @@ int rio_gp_shard_spill(rio_gp_t* h, uint32_t round, int last, uint64_t* d_y) {
     if (h->sh_state != 4) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_spill: call rio_gp_shard_merge first");
     HIPCHK(h, hipSetDevice(h->device));
     const SolveBufs b = shard_bufs(h);
-    launch_spill_round(h->plan, real_table(h), real_nodes(h), b, (int)round, last != 0, h->stream);
+    launch_fill(h->plan, real_table(h), real_nodes(h), b, false, false, true, (int)round, last != 0, h->stream);
     launch_shard_export_delta(h->plan, b, h->sh_gprev, (int)((round & 1) ^ 1), reinterpret_cast<u64*>(d_y), h->stream);
     h->sh_state = 5;
     return RIO_GP_OK;
@@ -1768,6 +1812,8 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         const u32 slot = (u32)(seq % kP2PSlots);
         h->plan = make_plan(h->n, h->m, 0);
         h->sb.fx = FxRows{};
+        fold_used(h);
+        h->solve_used_D = false;
         const Table t = real_table(h);
         const NodeTab nt = real_nodes(h);
         launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
@@ -1795,6 +1841,8 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (sc->done_valid[q]) HIPCHK(h, hipStreamWaitEvent(h->stream, sc->done[q], 0));
     h->plan = make_plan(h->n, h->m, 0);
     h->sb.fx = FxRows{};
+    fold_used(h);
+    h->solve_used_D = false;
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
@@ -1841,29 +1889,13 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
     return RIO_GP_OK;
 }
 
+#ifdef RIO_GP_LAB
+// ---- lab build only (librio_gp_lab.so, include/rio_gpu_placement_debug.h): policy knobs for the parity tests and A/B
+//      runs, the streaming / host round-trip probes.  None of it is in the product library.
 void rio_gp_debug_set_scan_nt(int mode) { set_scan_nt(mode); }
 void rio_gp_debug_set_part_shift(int shift) { set_part_shift(shift); }
 uint64_t rio_gp_debug_wave_row_lo(uint64_t n_objects, uint32_t n_nodes, uint32_t wave, uint32_t* n_waves) {
     return plan_wave_row_lo(n_objects, n_nodes, wave, n_waves);
-}
-
-int rio_gp_debug_cut_trace(rio_gp_t* h, int enable, uint64_t* out2048) {
-    if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (out2048 && cut_trace_read(reinterpret_cast<u64*>(out2048)) != 0) return fail(h, RIO_GP_EUPSTREAM, "cut trace read failed");
-    if (cut_trace_enable(enable) != 0) return fail(h, RIO_GP_EUPSTREAM, "cut trace enable failed");
-    return RIO_GP_OK;
-}
-
-int rio_gp_debug_ktrace(rio_gp_t* h, int table, uint64_t* out2048) {
-    if (!h || !out2048) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (ktrace_read(table, reinterpret_cast<u64*>(out2048)) != 0) return fail(h, RIO_GP_EUPSTREAM, "ktrace read failed");
-    return RIO_GP_OK;
 }
 
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
@@ -1875,11 +1907,20 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     return RIO_GP_OK;
 }
 
-int rio_gp_debug_set_fixup(rio_gp_t* h, int fused, int speculate) {
-    if (!h || fused < 0 || fused > 2 || speculate < 0 || speculate > 2) return RIO_GP_EINVAL;
+int rio_gp_debug_set_speculate(rio_gp_t* h, int speculate) {
+    if (!h || speculate < 0 || speculate > 2) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
-    h->fixup_mode = fused;
     h->spec_mode = speculate;
+    return RIO_GP_OK;
+}
+
+int rio_gp_debug_ktrace(rio_gp_t* h, int enable, int table, uint64_t* out2048) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out2048 && ktrace_read(table, reinterpret_cast<u64*>(out2048)) != 0) return fail(h, RIO_GP_EUPSTREAM, "ktrace read failed");
+    ktrace_enable(enable);
     return RIO_GP_OK;
 }
 
@@ -1899,6 +1940,7 @@ int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms) {
     if (*ms < 0) return fail(h, RIO_GP_EUPSTREAM, "stream probe failed");
     return RIO_GP_OK;
 }
+#endif  // RIO_GP_LAB
 
 int rio_gp_timer_begin(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;

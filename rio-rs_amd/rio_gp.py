@@ -21,8 +21,9 @@ FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleane
 FLAG_MASK = 0x0F
 OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM, ERANGE = range(6)
 
-SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "stream_probe.hip",
-                                                     "gpu_object_placement.cpp")]
+LAB_PATH = os.path.join(_DIR, "librio_gp_lab.so")   # the same sources + -DRIO_GP_LAB + stream_probe.hip (tests / tools only)
+SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "gpu_object_placement.cpp")]
+LAB_SOURCES = SOURCES + [os.path.join(_DIR, "csrc", "stream_probe.hip")]
 HEADERS = [os.path.join(_DIR, "csrc", "placement_kernels.h"),
            os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_placement_debug.h"),
            os.path.join(os.path.dirname(_DIR), "include", "rio_gpu_placement.h"),
@@ -53,32 +54,50 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> rio-rs_amd/librio_gp.so (in-tree, travels with gpurun)."""
-    srcs = [s for s in SOURCES if os.path.exists(s)]
+def _build_one(path, srcs, extra, force, verbose):
     deps = srcs + [x for x in HEADERS if os.path.exists(x)]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps):
-        return LIB_PATH
+    if not force and os.path.exists(path) and all(os.path.getmtime(d) <= os.path.getmtime(path) for d in deps):
+        return None
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I", os.path.join(os.path.dirname(_DIR), "include"), "-o", LIB_PATH] + srcs
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + extra + [
+        "-I", os.path.join(os.path.dirname(_DIR), "include"), "-o", path] + srcs
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    return subprocess.Popen(cmd)
+
+
+def build(force=False, verbose=False, lab=True):
+    """hipcc --offload-arch=gfx950 -> rio-rs_amd/librio_gp.so, the product (in-tree, travels with gpurun), and
+    librio_gp_lab.so, the lab build the parity tests and tools load for the policy knobs and probes."""
+    jobs = [_build_one(LIB_PATH, [s for s in SOURCES if os.path.exists(s)], [], force, verbose)]
+    if lab:
+        jobs.append(_build_one(LAB_PATH, [s for s in LAB_SOURCES if os.path.exists(s)], ["-DRIO_GP_LAB"], force, verbose))
+    for j in jobs:
+        if j is not None and j.wait() != 0:
+            raise RuntimeError("hipcc failed")
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 _vp = C.c_void_p
 _u32p = C.POINTER(C.c_uint32)
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        path = os.environ.get("RIO_GP_LIB", LIB_PATH)  # A/B runs of another build of the same sources (measurement aid)
+    """The product library: exactly the two public headers."""
+    return _load(False)
+
+
+def lab_lib():
+    """The lab build (tests / tools): the product's sources + -DRIO_GP_LAB (policy knobs, probes)."""
+    return _load(True)
+
+
+def _load(lab):
+    if lab not in _libs:
+        path = LAB_PATH if lab else os.environ.get("RIO_GP_LIB", LIB_PATH)  # RIO_GP_LIB: A/B runs of another build (measurement aid)
         if not os.path.exists(path):
-            raise RuntimeError("librio_gp.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+            raise RuntimeError("%s is not built (run __graft_entry__.build()); there is no CPU fallback" % os.path.basename(path))
         L = C.CDLL(path)
         L.rio_gp_create.argtypes = [C.POINTER(Cfg), C.POINTER(_vp)]
         L.rio_gp_destroy.argtypes = [_vp]
@@ -123,19 +142,21 @@ def lib():
         L.rio_gp_get_objects.argtypes = [_vp, C.c_uint64, _vp, _vp]
         L.rio_gp_set_num_objects.argtypes = [_vp, C.c_uint64]
         L.rio_gp_place_pending_dev.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp]
-        L.rio_gp_debug_set_scan_nt.argtypes = [C.c_int]
-        L.rio_gp_debug_set_scan_nt.restype = None
-        L.rio_gp_debug_set_part_shift.argtypes = [C.c_int]
-        L.rio_gp_debug_set_part_shift.restype = None
-        L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
-        L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
-        L.rio_gp_debug_cut_trace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
-        L.rio_gp_debug_ktrace.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint64)]
-        L.rio_gp_debug_set_fixup.argtypes = [_vp, C.c_int, C.c_int]
+        if lab:
+            L.rio_gp_debug_set_scan_nt.argtypes = [C.c_int]
+            L.rio_gp_debug_set_scan_nt.restype = None
+            L.rio_gp_debug_set_part_shift.argtypes = [C.c_int]
+            L.rio_gp_debug_set_part_shift.restype = None
+            L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+            L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
+            L.rio_gp_debug_set_speculate.argtypes = [_vp, C.c_int]
+            L.rio_gp_debug_ktrace.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+            L.rio_gp_debug_wave_row_lo.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+            L.rio_gp_debug_wave_row_lo.restype = C.c_uint64
         L.rio_gp_timer_begin.argtypes = [_vp]
         L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
-        _lib = L
-    return _lib
+        _libs[lab] = L
+    return _libs[lab]
 
 
 def _ptr(a):
@@ -149,24 +170,27 @@ def _u32(a):
 class GpuPlacement:
     """Dense-index layer: thin, 1:1 over rio_gp_*.  Arrays are numpy uint32/uint64."""
 
-    def __init__(self, max_objects, max_nodes, device=0, spill_rounds=2, flags=0):
+    def __init__(self, max_objects, max_nodes, device=0, spill_rounds=2, flags=0, lab=False):
+        """lab=True: the handle lives in the lab build (librio_gp_lab.so) — what the knob / probe methods need."""
+        self._lab = bool(lab)
+        self._L = lab_lib() if lab else lib()
         self._h = _vp()
         cfg = Cfg(C.sizeof(Cfg), device, max_objects, max_nodes, spill_rounds, flags, 0)
-        rc = lib().rio_gp_create(C.byref(cfg), C.byref(self._h))
+        rc = self._L.rio_gp_create(C.byref(cfg), C.byref(self._h))
         if rc != OK:
-            text = (lib().rio_gp_last_error(None) or b"").decode()
+            text = (self._L.rio_gp_last_error(None) or b"").decode()
             self._h = None
             raise ObjectPlacementError("Upstream" if rc in (EUPSTREAM, ENODEV, ENOMEM) else "Unknown", text, rc)
 
     # -- error convention (errors.rs:135-142) --
     def _chk(self, rc):
         if rc != OK:
-            text = (lib().rio_gp_last_error(self._h) or b"").decode()
+            text = (self._L.rio_gp_last_error(self._h) or b"").decode()
             raise ObjectPlacementError("Unknown" if rc == EINVAL else "Upstream", text, rc)
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().rio_gp_destroy(self._h)
+            self._L.rio_gp_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -176,10 +200,10 @@ class GpuPlacement:
         return self._h
 
     def backend(self):
-        return lib().rio_gp_backend(self._h).decode()
+        return self._L.rio_gp_backend(self._h).decode()
 
     def sync(self):
-        self._chk(lib().rio_gp_sync(self._h))
+        self._chk(self._L.rio_gp_sync(self._h))
 
     # -- tables --
     def set_nodes(self, cap=None, alive=None, m=None):
@@ -187,85 +211,85 @@ class GpuPlacement:
             m = len(cap) if cap is not None else len(alive)
         cap = None if cap is None else np.ascontiguousarray(cap, dtype=np.uint64)
         alive = None if alive is None else np.ascontiguousarray(alive, dtype=np.uint8)
-        self._chk(lib().rio_gp_set_nodes(self._h, m, _ptr(cap), _ptr(alive)))
+        self._chk(self._L.rio_gp_set_nodes(self._h, m, _ptr(cap), _ptr(alive)))
 
     def set_alive(self, node, alive):
-        self._chk(lib().rio_gp_set_alive(self._h, node, int(bool(alive))))
+        self._chk(self._L.rio_gp_set_alive(self._h, node, int(bool(alive))))
 
     def set_alive_all(self, alive):
         alive = np.ascontiguousarray(alive, dtype=np.uint8)
-        self._chk(lib().rio_gp_set_alive_all(self._h, len(alive), _ptr(alive)))
+        self._chk(self._L.rio_gp_set_alive_all(self._h, len(alive), _ptr(alive)))
 
     def get_nodes(self):
         m = self.num_nodes
         cap, alive, used = np.empty(m, np.uint64), np.empty(m, np.uint8), np.empty(m, np.uint64)
-        self._chk(lib().rio_gp_get_nodes(self._h, m, _ptr(cap), _ptr(alive), _ptr(used)))
+        self._chk(self._L.rio_gp_get_nodes(self._h, m, _ptr(cap), _ptr(alive), _ptr(used)))
         return cap, alive, used
 
     def set_objects(self, n, load=None, aff=None):
         load, aff = _u32(load), _u32(aff)
-        self._chk(lib().rio_gp_set_objects(self._h, n, _ptr(load), _ptr(aff)))
+        self._chk(self._L.rio_gp_set_objects(self._h, n, _ptr(load), _ptr(aff)))
 
     def set_object_attrs(self, idx, load=None, aff=None):
         """Change load and/or affinity of individual rows (either may be None = leave as is)."""
         idx, load, aff = _u32(idx), _u32(load), _u32(aff)
-        self._chk(lib().rio_gp_set_object_attrs(self._h, len(idx), _ptr(idx), _ptr(load), _ptr(aff)))
+        self._chk(self._L.rio_gp_set_object_attrs(self._h, len(idx), _ptr(idx), _ptr(load), _ptr(aff)))
 
     def get_objects(self):
         n = self.num_objects
         load, aff = np.empty(n, np.uint32), np.empty(n, np.uint32)
-        self._chk(lib().rio_gp_get_objects(self._h, n, _ptr(load), _ptr(aff)))
+        self._chk(self._L.rio_gp_get_objects(self._h, n, _ptr(load), _ptr(aff)))
         return load, aff
 
     def set_num_objects(self, n):
-        self._chk(lib().rio_gp_set_num_objects(self._h, n))
+        self._chk(self._L.rio_gp_set_num_objects(self._h, n))
 
     def set_objects_dev(self, n, d_load, d_aff):
-        self._chk(lib().rio_gp_set_objects_dev(self._h, n, _vp(d_load), _vp(d_aff)))
+        self._chk(self._L.rio_gp_set_objects_dev(self._h, n, _vp(d_load), _vp(d_aff)))
 
     def set_assign(self, assign):
         assign = _u32(assign)
-        self._chk(lib().rio_gp_set_assign(self._h, len(assign), _ptr(assign)))
+        self._chk(self._L.rio_gp_set_assign(self._h, len(assign), _ptr(assign)))
 
     def set_assign_dev(self, n, d_assign):
-        self._chk(lib().rio_gp_set_assign_dev(self._h, n, _vp(d_assign)))
+        self._chk(self._L.rio_gp_set_assign_dev(self._h, n, _vp(d_assign)))
 
     def get_assign(self):
         out = np.empty(self.num_objects, np.uint32)
-        self._chk(lib().rio_gp_get_assign(self._h, len(out), _ptr(out)))
+        self._chk(self._L.rio_gp_get_assign(self._h, len(out), _ptr(out)))
         return out
 
     def get_solved(self):
         out = np.empty(self.num_objects, np.uint32)
-        self._chk(lib().rio_gp_get_solved(self._h, len(out), _ptr(out)))
+        self._chk(self._L.rio_gp_get_solved(self._h, len(out), _ptr(out)))
         return out
 
     @property
     def num_objects(self):
-        return int(lib().rio_gp_num_objects(self._h))
+        return int(self._L.rio_gp_num_objects(self._h))
 
     @property
     def num_nodes(self):
-        return int(lib().rio_gp_num_nodes(self._h))
+        return int(self._L.rio_gp_num_nodes(self._h))
 
     # -- ObjectPlacement CRUD, batched --
     def lookup_batch(self, idx):
         idx = _u32(idx)
         out = np.empty(len(idx), np.uint32)
-        self._chk(lib().rio_gp_lookup_batch(self._h, len(idx), _ptr(idx), _ptr(out)))
+        self._chk(self._L.rio_gp_lookup_batch(self._h, len(idx), _ptr(idx), _ptr(out)))
         return out
 
     def update_batch(self, idx, node):
         idx, node = _u32(idx), _u32(node)
-        self._chk(lib().rio_gp_update_batch(self._h, len(idx), _ptr(idx), _ptr(node)))
+        self._chk(self._L.rio_gp_update_batch(self._h, len(idx), _ptr(idx), _ptr(node)))
 
     def remove_batch(self, idx):
         idx = _u32(idx)
-        self._chk(lib().rio_gp_remove_batch(self._h, len(idx), _ptr(idx)))
+        self._chk(self._L.rio_gp_remove_batch(self._h, len(idx), _ptr(idx)))
 
     def clean_server(self, node):
         ev = C.c_uint64(0)
-        self._chk(lib().rio_gp_clean_server(self._h, node, C.byref(ev)))
+        self._chk(self._L.rio_gp_clean_server(self._h, node, C.byref(ev)))
         return int(ev.value)
 
     def clean_servers(self, dead_nodes):
@@ -274,96 +298,94 @@ class GpuPlacement:
         bits[np.asarray(list(dead_nodes), np.int64)] = 1
         bm = np.packbits(bits, bitorder="little").view(np.uint64)
         ev = C.c_uint64(0)
-        self._chk(lib().rio_gp_clean_servers(self._h, _ptr(bm), C.byref(ev)))
+        self._chk(self._L.rio_gp_clean_servers(self._h, _ptr(bm), C.byref(ev)))
         return int(ev.value)
 
     # -- policy --
     def place_pending(self, idx, requester):
         idx, requester = _u32(idx), _u32(requester)
         node, flag = np.empty(len(idx), np.uint32), np.empty(len(idx), np.uint32)
-        self._chk(lib().rio_gp_place_pending(self._h, len(idx), _ptr(idx), _ptr(requester), _ptr(node), _ptr(flag)))
+        self._chk(self._L.rio_gp_place_pending(self._h, len(idx), _ptr(idx), _ptr(requester), _ptr(node), _ptr(flag)))
         return node, flag
 
     def place_pending_dev(self, n, d_idx, d_requester, d_out_node, d_out_flag=None):
         """Device pointers (ints): request and result arrays already resident in HBM."""
-        self._chk(lib().rio_gp_place_pending_dev(self._h, n, _vp(d_idx), _vp(d_requester), _vp(d_out_node),
+        self._chk(self._L.rio_gp_place_pending_dev(self._h, n, _vp(d_idx), _vp(d_requester), _vp(d_out_node),
                                                  _vp(d_out_flag) if d_out_flag else None))
 
     def solve(self):
         st = Stats()
-        self._chk(lib().rio_gp_solve(self._h, C.byref(st)))
+        self._chk(self._L.rio_gp_solve(self._h, C.byref(st)))
         return st.as_dict()
 
     def commit(self):
-        self._chk(lib().rio_gp_commit(self._h))
+        self._chk(self._L.rio_gp_commit(self._h))
 
     def tick(self):
         st = Stats()
-        self._chk(lib().rio_gp_tick(self._h, C.byref(st)))
+        self._chk(self._L.rio_gp_tick(self._h, C.byref(st)))
         return st.as_dict()
 
     def tick_async(self):
-        self._chk(lib().rio_gp_tick_async(self._h))
+        self._chk(self._L.rio_gp_tick_async(self._h))
 
     def tick_wait(self, cap=4096):
         """Counters of the asynchronous ticks completed since the last wait (the most recent `cap`), oldest first."""
         arr, n = (Stats * cap)(), C.c_uint32(0)
-        self._chk(lib().rio_gp_tick_wait(self._h, arr, cap, C.byref(n)))
+        self._chk(self._L.rio_gp_tick_wait(self._h, arr, cap, C.byref(n)))
         return [arr[k].as_dict() for k in range(min(cap, int(n.value)))]
 
     def solve_async(self):
-        self._chk(lib().rio_gp_solve_async(self._h))
+        self._chk(self._L.rio_gp_solve_async(self._h))
 
     def solve_wait(self):
         st, ns = Stats(), C.c_uint32(0)
-        self._chk(lib().rio_gp_solve_wait(self._h, C.byref(st), C.byref(ns)))
+        self._chk(self._L.rio_gp_solve_wait(self._h, C.byref(st), C.byref(ns)))
         return st.as_dict(), int(ns.value)
 
     def solve_profiled(self):
         a, b = C.c_float(0), C.c_float(0)
-        self._chk(lib().rio_gp_solve_profiled(self._h, C.byref(a), C.byref(b)))
+        self._chk(self._L.rio_gp_solve_profiled(self._h, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
 
+    # -- lab build only (GpuPlacement(..., lab=True)): policy knobs of the parity tests, probes --
+    def _need_lab(self):
+        if not self._lab:
+            raise RuntimeError("this method needs a handle of the lab build: GpuPlacement(..., lab=True)")
+
     def stream_probe(self, mode, reps=20):
+        self._need_lab()
         ms = C.c_float(0)
-        self._chk(lib().rio_gp_debug_stream_probe(self._h, mode, reps, C.byref(ms)))
+        self._chk(self._L.rio_gp_debug_stream_probe(self._h, mode, reps, C.byref(ms)))
         return float(ms.value)
 
-    def cut_trace(self, enable=True, read=False):
-        """k_cut_fused phase trace (measurement aid): returns [256][8] u64 = start, P0 end, P1 total, P2 total, P3 time,
-        nloc, S, groups (100 MHz ticks) of the last launch when read=True."""
-        out = (C.c_uint64 * 2048)() if read else None
-        self._chk(lib().rio_gp_debug_cut_trace(self._h, 1 if enable else 0, out))
-        return np.ctypeslib.as_array(out).reshape(256, 8).copy() if read else None
-
-    def ktrace(self, table):
-        """Phase trace of a fix-up kernel's last launch: [256][8] u64 of wall_clock64 (100 MHz); table 0 / 1 k_spill_apply
-        first / last round, 2 k_cut_apply_rank, 3 k_cut_find.  Enable with cut_trace(True)."""
-        out = (C.c_uint64 * 2048)()
-        self._chk(lib().rio_gp_debug_ktrace(self._h, table, out))
-        return np.ctypeslib.as_array(out).reshape(256, 8).copy()
+    def ktrace(self, enable=True, table=None):
+        """phase traces of the fix-up kernels (100 MHz ticks, [256][8]): table 0 k_resolve+search | 1 k_fill round 0 | 2 later rounds"""
+        self._need_lab()
+        out = (C.c_uint64 * 2048)() if table is not None else None
+        self._chk(self._L.rio_gp_debug_ktrace(self._h, 1 if enable else 0, 0 if table is None else table, out))
+        return np.ctypeslib.as_array(out).reshape(256, 8).copy() if table is not None else None
 
     def set_compact(self, mode, partitioned_crud=True, cut_pack="auto"):
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode).  partitioned_crud=False: big
         update / remove batches through the plain per-entry kernels (A/B runs, parity tests).  cut_pack: the same three
-        modes for packing at the cut pass of whole-table solves (k_cut_apply_rank<PACK>)."""
+        modes for packing at the cut pass of whole-table solves (round 0 of k_fill packs)."""
+        self._need_lab()
         modes = {"auto": 0, "always": 1, "never": 2}
-        self._chk(lib().rio_gp_debug_set_compact(self._h, modes.get(mode, mode) | (0 if partitioned_crud else 16) |
-                                                 (modes.get(cut_pack, cut_pack) << 5)))
+        self._chk(self._L.rio_gp_debug_set_compact(self._h, modes.get(mode, mode) | (0 if partitioned_crud else 16) |
+                                                   (modes.get(cut_pack, cut_pack) << 5)))
 
-    def set_fixup(self, fused=True, speculate="auto"):
-        """cut fix-up implementation: "split" / 2 (default: k_cut_find + k_cut_apply), True / 1 (one fused launch),
-        False / 0 (the unfused chain); speculative enqueue auto | always | never (results identical in every mode)."""
-        impl = {"split": 2, True: 1, False: 0}.get(fused, fused)
-        self._chk(lib().rio_gp_debug_set_fixup(self._h, int(impl),
-                                               {"auto": 0, "always": 1, "never": 2}.get(speculate, speculate)))
+    def set_speculate(self, speculate="auto"):
+        """speculative enqueue of the fix-up behind k_resolve: auto | always | never (results identical in every mode)."""
+        self._need_lab()
+        self._chk(self._L.rio_gp_debug_set_speculate(self._h, {"auto": 0, "always": 1, "never": 2}.get(speculate, speculate)))
 
     def timer_begin(self):
-        self._chk(lib().rio_gp_timer_begin(self._h))
+        self._chk(self._L.rio_gp_timer_begin(self._h))
 
     def timer_end(self):
         ms = C.c_float(0)
-        self._chk(lib().rio_gp_timer_end(self._h, C.byref(ms)))
+        self._chk(self._L.rio_gp_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
 
 
@@ -420,6 +442,12 @@ def _cstrs(items):
     for k, v in enumerate(items):
         arr[k] = None if v is None else v.encode()
     return arr
+
+
+def LabPlacement(*a, **k):
+    """GpuPlacement in the lab build (librio_gp_lab.so): the handle the knob / probe methods work on."""
+    k["lab"] = True
+    return GpuPlacement(*a, **k)
 
 
 class GpuObjectPlacement:

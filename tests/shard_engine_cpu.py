@@ -8,6 +8,8 @@ oracle (oracle/placement_oracle.c orc_tick) on machines without a GPU, over gloo
 world_size 2.  It is never imported by the product package.
 """
 import numpy as np
+
+import spec_tick
 import torch
 
 NONE = 0xFFFFFFFF
@@ -138,8 +140,7 @@ class CpuShardEngine:
     def spill(self, rnd, last, y):
         fre = np.where(self.alive & (self.cap > self.used), self.cap - self.used, 0).astype(np.uint64)
         nz = np.flatnonzero(fre > 0)
-        order = nz[np.lexsort((nz, -fre[nz].astype(object)))] if len(nz) else nz
-        order = np.array(sorted(nz.tolist(), key=lambda j: (-int(fre[j]), j)), dtype=np.int64)
+        order = np.array(sorted(nz.tolist(), key=lambda j: (-spec_tick.capacity_class(int(fre[j])), j)), dtype=np.int64)
         Cs = [0]
         for j in order:
             Cs.append(min(Cs[-1] + int(fre[j]), U64MAX))

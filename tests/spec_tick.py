@@ -6,6 +6,13 @@ INACTIVE = 0xFFFFFFFE   # affinity of a row that is not an object: kept if place
 SAT = (1 << 64) - 1
 
 
+def capacity_class(f):
+    """free capacity f > 0 rounded down to three significant bits, as an ordinal: the
+    water-fill takes the nodes class by class, emptiest class first, node index ascending inside a class"""
+    e = f.bit_length() - 1
+    return 4 * e + ((f >> (e - 2)) & 3 if e >= 2 else (f << (2 - e)) & 3)
+
+
 def tick(cur, load, aff, cap, alive, rounds=2):
     n, m = len(cur), len(cap)
     nxt = [NONE] * n
@@ -44,7 +51,7 @@ def tick(cur, load, aff, cap, alive, rounds=2):
         if not rest:
             break
         fr = [max(int(cap[j]) - used[j], 0) if alive[j] else 0 for j in range(m)]
-        order = sorted((j for j in range(m) if fr[j] > 0), key=lambda j: (-fr[j], j))
+        order = sorted((j for j in range(m) if fr[j] > 0), key=lambda j: (-capacity_class(fr[j]), j))
         C = [0]
         for j in order:
             C.append(min(C[-1] + fr[j], SAT))
@@ -73,7 +80,7 @@ def _waterfill(rest, load_of, cap, alive, used, rounds, place):
         if not rest:
             break
         fr = [max(int(cap[j]) - used[j], 0) if alive[j] else 0 for j in range(m)]
-        order = sorted((j for j in range(m) if fr[j] > 0), key=lambda j: (-fr[j], j))
+        order = sorted((j for j in range(m) if fr[j] > 0), key=lambda j: (-capacity_class(fr[j]), j))
         C = [0]
         for j in order:
             C.append(min(C[-1] + fr[j], SAT))

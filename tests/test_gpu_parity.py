@@ -22,18 +22,16 @@ def gp():
     return rio_gp
 
 
-# (packed fix-up, cut implementation, speculative enqueue): False = the unfused launch chain, True = one fused launch
-# (k_cut_fused), "split" = k_cut_find + k_cut_apply_rank (the default)
-FIXUP_VARIANTS = (("never", False, "never"), ("always", False, "never"),
-                  ("never", True, "always"), ("always", True, "always"), ("always", True, "never"),
-                  ("never", "split", "never"), ("always", "split", "always"), ("never", "split", "always"),
-                  ("always", "split", "never"),
-                  # packing at the cut pass of the whole-table solve (k_cut_apply_rank<PACK>), host-ordered and speculative
-                  ("cutpack", "split", "never"), ("cutpack", "split", "always"))
+# (packed fix-up, speculative enqueue) — the policies the product picks adaptively, forced through the lab build's knobs:
+# fix-up over the whole table with the cut search as a launch of its own | over the pending rows k_scan packed, with the
+# search inside k_resolve | whole table with round 0 of k_fill packing the rows that go on to the water-fill; enqueued after
+# the host has read the verdict | speculatively behind k_resolve (every kernel guards itself on the device)
+FIXUP_VARIANTS = (("never", "never"), ("always", "never"), ("never", "always"), ("always", "always"),
+                  ("cutpack", "never"), ("cutpack", "always"))
 
 
-def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
-    g = gp.GpuPlacement(max(n, 1), max(m, 1), spill_rounds=rounds)
+def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2, lab=False):
+    g = gp.GpuPlacement(max(n, 1), max(m, 1), spill_rounds=rounds, lab=lab)
     g.set_nodes(cap, alive, m=m)
     g.set_objects(n, load, aff)
     if cur is not None and n:
@@ -44,16 +42,17 @@ def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2):
 def _check_tick(gp, oracle, cur, load, aff, cap, alive, rounds=2):
     n, m = len(cur), len(cap)
     want, used, ost = oracle.tick(cur, load, aff, cap, alive, rounds)
-    # Every implementation of the fix-up must give the same bytes: over the whole table | over the packed pending rows;
-    # unfused launch chain | k_cut_fused with the scatter folded into the water-fill; enqueued after the host has read
-    # the verdict | speculatively behind k_resolve (device-side guards).
-    for mode in FIXUP_VARIANTS:
-        g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds)
-        if mode[0] == "cutpack":
+    # Every policy of the fix-up must give the same bytes — and so must the product library left to itself (first variant).
+    for mode in (None,) + FIXUP_VARIANTS:
+        g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds, lab=mode is not None)
+        if mode is None:
+            pass
+        elif mode[0] == "cutpack":
             g.set_compact("never", cut_pack="always")
         else:
             g.set_compact(mode[0], cut_pack="never")
-        g.set_fixup(fused=mode[1], speculate=mode[2])
+        if mode is not None:
+            g.set_speculate(mode[1])
         st = g.solve()
         got = g.get_solved()
         assert np.array_equal(got, want), (mode, np.flatnonzero(got != want)[:10])
@@ -101,10 +100,12 @@ def test_host_waits_without_the_runtime(gp, oracle):
             assert g.clean_server(j) == int((ref == j).sum()), step
             ref[ref == j] = NONE
     assert np.array_equal(g.get_assign(), ref)
-    # the probe kernels behind tools/sync_probe.py: both ways of waiting complete and take microseconds, not milliseconds
-    for mode in (20, 21, 22, 23):
-        assert 0 < g.stream_probe(mode, 200) * 1000.0 < 200.0, mode
     g.close()
+    # the probe kernels behind tools/sync_probe.py (lab build): both ways of waiting complete and take microseconds
+    gl = gp.LabPlacement(1024, 4)
+    for mode in (20, 21, 22, 23):
+        assert 0 < gl.stream_probe(mode, 200) * 1000.0 < 200.0, mode
+    gl.close()
     # synchronous ticks, alternating fast path and fix-up path: counters and tables of every tick against the oracle
     n, m = 300_000, 100
     cur, load, aff, cap, alive = _rand_case(np.random.default_rng(5), n, m, cap_scale=1.6, p_alive=1.0)
@@ -291,7 +292,7 @@ def test_crud_big_batches_partitioned_by_row_window(gp, oracle, seed, n, m, k):
     g = gp.GpuPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
     g.set_nodes(m=m, alive=np.ones(m, np.uint8))
     g.set_objects(n, load, None)
-    plain = gp.GpuPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
+    plain = gp.LabPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
     plain.set_compact("auto", partitioned_crud=False)
     plain.set_nodes(m=m, alive=np.ones(m, np.uint8))
     plain.set_objects(n, load, None)
@@ -364,12 +365,15 @@ def test_invalid_arguments_are_unknown_errors(gp):
         assert e.value.kind == "Unknown" and e.value.rc == gp.EINVAL
     assert np.all(g.get_assign() == NONE)       # nothing was mutated
     assert g.clean_server(7) == 0               # unknown address: retain() removes nothing
-    # the debug knobs reject what they do not know (modes are 0 | 1 | 2 in every field)
-    for bad in (3, 3 << 5, 7):
-        assert gp.lib().rio_gp_debug_set_compact(g.handle, bad) == gp.EINVAL
-    assert gp.lib().rio_gp_debug_set_fixup(g.handle, 3, 0) == gp.EINVAL
-    assert gp.lib().rio_gp_debug_set_compact(g.handle, 2 | 16 | (1 << 5)) == 0   # never | plain CRUD | cut-pass packing always
     g.close()
+    # the lab build's knobs reject what they do not know (modes are 0 | 1 | 2 in every field)
+    gl = gp.LabPlacement(10, 2)
+    for bad in (3, 3 << 5, 7):
+        assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, bad) == gp.EINVAL
+    assert gp.lab_lib().rio_gp_debug_set_speculate(gl.handle, 3) == gp.EINVAL
+    assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, 2 | 16 | (1 << 5)) == 0   # never | plain CRUD | cut-pass packing always
+    gl.close()
+    assert not hasattr(gp.lib(), "rio_gp_debug_set_compact")   # and the product library has none of them
 
 
 # ---- whole-table solve ---------------------------------------------------------------------------
@@ -544,15 +548,17 @@ def test_async_solves_match_sync(gp, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("fused,spec", [("split", "auto"), (True, "auto"), (False, "never"), (True, "always"), ("split", "always")])
-def test_churn_stream_adaptive_packed_fixup(gp, oracle, fused, spec):
+@pytest.mark.parametrize("spec", [None, "auto", "never", "always"])
+def test_churn_stream_adaptive_packed_fixup(gp, oracle, spec):
     """Config-5 shape: committed ticks while a different 10 % of the nodes is down each tick.  From the second tick
-    on the adaptive rule switches to the packed fix-up (few rows pending) and — fused fix-up — enqueues it
-    speculatively, without reading the verdict first; every tick must equal the oracle chain."""
+    on the adaptive rule switches to the packed fix-up (few rows pending: the cuts are searched inside k_resolve) and
+    enqueues it speculatively, without reading the verdict first; every tick must equal the oracle chain.
+    spec None = the product library left to itself."""
     cfg = synth.config("c3", n_override=1_500_000)
     n, m = cfg["n"], cfg["m"]
-    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"], synth.warm_assign(n, m))
-    g.set_fixup(fused=fused, speculate=spec)
+    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], cfg["alive"], synth.warm_assign(n, m), lab=spec is not None)
+    if spec is not None:
+        g.set_speculate(spec)
     ref = synth.warm_assign(n, m)
     for tick in range(6):
         alive = synth.churn_mask(m, 2 + tick)

@@ -32,8 +32,8 @@ def cfg_of(name):
     return synth.config(name)
 
 
-def _mk(gp, cfg, cur=None, rounds=2):
-    g = gp.GpuPlacement(cfg["n"], cfg["m"], spill_rounds=rounds)
+def _mk(gp, cfg, cur=None, rounds=2, lab=False):
+    g = gp.GpuPlacement(cfg["n"], cfg["m"], spill_rounds=rounds, lab=lab)
     g.set_nodes(cfg["cap"], cfg["alive"])
     g.set_objects(cfg["n"], cfg["load"], cfg["aff"])
     if cur is not None:
@@ -65,20 +65,17 @@ def test_config2_exact_every_fixup_variant(gp, oracle):
     assert st["slow_path"] == 0 and st["claimed"] == cfg["n"]
     g.close()
     tight = dict(cfg, cap=np.full(256, 3000, np.uint64))
-    for compact, impl, spec in (("never", 0, "never"), ("always", 0, "never"), ("never", 1, "always"), ("always", 1, "always"),
-                                ("always", 1, "never"), ("never", 2, "never"), ("always", 2, "always"), ("cutpack", 2, "always")):
-        g = _mk(gp, tight)
+    for compact, spec in ((None, None), ("never", "never"), ("always", "never"), ("never", "always"), ("always", "always"),
+                          ("cutpack", "never"), ("cutpack", "always")):
+        g = _mk(gp, tight, lab=compact is not None)   # (None: the product library left to itself)
         if compact == "cutpack":
             g.set_compact("never", cut_pack="always")
-        else:
+        elif compact is not None:
             g.set_compact(compact, cut_pack="never")
-        try:
-            g.set_fixup(fused=impl, speculate=spec)
-        except gp.ObjectPlacementError:
-            g.close()
-            continue  # a build without that implementation
+        if spec is not None:
+            g.set_speculate(spec)
         _, _, st = _same(g, oracle, tight["cur"], tight)
-        assert st["cut_nodes"] == 256 and st["unplaced"] > 0, (compact, impl, spec)
+        assert st["cut_nodes"] == 256 and st["unplaced"] > 0, (compact, spec)
         g.close()
 
 
@@ -102,7 +99,7 @@ def test_config3_contended_at_10m(gp, oracle):
     """The headline table with 0.9x of the load as capacity: ~1 020 cut nodes, ~1 M rows water-filled or unplaced."""
     cfg = cfg_of("c3")
     tight = dict(cfg, cap=(cfg["cap"].astype(np.float64) * 0.72).astype(np.uint64))
-    g = _mk(gp, tight)
+    g = _mk(gp, tight, lab=True)
     _, _, st = _same(g, oracle, tight["cur"], tight, commit=False)
     assert st["cut_nodes"] > 900 and st["unplaced"] > 0
     # the same table again: the first solve sent ~10 % of the rows to the water-fill, so this one packs them at the cut pass
@@ -114,15 +111,17 @@ def test_config3_contended_at_10m(gp, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("compact", ["auto", "never"])
+@pytest.mark.parametrize("compact", [None, "never"])
 def test_config5_churn_ticks_at_10m(gp, oracle, compact):
     """Six committed ticks of the config-5 stream at full size, every tick compared: ~1 M rows evicted and re-placed per
-    tick, hundreds of cut nodes, the packed fix-up from the second tick on (auto) or the whole-table fix-up (never)."""
+    tick, hundreds of cut nodes, the packed fix-up from the second tick on (product library) or the whole-table fix-up
+    (lab build, packed fix-up switched off)."""
     cfg = cfg_of("c3")
     n, m = cfg["n"], cfg["m"]
     ref = synth.warm_assign(n, m)
-    g = _mk(gp, cfg, cur=ref)
-    g.set_compact(compact)
+    g = _mk(gp, cfg, cur=ref, lab=compact is not None)   # None: the product library, adaptive
+    if compact is not None:
+        g.set_compact(compact)
     for tick in range(6):
         alive = synth.churn_mask(m, 2 + tick)
         g.set_alive_all(alive)

@@ -70,16 +70,7 @@ res["fast"] = {k: st[k] for k in ("claimed", "load_claimed", "slow_path")}
 g.set_assign_dev(n, torch.full((n,), -1, dtype=torch.int32, device=dev).data_ptr())
 cap2 = np.full(m, (total * 9) // (10 * m), np.uint64)
 g.set_nodes(cap2, np.ones(m, np.uint8))
-if os.environ.get("RIO_CUT_TRACE"):
-    g.cut_trace(True)
 t1 = time.perf_counter(); st2 = g.solve(); res["fixup_solve_ms"] = (time.perf_counter() - t1) * 1e3
-if os.environ.get("RIO_CUT_TRACE"):
-    tr = g.cut_trace(False, read=True).astype(np.int64)
-    tot = (tr[:, 1] - tr[:, 0]) + tr[:, 2] + tr[:, 3] + tr[:, 4]
-    res["cut_trace_worst"] = [{"wg": int(b), "nloc": int(tr[b, 5]), "S": int(tr[b, 6]), "P0_us": (tr[b, 1] - tr[b, 0]) / 100.0,
-                               "P1_us": tr[b, 2] / 100.0, "P2_us": tr[b, 3] / 100.0, "P2a_us": tr[b, 7] / 100.0,
-                               "P3_us": tr[b, 4] / 100.0} for b in np.argsort(-tot)[:4]]
-    res["cut_trace_median_P1_P3_us"] = [float(np.median(tr[:, 2])) / 100.0, float(np.median(tr[:, 4])) / 100.0]
 s2 = _as_tensor(rio_gp.lib().rio_gp_solved_dev(g.handle), n).clone()
 placed = s2 >= 0
 assert st2["slow_path"] == 1 and st2["claimed"] + st2["spilled"] + st2["unplaced"] == n, st2

@@ -12,14 +12,14 @@ from hipbuf import DevBuf
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 cfg = synth.config("c3")
 n, m = cfg["n"], cfg["m"]
-L, vp = rio_gp.lib(), C.c_void_p
+L, vp = rio_gp.lab_lib(), C.c_void_p
 idx = DevBuf((synth.r(np.arange(n, dtype=np.uint64), 7) % np.uint64(n)).astype(np.uint32))
 node = DevBuf(synth.warm_assign(n, m, stream=8))
 warm = synth.warm_assign(n, m)
 out = {}
 for name, shift, part in (("plain", 14, False), ("part_w4096", 12, True), ("part_w8192", 13, True), ("part_w16384", 14, True)):
     L.rio_gp_debug_set_part_shift(shift)
-    g = rio_gp.GpuPlacement(n, m)
+    g = rio_gp.LabPlacement(n, m)
     g.set_compact("auto", partitioned_crud=part)
     g.set_nodes(cfg["cap"], cfg["alive"])
     g.set_objects(n, cfg["load"], cfg["aff"])

@@ -18,17 +18,17 @@ for n in rows:
     reps = -(-n // base["n"])
     load = np.tile(base["load"], reps)[:n]
     aff = np.tile(base["aff"], reps)[:n]
-    g = rio_gp.GpuPlacement(n, m)
+    g = rio_gp.LabPlacement(n, m)
     g.set_nodes(synth.uniform_cap(load, m), np.ones(m, np.uint8))
     g.set_objects(n, load, aff)
     rec = {"rows": n}
     for code, name in ((2, "plain"), (1, "nt")):
-        rio_gp.lib().rio_gp_debug_set_scan_nt(code)
+        rio_gp.lab_lib().rio_gp_debug_set_scan_nt(code)
         for _ in range(5):
             g.solve_profiled()
         sc = [g.solve_profiled()[0] for _ in range(30)]
         rec["k_scan_%s_GBps" % name] = 16 * n / float(np.median(sc)) / 1e6
-    rio_gp.lib().rio_gp_debug_set_scan_nt(0)
+    rio_gp.lab_lib().rio_gp_debug_set_scan_nt(0)
     for mode, name, nb in ((0, "3r1w", 16), (5, "3r1w_8192wg", 16), (7, "3r1w_ntload", 16), (8, "3r1w_ntstore", 16),
                            (9, "3r1w_ntboth", 16), (3, "read3", 12), (4, "copy", 8), (2, "3r1w_wavecontig", 16)):
         ms = g.stream_probe(mode, 10)

@@ -8,7 +8,7 @@ for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import rio_gp, synth
 cfg = synth.config(sys.argv[1] if len(sys.argv) > 1 else "c3", n_override=int(sys.argv[2]) if len(sys.argv) > 2 else None)
-g = rio_gp.GpuPlacement(cfg["n"], cfg["m"])
+g = rio_gp.LabPlacement(cfg["n"], cfg["m"])
 g.set_nodes(cfg["cap"], cfg["alive"])
 g.set_objects(cfg["n"], cfg["load"], cfg["aff"])
 for _ in range(30):

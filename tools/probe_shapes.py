@@ -7,7 +7,7 @@ import sys
 sys.path[:0]=["rio-rs_amd","oracle"]
 import rio_gp, synth, numpy as np
 cfg=synth.config("c3"); n=cfg["n"]
-g=rio_gp.GpuPlacement(n,cfg["m"]); g.set_nodes(cfg["cap"],cfg["alive"]); g.set_objects(n,cfg["load"],cfg["aff"])
+g=rio_gp.LabPlacement(n,cfg["m"]); g.set_nodes(cfg["cap"],cfg["alive"]); g.set_objects(n,cfg["load"],cfg["aff"])
 for rnd in range(3):
     for mode,name in ((2,"wavecontig 256x1024"),(10,"wavecontig 512x1024"),(1,"blocktile 256x1024"),(11,"blocktile 512x1024"),(0,"gridstride 2048x256"),(5,"gridstride 8192x256")):
         ms=g.stream_probe(mode,30); print(rnd,name,"%.2f us %.0f GB/s"%(ms*1e3,16*n/ms/1e6))

@@ -14,7 +14,7 @@ phase = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 cfg = synth.config("c3")
 n, m = cfg["n"], cfg["m"]
-g = rio_gp.GpuPlacement(n, m)
+g = rio_gp.LabPlacement(n, m)
 g.set_nodes(cfg["cap"], cfg["alive"])
 g.set_objects(n, cfg["load"], cfg["aff"])
 if phase == "fast":                      # k_scan<.., TPI 2>, k_resolve
@@ -43,7 +43,7 @@ elif phase in ("crud", "crud_plain", "pp", "lookup_seq"):
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from hipbuf import DevBuf
-    L, h, vp = rio_gp.lib(), g.handle, C.c_void_p
+    L, h, vp = rio_gp.lab_lib(), g.handle, C.c_void_p
     idx = DevBuf((synth.r(np.arange(n, dtype=np.uint64), 7) % np.uint64(n)).astype(np.uint32))
     node = DevBuf(synth.warm_assign(n, m, stream=8))
     outb, flg = DevBuf(nbytes=4 * n), DevBuf(nbytes=4 * n)

@@ -19,7 +19,7 @@ out = []
 for m in ms_:
     aff = synth.affinity(nmax, m)
     for n in rows:
-        g = rio_gp.GpuPlacement(n, m)
+        g = rio_gp.LabPlacement(n, m)
         l, a = np.ascontiguousarray(load[:n]), np.ascontiguousarray(aff[:n])
         g.set_nodes(synth.uniform_cap(l, m), np.ones(m, np.uint8))
         g.set_objects(n, l, a)

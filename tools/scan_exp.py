@@ -6,7 +6,7 @@ import numpy as np
 import rio_gp, synth
 cfg = synth.config("c3")
 n, m = cfg["n"], cfg["m"]
-g = rio_gp.GpuPlacement(n, m)
+g = rio_gp.LabPlacement(n, m)
 g.set_nodes(cfg["cap"], cfg["alive"])
 g.set_objects(n, cfg["load"], cfg["aff"])
 g.set_assign(synth.warm_assign(n, m))

@@ -1,9 +1,7 @@
 #!/usr/bin/env python3
 """Workload for profiling the fix-up path (cut + water-fill): config-5 churn ticks, the contended cold solve
-and the skewed cold solve.  Usage: slowpath_workload.py [churn|contended|skew] [reps] [auto|always|never (packed)] [default|legacy|fusedk|fused|spec]
-  default = split cut fix-up (k_cut_find + k_cut_apply_rank), speculative enqueue after a solve that needed the fix-up (what the library does)
-  legacy  = the unfused launch chain, no speculation;  fusedk = ONE fused cut launch (k_cut_fused), speculation as default;
-  fused = k_cut_fused, never speculative;  spec = k_cut_fused, always speculative"""
+and the skewed cold solve.  Usage: slowpath_workload.py [churn|contended|skew] [reps] [auto|always|never (packed)] [default|nospec|spec]
+  default = speculative enqueue after a solve that needed the fix-up (what the library does); nospec / spec = never / always"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -14,12 +12,12 @@ which = sys.argv[1] if len(sys.argv) > 1 else "churn"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = synth.config("c3")
 n, m = cfg["n"], cfg["m"]
-g = rio_gp.GpuPlacement(n, m)
+g = rio_gp.LabPlacement(n, m)
 if len(sys.argv) > 3:
     g.set_compact(sys.argv[3])   # auto | always | never
 fx = sys.argv[4] if len(sys.argv) > 4 else "default"
 if fx != "default":
-    g.set_fixup(fused=(fx != "legacy"), speculate={"legacy": "never", "fusedk": "auto", "fused": "never", "spec": "always"}[fx])
+    g.set_speculate({"nospec": "never", "spec": "always"}[fx])
 res = {"which": which, "reps": reps, "n": n, "m": m, "compact": sys.argv[3] if len(sys.argv) > 3 else "auto", "fixup": fx}
 if which == "churn":
     g.set_nodes(cfg["cap"], cfg["alive"])

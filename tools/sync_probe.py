@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd")):
     sys.path.insert(0, p)
 import rio_gp
-g = rio_gp.GpuPlacement(1 << 16, 64)
+g = rio_gp.LabPlacement(1 << 16, 64)
 out = {}
 for mode, name in ((20, "launch + hipStreamSynchronize, request in kernel arguments"),
                    (21, "launch + spin on the pinned word, request in kernel arguments"),
