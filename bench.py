@@ -2,10 +2,13 @@
 """bench.py — placement decisions/sec + achieved HBM GB/s of the whole-table solve.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-A "step" is one whole-table solve (every row of the table gets a placement decision), inputs resident in HBM.
+A "step" is one whole-table pass of the placement solver (every row of the table gets a decision), inputs resident in HBM.
 
-  N = 1   BASELINE.json config 3 (the configuration the metric is quoted on): 10 M objects x 1 024 nodes, Zipf(1.1)
-          loads, cold start (every object pending); step = rio_gp_solve_async (k_scan + k_resolve).
+  N = 1   BASELINE.json config 3 (the configuration the metric is quoted on): 10 M objects x 1 024 nodes, Zipf(1.1) loads.
+          value = a pipelined stream of COMMITTED ticks (rio_gp_tick_async: k_scan + k_resolve (+ fix-up) + commit), starting
+          from the cold table.  The same line carries the un-committed cold re-solves (round 2's headline, named as such), the
+          synchronous dependent tick, config 2, config 4 on one GPU and the config-5 churn stream (synchronous + pipelined,
+          per-kernel spans, parity of the whole 110-tick stream against the oracle chain).
   N > 1   BASELINE.json config 4 as north_star states it: ONE table of 100 M objects x 4 096 nodes, rows sharded over
           the N ranks (12.5 M rows per GPU at N = 8), "scaling": "strong"; the weak-scaled config 3 (10 M rows per
           GPU of one N x 10 M-row table) is measured in the same run and reported under "weak_config3".
@@ -13,9 +16,10 @@ A "step" is one whole-table solve (every row of the table gets a placement decis
   value        = decisions of all ranks / max-over-ranks wall time of the K steps
   parity       = the solved assignment column, the per-node `used` vector and the counters compared bit for bit with
                  the CPU oracle's solve of the same table, in this very run (exit code 3 on a mismatch)
-  roofline     = k_scan (the streaming kernel, >90 % of a step): algorithmic 16 B/decision (read
-                 cur+load+aff, write assign) / its per-launch HIP-event time; `traffic` = HBM bytes per launch from
-                 rocprofv3 PMC passes run by this script (traffic_source says how they were obtained)
+  roofline     = k_scan (the streaming kernel, >85 % of a step): algorithmic 16 B/decision (read
+                 cur+load+aff, write assign) / its per-launch HIP-event time, on the cold table; `traffic` = HBM bytes per
+                 launch from rocprofv3 PMC passes run by this script; frac_dram_bound / frac_committed_tick /
+                 frac_dependent_tick = the same ratio for the whole step beyond the Infinity Cache and for whole ticks
   cpu_baseline = the CPU oracle port of the reference's per-object path, on a bounded sample
 """
 import argparse
@@ -67,8 +71,10 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run comparison with the CPU oracle")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline.traffic falls back to profiles/)")
     ap.add_argument("--no-c4", action="store_true", help="N=1: skip the config-4-on-one-GPU data point (100 M x 4 096)")
+    ap.add_argument("--no-c2", action="store_true", help="N=1: skip the config-2 record (1 M x 256)")
+    ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 record (10 % churn per tick, 110 ticks + oracle replay)")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaled config-3 second measurement")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "round2_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "round3_traffic.json"),
                     help="fallback for roofline.traffic when the in-run PMC passes are skipped or fail")
     return ap.parse_args()
 
@@ -214,16 +220,19 @@ def pmc_traffic_in_run(n_rows, timeout=240):
 
 # ------------------------------------------------------------------------------------------------ config 5 (churn)
 
-def bench_churn(a, g, cfg, saved_stdout):
+def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
     """BASELINE.json config 5: the config-3 table, warm; every step = one liveness push (10 % of the nodes down, the
     previous casualties back) + one committed whole-table tick (evict + re-place through the fix-up path).  Two timed
-    streams over the same masks: synchronous ticks (the host reads every tick's counters before the next push) and, when
-    the library offers it, pipelined ticks (rio_gp_tick_async: the counters are read back later; results identical)."""
+    streams over the same masks: synchronous ticks (the host reads every tick's counters before the next push) and pipelined
+    ticks (rio_gp_tick_async: the counters are read back later; results identical).  Parity: the oracle replays the whole
+    stream at full size.  Returns the record (also used as the `config5_churn` entry of the default line)."""
     import pyoracle
     import synth
+    steps = steps or a.steps
+    warmup = a.warmup if warmup is None else warmup
     n, m = cfg["n"], cfg["m"]
     warm = synth.warm_assign(n, m)
-    total = a.warmup + a.steps
+    total = warmup + steps
     masks = [synth.churn_mask(m, 2 + k) for k in range(total)]
 
     def reset():
@@ -232,21 +241,20 @@ def bench_churn(a, g, cfg, saved_stdout):
         g.tick()
 
     reset()
-    for k in range(a.warmup):
+    for k in range(warmup):
         g.set_alive_all(masks[k])
         g.tick()
     g.sync()
     moved = slow = 0
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        g.set_alive_all(masks[a.warmup + k])
+    for k in range(steps):
+        g.set_alive_all(masks[warmup + k])
         st = g.tick()
         moved += st["claimed"] + st["spilled"]
         slow += st["slow_path"]
     dt = time.perf_counter() - t0
     final_sync = g.get_assign()
     used_sync = g.get_nodes()[2]
-    # parity of the WHOLE committed stream, at full size: the oracle replays the same masks from the same warm table
     parity = None
     if not a.no_parity:
         ref = warm.copy()
@@ -259,44 +267,77 @@ def bench_churn(a, g, cfg, saved_stdout):
                   "against": "oracle/placement_oracle.c orc_tick chained over the same %d liveness masks; assignment column, "
                              "`used` and the last tick's counters after the final tick" % total,
                   "oracle_seconds": time.perf_counter() - t1}
-    piped = None
-    if hasattr(g, "tick_async"):
-        reset()
-        for k in range(a.warmup):
-            g.set_alive_all(masks[k])
-            g.tick_async()
-        g.tick_wait()
-        g.sync()
-        t0 = time.perf_counter()
-        for k in range(a.steps):
-            g.set_alive_all(masks[a.warmup + k])
-            g.tick_async()
-        sts = g.tick_wait()
-        dtp = time.perf_counter() - t0
-        piped = {"ms_per_step": dtp / a.steps * 1e3, "value": n * a.steps / dtp, "unit": "decisions/s",
-                 "frac_of_roofline": ALGO_BYTES_PER_DECISION * n * a.steps / dtp / 1e9 / HBM_PEAK_GBPS,
-                 "equal_to_synchronous_stream": bool(np.array_equal(g.get_assign(), final_sync)) and
-                 bool(np.array_equal(g.get_nodes()[2], used_sync)) and sts[-1] == st,
-                 "step": "rio_gp_set_alive_all + rio_gp_tick_async: nothing waits on the host between ticks, every tick's "
-                         "counters are read afterwards (rio_gp_tick_wait)"}
+    reset()
+    for k in range(warmup):
+        g.set_alive_all(masks[k])
+        g.tick_async()
+    g.tick_wait()
+    g.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        g.set_alive_all(masks[warmup + k])
+        g.tick_async()
+    sts = g.tick_wait()
+    dtp = time.perf_counter() - t0
+    frac = lambda sec: ALGO_BYTES_PER_DECISION * n * steps / sec / 1e9 / HBM_PEAK_GBPS
+    piped = {"ms_per_tick": dtp / steps * 1e3, "value": n * steps / dtp, "unit": "decisions/s", "frac_of_roofline": frac(dtp),
+             "equal_to_synchronous_stream": bool(np.array_equal(g.get_assign(), final_sync)) and
+             bool(np.array_equal(g.get_nodes()[2], used_sync)) and sts[-1] == st,
+             "step": "rio_gp_set_alive_all + rio_gp_tick_async: nothing waits on the host between ticks, every tick's "
+                     "counters are read afterwards (rio_gp_tick_wait)"}
+    spans = None
+    try:  # where a tick's time goes, measured by the kernels themselves (lab build: wall_clock64 phase traces)
+        gl = rio_gp.LabPlacement(n, m, device=local_rank)
+        gl.set_nodes(cfg["cap"], cfg["alive"])
+        gl.set_objects(n, cfg["load"], cfg["aff"])
+        gl.set_assign(warm)
+        gl.tick()
+        gl.ktrace(True)
+        for k in range(6):
+            gl.set_alive_all(masks[k % total])
+            gl.tick()
+        names = {3: "k_scan<COMPACT>", 0: "k_resolve<SEARCH>", 1: "k_fill round 0", 2: "k_fill round 1"}
+        tabs = {t: gl.ktrace(True, t).astype(np.int64) for t in names}
+        gl.ktrace(False)
+        gl.close()
+        base = min(int(t[t[:, 0] > 0][:, 0].min()) for t in tabs.values() if (t[:, 0] > 0).any())
+        spans = {names[k]: {"first_start_us": round((int(t[t[:, 0] > 0][:, 0].min()) - base) / 100.0, 1),
+                            "last_end_us": round((int(t[:, 7].max()) - base) / 100.0, 1)}
+                 for k, t in tabs.items() if (t[:, 0] > 0).any()}
+    except Exception as e:  # measurement aid only
+        spans = {"error": repr(e)}
+    return {
+        "workload": "config 5: %d objects x %d nodes, Zipf(1.1) load, cap 1.25x, warm; per tick 10 %% of the nodes flip and one "
+                    "committed tick evicts and re-places their objects (~1 M rows, hundreds of cut nodes)" % (n, m),
+        "ticks": steps, "warmup": warmup, "slow_path_ticks": slow,
+        "synchronous": {"ms_per_tick": dt / steps * 1e3, "value": n * steps / dt, "unit": "decisions/s", "frac_of_roofline": frac(dt),
+                        "step": "rio_gp_set_alive_all + rio_gp_tick (the host reads every tick's counters)"},
+        "pipelined": piped, "objects_moved_per_s": moved / dt, "stats_last_tick": st, "parity": parity,
+        "kernel_spans_on_device_us": spans,
+        "launches_per_tick": "k_store_words (liveness) + k_scan<COMPACT> + k_resolve<SEARCH> + k_fill (round 0) + k_fill (round 1)",
+    }
+
+
+def bench_churn(a, g, cfg, saved_stdout, rio_gp, local_rank):
+    """--workload c5: config 5 as the bench line of its own."""
+    rec = churn_record(a, g, cfg, rio_gp, local_rank)
+    n = cfg["n"]
     out = {
-        "metric": "placement decisions/sec, 10M objects x 1 024 nodes with 10 % node-failure churn per tick", "value": n * a.steps / dt,
-        "unit": "decisions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "config 5: %d objects x %d nodes, Zipf(1.1) load, cap 1.25x, warm; per step 10 %% of the nodes "
-                               "flip and one committed tick evicts and re-places their objects" % (n, m),
-                   "step": "rio_gp_set_alive_all + rio_gp_tick (synchronous: the host reads every tick's counters)",
-                   "slow_path_steps": slow},
-        "objects_moved_per_s": moved / dt, "stats_last_step": st, "parity": parity, "pipelined": piped,
-        "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_DECISION * n * a.steps / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": ALGO_BYTES_PER_DECISION * n * a.steps / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                     "traffic_source": "not measured for this workload (profiles/ holds the per-kernel PMC summaries of the fix-up path)",
-                     "kernel": "whole tick (dependent launches + host turn-around; latency-bound, DESIGN.md section 5)"},
+        "metric": "placement decisions/sec, 10M objects x 1 024 nodes with 10 % node-failure churn per tick",
+        "value": rec["pipelined"]["value"], "unit": "decisions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": rec["pipelined"]["ms_per_tick"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": rec["workload"], "step": rec["pipelined"]["step"], "slow_path_steps": rec["slow_path_ticks"]},
+        "config5_churn": rec, "parity": rec["parity"],
+        "roofline": {"bound": "hbm", "achieved": ALGO_BYTES_PER_DECISION * rec["pipelined"]["value"] / 1e9, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": rec["pipelined"]["frac_of_roofline"], "traffic": None,
+                     "traffic_source": "not measured for this workload (profiles/ holds the per-kernel summaries of the fix-up path)",
+                     "kernel": "whole committed tick (5 dependent launches; latency-bound, DESIGN.md section 5)"},
     }
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
-    if parity is not None and not parity["equal"]:
+    if rec["parity"] is not None and not rec["parity"]["equal"]:
         sys.exit(3)
 
 
@@ -516,25 +557,58 @@ def main():
     if workload == "c3w":
         g.set_assign(cfg["cur"])
     if workload == "c5":
-        return bench_churn(a, g, cfg, saved_stdout)
+        return bench_churn(a, g, cfg, saved_stdout, rio_gp, local_rank)
 
+    # ---- (1) the headline: a pipelined stream of COMMITTED ticks (rio_gp_tick_async: solve + fix-up if needed + commit, each
+    #      tick consuming the previous one's table; counters read afterwards).  The stream starts from the cold table (tick 1:
+    #      every object claims its requester), the K timed steps follow W warm-ups: every row gets its decision every tick.
+    for _ in range(a.warmup):
+        g.tick_async()
+    if a.warmup:
+        g.tick_wait()
+    dt, gpu_ms, sts, _ = timed_steps(a, g, None, torch, g.tick_async, lambda: (g.tick_wait(), 0))
+    st = sts[-1]
+    n_slow = sum(x["slow_path"] for x in sts)
+    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n
+    total_decisions = n * a.steps
+    # the synchronous form of the same tick (the host reads every tick's counters before the next one)
+    dep = None
+    try:
+        g.tick()
+        g.sync()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            g.tick()
+        dep = (time.perf_counter() - t0) / 100 * 1e3
+    except Exception:
+        dep = None
+
+    # ---- (2) the cold table, re-solved WITHOUT committing (round 2's headline, kept under its own name: a server never does
+    #      this, but it is the configuration the dominant kernel is profiled on — cold start, every row pending)
+    g.set_assign(cfg["cur"])
     for _ in range(a.warmup):
         g.solve_async()
     if a.warmup:
         g.solve_wait()
-    dt, gpu_ms, st, n_slow = timed_steps(a, g, None, torch, g.solve_async, g.solve_wait)
-    assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n
-    total_decisions = n * a.steps
+    g.sync()
+    t0 = time.perf_counter()
+    g.timer_begin()
+    for _ in range(a.steps):
+        g.solve_async()
+    cold_gpu_ms = g.timer_end()
+    cst, cold_slow = g.solve_wait()
+    g.sync()
+    cold_dt = time.perf_counter() - t0
 
     # per-launch duration of the dominant kernel, HIP events on the library's own stream
     scan_ms, res_ms = [], []
-    if n_slow == 0:
+    if cold_slow == 0:
         for _ in range(max(10, min(a.steps, 100))):
             s_ms, r_ms = g.solve_profiled()
             scan_ms.append(s_ms)
             res_ms.append(r_ms)
     probe = None
-    if n_slow == 0:
+    if cold_slow == 0:
         try:  # what this chip's memory system gives a plain grid-stride kernel with the same 3-in/1-out mix (lab build)
             gl = rio_gp.LabPlacement(n, m, device=local_rank)
             gl.set_objects(n, cfg["load"], cfg["aff"])
@@ -545,10 +619,10 @@ def main():
         except Exception as e:  # measurement aid only
             probe = {"error": str(e)}
     cold = None
-    if n_slow == 0 and not a.no_cold and workload == "c3":
+    if cold_slow == 0 and not a.no_cold and workload == "c3":
         # The headline table (160 MB of columns) fits the 256 MiB Infinity Cache, so repeated solves are partly served
         # by it.  Same kernel, same per-row inputs tiled 4x (640 MB of columns, capacities scaled): every launch streams
-        # from HBM.  Reported next to the headline, never instead of it: kernel-only AND whole-step (k_scan + k_resolve).
+        # from HBM.  Kernel-only AND whole-step (k_scan + k_resolve) AND committed ticks.
         try:
             k = 4
             loadk, affk = np.tile(cfg["load"], k), np.tile(cfg["aff"], k)
@@ -571,18 +645,32 @@ def main():
                 gb.solve_async()
             wms = gb.timer_end() / 30
             gb.solve_wait()
+            for _ in range(3):
+                gb.tick_async()
+            gb.tick_wait()
+            gb.sync()
+            gb.timer_begin()
+            for _ in range(30):
+                gb.tick_async()
+            tms = gb.timer_end() / 30
+            gb.tick_wait()
             gb.close()
             cms = float(np.mean(cs))
+            fr = lambda ms_: ALGO_BYTES_PER_DECISION * k * n / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS
             cold = {"rows": k * n, "column_bytes": 16 * k * n, "kernel_ms": cms,
-                    "achieved": ALGO_BYTES_PER_DECISION * k * n / (cms * 1e-3) / 1e9, "unit": "GB/s",
-                    "frac": ALGO_BYTES_PER_DECISION * k * n / (cms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                    "whole_step_ms": wms, "whole_step_achieved": ALGO_BYTES_PER_DECISION * k * n / (wms * 1e-3) / 1e9,
-                    "whole_step_frac": ALGO_BYTES_PER_DECISION * k * n / (wms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "achieved": ALGO_BYTES_PER_DECISION * k * n / (cms * 1e-3) / 1e9, "unit": "GB/s", "frac": fr(cms),
+                    "whole_step_ms": wms, "whole_step_frac": fr(wms), "committed_tick_ms": tms, "committed_tick_frac": fr(tms),
                     "stream_probe_GBps": ALGO_BYTES_PER_DECISION * k * n / pm / 1e6,
                     "note": "the headline rows tiled 4x: beyond the 256 MiB Infinity Cache; kernel = k_scan alone (dispatch events), "
-                            "whole step = k_scan + k_resolve back to back (30 pipelined steps between two events)"}
+                            "whole step = k_scan + k_resolve back to back, committed tick = rio_gp_tick_async (30 pipelined steps "
+                            "between two events each)"}
         except Exception as e:  # measurement aid only
             cold = {"error": str(e)}
+    parity = None
+    t_orc = None
+    if not a.no_parity:
+        g.set_assign(cfg["cur"])
+        parity, t_orc = parity_single(g, cfg)   # leaves the table committed (warm)
     c4one = None
     if not a.no_c4 and workload == "c3" and not a.objects:
         # BASELINE config 4 on ONE GPU (the N=1 point of the strong-scaling curve): 100 M x 4 096, parity at size
@@ -602,36 +690,77 @@ def main():
             t4 = (time.perf_counter() - t0) / 20
             sc4 = [g4.solve_profiled()[0] for _ in range(10)] if slow4 == 0 else []
             par4 = None if a.no_parity else parity_single(g4, c4)[0]
+            for _ in range(2):
+                g4.tick_async()
+            g4.tick_wait()
+            g4.sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                g4.tick_async()
+            g4.tick_wait()
+            tt4 = (time.perf_counter() - t0) / 10
             g4.close()
-            c4one = {"workload": "config 4 on one GPU: %d objects x %d nodes, Zipf(1.1), cap 1.25x, cold" % (c4["n"], c4["m"]),
-                     "value": c4["n"] / t4, "unit": "decisions/s", "ms_per_step": t4 * 1e3, "slow_path_steps": slow4,
+            fr4 = lambda sec: ALGO_BYTES_PER_DECISION * c4["n"] / sec / 1e9 / HBM_PEAK_GBPS
+            c4one = {"workload": "config 4 on one GPU: %d objects x %d nodes, Zipf(1.1), cap 1.25x" % (c4["n"], c4["m"]),
+                     "committed_tick": {"value": c4["n"] / tt4, "unit": "decisions/s", "ms_per_tick": tt4 * 1e3, "frac": fr4(tt4)},
+                     "cold_resolve_uncommitted": {"value": c4["n"] / t4, "unit": "decisions/s", "ms_per_step": t4 * 1e3,
+                                                  "frac": fr4(t4), "slow_path_steps": slow4},
                      "k_scan_ms": float(np.mean(sc4)) if sc4 else None,
-                     "k_scan_frac": (ALGO_BYTES_PER_DECISION * c4["n"] / (float(np.mean(sc4)) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if sc4 else None,
-                     "whole_step_frac": ALGO_BYTES_PER_DECISION * c4["n"] / t4 / 1e9 / HBM_PEAK_GBPS, "parity": par4}
+                     "k_scan_frac": fr4(float(np.mean(sc4)) * 1e-3) if sc4 else None, "parity": par4}
             del c4
         except Exception as e:  # measurement aid only
             c4one = {"error": repr(e)}
-    # a dependent stream of COMMITTED ticks over the same table (each tick consumes the previous tick's commit and the
-    # host reads its counters): the un-pipelined price of a step
-    dep = None
-    parity = None
-    t_orc = None
-    if not a.no_parity:
-        parity, t_orc = parity_single(g, cfg)   # leaves the table committed (warm)
-    try:
-        g.tick()
-        g.sync()
-        t0 = time.perf_counter()
-        for _ in range(100):
-            g.tick()
-        dep = (time.perf_counter() - t0) / 100 * 1e3
-    except Exception:
-        dep = None
+    c2rec = None
+    if not a.no_c2 and workload == "c3" and not a.objects:
+        # BASELINE config 2: 1 M x 256, load 1, cap 4 883, cold start — parity at size + the same three rates
+        try:
+            c2 = synth.config("c2")
+            g2 = rio_gp.GpuPlacement(c2["n"], c2["m"], device=local_rank)
+            g2.set_nodes(c2["cap"], c2["alive"])
+            g2.set_objects(c2["n"], c2["load"], c2["aff"])
+            par2 = None if a.no_parity else parity_single(g2, c2)[0]
+            g2.set_assign(c2["cur"])
+            for _ in range(10):
+                g2.solve_async()
+            g2.solve_wait()
+            g2.sync()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                g2.solve_async()
+            st2, slow2 = g2.solve_wait()
+            t2 = (time.perf_counter() - t0) / 200
+            sc2 = [g2.solve_profiled()[0] for _ in range(50)] if slow2 == 0 else []
+            for _ in range(10):
+                g2.tick_async()
+            g2.tick_wait()
+            g2.sync()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                g2.tick_async()
+            g2.tick_wait()
+            tt2 = (time.perf_counter() - t0) / 200
+            g2.close()
+            fr2 = lambda sec: ALGO_BYTES_PER_DECISION * c2["n"] / sec / 1e9 / HBM_PEAK_GBPS
+            c2rec = {"workload": "config 2: %d objects x %d nodes, load 1, cap %d (uniform), cold start" % (c2["n"], c2["m"], int(c2["cap"][0])),
+                     "committed_tick": {"value": c2["n"] / tt2, "unit": "decisions/s", "ms_per_tick": tt2 * 1e3, "frac": fr2(tt2)},
+                     "cold_resolve_uncommitted": {"value": c2["n"] / t2, "unit": "decisions/s", "ms_per_step": t2 * 1e3,
+                                                  "frac": fr2(t2), "slow_path_steps": slow2},
+                     "k_scan_ms": float(np.mean(sc2)) if sc2 else None,
+                     "k_scan_frac": fr2(float(np.mean(sc2)) * 1e-3) if sc2 else None,
+                     "note": "16 MB of columns: every launch is a handful of microseconds — latency, not bandwidth", "parity": par2}
+        except Exception as e:  # measurement aid only
+            c2rec = {"error": repr(e)}
+    c5rec = None
+    if not a.no_c5 and workload == "c3" and not a.objects:
+        try:
+            c5rec = churn_record(a, g, cfg, rio_gp, local_rank, steps=100, warmup=10)
+        except Exception as e:
+            c5rec = {"error": repr(e)}
 
     scan_avg = float(np.mean(scan_ms)) if scan_ms else None
     achieved = (ALGO_BYTES_PER_DECISION * n / (scan_avg * 1e-3) / 1e9) if scan_avg else None
     traffic, traffic_source, traffic_detail = None, "not measured", None
-    if not a.no_pmc and n_slow == 0 and workload == "c3":
+    if not a.no_pmc and cold_slow == 0 and workload == "c3":
         doc, src = pmc_traffic_in_run(n)
         if doc is not None:
             traffic, traffic_source = doc["hbm_bytes_per_launch"], src
@@ -642,22 +771,30 @@ def main():
         tj = json.load(open(a.traffic_json))
         if tj.get("n_rows") == n:  # measured for this row count only
             traffic = tj.get("hbm_bytes_per_launch")
-            traffic_source += "; value replayed from %s (rocprofv3 PMC passes of an earlier run of this build, tools/gpu_round.sh)" % \
+            traffic_source += "; value replayed from %s (rocprofv3 PMC passes of an earlier run of this build)" % \
                 os.path.relpath(a.traffic_json, ROOT)
-    whole = ALGO_BYTES_PER_DECISION * n / (gpu_ms / a.steps * 1e-3) / 1e9
+    fr = lambda sec: ALGO_BYTES_PER_DECISION * n / sec / 1e9 / HBM_PEAK_GBPS
+    tick_s = dt / a.steps
     out = {
         "metric": "placement decisions/sec + achieved HBM GB/s, 10M objects x 1 024 nodes",
         "value": total_decisions / dt, "unit": "decisions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": tick_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "config 3: %d objects x %d nodes, Zipf(1.1) load, cap 1.25x, cold start "
-                               "(all pending)" % (n, m) if workload == "c3" else workload,
+        "config": {"workload": "config 3: %d objects x %d nodes, Zipf(1.1) load, cap 1.25x; a stream of committed ticks that "
+                               "starts from the cold table (all pending)" % (n, m) if workload == "c3" else workload,
                    "objects_per_gpu": n, "nodes": m, "parallelism": "rows sharded x1",
-                   "step": "rio_gp_solve_async = k_scan + k_resolve on one stream; verdicts read at the end",
+                   "step": "rio_gp_tick_async = k_scan + k_resolve (+ the fix-up, guarded on the device) + commit, one stream, nothing "
+                           "waits on the host between ticks; every tick's counters are read at the end",
                    "exchange": None, "slow_path_steps": n_slow},
         "gpu_ms_per_step_events": gpu_ms / a.steps,
+        "committed_tick_frac": fr(tick_s),
         "dependent_tick_ms": dep,
-        "dependent_tick_frac": (ALGO_BYTES_PER_DECISION * n / (dep * 1e-3) / 1e9 / HBM_PEAK_GBPS) if dep else None,
+        "dependent_tick_frac": fr(dep * 1e-3) if dep else None,
+        "cold_resolve_uncommitted": {"value": n * a.steps / cold_dt, "unit": "decisions/s", "ms_per_step": cold_dt / a.steps * 1e3,
+                                     "gpu_ms_per_step_events": cold_gpu_ms / a.steps, "frac": fr(cold_dt / a.steps),
+                                     "slow_path_steps": cold_slow,
+                                     "note": "round 2's headline: rio_gp_solve_async of the SAME cold table back to back, never committed "
+                                             "(k_scan + k_resolve per step) — what the kernel figures below are profiled on, not what a server does"},
         "parity": parity,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
@@ -666,10 +803,18 @@ def main():
                      "kernel_ms_p10_p90": [float(np.percentile(scan_ms, 10)), float(np.percentile(scan_ms, 90))] if scan_ms else None,
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DECISION * n,
                      "resolve_kernel_ms": float(np.mean(res_ms)) if res_ms else None,
+                     "frac_note": "frac = k_scan on the 160 MB table, which fits the 256 MiB Infinity Cache (MALL-assisted); the DRAM-bound "
+                                  "and whole-tick fractions follow",
+                     "frac_dram_bound": cold.get("whole_step_frac") if isinstance(cold, dict) else None,
+                     "frac_dram_bound_kernel": cold.get("frac") if isinstance(cold, dict) else None,
+                     "frac_committed_tick": fr(tick_s),
+                     "frac_committed_tick_dram_bound": cold.get("committed_tick_frac") if isinstance(cold, dict) else None,
+                     "frac_dependent_tick": fr(dep * 1e-3) if dep else None,
                      "frac_of_measured_copy_peak_6290": (achieved / 6290.0) if achieved else None,
-                     "whole_step_achieved_GBps": whole, "whole_step_frac": whole / HBM_PEAK_GBPS,
                      "stream_probe": probe, "beyond_infinity_cache": cold},
+        "config2": c2rec,
         "config4_single_gpu": c4one,
+        "config5_churn": c5rec,
         "stats_last_step": st,
     }
     if not a.no_cpu_baseline:
@@ -683,7 +828,8 @@ def main():
         pass
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
-    bad = [p for p in (parity, (c4one or {}).get("parity")) if p is not None and not p["equal"]]
+    bad = [p for p in (parity, (c4one or {}).get("parity"), (c2rec or {}).get("parity"), (c5rec or {}).get("parity"))
+           if p is not None and not p["equal"]]
     if bad:
         sys.exit(3)
 

@@ -409,11 +409,12 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     if (fx_last) h->sb.fx.seq = seq;
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
-    // Adaptive packed fix-up: when the previous solve left few rows pending (a churn stream: most rows are kept),
+    // Adaptive packed fix-up: when the previous solve left few rows pending — but some: a stream without churn keeps the
+    // plain scan, two tiles in flight — (a churn stream: most rows are kept),
     // k_scan also packs this solve's pending rows per wave, and — if the verdict then asks for the fix-up — the cut
     // and water-fill kernels run over the packed rows only (O(pending) passes instead of O(rows)); results identical.
     const bool compact = h->compact_mode == 1 ||
-                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending * 4 <= h->n && h->n >= 65536);
+                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending > 0 && h->last_pending * 4 <= h->n && h->n >= 65536);
     // Speculative fix-up: when the previous solve needed the fix-up (a churn stream needs it every tick), its kernels
     // are enqueued right behind k_resolve instead of after a host round trip for the verdict.  Every fix-up kernel
     // guards itself on device (the cut search: stats->n_cut; the water-fill rounds: pending-row count), so a solve that
@@ -503,7 +504,7 @@ int tick_async_locked(rio_gp* h) {
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
     const bool compact = h->compact_mode == 1 ||
-                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending * 4 <= h->n && h->n >= 65536);
+                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending > 0 && h->last_pending * 4 <= h->n && h->n >= 65536);
     const u32 k = h->tick_n;
     use_fx_slot(h, 1 + k);
     h->tick_G[k] = h->plan.G;
