@@ -815,7 +815,8 @@ def main():
         "config2": c2rec,
         "config4_single_gpu": c4one,
         "config5_churn": c5rec,
-        "stats_last_step": st,
+        "stats_last_step": st,          # last committed tick of the stream: every row kept where the first tick put it
+        "stats_cold_step": cst,         # the cold table re-solved: every row pending
     }
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample, t_orc)

@@ -227,11 +227,12 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
 struct WordPack { u32 w[256]; };  // 8 192 bits = RIO_GP_MAX_NODES, passed by value as a kernel argument
 void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t s);
 
-// --- place_pending, micro-batch (n <= kSmallBatch): one launch; idx/req/out_* may be mapped host memory; *status = 1
-//     means "needs the general path", nothing was changed ---
-void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
-                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                     u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
+// --- place_pending, batches of up to kOneBatch requests: ONE workgroup, one launch; idx/req/out_* may be mapped host
+//     memory; *status = 1 means "needs the general path", nothing was changed ---
+constexpr int kOneBatch = 4096;
+void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
+                   const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
+                   u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead = nullptr);
@@ -242,6 +243,16 @@ void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const
                        u32* out_flag, hipStream_t s, u32* aff_life = nullptr, unsigned int* ticket = nullptr,
                        u32* done = nullptr, u32 seq = 0, bool flag_bits = true);  // ticket/done/seq: the several-workgroup
                        // completion word (launch_lookup); flag_bits: out_flag holds k_pp_mark_dead's REPLACED bits
+
+// place_pending over a window-sorted batch (big batches): see k_pp_win_gather.  scratch = part_scratch_words(n_obj, n) words.
+bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req);
+void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s);
+void launch_pp_win_gather(const u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
+                          uint2* vrec, u32* vcur, u32* vload, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st,
+                          hipStream_t s);
+void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
+                          const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,
+                          const DevStats* st, hipStream_t s);
 
 size_t scan_lds_bytes(u32 m);
 

@@ -244,11 +244,15 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
                                           const u32 m, const u32* alv, u64* hist, u32* __restrict__ next,
                                           u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt,
                                           const PackOut* pk = nullptr, u64* pk_pos = nullptr, u32* stage = nullptr,
-                                          u32* st_head = nullptr, u32* st_fill = nullptr) {
+                                          u32* st_head = nullptr, u32* st_fill = nullptr,
+                                          const uint4 xv = make_uint4(0, 0, 0, 0)) {
+    // COMPACT == 3 (virtual table of a big place_pending batch): rows are requests, xv = the objects they ask for; a claimant's
+    // optimistic node also goes straight into the REAL assignment column, pk->next[object] (one scattered store per first touch:
+    // the fix-up patches the same rows through the same indices, so no pass carries the decisions back afterwards)
     uint4 ov;
     u64 sp_local = 0;
     u32 any_sp = 0, pm = 0;
-#define RIOGP_ROW(C, A, L, O, E)                                                                       \
+#define RIOGP_ROW(C, A, L, O, E, X)                                                                    \
     {                                                                                                  \
         const bool inr = !CHECK || (i0 + E < wend);                                                    \
         const bool cin = C < m, ain = A < m;                                                           \
@@ -266,14 +270,15 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         if (!VIRT) evict_cnt += (u32)__popcll(__ballot(inr && !kept && C != kNone));                   \
         sp_local += sp ? (u64)L : 0;                                                                   \
         any_sp |= sp;                                                                                  \
-        if (COMPACT) pm |= (u32)(cl | sp) << E;                                                        \
+        if (COMPACT == 1 || COMPACT == 2) pm |= (u32)(cl | sp) << E;                                   \
+        if (COMPACT == 3 && cl) pk->next[X] = A;                                                       \
     }
-    RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0)
-    RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1)
-    RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2)
-    RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3)
+    RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0, xv.x)
+    RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1, xv.y)
+    RIOGP_ROW(cv.z, av.z, lv.z, ov.z, 2, xv.z)
+    RIOGP_ROW(cv.w, av.w, lv.w, ov.w, 3, xv.w)
 #undef RIOGP_ROW
-    if (COMPACT) {  // pending rows of this tile, in index order (lane-major, then element), to the wave's packed cursor
+    if (COMPACT == 1 || COMPACT == 2) {  // pending rows of this tile, in index order (lane-major, then element), to the wave's packed cursor
         const u64 b0 = __ballot(pm & 1u), b1 = __ballot(pm & 2u), b2 = __ballot(pm & 4u), b3 = __ballot(pm & 8u);
         if (b0 | b1 | b2 | b3) {
             const u64 lt = (1ull << (threadIdx.x & 63)) - 1ull;
@@ -366,13 +371,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
+    // COMPACT 3: pko.wcnt = the batch's invalid-entry counter; set -> the virtual table was not built: solve an empty one
+    if (COMPACT == 3 && *reinterpret_cast<const volatile u32*>(pko.wcnt)) wend = wstart;
     const u64 span = wend > wstart ? wend - wstart : 0;
     const u64 wfull = wstart + (span / kTile) * kTile;                  // end of the full tiles
     const u64 wgrp = wstart + (span / (kTile * TPI)) * (kTile * TPI);   // end of the full TPI-tile groups
 
     // first group of loads goes out BEFORE the LDS set-up and its barrier: HBM latency overlaps both
     u64 it = wstart;
-    uint4 cv[TPI], av[TPI], lv[TPI];
+    uint4 cv[TPI], av[TPI], lv[TPI], xv[TPI];  // (xv: COMPACT == 3 only — the objects the rows of a virtual table ask for)
     if (it < wgrp) {
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
@@ -380,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
             cv[q] = ld4<NT>(cur + i);
             av[q] = ld4<NT>(aff + i);
             lv[q] = ld4<NT>(load + i);
+            if (COMPACT == 3) xv[q] = ld4<NT>(pko.idx + i);
         }
     }
 
@@ -418,34 +426,37 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         // loads stay in flight while the current group is processed; on the wave's last iteration the
         // address is clamped to the group being processed (an L1/L2 hit, no HBM traffic, no over-read).
         const u64 pit = nit < wgrp ? nit : it;
-        uint4 cn[TPI], an[TPI], ln[TPI];
+        uint4 cn[TPI], an[TPI], ln[TPI], xn[TPI];
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
             cn[q] = ld4<NT>(cur + i);
             an[q] = ld4<NT>(aff + i);
             ln[q] = ld4<NT>(load + i);
+            if (COMPACT == 3) xn[q] = ld4<NT>(pko.idx + i);
         }
 #pragma unroll
         for (int q = 0; q < TPI; ++q)
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
                                                           m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
-                                                          claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill);
+                                                          claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill,
+                                                          COMPACT == 3 ? xv[q] : make_uint4(0, 0, 0, 0));
         it = nit;
 #pragma unroll
-        for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
+        for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; if (COMPACT == 3) xv[q] = xn[q]; }
     }
     for (; it < wend; it += kTile) {  // leftover full tiles (< TPI) and the ragged last tile of the table
         const u64 i = it + (u64)lane * 4;
         const uint4 c1 = *reinterpret_cast<const uint4*>(cur + i);
         const uint4 a1 = *reinterpret_cast<const uint4*>(aff + i);
         const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
+        const uint4 x1 = COMPACT == 3 ? *reinterpret_cast<const uint4*>(pko.idx + i) : make_uint4(0, 0, 0, 0);
         if (it < wfull)
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                          evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill);
+                                                          evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1);
         else
             scan_tile<VIRT, ALLALIVE, true, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                         evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill);
+                                                         evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1);
     }
     if (COMPACT == 2 && st_fill) {  // what is left in the ring (< 64 records)
         u32 x = st_head + (u32)lane;
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     if (lane == 0) {
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
-        if (COMPACT) pko.wcnt[gw] = (u32)(pk_pos - wstart);
+        if (COMPACT == 1 || COMPACT == 2) pko.wcnt[gw] = (u32)(pk_pos - wstart);
         atomicAdd(&bst[0], kept_cnt);
         atomicAdd(&bst[1], evict_cnt);
         atomicAdd(&bst[2], claim_cnt);
@@ -2348,7 +2359,10 @@ template <bool UPDATE>
 __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32* __restrict__ idx,
                                                      const u32* __restrict__ node, u64 n, u32 nbins, const u32 wshift,
                                                      u32* __restrict__ rec, uint2* __restrict__ rec2,
-                                                     unsigned short* __restrict__ start16, DevStats* st) {
+                                                     unsigned short* __restrict__ start16, DevStats* st, const bool none_ok,
+                                                     u32* __restrict__ host_err = nullptr) {
+    // host_err (optional, mapped host memory): set when the chunk holds an invalid entry, so the caller learns it without a
+    // copy-back — the kernels it has enqueued behind this one look at st->err and do nothing
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* part = reinterpret_cast<u64*>(smem);                 // [16] block-scan partials
     u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins] entries of this chunk per window
@@ -2380,11 +2394,14 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     for (int j = 0; j < 8; ++j) {
         const u64 k = (j < 4 ? k0 : k1) + (u64)(j & 3);
         const bool in = k < hi;
-        const bool ok = in && I[j] < n_obj && (!UPDATE || N[j] == kNone || N[j] < m);
+        const bool ok = in && I[j] < n_obj && (!UPDATE || (none_ok && N[j] == kNone) || N[j] < m);
         rk[j] = ok ? atomicAdd(&hist[I[j] >> wshift], 1u) : 0xFFFFFFFFu;  // the returned count = the entry's rank in its window
         bad += in && !ok;
     }
-    if (bad) atomicAdd(&st->err, (u64)bad);
+    if (bad) {
+        atomicAdd(&st->err, (u64)bad);
+        if (host_err) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
     {   // exclusive scan over the windows: up to 8 per thread
         const u32 per_t = (nbins + kBlock - 1) / kBlock;
@@ -2568,7 +2585,172 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
             if (rel[j]) atomicAdd(&used[j], (u64)0 - rel[j]);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// place_pending, big batches (>= 2^18 requests), partitioned by row window like the CRUD batches above.  A request of the
+// plain kernels (k_pp_mark_dead / elect / gather / scatter / output) makes eight or nine random 4-byte accesses to row-sized
+// arrays — each pulls a 128-byte line through the fabric: 6e9 requests/s for 10 M requests, 2 % of the roofline.  Here the
+// requests are sorted by row window once (k_part_bin, records {row in window | requester, batch position}) and every
+// row-side step works out of LDS, one workgroup per window:
+//   k_pp_win_gather  first request per row (ds_min on the batch position), the row's node and load (reads inside the window's
+//                    64 KB of each column), a requested object on a dead node marks that node for clean_server and counts as
+//                    pending; the virtual-table row {cur | load} — for a later request of the same object {skip | position of
+//                    the first} — leaves as ONE 8-byte store at the request's batch position (the only random access of this
+//                    step; k_pp_split turns the records into the solver's two columns);
+//   (solve)          the same kernels as every solve, over the virtual table in batch-position order — the requesters column
+//                    is the caller's own array; k_scan<COMPACT 3> and the fix-up write every first touch's node straight into
+//                    the real assignment column through the caller's object column (one random store per first touch);
+//   k_pp_win_output  in batch-position order, dense: a first request's answer is its virtual row's `next`, a later request
+//                    reads the first's (one random read per duplicate).
+// Two random accesses per request instead of nine.
+// ------------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void part_walk(const uint2* __restrict__ rec2, const u32 (&pbase)[kPartIters], const u32 (&pcnt)[kPartIters],
+                                          const u32 o16, F body) {
+#pragma unroll
+    for (int i = 0; i < kPartIters; i += kPartFlight) {  // kPartFlight pieces per lane in flight
+        uint2 x[kPartFlight];
+#pragma unroll
+        for (int q = 0; q < kPartFlight; ++q) x[q] = o16 < pcnt[i + q] ? rec2[pbase[i + q] + o16] : make_uint2(0, 0);
+#pragma unroll
+        for (int q = 0; q < kPartFlight; ++q)
+            if (o16 < pcnt[i + q]) body(x[q]);
+    }
+#pragma unroll 1
+    for (int i = 0; i < kPartIters; ++i)  // pieces of more than 16 records
+        for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) body(rec2[pbase[i] + o]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pp_win_gather(const u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
+                                                          u32 m, const u32* __restrict__ alive_bits,
+                                                          const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
+                                                          u32 nchunks, const u32 wshift, uint2* __restrict__ vrec,
+                                                          u32* __restrict__ dead_bits, u32* __restrict__ out_flag,
+                                                          u32* __restrict__ aff_life, const DevStats* __restrict__ st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (st->err) return;  // the binning kernel found an invalid entry: the call fails, nothing is touched
+    const u32 W = 1u << wshift;
+    u32* wpos = reinterpret_cast<u32*>(smem);  // [W] first batch position that asks for the row
+    u32* wreq = wpos + W;                      // [W] its requester (row lifecycle only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
+    const u64 base = (u64)b << wshift;
+    RIOGP_PART_DESCRIPTORS()
+    for (u32 r = tid; r < W; r += kBlock) wpos[r] = kNone;
+    __syncthreads();
+    part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) { atomicMin(&wpos[x.x & (W - 1)], x.y); });
+    __syncthreads();
+    // later requests of an object point at the first (no row is read here: the window's rows are read once, densely, below)
+    part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) {
+        const u32 row = x.x & (W - 1), k = x.y, f = wpos[row];
+        if (f != k) vrec[k] = make_uint2(kSkipMark, f);
+        else if (aff_life) wreq[row] = x.x >> kPartShiftMax;
+    });
+    __syncthreads();
+    // the requested rows of the window, in row order: the first request's virtual-table row {node | load} goes to its batch
+    // position (the one random store of this kernel per object)
+#pragma unroll
+    for (int q = 0; q < kPartRowVecs; ++q) {
+        const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
+        if (r4 >= W || base + r4 >= n_obj) continue;
+        const uint4 wp = *reinterpret_cast<const uint4*>(wpos + r4);
+        if (!__ballot((wp.x & wp.y & wp.z & wp.w) != kNone)) continue;  // nobody asks for any of the wave's 256 rows
+        const uint4 cv = *reinterpret_cast<const uint4*>(assign + base + r4);
+        const uint4 lv = *reinterpret_cast<const uint4*>(load + base + r4);
+#define RIOGP_FIRST(K, C, L, E)                                                                                    \
+        if (K != kNone) {                                                                                          \
+            const bool dead = C < m && !bit_of(alive_bits, C);  /* service.rs:227-237: clean_server of that node */ \
+            if (dead) {                                                                                            \
+                atomicOr(&dead_bits[C >> 5], 1u << (C & 31));                                                      \
+                if (out_flag) out_flag[K] = kFlagReplaced;                                                         \
+            }                                                                                                      \
+            /* row lifecycle: an object from its first request on, home = the requester (a row on a dead node: once */ \
+            /* clean_server has taken it out, k_pp_win_output) */                                                  \
+            if (aff_life && C >= m) aff_life[base + r4 + E] = wreq[r4 + E];                                        \
+            vrec[K] = make_uint2(dead ? kNone : C, L);                                                             \
+        }
+        RIOGP_FIRST(wp.x, cv.x, lv.x, 0)
+        RIOGP_FIRST(wp.y, cv.y, lv.y, 1)
+        RIOGP_FIRST(wp.z, cv.z, lv.z, 2)
+        RIOGP_FIRST(wp.w, cv.w, lv.w, 3)
+#undef RIOGP_FIRST
+    }
+}
+
+// virtual-table records {cur | load} -> the solver's two columns
+__global__ __launch_bounds__(256) void k_pp_split(const uint2* __restrict__ vrec, u64 n, u32* __restrict__ vcur, u32* __restrict__ vload) {
+    const u64 nv = n >> 1;  // two records per lane and load
+    for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += (u64)gridDim.x * 256) {
+        const uint4 x = *reinterpret_cast<const uint4*>(vrec + 2 * v);
+        *reinterpret_cast<uint2*>(vcur + 2 * v) = make_uint2(x.x, x.z);
+        *reinterpret_cast<uint2*>(vload + 2 * v) = make_uint2(x.y, x.w);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { vcur[n - 1] = vrec[n - 1].x; vload[n - 1] = vrec[n - 1].y; }
+}
+
 #undef RIOGP_PART_DESCRIPTORS
+
+// Outputs of a window-sorted batch, four requests per lane.  vnext = the solved virtual table's decisions (k_scan: kept ->
+// the row's node, claimant -> its requester; the fix-up: rejected and spilled rows -> their node, or NONE after the last
+// round); vload of a later request of an object = the batch position of the first.
+__global__ __launch_bounds__(256) void k_pp_win_output(const u32* __restrict__ idx, const u32* __restrict__ req, u64 n,
+                                                       const u32* __restrict__ vcur, const u32* __restrict__ vload,
+                                                       const u32* __restrict__ vnext, const u32* __restrict__ alive_bits,
+                                                       const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
+                                                       u32* __restrict__ out_flag, u32* __restrict__ aff_life,
+                                                       const DevStats* __restrict__ st) {
+    if (st->err) return;  // the batch holds an invalid entry: the call fails
+    const u64 nv = (n + 3) >> 2;
+    for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += (u64)gridDim.x * 256) {
+        const u64 k0 = v * 4;
+        uint4 c, x, r, f, l;
+        if (k0 + 4 <= n) {
+            c = *reinterpret_cast<const uint4*>(vcur + k0);
+            x = *reinterpret_cast<const uint4*>(vnext + k0);
+            r = *reinterpret_cast<const uint4*>(req + k0);
+            l = *reinterpret_cast<const uint4*>(vload + k0);
+            f = out_flag ? *reinterpret_cast<const uint4*>(out_flag + k0) : make_uint4(0, 0, 0, 0);
+        } else {
+            u32 t[5][4] = {};
+            for (u32 e = 0; k0 + e < n; ++e) {
+                t[0][e] = vcur[k0 + e]; t[1][e] = vnext[k0 + e]; t[2][e] = req[k0 + e]; t[3][e] = vload[k0 + e];
+                t[4][e] = out_flag ? out_flag[k0 + e] : 0u;
+            }
+            c = make_uint4(t[0][0], t[0][1], t[0][2], t[0][3]); x = make_uint4(t[1][0], t[1][1], t[1][2], t[1][3]);
+            r = make_uint4(t[2][0], t[2][1], t[2][2], t[2][3]); l = make_uint4(t[3][0], t[3][1], t[3][2], t[3][3]);
+            f = make_uint4(t[4][0], t[4][1], t[4][2], t[4][3]);
+        }
+        uint4 on, of;
+#define RIOGP_OUT(C, X, R, L, F, ON, OF, E)                                                              \
+        if (k0 + E < n) {                                                                                \
+            const u32 nd = C == kSkipMark ? vnext[L] : X;  /* a later request observes the first's */    \
+            u32 fl;                                                                                      \
+            if (nd == kNone) fl = 4u;                                       /* UNPLACED */               \
+            else if (C == kNone) {                                          /* this request placed it */ \
+                const bool claimed = bit_of(alive_bits, R) && (u32)(k0 + E) < cutidx[R];                 \
+                fl = (claimed ? 2u : 3u) | (F & kFlagReplaced);             /* PLACED | SPILLED */       \
+                if (aff_life && (F & kFlagReplaced)) aff_life[idx[k0 + E]] = R;                          \
+            } else fl = nd == R ? 0u : 1u;                                  /* LOCAL | REDIRECT */       \
+            if (C == kNone && nd == kNone) {                                                             \
+                fl |= F & kFlagReplaced;                                                                 \
+                if (aff_life && (F & kFlagReplaced)) aff_life[idx[k0 + E]] = R;                          \
+            }                                                                                            \
+            ON = nd; OF = fl;                                                                            \
+        } else { ON = 0; OF = 0; }
+        RIOGP_OUT(c.x, x.x, r.x, l.x, f.x, on.x, of.x, 0)
+        RIOGP_OUT(c.y, x.y, r.y, l.y, f.y, on.y, of.y, 1)
+        RIOGP_OUT(c.z, x.z, r.z, l.z, f.z, on.z, of.z, 2)
+        RIOGP_OUT(c.w, x.w, r.w, l.w, f.w, on.w, of.w, 3)
+#undef RIOGP_OUT
+        if (k0 + 4 <= n) {
+            *reinterpret_cast<uint4*>(out_node + k0) = on;
+            if (out_flag) *reinterpret_cast<uint4*>(out_flag + k0) = of;
+        } else {
+            const u32 a[4] = {on.x, on.y, on.z, on.w}, b[4] = {of.x, of.y, of.z, of.w};
+            for (u32 e = 0; k0 + e < n; ++e) { out_node[k0 + e] = a[e]; if (out_flag) out_flag[k0 + e] = b[e]; }
+        }
+    }
+}
 
 // clean_server(s) (local.rs:51-58): one coalesced pass, 4 B read per row, 4 B written per evicted row
 // counter: device accumulator of evicted rows.  ticket/host_out (optional): the last workgroup to finish copies the
@@ -2761,143 +2943,139 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
         out_node[k] = nd;
         // the column still holds k_pp_mark_dead's "found on a dead node" bits: the first request of the object keeps its own
         if (out_flag) out_flag[k] = fl | ((keep_mask && vcur[k] == kNone) ? (out_flag[k] & keep_mask) : 0u);
-        pos[i] = kNone;
+        if (pos) pos[i] = kNone;
     }
     if (done) signal_done_grid(ticket, done, seq);  // medium batches: the outputs sit in mapped pinned memory, the host spins
 }
 
 
 // ------------------------------------------------------------------------------------------------
-// place_pending, small batches (n <= kSmallBatch): the whole policy of service.rs:193-298 for a
-// micro-batch in ONE workgroup and ONE launch — request and result arrays are pinned host memory
-// mapped into the device (no staging copies), so a call is a launch and a wait.
-// Handles the common case completely: sticky hits (LOCAL / REDIRECT), first touch on a live
-// requester with room (PLACED), duplicates of one object in the batch.  Anything that needs the
-// heavy machinery — a requested object sitting on a dead node (clean_server of that node), a dead
-// requester, a full requester (water-fill) — makes it return status 1 having changed NOTHING, and
-// the caller runs the general path.  Results are identical either way (same ordered-prefix rule).
+// place_pending, batches of up to kOneBatch requests: the whole policy of service.rs:193-298 in ONE workgroup and ONE
+// launch — request and result arrays are pinned host memory mapped into the device (no staging copies), so a call is a
+// launch and a wait.  Handles the common case completely: sticky hits (LOCAL / REDIRECT), first touch on a live requester
+// with room (PLACED), duplicates of one object in the batch.  Anything that needs the heavy machinery — a requested object
+// sitting on a dead node (clean_server of that node), a dead requester, a requester whose free capacity the batch's first
+// touches exceed (strict prefix cut + water-fill) — makes it return status 1 having changed NOTHING, and the caller runs
+// the general path.  Results are identical either way: when every requester's TOTAL claim load fits its free capacity,
+// every index-ordered prefix fits too, so no ordered walk is needed to know that everybody is admitted.
+//   THREADS x PER requests: 256 x 1 (micro-batches, the reference's one-object-per-request flow) | 1024 x 4.
+//   The first request of an object decides (batch order): an open-addressing table in LDS keyed by the row, atomicMin on
+//   the batch position; later duplicates read the winner's result from the same slot.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 kPpTot = 2048;  // nodes up to which k_pp_small keeps a per-requester running total in LDS (16 KiB)
-__global__ __launch_bounds__(kSmallBatch) void k_pp_small(u32* __restrict__ assign, const u32* __restrict__ load,
-                                                          u32 m, const u64* __restrict__ cap,
-                                                          const u32* __restrict__ alive_bits, u64* __restrict__ used,
-                                                          u32* __restrict__ pos, const u32* __restrict__ idx,
-                                                          const u32* __restrict__ req, u32 n,
-                                                          u32* __restrict__ out_node, u32* __restrict__ out_flag,
-                                                          u32* __restrict__ status, u32* __restrict__ aff_life,
-                                                          u32* done, u32 seq, u32 ninl, uint4 ia, uint4 ib) {
-    __shared__ u32 s_req[kSmallBatch], s_load[kSmallBatch], s_res[kSmallBatch];
-    __shared__ u64 s_tot[kPpTot];  // claim load per requester so far, in batch order (m <= kPpTot)
-    __shared__ u32 s_own[kPpTot];  // claimants of a requester inside the wave being processed: duplicate detection
+constexpr u32 kPpTot = 2048;  // nodes up to which k_pp_one keeps a per-requester claim total in LDS (16 KiB)
+template <int THREADS, int PER>
+__global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, const u32* __restrict__ load, u32 m,
+                                                    const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
+                                                    u64* __restrict__ used, const u32* __restrict__ idx,
+                                                    const u32* __restrict__ req, u32 n, u32* __restrict__ out_node,
+                                                    u32* __restrict__ out_flag, u32* __restrict__ status,
+                                                    u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl, uint4 ia,
+                                                    uint4 ib) {
+    constexpr u32 kSlots = 2u * THREADS * PER;  // power of two
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_tot = reinterpret_cast<u64*>(smem);               // [kPpTot] claim load per requester
+    u32* hkey = reinterpret_cast<u32*>(s_tot + kPpTot);      // [kSlots] row of the slot
+    u32* hpos = hkey + kSlots;                               // [kSlots] first batch position of the row, then its final node
     __shared__ u32 s_general;
-    const u32 k = threadIdx.x;
-    const bool valid = k < n;
-    if (k == 0) s_general = 0;
-    u32 i = 0, r = 0, c = kNone, l = 0;
-    u64 cj = 0, uj = 0;
-    bool r_alive = false;
-    const bool election = n > 1;  // a single request is its object's first request: no scratch round trips
-    if (valid) {
-        i = ninl ? inl_sel(ia, k) : idx[k];
-        r = ninl ? inl_sel(ib, k) : req[k];
-        // everything a request may need is requested at once: the call is a chain of device round trips, not bandwidth
-        c = assign[i];
-        l = load[i];
-        cj = cap[r];
-        uj = used[r];
-        r_alive = bit_of(alive_bits, r);
-        if (election) atomicMin(&pos[i], k);  // the first request of an object decides (batch order)
+    const u32 tid = threadIdx.x;
+    if (tid == 0) s_general = m > kPpTot ? 1u : 0u;
+    for (u32 q = tid; q < kSlots; q += THREADS) { hkey[q] = kNone; hpos[q] = kNone; }
+    for (u32 q = tid; q < kPpTot; q += THREADS) s_tot[q] = 0;
+    u32 i[PER], r[PER], c[PER], l[PER], slot[PER];
+    u64 fre[PER];
+    bool valid[PER], r_alive[PER];
+    // everything a request may need is requested at once: the call is a chain of device round trips, not bandwidth.
+    // A thread takes PER CONSECUTIVE requests (k = PER * tid + q): with PER = 4 its indices and requesters arrive as one
+    // 16-byte read each from the mapped host buffer (PCIe read requests are what a 4 096-request call waits for) and its
+    // results leave as 16-byte stores.
+    uint4 iv4 = make_uint4(0, 0, 0, 0), rv4 = iv4;
+    if (PER == 4 && !ninl) {
+        iv4 = *reinterpret_cast<const uint4*>(idx + 4 * tid);  // (the staging rows are kMidBatch entries long)
+        rv4 = *reinterpret_cast<const uint4*>(req + 4 * tid);
     }
-    __syncthreads();
-    bool first = false, claim = false;
-    u32 winner = k;
-    if (valid) {
-        if (election) winner = __hip_atomic_load(&pos[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        first = winner == k;
-        const bool dead_cur = c < m && !bit_of(alive_bits, c);   // service.rs:227-237 -> clean_server: general path
-        const bool pending = first && c == kNone;
-        claim = pending && r_alive;
-        if (dead_cur || (pending && !claim)) s_general = 1;
-    }
-    s_req[k] = claim ? r : kNone;
-    s_load[k] = claim ? l : 0;
-    __syncthreads();
-    u32 nd = c;
-    // index-ordered inclusive prefix of the loads claiming requester r
-    u64 pre = 0;
-    if (m <= kPpTot) {
-        // Wave by wave, in batch order: the total of the earlier waves comes from a per-requester word in LDS that the last
-        // claimant of each requester in the wave advances; inside a wave a claimant whose requester nobody else of the wave
-        // claims (the usual case) has nothing to add up, otherwise the wave walks its 64 lanes with readlane.  The plain
-        // form below walks the LDS copy of the batch once per request: ~15 us for 256 requests, most of the call.
-        if (claim) { s_tot[r] = 0; s_own[r] = 0; }  // (every claimant of r stores the same zeros)
-        __syncthreads();
-        const int lane = (int)(k & 63u), wave = (int)(k >> 6);
-        const u32 rkey = claim ? r : kNone;
-        const int nwaves = (int)((n + 63u) >> 6);
-        for (int w = 0; w < nwaves; ++w) {
-            if (wave == w && __ballot(claim)) {
-                // do two claimants of this wave share a requester?  each takes a ticket from the requester's counter with a
-                // RETURNING LDS atomic: the second claimant of a requester gets a non-zero ticket, and one such lane is
-                // enough (the walk below is a wave-uniform decision).  A plain store + load of the same word does not work:
-                // the compiler forwards the store to the load (round-2 advisor finding: `shared` was compiled away and
-                // same-requester claimants of one wave were admitted past the requester's capacity).
-                u32 ticket = 0;
-                if (claim) ticket = atomicAdd(&s_own[r], 1u);
-                const bool shared = claim && ticket != 0;
-                u64 inw = claim ? (u64)l : 0ull;
-                bool later = false;
-                if (__ballot(shared)) {  // rare: the prefix over the lower lanes with the same requester, 64 readlane steps
-                    inw = 0;
-                    const int nsrc = (int)n - w * 64 < 64 ? (int)n - w * 64 : 64;  // requests of this wave
-                    for (int src = 0; src < nsrc; ++src) {
-                        const u32 rs = (u32)__builtin_amdgcn_readlane((int)rkey, src);
-                        const u32 ls = (u32)__builtin_amdgcn_readlane((int)l, src);
-                        const bool same = claim && rs == r;
-                        inw += (same && src <= lane) ? (u64)ls : 0ull;
-                        later |= same && src > lane;
-                    }
-                }
-                if (claim) {
-                    pre = s_tot[r] + inw;
-                    if (!later) s_tot[r] = pre;  // the requester's last claimant in this wave: total so far
-                    __hip_atomic_store(&s_own[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // for the later waves
-                }
-            }
-            __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 k = tid * PER + (u32)q;
+        valid[q] = k < n;
+        i[q] = 0; r[q] = 0; c[q] = kNone; l[q] = 0; fre[q] = 0; r_alive[q] = false;
+        if (valid[q]) {
+            i[q] = ninl ? inl_sel(ia, k) : (PER == 4 ? inl_sel(iv4, (u32)q) : idx[k]);
+            r[q] = ninl ? inl_sel(ib, k) : (PER == 4 ? inl_sel(rv4, (u32)q) : req[k]);
+            c[q] = assign[i[q]];
+            l[q] = load[i[q]];
+            const u64 cj = cap[r[q]], uj = used[r[q]];
+            fre[q] = cj > uj ? cj - uj : 0;
+            r_alive[q] = bit_of(alive_bits, r[q]);
         }
-    } else if (claim) {
-        for (u32 q = 0; q <= k; ++q) pre += (s_req[q] == r) ? (u64)s_load[q] : 0ull;
     }
-    if (claim) {
-        const u64 fre = cj > uj ? cj - uj : 0;
-        if (pre <= fre) nd = r;
-        else s_general = 1;  // requester full: water-fill needed
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        slot[q] = (i[q] * 2654435761u) >> 7 & (kSlots - 1);  // (row ids are < 2^31: kNone never is one)
+        if (valid[q]) {
+            for (;;) {
+                const u32 old = atomicCAS(&hkey[slot[q]], kNone, i[q]);
+                if (old == kNone || old == i[q]) break;
+                slot[q] = (slot[q] + 1) & (kSlots - 1);
+            }
+            atomicMin(&hpos[slot[q]], tid * PER + (u32)q);
+        }
     }
-    s_res[k] = nd;
+    __syncthreads();
+    bool first[PER], claim[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        first[q] = false; claim[q] = false;
+        if (valid[q]) {
+            first[q] = hpos[slot[q]] == tid * PER + (u32)q;
+            const bool dead_cur = c[q] < m && !bit_of(alive_bits, c[q]);   // service.rs:227-237 -> clean_server: general path
+            const bool pending = first[q] && c[q] == kNone;
+            claim[q] = pending && r_alive[q];
+            if (dead_cur || (pending && !claim[q])) s_general = 1;
+            if (claim[q] && r[q] < kPpTot) atomicAdd(&s_tot[r[q]], (u64)l[q]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (claim[q] && r[q] < kPpTot && s_tot[r[q]] > fre[q]) s_general = 1;  // the requester cannot take all its first touches
     __syncthreads();
     if (s_general) {  // hand over untouched
-        if (valid && election) pos[i] = kNone;
-        if (k == 0) *status = 1;
+        if (tid == 0) *status = 1;
         signal_done(done, seq);
         return;
     }
-    if (valid) {
-        u32 fl;
-        if (claim) {  // first touch (service.rs:244-252)
-            assign[i] = r;
-            atomicAdd(&used[r], (u64)l);
-            if (aff_life) aff_life[i] = r;  // row lifecycle: the object exists from its first touch, its home is the requester
-            fl = 2u;  // PLACED
+#pragma unroll
+    for (int q = 0; q < PER; ++q)  // the row's final node, for the later requests of the same object in this batch
+        if (valid[q] && first[q]) hpos[slot[q]] = claim[q] ? r[q] : c[q];
+    __syncthreads();
+    u32 ond[PER], ofl[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        ond[q] = kNone; ofl[q] = 0;
+        if (!valid[q]) continue;
+        if (claim[q]) {  // first touch (service.rs:244-252)
+            assign[i[q]] = r[q];
+            atomicAdd(&used[r[q]], (u64)l[q]);
+            if (aff_life) aff_life[i[q]] = r[q];  // row lifecycle: the object exists from its first touch, its home is the requester
+            ond[q] = r[q];
+            ofl[q] = 2u;  // PLACED
         } else {
-            nd = first ? c : s_res[winner];  // later duplicates observe what the first request decided
-            fl = (nd == kNone) ? 4u : (nd == r ? 0u : 1u);
+            ond[q] = hpos[slot[q]];  // (its own current node, or what the first request decided)
+            ofl[q] = (ond[q] == kNone) ? 4u : (ond[q] == r[q] ? 0u : 1u);
         }
-        out_node[k] = nd;
-        out_flag[k] = fl;
-        if (election) pos[i] = kNone;
     }
-    if (k == 0) *status = 0;
+    if (PER == 4) {
+        if (valid[0]) {  // (the result rows are kMidBatch entries long: a whole vector is always addressable)
+            *reinterpret_cast<uint4*>(out_node + 4 * tid) = make_uint4(ond[0], ond[PER > 1 ? 1 : 0], ond[PER > 2 ? 2 : 0], ond[PER > 3 ? 3 : 0]);
+            *reinterpret_cast<uint4*>(out_flag + 4 * tid) = make_uint4(ofl[0], ofl[PER > 1 ? 1 : 0], ofl[PER > 2 ? 2 : 0], ofl[PER > 3 ? 3 : 0]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            if (valid[q]) { out_node[tid * PER + q] = ond[q]; out_flag[tid * PER + q] = ofl[q]; }
+    }
+    if (tid == 0) *status = 0;
     signal_done(done, seq);
 }
 
@@ -3287,6 +3465,12 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
         return;
     }
     if (virt) {
+        if (t.pk_idx && t.real_next) {  // big place_pending batch: first touches also go straight into the real column
+            const PackOut sc{const_cast<u32*>(t.pk_idx), nullptr, nullptr, t.real_next, reinterpret_cast<u32*>(&b.stats->err)};
+            if (all_alive) launch_scan_t<true, true, 1, 3>(p, t, nt, b, s, e0, e1, &sc);
+            else launch_scan_t<true, false, 1, 3>(p, t, nt, b, s, e0, e1, &sc);
+            return;
+        }
         if (all_alive) launch_scan_t<true, true, 1>(p, t, nt, b, s, e0, e1);
         else launch_scan_t<true, false, 1>(p, t, nt, b, s, e0, e1);
         return;
@@ -3485,7 +3669,7 @@ void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32
         uint2* rec2 = reinterpret_cast<uint2*>(scratch);
         unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
         hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx + at,
-                           node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st);
+                           node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st, true);
         const size_t lds = ((size_t)1 << wshift) * sizeof(u64);
         hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, wshift);
     }
@@ -3500,11 +3684,45 @@ void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u3
         u32* rec = scratch;
         unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
         hipLaunchKernelGGL(k_part_bin<false>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(u32)), s, n_obj, m, idx + at,
-                           (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st);
+                           (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st, true);
         const size_t lds = ((size_t)1 << wshift) * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0) + 16;
         hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, m, load, rec, start16, chunks, used, aff_life,
                            wshift);
     }
+}
+// place_pending over a window-sorted batch (k_pp_win_*): scratch = part_scratch_words(n_obj, n) words (records + chunk table)
+void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s) {
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
+    const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
+    uint2* rec2 = reinterpret_cast<uint2*>(scratch);
+    unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
+    hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx, req, n,
+                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err);
+}
+void launch_pp_win_gather(const u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
+                          uint2* vrec, u32* vcur, u32* vload, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st,
+                          hipStream_t s) {
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
+    const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
+    const uint2* rec2 = reinterpret_cast<const uint2*>(scratch);
+    const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
+    (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
+    if (out_flag) (void)hipMemsetAsync(out_flag, 0, n * sizeof(u32), s);
+    hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), ((size_t)(aff_life ? 2 : 1) << wshift) * sizeof(u32), s, assign, load, n_obj, m,
+                       alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, out_flag, aff_life, st);
+    hipLaunchKernelGGL(k_pp_split, dim3(grid_for((n + 1) / 2, 256, 2048)), dim3(256), 0, s, vrec, n, vcur, vload);
+}
+void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
+                          const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,
+                          const DevStats* st, hipStream_t s) {
+    hipLaunchKernelGGL(k_pp_win_output, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, idx, req, n, vcur, vload, vnext,
+                       alive_bits, cutidx, m, out_node, out_flag, aff_life, st);
+}
+bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req) {
+    // (the windows' rows are only READ here, once and densely: it pays for sparser batches than the CRUD forms' n_obj / 8)
+    const u64 nbins = part_bins(n_obj);
+    return n >= ((u64)1 << 18) && n <= (u64)kPartMaxChunks * kPartSub && n * 32 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
+           (((uintptr_t)idx | (uintptr_t)req) & 15u) == 0;
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
                   u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life, u32 seq) {
@@ -3540,11 +3758,18 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
     if (!w) return;
     hipLaunchKernelGGL(k_pack_alive, dim3((w + 63) / 64), dim3(64), 0, s, alive_bytes, m, alive_bits);
 }
-void launch_pp_small(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used, u32* pos,
-                     const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                     u32* aff_life, u32* done, u32 seq, const SmallInline* inl) {
-    hipLaunchKernelGGL(k_pp_small, dim3(1), dim3(kSmallBatch), 0, s, assign, load, m, cap, alive_bits, used, pos, idx, req, n,
-                       out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl));
+void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
+                   const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
+                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl) {
+    if (n <= (u32)kSmallBatch) {
+        const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kSmallBatch) * sizeof(u32);
+        hipLaunchKernelGGL((k_pp_one<kSmallBatch, 1>), dim3(1), dim3(kSmallBatch), lds, s, assign, load, m, cap, alive_bits, used,
+                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl));
+    } else {
+        const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kOneBatch) * sizeof(u32);
+        hipLaunchKernelGGL((k_pp_one<kBlock, kOneBatch / kBlock>), dim3(1), dim3(kBlock), lds, s, assign, load, m, cap, alive_bits,
+                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr));
+    }
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead) {

@@ -182,6 +182,7 @@ struct rio_gp {
     u32 small_seq = 0;      // sequence number of the last micro-batch call; its completion word is row 5, word 0
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
+    DevBuf vrec;  // big place_pending batches: virtual-table records {cur | load}, 8 bytes per request
     DevBuf part;  // scratch of the partitioned update / remove batches (records + fragment tables)
     std::vector<void*> allocs;
 };
@@ -671,7 +672,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     memset(h->h_slots, 0, (size_t)2 * kRing * h->slot_rows * 8 * sizeof(u64));
     memset(h->h_fx, 0, (size_t)(1 + kRing) * kMaxBlocks * 8 * sizeof(u64));
     h->cs_words = (((size_t)h->cap_nodes + 31) / 32 + 8 + 1) & ~(size_t)1;  // bitmap words, then the u64 count (8 B aligned)
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cs), (h->cs_words + 2) * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cs), (h->cs_words + 4) * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_cs), h->h_cs, 0) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->cs_cnt), sizeof(u64)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->cs_ticket), sizeof(unsigned int)) != hipSuccess ||
@@ -724,6 +725,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& b : h->vt) if (b.p) (void)hipFree(b.p);
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
+    if (h->vrec.p) (void)hipFree(h->vrec.p);
     if (h->part.p) (void)hipFree(h->part.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     if (h->h_slots) (void)hipHostFree(h->h_slots);
@@ -1197,6 +1199,50 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     u32* assign = h->assign[h->cur];
     h->sb.fx = FxRows{};  // nobody reads the fix-up counters of the virtual-table solve: plain DevStats atomics, no pinned slot touched
     if ((rc = ensure_used(h))) return rc;
+    if (h->part_mode != 2 && !done_seq && pp_win_applicable(h->n, n, d_idx, d_req)) {
+        // Big batch: sorted by row window once, the row-side step out of LDS (k_pp_win_gather), the decisions written into the
+        // real column by the solve itself: two random accesses per request instead of nine.  The entries are validated by the
+        // binning kernel, which changes nothing.
+        if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32))) || (rc = ensure(h, h->vrec, n * sizeof(uint2)))) return rc;
+        // An invalid entry makes the call fail with nothing changed, and nobody waits to find out: the binning kernel raises a
+        // flag in mapped host memory and a device counter, every kernel enqueued behind it looks at the counter and does
+        // nothing (k_scan solves an empty table), and the host reads the flag when it picks up the verdict.
+        if ((rc = zero_stats(h))) return rc;
+        u32* const h_bad = h->h_cs + h->cs_words + 2;
+        *h_bad = 0;
+        launch_pp_bin(h->n, h->m, d_idx, d_req, n, (u32*)h->part.p, h->dstats, h->d_cs + h->cs_words + 2, h->stream);
+        launch_pp_win_gather(assign, h->load, h->n, h->m, h->alive_bits, n, (const u32*)h->part.p, (uint2*)h->vrec.p, vcur, vload,
+                             h->dead_bits, d_flag, aff_life(h), h->dstats, h->stream);
+        if (!h->all_alive)  // service.rs:227-237: every object of a dead node a request ran into is un-placed
+            launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
+        Plan vp = make_plan(n, h->m, 0);
+        const u64 seq = ++h->wait_seq;
+        vp.mark = seq;
+        Table vtab{vcur, vload, d_req /* the requesters ARE the affinity column of the virtual table */, vnext};
+        vtab.pk_idx = d_idx;      // virtual row -> real row: every decision of the solve also goes to assign[d_idx[k]]
+        vtab.real_next = assign;  // (in place: the rows that change are pending, nothing else reads them before the outputs)
+        const NodeTab vnt{h->cap, h->alive_bits, h->used};
+        h->sb.D = h->D;
+        launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
+        launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
+        enqueue_slow(h, vp, vtab, vnt, true, false);  // ahead of the verdict: its kernels guard themselves on the device
+        launch_pp_win_output(d_idx, d_req, n, vcur, vload, vnext, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag, aff_life(h), h->dstats,
+                             h->stream);
+        if (!spin_rows(h->h_slots, resolve_blocks(h->m), seq)) HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        if (*h_bad) {
+            if (check_entries)
+                return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
+            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: object index or requester out of range (nothing was changed)");
+        }
+        const DevStats v = reduce_slot(h, 0, h->m);
+        const bool vslow = v.n_cut > 0 || v.spillcand > 0;
+        std::swap(h->used, h->sb.used_cur);
+        h->used_parts = vslow;
+        h->parts_rounds = h->rounds;
+        h->have_solved = false;
+        return RIO_GP_OK;
+    }
     // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes.  With every node alive and
     //     the entries validated on the host there is nothing to mark, nothing to clean and no counter to read: four
     //     enqueues less on a path whose cost is its launches.
@@ -1265,9 +1311,9 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         }
         hs[4 * kSmallBatch] = 2;  // neither 0 nor 1: the kernel must write it
         const u32 seq = small_begin(h);
-        launch_pp_small(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, h->pos, ds, ds + kSmallBatch,
-                        (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h),
-                        small_done_dev(h), seq, in_args ? &inl : nullptr);
+        launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, ds, ds + kSmallBatch,
+                      (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h),
+                      small_done_dev(h), seq, in_args ? &inl : nullptr);
         if ((rc = small_wait(h, seq))) return rc;
         const u32 status = hs[4 * kSmallBatch];
         if (status == 0) {
@@ -1288,6 +1334,25 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         u32* dm = h->d_mid;
         memcpy(hm, idx, bytes);
         memcpy(hm + kMidBatch, requester, bytes);
+        if (n > (uint64_t)kSmallBatch) {
+            // first the one-workgroup kernel (k_pp_one, 1024 threads x 4 requests): sticky hits and first touches that fit —
+            // the whole call is ONE launch and one wait (4 096 requests: 46 -> ~15 us); anything heavier hands over untouched
+            if ((rc = ensure_used(h))) return rc;
+            h->h_small[4 * kSmallBatch] = 2;
+            const u32 seq1 = small_begin(h);
+            launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, dm, dm + kMidBatch, (u32)n,
+                          dm + 2 * kMidBatch, dm + 3 * kMidBatch, h->d_small + 4 * kSmallBatch, h->stream, aff_life(h),
+                          small_done_dev(h), seq1, nullptr);
+            if ((rc = small_wait(h, seq1))) return rc;
+            const u32 status = h->h_small[4 * kSmallBatch];
+            if (status == 0) {
+                memcpy(out_node, hm + 2 * kMidBatch, bytes);
+                if (out_flag) memcpy(out_flag, hm + 3 * kMidBatch, bytes);
+                h->have_solved = false;
+                return RIO_GP_OK;
+            }
+            if (status != 1) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_place_pending: one-workgroup kernel left no status");
+        }
         const u32 seq = small_begin(h);
         if ((rc = place_pending_general(h, n, dm, dm + kMidBatch, dm + 2 * kMidBatch, dm + 3 * kMidBatch, false, seq))) return rc;
         if ((rc = small_wait(h, seq))) return rc;

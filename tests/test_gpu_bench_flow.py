@@ -27,7 +27,13 @@ def test_bench_line_n1():
     assert d["n_gpus"] == 1 and d["unit"] == "decisions/s" and d["value"] > 1e9
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
-    assert d["stats_last_step"]["claimed"] + d["stats_last_step"]["spilled"] + d["stats_last_step"]["unplaced"] == 1000000
+    # the headline is a stream of committed ticks: by the last one every row is kept where the first tick put it ...
+    last = d["stats_last_step"]
+    assert last["kept"] + last["claimed"] + last["spilled"] + last["unplaced"] == 1000000 and last["kept"] > 0
+    assert d["committed_tick_frac"] > 0 and d["roofline"]["frac_committed_tick"] == d["committed_tick_frac"]
+    # ... and the cold table, re-solved without committing, is all pending rows
+    cold = d["stats_cold_step"]
+    assert cold["claimed"] + cold["spilled"] + cold["unplaced"] == 1000000 and d["cold_resolve_uncommitted"]["value"] > 1e9
     # the run checks itself against the oracle (and would have exited with rc 3 on a mismatch)
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 1000000
     assert d["dependent_tick_ms"] > 0 and "traffic_source" in d["roofline"]
@@ -42,14 +48,24 @@ def test_bench_headline_line_has_parity_traffic_and_config4():
     d = _one_json_line(r.stdout)
     assert d["config"]["objects_per_gpu"] == 10_000_000 and d["config"]["nodes"] == 1024
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 10_000_000
-    assert d["roofline"]["frac"] > 0.5 and d["roofline"]["whole_step_frac"] > 0.4
+    # the kernel the roofline is quoted on, and the honest denominators next to it: the DRAM-bound form of the same step,
+    # the committed tick (what `value` is), the dependent tick
+    rf = d["roofline"]
+    assert rf["frac"] > 0.5 and rf["frac_dram_bound"] > 0.4 and 0.2 < rf["frac_committed_tick"] < rf["frac"]
+    assert abs(d["value"] - 10_000_000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]       # value IS the committed tick
+    assert rf["frac_dependent_tick"] > 0.1 and d["cold_resolve_uncommitted"]["slow_path_steps"] == 0
+    c5 = d["config5_churn"]
+    assert c5["parity"]["equal"] is True and c5["pipelined"]["equal_to_synchronous_stream"] is True and c5["slow_path_ticks"] > 0
+    c2 = d["config2"]
+    assert c2["parity"]["equal"] is True and c2["committed_tick"]["value"] > 1e9
     if d["roofline"]["traffic"] is not None:   # rocprofv3 present: measured in this run, not replayed
         assert d["roofline"]["traffic_source"].startswith("measured in this run")
         assert 0.9 < d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"] < 1.3
     c4 = d["config4_single_gpu"]
-    assert c4["parity"]["equal"] is True and c4["parity"]["checked_rows"] == 100_000_000 and c4["slow_path_steps"] == 0
+    assert c4["parity"]["equal"] is True and c4["parity"]["checked_rows"] == 100_000_000
+    assert c4["cold_resolve_uncommitted"]["slow_path_steps"] == 0 and c4["committed_tick"]["frac"] > 0.3
     cold = d["roofline"]["beyond_infinity_cache"]
-    assert cold["rows"] == 40_000_000 and cold["whole_step_frac"] > 0.4
+    assert cold["rows"] == 40_000_000 and cold["whole_step_frac"] > 0.4 and cold["committed_tick_frac"] > 0.3
 
 
 @pytest.mark.parametrize("exchange", ["p2p", "torch"])
@@ -111,7 +127,9 @@ def test_bench_config5_churn_line():
                         "--objects", "1000000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_json_line(r.stdout)
-    assert d["n_gpus"] == 1 and d["value"] > 1e8 and d["objects_moved_per_s"] > 0
-    st = d["stats_last_step"]
+    rec = d["config5_churn"]
+    assert d["n_gpus"] == 1 and d["value"] > 1e8 and rec["objects_moved_per_s"] > 0 and d["value"] == rec["pipelined"]["value"]
+    st = rec["stats_last_tick"]
     assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == 1000000 and st["evicted"] > 0
+    assert d["parity"]["equal"] is True and rec["pipelined"]["equal_to_synchronous_stream"] is True
 

@@ -788,6 +788,70 @@ def test_place_pending_micro_batch_same_requester_capacity(gp, oracle):
         g.close()
 
 
+@pytest.mark.parametrize("seed,cap_mode", [(0, "inf"), (1, "tight"), (2, "roomy")])
+def test_place_pending_big_batches_partitioned_by_row_window(gp, oracle, seed, cap_mode):
+    """Batches of >= 2^18 requests are sorted by row window once, the row-side step works out of LDS (k_pp_win_gather) and the
+    solve writes its decisions into the table itself (k_scan<COMPACT 3>, k_fill through the object column): duplicates inside a batch (the first request decides), objects on dead nodes (clean_server of the whole
+    node, REPLACED), dead and full requesters (spill / unplaced), the row-lifecycle column — nodes, flags, table and `used`
+    against the sequential oracle, from host buffers and from device buffers."""
+    from hipbuf import DevBuf
+    rng = np.random.default_rng(5200 + seed)
+    n, m = 1_400_000, 300
+    load = rng.integers(0, 30, n).astype(np.uint32)
+    cap = {"inf": np.full(m, INF, np.uint64), "tight": rng.integers(0, int(load.sum() / m) + 5, m).astype(np.uint64),
+           "roomy": np.full(m, int(load.sum()), np.uint64)}[cap_mode]
+    alive = np.ones(m, np.uint8)
+    g = gp.GpuPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
+    plain = gp.LabPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)          # the same calls through the plain per-request kernels
+    plain.set_compact("auto", partitioned_crud=False)
+    for h in (g, plain):
+        h.set_nodes(cap, alive)
+        h.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step, k in enumerate((300_000, 1_000_000, 262_144, 700_001)):
+        if step >= 1:
+            for j in rng.integers(0, m, 12):
+                alive[j] ^= 1
+            g.set_alive_all(alive)
+            plain.set_alive_all(alive)
+        idx = rng.integers(0, n if step % 2 else n // 3, k).astype(np.uint32)   # (a third of the table: heavy duplication)
+        req = rng.integers(0, m, k).astype(np.uint32)
+        if step % 2 == 0:
+            node, flag = g.place_pending(idx, req)
+        else:
+            d_idx, d_req, d_node, d_flag = DevBuf(idx), DevBuf(req), DevBuf(nbytes=4 * k), DevBuf(nbytes=4 * k)
+            g.place_pending_dev(k, d_idx.ptr, d_req.ptr, d_node.ptr, d_flag.ptr)
+            node, flag = d_node.to_host(), d_flag.to_host()
+            for x in (d_idx, d_req, d_node, d_flag):
+                x.free()
+        pnode, pflag = plain.place_pending(idx, req)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(node, wnode), (step, np.flatnonzero(node != wnode)[:5])
+        assert np.array_equal(flag, wflag), (step, np.flatnonzero(flag != wflag)[:5])
+        assert np.array_equal(pnode, wnode) and np.array_equal(pflag, wflag), step
+        assert np.array_equal(g.get_assign(), ref), step
+        assert np.array_equal(g.get_nodes()[2], used), step
+        assert np.array_equal(g.get_objects()[1], plain.get_objects()[1]), step   # row lifecycle column: same as the plain kernels
+    plain.close()
+    # one index out of range: the call fails and NOTHING has changed (the kernels enqueued behind the validating one see its
+    # counter and do nothing) — then the same handle goes on working
+    life = g.get_objects()[1].copy()
+    g.set_assign(np.full(n, NONE, np.uint32)); ref[:] = NONE; used[:] = 0
+    bad = DevBuf(np.concatenate([np.arange(300_000, dtype=np.uint32), np.array([n], np.uint32)]))
+    rq, out = DevBuf(np.zeros(300_001, np.uint32)), DevBuf(nbytes=4 * 300_001)
+    with pytest.raises(gp.ObjectPlacementError) as e:
+        g.place_pending_dev(300_001, bad.ptr, rq.ptr, out.ptr)
+    assert e.value.rc == gp.EINVAL and np.array_equal(g.get_assign(), ref)
+    assert np.array_equal(g.get_nodes()[2], used) and np.array_equal(g.get_objects()[1], life)
+    idx = rng.integers(0, n, 300_000).astype(np.uint32)
+    req = rng.integers(0, m, 300_000).astype(np.uint32)
+    node, flag = g.place_pending(idx, req)
+    wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+    assert np.array_equal(node, wnode) and np.array_equal(flag, wflag) and np.array_equal(g.get_assign(), ref)
+    g.close()
+
+
 def test_place_pending_dev_equals_host_call(gp, oracle):
     """rio_gp_place_pending_dev: request / result arrays resident in HBM (torch tensors), same answers as the oracle;
     a bad entry fails the call before anything changes."""
