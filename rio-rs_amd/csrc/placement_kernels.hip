@@ -2753,8 +2753,8 @@ __global__ __launch_bounds__(256) void k_pp_win_output(const u32* __restrict__ i
 }
 
 // clean_server(s) (local.rs:51-58): one coalesced pass, 4 B read per row, 4 B written per evicted row
-// counter: device accumulator of evicted rows.  ticket/host_out (optional): the last workgroup to finish copies the
-// total into mapped host memory and resets counter and ticket, so a synchronous call needs no memset / copy-back.
+// counter: device accumulator of evicted rows.  ticket (non-null = synchronous call) / host_out: the last workgroup to
+// finish copies the total into mapped host memory and resets the counter, so the call needs no memset / copy-back.
 __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                const u32* __restrict__ dead_bits, u64* __restrict__ used,
                                                u64* __restrict__ counter, unsigned int* __restrict__ ticket,
@@ -2765,13 +2765,22 @@ __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 
     __shared__ u32 ev_total;
     const u32 mwords = (m + 31) / 32;
     const int tid = threadIdx.x;
-    // At most 256 workgroups of 1 024 threads, a grid-stride loop with the next vector in flight: the kernel ends with two
-    // returning atomics per workgroup on ONE address (count, ticket), and those serialise at ~10 ns each — 2 048 workgroups
-    // of 256 threads spent 40 us there, five times the 8 us of streaming the column.
+    // At most 256 workgroups of 1 024 threads in a grid-stride loop: the kernel ends with a returning atomic per workgroup on
+    // ONE address, and those serialise at ~10 ns each — 2 048 workgroups of 256 threads spent 40 us there, five times the
+    // 8 us of streaming the column.
     const u64 nvec = (n_obj + 3) / 4, stride = (u64)gridDim.x * kBlock;
     u64 v = (u64)blockIdx.x * kBlock + tid;
-    uint4 c = make_uint4(kNone, kNone, kNone, kNone);
-    if (v < nvec) c = *reinterpret_cast<const uint4*>(assign + v * 4);  // requested before the bitmap set-up below
+    // kCleanFlight vectors per lane in flight ahead of the ones being judged; the first is requested before the bitmap set-up
+    // below.  Measured on the 10 M-row column (rocprofv3, one node / 10 % of the nodes): 1 -> 13.3 / 16.8 us, 2 -> 13.7 / 17.5,
+    // 4 -> 14.8 / 18.0, 8 -> 17.7 / 19.5; 128 or 512 workgroups instead of 256 lose 2-4 us.  The pass is not latency-bound:
+    // ~3 us of launch, ~8 us of stream (the column comes from DRAM), the tail below.
+    constexpr int kCleanFlight = 1;
+    uint4 c[kCleanFlight];
+#pragma unroll
+    for (int q = 0; q < kCleanFlight; ++q) {
+        const u64 vq = v + (u64)q * stride;  // (past the end: the last vector again, unconditionally — a load behind a
+        c[q] = *reinterpret_cast<const uint4*>(assign + (vq < nvec ? vq : nvec - 1) * 4);  // branch would end the overlap)
+    }
     if (tid == 0) { any = 0; ev_total = 0; }
     __syncthreads();
     u32 mine = 0;
@@ -2783,47 +2792,67 @@ __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 
         for (u32 j = tid; j < m; j += kBlock)
             if (bit_of(db, j)) used[j] = 0;
     u32 ev = 0;
-    for (; v < nvec; v += stride) {
-        const u64 i0 = v * 4, vn = v + stride;
-        uint4 cn = make_uint4(kNone, kNone, kNone, kNone);
-        if (vn < nvec) cn = *reinterpret_cast<const uint4*>(assign + vn * 4);
-        const bool e0 = i0 + 0 < n_obj && c.x < m && bit_of(db, c.x), e1 = i0 + 1 < n_obj && c.y < m && bit_of(db, c.y);
-        const bool e2 = i0 + 2 < n_obj && c.z < m && bit_of(db, c.z), e3 = i0 + 3 < n_obj && c.w < m && bit_of(db, c.w);
-        const bool mine_ev = e0 | e1 | e2 | e3;
-        // A wave that evicts anything writes its whole kilobyte back, every lane its 16 bytes (unchanged rows keep their
-        // value; nothing else writes the column while this runs): full 128-byte lines instead of scattered 16-byte pieces
-        // of them.  The column is padded past n_obj.
-        if (__ballot(mine_ev)) {
-            c.x = e0 ? kNone : c.x; c.y = e1 ? kNone : c.y; c.z = e2 ? kNone : c.z; c.w = e3 ? kNone : c.w;
-            *reinterpret_cast<uint4*>(assign + i0) = c;
+    for (; v < nvec; v += (u64)kCleanFlight * stride) {
+        uint4 cn[kCleanFlight];
+#pragma unroll
+        for (int q = 0; q < kCleanFlight; ++q) {
+            const u64 vq = v + (u64)(kCleanFlight + q) * stride;
+            cn[q] = *reinterpret_cast<const uint4*>(assign + (vq < nvec ? vq : nvec - 1) * 4);
         }
-        if (mine_ev) {
-            if (aff_life) {  // row lifecycle: retain() drops the entries (local.rs:51-58); they come back on their next request
-                if (e0) aff_life[i0 + 0] = kAffInactive;
-                if (e1) aff_life[i0 + 1] = kAffInactive;
-                if (e2) aff_life[i0 + 2] = kAffInactive;
-                if (e3) aff_life[i0 + 3] = kAffInactive;
+#pragma unroll
+        for (int q = 0; q < kCleanFlight; ++q) {
+            const u64 i0 = (v + (u64)q * stride) * 4;  // (past the end: i0 >= n_obj, nothing is evicted or written)
+            uint4 x = c[q];
+            const bool e0 = i0 + 0 < n_obj && x.x < m && bit_of(db, x.x), e1 = i0 + 1 < n_obj && x.y < m && bit_of(db, x.y);
+            const bool e2 = i0 + 2 < n_obj && x.z < m && bit_of(db, x.z), e3 = i0 + 3 < n_obj && x.w < m && bit_of(db, x.w);
+            const bool mine_ev = e0 | e1 | e2 | e3;
+            // A wave with many evictions writes its whole kilobyte back, every lane its 16 bytes (unchanged rows keep their
+            // value; nothing else writes the column while this runs): full 128-byte lines instead of scattered 16-byte pieces
+            // of them.  With a few (one node of a thousand: a fifth of the waves hold one or two) only those lanes write —
+            // the kernel takes the same time either way, the column is not rewritten for nothing.  Padded past n_obj.
+            const u64 bal = __ballot(mine_ev);
+            if (bal) {
+                x.x = e0 ? kNone : x.x; x.y = e1 ? kNone : x.y; x.z = e2 ? kNone : x.z; x.w = e3 ? kNone : x.w;
+                if (i0 < n_obj && (mine_ev || __popcll(bal) > 16)) *reinterpret_cast<uint4*>(assign + i0) = x;
             }
-            ev += e0 + e1 + e2 + e3;
+            if (mine_ev) {
+                if (aff_life) {  // row lifecycle: retain() drops the entries (local.rs:51-58); they come back on their next request
+                    if (e0) aff_life[i0 + 0] = kAffInactive;
+                    if (e1) aff_life[i0 + 1] = kAffInactive;
+                    if (e2) aff_life[i0 + 2] = kAffInactive;
+                    if (e3) aff_life[i0 + 3] = kAffInactive;
+                }
+                ev += e0 + e1 + e2 + e3;
+            }
         }
-        c = cn;
+#pragma unroll
+        for (int q = 0; q < kCleanFlight; ++q) c[q] = cn[q];
     }
     ev = wave_sum32(ev);
     if ((tid & 63) == 0 && ev) atomicAdd(&ev_total, ev);
     __syncthreads();
     if (tid == 0) {
-        // returning atomic: its value is back (the add is performed at L2) before the ticket below depends on it
-        const u64 before = __hip_atomic_fetch_add(counter, (u64)ev_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket) {
-            const unsigned int t = __hip_atomic_fetch_add(ticket, 1u + (unsigned int)(before & 0ull), __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-            if (t == gridDim.x - 1) {
-                // the total, tagged with the caller's sequence number in bits 40..63: the host spins on the tag (one 8-byte store)
-                *host_out = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | ((u64)seq << 40);
-                __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        if (!ticket) {  // asynchronous callers: a plain accumulator
+            if (ev_total) atomicAdd(counter, (u64)ev_total);
+            return;
         }
+        // Synchronous call: count (bits 0..39) and arrival ticket (bits 40..63) travel in ONE returning atomic per workgroup.
+        // Returning atomics on one address serialise at ~12 ns each and every workgroup arrives at the same moment, so they
+        // go through two levels: eight counters on lines of their own (workgroups of one XCD share one), then the last
+        // arrival of each group adds its group's sum to counter[0] — 32 + 8 in a row instead of 256.
+        constexpr u64 kCnt = (1ull << 40) - 1;
+        const u32 groups = gridDim.x < 8u ? gridDim.x : 8u, grp = blockIdx.x % groups;
+        const u32 gsize = (gridDim.x - grp + groups - 1) / groups;
+        u64* gc = counter + (size_t)(1 + grp) * 16;
+        const u64 before = __hip_atomic_fetch_add(gc, (u64)ev_total + (1ull << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((before >> 40) != (u64)gsize - 1) return;
+        __hip_atomic_store(gc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 gsum = ((before & kCnt) + ev_total) & kCnt;
+        const u64 b2 = __hip_atomic_fetch_add(counter, gsum + (1ull << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((b2 >> 40) != (u64)groups - 1) return;
+        // the total, tagged with the caller's sequence number in bits 40..63: the host spins on the tag (one 8-byte store)
+        *host_out = (((b2 & kCnt) + gsum) & kCnt) | ((u64)seq << 40);
+        __hip_atomic_store(counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

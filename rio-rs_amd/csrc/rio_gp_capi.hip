@@ -674,9 +674,9 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     h->cs_words = (((size_t)h->cap_nodes + 31) / 32 + 8 + 1) & ~(size_t)1;  // bitmap words, then the u64 count (8 B aligned)
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_cs), (h->cs_words + 4) * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_cs), h->h_cs, 0) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->cs_cnt), sizeof(u64)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->cs_cnt), 9 * 16 * sizeof(u64)) != hipSuccess ||  // k_clean: total + 8 group counters, a line each
         hipMalloc(reinterpret_cast<void**>(&h->cs_ticket), sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(h->cs_cnt, 0, sizeof(u64)) != hipSuccess || hipMemset(h->cs_ticket, 0, sizeof(unsigned int)) != hipSuccess) {
+        hipMemset(h->cs_cnt, 0, 9 * 16 * sizeof(u64)) != hipSuccess || hipMemset(h->cs_ticket, 0, sizeof(unsigned int)) != hipSuccess) {
         h->err = "clean_server staging allocation failed";
         return bail(RIO_GP_ENOMEM);
     }
