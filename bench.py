@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-c2", action="store_true", help="N=1: skip the config-2 record (1 M x 256)")
     ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 record (10 % churn per tick, 110 ticks + oracle replay)")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaled config-3 second measurement")
+    ap.add_argument("--no-sharded-churn", action="store_true", help="N>1: skip the committed / churn tick streams of the sharded table")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "round3_traffic.json"),
                     help="fallback for roofline.traffic when the in-run PMC passes are skipped or fail")
     return ap.parse_args()
@@ -180,6 +181,79 @@ def parity_sharded(dist, backend, g, sol, workload, n_total, m, bounds, rank, wo
                                             "shard gathered" % n_total, "oracle_seconds": t_orc}
     if not eq_s:
         rec["stats_gpu"], rec["stats_oracle"] = st, ost
+    return rec
+
+
+def sharded_ticks(a, dist, torch, g, sol, workload, n_total, m, bounds, rank, world, cap, ticks=10):
+    """Committed ticks of the row-sharded table, after the parity step left it committed (warm): (i) `ticks` churn-free
+    ticks (every row kept: scan + exchange + verdict + commit), (ii) BASELINE config 5 on the sharded table: per tick a
+    liveness push (10 % of the nodes down, a different 10 % each tick) and one committed tick — the fix-up exchanges of
+    rio_gp_shard_cut / _merge / _spill, every phase a host round trip.  Max over ranks.  The final table of (ii) is
+    checked against the oracle chained over the same masks (rank 0, whole table) when that takes seconds, not minutes."""
+    import synth
+    dev = "cuda" if a.backend == "nccl" else "cpu"
+
+    def timed(step, k):
+        dist.barrier(); g.sync()
+        t0 = time.perf_counter()
+        out = [step(i) for i in range(k)]
+        g.sync()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), out
+
+    sol.tick()                                                   # (a warm-up of the committed path itself)
+    dt_keep, sts = timed(lambda i: sol.tick(), ticks)
+    keep = {"ms_per_tick": dt_keep / ticks * 1e3, "value": n_total * ticks / dt_keep, "unit": "decisions/s",
+            "slow_path_ticks": int(sum(x["slow_path"] for x in sts)),
+            "step": "ShardedSolver.tick: solve_async + solve_wait (verdict, global counters) + commit, the host in the loop"}
+    masks = [synth.churn_mask(m, k + 1) for k in range(ticks + 2)]
+
+    def churn(i):
+        g.set_alive_all(masks[i])
+        return sol.tick()
+    churn(0); churn(1)
+    dt_ch, sts = timed(lambda i: churn(i + 2), ticks)
+    moved = sum(x["claimed"] + x["spilled"] for x in sts)
+    rec = {"ticks": ticks, "committed_tick_no_churn": keep,
+           "churn": {"ms_per_tick": dt_ch / ticks * 1e3, "value": n_total * ticks / dt_ch, "unit": "decisions/s",
+                     "objects_moved_per_s": moved / dt_ch, "slow_path_ticks": int(sum(x["slow_path"] for x in sts)),
+                     "stats_last_tick": sts[-1],
+                     "step": "rio_gp_set_alive_all + ShardedSolver.tick: scan, exchange, verdict, cut + export, exchange, merge, "
+                             "then per water-fill round spill + export, exchange, merge; counters; commit — synchronous, every "
+                             "phase returns to the host (an asynchronous form of the sharded fix-up is not built)"}}
+    if a.no_parity or n_total * (ticks + 4) > 400_000_000:
+        rec["churn"]["parity"] = None
+        return rec
+    mine, used = g.get_assign(), g.get_nodes()[2]
+    nmax = max(bounds[r + 1] - bounds[r] for r in range(world))
+    pad = np.full(nmax, 0xFFFFFFFF, np.uint32)
+    pad[:len(mine)] = mine
+    t_rows, t_used = torch.from_numpy(pad.astype(np.int64)).to(dev), torch.from_numpy(used.astype(np.int64)).to(dev)
+    rows_all, used_all = [torch.empty_like(t_rows) for _ in range(world)], [torch.empty_like(t_used) for _ in range(world)]
+    dist.all_gather(rows_all, t_rows)
+    dist.all_gather(used_all, t_used)
+    if rank != 0:
+        return rec
+    import pyoracle
+    glob = synth.config(workload, n_override=n_total, start=0)
+    t0 = time.perf_counter()
+    ones = np.ones(m, np.uint8)
+    ref, wused, ost = pyoracle.tick(glob["cur"], glob["load"], glob["aff"], cap, glob["alive"], 2)   # the parity step's commit
+    for _ in range(ticks + 1):                                                                      # warm-up + churn-free ticks
+        ref, wused, ost = pyoracle.tick(ref, glob["load"], glob["aff"], cap, ones, 2)
+    for k in range(ticks + 2):
+        ref, wused, ost = pyoracle.tick(ref, glob["load"], glob["aff"], cap, masks[k], 2)
+    got = np.concatenate([rows_all[r].cpu().numpy().astype(np.uint32)[:bounds[r + 1] - bounds[r]] for r in range(world)])
+    keys = ("n_objects", "kept", "evicted", "claimed", "spilled", "unplaced", "load_kept", "load_claimed", "load_spilled",
+            "load_unplaced", "cut_nodes", "slow_path")
+    eq_a = bool(np.array_equal(got, ref))
+    eq_u = all(bool(np.array_equal(used_all[r].cpu().numpy().astype(np.uint64), wused)) for r in range(world))
+    eq_s = all(sts[-1][k] == ost[k] for k in keys)
+    rec["churn"]["parity"] = {"checked_rows": int(n_total), "ticks_replayed": 2 * ticks + 4, "equal": eq_a and eq_u and eq_s,
+                              "assign_equal": eq_a, "used_equal_on_every_rank": eq_u, "stats_equal": eq_s,
+                              "against": "oracle/placement_oracle.c orc_tick chained over the same ticks and liveness masks on the "
+                                         "WHOLE table (rank 0)", "oracle_seconds": time.perf_counter() - t0}
     return rec
 
 
@@ -437,9 +511,18 @@ def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank
     parity = None
     if not a.no_parity:
         parity = parity_sharded(dist, a.backend, g, sol, workload, n_total, m, bounds, rank, world, cfg["cap"])
+    ticks = None
+    if not a.no_sharded_churn:
+        if a.no_parity:
+            sol.tick()   # the committed (warm) table the tick streams start from
+        try:
+            ticks = sharded_ticks(a, dist, torch, g, sol, workload, n_total, m, bounds, rank, world, cfg["cap"],
+                                  ticks=max(2, min(a.steps, 10)))
+        except Exception as e:  # a second measurement: it must not take the line down with it
+            ticks = {"error": repr(e)[:300]}
     rec = {"value": n_total * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "gpu_ms_per_step_events": gpu_ms / a.steps,
            "rows_total": n_total, "rows_this_rank": n, "nodes": m, "exchange": kind, "exchange_ladder": tried,
-           "slow_path_steps": n_slow, "stats_last_step": st, "parity": parity,
+           "slow_path_steps": n_slow, "stats_last_step": st, "parity": parity, "committed_ticks": ticks,
            "whole_step_achieved_GBps": ALGO_BYTES_PER_DECISION * n / (gpu_ms / a.steps * 1e-3) / 1e9}
     g.close()
     return rec
@@ -534,16 +617,22 @@ def main():
                          "kernel": "whole sharded step on rank 0 (k_scan + exchange/resolve), HIP events on the library's stream",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DECISION * prim["rows_this_rank"]},
             "stats_last_step": prim["stats_last_step"],
+            "committed_ticks": prim["committed_ticks"],
         }
         if weak is not None:
             out["weak_config3"] = {"metric": "placement decisions/sec, 10M objects x 1 024 nodes per GPU (weak scaling)",
                                    "value": weak["value"], "unit": "decisions/s", "scaling": "weak", "ms_per_step": weak["ms_per_step"],
                                    "objects_per_gpu": weak["rows_this_rank"], "objects_total": weak["rows_total"], "nodes": weak["nodes"],
-                                   "exchange": weak["exchange"], "slow_path_steps": weak["slow_path_steps"], "parity": weak["parity"]}
+                                   "exchange": weak["exchange"], "slow_path_steps": weak["slow_path_steps"], "parity": weak["parity"],
+                                   "committed_ticks": weak["committed_ticks"]}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         bad = [p for p in (prim["parity"], weak["parity"] if weak else None) if p is not None and not p["equal"]]
+        for r_ in (prim, weak):
+            cp = ((r_ or {}).get("committed_ticks") or {}).get("churn", {}).get("parity") if r_ else None
+            if cp is not None and not cp["equal"]:
+                bad.append(cp)
         if bad:
             sys.exit(3)
         return

@@ -269,7 +269,7 @@ void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, c
 inline size_t shard_xchg_words(u32 m) { return 2 * (2 * (size_t)m + 8 * (size_t)((m + 7) / 8)); }  // two tagged words per value
 void launch_resolve_xchg(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* const* d_peers, u32 R, u32 rank,
                          size_t my_row_off, const u64* win_rows, size_t W, u64 seq, u64* p2p_err, u64* gprev, u64* gfinal,
-                         u64* host_partial, hipStream_t s);
+                         u64* host_partial, u32 co_resident, hipStream_t s);
 void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off, u64 seq,
                     hipStream_t s);
 void launch_p2p_wait_copy(const u64* win_slot, size_t W, u32 R, u32 words, const u64* flags, u64 seq, u64* err, u64* out,

@@ -3231,95 +3231,110 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
                                                       u32* __restrict__ cutidx, u64* __restrict__ gprev,
                                                       u64* __restrict__ gfinal, u32* __restrict__ forced_bits,
                                                       u64* __restrict__ rank_base, u64* __restrict__ partial,
-                                                      u64* __restrict__ host_partial) {
+                                                      u64* __restrict__ host_partial, const u32 nb /* node groups */) {
+    // gridDim.x == nb on a GPU of its own: one node group per workgroup, nobody waits for a workgroup of its own rank.
+    // Ranks that SHARE a device get a bounded grid (launch_resolve_xchg) and every workgroup walks its node groups: all
+    // sends first, then the waits — the spinning workgroups of all co-resident ranks then fit the chip next to the scan
+    // of a rank that is still on its way, whatever the number of nodes.
     __shared__ u64 part[kResRowGroups][16];
     __shared__ u64 vals[kXchgVals];      // what this workgroup sends (the first 16 are resolve_column_sums' tot[])
     __shared__ u64 got[32][kXchgVals];   // the same values of every rank (R <= 32)
     __shared__ u64 outc[8];              // partial verdict row
     __shared__ u32 nib;
     const int tid = threadIdx.x, lane = tid & 63;
-    const u32 m = p.m, G = p.G, nb = gridDim.x, b = blockIdx.x;
+    const u32 m = p.m, G = p.G;
     const u32 tag = (u32)seq;
-    // value index of word w (0..23) of this workgroup in a row
-    auto vidx = [&](u32 w) -> size_t {
-        return w < 8 ? (size_t)b * kResNodes + w : w < 16 ? (size_t)m + (size_t)b * kResNodes + (w - 8)
-                                                          : 2 * (size_t)m + (size_t)b * 8 + (w - 16);
-    };
-    auto wvalid = [&](u32 w) -> bool { return w >= 16 || b * kResNodes + (w & 7) < m; };
-    if (tid < 8) outc[tid] = 0;
-    if (tid >= 16 && tid < kXchgVals) vals[tid] = tid == kXchgVals - 1 ? 1ull : 0ull;
-    if (tid == 0) nib = 0;
-    u64 v[kResRows][2];
-    resolve_column_sums(H, b, G, v, part, vals);   // vals[0..7] kept sums, vals[8..15] claim sums
-    if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
-        u64 acc = 0;
-        for (u32 r = b + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
-        acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
-        if (lane < 4) vals[16 + 3 + lane] = acc;  // 3 kept  4 evicted  5 claimants  6 spill candidates (rows)
-    }
-    if (tid == 0) {
-        u64 a = 0, bb = 0;
-        for (int q = 0; q < kResNodes; ++q)
-            if (b * kResNodes + q < m) { a += vals[q]; bb += vals[q + kResNodes]; }
-        vals[16 + 0] = a;   // load kept
-        vals[16 + 1] = bb;  // load claimed
-    }
-    __syncthreads();
-    if (tid < 8) partial[(size_t)b * 8 + tid] = vals[16 + tid];  // this shard's own counters (rio_gp_shard_finish)
-    // send: this workgroup's values into this rank's row of EVERY window
-    for (u32 i = tid; i < (u32)kXchgVals * R; i += 256) {
-        const u32 w = i % kXchgVals;
-        if (wvalid(w)) xchg_put(peers[i / kXchgVals] + my_row_off, vidx(w), vals[w], tag);
-    }
-    // receive: the same values of every rank, polled word by word
-    for (u32 i = tid; i < (u32)kXchgVals * R; i += 256) {
-        const u32 w = i % kXchgVals, r = i / kXchgVals;
-        got[r][w] = wvalid(w) ? xchg_get(win_rows + (size_t)r * W, vidx(w), tag, p2p_err) : 0ull;
-    }
-    __syncthreads();
-    // resolve this workgroup's nodes against the global sums (k_shard_import's maths, node by node)
-    if (tid < kResNodes) {
-        const u32 jn = b * kResNodes + tid;
-        if (jn < m) {
-            u64 kept_glob = 0, claim_pre = 0, claim_glob = 0, claim_local = 0;
-            for (u32 r = 0; r < R; ++r) {
-                const u64 kx = got[r][tid], cx = got[r][kResNodes + tid];
-                kept_glob += kx;
-                if (r < rank) claim_pre += cx;
-                if (r == rank) claim_local = cx;
-                claim_glob += cx;
-            }
-            const u64 cj = cap[jn];
-            const u64 fre = (bit_of(alive_bits, jn) && cj > kept_glob) ? cj - kept_glob : 0;
-            const bool forced = claim_pre > fre;  // the node's prefix overflowed on a lower rank: everyone here is rejected
-            const u64 ukp = kept_glob + (forced ? fre : claim_pre);
-            used_kept[jn] = ukp;
-            claim_tot[jn] = claim_local;
-            used_cur[jn] = ukp + claim_local;
-            cutblk[jn] = kNoCut;
-            cutidx[jn] = kNoCut;
-            gprev[jn] = kept_glob;
-            gfinal[jn] = kept_glob + claim_glob;
-            if (forced) atomicOr(&nib, 1u << tid);
-            if (claim_glob > fre) atomicAdd(&outc[0], 1ull);                          // cut nodes (global)
-            if (forced || claim_local > fre - claim_pre) atomicAdd(&outc[2], 1ull);   // this rank has a local fix-up
+    for (u32 b = blockIdx.x; b < nb; b += gridDim.x) {  // ---- send
+        // value index of word w (0..23) of node group b in a row
+        auto vidx = [&](u32 w) -> size_t {
+            return w < 8 ? (size_t)b * kResNodes + w : w < 16 ? (size_t)m + (size_t)b * kResNodes + (w - 8)
+                                                              : 2 * (size_t)m + (size_t)b * 8 + (w - 16);
+        };
+        auto wvalid = [&](u32 w) -> bool { return w >= 16 || b * kResNodes + (w & 7) < m; };
+        if (tid >= 16 && tid < kXchgVals) vals[tid] = tid == kXchgVals - 1 ? 1ull : 0ull;
+        u64 v[kResRows][2];
+        resolve_column_sums(H, b, G, v, part, vals);   // vals[0..7] kept sums, vals[8..15] claim sums
+        if (tid >= 64 && tid < 128) {  // slice of the k_scan row counters: rows b, b+nb, ... of blkstat
+            u64 acc = 0;
+            for (u32 r = b + nb * (lane >> 2); r < G; r += nb * 16) acc += blkstat[(size_t)r * 4 + (lane & 3)];
+            acc += shfl_xor64(acc, 4); acc += shfl_xor64(acc, 8); acc += shfl_xor64(acc, 16); acc += shfl_xor64(acc, 32);
+            if (lane < 4) vals[16 + 3 + lane] = acc;  // 3 kept  4 evicted  5 claimants  6 spill candidates (rows)
         }
-    } else if (tid >= 16 && tid < kXchgVals) {  // global counters: word tid of this workgroup's slice, summed over the ranks
-        const int k = tid - 16;
-        u64 sum = 0;
-        for (u32 r = 0; r < R; ++r) sum += got[r][tid];
-        // verdict row: 0 cut nodes 1 spill rows 2 local fix-up 3 kept 4 evicted 5 claimants 6 load kept 7 load claimed
-        const int dst = k == 0 ? 6 : k == 1 ? 7 : k == 3 ? 3 : k == 4 ? 4 : k == 5 ? 5 : k == 6 ? 1 : -1;
-        if (dst >= 0) atomicAdd(&outc[dst], sum);
+        if (tid == 0) {
+            u64 a = 0, bb = 0;
+            for (int q = 0; q < kResNodes; ++q)
+                if (b * kResNodes + q < m) { a += vals[q]; bb += vals[q + kResNodes]; }
+            vals[16 + 0] = a;   // load kept
+            vals[16 + 1] = bb;  // load claimed
+        }
+        __syncthreads();
+        if (tid < 8) partial[(size_t)b * 8 + tid] = vals[16 + tid];  // this shard's own counters (rio_gp_shard_finish)
+        // this node group's values into this rank's row of EVERY window
+        for (u32 i = tid; i < (u32)kXchgVals * R; i += 256) {
+            const u32 w = i % kXchgVals;
+            if (wvalid(w)) xchg_put(peers[i / kXchgVals] + my_row_off, vidx(w), vals[w], tag);
+        }
+        __syncthreads();  // vals / part go round again
     }
-    __syncthreads();
-    if (tid == 0) {  // eight bits of the forced bitmap belong to this workgroup alone (8 | 32)
-        const u32 w = (b * kResNodes) >> 5, sh = (b * kResNodes) & 31;
-        atomicAnd(&forced_bits[w], ~(0xFFu << sh));
-        if (nib) atomicOr(&forced_bits[w], nib << sh);
-        if (b == 0) *rank_base = 0;
+    for (u32 b = blockIdx.x; b < nb; b += gridDim.x) {  // ---- receive and resolve
+        auto vidx = [&](u32 w) -> size_t {
+            return w < 8 ? (size_t)b * kResNodes + w : w < 16 ? (size_t)m + (size_t)b * kResNodes + (w - 8)
+                                                              : 2 * (size_t)m + (size_t)b * 8 + (w - 16);
+        };
+        auto wvalid = [&](u32 w) -> bool { return w >= 16 || b * kResNodes + (w & 7) < m; };
+        if (tid < 8) outc[tid] = 0;
+        if (tid == 0) nib = 0;
+        // the same values of every rank, polled word by word
+        for (u32 i = tid; i < (u32)kXchgVals * R; i += 256) {
+            const u32 w = i % kXchgVals, r = i / kXchgVals;
+            got[r][w] = wvalid(w) ? xchg_get(win_rows + (size_t)r * W, vidx(w), tag, p2p_err) : 0ull;
+        }
+        __syncthreads();
+        // resolve this group's nodes against the global sums (k_shard_import's maths, node by node)
+        if (tid < kResNodes) {
+            const u32 jn = b * kResNodes + tid;
+            if (jn < m) {
+                u64 kept_glob = 0, claim_pre = 0, claim_glob = 0, claim_local = 0;
+                for (u32 r = 0; r < R; ++r) {
+                    const u64 kx = got[r][tid], cx = got[r][kResNodes + tid];
+                    kept_glob += kx;
+                    if (r < rank) claim_pre += cx;
+                    if (r == rank) claim_local = cx;
+                    claim_glob += cx;
+                }
+                const u64 cj = cap[jn];
+                const u64 fre = (bit_of(alive_bits, jn) && cj > kept_glob) ? cj - kept_glob : 0;
+                const bool forced = claim_pre > fre;  // the node's prefix overflowed on a lower rank: everyone here is rejected
+                const u64 ukp = kept_glob + (forced ? fre : claim_pre);
+                used_kept[jn] = ukp;
+                claim_tot[jn] = claim_local;
+                used_cur[jn] = ukp + claim_local;
+                cutblk[jn] = kNoCut;
+                cutidx[jn] = kNoCut;
+                gprev[jn] = kept_glob;
+                gfinal[jn] = kept_glob + claim_glob;
+                if (forced) atomicOr(&nib, 1u << tid);
+                if (claim_glob > fre) atomicAdd(&outc[0], 1ull);                          // cut nodes (global)
+                if (forced || claim_local > fre - claim_pre) atomicAdd(&outc[2], 1ull);   // this rank has a local fix-up
+            }
+        } else if (tid >= 16 && tid < kXchgVals) {  // global counters: word tid of this group's slice, summed over the ranks
+            const int k = tid - 16;
+            u64 sum = 0;
+            for (u32 r = 0; r < R; ++r) sum += got[r][tid];
+            // verdict row: 0 cut nodes 1 spill rows 2 local fix-up 3 kept 4 evicted 5 claimants 6 load kept 7 load claimed
+            const int dst = k == 0 ? 6 : k == 1 ? 7 : k == 3 ? 3 : k == 4 ? 4 : k == 5 ? 5 : k == 6 ? 1 : -1;
+            if (dst >= 0) atomicAdd(&outc[dst], sum);
+        }
+        __syncthreads();
+        if (tid == 0) {  // eight bits of the forced bitmap belong to this node group alone (8 | 32)
+            const u32 w = (b * kResNodes) >> 5, sh = (b * kResNodes) & 31;
+            atomicAnd(&forced_bits[w], ~(0xFFu << sh));
+            if (nib) atomicOr(&forced_bits[w], nib << sh);
+            if (b == 0) *rank_base = 0;
+        }
+        if (tid < 8) host_partial[(size_t)b * 8 + tid] = outc[tid];
+        __syncthreads();  // got / outc / nib go round again
     }
-    if (tid < 8) host_partial[(size_t)b * 8 + tid] = outc[tid];
 }
 
 // global resolve of the all-gathered X records (RCCL paths): one workgroup, every node
@@ -3835,10 +3850,19 @@ void launch_shard_import(const Plan& p, const NodeTab& nt, const SolveBufs& b, c
 }
 void launch_resolve_xchg(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* const* d_peers, u32 R, u32 rank,
                          size_t my_row_off, const u64* win_rows, size_t W, u64 seq, u64* p2p_err, u64* gprev, u64* gfinal,
-                         u64* host_partial, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve_xchg, dim3(resolve_blocks(p.m)), dim3(256), 0, s, b.H, b.blkstat, p, d_peers, R, rank,
+                         u64* host_partial, u32 co_resident, hipStream_t s) {
+    // co_resident = ranks whose exchange kernels run on THIS device (1: a GPU of its own).  Sharing ranks spin on each other
+    // while a late one may still be scanning: together they keep to 512 workgroups of 256 threads — 8 of a CU's 32 wave
+    // slots and a few KB of its LDS — so that scan always finds room (see k_resolve_xchg).
+    const unsigned nb = resolve_blocks(p.m);
+    unsigned grid = nb;
+    if (co_resident > 1) {
+        const unsigned cap = 512u / co_resident > 8u ? 512u / co_resident : 8u;
+        if (grid > cap) grid = cap;
+    }
+    hipLaunchKernelGGL(k_resolve_xchg, dim3(grid), dim3(256), 0, s, b.H, b.blkstat, p, d_peers, R, rank,
                        my_row_off, win_rows, W, seq, p2p_err, nt.cap, nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot,
-                       b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits, b.rank_base, b.partial, host_partial);
+                       b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits, b.rank_base, b.partial, host_partial, nb);
 }
 void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off, u64 seq,
                     hipStream_t s) {

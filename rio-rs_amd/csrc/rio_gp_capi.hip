@@ -81,6 +81,7 @@ struct P2P {
     u64* d_err = nullptr;         // set by a waiting kernel that timed out
     u64* scratch = nullptr;       // [W] staging of the local record
     u64 seq = 0;
+    u32 co_resident = 1;          // ranks whose kernels run on THIS device, ours included (learnt at the handshake)
     size_t xdata_off(u32 slot, u32 r) const { return ((size_t)slot * R + r) * Wx; }
     size_t xwords() const { return (size_t)kP2PSlots * R * Wx; }
     size_t data_off(u32 slot, u32 r) const { return xwords() + ((size_t)slot * R + r) * W; }
@@ -1764,15 +1765,34 @@ int rio_gp_shard_p2p_connect(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&q->scratch), q->W * sizeof(u64)));
     HIPCHK(h, hipMemcpy(q->d_peers, bases.data(), n_ranks * sizeof(u64*), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(q->d_err, 0, sizeof(u64)));
-    // handshake: every rank stores a token into every peer's hello line and waits for all of theirs (3 s limit)
+    // handshake: every rank stores a token into every peer's hello line and waits for all of theirs (3 s limit).  Next to
+    // the token travels the identity of the device the rank runs on (hash of its PCI bus id): ranks that share a GPU — a test
+    // box, or a deployment that packs several shards on one device — must keep their spinning exchange kernels small enough
+    // to be co-resident (launch_resolve_xchg).
     const u64 token = 0xC0FFEE0000000001ull;
-    launch_p2p_put(q->scratch, 0, q->d_peers, n_ranks, 0, q->hello_off(rank), token, h->stream);
+    u64 devid = 1469598103934665603ull;
+    {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, h->device) != hipSuccess) {
+            (void)hipGetLastError();
+            snprintf(bus, sizeof bus, "device-%d", h->device);
+        }
+        for (const char* c = bus; *c; ++c) devid = (devid ^ (u64)(unsigned char)*c) * 1099511628211ull;
+        devid |= 1ull;
+    }
+    HIPCHK(h, hipMemcpyAsync(q->scratch, &devid, sizeof devid, hipMemcpyHostToDevice, h->stream));
+    launch_p2p_put(q->scratch, 1, q->d_peers, n_ranks, q->hello_off(rank) + 1, q->hello_off(rank), token, h->stream);
     launch_p2p_wait_copy(q->win, q->W, n_ranks, 0, q->win + q->hello_off(0), token, q->d_err, nullptr, h->stream);
     u64 err = 0;
+    std::vector<u64> hello((size_t)n_ranks * 8, 0);
     HIPCHK(h, hipMemcpyAsync(&err, q->d_err, sizeof err, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(hello.data(), q->win + q->hello_off(0), hello.size() * sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     if (err) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_shard_p2p_connect: a peer's handshake store never became visible");
+    q->co_resident = 0;
+    for (uint32_t r = 0; r < n_ranks; ++r) q->co_resident += hello[(size_t)r * 8 + 1] == devid;
+    if (q->co_resident == 0) q->co_resident = 1;
     return RIO_GP_OK;
 }
 
@@ -1894,7 +1914,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         xb.blkstat = h->sb.blkstat;
         launch_resolve_xchg(h->plan, nt, xb, q->d_peers, q->R, q->rank, q->xdata_off(slot, q->rank),
                             q->win + q->xdata_off(slot, 0), q->Wx, seq, q->d_err, h->sh_gprev, h->sh_gfinal,
-                            slot_dev(h, h->ring_n), h->stream);
+                            slot_dev(h, h->ring_n), q->co_resident, h->stream);
         h->sh_rows = resolve_blocks(h->m);
         h->ring_n++;
         h->have_solved = false;

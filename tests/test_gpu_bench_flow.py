@@ -84,32 +84,57 @@ def test_bench_two_ranks_as_the_driver_launches_it(exchange):
     assert d["config"]["exchange"] in ("p2p", "torch")
 
 
-def test_bench_config4_strong_scaling_two_ranks():
+@pytest.mark.parametrize("exchange", ["p2p", "torch"])
+def test_bench_config4_strong_scaling_two_ranks(exchange):
     """north_star's config 4 is what `bench.py --gpus N` measures for N > 1: ONE table split over the ranks (strong
-    scaling), here 2 M x 4 096 over two ranks that share the one GPU.  Two exchange kernels of 4 096 nodes cannot be
-    co-resident on one device, so this flow test runs the collective path (torch / gloo); on a real
-    node every rank has its own GPU and the ladder starts at the peer-to-peer windows.  The weak-scaled config 3 is the
-    second measurement of the same run, and both check themselves against the whole-table oracle."""
+    scaling), here 2 M x 4 096 over two ranks that share the one GPU — through the peer-to-peer windows (the default
+    first rung: ranks that find each other on one device at the handshake bound their exchange kernels' grids, so 512
+    node groups a rank no longer have to be co-resident workgroup by workgroup) and through the collective path (torch /
+    gloo).  The weak-scaled config 3 is the second measurement of the same run, and both check themselves against the
+    whole-table oracle."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
-           "--total-objects", "2000000", "--objects", "300000", "--backend", "gloo", "--same-device", "--exchange", "torch"]
+           "--total-objects", "2000000", "--objects", "300000", "--backend", "gloo", "--same-device", "--exchange", exchange]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["objects_total"] == 2_000_000 and d["config"]["objects_per_gpu"] == 1_000_000 and d["config"]["nodes"] == 4096
     assert d["config"]["workload"].startswith("config 4:")
-    assert d["config"]["exchange"] == "torch" and d["config"]["exchange_ladder"][0]["ok"] is True
+    assert d["config"]["exchange"] == exchange and d["config"]["exchange_ladder"][0]["ok"] is True
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 2_000_000
     w = d["weak_config3"]
     assert w["scaling"] == "weak" and w["objects_per_gpu"] == 300000 and w["nodes"] == 1024 and w["parity"]["equal"] is True
+    # the sharded table under committed ticks: churn-free (every row kept, fast path) and config 5's churn (10 % of the
+    # nodes flip per tick: every tick takes the fix-up exchanges), the final table against the chained oracle
+    for rec in (d["committed_ticks"], w["committed_ticks"]):
+        assert "error" not in rec, rec
+        assert rec["committed_tick_no_churn"]["slow_path_ticks"] == 0 and rec["committed_tick_no_churn"]["value"] > 0
+        ch = rec["churn"]
+        assert ch["slow_path_ticks"] == rec["ticks"] and ch["objects_moved_per_s"] > 0 and ch["stats_last_tick"]["evicted"] > 0
+        assert ch["parity"]["equal"] is True, ch["parity"]
+
+
+def test_bench_config4_eight_ranks_p2p_on_one_gpu():
+    """Config 4's node count (4 096) over EIGHT ranks on the one GPU, the driver's command line with its default exchange:
+    eight exchange kernels of 512 node groups each, kept to 64 workgroups a rank by the co-residency rule."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2",
+           "--total-objects", "4000000", "--objects", "200000", "--no-cpu-baseline", "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["nodes"] == 4096
+    assert d["config"]["exchange"] == "p2p" and d["config"]["exchange_ladder"][0]["ok"] is True, d["config"]
+    assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 4_000_000
+    assert d["weak_config3"]["parity"]["equal"] is True
 
 
 def test_bench_eight_ranks_on_one_gpu():
     """The driver's N=8 command line, all eight ranks on the one GPU of the box: eight processes exchanging through each
-    other's IPC-mapped windows, global capacities, one JSON line.  Workload c2 (256 nodes): ranks that SHARE a GPU must be
-    co-resident, and eight spinning exchange kernels at 1 024 nodes would fill the chip."""
+    other's IPC-mapped windows, global capacities, one JSON line (workload c2, 256 nodes)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "3",
