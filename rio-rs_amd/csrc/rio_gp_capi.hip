@@ -159,6 +159,12 @@ struct rio_gp {
     // packed fix-up (PackOut, placement_kernels.h): scratch columns + per-wave counts; chosen adaptively per tick
     PackOut pk{};
     bool last_pending_valid = false;
+    // A tick that took the fast path leaves every object placed; until the next call that changes an input of the solve
+    // (mut_epoch counts those) every further tick keeps every row where it is, and rio_gp_tick_async enqueues no speculative
+    // fix-up behind it: two launches a tick instead of five.  quiet_epoch = the mut_epoch such a tick was enqueued under.
+    u64 mut_epoch = 0, quiet_epoch = ~0ull;
+    u64 tick_mark[kRing] = {}, tick_epoch[kRing] = {};
+    u32 tick_peeked = 0;               // ticks [0, tick_peeked) of the ring have had their verdicts looked at
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
     int cutpack_mode = 0;  // the same for packing at the cut pass of whole-table solves (bits 5-6 of rio_gp_debug_set_compact)
@@ -393,7 +399,7 @@ int commit_enqueue(rio_gp* h) {
     h->used_valid = true;
     h->used_parts = h->solve_used_D;     // ... plus what its water-fill rounds admitted (D rows), folded in later
     h->parts_rounds = h->rounds;
-    h->have_solved = false;
+    h->have_solved = false;  // (not an input change: mut_epoch stays)
     return RIO_GP_OK;
 }
 
@@ -476,13 +482,29 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
 int commit_locked(rio_gp* h) { return commit_enqueue(h); }
 
 // wait for the asynchronous ticks in flight and turn their verdict slots + device-stats copies into rio_gp_stats
+// verdicts of enqueued ticks that have already landed in their pinned slots (every row carries the tick's mark): no wait
+void peek_ticks(rio_gp* h) {
+    const unsigned nb = resolve_blocks(h->m);
+    for (; h->tick_peeked < h->tick_n; ++h->tick_peeked) {
+        const u32 k = h->tick_peeked;
+        const volatile u64* rows = h->h_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8;
+        for (unsigned r = 0; r < nb; ++r)
+            if (rows[(size_t)r * 8 + 7] != h->tick_mark[k]) return;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const DevStats v = reduce_tick_slot(h, k, h->m);
+        if (!(v.n_cut > 0 || v.spillcand > 0) && h->tick_epoch[k] == h->mut_epoch) h->quiet_epoch = h->mut_epoch;
+    }
+}
+
 int harvest_ticks(rio_gp* h) {
     if (!h->tick_n) return RIO_GP_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    h->tick_peeked = 0;
     for (u32 k = 0; k < h->tick_n; ++k) {
         DevStats v = reduce_tick_slot(h, k, h->m);
         const bool slow = v.n_cut > 0 || v.spillcand > 0;
+        if (!slow && h->tick_epoch[k] == h->mut_epoch) h->quiet_epoch = h->mut_epoch;
         if (slow) fold_fx(h, 1 + k, h->tick_G[k], &v);
         rio_gp_stats st;
         fill_stats(v, h->n, &st);
@@ -502,16 +524,24 @@ int harvest_ticks(rio_gp* h) {
 int tick_async_locked(rio_gp* h) {
     if (h->ring_n) return fail(h, RIO_GP_EINVAL, "rio_gp_tick_async: rio_gp_solve_async solves are in flight (call rio_gp_solve_wait)");
     if (h->tick_n == (u32)kRing) { int rc = harvest_ticks(h); if (rc) return rc; }
+    peek_ticks(h);
+    // nothing has changed since a tick that left every object placed: this one keeps every row, no fix-up can be needed
+    // (lab builds: rio_gp_debug_set_speculate(always) keeps the launches)
+    const bool quiet = h->quiet_epoch == h->mut_epoch && h->spec_mode != 1;
     h->plan = make_plan(h->n, h->m, 0);
     const Table t = real_table(h);
     const NodeTab nt = real_nodes(h);
-    const bool compact = h->compact_mode == 1 ||
-                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending > 0 && h->last_pending * 4 <= h->n && h->n >= 65536);
+    const bool compact = !quiet && (h->compact_mode == 1 ||
+                         (h->compact_mode == 0 && h->last_pending_valid && h->last_pending > 0 && h->last_pending * 4 <= h->n && h->n >= 65536));
     const u32 k = h->tick_n;
     use_fx_slot(h, 1 + k);
     h->tick_G[k] = h->plan.G;
+    h->tick_epoch[k] = h->mut_epoch;
+    h->tick_mark[k] = h->plan.mark = (1ull << 40) | ++h->wait_seq;  // column 7 of the verdict rows: peek_ticks knows them by it
     enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8);
-    if (compact) {
+    if (quiet) {
+        // (k_scan + k_resolve only)
+    } else if (compact) {
         Plan pp = h->plan;
         pp.wcnt = h->pk.wcnt;
         Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
@@ -773,7 +803,7 @@ int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t
     for (uint32_t j = 0; j < m; ++j) h->all_alive = h->all_alive && h->h_alive[j];
     if (m != h->m) { h->used_valid = false; h->used_parts = false; }
     h->m = m;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     return RIO_GP_OK;
 }
 
@@ -790,7 +820,7 @@ static int push_alive_bits(rio_gp* h) {
     }
     launch_store_words(pk, words, h->alive_bits, h->stream);
     HIPCHK(h, hipGetLastError());
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     return RIO_GP_OK;
 }
 
@@ -842,7 +872,7 @@ static int set_objects_impl(rio_gp_t* h, uint64_t n, const uint32_t* load, const
     h->n = n;
     h->used_valid = true;
     h->used_parts = false;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     return RIO_GP_OK;
 }
 int rio_gp_set_objects(rio_gp_t* h, uint64_t n, const uint32_t* load, const uint32_t* aff) {
@@ -864,7 +894,7 @@ static int set_assign_impl(rio_gp_t* h, uint64_t n, const uint32_t* assign, hipM
     if (n) HIPCHK(h, hipMemcpyAsync(h->assign[h->cur], assign, n * sizeof(u32), kind, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->used_valid = false;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     return RIO_GP_OK;
 }
 int rio_gp_set_assign(rio_gp_t* h, uint64_t n, const uint32_t* a) { return set_assign_impl(h, n, a, hipMemcpyHostToDevice); }
@@ -915,7 +945,7 @@ int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const 
     launch_set_attrs(h->load, h->aff, h->n, (const u32*)h->stage[0].p, load ? (const u32*)h->stage[1].p : nullptr,
                      aff ? (const u32*)h->stage[2].p : nullptr, n, h->dstats, h->stream);
     if (load) h->used_valid = false;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     return read_stats(h);
 }
 
@@ -939,7 +969,7 @@ int rio_gp_set_num_objects(rio_gp_t* h, uint64_t n) {
     // placed row that drops out (or comes back) changes what `used` must count, so the vector is rebuilt before its next use
     if (n != h->n) h->used_valid = false;
     h->n = n;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     h->last_pending_valid = false;
     return RIO_GP_OK;
 }
@@ -1011,7 +1041,7 @@ static int update_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx, const
         launch_update(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, h->pos, h->dstats, h->stream, aff_life(h));
     }
     h->used_valid = false;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     if ((rc = read_stats(h))) return rc;
     if (h->h_stats[0].err) return fail(h, RIO_GP_EINVAL, "rio_gp_update_batch: invalid entries were skipped");
     return RIO_GP_OK;
@@ -1048,7 +1078,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         fold_used(h);
         launch_update_small(h->assign[h->cur], h->d_small, h->d_small + kSmallBatch, (u32)n, h->stream, aff_life(h),
                             small_done_dev(h), seq, in_args ? &inl : nullptr, h->used_valid ? h->used : nullptr, h->load, h->m);
-        h->have_solved = false;
+        h->have_solved = false; ++h->mut_epoch;
         return small_wait(h, seq);
     }
     if (n <= (uint64_t)kMidBatch) {
@@ -1060,7 +1090,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
         fold_used(h);
         launch_update(h->assign[h->cur], h->n, h->m, h->d_mid, h->d_mid + kMidBatch, n, h->pos, h->dstats, h->stream, aff_life(h),
                       h->mid_ticket, small_done_dev(h), seq, h->used_valid ? h->used : nullptr, h->load);
-        h->have_solved = false;
+        h->have_solved = false; ++h->mut_epoch;
         return small_wait(h, seq);
     }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32))) || (rc = ensure(h, h->stage[1], n * sizeof(u32)))) return rc;
@@ -1081,7 +1111,7 @@ static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, h->used_valid ? h->used : nullptr, h->dstats,
                       h->stream, aff_life(h));
     }
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     if ((rc = read_stats(h))) return rc;
     if (h->h_stats[0].err) return fail(h, RIO_GP_EINVAL, "rio_gp_remove_batch: invalid entries were skipped");
     return RIO_GP_OK;
@@ -1110,7 +1140,7 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
         fold_used(h);
         launch_remove_small(h->assign[h->cur], h->m, h->load, h->d_small, (u32)n, h->used_valid ? h->used : nullptr, h->stream,
                             aff_life(h), small_done_dev(h), seq, in_args ? &inl : nullptr);
-        h->have_solved = false;
+        h->have_solved = false; ++h->mut_epoch;
         return small_wait(h, seq);
     }
     if (n <= (uint64_t)kMidBatch) {  // medium batch, validated above: as update_batch
@@ -1119,7 +1149,7 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
         fold_used(h);
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, h->d_mid, n, h->used_valid ? h->used : nullptr, h->dstats,
                       h->stream, aff_life(h), small_done_dev(h), seq, nullptr, h->mid_ticket);
-        h->have_solved = false;
+        h->have_solved = false; ++h->mut_epoch;
         return small_wait(h, seq);
     }
     if ((rc = ensure(h, h->stage[0], n * sizeof(u32)))) return rc;
@@ -1142,7 +1172,7 @@ int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evi
     for (u32 w = 0; w < words32; ++w) h->h_cs[w] = 0;
     for (u32 j = 0; j < h->m; ++j)
         if ((dead_bitmap[j >> 6] >> (j & 63)) & 1ull) { h->h_cs[j >> 5] |= 1u << (j & 31); any = true; }
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     if (!any) return RIO_GP_OK;  // retain() with a predicate nothing matches
     const u32 seq = (small_begin(h) & 0xFFFFFFu) | 0x800000u;  // 24 bits, never 0
     fold_used(h);  // (k_clean zeroes the dead nodes' entries: what the last solve's rounds admitted there must be in first)
@@ -1241,7 +1271,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         std::swap(h->used, h->sb.used_cur);
         h->used_parts = vslow;
         h->parts_rounds = h->rounds;
-        h->have_solved = false;
+        h->have_solved = false; ++h->mut_epoch;
         return RIO_GP_OK;
     }
     // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes.  With every node alive and
@@ -1285,7 +1315,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     std::swap(h->used, h->sb.used_cur);  // the solve's `used` vector becomes the committed one (as commit does): no copy
     h->used_parts = vslow && h->sb.D != nullptr;  // + what the water-fill rounds admitted (D rows), folded in later
     h->parts_rounds = h->rounds;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     return RIO_GP_OK;
 }
 
@@ -1320,7 +1350,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         if (status == 0) {
             memcpy(out_node, hs + 2 * kSmallBatch, n * sizeof(u32));
             if (out_flag) memcpy(out_flag, hs + 3 * kSmallBatch, n * sizeof(u32));
-            h->have_solved = false;
+            h->have_solved = false; ++h->mut_epoch;
             return RIO_GP_OK;
         }
         if (status != 1) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_place_pending: micro-batch kernel left no status");
@@ -1349,7 +1379,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
             if (status == 0) {
                 memcpy(out_node, hm + 2 * kMidBatch, bytes);
                 if (out_flag) memcpy(out_flag, hm + 3 * kMidBatch, bytes);
-                h->have_solved = false;
+                h->have_solved = false; ++h->mut_epoch;
                 return RIO_GP_OK;
             }
             if (status != 1) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_place_pending: one-workgroup kernel left no status");
@@ -1456,7 +1486,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
     HIPCHK(h, hipGetLastError());
     h->ring_n++;
     h->ring_any = true;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     return RIO_GP_OK;
 }
 
@@ -1509,7 +1539,7 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventElapsedTime(scan_ms, h->ev0, h->ev1));
     HIPCHK(h, hipEventElapsedTime(resolve_ms, h->ev2, h->ev3));
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     h->ring_n = 0; h->ring_slow = 0; h->ring_any = false;
     const DevStats v = reduce_slot(h, 0, h->m);
     if (v.n_cut > 0 || v.spillcand > 0)
@@ -1571,7 +1601,7 @@ int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
     const SolveBufs lb = local_bufs(h);
     launch_resolve(h->plan, nt, lb, nullptr, h->stream);  // used_base = nullptr: purely local sums
     launch_shard_pack1(h->plan, lb, reinterpret_cast<u64*>(d_x), h->stream);
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     h->sh_state = 1;
     return RIO_GP_OK;
 }
@@ -1917,7 +1947,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
                             slot_dev(h, h->ring_n), q->co_resident, h->stream);
         h->sh_rows = resolve_blocks(h->m);
         h->ring_n++;
-        h->have_solved = false;
+        h->have_solved = false; ++h->mut_epoch;
         h->sh_state = 2;
         return RIO_GP_OK;
     }
@@ -1949,7 +1979,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     HIPCHK(h, hipEventRecord(sc->done[q], sc->side));
     sc->done_valid[q] = true;
     h->ring_n++;
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     h->sh_state = 2;
     return RIO_GP_OK;
 }
@@ -2022,7 +2052,7 @@ int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms) {
     // same columns the solve streams: cur/load/aff in, the ping-pong column out (an uncommitted solve is lost)
     *ms = stream_probe(mode, h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1], h->n, reps, h->stream, h->ev0,
                        h->ev1);
-    h->have_solved = false;
+    h->have_solved = false; ++h->mut_epoch;
     if (*ms < 0) return fail(h, RIO_GP_EUPSTREAM, "stream probe failed");
     return RIO_GP_OK;
 }

@@ -604,6 +604,69 @@ def test_async_ticks_equal_the_synchronous_stream(gp, oracle):
     g.close()
 
 
+def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle):
+    """A tick that took the fast path leaves every object placed: until an input of the solve changes, rio_gp_tick_async
+    enqueues k_scan + k_resolve only (no speculative fix-up).  Every kind of change must end that: liveness, removals,
+    updates onto other nodes, new loads / affinities, a new table, clean_server, requests — the tick right behind each is
+    compared with the oracle chain, with the verdicts of the earlier ticks given time to land (so the quiet rule is
+    actually in force when the change arrives)."""
+    import time
+    cfg = synth.config("c3", n_override=300_000)
+    n, m = cfg["n"], cfg["m"]
+    load, aff, cap = cfg["load"].copy(), cfg["aff"].copy(), cfg["cap"]
+    ref = synth.warm_assign(n, m)
+    alive = np.ones(m, np.uint8)
+    g = _mk(gp, n, m, load, aff, cap, alive, ref)
+    rng = np.random.default_rng(99)
+    want = []
+
+    def quiet_ticks(k=4):
+        nonlocal ref
+        for _ in range(k):
+            g.tick_async()
+            ref, used, ost = oracle.tick(ref, load, aff, cap, alive, 2)
+            want.append(ost)
+            time.sleep(0.003)      # the verdict lands; the next rio_gp_tick_async sees it
+
+    def changes():
+        nonlocal ref, alive
+        alive = synth.churn_mask(m, 7); g.set_alive_all(alive); yield "liveness: a tenth of the nodes dies"
+        alive = np.ones(m, np.uint8); g.set_alive_all(alive); yield "liveness: they come back"
+        idx = rng.choice(n, 20_000, replace=False).astype(np.uint32)
+        g.remove_batch(idx); ref[idx] = NONE; yield "remove"
+        idx = rng.choice(n, 30_000, replace=False).astype(np.uint32)
+        node = np.full(30_000, 5, np.uint32)                     # thirty thousand rows onto one node: far over its capacity
+        g.update_batch(idx, node); ref[idx] = 5; yield "update (kept rows stay: sticky)"
+        alive = np.ones(m, np.uint8); alive[5] = 0; g.set_alive(5, 0); yield "that node dies: its rows spill"
+        alive[5] = 1; g.set_alive(5, 1); yield "and comes back"
+        idx = rng.choice(n, 10_000, replace=False).astype(np.uint32)
+        load[idx] = rng.integers(0, 500, 10_000).astype(np.uint32); aff[idx] = rng.integers(0, m, 10_000).astype(np.uint32)
+        g.set_object_attrs(idx, load[idx], aff[idx]); yield "new loads and affinities"
+        ref = synth.warm_assign(n, m, stream=3); ref[::7] = NONE; g.set_assign(ref); yield "a new table with pending rows"
+        ev = g.clean_server(11); ref[ref == 11] = NONE; assert ev > 0; yield "clean_server"
+        idx = np.flatnonzero(ref == NONE)[:5000].astype(np.uint32)
+        used = oracle.recompute_used(ref, load, m)
+        req = rng.integers(0, m, idx.size).astype(np.uint32)
+        node, flag = g.place_pending(idx, req)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(node, wnode) and np.array_equal(flag, wflag); yield "place_pending"
+
+    quiet_ticks()
+    for what in changes():
+        g.tick_async()
+        ref, used, ost = oracle.tick(ref, load, aff, cap, alive, 2)
+        want.append(ost)
+        assert np.array_equal(g.get_assign(), ref), what
+        assert np.array_equal(g.get_nodes()[2], used), what
+        quiet_ticks()
+    got = g.tick_wait()
+    assert len(got) == len(want)
+    for k in range(len(want)):
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], used)
+    g.close()
+
+
 # ---- place_pending ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("seed,cap_inf", [(0, True), (1, False), (2, False), (3, True)])
