@@ -2999,15 +2999,18 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
                                                     const u32* __restrict__ req, u32 n, u32* __restrict__ out_node,
                                                     u32* __restrict__ out_flag, u32* __restrict__ status,
                                                     u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl, uint4 ia,
-                                                    uint4 ib) {
+                                                    uint4 ib, u32 n_obj_chk) {
+    // n_obj_chk != 0 (requests the host has not seen: rio_gp_place_pending_dev): the number of rows — an object index or a
+    // requester out of range ends the call with status 3 and nothing changed; the arrays are then exactly n entries long
+    // (no whole vector past the end)
     constexpr u32 kSlots = 2u * THREADS * PER;  // power of two
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* s_tot = reinterpret_cast<u64*>(smem);               // [kPpTot] claim load per requester
     u32* hkey = reinterpret_cast<u32*>(s_tot + kPpTot);      // [kSlots] row of the slot
     u32* hpos = hkey + kSlots;                               // [kSlots] first batch position of the row, then its final node
-    __shared__ u32 s_general;
+    __shared__ u32 s_general, s_bad;
     const u32 tid = threadIdx.x;
-    if (tid == 0) s_general = m > kPpTot ? 1u : 0u;
+    if (tid == 0) { s_general = m > kPpTot ? 1u : 0u; s_bad = 0; }
     for (u32 q = tid; q < kSlots; q += THREADS) { hkey[q] = kNone; hpos[q] = kNone; }
     for (u32 q = tid; q < kPpTot; q += THREADS) s_tot[q] = 0;
     u32 i[PER], r[PER], c[PER], l[PER], slot[PER];
@@ -3018,18 +3021,21 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
     // 16-byte read each from the mapped host buffer (PCIe read requests are what a 4 096-request call waits for) and its
     // results leave as 16-byte stores.
     uint4 iv4 = make_uint4(0, 0, 0, 0), rv4 = iv4;
-    if (PER == 4 && !ninl) {
-        iv4 = *reinterpret_cast<const uint4*>(idx + 4 * tid);  // (the staging rows are kMidBatch entries long)
+    const bool vec = PER == 4 && !ninl && (!n_obj_chk || 4 * tid + 4 <= n);  // (the staging rows are kMidBatch entries long)
+    if (vec) {
+        iv4 = *reinterpret_cast<const uint4*>(idx + 4 * tid);
         rv4 = *reinterpret_cast<const uint4*>(req + 4 * tid);
     }
+    bool bad = false;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const u32 k = tid * PER + (u32)q;
         valid[q] = k < n;
         i[q] = 0; r[q] = 0; c[q] = kNone; l[q] = 0; fre[q] = 0; r_alive[q] = false;
         if (valid[q]) {
-            i[q] = ninl ? inl_sel(ia, k) : (PER == 4 ? inl_sel(iv4, (u32)q) : idx[k]);
-            r[q] = ninl ? inl_sel(ib, k) : (PER == 4 ? inl_sel(rv4, (u32)q) : req[k]);
+            i[q] = ninl ? inl_sel(ia, k) : (vec ? inl_sel(iv4, (u32)q) : idx[k]);
+            r[q] = ninl ? inl_sel(ib, k) : (vec ? inl_sel(rv4, (u32)q) : req[k]);
+            if (n_obj_chk && (i[q] >= n_obj_chk || r[q] >= m)) { bad = true; valid[q] = false; i[q] = 0; r[q] = 0; continue; }
             c[q] = assign[i[q]];
             l[q] = load[i[q]];
             const u64 cj = cap[r[q]], uj = used[r[q]];
@@ -3038,6 +3044,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
         }
     }
     __syncthreads();
+    if (bad) s_bad = 1;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         slot[q] = (i[q] * 2654435761u) >> 7 & (kSlots - 1);  // (row ids are < 2^31: kNone never is one)
@@ -3069,8 +3076,8 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
     for (int q = 0; q < PER; ++q)
         if (claim[q] && r[q] < kPpTot && s_tot[r[q]] > fre[q]) s_general = 1;  // the requester cannot take all its first touches
     __syncthreads();
-    if (s_general) {  // hand over untouched
-        if (tid == 0) *status = 1;
+    if (s_general | s_bad) {  // hand over untouched (3: an entry out of range — the call fails)
+        if (tid == 0) *status = s_bad ? 3u : 1u;
         signal_done(done, seq);
         return;
     }
@@ -3094,7 +3101,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
             ofl[q] = (ond[q] == kNone) ? 4u : (ond[q] == r[q] ? 0u : 1u);
         }
     }
-    if (PER == 4) {
+    if (PER == 4 && (!n_obj_chk || 4 * tid + 4 <= n)) {
         if (valid[0]) {  // (the result rows are kMidBatch entries long: a whole vector is always addressable)
             *reinterpret_cast<uint4*>(out_node + 4 * tid) = make_uint4(ond[0], ond[PER > 1 ? 1 : 0], ond[PER > 2 ? 2 : 0], ond[PER > 3 ? 3 : 0]);
             *reinterpret_cast<uint4*>(out_flag + 4 * tid) = make_uint4(ofl[0], ofl[PER > 1 ? 1 : 0], ofl[PER > 2 ? 2 : 0], ofl[PER > 3 ? 3 : 0]);
@@ -3804,15 +3811,15 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
 }
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl) {
+                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk) {
     if (n <= (u32)kSmallBatch) {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kSmallBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kSmallBatch, 1>), dim3(1), dim3(kSmallBatch), lds, s, assign, load, m, cap, alive_bits, used,
-                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl));
+                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl), n_obj_chk);
     } else {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kOneBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kBlock, kOneBatch / kBlock>), dim3(1), dim3(kBlock), lds, s, assign, load, m, cap, alive_bits,
-                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr));
+                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk);
     }
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,

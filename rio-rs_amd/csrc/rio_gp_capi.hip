@@ -1412,7 +1412,28 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
     if (!n) return RIO_GP_OK;
     if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: batch too large");
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = place_pending_general(h, n, d_idx, d_requester, d_out_node, d_out_flag, true);
+    int rc;
+    if (n <= (uint64_t)kMidBatch / 4 && h->n < (1ull << 31) &&
+        (((uintptr_t)d_idx | (uintptr_t)d_requester | (uintptr_t)d_out_node | (uintptr_t)d_out_flag) & 15u) == 0) {
+        // up to 4 096 requests: the one-workgroup kernel first, reading the caller's device arrays in place (it validates the
+        // entries itself) — ONE launch and one wait when the batch is sticky hits and first touches that fit
+        if ((rc = ensure_used(h))) return rc;
+        h->h_small[4 * kSmallBatch] = 2;
+        const u32 seq = small_begin(h);
+        launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, d_idx, d_requester, (u32)n, d_out_node,
+                      d_out_flag ? d_out_flag : h->d_mid + 3 * kMidBatch, h->d_small + 4 * kSmallBatch, h->stream, aff_life(h),
+                      small_done_dev(h), seq, nullptr, (u32)h->n);
+        if ((rc = small_wait(h, seq))) return rc;
+        const u32 status = h->h_small[4 * kSmallBatch];
+        if (status == 0) {
+            h->have_solved = false; ++h->mut_epoch;
+            return RIO_GP_OK;
+        }
+        if (status == 3)
+            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
+        if (status != 1) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_place_pending_dev: one-workgroup kernel left no status");
+    }
+    rc = place_pending_general(h, n, d_idx, d_requester, d_out_node, d_out_flag, true);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());

@@ -953,6 +953,52 @@ def test_place_pending_dev_equals_host_call(gp, oracle):
     g.close()
 
 
+def test_place_pending_dev_small_batches_one_launch(gp, oracle):
+    """Device-resident batches of up to 4 096 requests go through the one-workgroup kernel first, reading the caller's
+    arrays in place: sizes that are not multiples of four (no vector past the end of an exact-size array), duplicates, a
+    flag array left out, entries out of range anywhere in the batch (status 3: EINVAL, nothing changed), requesters that are
+    dead or full (hand-over to the general path, same answers)."""
+    from hipbuf import DevBuf
+    rng = np.random.default_rng(81)
+    n, m = 150_000, 96
+    load = rng.integers(0, 40, n).astype(np.uint32)
+    cap = np.full(m, int(load.sum() // m // 3), np.uint64)           # tight: some requesters run full along the way
+    alive = np.ones(m, np.uint8)
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step, k in enumerate((1, 3, 7, 255, 256, 257, 1001, 4095, 4096, 2, 4093)):
+        if step == 6:
+            alive[[5, 40]] = 0
+            g.set_alive_all(alive)
+        idx = rng.integers(0, n if step % 2 else 3000, k).astype(np.uint32)      # (3 000 rows: duplicates, sticky hits)
+        req = rng.integers(0, m, k).astype(np.uint32)
+        d_idx, d_req, d_node, d_flag = DevBuf(idx), DevBuf(req), DevBuf(nbytes=4 * k), DevBuf(nbytes=4 * k)
+        g.place_pending_dev(k, d_idx.ptr, d_req.ptr, d_node.ptr, d_flag.ptr if step % 3 else None)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(d_node.to_host(), wnode), (step, k)
+        if step % 3:
+            assert np.array_equal(d_flag.to_host(), wflag), (step, k)
+        assert np.array_equal(g.get_assign(), ref), (step, k)
+        assert np.array_equal(g.get_nodes()[2], used), (step, k)
+        for x in (d_idx, d_req, d_node, d_flag):
+            x.free()
+    for k, where, what in ((9, 8, "idx"), (4096, 0, "req"), (1000, 999, "idx"), (257, 100, "req")):
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        req = rng.integers(0, m, k).astype(np.uint32)
+        if what == "idx":
+            idx[where] = n
+        else:
+            req[where] = m
+        d_idx, d_req, d_node = DevBuf(idx), DevBuf(req), DevBuf(nbytes=4 * k)
+        with pytest.raises(gp.ObjectPlacementError) as e:
+            g.place_pending_dev(k, d_idx.ptr, d_req.ptr, d_node.ptr)
+        assert e.value.rc == gp.EINVAL and np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], used)
+    g.close()
+
+
 def test_config1_ping_pong_plumbing(gp, oracle):
     """BASELINE config 1: 1 000 objects x 4 nodes: 1 000 misses -> first touch -> 1 000 hits ->
     clean_server(node 2) -> re-place, against the string-level reference policy."""

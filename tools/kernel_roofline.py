@@ -42,18 +42,17 @@ def specs(pending_rows):
         ("fast", r"k_scan<false, true, 2, 0", "k_scan (fast path, TPI 2)", 16 * N, "12 B read + 4 B written per row"),
         ("fast", r"k_resolve", "k_resolve", 2 * M * 8 * 256, "H: 2m u64 per block x 256 blocks"),
         ("churn", r"k_scan<false, false, 1, 2", "k_scan<COMPACT> (churn tick)", 16 * N + 16 * pk, "16 B/row + 16 B per packed pending row"),
-        ("churn", r"k_cut_find<true, false>", "k_cut_find (packed rows)", 12 * pk, "one pass over the packed pending rows of the blocks that own cuts (upper bound: all)"),
-        ("churn", r"k_cut_apply_rank<true, false>", "k_cut_apply_rank (packed rows)", 12 * pk, "12 B per packed pending row (+4 B per rejected)"),
-        ("churn", r"k_spill_rank", "k_spill_rank (round 1)", M * 24, "cap/used/alive of every node per workgroup"),
-        ("churn", r"k_spill_apply", "k_spill_apply (packed rows, both rounds)", 12 * pk, "next + load + idx of the packed rows (+8 B per placed)"),
-        ("churn_unpacked", r"k_cut_find<false, false>", "k_cut_find (whole table, churn)", 12 * N, "upper bound: every block owns a cut"),
-        ("churn_unpacked", r"k_cut_apply_rank<false, false>", "k_cut_apply_rank (whole table, churn)", 12 * N, "12 B/row"),
-        ("churn_unpacked", r"k_spill_apply", "k_spill_apply (whole table, churn)", 8 * N, "next + load per row"),
-        ("contended", r"k_cut_find<false, false>", "k_cut_find (whole table, contended)", 12 * N, "one pass over the blocks that own cuts (all)"),
-        ("contended", r"k_cut_apply_rank<false, false>", "k_cut_apply_rank (whole table, contended)", 12 * N, "12 B/row"),
-        ("contended", r"k_spill_apply", "k_spill_apply (whole table, contended)", 8 * N, "next + load per row"),
-        ("contended_packed", r"k_cut_apply_rank<false, true>", "k_cut_apply_rank<PACK> (whole table, contended: packs the water-fill rows)", 16 * N, "12 B read + 4 B written per row (+12 B per packed row)"),
-        ("contended_packed", r"k_spill_apply", "k_spill_apply (contended, rows packed at the cut pass; concentrated in the last workgroups)", 12 * N // 10, "next + load + idx of ~1 M packed rows"),
+        ("churn", r"k_resolve<true>", "k_resolve<SEARCH> (column sums + exact cuts over the packed rows)", 2 * M * 8 * 256 + 8 * pk, "H + affinity and load of the packed pending rows"),
+        ("churn", r"k_fill<true, true, true, false>", "k_fill round 0 (packed rows: re-mark, node order, water-fill)", 24 * pk, "pass A cur/aff/load + pass B next/load/idx of the packed rows (+4 B per placed row)"),
+        ("churn", r"k_fill<false, false, true, false>", "k_fill round 1 (packed rows)", 12 * pk, "next + load + idx of the packed rows (upper bound: most are placed by round 0)"),
+        ("churn_unpacked", r"k_cut_find<false>", "k_cut_find (whole table, churn)", 12 * N, "upper bound: every block owns a cut"),
+        ("churn_unpacked", r"k_fill<false, true, true, false>", "k_fill round 0 (whole table, churn)", 20 * N, "pass A 12 B/row + pass B next/load 8 B/row"),
+        ("churn_unpacked", r"k_fill<false, false, true, false>", "k_fill round 1 (whole table, churn)", 8 * N, "next + load per row"),
+        ("contended", r"k_cut_find<false>", "k_cut_find (whole table, contended)", 12 * N, "one pass over the blocks that own cuts (all)"),
+        ("contended", r"k_fill<false, true, true, false>", "k_fill round 0 (whole table, contended)", 20 * N, "pass A 12 B/row + pass B next/load 8 B/row"),
+        ("contended", r"k_fill<false, false, true, false>", "k_fill round 1 (whole table, contended)", 8 * N, "next + load per row"),
+        ("contended_packed", r"k_fill<false, true, true, true>", "k_fill<PACK> round 0 (whole table, contended: packs the water-fill rows)", 16 * N, "12 B read + 4 B written per row (+12 B per packed row)"),
+        ("contended_packed", r"k_fill<false, false, true, false>", "k_fill round 1 (contended, rows packed at the cut pass)", 12 * N // 10, "next + load + idx of ~1 M packed rows"),
         ("crud", r"k_lookup4", "k_lookup4 (10 M random indices)", 12 * N, "idx + gather + out per lookup"),
         ("lookup_seq", r"k_lookup4", "k_lookup4 (10 M sequential indices)", 12 * N, "idx + gather + out per lookup"),
         ("crud", r"k_part_bin<true>", "k_part_bin<update> (10 M random)", 8 * N, "idx + node per entry (update = bin + apply: 8 B/op over both)"),
@@ -63,13 +62,19 @@ def specs(pending_rows):
         ("crud_plain", r"k_update_elect", "k_update_elect (plain kernels, 10 M random)", 8 * N, "idx + node per entry (update = elect + apply)"),
         ("crud_plain", r"k_update_apply", "k_update_apply (plain kernels, 10 M random)", 8 * N, "see k_update_elect"),
         ("crud_plain", r"k_remove", "k_remove (plain kernel, 10 M random)", 8 * N, "idx + row per removal"),
-        ("crud", r"k_clean", "k_clean (10 % of the nodes)", 4 * N, "4 B/row read (+4 B per evicted row)"),
-        ("pp", r"k_pp_mark_dead", "k_pp_mark_dead (1 M requests)", 12 * 1_000_000, "idx + req + row per request"),
-        ("pp", r"k_pp_elect", "k_pp_elect", 8 * 1_000_000, "idx + scratch slot"),
-        ("pp", r"k_pp_gather", "k_pp_gather", 32 * 1_000_000, "idx, req, pos, assign, load in; 3 virtual columns out"),
-        ("pp", r"k_scan<true", "k_scan<VIRT> (1 M virtual rows)", 16 * 1_000_000, "16 B per virtual row"),
-        ("pp", r"k_pp_scatter", "k_pp_scatter", 16 * 1_000_000, "vcur, vnext, idx, assign"),
-        ("pp", r"k_pp_output", "k_pp_output", 24 * 1_000_000, "idx, req, assign, vcur in; node, flag out; scratch reset"),
+        ("crud", r"k_clean", "k_clean (10 % of the nodes)", 4 * N + 4 * N // 10, "4 B/row read + 4 B per evicted row"),
+        ("clean1", r"k_clean", "k_clean (one node)", 4 * N, "4 B/row read (+4 B per evicted row: 0.1 %)"),
+        ("pp", r"k_part_bin<true>", "k_part_bin (place_pending, 1 M requests)", 16 * 1000000, "idx + requester in, one 8-byte record out per request"),
+        ("pp", r"k_pp_win_gather", "k_pp_win_gather (1 M requests)", 16 * 1000000 + 8 * N, "record in + virtual row out per request; the windows' assignment and load columns once"),
+        ("pp", r"k_pp_split", "k_pp_split (1 M requests)", 16 * 1000000, "8 B in, 8 B out per request"),
+        ("pp", r"k_scan<true, true, 1, 3", "k_scan<VIRT, scatter> (1 M requests)", 24 * 1000000, "16 B per virtual row + the object column + one 4-byte store per first touch"),
+        ("pp", r"k_pp_win_output", "k_pp_win_output (1 M requests)", 28 * 1000000, "five columns in, node + flag out"),
+        ("pp10", r"k_part_bin<true>", "k_part_bin (place_pending, 10 M requests)", 16 * 10000000, "idx + requester in, one 8-byte record out per request"),
+        ("pp10", r"k_pp_win_gather", "k_pp_win_gather (10 M requests)", 16 * 10000000 + 8 * N, "record in + virtual row out per request; the windows' assignment and load columns once"),
+        ("pp10", r"k_pp_split", "k_pp_split (10 M requests)", 16 * 10000000, "8 B in, 8 B out per request"),
+        ("pp10", r"k_scan<true, true, 1, 3", "k_scan<VIRT, scatter> (10 M requests)", 24 * 10000000, "16 B per virtual row + the object column + one 4-byte store per first touch"),
+        ("pp10", r"k_pp_win_output", "k_pp_win_output (10 M requests)", 28 * 10000000, "five columns in, node + flag out"),
+        ("pp_small", r"k_pp_one<1024, 4>", "k_pp_one (4 096 host-buffer requests, one launch)", 28 * 4096, "idx + requester in over PCIe, node + flag out, the rows"),
     ]
 
 

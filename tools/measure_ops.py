@@ -154,6 +154,6 @@ for k in (1000, 100_000, 1_000_000, 10_000_000):
         L.rio_gp_place_pending_dev(h2 := g.handle, k, vp(perm.data_ptr()), vp(reqp.data_ptr()), vp(onode.data_ptr()), vp(oflag.data_ptr()))
         ts.append(g.timer_end() * 1e-3)
     rec("place_pending_dev batch=%d (cold rows)" % k, k, float(np.mean(ts[1:])), 28,
-        "device-resident requests; includes the validation read-back and the verdict wait (2 host waits)")
+        "device-resident requests, wall clock of the call (validated on the device, one verdict wait)")
 g.close()
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", tag + "_ops.json"), "w"), indent=1)
