@@ -184,46 +184,80 @@ def parity_sharded(dist, backend, g, sol, workload, n_total, m, bounds, rank, wo
     return rec
 
 
-def sharded_ticks(a, dist, torch, g, sol, workload, n_total, m, bounds, rank, world, cap, ticks=10):
-    """Committed ticks of the row-sharded table, after the parity step left it committed (warm): (i) `ticks` churn-free
-    ticks (every row kept: scan + exchange + verdict + commit), (ii) BASELINE config 5 on the sharded table: per tick a
-    liveness push (10 % of the nodes down, a different 10 % each tick) and one committed tick — the fix-up exchanges of
-    rio_gp_shard_cut / _merge / _spill, every phase a host round trip.  Max over ranks.  The final table of (ii) is
-    checked against the oracle chained over the same masks (rank 0, whole table) when that takes seconds, not minutes."""
+def sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, rank, world, cap, ticks=10):
+    """Committed ticks of the row-sharded table, after the parity step left it committed (warm): (i) churn-free ticks
+    (every row kept: scan + exchange + verdict + commit), (ii) BASELINE config 5 on the sharded table: per tick a liveness
+    push (10 % of the nodes down, a different 10 % each tick) and one committed tick with its fix-up exchanges —
+    synchronous (`ShardedSolver.tick`: every phase returns to the host) and, over the peer-to-peer windows, asynchronous
+    (`rio_gp_shard_tick_async`: the whole chain enqueued, guarded on the device, counters read at the end).  Max over ranks.
+    The final table is checked against the oracle chained over the same ticks and masks (rank 0, whole table) when that
+    takes seconds, not minutes."""
     import synth
     dev = "cuda" if a.backend == "nccl" else "cpu"
+    schedule = []                       # the liveness mask every executed tick ran under (None: unchanged)
+    masks = [synth.churn_mask(m, k + 1) for k in range(2 * ticks + 4)]
 
     def timed(step, k):
         dist.barrier(); g.sync()
         t0 = time.perf_counter()
         out = [step(i) for i in range(k)]
+        out = [x for x in out if x is not None]
+        fin = getattr(step, "finish", None)
+        if fin is not None:
+            out = fin()
         g.sync()
         t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), out
 
-    sol.tick()                                                   # (a warm-up of the committed path itself)
-    dt_keep, sts = timed(lambda i: sol.tick(), ticks)
-    keep = {"ms_per_tick": dt_keep / ticks * 1e3, "value": n_total * ticks / dt_keep, "unit": "decisions/s",
-            "slow_path_ticks": int(sum(x["slow_path"] for x in sts)),
-            "step": "ShardedSolver.tick: solve_async + solve_wait (verdict, global counters) + commit, the host in the loop"}
-    masks = [synth.churn_mask(m, k + 1) for k in range(ticks + 2)]
-
-    def churn(i):
-        g.set_alive_all(masks[i])
+    def keep_sync(i):
+        schedule.append(None)
         return sol.tick()
-    churn(0); churn(1)
-    dt_ch, sts = timed(lambda i: churn(i + 2), ticks)
-    moved = sum(x["claimed"] + x["spilled"] for x in sts)
-    rec = {"ticks": ticks, "committed_tick_no_churn": keep,
-           "churn": {"ms_per_tick": dt_ch / ticks * 1e3, "value": n_total * ticks / dt_ch, "unit": "decisions/s",
-                     "objects_moved_per_s": moved / dt_ch, "slow_path_ticks": int(sum(x["slow_path"] for x in sts)),
-                     "stats_last_tick": sts[-1],
-                     "step": "rio_gp_set_alive_all + ShardedSolver.tick: scan, exchange, verdict, cut + export, exchange, merge, "
-                             "then per water-fill round spill + export, exchange, merge; counters; commit — synchronous, every "
-                             "phase returns to the host (an asynchronous form of the sharded fix-up is not built)"}}
-    if a.no_parity or n_total * (ticks + 4) > 400_000_000:
-        rec["churn"]["parity"] = None
+
+    def churn_sync(i):
+        g.set_alive_all(masks[i]); schedule.append(masks[i])
+        return sol.tick()
+
+    def rec_of(dt, sts, k, step):
+        return {"ms_per_tick": dt / k * 1e3, "value": n_total * k / dt, "unit": "decisions/s",
+                "objects_moved_per_s": sum(x["claimed"] + x["spilled"] for x in sts) / dt,
+                "slow_path_ticks": int(sum(x["slow_path"] for x in sts)), "stats_last_tick": sts[-1], "step": step}
+
+    keep_sync(0)                                                 # (a warm-up of the committed path itself)
+    dt, sts = timed(keep_sync, ticks)
+    rec = {"ticks": ticks, "committed_tick_no_churn": rec_of(dt, sts, ticks,
+           "ShardedSolver.tick: solve_async + solve_wait (verdict, global counters) + commit, the host in the loop")}
+    churn_sync(0); churn_sync(1)
+    dt, sts = timed(lambda i: churn_sync(i + 2), ticks)
+    rec["churn"] = rec_of(dt, sts, ticks,
+                          "rio_gp_set_alive_all + ShardedSolver.tick: scan, exchange, verdict, cut + export, exchange, merge, then per "
+                          "water-fill round spill + export, exchange, merge; counters; commit — synchronous, every phase returns to the host")
+    last = sts[-1]
+    if kind == "p2p":
+        class KeepAsync:
+            def __call__(self, i):
+                schedule.append(None); sol.tick_async()
+            def finish(self):
+                return sol.tick_wait()
+
+        class ChurnAsync:
+            def __call__(self, i):
+                mk = masks[ticks + 2 + i]
+                g.set_alive_all(mk); schedule.append(mk); sol.tick_async()
+            def finish(self):
+                return sol.tick_wait()
+        KeepAsync()(0); sol.tick_wait()
+        dt, sts = timed(KeepAsync(), ticks)
+        rec["committed_tick_no_churn_async"] = rec_of(dt, sts, ticks,
+            "rio_gp_shard_tick_async: scan, one-launch exchange, the guarded fix-up chain (nothing to do), commit; nothing waits "
+            "on the host, counters read at the end")
+        dt, sts = timed(ChurnAsync(), ticks)
+        rec["churn_async"] = rec_of(dt, sts, ticks,
+            "rio_gp_set_alive_all + rio_gp_shard_tick_async: the same chain with its cut pass, water-fill rounds and three "
+            "peer-to-peer exchanges per tick, enqueued back to back")
+        last = sts[-1]
+    if a.no_parity or n_total * (len(schedule) + 2) > 600_000_000:
+        rec["parity"] = None
         return rec
     mine, used = g.get_assign(), g.get_nodes()[2]
     nmax = max(bounds[r + 1] - bounds[r] for r in range(world))
@@ -238,22 +272,23 @@ def sharded_ticks(a, dist, torch, g, sol, workload, n_total, m, bounds, rank, wo
     import pyoracle
     glob = synth.config(workload, n_override=n_total, start=0)
     t0 = time.perf_counter()
-    ones = np.ones(m, np.uint8)
-    ref, wused, ost = pyoracle.tick(glob["cur"], glob["load"], glob["aff"], cap, glob["alive"], 2)   # the parity step's commit
-    for _ in range(ticks + 1):                                                                      # warm-up + churn-free ticks
-        ref, wused, ost = pyoracle.tick(ref, glob["load"], glob["aff"], cap, ones, 2)
-    for k in range(ticks + 2):
-        ref, wused, ost = pyoracle.tick(ref, glob["load"], glob["aff"], cap, masks[k], 2)
+    alive = glob["alive"]
+    ref, wused, ost = pyoracle.tick(glob["cur"], glob["load"], glob["aff"], cap, alive, 2)   # the parity step's commit
+    for mk in schedule:
+        alive = alive if mk is None else mk
+        ref, wused, ost = pyoracle.tick(ref, glob["load"], glob["aff"], cap, alive, 2)
     got = np.concatenate([rows_all[r].cpu().numpy().astype(np.uint32)[:bounds[r + 1] - bounds[r]] for r in range(world)])
     keys = ("n_objects", "kept", "evicted", "claimed", "spilled", "unplaced", "load_kept", "load_claimed", "load_spilled",
-            "load_unplaced", "cut_nodes", "slow_path")
+            "load_unplaced", "cut_nodes", "slow_path", "rounds_run")
     eq_a = bool(np.array_equal(got, ref))
     eq_u = all(bool(np.array_equal(used_all[r].cpu().numpy().astype(np.uint64), wused)) for r in range(world))
-    eq_s = all(sts[-1][k] == ost[k] for k in keys)
-    rec["churn"]["parity"] = {"checked_rows": int(n_total), "ticks_replayed": 2 * ticks + 4, "equal": eq_a and eq_u and eq_s,
-                              "assign_equal": eq_a, "used_equal_on_every_rank": eq_u, "stats_equal": eq_s,
-                              "against": "oracle/placement_oracle.c orc_tick chained over the same ticks and liveness masks on the "
-                                         "WHOLE table (rank 0)", "oracle_seconds": time.perf_counter() - t0}
+    eq_s = all(last[k] == ost[k] for k in keys)
+    rec["parity"] = {"checked_rows": int(n_total), "ticks_replayed": len(schedule) + 1, "equal": eq_a and eq_u and eq_s,
+                     "assign_equal": eq_a, "used_equal_on_every_rank": eq_u, "stats_equal": eq_s,
+                     "against": "oracle/placement_oracle.c orc_tick chained over the same ticks and liveness masks on the WHOLE "
+                                "table (rank 0), after the last stream", "oracle_seconds": time.perf_counter() - t0}
+    if not eq_s:
+        rec["parity"]["stats_gpu"], rec["parity"]["stats_oracle"] = last, ost
     return rec
 
 
@@ -366,8 +401,12 @@ def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
         gl.set_objects(n, cfg["load"], cfg["aff"])
         gl.set_assign(warm)
         gl.tick()
+        for k in range(60):      # the stream's steady state: the first ticks after the warm table are ~10 us cheaper
+            gl.set_alive_all(masks[k % total])
+            gl.tick_async()
+        gl.tick_wait()
         gl.ktrace(True)
-        for k in range(6):
+        for k in range(60, 66):
             gl.set_alive_all(masks[k % total])
             gl.tick()
         names = {3: "k_scan<COMPACT>", 0: "k_resolve<SEARCH>", 1: "k_fill round 0", 2: "k_fill round 1"}
@@ -516,7 +555,7 @@ def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank
         if a.no_parity:
             sol.tick()   # the committed (warm) table the tick streams start from
         try:
-            ticks = sharded_ticks(a, dist, torch, g, sol, workload, n_total, m, bounds, rank, world, cfg["cap"],
+            ticks = sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, rank, world, cfg["cap"],
                                   ticks=max(2, min(a.steps, 10)))
         except Exception as e:  # a second measurement: it must not take the line down with it
             ticks = {"error": repr(e)[:300]}
@@ -630,7 +669,7 @@ def main():
         print(json.dumps(out), flush=True)
         bad = [p for p in (prim["parity"], weak["parity"] if weak else None) if p is not None and not p["equal"]]
         for r_ in (prim, weak):
-            cp = ((r_ or {}).get("committed_ticks") or {}).get("churn", {}).get("parity") if r_ else None
+            cp = ((r_ or {}).get("committed_ticks") or {}).get("parity") if r_ else None
             if cp is not None and not cp["equal"]:
                 bad.append(cp)
         if bad:

@@ -301,6 +301,23 @@ int rio_gp_shard_p2p_ready(rio_gp_t* h);
 /* Unmap the peers' windows and free ours (e.g. to fall back to RCCL after a time-out). */
 int rio_gp_shard_p2p_close(rio_gp_t* h);
 
+/* One COMMITTED tick of the row-sharded table with nothing waiting on the host (peer-to-peer windows only; the sharded twin
+ * of rio_gp_tick_async): the scan and the one-launch exchange, then the whole fix-up chain — exact cut on this rank, Y
+ * record out, everyone's in, one water-fill round per spill round, each followed by its exchange — every step guarded on the
+ * device, so a tick that needs none of it pays a handful of short launches, and the publication (two pointer swaps).  The
+ * result is what the synchronous sequence above computes.  All ranks must enqueue the same ticks in the same order; at most
+ * 64 may be in flight.  rio_gp_shard_tick_wait waits for them and returns the records of the last `cap` (oldest first),
+ * *n_out = how many had been enqueued: this rank's counters (sum them over the ranks) and the global verdict of each tick. */
+typedef struct rio_gp_shard_tick_info {
+    rio_gp_stats local;   /* this rank's rows (cut_nodes / slow_path / rounds_run of it: the global values below) */
+    uint64_t cut_nodes;   /* global */
+    uint64_t spill_rows;  /* global: rows that went to the water-fill before any cut */
+    uint32_t slow_path;   /* the tick needed the fix-up (on any rank) */
+    uint32_t rounds_run;  /* water-fill rounds that had rows pending */
+} rio_gp_shard_tick_info;
+int rio_gp_shard_tick_async(rio_gp_t* h);
+int rio_gp_shard_tick_wait(rio_gp_t* h, rio_gp_shard_tick_info* out, uint32_t cap, uint32_t* n_out);
+
 /* Optional: let the library issue the all-gathers itself through RCCL (resolved at run time with dlopen — the
  * copy already in the process, else librccl.so.1; `rccl_path` may name one, NULL = default search).  The host only
  * moves the 128-byte ncclUniqueId from rank 0 to the other ranks over its own control channel:

@@ -45,6 +45,9 @@ struct Plan {
                  // host spins on instead of waiting for the stream
     // packed fix-up (see PackOut): when set, wave gw's rows are only the first wcnt[gw] positions of its range
     const u32* wcnt;
+    // k_scan only (launch_scan sets it from NodeTab::alive_src): the liveness bitmap the kernel was given is a fresh one in
+    // mapped host memory; workgroup 0 copies it here, the device array the kernels behind the scan read
+    u32* alive_dst;
 };
 Plan make_plan(u64 n, u32 m, u32 max_blocks);
 u64 plan_wave_row_lo(u64 n, u32 m, u32 gw, u32* nw_out);  // first row of wave range gw, as the device computes it (debug / tests)
@@ -58,6 +61,7 @@ struct DevStats {
     u64 rounds_run;                                     // k_spill_rank
     u64 evicted_clean;                                  // k_clean
     u64 err;                                            // invalid entries seen by batch kernels
+    u64 local_fixup;                                    // row-sharded solve: nodes whose claimants of THIS rank need re-marking (k_resolve_xchg)
 };
 
 // Per-workgroup rows of the fix-up counters (a whole-table solve whose counters the host wants): workgroup b of the
@@ -96,6 +100,8 @@ struct SolveBufs {
     u32* forced_bits;        // [mwords]
     u64* rank_base;          // [1]
     const u64* pending_global;  // [1] rows still pending on ALL ranks (k_shard_import_delta), nullptr = local count
+    const u64* run_if = nullptr;  // the re-marking pass (k_fill<APPLY> without FILL) returns at once when *run_if == 0
+                                  // (asynchronous row-sharded tick: DevStats::local_fixup; nullptr = always run)
     // The claim load the cuts reject, for the ordered spill prefix of k_fill's round 0 (no pass over rows):
     u64* RP;         // [node groups][G] by node group, in the blocks BEFORE block b: k_scan zeroes, a k_resolve workgroup that owns
                      //   cut nodes stores its row (plain stores, whole lines); nullptr: not maintained
@@ -142,6 +148,9 @@ struct NodeTab {
     const u64* cap;         // [m]
     const u32* alive_bits;  // [mwords]
     const u64* used_base;   // [m] or nullptr (virtual table: the committed `used`)
+    // A liveness push that has not reached alive_bits yet (else nullptr): the bitmap in mapped pinned host memory.  The
+    // scan of the next solve reads it from there and brings alive_bits up to date on its way — the push costs no launch.
+    const u32* alive_src = nullptr;
 };
 
 // --- solve pipeline ---
@@ -275,6 +284,7 @@ void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_
 void launch_p2p_wait_copy(const u64* win_slot, size_t W, u32 R, u32 words, const u64* flags, u64 seq, u64* err, u64* out,
                           hipStream_t s);
 void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s);
+void launch_shard_tick_stats(const Plan& p, const SolveBufs& b, u64* out_host, u64 mark, hipStream_t s);
 void launch_shard_import_delta(const Plan& p, const SolveBufs& b, const u64* Yg, u32 rank, u32 R, u64* gprev,
                                u64* verdict_dev, u64* verdict_host, hipStream_t s);
 

@@ -149,6 +149,7 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     p.m = m;
     p.mwords = (m + 31) / 32;
     p.wcnt = nullptr;
+    p.alive_dst = nullptr;
     p.trace = trace_flag();
     p.mark = 1;
     if (max_blocks == 0 || max_blocks > kMaxBlocks) max_blocks = kMaxBlocks;
@@ -392,8 +393,12 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     }
 
     for (u32 k = tid; k < 2 * m + 2; k += kBlock) hist[k] = 0;
-    if (!ALLALIVE)
-        for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    if (!ALLALIVE || (p.alive_dst && blockIdx.x == 0))
+        for (u32 k = tid; k < p.mwords; k += kBlock) {
+            const u32 w = alive_bits[k];
+            if (!ALLALIVE) alv[k] = w;
+            if (p.alive_dst && blockIdx.x == 0) p.alive_dst[k] = w;  // a fresh bitmap (mapped host memory) -> the device array
+        }
     if (tid < 4) bst[tid] = 0;
     u64& bsum = *reinterpret_cast<u64*>(smem + 32);          // spill-candidate load of the whole block
     if (tid == 0) bsum = 0;
@@ -410,6 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
         stats->rounds_run = 0;
         stats->n_cut = 0;  // device-side "a node has a cut" flag (k_resolve / k_cutblk)
+        stats->local_fixup = 0;
     }
     __syncthreads();
 
@@ -1569,6 +1575,7 @@ struct FillArgs {
     DevStats* stats;
     const u32* pk_idx; u32* real_next;                             // rows are packed: decisions also go to real_next[pk_idx[pos]]
     const u64* rank_base; const u64* pending_global;               // row-sharded solve
+    const u64* run_if;                                             // APPLY only: nothing to do when *run_if == 0 (nullptr: run)
     FxRows fx;
     PackOut pko;                                                   // PACK
 };
@@ -1611,6 +1618,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
     RIOGP_KT(p, kt, 0);
     // ---- prologue: every global operand is requested before the first one is used, with clamped addresses instead of
     //      predicates (a load behind a branch turns every later wait into a wait for ALL loads)
+    if (APPLY && !FILL && a.run_if && *a.run_if == 0) return;  // (wave-uniform, before anything is requested)
     const u32 wc = *(p.wcnt ? p.wcnt + gw : a.wsp_cnt_in + gw);
     const u32 pc = a.wsp_cnt_in[gw];
     const u64 ncut = a.stats->n_cut;
@@ -3238,7 +3246,8 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
                                                       u32* __restrict__ cutidx, u64* __restrict__ gprev,
                                                       u64* __restrict__ gfinal, u32* __restrict__ forced_bits,
                                                       u64* __restrict__ rank_base, u64* __restrict__ partial,
-                                                      u64* __restrict__ host_partial, const u32 nb /* node groups */) {
+                                                      u64* __restrict__ host_partial, const u32 nb /* node groups */,
+                                                      DevStats* __restrict__ stats) {
     // gridDim.x == nb on a GPU of its own: one node group per workgroup, nobody waits for a workgroup of its own rank.
     // Ranks that SHARE a device get a bounded grid (launch_resolve_xchg) and every workgroup walks its node groups: all
     // sends first, then the waits — the spinning workgroups of all co-resident ranks then fit the chip next to the scan
@@ -3340,6 +3349,7 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
             if (b == 0) *rank_base = 0;
         }
         if (tid < 8) host_partial[(size_t)b * 8 + tid] = outc[tid];
+        if (tid == 0 && outc[2]) atomicAdd(&stats->local_fixup, outc[2]);  // (zeroed by k_scan) the guard of the asynchronous tick's re-marking pass
         __syncthreads();  // got / outc / nib go round again
     }
 }
@@ -3468,6 +3478,23 @@ __global__ __launch_bounds__(kBlock) void k_shard_import_delta(const u64* __rest
     }
 }
 
+// Asynchronous row-sharded tick: this rank's counters of the tick into its pinned record — k_resolve_xchg's partial rows
+// added up (0 load kept 1 load claimed 3 kept 4 evicted 5 claimants 6 spill candidates) | the fix-up counters of DevStats
+// (8 rejected 9 its load 10 spilled 11 its load 12 unplaced 13 its load) | 15 the tick's mark
+__global__ __launch_bounds__(64) void k_shard_tick_stats(const u64* __restrict__ partial, u32 nb, const DevStats* __restrict__ st,
+                                                         u64* __restrict__ out, u64 mark) {
+    const int tid = threadIdx.x;
+    if (tid < 8) {
+        u64 acc = 0;
+        for (u32 r = 0; r < nb; ++r) acc += partial[(size_t)r * 8 + tid];
+        out[tid] = acc;
+    } else if (tid < 16) {
+        const int k = tid - 8;
+        out[tid] = k == 0 ? st->rejected : k == 1 ? st->load_rejected : k == 2 ? st->spilled : k == 3 ? st->load_spilled
+                 : k == 4 ? st->unplaced : k == 5 ? st->load_unplaced : k == 7 ? mark : 0ull;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
@@ -3483,13 +3510,16 @@ static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, cons
                           hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr) {
     const size_t lds = scan_lds_bytes(p.m) + (COMPACT == 2 ? (size_t)kWaves * 4 * kStageCap * sizeof(u32) : 0);
     const PackOut pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
+    Plan pp = p;
+    pp.alive_dst = nt.alive_src ? const_cast<u32*>(nt.alive_bits) : nullptr;
+    const u32* abits = nt.alive_src ? nt.alive_src : nt.alive_bits;
     if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
         hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
-                              t.cur, t.load, t.aff, t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
+                              t.cur, t.load, t.aff, t.next, abits, pp, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
                               b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);
     else
         hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
-                           t.next, nt.alive_bits, p, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx, b.bsp_sum[0],
+                           t.next, abits, pp, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx, b.bsp_sum[0],
                            b.bsp_cnt[0], b.R, b.RP);
 }
 
@@ -3620,7 +3650,7 @@ void launch_fill(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
     a.last = last ? ((t.none_prewritten || pack) ? 2 : 1) : 0;
     a.stats = b.stats;
     a.pk_idx = t.pk_idx; a.real_next = pack ? t.next : t.real_next;
-    a.rank_base = b.rank_base; a.pending_global = b.pending_global;
+    a.rank_base = b.rank_base; a.pending_global = b.pending_global; a.run_if = b.run_if;
     a.fx = b.fx;
     a.pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t lds = fill_lds_bytes(p.m, p.mwords, pack != nullptr);
@@ -3869,7 +3899,7 @@ void launch_resolve_xchg(const Plan& p, const NodeTab& nt, const SolveBufs& b, u
     }
     hipLaunchKernelGGL(k_resolve_xchg, dim3(grid), dim3(256), 0, s, b.H, b.blkstat, p, d_peers, R, rank,
                        my_row_off, win_rows, W, seq, p2p_err, nt.cap, nt.alive_bits, b.used_kept, b.used_cur, b.claim_tot,
-                       b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits, b.rank_base, b.partial, host_partial, nb);
+                       b.cutblk, b.cutidx, gprev, gfinal, b.forced_bits, b.rank_base, b.partial, host_partial, nb, b.stats);
 }
 void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_t data_off, size_t flag_off, u64 seq,
                     hipStream_t s) {
@@ -3882,6 +3912,9 @@ void launch_p2p_wait_copy(const u64* win_slot, size_t W, u32 R, u32 words, const
 void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s) {
     hipLaunchKernelGGL(k_shard_export_delta, dim3(1), dim3(kBlock), 0, s, b.used_cur, base, b.wsp_sum[wsp_sel],
                        b.wsp_cnt[wsp_sel], p.nw, p.m, Y);
+}
+void launch_shard_tick_stats(const Plan& p, const SolveBufs& b, u64* out_host, u64 mark, hipStream_t s) {
+    hipLaunchKernelGGL(k_shard_tick_stats, dim3(1), dim3(64), 0, s, b.partial, resolve_blocks(p.m), b.stats, out_host, mark);
 }
 void launch_shard_import_delta(const Plan& p, const SolveBufs& b, const u64* Yg, u32 rank, u32 R, u64* gprev,
                                u64* verdict_dev, u64* verdict_host, hipStream_t s) {

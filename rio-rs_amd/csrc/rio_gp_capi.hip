@@ -111,6 +111,12 @@ struct rio_gp {
     // node table
     u64 *cap = nullptr, *used = nullptr;
     u32 *alive_bits = nullptr, *dead_bits = nullptr;
+    // A liveness push is a bitmap written into a ring slot of mapped pinned memory (no launch).  It reaches alive_bits with
+    // the next whole-table scan, which reads it from the slot (scan_nodes), or through flush_alive when something else
+    // needs the device array first.
+    u32 *h_alive_ring = nullptr, *d_alive_ring = nullptr;
+    u32 alive_slot_words = 0, alive_slot = 0;
+    bool alive_dirty = false;
     uint8_t* alive_bytes = nullptr;
     std::vector<uint8_t> h_alive;
     bool used_valid = true;
@@ -191,6 +197,9 @@ struct rio_gp {
     DevBuf vt[4], stage[4];
     DevBuf vrec;  // big place_pending batches: virtual-table records {cur | load}, 8 bytes per request
     DevBuf part;  // scratch of the partitioned update / remove batches (records + fragment tables)
+    DevBuf sh_y, sh_yg;   // asynchronous row-sharded tick: this rank's Y record, everyone's
+    u32 sh_tick_n = 0;    // asynchronous row-sharded ticks in flight (their records: verdict slots of the tick ring, h_fx slots)
+    u64 sh_tick_mark[kRing] = {};
     std::vector<void*> allocs;
 };
 
@@ -288,7 +297,29 @@ void fill_stats(const DevStats& d, u64 n, rio_gp_stats* s) {
 
 u32* aff_life(rio_gp* h) { return h->lifecycle ? h->aff : nullptr; }
 Table real_table(rio_gp* h) { return Table{h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1]}; }
-NodeTab real_nodes(rio_gp* h) { return NodeTab{h->cap, h->alive_bits, nullptr}; }
+constexpr u32 kAliveSlots = 2 * kRing + 4;  // every slot handed to a scan belongs to a solve or tick of a ring of kRing
+void launch_alive_words(rio_gp* h) {
+    WordPack pk;
+    const u32 words = (h->m + 31) / 32;
+    memcpy(pk.w, h->h_alive_ring + (size_t)h->alive_slot * h->alive_slot_words, sizeof(u32) * (words ? words : 1));
+    launch_store_words(pk, words, h->alive_bits, h->stream);
+}
+// the device's liveness bitmap is up to date after this (one tiny kernel if a push is pending)
+void flush_alive(rio_gp* h) {
+    if (!h->alive_dirty) return;
+    h->alive_dirty = false;
+    launch_alive_words(h);
+}
+NodeTab real_nodes(rio_gp* h) { flush_alive(h); return NodeTab{h->cap, h->alive_bits, nullptr}; }
+// the node tables for a whole-table solve that starts with k_scan: a pending liveness push rides in that launch
+NodeTab scan_nodes(rio_gp* h) {
+    NodeTab nt{h->cap, h->alive_bits, nullptr};
+    if (h->alive_dirty) {
+        h->alive_dirty = false;
+        nt.alive_src = h->d_alive_ring + (size_t)h->alive_slot * h->alive_slot_words;
+    }
+    return nt;
+}
 
 // The fix-up of a solve whose fast path said it needs one (or may need one: every kernel here guards itself on the
 // device, so the sequence can be enqueued before the host has read the verdict):
@@ -416,7 +447,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     const bool fx_last = h->rounds >= 1;
     if (fx_last) h->sb.fx.seq = seq;
     const Table t = real_table(h);
-    const NodeTab nt = real_nodes(h);
+    const NodeTab nt = scan_nodes(h);
     // Adaptive packed fix-up: when the previous solve left few rows pending — but some: a stream without churn keeps the
     // plain scan, two tiles in flight — (a churn stream: most rows are kept),
     // k_scan also packs this solve's pending rows per wave, and — if the verdict then asks for the fix-up — the cut
@@ -530,7 +561,7 @@ int tick_async_locked(rio_gp* h) {
     const bool quiet = h->quiet_epoch == h->mut_epoch && h->spec_mode != 1;
     h->plan = make_plan(h->n, h->m, 0);
     const Table t = real_table(h);
-    const NodeTab nt = real_nodes(h);
+    const NodeTab nt = scan_nodes(h);
     const bool compact = !quiet && (h->compact_mode == 1 ||
                          (h->compact_mode == 0 && h->last_pending_valid && h->last_pending > 0 && h->last_pending * 4 <= h->n && h->n >= 65536));
     const u32 k = h->tick_n;
@@ -713,6 +744,15 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     }
     h->allocs.push_back(h->cs_cnt);
     h->allocs.push_back(h->cs_ticket);
+    h->alive_slot_words = (((u32)h->cap_nodes + 31) / 32 + 4 + 31) & ~31u;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_alive_ring), (size_t)kAliveSlots * h->alive_slot_words * sizeof(u32),
+                      hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_alive_ring), h->h_alive_ring, 0) != hipSuccess) {
+        h->err = "hipHostMalloc(mapped liveness ring) failed";
+        (void)hipGetLastError();
+        rio_gp_destroy(h);
+        return RIO_GP_EUPSTREAM;
+    }
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_small), (size_t)6 * kSmallBatch * sizeof(u32), hipHostMallocMapped) !=
             hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_small), h->h_small, 0) != hipSuccess) {
@@ -764,6 +804,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_mid) (void)hipHostFree(h->h_mid);
     if (h->h_cs) (void)hipHostFree(h->h_cs);
+    if (h->h_alive_ring) (void)hipHostFree(h->h_alive_ring);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -799,6 +840,7 @@ int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t
     }
     launch_pack_alive(h->alive_bytes, m, h->alive_bits, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->alive_dirty = false;
     h->all_alive = true;
     for (uint32_t j = 0; j < m; ++j) h->all_alive = h->all_alive && h->h_alive[j];
     if (m != h->m) { h->used_valid = false; h->used_parts = false; }
@@ -807,19 +849,22 @@ int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t
     return RIO_GP_OK;
 }
 
-// Liveness push without a host wait: bitmap packed here, delivered in the arguments of one tiny kernel.
+// Liveness push without a host wait and without a launch: the bitmap is packed into a ring slot of mapped pinned memory;
+// the next whole-table scan reads it from there (scan_nodes), anything else that needs the device array first makes
+// flush_alive deliver it in the arguments of one tiny kernel.
 static int push_alive_bits(rio_gp* h) {
     static_assert(RIO_GP_MAX_NODES <= 256 * 32, "WordPack holds RIO_GP_MAX_NODES bits");
-    WordPack pk;
     const u32 words = (h->m + 31) / 32;
-    memset(pk.w, 0, sizeof(u32) * (words ? words : 1));
+    if (!h->alive_dirty) h->alive_slot = (h->alive_slot + 1) % kAliveSlots;  // (an unconsumed push is simply overwritten)
+    u32* w = h->h_alive_ring + (size_t)h->alive_slot * h->alive_slot_words;
+    memset(w, 0, sizeof(u32) * (words ? words : 1));
     h->all_alive = true;
     for (uint32_t j = 0; j < h->m; ++j) {
-        if (h->h_alive[j]) pk.w[j >> 5] |= 1u << (j & 31);
+        if (h->h_alive[j]) w[j >> 5] |= 1u << (j & 31);
         else h->all_alive = false;
     }
-    launch_store_words(pk, words, h->alive_bits, h->stream);
-    HIPCHK(h, hipGetLastError());
+    std::atomic_thread_fence(std::memory_order_release);
+    h->alive_dirty = true;
     h->have_solved = false; ++h->mut_epoch;
     return RIO_GP_OK;
 }
@@ -1222,6 +1267,7 @@ int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
 // done_seq != 0: the request / result arrays are mapped pinned memory and the last kernel stores the completion word
 static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const u32* d_req, u32* d_out, u32* d_flag,
                                  bool check_entries, u32 done_seq = 0) {
+    flush_alive(h);  // the request kernels read the device's liveness bitmap
     int rc;
     const size_t bytes = n * sizeof(u32);
     for (int q = 0; q < 4; ++q)
@@ -1329,6 +1375,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
     if (!n) return RIO_GP_OK;
     if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: batch too large");
     HIPCHK(h, hipSetDevice(h->device));
+    flush_alive(h);
     int rc;
     if (n <= (uint64_t)kSmallBatch) {
         // micro-batch: one workgroup, one launch, request/result arrays in mapped pinned memory (no staging copies)
@@ -1412,6 +1459,7 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
     if (!n) return RIO_GP_OK;
     if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: batch too large");
     HIPCHK(h, hipSetDevice(h->device));
+    flush_alive(h);
     int rc;
     if (n <= (uint64_t)kMidBatch / 4 && h->n < (1ull << 31) &&
         (((uintptr_t)d_idx | (uintptr_t)d_requester | (uintptr_t)d_out_node | (uintptr_t)d_out_flag) & 15u) == 0) {
@@ -1502,7 +1550,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
     h->plan = make_plan(h->n, h->m, 0);
     use_fx_slot(h, 0);
     const Table t = real_table(h);
-    const NodeTab nt = real_nodes(h);
+    const NodeTab nt = scan_nodes(h);
     enqueue_scan_resolve(h, t, nt, false, slot_dev(h, h->ring_n));
     HIPCHK(h, hipGetLastError());
     h->ring_n++;
@@ -1549,7 +1597,7 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     h->plan = make_plan(h->n, h->m, 0);
     use_fx_slot(h, 0);
     const Table t = real_table(h);
-    const NodeTab nt = real_nodes(h);
+    const NodeTab nt = scan_nodes(h);
     // hipExtLaunchKernelGGL start/stop events = the dispatch's own begin/end timestamps
     fold_used(h);
     h->sb.D = h->D;
@@ -2002,6 +2050,121 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     h->ring_n++;
     h->have_solved = false; ++h->mut_epoch;
     h->sh_state = 2;
+    return RIO_GP_OK;
+}
+
+// ---- asynchronous committed tick of the row-sharded table (peer-to-peer windows) ----
+// Record of tick k in pinned memory: k_resolve_xchg's partial verdict rows in the tick ring's slot k (d_slots), and in slot
+// 1 + k of the fix-up counter rows (h_fx; the row-sharded solve does not use them otherwise): rows 0-1 = this rank's counters
+// (k_shard_tick_stats, 16 words), row 2 + e = {rows, load} pending on all ranks after exchange e (k_shard_import_delta).
+static void shard_exchange_y(rio_gp* h, const SolveBufs& b, const u64* base, int wsp_sel, u64* verdict_host) {
+    P2P* q = h->p2p;
+    const u32 words = (u32)shard_words2(h->m);
+    u64* y = static_cast<u64*>(h->sh_y.p);
+    u64* yg = static_cast<u64*>(h->sh_yg.p);
+    launch_shard_export_delta(h->plan, b, base, wsp_sel, y, h->stream);
+    const u64 seq = ++q->seq;
+    const u32 slot = (u32)(seq % kP2PSlots);
+    launch_p2p_put(y, words, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq, h->stream);
+    launch_p2p_wait_copy(q->win + q->data_off(slot, 0), q->W, q->R, words, q->win + q->flag_off(slot, 0), seq, q->d_err, yg,
+                         h->stream);
+    launch_shard_import_delta(h->plan, b, yg, h->sh_rank, h->sh_R, h->sh_gprev, h->sh_verdict, verdict_host, h->stream);
+}
+
+int rio_gp_shard_tick_async(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    P2P* q = h->p2p;
+    if (!q || !q->d_peers) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: peer-to-peer windows only (rio_gp_shard_p2p_connect first)");
+    if (h->ring_n || h->tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: other asynchronous solves are in flight");
+    if (h->sh_tick_n == (u32)kRing) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: 64 ticks in flight (call rio_gp_shard_tick_wait)");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t ybytes = shard_words2(h->m) * sizeof(u64);
+    if ((rc = ensure(h, h->sh_y, ybytes)) || (rc = ensure(h, h->sh_yg, ybytes * q->R))) return rc;
+    const u32 k = h->sh_tick_n;
+    // (1) the fast path: k_scan -> k_resolve_xchg, verdict rows into this tick's slot of the tick ring
+    const u64 seq = ++q->seq;
+    const u32 slot = (u32)(seq % kP2PSlots);
+    h->plan = make_plan(h->n, h->m, 0);
+    h->sb.fx = FxRows{};
+    fold_used(h);
+    h->solve_used_D = false;
+    const Table t = real_table(h);
+    const NodeTab nt = real_nodes(h);
+    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream);
+    h->sh_rank = q->rank;
+    h->sh_R = q->R;
+    h->sh_side = nullptr;
+    SolveBufs b = shard_bufs(h);
+    b.H = h->sb.H;
+    b.blkstat = h->sb.blkstat;
+    u64* rows = h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8;
+    u64* rec = h->d_fx + (size_t)(1 + k) * kMaxBlocks * 8;
+    launch_resolve_xchg(h->plan, nt, b, q->d_peers, q->R, q->rank, q->xdata_off(slot, q->rank), q->win + q->xdata_off(slot, 0),
+                        q->Wx, seq, q->d_err, h->sh_gprev, h->sh_gfinal, rows, q->co_resident, h->stream);
+    // (2) exact cut on this rank: k_cutblk + k_cut_find guard themselves on the cut flag, the re-marking pass on the number
+    //     of nodes k_resolve_xchg found to need it here
+    b.run_if = &h->dstats->local_fixup;
+    launch_cut_find(h->plan, t, nt, b, false, h->stream, false);
+    launch_fill(h->plan, t, nt, b, false, true, false, 0, false, h->stream);
+    // (3) what this rank admitted, everyone's, the global `used`, this rank's spill base
+    shard_exchange_y(h, b, h->sb.used_kept, 0, rec + 16);
+    // (4) one water-fill round per spill round (a no-op on the device when nothing is pending anywhere), each with its exchange
+    for (u32 r = 0; r < h->rounds; ++r) {
+        launch_fill(h->plan, t, nt, b, false, false, true, (int)r, r + 1 == h->rounds, h->stream);
+        shard_exchange_y(h, b, h->sh_gprev, (int)((r & 1) ^ 1), rec + 8 * (size_t)(3 + r));
+    }
+    // (5) this rank's counters, (6) publication
+    h->sh_tick_mark[k] = (1ull << 41) | ++h->wait_seq;
+    launch_shard_tick_stats(h->plan, b, rec, h->sh_tick_mark[k], h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->have_solved = true;
+    if ((rc = commit_enqueue(h))) return rc;
+    h->sh_tick_n = k + 1;
+    h->sh_state = 0;
+    return RIO_GP_OK;
+}
+
+int rio_gp_shard_tick_wait(rio_gp_t* h, rio_gp_shard_tick_info* out, uint32_t cap, uint32_t* n_out) {
+    if (!h || !n_out || (cap && !out)) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    *n_out = 0;
+    if (!h->sh_tick_n) return RIO_GP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    const u32 n = h->sh_tick_n;
+    h->sh_tick_n = 0;
+    if (h->p2p && h->p2p->d_peers) { int rc = p2p_check(h); if (rc) return rc; }
+    const u32 nb = resolve_blocks(h->m);
+    const u32 take = n < cap ? n : cap;
+    for (u32 k = n - take; k < n; ++k) {
+        rio_gp_shard_tick_info& o = out[k - (n - take)];
+        const u64* rows = h->h_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8;
+        const u64* rec = h->h_fx + (size_t)(1 + k) * kMaxBlocks * 8;
+        if (rec[15] != h->sh_tick_mark[k]) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_shard_tick_wait: a tick left no record");
+        u64 x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (u32 r = 0; r < nb; ++r)
+            for (int c = 0; c < 8; ++c) x[c] += rows[(size_t)r * 8 + c];
+        DevStats v;
+        memset(&v, 0, sizeof v);
+        v.load_kept = rec[0]; v.load_claim_tot = rec[1];
+        v.kept = rec[3]; v.evicted = rec[4]; v.claimants = rec[5]; v.spillcand = rec[6];
+        const bool slow = x[0] > 0 || x[1] > 0;
+        if (slow) {
+            v.rejected = rec[8]; v.load_rejected = rec[9];
+            v.spilled = rec[10]; v.load_spilled = rec[11];
+            v.unplaced = rec[12]; v.load_unplaced = rec[13];
+        }
+        fill_stats(v, h->n, &o.local);
+        o.cut_nodes = x[0];
+        o.spill_rows = x[1];
+        o.slow_path = slow ? 1u : 0u;
+        o.rounds_run = 0;
+        for (u32 r = 0; slow && r < h->rounds; ++r) o.rounds_run += rec[8 * (size_t)(2 + r)] > 0;  // rows pending BEFORE round r
+    }
+    *n_out = n;
     return RIO_GP_OK;
 }
 

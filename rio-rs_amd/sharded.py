@@ -33,6 +33,11 @@ class ShardInfo(C.Structure):
                                           "claimants", "load_kept", "load_claim")]
 
 
+class ShardTickInfo(C.Structure):
+    _fields_ = [("local", rio_gp.Stats), ("cut_nodes", C.c_uint64), ("spill_rows", C.c_uint64),
+                ("slow_path", C.c_uint32), ("rounds_run", C.c_uint32)]
+
+
 _ready = False
 
 
@@ -61,6 +66,8 @@ def _lib():
         L.rio_gp_shard_p2p_connect.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
         L.rio_gp_shard_p2p_ready.argtypes = [vp]
         L.rio_gp_shard_p2p_close.argtypes = [vp]
+        L.rio_gp_shard_tick_async.argtypes = [vp]
+        L.rio_gp_shard_tick_wait.argtypes = [vp, C.POINTER(ShardTickInfo), C.c_uint32, C.POINTER(C.c_uint32)]
         _ready = True
     return L
 
@@ -118,6 +125,22 @@ class HipShardEngine:
 
     def commit(self):
         self.g.commit()
+
+    def tick_async(self):
+        """One committed tick, nothing waits on the host (peer-to-peer windows only): rio_gp_shard_tick_async."""
+        self.g._chk(_lib().rio_gp_shard_tick_async(self.g.handle))
+
+    def tick_wait(self, cap=64):
+        """Records of the ticks enqueued since the last wait, oldest first: this rank's counters + the global verdict."""
+        buf, n = (ShardTickInfo * cap)(), C.c_uint32(0)
+        self.g._chk(_lib().rio_gp_shard_tick_wait(self.g.handle, buf, cap, C.byref(n)))
+        out = []
+        for k in range(min(cap, int(n.value))):
+            d = buf[k].local.as_dict()
+            d.update(cut_nodes=int(buf[k].cut_nodes), spill_rows=int(buf[k].spill_rows), slow_path=int(buf[k].slow_path),
+                     rounds_run=int(buf[k].rounds_run))
+            out.append(d)
+        return out
 
     def sync(self):
         self.g.sync()
@@ -361,6 +384,34 @@ class ShardedSolver:
         st = self.solve()
         self.commit()
         return st
+
+    # -- committed ticks with nothing waiting on the host (HIP engines over peer-to-peer windows) --
+    def tick_async(self):
+        for e in self.engines:
+            e.tick_async()
+
+    def tick_wait(self):
+        """Global counters of every tick enqueued since the last wait (oldest first): each rank's records, summed over the
+        ranks with ONE all-gather for all the ticks."""
+        local = [e.tick_wait() for e in self.engines]
+        n = len(local[0])
+        if n == 0:
+            return []
+        nk = len(STAT_KEYS)
+        per = max(1, self.engines[0].words1 // nk)      # ticks per exchange: a record fits a window row
+        sg = np.zeros((n, nk), np.uint64)
+        for lo in range(0, n, per):
+            hi = min(n, lo + per)
+            dev = [e.new_buffer((hi - lo) * nk) for e in self.engines]
+            for d, recs in zip(dev, local):
+                self._copy_in(d, torch.tensor([[r[k] for k in STAT_KEYS] for r in recs[lo:hi]], dtype=torch.int64).reshape(-1))
+            sg[lo:hi] = self._gather(dev).cpu().numpy().reshape(self.R, hi - lo, nk).astype(np.uint64).sum(axis=0)
+        out = []
+        for k in range(n):
+            st = {key: int(sg[k][i]) for i, key in enumerate(STAT_KEYS)}
+            st.update(cut_nodes=local[0][k]["cut_nodes"], slow_path=local[0][k]["slow_path"], rounds_run=local[0][k]["rounds_run"])
+            out.append(st)
+        return out
 
 
 def shard_bounds(n, n_ranks):

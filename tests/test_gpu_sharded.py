@@ -208,6 +208,17 @@ def test_hip_shard_p2p_world1(gp, oracle):
         dist.destroy_process_group()
 
 
+ASYNC_TICKS = 9
+
+
+def _async_mask(m, k):
+    """liveness of tick k of the asynchronous stream: every third tick changes nothing, the others flip a few nodes"""
+    alive = np.ones(m, np.uint8)
+    if k % 3 != 2:
+        alive[np.random.default_rng(500 + k - (k % 3 == 1)).choice(m, 5, replace=False)] = 0    # (k, k+1 share a mask twice)
+    return alive
+
+
 def _proc(rank, world, port, out_dir):
     for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), HERE):
         if p not in sys.path:
@@ -233,8 +244,24 @@ def _proc(rank, world, port, out_dir):
         else:
             sol = sharded.ShardedSolver([eng], sharded.DistExchange(stage_through_host=True))
         st = sol.tick()
-        np.savez(os.path.join(out_dir, "g%d.npz" % rank), a=eng.g.get_assign(), used=eng.g.get_nodes()[2],
-                 st=np.array([st[k] for k in sorted(st)], np.uint64))
+        a1, u1 = eng.g.get_assign(), eng.g.get_nodes()[2]
+        extra = {}
+        if os.environ.get("RIO_TEST_EXCHANGE") == "p2p":
+            # asynchronous committed ticks (rio_gp_shard_tick_async): a churn stream with nothing waiting on the host —
+            # liveness flips, ticks that need the whole fix-up chain and ticks that need none of it, back to back
+            m = len(case[3])
+            sts = []
+            for k in range(ASYNC_TICKS):
+                eng.g.set_alive_all(_async_mask(m, k))
+                sol.tick_async()
+                if k == 3:
+                    sts += sol.tick_wait()      # a wait in the middle of the stream
+            sts += sol.tick_wait()
+            keys = sorted(sts[0])
+            extra = dict(a2=eng.g.get_assign(), used2=eng.g.get_nodes()[2],
+                         st2=np.array([[s_[k] for k in keys] for s_ in sts], np.uint64))
+        np.savez(os.path.join(out_dir, "g%d.npz" % rank), a=eng.g.get_assign() if not extra else a1, used=eng.g.get_nodes()[2] if not extra else u1,
+                 st=np.array([st[k] for k in sorted(st)], np.uint64), **extra)
         eng.g.close()
     finally:
         dist.destroy_process_group()
@@ -256,6 +283,17 @@ def test_hip_shards_several_processes_one_gpu(gp, oracle, tmp_path, exchange, wo
     for z in parts:
         assert np.array_equal(z["used"], used)
         assert [int(v) for v in z["st"]] == [ost[k] for k in sorted(ost)]
+    if exchange == "p2p":     # the asynchronous stream that followed, against the oracle chained over the same masks
+        cur, load, aff, cap, alive = case
+        ref, osts = want, []
+        for k in range(ASYNC_TICKS):
+            ref, used, ost = oracle.tick(ref, load, aff, cap, _async_mask(len(cap), k), 2)
+            osts.append([ost[key] for key in sorted(ost)])
+        assert np.array_equal(np.concatenate([z["a2"] for z in parts]), ref)
+        for z in parts:
+            assert np.array_equal(z["used2"], used)
+            assert z["st2"].astype(np.int64).tolist() == osts
+        assert any(o[sorted(ost).index("slow_path")] for o in osts)
 
 
 def test_soak_three_processes_peer_to_peer(gp):

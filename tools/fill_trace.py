@@ -5,7 +5,7 @@ max over the workgroups of every phase's duration (us), measured by the kernels 
           first half searched | both halves | end
   table 1 k_fill round 0, table 2 later rounds: start | prologue + pending | order of the nodes | pass A | pass B set up |
           pass B rows | block sync | end
-Usage: fill_trace.py [ticks]"""
+Usage: fill_trace.py [ticks] [ticks of churn before the traced ones]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -20,11 +20,16 @@ g.set_nodes(cfg["cap"], cfg["alive"])
 g.set_objects(n, cfg["load"], cfg["aff"])
 g.set_assign(synth.warm_assign(n, m))
 g.tick()
+warm_ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 60   # the stream's steady state (the first ticks are ~10 us cheaper)
+for k in range(warm_ticks):
+    g.set_alive_all(synth.churn_mask(m, 2 + k))
+    g.tick_async()
+g.tick_wait()
 g.ktrace(True)
 import ctypes as C
-for k in range(ticks):
+for k in range(warm_ticks, warm_ticks + ticks):
     mask = synth.churn_mask(m, 2 + k)
-    before = g.get_assign() if k == ticks - 1 else None
+    before = g.get_assign() if k == warm_ticks + ticks - 1 else None
     g.set_alive_all(mask)
     st = g.tick()
 # pending rows per wave range of the last tick (the split the kernels use)
