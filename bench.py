@@ -646,6 +646,9 @@ def main():
                                           "library on a second stream -> k_shard_import; verdicts read at the end" % (8 * (2 * m + 8)),
                                 "torch": "row-sharded solve: k_scan + k_resolve + pack -> torch.distributed all_gather (RCCL) of %d "
                                          "B/rank -> k_shard_import; verdicts read at the end" % (8 * (2 * m + 8))}[prim["exchange"]],
+                       "value_is": "back-to-back re-solves of the cold sharded table, NOT committed (rio_gp_shard_solve_async; what "
+                                   "round 2 measured); committed ticks of the same table — churn-free and with config 5's churn, "
+                                   "synchronous and asynchronous — are under committed_ticks",
                        "exchange": prim["exchange"], "exchange_ladder": prim["exchange_ladder"],
                        "peer_access": peer_matrix(torch, world, a.same_device), "slow_path_steps": prim["slow_path_steps"]},
             "gpu_ms_per_step_events": prim["gpu_ms_per_step_events"],
@@ -704,9 +707,10 @@ def main():
     try:
         g.tick()
         g.sync()
+        st_c = rio_gp.Stats()
         t0 = time.perf_counter()
         for _ in range(100):
-            g.tick()
+            g.tick_struct(st_c)   # (the C call alone: the host reads the tick's counters, no Python dictionary is built)
         dep = (time.perf_counter() - t0) / 100 * 1e3
     except Exception:
         dep = None

@@ -326,6 +326,12 @@ class GpuPlacement:
         self._chk(self._L.rio_gp_tick(self._h, C.byref(st)))
         return st.as_dict()
 
+    def tick_struct(self, st):
+        """rio_gp_tick into a caller-held Stats structure: the C call alone (timing loops; no dictionary is built)."""
+        rc = self._L.rio_gp_tick(self._h, C.byref(st))
+        if rc:
+            self._chk(rc)
+
     def tick_async(self):
         self._chk(self._L.rio_gp_tick_async(self._h))
 
