@@ -61,6 +61,19 @@ for k in range(ticks):
     if not (np.array_equal(node, wnode) and np.array_equal(flag, wflag) and np.array_equal(g.get_assign(), ref)):
         print(json.dumps({"tick": k, "place_pending_mismatch": True}))
         sys.exit(4)
+    if k % 5 == 4:
+        # asynchronous ticks with nothing changed in between: the first may need the fix-up (requests above, unplaced rows),
+        # the later ones run without the speculative fix-up launches once a fast tick's verdict has landed
+        wants = []
+        for j in range(4):
+            g.tick_async()
+            ref, used, ost = pyoracle.tick(ref, load, aff, cap, alive)
+            wants.append(ost)
+            if j == 1:
+                time.sleep(0.002)
+        if g.tick_wait() != wants or not np.array_equal(g.get_assign(), ref) or not np.array_equal(g.get_nodes()[2], used):
+            print(json.dumps({"tick": k, "async_ticks_mismatch": True}))
+            sys.exit(6)
     lq = rng.integers(0, n, int(rng.choice([1, 4, 5, 256, 257, 3000, 20000]))).astype(np.uint32)
     if not np.array_equal(g.lookup_batch(lq), ref[lq]):
         print(json.dumps({"tick": k, "lookup_mismatch": True}))

@@ -48,6 +48,25 @@ def proc(rank, world, port, ticks, n, m, seed, out_dir):
                 for _ in range(9):
                     sol.solve_async()
                 sol.solve_wait()
+            if k % 3 == 2:
+                # asynchronous committed ticks (rio_gp_shard_tick_async): three in a row, a liveness flip before each of the
+                # last two, nothing waits on the host until the records are collected
+                wants = []
+                for j in range(3):
+                    if j:
+                        flip = rng.random(m) < 0.05
+                        alive = np.where(flip, 1 - alive, alive).astype(np.uint8)
+                        if alive.sum() < m // 2:
+                            alive[:] = 1
+                        g.set_alive_all(alive)
+                    sol.tick_async()
+                    ref, used, ost = pyoracle.tick(ref, load, aff, cap, alive)
+                    wants.append(ost)
+                sts = sol.tick_wait()
+                if not (sts == wants and np.array_equal(g.get_assign(), ref[lo:hi]) and np.array_equal(g.get_nodes()[2], used)):
+                    raise SystemExit("rank %d: asynchronous ticks at %d differ from the oracle" % (rank, k))
+                slow += sum(x["slow_path"] for x in sts)
+                continue
             st = sol.tick()
             want, used, ost = pyoracle.tick(ref, load, aff, cap, alive)
             if not (np.array_equal(g.get_assign(), want[lo:hi]) and st == ost and np.array_equal(g.get_nodes()[2], used)):
