@@ -62,6 +62,8 @@ struct DevStats {
     u64 evicted_clean;                                  // k_clean
     u64 err;                                            // invalid entries seen by batch kernels
     u64 local_fixup;                                    // row-sharded solve: nodes whose claimants of THIS rank need re-marking (k_resolve_xchg)
+    u64 global_slow;                                    // row-sharded solve: != 0 iff the solve needs the fix-up on ANY rank (the same
+                                                        // value on every rank: it is computed from the all-gathered sums)
 };
 
 // Per-workgroup rows of the fix-up counters (a whole-table solve whose counters the host wants): workgroup b of the
@@ -284,6 +286,13 @@ void launch_p2p_put(const u64* src, u32 words, u64* const* d_peers, u32 R, size_
 void launch_p2p_wait_copy(const u64* win_slot, size_t W, u32 R, u32 words, const u64* flags, u64 seq, u64* err, u64* out,
                           hipStream_t s);
 void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s);
+// asynchronous row-sharded tick: one exchange of the fix-up record in two launches (export + put | wait + import), both
+// no-ops — no store to a peer, no wait for one — when the solve needs no fix-up anywhere (DevStats::global_slow)
+void launch_shard_export_put(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* const* d_peers, u32 R,
+                             size_t data_off, size_t flag_off, u64 seq, hipStream_t s);
+void launch_shard_wait_import(const Plan& p, const SolveBufs& b, const u64* win_slot, size_t W, const u64* flags, u64 seq,
+                              u64* err, u32 rank, u32 R, u64* gprev, const u64* gfinal, u64* verdict_dev, u64* verdict_host,
+                              hipStream_t s);
 void launch_shard_tick_stats(const Plan& p, const SolveBufs& b, u64* out_host, u64 mark, hipStream_t s);
 void launch_shard_import_delta(const Plan& p, const SolveBufs& b, const u64* Yg, u32 rank, u32 R, u64* gprev,
                                u64* verdict_dev, u64* verdict_host, hipStream_t s);

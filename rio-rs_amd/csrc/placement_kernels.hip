@@ -416,6 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         stats->rounds_run = 0;
         stats->n_cut = 0;  // device-side "a node has a cut" flag (k_resolve / k_cutblk)
         stats->local_fixup = 0;
+        stats->global_slow = 0;
     }
     __syncthreads();
 
@@ -3350,6 +3351,7 @@ __global__ __launch_bounds__(256) void k_resolve_xchg(const u64* __restrict__ H,
         }
         if (tid < 8) host_partial[(size_t)b * 8 + tid] = outc[tid];
         if (tid == 0 && outc[2]) atomicAdd(&stats->local_fixup, outc[2]);  // (zeroed by k_scan) the guard of the asynchronous tick's re-marking pass
+        if (tid == 0 && (outc[0] | outc[1])) atomicAdd(&stats->global_slow, 1ull);  // cut nodes or spill rows anywhere: the same on every rank
         __syncthreads();  // got / outc / nib go round again
     }
 }
@@ -3471,6 +3473,76 @@ __global__ __launch_bounds__(kBlock) void k_shard_import_delta(const u64* __rest
             if (r < rank) base += l;
             load += l;
             rows += Yg[r * W + m + 1];
+        }
+        *rank_base = base;
+        verdict_dev[0] = rows; verdict_dev[1] = load;
+        if (verdict_host) { verdict_host[0] = rows; verdict_host[1] = load; }
+    }
+}
+
+// Asynchronous row-sharded tick, one exchange of the fix-up record in two launches.  k_shard_export_put = k_shard_export_delta
+// + k_p2p_put: Y = [used_cur - base | spill load still pending here | its rows] straight into this rank's row of every
+// window, then the flag.  k_shard_wait_import = k_p2p_wait_copy + k_shard_import_delta: everyone's record out of the own
+// window -> global `used`, this rank's spill base, rows pending anywhere.  When the solve needs no fix-up on ANY rank
+// (DevStats::global_slow == 0, the same on every rank) neither stores to a peer nor waits for one: `used` = the fast path's
+// global vector, nothing pending.
+__global__ __launch_bounds__(kBlock) void k_shard_export_put(const u64* __restrict__ used_cur, const u64* __restrict__ base,
+                                                             const u64* __restrict__ wsp_sum, const u32* __restrict__ wsp_cnt,
+                                                             u32 nw, u32 m, u64* const* __restrict__ peers, u32 R, size_t data_off,
+                                                             size_t flag_off, u64 seq, const DevStats* __restrict__ st) {
+    __shared__ u64 red[2];
+    if (st->global_slow == 0) return;
+    const int tid = threadIdx.x;
+    if (tid < 2) red[tid] = 0;
+    __syncthreads();
+    for (u32 j = tid; j < m; j += kBlock) {
+        const u64 y = used_cur[j] - base[j];
+        for (u32 r = 0; r < R; ++r) RIOGP_SYS_STORE(peers[r] + data_off + j, y);
+    }
+    u64 s = 0, c = 0;
+    for (u32 w = tid; w < nw; w += kBlock) { s += wsp_sum[w]; c += wsp_cnt[w]; }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((tid & 63) == 0) { atomicAdd(&red[0], s); atomicAdd(&red[1], c); }
+    __syncthreads();
+    if (tid < 2)
+        for (u32 r = 0; r < R; ++r) RIOGP_SYS_STORE(peers[r] + data_off + m + tid, red[tid]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((u32)tid < R) RIOGP_SYS_STORE(peers[tid] + flag_off, seq);
+}
+
+__global__ __launch_bounds__(kBlock) void k_shard_wait_import(const u64* __restrict__ win_slot, size_t W,
+                                                              const u64* __restrict__ flags, u64 seq, u64* __restrict__ err,
+                                                              u32 rank, u32 R, u32 m, u64* __restrict__ gprev,
+                                                              const u64* __restrict__ gfinal, u64* __restrict__ used_cur,
+                                                              u64* __restrict__ rank_base, u64* __restrict__ verdict_dev,
+                                                              u64* __restrict__ verdict_host, const DevStats* __restrict__ st) {
+    const int tid = threadIdx.x;
+    if (st->global_slow == 0) {  // fast path everywhere: nothing was sent, nothing is pending
+        for (u32 j = tid; j < m; j += kBlock) used_cur[j] = gfinal[j];
+        if (tid == 0) {
+            *rank_base = 0;
+            verdict_dev[0] = 0; verdict_dev[1] = 0;
+            if (verdict_host) { verdict_host[0] = 0; verdict_host[1] = 0; }
+        }
+        return;
+    }
+    p2p_wait(flags, R, seq, err);
+    for (u32 j = tid; j < m; j += kBlock) {
+        u64 g = gprev[j];
+        for (u32 r = 0; r < R; ++r) g += RIOGP_SYS_LOAD(win_slot + (size_t)r * W + j);
+        gprev[j] = g;
+        used_cur[j] = g;
+    }
+    if (tid == 0) {
+        u64 base = 0, load = 0, rows = 0;
+        for (u32 r = 0; r < R; ++r) {
+            const u64 l = RIOGP_SYS_LOAD(win_slot + (size_t)r * W + m);
+            if (r < rank) base += l;
+            load += l;
+            rows += RIOGP_SYS_LOAD(win_slot + (size_t)r * W + m + 1);
         }
         *rank_base = base;
         verdict_dev[0] = rows; verdict_dev[1] = load;
@@ -3912,6 +3984,17 @@ void launch_p2p_wait_copy(const u64* win_slot, size_t W, u32 R, u32 words, const
 void launch_shard_export_delta(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* Y, hipStream_t s) {
     hipLaunchKernelGGL(k_shard_export_delta, dim3(1), dim3(kBlock), 0, s, b.used_cur, base, b.wsp_sum[wsp_sel],
                        b.wsp_cnt[wsp_sel], p.nw, p.m, Y);
+}
+void launch_shard_export_put(const Plan& p, const SolveBufs& b, const u64* base, int wsp_sel, u64* const* d_peers, u32 R,
+                             size_t data_off, size_t flag_off, u64 seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_shard_export_put, dim3(1), dim3(kBlock), 0, s, b.used_cur, base, b.wsp_sum[wsp_sel], b.wsp_cnt[wsp_sel],
+                       p.nw, p.m, d_peers, R, data_off, flag_off, seq, b.stats);
+}
+void launch_shard_wait_import(const Plan& p, const SolveBufs& b, const u64* win_slot, size_t W, const u64* flags, u64 seq,
+                              u64* err, u32 rank, u32 R, u64* gprev, const u64* gfinal, u64* verdict_dev, u64* verdict_host,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(k_shard_wait_import, dim3(1), dim3(kBlock), 0, s, win_slot, W, flags, seq, err, rank, R, p.m, gprev, gfinal,
+                       b.used_cur, b.rank_base, verdict_dev, verdict_host, b.stats);
 }
 void launch_shard_tick_stats(const Plan& p, const SolveBufs& b, u64* out_host, u64 mark, hipStream_t s) {
     hipLaunchKernelGGL(k_shard_tick_stats, dim3(1), dim3(64), 0, s, b.partial, resolve_blocks(p.m), b.stats, out_host, mark);

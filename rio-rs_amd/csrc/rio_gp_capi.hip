@@ -197,7 +197,6 @@ struct rio_gp {
     DevBuf vt[4], stage[4];
     DevBuf vrec;  // big place_pending batches: virtual-table records {cur | load}, 8 bytes per request
     DevBuf part;  // scratch of the partitioned update / remove batches (records + fragment tables)
-    DevBuf sh_y, sh_yg;   // asynchronous row-sharded tick: this rank's Y record, everyone's
     u32 sh_tick_n = 0;    // asynchronous row-sharded ticks in flight (their records: verdict slots of the tick ring, h_fx slots)
     u64 sh_tick_mark[kRing] = {};
     std::vector<void*> allocs;
@@ -2059,16 +2058,12 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
 // (k_shard_tick_stats, 16 words), row 2 + e = {rows, load} pending on all ranks after exchange e (k_shard_import_delta).
 static void shard_exchange_y(rio_gp* h, const SolveBufs& b, const u64* base, int wsp_sel, u64* verdict_host) {
     P2P* q = h->p2p;
-    const u32 words = (u32)shard_words2(h->m);
-    u64* y = static_cast<u64*>(h->sh_y.p);
-    u64* yg = static_cast<u64*>(h->sh_yg.p);
-    launch_shard_export_delta(h->plan, b, base, wsp_sel, y, h->stream);
     const u64 seq = ++q->seq;
     const u32 slot = (u32)(seq % kP2PSlots);
-    launch_p2p_put(y, words, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq, h->stream);
-    launch_p2p_wait_copy(q->win + q->data_off(slot, 0), q->W, q->R, words, q->win + q->flag_off(slot, 0), seq, q->d_err, yg,
-                         h->stream);
-    launch_shard_import_delta(h->plan, b, yg, h->sh_rank, h->sh_R, h->sh_gprev, h->sh_verdict, verdict_host, h->stream);
+    launch_shard_export_put(h->plan, b, base, wsp_sel, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq,
+                            h->stream);
+    launch_shard_wait_import(h->plan, b, q->win + q->data_off(slot, 0), q->W, q->win + q->flag_off(slot, 0), seq, q->d_err,
+                             h->sh_rank, h->sh_R, h->sh_gprev, h->sh_gfinal, h->sh_verdict, verdict_host, h->stream);
 }
 
 int rio_gp_shard_tick_async(rio_gp_t* h) {
@@ -2080,8 +2075,6 @@ int rio_gp_shard_tick_async(rio_gp_t* h) {
     if (h->sh_tick_n == (u32)kRing) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: 64 ticks in flight (call rio_gp_shard_tick_wait)");
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
-    const size_t ybytes = shard_words2(h->m) * sizeof(u64);
-    if ((rc = ensure(h, h->sh_y, ybytes)) || (rc = ensure(h, h->sh_yg, ybytes * q->R))) return rc;
     const u32 k = h->sh_tick_n;
     // (1) the fast path: k_scan -> k_resolve_xchg, verdict rows into this tick's slot of the tick ring
     const u64 seq = ++q->seq;
