@@ -184,7 +184,7 @@ def parity_sharded(dist, backend, g, sol, workload, n_total, m, bounds, rank, wo
     return rec
 
 
-def sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, rank, world, cap, ticks=10):
+def sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, rank, world, cap, ticks=10, phase=None):
     """Committed ticks of the row-sharded table, after the parity step left it committed (warm): (i) churn-free ticks
     (every row kept: scan + exchange + verdict + commit), (ii) BASELINE config 5 on the sharded table: per tick a liveness
     push (10 % of the nodes down, a different 10 % each tick) and one committed tick with its fix-up exchanges —
@@ -197,18 +197,35 @@ def sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, ra
     schedule = []                       # the liveness mask every executed tick ran under (None: unchanged)
     masks = [synth.churn_mask(m, k + 1) for k in range(2 * ticks + 4)]
 
-    def timed(step, k):
-        dist.barrier(); g.sync()
-        t0 = time.perf_counter()
-        out = [step(i) for i in range(k)]
-        out = [x for x in out if x is not None]
-        fin = getattr(step, "finish", None)
-        if fin is not None:
-            out = fin()
-        g.sync()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    class PhaseFailed(Exception):
+        pass
+
+    def timed(step, k, warm=0):
+        """`warm` untimed calls, then k timed ones.  Every rank ends the phase with exactly ONE collective that carries its time
+        and whether it failed, so a rank whose exchange timed out cannot leave the others waiting in a collective of their own:
+        all ranks give the phase up together."""
+        dt, fail, why, out = 0.0, 0.0, "", None
+        try:
+            fin = getattr(step, "finish", None)
+            for i in range(warm):
+                step(i)
+            if warm and fin is not None:
+                fin()
+            g.sync()
+            t0 = time.perf_counter()
+            out = [step(warm + i) for i in range(k)]
+            out = [x for x in out if x is not None]
+            if fin is not None:
+                out = fin()
+            g.sync()
+            dt = time.perf_counter() - t0
+        except Exception as e:
+            fail, why = 1.0, repr(e)[:200]
+        t = torch.tensor([dt, fail], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), out
+        if float(t[1].item()):
+            raise PhaseFailed(why or "failed on another rank")
+        return float(t[0].item()), out
 
     def keep_sync(i):
         schedule.append(None)
@@ -223,12 +240,13 @@ def sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, ra
                 "objects_moved_per_s": sum(x["claimed"] + x["spilled"] for x in sts) / dt,
                 "slow_path_ticks": int(sum(x["slow_path"] for x in sts)), "stats_last_tick": sts[-1], "step": step}
 
-    keep_sync(0)                                                 # (a warm-up of the committed path itself)
-    dt, sts = timed(keep_sync, ticks)
+    phase = phase if phase is not None else []
+    phase.append("committed ticks, synchronous")
+    dt, sts = timed(keep_sync, ticks, warm=1)
     rec = {"ticks": ticks, "committed_tick_no_churn": rec_of(dt, sts, ticks,
            "ShardedSolver.tick: solve_async + solve_wait (verdict, global counters) + commit, the host in the loop")}
-    churn_sync(0); churn_sync(1)
-    dt, sts = timed(lambda i: churn_sync(i + 2), ticks)
+    phase.append("churn ticks, synchronous")
+    dt, sts = timed(churn_sync, ticks, warm=2)
     rec["churn"] = rec_of(dt, sts, ticks,
                           "rio_gp_set_alive_all + ShardedSolver.tick: scan, exchange, verdict, cut + export, exchange, merge, then per "
                           "water-fill round spill + export, exchange, merge; counters; commit — synchronous, every phase returns to the host")
@@ -242,20 +260,22 @@ def sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, ra
 
         class ChurnAsync:
             def __call__(self, i):
-                mk = masks[ticks + 2 + i]
+                mk = masks[ticks + 2 + i]   # (continues the synchronous stream's masks)
                 g.set_alive_all(mk); schedule.append(mk); sol.tick_async()
             def finish(self):
                 return sol.tick_wait()
-        KeepAsync()(0); sol.tick_wait()
-        dt, sts = timed(KeepAsync(), ticks)
+        phase.append("committed ticks, asynchronous")
+        dt, sts = timed(KeepAsync(), ticks, warm=1)
         rec["committed_tick_no_churn_async"] = rec_of(dt, sts, ticks,
             "rio_gp_shard_tick_async: scan, one-launch exchange, the guarded fix-up chain (nothing to do), commit; nothing waits "
             "on the host, counters read at the end")
+        phase.append("churn ticks, asynchronous")
         dt, sts = timed(ChurnAsync(), ticks)
         rec["churn_async"] = rec_of(dt, sts, ticks,
             "rio_gp_set_alive_all + rio_gp_shard_tick_async: the same chain with its cut pass, water-fill rounds and three "
             "peer-to-peer exchanges per tick, enqueued back to back")
         last = sts[-1]
+    phase.append("parity of the tick streams")
     if a.no_parity or n_total * (len(schedule) + 2) > 600_000_000:
         rec["parity"] = None
         return rec
@@ -551,14 +571,19 @@ def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank
     if not a.no_parity:
         parity = parity_sharded(dist, a.backend, g, sol, workload, n_total, m, bounds, rank, world, cfg["cap"])
     ticks = None
-    if not a.no_sharded_churn:
+    if a.same_device and world > 4 and not a.no_sharded_churn:
+        ticks = {"skipped": "%d processes time-share ONE GPU in this flow test: the tick streams' in-kernel waits run into the "
+                            "scheduler's time slices (seconds per exchange); they are exercised with 2 ranks here and with up to "
+                            "8 processes on small tables in tests/test_gpu_sharded.py" % world}
+    elif not a.no_sharded_churn:
         if a.no_parity:
             sol.tick()   # the committed (warm) table the tick streams start from
+        phase = []
         try:
             ticks = sharded_ticks(a, dist, torch, g, sol, kind, workload, n_total, m, bounds, rank, world, cfg["cap"],
-                                  ticks=max(2, min(a.steps, 10)))
+                                  ticks=max(2, min(a.steps, 10)), phase=phase)
         except Exception as e:  # a second measurement: it must not take the line down with it
-            ticks = {"error": repr(e)[:300]}
+            ticks = {"error": repr(e)[:300], "during": phase[-1] if phase else None}
     rec = {"value": n_total * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "gpu_ms_per_step_events": gpu_ms / a.steps,
            "rows_total": n_total, "rows_this_rank": n, "nodes": m, "exchange": kind, "exchange_ladder": tried,
            "slow_path_steps": n_slow, "stats_last_step": st, "parity": parity, "committed_ticks": ticks,

@@ -267,7 +267,7 @@ def _proc(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,world", [("gloo", 2), ("p2p", 2), ("p2p", 3), ("p2p", 5)])
+@pytest.mark.parametrize("exchange,world", [("gloo", 2), ("p2p", 2), ("p2p", 3), ("p2p", 5), ("p2p", 8)])
 def test_hip_shards_several_processes_one_gpu(gp, oracle, tmp_path, exchange, world, monkeypatch):
     """One process per rank, all on the one GPU of the box: real cross-process windows, every rank's claim prefix over
     the lower ranks, forced nodes, back-to-back steps (slot reuse), then a committed tick with the fix-up exchanges."""
