@@ -571,11 +571,7 @@ def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank
     if not a.no_parity:
         parity = parity_sharded(dist, a.backend, g, sol, workload, n_total, m, bounds, rank, world, cfg["cap"])
     ticks = None
-    if a.same_device and world > 4 and not a.no_sharded_churn:
-        ticks = {"skipped": "%d processes time-share ONE GPU in this flow test: the tick streams' in-kernel waits run into the "
-                            "scheduler's time slices (seconds per exchange); they are exercised with 2 ranks here and with up to "
-                            "8 processes on small tables in tests/test_gpu_sharded.py" % world}
-    elif not a.no_sharded_churn:
+    if not a.no_sharded_churn:
         if a.no_parity:
             sol.tick()   # the committed (warm) table the tick streams start from
         phase = []

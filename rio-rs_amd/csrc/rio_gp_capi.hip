@@ -81,6 +81,12 @@ struct P2P {
     u64* d_err = nullptr;         // set by a waiting kernel that timed out
     u64* scratch = nullptr;       // [W] staging of the local record
     u64 seq = 0;
+    // Window slots rotate per KIND of exchange (tagged one-launch exchange | raw fix-up records), not with the sequence number:
+    // a tick takes 1 + (1 + rounds) sequence numbers, and when that is a multiple of kP2PSlots every tick's tagged exchange
+    // would land in the same slot — a rank that is through a churn-free tick (no further wait on its peers) would overwrite
+    // the words a slower rank has not read yet, which then waits for a tag that is gone.  With slots of their own two
+    // consecutive exchanges of a kind never share one, and no rank is ever more than one exchange ahead of another.
+    u64 xslot_n = 0, yslot_n = 0;
     u32 co_resident = 1;          // ranks whose kernels run on THIS device, ours included (learnt at the handshake)
     size_t xdata_off(u32 slot, u32 r) const { return ((size_t)slot * R + r) * Wx; }
     size_t xwords() const { return (size_t)kP2PSlots * R * Wx; }
@@ -1988,12 +1994,12 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (h->p2p && h->p2p->d_peers) {
         // peer-to-peer, ONE stream, two launches, no collective call and no host wait: k_scan -> k_resolve_xchg.
         // Stream order is the flow control: a rank's record j+1 leaves only after it consumed everyone's record j,
-        // so none of the 4 window slots is overwritten while its owner still reads it.  (Running the exchange on a
+        // so none of the 4 window slots (P2P::xslot_n) is overwritten while its owner still reads it.  (Running the exchange on a
         // second stream under the next scan was measured SLOWER on gfx950: two event records + two stream waits per
         // solve cost more than the 5 us they hide.)
         P2P* q = h->p2p;
         const u64 seq = ++q->seq;
-        const u32 slot = (u32)(seq % kP2PSlots);
+        const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
         h->plan = make_plan(h->n, h->m, 0);
         h->sb.fx = FxRows{};
         fold_used(h);
@@ -2059,7 +2065,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
 static void shard_exchange_y(rio_gp* h, const SolveBufs& b, const u64* base, int wsp_sel, u64* verdict_host) {
     P2P* q = h->p2p;
     const u64 seq = ++q->seq;
-    const u32 slot = (u32)(seq % kP2PSlots);
+    const u32 slot = (u32)(q->yslot_n++ % kP2PSlots);
     launch_shard_export_put(h->plan, b, base, wsp_sel, q->d_peers, q->R, q->data_off(slot, q->rank), q->flag_off(slot, q->rank), seq,
                             h->stream);
     launch_shard_wait_import(h->plan, b, q->win + q->data_off(slot, 0), q->W, q->win + q->flag_off(slot, 0), seq, q->d_err,
@@ -2078,7 +2084,7 @@ int rio_gp_shard_tick_async(rio_gp_t* h) {
     const u32 k = h->sh_tick_n;
     // (1) the fast path: k_scan -> k_resolve_xchg, verdict rows into this tick's slot of the tick ring
     const u64 seq = ++q->seq;
-    const u32 slot = (u32)(seq % kP2PSlots);
+    const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
     h->plan = make_plan(h->n, h->m, 0);
     h->sb.fx = FxRows{};
     fold_used(h);
@@ -2169,7 +2175,7 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
         P2P* q = h->p2p;
         if (words > q->W) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_exchange: record larger than the window row");
         const u64 seq = ++q->seq;
-        const u32 slot = (u32)(seq % kP2PSlots);
+        const u32 slot = (u32)(q->yslot_n++ % kP2PSlots);
         launch_p2p_put(reinterpret_cast<const u64*>(d_in), (u32)words, q->d_peers, q->R, q->data_off(slot, q->rank),
                        q->flag_off(slot, q->rank), seq, h->stream);
         launch_p2p_wait_copy(q->win + q->data_off(slot, 0), q->W, q->R, (u32)words, q->win + q->flag_off(slot, 0), seq,

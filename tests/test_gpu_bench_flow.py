@@ -135,6 +135,12 @@ def test_bench_config4_eight_ranks_p2p_on_one_gpu():
     assert d["config"]["exchange"] == "p2p" and d["config"]["exchange_ladder"][0]["ok"] is True, d["config"]
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 4_000_000
     assert d["weak_config3"]["parity"]["equal"] is True
+    # the committed / churn tick streams, synchronous and asynchronous, between eight processes: every tick of a quiet
+    # asynchronous stream lands in the next window slot (a rank that is through a tick must not overwrite what a slower one
+    # has not read — found exactly here, with a tick that took four sequence numbers and four slots)
+    for rec in (d["committed_ticks"], d["weak_config3"]["committed_ticks"]):
+        assert "error" not in rec, rec
+        assert rec["parity"]["equal"] is True and rec["churn_async"]["slow_path_ticks"] == rec["ticks"]
 
 
 def test_bench_eight_ranks_on_one_gpu():
