@@ -176,6 +176,7 @@ struct rio_gp {
     // fix-up behind it: two launches a tick instead of five.  quiet_epoch = the mut_epoch such a tick was enqueued under.
     u64 mut_epoch = 0, quiet_epoch = ~0ull;
     u64 tick_mark[kRing] = {}, tick_epoch[kRing] = {};
+    bool tick_quiet[kRing] = {};       // the tick was enqueued without its fix-up (checked against its verdict when harvested)
     u32 tick_peeked = 0;               // ticks [0, tick_peeked) of the ring have had their verdicts looked at
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
@@ -540,6 +541,10 @@ int harvest_ticks(rio_gp* h) {
     for (u32 k = 0; k < h->tick_n; ++k) {
         DevStats v = reduce_tick_slot(h, k, h->m);
         const bool slow = v.n_cut > 0 || v.spillcand > 0;
+        if (slow && h->tick_quiet[k]) {  // cannot happen (see mut_epoch); if it ever does it must not pass silently
+            h->tick_n = 0;
+            return fail(h, RIO_GP_EUPSTREAM, "rio_gp_tick_wait: a tick that was enqueued without its fix-up needed one (tables are stale: reload them)");
+        }
         if (!slow && h->tick_epoch[k] == h->mut_epoch) h->quiet_epoch = h->mut_epoch;
         if (slow) fold_fx(h, 1 + k, h->tick_G[k], &v);
         rio_gp_stats st;
@@ -573,6 +578,7 @@ int tick_async_locked(rio_gp* h) {
     use_fx_slot(h, 1 + k);
     h->tick_G[k] = h->plan.G;
     h->tick_epoch[k] = h->mut_epoch;
+    h->tick_quiet[k] = quiet;
     h->tick_mark[k] = h->plan.mark = (1ull << 40) | ++h->wait_seq;  // column 7 of the verdict rows: peek_ticks knows them by it
     enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8);
     if (quiet) {
