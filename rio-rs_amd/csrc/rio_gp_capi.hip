@@ -171,6 +171,7 @@ struct rio_gp {
     // packed fix-up (PackOut, placement_kernels.h): scratch columns + per-wave counts; chosen adaptively per tick
     PackOut pk{};
     bool last_pending_valid = false;
+    bool searched = false;             // the last enqueue_scan_resolve had k_resolve search the cuts itself
     // A tick that took the fast path leaves every object placed; until the next call that changes an input of the solve
     // (mut_epoch counts those) every further tick keeps every row where it is, and rio_gp_tick_async enqueues no speculative
     // fix-up behind it: two launches a tick instead of five.  quiet_epoch = the mut_epoch such a tick was enqueued under.
@@ -303,6 +304,7 @@ void fill_stats(const DevStats& d, u64 n, rio_gp_stats* s) {
 
 u32* aff_life(rio_gp* h) { return h->lifecycle ? h->aff : nullptr; }
 Table real_table(rio_gp* h) { return Table{h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1]}; }
+constexpr u64 kSearchMaxBlockRows = 1u << 17;  // rows per block up to which k_resolve searches the cuts itself
 constexpr u32 kAliveSlots = 2 * kRing + 4;  // every slot handed to a scan belongs to a solve or tick of a ring of kRing
 void launch_alive_words(rio_gp* h) {
     WordPack pk;
@@ -362,9 +364,14 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     h->sb.D = h->D;
     h->solve_used_D = h->sb.D != nullptr;
     launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
+    // The exact cut search rides in k_resolve when a block's packed rows are few enough for a wave pair per node to stream
+    // (config 3: 39 K rows a block, 18 us against 6 + 14 for a resolve and a search launch of their own); on big blocks
+    // (config 4 on one GPU: 390 K rows, ~39 K packed) a wave pair per node takes 91 us where k_cut_find's (block, node slice)
+    // work items spread over the chip take 36: there the search stays a launch of its own.
+    h->searched = compact && h->plan.G && h->n / h->plan.G <= kSearchMaxBlockRows;
     Plan rp = h->plan;
-    if (compact) rp.wcnt = h->pk.wcnt;
-    launch_resolve(rp, nt, h->sb, host_rows, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr,
+    if (h->searched) rp.wcnt = h->pk.wcnt;
+    launch_resolve(rp, nt, h->sb, host_rows, h->stream, nullptr, nullptr, h->searched ? &h->pk : nullptr,
                    h->used_parts ? h->used : nullptr, h->parts_rounds);
     h->used_parts = false;
 }
@@ -486,7 +493,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
             Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
             vt.pk_idx = h->pk.idx;  // the water-fill writes every decision through pk.idx into the real column itself
             vt.real_next = t.next;
-            enqueue_slow(h, pp, vt, nt, true, true);
+            enqueue_slow(h, pp, vt, nt, true, h->searched);
         } else {
             enqueue_slow(h, h->plan, t, nt, false, false, cutpack);
         }
@@ -589,7 +596,7 @@ int tick_async_locked(rio_gp* h) {
         Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
         vt.pk_idx = h->pk.idx;
         vt.real_next = t.next;
-        enqueue_slow(h, pp, vt, nt, true, true);
+        enqueue_slow(h, pp, vt, nt, true, h->searched);
     } else {
         enqueue_slow(h, h->plan, t, nt, false, false);
     }
