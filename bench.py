@@ -447,7 +447,7 @@ def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
                         "step": "rio_gp_set_alive_all + rio_gp_tick (the host reads every tick's counters)"},
         "pipelined": piped, "objects_moved_per_s": moved / dt, "stats_last_tick": st, "parity": parity,
         "kernel_spans_on_device_us": spans,
-        "launches_per_tick": "k_store_words (liveness) + k_scan<COMPACT> + k_resolve<SEARCH> + k_fill (round 0) + k_fill (round 1)",
+        "launches_per_tick": "k_scan<COMPACT> (reads the pushed liveness bitmap from mapped pinned memory) + k_resolve<SEARCH> + k_fill (round 0) + k_fill (round 1)",
     }
 
 

@@ -137,7 +137,9 @@ int rio_gp_sync(rio_gp_t* h);
  * cluster/storage/mod.rs:20-58).  cap == NULL -> all RIO_GP_CAP_INF; alive == NULL -> all 1. */
 int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t* alive);
 /* MembershipStorage::set_is_active (cluster/storage/mod.rs:80) pushed instead of polled
- * (is_active, mod.rs:102-110). */
+ * (is_active, mod.rs:102-110).  A push costs no device work of its own: the bitmap waits in mapped pinned memory and
+ * reaches the device with the next whole-table solve or tick (whose scan reads it from there), or with one tiny kernel
+ * when a request batch needs it first.  Every later call sees the new liveness. */
 int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive);
 int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive);
 int rio_gp_get_nodes(rio_gp_t* h, uint32_t m, uint64_t* cap, uint8_t* alive, uint64_t* used);
