@@ -163,9 +163,21 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
 // search (with p.wcnt set): the packed pending rows — k_resolve also finds the exact cut rows (no k_cut_find launch).
 // fold_into: the committed `used` vector still waiting for the D rows of the previous committed solve (folded in before
 // b.D is zeroed), fold_rounds = that solve's rounds.
+// kept_from: the scan built no kept histogram (launch_inc_scan) — the kept load of a node is the committed vector's entry
+// where the node is alive (read after the fold when it is fold_into itself).
 void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const PackOut* search = nullptr,
-                    u64* fold_into = nullptr, u32 fold_rounds = 0);
+                    u64* fold_into = nullptr, u32 fold_rounds = 0, const u64* kept_from = nullptr);
+// The scan of a COMMITTED tick over a mostly-placed table: only the assignment column is streamed, and updated in place;
+// pending rows -> pack (per wave range of p).  hist: per-block histograms / spill totals built here (fix-up over the row
+// ranges); else launch_rebal deals the rows out evenly over rebal_plan(p) into `dst` and builds them there.
+bool inc_scan_fits(u32 m);
+void launch_inc_scan(const Plan& p, u32* assign, const u32* load, const u32* aff, const NodeTab& nt, const SolveBufs& b,
+                     const PackOut& pack, bool hist, hipStream_t s);
+Plan rebal_plan(const Plan& p);
+u64 rebal_rows(u64 n);  // rows of the balanced columns for a table of n rows (+ the usual padding)
+void launch_rebal(const Plan& p, const Plan& pv, const PackOut& src, const NodeTab& nt, const PackOut& dst, const SolveBufs& b,
+                  hipStream_t s);
 unsigned resolve_blocks(u32 m);
 void set_scan_nt(int mode);  // 0 by table size | 1 always | 2 never: non-temporal column streams in k_scan
 // The exact cut search as a launch of its own (k_cut_find; guards itself on the device).  have_cutblk: launch_resolve of

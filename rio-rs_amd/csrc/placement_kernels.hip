@@ -503,6 +503,368 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1i k_inc_scan — the scan of a COMMITTED tick over a table that is mostly placed (the clean_server rebalance stream,
+//     BASELINE config 5; local.rs:51-58 + service.rs:227-252 batched): only the assignment column is streamed (4 B/row
+//     instead of 12 B read + 4 B written), and it is updated IN PLACE.
+//       * a row on a live node is kept: nothing else of it is read, nothing is written;
+//       * the kept load of node j needs no histogram: it is the committed used[j] where j is alive and 0 where it is not
+//         (k_resolve takes it from there: ResolveArgs::kept_from) — valid whenever the library's `used` vector is;
+//       * only the PENDING rows (unplaced, or on a node that is not alive: clean_server folded in) have their load and affinity
+//         gathered — lanes without one issue no request —, get their optimistic value written back (claimant -> affinity,
+//         not an object -> NONE, the rest -> spill mark; one 16-byte store per lane that holds one) and are packed, in index
+//         order, to the front of the wave's range of the pack columns, exactly like k_scan<COMPACT>: the fix-up kernels run
+//         over them unchanged and write their decisions through pk_idx into the same column.
+//     HIST: the per-block claim histograms, spill totals and optimistic `next` of the packed rows are built here (the
+//     fix-up follows the row ranges).  !HIST: the rows are only extracted; k_rebal deals them out evenly and builds those.
+//     A wave works in batches of kIncB tiles: the next batch's assignment vectors are in flight while this batch's pending
+//     lanes fetch their load / affinity vectors.
+// ------------------------------------------------------------------------------------------------
+constexpr int kIncB = 4;
+
+template <bool HIST>
+__global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, const u32* __restrict__ load,
+                                                     const u32* __restrict__ aff, const u32* __restrict__ alive_bits, Plan p,
+                                                     u64* __restrict__ H, u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
+                                                     u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko,
+                                                     FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt,
+                                                     u64* __restrict__ R, u64* __restrict__ RP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m;
+    u32* bst = reinterpret_cast<u32*>(smem);                 // [4]
+    u64* hist = reinterpret_cast<u64*>(smem + kSmall);       // [2m + 2] (kept half unused: k_scan's layout, H lines alike)
+    u32* alv = reinterpret_cast<u32*>(hist + 2 * m + 2);     // [mwords]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RIOGP_KT(p, 3, 0);
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+    // tile t of the wave's range, or — past its end — a tile that is certainly readable (its rows are judged by nobody)
+    const u64 safe = wstart < wend ? wstart : 0ull;
+    u64 it = wstart;
+    uint4 cv[kIncB];
+#pragma unroll
+    for (int q = 0; q < kIncB; ++q) {
+        const u64 t = it + (u64)q * kTile;
+        cv[q] = *reinterpret_cast<const uint4*>(assign + (t < wend ? t : safe) + (u64)lane * 4);
+    }
+
+    if (HIST)
+        for (u32 k = tid; k < 2 * m + 2; k += kBlock) hist[k] = 0;
+    for (u32 k = tid; k < p.mwords; k += kBlock) {
+        const u32 w = alive_bits[k];
+        alv[k] = w;
+        if (p.alive_dst && blockIdx.x == 0) p.alive_dst[k] = w;  // a fresh bitmap (mapped host memory) -> the device array
+    }
+    if (tid < 4) bst[tid] = 0;
+    u64& bsum = *reinterpret_cast<u64*>(smem + 32);
+    if (tid == 0) bsum = 0;
+    if (fx.dev && tid < 8) fx.dev[(size_t)blockIdx.x * 8 + tid] = 0;
+    if (R && tid == 0) R[blockIdx.x] = 0;
+    if (RP) {
+        const u32 ngr = (m + 7) >> 3;
+        for (u32 k = tid; k < ngr; k += kBlock) RP[(size_t)blockIdx.x * ngr + k] = 0;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        stats->rejected = 0; stats->load_rejected = 0;
+        stats->spilled = 0; stats->load_spilled = 0; stats->unplaced = 0; stats->load_unplaced = 0;
+        stats->rounds_run = 0;
+        stats->n_cut = 0;
+        stats->local_fixup = 0;
+        stats->global_slow = 0;
+    }
+    __syncthreads();
+
+    u64 sp_sum = 0;
+    u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;  // per LANE here (summed over the wave at the end)
+    u64 pk_pos = wstart;  // this wave's packed write cursor (wave-uniform)
+    u32* stage = reinterpret_cast<u32*>(smem + scan_lds_bytes_dev(p.m)) + (size_t)wave * 4 * kStageCap;
+    u32 st_head = 0, st_fill = 0;
+
+    while (it < wend) {
+        const u64 nit = it + (u64)kIncB * kTile;
+        uint4 cn[kIncB];
+#pragma unroll
+        for (int q = 0; q < kIncB; ++q) {
+            const u64 t = nit + (u64)q * kTile;
+            cn[q] = *reinterpret_cast<const uint4*>(assign + (t < wend ? t : safe) + (u64)lane * 4);
+        }
+        u32 pm[kIncB];  // which of the lane's four rows of tile q are pending
+        u32 anyp = 0;
+#pragma unroll
+        for (int q = 0; q < kIncB; ++q) {
+            const u64 i0 = it + (u64)q * kTile + (u64)lane * 4;
+            u32 mq = 0;
+#define RIOGP_ROW(C, E)                                                               \
+            {                                                                         \
+                const bool inr = i0 + E < wend;                                       \
+                const bool cin = C < m;                                               \
+                const bool kept = inr && cin && bit_of(alv, cin ? C : 0u);            \
+                kept_cnt += (u32)kept;                                                \
+                evict_cnt += (u32)(inr && !kept && C != kNone);                       \
+                mq |= (u32)(inr && !kept) << E;                                       \
+            }
+            RIOGP_ROW(cv[q].x, 0)
+            RIOGP_ROW(cv[q].y, 1)
+            RIOGP_ROW(cv[q].z, 2)
+            RIOGP_ROW(cv[q].w, 3)
+#undef RIOGP_ROW
+            pm[q] = mq;
+            anyp |= mq;
+        }
+        if (__ballot(anyp != 0)) {  // (wave-uniform; a stream without churn never gets here)
+            uint4 av[kIncB], lv[kIncB];
+#pragma unroll
+            for (int q = 0; q < kIncB; ++q) {
+                av[q] = make_uint4(0, 0, 0, 0);
+                lv[q] = make_uint4(0, 0, 0, 0);
+                if (pm[q]) {  // only the lanes that hold a pending row ask
+                    const u64 i0 = it + (u64)q * kTile + (u64)lane * 4;
+                    av[q] = *reinterpret_cast<const uint4*>(aff + i0);
+                    lv[q] = *reinterpret_cast<const uint4*>(load + i0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kIncB; ++q) {
+                if (!__ballot(pm[q] != 0)) continue;  // wave-uniform
+                const u64 i0 = it + (u64)q * kTile + (u64)lane * 4;
+                uint4 ov = cv[q];
+                u32 km = 0;  // rows that go on (claimants and spill candidates): packed
+#define RIOGP_ROW(A, L, O, E)                                                         \
+                if (pm[q] & (1u << E)) {                                              \
+                    const bool ain = A < m;                                           \
+                    const bool dead = A == kAffInactive;                              \
+                    const bool cl = ain && bit_of(alv, ain ? A : 0u);                 \
+                    const bool sp = !cl && !dead;                                     \
+                    O = cl ? A : (dead ? kNone : kSpillMark);                         \
+                    if (HIST && cl) atomicAdd(&hist[m + A], (u64)L);                  \
+                    claim_cnt += (u32)cl;                                             \
+                    sp_cnt += (u32)sp;                                                \
+                    sp_sum += sp ? (u64)L : 0ull;                                     \
+                    km |= (u32)(cl | sp) << E;                                        \
+                }
+                RIOGP_ROW(av[q].x, lv[q].x, ov.x, 0)
+                RIOGP_ROW(av[q].y, lv[q].y, ov.y, 1)
+                RIOGP_ROW(av[q].z, lv[q].z, ov.z, 2)
+                RIOGP_ROW(av[q].w, lv[q].w, ov.w, 3)
+#undef RIOGP_ROW
+                if (pm[q]) *reinterpret_cast<uint4*>(assign + i0) = ov;  // in place; the lane's kept rows keep their value
+                const u64 b0 = __ballot(km & 1u), b1 = __ballot(km & 2u), b2 = __ballot(km & 4u), b3 = __ballot(km & 8u);
+                if (b0 | b1 | b2 | b3) {
+                    const u64 lt = (1ull << lane) - 1ull;
+                    const u32 rank = (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+                    const u32 cnt = (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+                    u32 e = st_head + st_fill + rank;
+#define RIOGP_PK(E, A, L, O)                                                                              \
+                    if (km & (1u << E)) {                                                                 \
+                        const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
+                        stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; stage[2 * kStageCap + x] = A;  \
+                        if (HIST) stage[3 * kStageCap + x] = O;                                           \
+                        ++e;                                                                              \
+                    }
+                    RIOGP_PK(0, av[q].x, lv[q].x, ov.x)
+                    RIOGP_PK(1, av[q].y, lv[q].y, ov.y)
+                    RIOGP_PK(2, av[q].z, lv[q].z, ov.z)
+                    RIOGP_PK(3, av[q].w, lv[q].w, ov.w)
+#undef RIOGP_PK
+                    st_fill += cnt;
+                    __builtin_amdgcn_wave_barrier();
+                    while (st_fill >= 64u) {  // wave-uniform
+                        u32 x = st_head + (u32)lane;
+                        x = x >= kStageCap ? x - kStageCap : x;
+                        const u64 o = pk_pos + (u32)lane;
+                        pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
+                        if (HIST) pko.next[o] = stage[3 * kStageCap + x];
+                        st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
+                        st_fill -= 64u;
+                        pk_pos += 64u;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+        it = nit;
+#pragma unroll
+        for (int q = 0; q < kIncB; ++q) cv[q] = cn[q];
+    }
+    if (st_fill) {  // what is left in the ring (< 64 records)
+        u32 x = st_head + (u32)lane;
+        x = x >= kStageCap ? x - kStageCap : x;
+        if ((u32)lane < st_fill) {
+            const u64 o = pk_pos + (u32)lane;
+            pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
+            if (HIST) pko.next[o] = stage[3 * kStageCap + x];
+        }
+        pk_pos += st_fill;
+    }
+    sp_sum = wave_sum(sp_sum);
+    sp_cnt = wave_sum32(sp_cnt);
+    kept_cnt = wave_sum32(kept_cnt);
+    evict_cnt = wave_sum32(evict_cnt);
+    claim_cnt = wave_sum32(claim_cnt);
+    if (lane == 0) {
+        if (HIST) { wsp_sum[gw] = sp_sum; wsp_cnt[gw] = sp_cnt; }
+        pko.wcnt[gw] = (u32)(pk_pos - wstart);
+        atomicAdd(&bst[0], kept_cnt);
+        atomicAdd(&bst[1], evict_cnt);
+        atomicAdd(&bst[2], claim_cnt);
+        atomicAdd(&bst[3], sp_cnt);
+        if (sp_sum) atomicAdd(&bsum, sp_sum);
+    }
+    __syncthreads();
+    if (HIST) {
+        if (tid == 0) { bsp_sum[blockIdx.x] = bsum; bsp_cnt[blockIdx.x] = bst[3]; }
+        const u32 ng = (m + 7) >> 3;
+        for (u32 k = tid; k < ng * 16; k += kBlock) {
+            const u32 g = k >> 4, c = k & 15, j = g * 8 + (c & 7);
+            H[h_line(g, blockIdx.x, p.G) + c] = (c >= 8 && j < m) ? hist[m + j] : 0ull;
+        }
+    }
+    if (tid < 4) blkstat[(size_t)blockIdx.x * 4 + tid] = bst[tid];
+    RIOGP_KT(p, 3, 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1r k_rebal — deals the pending rows k_inc_scan<false> extracted out EVENLY, in index order, and is the "scan" of the
+//     fix-up's table: the rows sit, per wave range of the real table, at the front of the range (counts in src.wcnt); their
+//     exclusive prefix gives every row a dense position d, and wave v of the balanced table pv (uniform wave ranges of
+//     ctiles tiles) takes the dense tiles [v T/nw, (v+1) T/nw) of the T = ceil(P/256) tiles.  A churn tick's evicted rows sit
+//     in clusters (a node's rows are index runs: the interval water-fill put them there), so a workgroup of the row-range
+//     decomposition holds up to four times the mean and every fix-up kernel takes as long as its busiest workgroup; over
+//     the balanced table every workgroup of the cut search and of the water-fill rounds holds P/G rows.  Index order =
+//     (wave, position) order is the same in both layouts, so the solve is the same solve.
+//     Per balanced block: claim histograms -> H, spill totals, optimistic `next` (claimant -> affinity, else spill mark) —
+//     what k_scan builds for its own blocks.
+// ------------------------------------------------------------------------------------------------
+__device__ u64 block_excl_scan_1024(u64 v, bool saturating, u64* lds_part /*[16]*/, u64* total);  // (defined with the cut search)
+__host__ __device__ __forceinline__ size_t rebal_lds_bytes(u32 m, u32 nw) {
+    return scan_lds_bytes_dev(m) + ((size_t)nw + 8) * sizeof(u32) + 16 * sizeof(u64);
+}
+__global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx, const u32* __restrict__ s_load,
+                                                  const u32* __restrict__ s_aff, const u32* __restrict__ s_wcnt, Plan p, Plan pv,
+                                                  const u32* __restrict__ alive_bits, u32* __restrict__ d_idx,
+                                                  u32* __restrict__ d_load, u32* __restrict__ d_aff, u32* __restrict__ d_next,
+                                                  u32* __restrict__ d_wcnt, u64* __restrict__ H, u64* __restrict__ wsp_sum,
+                                                  u32* __restrict__ wsp_cnt, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 m = p.m, nw = p.nw;
+    u32* bst = reinterpret_cast<u32*>(smem);                 // [4]
+    u64* hist = reinterpret_cast<u64*>(smem + kSmall);       // [2m + 2]
+    u32* alv = reinterpret_cast<u32*>(hist + 2 * m + 2);     // [mwords]
+    u32* pre = reinterpret_cast<u32*>(smem + scan_lds_bytes_dev(m));  // [nw + 1] rows packed before source wave s
+    u64* part = reinterpret_cast<u64*>(pre + nw + 8);        // [16] block-scan partials (nw is a multiple of 16: aligned)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the source counts first (the only dependent global read of the prologue), four per thread
+    u32 c4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 g4 = (u32)tid * 4u + (u32)k;
+        c4[k] = s_wcnt[g4 < nw ? g4 : nw - 1];
+    }
+    for (u32 k = tid; k < 2 * m + 2; k += kBlock) hist[k] = 0;
+    for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
+    if (tid < 4) bst[tid] = 0;
+    u64& bsum = *reinterpret_cast<u64*>(smem + 32);
+    if (tid == 0) bsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if ((u32)tid * 4u + (u32)k >= nw) c4[k] = 0;
+    u64 total = 0;
+    u64 ex = block_excl_scan_1024((u64)c4[0] + c4[1] + c4[2] + c4[3], false, part, &total);  // (two barriers inside)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 g4 = (u32)tid * 4u + (u32)k;
+        if (g4 <= nw) pre[g4] = (u32)ex;
+        ex += c4[k];
+    }
+    if (tid == kBlock - 1 && nw == (u32)kBlock * 4u) pre[nw] = (u32)total;
+    __syncthreads();
+    const u32 P = (u32)total;
+    const u32 T = (P + (u32)kTile - 1u) / (u32)kTile;
+    const u32 tq = T / nw, tr = T - tq * nw;
+    const u64 gw = (u64)blockIdx.x * kWaves + wave;
+    const u64 tlo = gw * tq + ((gw * tr * p.div_magic) >> 38), thi = (gw + 1) * tq + (((gw + 1) * tr * p.div_magic) >> 38);
+    const u64 dlo = tlo * kTile < P ? tlo * kTile : P, dhi = thi * kTile < P ? thi * kTile : P;
+    const u64 obase = wave_row_lo(pv, gw);  // this wave's range of the balanced columns
+    u64 sp_sum = 0;
+    u32 sp_cnt = 0, claim_cnt = 0;  // per lane
+    // source wave of the range's first row: the last s with pre[s] <= dlo (wave-uniform)
+    u32 s_lo = 0;
+    {
+        u32 lo = 0, hi = nw;
+        while (hi - lo > 1) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (pre[mid] <= (u32)dlo) lo = mid; else hi = mid;
+        }
+        s_lo = lo;
+    }
+    for (u64 d0 = dlo; d0 < dhi; d0 += kTile) {
+        const u32 d = (u32)d0 + (u32)lane * 4u;
+        // this lane's source wave: the last s in [s_lo, nw) with pre[s] <= d
+        u32 s = s_lo;
+        {
+            u32 lo = s_lo, hi = nw;
+            while (hi - lo > 1) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                if (pre[mid] <= d) lo = mid; else hi = mid;
+            }
+            s = lo;
+        }
+        u32 ix[4] = {0, 0, 0, 0}, ld[4] = {0, 0, 0, 0}, af[4] = {kNone, kNone, kNone, kNone};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 de = d + (u32)e;
+            if (de < (u32)dhi) {
+                while (s + 1 < nw && pre[s + 1] <= de) ++s;  // (source waves without rows are stepped over)
+                const u64 at = wave_row_lo(p, s) + (de - pre[s]);
+                ix[e] = s_idx[at]; ld[e] = s_load[at]; af[e] = s_aff[at];
+            }
+        }
+        uint4 nx = make_uint4(kNone, kNone, kNone, kNone);
+#define RIOGP_ROW(E, O)                                                               \
+        if (d + E < (u32)dhi) {                                                       \
+            const u32 A = af[E];                                                      \
+            const bool ain = A < m;                                                   \
+            const bool cl = ain && bit_of(alv, ain ? A : 0u);                         \
+            O = cl ? A : kSpillMark;                                                  \
+            if (cl) atomicAdd(&hist[m + A], (u64)ld[E]);                              \
+            claim_cnt += (u32)cl;                                                     \
+            sp_cnt += (u32)!cl;                                                       \
+            sp_sum += cl ? 0ull : (u64)ld[E];                                         \
+        }
+        RIOGP_ROW(0, nx.x)
+        RIOGP_ROW(1, nx.y)
+        RIOGP_ROW(2, nx.z)
+        RIOGP_ROW(3, nx.w)
+#undef RIOGP_ROW
+        const u64 o = obase + (d0 - dlo) + (u64)lane * 4;  // (whole vectors: the columns are padded, rows past the count are never read as rows)
+        *reinterpret_cast<uint4*>(d_idx + o) = make_uint4(ix[0], ix[1], ix[2], ix[3]);
+        *reinterpret_cast<uint4*>(d_load + o) = make_uint4(ld[0], ld[1], ld[2], ld[3]);
+        *reinterpret_cast<uint4*>(d_aff + o) = make_uint4(af[0], af[1], af[2], af[3]);
+        *reinterpret_cast<uint4*>(d_next + o) = nx;
+        // the next tile starts where this tile's last row came from
+        const u32 s_last = (u32)__builtin_amdgcn_readlane((int)s, 63);
+        s_lo = s_last;
+    }
+    sp_sum = wave_sum(sp_sum);
+    sp_cnt = wave_sum32(sp_cnt);
+    claim_cnt = wave_sum32(claim_cnt);
+    if (lane == 0) {
+        wsp_sum[gw] = sp_sum;
+        wsp_cnt[gw] = sp_cnt;
+        d_wcnt[gw] = (u32)(dhi - dlo);
+        atomicAdd(&bst[3], sp_cnt);
+        if (sp_sum) atomicAdd(&bsum, sp_sum);
+    }
+    __syncthreads();
+    if (tid == 0) { bsp_sum[blockIdx.x] = bsum; bsp_cnt[blockIdx.x] = bst[3]; }
+    const u32 ng = (m + 7) >> 3;
+    for (u32 k = tid; k < ng * 16; k += kBlock) {
+        const u32 g = k >> 4, c = k & 15, j = g * 8 + (c & 7);
+        H[h_line(g, blockIdx.x, pv.G) + c] = (c >= 8 && j < m) ? hist[m + j] : 0ull;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2  k_resolve — per node: used = sum over blocks of the kept histogram, claim total, free, and
 //     the verdict "claims fit" (fast path) or "cut" (fix-up needed).  Workgroup g owns node group g
 //     (8 nodes) and reads exactly its G contiguous 128-byte lines of H ({kept x8 | claim x8} per
@@ -568,6 +930,9 @@ struct ResolveArgs {
     u32 fold_rounds;
     // SEARCH: the packed pending rows (affinity, load) of every wave range
     const u32* pk_aff; const u32* pk_load;
+    // the scan built no kept histogram (k_inc_scan): the kept load of node j is this committed vector's entry (after the fold
+    // above, when it is the vector folded into) where j is alive, 0 where it is not; nullptr: the column sums of H
+    const u64* kept_from;
 };
 
 template <bool SEARCH>
@@ -589,18 +954,20 @@ __global__ __launch_bounds__(SEARCH ? kBlock : 256) void k_resolve(const Resolve
     const u32 j = g * kResNodes + (u32)tid;          // node of thread tid < 8
     const bool valid = tid < kResNodes && j < m;
     // node-table operands of the verdict are requested up front so their latency overlaps the H loads
-    u64 cj = 0, ub = 0;
+    u64 cj = 0, ub = 0, kf = 0;
     bool alive_j = false;
     if (valid) {
         cj = a.cap[j];
         alive_j = bit_of(a.alive_bits, j);
         if (a.used_base) ub = a.used_base[j];
+        if (a.kept_from) kf = a.kept_from[j];
         // the rounds' admitted-load vectors: what the previous committed solve left goes into the committed `used` first
         if (a.D) {
             if (a.fold_into) {
                 u64 f = a.fold_into[j];
                 for (u32 r = 0; r < a.fold_rounds; ++r) f += a.D[(size_t)r * m + j];
                 a.fold_into[j] = f;
+                if (a.kept_from == a.fold_into) kf = f;
             }
             for (u32 r = 0; r < kFillRounds; ++r) a.D[(size_t)r * m + j] = 0;
         }
@@ -620,7 +987,7 @@ __global__ __launch_bounds__(SEARCH ? kBlock : 256) void k_resolve(const Resolve
     resolve_column_sums(a.H, g, G, v, part, tot);      // two barriers inside: red / cutmask are published
     if (SEARCH) RIOGP_KT(p, 0, 1);
     if (valid) {
-        const u64 kept_load = tot[tid], ctot = tot[tid + kResNodes];
+        const u64 kept_load = a.kept_from ? (alive_j ? kf : 0ull) : tot[tid], ctot = tot[tid + kResNodes];
         const u64 used = kept_load + ub;
         const u64 fre = (alive_j && cj > used) ? cj - used : 0;
         a.used_kept[j] = used;
@@ -2778,6 +3145,7 @@ __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 
     // ONE address, and those serialise at ~10 ns each — 2 048 workgroups of 256 threads spent 40 us there, five times the
     // 8 us of streaming the column.
     const u64 nvec = (n_obj + 3) / 4, stride = (u64)gridDim.x * kBlock;
+    const u64 vlast = nvec ? nvec - 1 : 0;  // (an empty table: vector 0 of the padded column, judged by nobody)
     u64 v = (u64)blockIdx.x * kBlock + tid;
     // kCleanFlight vectors per lane in flight ahead of the ones being judged; the first is requested before the bitmap set-up
     // below.  Measured on the 10 M-row column (rocprofv3, one node / 10 % of the nodes): 1 -> 13.3 / 16.8 us, 2 -> 13.7 / 17.5,
@@ -2788,7 +3156,7 @@ __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 
 #pragma unroll
     for (int q = 0; q < kCleanFlight; ++q) {
         const u64 vq = v + (u64)q * stride;  // (past the end: the last vector again, unconditionally — a load behind a
-        c[q] = *reinterpret_cast<const uint4*>(assign + (vq < nvec ? vq : nvec - 1) * 4);  // branch would end the overlap)
+        c[q] = *reinterpret_cast<const uint4*>(assign + (vq < nvec ? vq : vlast) * 4);     // branch would end the overlap)
     }
     if (tid == 0) { any = 0; ev_total = 0; }
     __syncthreads();
@@ -2806,7 +3174,7 @@ __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 
 #pragma unroll
         for (int q = 0; q < kCleanFlight; ++q) {
             const u64 vq = v + (u64)(kCleanFlight + q) * stride;
-            cn[q] = *reinterpret_cast<const uint4*>(assign + (vq < nvec ? vq : nvec - 1) * 4);
+            cn[q] = *reinterpret_cast<const uint4*>(assign + (vq < nvec ? vq : vlast) * 4);
         }
 #pragma unroll
         for (int q = 0; q < kCleanFlight; ++q) {
@@ -3637,13 +4005,50 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
     else launch_scan_t<false, false, 2>(p, t, nt, b, s, e0, e1);
 }
 
+// The scan of a committed tick over a mostly-placed table (k_inc_scan): t.cur is read and updated in place (t.next is not
+// used), the pending rows go to `pack`.  hist: the per-block claim histograms / spill totals / optimistic `next` of the packed
+// rows are built here; else launch_rebal builds them over the balanced layout.
+bool inc_scan_fits(u32 m) { return scan_lds_bytes(m) + (size_t)kWaves * 4 * kStageCap * sizeof(u32) <= (size_t)160 * 1024; }
+void launch_inc_scan(const Plan& p, u32* assign, const u32* load, const u32* aff, const NodeTab& nt, const SolveBufs& b,
+                     const PackOut& pack, bool hist, hipStream_t s) {
+    const size_t lds = scan_lds_bytes(p.m) + (size_t)kWaves * 4 * kStageCap * sizeof(u32);
+    Plan pp = p;
+    pp.wcnt = nullptr;
+    pp.alive_dst = nt.alive_src ? const_cast<u32*>(nt.alive_bits) : nullptr;
+    const u32* abits = nt.alive_src ? nt.alive_src : nt.alive_bits;
+    if (hist)
+        hipLaunchKernelGGL((k_inc_scan<true>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.H, b.blkstat,
+                           b.wsp_sum[0], b.wsp_cnt[0], b.stats, pack, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);
+    else
+        hipLaunchKernelGGL((k_inc_scan<false>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.H, b.blkstat,
+                           b.wsp_sum[0], b.wsp_cnt[0], b.stats, pack, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);
+}
+// The balanced table of the rows k_inc_scan<false> extracted: uniform wave ranges of ceil(tiles / nw) tiles each, as many
+// waves and blocks as the real table's plan (the columns hold rebal_rows(p) rows + the usual padding).
+Plan rebal_plan(const Plan& p) {
+    const u64 ctiles = (p.tiles + p.nw - 1) / p.nw;
+    Plan pv = make_plan((u64)p.nw * ctiles * kTile, p.m, p.G);
+    pv.mark = p.mark;
+    return pv;
+}
+u64 rebal_rows(u64 n) {
+    const Plan p = make_plan(n, 1, 0);
+    return (u64)p.nw * ((p.tiles + p.nw - 1) / p.nw) * kTile;
+}
+void launch_rebal(const Plan& p, const Plan& pv, const PackOut& src, const NodeTab& nt, const PackOut& dst, const SolveBufs& b,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_rebal, dim3(p.G), dim3(kBlock), rebal_lds_bytes(p.m, p.nw), s, src.idx, src.load, src.aff, src.wcnt, p, pv,
+                       nt.alive_bits, dst.idx, dst.load, dst.aff, dst.next, dst.wcnt, b.H, b.wsp_sum[0], b.wsp_cnt[0],
+                       b.bsp_sum[0], b.bsp_cnt[0]);
+}
+
 unsigned resolve_blocks(u32 m) {
     unsigned g = (m + kResNodes - 1) / kResNodes;
     return g ? g : 1;
 }
 
 void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
-                    hipEvent_t e0, hipEvent_t e1, const PackOut* search, u64* fold_into, u32 fold_rounds) {
+                    hipEvent_t e0, hipEvent_t e1, const PackOut* search, u64* fold_into, u32 fold_rounds, const u64* kept_from) {
     const unsigned grid = resolve_blocks(p.m);
     ResolveArgs a;
     a.H = b.H; a.blkstat = b.blkstat; a.p = p;
@@ -3652,6 +4057,7 @@ void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* h
     a.partial = b.partial; a.host_partial = host_partial; a.budget = b.budget; a.admpre = b.admpre; a.stats = b.stats;
     a.RP = b.RP; a.D = b.D; a.fold_into = b.D ? fold_into : nullptr; a.fold_rounds = fold_rounds;
     a.pk_aff = search ? search->aff : nullptr; a.pk_load = search ? search->load : nullptr;
+    a.kept_from = kept_from;
     const bool srch = search != nullptr && p.wcnt != nullptr;
     if (e0 && e1) {
         if (srch) hipExtLaunchKernelGGL(k_resolve<true>, dim3(grid), dim3(kBlock), 0, s, e0, e1, 0, a);

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -181,6 +182,14 @@ struct rio_gp {
     u32 tick_peeked = 0;               // ticks [0, tick_peeked) of the ring have had their verdicts looked at
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
+    // A committed tick over a mostly-placed table streams the assignment column alone and updates it in place (k_inc_scan):
+    // 0 auto = with the pending rows dealt out evenly to the fix-up's workgroups (k_rebal) | 1 the same, the fix-up following
+    // the row ranges (no k_rebal) | 2 never | 3 = 0 (bits 7-8 of rio_gp_debug_set_compact; A/B runs, parity tests)
+    int inc_mode = 0;
+    int inc_now = 0;            // how the solve waiting for its commit scanned: 0 k_scan | 1 k_inc_scan<hist> | 2 k_inc_scan + k_rebal
+    bool solve_inplace = false; // ... and wrote its decisions into the committed column itself: the commit swaps no columns
+    PackOut pk2{};              // the balanced pack columns (k_rebal)
+    Plan vplan{};               // the plan of the packed table the fix-up of the solve in flight runs over
     int cutpack_mode = 0;  // the same for packing at the cut pass of whole-table solves (bits 5-6 of rio_gp_debug_set_compact)
     u64 last_fix_rows = 0;  // rows the previous solve sent to the water-fill (spill candidates + rejected claimants)
     bool last_fix_valid = false;
@@ -360,20 +369,43 @@ void fold_used(rio_gp* h) {
 }
 // scan + resolve of one solve over the REAL table: the packed pending rows' cuts are searched inside k_resolve, the previous
 // committed solve's D rows are folded into the committed vector before k_resolve zeroes them
-void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool compact, u64* host_rows) {
+void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool compact, u64* host_rows, int inc = 0) {
     h->sb.D = h->D;
     h->solve_used_D = h->sb.D != nullptr;
-    launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
+    h->inc_now = inc;
+    h->solve_inplace = inc != 0;
+    const PackOut& pkx = inc == 2 ? h->pk2 : h->pk;  // where the fix-up finds the packed rows
+    h->vplan = h->plan;
+    if (inc) {
+        // (t.cur is read AND written: the tick is committed, nobody is promised the table as it was)
+        launch_inc_scan(h->plan, h->assign[h->cur], h->load, h->aff, nt, h->sb, h->pk, inc == 1, h->stream);
+        if (inc == 2) {
+            h->vplan = rebal_plan(h->plan);
+            launch_rebal(h->plan, h->vplan, h->pk, nt, h->pk2, h->sb, h->stream);
+        }
+    } else {
+        launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
+    }
+    h->vplan.wcnt = compact ? pkx.wcnt : nullptr;
     // The exact cut search rides in k_resolve when a block's packed rows are few enough for a wave pair per node to stream
     // (config 3: 39 K rows a block, 18 us against 6 + 14 for a resolve and a search launch of their own); on big blocks
     // (config 4 on one GPU: 390 K rows, ~39 K packed) a wave pair per node takes 91 us where k_cut_find's (block, node slice)
     // work items spread over the chip take 36: there the search stays a launch of its own.
     h->searched = compact && h->plan.G && h->n / h->plan.G <= kSearchMaxBlockRows;
-    Plan rp = h->plan;
-    if (h->searched) rp.wcnt = h->pk.wcnt;
-    launch_resolve(rp, nt, h->sb, host_rows, h->stream, nullptr, nullptr, h->searched ? &h->pk : nullptr,
-                   h->used_parts ? h->used : nullptr, h->parts_rounds);
+    Plan rp = h->vplan;
+    if (!h->searched) rp.wcnt = nullptr;
+    launch_resolve(rp, nt, h->sb, host_rows, h->stream, nullptr, nullptr, h->searched ? &pkx : nullptr,
+                   h->used_parts ? h->used : nullptr, h->parts_rounds, inc ? h->used : nullptr);
     h->used_parts = false;
+}
+// the fix-up over the rows the scan packed (compact): the water-fill writes every decision through the packed rows' indices
+// into the real column itself — the other assignment column, or (k_inc_scan) the committed one
+void enqueue_slow_packed(rio_gp* h, const NodeTab& nt) {
+    const PackOut& pkx = h->inc_now == 2 ? h->pk2 : h->pk;
+    Table vt{h->pos /* all-NONE column: every packed row is pending */, pkx.load, pkx.aff, pkx.next};
+    vt.pk_idx = pkx.idx;
+    vt.real_next = h->solve_inplace ? h->assign[h->cur] : h->assign[h->cur ^ 1];
+    enqueue_slow(h, h->vplan, vt, nt, true, h->searched, false);
 }
 
 u64* slot_dev(rio_gp* h, u32 k) { return h->d_slots + (size_t)(k % kRing) * h->slot_rows * 8; }
@@ -438,13 +470,21 @@ int merge_slow(rio_gp* h, DevStats* v) {
 
 int commit_enqueue(rio_gp* h) {
     if (!h->have_solved) return fail(h, RIO_GP_EINVAL, "rio_gp_commit: no solve to commit");
-    h->cur ^= 1;
+    if (!h->solve_inplace) h->cur ^= 1;  // (k_inc_scan and its fix-up wrote the committed column itself)
+    h->solve_inplace = false;
     std::swap(h->used, h->sb.used_cur);  // publication = two pointer swaps: the solve's `used` vector becomes the committed one
     h->used_valid = true;
     h->used_parts = h->solve_used_D;     // ... plus what its water-fill rounds admitted (D rows), folded in later
     h->parts_rounds = h->rounds;
     h->have_solved = false;  // (not an input change: mut_epoch stays)
     return RIO_GP_OK;
+}
+
+// 0 k_scan | 1 k_inc_scan building the histograms itself | 2 k_inc_scan + k_rebal.  Only a COMMITTED tick may work in place,
+// only a valid `used` vector can stand in for the kept histogram, and the packing rings must fit next to the histograms.
+int inc_choice(rio_gp* h, bool compact, bool commit) {
+    if (!compact || !commit || !h->used_valid || h->inc_mode == 2 || !inc_scan_fits(h->m) || h->m == 0) return 0;
+    return h->inc_mode == 1 ? 1 : 2;
 }
 
 // One whole-table solve; with `commit` the publication (two pointer swaps) happens before the last wait.
@@ -477,7 +517,10 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     // the later rounds run over them instead of streaming the table again.  Results identical.
     const bool cutpack = !compact && (h->cutpack_mode == 1 ||
                                       (h->cutpack_mode == 0 && h->last_fix_valid && h->last_fix_rows * 4 <= h->n && h->n >= 65536));
-    enqueue_scan_resolve(h, t, nt, compact, slot_dev(h, 0));
+    // ... and when the tick is committed and the library's `used` vector is valid, the scan streams the assignment column
+    // alone and works in place (k_inc_scan)
+    const int inc = inc_choice(h, compact, commit);
+    enqueue_scan_resolve(h, t, nt, compact, slot_dev(h, 0), inc);
     DevStats v;
     bool slow = false;
     const u64* vrows = h->h_slots;  // slot 0 of the solve ring
@@ -487,16 +530,8 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
         slow = v.n_cut > 0 || v.spillcand > 0;
     }
     if (spec || slow) {
-        if (compact) {
-            Plan pp = h->plan;
-            pp.wcnt = h->pk.wcnt;
-            Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
-            vt.pk_idx = h->pk.idx;  // the water-fill writes every decision through pk.idx into the real column itself
-            vt.real_next = t.next;
-            enqueue_slow(h, pp, vt, nt, true, h->searched);
-        } else {
-            enqueue_slow(h, h->plan, t, nt, false, false, cutpack);
-        }
+        if (compact) enqueue_slow_packed(h, nt);
+        else enqueue_slow(h, h->plan, t, nt, false, false, cutpack);
     }
     h->have_solved = true;
     h->ring_n = 0; h->ring_slow = 0; h->ring_any = false;
@@ -571,6 +606,8 @@ int harvest_ticks(rio_gp* h) {
 // pinned record.  The result is the one rio_gp_tick computes; only the counters arrive later (rio_gp_tick_wait).
 int tick_async_locked(rio_gp* h) {
     if (h->ring_n) return fail(h, RIO_GP_EINVAL, "rio_gp_tick_async: rio_gp_solve_async solves are in flight (call rio_gp_solve_wait)");
+    // (the row-sharded ticks keep their records in the same verdict slots and counter rows)
+    if (h->sh_tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_tick_async: row-sharded ticks are in flight (call rio_gp_shard_tick_wait)");
     if (h->tick_n == (u32)kRing) { int rc = harvest_ticks(h); if (rc) return rc; }
     peek_ticks(h);
     // nothing has changed since a tick that left every object placed: this one keeps every row, no fix-up can be needed
@@ -587,16 +624,11 @@ int tick_async_locked(rio_gp* h) {
     h->tick_epoch[k] = h->mut_epoch;
     h->tick_quiet[k] = quiet;
     h->tick_mark[k] = h->plan.mark = (1ull << 40) | ++h->wait_seq;  // column 7 of the verdict rows: peek_ticks knows them by it
-    enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8);
+    enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, inc_choice(h, compact, true));
     if (quiet) {
         // (k_scan + k_resolve only)
     } else if (compact) {
-        Plan pp = h->plan;
-        pp.wcnt = h->pk.wcnt;
-        Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
-        vt.pk_idx = h->pk.idx;
-        vt.real_next = t.next;
-        enqueue_slow(h, pp, vt, nt, true, h->searched);
+        enqueue_slow_packed(h, nt);
     } else {
         enqueue_slow(h, h->plan, t, nt, false, false);
     }
@@ -719,8 +751,11 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_EUPSTREAM);
     }
     const size_t R = h->cap_rows, M = h->cap_nodes, W = (size_t)kMaxBlocks * kWaves;
+    // the balanced pack columns (k_rebal) have uniform wave ranges: up to a tile per wave range more than the table; the
+    // all-NONE column stands in for their `cur` column as well
+    const size_t R2 = std::max((size_t)rebal_rows(h->cap_obj) + 8 * kTile, R);
 #define A(ptr, cnt) if ((rc = dalloc(h, &(ptr), (cnt))) != RIO_GP_OK) return bail(rc)
-    A(h->assign[0], R); A(h->assign[1], R); A(h->load, R); A(h->aff, R); A(h->pos, R);
+    A(h->assign[0], R); A(h->assign[1], R); A(h->load, R); A(h->aff, R); A(h->pos, R2);
     A(h->cap, M); A(h->used, M); A(h->alive_bits, (M + 31) / 32 + 4); A(h->dead_bits, (M + 31) / 32 + 4);
     A(h->alive_bytes, M);
     A(h->sb.H, (size_t)((M + 7) / 8) * kMaxBlocks * 16); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
@@ -731,6 +766,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.admpre, M); A(h->sb.cutidx, M); A(h->dstats, 1); A(h->fx_dev, (size_t)kMaxBlocks * 8);
     A(h->sb.R, (size_t)kMaxBlocks); A(h->sb.RP, (size_t)kMaxBlocks * resolve_blocks((u32)M)); A(h->D, (size_t)kFillRounds * M);
     A(h->pk.idx, R); A(h->pk.load, R); A(h->pk.aff, R); A(h->pk.next, R); A(h->pk.wcnt, W);
+    A(h->pk2.idx, R2); A(h->pk2.load, R2); A(h->pk2.aff, R2); A(h->pk2.next, R2); A(h->pk2.wcnt, W);
     A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
 #undef A
@@ -789,7 +825,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     // every row starts unplaced; the position scratch is all-ones between calls
     launch_fill_u32(h->assign[0], R, kNone, h->stream);
     launch_fill_u32(h->assign[1], R, kNone, h->stream);
-    launch_fill_u32(h->pos, R, kNone, h->stream);
+    launch_fill_u32(h->pos, R2, kNone, h->stream);
     launch_fill_u32(h->load, R, 0, h->stream);
     launch_fill_u32(h->aff, R, kNone, h->stream);
     (void)hipMemsetAsync(h->used, 0, M * sizeof(u64), h->stream);
@@ -1236,7 +1272,7 @@ int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evi
     for (u32 j = 0; j < h->m; ++j)
         if ((dead_bitmap[j >> 6] >> (j & 63)) & 1ull) { h->h_cs[j >> 5] |= 1u << (j & 31); any = true; }
     h->have_solved = false; ++h->mut_epoch;
-    if (!any) return RIO_GP_OK;  // retain() with a predicate nothing matches
+    if (!any || h->n == 0) return RIO_GP_OK;  // retain() with a predicate nothing matches, or over an empty map
     const u32 seq = (small_begin(h) & 0xFFFFFFu) | 0x800000u;  // 24 bits, never 0
     fold_used(h);  // (k_clean zeroes the dead nodes' entries: what the last solve's rounds admitted there must be in first)
     launch_clean(h->assign[h->cur], h->n, h->m, h->d_cs, h->used_valid ? h->used : nullptr, h->dstats, h->stream,
@@ -1476,6 +1512,10 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
     std::lock_guard<std::mutex> g(h->mu);
     if (!n) return RIO_GP_OK;
     if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: batch too large");
+    // an empty table (or no nodes): every entry is out of range, and the one-workgroup kernel's "0 rows = the host has
+    // validated the entries" convention must not be reached with entries nobody has looked at
+    if (h->n == 0 || h->m == 0)
+        return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
     HIPCHK(h, hipSetDevice(h->device));
     flush_alive(h);
     int rc;
@@ -1555,6 +1595,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipSetDevice(h->device));  // a host with several handles (one per GPU) calls from any thread
+    if (h->sh_tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_solve_async: row-sharded ticks are in flight (call rio_gp_shard_tick_wait)");
     // the verdict ring holds kRing solves: fold the oldest slot's verdict into the running count before it is overwritten
     // (rio_gp_solve_wait reports how many of ALL the solves since the last wait took the fix-up path)
     if (h->ring_n >= (u32)kRing) {
@@ -2004,6 +2045,7 @@ uint32_t rio_gp_shard_comm_ranks(rio_gp_t* h) { return h && h->sc ? h->sc->R : 0
 int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
+    if (h->sh_tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_solve_async: row-sharded ticks are in flight (call rio_gp_shard_tick_wait)");
     if (h->p2p && h->p2p->d_peers) {
         // peer-to-peer, ONE stream, two launches, no collective call and no host wait: k_scan -> k_resolve_xchg.
         // Stream order is the flow control: a rank's record j+1 leaves only after it consumed everyone's record j,
@@ -2211,11 +2253,12 @@ uint64_t rio_gp_debug_wave_row_lo(uint64_t n_objects, uint32_t n_nodes, uint32_t
 }
 
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
-    if (!h || mode < 0 || mode >= 128 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
+    if (!h || mode < 0 || mode >= 512 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
     std::lock_guard<std::mutex> g(h->mu);
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
     h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
     h->compact_mode = mode & 15;
+    h->inc_mode = (mode >> 7) & 3;       // bits 7-8: in-place scan of committed ticks, 0 auto (balanced fix-up) | 1 row-range fix-up | 2 never
     return RIO_GP_OK;
 }
 

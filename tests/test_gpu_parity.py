@@ -572,6 +572,50 @@ def test_churn_stream_adaptive_packed_fixup(gp, oracle, spec):
     g.close()
 
 
+INC_VARIANTS = (("auto", "auto"), ("auto", "always"), ("ranges", "never"), ("ranges", "always"), ("never", "auto"))
+
+
+@pytest.mark.parametrize("seed,n,m", [(0, 1, 1), (1, 255, 3), (2, 4097, 64), (3, 70_001, 33), (4, 300_000, 1024),
+                                      (5, 1_000_003, 256), (6, 777_777, 4096), (7, 65_536 * 5, 8), (8, 2_000_000, 1000)])
+def test_committed_ticks_in_place_scan_every_variant(gp, oracle, seed, n, m):
+    """The in-place scan of committed ticks (k_inc_scan: only the assignment column is streamed, the kept load comes from the
+    committed `used` vector, the decisions go into the committed column itself) — with the pending rows dealt out evenly to
+    the fix-up's workgroups (k_rebal), with the fix-up following the row ranges, and switched off (k_scan<COMPACT>), each
+    with the fix-up enqueued speculatively or after the verdict: ten ticks of churn over random tables with unplaced rows,
+    rows that are not objects, zero capacities and loads, table sizes around every tile / block boundary.  Every tick's
+    table, `used` and counters against the oracle chain."""
+    rng = np.random.default_rng(8800 + seed)
+    cur, load, aff, cap, alive = _rand_case(rng, n, m, p_none=0.1, cap_scale=1.3, p_alive=0.9, max_load=300 if seed % 2 else 3)
+    aff[rng.random(n) < 0.05] = 0xFFFFFFFE   # rows that are not objects
+    masks = [(rng.random(m) < 0.88).astype(np.uint8) for _ in range(10)]
+    masks[4] = np.ones(m, np.uint8)           # a tick in which everybody is alive
+    masks[7] = np.zeros(m, np.uint8)          # ... and one in which nobody is
+    for inc, spec in INC_VARIANTS:
+        g = _mk(gp, n, m, load, aff, cap, alive, cur, 2, lab=True)
+        g.set_compact("always", inc=inc)      # (the adaptive rule would keep small tables on the whole-table fix-up)
+        g.set_speculate(spec)
+        ref = cur.copy()
+        for t, mask in enumerate(masks):
+            g.set_alive_all(mask)
+            ref, used, ost = oracle.tick(ref, load, aff, cap, mask, 2)
+            st = g.tick() if t % 3 else None
+            if st is None:                     # every third tick through the asynchronous entry point
+                g.tick_async()
+                st = g.tick_wait()[-1]
+            assert st == ost, (inc, spec, t, st, ost)
+            got = g.get_assign()
+            assert np.array_equal(got, ref), (inc, spec, t, np.flatnonzero(got != ref)[:10])
+            assert np.array_equal(g.get_nodes()[2], used), (inc, spec, t)
+        # an un-committed solve right behind the in-place ticks: it must not touch the committed column
+        ref2, used2, ost2 = oracle.tick(ref, load, aff, cap, masks[0], 2)
+        g.set_alive_all(masks[0])
+        assert g.solve() == ost2
+        assert np.array_equal(g.get_solved(), ref2) and np.array_equal(g.get_assign(), ref)
+        g.commit()
+        assert np.array_equal(g.get_assign(), ref2) and np.array_equal(g.get_nodes()[2], used2)
+        g.close()
+
+
 def test_async_ticks_equal_the_synchronous_stream(gp, oracle):
     """rio_gp_tick_async: committed ticks enqueued back to back with liveness pushes in between, nothing waits on the host;
     tables and counters must be exactly those of the same sequence of rio_gp_tick calls (= the oracle chain), including
