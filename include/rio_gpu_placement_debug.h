@@ -21,8 +21,8 @@ extern "C" {
  * per-entry kernels instead of the window-partitioned ones.  + (mode << 5), mode 0 | 1 | 2 as above: packing at the cut pass
  * of a whole-table solve (adaptive: when the previous solve sent <= 25 % of the rows to the water-fill).
  * + (inc << 7): the in-place scan of COMMITTED ticks over a mostly-placed table (k_inc_scan: only the assignment column is
- * streamed; used whenever the packed fix-up is and the `used` vector is valid) — 0 = with the pending rows dealt out evenly to
- * the fix-up's workgroups (k_rebal; default) | 1 = the fix-up follows the row ranges | 2 = never (k_scan<COMPACT>). */
+ * streamed, then k_rebal deals the pending rows out evenly to the fix-up's workgroups) — 0 = whenever the packed fix-up is used
+ * and the `used` vector is valid (default) | 2 = never (k_scan<COMPACT>). */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 /* speculative enqueue of the fix-up behind k_resolve, without waiting for the verdict: 0 (default) = when the previous
  * solve needed it | 1 = always | 2 = never. */

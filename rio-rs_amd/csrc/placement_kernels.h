@@ -168,12 +168,13 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
 void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* host_partial, hipStream_t s,
                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const PackOut* search = nullptr,
                     u64* fold_into = nullptr, u32 fold_rounds = 0, const u64* kept_from = nullptr);
-// The scan of a COMMITTED tick over a mostly-placed table: only the assignment column is streamed, and updated in place;
-// pending rows -> pack (per wave range of p).  hist: per-block histograms / spill totals built here (fix-up over the row
-// ranges); else launch_rebal deals the rows out evenly over rebal_plan(p) into `dst` and builds them there.
+// The scan of a COMMITTED tick over a mostly-placed table (k_inc_scan): cur / load / aff are streamed like k_scan does, the
+// assignment column is updated in place and only where a row's value changes, no histogram is built; the pending rows ->
+// pack (per wave range of p).  launch_rebal deals them out evenly over rebal_plan(p) into `dst` and builds the fix-up's
+// per-block histograms and spill totals there.
 bool inc_scan_fits(u32 m);
 void launch_inc_scan(const Plan& p, u32* assign, const u32* load, const u32* aff, const NodeTab& nt, const SolveBufs& b,
-                     const PackOut& pack, bool hist, hipStream_t s);
+                     const PackOut& pack, hipStream_t s);
 Plan rebal_plan(const Plan& p);
 u64 rebal_rows(u64 n);  // rows of the balanced columns for a table of n rows (+ the usual padding)
 void launch_rebal(const Plan& p, const Plan& pv, const PackOut& src, const NodeTab& nt, const PackOut& dst, const SolveBufs& b,

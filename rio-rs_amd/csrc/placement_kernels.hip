@@ -128,7 +128,7 @@ __device__ __forceinline__ bool bit_of(const u32* bits, u32 j) { return (bits[j 
 // Phase traces (lab build only; compiled out of the product): workgroup b stores wall_clock64() (100 MHz) at phase
 // boundary `slot` of kernel table `tab` into g_kt[tab][b][slot] when the plan's trace flag is set.
 #ifdef RIO_GP_LAB
-constexpr int kKtTables = 5;
+constexpr int kKtTables = 6;
 __device__ u64 g_kt[kKtTables][kMaxBlocks * 8];
 static int g_trace_host = 0;
 #define RIOGP_KT(pl, tab, slot) do { if (threadIdx.x == 0 && (pl).trace && blockIdx.x < kMaxBlocks) g_kt[tab][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
@@ -504,60 +504,59 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 
 // ------------------------------------------------------------------------------------------------
 // K1i k_inc_scan — the scan of a COMMITTED tick over a table that is mostly placed (the clean_server rebalance stream,
-//     BASELINE config 5; local.rs:51-58 + service.rs:227-252 batched): only the assignment column is streamed (4 B/row
-//     instead of 12 B read + 4 B written), and it is updated IN PLACE.
-//       * a row on a live node is kept: nothing else of it is read, nothing is written;
-//       * the kept load of node j needs no histogram: it is the committed used[j] where j is alive and 0 where it is not
-//         (k_resolve takes it from there: ResolveArgs::kept_from) — valid whenever the library's `used` vector is;
-//       * only the PENDING rows (unplaced, or on a node that is not alive: clean_server folded in) have their load and affinity
-//         gathered — lanes without one issue no request —, get their optimistic value written back (claimant -> affinity,
-//         not an object -> NONE, the rest -> spill mark; one 16-byte store per lane that holds one) and are packed, in index
-//         order, to the front of the wave's range of the pack columns, exactly like k_scan<COMPACT>: the fix-up kernels run
-//         over them unchanged and write their decisions through pk_idx into the same column.
-//     HIST: the per-block claim histograms, spill totals and optimistic `next` of the packed rows are built here (the
-//     fix-up follows the row ranges).  !HIST: the rows are only extracted; k_rebal deals them out evenly and builds those.
-//     A wave works in batches of kIncB tiles: the next batch's assignment vectors are in flight while this batch's pending
-//     lanes fetch their load / affinity vectors.
+//     BASELINE config 5; local.rs:51-58 + service.rs:227-252 batched).  It reads what k_scan reads — cur, load, aff,
+//     12 B/row, coalesced — and differs in what it does NOT do:
+//       * the assignment column is updated IN PLACE (the tick is committed: nobody is promised the table as it was), and only
+//         where a row's value changes here: a claimant takes its affinity node, an evicted row that is not an object becomes
+//         NONE — one 16-byte store per lane that holds such a row.  Kept rows are not rewritten (k_scan: 4 B/row), and a
+//         spill candidate's row is left to the water-fill's last round, which writes it whatever becomes of it;
+//       * no kept histogram: the kept load of node j is the committed used[j] where j is alive and 0 where it is not
+//         (k_resolve takes it from there: ResolveArgs::kept_from — valid whenever the library's `used` vector is), so only
+//         the pending rows (a tenth of the table per churn tick) cost an LDS operation at all;
+//       * no claim histogram either: the pending rows are packed {row, load, affinity}, in index order, to the front of the
+//         wave's range of the pack columns (k_scan<COMPACT>'s rings), and k_rebal deals them out evenly to the fix-up's
+//         workgroups and builds the per-block histograms and spill totals over THAT layout.
+//     Why the load / affinity columns are streamed and not gathered for the pending rows only: the rows a churn tick evicts
+//     are not clustered at the granularity that matters — after 60 ticks of the config-5 stream 73 % of the 128-byte lines
+//     and 58 % of the 64-byte segments of a column hold one (97 % / 81 % in the first ticks), and a gather per pending row is
+//     two million random accesses at 17-20 ns chip-wide each: measured 34 us for the kernel against 21 for the stream.
 // ------------------------------------------------------------------------------------------------
-constexpr int kIncB = 4;
-
-template <bool HIST>
+__host__ __device__ __forceinline__ size_t inc_lds_base(u32 m) {  // small | alive bitmap (k_inc_scan's fixed part of the LDS)
+    return (kSmall + (size_t)(((m + 31) / 32 + 3) & ~3u) * sizeof(u32) + 63) & ~(size_t)63;
+}
+template <int TPI, bool NT>
 __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, const u32* __restrict__ load,
                                                      const u32* __restrict__ aff, const u32* __restrict__ alive_bits, Plan p,
-                                                     u64* __restrict__ H, u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
-                                                     u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko,
-                                                     FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt,
-                                                     u64* __restrict__ R, u64* __restrict__ RP) {
+                                                     u64* __restrict__ blkstat, DevStats* __restrict__ stats, PackOut pko,
+                                                     FxRows fx, u64* __restrict__ R, u64* __restrict__ RP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u32* bst = reinterpret_cast<u32*>(smem);                 // [4]
-    u64* hist = reinterpret_cast<u64*>(smem + kSmall);       // [2m + 2] (kept half unused: k_scan's layout, H lines alike)
-    u32* alv = reinterpret_cast<u32*>(hist + 2 * m + 2);     // [mwords]
+    u32* alv = reinterpret_cast<u32*>(smem + kSmall);        // [mwords]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     RIOGP_KT(p, 3, 0);
     const u64 gw = (u64)blockIdx.x * kWaves + wave;
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
-    // tile t of the wave's range, or — past its end — a tile that is certainly readable (its rows are judged by nobody)
-    const u64 safe = wstart < wend ? wstart : 0ull;
+    const u64 span = wend > wstart ? wend - wstart : 0;
+    const u64 wgrp = wstart + (span / (kTile * TPI)) * (kTile * TPI);   // end of the full TPI-tile groups
     u64 it = wstart;
-    uint4 cv[kIncB];
+    uint4 cv[TPI], av[TPI], lv[TPI];
+    if (it < wgrp) {
 #pragma unroll
-    for (int q = 0; q < kIncB; ++q) {
-        const u64 t = it + (u64)q * kTile;
-        cv[q] = *reinterpret_cast<const uint4*>(assign + (t < wend ? t : safe) + (u64)lane * 4);
+        for (int q = 0; q < TPI; ++q) {
+            const u64 i = it + (u64)q * kTile + (u64)lane * 4;
+            cv[q] = ld4<NT>(assign + i);
+            av[q] = ld4<NT>(aff + i);
+            lv[q] = ld4<NT>(load + i);
+        }
     }
-
-    if (HIST)
-        for (u32 k = tid; k < 2 * m + 2; k += kBlock) hist[k] = 0;
     for (u32 k = tid; k < p.mwords; k += kBlock) {
         const u32 w = alive_bits[k];
         alv[k] = w;
         if (p.alive_dst && blockIdx.x == 0) p.alive_dst[k] = w;  // a fresh bitmap (mapped host memory) -> the device array
     }
     if (tid < 4) bst[tid] = 0;
-    u64& bsum = *reinterpret_cast<u64*>(smem + 32);
-    if (tid == 0) bsum = 0;
     if (fx.dev && tid < 8) fx.dev[(size_t)blockIdx.x * 8 + tid] = 0;
     if (R && tid == 0) R[blockIdx.x] = 0;
     if (RP) {
@@ -573,118 +572,94 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
         stats->global_slow = 0;
     }
     __syncthreads();
+    RIOGP_KT(p, 3, 1);
 
-    u64 sp_sum = 0;
-    u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;  // per LANE here (summed over the wave at the end)
+    u32 kept_cnt = 0, evict_cnt = 0, claim_cnt = 0, sp_cnt = 0;  // per LANE here (summed over the wave at the end)
     u64 pk_pos = wstart;  // this wave's packed write cursor (wave-uniform)
-    u32* stage = reinterpret_cast<u32*>(smem + scan_lds_bytes_dev(p.m)) + (size_t)wave * 4 * kStageCap;
+    // this wave's packing ring: three columns of kStageCap words behind the bitmap
+    u32* stage = reinterpret_cast<u32*>(smem + inc_lds_base(m)) + (size_t)wave * 3 * kStageCap;
     u32 st_head = 0, st_fill = 0;
+    const u64 lt = (1ull << lane) - 1ull;
 
-    while (it < wend) {
-        const u64 nit = it + (u64)kIncB * kTile;
-        uint4 cn[kIncB];
-#pragma unroll
-        for (int q = 0; q < kIncB; ++q) {
-            const u64 t = nit + (u64)q * kTile;
-            cn[q] = *reinterpret_cast<const uint4*>(assign + (t < wend ? t : safe) + (u64)lane * 4);
+    // one tile: classify, write the lane's vector back if a row of it changed, pack the rows that go on
+    auto tile = [&](const uint4 c, const uint4 a, const uint4 l, const u64 i0) {
+        uint4 ov = c;
+        u32 km = 0;
+        bool chg = false;
+#define RIOGP_ROW(C, A, L, O, E)                                                      \
+        {                                                                             \
+            const bool inr = i0 + E < wend;                                           \
+            const bool cin = C < m, ain = A < m;                                      \
+            const bool kept = inr && cin && bit_of(alv, cin ? C : 0u);                \
+            const bool pend = inr && !kept;                                           \
+            const bool ev = pend && C != kNone;                                       \
+            const bool dead = A == kAffInactive;                                      \
+            const bool cl = pend && ain && bit_of(alv, ain ? A : 0u);                 \
+            const bool sp = pend && !cl && !dead;                                     \
+            O = cl ? A : ((ev && dead) ? kNone : C);                                  \
+            chg |= cl | (ev && dead);                                                 \
+            kept_cnt += (u32)kept; evict_cnt += (u32)ev;                              \
+            claim_cnt += (u32)cl; sp_cnt += (u32)sp;                                  \
+            km |= (u32)(cl | sp) << E;                                                \
         }
-        u32 pm[kIncB];  // which of the lane's four rows of tile q are pending
-        u32 anyp = 0;
-#pragma unroll
-        for (int q = 0; q < kIncB; ++q) {
-            const u64 i0 = it + (u64)q * kTile + (u64)lane * 4;
-            u32 mq = 0;
-#define RIOGP_ROW(C, E)                                                               \
-            {                                                                         \
-                const bool inr = i0 + E < wend;                                       \
-                const bool cin = C < m;                                               \
-                const bool kept = inr && cin && bit_of(alv, cin ? C : 0u);            \
-                kept_cnt += (u32)kept;                                                \
-                evict_cnt += (u32)(inr && !kept && C != kNone);                       \
-                mq |= (u32)(inr && !kept) << E;                                       \
-            }
-            RIOGP_ROW(cv[q].x, 0)
-            RIOGP_ROW(cv[q].y, 1)
-            RIOGP_ROW(cv[q].z, 2)
-            RIOGP_ROW(cv[q].w, 3)
+        RIOGP_ROW(c.x, a.x, l.x, ov.x, 0)
+        RIOGP_ROW(c.y, a.y, l.y, ov.y, 1)
+        RIOGP_ROW(c.z, a.z, l.z, ov.z, 2)
+        RIOGP_ROW(c.w, a.w, l.w, ov.w, 3)
 #undef RIOGP_ROW
-            pm[q] = mq;
-            anyp |= mq;
-        }
-        if (__ballot(anyp != 0)) {  // (wave-uniform; a stream without churn never gets here)
-            uint4 av[kIncB], lv[kIncB];
-#pragma unroll
-            for (int q = 0; q < kIncB; ++q) {
-                av[q] = make_uint4(0, 0, 0, 0);
-                lv[q] = make_uint4(0, 0, 0, 0);
-                if (pm[q]) {  // only the lanes that hold a pending row ask
-                    const u64 i0 = it + (u64)q * kTile + (u64)lane * 4;
-                    av[q] = *reinterpret_cast<const uint4*>(aff + i0);
-                    lv[q] = *reinterpret_cast<const uint4*>(load + i0);
-                }
+        if (chg) *reinterpret_cast<uint4*>(assign + i0) = ov;  // (a lane's rows past the end of the table are padding)
+        const u64 b0 = __ballot(km & 1u), b1 = __ballot(km & 2u), b2 = __ballot(km & 4u), b3 = __ballot(km & 8u);
+        if (b0 | b1 | b2 | b3) {  // (wave-uniform) index order = lane-major, then element
+            u32 e = st_head + st_fill + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+#define RIOGP_PK(E, A, L)                                                                                 \
+            if (km & (1u << E)) {                                                                         \
+                const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
+                stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; stage[2 * kStageCap + x] = A;         \
+                ++e;                                                                                      \
             }
-#pragma unroll
-            for (int q = 0; q < kIncB; ++q) {
-                if (!__ballot(pm[q] != 0)) continue;  // wave-uniform
-                const u64 i0 = it + (u64)q * kTile + (u64)lane * 4;
-                uint4 ov = cv[q];
-                u32 km = 0;  // rows that go on (claimants and spill candidates): packed
-#define RIOGP_ROW(A, L, O, E)                                                         \
-                if (pm[q] & (1u << E)) {                                              \
-                    const bool ain = A < m;                                           \
-                    const bool dead = A == kAffInactive;                              \
-                    const bool cl = ain && bit_of(alv, ain ? A : 0u);                 \
-                    const bool sp = !cl && !dead;                                     \
-                    O = cl ? A : (dead ? kNone : kSpillMark);                         \
-                    if (HIST && cl) atomicAdd(&hist[m + A], (u64)L);                  \
-                    claim_cnt += (u32)cl;                                             \
-                    sp_cnt += (u32)sp;                                                \
-                    sp_sum += sp ? (u64)L : 0ull;                                     \
-                    km |= (u32)(cl | sp) << E;                                        \
-                }
-                RIOGP_ROW(av[q].x, lv[q].x, ov.x, 0)
-                RIOGP_ROW(av[q].y, lv[q].y, ov.y, 1)
-                RIOGP_ROW(av[q].z, lv[q].z, ov.z, 2)
-                RIOGP_ROW(av[q].w, lv[q].w, ov.w, 3)
-#undef RIOGP_ROW
-                if (pm[q]) *reinterpret_cast<uint4*>(assign + i0) = ov;  // in place; the lane's kept rows keep their value
-                const u64 b0 = __ballot(km & 1u), b1 = __ballot(km & 2u), b2 = __ballot(km & 4u), b3 = __ballot(km & 8u);
-                if (b0 | b1 | b2 | b3) {
-                    const u64 lt = (1ull << lane) - 1ull;
-                    const u32 rank = (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
-                    const u32 cnt = (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-                    u32 e = st_head + st_fill + rank;
-#define RIOGP_PK(E, A, L, O)                                                                              \
-                    if (km & (1u << E)) {                                                                 \
-                        const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
-                        stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; stage[2 * kStageCap + x] = A;  \
-                        if (HIST) stage[3 * kStageCap + x] = O;                                           \
-                        ++e;                                                                              \
-                    }
-                    RIOGP_PK(0, av[q].x, lv[q].x, ov.x)
-                    RIOGP_PK(1, av[q].y, lv[q].y, ov.y)
-                    RIOGP_PK(2, av[q].z, lv[q].z, ov.z)
-                    RIOGP_PK(3, av[q].w, lv[q].w, ov.w)
+            RIOGP_PK(0, a.x, l.x)
+            RIOGP_PK(1, a.y, l.y)
+            RIOGP_PK(2, a.z, l.z)
+            RIOGP_PK(3, a.w, l.w)
 #undef RIOGP_PK
-                    st_fill += cnt;
-                    __builtin_amdgcn_wave_barrier();
-                    while (st_fill >= 64u) {  // wave-uniform
-                        u32 x = st_head + (u32)lane;
-                        x = x >= kStageCap ? x - kStageCap : x;
-                        const u64 o = pk_pos + (u32)lane;
-                        pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
-                        if (HIST) pko.next[o] = stage[3 * kStageCap + x];
-                        st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
-                        st_fill -= 64u;
-                        pk_pos += 64u;
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
+            st_fill += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            __builtin_amdgcn_wave_barrier();
+            while (st_fill >= 64u) {  // wave-uniform: 64 records leave as three coalesced 256-byte stores
+                u32 x = st_head + (u32)lane;
+                x = x >= kStageCap ? x - kStageCap : x;
+                const u64 o = pk_pos + (u32)lane;
+                pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
+                st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
+                st_fill -= 64u;
+                pk_pos += 64u;
+                __builtin_amdgcn_wave_barrier();
             }
         }
+    };
+
+    while (it < wgrp) {
+        const u64 nit = it + (u64)kTile * TPI;
+        const u64 pit = nit < wgrp ? nit : it;  // (the last iteration re-requests its own group: a hit, no over-read)
+        uint4 cn[TPI], an[TPI], ln[TPI];
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
+            cn[q] = ld4<NT>(assign + i);
+            an[q] = ld4<NT>(aff + i);
+            ln[q] = ld4<NT>(load + i);
+        }
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) tile(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4);
         it = nit;
 #pragma unroll
-        for (int q = 0; q < kIncB; ++q) cv[q] = cn[q];
+        for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
+    }
+    for (; it < wend; it += kTile) {  // leftover tiles (< TPI) and the ragged last tile of the table
+        const u64 i = it + (u64)lane * 4;
+        const uint4 c1 = *reinterpret_cast<const uint4*>(assign + i);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(aff + i);
+        const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
+        tile(c1, a1, l1, i);
     }
     if (st_fill) {  // what is left in the ring (< 64 records)
         u32 x = st_head + (u32)lane;
@@ -692,33 +667,22 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
         if ((u32)lane < st_fill) {
             const u64 o = pk_pos + (u32)lane;
             pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
-            if (HIST) pko.next[o] = stage[3 * kStageCap + x];
         }
         pk_pos += st_fill;
     }
-    sp_sum = wave_sum(sp_sum);
-    sp_cnt = wave_sum32(sp_cnt);
+    RIOGP_KT(p, 3, 2);
     kept_cnt = wave_sum32(kept_cnt);
     evict_cnt = wave_sum32(evict_cnt);
     claim_cnt = wave_sum32(claim_cnt);
+    sp_cnt = wave_sum32(sp_cnt);
     if (lane == 0) {
-        if (HIST) { wsp_sum[gw] = sp_sum; wsp_cnt[gw] = sp_cnt; }
         pko.wcnt[gw] = (u32)(pk_pos - wstart);
         atomicAdd(&bst[0], kept_cnt);
         atomicAdd(&bst[1], evict_cnt);
         atomicAdd(&bst[2], claim_cnt);
         atomicAdd(&bst[3], sp_cnt);
-        if (sp_sum) atomicAdd(&bsum, sp_sum);
     }
     __syncthreads();
-    if (HIST) {
-        if (tid == 0) { bsp_sum[blockIdx.x] = bsum; bsp_cnt[blockIdx.x] = bst[3]; }
-        const u32 ng = (m + 7) >> 3;
-        for (u32 k = tid; k < ng * 16; k += kBlock) {
-            const u32 g = k >> 4, c = k & 15, j = g * 8 + (c & 7);
-            H[h_line(g, blockIdx.x, p.G) + c] = (c >= 8 && j < m) ? hist[m + j] : 0ull;
-        }
-    }
     if (tid < 4) blkstat[(size_t)blockIdx.x * 4 + tid] = bst[tid];
     RIOGP_KT(p, 3, 7);
 }
@@ -754,12 +718,9 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
     u64* part = reinterpret_cast<u64*>(pre + nw + 8);        // [16] block-scan partials (nw is a multiple of 16: aligned)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the source counts first (the only dependent global read of the prologue), four per thread
-    u32 c4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const u32 g4 = (u32)tid * 4u + (u32)k;
-        c4[k] = s_wcnt[g4 < nw ? g4 : nw - 1];
-    }
+    RIOGP_KT(p, 5, 0);
+    const uint4 cq = *reinterpret_cast<const uint4*>(s_wcnt + (size_t)tid * 4);  // (the array holds kMaxBlocks * kWaves words whatever nw is)
+    u32 c4[4] = {cq.x, cq.y, cq.z, cq.w};
     for (u32 k = tid; k < 2 * m + 2; k += kBlock) hist[k] = 0;
     for (u32 k = tid; k < p.mwords; k += kBlock) alv[k] = alive_bits[k];
     if (tid < 4) bst[tid] = 0;
@@ -778,6 +739,7 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
     }
     if (tid == kBlock - 1 && nw == (u32)kBlock * 4u) pre[nw] = (u32)total;
     __syncthreads();
+    RIOGP_KT(p, 5, 1);
     const u32 P = (u32)total;
     const u32 T = (P + (u32)kTile - 1u) / (u32)kTile;
     const u32 tq = T / nw, tr = T - tq * nw;
@@ -786,7 +748,7 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
     const u64 dlo = tlo * kTile < P ? tlo * kTile : P, dhi = thi * kTile < P ? thi * kTile : P;
     const u64 obase = wave_row_lo(pv, gw);  // this wave's range of the balanced columns
     u64 sp_sum = 0;
-    u32 sp_cnt = 0, claim_cnt = 0;  // per lane
+    u32 sp_cnt = 0;  // per lane
     // source wave of the range's first row: the last s with pre[s] <= dlo (wave-uniform)
     u32 s_lo = 0;
     {
@@ -827,7 +789,6 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
             const bool cl = ain && bit_of(alv, ain ? A : 0u);                         \
             O = cl ? A : kSpillMark;                                                  \
             if (cl) atomicAdd(&hist[m + A], (u64)ld[E]);                              \
-            claim_cnt += (u32)cl;                                                     \
             sp_cnt += (u32)!cl;                                                       \
             sp_sum += cl ? 0ull : (u64)ld[E];                                         \
         }
@@ -845,9 +806,9 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
         const u32 s_last = (u32)__builtin_amdgcn_readlane((int)s, 63);
         s_lo = s_last;
     }
+    RIOGP_KT(p, 5, 2);
     sp_sum = wave_sum(sp_sum);
     sp_cnt = wave_sum32(sp_cnt);
-    claim_cnt = wave_sum32(claim_cnt);
     if (lane == 0) {
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
@@ -862,6 +823,7 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
         const u32 g = k >> 4, c = k & 15, j = g * 8 + (c & 7);
         H[h_line(g, blockIdx.x, pv.G) + c] = (c >= 8 && j < m) ? hist[m + j] : 0ull;
     }
+    RIOGP_KT(p, 5, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4005,25 +3967,25 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
     else launch_scan_t<false, false, 2>(p, t, nt, b, s, e0, e1);
 }
 
-// The scan of a committed tick over a mostly-placed table (k_inc_scan): t.cur is read and updated in place (t.next is not
-// used), the pending rows go to `pack`.  hist: the per-block claim histograms / spill totals / optimistic `next` of the packed
-// rows are built here; else launch_rebal builds them over the balanced layout.
-bool inc_scan_fits(u32 m) { return scan_lds_bytes(m) + (size_t)kWaves * 4 * kStageCap * sizeof(u32) <= (size_t)160 * 1024; }
+// The scan of a committed tick over a mostly-placed table (k_inc_scan): the assignment column is read and updated in place,
+// the pending rows go to `pack` (per wave range of p); launch_rebal deals them out evenly and builds the fix-up's histograms.
+static size_t inc_lds_bytes(u32 m) { return inc_lds_base(m) + (size_t)kWaves * 3 * kStageCap * sizeof(u32); }
+bool inc_scan_fits(u32 m) { return inc_lds_bytes(m) <= (size_t)160 * 1024; }
 void launch_inc_scan(const Plan& p, u32* assign, const u32* load, const u32* aff, const NodeTab& nt, const SolveBufs& b,
-                     const PackOut& pack, bool hist, hipStream_t s) {
-    const size_t lds = scan_lds_bytes(p.m) + (size_t)kWaves * 4 * kStageCap * sizeof(u32);
+                     const PackOut& pack, hipStream_t s) {
+    const size_t lds = inc_lds_bytes(p.m);
     Plan pp = p;
     pp.wcnt = nullptr;
     pp.alive_dst = nt.alive_src ? const_cast<u32*>(nt.alive_bits) : nullptr;
     const u32* abits = nt.alive_src ? nt.alive_src : nt.alive_bits;
-    if (hist)
-        hipLaunchKernelGGL((k_inc_scan<true>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.H, b.blkstat,
-                           b.wsp_sum[0], b.wsp_cnt[0], b.stats, pack, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);
+    if (g_scan_nt_mode == 1 || (g_scan_nt_mode == 0 && p.n >= kScanNtRows))
+        hipLaunchKernelGGL((k_inc_scan<2, true>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.blkstat, b.stats,
+                           pack, b.fx, b.R, b.RP);
     else
-        hipLaunchKernelGGL((k_inc_scan<false>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.H, b.blkstat,
-                           b.wsp_sum[0], b.wsp_cnt[0], b.stats, pack, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);
+        hipLaunchKernelGGL((k_inc_scan<2, false>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.blkstat, b.stats,
+                           pack, b.fx, b.R, b.RP);
 }
-// The balanced table of the rows k_inc_scan<false> extracted: uniform wave ranges of ceil(tiles / nw) tiles each, as many
+// The balanced table of the rows k_inc_scan packed: uniform wave ranges of ceil(tiles / nw) tiles each, as many
 // waves and blocks as the real table's plan (the columns hold rebal_rows(p) rows + the usual padding).
 Plan rebal_plan(const Plan& p) {
     const u64 ctiles = (p.tiles + p.nw - 1) / p.nw;

@@ -182,11 +182,11 @@ struct rio_gp {
     u32 tick_peeked = 0;               // ticks [0, tick_peeked) of the ring have had their verdicts looked at
     u64 last_pending = 0;
     int compact_mode = 0;  // 0 auto | 1 always | 2 never (rio_gp_debug_set_compact)
-    // A committed tick over a mostly-placed table streams the assignment column alone and updates it in place (k_inc_scan):
-    // 0 auto = with the pending rows dealt out evenly to the fix-up's workgroups (k_rebal) | 1 the same, the fix-up following
-    // the row ranges (no k_rebal) | 2 never | 3 = 0 (bits 7-8 of rio_gp_debug_set_compact; A/B runs, parity tests)
+    // A committed tick over a mostly-placed table updates the assignment column in place and builds no kept histogram
+    // (k_inc_scan), then k_rebal deals the pending rows out evenly to the fix-up's workgroups: 0 auto | 2 never (bits 7-8
+    // of rio_gp_debug_set_compact; A/B runs, parity tests)
     int inc_mode = 0;
-    int inc_now = 0;            // how the solve waiting for its commit scanned: 0 k_scan | 1 k_inc_scan<hist> | 2 k_inc_scan + k_rebal
+    int inc_now = 0;            // how the solve waiting for its commit scanned: 0 k_scan | 2 k_inc_scan + k_rebal
     bool solve_inplace = false; // ... and wrote its decisions into the committed column itself: the commit swaps no columns
     PackOut pk2{};              // the balanced pack columns (k_rebal)
     Plan vplan{};               // the plan of the packed table the fix-up of the solve in flight runs over
@@ -378,11 +378,9 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     h->vplan = h->plan;
     if (inc) {
         // (t.cur is read AND written: the tick is committed, nobody is promised the table as it was)
-        launch_inc_scan(h->plan, h->assign[h->cur], h->load, h->aff, nt, h->sb, h->pk, inc == 1, h->stream);
-        if (inc == 2) {
-            h->vplan = rebal_plan(h->plan);
-            launch_rebal(h->plan, h->vplan, h->pk, nt, h->pk2, h->sb, h->stream);
-        }
+        launch_inc_scan(h->plan, h->assign[h->cur], h->load, h->aff, nt, h->sb, h->pk, h->stream);
+        h->vplan = rebal_plan(h->plan);
+        launch_rebal(h->plan, h->vplan, h->pk, nt, h->pk2, h->sb, h->stream);
     } else {
         launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
     }
@@ -480,11 +478,11 @@ int commit_enqueue(rio_gp* h) {
     return RIO_GP_OK;
 }
 
-// 0 k_scan | 1 k_inc_scan building the histograms itself | 2 k_inc_scan + k_rebal.  Only a COMMITTED tick may work in place,
-// only a valid `used` vector can stand in for the kept histogram, and the packing rings must fit next to the histograms.
+// 0 k_scan | 2 k_inc_scan + k_rebal.  Only a COMMITTED tick may work in place, only a valid `used` vector can stand in for
+// the kept histogram, and the rings of pending rows must fit the LDS next to the liveness bitmap.
 int inc_choice(rio_gp* h, bool compact, bool commit) {
     if (!compact || !commit || !h->used_valid || h->inc_mode == 2 || !inc_scan_fits(h->m) || h->m == 0) return 0;
-    return h->inc_mode == 1 ? 1 : 2;
+    return 2;
 }
 
 // One whole-table solve; with `commit` the publication (two pointer swaps) happens before the last wait.
@@ -2258,7 +2256,7 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
     h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
     h->compact_mode = mode & 15;
-    h->inc_mode = (mode >> 7) & 3;       // bits 7-8: in-place scan of committed ticks, 0 auto (balanced fix-up) | 1 row-range fix-up | 2 never
+    h->inc_mode = ((mode >> 7) & 3) == 2 ? 2 : 0;  // bits 7-8: in-place scan of committed ticks, 0 auto | 2 never
     return RIO_GP_OK;
 }
 

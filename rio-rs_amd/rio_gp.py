@@ -376,11 +376,11 @@ class GpuPlacement:
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode).  partitioned_crud=False: big
         update / remove batches through the plain per-entry kernels (A/B runs, parity tests).  cut_pack: the same three
         modes for packing at the cut pass of whole-table solves (round 0 of k_fill packs).  inc: the in-place scan of
-        committed ticks over a mostly-placed table (k_inc_scan) — "auto": with the pending rows dealt out evenly to the
-        fix-up's workgroups (k_rebal) | "ranges": the fix-up follows the row ranges | "never": k_scan<COMPACT>."""
+        committed ticks over a mostly-placed table (k_inc_scan, then k_rebal deals the pending rows out evenly to the
+        fix-up's workgroups) — "auto": whenever the packed fix-up is used and `used` is valid | "never": k_scan<COMPACT>."""
         self._need_lab()
         modes = {"auto": 0, "always": 1, "never": 2}
-        incs = {"auto": 0, "ranges": 1, "never": 2}
+        incs = {"auto": 0, "never": 2}
         self._chk(self._L.rio_gp_debug_set_compact(self._h, modes.get(mode, mode) | (0 if partitioned_crud else 16) |
                                                    (modes.get(cut_pack, cut_pack) << 5) | (incs.get(inc, inc) << 7)))
 

@@ -572,16 +572,16 @@ def test_churn_stream_adaptive_packed_fixup(gp, oracle, spec):
     g.close()
 
 
-INC_VARIANTS = (("auto", "auto"), ("auto", "always"), ("ranges", "never"), ("ranges", "always"), ("never", "auto"))
+INC_VARIANTS = (("auto", "auto"), ("auto", "always"), ("auto", "never"), ("never", "auto"))
 
 
 @pytest.mark.parametrize("seed,n,m", [(0, 1, 1), (1, 255, 3), (2, 4097, 64), (3, 70_001, 33), (4, 300_000, 1024),
                                       (5, 1_000_003, 256), (6, 777_777, 4096), (7, 65_536 * 5, 8), (8, 2_000_000, 1000)])
 def test_committed_ticks_in_place_scan_every_variant(gp, oracle, seed, n, m):
     """The in-place scan of committed ticks (k_inc_scan: only the assignment column is streamed, the kept load comes from the
-    committed `used` vector, the decisions go into the committed column itself) — with the pending rows dealt out evenly to
-    the fix-up's workgroups (k_rebal), with the fix-up following the row ranges, and switched off (k_scan<COMPACT>), each
-    with the fix-up enqueued speculatively or after the verdict: ten ticks of churn over random tables with unplaced rows,
+    committed `used` vector, the decisions go into the committed column itself, the pending rows are dealt out evenly to the
+    fix-up's workgroups by k_rebal) with the fix-up enqueued speculatively or after the verdict, and switched off
+    (k_scan<COMPACT>): ten ticks of churn over random tables with unplaced rows,
     rows that are not objects, zero capacities and loads, table sizes around every tile / block boundary.  Every tick's
     table, `used` and counters against the oracle chain."""
     rng = np.random.default_rng(8800 + seed)

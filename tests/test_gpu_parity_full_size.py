@@ -111,18 +111,18 @@ def test_config3_contended_at_10m(gp, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("compact", [None, "never", "inc-ranges", "inc-never"])
+@pytest.mark.parametrize("compact", [None, "never", "inc-never"])
 def test_config5_churn_ticks_at_10m(gp, oracle, compact):
     """Six committed ticks of the config-5 stream at full size, every tick compared: ~1 M rows evicted and re-placed per
     tick, hundreds of cut nodes, the packed fix-up from the second tick on (product library) or the whole-table fix-up
     (lab build, packed fix-up switched off).  The product library scans committed ticks in place (k_inc_scan + k_rebal); the
-    lab build also runs the stream with the fix-up following the row ranges and with the in-place scan switched off."""
+    lab build also runs the stream with the in-place scan switched off."""
     cfg = cfg_of("c3")
     n, m = cfg["n"], cfg["m"]
     ref = synth.warm_assign(n, m)
     g = _mk(gp, cfg, cur=ref, lab=compact is not None)   # None: the product library, adaptive
-    if compact in ("inc-ranges", "inc-never"):   # the in-place scan with the fix-up following the row ranges | switched off
-        g.set_compact("auto", inc=compact[4:])
+    if compact == "inc-never":   # the packed fix-up behind k_scan<COMPACT>: round 3's tick
+        g.set_compact("auto", inc="never")
     elif compact is not None:
         g.set_compact(compact)
     for tick in range(6):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Config-5 churn tick (10 M x 1 024, 10 % of the nodes flip per tick) under the scan variants of the lab build:
   never   k_scan<COMPACT> streams cur/load/aff and rewrites the column (round 3's tick)
-  ranges  k_inc_scan<hist>: the assignment column alone, in place; the fix-up follows the row ranges
-  auto    k_inc_scan + k_rebal: the pending rows dealt out evenly to the fix-up's workgroups (the product's choice)
+  auto    k_inc_scan (the assignment column alone, in place) + k_rebal (the pending rows dealt out evenly to the fix-up's
+          workgroups): the product's choice
 Per variant: us per tick pipelined (rio_gp_tick_async) and synchronous (rio_gp_tick), in the stream's steady state, the
 kernels' own spans (wall_clock64 phase traces), and the final table compared across the variants.
 Usage: c5_variants.py [ticks=100] [warm=60] [config=c3|c4]"""
@@ -26,7 +26,7 @@ warm = synth.warm_assign(n, m)
 masks = [synth.churn_mask(m, 2 + k) for k in range(warm_ticks + 2 * ticks + 8)]
 out = {"n": n, "m": m, "ticks": ticks, "warm_ticks": warm_ticks}
 final = {}
-for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "ranges", "auto")):
+for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "auto")):
     g = rio_gp.LabPlacement(n, m)
     g.set_compact("auto", inc=inc)
     g.set_nodes(cfg["cap"], cfg["alive"])
@@ -56,7 +56,7 @@ for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "ranges",
         for _ in range(6):
             g.set_alive_all(masks[k]); k += 1
             g.tick()
-        names = {3: "scan", 0: "resolve", 1: "fill0", 2: "fill1"}
+        names = {3: "scan", 5: "rebal", 0: "resolve", 1: "fill0", 2: "fill1"}
         tabs = {t: g.ktrace(True, t).astype(np.int64) for t in names}
         g.ktrace(False)
         base = min(int(t[t[:, 0] > 0][:, 0].min()) for t in tabs.values() if (t[:, 0] > 0).any())
@@ -66,8 +66,12 @@ for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "ranges",
             if not len(rows):
                 continue
             dur = (rows[:, 7] - rows[:, 0]) / 100.0
+            rel = (rows - rows[:, :1]) / 100.0
+            rel[rows == 0] = np.nan
             spans[names[t]] = {"start": round((int(rows[:, 0].min()) - base) / 100.0, 1), "end": round((int(rows[:, 7].max()) - base) / 100.0, 1),
-                               "wg_median_us": round(float(np.median(dur)), 1), "wg_max_us": round(float(dur.max()), 1)}
+                               "wg_median_us": round(float(np.median(dur)), 1), "wg_max_us": round(float(dur.max()), 1),
+                               "phase_median_us": [None if np.isnan(x) else round(float(x), 1) for x in np.nanmedian(rel, axis=0)],
+                               "phase_max_us": [None if np.isnan(x) else round(float(x), 1) for x in np.nanmax(rel, axis=0)]}
         rec["spans_us"] = spans
     except Exception as e:  # measurement aid
         rec["spans_us"] = {"error": repr(e)}
