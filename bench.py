@@ -11,11 +11,19 @@ A "step" is one whole-table pass of the placement solver (every row of the table
           per-kernel spans, parity of the whole 110-tick stream against the oracle chain).
   N > 1   BASELINE.json config 4 as north_star states it: ONE table of 100 M objects x 4 096 nodes, rows sharded over
           the N ranks (12.5 M rows per GPU at N = 8), "scaling": "strong"; the weak-scaled config 3 (10 M rows per
-          GPU of one N x 10 M-row table) is measured in the same run and reported under "weak_config3".
+          GPU of one N x 10 M-row table) is measured in the same run and reported under "weak_config3".  value = a stream
+          of COMMITTED ticks of that table (rio_gp_shard_tick_async over the peer-to-peer windows, ShardedSolver.tick over
+          the collective rungs) — the same quantity the N = 1 line carries for config 4 on one GPU.
+  every N `scaling_points` = {strong_config4_committed_tick, weak_config3_committed_tick}: the two curves' points under
+          the same keys and the same definition strings at every N (the un-committed re-solves rounds 2-3 reported
+          at N > 1 are kept under `cold_resolve_uncommitted`).
 
-  value        = decisions of all ranks / max-over-ranks wall time of the K steps
+  value        = decisions of all ranks / max-over-ranks wall time of the K steps; the timed region ends with the
+                 library's own wait (rio_gp_tick_wait into a preallocated array), the counters become dictionaries afterwards
   parity       = the solved assignment column, the per-node `used` vector and the counters compared bit for bit with
-                 the CPU oracle's solve of the same table, in this very run (exit code 3 on a mismatch)
+                 the CPU oracle's solve of the same table, in this very run (exit code 3 on a mismatch); N = 1:
+                 parity.against_reference_port = the same column against the map the cpu_baseline leg's string-level
+                 restatement of LocalObjectPlacement + get_or_create_placement built, read back object by object
   roofline     = k_scan (the streaming kernel, >85 % of a step): algorithmic 16 B/decision (read
                  cur+load+aff, write assign) / its per-launch HIP-event time, on the cold table; `traffic` = HBM bytes per
                  launch from rocprofv3 PMC passes run by this script; frac_dram_bound / frac_committed_tick /
@@ -38,6 +46,13 @@ for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), 
 import numpy as np  # noqa: E402
 
 ALGO_BYTES_PER_DECISION = 16
+# ONE definition of the quantity every line reports, whatever N: the strings below are copied verbatim into the N = 1 and the
+# N > 1 lines (`scaling_points`), so that a 1/2/4/8 curve is built from like quantities
+DEF_TICK = ("committed ticks (solve + fix-up if needed + commit, each tick consuming the previous tick's table), a stream that starts "
+            "from the cold table (tick 1: every object claims its requester); the timed ticks follow the warm-ups: every row gets "
+            "its decision every tick and is kept; decisions/s = rows of the WHOLE table x ticks / max-over-ranks wall time")
+DEF_STRONG = "BASELINE config 4, strong scaling: ONE table of 100 M objects x 4 096 nodes, rows sharded contiguously over the N ranks; " + DEF_TICK
+DEF_WEAK = "BASELINE config 3, weak scaling: 10 M objects x 1 024 nodes PER GPU (one N x 10 M-row table, capacities from the global load); " + DEF_TICK
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 C4_ROWS, C4_NODES = 100_000_000, 4096
 
@@ -82,13 +97,27 @@ def parse():
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 
-def cpu_baseline(cfg, sample, array_oracle_seconds=None):
-    """Time the oracle port of the reference's per-object path on this box's host cores (bounded)."""
+def cpu_baseline(cfg, sample, array_oracle_seconds=None, gpu_cold_column=None):
+    """Time the oracle port of the reference's per-object path on this box's host cores (bounded).  The map the
+    single-thread leg builds is not thrown away: every object is looked up again and the answers are compared with the
+    column the GPU solved from the same cold table (returned as the second value: parity.against_reference_port)."""
     import pyoracle
     n = min(sample, cfg["n"])
     aff = np.ascontiguousarray(cfg["aff"][:n])
     cores = os.cpu_count() or 1
-    t1, _ = pyoracle.bench_policy(n, cfg["m"], aff, threads=1)                       # cold: miss -> first touch -> update
+    t1, port_nodes = pyoracle.policy_readback(n, cfg["m"], aff)                      # cold: miss -> first touch -> update
+    against_port = None
+    if gpu_cold_column is not None:
+        eq = bool(np.array_equal(port_nodes, gpu_cold_column[:n]))
+        against_port = {"rows": int(n), "equal": eq,
+                        "against": "the string-level restatement of LocalObjectPlacement + Service::get_or_create_placement "
+                                   "(oracle/local_placement_oracle.cpp; local.rs:22-49, service.rs:193-254): the map the "
+                                   "cpu_baseline leg built with one call per object (requester = the object's affinity node, "
+                                   "every member active), read back with one lookup per object, against the GPU's solve of "
+                                   "the same cold table (capacity 1.25x: no node is cut, so the solver IS the reference policy)"}
+        if not eq:
+            bad = np.flatnonzero(port_nodes != gpu_cold_column[:n])
+            against_port["first_mismatches"] = [[int(i), int(gpu_cold_column[i]), int(port_nodes[i])] for i in bad[:5]]
     nT = min(n, 1_000_000)
     tT, _ = pyoracle.bench_policy(nT, cfg["m"], aff[:nT], threads=cores)             # all cores on ONE shared map
     nW = min(n, 20_000)
@@ -103,7 +132,7 @@ def cpu_baseline(cfg, sample, array_oracle_seconds=None):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {
+    return against_port, {
         "value": best_v, "unit": "decisions/s", "cores": best_c, "kind": "port",
         "sample": "cold get_or_create_placement per object (service.rs:193-254 restated in C++: string keys, "
                   "unordered_map behind a shared_mutex, %d-member LocalStorage) over the first %d objects of the "
@@ -141,6 +170,7 @@ def parity_single(g, cfg, rounds=2):
         rec["first_mismatches"] = [[int(i), int(got[i]), int(want[i])] for i in bad[:5]]
     if not eq_s:
         rec["stats_gpu"], rec["stats_oracle"] = st, ost
+    rec["_solved_column"] = got   # (popped by the caller: compared with the reference port's map)
     return rec, t_orc
 
 
@@ -429,7 +459,7 @@ def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
         for k in range(60, 66):
             gl.set_alive_all(masks[k % total])
             gl.tick()
-        names = {3: "k_scan<COMPACT>", 0: "k_resolve<SEARCH>", 1: "k_fill round 0", 2: "k_fill round 1"}
+        names = {3: "k_inc_scan", 5: "k_rebal", 0: "k_resolve<SEARCH>", 1: "k_fill round 0", 2: "k_fill round 1"}
         tabs = {t: gl.ktrace(True, t).astype(np.int64) for t in names}
         gl.ktrace(False)
         gl.close()
@@ -447,7 +477,9 @@ def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
                         "step": "rio_gp_set_alive_all + rio_gp_tick (the host reads every tick's counters)"},
         "pipelined": piped, "objects_moved_per_s": moved / dt, "stats_last_tick": st, "parity": parity,
         "kernel_spans_on_device_us": spans,
-        "launches_per_tick": "k_scan<COMPACT> (reads the pushed liveness bitmap from mapped pinned memory) + k_resolve<SEARCH> + k_fill (round 0) + k_fill (round 1)",
+        "launches_per_tick": "k_inc_scan (cur/load/aff streamed, the column updated in place, no histogram; reads the pushed liveness "
+                             "bitmap from mapped pinned memory) + k_rebal (pending rows dealt out evenly, per-block histograms) + "
+                             "k_resolve<SEARCH> + k_fill (round 0) + k_fill (round 1)",
     }
 
 
@@ -491,6 +523,8 @@ def make_sharded_solver(a, dist, g, local_rank, rank, n_global, load_total):
             ex = {"p2p": sharded.P2PExchange, "native": sharded.NativeRcclExchange}[kind](eng) if kind != "torch" \
                 else sharded.DistExchange()
             sol = sharded.ShardedSolver([eng], ex, spill_rounds=2, pipeline=(kind == "torch" and not a.no_pipeline))
+            if kind == os.environ.get("RIO_GP_BENCH_FAIL_RUNG") and str(rank) == os.environ.get("RIO_GP_BENCH_FAIL_RANK", "0"):
+                raise RuntimeError("injected failure of rung '%s' on rank %d (flow test)" % (kind, rank))
             for _ in range(max(a.warmup, 2)):
                 sol.solve_async()
             st, n_slow = sol.solve_wait()
@@ -513,7 +547,12 @@ def make_sharded_solver(a, dist, g, local_rank, rank, n_global, load_total):
     raise SystemExit("no exchange path could be set up")
 
 
-def timed_steps(a, g, dist, torch, step, wait):
+def timed_steps(a, g, dist, torch, step, wait, wait_c=None):
+    """K steps between two barriers (N > 1: dist.barrier) + device synchronisation on both sides.  The closing
+    synchronisation of the timed region is the library's own wait — `wait_c`, one C call that waits for the handle's stream
+    (the only stream with work on it) and copies the counters into a preallocated array — when the caller has one: nothing
+    of the host's bookkeeping (Python dictionaries of K ticks' counters, a second wait on an event, torch's synchronise over
+    streams that carry nothing) sits between the last step and the clock.  `wait` then only converts what `wait_c` fetched."""
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -524,10 +563,19 @@ def timed_steps(a, g, dist, torch, step, wait):
     g.timer_begin()
     for _ in range(a.steps):
         step()
+    g.timer_stop()              # the closing event is recorded behind the last step; it is read after the clock
+    if wait_c is not None:
+        wait_c()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        st, n_slow = wait()
+    else:
+        st, n_slow = wait()
+        barrier()
+        dt = time.perf_counter() - t0
     gpu_ms = g.timer_end()
-    st, n_slow = wait()
-    barrier()
-    dt = time.perf_counter() - t0
     if dist is not None:
         dev = "cuda" if a.backend == "nccl" else "cpu"
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -565,8 +613,43 @@ def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank
     g.set_nodes(cfg["cap"], cfg["alive"])
     g.set_objects(n, cfg["load"], cfg["aff"])
     sol, kind, tried = make_sharded_solver(a, dist, g, local_rank, rank, n_total, load_total)
-    dt, gpu_ms, st, n_slow = timed_steps(a, g, dist, torch, sol.solve_async, sol.solve_wait)
+    none_col = np.full(n, 0xFFFFFFFF, np.uint32)
+    # ---- (1) the headline: a stream of COMMITTED ticks of the sharded table, from the cold table (tick 1: every object claims
+    #      its requester), W warm-ups then K timed ticks — the quantity the N = 1 line reports for the same table.  Over the
+    #      peer-to-peer windows a tick is rio_gp_shard_tick_async (nothing waits on the host; at most 48 in flight before
+    #      their records are fetched); over the collective rungs it is ShardedSolver.tick (the host sequences the exchanges).
+    asynchronous = kind == "p2p"
+    inflight, fetched = [0], []
+
+    def tick_step():
+        if asynchronous:
+            if inflight[0] == 48:
+                fetched.append(sol.tick_wait_local()); inflight[0] = 0
+            sol.tick_async(); inflight[0] += 1
+        else:
+            fetched.append(sol.tick())
+
+    def tick_fetch():
+        if asynchronous and inflight[0]:
+            fetched.append(sol.tick_wait_local()); inflight[0] = 0
+
+    def tick_stats():
+        sts = []
+        for x in fetched:
+            sts.extend(sol.tick_reduce(x) if asynchronous else [x])
+        del fetched[:]
+        return sts, sum(t["slow_path"] for t in sts)
+
+    for _ in range(a.warmup):
+        tick_step()
+    tick_fetch()
+    tick_stats()
+    dt, gpu_ms, sts, n_slow = timed_steps(a, g, dist, torch, tick_step, tick_stats, wait_c=tick_fetch)
+    st = sts[-1]
     assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n_total
+    # ---- (2) round 2's quantity, kept under its own name: the cold table re-solved back to back WITHOUT committing
+    g.set_assign(none_col)
+    cdt, cgpu_ms, cst, cslow = timed_steps(a, g, dist, torch, sol.solve_async, sol.solve_wait)
     parity = None
     if not a.no_parity:
         parity = parity_sharded(dist, a.backend, g, sol, workload, n_total, m, bounds, rank, world, cfg["cap"])
@@ -580,9 +663,34 @@ def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank
                                   ticks=max(2, min(a.steps, 10)), phase=phase)
         except Exception as e:  # a second measurement: it must not take the line down with it
             ticks = {"error": repr(e)[:300], "during": phase[-1] if phase else None}
+    # who ran where, and what RCCL was asked for (control plane: torch.distributed's group when its backend is nccl = RCCL;
+    # data path: the library's own communicator of the `native` rung — none over the peer-to-peer windows)
+    import sharded as _sh
+    info = {"rank": rank, "device": int(local_rank), "exchange": kind,
+            "native_rung_comm_ranks": int(_sh._lib().rio_gp_shard_comm_ranks(g.handle))}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        info["device_name"] = pr.name
+        info["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    except Exception:
+        pass
+    infos = [None] * world
+    dist.all_gather_object(infos, info)
     rec = {"value": n_total * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "gpu_ms_per_step_events": gpu_ms / a.steps,
            "rows_total": n_total, "rows_this_rank": n, "nodes": m, "exchange": kind, "exchange_ladder": tried,
            "slow_path_steps": n_slow, "stats_last_step": st, "parity": parity, "committed_ticks": ticks,
+           "asynchronous": asynchronous, "ranks": infos,
+           "rccl": {"control_plane_backend": a.backend,
+                    "control_plane_communicators": 1 if a.backend == "nccl" else 0,
+                    "data_path_communicators": 1 if kind == "native" else 0,
+                    "data_path_comm_ranks": [x["native_rung_comm_ranks"] for x in infos],
+                    "note": "p2p rung: no collective on the data path (stores into the peers' IPC-mapped windows); native rung: ONE "
+                            "ncclComm of the library's own, world ranks; torch rung: the control plane's group carries the records"},
+           "cold_resolve_uncommitted": {"value": n_total * a.steps / cdt, "unit": "decisions/s", "ms_per_step": cdt / a.steps * 1e3,
+                                        "gpu_ms_per_step_events": cgpu_ms / a.steps, "slow_path_steps": cslow,
+                                        "stats_last_step": cst,
+                                        "note": "rio_gp_shard_solve_async of the SAME cold table back to back, never committed "
+                                                "(what rounds 2-3 reported as `value` at N > 1)"},
            "whole_step_achieved_GBps": ALGO_BYTES_PER_DECISION * n / (gpu_ms / a.steps * 1e-3) / 1e9}
     g.close()
     return rec
@@ -659,7 +767,7 @@ def main():
                                        % (workload, prim["rows_this_rank"], m, prim["rows_total"])),
                        "objects_per_gpu": prim["rows_this_rank"], "objects_total": prim["rows_total"], "nodes": m,
                        "parallelism": "rows sharded x%d" % world,
-                       "step": {"p2p": "row-sharded solve: k_scan -> k_resolve_xchg (every workgroup stores its eight nodes' local sums "
+                       "fast_path_of_a_tick": {"p2p": "row-sharded solve: k_scan -> k_resolve_xchg (every workgroup stores its eight nodes' local sums "
                                        "straight into every peer's HBM window over xGMI as data-tagged 8-byte words, polls the same "
                                        "words of every rank and resolves its nodes); one stream, two launches, no collective call, "
                                        "no flag; verdicts read at the end",
@@ -667,9 +775,12 @@ def main():
                                           "library on a second stream -> k_shard_import; verdicts read at the end" % (8 * (2 * m + 8)),
                                 "torch": "row-sharded solve: k_scan + k_resolve + pack -> torch.distributed all_gather (RCCL) of %d "
                                          "B/rank -> k_shard_import; verdicts read at the end" % (8 * (2 * m + 8))}[prim["exchange"]],
-                       "value_is": "back-to-back re-solves of the cold sharded table, NOT committed (rio_gp_shard_solve_async; what "
-                                   "round 2 measured); committed ticks of the same table — churn-free and with config 5's churn, "
-                                   "synchronous and asynchronous — are under committed_ticks",
+                       "value_is": DEF_STRONG if strong else DEF_WEAK,
+                       "tick": "rio_gp_shard_tick_async: scan, one-launch exchange over the peer-to-peer windows, the guarded fix-up "
+                               "chain, commit; nothing waits on the host, at most 48 ticks in flight" if prim["asynchronous"] else
+                               "ShardedSolver.tick: solve_async + solve_wait (verdict, exchanges, global counters) + commit; the host "
+                               "sequences the exchanges of the '%s' rung" % prim["exchange"],
+                       "ranks": prim["ranks"], "rccl": prim["rccl"],
                        "exchange": prim["exchange"], "exchange_ladder": prim["exchange_ladder"],
                        "peer_access": peer_matrix(torch, world, a.same_device), "slow_path_steps": prim["slow_path_steps"]},
             "gpu_ms_per_step_events": prim["gpu_ms_per_step_events"],
@@ -680,13 +791,20 @@ def main():
                          "kernel": "whole sharded step on rank 0 (k_scan + exchange/resolve), HIP events on the library's stream",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DECISION * prim["rows_this_rank"]},
             "stats_last_step": prim["stats_last_step"],
+            "cold_resolve_uncommitted": prim["cold_resolve_uncommitted"],
             "committed_ticks": prim["committed_ticks"],
         }
+        pt = lambda r_: {"value": r_["value"], "unit": "decisions/s", "ms_per_tick": r_["ms_per_step"], "n_gpus": world,
+                         "rows_total": r_["rows_total"], "exchange": r_["exchange"]}
+        out["scaling_points"] = {"strong_config4_committed_tick": dict(pt(prim), definition=DEF_STRONG) if strong else None,
+                                 "weak_config3_committed_tick": dict(pt(weak), definition=DEF_WEAK) if weak is not None else
+                                 (dict(pt(prim), definition=DEF_WEAK) if workload == "c3" else None)}
         if weak is not None:
             out["weak_config3"] = {"metric": "placement decisions/sec, 10M objects x 1 024 nodes per GPU (weak scaling)",
                                    "value": weak["value"], "unit": "decisions/s", "scaling": "weak", "ms_per_step": weak["ms_per_step"],
                                    "objects_per_gpu": weak["rows_this_rank"], "objects_total": weak["rows_total"], "nodes": weak["nodes"],
                                    "exchange": weak["exchange"], "slow_path_steps": weak["slow_path_steps"], "parity": weak["parity"],
+                                   "value_is": DEF_WEAK, "cold_resolve_uncommitted": weak["cold_resolve_uncommitted"],
                                    "committed_ticks": weak["committed_ticks"]}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -718,7 +836,10 @@ def main():
         g.tick_async()
     if a.warmup:
         g.tick_wait()
-    dt, gpu_ms, sts, _ = timed_steps(a, g, None, torch, g.tick_async, lambda: (g.tick_wait(), 0))
+    tick_arr = (rio_gp.Stats * max(a.steps, 1))()
+    tick_got = []
+    dt, gpu_ms, sts, _ = timed_steps(a, g, None, torch, g.tick_async, lambda: (g.stats_list(tick_arr, tick_got[0]), 0),
+                                     wait_c=lambda: tick_got.append(g.tick_wait_into(tick_arr)))
     st = sts[-1]
     n_slow = sum(x["slow_path"] for x in sts)
     assert st["kept"] + st["claimed"] + st["spilled"] + st["unplaced"] == n
@@ -821,9 +942,11 @@ def main():
             cold = {"error": str(e)}
     parity = None
     t_orc = None
+    cold_column = None
     if not a.no_parity:
         g.set_assign(cfg["cur"])
         parity, t_orc = parity_single(g, cfg)   # leaves the table committed (warm)
+        cold_column = parity.pop("_solved_column")
     c4one = None
     if not a.no_c4 and workload == "c3" and not a.objects:
         # BASELINE config 4 on ONE GPU (the N=1 point of the strong-scaling curve): 100 M x 4 096, parity at size
@@ -843,6 +966,8 @@ def main():
             t4 = (time.perf_counter() - t0) / 20
             sc4 = [g4.solve_profiled()[0] for _ in range(10)] if slow4 == 0 else []
             par4 = None if a.no_parity else parity_single(g4, c4)[0]
+            if par4 is not None:
+                par4.pop("_solved_column", None)
             for _ in range(2):
                 g4.tick_async()
             g4.tick_wait()
@@ -872,6 +997,8 @@ def main():
             g2.set_nodes(c2["cap"], c2["alive"])
             g2.set_objects(c2["n"], c2["load"], c2["aff"])
             par2 = None if a.no_parity else parity_single(g2, c2)[0]
+            if par2 is not None:
+                par2.pop("_solved_column", None)
             g2.set_assign(c2["cur"])
             for _ in range(10):
                 g2.solve_async()
@@ -953,6 +1080,7 @@ def main():
                      "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                      "traffic_source": traffic_source, "traffic_detail": traffic_detail,
                      "kernel": "k_scan", "kernel_ms": scan_avg,
+                     "gpu_ms_per_step_events": gpu_ms / a.steps,   # the committed-tick stream between two HIP events on the library's stream
                      "kernel_ms_p10_p90": [float(np.percentile(scan_ms, 10)), float(np.percentile(scan_ms, 90))] if scan_ms else None,
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DECISION * n,
                      "resolve_kernel_ms": float(np.mean(res_ms)) if res_ms else None,
@@ -965,14 +1093,23 @@ def main():
                      "frac_dependent_tick": fr(dep * 1e-3) if dep else None,
                      "frac_of_measured_copy_peak_6290": (achieved / 6290.0) if achieved else None,
                      "stream_probe": probe, "beyond_infinity_cache": cold},
+        "scaling_points": {
+            "strong_config4_committed_tick": (dict(c4one["committed_tick"], n_gpus=1, rows_total=C4_ROWS, exchange=None,
+                                                   definition=DEF_STRONG) if isinstance(c4one, dict) and "committed_tick" in c4one else None),
+            "weak_config3_committed_tick": ({"value": total_decisions / dt, "unit": "decisions/s", "ms_per_tick": tick_s * 1e3, "n_gpus": 1,
+                                             "rows_total": n, "exchange": None, "definition": DEF_WEAK} if workload == "c3" and not a.objects else None)},
         "config2": c2rec,
         "config4_single_gpu": c4one,
         "config5_churn": c5rec,
         "stats_last_step": st,          # last committed tick of the stream: every row kept where the first tick put it
         "stats_cold_step": cst,         # the cold table re-solved: every row pending
     }
+    port_parity = None
     if not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample, t_orc)
+        port_parity, out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample, t_orc, cold_column if workload in ("c3", "c2") else None)
+        if parity is not None and port_parity is not None:
+            parity["against_reference_port"] = port_parity
+            parity["equal"] = parity["equal"] and port_parity["equal"]
     g.close()
     sys.stdout.flush()
     try:

@@ -335,6 +335,9 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
 
 /* ---- measurement hooks (HIP events on the handle's own stream) -------------------------- */
 int rio_gp_timer_begin(rio_gp_t* h);
+/* rio_gp_timer_stop records the closing event behind the work enqueued so far and returns at once; rio_gp_timer_end waits
+ * for the closing event (recording it first when nobody has) and reports the milliseconds between the two. */
+int rio_gp_timer_stop(rio_gp_t* h);
 int rio_gp_timer_end(rio_gp_t* h, float* ms);
 /* One fast-path solve with a HIP-event pair around EACH kernel launch (so the durations are
  * per-launch, not host-paired): scan_ms = the streaming kernel k_scan (16 algorithmic B/row),

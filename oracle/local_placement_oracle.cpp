@@ -269,6 +269,47 @@ double lpo_bench_policy(uint64_t n_objects, uint32_t m_nodes, const uint32_t* af
     return s;
 }
 
+/*
+ * The same per-object path with its RESULT kept (bench.py's parity.against_reference_port, tests/): one shared
+ * LocalObjectPlacement, optionally pre-populated from cur[] (a warm table: update("Obj", i -> address of cur[i]) for
+ * every cur[i] != NONE, local.rs:22-40), one LocalStorage of m members whose `active` flags come from alive[] (nullptr:
+ * all active); then ONE get_or_create_placement per object, in index order, requester = node aff[i] (service.rs:193-254:
+ * an object found on an inactive server has that server cleaned — every entry of it, local.rs:51-58 — and is first-touched
+ * on the requester); then every object is looked up again (local.rs:42-49) and its address turned back into the node's
+ * index: out[i] = node, or 0xFFFFFFFF for a miss.  Returns the seconds the get_or_create_placement calls took
+ * (single thread).
+ */
+double lpo_policy_readback(uint64_t n_objects, uint32_t m_nodes, const uint32_t* aff, const uint8_t* alive,
+                           const uint32_t* cur, uint32_t* out) {
+    LocalObjectPlacement provider;
+    LocalStorage storage;
+    std::vector<std::string> addr(m_nodes);
+    std::unordered_map<std::string, uint32_t> index_of;
+    for (uint32_t j = 0; j < m_nodes; ++j) {
+        addr[j] = node_address(j);
+        index_of[addr[j]] = j;
+        size_t c = addr[j].find(':');
+        storage.members.push_back(Member{addr[j].substr(0, c), addr[j].substr(c + 1), alive ? alive[j] != 0 : true});
+    }
+    if (cur)
+        for (uint64_t i = 0; i < n_objects; ++i)
+            if (cur[i] < m_nodes) provider.update("Obj", std::to_string(i).c_str(), addr[cur[i]].c_str());
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t i = 0; i < n_objects; ++i) {
+        std::string id = std::to_string(i);
+        std::string r = get_or_create_placement(provider, storage, addr[aff[i] % m_nodes], "Obj", id.c_str());
+        if (r.empty()) std::abort();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    for (uint64_t i = 0; i < n_objects; ++i) {
+        std::string a;
+        if (!provider.lookup("Obj", std::to_string(i).c_str(), &a)) { out[i] = 0xFFFFFFFFu; continue; }
+        auto it = index_of.find(a);
+        out[i] = it == index_of.end() ? 0xFFFFFFFEu : it->second;
+    }
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
 /* clean_server on a populated map: n_objects entries spread over m_nodes addresses; times
  * retain() for one address (local.rs:51-58).  Returns seconds. */
 double lpo_bench_clean_server(uint64_t n_objects, uint32_t m_nodes, const uint32_t* node_of, uint32_t victim) {

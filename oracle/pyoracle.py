@@ -80,6 +80,8 @@ def lib():
         L.lpo_check_address_mismatch.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
         L.lpo_bench_policy.argtypes = [C.c_uint64, C.c_uint32, u32p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.lpo_bench_policy.restype = C.c_double
+        L.lpo_policy_readback.argtypes = [C.c_uint64, C.c_uint32, u32p, C.c_void_p, C.c_void_p, u32p]
+        L.lpo_policy_readback.restype = C.c_double
         L.lpo_bench_clean_server.argtypes = [C.c_uint64, C.c_uint32, u32p, C.c_uint32]
         L.lpo_bench_clean_server.restype = C.c_double
         L.lpo_hardware_concurrency.restype = C.c_uint
@@ -243,6 +245,19 @@ def bench_policy(n_objects, m_nodes, aff, threads=1, warm=False):
     dec = C.c_uint64(0)
     s = lib().lpo_bench_policy(n_objects, m_nodes, _u32(aff), threads, int(warm), C.byref(dec))
     return float(s), int(dec.value)
+
+
+def policy_readback(n_objects, m_nodes, aff, alive=None, cur=None):
+    """One get_or_create_placement per object on the string restatement of LocalObjectPlacement + Service (optionally over
+    a warm map and with inactive members), then every object looked up again: (seconds of the calls, node index per object
+    — 0xFFFFFFFF for a miss)."""
+    aff = _u32(aff)
+    out = np.empty(n_objects, np.uint32)
+    al = None if alive is None else _u8(alive)
+    cu = None if cur is None else _u32(cur)
+    s = lib().lpo_policy_readback(n_objects, m_nodes, aff, None if al is None else al.ctypes.data_as(C.c_void_p),
+                                  None if cu is None else cu.ctypes.data_as(C.c_void_p), out)
+    return float(s), out
 
 
 def hardware_concurrency():

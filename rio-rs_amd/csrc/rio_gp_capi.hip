@@ -214,6 +214,7 @@ struct rio_gp {
     DevBuf vt[4], stage[4];
     DevBuf vrec;  // big place_pending batches: virtual-table records {cur | load}, 8 bytes per request
     DevBuf part;  // scratch of the partitioned update / remove batches (records + fragment tables)
+    bool timer_stopped = false;  // rio_gp_timer_stop has recorded the closing event of the measurement in progress
     u32 sh_tick_n = 0;    // asynchronous row-sharded ticks in flight (their records: verdict slots of the tick ring, h_fx slots)
     u64 sh_tick_mark[kRing] = {};
     std::vector<void*> allocs;
@@ -2299,13 +2300,23 @@ int rio_gp_timer_begin(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    h->timer_stopped = false;
+    return RIO_GP_OK;
+}
+
+int rio_gp_timer_stop(rio_gp_t* h) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->timer_stopped = true;
     return RIO_GP_OK;
 }
 
 int rio_gp_timer_end(rio_gp_t* h, float* ms) {
     if (!h || !ms) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    if (!h->timer_stopped) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->timer_stopped = false;
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
     return RIO_GP_OK;

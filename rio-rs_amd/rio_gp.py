@@ -154,6 +154,7 @@ def _load(lab):
             L.rio_gp_debug_wave_row_lo.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
             L.rio_gp_debug_wave_row_lo.restype = C.c_uint64
         L.rio_gp_timer_begin.argtypes = [_vp]
+        L.rio_gp_timer_stop.argtypes = [_vp]
         L.rio_gp_timer_end.argtypes = [_vp, C.POINTER(C.c_float)]
         _libs[lab] = L
     return _libs[lab]
@@ -341,6 +342,19 @@ class GpuPlacement:
         self._chk(self._L.rio_gp_tick_wait(self._h, arr, cap, C.byref(n)))
         return [arr[k].as_dict() for k in range(min(cap, int(n.value)))]
 
+    def tick_wait_into(self, arr):
+        """rio_gp_tick_wait into a caller-held (Stats * cap) array: the C call alone (timing loops; no dictionary is built).
+        Returns the number of ticks completed since the last wait; stats_list(arr, n) turns them into dictionaries."""
+        n = C.c_uint32(0)
+        rc = self._L.rio_gp_tick_wait(self._h, arr, len(arr), C.byref(n))
+        if rc:
+            self._chk(rc)
+        return int(n.value)
+
+    @staticmethod
+    def stats_list(arr, n):
+        return [arr[k].as_dict() for k in range(min(len(arr), n))]
+
     def solve_async(self):
         self._chk(self._L.rio_gp_solve_async(self._h))
 
@@ -391,6 +405,10 @@ class GpuPlacement:
 
     def timer_begin(self):
         self._chk(self._L.rio_gp_timer_begin(self._h))
+
+    def timer_stop(self):
+        """record the closing event behind the work enqueued so far; nobody waits (timer_end does, later)"""
+        self._chk(self._L.rio_gp_timer_stop(self._h))
 
     def timer_end(self):
         ms = C.c_float(0)

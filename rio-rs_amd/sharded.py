@@ -390,10 +390,17 @@ class ShardedSolver:
         for e in self.engines:
             e.tick_async()
 
+    def tick_wait_local(self):
+        """Wait for the ticks enqueued since the last wait on THIS process's engines and fetch their local records (the C
+        call alone: no exchange between the ranks) — what a timing loop ends on; tick_reduce turns them into global counters."""
+        return [e.tick_wait() for e in self.engines]
+
     def tick_wait(self):
         """Global counters of every tick enqueued since the last wait (oldest first): each rank's records, summed over the
         ranks with ONE all-gather for all the ticks."""
-        local = [e.tick_wait() for e in self.engines]
+        return self.tick_reduce(self.tick_wait_local())
+
+    def tick_reduce(self, local):
         n = len(local[0])
         if n == 0:
             return []

@@ -37,6 +37,10 @@ def test_bench_line_n1():
     # the run checks itself against the oracle (and would have exited with rc 3 on a mismatch)
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 1000000
     assert d["dependent_tick_ms"] > 0 and "traffic_source" in d["roofline"]
+    # ... and against the string-level restatement of the reference: the map the cpu_baseline leg built, read back
+    port = d["parity"]["against_reference_port"]
+    assert port["equal"] is True and port["rows"] == 20000
+    assert d["roofline"]["gpu_ms_per_step_events"] > 0
 
 
 def test_bench_headline_line_has_parity_traffic_and_config4():
@@ -48,6 +52,13 @@ def test_bench_headline_line_has_parity_traffic_and_config4():
     d = _one_json_line(r.stdout)
     assert d["config"]["objects_per_gpu"] == 10_000_000 and d["config"]["nodes"] == 1024
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 10_000_000
+    # the reference restatement's own map (200 000 get_or_create_placement calls here, 10 M in the driver's run), read back
+    assert d["parity"]["against_reference_port"]["equal"] is True and d["parity"]["against_reference_port"]["rows"] == 200_000
+    # one comparable quantity for every N: the points of the strong (config 4) and weak (config 3) curves under the same keys
+    sp = d["scaling_points"]
+    assert sp["strong_config4_committed_tick"]["n_gpus"] == 1 and sp["strong_config4_committed_tick"]["rows_total"] == 100_000_000
+    assert sp["strong_config4_committed_tick"]["value"] == d["config4_single_gpu"]["committed_tick"]["value"]
+    assert sp["weak_config3_committed_tick"]["value"] == d["value"] and "committed ticks" in sp["weak_config3_committed_tick"]["definition"]
     # the kernel the roofline is quoted on, and the honest denominators next to it: the DRAM-bound form of the same step,
     # the committed tick (what `value` is), the dependent tick
     rf = d["roofline"]
@@ -84,6 +95,50 @@ def test_bench_two_ranks_as_the_driver_launches_it(exchange):
     assert d["config"]["exchange"] in ("p2p", "torch")
 
 
+def _check_scaling_fields(d, world, exchange):
+    """What every N > 1 line says about itself, in the same words at every N: `value` = committed ticks of the ONE config-4
+    table (the definition string is the N = 1 line's), who ran where, and what RCCL was asked for."""
+    import bench
+    assert d["config"]["value_is"] == bench.DEF_STRONG and d["weak_config3"]["value_is"] == bench.DEF_WEAK
+    sp = d["scaling_points"]
+    assert sp["strong_config4_committed_tick"]["value"] == d["value"] and sp["strong_config4_committed_tick"]["n_gpus"] == world
+    assert sp["strong_config4_committed_tick"]["definition"] == bench.DEF_STRONG
+    assert sp["weak_config3_committed_tick"]["value"] == d["weak_config3"]["value"]
+    assert sp["weak_config3_committed_tick"]["definition"] == bench.DEF_WEAK
+    last = d["stats_last_step"]      # a committed stream: by the timed ticks every row is kept where tick 1 put it
+    assert last["kept"] == last["n_objects"] == d["config"]["objects_total"] and last["slow_path"] == 0
+    cold = d["cold_resolve_uncommitted"]   # ... and rounds 2-3's quantity next to it, under its own name
+    assert cold["stats_last_step"]["claimed"] == d["config"]["objects_total"] and cold["value"] > 0
+    ranks = d["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(world)) and all(r["exchange"] == exchange for r in ranks)
+    assert all(r["device"] == 0 for r in ranks)          # --same-device
+    rc = d["config"]["rccl"]
+    assert rc["control_plane_backend"] == "gloo" and rc["control_plane_communicators"] == 0
+    assert rc["data_path_communicators"] == (1 if exchange == "native" else 0)
+    assert rc["data_path_comm_ranks"] == [world if exchange == "native" else 0] * world
+    assert "peer_access" in d["config"] and ("tick_async" in d["config"]["tick"]) == (exchange == "p2p")
+
+
+def test_bench_ladder_one_rank_fails_p2p_every_rank_lands_on_the_same_rung():
+    """The exchange ladder p2p -> native -> torch is agreed by ALL ranks: here the p2p rung is made to fail on rank 1 only,
+    after the windows are mapped (its peers are already polling for its words: they time out inside their kernels), and every
+    rank must drop it together and land on the same next rung that works — on this box, where both processes share the one
+    GPU, RCCL refuses the native rung on every rank too, so that is `torch` (over gloo); with a GPU per rank it is `native`."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--total-objects", "600000", "--no-weak", "--no-sharded-churn", "--no-cpu-baseline", "--backend", "gloo", "--same-device"]
+    env = dict(os.environ, RIO_GP_BENCH_FAIL_RUNG="p2p", RIO_GP_BENCH_FAIL_RANK="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    ladder = d["config"]["exchange_ladder"]
+    assert ladder[0]["path"] == "p2p" and ladder[0]["ok"] is False
+    assert d["config"]["exchange"] in ("native", "torch") and ladder[-1]["ok"] is True and ladder[-1]["path"] == d["config"]["exchange"]
+    assert all(x["exchange"] == d["config"]["exchange"] for x in d["config"]["ranks"])
+    assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 600_000
+
+
 @pytest.mark.parametrize("exchange", ["p2p", "torch"])
 def test_bench_config4_strong_scaling_two_ranks(exchange):
     """north_star's config 4 is what `bench.py --gpus N` measures for N > 1: ONE table split over the ranks (strong
@@ -104,6 +159,7 @@ def test_bench_config4_strong_scaling_two_ranks(exchange):
     assert d["config"]["workload"].startswith("config 4:")
     assert d["config"]["exchange"] == exchange and d["config"]["exchange_ladder"][0]["ok"] is True
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 2_000_000
+    _check_scaling_fields(d, 2, exchange)
     w = d["weak_config3"]
     assert w["scaling"] == "weak" and w["objects_per_gpu"] == 300000 and w["nodes"] == 1024 and w["parity"]["equal"] is True
     # the sharded table under committed ticks: churn-free (every row kept, fast path) and config 5's churn (10 % of the
@@ -135,6 +191,7 @@ def test_bench_config4_eight_ranks_p2p_on_one_gpu():
     assert d["config"]["exchange"] == "p2p" and d["config"]["exchange_ladder"][0]["ok"] is True, d["config"]
     assert d["parity"]["equal"] is True and d["parity"]["checked_rows"] == 4_000_000
     assert d["weak_config3"]["parity"]["equal"] is True
+    _check_scaling_fields(d, 8, "p2p")
     # the committed / churn tick streams, synchronous and asynchronous, between eight processes: every tick of a quiet
     # asynchronous stream lands in the next window slot (a rank that is through a tick must not overwrite what a slower one
     # has not read — found exactly here, with a tick that took four sequence numbers and four slots)
@@ -155,7 +212,8 @@ def test_bench_eight_ranks_on_one_gpu():
     d = _one_json_line(r.stdout)
     assert d["n_gpus"] == 8 and d["config"]["exchange"] == "p2p", d["config"]
     st = d["stats_last_step"]
-    assert st["n_objects"] == 8_000_000 and st["claimed"] == 8_000_000 and d["config"]["slow_path_steps"] == 0
+    assert st["n_objects"] == 8_000_000 and st["kept"] == 8_000_000 and d["config"]["slow_path_steps"] == 0   # committed ticks
+    assert d["cold_resolve_uncommitted"]["stats_last_step"]["claimed"] == 8_000_000
 
 
 def test_bench_config5_churn_line():

@@ -512,6 +512,44 @@ def test_tick_equals_reference_policy_capacity_infinite(gp, oracle):
         assert want == synth.node_address(int(got[i]))
 
 
+def test_reference_port_read_back_against_the_gpu_at_1m(gp, oracle):
+    """ONE hop to the reference's own semantics at a size that means something: 1 M objects x 256 nodes, a warm table with
+    unplaced objects, 15 % of the nodes dead.  The string-level restatement of LocalObjectPlacement +
+    Service::get_or_create_placement (local.rs:22-68, service.rs:193-254) serves one request per object — objects found on
+    dead servers have those servers cleaned and are first-touched on the requester — and is read back object by object;
+    the GPU's committed tick over the same table (capacity unbounded, load 1: the solver IS the reference policy) must
+    leave the same column.  (bench.py does this at 10 M rows on the cold table: parity.against_reference_port.)"""
+    rng = np.random.default_rng(4242)
+    n, m = 1_000_000, 256
+    alive = (rng.random(m) < 0.85).astype(np.uint8)
+    live = np.flatnonzero(alive)
+    aff = live[rng.integers(0, len(live), n)].astype(np.uint32)
+    cur = rng.integers(0, m, n).astype(np.uint32)
+    cur[rng.random(n) < 0.2] = NONE
+    load = np.ones(n, np.uint32)
+    cap = np.full(m, INF, np.uint64)
+    _, port = oracle.policy_readback(n, m, aff, alive, cur)
+    g = _mk(gp, n, m, load, aff, cap, alive, cur)
+    st = g.tick()
+    got = g.get_assign()
+    assert np.array_equal(got, port), np.flatnonzero(got != port)[:10]
+    assert st["spilled"] == 0 and st["unplaced"] == 0 and st["evicted"] > 100_000 and st["kept"] > 500_000
+    # a second tick over the committed table (the in-place scan's turf): liveness changes again, the port serves every
+    # object again on its own map
+    alive2 = alive.copy()
+    alive2[live[:20]] = 0
+    live2 = np.flatnonzero(alive2)
+    aff2 = aff.copy()
+    gone = alive2[aff] == 0
+    aff2[gone] = live2[rng.integers(0, len(live2), int(gone.sum()))]
+    g.set_object_attrs(np.flatnonzero(gone).astype(np.uint32), None, aff2[gone])
+    g.set_alive_all(alive2)
+    g.tick()
+    _, port2 = oracle.policy_readback(n, m, aff2, alive2, port)
+    assert np.array_equal(g.get_assign(), port2)
+    g.close()
+
+
 def test_solve_is_deterministic_and_idempotent(gp, oracle):
     rng = np.random.default_rng(21)
     cur, load, aff, cap, alive = _rand_case(rng, 600_000, 512, cap_scale=1.1, max_load=1000)
