@@ -128,10 +128,11 @@ __device__ __forceinline__ bool bit_of(const u32* bits, u32 j) { return (bits[j 
 // Phase traces (lab build only; compiled out of the product): workgroup b stores wall_clock64() (100 MHz) at phase
 // boundary `slot` of kernel table `tab` into g_kt[tab][b][slot] when the plan's trace flag is set.
 #ifdef RIO_GP_LAB
-constexpr int kKtTables = 6;
+constexpr int kKtTables = 7;
 __device__ u64 g_kt[kKtTables][kMaxBlocks * 8];
 static int g_trace_host = 0;
 #define RIOGP_KT(pl, tab, slot) do { if (threadIdx.x == 0 && (pl).trace && blockIdx.x < kMaxBlocks) g_kt[tab][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#define RIOGP_KTF(flag, tab, slot) do { if (threadIdx.x == 0 && (flag) && blockIdx.x < kMaxBlocks) g_kt[tab][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
 int ktrace_enable(int on) { g_trace_host = on; return 0; }
 int ktrace_read(int table, u64* out) {
     if (table < 0 || table >= kKtTables) return -1;
@@ -140,6 +141,7 @@ int ktrace_read(int table, u64* out) {
 static inline u32 trace_flag() { return (u32)g_trace_host; }
 #else
 #define RIOGP_KT(pl, tab, slot) do { } while (0)
+#define RIOGP_KTF(flag, tab, slot) do { } while (0)
 static inline u32 trace_flag() { return 0; }
 #endif
 
@@ -3338,7 +3340,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
                                                     const u32* __restrict__ req, u32 n, u32* __restrict__ out_node,
                                                     u32* __restrict__ out_flag, u32* __restrict__ status,
                                                     u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl, uint4 ia,
-                                                    uint4 ib, u32 n_obj_chk) {
+                                                    uint4 ib, u32 n_obj_chk, u32 trace) {
     // n_obj_chk != 0 (requests the host has not seen: rio_gp_place_pending_dev): the number of rows — an object index or a
     // requester out of range ends the call with status 3 and nothing changed; the arrays are then exactly n entries long
     // (no whole vector past the end)
@@ -3349,6 +3351,8 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
     u32* hpos = hkey + kSlots;                               // [kSlots] first batch position of the row, then its final node
     __shared__ u32 s_general, s_bad;
     const u32 tid = threadIdx.x;
+    (void)trace;
+    RIOGP_KTF(trace, 6, 0);
     if (tid == 0) { s_general = m > kPpTot ? 1u : 0u; s_bad = 0; }
     for (u32 q = tid; q < kSlots; q += THREADS) { hkey[q] = kNone; hpos[q] = kNone; }
     for (u32 q = tid; q < kPpTot; q += THREADS) s_tot[q] = 0;
@@ -3383,6 +3387,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
         }
     }
     __syncthreads();
+    RIOGP_KTF(trace, 6, 1);
     if (bad) s_bad = 1;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -3397,6 +3402,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
         }
     }
     __syncthreads();
+    RIOGP_KTF(trace, 6, 2);
     bool first[PER], claim[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -3415,6 +3421,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
     for (int q = 0; q < PER; ++q)
         if (claim[q] && r[q] < kPpTot && s_tot[r[q]] > fre[q]) s_general = 1;  // the requester cannot take all its first touches
     __syncthreads();
+    RIOGP_KTF(trace, 6, 3);
     if (s_general | s_bad) {  // hand over untouched (3: an entry out of range — the call fails)
         if (tid == 0) *status = s_bad ? 3u : 1u;
         signal_done(done, seq);
@@ -3424,6 +3431,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
     for (int q = 0; q < PER; ++q)  // the row's final node, for the later requests of the same object in this batch
         if (valid[q] && first[q]) hpos[slot[q]] = claim[q] ? r[q] : c[q];
     __syncthreads();
+    RIOGP_KTF(trace, 6, 4);
     u32 ond[PER], ofl[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -3451,7 +3459,9 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
             if (valid[q]) { out_node[tid * PER + q] = ond[q]; out_flag[tid * PER + q] = ofl[q]; }
     }
     if (tid == 0) *status = 0;
+    RIOGP_KTF(trace, 6, 5);
     signal_done(done, seq);
+    RIOGP_KTF(trace, 6, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4285,11 +4295,11 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
     if (n <= (u32)kSmallBatch) {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kSmallBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kSmallBatch, 1>), dim3(1), dim3(kSmallBatch), lds, s, assign, load, m, cap, alive_bits, used,
-                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl), n_obj_chk);
+                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl), n_obj_chk, trace_flag());
     } else {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kOneBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kBlock, kOneBatch / kBlock>), dim3(1), dim3(kBlock), lds, s, assign, load, m, cap, alive_bits,
-                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk);
+                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk, trace_flag());
     }
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,

@@ -108,7 +108,8 @@ def _check_scaling_fields(d, world, exchange):
     last = d["stats_last_step"]      # a committed stream: by the timed ticks every row is kept where tick 1 put it
     assert last["kept"] == last["n_objects"] == d["config"]["objects_total"] and last["slow_path"] == 0
     cold = d["cold_resolve_uncommitted"]   # ... and rounds 2-3's quantity next to it, under its own name
-    assert cold["stats_last_step"]["claimed"] == d["config"]["objects_total"] and cold["value"] > 0
+    cs = cold["stats_last_step"]           # (the cold table: every row pending)
+    assert cs["kept"] == 0 and cs["claimed"] + cs["spilled"] + cs["unplaced"] == d["config"]["objects_total"] and cold["value"] > 0
     ranks = d["config"]["ranks"]
     assert [r["rank"] for r in ranks] == list(range(world)) and all(r["exchange"] == exchange for r in ranks)
     assert all(r["device"] == 0 for r in ranks)          # --same-device

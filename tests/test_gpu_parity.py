@@ -1147,7 +1147,7 @@ def test_full_size_config3_properties(gp):
 
 def test_soak_churn_stream_against_the_oracle():
     """120 ticks of membership churn with load / affinity edits, removals and request micro-batches in between, every
-    tick and every batch compared with the oracle (tools/soak_churn.py; profiles/r03_soak.json holds 4 900 such ticks)."""
+    tick and every batch compared with the oracle (tools/soak_churn.py; profiles/archive/r03_soak.json holds 4 900 such ticks)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -299,7 +299,7 @@ def test_hip_shards_several_processes_one_gpu(gp, oracle, tmp_path, exchange, wo
 def test_soak_three_processes_peer_to_peer(gp):
     """40 committed ticks with membership churn and bursts of back-to-back asynchronous solves between three processes on
     the one GPU; every rank checks its rows and the global `used` vector against the whole-table oracle after every tick
-    (tools/soak_sharded.py; profiles/r03_soak_sharded.json holds longer runs)."""
+    (tools/soak_sharded.py; profiles/archive/r03_soak_sharded.json holds longer runs)."""
     import json
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_sharded.py"), "3", "40", "90000", "96", "11"],
