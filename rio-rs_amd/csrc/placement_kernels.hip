@@ -3465,6 +3465,147 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same call for batches between 1 024 and kOneBatch requests, in THREE launches.  What the one-workgroup kernel spends
+// on such a batch is not the decision: of the 38 us of a 4 096-request first-touch batch 21 go into reading the requests
+// over PCIe and gathering every request's row and node operands from ONE compute unit (sixteen thousand random lane-requests
+// through one texture path), 10 into draining 8 192 scattered stores and atomics and the results' PCIe writes behind one
+// fence (its own phase stamps: tools/pp_one_trace.py).  Both ends are spread over the chip here, the decision stays where
+// it was — one workgroup, one LDS table, no cross-workgroup protocol (kernel boundaries order the three):
+//   k_pp_stage   256 threads x 1 request: request (mapped host or device memory) -> {row, requester, cur, load | free
+//                capacity of the requester, its liveness} in a device staging table; an entry out of range raises the flag
+//   k_pp_decide  ONE workgroup, 1 024 x 4: k_pp_one's decision over the staged records (coalesced reads) -> per request
+//                {node, flag | claim bit} back into the staging table, the requesters' claim totals into `used`, the status
+//   k_pp_apply   256 threads x 1 request, nothing to do unless the status is 0: results to the caller's arrays, first
+//                touches into the assignment column (and the lifecycle column); the last workgroup stores the completion word
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pp_stage(const u32* __restrict__ assign, const u32* __restrict__ load, u32 m,
+                                                  const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
+                                                  const u64* __restrict__ used, const u32* __restrict__ idx,
+                                                  const u32* __restrict__ req, u32 n, uint4* __restrict__ rec,
+                                                  uint4* __restrict__ rec2, u32* __restrict__ st, u32 n_obj_chk) {
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st[1] = 2u;  // status: "not decided" until k_pp_decide says otherwise
+    if (k >= n) return;
+    u32 i = idx[k], r = req[k];
+    bool bad = false;
+    if (n_obj_chk && (i >= n_obj_chk || r >= m)) { bad = true; i = 0; r = 0; }
+    const u32 c = assign[i], l = load[i];
+    const u64 cj = cap[r], uj = used[r];
+    const u64 fre = cj > uj ? cj - uj : 0;
+    rec[k] = make_uint4(i, r, c, l);
+    rec2[k] = make_uint4((u32)fre, (u32)(fre >> 32), bit_of(alive_bits, r) ? 1u : 0u, bad ? 1u : 0u);
+    if (bad) atomicOr(&st[0], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pp_decide(const uint4* __restrict__ rec, const uint4* __restrict__ rec2, u32 n,
+                                                      u32 m, const u32* __restrict__ alive_bits, u64* __restrict__ used,
+                                                      uint2* __restrict__ res, u32* __restrict__ st, u32* __restrict__ status) {
+    constexpr int PER = kOneBatch / kBlock;
+    constexpr u32 kSlots = 2u * kOneBatch;  // power of two
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_tot = reinterpret_cast<u64*>(smem);               // [kPpTot] claim load per requester
+    u32* hkey = reinterpret_cast<u32*>(s_tot + kPpTot);      // [kSlots] row of the slot
+    u32* hpos = hkey + kSlots;                               // [kSlots] first batch position of the row, then its final node
+    __shared__ u32 s_general;
+    const u32 tid = threadIdx.x;
+    const u32 bad_any = st[0];
+    if (tid == 0) s_general = m > kPpTot ? 1u : 0u;
+    for (u32 q = tid; q < kSlots; q += kBlock) { hkey[q] = kNone; hpos[q] = kNone; }
+    for (u32 q = tid; q < kPpTot; q += kBlock) s_tot[q] = 0;
+    u32 i[PER], r[PER], c[PER], l[PER], slot[PER];
+    u64 fre[PER];
+    bool valid[PER], r_alive[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 k = tid * PER + (u32)q;
+        valid[q] = k < n;
+        const uint4 a = rec[valid[q] ? k : 0u], b = rec2[valid[q] ? k : 0u];
+        i[q] = a.x; r[q] = a.y; c[q] = a.z; l[q] = a.w;
+        fre[q] = ((u64)b.y << 32) | b.x;
+        r_alive[q] = b.z != 0;
+    }
+    __syncthreads();
+    if (bad_any) {  // an entry out of range: the call fails, nothing is changed (block-uniform)
+        if (tid == 0) { st[0] = 0; st[1] = 3u; *status = 3u; }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        slot[q] = (i[q] * 2654435761u) >> 7 & (kSlots - 1);
+        if (valid[q]) {
+            for (;;) {
+                const u32 old = atomicCAS(&hkey[slot[q]], kNone, i[q]);
+                if (old == kNone || old == i[q]) break;
+                slot[q] = (slot[q] + 1) & (kSlots - 1);
+            }
+            atomicMin(&hpos[slot[q]], tid * PER + (u32)q);
+        }
+    }
+    __syncthreads();
+    bool first[PER], claim[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        first[q] = false; claim[q] = false;
+        if (valid[q]) {
+            first[q] = hpos[slot[q]] == tid * PER + (u32)q;
+            const bool dead_cur = c[q] < m && !bit_of(alive_bits, c[q]);   // service.rs:227-237 -> clean_server: general path
+            const bool pending = first[q] && c[q] == kNone;
+            claim[q] = pending && r_alive[q];
+            if (dead_cur || (pending && !claim[q])) s_general = 1;
+            if (claim[q] && r[q] < kPpTot) atomicAdd(&s_tot[r[q]], (u64)l[q]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (claim[q] && r[q] < kPpTot && s_tot[r[q]] > fre[q]) s_general = 1;  // the requester cannot take all its first touches
+    __syncthreads();
+    if (s_general) {  // hand over untouched
+        if (tid == 0) { st[1] = 1u; *status = 1u; }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)  // the row's final node, for the later requests of the same object in this batch
+        if (valid[q] && first[q]) hpos[slot[q]] = claim[q] ? r[q] : c[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (!valid[q]) continue;
+        u32 nd, fl;
+        if (claim[q]) { nd = r[q]; fl = 2u | 0x100u; }  // PLACED (+ "this request writes the table")
+        else {
+            nd = hpos[slot[q]];  // (its own current node, or what the first request decided)
+            fl = (nd == kNone) ? 4u : (nd == r[q] ? 0u : 1u);
+        }
+        res[tid * PER + (u32)q] = make_uint2(nd, fl);
+    }
+    // the requesters' new `used`: one plain read-modify-write per requester that was claimed (this workgroup is alone)
+    for (u32 j = tid; j < m && j < kPpTot; j += kBlock) {
+        const u64 t = s_tot[j];
+        if (t) used[j] += t;
+    }
+    if (tid == 0) { st[1] = 0u; *status = 0u; }
+}
+
+__global__ __launch_bounds__(256) void k_pp_apply(u32* __restrict__ assign, const uint4* __restrict__ rec,
+                                                  const uint2* __restrict__ res, u32 n, u32* __restrict__ out_node,
+                                                  u32* __restrict__ out_flag, const u32* __restrict__ st,
+                                                  u32* __restrict__ aff_life, unsigned int* ticket, u32* done, u32 seq) {
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    if (st[1] == 0u && k < n) {
+        const uint2 x = res[k];
+        out_node[k] = x.x;
+        out_flag[k] = x.y & 0xFFu;
+        if (x.y & 0x100u) {  // first touch (service.rs:244-252)
+            const uint4 a = rec[k];
+            assign[a.x] = a.y;
+            if (aff_life) aff_life[a.x] = a.y;  // row lifecycle: the object exists from its first touch, its home is the requester
+        }
+    }
+    if (done) signal_done_grid(ticket, done, seq);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row-sharded solve: rank r owns the contiguous rows [off_r, off_r + n_r); shard order
 // = index order, node tables are replicated.  The only cross-rank data are M-vectors:
 //   exchange #1  X_r = [kept_local[m] | claim_local[m] | 8 counters]          (every solve)
@@ -4291,7 +4432,20 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
 }
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk) {
+                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk, void* stage, unsigned int* ticket) {
+    if (stage && ticket && done && n > (u32)kPpStagedFrom && m <= kPpTot) {  // three launches: stage | decide | apply
+        uint4* rec = static_cast<uint4*>(stage);
+        uint4* rec2 = rec + kOneBatch;
+        uint2* res = reinterpret_cast<uint2*>(rec2 + kOneBatch);
+        u32* st = reinterpret_cast<u32*>(res + kOneBatch);  // [0] bad-entry flag (0 between calls) | [1] status
+        const unsigned g = (n + 255u) / 256u;
+        hipLaunchKernelGGL(k_pp_stage, dim3(g), dim3(256), 0, s, assign, load, m, cap, alive_bits, used, idx, req, n, rec, rec2, st,
+                           n_obj_chk);
+        const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kOneBatch) * sizeof(u32);
+        hipLaunchKernelGGL(k_pp_decide, dim3(1), dim3(kBlock), lds, s, rec, rec2, n, m, alive_bits, used, res, st, status);
+        hipLaunchKernelGGL(k_pp_apply, dim3(g), dim3(256), 0, s, assign, rec, res, n, out_node, out_flag, st, aff_life, ticket, done, seq);
+        return;
+    }
     if (n <= (u32)kSmallBatch) {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kSmallBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kSmallBatch, 1>), dim3(1), dim3(kSmallBatch), lds, s, assign, load, m, cap, alive_bits, used,

@@ -209,6 +209,7 @@ struct rio_gp {
     u32* h_mid = nullptr;   // medium batches (<= kMidBatch), mapped pinned memory, [4][kMidBatch] u32: lookup idx | out; place_pending idx | req | out | flag
     u32* d_mid = nullptr;
     unsigned int* mid_ticket = nullptr;  // device word of the several-workgroup completion protocol
+    void* pp_stage = nullptr;            // staging table of the three-launch request path (k_pp_stage / _decide / _apply)
     u32 small_seq = 0;      // sequence number of the last micro-batch call; its completion word is row 5, word 0
     // virtual table (place_pending) and staging for host-pointer calls
     DevBuf vt[4], stage[4];
@@ -821,6 +822,11 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     h->allocs.push_back(h->mid_ticket);
+    if (hipMalloc(&h->pp_stage, pp_stage_bytes()) != hipSuccess || hipMemset(h->pp_stage, 0, pp_stage_bytes()) != hipSuccess) {
+        h->err = "request staging allocation failed";
+        return bail(RIO_GP_ENOMEM);
+    }
+    h->allocs.push_back(h->pp_stage);
     // every row starts unplaced; the position scratch is all-ones between calls
     launch_fill_u32(h->assign[0], R, kNone, h->stream);
     launch_fill_u32(h->assign[1], R, kNone, h->stream);
@@ -1473,7 +1479,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
             const u32 seq1 = small_begin(h);
             launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, dm, dm + kMidBatch, (u32)n,
                           dm + 2 * kMidBatch, dm + 3 * kMidBatch, h->d_small + 4 * kSmallBatch, h->stream, aff_life(h),
-                          small_done_dev(h), seq1, nullptr);
+                          small_done_dev(h), seq1, nullptr, 0, h->pp_stage, h->mid_ticket);
             if ((rc = small_wait(h, seq1))) return rc;
             const u32 status = h->h_small[4 * kSmallBatch];
             if (status == 0) {
@@ -1527,7 +1533,7 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
         const u32 seq = small_begin(h);
         launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, d_idx, d_requester, (u32)n, d_out_node,
                       d_out_flag ? d_out_flag : h->d_mid + 3 * kMidBatch, h->d_small + 4 * kSmallBatch, h->stream, aff_life(h),
-                      small_done_dev(h), seq, nullptr, (u32)h->n);
+                      small_done_dev(h), seq, nullptr, (u32)h->n, h->pp_stage, h->mid_ticket);
         if ((rc = small_wait(h, seq))) return rc;
         const u32 status = h->h_small[4 * kSmallBatch];
         if (status == 0) {

@@ -823,8 +823,9 @@ def test_place_pending_replaced_flag(gp, oracle):
 
 
 def test_place_pending_batch_sizes_around_every_path_boundary(gp, oracle):
-    """place_pending: one workgroup up to 256 requests, the general path over mapped pinned memory (completion word stored by
-    the output kernel's last workgroup) up to 4 096, staging copies beyond — the sizes on both sides of every boundary, with
+    """place_pending: one workgroup up to 1 024 requests, three launches (requests and rows gathered by many workgroups, the
+    decision in one, results and table stores by many) up to 4 096 — or the general path over mapped pinned memory when
+    the batch needs it —, staging copies beyond — the sizes on both sides of every boundary, with
     nodes dying in between, every call against the sequential oracle (nodes, flags, table, `used`)."""
     rng = np.random.default_rng(21)
     n, m = 300_000, 50
@@ -836,7 +837,7 @@ def test_place_pending_batch_sizes_around_every_path_boundary(gp, oracle):
     g.set_objects(n, load, None)
     ref = np.full(n, NONE, np.uint32)
     used = np.zeros(m, np.uint64)
-    for step, k in enumerate((256, 257, 1000, 4095, 4096, 4097, 20_000, 300, 2048, 257)):
+    for step, k in enumerate((256, 257, 1000, 1024, 1025, 4095, 4096, 4097, 20_000, 300, 2048, 257)):
         if step % 3 == 2:
             j = int(rng.integers(m))
             alive[j] ^= 1
@@ -1051,8 +1052,8 @@ def test_place_pending_dev_small_batches_one_launch(gp, oracle):
     g.set_objects(n, load, None)
     ref = np.full(n, NONE, np.uint32)
     used = np.zeros(m, np.uint64)
-    for step, k in enumerate((1, 3, 7, 255, 256, 257, 1001, 4095, 4096, 2, 4093)):
-        if step == 6:
+    for step, k in enumerate((1, 3, 7, 255, 256, 257, 1001, 1024, 1025, 4095, 4096, 2, 4093)):
+        if step == 8:
             alive[[5, 40]] = 0
             g.set_alive_all(alive)
         idx = rng.integers(0, n if step % 2 else 3000, k).astype(np.uint32)      # (3 000 rows: duplicates, sticky hits)
