@@ -35,7 +35,8 @@ typedef struct rio_op_cfg {
     uint64_t max_objects;  /* distinct object keys the table can hold */
     uint32_t max_nodes;    /* distinct server addresses */
     uint32_t spill_rounds; /* 0 -> 2 */
-    uint32_t flags;        /* reserved */
+    uint32_t flags;        /* 0, or RIO_GP_CFG_REF_SELF_ASSIGN (rio_gpu_placement.h): get_or_create_placement first-touches the
+                            * requester whether or not membership marks it active, as service.rs:244-252 does */
     uint32_t reserved;
 } rio_op_cfg;
 
@@ -107,6 +108,21 @@ int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* co
  * server can warm-start from, or write back to, the placement DB of a SqliteObjectPlacement deployment. */
 int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_names, const char* const** object_ids,
                     const char* const** server_addresses);
+
+/* Keys with their lengths.  ObjectId(String, String) (service_object.rs:19-26) holds any Rust string, a NUL byte included;
+ * the entry points above take NUL-terminated strings and would cut such a key short.  These take struct_name / object_id
+ * as (pointer, length) and are otherwise the same calls (the Rust adapter binds THESE: rio-rs_amd/rust/src/gpu.rs).
+ * Server addresses stay NUL-terminated: an address is "{ip}:{port}" of a Member (cluster/storage/mod.rs:56-58).
+ * rio_op_snapshot hands out NUL-terminated copies; rio_op_snapshot_key_lengths gives the true lengths of the struct_name /
+ * object_id strings of the CALLING THREAD's last snapshot (arrays of n entries, valid until its next snapshot). */
+int rio_op_update_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id, size_t object_id_len,
+                    const char* server_address);
+int rio_op_lookup_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id, size_t object_id_len,
+                    char* out, size_t out_cap, int* found);
+int rio_op_remove_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id, size_t object_id_len);
+int rio_op_get_or_create_placement_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id,
+                                     size_t object_id_len, const char* self_address, char* out, size_t out_cap, uint32_t* flag);
+int rio_op_snapshot_key_lengths(rio_op_t* p, const size_t** struct_name_lens, const size_t** object_id_lens);
 
 /* Whole-table re-solve over the interned tables (rio_gp_tick). */
 int rio_op_tick(rio_op_t* p, rio_gp_stats* stats);

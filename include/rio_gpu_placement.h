@@ -67,6 +67,16 @@ extern "C" {
  * object (affinity = the node / the requester), update(i, NONE), remove and clean_server make it a non-object again.
  * Without the flag the affinity column is only ever written by rio_gp_set_objects / rio_gp_set_object_attrs. */
 #define RIO_GP_CFG_ROW_LIFECYCLE 1u
+/* Reference-faithful first touch.  By default a node (a requester) that membership marks inactive is not a placement target:
+ * a pending object whose affinity node / requester is not alive goes to the water-fill.  The reference has no such test —
+ * Service::get_or_create_placement updates the object onto self.address whatever the membership says about self
+ * (service.rs:244-252), and evicts it again on the next touch (service.rs:227-237).  With this flag the solver does the
+ * same: a pending row claims its affinity node (a place_pending request: its requester) whether or not that node is alive,
+ * against the node's whole capacity; rows on nodes that are not alive are still evicted, and the water-fill still places
+ * on live nodes only.  With unbounded capacities rio_gp_tick / rio_gp_place_pending then equal the reference request by
+ * request for ANY membership (tests/test_gpu_object_placement.py).  Single-GPU handles only: the rio_gp_shard_* calls
+ * return RIO_GP_EINVAL on a handle created with it. */
+#define RIO_GP_CFG_REF_SELF_ASSIGN 2u
 
 /* return codes */
 #define RIO_GP_OK 0

@@ -176,6 +176,17 @@ static uint64_t spill_rounds(uint64_t* rem, uint64_t n_rem, const uint32_t* obj_
 int orc_tick(const uint32_t* cur, const uint32_t* load, const uint32_t* aff, uint64_t n_obj,
              const uint64_t* cap, const uint8_t* alive, uint32_t m, uint32_t rounds,
              uint32_t* next, uint64_t* used_out, orc_stats* st) {
+    return orc_tick_ex(cur, load, aff, n_obj, cap, alive, m, rounds, 0u, next, used_out, st);
+}
+
+/* flags & ORC_REF_SELF_ASSIGN (= RIO_GP_CFG_REF_SELF_ASSIGN): a pending row claims its affinity node whether or not
+ * membership marks it active, against the node's whole capacity — service.rs:244-252 updates the object onto self.address
+ * without asking is_active(self); the eviction of rows on inactive nodes (pass 1) and the water-fill (live nodes only)
+ * are unchanged. */
+int orc_tick_ex(const uint32_t* cur, const uint32_t* load, const uint32_t* aff, uint64_t n_obj,
+                const uint64_t* cap, const uint8_t* alive, uint32_t m, uint32_t rounds, uint32_t flags,
+                uint32_t* next, uint64_t* used_out, orc_stats* st) {
+    const int self_assign = (flags & ORC_REF_SELF_ASSIGN) != 0;
     orc_stats s;
     memset(&s, 0, sizeof s);
     s.n_objects = n_obj;
@@ -206,13 +217,14 @@ int orc_tick(const uint32_t* cur, const uint32_t* load, const uint32_t* aff, uin
     }
     /* pass 2 — affinity claim (first touch, service.rs:244-252), capacity-gated: claimants of
      * node a in index order; admitted iff the inclusive prefix of load <= free[a]. */
-    for (uint32_t j = 0; j < m; ++j) fre[j] = node_free(cap, alive, used, j);
+    for (uint32_t j = 0; j < m; ++j)
+        fre[j] = self_assign ? (cap[j] > used[j] ? cap[j] - used[j] : 0) : node_free(cap, alive, used, j);
     uint64_t n_rem = 0;
     for (uint64_t i = 0; i < n_obj; ++i) {
         if (kept[i]) continue;
         uint32_t a = aff[i];
         if (a == ORC_AFF_INACTIVE) { --s.n_objects; continue; } /* not an object (row lifecycle): never placed */
-        if (a != ORC_NONE && a < m && alive[a]) {
+        if (a != ORC_NONE && a < m && (alive[a] || self_assign)) {
             run[a] += load[i];
             if (run[a] <= fre[a]) {
                 next[i] = a;
@@ -253,6 +265,15 @@ int orc_place_pending(uint32_t* assign, const uint32_t* load, uint64_t n_obj, co
                       const uint8_t* alive, uint64_t* used, uint32_t m, uint32_t rounds,
                       const uint32_t* idx, const uint32_t* requester, uint64_t n,
                       uint32_t* out_node, uint32_t* out_flag) {
+    return orc_place_pending_ex(assign, load, n_obj, cap, alive, used, m, rounds, 0u, idx, requester, n, out_node, out_flag);
+}
+
+/* flags & ORC_REF_SELF_ASSIGN: first touch goes to the requester whether or not it is an active member (see orc_tick_ex) */
+int orc_place_pending_ex(uint32_t* assign, const uint32_t* load, uint64_t n_obj, const uint64_t* cap,
+                         const uint8_t* alive, uint64_t* used, uint32_t m, uint32_t rounds, uint32_t flags,
+                         const uint32_t* idx, const uint32_t* requester, uint64_t n,
+                         uint32_t* out_node, uint32_t* out_flag) {
+    const int self_assign = (flags & ORC_REF_SELF_ASSIGN) != 0;
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= n_obj || requester[k] >= m) return 1;
     uint64_t words = ((uint64_t)m + 63) / 64;
@@ -286,14 +307,15 @@ int orc_place_pending(uint32_t* assign, const uint32_t* load, uint64_t n_obj, co
         if (seen[idx[k]] == ORC_NONE) { seen[idx[k]] = (uint32_t)k; first[k] = 1; }
     /* (3) first touch on the requester (service.rs:244-252), capacity-gated by the
      *     position-ordered prefix rule; requester must be an active member. */
-    for (uint32_t j = 0; j < m; ++j) fre[j] = node_free(cap, alive, used, j);
+    for (uint32_t j = 0; j < m; ++j)
+        fre[j] = self_assign ? (cap[j] > used[j] ? cap[j] - used[j] : 0) : node_free(cap, alive, used, j);
     uint64_t n_rem = 0;
     for (uint64_t k = 0; k < n; ++k) {
         slot_node[k] = ORC_NONE;
         if (!first[k]) continue;
         uint32_t row = idx[k], c = assign[row], r = requester[k];
         if (c != ORC_NONE) { state[k] = 1; continue; } /* sticky */
-        if (alive[r]) {
+        if (alive[r] || self_assign) {
             run[r] += load[row];
             if (run[r] <= fre[r]) { slot_node[k] = r; state[k] = 2; continue; }
         }

@@ -56,6 +56,17 @@ int orc_tick(const uint32_t* cur, const uint32_t* load, const uint32_t* aff, uin
              const uint64_t* cap, const uint8_t* alive, uint32_t m, uint32_t rounds,
              uint32_t* next, uint64_t* used_out, orc_stats* st);
 
+/* flags of the _ex forms: ORC_REF_SELF_ASSIGN = RIO_GP_CFG_REF_SELF_ASSIGN — a claim / first touch does not need an active
+ * node (service.rs:244-252 self-assigns without asking is_active(self)) */
+#define ORC_REF_SELF_ASSIGN 2u
+int orc_tick_ex(const uint32_t* cur, const uint32_t* load, const uint32_t* aff, uint64_t n_obj,
+                const uint64_t* cap, const uint8_t* alive, uint32_t m, uint32_t rounds, uint32_t flags,
+                uint32_t* next, uint64_t* used_out, orc_stats* st);
+int orc_place_pending_ex(uint32_t* assign, const uint32_t* load, uint64_t n_obj, const uint64_t* cap,
+                         const uint8_t* alive, uint64_t* used, uint32_t m, uint32_t rounds, uint32_t flags,
+                         const uint32_t* idx, const uint32_t* requester, uint64_t n,
+                         uint32_t* out_node, uint32_t* out_flag);
+
 /* Batched get_or_create_placement (service.rs:193-298), see rio_gp_place_pending. */
 int orc_place_pending(uint32_t* assign, const uint32_t* load, uint64_t n_obj, const uint64_t* cap,
                       const uint8_t* alive, uint64_t* used, uint32_t m, uint32_t rounds,

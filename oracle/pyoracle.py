@@ -58,6 +58,10 @@ def lib():
                                C.POINTER(Stats)]
         L.orc_place_pending.argtypes = [u32p, u32p, C.c_uint64, u64p, u8p, u64p, C.c_uint32, C.c_uint32,
                                         u32p, u32p, C.c_uint64, u32p, u32p]
+        L.orc_tick_ex.argtypes = [u32p, u32p, u32p, C.c_uint64, u64p, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u64p,
+                                  C.POINTER(Stats)]
+        L.orc_place_pending_ex.argtypes = [u32p, u32p, C.c_uint64, u64p, u8p, u64p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           u32p, u32p, C.c_uint64, u32p, u32p]
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_splitmix64.restype = C.c_uint64
         # string layer
@@ -140,25 +144,29 @@ def recompute_used(assign, load, m):
     return used
 
 
-def tick(cur, load, aff, cap, alive, rounds=2):
+REF_SELF_ASSIGN = 2   # ORC_REF_SELF_ASSIGN = RIO_GP_CFG_REF_SELF_ASSIGN
+
+
+def tick(cur, load, aff, cap, alive, rounds=2, flags=0):
+    """flags=REF_SELF_ASSIGN: a claim does not need an active node (service.rs:244-252 self-assigns unconditionally)."""
     cur, load, aff, cap, alive = _u32(cur), _u32(load), _u32(aff), _u64(cap), _u8(alive)
     n, m = len(cur), len(cap)
     nxt = np.empty(n, np.uint32)
     used = np.zeros(max(m, 1), np.uint64)
     st = Stats()
-    rc = lib().orc_tick(cur, load, aff, n, cap, alive, m, rounds, nxt, used, C.byref(st))
+    rc = lib().orc_tick_ex(cur, load, aff, n, cap, alive, m, rounds, flags, nxt, used, C.byref(st))
     if rc:
         raise RuntimeError("orc_tick rc=%d" % rc)
     return nxt, used[:m], st.as_dict()
 
 
-def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2):
+def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2, flags=0):
     """In place on `assign` and `used`; returns (out_node, out_flag)."""
     idx, requester = _u32(idx), _u32(requester)
     out_node = np.empty(len(idx), np.uint32)
     out_flag = np.empty(len(idx), np.uint32)
-    rc = lib().orc_place_pending(assign, _u32(load), len(assign), _u64(cap), _u8(alive), used, len(cap), rounds,
-                                 idx, requester, len(idx), out_node, out_flag)
+    rc = lib().orc_place_pending_ex(assign, _u32(load), len(assign), _u64(cap), _u8(alive), used, len(cap), rounds, flags,
+                                    idx, requester, len(idx), out_node, out_flag)
     if rc:
         raise ValueError("orc_place_pending rc=%d" % rc)
     return out_node, out_flag

@@ -46,6 +46,7 @@ thread_local size_t t_addr_len = 0;
 // rio_op_snapshot's arrays: copies, owned by the calling thread until its next snapshot
 thread_local std::vector<std::string> t_snap_store;
 thread_local std::vector<const char*> t_snap_ty, t_snap_id, t_snap_addr;
+thread_local std::vector<size_t> t_snap_tylen, t_snap_idlen;
 
 // One single-object call waiting for its device round trip (see run_combined).
 struct Req {
@@ -96,10 +97,20 @@ struct State {
     std::atomic<int> refs{1};
 };
 
-std::string key_of(const char* ty, const char* id) {  // local.rs:26-29,43,61
-    std::string k(ty ? ty : "");
+// A key part as the caller handed it over: NUL-terminated (len < 0) or with its length (the _n entry points: a Rust
+// String may hold a NUL byte, service_object.rs:19-26).
+struct Part {
+    const char* p;
+    ptrdiff_t len;
+    Part(const char* c) : p(c ? c : ""), len(-1) {}
+    Part(const char* c, size_t n) : p(c ? c : ""), len((ptrdiff_t)(c ? n : 0)) {}
+    Part(const std::string& str) : p(str.data()), len((ptrdiff_t)str.size()) {}
+    std::string str() const { return len < 0 ? std::string(p) : std::string(p, (size_t)len); }
+};
+std::string key_of(const Part& ty, const Part& id) {  // local.rs:26-29,43,61
+    std::string k = ty.str();
     k += '.';
-    k += id ? id : "";
+    k += id.str();
     return k;
 }
 
@@ -187,7 +198,7 @@ int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, b
 // find or create the row of a key (imu held).  kFull: no free row — the caller releases its locks, runs reclaim() and retries.
 // use: the call makes (or unmakes) an object of the key — update, get_or_create_placement, remove; a key whose row is
 // held for a load set ahead of its first use (row_keep) is an ordinary key from then on
-int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* out, bool use = false) {
+int intern_row(State* s, const Part& ty, const Part& id, bool create, uint32_t* out, bool use = false) {
     const std::string key = key_of(ty, id);
     auto it = s->rows.find(key);
     if (it != s->rows.end()) {
@@ -212,7 +223,7 @@ int intern_row(State* s, const char* ty, const char* id, bool create, uint32_t* 
         return kFull;
     }
     s->rows.emplace(key, row);
-    s->row_key[row] = std::make_pair(std::string(ty ? ty : ""), std::string(id ? id : ""));
+    s->row_key[row] = std::make_pair(ty.str(), id.str());
     s->row_live[row] = 1;
     s->row_keep[row] = use ? 0 : 1;  // created without a use: rio_op_set_object_load ahead of the first update / request
     *out = row;
@@ -246,7 +257,7 @@ int reclaim(State* s) {
         if (rc == RIO_GP_OK) {
             for (uint64_t r = 0; r < n; ++r)
                 if (s->row_live[r] && !s->row_keep[r] && assign[r] == RIO_GP_NONE && aff[r] == RIO_GP_AFF_INACTIVE) {
-                    s->rows.erase(key_of(s->row_key[r].first.c_str(), s->row_key[r].second.c_str()));
+                    s->rows.erase(key_of(s->row_key[r].first, s->row_key[r].second));
                     s->row_key[r] = std::pair<std::string, std::string>();
                     s->row_live[r] = 0;
                     s->free_rows.push_back((uint32_t)r);
@@ -504,7 +515,7 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     g.max_objects = cfg->max_objects;
     g.max_nodes = cfg->max_nodes;
     g.spill_rounds = cfg->spill_rounds;
-    g.flags = RIO_GP_CFG_ROW_LIFECYCLE;
+    g.flags = RIO_GP_CFG_ROW_LIFECYCLE | (cfg->flags & RIO_GP_CFG_REF_SELF_ASSIGN);
     rio_gp_t* gp = nullptr;
     int rc = rio_gp_create(&g, &gp);
     if (rc) {
@@ -587,7 +598,7 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
     });
 }
 
-int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr) {
+static int op_update(rio_op_t* p, const Part& ty, const Part& id, const char* addr) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
     Req r;
@@ -632,7 +643,12 @@ int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
     return RIO_GP_OK;
 }
 
-int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t cap, int* found) {
+int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr) { return op_update(p, Part(ty), Part(id), addr); }
+int rio_op_update_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, size_t id_len, const char* addr) {
+    return op_update(p, Part(ty, ty_len), Part(id, id_len), addr);
+}
+
+static int op_lookup(rio_op_t* p, const Part& ty, const Part& id, char* out, size_t cap, int* found) {
     if (!p || !found) return RIO_GP_EINVAL;
     State* s = p->s;
     Req r;
@@ -656,6 +672,13 @@ int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t
     return RIO_GP_OK;
 }
 
+int rio_op_lookup(rio_op_t* p, const char* ty, const char* id, char* out, size_t cap, int* found) {
+    return op_lookup(p, Part(ty), Part(id), out, cap, found);
+}
+int rio_op_lookup_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, size_t id_len, char* out, size_t cap, int* found) {
+    return op_lookup(p, Part(ty, ty_len), Part(id, id_len), out, cap, found);
+}
+
 size_t rio_op_last_address_len(rio_op_t*) { return t_addr_len; }
 
 int rio_op_clean_server(rio_op_t* p, const char* address) {
@@ -672,7 +695,7 @@ int rio_op_clean_server(rio_op_t* p, const char* address) {
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
 }
 
-int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
+static int op_remove(rio_op_t* p, const Part& ty, const Part& id) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
     Req r;
@@ -684,6 +707,11 @@ int rio_op_remove(rio_op_t* p, const char* ty, const char* id) {
         return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;  // absent: no-op (local.rs:60-68)
     });
     return rc == kNoop ? RIO_GP_OK : rc;
+}
+
+int rio_op_remove(rio_op_t* p, const char* ty, const char* id) { return op_remove(p, Part(ty), Part(id)); }
+int rio_op_remove_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, size_t id_len) {
+    return op_remove(p, Part(ty, ty_len), Part(id, id_len));
 }
 
 int rio_op_len(rio_op_t* p, uint64_t* out) {
@@ -744,8 +772,8 @@ int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* co
     });
 }
 
-int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, const char* self_address, char* out,
-                                   size_t cap, uint32_t* flag) {
+static int op_get_or_create(rio_op_t* p, const Part& ty, const Part& id, const char* self_address, char* out, size_t cap,
+                            uint32_t* flag) {
     if (!p || !self_address) return RIO_GP_EINVAL;
     State* s = p->s;
     Req r;
@@ -761,6 +789,27 @@ int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, 
     std::lock_guard<std::mutex> gi(s->imu);
     // RIO_GP_ERANGE: the decision is made and *flag is set; the address is one rio_op_lookup away (a pure read)
     return copy_out(r.node == RIO_GP_NONE ? std::string() : s->node_addr[r.node], out, cap);
+}
+
+int rio_op_get_or_create_placement(rio_op_t* p, const char* ty, const char* id, const char* self_address, char* out,
+                                   size_t cap, uint32_t* flag) {
+    return op_get_or_create(p, Part(ty), Part(id), self_address, out, cap, flag);
+}
+int rio_op_get_or_create_placement_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, size_t id_len,
+                                     const char* self_address, char* out, size_t cap, uint32_t* flag) {
+    return op_get_or_create(p, Part(ty, ty_len), Part(id, id_len), self_address, out, cap, flag);
+}
+
+int rio_op_snapshot_key_lengths(rio_op_t* p, const size_t** struct_name_lens, const size_t** object_id_lens) {
+    if (!p || !struct_name_lens || !object_id_lens) return RIO_GP_EINVAL;
+    t_snap_tylen.clear(); t_snap_idlen.clear();
+    for (size_t k = 0; k + 2 < t_snap_store.size(); k += 3) {
+        t_snap_tylen.push_back(t_snap_store[k].size());
+        t_snap_idlen.push_back(t_snap_store[k + 1].size());
+    }
+    *struct_name_lens = t_snap_tylen.data();
+    *object_id_lens = t_snap_idlen.data();
+    return RIO_GP_OK;
 }
 
 int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_names, const char* const** object_ids,

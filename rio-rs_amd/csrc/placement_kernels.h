@@ -41,6 +41,9 @@ struct Plan {
     u32 m;       // nodes
     u32 mwords;  // ceil(m/32)
     u32 trace;   // lab build: phase traces of the fix-up kernels (0 in the product)
+    u32 sa;      // RIO_GP_CFG_REF_SELF_ASSIGN: a pending row claims its affinity node (a request: its requester) whether or not
+                 // membership marks that node active, against the node's whole capacity (service.rs:244-252 self-assigns
+                 // unconditionally); the water-fill still places on live nodes only.  0: a claim needs a live node
     u64 mark;    // what k_resolve stores in column 7 of its partial rows ("row present"): 1, or the sequence number the
                  // host spins on instead of waiting for the stream
     // packed fix-up (see PackOut): when set, wave gw's rows are only the first wcnt[gw] positions of its range
@@ -262,7 +265,7 @@ inline size_t pp_stage_bytes() { return (size_t)kOneBatch * (16 + 16 + 8) + 64; 
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
                    u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr, u32 n_obj_chk = 0,
-                   void* stage = nullptr, unsigned int* ticket = nullptr);
+                   void* stage = nullptr, unsigned int* ticket = nullptr, u32 sa = 0);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead = nullptr);
@@ -271,7 +274,7 @@ void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const 
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
                        u32* pos_scratch, const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node,
                        u32* out_flag, hipStream_t s, u32* aff_life = nullptr, unsigned int* ticket = nullptr,
-                       u32* done = nullptr, u32 seq = 0, bool flag_bits = true);  // ticket/done/seq: the several-workgroup
+                       u32* done = nullptr, u32 seq = 0, bool flag_bits = true, u32 sa = 0);  // ticket/done/seq: the several-workgroup
                        // completion word (launch_lookup); flag_bits: out_flag holds k_pp_mark_dead's REPLACED bits
 
 // place_pending over a window-sorted batch (big batches): see k_pp_win_gather.  scratch = part_scratch_words(n_obj, n) words.
@@ -282,7 +285,7 @@ void launch_pp_win_gather(const u32* assign, const u32* load, u64 n_obj, u32 m, 
                           hipStream_t s);
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,
-                          const DevStats* st, hipStream_t s);
+                          const DevStats* st, hipStream_t s, u32 sa = 0);
 
 size_t scan_lds_bytes(u32 m);
 

@@ -153,6 +153,7 @@ Plan make_plan(u64 n, u32 m, u32 max_blocks) {
     p.wcnt = nullptr;
     p.alive_dst = nullptr;
     p.trace = trace_flag();
+    p.sa = 0;
     p.mark = 1;
     if (max_blocks == 0 || max_blocks > kMaxBlocks) max_blocks = kMaxBlocks;
     u64 tiles = (n + kTile - 1) / kTile;
@@ -194,14 +195,14 @@ size_t scan_lds_bytes(u32 m) { return scan_lds_bytes_dev(m); }
 // VIRT (virtual table of place_pending): rows are requests; "kept" = already placed (dead nodes
 // were evicted beforehand), kSkipMark rows are duplicate requests and take no part.
 template <bool VIRT>
-__device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv) {
+__device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv, u32 sa = 0) {
     if (VIRT) {
         if (c == kSkipMark) return 3;
         if (c < m) return 0;
     } else {
         if (c < m && bit_of(alv, c)) return 0;
     }
-    if (a < m && bit_of(alv, a)) return 1;
+    if (a < m && (sa || bit_of(alv, a))) return 1;
     if (!VIRT && a == kAffInactive) return 3;  // not an object: takes no part
     return 2;
 }
@@ -248,7 +249,7 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
                                           u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt,
                                           const PackOut* pk = nullptr, u64* pk_pos = nullptr, u32* stage = nullptr,
                                           u32* st_head = nullptr, u32* st_fill = nullptr,
-                                          const uint4 xv = make_uint4(0, 0, 0, 0)) {
+                                          const uint4 xv = make_uint4(0, 0, 0, 0), const u32 sa = 0) {
     // COMPACT == 3 (virtual table of a big place_pending batch): rows are requests, xv = the objects they ask for; a claimant's
     // optimistic node also goes straight into the REAL assignment column, pk->next[object] (one scattered store per first touch:
     // the fix-up patches the same rows through the same indices, so no pass carries the decisions back afterwards)
@@ -263,7 +264,7 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         const bool skip = VIRT && C == kSkipMark;                                                      \
         const bool dead = !VIRT && A == kAffInactive;                                                  \
         const bool kept = inr && cin && (VIRT || ALLALIVE || bit_of(alv, cc));                         \
-        const bool cl = inr && !kept && !skip && ain && (ALLALIVE || bit_of(alv, aa));                 \
+        const bool cl = inr && !kept && !skip && ain && (ALLALIVE || sa || bit_of(alv, aa));           \
         const bool sp = inr && !kept && !cl && !skip && !dead;                                         \
         const u32 bin = (kept && !VIRT) ? cc : (cl ? m + aa : 2 * m);                                  \
         atomicAdd(&hist[bin], (u64)L);                                                                 \
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
                                                           m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
                                                           claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill,
-                                                          COMPACT == 3 ? xv[q] : make_uint4(0, 0, 0, 0));
+                                                          COMPACT == 3 ? xv[q] : make_uint4(0, 0, 0, 0), p.sa);
         it = nit;
 #pragma unroll
         for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; if (COMPACT == 3) xv[q] = xn[q]; }
@@ -462,10 +463,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         const uint4 x1 = COMPACT == 3 ? *reinterpret_cast<const uint4*>(pko.idx + i) : make_uint4(0, 0, 0, 0);
         if (it < wfull)
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                          evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1);
+                                                          evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1, p.sa);
         else
             scan_tile<VIRT, ALLALIVE, true, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                         evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1);
+                                                         evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1, p.sa);
     }
     if (COMPACT == 2 && st_fill) {  // what is left in the ring (< 64 records)
         u32 x = st_head + (u32)lane;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
             const bool pend = inr && !kept;                                           \
             const bool ev = pend && C != kNone;                                       \
             const bool dead = A == kAffInactive;                                      \
-            const bool cl = pend && ain && bit_of(alv, ain ? A : 0u);                 \
+            const bool cl = pend && ain && (p.sa || bit_of(alv, ain ? A : 0u));       \
             const bool sp = pend && !cl && !dead;                                     \
             O = cl ? A : ((ev && dead) ? kNone : C);                                  \
             chg |= cl | (ev && dead);                                                 \
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
         if (d + E < (u32)dhi) {                                                       \
             const u32 A = af[E];                                                      \
             const bool ain = A < m;                                                   \
-            const bool cl = ain && bit_of(alv, ain ? A : 0u);                         \
+            const bool cl = ain && (p.sa || bit_of(alv, ain ? A : 0u));               \
             O = cl ? A : kSpillMark;                                                  \
             if (cl) atomicAdd(&hist[m + A], (u64)ld[E]);                              \
             sp_cnt += (u32)!cl;                                                       \
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(SEARCH ? kBlock : 256) void k_resolve(const Resolve
     if (valid) {
         const u64 kept_load = a.kept_from ? (alive_j ? kf : 0ull) : tot[tid], ctot = tot[tid + kResNodes];
         const u64 used = kept_load + ub;
-        const u64 fre = (alive_j && cj > used) ? cj - used : 0;
+        const u64 fre = ((alive_j || p.sa) && cj > used) ? cj - used : 0;  // (what the claimants may take)
         a.used_kept[j] = used;
         a.claim_tot[j] = ctot;
         a.cutblk[j] = kNoCut;
@@ -1215,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_cutblk(const u64* __restrict__ H, Plan 
     u64 fre = 0, ctot = 0;
     if (valid) {
         const u64 c = cap[j], used = used_kept[j];
-        fre = (bit_of(alive_bits, j) && c > used) ? c - used : 0;
+        fre = ((p.sa || bit_of(alive_bits, j)) && c > used) ? c - used : 0;
         ctot = claim_tot[j];
     }
     const bool has_cut = valid && ctot > fre;
@@ -1294,6 +1295,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                                                  const u32* __restrict__ forced_bits, u32* __restrict__ cutidx,
                                                  u64* __restrict__ used_cur, const u32 tcap, u64* __restrict__ R) {
     const u32 m = p.m, mr = (m + 7) & ~7u;
+    const bool sa_ = p.sa != 0;  // claims do not need a live node (Plan::sa)
     u32& nlocal = *reinterpret_cast<u32*>(smem);
     u64* red = reinterpret_cast<u64*>(smem + 16);                            // [2]
     u32* thr = reinterpret_cast<u32*>(smem + kSmall);                        // [mr] reject threshold by node
@@ -1395,7 +1397,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                 // no per-row atomics, and tiles outside the node's current range are not even read.  The general pass below
                 // spends ~240 instructions per tile and wave on this, 12 us per pass on the one CU that owns the item.
                 const u32 nd0 = (u32)node_of[g0];
-                const bool live0 = bit_of(alv, nd0);
+                const bool live0 = p.sa || bit_of(alv, nd0);
                 const u32 rs0 = (u32)st_rs[0];
                 for (u64 it = wstart; it < wend; it += kTile) {
                     const u32 tb = (u32)((it - bstart) / kTile);
@@ -1454,7 +1456,7 @@ __device__ __forceinline__ void cut_search_block(unsigned char* smem, const u32 
                         const u32 cx = cin ? C : 0u, ax = ain ? A : 0u;                                        \
                         const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                                \
                         const u32 ls = (u32)slot[ax] - g0;  /* kSlotNone - g0 >= kn always */                  \
-                        bool hit = (i0 + E < wend) & !kept & !(VIRT && C == kSkipMark) & ain & bit_of(alv, ax) & (ls < kn); \
+                        bool hit = (i0 + E < wend) & !kept & !(VIRT && C == kSkipMark) & ain & (sa_ | bit_of(alv, ax)) & (ls < kn); \
                         u32 t = 0;                                                                             \
                         if (level == 0) {                                                                      \
                             t = t_lvl0;  /* every range is the whole block: the piece is a property of the tile */ \
@@ -1929,6 +1931,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Plan& p = a.p;
     const u32 m = p.m;
+    const bool sa_ = p.sa != 0;  // claims do not need a live node (Plan::sa)
     // red[16]: 0 spill load of the earlier blocks | 1 pending rows anywhere | 2 placed rows | 3 placed load | 4 remaining load |
     //          5 remaining rows | 6 rejected rows | 7 rejected load | 8 nodes with room (u32)
     u64* red = reinterpret_cast<u64*>(smem);                      // [16]
@@ -2129,7 +2132,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
                 const bool kept = VIRT ? cin : (cin & bit_of(alv, cx));                              \
                 const bool skip = VIRT && CC == kSkipMark;                                           \
                 const bool dead = !VIRT && A == kAffInactive;                                        \
-                const bool cl = inr & !kept & !skip & ain & bit_of(alv, ax);                         \
+                const bool cl = inr & !kept & !skip & ain & (sa_ | bit_of(alv, ax));                 \
                 const bool sp = inr & !kept & !skip & !cl & !dead;                                   \
                 const bool rej = cl & ((u32)(i0 + E) >= thr[ax]);                                    \
                 const u32 mark = PACK ? kNone : kSpillMark;                                          \
@@ -3038,7 +3041,7 @@ __global__ __launch_bounds__(256) void k_pp_win_output(const u32* __restrict__ i
                                                        const u32* __restrict__ vnext, const u32* __restrict__ alive_bits,
                                                        const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
                                                        u32* __restrict__ out_flag, u32* __restrict__ aff_life,
-                                                       const DevStats* __restrict__ st) {
+                                                       const DevStats* __restrict__ st, u32 sa) {
     if (st->err) return;  // the batch holds an invalid entry: the call fails
     const u64 nv = (n + 3) >> 2;
     for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += (u64)gridDim.x * 256) {
@@ -3067,7 +3070,7 @@ __global__ __launch_bounds__(256) void k_pp_win_output(const u32* __restrict__ i
             u32 fl;                                                                                      \
             if (nd == kNone) fl = 4u;                                       /* UNPLACED */               \
             else if (C == kNone) {                                          /* this request placed it */ \
-                const bool claimed = bit_of(alive_bits, R) && (u32)(k0 + E) < cutidx[R];                 \
+                const bool claimed = (sa || bit_of(alive_bits, R)) && (u32)(k0 + E) < cutidx[R];         \
                 fl = (claimed ? 2u : 3u) | (F & kFlagReplaced);             /* PLACED | SPILLED */       \
                 if (aff_life && (F & kFlagReplaced)) aff_life[idx[k0 + E]] = R;                          \
             } else fl = nd == R ? 0u : 1u;                                  /* LOCAL | REDIRECT */       \
@@ -3298,7 +3301,8 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
                             u32* __restrict__ pos, const u32* __restrict__ alive_bits,
                             const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
                             u32* __restrict__ out_flag, u32* __restrict__ aff_life, unsigned int* ticket, u32* done,
-                            u32 seq, u32 keep_mask /* kFlagReplaced, or 0 when k_pp_mark_dead did not run (every node alive) */) {
+                            u32 seq, u32 keep_mask /* kFlagReplaced, or 0 when k_pp_mark_dead did not run (every node alive) */,
+                            u32 sa) {
     for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
         const u32 i = idx[k], r = req[k];
         const u32 nd = assign[i];
@@ -3307,7 +3311,7 @@ __global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restric
         u32 fl;
         if (nd == kNone) fl = 4u;                                  // UNPLACED
         else if (vcur[k] == kNone) {                               // this request placed the row
-            const bool claimed = bit_of(alive_bits, r) && (cutidx == nullptr || (u32)k < cutidx[r]);
+            const bool claimed = (sa || bit_of(alive_bits, r)) && (cutidx == nullptr || (u32)k < cutidx[r]);
             fl = claimed ? 2u : 3u;                                // PLACED | SPILLED
         } else fl = (nd == r) ? 0u : 1u;                           // LOCAL | REDIRECT
         out_node[k] = nd;
@@ -3340,7 +3344,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
                                                     const u32* __restrict__ req, u32 n, u32* __restrict__ out_node,
                                                     u32* __restrict__ out_flag, u32* __restrict__ status,
                                                     u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl, uint4 ia,
-                                                    uint4 ib, u32 n_obj_chk, u32 trace) {
+                                                    uint4 ib, u32 n_obj_chk, u32 trace, u32 sa) {
     // n_obj_chk != 0 (requests the host has not seen: rio_gp_place_pending_dev): the number of rows — an object index or a
     // requester out of range ends the call with status 3 and nothing changed; the arrays are then exactly n entries long
     // (no whole vector past the end)
@@ -3383,7 +3387,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
             l[q] = load[i[q]];
             const u64 cj = cap[r[q]], uj = used[r[q]];
             fre[q] = cj > uj ? cj - uj : 0;
-            r_alive[q] = bit_of(alive_bits, r[q]);
+            r_alive[q] = sa || bit_of(alive_bits, r[q]);
         }
     }
     __syncthreads();
@@ -3482,7 +3486,7 @@ __global__ __launch_bounds__(256) void k_pp_stage(const u32* __restrict__ assign
                                                   const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
                                                   const u64* __restrict__ used, const u32* __restrict__ idx,
                                                   const u32* __restrict__ req, u32 n, uint4* __restrict__ rec,
-                                                  uint4* __restrict__ rec2, u32* __restrict__ st, u32 n_obj_chk) {
+                                                  uint4* __restrict__ rec2, u32* __restrict__ st, u32 n_obj_chk, u32 sa) {
     const u32 k = blockIdx.x * 256u + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x == 0) st[1] = 2u;  // status: "not decided" until k_pp_decide says otherwise
     if (k >= n) return;
@@ -3493,7 +3497,7 @@ __global__ __launch_bounds__(256) void k_pp_stage(const u32* __restrict__ assign
     const u64 cj = cap[r], uj = used[r];
     const u64 fre = cj > uj ? cj - uj : 0;
     rec[k] = make_uint4(i, r, c, l);
-    rec2[k] = make_uint4((u32)fre, (u32)(fre >> 32), bit_of(alive_bits, r) ? 1u : 0u, bad ? 1u : 0u);
+    rec2[k] = make_uint4((u32)fre, (u32)(fre >> 32), (sa || bit_of(alive_bits, r)) ? 1u : 0u, bad ? 1u : 0u);
     if (bad) atomicOr(&st[0], 1u);
 }
 
@@ -4142,6 +4146,7 @@ Plan rebal_plan(const Plan& p) {
     const u64 ctiles = (p.tiles + p.nw - 1) / p.nw;
     Plan pv = make_plan((u64)p.nw * ctiles * kTile, p.m, p.G);
     pv.mark = p.mark;
+    pv.sa = p.sa;
     return pv;
 }
 u64 rebal_rows(u64 n) {
@@ -4386,9 +4391,9 @@ void launch_pp_win_gather(const u32* assign, const u32* load, u64 n_obj, u32 m, 
 }
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,
-                          const DevStats* st, hipStream_t s) {
+                          const DevStats* st, hipStream_t s, u32 sa) {
     hipLaunchKernelGGL(k_pp_win_output, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, idx, req, n, vcur, vload, vnext,
-                       alive_bits, cutidx, m, out_node, out_flag, aff_life, st);
+                       alive_bits, cutidx, m, out_node, out_flag, aff_life, st, sa);
 }
 bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req) {
     // (the windows' rows are only READ here, once and densely: it pays for sparser batches than the CRUD forms' n_obj / 8)
@@ -4432,7 +4437,7 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
 }
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk, void* stage, unsigned int* ticket) {
+                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk, void* stage, unsigned int* ticket, u32 sa) {
     if (stage && ticket && done && n > (u32)kPpStagedFrom && m <= kPpTot) {  // three launches: stage | decide | apply
         uint4* rec = static_cast<uint4*>(stage);
         uint4* rec2 = rec + kOneBatch;
@@ -4440,7 +4445,7 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
         u32* st = reinterpret_cast<u32*>(res + kOneBatch);  // [0] bad-entry flag (0 between calls) | [1] status
         const unsigned g = (n + 255u) / 256u;
         hipLaunchKernelGGL(k_pp_stage, dim3(g), dim3(256), 0, s, assign, load, m, cap, alive_bits, used, idx, req, n, rec, rec2, st,
-                           n_obj_chk);
+                           n_obj_chk, sa);
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kOneBatch) * sizeof(u32);
         hipLaunchKernelGGL(k_pp_decide, dim3(1), dim3(kBlock), lds, s, rec, rec2, n, m, alive_bits, used, res, st, status);
         hipLaunchKernelGGL(k_pp_apply, dim3(g), dim3(256), 0, s, assign, rec, res, n, out_node, out_flag, st, aff_life, ticket, done, seq);
@@ -4449,11 +4454,11 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
     if (n <= (u32)kSmallBatch) {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kSmallBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kSmallBatch, 1>), dim3(1), dim3(kSmallBatch), lds, s, assign, load, m, cap, alive_bits, used,
-                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl), n_obj_chk, trace_flag());
+                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl), n_obj_chk, trace_flag(), sa);
     } else {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kOneBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kBlock, kOneBatch / kBlock>), dim3(1), dim3(kBlock), lds, s, assign, load, m, cap, alive_bits,
-                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk, trace_flag());
+                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk, trace_flag(), sa);
     }
 }
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
@@ -4470,12 +4475,12 @@ void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const 
 }
 void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext, u32* pos,
                        const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node, u32* out_flag,
-                       hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq, bool flag_bits) {
+                       hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq, bool flag_bits, u32 sa) {
     const unsigned g = grid_for(n, 256, 4096);
     hipLaunchKernelGGL(k_pp_scatter, dim3(g), dim3(256), 0, s, assign, idx, n, vcur, vnext);
     hipLaunchKernelGGL(k_pp_output, dim3(g), dim3(256), 0, s, assign, idx, req, n, vcur, pos, alive_bits,
                        cutidx_or_null, m, out_node, out_flag, aff_life, ticket, (ticket ? done : nullptr), seq,
-                       flag_bits ? kFlagReplaced : 0u);
+                       flag_bits ? kFlagReplaced : 0u, sa);
 }
 
 void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s) {

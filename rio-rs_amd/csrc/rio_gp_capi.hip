@@ -104,6 +104,7 @@ struct rio_gp {
     std::string err;
     int device = 0;
     bool lifecycle = false;            // RIO_GP_CFG_ROW_LIFECYCLE: the affinity column also says which rows are objects
+    u32 sa = 0;                        // RIO_GP_CFG_REF_SELF_ASSIGN: claims / first touches do not need a live node (Plan::sa)
     hipStream_t stream = nullptr;      // the stream every call of this handle is enqueued on
     hipStream_t own_stream = nullptr;  // created by rio_gp_create (rio_gp_set_stream may point `stream` elsewhere)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -314,6 +315,11 @@ void fill_stats(const DevStats& d, u64 n, rio_gp_stats* s) {
 }
 
 u32* aff_life(rio_gp* h) { return h->lifecycle ? h->aff : nullptr; }
+Plan hplan(rio_gp* h, u64 n) {  // the decomposition of a table of n rows under this handle's policy flags
+    Plan p = make_plan(n, h->m, 0);
+    p.sa = h->sa;
+    return p;
+}
 Table real_table(rio_gp* h) { return Table{h->assign[h->cur], h->load, h->aff, h->assign[h->cur ^ 1]}; }
 constexpr u64 kSearchMaxBlockRows = 1u << 17;  // rows per block up to which k_resolve searches the cuts itself
 constexpr u32 kAliveSlots = 2 * kRing + 4;  // every slot handed to a scan belongs to a solve or tick of a ring of kRing
@@ -491,7 +497,7 @@ int inc_choice(rio_gp* h, bool compact, bool commit) {
 // Host waits: verdict + completion when the fix-up is needed, verdict only on the fast path — and ONE wait when the
 // fix-up was enqueued speculatively (below).
 int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
-    h->plan = make_plan(h->n, h->m, 0);
+    h->plan = hplan(h, h->n);
     h->ring_n = 0; h->ring_slow = 0; h->ring_any = false;
     use_fx_slot(h, 0);
     const u64 seq = ++h->wait_seq;
@@ -613,7 +619,7 @@ int tick_async_locked(rio_gp* h) {
     // nothing has changed since a tick that left every object placed: this one keeps every row, no fix-up can be needed
     // (lab builds: rio_gp_debug_set_speculate(always) keeps the launches)
     const bool quiet = h->quiet_epoch == h->mut_epoch && h->spec_mode != 1;
-    h->plan = make_plan(h->n, h->m, 0);
+    h->plan = hplan(h, h->n);
     const Table t = real_table(h);
     const NodeTab nt = scan_nodes(h);
     const bool compact = !quiet && (h->compact_mode == 1 ||
@@ -729,6 +735,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     rio_gp* h = new rio_gp();
     h->device = cfg->device;
     h->lifecycle = (cfg->flags & RIO_GP_CFG_ROW_LIFECYCLE) != 0;
+    h->sa = (cfg->flags & RIO_GP_CFG_REF_SELF_ASSIGN) ? 1u : 0u;
     h->cap_obj = cfg->max_objects;
     h->cap_rows = ((cfg->max_objects + kTile - 1) / kTile) * kTile + 8 * kTile;  // k_scan prefetches past the end
     h->cap_nodes = cfg->max_nodes ? cfg->max_nodes : 1;
@@ -1351,7 +1358,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
                              h->dead_bits, d_flag, aff_life(h), h->dstats, h->stream);
         if (!h->all_alive)  // service.rs:227-237: every object of a dead node a request ran into is un-placed
             launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
-        Plan vp = make_plan(n, h->m, 0);
+        Plan vp = hplan(h, n);
         const u64 seq = ++h->wait_seq;
         vp.mark = seq;
         Table vtab{vcur, vload, d_req /* the requesters ARE the affinity column of the virtual table */, vnext};
@@ -1363,7 +1370,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
         enqueue_slow(h, vp, vtab, vnt, true, false);  // ahead of the verdict: its kernels guard themselves on the device
         launch_pp_win_output(d_idx, d_req, n, vcur, vload, vnext, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag, aff_life(h), h->dstats,
-                             h->stream);
+                             h->stream, h->sa);
         if (!spin_rows(h->h_slots, resolve_blocks(h->m), seq)) HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         if (*h_bad) {
@@ -1397,7 +1404,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     // (2)(3) first request per row decides; gather the virtual table (rows = requests)
     launch_pp_gather(assign, h->load, d_idx, d_req, n, h->pos, vcur, vload, vaff, h->stream);
     // (4) solve the virtual table against the committed `used`
-    Plan vp = make_plan(n, h->m, 0);
+    Plan vp = hplan(h, n);
     const u64 seq = ++h->wait_seq;
     vp.mark = seq;  // k_resolve's pinned partial rows carry it: the verdict is waited for without the runtime (spin_rows)
     const Table vtab{vcur, vload, vaff, vnext};
@@ -1416,7 +1423,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     // (5) publish, outputs, new `used`
     launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
                       h->stream, aff_life(h), done_seq ? h->mid_ticket : nullptr, done_seq ? small_done_dev(h) : nullptr, done_seq,
-                      mark);
+                      mark, h->sa);
     std::swap(h->used, h->sb.used_cur);  // the solve's `used` vector becomes the committed one (as commit does): no copy
     h->used_parts = vslow && h->sb.D != nullptr;  // + what the water-fill rounds admitted (D rows), folded in later
     h->parts_rounds = h->rounds;
@@ -1450,7 +1457,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         const u32 seq = small_begin(h);
         launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, ds, ds + kSmallBatch,
                       (u32)n, ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h),
-                      small_done_dev(h), seq, in_args ? &inl : nullptr);
+                      small_done_dev(h), seq, in_args ? &inl : nullptr, 0, nullptr, nullptr, h->sa);
         if ((rc = small_wait(h, seq))) return rc;
         const u32 status = hs[4 * kSmallBatch];
         if (status == 0) {
@@ -1479,7 +1486,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
             const u32 seq1 = small_begin(h);
             launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, dm, dm + kMidBatch, (u32)n,
                           dm + 2 * kMidBatch, dm + 3 * kMidBatch, h->d_small + 4 * kSmallBatch, h->stream, aff_life(h),
-                          small_done_dev(h), seq1, nullptr, 0, h->pp_stage, h->mid_ticket);
+                          small_done_dev(h), seq1, nullptr, 0, h->pp_stage, h->mid_ticket, h->sa);
             if ((rc = small_wait(h, seq1))) return rc;
             const u32 status = h->h_small[4 * kSmallBatch];
             if (status == 0) {
@@ -1533,7 +1540,7 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
         const u32 seq = small_begin(h);
         launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, d_idx, d_requester, (u32)n, d_out_node,
                       d_out_flag ? d_out_flag : h->d_mid + 3 * kMidBatch, h->d_small + 4 * kSmallBatch, h->stream, aff_life(h),
-                      small_done_dev(h), seq, nullptr, (u32)h->n, h->pp_stage, h->mid_ticket);
+                      small_done_dev(h), seq, nullptr, (u32)h->n, h->pp_stage, h->mid_ticket, h->sa);
         if ((rc = small_wait(h, seq))) return rc;
         const u32 status = h->h_small[4 * kSmallBatch];
         if (status == 0) {
@@ -1611,7 +1618,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
         }
         h->ring_n = 0;
     }
-    h->plan = make_plan(h->n, h->m, 0);
+    h->plan = hplan(h, h->n);
     use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = scan_nodes(h);
@@ -1658,7 +1665,7 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->ev2) { HIPCHK(h, hipEventCreate(&h->ev2)); HIPCHK(h, hipEventCreate(&h->ev3)); }
-    h->plan = make_plan(h->n, h->m, 0);
+    h->plan = hplan(h, h->n);
     use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = scan_nodes(h);
@@ -1724,7 +1731,8 @@ static SolveBufs shard_bufs(rio_gp* h) {
 int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
     if (!h || !d_x) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
-    h->plan = make_plan(h->n, h->m, 0);
+    if (h->sa) return fail(h, RIO_GP_EINVAL, "row-sharded solves do not implement RIO_GP_CFG_REF_SELF_ASSIGN (single-GPU handles only)");
+    h->plan = hplan(h, h->n);
     h->sb.fx = FxRows{};  // row-sharded solve: the fix-up counters are summed in DevStats (rio_gp_shard_finish reads them)
     fold_used(h);
     h->solve_used_D = false;
@@ -2050,6 +2058,7 @@ uint32_t rio_gp_shard_comm_ranks(rio_gp_t* h) { return h && h->sc ? h->sc->R : 0
 int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
+    if (h->sa) return fail(h, RIO_GP_EINVAL, "row-sharded solves do not implement RIO_GP_CFG_REF_SELF_ASSIGN (single-GPU handles only)");
     if (h->sh_tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_solve_async: row-sharded ticks are in flight (call rio_gp_shard_tick_wait)");
     if (h->p2p && h->p2p->d_peers) {
         // peer-to-peer, ONE stream, two launches, no collective call and no host wait: k_scan -> k_resolve_xchg.
@@ -2060,7 +2069,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         P2P* q = h->p2p;
         const u64 seq = ++q->seq;
         const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
-        h->plan = make_plan(h->n, h->m, 0);
+        h->plan = hplan(h, h->n);
         h->sb.fx = FxRows{};
         fold_used(h);
         h->solve_used_D = false;
@@ -2089,7 +2098,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (!sc) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_solve_async: set up rio_gp_shard_p2p_connect or rio_gp_shard_comm_init first");
     const int q = (int)(sc->k++ % kShardRing);
     if (sc->done_valid[q]) HIPCHK(h, hipStreamWaitEvent(h->stream, sc->done[q], 0));
-    h->plan = make_plan(h->n, h->m, 0);
+    h->plan = hplan(h, h->n);
     h->sb.fx = FxRows{};
     fold_used(h);
     h->solve_used_D = false;
@@ -2135,6 +2144,7 @@ static void shard_exchange_y(rio_gp* h, const SolveBufs& b, const u64* base, int
 int rio_gp_shard_tick_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
+    if (h->sa) return fail(h, RIO_GP_EINVAL, "row-sharded solves do not implement RIO_GP_CFG_REF_SELF_ASSIGN (single-GPU handles only)");
     P2P* q = h->p2p;
     if (!q || !q->d_peers) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: peer-to-peer windows only (rio_gp_shard_p2p_connect first)");
     if (h->ring_n || h->tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: other asynchronous solves are in flight");
@@ -2145,7 +2155,7 @@ int rio_gp_shard_tick_async(rio_gp_t* h) {
     // (1) the fast path: k_scan -> k_resolve_xchg, verdict rows into this tick's slot of the tick ring
     const u64 seq = ++q->seq;
     const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
-    h->plan = make_plan(h->n, h->m, 0);
+    h->plan = hplan(h, h->n);
     h->sb.fx = FxRows{};
     fold_used(h);
     h->solve_used_D = false;

@@ -16,6 +16,7 @@ NONE = 0xFFFFFFFF
 CAP_INF = 0xFFFFFFFFFFFFFFFF
 AFF_INACTIVE = 0xFFFFFFFE       # RIO_GP_AFF_INACTIVE: affinity of a row that is not an object
 CFG_ROW_LIFECYCLE = 1           # RIO_GP_CFG_ROW_LIFECYCLE
+CFG_REF_SELF_ASSIGN = 2         # RIO_GP_CFG_REF_SELF_ASSIGN: claims / first touches do not need a live node (service.rs:244-252)
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleaned and re-placed by this request
 FLAG_MASK = 0x0F
@@ -445,6 +446,13 @@ def _oplib():
         L.rio_op_last_address_len.restype = C.c_size_t
         L.rio_op_clean_server.argtypes = [_vp, C.c_char_p]
         L.rio_op_remove.argtypes = [_vp, C.c_char_p, C.c_char_p]
+        # keys with their lengths (a key may hold a NUL byte: service_object.rs:19-26)
+        L.rio_op_update_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
+        L.rio_op_lookup_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.rio_op_remove_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.rio_op_get_or_create_placement_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p,
+                                                       C.c_size_t, C.POINTER(C.c_uint32)]
+        L.rio_op_snapshot_key_lengths.argtypes = [_vp, C.POINTER(C.POINTER(C.c_size_t)), C.POINTER(C.POINTER(C.c_size_t))]
         L.rio_op_len.argtypes = [_vp, C.POINTER(C.c_uint64)]
         L.rio_op_update_batch.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp]
         L.rio_op_lookup_batch.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp]
@@ -481,12 +489,12 @@ class GpuObjectPlacement:
     """Drop-in for LocalObjectPlacement (object_placement/local.rs): same five methods, same
     Option/None conventions; `clone()` shares the map like the Arc does."""
 
-    def __init__(self, max_objects=1 << 16, max_nodes=256, device=0, spill_rounds=2, _h=None):
+    def __init__(self, max_objects=1 << 16, max_nodes=256, device=0, spill_rounds=2, _h=None, flags=0):
         if _h is not None:
             self._h = _h
             return
         self._h = _vp()
-        cfg = OpCfg(C.sizeof(OpCfg), device, max_objects, max_nodes, spill_rounds, 0, 0)
+        cfg = OpCfg(C.sizeof(OpCfg), device, max_objects, max_nodes, spill_rounds, flags, 0)
         rc = _oplib().rio_op_create(C.byref(cfg), C.byref(self._h))
         if rc != OK:
             text = (_oplib().rio_op_last_error(None) or b"").decode()
@@ -513,8 +521,10 @@ class GpuObjectPlacement:
         self._chk(_oplib().rio_op_prepare(self._h))
 
     def update(self, struct_name, object_id, server_address):
+        """Keys travel with their lengths (rio_op_*_n): a NUL byte inside a key is part of the key."""
         a = None if server_address is None else server_address.encode()
-        self._chk(_oplib().rio_op_update(self._h, struct_name.encode(), object_id.encode(), a))
+        t, i = struct_name.encode(), object_id.encode()
+        self._chk(_oplib().rio_op_update_n(self._h, t, len(t), i, len(i), a))
 
     def lookup(self, struct_name, object_id, _cap=512):
         """Option<String> of any length (local.rs:42-49): a buffer that is too small is RIO_GP_ERANGE plus the length to
@@ -522,7 +532,8 @@ class GpuObjectPlacement:
         L, cap = _oplib(), _cap
         while True:
             buf, found = C.create_string_buffer(cap), C.c_int(0)
-            rc = L.rio_op_lookup(self._h, struct_name.encode(), object_id.encode(), buf, cap, C.byref(found))
+            t, i = struct_name.encode(), object_id.encode()
+            rc = L.rio_op_lookup_n(self._h, t, len(t), i, len(i), buf, cap, C.byref(found))
             if rc == ERANGE:
                 cap = int(L.rio_op_last_address_len(self._h)) + 1
                 continue
@@ -533,7 +544,8 @@ class GpuObjectPlacement:
         self._chk(_oplib().rio_op_clean_server(self._h, address.encode()))
 
     def remove(self, struct_name, object_id):
-        self._chk(_oplib().rio_op_remove(self._h, struct_name.encode(), object_id.encode()))
+        t, i = struct_name.encode(), object_id.encode()
+        self._chk(_oplib().rio_op_remove_n(self._h, t, len(t), i, len(i)))
 
     def __len__(self):
         out = C.c_uint64(0)
@@ -563,8 +575,9 @@ class GpuObjectPlacement:
 
     def get_or_create_placement(self, struct_name, object_id, self_address, _cap=512):
         buf, flag = C.create_string_buffer(_cap), C.c_uint32(0)
-        rc = _oplib().rio_op_get_or_create_placement(self._h, struct_name.encode(), object_id.encode(),
-                                                     self_address.encode(), buf, _cap, C.byref(flag))
+        t, i = struct_name.encode(), object_id.encode()
+        rc = _oplib().rio_op_get_or_create_placement_n(self._h, t, len(t), i, len(i), self_address.encode(), buf, _cap,
+                                                       C.byref(flag))
         if rc == ERANGE:  # the decision is made, the flag is set: the (long) address is one lookup away
             return self.lookup(struct_name, object_id), int(flag.value)
         self._chk(rc)
@@ -587,4 +600,8 @@ class GpuObjectPlacement:
         n = C.c_uint64(0)
         ty, oid, addr = C.POINTER(C.c_char_p)(), C.POINTER(C.c_char_p)(), C.POINTER(C.c_char_p)()
         self._chk(_oplib().rio_op_snapshot(self._h, C.byref(n), C.byref(ty), C.byref(oid), C.byref(addr)))
-        return [(ty[k].decode(), oid[k].decode(), addr[k].decode()) for k in range(n.value)]
+        tl, il = C.POINTER(C.c_size_t)(), C.POINTER(C.c_size_t)()
+        self._chk(_oplib().rio_op_snapshot_key_lengths(self._h, C.byref(tl), C.byref(il)))
+        tyv, idv = C.cast(ty, C.POINTER(C.c_void_p)), C.cast(oid, C.POINTER(C.c_void_p))   # (c_char_p would stop at a NUL)
+        return [(C.string_at(tyv[k], tl[k]).decode(), C.string_at(idv[k], il[k]).decode(), addr[k].decode())
+                for k in range(n.value)]

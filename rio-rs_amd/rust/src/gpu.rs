@@ -41,6 +41,7 @@ struct RioOpCfg {
 }
 
 const RIO_GP_OK: c_int = 0;
+const RIO_GP_CFG_REF_SELF_ASSIGN: u32 = 2; // include/rio_gpu_placement.h
 const RIO_GP_EINVAL: c_int = 1;
 /// the output buffer was too small: nothing is truncated, `rio_op_last_address_len` says what is needed
 const RIO_GP_ERANGE: c_int = 5;
@@ -70,19 +71,22 @@ extern "C" {
     fn rio_op_release(p: *mut c_void);
     fn rio_op_prepare(p: *mut c_void) -> c_int;
     fn rio_op_last_error(p: *mut c_void) -> *const c_char;
-    fn rio_op_update(p: *mut c_void, ty: *const c_char, id: *const c_char, addr: *const c_char) -> c_int;
-    fn rio_op_lookup(p: *mut c_void, ty: *const c_char, id: *const c_char, out: *mut c_char, cap: usize,
-                     found: *mut c_int) -> c_int;
+    // keys travel with their lengths (`_n`): a Rust String may hold a NUL byte (service_object.rs:19-26)
+    fn rio_op_update_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize,
+                       addr: *const c_char) -> c_int;
+    fn rio_op_lookup_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize,
+                       out: *mut c_char, cap: usize, found: *mut c_int) -> c_int;
     fn rio_op_last_address_len(p: *mut c_void) -> usize;
     fn rio_op_clean_server(p: *mut c_void, addr: *const c_char) -> c_int;
-    fn rio_op_remove(p: *mut c_void, ty: *const c_char, id: *const c_char) -> c_int;
+    fn rio_op_remove_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize) -> c_int;
     fn rio_op_set_member(p: *mut c_void, addr: *const c_char, active: c_int, capacity: u64) -> c_int;
     fn rio_op_tick(p: *mut c_void, stats: *mut RioGpStats) -> c_int;
     fn rio_op_snapshot(p: *mut c_void, n_out: *mut u64, tys: *mut *const *const c_char, ids: *mut *const *const c_char,
                        addrs: *mut *const *const c_char) -> c_int;
-    fn rio_op_get_or_create_placement(p: *mut c_void, ty: *const c_char, id: *const c_char,
-                                      self_addr: *const c_char, out: *mut c_char, cap: usize,
-                                      flag: *mut u32) -> c_int;
+    fn rio_op_snapshot_key_lengths(p: *mut c_void, ty_lens: *mut *const usize, id_lens: *mut *const usize) -> c_int;
+    fn rio_op_get_or_create_placement_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize,
+                                        self_addr: *const c_char, out: *mut c_char, cap: usize,
+                                        flag: *mut u32) -> c_int;
 }
 
 /// One reference on the shared native state; `Drop` releases it (the HBM tables go with the last).
@@ -118,10 +122,15 @@ impl GpuObjectPlacement {
         #[builder(default = 1 << 24)] max_objects: u64,
         #[builder(default = 4096)] max_nodes: u32,
         #[builder(default = 2)] spill_rounds: u32,
+        /// `true`: first touch goes to `self.address` whether or not membership marks it active, exactly like
+        /// `Service::get_or_create_placement` (service.rs:244-252); `false` (default): an inactive requester is not a
+        /// placement target and its first touches go to the water-fill (RIO_GP_CFG_REF_SELF_ASSIGN)
+        #[builder(default = false)] reference_self_assign: bool,
     ) -> Result<Self, ObjectPlacementError> {
         let cfg = RioOpCfg {
             struct_size: std::mem::size_of::<RioOpCfg>() as u32,
-            device, max_objects, max_nodes, spill_rounds, flags: 0, reserved: 0,
+            device, max_objects, max_nodes, spill_rounds,
+            flags: if reference_self_assign { RIO_GP_CFG_REF_SELF_ASSIGN } else { 0 }, reserved: 0,
         };
         let mut h: *mut c_void = std::ptr::null_mut();
         let rc = unsafe { rio_op_create(&cfg, &mut h) };
@@ -143,14 +152,15 @@ impl GpuObjectPlacement {
     /// lookup + is_active + clean_server + update.
     pub fn get_or_create_placement(&self, object_id: &ObjectId, self_address: &str)
         -> Result<(Option<String>, u32), ObjectPlacementError> {
-        let (ty, id, me) = (cstr(&object_id.0)?, cstr(&object_id.1)?, cstr(self_address)?);
+        let (ty, id, me) = (&object_id.0, &object_id.1, cstr(self_address)?);
         let mut buf = vec![0 as c_char; 512];
         let mut flag = 0u32;
-        let rc = unsafe { rio_op_get_or_create_placement(self.inner.0, ty.as_ptr(), id.as_ptr(), me.as_ptr(),
-                                                         buf.as_mut_ptr(), buf.len(), &mut flag) };
+        let rc = unsafe { rio_op_get_or_create_placement_n(self.inner.0, ty.as_ptr() as *const c_char, ty.len(),
+                                                           id.as_ptr() as *const c_char, id.len(), me.as_ptr(),
+                                                           buf.as_mut_ptr(), buf.len(), &mut flag) };
         if rc == RIO_GP_ERANGE {
             // the decision is made and `flag` is set; an address longer than the buffer is one lookup (a pure read) away
-            return Ok((lookup_owned(self, &ty, &id)?, flag));
+            return Ok((lookup_owned(self, ty, id)?, flag));
         }
         check(rc, self)?;
         let s = unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
@@ -174,19 +184,26 @@ impl GpuObjectPlacement {
     pub fn snapshot(&self) -> Result<Vec<(String, String, String)>, ObjectPlacementError> {
         let (mut n, mut ty, mut id, mut ad) = (0u64, std::ptr::null(), std::ptr::null(), std::ptr::null());
         check(unsafe { rio_op_snapshot(self.inner.0, &mut n, &mut ty, &mut id, &mut ad) }, self)?;
+        let (mut tl, mut il) = (std::ptr::null(), std::ptr::null());
+        check(unsafe { rio_op_snapshot_key_lengths(self.inner.0, &mut tl, &mut il) }, self)?;
         let s = |p: *const *const c_char, k: usize| unsafe { CStr::from_ptr(*p.add(k)).to_string_lossy().into_owned() };
-        Ok((0..n as usize).map(|k| (s(ty, k), s(id, k), s(ad, k))).collect())
+        // key parts by their true lengths (a NUL byte inside a key is part of the key)
+        let key = |p: *const *const c_char, l: *const usize, k: usize| unsafe {
+            String::from_utf8_lossy(std::slice::from_raw_parts(*p.add(k) as *const u8, *l.add(k))).into_owned()
+        };
+        Ok((0..n as usize).map(|k| (key(ty, tl, k), key(id, il, k), s(ad, k))).collect())
     }
 }
 
 /// `lookup` into an owned `String` of ANY length (local.rs:42-49 returns `Option<String>`): the native call never
 /// truncates — a buffer that is too small comes back as RIO_GP_ERANGE together with the length to allocate.
 /// Runs on the calling thread (`rio_op_last_address_len` is that thread's).
-fn lookup_owned(me: &GpuObjectPlacement, ty: &CString, id: &CString) -> Result<Option<String>, ObjectPlacementError> {
+fn lookup_owned(me: &GpuObjectPlacement, ty: &str, id: &str) -> Result<Option<String>, ObjectPlacementError> {
     let mut buf = vec![0 as c_char; 512];
     loop {
         let mut found: c_int = 0;
-        let rc = unsafe { rio_op_lookup(me.inner.0, ty.as_ptr(), id.as_ptr(), buf.as_mut_ptr(), buf.len(), &mut found) };
+        let rc = unsafe { rio_op_lookup_n(me.inner.0, ty.as_ptr() as *const c_char, ty.len(), id.as_ptr() as *const c_char,
+                                          id.len(), buf.as_mut_ptr(), buf.len(), &mut found) };
         if rc == RIO_GP_ERANGE {
             // (another writer may have moved the object to an even longer address meanwhile: loop)
             buf = vec![0 as c_char; unsafe { rio_op_last_address_len(me.inner.0) } + 1];
@@ -197,6 +214,7 @@ fn lookup_owned(me: &GpuObjectPlacement, ty: &CString, id: &CString) -> Result<O
     }
 }
 
+/// server addresses only ("{ip}:{port}" of a Member: no NUL byte can be part of one); object keys travel with their lengths
 fn cstr(s: &str) -> Result<CString, ObjectPlacementError> {
     CString::new(s).map_err(|e| ObjectPlacementError::Unknown(e.to_string()))
 }
@@ -233,8 +251,7 @@ impl ObjectPlacement for GpuObjectPlacement {
 
     // mod.rs:46-49 / local.rs:22-40
     async fn update(&self, object_placement: ObjectPlacementItem) -> Result<(), ObjectPlacementError> {
-        let ty = cstr(&object_placement.object_id.0)?;
-        let id = cstr(&object_placement.object_id.1)?;
+        let ObjectId(ty, id) = object_placement.object_id.clone();
         let addr = match &object_placement.server_address {
             Some(a) => Some(cstr(a)?),
             None => None, // None deletes (local.rs:36-37)
@@ -242,14 +259,15 @@ impl ObjectPlacement for GpuObjectPlacement {
         let me = self.clone();
         blocking(move || {
             let ap = addr.as_ref().map_or(std::ptr::null(), |a| a.as_ptr());
-            check(unsafe { rio_op_update(me.inner.0, ty.as_ptr(), id.as_ptr(), ap) }, &me)
+            check(unsafe { rio_op_update_n(me.inner.0, ty.as_ptr() as *const c_char, ty.len(), id.as_ptr() as *const c_char,
+                                           id.len(), ap) }, &me)
         })
         .await
     }
 
     // mod.rs:50 / local.rs:42-49: a miss is Ok(None)
     async fn lookup(&self, object_id: &ObjectId) -> Result<Option<String>, ObjectPlacementError> {
-        let (ty, id) = (cstr(&object_id.0)?, cstr(&object_id.1)?);
+        let (ty, id) = (object_id.0.clone(), object_id.1.clone());
         let me = self.clone();
         blocking(move || lookup_owned(&me, &ty, &id)).await
     }
@@ -263,15 +281,31 @@ impl ObjectPlacement for GpuObjectPlacement {
 
     // mod.rs:55 / local.rs:60-68
     async fn remove(&self, object_id: &ObjectId) -> Result<(), ObjectPlacementError> {
-        let (ty, id) = (cstr(&object_id.0)?, cstr(&object_id.1)?);
+        let (ty, id) = (object_id.0.clone(), object_id.1.clone());
         let me = self.clone();
-        blocking(move || check(unsafe { rio_op_remove(me.inner.0, ty.as_ptr(), id.as_ptr()) }, &me)).await
+        blocking(move || {
+            check(unsafe { rio_op_remove_n(me.inner.0, ty.as_ptr() as *const c_char, ty.len(), id.as_ptr() as *const c_char, id.len()) }, &me)
+        })
+        .await
     }
 }
 
 #[cfg(test)]
 mod test {
     use super::*;
+
+    // ObjectId holds any Rust string (service_object.rs:19-26): a NUL byte is part of the key, not its end
+    #[tokio::test]
+    async fn keys_with_an_interior_nul_are_distinct_keys() {
+        let p = GpuObjectPlacement::builder().build().unwrap();
+        let a = ObjectId("t".to_string(), "a\0b".to_string());
+        let b = ObjectId("t".to_string(), "a".to_string());
+        p.update(ObjectPlacementItem::new(a.clone(), Some("0.0.0.0:81".to_string()))).await.unwrap();
+        assert_eq!(p.lookup(&a).await.unwrap().as_deref(), Some("0.0.0.0:81"));
+        assert!(p.lookup(&b).await.unwrap().is_none());
+        p.remove(&a).await.unwrap();
+        assert!(p.lookup(&a).await.unwrap().is_none());
+    }
 
     // the same assertions as local.rs:71-123, against the GPU provider
     #[tokio::test]

@@ -13,7 +13,9 @@ def capacity_class(f):
     return 4 * e + ((f >> (e - 2)) & 3 if e >= 2 else (f << (2 - e)) & 3)
 
 
-def tick(cur, load, aff, cap, alive, rounds=2):
+def tick(cur, load, aff, cap, alive, rounds=2, self_assign=False):
+    """self_assign (RIO_GP_CFG_REF_SELF_ASSIGN): step 2 lets a pending row claim its affinity node whether or not that node is
+    alive, against the node's whole capacity (the reference's first touch asks nobody: service.rs:244-252)."""
     n, m = len(cur), len(cap)
     nxt = [NONE] * n
     used = [0] * m
@@ -27,7 +29,7 @@ def tick(cur, load, aff, cap, alive, rounds=2):
         else:
             pending.append(i)
     # 2. claim (first touch) with the strict prefix cut, node by node, claimants in index order
-    free = [max(int(cap[j]) - used[j], 0) if alive[j] else 0 for j in range(m)]
+    free = [max(int(cap[j]) - used[j], 0) if (alive[j] or self_assign) else 0 for j in range(m)]
     running = [0] * m
     closed = [False] * m
     rest = []
@@ -35,7 +37,7 @@ def tick(cur, load, aff, cap, alive, rounds=2):
         a = int(aff[i])
         if a == INACTIVE:
             continue                  # not an object: takes no part, stays NONE
-        if not up(a):
+        if not (up(a) or (self_assign and a < m)):
             rest.append(i)
             continue
         if not closed[a] and running[a] + int(load[i]) <= free[a]:
@@ -101,7 +103,7 @@ def _waterfill(rest, load_of, cap, alive, used, rounds, place):
     return rest
 
 
-def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2):
+def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2, self_assign=False):
     """The batched policy as include/rio_gpu_placement.h words it (service.rs:193-298 with capacity): in place on
     `assign` and `used` (python lists); returns (out_node, out_flag)."""
     m = len(cap)
@@ -114,7 +116,7 @@ def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2):
                 assign[r] = NONE
         for d in dead:
             used[d] = 0
-    free = [max(int(cap[j]) - used[j], 0) if alive[j] else 0 for j in range(m)]
+    free = [max(int(cap[j]) - used[j], 0) if (alive[j] or self_assign) else 0 for j in range(m)]
     run = [0] * m
     decided, how, rest = {}, {}, []
     for k, (i, r) in enumerate(zip(idx, requester)):
@@ -124,7 +126,7 @@ def place_pending(assign, load, cap, alive, used, idx, requester, rounds=2):
         if assign[i] != NONE:
             how[k] = "sticky"
             continue
-        if alive[r]:
+        if alive[r] or self_assign:            # (self_assign: the requester takes its first touch whatever membership says)
             run[r] += int(load[i])             # strict prefix: an overflow stays an overflow for everyone after it
             if run[r] <= free[r]:
                 how[k] = ("placed", r)

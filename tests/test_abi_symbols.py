@@ -158,6 +158,7 @@ _RUST_OF_C = {
     "rio_op_t*": "*mut c_void", "rio_gp_t*": "*mut c_void", "rio_op_t**": "*mut *mut c_void",
     "const rio_op_cfg*": "*const RioOpCfg", "rio_gp_stats*": "*mut RioGpStats",
     "const char*const**": "*mut *const *const c_char", "const char*const*": "*const *const c_char",
+    "const size_t**": "*mut *const usize",
 }
 
 
@@ -189,7 +190,8 @@ def test_rust_adapter_declares_the_same_signatures():
             assert ct in _RUST_OF_C, "%s: no Rust mapping known for C type %r" % (name, ct)
             assert _RUST_OF_C[ct] == rt, "%s parameter %d: header says %s (= %s), gpu.rs says %s" % (name, k, ct, _RUST_OF_C[ct], rt)
         assert _RUST_OF_C[cret] == ret, "%s return: header %s, gpu.rs %r" % (name, cret, ret)
-    for needed in ("rio_op_update", "rio_op_lookup", "rio_op_clean_server", "rio_op_remove", "rio_op_clone"):
+    # object keys travel with their lengths (a Rust String may hold a NUL byte: service_object.rs:19-26)
+    for needed in ("rio_op_update_n", "rio_op_lookup_n", "rio_op_clean_server", "rio_op_remove_n", "rio_op_clone"):
         assert needed in decls, needed
     # the trait impl itself: the five methods of ObjectPlacement, none of which may block an async worker
     for method in ("fn prepare", "fn update", "fn lookup", "fn clean_server", "fn remove"):

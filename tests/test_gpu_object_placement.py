@@ -108,6 +108,28 @@ def test_move_object_on_server_failure(gp):
     assert first != second                                             # assert_ne!(first_server, second_server)
 
 
+def test_keys_with_an_interior_nul_are_keys_of_their_own(gp):
+    """ObjectId(String, String) holds any Rust string (service_object.rs:19-26), a NUL byte included; the length-carrying
+    entry points (rio_op_*_n, what the Rust adapter and this binding use) keep such keys apart from their prefixes, through
+    every trait method, the policy call and the snapshot — and the NUL-terminated entry points still see the prefix only."""
+    import ctypes as C
+    p = gp.GpuObjectPlacement(max_objects=64, max_nodes=8)
+    p.set_member("h:1", True)
+    p.update("T", "a\0b", "h:1")
+    assert p.lookup("T", "a\0b") == "h:1" and p.lookup("T", "a") is None and p.lookup("T", "a\0c") is None
+    p.update("T\0x", "a", "h:2")                                   # ... in the struct name as well
+    assert p.lookup("T\0x", "a") == "h:2" and p.lookup("T", "a") is None
+    got, flag = p.get_or_create_placement("T", "a\0c", "h:1")
+    assert got == "h:1" and flag == gp.FLAG_PLACED and p.lookup("T", "a\0c") == "h:1"
+    assert sorted(p.snapshot()) == [("T", "a\0b", "h:1"), ("T", "a\0c", "h:1"), ("T\0x", "a", "h:2")]
+    p.remove("T", "a\0b")
+    assert p.lookup("T", "a\0b") is None and p.lookup("T", "a\0c") == "h:1" and len(p) == 2
+    # the NUL-terminated twin of the same call addresses the key that ends at the NUL
+    found, buf = C.c_int(0), C.create_string_buffer(64)
+    assert gp._oplib().rio_op_lookup(p._h, b"T", b"a\0c", buf, 64, C.byref(found)) == 0 and found.value == 0
+    p.close()
+
+
 # service.rs:213-223: a malformed record is removed (only that record) and the object re-placed
 def test_policy_bad_record_removed(gp, oracle):
     p, o = gp.GpuObjectPlacement(), oracle.LocalObjectPlacement()
@@ -122,13 +144,16 @@ def test_policy_bad_record_removed(gp, oracle):
     assert p.lookup("T", "y") == o.lookup("T", "y") == "nocolon"       # the other bad record is untouched
 
 
-@pytest.mark.parametrize("seed", [0, 1])
-def test_random_differential_vs_reference_restatement(gp, oracle, seed):
+@pytest.mark.parametrize("seed,self_assign", [(0, False), (1, False), (2, True), (3, True)])
+def test_random_differential_vs_reference_restatement(gp, oracle, seed, self_assign):
     """Random trait calls + policy requests: the GPU provider and the C++ restatement of
-    LocalObjectPlacement + service.rs policy must agree on every observable."""
+    LocalObjectPlacement + service.rs policy must agree on every observable.  self_assign: the provider is created with
+    RIO_GP_CFG_REF_SELF_ASSIGN and the requests come from ANY member, inactive ones included — the reference first-touches
+    the requester without asking whether it is active (service.rs:244-252), and so does the provider then."""
     rng = np.random.default_rng(seed)
     addrs = ["10.0.0.%d:%d" % (k, 5000 + k) for k in range(6)]
-    p, o, st = gp.GpuObjectPlacement(max_objects=2048, max_nodes=32), oracle.LocalObjectPlacement(), oracle.LocalStorage()
+    p = gp.GpuObjectPlacement(max_objects=2048, max_nodes=32, flags=gp.CFG_REF_SELF_ASSIGN if self_assign else 0)
+    o, st = oracle.LocalObjectPlacement(), oracle.LocalStorage()
     alive = [True] * len(addrs)
     for a in addrs:
         ip, port = a.split(":")
@@ -158,12 +183,13 @@ def test_random_differential_vs_reference_restatement(gp, oracle, seed):
             st.set_is_active(ip, port, alive[k])
             p.set_member(addrs[k], alive[k])
         elif r < 0.75:
-            me = addrs[int(rng.choice([k for k in range(len(addrs)) if alive[k]]))]
+            me = addrs[int(rng.choice([k for k in range(len(addrs)) if alive[k] or self_assign]))]
             got, flag = p.get_or_create_placement(ty, oid, me)
             want = oracle.get_or_create_placement(o, st, me, ty, oid)
             assert got == want, (step, ty, oid)
             verdict = oracle.check_address_mismatch(o, st, me, want)
-            assert verdict == ("ok" if flag & gp.FLAG_MASK in (gp.FLAG_LOCAL, gp.FLAG_PLACED) else "redirect")
+            if alive[addrs.index(want)] or want == me:   # (placed on an inactive requester other than me: the reference would clean it)
+                assert verdict == ("ok" if flag & gp.FLAG_MASK in (gp.FLAG_LOCAL, gp.FLAG_PLACED) else "redirect")
         else:
             assert p.lookup(ty, oid) == o.lookup(ty, oid), step
     for ty, oid in keys:

@@ -512,6 +512,74 @@ def test_tick_equals_reference_policy_capacity_infinite(gp, oracle):
         assert want == synth.node_address(int(got[i]))
 
 
+@pytest.mark.parametrize("seed,n,m", [(0, 3000, 12), (1, 200_000, 64), (2, 700_001, 1024)])
+def test_reference_self_assign_ticks_and_requests(gp, oracle, seed, n, m):
+    """RIO_GP_CFG_REF_SELF_ASSIGN (service.rs:244-252: the first touch asks nobody whether the requester is an active member):
+    pending rows claim their affinity node — requests their requester — whether or not it is alive, against its whole
+    capacity; rows on dead nodes are still evicted, the water-fill still places on live nodes only.  Whole-table solves in
+    every fix-up variant, committed ticks (the in-place scan included) and request batches through every path (one
+    workgroup, three launches, general, window-sorted), with finite capacities so that dead nodes are cut too — against the
+    oracle with the same flag; and with unbounded capacities against the string-level restatement of the reference itself."""
+    rng = np.random.default_rng(6600 + seed)
+    cur, load, aff, cap, alive = _rand_case(rng, n, m, p_none=0.4, cap_scale=1.1, p_alive=0.7, max_load=40)
+    flags = gp.CFG_REF_SELF_ASSIGN
+    want, used, ost = oracle.tick(cur, load, aff, cap, alive, 2, flags=oracle.REF_SELF_ASSIGN)
+    assert int((alive[want[want != NONE]] == 0).sum()) > 0            # rows really are claimed onto dead nodes
+    for mode in (None,) + FIXUP_VARIANTS:
+        g = gp.GpuPlacement(n, m, flags=flags, lab=mode is not None)
+        g.set_nodes(cap, alive)
+        g.set_objects(n, load, aff)
+        g.set_assign(cur)
+        if mode is not None:
+            g.set_compact("never" if mode[0] == "cutpack" else mode[0], cut_pack="always" if mode[0] == "cutpack" else "never")
+            g.set_speculate(mode[1])
+        assert g.solve() == ost, mode
+        assert np.array_equal(g.get_solved(), want), mode
+        g.commit()
+        assert np.array_equal(g.get_nodes()[2], used), mode
+        # committed ticks with liveness flips behind it (the in-place scan when the rule picks it: rows on dead nodes are
+        # evicted and claim their dead affinity nodes again)
+        ref = want
+        for t in range(3):
+            mask = (np.random.default_rng(70 + t).random(m) < 0.75).astype(np.uint8)
+            g.set_alive_all(mask)
+            ref, u2, o2 = oracle.tick(ref, load, aff, cap, mask, 2, flags=oracle.REF_SELF_ASSIGN)
+            assert g.tick() == o2, (mode, t)
+            assert np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], u2), (mode, t)
+        g.close()
+    # request batches: requesters are ANY member, dead ones included
+    g = gp.GpuPlacement(n, m, flags=flags)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    uref = np.zeros(m, np.uint64)
+    for k in (3, 200, 900, 3000, 4096, 20_000, min(n, 300_000)):
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        req = rng.integers(0, m, k).astype(np.uint32)
+        node, flag = g.place_pending(idx, req)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, uref, idx, req, flags=oracle.REF_SELF_ASSIGN)
+        assert np.array_equal(node, wnode) and np.array_equal(flag, wflag), k
+        assert np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], uref), k
+    g.close()
+    # unbounded capacities, one request per object, inactive requesters that hold nothing when the batch starts: the
+    # reference's own map, read back (tests/test_reference_port_readback.py has the reasoning)
+    if n <= 200_000:
+        dead = np.flatnonzero(alive == 0)
+        senders = np.concatenate([np.flatnonzero(alive), dead[::2]])
+        aff2 = senders[rng.integers(0, len(senders), n)].astype(np.uint32)
+        cur2 = cur.copy()
+        cur2[np.isin(cur2, dead[::2])] = NONE
+        ones = np.ones(n, np.uint32)
+        _, port = oracle.policy_readback(n, m, aff2, alive, cur2)
+        g = gp.GpuPlacement(n, m, flags=flags)
+        g.set_nodes(np.full(m, INF, np.uint64), alive)
+        g.set_objects(n, ones, aff2)
+        g.set_assign(cur2)
+        g.tick()
+        assert np.array_equal(g.get_assign(), port)
+        g.close()
+
+
 def test_reference_port_read_back_against_the_gpu_at_1m(gp, oracle):
     """ONE hop to the reference's own semantics at a size that means something: 1 M objects x 256 nodes, a warm table with
     unplaced objects, 15 % of the nodes dead.  The string-level restatement of LocalObjectPlacement +

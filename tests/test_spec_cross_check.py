@@ -35,6 +35,10 @@ def test_c_oracle_equals_the_written_specification(oracle, seed):
     got, gused = spec_tick.tick(cur.tolist(), load.tolist(), aff.tolist(), cap.tolist(), alive.tolist(), rounds)
     assert got == want.tolist()
     assert gused == used.tolist()
+    # ... and under RIO_GP_CFG_REF_SELF_ASSIGN (a claim does not need an active node: service.rs:244-252)
+    want_sa, used_sa, _ = oracle.tick(cur, load, aff, cap, alive, rounds, flags=oracle.REF_SELF_ASSIGN)
+    got_sa, gused_sa = spec_tick.tick(cur.tolist(), load.tolist(), aff.tolist(), cap.tolist(), alive.tolist(), rounds, self_assign=True)
+    assert got_sa == want_sa.tolist() and gused_sa == used_sa.tolist()
     placed = [g != NONE for g in got]
     inactive = sum(1 for i in range(n) if aff[i] == spec_tick.INACTIVE and got[i] == NONE)
     assert st["n_objects"] == n - inactive
@@ -68,4 +72,10 @@ def test_c_oracle_place_pending_equals_the_written_contract(oracle, seed):
     a1, u1 = assign.copy(), used.copy()
     onode, oflag = oracle.place_pending(a1, load, cap, alive, u1, idx, req, rounds)
     assert onode.tolist() == snode and oflag.tolist() == sflag
+    a3, u3 = assign.tolist(), [int(x) for x in used]
+    snode, sflag = spec_tick.place_pending(a3, load.tolist(), cap.tolist(), alive.tolist(), u3, idx.tolist(), req.tolist(), rounds,
+                                           self_assign=True)
+    a4, u4 = assign.copy(), used.copy()
+    onode, oflag = oracle.place_pending(a4, load, cap, alive, u4, idx, req, rounds, flags=oracle.REF_SELF_ASSIGN)
+    assert onode.tolist() == snode and oflag.tolist() == sflag and a4.tolist() == a3 and u4.tolist() == u3
     assert a1.tolist() == a2 and [int(x) for x in u1] == u2
