@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copy the summaries of one evidence pass (tools/round3_pass.sh <tag>, merged back under gpurun_out/) into profiles/ under
+"""Copy the summaries of one evidence pass (tools/round4_pass.sh <tag>, merged back under gpurun_out/) into profiles/ under
 the round prefix: gpurun_out/ is scratch, profiles/ is tracked.  Usage: collect_profiles.py <tag> [round-prefix]"""
 import glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pre = sys.argv[2] if len(sys.argv) > 2 else "round3"
+pre = sys.argv[2] if len(sys.argv) > 2 else "round4"
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 def cp(a, b):
     a = os.path.join(src, a)
@@ -14,7 +14,8 @@ def cp(a, b):
 for name in ("bench_n1.json", "bench_c5.json", "kernel_roofline.json", "kernel_roofline.txt", "churn_timeline.txt",
              "ops.json", "pytest_gpu.log", "smoke.log", "slowpath_churn.json", "slowpath_contended.json", "slowpath_skew.json",
              "latency.txt", "place_pending.json", "place_pending_timeline.txt", "clean.json",
-             "bench_sharded_2ranks_one_gpu.json", "bench_sharded_8ranks_one_gpu.json"):
+             "bench_sharded_2ranks_one_gpu.json", "bench_sharded_8ranks_one_gpu.json", "c5_variants.json", "fill_trace.json",
+             "pp_host_batches.txt", "c4_tick.json"):
     cp("%s_%s" % (tag, name), "%s_%s" % (pre, name))
 cp("crud_ab.json", pre + "_crud_ab.json")
 for f in glob.glob(os.path.join(src, tag + "_prof", "*kernel_stats.csv")):

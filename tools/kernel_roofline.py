@@ -41,7 +41,12 @@ def specs(pending_rows):
     return [
         ("fast", r"k_scan<false, true, 2, 0", "k_scan (fast path, TPI 2)", 16 * N, "12 B read + 4 B written per row"),
         ("fast", r"k_resolve", "k_resolve", 2 * M * 8 * 256, "H: 2m u64 per block x 256 blocks"),
-        ("churn", r"k_scan<false, false, 1, 2", "k_scan<COMPACT> (churn tick)", 16 * N + 16 * pk, "16 B/row + 16 B per packed pending row"),
+        ("churn", r"k_inc_scan<2, false>", "k_inc_scan (churn tick: in place, no histogram)", 16 * N, "SURVEY 8d's tick figure, 16 B/row; the kernel itself moves 12 B/row + 12 B per packed pending row + the changed vectors"),
+        ("churn", r"k_rebal", "k_rebal (pending rows dealt out evenly + per-block histograms)", 28 * pk + 2 * M * 8 * 256, "12 B in + 16 B out per pending row, H"),
+        ("churn_noinc", r"k_scan<false, false, 1, 2", "k_scan<COMPACT> (churn tick, in-place scan switched off)", 16 * N + 16 * pk, "16 B/row + 16 B per packed pending row"),
+        ("churn_noinc", r"k_resolve<true>", "k_resolve<SEARCH> (row-range layout)", 2 * M * 8 * 256 + 8 * pk, "H + affinity and load of the packed pending rows"),
+        ("churn_noinc", r"k_fill<true, true, true, false>", "k_fill round 0 (row-range layout)", 24 * pk, "as below"),
+        ("churn_noinc", r"k_fill<false, false, true, false>", "k_fill round 1 (row-range layout)", 12 * pk, "as below"),
         ("churn", r"k_resolve<true>", "k_resolve<SEARCH> (column sums + exact cuts over the packed rows)", 2 * M * 8 * 256 + 8 * pk, "H + affinity and load of the packed pending rows"),
         ("churn", r"k_fill<true, true, true, false>", "k_fill round 0 (packed rows: re-mark, node order, water-fill)", 24 * pk, "pass A cur/aff/load + pass B next/load/idx of the packed rows (+4 B per placed row)"),
         ("churn", r"k_fill<false, false, true, false>", "k_fill round 1 (packed rows)", 12 * pk, "next + load + idx of the packed rows (upper bound: most are placed by round 0)"),
@@ -74,7 +79,10 @@ def specs(pending_rows):
         ("pp10", r"k_pp_split", "k_pp_split (10 M requests)", 16 * 10000000, "8 B in, 8 B out per request"),
         ("pp10", r"k_scan<true, true, 1, 3", "k_scan<VIRT, scatter> (10 M requests)", 24 * 10000000, "16 B per virtual row + the object column + one 4-byte store per first touch"),
         ("pp10", r"k_pp_win_output", "k_pp_win_output (10 M requests)", 28 * 10000000, "five columns in, node + flag out"),
-        ("pp_small", r"k_pp_one<1024, 4>", "k_pp_one (4 096 host-buffer requests, one launch)", 28 * 4096, "idx + requester in over PCIe, node + flag out, the rows"),
+        ("pp_small", r"k_pp_stage", "k_pp_stage (4 096 host-buffer requests: requests + rows -> staging table)", 12 * 4096, "idx + requester in over PCIe, the rows"),
+        ("pp_small", r"k_pp_decide", "k_pp_decide (one workgroup: the decision over the staged records)", 40 * 4096, "32 B staged record in, 8 B result out"),
+        ("pp_small", r"k_pp_apply", "k_pp_apply (results out over PCIe, first touches into the column)", 16 * 4096, "8 B result in, node + flag out"),
+        ("pp_1000", r"k_pp_one<1024, 4>", "k_pp_one (1 000 host-buffer requests, one launch)", 28 * 1000, "idx + requester in over PCIe, node + flag out, the rows"),
     ]
 
 

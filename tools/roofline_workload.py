@@ -2,7 +2,7 @@
 """One PHASE of the hot path per process, for the rocprofv3 passes of tools/kernel_roofline.sh (kernel trace + the two PMC
 passes): every kernel DESIGN.md section 4 names runs in exactly one phase with known algorithmic bytes, so that its
 duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round3_kernel_roofline.json).
-Usage: roofline_workload.py <fast|churn|churn_unpacked|contended|contended_packed|crud|crud_plain|lookup_seq|clean1|pp|pp10|pp_small|probes> [reps]"""
+Usage: roofline_workload.py <fast|churn|churn_noinc|churn_unpacked|contended|contended_packed|crud|crud_plain|lookup_seq|clean1|pp|pp10|pp_small|probes> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -21,9 +21,11 @@ if phase == "fast":                      # k_scan<.., TPI 2>, k_resolve
     for _ in range(reps * 3):
         g.solve_async()
     g.solve_wait()
-elif phase in ("churn", "churn_unpacked"):   # k_scan<COMPACT>, k_resolve<SEARCH>, k_fill round 0 / round 1 (packed rows)
+elif phase in ("churn", "churn_noinc", "churn_unpacked"):   # k_inc_scan + k_rebal (or k_scan<COMPACT>), k_resolve<SEARCH>, k_fill rounds
     if phase == "churn_unpacked":
         g.set_compact("never", cut_pack="never")
+    if phase == "churn_noinc":
+        g.set_compact("auto", inc="never")
     g.set_assign(synth.warm_assign(n, m))
     g.tick()
     for k in range(reps + 2):
@@ -39,7 +41,7 @@ elif phase in ("contended", "contended_packed"):   # the same fix-up kernels ove
     g.set_compact("auto", cut_pack="always" if phase == "contended_packed" else "never")
     for _ in range(reps):
         g.solve()
-elif phase in ("crud", "crud_plain", "pp", "pp10", "pp_small", "clean1", "lookup_seq"):
+elif phase in ("crud", "crud_plain", "pp", "pp10", "pp_small", "pp_1000", "clean1", "lookup_seq"):
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from hipbuf import DevBuf
@@ -71,8 +73,9 @@ elif phase in ("crud", "crud_plain", "pp", "pp10", "pp_small", "clean1", "lookup
             g.set_assign(synth.warm_assign(n, m))
             g.get_nodes()
             g.clean_server(3 + k)
-    elif phase == "pp_small":            # k_pp_one: 4 096 requests from host buffers, first touch then sticky
-        ii = (synth.r(np.arange(4096, dtype=np.uint64), 7) % np.uint64(n)).astype(np.uint32)
+    elif phase in ("pp_small", "pp_1000"):   # 4 096 requests (three launches) / 1 000 (k_pp_one) from host buffers, first touch then sticky
+        kk = 4096 if phase == "pp_small" else 1000
+        ii = (synth.r(np.arange(kk, dtype=np.uint64), 7) % np.uint64(n)).astype(np.uint32)
         rq = cfg["aff"][ii]
         for _ in range(reps):
             g.place_pending(ii, rq)

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-tick timeline from a rocprofv3 kernel trace of the churn stream: for the last ticks, every kernel's start offset
-(from the tick's first kernel), duration and the idle gap before it.  A tick starts at each k_scan launch."""
+(from the tick's first kernel), duration and the idle gap before it.  A tick starts at each k_scan / k_inc_scan launch."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ticks, cur = [], None
 for r in rows:
     name = r["Kernel_Name"].replace("void ", "").replace("riogp::", "").split("(")[0]
-    if name.startswith("k_scan"):
+    if name.startswith("k_scan") or name.startswith("k_inc_scan"):
         cur = []
         ticks.append(cur)
     if cur is not None:
