@@ -220,6 +220,7 @@ __device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv, u32
 //     on a live node and takes no part otherwise — neither claimant nor spill candidate.
 // ------------------------------------------------------------------------------------------------
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // four consecutive words at any word address
 constexpr u32 kStageCap = 320;  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
 
 // NT: non-temporal column streams for tables beyond the 256 MiB Infinity Cache (measured +1-2 % at 40-100 M rows and
@@ -584,6 +585,11 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
     u32 st_head = 0, st_fill = 0;
     const u64 lt = (1ull << lane) - 1ull;
 
+#ifdef RIO_GP_LAB   // timing experiments only (results are wrong): trace flag bit 1 = no packing, bit 2 = no in-place stores
+    const bool dbg_nopack = (p.trace & 2u) != 0, dbg_nostore = (p.trace & 4u) != 0;
+#else
+    constexpr bool dbg_nopack = false, dbg_nostore = false;
+#endif
     // one tile: classify, write the lane's vector back if a row of it changed, pack the rows that go on
     auto tile = [&](const uint4 c, const uint4 a, const uint4 l, const u64 i0) {
         uint4 ov = c;
@@ -610,7 +616,8 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
         RIOGP_ROW(c.z, a.z, l.z, ov.z, 2)
         RIOGP_ROW(c.w, a.w, l.w, ov.w, 3)
 #undef RIOGP_ROW
-        if (chg) *reinterpret_cast<uint4*>(assign + i0) = ov;  // (a lane's rows past the end of the table are padding)
+        if (chg && !dbg_nostore) *reinterpret_cast<uint4*>(assign + i0) = ov;  // (a lane's rows past the end of the table are padding)
+        if (dbg_nopack) km = 0;
         const u64 b0 = __ballot(km & 1u), b1 = __ballot(km & 2u), b2 = __ballot(km & 4u), b3 = __ballot(km & 8u);
         if (b0 | b1 | b2 | b3) {  // (wave-uniform) index order = lane-major, then element
             u32 e = st_head + st_fill + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
@@ -775,13 +782,24 @@ __global__ __launch_bounds__(kBlock) void k_rebal(const u32* __restrict__ s_idx,
             s = lo;
         }
         u32 ix[4] = {0, 0, 0, 0}, ld[4] = {0, 0, 0, 0}, af[4] = {kNone, kNone, kNone, kNone};
+        if (d + 3u < (u32)dhi && d + 3u < pre[s + 1 < nw ? s + 1 : nw]) {
+            // the lane's four rows lie in ONE source wave's piece (the rule on big tables, where a wave range holds thousands
+            // of pending rows): three 16-byte reads at a 4-byte-aligned address instead of twelve 4-byte ones
+            const u64 at = wave_row_lo(p, s) + (d - pre[s]);
+            const u32x4u vi = *reinterpret_cast<const u32x4u*>(s_idx + at), vl = *reinterpret_cast<const u32x4u*>(s_load + at),
+                         va = *reinterpret_cast<const u32x4u*>(s_aff + at);
+            ix[0] = vi.x; ix[1] = vi.y; ix[2] = vi.z; ix[3] = vi.w;
+            ld[0] = vl.x; ld[1] = vl.y; ld[2] = vl.z; ld[3] = vl.w;
+            af[0] = va.x; af[1] = va.y; af[2] = va.z; af[3] = va.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const u32 de = d + (u32)e;
-            if (de < (u32)dhi) {
-                while (s + 1 < nw && pre[s + 1] <= de) ++s;  // (source waves without rows are stepped over)
-                const u64 at = wave_row_lo(p, s) + (de - pre[s]);
-                ix[e] = s_idx[at]; ld[e] = s_load[at]; af[e] = s_aff[at];
+            for (int e = 0; e < 4; ++e) {
+                const u32 de = d + (u32)e;
+                if (de < (u32)dhi) {
+                    while (s + 1 < nw && pre[s + 1] <= de) ++s;  // (source waves without rows are stepped over)
+                    const u64 at = wave_row_lo(p, s) + (de - pre[s]);
+                    ix[e] = s_idx[at]; ld[e] = s_load[at]; af[e] = s_aff[at];
+                }
             }
         }
         uint4 nx = make_uint4(kNone, kNone, kNone, kNone);
@@ -4086,7 +4104,12 @@ static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, cons
 constexpr u64 kScanNtRows = (u64)20 << 20;  // 16 B/row * 20 Mi rows = 320 MiB of columns
 int g_scan_nt_mode = 0;  // 0 by size | 1 always | 2 never (lab builds: rio_gp_debug_set_scan_nt, A/B runs)
 int g_scan_stage = 1;    // packing through LDS rings (0: straight from registers; lab builds, A/B runs)
-void set_scan_nt(int mode) { g_scan_nt_mode = mode & 3; g_scan_stage = (mode & 16) ? 0 : 1; }
+int g_inc_tpi = 2;       // tiles per wave-iteration of k_inc_scan: 1 | 2 | 4 (lab builds: bits 5-6 of rio_gp_debug_set_scan_nt, A/B runs)
+void set_scan_nt(int mode) {
+    g_scan_nt_mode = mode & 3;
+    g_scan_stage = (mode & 16) ? 0 : 1;
+    g_inc_tpi = ((mode >> 5) & 3) == 1 ? 1 : ((mode >> 5) & 3) == 2 ? 4 : 2;
+}
 
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
                  hipStream_t s, hipEvent_t e0, hipEvent_t e1, const PackOut* pack) {
@@ -4133,12 +4156,13 @@ void launch_inc_scan(const Plan& p, u32* assign, const u32* load, const u32* aff
     pp.wcnt = nullptr;
     pp.alive_dst = nt.alive_src ? const_cast<u32*>(nt.alive_bits) : nullptr;
     const u32* abits = nt.alive_src ? nt.alive_src : nt.alive_bits;
-    if (g_scan_nt_mode == 1 || (g_scan_nt_mode == 0 && p.n >= kScanNtRows))
-        hipLaunchKernelGGL((k_inc_scan<2, true>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.blkstat, b.stats,
-                           pack, b.fx, b.R, b.RP);
-    else
-        hipLaunchKernelGGL((k_inc_scan<2, false>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, b.blkstat, b.stats,
-                           pack, b.fx, b.R, b.RP);
+    const bool ntl = g_scan_nt_mode == 1 || (g_scan_nt_mode == 0 && p.n >= kScanNtRows);
+#define RIOGP_INC(TPI_, NT_) hipLaunchKernelGGL((k_inc_scan<TPI_, NT_>), dim3(p.G), dim3(kBlock), lds, s, assign, load, aff, abits, pp, \
+                                                b.blkstat, b.stats, pack, b.fx, b.R, b.RP)
+    if (g_inc_tpi == 1) { if (ntl) RIOGP_INC(1, true); else RIOGP_INC(1, false); }
+    else if (g_inc_tpi == 4) { if (ntl) RIOGP_INC(4, true); else RIOGP_INC(4, false); }
+    else { if (ntl) RIOGP_INC(2, true); else RIOGP_INC(2, false); }
+#undef RIOGP_INC
 }
 // The balanced table of the rows k_inc_scan packed: uniform wave ranges of ceil(tiles / nw) tiles each, as many
 // waves and blocks as the real table's plan (the columns hold rebal_rows(p) rows + the usual padding).

@@ -490,6 +490,11 @@ int commit_enqueue(rio_gp* h) {
 // the kept histogram, and the rings of pending rows must fit the LDS next to the liveness bitmap.
 int inc_choice(rio_gp* h, bool compact, bool commit) {
     if (!compact || !commit || !h->used_valid || h->inc_mode == 2 || !inc_scan_fits(h->m) || h->m == 0) return 0;
+    // Tables whose blocks are beyond the in-resolve cut search (config 4 on one GPU: 390 K rows a block) keep k_scan<COMPACT>:
+    // measured there (100 M x 4 096, same box) k_inc_scan 352-397 us against 413, but k_rebal adds 63-76 us and the tick's
+    // largest part — round 0's 8 M scattered decision stores into a 400 MB column — does not care how the rows are dealt out:
+    // 794-844 us pipelined against 771-776.  (lab builds: inc "always" keeps the path for A/B runs)
+    if (h->inc_mode != 1 && h->plan.G && h->n / h->plan.G > kSearchMaxBlockRows) return 0;
     return 2;
 }
 
@@ -2273,7 +2278,8 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
     h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
     h->compact_mode = mode & 15;
-    h->inc_mode = ((mode >> 7) & 3) == 2 ? 2 : 0;  // bits 7-8: in-place scan of committed ticks, 0 auto | 2 never
+    h->inc_mode = (mode >> 7) & 3;       // bits 7-8: in-place scan of committed ticks, 0 auto | 1 whatever the table's size | 2 never
+    if (h->inc_mode == 3) h->inc_mode = 0;
     return RIO_GP_OK;
 }
 

@@ -153,6 +153,17 @@ def test_config4_one_gpu_at_100m(gp, oracle):
     assert np.array_equal(g.get_assign(), want)
     assert np.array_equal(g.get_nodes()[2], used)
     g.close()
+    # the same size through the in-place scan + k_rebal (the product keeps k_scan<COMPACT> on tables whose blocks are too big
+    # for the in-resolve cut search; the lab build's "always" runs it there too: the cuts of the balanced rows are then found
+    # by k_cut_find over the packed table)
+    gl = _mk(gp, cfg, cur=want, lab=True)
+    gl.set_compact("always", inc="always")
+    alive2 = synth.churn_mask(cfg["m"], 4)
+    gl.set_alive_all(alive2)
+    want2, used2, ost2 = oracle.tick(want, cfg["load"], cfg["aff"], cfg["cap"], alive2, 2)
+    assert gl.tick() == ost2
+    assert np.array_equal(gl.get_assign(), want2) and np.array_equal(gl.get_nodes()[2], used2)
+    gl.close()
 
 
 def test_config4_as_8_row_shards(gp, oracle):

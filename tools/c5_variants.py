@@ -18,6 +18,8 @@ import numpy as np  # noqa: E402
 import rio_gp  # noqa: E402
 import synth  # noqa: E402
 
+if os.environ.get("RIO_NT"):   # non-temporal column streams of the scans: 0 by table size | 1 always | 2 never (A/B runs)
+    rio_gp.lab_lib().rio_gp_debug_set_scan_nt(int(os.environ["RIO_NT"]))
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 warm_ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 cfg = synth.config(sys.argv[3] if len(sys.argv) > 3 else "c3")
@@ -39,12 +41,26 @@ for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "auto")):
         g.tick_async()
     g.tick_wait()
     g.sync()
+    if os.environ.get("RIO_INC_DEBUG"):   # timing experiments (results wrong): 2 no packing | 4 no in-place stores | 6 both
+        import ctypes as C
+        rio_gp.lab_lib().rio_gp_debug_ktrace(g.handle, int(os.environ["RIO_INC_DEBUG"]), 0, None)
     t0 = time.perf_counter()
     for _ in range(ticks):
         g.set_alive_all(masks[k]); k += 1
         g.tick_async()
-    sts = g.tick_wait()
+    try:
+        sts = g.tick_wait()
+    except Exception as e:
+        sts = [{"error": repr(e)}]
     dtp = time.perf_counter() - t0
+    if os.environ.get("RIO_INC_DEBUG"):
+        tr = g.ktrace(True, 3).astype(np.int64)
+        rows = tr[tr[:, 0] > 0]
+        out[inc] = {"pipelined_us": dtp / ticks * 1e6, "debug": os.environ["RIO_INC_DEBUG"],
+                    "scan_wg_median_us": float(np.median((rows[:, 7] - rows[:, 0]) / 100.0)),
+                    "scan_span_us": float((rows[:, 7].max() - rows[:, 0].min()) / 100.0),
+                    "scan_loop_end_median_us": float(np.median((rows[:, 2] - rows[:, 0]) / 100.0))}
+        os._exit(0 if not print(json.dumps(out)) else 0)
     t0 = time.perf_counter()
     for _ in range(ticks):
         g.set_alive_all(masks[k]); k += 1
