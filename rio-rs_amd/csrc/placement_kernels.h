@@ -147,6 +147,11 @@ struct Table {
     // the packing pass has already stored NONE into the real row of every packed row (k_cut_apply_rank<PACK>): the last
     // round then writes only the rows it places, not one scattered NONE per row it could not place
     bool none_prewritten = false;
+    // virtual table of a window-sorted request batch (k_pp_win_gather): its rows arrive as 8-byte records {cur | load} — the
+    // scan reads them and leaves cur / load as columns for the kernels behind it — and the alive requesters' first touches
+    // are already in the real column (the scan stores only those whose requester is not alive: RIO_GP_CFG_REF_SELF_ASSIGN)
+    const uint2* vrec = nullptr;
+    bool prewritten = false;
 };
 
 struct NodeTab {
@@ -280,7 +285,7 @@ void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const
 // place_pending over a window-sorted batch (big batches): see k_pp_win_gather.  scratch = part_scratch_words(n_obj, n) words.
 bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req);
 void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s);
-void launch_pp_win_gather(const u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
+void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
                           uint2* vrec, u32* vcur, u32* vload, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st,
                           hipStream_t s);
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,

@@ -253,7 +253,10 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
                                           const uint4 xv = make_uint4(0, 0, 0, 0), const u32 sa = 0) {
     // COMPACT == 3 (virtual table of a big place_pending batch): rows are requests, xv = the objects they ask for; a claimant's
     // optimistic node also goes straight into the REAL assignment column, pk->next[object] (one scattered store per first touch:
-    // the fix-up patches the same rows through the same indices, so no pass carries the decisions back afterwards)
+    // the fix-up patches the same rows through the same indices, so no pass carries the decisions back afterwards) — unless
+    // the window kernel has already written it there, densely (pk->load != nullptr: k_pp_win_gather writes the requester of
+    // every pending row's first request when that requester is ALIVE; a requester that is not — RIO_GP_CFG_REF_SELF_ASSIGN —
+    // must wait for clean_server, which runs between the two kernels, and is stored here)
     uint4 ov;
     u64 sp_local = 0;
     u32 any_sp = 0, pm = 0;
@@ -276,7 +279,7 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         sp_local += sp ? (u64)L : 0;                                                                   \
         any_sp |= sp;                                                                                  \
         if (COMPACT == 1 || COMPACT == 2) pm |= (u32)(cl | sp) << E;                                   \
-        if (COMPACT == 3 && cl) pk->next[X] = A;                                                       \
+        if (COMPACT == 3 && cl && !(pk->load && (ALLALIVE || bit_of(alv, aa)))) pk->next[X] = A;      \
     }
     RIOGP_ROW(cv.x, av.x, lv.x, ov.x, 0, xv.x)
     RIOGP_ROW(cv.y, av.y, lv.y, ov.y, 1, xv.y)
@@ -385,16 +388,31 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     // first group of loads goes out BEFORE the LDS set-up and its barrier: HBM latency overlaps both
     u64 it = wstart;
     uint4 cv[TPI], av[TPI], lv[TPI], xv[TPI];  // (xv: COMPACT == 3 only — the objects the rows of a virtual table ask for)
+    // COMPACT == 3 with pko.aff set: the virtual table arrives as 8-byte records {cur | load} (k_pp_win_gather's vrec); the
+    // two halves of a lane's 32 bytes travel in cv / lv, are told apart where they are used, and leave again as the two
+    // columns `cur` / `load` the kernels behind this one read (what a split pass of its own did: 28 us per 10 M requests)
+    const bool vrec = COMPACT == 3 && pko.aff != nullptr;
+    const u32* const csrc = vrec ? pko.aff : cur;
+    const u32* const lsrc = vrec ? pko.aff + 4 : load;
+    const int vsh = vrec ? 1 : 0;  // (records: 2 words per row)
     if (it < wgrp) {
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u64 i = it + (u64)q * kTile + (u64)lane * 4;
-            cv[q] = ld4<NT>(cur + i);
+            cv[q] = ld4<NT>(csrc + (i << vsh));
             av[q] = ld4<NT>(aff + i);
-            lv[q] = ld4<NT>(load + i);
+            lv[q] = ld4<NT>(lsrc + (i << vsh));
             if (COMPACT == 3) xv[q] = ld4<NT>(pko.idx + i);
         }
     }
+    auto unrec = [&](uint4& c, uint4& l, const u64 i) {  // records -> columns (and out to the column arrays)
+        if (!vrec) return;
+        const uint4 a = c, b = l;
+        c = make_uint4(a.x, a.z, b.x, b.z);
+        l = make_uint4(a.y, a.w, b.y, b.w);
+        *reinterpret_cast<uint4*>(const_cast<u32*>(cur) + i) = c;
+        *reinterpret_cast<uint4*>(const_cast<u32*>(load) + i) = l;
+    };
 
     for (u32 k = tid; k < 2 * m + 2; k += kBlock) hist[k] = 0;
     if (!ALLALIVE || (p.alive_dst && blockIdx.x == 0))
@@ -441,27 +459,30 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
-            cn[q] = ld4<NT>(cur + i);
+            cn[q] = ld4<NT>(csrc + (i << vsh));
             an[q] = ld4<NT>(aff + i);
-            ln[q] = ld4<NT>(load + i);
+            ln[q] = ld4<NT>(lsrc + (i << vsh));
             if (COMPACT == 3) xn[q] = ld4<NT>(pko.idx + i);
         }
 #pragma unroll
-        for (int q = 0; q < TPI; ++q)
+        for (int q = 0; q < TPI; ++q) {
+            if (COMPACT == 3) unrec(cv[q], lv[q], it + (u64)q * kTile + (u64)lane * 4);
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
                                                           m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
                                                           claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill,
                                                           COMPACT == 3 ? xv[q] : make_uint4(0, 0, 0, 0), p.sa);
+        }
         it = nit;
 #pragma unroll
         for (int q = 0; q < TPI; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; if (COMPACT == 3) xv[q] = xn[q]; }
     }
     for (; it < wend; it += kTile) {  // leftover full tiles (< TPI) and the ragged last tile of the table
         const u64 i = it + (u64)lane * 4;
-        const uint4 c1 = *reinterpret_cast<const uint4*>(cur + i);
+        uint4 c1 = *reinterpret_cast<const uint4*>(csrc + (i << vsh));
         const uint4 a1 = *reinterpret_cast<const uint4*>(aff + i);
-        const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
+        uint4 l1 = *reinterpret_cast<const uint4*>(lsrc + (i << vsh));
         const uint4 x1 = COMPACT == 3 ? *reinterpret_cast<const uint4*>(pko.idx + i) : make_uint4(0, 0, 0, 0);
+        if (COMPACT == 3) unrec(c1, l1, i);
         if (it < wfull)
             scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
                                                           evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1, p.sa);
@@ -2957,10 +2978,13 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
 //                    64 KB of each column), a requested object on a dead node marks that node for clean_server and counts as
 //                    pending; the virtual-table row {cur | load} — for a later request of the same object {skip | position of
 //                    the first} — leaves as ONE 8-byte store at the request's batch position (the only random access of this
-//                    step; k_pp_split turns the records into the solver's two columns);
+//                    step); the window's rows are read once, densely, and a pending row whose first requester is alive gets
+//                    that requester written back in the same pass: its optimistic placement;
 //   (solve)          the same kernels as every solve, over the virtual table in batch-position order — the requesters column
-//                    is the caller's own array; k_scan<COMPACT 3> and the fix-up write every first touch's node straight into
-//                    the real assignment column through the caller's object column (one random store per first touch);
+//                    is the caller's own array; k_scan<COMPACT 3> reads the 8-byte records, leaves them as the two columns the
+//                    kernels behind it read, and the fix-up writes what it changes into the real assignment column through the
+//                    caller's object column (a first touch on a requester that is not alive — REF_SELF_ASSIGN — is stored by
+//                    the scan: clean_server runs between the window kernel and the solve);
 //   k_pp_win_output  in batch-position order, dense: a first request's answer is its virtual row's `next`, a later request
 //                    reads the first's (one random read per duplicate).
 // Two random accesses per request instead of nine.
@@ -2982,7 +3006,7 @@ __device__ __forceinline__ void part_walk(const uint2* __restrict__ rec2, const 
         for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) body(rec2[pbase[i] + o]);
 }
 
-__global__ __launch_bounds__(kBlock) void k_pp_win_gather(const u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
+__global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
                                                           u32 m, const u32* __restrict__ alive_bits,
                                                           const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
                                                           u32 nchunks, const u32 wshift, uint2* __restrict__ vrec,
@@ -2992,7 +3016,7 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(const u32* __restrict_
     if (st->err) return;  // the binning kernel found an invalid entry: the call fails, nothing is touched
     const u32 W = 1u << wshift;
     u32* wpos = reinterpret_cast<u32*>(smem);  // [W] first batch position that asks for the row
-    u32* wreq = wpos + W;                      // [W] its requester (row lifecycle only)
+    u32* wreq = wpos + W;                      // [W] its requester
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
     const u64 base = (u64)b << wshift;
@@ -3005,11 +3029,16 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(const u32* __restrict_
     part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) {
         const u32 row = x.x & (W - 1), k = x.y, f = wpos[row];
         if (f != k) vrec[k] = make_uint2(kSkipMark, f);
-        else if (aff_life) wreq[row] = x.x >> kPartShiftMax;
+        else wreq[row] = x.x >> kPartShiftMax;
     });
     __syncthreads();
     // the requested rows of the window, in row order: the first request's virtual-table row {node | load} goes to its batch
-    // position (the one random store of this kernel per object)
+    // position (the one random store of this kernel per object).  A pending row (unplaced, or found on a dead node) whose
+    // first requester is ALIVE also gets that requester written into the real column right here, densely, as its optimistic
+    // placement — what the solve's scan used to do with one scattered 4-byte store per first touch (130 of its 174 us at
+    // 10 M requests); the fix-up overwrites it through the same row if the claim is rejected, and clean_server (which runs
+    // behind this kernel for the dead nodes the requests ran into) cannot take it for a row of a dead node: its value is a
+    // live node now.
 #pragma unroll
     for (int q = 0; q < kPartRowVecs; ++q) {
         const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
@@ -3018,7 +3047,9 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(const u32* __restrict_
         if (!__ballot((wp.x & wp.y & wp.z & wp.w) != kNone)) continue;  // nobody asks for any of the wave's 256 rows
         const uint4 cv = *reinterpret_cast<const uint4*>(assign + base + r4);
         const uint4 lv = *reinterpret_cast<const uint4*>(load + base + r4);
-#define RIOGP_FIRST(K, C, L, E)                                                                                    \
+        uint4 ov = cv;
+        bool chg = false;
+#define RIOGP_FIRST(K, C, L, O, E)                                                                                 \
         if (K != kNone) {                                                                                          \
             const bool dead = C < m && !bit_of(alive_bits, C);  /* service.rs:227-237: clean_server of that node */ \
             if (dead) {                                                                                            \
@@ -3027,26 +3058,18 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(const u32* __restrict_
             }                                                                                                      \
             /* row lifecycle: an object from its first request on, home = the requester (a row on a dead node: once */ \
             /* clean_server has taken it out, k_pp_win_output) */                                                  \
-            if (aff_life && C >= m) aff_life[base + r4 + E] = wreq[r4 + E];                                        \
+            const u32 rq = wreq[r4 + E];                                                                           \
+            if (aff_life && C >= m) aff_life[base + r4 + E] = rq;                                                  \
             vrec[K] = make_uint2(dead ? kNone : C, L);                                                             \
+            if ((dead || C == kNone) && rq < m && bit_of(alive_bits, rq)) { O = rq; chg = true; }                  \
         }
-        RIOGP_FIRST(wp.x, cv.x, lv.x, 0)
-        RIOGP_FIRST(wp.y, cv.y, lv.y, 1)
-        RIOGP_FIRST(wp.z, cv.z, lv.z, 2)
-        RIOGP_FIRST(wp.w, cv.w, lv.w, 3)
+        RIOGP_FIRST(wp.x, cv.x, lv.x, ov.x, 0)
+        RIOGP_FIRST(wp.y, cv.y, lv.y, ov.y, 1)
+        RIOGP_FIRST(wp.z, cv.z, lv.z, ov.z, 2)
+        RIOGP_FIRST(wp.w, cv.w, lv.w, ov.w, 3)
 #undef RIOGP_FIRST
+        if (__ballot(chg)) *reinterpret_cast<uint4*>(assign + base + r4) = ov;  // (whole lines; unchanged rows keep their value)
     }
-}
-
-// virtual-table records {cur | load} -> the solver's two columns
-__global__ __launch_bounds__(256) void k_pp_split(const uint2* __restrict__ vrec, u64 n, u32* __restrict__ vcur, u32* __restrict__ vload) {
-    const u64 nv = n >> 1;  // two records per lane and load
-    for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += (u64)gridDim.x * 256) {
-        const uint4 x = *reinterpret_cast<const uint4*>(vrec + 2 * v);
-        *reinterpret_cast<uint2*>(vcur + 2 * v) = make_uint2(x.x, x.z);
-        *reinterpret_cast<uint2*>(vload + 2 * v) = make_uint2(x.y, x.w);
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { vcur[n - 1] = vrec[n - 1].x; vload[n - 1] = vrec[n - 1].y; }
 }
 
 #undef RIOGP_PART_DESCRIPTORS
@@ -4127,7 +4150,10 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
     }
     if (virt) {
         if (t.pk_idx && t.real_next) {  // big place_pending batch: first touches also go straight into the real column
-            const PackOut sc{const_cast<u32*>(t.pk_idx), nullptr, nullptr, t.real_next, reinterpret_cast<u32*>(&b.stats->err)};
+            // (load: a flag, never dereferenced — the window kernel has written the alive requesters' first touches into the real
+            //  column already; aff: the virtual table as 8-byte records, split into t.cur / t.load by this scan)
+            const PackOut sc{const_cast<u32*>(t.pk_idx), t.prewritten ? reinterpret_cast<u32*>(uintptr_t(16)) : nullptr,
+                             const_cast<u32*>(reinterpret_cast<const u32*>(t.vrec)), t.real_next, reinterpret_cast<u32*>(&b.stats->err)};
             if (all_alive) launch_scan_t<true, true, 1, 3>(p, t, nt, b, s, e0, e1, &sc);
             else launch_scan_t<true, false, 1, 3>(p, t, nt, b, s, e0, e1, &sc);
             return;
@@ -4400,7 +4426,7 @@ void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32*
     hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx, req, n,
                        nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err);
 }
-void launch_pp_win_gather(const u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
+void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
                           uint2* vrec, u32* vcur, u32* vload, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st,
                           hipStream_t s) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
@@ -4409,9 +4435,9 @@ void launch_pp_win_gather(const u32* assign, const u32* load, u64 n_obj, u32 m, 
     const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
     (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
     if (out_flag) (void)hipMemsetAsync(out_flag, 0, n * sizeof(u32), s);
-    hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), ((size_t)(aff_life ? 2 : 1) << wshift) * sizeof(u32), s, assign, load, n_obj, m,
+    hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), ((size_t)2 << wshift) * sizeof(u32), s, assign, load, n_obj, m,
                        alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, out_flag, aff_life, st);
-    hipLaunchKernelGGL(k_pp_split, dim3(grid_for((n + 1) / 2, 256, 2048)), dim3(256), 0, s, vrec, n, vcur, vload);
+    (void)vcur; (void)vload;  // (the solve's scan splits the records into the two columns on its way: Table::vrec)
 }
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,

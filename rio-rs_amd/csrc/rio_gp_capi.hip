@@ -1369,6 +1369,8 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         Table vtab{vcur, vload, d_req /* the requesters ARE the affinity column of the virtual table */, vnext};
         vtab.pk_idx = d_idx;      // virtual row -> real row: every decision of the solve also goes to assign[d_idx[k]]
         vtab.real_next = assign;  // (in place: the rows that change are pending, nothing else reads them before the outputs)
+        vtab.vrec = (const uint2*)h->vrec.p;  // the scan reads the records and writes vcur / vload for the kernels behind it
+        vtab.prewritten = true;               // k_pp_win_gather has put the alive requesters' first touches into the column
         const NodeTab vnt{h->cap, h->alive_bits, h->used};
         h->sb.D = h->D;
         launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
