@@ -237,7 +237,13 @@ def test_snapshot_round_trip_in_the_reference_schema(gp, tmp_path):
     c = gp.GpuObjectPlacement(max_objects=4096, max_nodes=16)
     assert snapshot.load_sqlite(c, path2) == len(keys)
     assert c.lookup("Room", "1") == "10.9.9.9:1" and c.lookup("a.b", "c") == addrs[300] and len(c) == len(keys)
-    for x in (a, b, c):
+    # the Postgres twin (migrations/0001-postgres-init.sql): a psql script with one COPY block, and back
+    script = str(tmp_path / "placement.pg.sql")
+    assert snapshot.dump_postgres_script(a, script) == n
+    d = gp.GpuObjectPlacement(max_objects=4096, max_nodes=16)
+    assert snapshot.load_postgres_script(d, script) == n
+    assert {k: d.lookup(*k) for k in keys} == want and len(d) == n
+    for x in (a, b, c, d):
         x.close()
 
 
