@@ -284,7 +284,8 @@ void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const
 
 // place_pending over a window-sorted batch (big batches): see k_pp_win_gather.  scratch = part_scratch_words(n_obj, n) words.
 bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req);
-void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s);
+void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s,
+                   u32* dead_bits, u32* out_flag);  // (clears both: the flag column densely, chunk by chunk)
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
                           uint2* vrec, u32* vcur, u32* vload, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st,
                           hipStream_t s);

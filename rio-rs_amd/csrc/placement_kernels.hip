@@ -2742,9 +2742,12 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
                                                      const u32* __restrict__ node, u64 n, u32 nbins, const u32 wshift,
                                                      u32* __restrict__ rec, uint2* __restrict__ rec2,
                                                      unsigned short* __restrict__ start16, DevStats* st, const bool none_ok,
-                                                     u32* __restrict__ host_err = nullptr) {
+                                                     u32* __restrict__ host_err = nullptr, u32* __restrict__ zero_flags = nullptr,
+                                                     u32* __restrict__ zero_bits = nullptr, const u32 zero_words = 0) {
     // host_err (optional, mapped host memory): set when the chunk holds an invalid entry, so the caller learns it without a
     // copy-back — the kernels it has enqueued behind this one look at st->err and do nothing
+    // zero_flags / zero_bits (place_pending): the per-request flag column (this chunk's slice of it, densely) and the bitmap
+    // of dead nodes the requests run into are cleared here — two memset launches less in front of the window kernel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* part = reinterpret_cast<u64*>(smem);                 // [16] block-scan partials
     u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins] entries of this chunk per window
@@ -2767,6 +2770,16 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     uint4 na = make_uint4(0, 0, 0, 0), nb = na;
     if (UPDATE) { na = load4(node, k0); nb = load4(node, k1); }
     for (u32 b = tid; b < nbins; b += kBlock) hist[b] = 0;
+    if (zero_flags) {
+        const bool al = (reinterpret_cast<uintptr_t>(zero_flags) & 15u) == 0;
+        for (u64 k = k0; k <= k1; k += k1 - k0) {
+            if (al && k + 4 <= hi) *reinterpret_cast<uint4*>(zero_flags + k) = make_uint4(0, 0, 0, 0);
+            else
+                for (u32 e = 0; e < 4 && k + e < hi; ++e) zero_flags[k + e] = 0;
+        }
+    }
+    if (zero_bits && c == 0)
+        for (u32 w = tid; w < zero_words; w += kBlock) zero_bits[w] = 0;
     __syncthreads();
     const u32 I[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
     const u32 N[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
@@ -4418,13 +4431,14 @@ void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u3
     }
 }
 // place_pending over a window-sorted batch (k_pp_win_*): scratch = part_scratch_words(n_obj, n) words (records + chunk table)
-void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s) {
+void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s,
+                   u32* dead_bits, u32* out_flag) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
     uint2* rec2 = reinterpret_cast<uint2*>(scratch);
     unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
     hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx, req, n,
-                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err);
+                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, out_flag, dead_bits, (m + 31) / 32);
 }
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
                           uint2* vrec, u32* vcur, u32* vload, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st,
@@ -4433,8 +4447,7 @@ void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const 
     const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
     const uint2* rec2 = reinterpret_cast<const uint2*>(scratch);
     const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
-    (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
-    if (out_flag) (void)hipMemsetAsync(out_flag, 0, n * sizeof(u32), s);
+    // (dead_bits and out_flag were cleared by the binning kernel: launch_pp_bin)
     hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), ((size_t)2 << wshift) * sizeof(u32), s, assign, load, n_obj, m,
                        alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, out_flag, aff_life, st);
     (void)vcur; (void)vload;  // (the solve's scan splits the records into the two columns on its way: Table::vrec)

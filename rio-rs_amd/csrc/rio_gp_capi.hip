@@ -1358,7 +1358,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         if ((rc = zero_stats(h))) return rc;
         u32* const h_bad = h->h_cs + h->cs_words + 2;
         *h_bad = 0;
-        launch_pp_bin(h->n, h->m, d_idx, d_req, n, (u32*)h->part.p, h->dstats, h->d_cs + h->cs_words + 2, h->stream);
+        launch_pp_bin(h->n, h->m, d_idx, d_req, n, (u32*)h->part.p, h->dstats, h->d_cs + h->cs_words + 2, h->stream, h->dead_bits, d_flag);
         launch_pp_win_gather(assign, h->load, h->n, h->m, h->alive_bits, n, (const u32*)h->part.p, (uint2*)h->vrec.p, vcur, vload,
                              h->dead_bits, d_flag, aff_life(h), h->dstats, h->stream);
         if (!h->all_alive)  // service.rs:227-237: every object of a dead node a request ran into is un-placed
