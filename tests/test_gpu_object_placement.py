@@ -144,7 +144,7 @@ def test_policy_bad_record_removed(gp, oracle):
     assert p.lookup("T", "y") == o.lookup("T", "y") == "nocolon"       # the other bad record is untouched
 
 
-@pytest.mark.parametrize("seed,self_assign", [(0, False), (1, False), (2, True), (3, True)])
+@pytest.mark.parametrize("seed,self_assign", [(0, False), (1, False), (2, True), (3, True)] + [(s, s % 2 == 1) for s in range(4, 12)])
 def test_random_differential_vs_reference_restatement(gp, oracle, seed, self_assign):
     """Random trait calls + policy requests: the GPU provider and the C++ restatement of
     LocalObjectPlacement + service.rs policy must agree on every observable.  self_assign: the provider is created with
