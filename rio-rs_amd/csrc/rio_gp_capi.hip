@@ -88,6 +88,10 @@ struct P2P {
     // the words a slower rank has not read yet, which then waits for a tag that is gone.  With slots of their own two
     // consecutive exchanges of a kind never share one, and no rank is ever more than one exchange ahead of another.
     u64 xslot_n = 0, yslot_n = 0;
+    // A call that has taken sequence numbers / window slots and then fails (a launch error) leaves this rank's counters ahead
+    // of what its peers will ever see: every later exchange would wait for, or overwrite, the wrong record.  The session is
+    // marked and every later call on it fails with RIO_GP_EUPSTREAM until the windows are connected afresh.
+    bool out_of_step = false;
     u32 co_resident = 1;          // ranks whose kernels run on THIS device, ours included (learnt at the handshake)
     size_t xdata_off(u32 slot, u32 r) const { return ((size_t)slot * R + r) * Wx; }
     size_t xwords() const { return (size_t)kP2PSlots * R * Wx; }
@@ -96,6 +100,13 @@ struct P2P {
     size_t hello_off(u32 r) const { return xwords() + (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)r * 8; }
     size_t total_words() const { return xwords() + (size_t)kP2PSlots * R * W + (size_t)kP2PSlots * R * 8 + (size_t)R * 8; }
 };
+
+struct StepGuard {  // see P2P::out_of_step
+    P2P* q;
+    bool done = false;
+    ~StepGuard() { if (q && !done) q->out_of_step = true; }
+};
+static const char* const kOutOfStep = "the peer-to-peer session lost step with its peers in an earlier failed call (connect the windows again)";
 
 struct rio_gp {
     ShardComm* sc = nullptr;
@@ -2074,6 +2085,8 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         // second stream under the next scan was measured SLOWER on gfx950: two event records + two stream waits per
         // solve cost more than the 5 us they hide.)
         P2P* q = h->p2p;
+        if (q->out_of_step) return fail(h, RIO_GP_EUPSTREAM, kOutOfStep);
+        StepGuard step{q};
         const u64 seq = ++q->seq;
         const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
         h->plan = hplan(h, h->n);
@@ -2099,6 +2112,8 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         h->ring_n++;
         h->have_solved = false; ++h->mut_epoch;
         h->sh_state = 2;
+        HIPCHK(h, hipGetLastError());
+        step.done = true;
         return RIO_GP_OK;
     }
     ShardComm* sc = h->sc;
@@ -2156,10 +2171,12 @@ int rio_gp_shard_tick_async(rio_gp_t* h) {
     if (!q || !q->d_peers) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: peer-to-peer windows only (rio_gp_shard_p2p_connect first)");
     if (h->ring_n || h->tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: other asynchronous solves are in flight");
     if (h->sh_tick_n == (u32)kRing) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: 64 ticks in flight (call rio_gp_shard_tick_wait)");
+    if (q->out_of_step) return fail(h, RIO_GP_EUPSTREAM, kOutOfStep);
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     const u32 k = h->sh_tick_n;
     // (1) the fast path: k_scan -> k_resolve_xchg, verdict rows into this tick's slot of the tick ring
+    StepGuard step{q};  // (every sequence number this tick takes — its own and its exchanges' — is taken before any check below)
     const u64 seq = ++q->seq;
     const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
     h->plan = hplan(h, h->n);
@@ -2199,6 +2216,7 @@ int rio_gp_shard_tick_async(rio_gp_t* h) {
     if ((rc = commit_enqueue(h))) return rc;
     h->sh_tick_n = k + 1;
     h->sh_state = 0;
+    step.done = true;
     return RIO_GP_OK;
 }
 
@@ -2251,6 +2269,7 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
     if (h->p2p && h->p2p->d_peers) {
         P2P* q = h->p2p;
         if (words > q->W) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_exchange: record larger than the window row");
+        if (q->out_of_step) return fail(h, RIO_GP_EUPSTREAM, kOutOfStep);
         const u64 seq = ++q->seq;
         const u32 slot = (u32)(q->yslot_n++ % kP2PSlots);
         launch_p2p_put(reinterpret_cast<const u64*>(d_in), (u32)words, q->d_peers, q->R, q->data_off(slot, q->rank),
