@@ -14,7 +14,7 @@ def cp(a, b):
 for name in ("bench_n1.json", "bench_c5.json", "kernel_roofline.json", "kernel_roofline.txt", "churn_timeline.txt",
              "ops.json", "pytest_gpu.log", "smoke.log", "slowpath_churn.json", "slowpath_contended.json", "slowpath_skew.json",
              "latency.txt", "place_pending.json", "place_pending_timeline.txt", "clean.json",
-             "bench_sharded_2ranks_one_gpu.json", "bench_sharded_8ranks_one_gpu.json", "c5_variants.json", "fill_trace.json",
+             "bench_sharded_2ranks_one_gpu.json", "bench_sharded_8ranks_one_gpu.json", "c5_variants.json", "c4_variants.json", "fill_trace.json",
              "pp_host_batches.txt", "c4_tick.json", "fuzz.json"):
     cp("%s_%s" % (tag, name), "%s_%s" % (pre, name))
 cp("crud_ab.json", pre + "_crud_ab.json")

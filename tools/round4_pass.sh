@@ -28,10 +28,11 @@ if [ -z "$QUICK" ]; then
   timeout 300 python tools/crud_ab.py 5 > $OUT/${TAG}_crud_ab.log 2>&1
   ( timeout 200 python tools/sync_probe.py; timeout 200 python tools/latency_probe.py | tail -1; timeout 200 python tools/latency_small_ops.py | tail -1; timeout 200 python tools/tick_rate_probe.py ) > $OUT/${TAG}_latency.txt 2>&1
   timeout 300 python tools/c5_variants.py 100 60 c3 > $OUT/${TAG}_c5_variants.json 2> $OUT/${TAG}_c5_variants.err
+  timeout 400 python tools/c5_variants.py 30 12 c4 never,auto,always > $OUT/${TAG}_c4_variants.json 2> $OUT/${TAG}_c4_variants.err
   timeout 500 python tests/test_gpu_fuzz.py 200 1000 > $OUT/${TAG}_fuzz.json 2> $OUT/${TAG}_fuzz.err
   timeout 300 python tools/fill_trace.py 6 60 > $OUT/${TAG}_fill_trace.json 2> $OUT/${TAG}_fill_trace.err
   ( for k in 4096 2000 1000; do timeout 200 python tools/pp_one_trace.py $k 200; done ) > $OUT/${TAG}_pp_host_batches.txt 2> $OUT/${TAG}_pp_host_batches.err
-  ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c4 -o c4 -- python $ROOT/tools/c4_tick_probe.py 4 ) > $OUT/${TAG}_c4_tick.json 2> $OUT/${TAG}_c4_tick.err
+  ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_c4 -o c4 -- python $ROOT/tools/c4_tick_probe.py 8 ) > $OUT/${TAG}_c4_tick.json 2> $OUT/${TAG}_c4_tick.err
   for w in churn contended skew; do
     timeout 300 python tools/slowpath_workload.py $w 40 > $OUT/${TAG}_slowpath_$w.json 2> $OUT/${TAG}_slowpath_$w.err
   done
@@ -55,6 +56,7 @@ if [ -z "$QUICK" ]; then
   tail -14 $OUT/${TAG}_churn_timeline.txt
   echo "---- churn variants"; cut -c1-3000 $OUT/${TAG}_c5_variants.json
   echo "---- fuzz"; cat $OUT/${TAG}_fuzz.json; tail -5 $OUT/${TAG}_fuzz.err
+  echo "---- churn variants, config 4"; cut -c1-3000 $OUT/${TAG}_c4_variants.json
   echo "---- host batches"; cat $OUT/${TAG}_pp_host_batches.txt
   echo "---- c4 churn tick"; cat $OUT/${TAG}_c4_tick.json; find $OUT/${TAG}_prof_c4 -name "*kernel_stats.csv" | head -1 | xargs cut -c1-60,180-300 | head -12
   echo "---- latencies"; cat $OUT/${TAG}_latency.txt
