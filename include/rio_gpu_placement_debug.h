@@ -20,10 +20,9 @@ extern "C" {
  * <= 25 % of the rows pending), 1 = always, 2 = never.  + 16: big update / remove batches (>= 2^18 entries) go through the plain
  * per-entry kernels instead of the window-partitioned ones.  + (mode << 5), mode 0 | 1 | 2 as above: packing at the cut pass
  * of a whole-table solve (adaptive: when the previous solve sent <= 25 % of the rows to the water-fill).
- * + (inc << 7): the in-place scan of COMMITTED ticks over a mostly-placed table (k_inc_scan: only the assignment column is
- * streamed, then k_rebal deals the pending rows out evenly to the fix-up's workgroups) — 0 = whenever the packed fix-up is used
- * and the `used` vector is valid, on tables of up to 2^17 rows a block (default) | 1 = the same on any table | 2 = never
- * (k_scan<COMPACT>). */
+ * + (inc << 7): the in-place scan of COMMITTED ticks over a mostly-placed table (k_inc_scan: the assignment column is updated
+ * in place, then k_rebal deals the pending rows out evenly to the fix-up's workgroups) — 0 or 1 = whenever the packed fix-up
+ * is used and the `used` vector is valid (default) | 2 = never (k_scan<COMPACT>). */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 /* speculative enqueue of the fix-up behind k_resolve, without waiting for the verdict: 0 (default) = when the previous
  * solve needed it | 1 = always | 2 = never. */

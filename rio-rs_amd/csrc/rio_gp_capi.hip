@@ -501,11 +501,9 @@ int commit_enqueue(rio_gp* h) {
 // the kept histogram, and the rings of pending rows must fit the LDS next to the liveness bitmap.
 int inc_choice(rio_gp* h, bool compact, bool commit) {
     if (!compact || !commit || !h->used_valid || h->inc_mode == 2 || !inc_scan_fits(h->m) || h->m == 0) return 0;
-    // Tables whose blocks are beyond the in-resolve cut search (config 4 on one GPU: 390 K rows a block) keep k_scan<COMPACT>:
-    // measured there (100 M x 4 096, same box) k_inc_scan 352-397 us against 413, but k_rebal adds 63-76 us and the tick's
-    // largest part — round 0's 8 M scattered decision stores into a 400 MB column — does not care how the rows are dealt out:
-    // 794-844 us pipelined against 771-776.  (lab builds: inc "always" keeps the path for A/B runs)
-    if (h->inc_mode != 1 && h->plan.G && h->n / h->plan.G > kSearchMaxBlockRows) return 0;
+    // (Tables whose blocks are beyond the in-resolve cut search — config 4 on one GPU, 390 K rows a block — take this path too:
+    // 100 M x 4 096, three boxes, same-run A/B: 700-720 us pipelined against 734-797 with k_scan<COMPACT>; round 0 of the
+    // water-fill alone is 60-90 us shorter over the balanced rows.  The cut search stays k_cut_find's launch there.)
     return 2;
 }
 

@@ -395,7 +395,7 @@ class GpuPlacement:
         fix-up's workgroups) — "auto": whenever the packed fix-up is used and `used` is valid | "never": k_scan<COMPACT>."""
         self._need_lab()
         modes = {"auto": 0, "always": 1, "never": 2}
-        incs = {"auto": 0, "always": 1, "never": 2}   # "always": also on tables whose blocks are too big for the in-resolve cut search
+        incs = {"auto": 0, "always": 1, "never": 2}   # ("always" = "auto" since the size limit of the in-place tick went)
         self._chk(self._L.rio_gp_debug_set_compact(self._h, modes.get(mode, mode) | (0 if partitioned_crud else 16) |
                                                    (modes.get(cut_pack, cut_pack) << 5) | (incs.get(inc, inc) << 7)))
 

@@ -28,7 +28,8 @@ warm = synth.warm_assign(n, m)
 masks = [synth.churn_mask(m, 2 + k) for k in range(warm_ticks + 2 * ticks + 8)]
 out = {"n": n, "m": m, "ticks": ticks, "warm_ticks": warm_ticks}
 final = {}
-for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "auto")):
+for name in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "auto")):
+    inc = name.partition("#")[0]   # ("<inc>#2": the same variant again, to see run-order effects)
     g = rio_gp.LabPlacement(n, m)
     g.set_compact("auto", inc=inc)
     g.set_nodes(cfg["cap"], cfg["alive"])
@@ -56,7 +57,7 @@ for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "auto")):
     if os.environ.get("RIO_INC_DEBUG"):
         tr = g.ktrace(True, 3).astype(np.int64)
         rows = tr[tr[:, 0] > 0]
-        out[inc] = {"pipelined_us": dtp / ticks * 1e6, "debug": os.environ["RIO_INC_DEBUG"],
+        out[name] = {"pipelined_us": dtp / ticks * 1e6, "debug": os.environ["RIO_INC_DEBUG"],
                     "scan_wg_median_us": float(np.median((rows[:, 7] - rows[:, 0]) / 100.0)),
                     "scan_span_us": float((rows[:, 7].max() - rows[:, 0].min()) / 100.0),
                     "scan_loop_end_median_us": float(np.median((rows[:, 2] - rows[:, 0]) / 100.0))}
@@ -91,9 +92,9 @@ for inc in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "auto")):
         rec["spans_us"] = spans
     except Exception as e:  # measurement aid
         rec["spans_us"] = {"error": repr(e)}
-    final[inc] = (g.get_assign(), g.get_nodes()[2])
+    final[name] = (g.get_assign(), g.get_nodes()[2])
     g.close()
-    out[inc] = rec
+    out[name] = rec
 keys = list(final)
 out["tables_equal_across_variants"] = all(np.array_equal(final[keys[0]][0], final[q][0]) and np.array_equal(final[keys[0]][1], final[q][1])
                                           for q in keys[1:])

@@ -28,7 +28,7 @@ if [ -z "$QUICK" ]; then
   timeout 300 python tools/crud_ab.py 5 > $OUT/${TAG}_crud_ab.log 2>&1
   ( timeout 200 python tools/sync_probe.py; timeout 200 python tools/latency_probe.py | tail -1; timeout 200 python tools/latency_small_ops.py | tail -1; timeout 200 python tools/tick_rate_probe.py ) > $OUT/${TAG}_latency.txt 2>&1
   timeout 300 python tools/c5_variants.py 100 60 c3 > $OUT/${TAG}_c5_variants.json 2> $OUT/${TAG}_c5_variants.err
-  timeout 400 python tools/c5_variants.py 30 12 c4 never,auto,always > $OUT/${TAG}_c4_variants.json 2> $OUT/${TAG}_c4_variants.err
+  timeout 400 python tools/c5_variants.py 60 12 c4 "auto,never,auto#2,never#2" > $OUT/${TAG}_c4_variants.json 2> $OUT/${TAG}_c4_variants.err
   timeout 500 python tests/test_gpu_fuzz.py 200 1000 > $OUT/${TAG}_fuzz.json 2> $OUT/${TAG}_fuzz.err
   timeout 300 python tools/fill_trace.py 6 60 > $OUT/${TAG}_fill_trace.json 2> $OUT/${TAG}_fill_trace.err
   ( for k in 4096 2000 1000; do timeout 200 python tools/pp_one_trace.py $k 200; done ) > $OUT/${TAG}_pp_host_batches.txt 2> $OUT/${TAG}_pp_host_batches.err
