@@ -75,6 +75,9 @@ def test_bench_headline_line_has_parity_traffic_and_config4():
     c4 = d["config4_single_gpu"]
     assert c4["parity"]["equal"] is True and c4["parity"]["checked_rows"] == 100_000_000
     assert c4["cold_resolve_uncommitted"]["slow_path_steps"] == 0 and c4["committed_tick"]["frac"] > 0.3
+    ch4 = c4["churn_tick_pipelined"]    # config 5's churn on config 4's table, replayed by the oracle at 100 M rows
+    assert ch4["parity"]["equal"] is True and ch4["parity"]["ticks_replayed"] == 13 and ch4["stats_last_tick"]["slow_path"] == 1
+    assert 0.2 < ch4["ms_per_tick"] < 3.0
     cold = d["roofline"]["beyond_infinity_cache"]
     assert cold["rows"] == 40_000_000 and cold["whole_step_frac"] > 0.4 and cold["committed_tick_frac"] > 0.3
 
