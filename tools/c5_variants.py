@@ -61,7 +61,7 @@ for name in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("never", "auto"))
                     "scan_wg_median_us": float(np.median((rows[:, 7] - rows[:, 0]) / 100.0)),
                     "scan_span_us": float((rows[:, 7].max() - rows[:, 0].min()) / 100.0),
                     "scan_loop_end_median_us": float(np.median((rows[:, 2] - rows[:, 0]) / 100.0))}
-        os._exit(0 if not print(json.dumps(out)) else 0)
+        print(json.dumps(out), flush=True); os._exit(0)
     t0 = time.perf_counter()
     for _ in range(ticks):
         g.set_alive_all(masks[k]); k += 1
