@@ -5,7 +5,8 @@ capacities (unbounded / tight / zero), loads, affinities (nodes, NONE, RIO_GP_AF
 self-assignment switch on or off — then 12-30 operations drawn from everything the dense layer offers: committed and
 uncommitted solves (synchronous, asynchronous streams), liveness flips, update / remove / lookup batches, clean_server(s),
 place_pending at every batch-size regime (one workgroup, three launches, plain kernels, window-sorted), new loads /
-affinities / capacities.  The fix-up policies the product picks adaptively are also forced through the lab build's knobs, by
+affinities / capacities.  A second kind of scenario drives the ROW-SHARDED solve (G handles on the one device, random shard
+boundaries with empty shards, streams of committed ticks with liveness changes) against the whole-table oracle.  The fix-up policies the product picks adaptively are also forced through the lab build's knobs, by
 seed.  The seeds are fixed: a failure names the seed and the operation.
 
     python tests/test_gpu_fuzz.py <seconds> [first_seed]     # a longer campaign (tools/round4_pass.sh runs one)
@@ -247,6 +248,69 @@ def test_random_operation_sequences(gp, oracle, seed):
     Scenario(gp, oracle, seed).run()
 
 
+def _sharded_scenario(gp, oracle, seed):
+    """The row-sharded solve as G handles on the one device, sequenced by the ShardedSolver the multi-GPU
+    bench uses: random shard boundaries (empty and one-row shards included), a stream of committed ticks with liveness
+    changes between them, every tick against the WHOLE-table oracle (rows, the global `used` on every rank, the counters)."""
+    import sharded
+    import torch
+    rng = np.random.default_rng(0x5A4D0000 + seed)
+    n = _pick(rng, _SIZES, 200_000)
+    m = int(rng.choice([1, 2, 7, 33, 64, 257, 1024, 3000]))
+    rounds = int(rng.choice([1, 2, 2, 3]))
+    G = int(rng.choice([1, 2, 3, 5, 8]))
+    load = (rng.integers(0, 30, n) if rng.random() < 0.5 else rng.zipf(1.3, n).clip(0, 60000)).astype(np.uint32)
+    aff = rng.integers(0, m, n).astype(np.uint32)
+    aff[rng.random(n) < 0.1] = NONE
+    if rng.random() < 0.3:
+        aff[rng.random(n) < 0.4] = int(rng.integers(m))
+    total = int(load.sum())
+    cap = [np.full(m, INF, np.uint64), rng.integers(0, total // m + 5, m).astype(np.uint64),
+           np.full(m, (total * 5 // 4) // m + 1, np.uint64)][int(rng.integers(3))]
+    alive = (rng.random(m) > rng.choice([0.0, 0.1, 0.5])).astype(np.uint8)
+    ref = rng.integers(0, m, n).astype(np.uint32)
+    ref[rng.random(n) < rng.choice([0.02, 0.5, 1.0])] = NONE
+    cuts = sorted(int(x) for x in rng.integers(0, n + 1, G - 1))
+    bounds = [0] + cuts + [n]
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    engines = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        g = gp.GpuPlacement(max(hi - lo, 1), m, spill_rounds=rounds)
+        g.set_nodes(cap, alive, m=m)
+        g.set_objects(hi - lo, load[lo:hi], aff[lo:hi])
+        if hi > lo:
+            g.set_assign(ref[lo:hi])
+        engines.append(sharded.HipShardEngine(g, 0, stream))
+    sol = sharded.ShardedSolver(engines, sharded.LocalExchange(G), spill_rounds=rounds)
+    try:
+        for step in range(int(rng.integers(3, 7))):
+            if step:
+                k = rng.integers(3)
+                if k == 0:
+                    alive = (rng.random(m) > 0.1).astype(np.uint8)
+                elif k == 1:
+                    alive = np.ones(m, np.uint8)
+                else:
+                    alive[int(rng.integers(m))] ^= 1
+                for e in engines:
+                    e.g.set_alive_all(alive)
+            st = sol.tick()
+            ref, used, ost = oracle.tick(ref, load, aff, cap, alive, rounds)
+            got = np.concatenate([e.g.get_assign() if e.g.num_objects else np.zeros(0, np.uint32) for e in engines])
+            assert np.array_equal(got, ref), (seed, step, bounds, np.flatnonzero(got != ref)[:8])
+            assert st == ost, (seed, step, st, ost)
+            for e in engines:
+                assert np.array_equal(e.g.get_nodes()[2], used), (seed, step)
+    finally:
+        for e in engines:
+            e.g.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RIO_FUZZ_SHARD_SEEDS", "24"))))
+def test_random_sharded_tick_streams(gp, oracle, seed):
+    _sharded_scenario(gp, oracle, seed)
+
+
 if __name__ == "__main__":
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -260,6 +324,11 @@ if __name__ == "__main__":
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     t0, ops, first, cov = time.time(), 0, seed, {}
     while time.time() - t0 < budget:
+        if seed % 10 == 9:   # every tenth scenario: a row-sharded tick stream (G handles on the device)
+            _sharded_scenario(rio_gp, pyoracle, seed)
+            cov["row-sharded tick streams"] = cov.get("row-sharded tick streams", 0) + 1
+            seed += 1
+            continue
         sc = Scenario(rio_gp, pyoracle, seed, big=True)
         ops += sc.run()
         for k, v in sc.count.items():
