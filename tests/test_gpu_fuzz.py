@@ -316,6 +316,12 @@ if __name__ == "__main__":
     for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     import json
+    try:   # (two HIP runtimes in the process: torch's has to come up first — see tests/conftest.py)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     import pyoracle
     import rio_gp
     rio_gp.build()
