@@ -43,7 +43,7 @@ class Scenario:
         self.n = n = _pick(rng, _SIZES + (524288, 1_000_000), 2_000_000 if big else 300_000)
         if big and rng.random() < 0.3:   # a campaign spends a third of its scenarios on tables of 10^5 .. 2 x 10^6 rows
             self.n = n = int(np.exp(rng.uniform(np.log(100_000), np.log(2_000_000))))
-        self.m = m = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 100, 255, 256, 257, 1000, 1024, 1025, 4096, 5000]))
+        self.m = m = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 100, 255, 256, 257, 1000, 1024, 1025, 4096, 5000, 8191, 8192]))
         self.rounds = int(rng.choice([1, 2, 2, 2, 3]))
         self.sa = bool(rng.random() < 0.25)
         self.flags = gp.CFG_REF_SELF_ASSIGN if self.sa else 0
@@ -256,7 +256,7 @@ def _sharded_scenario(gp, oracle, seed):
     import torch
     rng = np.random.default_rng(0x5A4D0000 + seed)
     n = _pick(rng, _SIZES, 200_000)
-    m = int(rng.choice([1, 2, 7, 33, 64, 257, 1024, 3000]))
+    m = int(rng.choice([1, 2, 7, 33, 64, 257, 1024, 3000, 8192]))
     rounds = int(rng.choice([1, 2, 2, 3]))
     G = int(rng.choice([1, 2, 3, 5, 8]))
     load = (rng.integers(0, 30, n) if rng.random() < 0.5 else rng.zipf(1.3, n).clip(0, 60000)).astype(np.uint32)
