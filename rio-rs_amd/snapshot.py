@@ -12,6 +12,7 @@ The Postgres twin (migrations/0001-postgres-init.sql) is at the end of the file.
 
 Not on the hot path: one D2H copy of the assignment column and a host loop over the interned keys.
 """
+import re
 import sqlite3
 
 SCHEMA = (
@@ -84,6 +85,7 @@ PG_UPSERT = ("INSERT INTO object_placement(struct_name, object_id, server_addres
 PG_SELECT_ALL = ("SELECT struct_name, object_id, server_address FROM object_placement "
                  "WHERE server_address IS NOT NULL ORDER BY struct_name, object_id")
 
+_COPY_HEAD = re.compile(r'copy\s+(?:"?\w+"?\.)?"?object_placement"?\s*(\(|from\b)')   # (not object_placement_anything_else)
 _COPY_ESC = {"\\": "\\\\", "\t": "\\t", "\n": "\\n", "\r": "\\r", "\b": "\\b", "\f": "\\f", "\v": "\\v"}
 _COPY_UNESC = {"\\": "\\", "t": "\t", "n": "\n", "r": "\r", "b": "\b", "f": "\f", "v": "\v"}
 
@@ -196,7 +198,7 @@ def load_postgres_script(placement, path, batch=65536):
             if cols is None:
                 s = line.strip()
                 low = s.lower()
-                if low.startswith("copy ") and "object_placement" in low.split("(")[0] and low.rstrip(";").endswith("from stdin"):
+                if _COPY_HEAD.match(low) and low.rstrip(";").rstrip().endswith("from stdin"):
                     inside = s[s.index("(") + 1:s.index(")")] if "(" in s else "struct_name, object_id, server_address"
                     cols = [c.strip().strip('"').lower() for c in inside.split(",")]
                     want = ("struct_name", "object_id", "server_address")

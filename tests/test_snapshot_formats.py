@@ -92,6 +92,7 @@ def test_script_round_trip_and_pg_dump_shape(tmp_path):
     dump = str(tmp_path / "pg_dump.sql")
     with open(dump, "w", encoding="utf-8", newline="\n") as f:
         f.write("SET client_encoding = 'UTF8';\nCOPY public.other (a) FROM stdin;\nx\n\\.\n\n"
+                "COPY public.object_placement_history (struct_name, object_id, server_address) FROM stdin;\nOld\t1\th:0\n\\.\n\n"
                 "COPY public.object_placement (server_address, struct_name, object_id) FROM stdin;\n"
                 "h:9\tRoom\t77\n\\N\tRoom\t78\nh:1\\tx\tT\\\\\tq\n\\.\n\nSELECT 1;\n")
     c = MapPlacement()
