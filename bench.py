@@ -38,6 +38,10 @@ import sys
 import tempfile
 import time
 
+# the host driver of these boxes supports dmabuf IPC only: without this the peer-to-peer windows (hipIpcGetMemHandle) and RCCL
+# fail across processes.  Set before any HIP runtime comes up; an operator's own value wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
