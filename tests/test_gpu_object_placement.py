@@ -182,6 +182,19 @@ def test_random_differential_vs_reference_restatement(gp, oracle, seed, self_ass
             ip, port = addrs[k].split(":")
             st.set_is_active(ip, port, alive[k])
             p.set_member(addrs[k], alive[k])
+        elif r < 0.42 and not self_assign:
+            # the batched form (rio_op_get_or_create_placement_batch): n requests "as if sequentially in array order" — the
+            # restatement serves them one by one
+            kk = int(rng.integers(2, 40))
+            bkeys = [keys[int(rng.integers(len(keys)))] for _ in range(kk)]
+            live = [k for k in range(len(addrs)) if alive[k]]
+            mes = [addrs[int(rng.choice(live))] for _ in range(kk)]
+            got, flags = p.get_or_create_placement_batch(bkeys, mes)
+            for (bty, boid), me, g1, f1 in zip(bkeys, mes, got, flags):
+                want = oracle.get_or_create_placement(o, st, me, bty, boid)
+                assert g1 == want, (step, bty, boid, me)
+                verdict = oracle.check_address_mismatch(o, st, me, want)
+                assert verdict == ("ok" if int(f1) & gp.FLAG_MASK in (gp.FLAG_LOCAL, gp.FLAG_PLACED) else "redirect"), (step, bty, boid)
         elif r < 0.75:
             me = addrs[int(rng.choice([k for k in range(len(addrs)) if alive[k] or self_assign]))]
             got, flag = p.get_or_create_placement(ty, oid, me)
