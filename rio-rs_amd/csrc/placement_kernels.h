@@ -262,15 +262,16 @@ void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t 
 // --- place_pending, batches of up to kOneBatch requests: ONE workgroup, one launch; idx/req/out_* may be mapped host
 //     memory; *status = 1 means "needs the general path", nothing was changed ---
 constexpr int kOneBatch = 4096;
-// stage + ticket (device memory: pp_stage_bytes() of scratch, one zeroed word): batches of more than kPpStagedFrom requests go
-// through three launches — requests and their rows gathered by many workgroups, the decision in one, results and table
-// stores by many again (k_pp_stage / k_pp_decide / k_pp_apply) — instead of one workgroup doing all of it
-constexpr int kPpStagedFrom = 1024;
+// stage + ticket (device memory: pp_stage_bytes() of scratch, one zeroed word): batches of more than kPpStagedFrom requests
+// from HOST buffers (host_io; device-resident batches: more than 1 024) go through three launches — requests and their rows
+// gathered by many workgroups, the decision in one, results and table stores by many again (k_pp_stage / k_pp_decide /
+// k_pp_apply) — instead of one workgroup doing all of it
+constexpr int kPpStagedFrom = 256;
 inline size_t pp_stage_bytes() { return (size_t)kOneBatch * (16 + 16 + 8) + 64; }
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
                    u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr, u32 n_obj_chk = 0,
-                   void* stage = nullptr, unsigned int* ticket = nullptr, u32 sa = 0);
+                   void* stage = nullptr, unsigned int* ticket = nullptr, u32 sa = 0, bool host_io = false);
 // --- place_pending glue (virtual table) ---
 void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
                          u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead = nullptr);

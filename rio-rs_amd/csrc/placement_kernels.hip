@@ -4382,7 +4382,12 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
 int g_part_shift = 14;  // rows per window = 1 << shift (rio_gp_debug_set_part_shift: 12..14)
-void set_part_shift(int shift) { g_part_shift = shift < 12 ? 12 : shift > (int)kPartShiftMax ? (int)kPartShiftMax : shift; }
+int g_pp_staged_from = kPpStagedFrom;  // host-buffer batches (lab builds: bits 8.. of rio_gp_debug_set_part_shift, A/B runs)
+void set_part_shift(int v) {
+    const int shift = v & 0xFF;
+    g_part_shift = shift < 12 ? 12 : shift > (int)kPartShiftMax ? (int)kPartShiftMax : shift;
+    if (v >> 8) g_pp_staged_from = v >> 8;
+}
 static inline u64 part_bins(u64 n_obj) { return (n_obj + ((u64)1 << g_part_shift) - 1) >> g_part_shift; }
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node) {
     const u64 nbins = part_bins(n_obj);
@@ -4500,8 +4505,13 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
 }
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
-                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk, void* stage, unsigned int* ticket, u32 sa) {
-    if (stage && ticket && done && n > (u32)kPpStagedFrom && m <= kPpTot) {  // three launches: stage | decide | apply
+                   u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk, void* stage, unsigned int* ticket, u32 sa,
+                   bool host_io) {
+    // Three launches (stage | decide | apply) when the requests and results are mapped HOST memory and the batch is beyond the
+    // small kernel's 256: the one-workgroup kernel reads them over PCIe from ONE compute unit.  Same run, us per call,
+    // one workgroup -> three launches: 300 requests 26-28 -> 24.7-24.9, 1 000: 28.3-33 -> 25.2-26, 1 024: 28.5-33 -> 24.8-26.4
+    // (tools/pp_staged_ab.py).  Device-resident requests (_dev) stay with the single launch up to 1 024.
+    if (stage && ticket && done && n > (u32)(host_io ? g_pp_staged_from : kOneBatch / 4) && m <= kPpTot) {
         uint4* rec = static_cast<uint4*>(stage);
         uint4* rec2 = rec + kOneBatch;
         uint2* res = reinterpret_cast<uint2*>(rec2 + kOneBatch);

@@ -1502,7 +1502,7 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
             const u32 seq1 = small_begin(h);
             launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, dm, dm + kMidBatch, (u32)n,
                           dm + 2 * kMidBatch, dm + 3 * kMidBatch, h->d_small + 4 * kSmallBatch, h->stream, aff_life(h),
-                          small_done_dev(h), seq1, nullptr, 0, h->pp_stage, h->mid_ticket, h->sa);
+                          small_done_dev(h), seq1, nullptr, 0, h->pp_stage, h->mid_ticket, h->sa, true);
             if ((rc = small_wait(h, seq1))) return rc;
             const u32 status = h->h_small[4 * kSmallBatch];
             if (status == 0) {
