@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One PHASE of the hot path per process, for the rocprofv3 passes of tools/kernel_roofline.sh (kernel trace + the two PMC
 passes): every kernel DESIGN.md section 4 names runs in exactly one phase with known algorithmic bytes, so that its
-duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round3_kernel_roofline.json).
+duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round4_kernel_roofline.json).
 Usage: roofline_workload.py <fast|churn|churn_noinc|churn_unpacked|contended|contended_packed|crud|crud_plain|lookup_seq|clean1|pp|pp10|pp_small|probes> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
