@@ -680,6 +680,8 @@ def run_sharded(a, dist, torch, rio_gp, synth, workload, rank, world, local_rank
         pass
     infos = [None] * world
     dist.all_gather_object(infos, info)
+    if not a.same_device and len({(x.get("pci_bus_id"), x["device"]) for x in infos}) != world:
+        raise SystemExit("bench.py: the %d ranks do not run on %d distinct devices: %r" % (world, world, infos))
     rec = {"value": n_total * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "gpu_ms_per_step_events": gpu_ms / a.steps,
            "rows_total": n_total, "rows_this_rank": n, "nodes": m, "exchange": kind, "exchange_ladder": tried,
            "slow_path_steps": n_slow, "stats_last_step": st, "parity": parity, "committed_ticks": ticks,
@@ -713,8 +715,45 @@ def peer_matrix(torch, world, same_device):
 
 # ------------------------------------------------------------------------------------------------ main
 
+def visible_devices():
+    """HIP devices this process can see (hipGetDeviceCount through ctypes: no torch import in the launcher)."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return int(n.value) if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): become the launcher —
+    re-exec under torch.distributed.run with one rank per GPU (rank i -> device i) and the same arguments, so that the command
+    prints ONE line with n_gpus = N.  Fewer than N visible devices is an error, never a silent one-GPU line (unless
+    --same-device, the one-GPU flow test)."""
+    have = visible_devices()
+    if not a.same_device and have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to run (a line measured on fewer GPUs than "
+                         "it names would be wrong; --same-device runs every rank on device 0 as a flow test)\n" % (a.gpus, have))
+        raise SystemExit(2)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %d ranks myself: %s\n" % (a.gpus, a.gpus, " ".join(cmd)))
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)  # (does not return)
     # stdout carries exactly ONE line, the JSON: libraries that write to C stdout (RCCL prints a version banner from
     # every rank) are pointed at stderr for the whole run; fd 1 is restored only for rank 0's final print
     sys.stdout.flush()
@@ -723,8 +762,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if a.gpus != world:  # (a launcher that started another number of ranks than the line would name)
+        raise SystemExit("--gpus %d must equal WORLD_SIZE %d" % (a.gpus, world))
     import torch
     import rio_gp
     import synth
@@ -733,6 +772,8 @@ def main():
     rio_gp.build()
     if a.same_device:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks, %d visible device(s): one GPU per rank or --same-device" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     workload = a.workload or ("c3" if world == 1 else "c4")
     dist = None

@@ -22,6 +22,7 @@ constexpr int kTile = 256;           // objects per wave-iteration: 64 lanes x d
 constexpr u32 kMaxBlocks = 256;      // = CUs; rows of the per-block histogram table
 constexpr u32 kMaxSubs = 256;
 constexpr int kMidBatch = 16384;     // lookups of up to this many entries go through mapped pinned memory and a completion word
+constexpr int kReqBatch = 65536;     // place_pending batches from host buffers of up to this many requests: mapped pinned memory, no staging copies
 constexpr int kSmallBatch = 256;     // place_pending / lookup micro-batches served by one workgroup and one launch        // sub-chunks per block for the exact-cut refinement
 
 // Work decomposition of a table of n rows.  Index order is the only order that matters:
@@ -152,6 +153,9 @@ struct Table {
     // are already in the real column (the scan stores only those whose requester is not alive: RIO_GP_CFG_REF_SELF_ASSIGN)
     const uint2* vrec = nullptr;
     bool prewritten = false;
+    // plain virtual table (general request path): when *skip_if != 0 the batch held an invalid entry and the table was not
+    // built — the scan solves an empty one
+    const u32* skip_if = nullptr;
 };
 
 struct NodeTab {
@@ -249,7 +253,8 @@ void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u3
 // mapped host memory by the last workgroup (dead_bits may itself be mapped host memory).
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used_or_null, DevStats* st, hipStream_t s,
                   u64* counter = nullptr, unsigned int* ticket = nullptr, u64* host_out = nullptr, u32* aff_life = nullptr,
-                  u32 seq = 0 /* != 0: *host_out = total | seq << 40, the word the host spins on */);
+                  u32 seq = 0 /* != 0: *host_out = total | seq << 40, the word the host spins on */,
+                  const u32* skip_if = nullptr /* asynchronous form: do nothing when *skip_if != 0 */);
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s);
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s);
 void launch_set_attrs(u32* load, u32* aff, u64 n_obj, const u32* idx, const u32* nload, const u32* naff, u64 n,
@@ -272,16 +277,21 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
                    u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr, u32 n_obj_chk = 0,
                    void* stage = nullptr, unsigned int* ticket = nullptr, u32 sa = 0, bool host_io = false);
-// --- place_pending glue (virtual table) ---
-void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
-                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead = nullptr);
-void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const u32* req, u64 n, u32* pos_scratch,
-                      u32* vcur, u32* vload, u32* vaff, hipStream_t s);
-void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
-                       u32* pos_scratch, const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node,
-                       u32* out_flag, hipStream_t s, u32* aff_life = nullptr, unsigned int* ticket = nullptr,
-                       u32* done = nullptr, u32 seq = 0, bool flag_bits = true, u32 sa = 0);  // ticket/done/seq: the several-workgroup
-                       // completion word (launch_lookup); flag_bits: out_flag holds k_pp_mark_dead's REPLACED bits
+// --- place_pending, the general request path (k_ppm_first / k_ppm_gather / solve of the virtual table / k_ppm_output) ---
+// bad: device word, 0 between calls (raised by k_ppm_first on an invalid entry, put back by k_ppm_output's last workgroup);
+// s_idx / s_req != nullptr: idx / req are mapped HOST memory, copied to these device arrays on the way (use them afterwards);
+// dead_bits / vflag != nullptr: some node is not alive — nodes that requests run into are marked, REPLACED bits per request
+void launch_ppm_first(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req, u64 n,
+                      u32* pos_scratch, u32* s_idx, u32* s_req, u32* dead_bits, u32* vflag, u32* bad, hipStream_t s);
+void launch_ppm_gather(const u32* assign, const u32* load, const u32* idx, u64 n, const u32* pos_scratch, u32* vcur, u32* vload,
+                       u32* vfirst, const u32* bad, hipStream_t s);
+// *status (mapped host memory): 0 done | 1 the solve needs the fix-up and it was not enqueued (fixup_done == false): nothing
+// was changed, enqueue it and launch this again with fixup_done | 3 invalid entry: nothing was changed.  Ends with the
+// several-workgroup completion word (ticket / done / seq).
+void launch_ppm_output(u32* assign, u64 n_obj, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
+                       const u32* vfirst, const u32* vflag, u32* pos_scratch, const u32* alive_bits, const SolveBufs& b,
+                       const Plan& vp, u32* out_node, u32* out_flag, u32* aff_life, u32* bad, bool fixup_done, u32* status,
+                       unsigned int* ticket, u32* done, u32 seq, hipStream_t s);
 
 // place_pending over a window-sorted batch (big batches): see k_pp_win_gather.  scratch = part_scratch_words(n_obj, n) words.
 bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req);

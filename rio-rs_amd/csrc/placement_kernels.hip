@@ -380,7 +380,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
     // COMPACT 3: pko.wcnt = the batch's invalid-entry counter; set -> the virtual table was not built: solve an empty one
-    if (COMPACT == 3 && *reinterpret_cast<const volatile u32*>(pko.wcnt)) wend = wstart;
+    // (the plain virtual table of the general request path: the same word, when the caller passes one)
+    if ((COMPACT == 3 || (VIRT && COMPACT == 0 && pko.wcnt)) && *reinterpret_cast<const volatile u32*>(pko.wcnt)) wend = wstart;
     const u64 span = wend > wstart ? wend - wstart : 0;
     const u64 wfull = wstart + (span / kTile) * kTile;                  // end of the full tiles
     const u64 wgrp = wstart + (span / (kTile * TPI)) * (kTile * TPI);   // end of the full TPI-tile groups
@@ -3155,8 +3156,10 @@ __global__ __launch_bounds__(256) void k_pp_win_output(const u32* __restrict__ i
 __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                const u32* __restrict__ dead_bits, u64* __restrict__ used,
                                                u64* __restrict__ counter, unsigned int* __restrict__ ticket,
-                                               u64* __restrict__ host_out, u32* __restrict__ aff_life, u32 seq) {
+                                               u64* __restrict__ host_out, u32* __restrict__ aff_life, u32 seq,
+                                               const u32* __restrict__ skip_if) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (skip_if && *skip_if) return;  // request path: the batch holds an invalid entry, the call changes nothing (asynchronous form only)
     u32* db = reinterpret_cast<u32*>(smem);
     __shared__ u32 any;
     __shared__ u32 ev_total;
@@ -3303,77 +3306,166 @@ __global__ __launch_bounds__(kBlock) void k_used(const u32* __restrict__ assign,
 }
 
 // ------------------------------------------------------------------------------------------------
-// place_pending glue: requests -> virtual table -> solve -> scatter
+// place_pending, the general request path (any batch the one-workgroup and the window-sorted forms do not take: 4 097 ...
+// 2^18 requests, sparse or unaligned bigger ones, small ones that ran into a dead node or a full requester):
+//     k_ppm_first   validate | first request per row (atomicMin of the batch position into the row-sized scratch) | mark the
+//                   dead nodes requests run into (service.rs:227-237) | device copies of requests that live in mapped HOST memory
+//     [k_clean]     only when a node is not alive
+//     k_ppm_gather  the virtual table (rows = requests): cur of the first request, kSkipMark for later ones, load, and the
+//                   position of the row's first request (what the output kernel needs instead of the scratch)
+//     k_scan<VIRT> -> k_resolve -> [fix-up, speculative when the last batch needed it]
+//     k_ppm_output  decisions into the real column (first requests), answers in batch order (duplicates read the first's
+//                   virtual row), scratch reset, completion word.
+//   Nothing waits on the host in between (round 4: two round trips, 67-70 us for 8 192 requests).  An invalid entry raises
+//   *bad (a device word the last workgroup of the output kernel puts back to 0): every kernel behind k_ppm_first looks at it
+//   and changes nothing, the output kernel undoes the election marks and reports status 3.  A solve that needs the cut /
+//   water-fill when the fix-up was not enqueued leaves everything as it is and reports status 1: the host enqueues the
+//   fix-up and this kernel again (one extra round trip, on the first contended batch only).
 // ------------------------------------------------------------------------------------------------
-// (1) service.rs:227-237: a requested row placed on a dead node marks that node for clean_server
-__global__ void k_pp_mark_dead(const u32* __restrict__ assign, u64 n_obj, u32 m, const u32* __restrict__ alive_bits,
-                               const u32* __restrict__ idx, const u32* __restrict__ req, u64 n,
-                               u32* __restrict__ dead_bits, DevStats* st, u32* __restrict__ req_dead) {
-    // req_dead (optional, the call's flag column): RIO_GP_FLAG_REPLACED for a request that finds its object on a dead node,
-    // 0 otherwise — k_pp_output keeps the bit for the FIRST request of the object (service.rs:268-285)
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
-        const u32 i = idx[k];
-        if (i >= n_obj || req[k] >= m) { atomicAdd(&st->err, 1ull); if (req_dead) req_dead[k] = 0; continue; }
+constexpr u32 kPpmOk = 0, kPpmNeedFix = 1, kPpmBad = 3;
+__global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assign, u64 n_obj, u32 m,
+                                                   const u32* __restrict__ alive_bits, const u32* __restrict__ idx,
+                                                   const u32* __restrict__ req, u64 n, u32* __restrict__ pos,
+                                                   u32* __restrict__ s_idx, u32* __restrict__ s_req,
+                                                   u32* __restrict__ dead_bits, u32* __restrict__ vflag, u32* __restrict__ bad) {
+    // s_idx / s_req (host_io): idx / req are mapped host memory, read ONCE here, 16 bytes per lane, and left in device memory
+    // for the kernels behind; dead_bits / vflag (some node is not alive): RIO_GP_FLAG_REPLACED for a request that finds its
+    // object on a dead node, 0 otherwise — the output kernel keeps the bit for the FIRST request of the object (service.rs:268-285)
+    u32 nbad = 0;
+    auto one = [&](u64 k, u32 i, u32 r) -> u32 {
+        if (i >= n_obj || r >= m) { ++nbad; return 0u; }
+        atomicMin(&pos[i], (u32)k);
+        if (!dead_bits) return 0u;
         const u32 c = assign[i];
         const bool dead = c < m && !bit_of(alive_bits, c);
         if (dead) atomicOr(&dead_bits[c >> 5], 1u << (c & 31));
-        if (req_dead) req_dead[k] = dead ? kFlagReplaced : 0u;
+        return dead ? kFlagReplaced : 0u;
+    };
+    const u64 nvec = n >> 2, stride = (u64)gridDim.x * 256;
+    for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        const uint4 iv = *reinterpret_cast<const uint4*>(idx + 4 * v), rv = *reinterpret_cast<const uint4*>(req + 4 * v);
+        if (s_idx) { *reinterpret_cast<uint4*>(s_idx + 4 * v) = iv; *reinterpret_cast<uint4*>(s_req + 4 * v) = rv; }
+        uint4 f;
+        f.x = one(4 * v + 0, iv.x, rv.x); f.y = one(4 * v + 1, iv.y, rv.y);
+        f.z = one(4 * v + 2, iv.z, rv.z); f.w = one(4 * v + 3, iv.w, rv.w);
+        if (dead_bits) *reinterpret_cast<uint4*>(vflag + 4 * v) = f;
     }
-}
-// (2) first request of a row decides (atomicMin of position), (3) gather the virtual table
-__global__ void k_pp_elect(const u32* __restrict__ idx, u64 n, u64 n_obj, u32* __restrict__ pos) {
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
-        const u32 i = idx[k];
-        if (i < n_obj) atomicMin(&pos[i], (u32)k);
+    const u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x;  // ragged tail (< 4 entries)
+    if (k < n) {
+        const u32 i = idx[k], r = req[k];
+        if (s_idx) { s_idx[k] = i; s_req[k] = r; }
+        const u32 f = one(k, i, r);
+        if (dead_bits) vflag[k] = f;
     }
+    if (nbad) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_pp_gather(const u32* __restrict__ assign, const u32* __restrict__ load,
-                            const u32* __restrict__ idx, const u32* __restrict__ req, u64 n,
-                            const u32* __restrict__ pos, u32* __restrict__ vcur, u32* __restrict__ vload,
-                            u32* __restrict__ vaff) {
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
-        const u32 i = idx[k];
-        const bool first = pos[i] == (u32)k;
-        vcur[k] = first ? assign[i] : kSkipMark;
+
+__global__ __launch_bounds__(256) void k_ppm_gather(const u32* __restrict__ assign, const u32* __restrict__ load,
+                                                    const u32* __restrict__ idx, u64 n, const u32* __restrict__ pos,
+                                                    u32* __restrict__ vcur, u32* __restrict__ vload, u32* __restrict__ vfirst,
+                                                    const u32* __restrict__ bad) {
+    if (*bad) return;  // (every entry is valid from here on)
+    const u64 nvec = n >> 2, stride = (u64)gridDim.x * 256;
+    for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        const uint4 iv = *reinterpret_cast<const uint4*>(idx + 4 * v);
+        // twelve independent gathers in flight per lane before the first is used
+        const u32 p0 = pos[iv.x], p1 = pos[iv.y], p2 = pos[iv.z], p3 = pos[iv.w];
+        const u32 a0 = assign[iv.x], a1 = assign[iv.y], a2 = assign[iv.z], a3 = assign[iv.w];
+        const uint4 lv = make_uint4(load[iv.x], load[iv.y], load[iv.z], load[iv.w]);
+        const u32 k0 = (u32)(4 * v);
+        *reinterpret_cast<uint4*>(vfirst + 4 * v) = make_uint4(p0, p1, p2, p3);
+        *reinterpret_cast<uint4*>(vcur + 4 * v) = make_uint4(p0 == k0 ? a0 : kSkipMark, p1 == k0 + 1 ? a1 : kSkipMark,
+                                                             p2 == k0 + 2 ? a2 : kSkipMark, p3 == k0 + 3 ? a3 : kSkipMark);
+        *reinterpret_cast<uint4*>(vload + 4 * v) = lv;
+    }
+    const u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) {
+        const u32 i = idx[k], f = pos[i];
+        vfirst[k] = f;
+        vcur[k] = f == (u32)k ? assign[i] : kSkipMark;
         vload[k] = load[i];
-        vaff[k] = req[k];
     }
 }
-// (4) winners publish their new node
-__global__ void k_pp_scatter(u32* __restrict__ assign, const u32* __restrict__ idx, u64 n,
-                             const u32* __restrict__ vcur, const u32* __restrict__ vnext) {
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
-        if (vcur[k] == kNone) {
-            const u32 nd = vnext[k];
-            if (nd < kSkipMark) assign[idx[k]] = nd;
+
+struct PpmOutArgs {
+    u32* assign; const u32* idx; const u32* req; u64 n; u64 n_obj;
+    const u32* vcur; const u32* vnext; const u32* vfirst; const u32* vflag;  // vflag: nullptr when every node is alive
+    u32* pos; const u32* alive_bits; const u32* cutidx; u32 m; u32 sa;
+    u32* out_node; u32* out_flag; u32* aff_life;
+    u32* bad; const DevStats* stats; const u32* bsp_cnt; u32 G; u32 fixup_done;
+    u32* status; unsigned int* ticket; u32* done; u32 seq;
+};
+__global__ __launch_bounds__(256) void k_ppm_output(const PpmOutArgs a) {
+    const u32 isbad = *a.bad;
+    // did the solve of the virtual table need the cut / water-fill?  (a node with a cut, or a row k_scan sent to the water-fill)
+    const u32 pend = (!a.fixup_done && threadIdx.x < a.G) ? a.bsp_cnt[threadIdx.x] : 0u;
+    const bool slow = __syncthreads_or(pend != 0u || (!a.fixup_done && threadIdx.x == 0 && a.stats->n_cut != 0));
+    const u32 st = isbad ? kPpmBad : (slow ? kPpmNeedFix : kPpmOk);
+    const u64 stride = (u64)gridDim.x * 256;
+    if (st == kPpmBad) {  // the valid entries' election marks go back to all-ones; nothing else was changed
+        for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < a.n; k += stride) {
+            const u32 i = a.idx[k];
+            if (i < a.n_obj && a.req[k] < a.m) a.pos[i] = kNone;
+        }
+    } else if (st == kPpmOk) {
+        auto one = [&](u64 k, u32 i, u32 r, u32 first, u32& nd_out) -> u32 {
+            const bool mine = first == (u32)k;
+            const u32 c0 = a.vcur[first];           // the row as its first request found it: a node (sticky) or NONE (pending)
+            const bool placed_now = c0 == kNone;
+            u32 nd = c0;
+            if (placed_now) {
+                const u32 nx = a.vnext[first];
+                nd = nx < kSkipMark ? nx : kNone;    // (kSpillMark: no room anywhere)
+            }
+            if (mine) {
+                if (placed_now) {
+                    if (nd != kNone) a.assign[i] = nd;
+                    // row lifecycle: the first request of a pending row makes it an object (placed or not), home = the requester
+                    if (a.aff_life) a.aff_life[i] = r;
+                }
+                a.pos[i] = kNone;
+            }
+            u32 fl;
+            if (nd == kNone) fl = 4u;                                  // UNPLACED
+            else if (mine && placed_now) {                             // this request placed the row
+                const bool claimed = (a.sa || bit_of(a.alive_bits, r)) && (u32)k < a.cutidx[r];
+                fl = claimed ? 2u : 3u;                                // PLACED | SPILLED
+            } else fl = (nd == r) ? 0u : 1u;                           // LOCAL | REDIRECT
+            // the first request of an object it found on a server that is not alive keeps that fact, whatever the outcome
+            if (mine && placed_now && a.vflag) fl |= a.vflag[k] & kFlagReplaced;
+            nd_out = nd;
+            return fl;
+        };
+        const u64 nvec = a.n >> 2;
+        for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+            const uint4 iv = *reinterpret_cast<const uint4*>(a.idx + 4 * v), rv = *reinterpret_cast<const uint4*>(a.req + 4 * v);
+            const uint4 fv = *reinterpret_cast<const uint4*>(a.vfirst + 4 * v);
+            uint4 on, of;
+            of.x = one(4 * v + 0, iv.x, rv.x, fv.x, on.x); of.y = one(4 * v + 1, iv.y, rv.y, fv.y, on.y);
+            of.z = one(4 * v + 2, iv.z, rv.z, fv.z, on.z); of.w = one(4 * v + 3, iv.w, rv.w, fv.w, on.w);
+            *reinterpret_cast<uint4*>(a.out_node + 4 * v) = on;
+            if (a.out_flag) *reinterpret_cast<uint4*>(a.out_flag + 4 * v) = of;
+        }
+        const u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x;
+        if (k < a.n) {
+            u32 nd;
+            const u32 fl = one(k, a.idx[k], a.req[k], a.vfirst[k], nd);
+            a.out_node[k] = nd;
+            if (a.out_flag) a.out_flag[k] = fl;
         }
     }
-}
-// (5) outputs + scratch reset
-__global__ void k_pp_output(const u32* __restrict__ assign, const u32* __restrict__ idx,
-                            const u32* __restrict__ req, u64 n, const u32* __restrict__ vcur,
-                            u32* __restrict__ pos, const u32* __restrict__ alive_bits,
-                            const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
-                            u32* __restrict__ out_flag, u32* __restrict__ aff_life, unsigned int* ticket, u32* done,
-                            u32 seq, u32 keep_mask /* kFlagReplaced, or 0 when k_pp_mark_dead did not run (every node alive) */,
-                            u32 sa) {
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (u64)gridDim.x * blockDim.x) {
-        const u32 i = idx[k], r = req[k];
-        const u32 nd = assign[i];
-        // row lifecycle: the first request of a pending row makes it an object (placed or not), home = the requester
-        if (aff_life && vcur[k] == kNone) aff_life[i] = r;
-        u32 fl;
-        if (nd == kNone) fl = 4u;                                  // UNPLACED
-        else if (vcur[k] == kNone) {                               // this request placed the row
-            const bool claimed = (sa || bit_of(alive_bits, r)) && (cutidx == nullptr || (u32)k < cutidx[r]);
-            fl = claimed ? 2u : 3u;                                // PLACED | SPILLED
-        } else fl = (nd == r) ? 0u : 1u;                           // LOCAL | REDIRECT
-        out_node[k] = nd;
-        // the column still holds k_pp_mark_dead's "found on a dead node" bits: the first request of the object keeps its own
-        if (out_flag) out_flag[k] = fl | ((keep_mask && vcur[k] == kNone) ? (out_flag[k] & keep_mask) : 0u);
-        if (pos) pos[i] = kNone;
+    // status, then the completion word; the last workgroup to arrive also puts the bad-entry word back to 0 (everybody has read it)
+    if (threadIdx.x == 0) __hip_atomic_store(a.status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st != kPpmNeedFix) __hip_atomic_store(a.bad, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.done, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    if (done) signal_done_grid(ticket, done, seq);  // medium batches: the outputs sit in mapped pinned memory, the host spins
 }
 
 
@@ -4171,8 +4263,9 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
             else launch_scan_t<true, false, 1, 3>(p, t, nt, b, s, e0, e1, &sc);
             return;
         }
-        if (all_alive) launch_scan_t<true, true, 1>(p, t, nt, b, s, e0, e1);
-        else launch_scan_t<true, false, 1>(p, t, nt, b, s, e0, e1);
+        const PackOut guard{nullptr, nullptr, nullptr, nullptr, const_cast<u32*>(t.skip_if)};  // (wcnt: solve an empty table when set)
+        if (all_alive) launch_scan_t<true, true, 1>(p, t, nt, b, s, e0, e1, &guard);
+        else launch_scan_t<true, false, 1>(p, t, nt, b, s, e0, e1, &guard);
         return;
     }
     if (g_scan_nt_mode == 1 || (g_scan_nt_mode == 0 && p.n >= kScanNtRows)) {
@@ -4470,10 +4563,10 @@ bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req) {
            (((uintptr_t)idx | (uintptr_t)req) & 15u) == 0;
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
-                  u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life, u32 seq) {
+                  u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life, u32 seq, const u32* skip_if) {
     const size_t lds = (size_t)((m + 31) / 32 + 4) * sizeof(u32);
     hipLaunchKernelGGL(k_clean, dim3(grid_for((n_obj + 3) / 4, kBlock, 256)), dim3(kBlock), lds, s, assign, n_obj, m,
-                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out, aff_life, seq);
+                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out, aff_life, seq, skip_if);
 }
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s) {
     (void)hipMemsetAsync(used, 0, (size_t)m * sizeof(u64), s);
@@ -4534,26 +4627,29 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
                            used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk, trace_flag(), sa);
     }
 }
-void launch_pp_mark_dead(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req,
-                         u64 n, u32* dead_bits, DevStats* st, hipStream_t s, u32* req_dead) {
-    (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
-    hipLaunchKernelGGL(k_pp_mark_dead, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, alive_bits, idx,
-                       req, n, dead_bits, st, req_dead);
+void launch_ppm_first(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req, u64 n,
+                      u32* pos, u32* s_idx, u32* s_req, u32* dead_bits, u32* vflag, u32* bad, hipStream_t s) {
+    if (dead_bits) (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
+    hipLaunchKernelGGL(k_ppm_first, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, alive_bits, idx, req,
+                       n, pos, s_idx, s_req, dead_bits, vflag, bad);
 }
-void launch_pp_gather(const u32* assign, const u32* load, const u32* idx, const u32* req, u64 n, u32* pos, u32* vcur,
-                      u32* vload, u32* vaff, hipStream_t s) {
-    const unsigned g = grid_for(n, 256, 4096);
-    hipLaunchKernelGGL(k_pp_elect, dim3(g), dim3(256), 0, s, idx, n, (u64)~0ull, pos);
-    hipLaunchKernelGGL(k_pp_gather, dim3(g), dim3(256), 0, s, assign, load, idx, req, n, pos, vcur, vload, vaff);
+void launch_ppm_gather(const u32* assign, const u32* load, const u32* idx, u64 n, const u32* pos, u32* vcur, u32* vload,
+                       u32* vfirst, const u32* bad, hipStream_t s) {
+    hipLaunchKernelGGL(k_ppm_gather, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, assign, load, idx, n, pos, vcur,
+                       vload, vfirst, bad);
 }
-void launch_pp_scatter(u32* assign, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext, u32* pos,
-                       const u32* alive_bits, const u32* cutidx_or_null, u32 m, u32* out_node, u32* out_flag,
-                       hipStream_t s, u32* aff_life, unsigned int* ticket, u32* done, u32 seq, bool flag_bits, u32 sa) {
-    const unsigned g = grid_for(n, 256, 4096);
-    hipLaunchKernelGGL(k_pp_scatter, dim3(g), dim3(256), 0, s, assign, idx, n, vcur, vnext);
-    hipLaunchKernelGGL(k_pp_output, dim3(g), dim3(256), 0, s, assign, idx, req, n, vcur, pos, alive_bits,
-                       cutidx_or_null, m, out_node, out_flag, aff_life, ticket, (ticket ? done : nullptr), seq,
-                       flag_bits ? kFlagReplaced : 0u, sa);
+void launch_ppm_output(u32* assign, u64 n_obj, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
+                       const u32* vfirst, const u32* vflag, u32* pos, const u32* alive_bits, const SolveBufs& b, const Plan& vp,
+                       u32* out_node, u32* out_flag, u32* aff_life, u32* bad, bool fixup_done, u32* status, unsigned int* ticket,
+                       u32* done, u32 seq, hipStream_t s) {
+    PpmOutArgs a;
+    a.assign = assign; a.idx = idx; a.req = req; a.n = n; a.n_obj = n_obj;
+    a.vcur = vcur; a.vnext = vnext; a.vfirst = vfirst; a.vflag = vflag;
+    a.pos = pos; a.alive_bits = alive_bits; a.cutidx = b.cutidx; a.m = vp.m; a.sa = vp.sa;
+    a.out_node = out_node; a.out_flag = out_flag; a.aff_life = aff_life;
+    a.bad = bad; a.stats = b.stats; a.bsp_cnt = b.bsp_cnt[0]; a.G = vp.G; a.fixup_done = fixup_done ? 1u : 0u;
+    a.status = status; a.ticket = ticket; a.done = done; a.seq = seq;
+    hipLaunchKernelGGL(k_ppm_output, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, a);
 }
 
 void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s) {

@@ -221,6 +221,11 @@ struct rio_gp {
     u32* h_mid = nullptr;   // medium batches (<= kMidBatch), mapped pinned memory, [4][kMidBatch] u32: lookup idx | out; place_pending idx | req | out | flag
     u32* d_mid = nullptr;
     unsigned int* mid_ticket = nullptr;  // device word of the several-workgroup completion protocol
+    u32* h_req = nullptr;   // request batches of up to kReqBatch entries from host buffers, mapped pinned memory, [4][kReqBatch] u32: idx | req | out | flag
+    u32* d_req = nullptr;
+    u32* pp_bad = nullptr;  // device word of the general request path: != 0 while a batch with an invalid entry is in flight
+    bool pp_last_slow = false;  // the last general-path request batch needed the cut / water-fill: the next one enqueues it speculatively
+    DevBuf rq[4];           // staging of bigger host-buffer request batches (the general path's own scratch is vt / stage)
     void* pp_stage = nullptr;            // staging table of the three-launch request path (k_pp_stage / _decide / _apply)
     u32 small_seq = 0;      // sequence number of the last micro-batch call; its completion word is row 5, word 0
     // virtual table (place_pending) and staging for host-pointer calls
@@ -843,6 +848,13 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     h->allocs.push_back(h->mid_ticket);
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_req), (size_t)4 * kReqBatch * sizeof(u32), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_req), h->h_req, 0) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->pp_bad), 64) != hipSuccess || hipMemset(h->pp_bad, 0, 64) != hipSuccess) {
+        h->err = "hipHostMalloc(mapped request staging) failed";
+        return bail(RIO_GP_ENOMEM);
+    }
+    h->allocs.push_back(h->pp_bad);
     if (hipMalloc(&h->pp_stage, pp_stage_bytes()) != hipSuccess || hipMemset(h->pp_stage, 0, pp_stage_bytes()) != hipSuccess) {
         h->err = "request staging allocation failed";
         return bail(RIO_GP_ENOMEM);
@@ -876,6 +888,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& b : h->vt) if (b.p) (void)hipFree(b.p);
     for (auto& b : h->stage) if (b.p) (void)hipFree(b.p);
+    for (auto& b : h->rq) if (b.p) (void)hipFree(b.p);
     if (h->vrec.p) (void)hipFree(h->vrec.p);
     if (h->part.p) (void)hipFree(h->part.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
@@ -883,6 +896,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->h_fx) (void)hipHostFree(h->h_fx);
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_mid) (void)hipHostFree(h->h_mid);
+    if (h->h_req) (void)hipHostFree(h->h_req);
     if (h->h_cs) (void)hipHostFree(h->h_cs);
     if (h->h_alive_ring) (void)hipHostFree(h->h_alive_ring);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1340,13 +1354,14 @@ int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
 
 // ---- policy -------------------------------------------------------------------------------
 
-// The general path of place_pending over DEVICE-resident request / result arrays (the host-pointer call stages into
-// these, the _dev call hands its own): mark dead -> clean -> elect first request -> gather the virtual table -> solve it
-// against the committed `used` (same kernels, VIRT) -> scatter + outputs.  check_entries: the entries were not
-// validated on the host, so k_pp_mark_dead's count of bad ones is read BEFORE anything is changed.
-// done_seq != 0: the request / result arrays are mapped pinned memory and the last kernel stores the completion word
+// The general path of place_pending (any batch the one-workgroup kernels do not finish): the window-sorted form for big dense
+// batches, else k_ppm_first -> [k_clean] -> k_ppm_gather -> solve of the virtual table against the committed `used` (same
+// kernels, VIRT) -> [fix-up] -> k_ppm_output, with nothing waiting on the host in between (placement_kernels.hip).
+// d_idx / d_req / d_out / d_flag: device-resident arrays, or (host_io) rows of mapped pinned host memory — then the first
+// kernel leaves device copies of the requests for the kernels behind it and the last one writes the results over PCIe.
+// Synchronous: returns when the results are in d_out / d_flag.  dev_api: the entries were NOT validated on the host.
 static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const u32* d_req, u32* d_out, u32* d_flag,
-                                 bool check_entries, u32 done_seq = 0) {
+                                 bool host_io, bool dev_api) {
     flush_alive(h);  // the request kernels read the device's liveness bitmap
     int rc;
     const size_t bytes = n * sizeof(u32);
@@ -1356,7 +1371,8 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     u32* assign = h->assign[h->cur];
     h->sb.fx = FxRows{};  // nobody reads the fix-up counters of the virtual-table solve: plain DevStats atomics, no pinned slot touched
     if ((rc = ensure_used(h))) return rc;
-    if (h->part_mode != 2 && !done_seq && pp_win_applicable(h->n, n, d_idx, d_req)) {
+    const char* const who = dev_api ? "rio_gp_place_pending_dev" : "rio_gp_place_pending";
+    if (h->part_mode != 2 && !host_io && pp_win_applicable(h->n, n, d_idx, d_req)) {
         // Big batch: sorted by row window once, the row-side step out of LDS (k_pp_win_gather), the decisions written into the
         // real column by the solve itself: two random accesses per request instead of nine.  The entries are validated by the
         // binning kernel, which changes nothing.
@@ -1387,13 +1403,9 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         enqueue_slow(h, vp, vtab, vnt, true, false);  // ahead of the verdict: its kernels guard themselves on the device
         launch_pp_win_output(d_idx, d_req, n, vcur, vload, vnext, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag, aff_life(h), h->dstats,
                              h->stream, h->sa);
-        if (!spin_rows(h->h_slots, resolve_blocks(h->m), seq)) HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
-        if (*h_bad) {
-            if (check_entries)
-                return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
-            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: object index or requester out of range (nothing was changed)");
-        }
+        if (*h_bad) return fail(h, RIO_GP_EINVAL, std::string(who) + ": object index or requester out of range (nothing was changed)");
         const DevStats v = reduce_slot(h, 0, h->m);
         const bool vslow = v.n_cut > 0 || v.spillcand > 0;
         std::swap(h->used, h->sb.used_cur);
@@ -1402,44 +1414,61 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         h->have_solved = false; ++h->mut_epoch;
         return RIO_GP_OK;
     }
-    // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes.  With every node alive and
-    //     the entries validated on the host there is nothing to mark, nothing to clean and no counter to read: four
-    //     enqueues less on a path whose cost is its launches.
-    const bool mark = check_entries || !h->all_alive;
-    if (mark) {
-        if ((rc = zero_stats(h))) return rc;
-        launch_pp_mark_dead(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->dead_bits, h->dstats, h->stream, d_flag);
-        if (check_entries) {
-            if ((rc = read_stats(h))) return rc;
-            if (h->h_stats[0].err)
-                return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
-        }
-        if (!h->all_alive)
-            launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
+    // device copies of requests that live in mapped host memory; the REPLACED bits of requests that ran into a dead node
+    u32 *s_idx = nullptr, *s_req = nullptr, *vflag = nullptr;
+    if (host_io) {
+        if ((rc = ensure(h, h->stage[0], bytes)) || (rc = ensure(h, h->stage[1], bytes))) return rc;
+        s_idx = (u32*)h->stage[0].p; s_req = (u32*)h->stage[1].p;
     }
-    // (2)(3) first request per row decides; gather the virtual table (rows = requests)
-    launch_pp_gather(assign, h->load, d_idx, d_req, n, h->pos, vcur, vload, vaff, h->stream);
-    // (4) solve the virtual table against the committed `used`
+    const bool mark = !h->all_alive;  // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
+    if (mark) {
+        if ((rc = ensure(h, h->stage[2], bytes))) return rc;
+        vflag = (u32*)h->stage[2].p;
+    }
+    u32* const h_status = h->h_small + 4 * kSmallBatch;
+    u32* const d_status = h->d_small + 4 * kSmallBatch;
+    *h_status = 2;  // neither 0, 1 nor 3: the output kernel must write it
+    launch_ppm_first(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->pos, s_idx, s_req, mark ? h->dead_bits : nullptr, vflag,
+                     h->pp_bad, h->stream);
+    const u32* const k_idx = host_io ? s_idx : d_idx;
+    const u32* const k_req = host_io ? s_req : d_req;
+    if (mark) launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h), 0, h->pp_bad);
+    // (2)(3) the virtual table (rows = requests): the first request per row decides
+    launch_ppm_gather(assign, h->load, k_idx, n, h->pos, vcur, vload, vaff /* position of the row's first request */, h->pp_bad, h->stream);
+    // (4) solve it against the committed `used`
     Plan vp = hplan(h, n);
-    const u64 seq = ++h->wait_seq;
-    vp.mark = seq;  // k_resolve's pinned partial rows carry it: the verdict is waited for without the runtime (spin_rows)
-    const Table vtab{vcur, vload, vaff, vnext};
+    const u64 mk = ++h->wait_seq;
+    vp.mark = mk;
+    Table vtab{vcur, vload, k_req /* the requesters ARE the affinity column of the virtual table */, vnext};
+    vtab.skip_if = h->pp_bad;
     const NodeTab vnt{h->cap, h->alive_bits, h->used};  // (ensure_used above folded whatever the last solve's rounds had left)
     h->sb.D = h->D;
     launch_scan(vp, vtab, vnt, h->sb, true, h->all_alive, h->stream);
     launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
-    if (!spin_rows(h->h_slots, resolve_blocks(h->m), seq)) HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
-    bool vslow = false;
-    {
-        const DevStats v = reduce_slot(h, 0, h->m);
-        vslow = v.n_cut > 0 || v.spillcand > 0;
-        if (vslow) enqueue_slow(h, vp, vtab, vnt, true, false);
+    // the fix-up ahead of the verdict when the last batch needed it (its kernels guard themselves on the device); otherwise the
+    // output kernel finds out on the device and hands back status 1 having changed nothing
+    bool fixed = h->spec_mode != 2 && (h->spec_mode == 1 || h->pp_last_slow);
+    if (fixed) enqueue_slow(h, vp, vtab, vnt, true, false);
+    // (5) publish, outputs, scratch reset, completion word
+    u32 seq = small_begin(h);
+    launch_ppm_output(assign, h->n, k_idx, k_req, n, vcur, vnext, vaff, vflag, h->pos, h->alive_bits, h->sb, vp, d_out, d_flag,
+                      aff_life(h), h->pp_bad, fixed, d_status, h->mid_ticket, small_done_dev(h), seq, h->stream);
+    if ((rc = small_wait(h, seq))) return rc;
+    if (*h_status == 1 && !fixed) {
+        enqueue_slow(h, vp, vtab, vnt, true, false);
+        fixed = true;
+        *h_status = 2;
+        seq = small_begin(h);
+        launch_ppm_output(assign, h->n, k_idx, k_req, n, vcur, vnext, vaff, vflag, h->pos, h->alive_bits, h->sb, vp, d_out, d_flag,
+                          aff_life(h), h->pp_bad, true, d_status, h->mid_ticket, small_done_dev(h), seq, h->stream);
+        if ((rc = small_wait(h, seq))) return rc;
     }
-    // (5) publish, outputs, new `used`
-    launch_pp_scatter(assign, d_idx, d_req, n, vcur, vnext, h->pos, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag,
-                      h->stream, aff_life(h), done_seq ? h->mid_ticket : nullptr, done_seq ? small_done_dev(h) : nullptr, done_seq,
-                      mark, h->sa);
+    HIPCHK(h, hipGetLastError());
+    if (*h_status == 3) return fail(h, RIO_GP_EINVAL, std::string(who) + ": object index or requester out of range (nothing was changed)");
+    if (*h_status != 0) return fail(h, RIO_GP_EUPSTREAM, std::string(who) + ": the output kernel left no status");
+    const DevStats v = reduce_slot(h, 0, h->m);  // (k_resolve's pinned rows landed before the completion word)
+    const bool vslow = v.n_cut > 0 || v.spillcand > 0;
+    h->pp_last_slow = vslow;
     std::swap(h->used, h->sb.used_cur);  // the solve's `used` vector becomes the committed one (as commit does): no copy
     h->used_parts = vslow && h->sb.D != nullptr;  // + what the water-fill rounds admitted (D rows), folded in later
     h->parts_rounds = h->rounds;
@@ -1487,9 +1516,8 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
     }
     const size_t bytes = n * sizeof(u32);
     if (n <= (uint64_t)kMidBatch / 4) {
-        // medium batch (<= 4 096 requests): requests and results in mapped pinned memory (the kernels of the general path read
-        // and write them in place — five kernels re-read them over PCIe, which is why the bound is lower than for lookups),
-        // the output kernel's last workgroup stores the completion word: four staging copies and the stream wait less per call
+        // medium batch (<= 4 096 requests): requests and results in mapped pinned memory, the last kernel's last workgroup
+        // stores the completion word: no staging copies, no stream wait
         u32* hm = h->h_mid;
         u32* dm = h->d_mid;
         memcpy(hm, idx, bytes);
@@ -1513,20 +1541,29 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
             }
             if (status != 1) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_place_pending: one-workgroup kernel left no status");
         }
-        const u32 seq = small_begin(h);
-        if ((rc = place_pending_general(h, n, dm, dm + kMidBatch, dm + 2 * kMidBatch, dm + 3 * kMidBatch, false, seq))) return rc;
-        if ((rc = small_wait(h, seq))) return rc;
+        if ((rc = place_pending_general(h, n, dm, dm + kMidBatch, dm + 2 * kMidBatch, dm + 3 * kMidBatch, true, false))) return rc;
         memcpy(out_node, hm + 2 * kMidBatch, bytes);
         if (out_flag) memcpy(out_flag, hm + 3 * kMidBatch, bytes);
         return RIO_GP_OK;
     }
-    for (int q = 0; q < 4; ++q)
-        if ((rc = ensure(h, h->stage[q], bytes))) return rc;
-    u32 *d_idx = (u32*)h->stage[0].p, *d_req = (u32*)h->stage[1].p, *d_out = (u32*)h->stage[2].p,
-        *d_flag = (u32*)h->stage[3].p;
+    if (n <= (uint64_t)kReqBatch) {
+        // up to 65 536 requests: requests and results in mapped pinned memory — the first kernel of the general path reads them
+        // over PCIe once (and leaves device copies), the last one writes the results back; no staging copies through the runtime
+        u32* hq = h->h_req;
+        u32* dq = h->d_req;
+        memcpy(hq, idx, bytes);
+        memcpy(hq + kReqBatch, requester, bytes);
+        if ((rc = place_pending_general(h, n, dq, dq + kReqBatch, dq + 2 * kReqBatch, dq + 3 * kReqBatch, true, false))) return rc;
+        memcpy(out_node, hq + 2 * kReqBatch, bytes);
+        if (out_flag) memcpy(out_flag, hq + 3 * kReqBatch, bytes);
+        return RIO_GP_OK;
+    }
+    for (int q = 0; q < 2; ++q)
+        if ((rc = ensure(h, h->rq[q], bytes)) || (rc = ensure(h, h->rq[2 + q], bytes))) return rc;
+    u32 *d_idx = (u32*)h->rq[0].p, *d_req = (u32*)h->rq[1].p, *d_out = (u32*)h->rq[2].p, *d_flag = (u32*)h->rq[3].p;
     HIPCHK(h, hipMemcpyAsync(d_idx, idx, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_req, requester, bytes, hipMemcpyHostToDevice, h->stream));
-    if ((rc = place_pending_general(h, n, d_idx, d_req, d_out, d_flag, false))) return rc;
+    if ((rc = place_pending_general(h, n, d_idx, d_req, d_out, d_flag, false, false))) return rc;
     HIPCHK(h, hipMemcpyAsync(out_node, d_out, bytes, hipMemcpyDeviceToHost, h->stream));
     if (out_flag) HIPCHK(h, hipMemcpyAsync(out_flag, d_flag, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1567,11 +1604,7 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
             return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: object index or requester out of range (nothing was changed)");
         if (status != 1) return fail(h, RIO_GP_EUPSTREAM, "rio_gp_place_pending_dev: one-workgroup kernel left no status");
     }
-    rc = place_pending_general(h, n, d_idx, d_requester, d_out_node, d_out_flag, true);
-    if (rc) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
-    return RIO_GP_OK;
+    return place_pending_general(h, n, d_idx, d_requester, d_out_node, d_out_flag, false, true);
 }
 
 int rio_gp_solve(rio_gp_t* h, rio_gp_stats* stats) {

@@ -98,6 +98,24 @@ def test_bench_two_ranks_as_the_driver_launches_it(exchange):
     assert d["config"]["exchange"] in ("p2p", "torch")
 
 
+def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` started the way the driver starts the N = 1 line (no torchrun, no WORLD_SIZE) must not
+    print a one-GPU line under another name: it starts the two ranks itself and prints ONE line with n_gpus = 2 — and without
+    --same-device on this one-GPU box it refuses loudly instead."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "c2",
+           "--objects", "300000", "--no-cpu-baseline", "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["objects_per_gpu"] == 300000 and d["stats_last_step"]["n_objects"] == 600000
+    assert [x["rank"] for x in d["config"]["ranks"]] == [0, 1]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([c for c in cmd if c != "--same-device"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert r.returncode == 2 and r.stdout.strip() == "" and "refusing to run" in r.stderr
+
+
 def _check_scaling_fields(d, world, exchange):
     """What every N > 1 line says about itself, in the same words at every N: `value` = committed ticks of the ONE config-4
     table (the definition string is the N = 1 line's), who ran where, and what RCCL was asked for."""

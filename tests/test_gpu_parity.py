@@ -905,7 +905,7 @@ def test_place_pending_batch_sizes_around_every_path_boundary(gp, oracle):
     g.set_objects(n, load, None)
     ref = np.full(n, NONE, np.uint32)
     used = np.zeros(m, np.uint64)
-    for step, k in enumerate((256, 257, 1000, 1024, 1025, 4095, 4096, 4097, 20_000, 300, 2048, 257)):
+    for step, k in enumerate((256, 257, 1000, 1024, 1025, 4095, 4096, 4097, 20_000, 300, 2048, 257, 65_535, 65_536, 65_537, 8192)):
         if step % 3 == 2:
             j = int(rng.integers(m))
             alive[j] ^= 1
@@ -1101,6 +1101,60 @@ def test_place_pending_dev_equals_host_call(gp, oracle):
         g.place_pending_dev(4, bad.ptr, rq.ptr, out.ptr)
     assert e.value.rc == gp.EINVAL
     assert np.array_equal(g.get_assign(), ref)                                       # nothing was changed
+    g.close()
+
+
+@pytest.mark.parametrize("speculate", ["auto", "always", "never"])
+def test_place_pending_general_path_no_host_round_trip(gp, oracle, speculate):
+    """The general request path (k_ppm_first / k_ppm_gather / solve / k_ppm_output: 4 097 ... 2^18 requests, or anything the
+    one-workgroup kernels hand over) enqueues everything and waits once: an invalid entry anywhere in a device-resident batch
+    fails the call with NOTHING changed (table, `used`, the election scratch: the next call is right), a solve that needs the
+    cut / water-fill is found out on the device (status 1 -> fix-up -> outputs) or has its fix-up enqueued ahead of the verdict,
+    dead nodes in the way are cleaned (REPLACED), from device arrays and from host buffers — every call against the oracle."""
+    from hipbuf import DevBuf
+    rng = np.random.default_rng(333)
+    n, m = 500_000, 120
+    load = rng.integers(0, 25, n).astype(np.uint32)
+    cap = np.full(m, int(load.sum() // m // 4), np.uint64)     # tight: batches run requesters full along the way
+    alive = np.ones(m, np.uint8)
+    g = gp.LabPlacement(n, m, spill_rounds=2)
+    g.set_speculate(speculate)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step, k in enumerate((4097, 8192, 5000, 65_536, 16_384, 70_001, 131_072, 6001, 4100)):
+        if step in (3, 6):
+            for j in rng.integers(0, m, 6):
+                alive[j] ^= 1
+            g.set_alive_all(alive)
+        idx = rng.integers(0, n if step % 2 else n // 8, k).astype(np.uint32)
+        req = rng.integers(0, m, k).astype(np.uint32)                      # dead requesters included
+        if step % 3 == 1:   # a batch with ONE invalid entry first: nothing may change
+            bi, br = idx.copy(), req.copy()
+            if step % 2:
+                bi[int(rng.integers(k))] = n
+            else:
+                br[int(rng.integers(k))] = m
+            d_idx, d_req, d_node = DevBuf(bi), DevBuf(br), DevBuf(nbytes=4 * k)
+            with pytest.raises(gp.ObjectPlacementError) as e:
+                g.place_pending_dev(k, d_idx.ptr, d_req.ptr, d_node.ptr)
+            assert e.value.rc == gp.EINVAL and np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], used)
+            for x in (d_idx, d_req, d_node):
+                x.free()
+        if step % 2 == 0:
+            d_idx, d_req, d_node, d_flag = DevBuf(idx), DevBuf(req), DevBuf(nbytes=4 * k), DevBuf(nbytes=4 * k)
+            g.place_pending_dev(k, d_idx.ptr, d_req.ptr, d_node.ptr, d_flag.ptr)
+            node, flag = d_node.to_host(), d_flag.to_host()
+            for x in (d_idx, d_req, d_node, d_flag):
+                x.free()
+        else:
+            node, flag = g.place_pending(idx, req)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(node, wnode), (step, k, np.flatnonzero(node != wnode)[:5])
+        assert np.array_equal(flag, wflag), (step, k, np.flatnonzero(flag != wflag)[:5])
+        assert np.array_equal(g.get_assign(), ref), (step, k)
+        assert np.array_equal(g.get_nodes()[2], used), (step, k)
     g.close()
 
 
