@@ -35,10 +35,14 @@ typedef struct rio_op_cfg {
     uint64_t max_objects;  /* distinct object keys the table can hold */
     uint32_t max_nodes;    /* distinct server addresses */
     uint32_t spill_rounds; /* 0 -> 2 */
-    uint32_t flags;        /* 0, or RIO_GP_CFG_REF_SELF_ASSIGN (rio_gpu_placement.h): get_or_create_placement first-touches the
-                            * requester whether or not membership marks it active, as service.rs:244-252 does */
+    uint32_t flags;        /* 0 = the reference's behaviour: get_or_create_placement first-touches the requester whether or not
+                            * membership marks it active, as service.rs:244-252 does (the dense layer's
+                            * RIO_GP_CFG_REF_SELF_ASSIGN; that bit is accepted here and changes nothing).
+                            * RIO_OP_CFG_LIVE_FIRST_TOUCH opts OUT: a requester that membership marks inactive is not a
+                            * placement target, its first touches go to the water-fill (the capacity-aware extension) */
     uint32_t reserved;
 } rio_op_cfg;
+#define RIO_OP_CFG_LIVE_FIRST_TOUCH 4u
 
 /* LocalObjectPlacement::default() + ObjectPlacement::prepare (local.rs:15-18, mod.rs:42-44). */
 int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out);
@@ -123,6 +127,18 @@ int rio_op_remove_n(rio_op_t* p, const char* struct_name, size_t struct_name_len
 int rio_op_get_or_create_placement_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id,
                                      size_t object_id_len, const char* self_address, char* out, size_t out_cap, uint32_t* flag);
 int rio_op_snapshot_key_lengths(rio_op_t* p, const size_t** struct_name_lens, const size_t** object_id_lens);
+/* ... and the batched calls: struct_names[k] / object_ids[k] point at struct_name_lens[k] / object_id_lens[k] bytes (any byte, a
+ * NUL included); otherwise rio_op_update_batch / rio_op_lookup_batch / rio_op_get_or_create_placement_batch /
+ * rio_op_set_object_load.  Loading a snapshot whose keys may hold NUL bytes is rio_op_update_batch_n. */
+int rio_op_update_batch_n(rio_op_t* p, uint64_t n, const char* const* struct_names, const size_t* struct_name_lens,
+                          const char* const* object_ids, const size_t* object_id_lens, const char* const* server_addresses);
+int rio_op_lookup_batch_n(rio_op_t* p, uint64_t n, const char* const* struct_names, const size_t* struct_name_lens,
+                          const char* const* object_ids, const size_t* object_id_lens, uint32_t* out_node_ids);
+int rio_op_get_or_create_placement_batch_n(rio_op_t* p, uint64_t n, const char* const* struct_names, const size_t* struct_name_lens,
+                                           const char* const* object_ids, const size_t* object_id_lens,
+                                           const char* const* self_addresses, uint32_t* out_node_ids, uint32_t* out_flags);
+int rio_op_set_object_load_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id, size_t object_id_len,
+                             uint32_t load);
 
 /* Whole-table re-solve over the interned tables (rio_gp_tick). */
 int rio_op_tick(rio_op_t* p, rio_gp_stats* stats);

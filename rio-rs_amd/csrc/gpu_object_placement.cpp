@@ -107,6 +107,13 @@ struct Part {
     Part(const std::string& str) : p(str.data()), len((ptrdiff_t)str.size()) {}
     std::string str() const { return len < 0 ? std::string(p) : std::string(p, (size_t)len); }
 };
+// the keys of a batched call: NUL-terminated arrays, or arrays with lengths (the _batch_n entry points)
+struct Keys {
+    const char* const* tys; const size_t* tyl;
+    const char* const* ids; const size_t* idl;
+    Part ty(uint64_t k) const { return tyl ? Part(tys[k], tyl[k]) : Part(tys[k]); }
+    Part id(uint64_t k) const { return idl ? Part(ids[k], idl[k]) : Part(ids[k]); }
+};
 std::string key_of(const Part& ty, const Part& id) {  // local.rs:26-29,43,61
     std::string k = ty.str();
     k += '.';
@@ -515,7 +522,9 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     g.max_objects = cfg->max_objects;
     g.max_nodes = cfg->max_nodes;
     g.spill_rounds = cfg->spill_rounds;
-    g.flags = RIO_GP_CFG_ROW_LIFECYCLE | (cfg->flags & RIO_GP_CFG_REF_SELF_ASSIGN);
+    // reference-faithful unless the caller opts out: get_or_create_placement first-touches the requester whatever membership
+    // says about it (service.rs:244-252)
+    g.flags = RIO_GP_CFG_ROW_LIFECYCLE | ((cfg->flags & RIO_OP_CFG_LIVE_FIRST_TOUCH) ? 0u : RIO_GP_CFG_REF_SELF_ASSIGN);
     rio_gp_t* gp = nullptr;
     int rc = rio_gp_create(&g, &gp);
     if (rc) {
@@ -569,9 +578,8 @@ const char* rio_op_node_address(rio_op_t* p, uint32_t node_id) {
     return node_id < p->s->node_addr.size() ? p->s->node_addr[node_id].c_str() : nullptr;
 }
 
-int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids,
-                        const char* const* addrs) {
-    if (!p || (n && (!tys || !ids || !addrs))) return RIO_GP_EINVAL;
+static int op_update_batch(rio_op_t* p, uint64_t n, const Keys& ks, const char* const* addrs) {
+    if (!p || (n && (!ks.tys || !ks.ids || !addrs))) return RIO_GP_EINVAL;
     State* s = p->s;
     return compound_call(s, [&]() -> int {
         std::vector<uint32_t> rows, nodes;
@@ -581,10 +589,10 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
             uint32_t row = RIO_GP_NONE, node = RIO_GP_NONE;
             int rc;
             if (addrs[k]) {  // Some(address): entry(key) = address
-                if ((rc = intern_row(s, tys[k], ids[k], true, &row, true))) return rc;
+                if ((rc = intern_row(s, ks.ty(k), ks.id(k), true, &row, true))) return rc;
                 if ((rc = intern_node(s, addrs[k], true, &node))) return rc;
             } else {         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
-                if ((rc = intern_row(s, tys[k], ids[k], false, &row, true))) return rc;
+                if ((rc = intern_row(s, ks.ty(k), ks.id(k), false, &row, true))) return rc;
                 if (row == RIO_GP_NONE) continue;
             }
             rows.push_back(row);
@@ -596,6 +604,15 @@ int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
         rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), nodes.data());
         return rc ? gp_fail(s, rc) : RIO_GP_OK;
     });
+}
+
+int rio_op_update_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids, const char* const* addrs) {
+    return op_update_batch(p, n, Keys{tys, nullptr, ids, nullptr}, addrs);
+}
+int rio_op_update_batch_n(rio_op_t* p, uint64_t n, const char* const* tys, const size_t* tyl, const char* const* ids, const size_t* idl,
+                          const char* const* addrs) {
+    if (n && (!tyl || !idl)) return RIO_GP_EINVAL;
+    return op_update_batch(p, n, Keys{tys, tyl, ids, idl}, addrs);
 }
 
 static int op_update(rio_op_t* p, const Part& ty, const Part& id, const char* addr) {
@@ -617,15 +634,15 @@ static int op_update(rio_op_t* p, const Part& ty, const Part& id, const char* ad
     return rc == kNoop ? RIO_GP_OK : rc;
 }
 
-int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids, uint32_t* out) {
-    if (!p || (n && (!tys || !ids || !out))) return RIO_GP_EINVAL;
+static int op_lookup_batch(rio_op_t* p, uint64_t n, const Keys& ks, uint32_t* out) {
+    if (!p || (n && (!ks.tys || !ks.ids || !out))) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
     std::lock_guard<std::mutex> gi(s->imu);
     std::vector<uint32_t> rows, where;
     for (uint64_t k = 0; k < n; ++k) {
         uint32_t row;
-        int rc = intern_row(s, tys[k], ids[k], false, &row);
+        int rc = intern_row(s, ks.ty(k), ks.id(k), false, &row);
         if (rc) return rc;
         out[k] = RIO_GP_NONE;  // unknown key: Ok(None)
         if (row != RIO_GP_NONE) {
@@ -641,6 +658,15 @@ int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const c
     if (rc) return gp_fail(s, rc);
     for (size_t q = 0; q < rows.size(); ++q) out[where[q]] = res[q];
     return RIO_GP_OK;
+}
+
+int rio_op_lookup_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids, uint32_t* out) {
+    return op_lookup_batch(p, n, Keys{tys, nullptr, ids, nullptr}, out);
+}
+int rio_op_lookup_batch_n(rio_op_t* p, uint64_t n, const char* const* tys, const size_t* tyl, const char* const* ids, const size_t* idl,
+                          uint32_t* out) {
+    if (n && (!tyl || !idl)) return RIO_GP_EINVAL;
+    return op_lookup_batch(p, n, Keys{tys, tyl, ids, idl}, out);
 }
 
 int rio_op_update(rio_op_t* p, const char* ty, const char* id, const char* addr) { return op_update(p, Part(ty), Part(id), addr); }
@@ -741,7 +767,7 @@ int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t cap
     return sync_device(s, true);
 }
 
-int rio_op_set_object_load(rio_op_t* p, const char* ty, const char* id, uint32_t load) {
+static int op_set_object_load(rio_op_t* p, const Part& ty, const Part& id, uint32_t load) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
     return compound_call(s, [&]() -> int {
@@ -755,21 +781,36 @@ int rio_op_set_object_load(rio_op_t* p, const char* ty, const char* id, uint32_t
     });
 }
 
-int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids,
-                                         const char* const* selfs, uint32_t* out_node, uint32_t* out_flag) {
-    if (!p || (n && (!tys || !ids || !selfs || !out_node))) return RIO_GP_EINVAL;
+int rio_op_set_object_load(rio_op_t* p, const char* ty, const char* id, uint32_t load) { return op_set_object_load(p, Part(ty), Part(id), load); }
+int rio_op_set_object_load_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, size_t id_len, uint32_t load) {
+    return op_set_object_load(p, Part(ty, ty_len), Part(id, id_len), load);
+}
+
+static int op_get_or_create_batch(rio_op_t* p, uint64_t n, const Keys& ks, const char* const* selfs, uint32_t* out_node,
+                                  uint32_t* out_flag) {
+    if (!p || (n && (!ks.tys || !ks.ids || !selfs || !out_node))) return RIO_GP_EINVAL;
     State* s = p->s;
     return compound_call(s, [&]() -> int {
         std::vector<uint32_t> rows(n), reqs(n);
         for (uint64_t k = 0; k < n; ++k) {
             int rc;
-            if ((rc = intern_row(s, tys[k], ids[k], true, &rows[k], true))) return rc;
+            if ((rc = intern_row(s, ks.ty(k), ks.id(k), true, &rows[k], true))) return rc;
             if ((rc = intern_node(s, selfs[k], true, &reqs[k], true))) return rc;  // a server answering requests is up
         }
         int rc;
         if ((rc = sync_device(s, true))) return rc;
         return policy_batch(s, rows, reqs, out_node, out_flag);
     });
+}
+
+int rio_op_get_or_create_placement_batch(rio_op_t* p, uint64_t n, const char* const* tys, const char* const* ids,
+                                         const char* const* selfs, uint32_t* out_node, uint32_t* out_flag) {
+    return op_get_or_create_batch(p, n, Keys{tys, nullptr, ids, nullptr}, selfs, out_node, out_flag);
+}
+int rio_op_get_or_create_placement_batch_n(rio_op_t* p, uint64_t n, const char* const* tys, const size_t* tyl, const char* const* ids,
+                                           const size_t* idl, const char* const* selfs, uint32_t* out_node, uint32_t* out_flag) {
+    if (n && (!tyl || !idl)) return RIO_GP_EINVAL;
+    return op_get_or_create_batch(p, n, Keys{tys, tyl, ids, idl}, selfs, out_node, out_flag);
 }
 
 static int op_get_or_create(rio_op_t* p, const Part& ty, const Part& id, const char* self_address, char* out, size_t cap,

@@ -106,7 +106,8 @@ struct StepGuard {  // see P2P::out_of_step
     bool done = false;
     ~StepGuard() { if (q && !done) q->out_of_step = true; }
 };
-static const char* const kOutOfStep = "the peer-to-peer session lost step with its peers in an earlier failed call (connect the windows again)";
+static const char* const kOutOfStep = "the peer-to-peer session lost step with its peers in an earlier failed call: close it on every rank "
+                                      "(rio_gp_shard_p2p_close), then export and connect fresh windows";
 
 struct rio_gp {
     ShardComm* sc = nullptr;
@@ -490,6 +491,25 @@ int merge_slow(rio_gp* h, DevStats* v) {
     return RIO_GP_OK;
 }
 
+// A solve that works in place (k_inc_scan) has rewritten part of the committed column by the time anything behind it can
+// fail.  If the call does not reach its commit, the flags must not outlive it (a later solve that does not pass through
+// enqueue_scan_resolve — the row-sharded calls, rio_gp_solve_wait + rio_gp_commit — would skip its column swap and publish a
+// stale column), and the table is no longer what the `used` vector and the pending-row statistics describe: the next tick
+// re-solves it from scratch (plain k_scan: the kept histogram is rebuilt from the rows).
+struct InplaceGuard {
+    rio_gp* h;
+    bool ok = false;
+    ~InplaceGuard() {
+        if (ok) return;
+        if (h->solve_inplace) { h->used_valid = false; h->used_parts = false; h->last_pending_valid = false; h->last_fix_valid = false; }
+        h->solve_inplace = false;
+        h->inc_now = 0;
+        h->have_solved = false;
+    }
+};
+// every solve entry point that does not go through enqueue_scan_resolve starts from "not in place"
+void reset_inplace(rio_gp* h) { h->solve_inplace = false; h->inc_now = 0; }
+
 int commit_enqueue(rio_gp* h) {
     if (!h->have_solved) return fail(h, RIO_GP_EINVAL, "rio_gp_commit: no solve to commit");
     if (!h->solve_inplace) h->cur ^= 1;  // (k_inc_scan and its fix-up wrote the committed column itself)
@@ -516,6 +536,7 @@ int inc_choice(rio_gp* h, bool compact, bool commit) {
 // Host waits: verdict + completion when the fix-up is needed, verdict only on the fast path — and ONE wait when the
 // fix-up was enqueued speculatively (below).
 int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
+    InplaceGuard ipg{h};
     h->plan = hplan(h, h->n);
     h->ring_n = 0; h->ring_slow = 0; h->ring_any = false;
     use_fx_slot(h, 0);
@@ -580,6 +601,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     h->last_fix_valid = true;
     h->last_slow = slow;
     fill_stats(v, h->n, stats);
+    ipg.ok = true;
     return RIO_GP_OK;
 }
 
@@ -638,6 +660,7 @@ int tick_async_locked(rio_gp* h) {
     // nothing has changed since a tick that left every object placed: this one keeps every row, no fix-up can be needed
     // (lab builds: rio_gp_debug_set_speculate(always) keeps the launches)
     const bool quiet = h->quiet_epoch == h->mut_epoch && h->spec_mode != 1;
+    InplaceGuard ipg{h};
     h->plan = hplan(h, h->n);
     const Table t = real_table(h);
     const NodeTab nt = scan_nodes(h);
@@ -662,6 +685,7 @@ int tick_async_locked(rio_gp* h) {
     if (rc) return rc;
     HIPCHK(h, hipGetLastError());
     h->tick_n = k + 1;
+    ipg.ok = true;
     return RIO_GP_OK;
 }
 
@@ -1667,6 +1691,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
         }
         h->ring_n = 0;
     }
+    reset_inplace(h);
     h->plan = hplan(h, h->n);
     use_fx_slot(h, 0);
     const Table t = real_table(h);
@@ -1714,6 +1739,7 @@ int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     std::lock_guard<std::mutex> g(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->ev2) { HIPCHK(h, hipEventCreate(&h->ev2)); HIPCHK(h, hipEventCreate(&h->ev3)); }
+    reset_inplace(h);
     h->plan = hplan(h, h->n);
     use_fx_slot(h, 0);
     const Table t = real_table(h);
@@ -1781,6 +1807,7 @@ int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
     if (!h || !d_x) return RIO_GP_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);
     if (h->sa) return fail(h, RIO_GP_EINVAL, "row-sharded solves do not implement RIO_GP_CFG_REF_SELF_ASSIGN (single-GPU handles only)");
+    reset_inplace(h);
     h->plan = hplan(h, h->n);
     h->sb.fx = FxRows{};  // row-sharded solve: the fix-up counters are summed in DevStats (rio_gp_shard_finish reads them)
     fold_used(h);
@@ -2120,6 +2147,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
         StepGuard step{q};
         const u64 seq = ++q->seq;
         const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
+        reset_inplace(h);
         h->plan = hplan(h, h->n);
         h->sb.fx = FxRows{};
         fold_used(h);
@@ -2151,6 +2179,7 @@ int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (!sc) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_solve_async: set up rio_gp_shard_p2p_connect or rio_gp_shard_comm_init first");
     const int q = (int)(sc->k++ % kShardRing);
     if (sc->done_valid[q]) HIPCHK(h, hipStreamWaitEvent(h->stream, sc->done[q], 0));
+    reset_inplace(h);
     h->plan = hplan(h, h->n);
     h->sb.fx = FxRows{};
     fold_used(h);
@@ -2210,6 +2239,7 @@ int rio_gp_shard_tick_async(rio_gp_t* h) {
     StepGuard step{q};  // (every sequence number this tick takes — its own and its exchanges' — is taken before any check below)
     const u64 seq = ++q->seq;
     const u32 slot = (u32)(q->xslot_n++ % kP2PSlots);
+    reset_inplace(h);
     h->plan = hplan(h, h->n);
     h->sb.fx = FxRows{};
     fold_used(h);
@@ -2301,13 +2331,16 @@ int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, ui
         P2P* q = h->p2p;
         if (words > q->W) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_exchange: record larger than the window row");
         if (q->out_of_step) return fail(h, RIO_GP_EUPSTREAM, kOutOfStep);
+        StepGuard step{q};  // (a failure behind the sequence number / slot taken here leaves the ranks out of step: marked)
         const u64 seq = ++q->seq;
         const u32 slot = (u32)(q->yslot_n++ % kP2PSlots);
         launch_p2p_put(reinterpret_cast<const u64*>(d_in), (u32)words, q->d_peers, q->R, q->data_off(slot, q->rank),
                        q->flag_off(slot, q->rank), seq, h->stream);
         launch_p2p_wait_copy(q->win + q->data_off(slot, 0), q->W, q->R, (u32)words, q->win + q->flag_off(slot, 0), seq,
                              q->d_err, reinterpret_cast<u64*>(d_out), h->stream);
-        return p2p_check(h);
+        const int rc = p2p_check(h);
+        step.done = rc == RIO_GP_OK;
+        return rc;
     }
     if (!h->sc) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_exchange: call rio_gp_shard_comm_init first");
     const int rc = h->sc->api.AllGather(d_in, d_out, (size_t)words, kNcclUint64, h->sc->comm, h->stream);

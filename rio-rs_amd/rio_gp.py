@@ -17,6 +17,7 @@ CAP_INF = 0xFFFFFFFFFFFFFFFF
 AFF_INACTIVE = 0xFFFFFFFE       # RIO_GP_AFF_INACTIVE: affinity of a row that is not an object
 CFG_ROW_LIFECYCLE = 1           # RIO_GP_CFG_ROW_LIFECYCLE
 CFG_REF_SELF_ASSIGN = 2         # RIO_GP_CFG_REF_SELF_ASSIGN: claims / first touches do not need a live node (service.rs:244-252)
+OP_CFG_LIVE_FIRST_TOUCH = 4     # RIO_OP_CFG_LIVE_FIRST_TOUCH (string layer, whose DEFAULT is the reference's self-assignment): opt out
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleaned and re-placed by this request
 FLAG_MASK = 0x0F
@@ -463,6 +464,10 @@ def _oplib():
         L.rio_op_get_or_create_placement.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,
                                                      C.POINTER(C.c_uint32)]
         L.rio_op_get_or_create_placement_batch.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
+        L.rio_op_update_batch_n.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
+        L.rio_op_lookup_batch_n.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]
+        L.rio_op_get_or_create_placement_batch_n.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.rio_op_set_object_load_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint32]
         L.rio_op_tick.argtypes = [_vp, C.POINTER(Stats)]
         L.rio_op_snapshot.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_char_p)),
                                       C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_char_p))]
@@ -473,10 +478,22 @@ def _oplib():
 
 
 def _cstrs(items):
+    """NUL-terminated strings (server addresses: "{ip}:{port}" of a Member never holds a NUL — refused if one does)."""
     arr = (C.c_char_p * len(items))()
     for k, v in enumerate(items):
+        if v is not None and "\0" in v:
+            raise ValueError("a server address cannot hold a NUL byte: %r" % (v,))
         arr[k] = None if v is None else v.encode()
     return arr
+
+
+def _keys(items):
+    """Key parts with their lengths (the rio_op_*_batch_n entry points): a NUL byte inside a key is part of the key.
+    Returns (pointer array, length array, the byte strings the pointers borrow)."""
+    enc = [v.encode() for v in items]
+    ptrs = (C.c_char_p * len(enc))(*enc)
+    lens = (C.c_size_t * len(enc))(*[len(b) for b in enc])
+    return ptrs, lens, enc
 
 
 def LabPlacement(*a, **k):
@@ -554,13 +571,15 @@ class GpuObjectPlacement:
 
     # -- batched / membership / policy --
     def update_batch(self, keys, addresses):
-        tys, ids = _cstrs([k[0] for k in keys]), _cstrs([k[1] for k in keys])
-        self._chk(_oplib().rio_op_update_batch(self._h, len(keys), tys, ids, _cstrs(addresses)))
+        tys, tyl, _t = _keys([k[0] for k in keys])
+        ids, idl, _i = _keys([k[1] for k in keys])
+        self._chk(_oplib().rio_op_update_batch_n(self._h, len(keys), tys, tyl, ids, idl, _cstrs(addresses)))
 
     def lookup_batch(self, keys):
-        tys, ids = _cstrs([k[0] for k in keys]), _cstrs([k[1] for k in keys])
+        tys, tyl, _t = _keys([k[0] for k in keys])
+        ids, idl, _i = _keys([k[1] for k in keys])
         out = np.empty(len(keys), np.uint32)
-        self._chk(_oplib().rio_op_lookup_batch(self._h, len(keys), tys, ids, _ptr(out)))
+        self._chk(_oplib().rio_op_lookup_batch_n(self._h, len(keys), tys, tyl, ids, idl, _ptr(out)))
         return [None if v == NONE else self.node_address(int(v)) for v in out]
 
     def node_address(self, node_id):
@@ -571,7 +590,8 @@ class GpuObjectPlacement:
         self._chk(_oplib().rio_op_set_member(self._h, address.encode(), int(bool(active)), capacity))
 
     def set_object_load(self, struct_name, object_id, load):
-        self._chk(_oplib().rio_op_set_object_load(self._h, struct_name.encode(), object_id.encode(), load))
+        t, i = struct_name.encode(), object_id.encode()
+        self._chk(_oplib().rio_op_set_object_load_n(self._h, t, len(t), i, len(i), load))
 
     def get_or_create_placement(self, struct_name, object_id, self_address, _cap=512):
         buf, flag = C.create_string_buffer(_cap), C.c_uint32(0)
@@ -584,10 +604,11 @@ class GpuObjectPlacement:
         return (buf.value.decode() or None), int(flag.value)
 
     def get_or_create_placement_batch(self, keys, self_addresses):
-        tys, ids = _cstrs([k[0] for k in keys]), _cstrs([k[1] for k in keys])
+        tys, tyl, _t = _keys([k[0] for k in keys])
+        ids, idl, _i = _keys([k[1] for k in keys])
         node, flag = np.empty(len(keys), np.uint32), np.empty(len(keys), np.uint32)
-        self._chk(_oplib().rio_op_get_or_create_placement_batch(self._h, len(keys), tys, ids, _cstrs(self_addresses),
-                                                                _ptr(node), _ptr(flag)))
+        self._chk(_oplib().rio_op_get_or_create_placement_batch_n(self._h, len(keys), tys, tyl, ids, idl, _cstrs(self_addresses),
+                                                                  _ptr(node), _ptr(flag)))
         return [None if v == NONE else self.node_address(int(v)) for v in node], flag
 
     def tick(self):

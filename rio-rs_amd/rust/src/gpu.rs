@@ -41,7 +41,7 @@ struct RioOpCfg {
 }
 
 const RIO_GP_OK: c_int = 0;
-const RIO_GP_CFG_REF_SELF_ASSIGN: u32 = 2; // include/rio_gpu_placement.h
+const RIO_OP_CFG_LIVE_FIRST_TOUCH: u32 = 4; // include/rio_gpu_object_placement.h
 const RIO_GP_EINVAL: c_int = 1;
 /// the output buffer was too small: nothing is truncated, `rio_op_last_address_len` says what is needed
 const RIO_GP_ERANGE: c_int = 5;
@@ -87,6 +87,15 @@ extern "C" {
     fn rio_op_get_or_create_placement_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize,
                                         self_addr: *const c_char, out: *mut c_char, cap: usize,
                                         flag: *mut u32) -> c_int;
+    // the batched calls, keys with their lengths as well
+    fn rio_op_update_batch_n(p: *mut c_void, n: u64, tys: *const *const c_char, ty_lens: *const usize, ids: *const *const c_char,
+                             id_lens: *const usize, addrs: *const *const c_char) -> c_int;
+    fn rio_op_lookup_batch_n(p: *mut c_void, n: u64, tys: *const *const c_char, ty_lens: *const usize, ids: *const *const c_char,
+                             id_lens: *const usize, out_node_ids: *mut u32) -> c_int;
+    fn rio_op_get_or_create_placement_batch_n(p: *mut c_void, n: u64, tys: *const *const c_char, ty_lens: *const usize,
+                                              ids: *const *const c_char, id_lens: *const usize, self_addrs: *const *const c_char,
+                                              out_node_ids: *mut u32, out_flags: *mut u32) -> c_int;
+    fn rio_op_node_address(p: *mut c_void, node_id: u32) -> *const c_char;
 }
 
 /// One reference on the shared native state; `Drop` releases it (the HBM tables go with the last).
@@ -122,15 +131,16 @@ impl GpuObjectPlacement {
         #[builder(default = 1 << 24)] max_objects: u64,
         #[builder(default = 4096)] max_nodes: u32,
         #[builder(default = 2)] spill_rounds: u32,
-        /// `true`: first touch goes to `self.address` whether or not membership marks it active, exactly like
-        /// `Service::get_or_create_placement` (service.rs:244-252); `false` (default): an inactive requester is not a
-        /// placement target and its first touches go to the water-fill (RIO_GP_CFG_REF_SELF_ASSIGN)
-        #[builder(default = false)] reference_self_assign: bool,
+        /// `true` (default): first touch goes to `self.address` whether or not membership marks it active, exactly like
+        /// `Service::get_or_create_placement` (service.rs:244-252); `false` opts out — an inactive requester is not a
+        /// placement target and its first touches go to the water-fill (RIO_OP_CFG_LIVE_FIRST_TOUCH, the capacity-aware
+        /// extension)
+        #[builder(default = true)] reference_self_assign: bool,
     ) -> Result<Self, ObjectPlacementError> {
         let cfg = RioOpCfg {
             struct_size: std::mem::size_of::<RioOpCfg>() as u32,
             device, max_objects, max_nodes, spill_rounds,
-            flags: if reference_self_assign { RIO_GP_CFG_REF_SELF_ASSIGN } else { 0 }, reserved: 0,
+            flags: if reference_self_assign { 0 } else { RIO_OP_CFG_LIVE_FIRST_TOUCH }, reserved: 0,
         };
         let mut h: *mut c_void = std::ptr::null_mut();
         let rc = unsafe { rio_op_create(&cfg, &mut h) };
@@ -168,7 +178,57 @@ impl GpuObjectPlacement {
     }
 }
 
+/// (pointer, length) arrays over borrowed key parts: what the `_batch_n` entry points take
+struct KeyArrays { ty: Vec<*const c_char>, tl: Vec<usize>, id: Vec<*const c_char>, il: Vec<usize> }
+fn key_arrays(keys: &[ObjectId]) -> KeyArrays {
+    KeyArrays {
+        ty: keys.iter().map(|k| k.0.as_ptr() as *const c_char).collect(), tl: keys.iter().map(|k| k.0.len()).collect(),
+        id: keys.iter().map(|k| k.1.as_ptr() as *const c_char).collect(), il: keys.iter().map(|k| k.1.len()).collect(),
+    }
+}
+
 impl GpuObjectPlacement {
+    fn node_address(&self, node: u32) -> Option<String> {
+        if node == u32::MAX { return None; }
+        let p = unsafe { rio_op_node_address(self.inner.0, node) };  // storage that never moves (a deque of immutable strings)
+        if p.is_null() { None } else { Some(unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned()) }
+    }
+
+    /// `update` for many items in ONE device call (warm start from a placement database: INTEGRATION.md).  Call from a
+    /// blocking context (`spawn_blocking`).
+    pub fn update_batch(&self, items: &[ObjectPlacementItem]) -> Result<(), ObjectPlacementError> {
+        let keys: Vec<ObjectId> = items.iter().map(|i| i.object_id.clone()).collect();
+        let ka = key_arrays(&keys);
+        let addrs: Vec<Option<CString>> = items.iter().map(|i| i.server_address.as_deref().map(cstr).transpose()).collect::<Result<_, _>>()?;
+        let ap: Vec<*const c_char> = addrs.iter().map(|a| a.as_ref().map_or(std::ptr::null(), |c| c.as_ptr())).collect();
+        check(unsafe { rio_op_update_batch_n(self.inner.0, keys.len() as u64, ka.ty.as_ptr(), ka.tl.as_ptr(), ka.id.as_ptr(),
+                                             ka.il.as_ptr(), ap.as_ptr()) }, self)
+    }
+
+    /// `lookup` for many keys in ONE device call.
+    pub fn lookup_batch(&self, keys: &[ObjectId]) -> Result<Vec<Option<String>>, ObjectPlacementError> {
+        let ka = key_arrays(keys);
+        let mut out = vec![u32::MAX; keys.len()];
+        check(unsafe { rio_op_lookup_batch_n(self.inner.0, keys.len() as u64, ka.ty.as_ptr(), ka.tl.as_ptr(), ka.id.as_ptr(),
+                                             ka.il.as_ptr(), out.as_mut_ptr()) }, self)?;
+        Ok(out.into_iter().map(|n| self.node_address(n)).collect())
+    }
+
+    /// `Service::get_or_create_placement` for a batch of requests `(object, server the request arrived at)`, processed as if
+    /// sequentially in slice order (service.rs:193-298): one device call for a front-end that pre-routes request batches.
+    pub fn get_or_create_placement_batch(&self, requests: &[(ObjectId, String)])
+        -> Result<Vec<(Option<String>, u32)>, ObjectPlacementError> {
+        let keys: Vec<ObjectId> = requests.iter().map(|r| r.0.clone()).collect();
+        let ka = key_arrays(&keys);
+        let me: Vec<CString> = requests.iter().map(|r| cstr(&r.1)).collect::<Result<_, _>>()?;
+        let mp: Vec<*const c_char> = me.iter().map(|c| c.as_ptr()).collect();
+        let (mut node, mut flag) = (vec![u32::MAX; keys.len()], vec![0u32; keys.len()]);
+        check(unsafe { rio_op_get_or_create_placement_batch_n(self.inner.0, keys.len() as u64, ka.ty.as_ptr(), ka.tl.as_ptr(),
+                                                              ka.id.as_ptr(), ka.il.as_ptr(), mp.as_ptr(), node.as_mut_ptr(),
+                                                              flag.as_mut_ptr()) }, self)?;
+        Ok(node.into_iter().zip(flag).map(|(n, f)| (self.node_address(n), f)).collect())
+    }
+
     /// Eager rebalance (the batched form of the lazy `clean_server` + first-touch path):
     /// every object gets a decision in one call; evicted objects are re-placed at once.
     pub fn tick(&self) -> Result<RioGpStats, ObjectPlacementError> {
@@ -305,6 +365,20 @@ mod test {
         assert!(p.lookup(&b).await.unwrap().is_none());
         p.remove(&a).await.unwrap();
         assert!(p.lookup(&a).await.unwrap().is_none());
+    }
+
+    // ... through the batched calls too (`_batch_n`: pointer + length arrays)
+    #[tokio::test]
+    async fn batched_calls_keep_interior_nuls() {
+        let p = GpuObjectPlacement::builder().build().unwrap();
+        let a = ObjectId("t".to_string(), "a\0b".to_string());
+        let b = ObjectId("t".to_string(), "a".to_string());
+        p.update_batch(&[ObjectPlacementItem::new(a.clone(), Some("0.0.0.0:81".to_string())),
+                         ObjectPlacementItem::new(b.clone(), Some("0.0.0.0:82".to_string()))]).unwrap();
+        let got = p.lookup_batch(&[a.clone(), b.clone()]).unwrap();
+        assert_eq!(got, vec![Some("0.0.0.0:81".to_string()), Some("0.0.0.0:82".to_string())]);
+        let r = p.get_or_create_placement_batch(&[(a, "0.0.0.0:83".to_string())]).unwrap();
+        assert_eq!(r[0].0.as_deref(), Some("0.0.0.0:81"));
     }
 
     // the same assertions as local.rs:71-123, against the GPU provider

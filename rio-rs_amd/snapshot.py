@@ -62,8 +62,9 @@ def load_sqlite(placement, path, batch=65536):
 # The Postgres twin (rio-rs/src/object_placement/migrations/0001-postgres-init.sql:1-9; upsert of
 # rio-rs/src/object_placement/postgres.rs:74-85, lookup :89-98).  Same three columns, same key, same index.  Two transports:
 #   * a DB-API 2 connection with the `format` paramstyle (psycopg2 / psycopg 3 — neither ships in this image, so the tests drive
-#     these functions through a shim that hands the statements to SQLite; the statements are the reference's own text with
-#     $n turned into %s);
+#     these functions through a shim that hands the statements to SQLite; the statements are the reference's text with
+#     $n turned into %s — the upsert's `DO UPDATE SET server_address = excluded.server_address` stands for postgres.rs:79's
+#     `= $3`, which it equals: one bound value less);
 #   * a script `psql -f` loads: the DDL + one `COPY object_placement (...) FROM stdin` block in COPY's text format, which is
 #     also what `pg_dump --data-only --table object_placement` writes — load_postgres_script reads either.
 # Postgres TEXT cannot hold a NUL byte: a key with one (ObjectId holds any Rust string) is refused here with ValueError, as
@@ -105,34 +106,46 @@ def copy_escape(value):
 
 
 def copy_unescape(field):
+    """Inverse of copy_escape for one field of COPY's text format.  \\ooo and \\xhh stand for BYTES of the server encoding
+    (UTF-8 here), not code points: consecutive escaped bytes are collected and decoded together, so a character somebody
+    wrote as \\303\\251 comes back as the one character it is (pg_dump itself never emits these escapes)."""
     if field == "\\N":
         return None
-    out, i, n = [], 0, len(field)
+    out, raw, i, n = [], bytearray(), 0, len(field)
+
+    def flush():
+        if raw:
+            out.append(bytes(raw).decode("utf-8"))   # an invalid sequence raises: a key is never silently changed
+            raw.clear()
     while i < n:
         ch = field[i]
         if ch != "\\" or i + 1 == n:
+            flush()
             out.append(ch)
             i += 1
             continue
         nx = field[i + 1]
         if nx in _COPY_UNESC:
+            flush()
             out.append(_COPY_UNESC[nx])
             i += 2
-        elif nx in "01234567":            # \ooo
+        elif nx in "01234567":            # \ooo: one byte
             j = i + 1
             while j < n and j < i + 4 and field[j] in "01234567":
                 j += 1
-            out.append(chr(int(field[i + 1:j], 8)))
+            raw.append(int(field[i + 1:j], 8) & 0xFF)
             i = j
-        elif nx == "x" and i + 2 < n and field[i + 2] in "0123456789abcdefABCDEF":   # \xh, \xhh
+        elif nx == "x" and i + 2 < n and field[i + 2] in "0123456789abcdefABCDEF":   # \xh, \xhh: one byte
             j = i + 2
             while j < n and j < i + 4 and field[j] in "0123456789abcdefABCDEF":
                 j += 1
-            out.append(chr(int(field[i + 2:j], 16)))
+            raw.append(int(field[i + 2:j], 16))
             i = j
         else:                              # any other backslashed character stands for itself
+            flush()
             out.append(nx)
             i += 2
+    flush()
     return "".join(out)
 
 

@@ -2,7 +2,8 @@
 // just enough of it for the string layer (rio-rs_amd/csrc/gpu_object_placement.cpp) to run under ThreadSanitizer on a
 // machine without a GPU (tests/test_host_layer_races.py).  It is linked into that one test binary and nowhere else; the
 // product library has no CPU path.  Policy = the capacity-free reference policy (service.rs:193-254): sticky if the node
-// is alive, else first touch on the requester.  Like the real library it VALIDATES every index against the row count
+// is alive, else clean_server of the node it sat on and first touch on the requester (alive or, under
+// RIO_GP_CFG_REF_SELF_ASSIGN, whatever membership says).  Like the real library it VALIDATES every index against the row count
 // and the node table it was given (RIO_GP_EINVAL, nothing mutated) — which is what exposes an id that reaches the
 // "device" ahead of the table entry it refers to — and it keeps the row-lifecycle column (RIO_GP_CFG_ROW_LIFECYCLE).
 #include <cstring>
@@ -17,6 +18,7 @@ struct rio_gp {
     std::vector<uint32_t> assign, aff, load;
     std::vector<uint8_t> alive;
     uint64_t n = 0;
+    bool sa = false;  // RIO_GP_CFG_REF_SELF_ASSIGN
     std::string err;
     int fail(const char* m) { err = m; return RIO_GP_EINVAL; }
 };
@@ -31,6 +33,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     h->assign.assign(cfg->max_objects, RIO_GP_NONE);
     h->aff.assign(cfg->max_objects, RIO_GP_AFF_INACTIVE);
     h->load.assign(cfg->max_objects, 1);
+    h->sa = (cfg->flags & RIO_GP_CFG_REF_SELF_ASSIGN) != 0;
     *out = h;
     return RIO_GP_OK;
 }
@@ -132,9 +135,16 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         uint32_t fl;
         if (up) fl = a == req[k] ? RIO_GP_FLAG_LOCAL : RIO_GP_FLAG_REDIRECT;
         else {
+            uint32_t rep = 0;
+            if (a != RIO_GP_NONE) {  // service.rs:227-237: the node it sits on is not alive — clean_server(that node), every object of it
+                const uint32_t dead = a;
+                rep = RIO_GP_FLAG_REPLACED;
+                for (uint64_t i = 0; i < h->n; ++i)
+                    if (h->assign[i] == dead) { h->assign[i] = RIO_GP_NONE; h->aff[i] = RIO_GP_AFF_INACTIVE; }
+            }
             h->aff[idx[k]] = req[k];
-            if (h->alive[req[k]]) { a = req[k]; fl = RIO_GP_FLAG_PLACED; }
-            else { a = RIO_GP_NONE; fl = RIO_GP_FLAG_UNPLACED; }
+            if (h->alive[req[k]] || h->sa) { a = req[k]; fl = RIO_GP_FLAG_PLACED | rep; }  // service.rs:244-252 asks nobody
+            else { a = RIO_GP_NONE; fl = RIO_GP_FLAG_UNPLACED | rep; }
         }
         out_node[k] = a;
         if (out_flag) out_flag[k] = fl;

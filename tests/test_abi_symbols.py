@@ -158,7 +158,7 @@ _RUST_OF_C = {
     "rio_op_t*": "*mut c_void", "rio_gp_t*": "*mut c_void", "rio_op_t**": "*mut *mut c_void",
     "const rio_op_cfg*": "*const RioOpCfg", "rio_gp_stats*": "*mut RioGpStats",
     "const char*const**": "*mut *const *const c_char", "const char*const*": "*const *const c_char",
-    "const size_t**": "*mut *const usize",
+    "const size_t**": "*mut *const usize", "const size_t*": "*const usize",
 }
 
 

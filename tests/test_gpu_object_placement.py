@@ -127,6 +127,28 @@ def test_keys_with_an_interior_nul_are_keys_of_their_own(gp):
     # the NUL-terminated twin of the same call addresses the key that ends at the NUL
     found, buf = C.c_int(0), C.create_string_buffer(64)
     assert gp._oplib().rio_op_lookup(p._h, b"T", b"a\0c", buf, 64, C.byref(found)) == 0 and found.value == 0
+    # ... and the BATCHED calls carry the lengths too (rio_op_*_batch_n; round-4 advisor finding: update_batch cut "a\0b" down to
+    # "a", so a snapshot written with the key and loaded back through update_batch overwrote another object)
+    p.update_batch([("T", "k\0one"), ("T", "k"), ("T\0y", "k\0one")], ["h:1", "h:2", None])
+    assert p.lookup_batch([("T", "k\0one"), ("T", "k"), ("T", "k\0two"), ("T\0y", "k\0one")]) == ["h:1", "h:2", None, None]
+    got, flags = p.get_or_create_placement_batch([("T", "k\0two"), ("T", "k\0one"), ("T", "k")], ["h:1", "h:1", "h:1"])
+    assert got == ["h:1", "h:1", "h:2"] and list(flags) == [gp.FLAG_PLACED, gp.FLAG_LOCAL, gp.FLAG_REDIRECT]
+    p.set_object_load("T", "w\0x", 7)
+    p.update("T", "w", "h:1")                                       # (a key of its own: the load stays with "w\0x")
+    idx = {k: v for v, k in enumerate([r[:2] for r in p.snapshot()])}
+    assert ("T", "k\0one") in idx and ("T", "k\0two") in idx and ("T", "w") in idx and ("T", "w\0x") not in idx
+    with pytest.raises(ValueError):
+        p.update_batch([("T", "z")], ["h\0:1"])                     # an address cannot hold a NUL ("{ip}:{port}" of a Member)
+    # round trip through the SQLite twin of the table: every key comes back as the key it was
+    import os, tempfile, snapshot
+    before = sorted(p.snapshot())
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "placement.sqlite3")
+        snapshot.dump_sqlite(p, path)
+        q = gp.GpuObjectPlacement(max_objects=64, max_nodes=8)
+        snapshot.load_sqlite(q, path)
+        assert sorted(q.snapshot()) == before
+        q.close()
     p.close()
 
 
@@ -147,12 +169,13 @@ def test_policy_bad_record_removed(gp, oracle):
 @pytest.mark.parametrize("seed,self_assign", [(0, False), (1, False), (2, True), (3, True)] + [(s, s % 2 == 1) for s in range(4, 12)])
 def test_random_differential_vs_reference_restatement(gp, oracle, seed, self_assign):
     """Random trait calls + policy requests: the GPU provider and the C++ restatement of
-    LocalObjectPlacement + service.rs policy must agree on every observable.  self_assign: the provider is created with
-    RIO_GP_CFG_REF_SELF_ASSIGN and the requests come from ANY member, inactive ones included — the reference first-touches
-    the requester without asking whether it is active (service.rs:244-252), and so does the provider then."""
+    LocalObjectPlacement + service.rs policy must agree on every observable.  self_assign: the provider is created with its
+    DEFAULT flags (the reference's behaviour) and the requests come from ANY member, inactive ones included — the reference
+    first-touches the requester without asking whether it is active (service.rs:244-252), and so does the provider; the
+    other seeds opt out (RIO_OP_CFG_LIVE_FIRST_TOUCH) and keep to requesters that are up."""
     rng = np.random.default_rng(seed)
     addrs = ["10.0.0.%d:%d" % (k, 5000 + k) for k in range(6)]
-    p = gp.GpuObjectPlacement(max_objects=2048, max_nodes=32, flags=gp.CFG_REF_SELF_ASSIGN if self_assign else 0)
+    p = gp.GpuObjectPlacement(max_objects=2048, max_nodes=32, flags=0 if self_assign else gp.OP_CFG_LIVE_FIRST_TOUCH)
     o, st = oracle.LocalObjectPlacement(), oracle.LocalStorage()
     alive = [True] * len(addrs)
     for a in addrs:

@@ -226,10 +226,8 @@ def test_string_layer_equals_the_reference_restatement(oracle, oplib, ops):
                 members.set_is_active(ip, port, bool(y))
                 active[ADDRS[x]] = bool(y)
                 assert oplib.rio_op_set_member(op.h, ADDRS[x].encode(), y, INF) == 0
-            else:  # a request arriving at a server that is up (a down requester is the documented divergence)
-                me = ADDRS[y]
-                if not active[me]:
-                    continue
+            else:  # a request arriving at ANY member: the reference first-touches self.address whatever membership says about it
+                me = ADDRS[y]  # (service.rs:244-252) — and so does the string layer by default (round-4 verdict, item 6)
                 ty, oid = KEYS[x]
                 buf, flag = C.create_string_buffer(128), C.c_uint32(0)
                 assert oplib.rio_op_get_or_create_placement(op.h, ty.encode(), oid.encode(), me.encode(), buf, 128, C.byref(flag)) == 0

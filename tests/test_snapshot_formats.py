@@ -76,6 +76,10 @@ def test_copy_text_escaping_round_trips_every_character_class():
             assert snapshot.copy_unescape(e) == x
     assert snapshot.copy_escape(None) == "\\N" and snapshot.copy_escape("\\N") == "\\\\N"
     assert snapshot.copy_unescape("a\\101\\x41\\q") == "aAAq"   # octal, hex, and "any other character stands for itself"
+    # \ooo / \xhh are BYTES of the server encoding (round-4 advisor finding): two escaped bytes are one character
+    assert snapshot.copy_unescape("caf\\303\\251") == "caf\u00e9" and snapshot.copy_unescape("\\xe2\\x82\\xac!") == "\u20ac!"
+    with pytest.raises(UnicodeDecodeError):
+        snapshot.copy_unescape("bad\\303x")                      # half a character: refused, never silently changed
 
 
 def test_script_round_trip_and_pg_dump_shape(tmp_path):
