@@ -1,12 +1,18 @@
 /* c_host_threads.c — the trait-level boundary (include/rio_gpu_object_placement.h) under concurrent callers, as the
  * reference calls it: one task per connection, every request a lookup / get_or_create_placement of ONE object
- * (rio-rs/src/service.rs:193-254, server.rs:292-304).  T threads hammer one shared provider; the library's combining
- * front-end lets concurrent single-object calls share a device round trip.  Prints one JSON line per thread count.
+ * (rio-rs/src/service.rs:193-254, server.rs:292-304).  T threads hammer one shared provider.  Prints one JSON line per
+ * (provider, call, thread count):
+ *   provider "shadow"     the default: answers the device has given are remembered on the host, a hit costs no round trip
+ *            "device"     RIO_OP_CFG_NO_HOST_SHADOW: every call goes to the device; concurrent callers share round trips
+ *                         (flat combining)
+ *   call     lookup                    known, placed keys (local.rs:42-49)
+ *            get_or_create_placement   sticky hits from any of 8 servers (service.rs:199-242)
+ *            churn                     9 lookups, then remove + get_or_create_placement of one object of the caller's own
+ *                                      (a first touch: always the device) — the mix a server with ~10 % activations sees
  *
  * Build:  gcc -O2 -std=c99 -pthread -I include examples/c_host_threads.c -o examples/c_host_threads -L rio-rs_amd \
  *             -lrio_gp -Wl,-rpath,$PWD/rio-rs_amd -Wl,-rpath,/opt/rocm/lib
- * Run:    examples/c_host_threads [objects=20000] [calls_per_thread=2000] [max_threads=16]
- * (more calling threads than cores only adds scheduler noise: the box used for profiles/ has a 16-CPU quota)
+ * Run:    examples/c_host_threads [objects=20000] [calls_per_thread=2000] [max_threads=256] [collect_ns=0 (default)]
  */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
@@ -25,49 +31,56 @@ static double now_s(void) {
 
 typedef struct {
     rio_op_t* p;
-    int tid, calls, objects, mode; /* mode 0 lookup | 1 get_or_create_placement */
+    int tid, calls, objects, mode; /* mode 0 lookup | 1 get_or_create_placement | 2 churn */
     int bad;
 } job;
 
 static void* worker(void* arg) {
     job* j = (job*)arg;
-    char id[32], out[64], self[32];
+    char id[32], out[64], self[32], own[32];
     int k, found;
     uint32_t flag;
     unsigned x = 12345u + 977u * (unsigned)j->tid;
     snprintf(self, sizeof self, "10.0.0.%d:5000", j->tid % 8);
+    snprintf(own, sizeof own, "own%d", j->tid);
     for (k = 0; k < j->calls; ++k) {
         x = x * 1664525u + 1013904223u;
         snprintf(id, sizeof id, "%u", (x >> 8) % (unsigned)j->objects);
-        if (j->mode == 0) {
+        if (j->mode == 2 && k % 10 == 9) { /* an activation: the object is not placed, the request first-touches it */
+            if (rio_op_remove(j->p, "Own", own) != RIO_GP_OK) j->bad++;
+            if (rio_op_get_or_create_placement(j->p, "Own", own, self, out, sizeof out, &flag) != RIO_GP_OK) j->bad++;
+            else if (strcmp(out, self) != 0 || (flag & RIO_GP_FLAG_MASK) != RIO_GP_FLAG_PLACED) j->bad++;
+        } else if (j->mode != 1) {
             char want[32];
             if (rio_op_lookup(j->p, "Obj", id, out, sizeof out, &found) != RIO_GP_OK) { j->bad++; continue; }
             snprintf(want, sizeof want, "10.0.0.%u:5000", (unsigned)atoi(id) % 8u);
             if (!found || strcmp(out, want) != 0) j->bad++;
         } else {
-            if (rio_op_get_or_create_placement(j->p, "Obj", id, self, out, sizeof out, &flag) != RIO_GP_OK) j->bad++;
-            else if (!out[0]) j->bad++; /* capacity is unbounded: every object ends up somewhere */
+            char want[32];
+            if (rio_op_get_or_create_placement(j->p, "Obj", id, self, out, sizeof out, &flag) != RIO_GP_OK) { j->bad++; continue; }
+            snprintf(want, sizeof want, "10.0.0.%u:5000", (unsigned)atoi(id) % 8u);
+            if (strcmp(out, want) != 0 || flag != (strcmp(want, self) == 0 ? RIO_GP_FLAG_LOCAL : RIO_GP_FLAG_REDIRECT)) j->bad++;
         }
     }
     return 0;
 }
 
-int main(int argc, char** argv) {
-    const int objects = argc > 1 ? atoi(argv[1]) : 20000, calls = argc > 2 ? atoi(argv[2]) : 2000;
-    const int max_threads = argc > 3 ? atoi(argv[3]) : 16;
-    const int counts[] = {1, 4, 16, 64, 256};
+static uint32_t g_collect_ns = 0;
+static rio_op_t* provider(int objects, uint32_t flags) {
     rio_op_cfg cfg;
     rio_op_t* p = 0;
-    int i, c, mode;
+    int i;
     memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = (uint32_t)sizeof cfg;
-    cfg.max_objects = (uint64_t)objects * 2;
+    cfg.max_objects = (uint64_t)objects * 2 + 1024;
     cfg.max_nodes = 64;
-    if (rio_op_create(&cfg, &p) != RIO_GP_OK) { fprintf(stderr, "rio_op_create: %s\n", rio_op_last_error(0)); return 1; }
+    cfg.flags = flags;
+    cfg.collect_ns = g_collect_ns;
+    if (rio_op_create(&cfg, &p) != RIO_GP_OK) { fprintf(stderr, "rio_op_create: %s\n", rio_op_last_error(0)); return 0; }
     for (i = 0; i < 8; ++i) {
         char a[32];
         snprintf(a, sizeof a, "10.0.0.%d:5000", i);
-        if (rio_op_set_member(p, a, 1, RIO_GP_CAP_INF) != RIO_GP_OK) return 1;
+        if (rio_op_set_member(p, a, 1, RIO_GP_CAP_INF) != RIO_GP_OK) return 0;
     }
     { /* objects 0..objects-1 placed on node (i mod 8) in one batched update */
         const char** ty = malloc(sizeof(char*) * (size_t)objects);
@@ -79,27 +92,49 @@ int main(int argc, char** argv) {
             snprintf(ads + (size_t)i * 24, 24, "10.0.0.%d:5000", i % 8);
             ty[i] = "Obj"; id[i] = ids + (size_t)i * 16; ad[i] = ads + (size_t)i * 24;
         }
-        if (rio_op_update_batch(p, (uint64_t)objects, ty, id, ad) != RIO_GP_OK) { fprintf(stderr, "%s\n", rio_op_last_error(p)); return 1; }
+        if (rio_op_update_batch(p, (uint64_t)objects, ty, id, ad) != RIO_GP_OK) { fprintf(stderr, "%s\n", rio_op_last_error(p)); return 0; }
         free(ty); free(id); free(ad); free(ids); free(ads);
     }
-    for (mode = 0; mode < 2; ++mode)
-        for (c = 0; c < (int)(sizeof counts / sizeof counts[0]); ++c) {
-            const int T = counts[c];
-            if (T > max_threads) continue;
-            pthread_t* th = malloc(sizeof(pthread_t) * (size_t)T);
-            job* jobs = malloc(sizeof(job) * (size_t)T);
-            double t0, dt;
-            int bad = 0;
-            for (i = 0; i < T; ++i) { jobs[i].p = p; jobs[i].tid = i; jobs[i].calls = calls; jobs[i].objects = objects; jobs[i].mode = mode; jobs[i].bad = 0; }
-            t0 = now_s();
-            for (i = 0; i < T; ++i) pthread_create(&th[i], 0, worker, &jobs[i]);
-            for (i = 0; i < T; ++i) { pthread_join(th[i], 0); bad += jobs[i].bad; }
-            dt = now_s() - t0;
-            printf("{\"call\": \"%s\", \"threads\": %d, \"calls\": %d, \"calls_per_s\": %.4e, \"us_per_call_per_thread\": %.2f, \"wrong\": %d}\n",
-                   mode ? "get_or_create_placement" : "lookup", T, T * calls, (double)T * calls / dt, dt / calls * 1e6, bad);
-            free(th); free(jobs);
-            if (bad) { rio_op_release(p); return 3; }
-        }
-    rio_op_release(p);
+    return p;
+}
+
+int main(int argc, char** argv) {
+    const int objects = argc > 1 ? atoi(argv[1]) : 20000, calls = argc > 2 ? atoi(argv[2]) : 2000;
+    const int max_threads = argc > 3 ? atoi(argv[3]) : 256;
+    const int counts[] = {1, 4, 16, 64, 256};
+    const char* names[] = {"lookup", "get_or_create_placement", "churn"};
+    int i, c, mode, prov;
+    g_collect_ns = argc > 4 ? (uint32_t)atoi(argv[4]) : 0u; /* 0 = the library's default, 1 = no collect window */
+    for (prov = 0; prov < 2; ++prov) {
+        rio_op_t* p = provider(objects, prov ? RIO_OP_CFG_NO_HOST_SHADOW : 0u);
+        if (!p) return 1;
+        for (mode = 0; mode < 3; ++mode)
+            for (c = 0; c < (int)(sizeof counts / sizeof counts[0]); ++c) {
+                const int T = counts[c];
+                uint64_t b0 = 0, r0 = 0, b1 = 0, r1 = 0;
+                pthread_t* th;
+                job* jobs;
+                double t0, dt;
+                int bad = 0;
+                if (T > max_threads) continue;
+                th = malloc(sizeof(pthread_t) * (size_t)T);
+                jobs = malloc(sizeof(job) * (size_t)T);
+                for (i = 0; i < T; ++i) { jobs[i].p = p; jobs[i].tid = i; jobs[i].calls = calls; jobs[i].objects = objects; jobs[i].mode = mode; jobs[i].bad = 0; }
+                rio_op_device_round_trips(p, &b0, &r0);
+                t0 = now_s();
+                for (i = 0; i < T; ++i) pthread_create(&th[i], 0, worker, &jobs[i]);
+                for (i = 0; i < T; ++i) { pthread_join(th[i], 0); bad += jobs[i].bad; }
+                dt = now_s() - t0;
+                rio_op_device_round_trips(p, &b1, &r1);
+                printf("{\"provider\": \"%s\", \"call\": \"%s\", \"threads\": %d, \"calls\": %d, \"calls_per_s\": %.4e, "
+                       "\"us_per_call_per_thread\": %.2f, \"device_round_trips\": %llu, \"requests_on_device\": %llu, \"collect_ns\": %u, \"wrong\": %d}\n",
+                       prov ? "device" : "shadow", names[mode], T, T * calls, (double)T * calls / dt, dt / calls * 1e6,
+                       (unsigned long long)(b1 - b0), (unsigned long long)(r1 - r0), g_collect_ns ? g_collect_ns : RIO_OP_DEFAULT_COLLECT_NS, bad);
+                fflush(stdout);
+                free(th); free(jobs);
+                if (bad) { rio_op_release(p); return 3; }
+            }
+        rio_op_release(p);
+    }
     return 0;
 }

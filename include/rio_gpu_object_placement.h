@@ -40,9 +40,21 @@ typedef struct rio_op_cfg {
                             * RIO_GP_CFG_REF_SELF_ASSIGN; that bit is accepted here and changes nothing).
                             * RIO_OP_CFG_LIVE_FIRST_TOUCH opts OUT: a requester that membership marks inactive is not a
                             * placement target, its first touches go to the water-fill (the capacity-aware extension) */
-    uint32_t reserved;
+    uint32_t collect_ns;   /* single-object calls that need the device share round trips (flat combining): how long a thread that
+                            * takes over the device waits for more callers to publish before it takes its batch, in ns, when the
+                            * batch before was shared; 0 = the default (RIO_OP_DEFAULT_COLLECT_NS), 1 = do not wait */
 } rio_op_cfg;
+#define RIO_OP_DEFAULT_COLLECT_NS 1500u
 #define RIO_OP_CFG_LIVE_FIRST_TOUCH 4u
+/* Host shadow of the assignment column.  The reference calls lookup / get_or_create_placement once per request from one task per
+ * connection (server.rs:292-304) and LocalObjectPlacement answers a hit from a hash map (local.rs:42-49); a device round trip per
+ * call is 8-11 us however well concurrent callers share it.  So the string layer remembers, per row, the last answer the DEVICE
+ * gave (node + a validity stamp) and answers a later rio_op_lookup of that key — and a rio_op_get_or_create_placement whose object
+ * sits on a server that is an active member: the sticky path of service.rs:199-242 — from there.  It never decides anything:
+ * first touches, evictions, capacities and ticks are the GPU's, and whatever may move rows the layer cannot name (clean_server,
+ * rio_op_tick, a request that ran into a dead server, reclaimed keys) invalidates by stamp.  This flag switches the shadow off
+ * (every call goes to the device): A/B measurements, examples/c_host_threads.c. */
+#define RIO_OP_CFG_NO_HOST_SHADOW 8u
 
 /* LocalObjectPlacement::default() + ObjectPlacement::prepare (local.rs:15-18, mod.rs:42-44). */
 int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out);
@@ -142,8 +154,14 @@ int rio_op_set_object_load_n(rio_op_t* p, const char* struct_name, size_t struct
 
 /* Whole-table re-solve over the interned tables (rio_gp_tick). */
 int rio_op_tick(rio_op_t* p, rio_gp_stats* stats);
-/* The dense handle underneath (borrowed). */
+/* The dense handle underneath (borrowed).  A mutation made through it bypasses the host shadow: follow it with
+ * rio_op_invalidate_cache. */
 rio_gp_t* rio_op_dense(rio_op_t* p);
+/* Drop everything the host shadow holds (RIO_OP_CFG_NO_HOST_SHADOW's comment): the next lookup of every key asks the device. */
+int rio_op_invalidate_cache(rio_op_t* p);
+/* How often the single-object calls went to the device so far: combined batches (one round trip each) and the requests they
+ * carried.  calls made - *requests = calls answered from the host shadow or without any device work. */
+int rio_op_device_round_trips(rio_op_t* p, uint64_t* batches, uint64_t* requests);
 
 #ifdef __cplusplus
 }

@@ -15,17 +15,32 @@
 // are reclaimed lazily, when the table runs full (reclaim()).
 //
 // Locks (always taken in this order): mu — compound operations and every device call sequence; imu — the interning
-// tables; qmu — the combiner's queue.  What the device knows of the host tables (node table, row count) is brought
-// up to date under mu by sync_device() BEFORE any device call that may carry a new id, by whichever thread issues
-// that call: an id can therefore never reach the device ahead of the table entry it refers to, whoever interned it.
+// tables, a reader-writer lock: calls whose key and address are already interned (every lookup, every sticky request) take it
+// shared.  Single-object calls that need the device publish themselves on a lock-free list; whoever gets mu next serves
+// everything published (flat combining, run_combined).  What the device knows of the host tables (node table, row count)
+// is brought up to date under mu by sync_device() BEFORE any device call that may carry a new id, by whichever thread
+// issues that call: an id can therefore never reach the device ahead of the table entry it refers to, whoever interned it.
+//
+// Host shadow of the assignment column (Shadow below).  The reference calls lookup / get_or_create_placement once per request
+// from one task per connection (server.rs:292-304), and LocalObjectPlacement answers a hit from a hash map in ~100 ns
+// (local.rs:42-49); a device round trip per call is 8-11 us however well it is shared.  So every answer the device gives
+// for a row is remembered on the host — node + a stamp — and a later lookup / sticky request of that row is answered from
+// there, under the shared table lock, without the device.  The shadow is a cache of DEVICE decisions, never a decision of
+// its own: first touches, evictions, capacity and ticks all run on the GPU, and every call that changes rows it cannot
+// name (clean_server, a tick, a request batch that cleaned a dead node, reclaimed keys) invalidates by stamp.
+// rio_op_cfg.flags & RIO_OP_CFG_NO_HOST_SHADOW switches it off (A/B runs: examples/c_host_threads.c measures both).
 #include <sched.h>
+#include <time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -36,6 +51,8 @@ namespace {
 
 constexpr int kFull = -1000;  // internal: the object table has no free row (reclaim, then retry)
 constexpr int kNoop = -1001;  // internal: nothing to do on the device (an unknown key looked up / removed / deleted)
+constexpr int kUpgrade = -1002;  // internal: the call has to change the interning tables — again, under the exclusive lock
+constexpr int kHit = -1003;      // internal: answered from the host shadow, no device round trip
 
 // Text of the calling thread's last failed call (rio_op_last_error): a failure is reported to the thread that made
 // the call, so its text is that thread's too — no lock, no race with other callers' failures.
@@ -55,18 +72,75 @@ struct Req {
     uint32_t node = RIO_GP_NONE, flag = 0;
     int rc = RIO_GP_OK;
     std::string err;          // text of ITS failure (a request that fails does not fail its batch-mates)
+    Req* next = nullptr;      // the lock-free list of published requests (newest first)
     std::atomic<int> done{0};  // set LAST by the serving thread: the request lives on its caller's stack
+};
+
+// Host shadow of the assignment column: entry = stamp << 16 | node (0xFFFF = not placed), one atomic u64 per row, in chunks of
+// 65 536 rows allocated as rows are handed out.  Writers hold State::mu (the order of the device calls IS the order of the
+// writes); readers hold nothing but the shared table lock that keeps their row id theirs.
+//   valid(entry) = stamp >= base  &&  (node == none || stamp >= clean_stamp[node])
+//   clean_server(j): clean_stamp[j] = ++clock  (the rows that sat on j are gone; every other row's entry stays good)
+//   tick / a request batch that ran into a dead node / anything that moves rows it cannot name: base = ++clock
+struct Shadow {
+    static constexpr uint32_t kBits = 16, kNoneNode = 0xFFFFu;
+    bool enabled = true;
+    size_t nchunks = 0;
+    std::unique_ptr<std::atomic<std::atomic<uint64_t>*>[]> chunks;
+    std::unique_ptr<std::atomic<uint64_t>[]> clean_stamp;
+    std::atomic<uint64_t> clock{1}, base{1};
+    void init(uint64_t max_objects, uint32_t max_nodes, bool on) {
+        enabled = on;
+        nchunks = (size_t)((max_objects + (1u << kBits) - 1) >> kBits);
+        chunks.reset(new std::atomic<std::atomic<uint64_t>*>[nchunks ? nchunks : 1]);
+        for (size_t c = 0; c < (nchunks ? nchunks : 1); ++c) chunks[c].store(nullptr, std::memory_order_relaxed);
+        clean_stamp.reset(new std::atomic<uint64_t>[max_nodes ? max_nodes : 1]);
+        for (uint32_t j = 0; j < (max_nodes ? max_nodes : 1); ++j) clean_stamp[j].store(0, std::memory_order_relaxed);
+    }
+    ~Shadow() {
+        for (size_t c = 0; c < nchunks; ++c) delete[] chunks[c].load(std::memory_order_relaxed);
+    }
+    bool get(uint32_t row, uint32_t* node) const {  // (any thread; the caller's row id is pinned by the shared table lock)
+        if (!enabled) return false;
+        const std::atomic<uint64_t>* ch = chunks[row >> kBits].load(std::memory_order_acquire);
+        if (!ch) return false;
+        const uint64_t e = ch[row & ((1u << kBits) - 1)].load(std::memory_order_acquire);
+        const uint64_t stamp = e >> 16;
+        const uint32_t nd = (uint32_t)(e & 0xFFFFu);
+        if (stamp < base.load(std::memory_order_acquire)) return false;
+        if (nd != kNoneNode && stamp < clean_stamp[nd].load(std::memory_order_acquire)) return false;
+        *node = nd == kNoneNode ? RIO_GP_NONE : nd;
+        return true;
+    }
+    void put(uint32_t row, uint32_t node) {  // mu held: what the device just said (or was just told) about the row
+        if (!enabled) return;
+        std::atomic<uint64_t>* ch = chunks[row >> kBits].load(std::memory_order_relaxed);
+        if (!ch) {
+            ch = new std::atomic<uint64_t>[1u << kBits];
+            for (uint32_t k = 0; k < (1u << kBits); ++k) ch[k].store(0, std::memory_order_relaxed);
+            chunks[row >> kBits].store(ch, std::memory_order_release);
+        }
+        const uint64_t nd = node == RIO_GP_NONE ? kNoneNode : (node & 0xFFFFu);
+        ch[row & ((1u << kBits) - 1)].store((clock.load(std::memory_order_relaxed) << 16) | nd, std::memory_order_release);
+    }
+    void erase(uint32_t row) {  // mu + exclusive table lock held: the row changes hands (reclaim)
+        std::atomic<uint64_t>* ch = chunks[row >> kBits].load(std::memory_order_relaxed);
+        if (ch) ch[row & ((1u << kBits) - 1)].store(0, std::memory_order_release);
+    }
+    void clean(uint32_t node) { clean_stamp[node].store(clock.fetch_add(1, std::memory_order_acq_rel) + 1, std::memory_order_release); }
+    void invalidate_all() { base.store(clock.fetch_add(1, std::memory_order_acq_rel) + 1, std::memory_order_release); }
 };
 
 struct State {
     std::mutex mu;    // compound operations and their device call sequences (taken first)
-    std::mutex imu;   // the interning tables below (taken second, or alone by the combined single-object calls, which
-                      // must be able to intern and queue while the serving thread waits for the device)
-    std::mutex qmu;                    // combiner: queue of single-object calls + who is serving it
-    std::condition_variable qcv;
-    std::vector<Req*> queue;
-    std::atomic<bool> serving{false};   // written under qmu; waiters also read it while they spin
-    int sleepers = 0;                  // waiters that gave up spinning and sleep on qcv
+    std::shared_mutex imu;  // the interning tables below (taken second, or alone by the single-object calls, which must be
+                            // able to intern and publish while the serving thread waits for the device); shared: read-only use
+    std::atomic<Req*> pending{nullptr};  // published single-object calls nobody has served yet (newest first)
+    std::vector<Req*> batch;             // (under mu) the requests the serving thread took off the list, oldest first
+    Shadow shadow;
+    uint64_t dev_batches = 0, dev_requests = 0;  // (under mu) device round trips of combined batches / requests they carried
+    size_t last_batch = 0;                       // (under mu) requests of the last combined batch
+    uint32_t collect_ns = 0;                     // rio_op_cfg.collect_ns
     rio_gp_t* gp = nullptr;
     uint64_t max_objects = 0;
     uint32_t max_nodes = 0;
@@ -86,7 +160,7 @@ struct State {
     uint64_t node_version = 1;                        // bumped on every change of the node table
     uint64_t shape_version = 1;                       // bumped when a node is added or a capacity changes (not on liveness flips)
     bool reclaiming = false;                          // single-object calls wait (rcv) while keys are being reclaimed
-    std::condition_variable rcv;
+    std::condition_variable_any rcv;
     // --- under mu ---
     uint64_t pushed_version = 0;                      // node_version the device holds
     uint64_t pushed_shape = 0;
@@ -145,7 +219,7 @@ int sync_device(State* s, bool imu_held) {
     uint64_t version, shape, nrows;
     uint32_t m;
     {
-        std::unique_lock<std::mutex> li(s->imu, std::defer_lock);
+        std::shared_lock<std::shared_mutex> li(s->imu, std::defer_lock);
         if (!imu_held) li.lock();
         version = s->node_version;
         shape = s->shape_version;
@@ -175,8 +249,8 @@ int sync_device(State* s, bool imu_held) {
     return RIO_GP_OK;
 }
 
-// find or create the node id of an address (imu held)
-int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, bool mark_up = false) {
+// find or create the node id of an address (imu held; excl: exclusively — a shared holder that would have to create gets kUpgrade)
+int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, bool mark_up = false, bool excl = true) {
     auto it = s->nodes.find(addr);
     if (it != s->nodes.end()) {
         *out = it->second;
@@ -186,6 +260,7 @@ int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, b
         *out = RIO_GP_NONE;
         return RIO_GP_OK;
     }
+    if (!excl) return kUpgrade;
     if (s->node_addr.size() >= s->max_nodes) return fail(RIO_GP_EINVAL, "node table full (max_nodes)");
     const uint32_t id = (uint32_t)s->node_addr.size();
     s->nodes.emplace(addr, id);
@@ -205,18 +280,22 @@ int intern_node(State* s, const std::string& addr, bool create, uint32_t* out, b
 // find or create the row of a key (imu held).  kFull: no free row — the caller releases its locks, runs reclaim() and retries.
 // use: the call makes (or unmakes) an object of the key — update, get_or_create_placement, remove; a key whose row is
 // held for a load set ahead of its first use (row_keep) is an ordinary key from then on
-int intern_row(State* s, const Part& ty, const Part& id, bool create, uint32_t* out, bool use = false) {
+int intern_row(State* s, const Part& ty, const Part& id, bool create, uint32_t* out, bool use = false, bool excl = true) {
     const std::string key = key_of(ty, id);
     auto it = s->rows.find(key);
     if (it != s->rows.end()) {
         *out = it->second;
-        if (use) s->row_keep[it->second] = 0;
+        if (use && s->row_keep[it->second]) {
+            if (!excl) return kUpgrade;
+            s->row_keep[it->second] = 0;
+        }
         return RIO_GP_OK;
     }
     if (!create) {
         *out = RIO_GP_NONE;
         return RIO_GP_OK;
     }
+    if (!excl) return kUpgrade;
     uint32_t row;
     if (!s->free_rows.empty()) {
         row = s->free_rows.back();
@@ -244,7 +323,7 @@ int intern_row(State* s, const Part& ty, const Part& id, bool create, uint32_t* 
 // by mu.  EINVAL when every row belongs to a live object.
 int reclaim(State* s) {
     {
-        std::unique_lock<std::mutex> li(s->imu);
+        std::unique_lock<std::shared_mutex> li(s->imu);
         while (s->reclaiming) s->rcv.wait(li);  // someone else is at it: wait, then let the caller retry
         if (!s->free_rows.empty() || s->hi_rows < s->max_objects) return RIO_GP_OK;
         s->reclaiming = true;
@@ -254,7 +333,7 @@ int reclaim(State* s) {
     size_t got = 0;
     {
         std::lock_guard<std::mutex> g(s->mu);
-        std::lock_guard<std::mutex> gi(s->imu);
+        std::lock_guard<std::shared_mutex> gi(s->imu);
         const uint64_t n = s->hi_rows;
         std::vector<uint32_t> assign(n ? n : 1), aff(n ? n : 1), gone, ones;
         if ((rc = sync_device(s, true)) == RIO_GP_OK) {
@@ -267,6 +346,7 @@ int reclaim(State* s) {
                     s->rows.erase(key_of(s->row_key[r].first, s->row_key[r].second));
                     s->row_key[r] = std::pair<std::string, std::string>();
                     s->row_live[r] = 0;
+                    s->shadow.erase((uint32_t)r);  // the row changes hands: what the shadow knew of it belonged to the old key
                     s->free_rows.push_back((uint32_t)r);
                     gone.push_back((uint32_t)r);
                 }
@@ -303,7 +383,7 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
     const uint64_t n = rows.size();
     bool any_malformed;
     {
-        std::unique_lock<std::mutex> li(s->imu, std::defer_lock);
+        std::shared_lock<std::shared_mutex> li(s->imu, std::defer_lock);
         if (!tables_locked) li.lock();
         any_malformed = s->n_malformed != 0;
     }
@@ -313,7 +393,7 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
         int rc = rio_gp_lookup_batch(s->gp, n, rows.data(), cur.data());
         if (rc) return gp_fail(s, rc);
         {
-            std::unique_lock<std::mutex> li(s->imu, std::defer_lock);
+            std::shared_lock<std::shared_mutex> li(s->imu, std::defer_lock);
             if (!tables_locked) li.lock();
             for (uint64_t k = 0; k < n; ++k)
                 if (cur[k] != RIO_GP_NONE && s->node_malformed[cur[k]]) bad.push_back(rows[k]);
@@ -321,37 +401,50 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
         if (!bad.empty() && (rc = rio_gp_remove_batch(s->gp, bad.size(), bad.data()))) return gp_fail(s, rc);
     }
     int rc = rio_gp_place_pending(s->gp, n, rows.data(), reqs.data(), out_node, out_flag);
-    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+    if (rc) return gp_fail(s, rc);
+    // the shadow follows: a request that found its object on a dead node had that node cleaned (every object of it: rows this
+    // batch does not name), so everything older than this batch is dropped first; then every requested row is where the
+    // device just said it is
+    bool cleaned = false;
+    for (uint64_t k = 0; k < n && !cleaned && out_flag; ++k) cleaned = (out_flag[k] & RIO_GP_FLAG_REPLACED) != 0;
+    if (cleaned || !out_flag) s->shadow.invalidate_all();
+    for (uint64_t k = 0; k < n; ++k) s->shadow.put(rows[k], out_node[k]);
+    return RIO_GP_OK;
 }
 
-// Combining front-end for the single-object calls (ObjectPlacement::lookup, get_or_create_placement): the reference is
-// called from one tokio task per connection (server.rs:292-304), and one device round trip per call (16-22 us behind a
-// mutex) would cap a provider at ~5e4 calls/s however many tasks call it.  Callers queue their request; whoever finds
-// nobody serving becomes the server: it takes up to kCombine queued requests, runs ONE batched device call per kind (the
-// micro-batch kernels: one launch + one wait for <= 256 requests), publishes the results, serves at most one more batch
-// after the one that held its own request and then hands the role to a queued waiter (bounded tenure: run_combined).
-// A lone caller pays exactly what it paid before; N concurrent callers share a round trip.  Requests of one
-// batch keep their arrival order (the first request for an object decides, as in rio_gp_place_pending).
-constexpr size_t kCombine = 256;
+// Combining front-end for the single-object calls that need the device (a lookup the shadow cannot answer, a first touch,
+// update, remove): the reference is called from one tokio task per connection (server.rs:292-304), and one device round trip
+// per call (8-11 us behind a mutex) would cap a provider at ~1e5 calls/s however many tasks call it.  Flat combining: a caller
+// interns its key, publishes its request on a lock-free list and then tries to become the server — whoever gets `mu` takes
+// EVERYTHING published so far (its own request included: it was published before the lock was asked for), runs ONE batched
+// device call per kind (the micro-batch kernels: one launch + one wait for <= 256 requests), publishes the results and
+// releases the lock.  Tenure is exactly one batch, so a server always returns to its own caller (round-2 advisor finding);
+// requests published while a batch is on the device are the next server's batch.  A lone caller pays exactly what it paid
+// before; N concurrent callers share a round trip.  Requests of one batch keep their arrival order (the first request for an
+// object decides, as in rio_gp_place_pending).  Round 4's queue + condition variable + hand-over protocol collapsed under
+// many callers (64 threads: 1.1e5 lookups/s, fewer than one thread alone): every waiter fought for the queue's mutex.
 
 // one batched device call for the requests `who` of one kind; t_err holds the text when it fails
 int run_kind(State* s, int kind, std::vector<uint32_t>& rows, std::vector<uint32_t>& reqs, uint32_t* res, uint32_t* fl) {
     int rc;
+    const size_t n = rows.size();
     if (kind == 0) {
-        if ((rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res))) gp_fail(s, rc);
+        if ((rc = rio_gp_lookup_batch(s->gp, n, rows.data(), res))) gp_fail(s, rc);
+        else for (size_t k = 0; k < n; ++k) s->shadow.put(rows[k], res[k]);
     } else if (kind == 1) {
         rc = policy_batch(s, rows, reqs, res, fl, false);
     } else if (kind == 2) {
-        if ((rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), reqs.data()))) gp_fail(s, rc);
+        if ((rc = rio_gp_update_batch(s->gp, n, rows.data(), reqs.data()))) gp_fail(s, rc);
+        else for (size_t k = 0; k < n; ++k) s->shadow.put(rows[k], reqs[k]);  // (in order: the last writer of a row wins here too)
     } else {
-        if ((rc = rio_gp_remove_batch(s->gp, rows.size(), rows.data()))) gp_fail(s, rc);
+        if ((rc = rio_gp_remove_batch(s->gp, n, rows.data()))) gp_fail(s, rc);
+        else for (size_t k = 0; k < n; ++k) s->shadow.put(rows[k], RIO_GP_NONE);
     }
     return rc;
 }
 
-void serve(State* s, std::vector<Req*>& batch) {
-    std::lock_guard<std::mutex> g(s->mu);  // NOT imu: callers keep interning and queueing during the device round trip
-    // every id in this batch was interned before its request was queued: whatever the device does not know yet of the
+void serve(State* s, std::vector<Req*>& batch) {  // mu held (NOT imu: callers keep interning and publishing during the round trip)
+    // every id in this batch was interned before its request was published: whatever the device does not know yet of the
     // node table or the row count goes there now, ahead of the requests (the serving thread may not be the one that
     // interned the new address)
     const int src = sync_device(s, false);
@@ -359,6 +452,8 @@ void serve(State* s, std::vector<Req*>& batch) {
         for (Req* r : batch) { r->rc = src; r->err = t_err; }
         return;
     }
+    ++s->dev_batches;
+    s->dev_requests += batch.size();
     std::vector<uint32_t> rows, reqs, res, fl;
     std::vector<Req*> who;
     // writes first, in arrival order (sequential last-writer-wins, local.rs:22-40), then the reads and the policy calls:
@@ -392,83 +487,64 @@ void serve(State* s, std::vector<Req*>& batch) {
 }
 
 int run_combined(State* s, Req* mine) {
-    std::unique_lock<std::mutex> lk(s->qmu);
-    s->queue.push_back(mine);
-    // Wait for the result, or for the server's role: a server hands the role over after its own batch plus one more
-    // (below), so a waiter also looks at `serving` and takes over when nobody serves a queue that still holds its request.
-    while (s->serving.load(std::memory_order_relaxed)) {
-        // a device round trip is 15-25 us: spin on the own flag first (a futex sleep + wake costs more than the wait and,
-        // with hundreds of waiters, serialises them), sleep only when it takes much longer
-        lk.unlock();
-        bool look = false;
-        for (int spin = 0; spin < 400 && !look; ++spin) {  // ~10 us of pure spinning
-            if (mine->done.load(std::memory_order_acquire)) return mine->rc;
-            look = !s->serving.load(std::memory_order_acquire);
-            __builtin_ia32_pause();
-        }
-        for (int y = 0; y < 200 && !look; ++y) {           // then give the core away between looks (more threads than cores)
-            if (mine->done.load(std::memory_order_acquire)) return mine->rc;
-            look = !s->serving.load(std::memory_order_acquire);
-            sched_yield();
-        }
-        lk.lock();
+    // publish (newest first; the server reverses)
+    Req* head = s->pending.load(std::memory_order_relaxed);
+    do mine->next = head;
+    while (!s->pending.compare_exchange_weak(head, mine, std::memory_order_release, std::memory_order_relaxed));
+    for (unsigned spin = 0;; ++spin) {
         if (mine->done.load(std::memory_order_acquire)) return mine->rc;
-        if (!look && s->serving.load(std::memory_order_relaxed)) {
-            ++s->sleepers;
-            s->qcv.wait(lk, [&] { return mine->done.load(std::memory_order_acquire) != 0 || !s->serving.load(std::memory_order_relaxed); });
-            --s->sleepers;
-            if (mine->done.load(std::memory_order_acquire)) return mine->rc;
+        if (s->mu.try_lock()) {
+            // Not done and the lock is ours: nobody is serving, so our request is still on the list — every batch that was
+            // taken off it has been served to the end (its server held this lock until it had published every result).
+            if (!mine->done.load(std::memory_order_acquire)) {
+                if (s->collect_ns > 1 && s->last_batch > 1) {
+                    // other callers are active: the ones the last batch served are on their way back with their next request
+                    // (closed-loop callers alternate between two cohorts otherwise, each batch carrying half of them) — a
+                    // microsecond or two of collecting turns "half, then the other half" into "everyone" per round trip
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (std::chrono::steady_clock::now() - t0 < std::chrono::nanoseconds(s->collect_ns)) __builtin_ia32_pause();
+                }
+                std::vector<Req*>& batch = s->batch;
+                batch.clear();
+                for (Req* r = s->pending.exchange(nullptr, std::memory_order_acquire); r; r = r->next) batch.push_back(r);
+                std::reverse(batch.begin(), batch.end());  // arrival order
+                s->last_batch = batch.size();
+                serve(s, batch);
+                for (Req* r : batch)
+                    if (r != mine) r->done.store(1, std::memory_order_release);  // last touch of *r: it lives on its caller's stack
+            }
+            s->mu.unlock();
+            return mine->rc;
         }
+        // somebody else is on the device (8-11 us), or a compound call holds the lock: spin on the own flag first (a futex
+        // sleep + wake costs more than the wait), give the core away when it takes longer (more callers than cores), and
+        // sleep in earnest when it takes much longer (a snapshot, a reclaim, a big batched call)
+        if (spin < 256) __builtin_ia32_pause();
+        else if (spin < 4096) sched_yield();
+        else { const timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
     }
-    // Nobody serves and this request is still queued: this thread is the server.  Its tenure is bounded — the batches up
-    // to the one that holds its own request, plus at most ONE more (the requests that arrived meanwhile) — and then the
-    // role is handed to a queued waiter: with closed-loop callers the queue never drains (each caller's next request
-    // arrives while the others' are served), and a server that loops "until empty" never returns to its own caller
-    // (round-2 advisor finding; in the Rust binding that pins a tokio blocking-pool thread).
-    s->serving.store(true, std::memory_order_relaxed);
-    std::vector<Req*> batch;
-    size_t last_batch = 1;
-    bool own_done = false;
-    int extra = 0;
-    while (!s->queue.empty() && !(own_done && extra >= 1)) {
-        if (last_batch > 1 && s->queue.size() < last_batch) {
-            // other callers are active and on their way back with their next request: a few microseconds of collecting
-            // turn "one, then everyone else" into "everyone" per device round trip
-            lk.unlock();
-            const auto t0 = std::chrono::steady_clock::now();
-            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(4)) __builtin_ia32_pause();
-            lk.lock();
-        }
-        const size_t take = s->queue.size() < kCombine ? s->queue.size() : kCombine;
-        batch.assign(s->queue.begin(), s->queue.begin() + take);
-        s->queue.erase(s->queue.begin(), s->queue.begin() + take);
-        lk.unlock();
-        serve(s, batch);
-        if (own_done) ++extra;
-        for (Req* r : batch) {
-            if (r != mine) r->done.store(1, std::memory_order_release);  // last touch of *r
-            else own_done = true;
-        }
-        last_batch = batch.size();
-        lk.lock();
-        if (s->sleepers) s->qcv.notify_all();
-    }
-    s->serving.store(false, std::memory_order_release);
-    if (!s->queue.empty() && s->sleepers) s->qcv.notify_all();  // spinning waiters see `serving`; sleeping ones are woken
-    return mine->rc;
 }
 
-// A single-object call: intern under imu (held off while keys are being reclaimed), count as in flight while its row id
-// is on its way to the device (reclaim() waits for that count to drain before it forgets any key).
-// `intern` fills the request and returns RIO_GP_OK, kFull, an error, or kNoop = "nothing to do" (e.g. lookup of an unknown key).
+// A single-object call: intern under imu — shared first: a key and an address that are already known change nothing, and
+// such a call may be answered from the host shadow right there (kHit); exclusively when something has to be created —
+// (held off while keys are being reclaimed), count as in flight while its row id is on its way to the device (reclaim()
+// waits for that count to drain before it forgets any key).
+// `intern(excl)` fills the request and returns RIO_GP_OK, kFull, an error, kNoop = "nothing to do" (e.g. lookup of an unknown
+// key), kHit = answered, or (excl == false only) kUpgrade.
 template <typename F>
 int single_call(State* s, Req* r, F intern) {
     for (int attempt = 0;; ++attempt) {
         int rc;
         {
-            std::unique_lock<std::mutex> li(s->imu);
+            std::shared_lock<std::shared_mutex> li(s->imu);
             while (s->reclaiming) s->rcv.wait(li);
-            rc = intern();
+            rc = intern(false);
+            if (rc == RIO_GP_OK) s->inflight.fetch_add(1, std::memory_order_acq_rel);
+        }
+        if (rc == kUpgrade) {
+            std::unique_lock<std::shared_mutex> li(s->imu);
+            while (s->reclaiming) s->rcv.wait(li);
+            rc = intern(true);
             if (rc == RIO_GP_OK) s->inflight.fetch_add(1, std::memory_order_acq_rel);
         }
         if (rc == kFull && attempt == 0) {
@@ -491,7 +567,7 @@ int compound_call(State* s, F body) {
         int rc;
         {
             std::lock_guard<std::mutex> g(s->mu);
-            std::lock_guard<std::mutex> gi(s->imu);
+            std::lock_guard<std::shared_mutex> gi(s->imu);
             rc = body();
         }
         if (rc == kFull && attempt == 0) {
@@ -545,6 +621,8 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     s->max_nodes = cfg->max_nodes;
     s->pushed_version = s->node_version;  // the empty node table is on the device
     s->pushed_shape = s->shape_version;
+    s->shadow.init(cfg->max_objects, cfg->max_nodes, (cfg->flags & RIO_OP_CFG_NO_HOST_SHADOW) == 0);
+    s->collect_ns = cfg->collect_ns ? cfg->collect_ns : RIO_OP_DEFAULT_COLLECT_NS;
     *out = new rio_op{s};
     return RIO_GP_OK;
 }
@@ -573,7 +651,7 @@ rio_gp_t* rio_op_dense(rio_op_t* p) { return p ? p->s->gp : nullptr; }
 
 const char* rio_op_node_address(rio_op_t* p, uint32_t node_id) {
     if (!p) return nullptr;
-    std::lock_guard<std::mutex> gi(p->s->imu);
+    std::shared_lock<std::shared_mutex> gi(p->s->imu);
     // node_addr is a deque of strings that are never modified: the pointer stays valid for the life of the provider
     return node_id < p->s->node_addr.size() ? p->s->node_addr[node_id].c_str() : nullptr;
 }
@@ -602,7 +680,9 @@ static int op_update_batch(rio_op_t* p, uint64_t n, const Keys& ks, const char* 
         if ((rc = sync_device(s, true))) return rc;
         if (rows.empty()) return RIO_GP_OK;
         rc = rio_gp_update_batch(s->gp, rows.size(), rows.data(), nodes.data());
-        return rc ? gp_fail(s, rc) : RIO_GP_OK;
+        if (rc) return gp_fail(s, rc);
+        for (size_t k = 0; k < rows.size(); ++k) s->shadow.put(rows[k], nodes[k]);  // (in order: the last writer of a row wins)
+        return RIO_GP_OK;
     });
 }
 
@@ -621,14 +701,14 @@ static int op_update(rio_op_t* p, const Part& ty, const Part& id, const char* ad
     Req r;
     r.kind = 2;
     r.req = RIO_GP_NONE;
-    const int rc = single_call(s, &r, [&]() -> int {
+    const int rc = single_call(s, &r, [&](bool excl) -> int {
         int rc;
         if (addr) {  // Some(address): entry(key) = address
-            if ((rc = intern_row(s, ty, id, true, &r.row, true))) return rc;
-            return intern_node(s, addr, true, &r.req);
+            if ((rc = intern_row(s, ty, id, true, &r.row, true, excl))) return rc;
+            return intern_node(s, addr, true, &r.req, false, excl);
         }
         // None: remove(key) (local.rs:36-37) — an unknown key stays unknown
-        if ((rc = intern_row(s, ty, id, false, &r.row, true))) return rc;
+        if ((rc = intern_row(s, ty, id, false, &r.row, true, excl))) return rc;
         return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;
     });
     return rc == kNoop ? RIO_GP_OK : rc;
@@ -638,7 +718,7 @@ static int op_lookup_batch(rio_op_t* p, uint64_t n, const Keys& ks, uint32_t* ou
     if (!p || (n && (!ks.tys || !ks.ids || !out))) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
+    std::shared_lock<std::shared_mutex> gi(s->imu);
     std::vector<uint32_t> rows, where;
     for (uint64_t k = 0; k < n; ++k) {
         uint32_t row;
@@ -656,7 +736,7 @@ static int op_lookup_batch(rio_op_t* p, uint64_t n, const Keys& ks, uint32_t* ou
     std::vector<uint32_t> res(rows.size());
     rc = rio_gp_lookup_batch(s->gp, rows.size(), rows.data(), res.data());
     if (rc) return gp_fail(s, rc);
-    for (size_t q = 0; q < rows.size(); ++q) out[where[q]] = res[q];
+    for (size_t q = 0; q < rows.size(); ++q) { out[where[q]] = res[q]; s->shadow.put(rows[q], res[q]); }
     return RIO_GP_OK;
 }
 
@@ -682,17 +762,27 @@ static int op_lookup(rio_op_t* p, const Part& ty, const Part& id, char* out, siz
     r.req = RIO_GP_NONE;
     *found = 0;
     t_addr_len = 0;
-    const int rc = single_call(s, &r, [&]() -> int {
+    int hit_rc = RIO_GP_OK;
+    const int rc = single_call(s, &r, [&](bool) -> int {
         const int rc = intern_row(s, ty, id, false, &r.row);
         if (rc) return rc;
-        return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;  // unknown key: Ok(None), no device work
+        if (r.row == RIO_GP_NONE) return kNoop;  // unknown key: Ok(None), no device work
+        // what the device last said about this row, if nothing has happened since that could have moved it: the answer
+        // (local.rs:42-49 is a hash-map read; so is this).  The address is copied out here, under the table lock.
+        if (s->shadow.get(r.row, &r.node)) {
+            *found = r.node != RIO_GP_NONE;
+            if (*found) hit_rc = copy_out(s->node_addr[r.node], out, cap);
+            return kHit;
+        }
+        return RIO_GP_OK;
     });
     if (rc == kNoop) return RIO_GP_OK;
+    if (rc == kHit) return hit_rc;
     if (rc) return rc;
     *found = r.node != RIO_GP_NONE;
     t_addr_len = 0;
     if (*found) {
-        std::lock_guard<std::mutex> gi(s->imu);
+        std::shared_lock<std::shared_mutex> gi(s->imu);
         return copy_out(s->node_addr[r.node], out, cap);  // RIO_GP_ERANGE: *found is set, nothing was copied
     }
     return RIO_GP_OK;
@@ -711,14 +801,16 @@ int rio_op_clean_server(rio_op_t* p, const char* address) {
     if (!p || !address) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
+    std::shared_lock<std::shared_mutex> gi(s->imu);
     uint32_t node;
     int rc = intern_node(s, address, false, &node);
     if (rc) return rc;
     if (node == RIO_GP_NONE) return RIO_GP_OK;  // nothing was ever placed there: retain() removes nothing
     if ((rc = sync_device(s, true))) return rc;
     rc = rio_gp_clean_server(s->gp, node, nullptr);
-    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+    if (rc) return gp_fail(s, rc);
+    s->shadow.clean(node);  // whatever the shadow held for rows of that node is void; every other row's entry stands
+    return RIO_GP_OK;
 }
 
 static int op_remove(rio_op_t* p, const Part& ty, const Part& id) {
@@ -727,8 +819,8 @@ static int op_remove(rio_op_t* p, const Part& ty, const Part& id) {
     Req r;
     r.kind = 3;
     r.req = RIO_GP_NONE;
-    const int rc = single_call(s, &r, [&]() -> int {
-        const int rc = intern_row(s, ty, id, false, &r.row, true);
+    const int rc = single_call(s, &r, [&](bool excl) -> int {
+        const int rc = intern_row(s, ty, id, false, &r.row, true, excl);
         if (rc) return rc;
         return r.row == RIO_GP_NONE ? kNoop : RIO_GP_OK;  // absent: no-op (local.rs:60-68)
     });
@@ -754,7 +846,7 @@ int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t cap
     if (!p || !address) return RIO_GP_EINVAL;
     State* s = p->s;
     std::lock_guard<std::mutex> g(s->mu);
-    std::lock_guard<std::mutex> gi(s->imu);
+    std::lock_guard<std::shared_mutex> gi(s->imu);
     uint32_t node;
     int rc = intern_node(s, address, true, &node);
     if (rc) return rc;
@@ -820,14 +912,28 @@ static int op_get_or_create(rio_op_t* p, const Part& ty, const Part& id, const c
     Req r;
     r.kind = 1;
     t_addr_len = 0;
-    const int rc = single_call(s, &r, [&]() -> int {
+    int hit_rc = RIO_GP_OK;
+    const int rc = single_call(s, &r, [&](bool excl) -> int {
         int rc;
-        if ((rc = intern_row(s, ty, id, true, &r.row, true))) return rc;
-        return intern_node(s, self_address, true, &r.req, true);  // a server answering requests is up
+        if ((rc = intern_row(s, ty, id, true, &r.row, true, excl))) return rc;
+        if ((rc = intern_node(s, self_address, true, &r.req, true, excl))) return rc;  // a server answering requests is up
+        // The sticky path of service.rs:199-242 — lookup, the server it names is an active member, return it — from the host
+        // shadow: the object is where the device last put it, nothing has happened since that could have moved it, and that
+        // server is up and well-formed.  Anything else (pending, on a server that is not active, malformed) is the device's.
+        uint32_t nd;
+        if (s->shadow.get(r.row, &nd) && nd != RIO_GP_NONE && nd < s->node_alive.size() && s->node_alive[nd] && !s->node_malformed[nd]) {
+            r.node = nd;
+            r.flag = nd == r.req ? RIO_GP_FLAG_LOCAL : RIO_GP_FLAG_REDIRECT;
+            if (flag) *flag = r.flag;
+            hit_rc = copy_out(s->node_addr[nd], out, cap);
+            return kHit;
+        }
+        return RIO_GP_OK;
     });
+    if (rc == kHit) return hit_rc;
     if (rc) return rc;
     if (flag) *flag = r.flag;
-    std::lock_guard<std::mutex> gi(s->imu);
+    std::shared_lock<std::shared_mutex> gi(s->imu);
     // RIO_GP_ERANGE: the decision is made and *flag is set; the address is one rio_op_lookup away (a pure read)
     return copy_out(r.node == RIO_GP_NONE ? std::string() : s->node_addr[r.node], out, cap);
 }
@@ -861,7 +967,7 @@ int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_nam
     t_snap_ty.clear(); t_snap_id.clear(); t_snap_addr.clear();
     {
         std::lock_guard<std::mutex> g(s->mu);
-        std::lock_guard<std::mutex> gi(s->imu);
+        std::shared_lock<std::shared_mutex> gi(s->imu);
         int rc;
         if ((rc = sync_device(s, true))) return rc;
         const uint64_t n = s->hi_rows;
@@ -895,7 +1001,23 @@ int rio_op_tick(rio_op_t* p, rio_gp_stats* stats) {
     int rc;
     if ((rc = sync_device(s, false))) return rc;
     rc = rio_gp_tick(s->gp, stats);
+    s->shadow.invalidate_all();  // a whole-table solve may move any pending or evicted row (also when it failed half-way)
     return rc ? gp_fail(s, rc) : RIO_GP_OK;
+}
+
+int rio_op_invalidate_cache(rio_op_t* p) {
+    if (!p) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(p->s->mu);
+    p->s->shadow.invalidate_all();
+    return RIO_GP_OK;
+}
+
+int rio_op_device_round_trips(rio_op_t* p, uint64_t* batches, uint64_t* requests) {
+    if (!p) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(p->s->mu);
+    if (batches) *batches = p->s->dev_batches;
+    if (requests) *requests = p->s->dev_requests;
+    return RIO_GP_OK;
 }
 
 }  // extern "C"

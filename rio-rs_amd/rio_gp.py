@@ -17,6 +17,7 @@ CAP_INF = 0xFFFFFFFFFFFFFFFF
 AFF_INACTIVE = 0xFFFFFFFE       # RIO_GP_AFF_INACTIVE: affinity of a row that is not an object
 CFG_ROW_LIFECYCLE = 1           # RIO_GP_CFG_ROW_LIFECYCLE
 CFG_REF_SELF_ASSIGN = 2         # RIO_GP_CFG_REF_SELF_ASSIGN: claims / first touches do not need a live node (service.rs:244-252)
+OP_CFG_NO_HOST_SHADOW = 8       # RIO_OP_CFG_NO_HOST_SHADOW: every single-object call goes to the device (A/B runs)
 OP_CFG_LIVE_FIRST_TOUCH = 4     # RIO_OP_CFG_LIVE_FIRST_TOUCH (string layer, whose DEFAULT is the reference's self-assignment): opt out
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleaned and re-placed by this request
@@ -423,7 +424,7 @@ class GpuPlacement:
 class OpCfg(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("max_objects", C.c_uint64),
                 ("max_nodes", C.c_uint32), ("spill_rounds", C.c_uint32), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("collect_ns", C.c_uint32)]
 
 
 _op_ready = False
@@ -473,6 +474,8 @@ def _oplib():
                                       C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_char_p))]
         L.rio_op_dense.argtypes = [_vp]
         L.rio_op_dense.restype = _vp
+        L.rio_op_invalidate_cache.argtypes = [_vp]
+        L.rio_op_device_round_trips.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _op_ready = True
     return L
 
@@ -615,6 +618,15 @@ class GpuObjectPlacement:
         st = Stats()
         self._chk(_oplib().rio_op_tick(self._h, C.byref(st)))
         return st.as_dict()
+
+    def invalidate_cache(self):
+        self._chk(_oplib().rio_op_invalidate_cache(self._h))
+
+    def device_round_trips(self):
+        """(combined batches, requests they carried) of the single-object calls so far."""
+        b, r = C.c_uint64(0), C.c_uint64(0)
+        self._chk(_oplib().rio_op_device_round_trips(self._h, C.byref(b), C.byref(r)))
+        return int(b.value), int(r.value)
 
     def snapshot(self):
         """Every placed entry as (struct_name, object_id, server_address) — the reference's table columns."""

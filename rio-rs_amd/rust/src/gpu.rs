@@ -37,7 +37,7 @@ struct RioOpCfg {
     max_nodes: u32,
     spill_rounds: u32,
     flags: u32,
-    reserved: u32,
+    collect_ns: u32,
 }
 
 const RIO_GP_OK: c_int = 0;
@@ -140,7 +140,7 @@ impl GpuObjectPlacement {
         let cfg = RioOpCfg {
             struct_size: std::mem::size_of::<RioOpCfg>() as u32,
             device, max_objects, max_nodes, spill_rounds,
-            flags: if reference_self_assign { 0 } else { RIO_OP_CFG_LIVE_FIRST_TOUCH }, reserved: 0,
+            flags: if reference_self_assign { 0 } else { RIO_OP_CFG_LIVE_FIRST_TOUCH }, collect_ns: 0,
         };
         let mut h: *mut c_void = std::ptr::null_mut();
         let rc = unsafe { rio_op_create(&cfg, &mut h) };

@@ -23,6 +23,18 @@ struct rio_gp {
     int fail(const char* m) { err = m; return RIO_GP_EINVAL; }
 };
 
+// -DSTUB_LATENCY_US=n (measurement aid, tools/host_layer_scaling.sh): every batched call holds the "device" for n microseconds,
+// the way a launch + wait does — the string layer's combiner is then measured against something shaped like a device
+#ifdef STUB_LATENCY_US
+#include <chrono>
+static void device_latency() {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(STUB_LATENCY_US)) {}
+}
+#else
+static void device_latency() {}
+#endif
+
 extern "C" {
 uint32_t rio_gp_abi_version(void) { return RIO_GP_ABI_VERSION; }
 const char* rio_gp_last_error(rio_gp_t* h) { return h ? h->err.c_str() : "stub"; }
@@ -71,6 +83,7 @@ int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive) {
 }
 int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* out) {
     std::lock_guard<std::mutex> g(h->mu);
+    device_latency();
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n) return h->fail("stub: object index out of range");
     for (uint64_t k = 0; k < n; ++k) out[k] = h->assign[idx[k]];
@@ -78,6 +91,7 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
 }
 int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* node) {
     std::lock_guard<std::mutex> g(h->mu);
+    device_latency();
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n || (node[k] != RIO_GP_NONE && node[k] >= h->alive.size()))
             return h->fail("stub: index or node out of range");
@@ -89,6 +103,7 @@ int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint
 }
 int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     std::lock_guard<std::mutex> g(h->mu);
+    device_latency();
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n) return h->fail("stub: object index out of range");
     for (uint64_t k = 0; k < n; ++k) { h->assign[idx[k]] = RIO_GP_NONE; h->aff[idx[k]] = RIO_GP_AFF_INACTIVE; }
@@ -127,6 +142,7 @@ int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out) {
 }
 int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* req, uint32_t* out_node, uint32_t* out_flag) {
     std::lock_guard<std::mutex> g(h->mu);
+    device_latency();
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n || req[k] >= h->alive.size()) return h->fail("stub: object index or requester out of range");
     for (uint64_t k = 0; k < n; ++k) {

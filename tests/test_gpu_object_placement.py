@@ -234,6 +234,76 @@ def test_random_differential_vs_reference_restatement(gp, oracle, seed, self_ass
     assert p.lookup_batch(keys) == [o.lookup(*k) for k in keys]
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_host_shadow_answers_exactly_what_the_device_would(gp, seed):
+    """The host shadow (rio_gpu_object_placement.h: RIO_OP_CFG_NO_HOST_SHADOW) is a cache of device answers, never a decision:
+    two providers fed the same random stream — trait calls, batched calls, membership flips, clean_server, policy requests from
+    servers that are up or not, whole-table ticks, key reclaim on a small table — one with the shadow, one without, must agree
+    on every answer and every flag; and the one with the shadow must have gone to the device far less often."""
+    rng = np.random.default_rng(900 + seed)
+    addrs = ["10.1.0.%d:%d" % (k, 7000 + k) for k in range(7)] + ["nocolon"]
+    a = gp.GpuObjectPlacement(max_objects=160, max_nodes=16)
+    b = gp.GpuObjectPlacement(max_objects=160, max_nodes=16, flags=gp.OP_CFG_NO_HOST_SHADOW)
+    alive = [True] * len(addrs)
+    for x in addrs[:-1]:
+        for p in (a, b):
+            p.set_member(x, True, capacity=40 if seed % 2 else gp.CAP_INF)     # (odd seeds: capacities bind, rows spill)
+    keys = [("T%d" % (k % 3), "k%d" % k) for k in range(140)]
+    for step in range(700):
+        r = rng.random()
+        ty, oid = keys[int(rng.integers(len(keys)))]
+        if r < 0.10:
+            x = addrs[int(rng.integers(len(addrs)))]
+            a.update(ty, oid, x); b.update(ty, oid, x)
+        elif r < 0.16:
+            a.remove(ty, oid); b.remove(ty, oid)
+        elif r < 0.19:
+            x = addrs[int(rng.integers(len(addrs)))]
+            a.clean_server(x); b.clean_server(x)
+        elif r < 0.24:
+            k = int(rng.integers(len(addrs) - 1))
+            alive[k] = not alive[k]
+            a.set_member(addrs[k], alive[k]); b.set_member(addrs[k], alive[k])
+        elif r < 0.27:
+            assert a.tick() == b.tick(), step
+        elif r < 0.31:
+            kk = int(rng.integers(2, 30))
+            bk = [keys[int(rng.integers(len(keys)))] for _ in range(kk)]
+            me = [addrs[int(rng.integers(len(addrs) - 1))] for _ in range(kk)]
+            ga, fa = a.get_or_create_placement_batch(bk, me)
+            gb, fb = b.get_or_create_placement_batch(bk, me)
+            assert ga == gb and list(fa) == list(fb), step
+        elif r < 0.35:
+            bk = [keys[int(rng.integers(len(keys)))] for _ in range(int(rng.integers(1, 50)))]
+            assert a.lookup_batch(bk) == b.lookup_batch(bk), step
+        elif r < 0.38:    # new keys until the table is full: removed / cleaned keys are reclaimed, their rows change hands
+            nk = ("N", "n%d" % step)
+            x = addrs[int(rng.integers(len(addrs) - 1))]
+            ra = rb = None
+            try:
+                a.update(nk[0], nk[1], x)
+            except gp.ObjectPlacementError as e:
+                ra = e.rc
+            try:
+                b.update(nk[0], nk[1], x)
+            except gp.ObjectPlacementError as e:
+                rb = e.rc
+            assert ra == rb, step
+            if ra is None:
+                keys.append(nk)
+        elif r < 0.70:
+            me = addrs[int(rng.integers(len(addrs) - 1))]
+            assert a.get_or_create_placement(ty, oid, me) == b.get_or_create_placement(ty, oid, me), (step, ty, oid, me)
+        else:
+            assert a.lookup(ty, oid) == b.lookup(ty, oid), (step, ty, oid)
+    for k in keys:
+        assert a.lookup(*k) == b.lookup(*k)
+    assert len(a) == len(b) and sorted(a.snapshot()) == sorted(b.snapshot())
+    (_, ra), (_, rb) = a.device_round_trips(), b.device_round_trips()
+    assert ra < rb * 0.8, (ra, rb)      # lookups and sticky requests of rows the device has answered for stay on the host
+    a.close(); b.close()
+
+
 def test_snapshot_round_trip_in_the_reference_schema(gp, tmp_path):
     """dump -> a SQLite file in the reference's layout -> readable by the REFERENCE's own SELECT
     (sqlite.rs:87-93, text carried by the golden fixture) -> load into a fresh table; and the other way round:

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The two C hosts of examples/ against the library of this tree: pipelined solves + churn ticks from C99 (c_host), and the
-# trait-shaped single-object calls from 1 / 4 / 16 pthreads sharing one provider (c_host_threads).  Usage: tools/c_hosts.sh <tag>
+# trait-shaped single-object calls from 1 / 4 / 16 / 64 / 256 pthreads sharing one provider (c_host_threads: with the host
+# shadow and with every call on the device, default collect window and none).  Usage: tools/c_hosts.sh <tag>
 TAG=${1:-chost}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -9,5 +10,7 @@ cd $ROOT
 gcc -O2 -std=c99 -I include examples/c_host.c -o /tmp/c_host -L rio-rs_amd -lrio_gp -Wl,-rpath,$ROOT/rio-rs_amd -Wl,-rpath,/opt/rocm/lib -lm || exit 1
 gcc -O2 -std=c99 -pthread -I include examples/c_host_threads.c -o /tmp/c_host_threads -L rio-rs_amd -lrio_gp -Wl,-rpath,$ROOT/rio-rs_amd -Wl,-rpath,/opt/rocm/lib -lm || exit 1
 timeout 300 /tmp/c_host 10000000 1024 100 200 > $OUT/${TAG}_c_host.json 2> $OUT/${TAG}_c_host.err
-timeout 300 /tmp/c_host_threads > $OUT/${TAG}_c_host_threads.json 2> $OUT/${TAG}_c_host_threads.err
+( echo "{\"host\": \"$(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2 | sed 's/^ //')\", \"hardware_threads\": $(nproc)}"
+  timeout 600 /tmp/c_host_threads 20000 2000 256 0
+  timeout 600 /tmp/c_host_threads 20000 2000 256 1 | grep '"device"' ) > $OUT/${TAG}_c_host_threads.json 2> $OUT/${TAG}_c_host_threads.err
 cat $OUT/${TAG}_c_host.json $OUT/${TAG}_c_host_threads.json
