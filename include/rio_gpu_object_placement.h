@@ -152,7 +152,9 @@ int rio_op_get_or_create_placement_batch_n(rio_op_t* p, uint64_t n, const char* 
 int rio_op_set_object_load_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id, size_t object_id_len,
                              uint32_t load);
 
-/* Whole-table re-solve over the interned tables (rio_gp_tick). */
+/* Whole-table re-solve over the interned tables (rio_gp_tick): the eager form of the reference's lazy clean_server + first-touch
+ * path — every object that sits on a server that is not an active member is evicted and re-placed at once.  A tick has no
+ * requester that vouches for itself, so it places on active members only, whatever rio_op_cfg.flags says about requests. */
 int rio_op_tick(rio_op_t* p, rio_gp_stats* stats);
 /* The dense handle underneath (borrowed).  A mutation made through it bypasses the host shadow: follow it with
  * rio_op_invalidate_cache. */

@@ -135,6 +135,10 @@ void rio_gp_destroy(rio_gp_t* h);
 /* Text of the last failure on this handle (or of the last failed create when h == NULL).
  * The Rust adapter wraps it as ObjectPlacementError::{Upstream,Unknown}(text). */
 const char* rio_gp_last_error(rio_gp_t* h);
+/* Change RIO_GP_CFG_REF_SELF_ASSIGN after creation (the only bit that may change; every other bit of `flags` must equal the
+ * handle's).  The string layer uses it around rio_op_tick: a whole-table solve has no requester that vouches for itself, so it
+ * places on active members only even when requests self-assign.  Counts as a change of the solve's inputs. */
+int rio_gp_set_flags(rio_gp_t* h, uint32_t flags);
 /* "hip:gfx950" — there is no other backend. */
 const char* rio_gp_backend(rio_gp_t* h);
 uint32_t rio_gp_abi_version(void);

@@ -66,7 +66,7 @@ thread_local std::vector<const char*> t_snap_ty, t_snap_id, t_snap_addr;
 thread_local std::vector<size_t> t_snap_tylen, t_snap_idlen;
 
 // One single-object call waiting for its device round trip (see run_combined).
-struct Req {
+struct alignas(64) Req {      // (a line of its own: its caller spins on `done` while every other waiter spins on theirs)
     int kind;                 // 0 lookup | 1 get_or_create_placement | 2 update | 3 remove
     uint32_t row, req;        // dense ids (req: requester node for kind 1, new node or NONE for kind 2)
     uint32_t node = RIO_GP_NONE, flag = 0;
@@ -132,15 +132,19 @@ struct Shadow {
 };
 
 struct State {
-    std::mutex mu;    // compound operations and their device call sequences (taken first)
-    std::shared_mutex imu;  // the interning tables below (taken second, or alone by the single-object calls, which must be
-                            // able to intern and publish while the serving thread waits for the device); shared: read-only use
-    std::atomic<Req*> pending{nullptr};  // published single-object calls nobody has served yet (newest first)
-    std::vector<Req*> batch;             // (under mu) the requests the serving thread took off the list, oldest first
+    // (the words many threads hammer at once sit on cache lines of their own: 64 waiters trying the device lock on the line the
+    //  publishers' list head and the table lock's reader count live on cost 50 us per combined batch, measured)
+    alignas(64) std::mutex mu;    // compound operations and their device call sequences (taken first)
+    alignas(64) std::atomic<int> busy{0};  // somebody holds mu: waiters look at this (a shared read) before they try the lock
+    alignas(64) std::shared_mutex imu;  // the interning tables below (taken second, or alone by the single-object calls, which must
+                            // be able to intern and publish while the serving thread waits for the device); shared: read-only use
+    alignas(64) std::atomic<Req*> pending{nullptr};  // published single-object calls nobody has served yet (newest first)
+    alignas(64) std::vector<Req*> batch;  // (under mu) the requests the serving thread took off the list, oldest first
     Shadow shadow;
     uint64_t dev_batches = 0, dev_requests = 0;  // (under mu) device round trips of combined batches / requests they carried
     size_t last_batch = 0;                       // (under mu) requests of the last combined batch
     uint32_t collect_ns = 0;                     // rio_op_cfg.collect_ns
+    bool self_assign = true;                     // requests first-touch their requester whatever membership says (the default)
     rio_gp_t* gp = nullptr;
     uint64_t max_objects = 0;
     uint32_t max_nodes = 0;
@@ -205,6 +209,14 @@ int fail(int rc, const std::string& m) {
     t_err = m;
     return rc;
 }
+// mu for a compound call: taken blocking, and marked busy so that single-object callers wait on the flag, not on the lock word
+struct DevLock {
+    State* s;
+    explicit DevLock(State* st) : s(st) { s->mu.lock(); s->busy.store(1, std::memory_order_relaxed); }
+    ~DevLock() { s->busy.store(0, std::memory_order_release); s->mu.unlock(); }
+    DevLock(const DevLock&) = delete;
+    DevLock& operator=(const DevLock&) = delete;
+};
 int gp_fail(State* s, int rc) {  // only directly after the failing rio_gp_* call, under mu (nobody else calls the handle)
     const char* e = rio_gp_last_error(s->gp);
     t_err = e ? e : "";
@@ -332,7 +344,7 @@ int reclaim(State* s) {
     int rc = RIO_GP_OK;
     size_t got = 0;
     {
-        std::lock_guard<std::mutex> g(s->mu);
+        DevLock g(s);
         std::lock_guard<std::shared_mutex> gi(s->imu);
         const uint64_t n = s->hi_rows;
         std::vector<uint32_t> assign(n ? n : 1), aff(n ? n : 1), gone, ones;
@@ -493,7 +505,8 @@ int run_combined(State* s, Req* mine) {
     while (!s->pending.compare_exchange_weak(head, mine, std::memory_order_release, std::memory_order_relaxed));
     for (unsigned spin = 0;; ++spin) {
         if (mine->done.load(std::memory_order_acquire)) return mine->rc;
-        if (s->mu.try_lock()) {
+        if (!s->busy.load(std::memory_order_relaxed) && s->mu.try_lock()) {
+            s->busy.store(1, std::memory_order_relaxed);
             // Not done and the lock is ours: nobody is serving, so our request is still on the list — every batch that was
             // taken off it has been served to the end (its server held this lock until it had published every result).
             if (!mine->done.load(std::memory_order_acquire)) {
@@ -513,14 +526,16 @@ int run_combined(State* s, Req* mine) {
                 for (Req* r : batch)
                     if (r != mine) r->done.store(1, std::memory_order_release);  // last touch of *r: it lives on its caller's stack
             }
+            s->busy.store(0, std::memory_order_release);
             s->mu.unlock();
             return mine->rc;
         }
-        // somebody else is on the device (8-11 us), or a compound call holds the lock: spin on the own flag first (a futex
-        // sleep + wake costs more than the wait), give the core away when it takes longer (more callers than cores), and
-        // sleep in earnest when it takes much longer (a snapshot, a reclaim, a big batched call)
-        if (spin < 256) __builtin_ia32_pause();
-        else if (spin < 4096) sched_yield();
+        // somebody else is on the device (8-11 us), or a compound call holds the lock: spin — on the own flag and a shared read
+        // of `busy`, nothing that takes a cache line away from the thread that serves — (a futex sleep + wake costs more than
+        // the wait), give the core away when it takes longer (more callers than cores), and sleep in earnest when it takes much
+        // longer (a snapshot, a reclaim, a big batched call)
+        if (spin < 2048) { for (unsigned q = 0, e = spin < 16 ? 1u : 8u; q < e; ++q) __builtin_ia32_pause(); }
+        else if (spin < 8192) sched_yield();
         else { const timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
     }
 }
@@ -566,7 +581,7 @@ int compound_call(State* s, F body) {
     for (int attempt = 0;; ++attempt) {
         int rc;
         {
-            std::lock_guard<std::mutex> g(s->mu);
+            DevLock g(s);
             std::lock_guard<std::shared_mutex> gi(s->imu);
             rc = body();
         }
@@ -623,6 +638,7 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     s->pushed_shape = s->shape_version;
     s->shadow.init(cfg->max_objects, cfg->max_nodes, (cfg->flags & RIO_OP_CFG_NO_HOST_SHADOW) == 0);
     s->collect_ns = cfg->collect_ns ? cfg->collect_ns : RIO_OP_DEFAULT_COLLECT_NS;
+    s->self_assign = (cfg->flags & RIO_OP_CFG_LIVE_FIRST_TOUCH) == 0;
     *out = new rio_op{s};
     return RIO_GP_OK;
 }
@@ -717,7 +733,7 @@ static int op_update(rio_op_t* p, const Part& ty, const Part& id, const char* ad
 static int op_lookup_batch(rio_op_t* p, uint64_t n, const Keys& ks, uint32_t* out) {
     if (!p || (n && (!ks.tys || !ks.ids || !out))) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
+    DevLock g(s);
     std::shared_lock<std::shared_mutex> gi(s->imu);
     std::vector<uint32_t> rows, where;
     for (uint64_t k = 0; k < n; ++k) {
@@ -800,7 +816,7 @@ size_t rio_op_last_address_len(rio_op_t*) { return t_addr_len; }
 int rio_op_clean_server(rio_op_t* p, const char* address) {
     if (!p || !address) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
+    DevLock g(s);
     std::shared_lock<std::shared_mutex> gi(s->imu);
     uint32_t node;
     int rc = intern_node(s, address, false, &node);
@@ -835,7 +851,7 @@ int rio_op_remove_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, 
 int rio_op_len(rio_op_t* p, uint64_t* out) {
     if (!p || !out) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
+    DevLock g(s);
     int rc;
     if ((rc = sync_device(s, false))) return rc;
     rc = rio_gp_count_placed(s->gp, out);
@@ -845,7 +861,7 @@ int rio_op_len(rio_op_t* p, uint64_t* out) {
 int rio_op_set_member(rio_op_t* p, const char* address, int active, uint64_t capacity) {
     if (!p || !address) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
+    DevLock g(s);
     std::lock_guard<std::shared_mutex> gi(s->imu);
     uint32_t node;
     int rc = intern_node(s, address, true, &node);
@@ -966,7 +982,7 @@ int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_nam
     t_snap_store.clear();
     t_snap_ty.clear(); t_snap_id.clear(); t_snap_addr.clear();
     {
-        std::lock_guard<std::mutex> g(s->mu);
+        DevLock g(s);
         std::shared_lock<std::shared_mutex> gi(s->imu);
         int rc;
         if ((rc = sync_device(s, true))) return rc;
@@ -997,24 +1013,33 @@ int rio_op_snapshot(rio_op_t* p, uint64_t* n_out, const char* const** struct_nam
 int rio_op_tick(rio_op_t* p, rio_gp_stats* stats) {
     if (!p) return RIO_GP_EINVAL;
     State* s = p->s;
-    std::lock_guard<std::mutex> g(s->mu);
+    DevLock g(s);
     int rc;
     if ((rc = sync_device(s, false))) return rc;
+    // A whole-table solve has no requester that vouches for itself: it places on servers that are active members only, also when
+    // requests first-touch their requester whatever membership says (the default: service.rs:244-252) — an object evicted from a
+    // dead server would otherwise claim that same server, its home, again.
+    if (s->self_assign && (rc = rio_gp_set_flags(s->gp, RIO_GP_CFG_ROW_LIFECYCLE))) return gp_fail(s, rc);
     rc = rio_gp_tick(s->gp, stats);
+    if (rc) gp_fail(s, rc);
     s->shadow.invalidate_all();  // a whole-table solve may move any pending or evicted row (also when it failed half-way)
-    return rc ? gp_fail(s, rc) : RIO_GP_OK;
+    if (s->self_assign) {
+        const int rc2 = rio_gp_set_flags(s->gp, RIO_GP_CFG_ROW_LIFECYCLE | RIO_GP_CFG_REF_SELF_ASSIGN);
+        if (rc2 && !rc) return gp_fail(s, rc2);
+    }
+    return rc;
 }
 
 int rio_op_invalidate_cache(rio_op_t* p) {
     if (!p) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(p->s->mu);
+    DevLock g(p->s);
     p->s->shadow.invalidate_all();
     return RIO_GP_OK;
 }
 
 int rio_op_device_round_trips(rio_op_t* p, uint64_t* batches, uint64_t* requests) {
     if (!p) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(p->s->mu);
+    DevLock g(p->s);
     if (batches) *batches = p->s->dev_batches;
     if (requests) *requests = p->s->dev_requests;
     return RIO_GP_OK;

@@ -219,6 +219,20 @@ __device__ __forceinline__ int classify(u32 c, u32 a, u32 m, const u32* alv, u32
 //     never interned, removed, or dropped by clean_server): it is kept if it happens to be placed
 //     on a live node and takes no part otherwise — neither claimant nor spill candidate.
 // ------------------------------------------------------------------------------------------------
+// Answer record of one request, 8 bytes at its batch position (k_pp_win_gather -> k_pp_win_split, or -> k_scan<COMPACT 3> when the
+// batch needs the solve): word 0 = node (16 bits, 0xFFFF = none) | flag << 16 (8 bits) | later request of its object << 31;
+// word 1 = the row's load (first request of an object) or the batch position of the first request (later ones).
+__host__ __device__ __forceinline__ u32 pp_ans(u32 node, u32 flag, bool later) {
+    return (node == kNone ? 0xFFFFu : (node & 0xFFFFu)) | (flag << 16) | (later ? 0x80000000u : 0u);
+}
+__host__ __device__ __forceinline__ u32 pp_ans_node(u32 w) { return (w & 0xFFFFu) == 0xFFFFu ? kNone : (w & 0xFFFFu); }
+__host__ __device__ __forceinline__ u32 pp_ans_flag(u32 w) { return (w >> 16) & 0xFFu; }
+// ... as the `cur` column of the virtual table: a later request takes no part, a row its first request placed (or could not
+// place) was pending, anything else is kept where it is
+__host__ __device__ __forceinline__ u32 pp_ans_cur(u32 w) {
+    return (w >> 31) ? kSkipMark : ((pp_ans_flag(w) & 0xFu) >= 2u ? kNone : pp_ans_node(w));
+}
+
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // four consecutive words at any word address
 constexpr u32 kStageCap = 320;  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     auto unrec = [&](uint4& c, uint4& l, const u64 i) {  // records -> columns (and out to the column arrays)
         if (!vrec) return;
         const uint4 a = c, b = l;
-        c = make_uint4(a.x, a.z, b.x, b.z);
+        c = make_uint4(pp_ans_cur(a.x), pp_ans_cur(a.z), pp_ans_cur(b.x), pp_ans_cur(b.z));  // (answer records: k_pp_win_gather)
         l = make_uint4(a.y, a.w, b.y, b.w);
         *reinterpret_cast<uint4*>(const_cast<u32*>(cur) + i) = c;
         *reinterpret_cast<uint4*>(const_cast<u32*>(load) + i) = l;
@@ -2744,7 +2758,8 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
                                                      u32* __restrict__ rec, uint2* __restrict__ rec2,
                                                      unsigned short* __restrict__ start16, DevStats* st, const bool none_ok,
                                                      u32* __restrict__ host_err = nullptr, u32* __restrict__ zero_flags = nullptr,
-                                                     u32* __restrict__ zero_bits = nullptr, const u32 zero_words = 0) {
+                                                     u32* __restrict__ zero_bits = nullptr, const u32 zero_words = 0,
+                                                     u64* __restrict__ zero_u64 = nullptr, const u32 zero_u64_words = 0) {
     // host_err (optional, mapped host memory): set when the chunk holds an invalid entry, so the caller learns it without a
     // copy-back — the kernels it has enqueued behind this one look at st->err and do nothing
     // zero_flags / zero_bits (place_pending): the per-request flag column (this chunk's slice of it, densely) and the bitmap
@@ -2781,6 +2796,8 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     }
     if (zero_bits && c == 0)
         for (u32 w = tid; w < zero_words; w += kBlock) zero_bits[w] = 0;
+    if (zero_u64 && c == (nchunks > 1 ? 1u : 0u))  // (place_pending: the per-requester claim loads + the window kernel's counter)
+        for (u32 w = tid; w < zero_u64_words; w += kBlock) zero_u64[w] = 0;
     __syncthreads();
     const u32 I[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
     const u32 N[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
@@ -3020,70 +3037,144 @@ __device__ __forceinline__ void part_walk(const uint2* __restrict__ rec2, const 
         for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) body(rec2[pbase[i] + o]);
 }
 
+// fast[0] = requests this kernel could not answer by itself (an object on a dead node: clean_server first; a pending object
+// whose requester is not an active member: water-fill, or the reference's unconditional self-assignment) — the call then runs
+// the solve over the records; claim[m] = load the first touches put on every requester (k_pp_win_verdict checks it against
+// the free capacity).  Both zeroed by the binning kernel.
 __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
                                                           u32 m, const u32* __restrict__ alive_bits,
                                                           const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
                                                           u32 nchunks, const u32 wshift, uint2* __restrict__ vrec,
                                                           u32* __restrict__ dead_bits, u32* __restrict__ out_flag,
-                                                          u32* __restrict__ aff_life, const DevStats* __restrict__ st) {
+                                                          u32* __restrict__ aff_life, const DevStats* __restrict__ st,
+                                                          u64* __restrict__ claim, u64* __restrict__ fast, const u32 lds_hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->err) return;  // the binning kernel found an invalid entry: the call fails, nothing is touched
     const u32 W = 1u << wshift;
-    u32* wpos = reinterpret_cast<u32*>(smem);  // [W] first batch position that asks for the row
-    u32* wreq = wpos + W;                      // [W] its requester
+    u64* wfirst = reinterpret_cast<u64*>(smem);  // [W] {first batch position that asks for the row | its requester}, then {.. | the row's node}
+    u64* hist = wfirst + W;                      // [m] claim load per requester (lds_hist; else straight into `claim`)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
     const u64 base = (u64)b << wshift;
     RIOGP_PART_DESCRIPTORS()
-    for (u32 r = tid; r < W; r += kBlock) wpos[r] = kNone;
+    for (u32 r = tid; r < W; r += kBlock) wfirst[r] = ~0ull;
+    if (lds_hist)
+        for (u32 j = tid; j < m; j += kBlock) hist[j] = 0;
     __syncthreads();
-    part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) { atomicMin(&wpos[x.x & (W - 1)], x.y); });
-    __syncthreads();
-    // later requests of an object point at the first (no row is read here: the window's rows are read once, densely, below)
+    // the first request of every row decides: ds_min_u64 on {position | requester} (one walk gives both)
     part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) {
-        const u32 row = x.x & (W - 1), k = x.y, f = wpos[row];
-        if (f != k) vrec[k] = make_uint2(kSkipMark, f);
-        else wreq[row] = x.x >> kPartShiftMax;
+        atomicMin(&wfirst[x.x & (W - 1)], ((u64)x.y << 32) | (u64)(x.x >> kPartShiftMax));
     });
     __syncthreads();
-    // the requested rows of the window, in row order: the first request's virtual-table row {node | load} goes to its batch
-    // position (the one random store of this kernel per object).  A pending row (unplaced, or found on a dead node) whose
-    // first requester is ALIVE also gets that requester written into the real column right here, densely, as its optimistic
-    // placement — what the solve's scan used to do with one scattered 4-byte store per first touch (130 of its 174 us at
-    // 10 M requests); the fix-up overwrites it through the same row if the claim is rejected, and clean_server (which runs
-    // behind this kernel for the dead nodes the requests ran into) cannot take it for a row of a dead node: its value is a
-    // live node now.
+    // The requested rows of the window, in row order, read ONCE and densely.  Each gets its answer: sticky (the node it is on),
+    // or — pending: unplaced, or found on a dead node — its first requester when that one is an active member: written into
+    // the real column right here, densely, as its placement (what the solve's scan used to do with one scattered 4-byte
+    // store per first touch: 130 of its 174 us at 10 M requests).  If the batch turns out to need the solve (k_pp_win_verdict)
+    // that placement is the optimistic one the fix-up overwrites through the same row when the claim is rejected; and
+    // clean_server (which runs behind this kernel for the dead nodes the requests ran into) cannot take it for a row of a dead
+    // node: its value is a live node now.  The first request's record goes to its batch position (the one random store of
+    // this kernel per object).
+    u32 slow = 0;
 #pragma unroll
     for (int q = 0; q < kPartRowVecs; ++q) {
         const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
         if (r4 >= W || base + r4 >= n_obj) continue;
-        const uint4 wp = *reinterpret_cast<const uint4*>(wpos + r4);
-        if (!__ballot((wp.x & wp.y & wp.z & wp.w) != kNone)) continue;  // nobody asks for any of the wave's 256 rows
+        const u64 e0 = wfirst[r4], e1 = wfirst[r4 + 1], e2 = wfirst[r4 + 2], e3 = wfirst[r4 + 3];
+        if (!__ballot((e0 & e1 & e2 & e3) != ~0ull)) continue;  // nobody asks for any of the wave's 256 rows
         const uint4 cv = *reinterpret_cast<const uint4*>(assign + base + r4);
         const uint4 lv = *reinterpret_cast<const uint4*>(load + base + r4);
         uint4 ov = cv;
         bool chg = false;
-#define RIOGP_FIRST(K, C, L, O, E)                                                                                 \
-        if (K != kNone) {                                                                                          \
+#define RIOGP_FIRST(EW, C, L, O, E)                                                                                \
+        if (EW != ~0ull) {                                                                                         \
+            const u32 K = (u32)(EW >> 32), rq = (u32)EW;                                                           \
             const bool dead = C < m && !bit_of(alive_bits, C);  /* service.rs:227-237: clean_server of that node */ \
+            u32 fl, nd;                                                                                            \
             if (dead) {                                                                                            \
                 atomicOr(&dead_bits[C >> 5], 1u << (C & 31));                                                      \
                 if (out_flag) out_flag[K] = kFlagReplaced;                                                         \
+                ++slow;                                                                                            \
             }                                                                                                      \
             /* row lifecycle: an object from its first request on, home = the requester (a row on a dead node: once */ \
             /* clean_server has taken it out, k_pp_win_output) */                                                  \
-            const u32 rq = wreq[r4 + E];                                                                           \
             if (aff_life && C >= m) aff_life[base + r4 + E] = rq;                                                  \
-            vrec[K] = make_uint2(dead ? kNone : C, L);                                                             \
-            if ((dead || C == kNone) && rq < m && bit_of(alive_bits, rq)) { O = rq; chg = true; }                  \
+            if (C < m && !dead) { nd = C; fl = C == rq ? 0u : 1u; }         /* sticky: LOCAL | REDIRECT */          \
+            else if (rq < m && bit_of(alive_bits, rq)) {                    /* first touch on the requester: PLACED */ \
+                nd = rq; fl = 2u | (dead ? kFlagReplaced : 0u);                                                    \
+                O = rq; chg = true;                                                                                \
+                if (lds_hist) atomicAdd(&hist[rq], (u64)L); else if (L) atomicAdd(&claim[rq], (u64)L);             \
+            } else { nd = kNone; fl = 4u | (dead ? kFlagReplaced : 0u); ++slow; }  /* the solve's to decide */       \
+            vrec[K] = make_uint2(pp_ans(nd, fl, false), L);                                                        \
+            wfirst[r4 + E] = (EW & 0xFFFFFFFF00000000ull) | nd;  /* what later requests of the row observe */       \
         }
-        RIOGP_FIRST(wp.x, cv.x, lv.x, ov.x, 0)
-        RIOGP_FIRST(wp.y, cv.y, lv.y, ov.y, 1)
-        RIOGP_FIRST(wp.z, cv.z, lv.z, ov.z, 2)
-        RIOGP_FIRST(wp.w, cv.w, lv.w, ov.w, 3)
+        RIOGP_FIRST(e0, cv.x, lv.x, ov.x, 0)
+        RIOGP_FIRST(e1, cv.y, lv.y, ov.y, 1)
+        RIOGP_FIRST(e2, cv.z, lv.z, ov.z, 2)
+        RIOGP_FIRST(e3, cv.w, lv.w, ov.w, 3)
 #undef RIOGP_FIRST
         if (__ballot(chg)) *reinterpret_cast<uint4*>(assign + base + r4) = ov;  // (whole lines; unchanged rows keep their value)
     }
+    __syncthreads();
+    // later requests of an object observe the first's (LOCAL / REDIRECT, or UNPLACED): their record carries the answer and
+    // the position of the first
+    part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) {
+        const u64 e = wfirst[x.x & (W - 1)];
+        const u32 k = x.y, f = (u32)(e >> 32), nd = (u32)e, rq = x.x >> kPartShiftMax;
+        if (f != k) vrec[k] = make_uint2(pp_ans(nd, nd == kNone ? 4u : (nd == rq ? 0u : 1u), true), f);
+    });
+    if (lds_hist)
+        for (u32 j = tid; j < m; j += kBlock)
+            if (hist[j]) atomicAdd(&claim[j], hist[j]);
+    slow = wave_sum32(slow);
+    if (lane == 0 && slow) atomicAdd(fast, (u64)slow);
+}
+
+// Does the batch need the solve?  No, when every request was answered by the window kernel and every requester's first
+// touches fit its free capacity (then every index-ordered prefix of them fits too: nobody is cut, no ordered walk is needed
+// — k_pp_one's argument, for any batch size): the answers are final, `used` takes the claims, k_pp_win_split hands the
+// answers out.  Otherwise nothing is changed here and the host enqueues the solve over the same records.
+// verdict: device word for k_pp_win_split | mapped host word for the caller: 1 final | 2 needs the solve | 3 invalid entry
+__global__ __launch_bounds__(kBlock) void k_pp_win_verdict(u32 m, const u64* __restrict__ cap, const u32* __restrict__ alive_bits,
+                                                           u64* __restrict__ used, const u64* __restrict__ claim,
+                                                           const u64* __restrict__ fast, const DevStats* __restrict__ st,
+                                                           u32* __restrict__ verdict_dev, u32* __restrict__ verdict_host) {
+    const int tid = threadIdx.x;
+    const bool bad = st->err != 0;
+    bool over = false;
+    for (u32 j = tid; j < m; j += kBlock) {
+        const u64 c = claim[j];
+        if (!c) continue;
+        const u64 cp = cap[j], u = used[j];
+        over = over || !bit_of(alive_bits, j) || cp <= u || c > cp - u;
+    }
+    const bool need = __syncthreads_or(over) || fast[0] != 0;
+    if (!bad && !need)
+        for (u32 j = tid; j < m; j += kBlock) used[j] += claim[j];
+    if (tid == 0) {
+        const u32 v = bad ? 3u : (need ? 2u : 1u);
+        *verdict_dev = v;
+        __hip_atomic_store(verdict_host, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The answers in batch order, densely: records -> the caller's node / flag columns (final verdict only), then the completion word
+__global__ __launch_bounds__(256) void k_pp_win_split(const uint2* __restrict__ vrec, u64 n, u32* __restrict__ out_node,
+                                                      u32* __restrict__ out_flag, const u32* __restrict__ verdict,
+                                                      unsigned int* ticket, u32* done, u32 seq) {
+    if (*verdict == 1u) {
+        const u64 nv = n >> 1, stride = (u64)gridDim.x * 256;
+        for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += stride) {  // two requests (one 16-byte read) per lane
+            const uint4 r = *reinterpret_cast<const uint4*>(vrec + 2 * v);
+            *reinterpret_cast<uint2*>(out_node + 2 * v) = make_uint2(pp_ans_node(r.x), pp_ans_node(r.z));
+            if (out_flag) *reinterpret_cast<uint2*>(out_flag + 2 * v) = make_uint2(pp_ans_flag(r.x), pp_ans_flag(r.z));
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const uint2 r = vrec[n - 1];
+            out_node[n - 1] = pp_ans_node(r.x);
+            if (out_flag) out_flag[n - 1] = pp_ans_flag(r.x);
+        }
+    }
+    signal_done_grid(ticket, done, seq);
 }
 
 #undef RIOGP_PART_DESCRIPTORS
@@ -4530,25 +4621,39 @@ void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u3
 }
 // place_pending over a window-sorted batch (k_pp_win_*): scratch = part_scratch_words(n_obj, n) words (records + chunk table)
 void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s,
-                   u32* dead_bits, u32* out_flag) {
+                   u32* dead_bits, u32* out_flag, u64* claim_fast) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
     uint2* rec2 = reinterpret_cast<uint2*>(scratch);
     unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
     hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx, req, n,
-                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, out_flag, dead_bits, (m + 31) / 32);
+                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, out_flag, dead_bits, (m + 31) / 32,
+                       claim_fast, m + 1);
 }
+// claim_fast: [m] claim loads + [1] the "could not answer by itself" counter, zeroed by launch_pp_bin
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
-                          uint2* vrec, u32* vcur, u32* vload, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st,
+                          uint2* vrec, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st, u64* claim_fast,
                           hipStream_t s) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
     const uint2* rec2 = reinterpret_cast<const uint2*>(scratch);
     const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
-    // (dead_bits and out_flag were cleared by the binning kernel: launch_pp_bin)
-    hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), ((size_t)2 << wshift) * sizeof(u32), s, assign, load, n_obj, m,
-                       alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, out_flag, aff_life, st);
-    (void)vcur; (void)vload;  // (the solve's scan splits the records into the two columns on its way: Table::vrec)
+    // (dead_bits, out_flag and claim_fast were cleared by the binning kernel: launch_pp_bin)
+    const size_t win = ((size_t)1 << wshift) * sizeof(u64);
+    const u32 lds_hist = win + (size_t)m * sizeof(u64) <= (size_t)160 * 1024 ? 1u : 0u;  // else: global atomics per first touch
+    hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), win + (lds_hist ? (size_t)m * sizeof(u64) : 0), s, assign, load,
+                       n_obj, m, alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, out_flag, aff_life, st, claim_fast,
+                       claim_fast + m, lds_hist);
+}
+void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* used, const u64* claim_fast, const DevStats* st,
+                           u32* verdict_dev, u32* verdict_host, hipStream_t s) {
+    hipLaunchKernelGGL(k_pp_win_verdict, dim3(1), dim3(kBlock), 0, s, m, cap, alive_bits, used, claim_fast, claim_fast + m, st,
+                       verdict_dev, verdict_host);
+}
+void launch_pp_win_split(const uint2* vrec, u64 n, u32* out_node, u32* out_flag, const u32* verdict, unsigned int* ticket, u32* done,
+                         u32 seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_pp_win_split, dim3(grid_for((n + 1) / 2, 256, 2048)), dim3(256), 0, s, vrec, n, out_node, out_flag, verdict,
+                       ticket, done, seq);
 }
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,

@@ -225,6 +225,8 @@ struct rio_gp {
     u32* h_req = nullptr;   // request batches of up to kReqBatch entries from host buffers, mapped pinned memory, [4][kReqBatch] u32: idx | req | out | flag
     u32* d_req = nullptr;
     u32* pp_bad = nullptr;  // device word of the general request path: != 0 while a batch with an invalid entry is in flight
+                            // ([1]: the window-sorted path's verdict word)
+    u64* pp_claim = nullptr;  // [max_nodes + 1] window-sorted request path: claim load per requester + its "needs the solve" counter
     bool pp_last_slow = false;  // the last general-path request batch needed the cut / water-fill: the next one enqueues it speculatively
     DevBuf rq[4];           // staging of bigger host-buffer request batches (the general path's own scratch is vt / stage)
     void* pp_stage = nullptr;            // staging table of the three-launch request path (k_pp_stage / _decide / _apply)
@@ -879,6 +881,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         return bail(RIO_GP_ENOMEM);
     }
     h->allocs.push_back(h->pp_bad);
+    if ((rc = dalloc(h, &h->pp_claim, (size_t)h->cap_nodes + 1)) != RIO_GP_OK) return bail(rc);
     if (hipMalloc(&h->pp_stage, pp_stage_bytes()) != hipSuccess || hipMemset(h->pp_stage, 0, pp_stage_bytes()) != hipSuccess) {
         h->err = "request staging allocation failed";
         return bail(RIO_GP_ENOMEM);
@@ -929,6 +932,17 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->ev3) (void)hipEventDestroy(h->ev3);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+}
+
+int rio_gp_set_flags(rio_gp_t* h, uint32_t flags) {
+    if (!h) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    const uint32_t fixed = h->lifecycle ? RIO_GP_CFG_ROW_LIFECYCLE : 0u;
+    if ((flags & ~RIO_GP_CFG_REF_SELF_ASSIGN) != fixed) return fail(h, RIO_GP_EINVAL, "rio_gp_set_flags: only RIO_GP_CFG_REF_SELF_ASSIGN may change");
+    const u32 sa = (flags & RIO_GP_CFG_REF_SELF_ASSIGN) ? 1u : 0u;
+    if (sa && (h->p2p || h->sc)) return fail(h, RIO_GP_EINVAL, "rio_gp_set_flags: row-sharded handles do not implement RIO_GP_CFG_REF_SELF_ASSIGN");
+    if (sa != h->sa) { h->sa = sa; h->have_solved = false; ++h->mut_epoch; }
+    return RIO_GP_OK;
 }
 
 int rio_gp_sync(rio_gp_t* h) {
@@ -1407,11 +1421,31 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         if ((rc = zero_stats(h))) return rc;
         u32* const h_bad = h->h_cs + h->cs_words + 2;
         *h_bad = 0;
-        launch_pp_bin(h->n, h->m, d_idx, d_req, n, (u32*)h->part.p, h->dstats, h->d_cs + h->cs_words + 2, h->stream, h->dead_bits, d_flag);
-        launch_pp_win_gather(assign, h->load, h->n, h->m, h->alive_bits, n, (const u32*)h->part.p, (uint2*)h->vrec.p, vcur, vload,
-                             h->dead_bits, d_flag, aff_life(h), h->dstats, h->stream);
+        u32* const h_status = h->h_small + 4 * kSmallBatch;
+        *h_status = 0;
+        launch_pp_bin(h->n, h->m, d_idx, d_req, n, (u32*)h->part.p, h->dstats, h->d_cs + h->cs_words + 2, h->stream, h->dead_bits, d_flag,
+                      h->pp_claim);
+        // The window kernel answers every request it can by itself — sticky hits, first touches on requesters that are active
+        // members, later requests of an object — and records what the first touches ask of every requester; when every total
+        // fits (k_pp_win_verdict) the answers are final and k_pp_win_split hands them out: no virtual table, no solve.
+        launch_pp_win_gather(assign, h->load, h->n, h->m, h->alive_bits, n, (const u32*)h->part.p, (uint2*)h->vrec.p, h->dead_bits,
+                             d_flag, aff_life(h), h->dstats, h->pp_claim, h->stream);
         if (!h->all_alive)  // service.rs:227-237: every object of a dead node a request ran into is un-placed
             launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
+        launch_pp_win_verdict(h->m, h->cap, h->alive_bits, h->used, h->pp_claim, h->dstats, h->pp_bad + 1, h->d_small + 4 * kSmallBatch,
+                              h->stream);
+        const u32 seq1 = small_begin(h);
+        launch_pp_win_split((const uint2*)h->vrec.p, n, d_out, d_flag, h->pp_bad + 1, h->mid_ticket, small_done_dev(h), seq1, h->stream);
+        if ((rc = small_wait(h, seq1))) return rc;
+        HIPCHK(h, hipGetLastError());
+        if (*h_bad || *h_status == 3) return fail(h, RIO_GP_EINVAL, std::string(who) + ": object index or requester out of range (nothing was changed)");
+        if (*h_status == 1) {  // final: `used` has taken the claims in place
+            h->have_solved = false; ++h->mut_epoch;
+            return RIO_GP_OK;
+        }
+        if (*h_status != 2) return fail(h, RIO_GP_EUPSTREAM, std::string(who) + ": the window kernels left no verdict");
+        // The batch needs the solve (a requester would run full, a dead node was in the way, a requester is not an active
+        // member): over the same records, the window kernel's placements standing as the optimistic ones.
         Plan vp = hplan(h, n);
         const u64 seq = ++h->wait_seq;
         vp.mark = seq;
@@ -1429,7 +1463,6 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
                              h->stream, h->sa);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
-        if (*h_bad) return fail(h, RIO_GP_EINVAL, std::string(who) + ": object index or requester out of range (nothing was changed)");
         const DevStats v = reduce_slot(h, 0, h->m);
         const bool vslow = v.n_cut > 0 || v.spillcand > 0;
         std::swap(h->used, h->sb.used_cur);

@@ -50,6 +50,11 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     return RIO_GP_OK;
 }
 void rio_gp_destroy(rio_gp_t* h) { delete h; }
+int rio_gp_set_flags(rio_gp_t* h, uint32_t flags) {
+    std::lock_guard<std::mutex> g(h->mu);
+    h->sa = (flags & RIO_GP_CFG_REF_SELF_ASSIGN) != 0;
+    return RIO_GP_OK;
+}
 int rio_gp_set_objects(rio_gp_t* h, uint64_t n, const uint32_t*, const uint32_t*) {
     std::lock_guard<std::mutex> g(h->mu);
     if (n > h->assign.size()) return h->fail("stub: n exceeds max_objects");

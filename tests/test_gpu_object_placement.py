@@ -129,6 +129,7 @@ def test_keys_with_an_interior_nul_are_keys_of_their_own(gp):
     assert gp._oplib().rio_op_lookup(p._h, b"T", b"a\0c", buf, 64, C.byref(found)) == 0 and found.value == 0
     # ... and the BATCHED calls carry the lengths too (rio_op_*_batch_n; round-4 advisor finding: update_batch cut "a\0b" down to
     # "a", so a snapshot written with the key and loaded back through update_batch overwrote another object)
+    p.set_member("h:2", True)
     p.update_batch([("T", "k\0one"), ("T", "k"), ("T\0y", "k\0one")], ["h:1", "h:2", None])
     assert p.lookup_batch([("T", "k\0one"), ("T", "k"), ("T", "k\0two"), ("T\0y", "k\0one")]) == ["h:1", "h:2", None, None]
     got, flags = p.get_or_create_placement_batch([("T", "k\0two"), ("T", "k\0one"), ("T", "k")], ["h:1", "h:1", "h:1"])
@@ -370,11 +371,18 @@ def test_concurrent_single_object_calls_share_round_trips(gp, tmp_path):
     r = subprocess.run([str(exe), "5000", "400", "8"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(rows) == 4 and all(x["wrong"] == 0 for x in rows)          # 2 calls x threads {1, 4}; 8 is not in the ladder
-    for call in ("lookup", "get_or_create_placement"):
-        one = [x for x in rows if x["call"] == call and x["threads"] == 1][0]["calls_per_s"]
-        four = [x for x in rows if x["call"] == call and x["threads"] == 4][0]["calls_per_s"]
-        assert four > 0.5 * one, (call, one, four)   # shares round trips (measured 1.6x); the bound only guards against a convoy
+    # 2 providers (host shadow | every call on the device) x 3 calls x threads {1, 4}; 8 is not in the ladder
+    assert len(rows) == 12 and all(x["wrong"] == 0 for x in rows)
+    pick = lambda prov, call, t: [x for x in rows if x["provider"] == prov and x["call"] == call and x["threads"] == t][0]
+    for call in ("lookup", "get_or_create_placement", "churn"):
+        one, four = pick("device", call, 1), pick("device", call, 4)
+        assert four["calls_per_s"] > 0.5 * one["calls_per_s"], (call, one, four)   # shares round trips; the bound only guards against a convoy
+        assert four["device_round_trips"] < four["requests_on_device"]          # ... and did share some
+    for call in ("lookup", "get_or_create_placement"):   # known, placed keys: the shadow answers, the device is not asked
+        for t in (1, 4):
+            x = pick("shadow", call, t)
+            assert x["requests_on_device"] == 0 and x["calls_per_s"] > 3 * pick("device", call, t)["calls_per_s"], x
+    assert pick("shadow", "churn", 4)["requests_on_device"] > 0                 # first touches are the device's
 
 
 
