@@ -443,7 +443,17 @@ def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
     sts = g.tick_wait()
     dtp = time.perf_counter() - t0
     frac = lambda sec: ALGO_BYTES_PER_DECISION * n * steps / sec / 1e9 / HBM_PEAK_GBPS
+    # SURVEY.md section 8d's own accounting for config 5: the clean_server scan (4 B per object) + 4 B per evicted row + a placement
+    # decision (16 B) per re-placed row — what the reference's clean_server + per-request path would move for the same
+    # effect; ~60 MB per tick at 10 M rows where the full-tick accounting above counts 160 MB
+    ev_rows = sum(x["evicted"] for x in sts)
+    re_rows = sum(x["claimed"] + x["spilled"] + x["unplaced"] for x in sts)
+    survey_bytes = 4 * n * steps + 4 * ev_rows + 16 * re_rows
     piped = {"ms_per_tick": dtp / steps * 1e3, "value": n * steps / dtp, "unit": "decisions/s", "frac_of_roofline": frac(dtp),
+             "frac_survey_accounting": survey_bytes / dtp / 1e9 / HBM_PEAK_GBPS,
+             "survey_accounting": {"bytes_per_tick": survey_bytes / steps, "evicted_rows_per_tick": ev_rows / steps,
+                                   "replaced_rows_per_tick": re_rows / steps,
+                                   "definition": "SURVEY.md 8d, config 5: 4 B/object scan + 4 B per evicted row + 16 B per re-placed row"},
              "equal_to_synchronous_stream": bool(np.array_equal(g.get_assign(), final_sync)) and
              bool(np.array_equal(g.get_nodes()[2], used_sync)) and sts[-1] == st,
              "step": "rio_gp_set_alive_all + rio_gp_tick_async: nothing waits on the host between ticks, every tick's "
@@ -478,6 +488,7 @@ def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
                     "committed tick evicts and re-places their objects (~1 M rows, hundreds of cut nodes)" % (n, m),
         "ticks": steps, "warmup": warmup, "slow_path_ticks": slow,
         "synchronous": {"ms_per_tick": dt / steps * 1e3, "value": n * steps / dt, "unit": "decisions/s", "frac_of_roofline": frac(dt),
+                        "frac_survey_accounting": survey_bytes / dt / 1e9 / HBM_PEAK_GBPS,
                         "step": "rio_gp_set_alive_all + rio_gp_tick (the host reads every tick's counters)"},
         "pipelined": piped, "objects_moved_per_s": moved / dt, "stats_last_tick": st, "parity": parity,
         "kernel_spans_on_device_us": spans,

@@ -66,14 +66,35 @@ thread_local std::vector<const char*> t_snap_ty, t_snap_id, t_snap_addr;
 thread_local std::vector<size_t> t_snap_tylen, t_snap_idlen;
 
 // One single-object call waiting for its device round trip (see run_combined).
-struct alignas(64) Req {      // (a line of its own: its caller spins on `done` while every other waiter spins on theirs)
+// One single-object call waiting for its device round trip (see run_combined).  The struct is a cache line of its own: its
+// caller spins on `result` while every other waiter spins on theirs.  The serving thread reads the inputs once and answers
+// with ONE store — node, flag, return code and the "done" bit packed into a word: with the answer spread over four fields the
+// waiter's polling pulled the line back between the server's stores, four or five transfers per request, 40 us of a 64-request
+// batch (measured).
+struct alignas(64) Req {
     int kind;                 // 0 lookup | 1 get_or_create_placement | 2 update | 3 remove
     uint32_t row, req;        // dense ids (req: requester node for kind 1, new node or NONE for kind 2)
+    std::atomic<uint64_t> result{0};  // kDone | rc << 40 | flag << 32 | node: stored LAST, and once, by the serving thread (the
+                                      // request lives on its caller's stack)
+    std::string err;          // text of ITS failure (a request that fails does not fail its batch-mates): written before `result`
+    // the caller's view of the answer, unpacked by the caller itself
     uint32_t node = RIO_GP_NONE, flag = 0;
     int rc = RIO_GP_OK;
-    std::string err;          // text of ITS failure (a request that fails does not fail its batch-mates)
-    Req* next = nullptr;      // the lock-free list of published requests (newest first)
-    std::atomic<int> done{0};  // set LAST by the serving thread: the request lives on its caller's stack
+    static constexpr uint64_t kDone = 1ull << 63;
+    static uint64_t pack(int rc, uint32_t node, uint32_t flag) {
+        return kDone | ((uint64_t)(uint8_t)rc << 40) | ((uint64_t)(flag & 0xFFu) << 32) | node;
+    }
+    void unpack(uint64_t w) { node = (uint32_t)w; flag = (uint32_t)(w >> 32) & 0xFFu; rc = (int)((w >> 40) & 0xFFu); }
+};
+
+// Where a caller leaves its request for the serving thread: 32 bytes, filled by the caller (in parallel with every other caller),
+// read by the server as an array — a linked list through the callers' own stack frames cost the server a dependent cache miss
+// per request (25 us for 28 requests, measured at 64 callers over two sockets).
+constexpr uint32_t kSlots = 512;
+struct alignas(32) Slot {
+    std::atomic<uint64_t> tag{0};  // (generation + 1) << 8 | kind: stored LAST by the caller; the server waits for its generation's tag
+    uint32_t row = 0, req = 0;
+    Req* r = nullptr;
 };
 
 // Host shadow of the assignment column: entry = stamp << 16 | node (0xFFFF = not placed), one atomic u64 per row, in chunks of
@@ -138,8 +159,14 @@ struct State {
     alignas(64) std::atomic<int> busy{0};  // somebody holds mu: waiters look at this (a shared read) before they try the lock
     alignas(64) std::shared_mutex imu;  // the interning tables below (taken second, or alone by the single-object calls, which must
                             // be able to intern and publish while the serving thread waits for the device); shared: read-only use
-    alignas(64) std::atomic<Req*> pending{nullptr};  // published single-object calls nobody has served yet (newest first)
+    // Published single-object calls: tickets of the current generation (generation << 32 | requests so far) and two slot arrays
+    // (generation & 1).  A caller takes a ticket, fills its slot and tags it; ticket 0 of a generation serves that generation.
+    alignas(64) std::atomic<uint64_t> ticket{0};
+    alignas(64) Slot slots[2][kSlots];
     alignas(64) std::vector<Req*> batch;  // (under mu) the requests the serving thread took off the list, oldest first
+    std::vector<uint64_t> results;        // (under mu) their packed answers
+    std::vector<int> sv_kind;             // (under mu) serve()'s scratch: no allocation per batch
+    std::vector<uint32_t> sv_row, sv_req, sv_rows, sv_reqs, sv_res, sv_fl, sv_who;
     Shadow shadow;
     uint64_t dev_batches = 0, dev_requests = 0;  // (under mu) device round trips of combined batches / requests they carried
     size_t last_batch = 0;                       // (under mu) requests of the last combined batch
@@ -155,14 +182,15 @@ struct State {
     std::vector<uint8_t> row_keep;                    // key created by rio_op_set_object_load and not used since: its load is
                                                       // what the caller set, so reclaim() must not recycle (and reset) the row
     std::vector<uint32_t> free_rows;                  // reclaimed rows, ready for new keys
-    uint64_t hi_rows = 0;                             // rows ever handed out: every row id is < hi_rows
+    std::atomic<uint64_t> hi_rows{0};                 // rows ever handed out: every row id is < hi_rows (atomic: sync_device looks
+                                                      // at it and at the two versions below without the table lock)
     std::unordered_map<std::string, uint32_t> nodes;  // address -> node id
     std::deque<std::string> node_addr;                // deque: element addresses are stable (rio_op_node_address)
     std::vector<uint8_t> node_alive, node_malformed;
     std::vector<uint64_t> node_cap;
     uint32_t n_malformed = 0;
-    uint64_t node_version = 1;                        // bumped on every change of the node table
-    uint64_t shape_version = 1;                       // bumped when a node is added or a capacity changes (not on liveness flips)
+    std::atomic<uint64_t> node_version{1};            // bumped on every change of the node table
+    std::atomic<uint64_t> shape_version{1};           // bumped when a node is added or a capacity changes (not on liveness flips)
     bool reclaiming = false;                          // single-object calls wait (rcv) while keys are being reclaimed
     std::condition_variable_any rcv;
     // --- under mu ---
@@ -226,6 +254,10 @@ int gp_fail(State* s, int rc) {  // only directly after the failing rio_gp_* cal
 // Bring the device's copy of the host tables up to date: the node table (any new address, liveness or capacity change)
 // and the row count.  Requires mu; imu is taken here unless the caller already holds it.
 int sync_device(State* s, bool imu_held) {
+    // (the common case — nothing new since the last device call — takes no lock: with 64 callers interning, the serving thread
+    //  queued 20 us per batch for a reader slot of the table lock here)
+    if (s->node_version.load(std::memory_order_acquire) == s->pushed_version &&
+        s->hi_rows.load(std::memory_order_acquire) == s->pushed_rows) return RIO_GP_OK;
     std::vector<uint64_t> cap;
     std::vector<uint8_t> alive;
     uint64_t version, shape, nrows;
@@ -313,7 +345,7 @@ int intern_row(State* s, const Part& ty, const Part& id, bool create, uint32_t* 
         row = s->free_rows.back();
         s->free_rows.pop_back();
     } else if (s->hi_rows < s->max_objects) {
-        row = (uint32_t)s->hi_rows++;
+        row = (uint32_t)s->hi_rows.fetch_add(1, std::memory_order_acq_rel);
         s->row_key.emplace_back();
         s->row_live.push_back(0);
         s->row_keep.push_back(0);
@@ -426,15 +458,19 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
 
 // Combining front-end for the single-object calls that need the device (a lookup the shadow cannot answer, a first touch,
 // update, remove): the reference is called from one tokio task per connection (server.rs:292-304), and one device round trip
-// per call (8-11 us behind a mutex) would cap a provider at ~1e5 calls/s however many tasks call it.  Flat combining: a caller
-// interns its key, publishes its request on a lock-free list and then tries to become the server — whoever gets `mu` takes
-// EVERYTHING published so far (its own request included: it was published before the lock was asked for), runs ONE batched
-// device call per kind (the micro-batch kernels: one launch + one wait for <= 256 requests), publishes the results and
-// releases the lock.  Tenure is exactly one batch, so a server always returns to its own caller (round-2 advisor finding);
-// requests published while a batch is on the device are the next server's batch.  A lone caller pays exactly what it paid
-// before; N concurrent callers share a round trip.  Requests of one batch keep their arrival order (the first request for an
-// object decides, as in rio_gp_place_pending).  Round 4's queue + condition variable + hand-over protocol collapsed under
-// many callers (64 threads: 1.1e5 lookups/s, fewer than one thread alone): every waiter fought for the queue's mutex.
+// per call (8-11 us behind a mutex) would cap a provider at ~1e5 calls/s however many tasks call it.  Flat combining, with the
+// roles settled at publication: a caller interns its key, takes a TICKET of the current generation, fills the slot the ticket
+// names (32 bytes, in parallel with every other caller) and tags it.  Ticket 0 serves its generation: it waits for `mu`,
+// closes the generation (later tickets belong to the next one, whose ticket 0 is already waiting for the lock), reads the
+// slots as an array, runs ONE batched device call per kind (the micro-batch kernels: one launch + one wait for <= 256
+// requests), answers every caller with one store into that caller's own cache line and releases the lock.  Everybody else
+// waits for its answer on a line nobody else touches.  Tenure is exactly one batch, so a server always returns to its own
+// caller (round-2 advisor finding).  A lone caller pays exactly what it paid before; N concurrent callers share a round trip.
+// Requests of one batch keep their arrival (ticket) order: the first request for an object decides, as in
+// rio_gp_place_pending.  What this replaced, measured at 64 callers on the 2-socket host: round 4's queue + condition variable
+// (1.1e5 lookups/s: every waiter fought for the queue's mutex), then a lock-free list with every waiter trying the device lock
+// (the lock lay free for 33 us per batch, or was stormed), a linked list through the callers' stack frames (a dependent cache
+// miss per request: 25 us per batch) and answers spread over four fields of a line the caller polls (40 us per batch).
 
 // one batched device call for the requests `who` of one kind; t_err holds the text when it fails
 int run_kind(State* s, int kind, std::vector<uint32_t>& rows, std::vector<uint32_t>& reqs, uint32_t* res, uint32_t* fl) {
@@ -455,33 +491,38 @@ int run_kind(State* s, int kind, std::vector<uint32_t>& rows, std::vector<uint32
     return rc;
 }
 
-void serve(State* s, std::vector<Req*>& batch) {  // mu held (NOT imu: callers keep interning and publishing during the round trip)
+// results[i] = the packed answer of batch[i] (Req::pack); error texts go into the requests themselves
+void serve(State* s, std::vector<Req*>& batch, std::vector<uint64_t>& results) {  // mu held (NOT imu: callers keep interning and
+                                                                                  // publishing during the round trip)
+    results.assign(batch.size(), 0);
     // every id in this batch was interned before its request was published: whatever the device does not know yet of the
     // node table or the row count goes there now, ahead of the requests (the serving thread may not be the one that
     // interned the new address)
     const int src = sync_device(s, false);
     if (src) {
-        for (Req* r : batch) { r->rc = src; r->err = t_err; }
+        for (size_t i = 0; i < batch.size(); ++i) { batch[i]->err = t_err; results[i] = Req::pack(src, RIO_GP_NONE, 0); }
         return;
     }
     ++s->dev_batches;
     s->dev_requests += batch.size();
-    std::vector<uint32_t> rows, reqs, res, fl;
-    std::vector<Req*> who;
+    // (the requests' inputs were copied out of the slots by the caller: sv_kind / sv_row / sv_req)
+    std::vector<int>& kinds = s->sv_kind;
+    std::vector<uint32_t>&arow = s->sv_row, &areq = s->sv_req, &rows = s->sv_rows, &reqs = s->sv_reqs, &res = s->sv_res, &fl = s->sv_fl;
+    std::vector<uint32_t>& who = s->sv_who;
     // writes first, in arrival order (sequential last-writer-wins, local.rs:22-40), then the reads and the policy calls:
     // a caller only returns after the batch, so any order inside it is a valid linearisation of concurrent calls
     for (int kind : {2, 3, 0, 1}) {
         rows.clear(); reqs.clear(); who.clear();
-        for (Req* r : batch)
-            if (r->kind == kind) { rows.push_back(r->row); reqs.push_back(r->req); who.push_back(r); }
+        for (size_t i = 0; i < batch.size(); ++i)
+            if (kinds[i] == kind) { rows.push_back(arow[i]); reqs.push_back(areq[i]); who.push_back((uint32_t)i); }
         if (who.empty()) continue;
         res.assign(who.size(), RIO_GP_NONE);
         fl.assign(who.size(), 0);
         int rc = run_kind(s, kind, rows, reqs, res.data(), fl.data());
         if (rc == RIO_GP_OK || who.size() == 1) {
             for (size_t k = 0; k < who.size(); ++k) {
-                who[k]->rc = rc; who[k]->node = res[k]; who[k]->flag = fl[k];
-                if (rc) who[k]->err = t_err;
+                if (rc) batch[who[k]]->err = t_err;
+                results[who[k]] = Req::pack(rc, res[k], fl[k]);
             }
             continue;
         }
@@ -492,52 +533,94 @@ void serve(State* s, std::vector<Req*>& batch) {  // mu held (NOT imu: callers k
             r1[0] = rows[k]; q1[0] = reqs[k];
             uint32_t nd = RIO_GP_NONE, f = 0;
             rc = run_kind(s, kind, r1, q1, &nd, &f);
-            who[k]->rc = rc; who[k]->node = nd; who[k]->flag = f;
-            if (rc) who[k]->err = t_err;
+            if (rc) batch[who[k]]->err = t_err;
+            results[who[k]] = Req::pack(rc, nd, f);
         }
     }
 }
 
+// how long a waiter has been at it, in nanoseconds (steady clock: a pause is 10-40 ns depending on the core, so iteration
+// counts say nothing about time)
+static inline long long waited_ns(const std::chrono::steady_clock::time_point t0) {
+    return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+// A device round trip is 8-15 us, and a caller waits for one to three of them: spin (a futex sleep + wake costs more than the
+// wait); give the core away when it takes longer than `spin_ns` (more callers than cores; a compound call holds the device),
+// sleep in earnest when it takes much longer (a snapshot, a reclaim, a big batched call).
+static inline void wait_step(unsigned spin, const std::chrono::steady_clock::time_point t0, long long spin_ns) {
+    if (spin < 64) { __builtin_ia32_pause(); return; }
+    for (int q = 0; q < 4; ++q) __builtin_ia32_pause();
+    if ((spin & 63u) != 0) return;
+    const long long ns = waited_ns(t0);
+    if (ns > 20 * spin_ns) { const timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
+    else if (ns > spin_ns) sched_yield();
+}
+
 int run_combined(State* s, Req* mine) {
-    // publish (newest first; the server reverses)
-    Req* head = s->pending.load(std::memory_order_relaxed);
-    do mine->next = head;
-    while (!s->pending.compare_exchange_weak(head, mine, std::memory_order_release, std::memory_order_relaxed));
+    // publish: a ticket of the current generation, then the slot it names
+    uint64_t gen;
+    uint32_t idx;
+    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; ++spin) {
-        if (mine->done.load(std::memory_order_acquire)) return mine->rc;
-        if (!s->busy.load(std::memory_order_relaxed) && s->mu.try_lock()) {
-            s->busy.store(1, std::memory_order_relaxed);
-            // Not done and the lock is ours: nobody is serving, so our request is still on the list — every batch that was
-            // taken off it has been served to the end (its server held this lock until it had published every result).
-            if (!mine->done.load(std::memory_order_acquire)) {
-                if (s->collect_ns > 1 && s->last_batch > 1) {
-                    // other callers are active: the ones the last batch served are on their way back with their next request
-                    // (closed-loop callers alternate between two cohorts otherwise, each batch carrying half of them) — a
-                    // microsecond or two of collecting turns "half, then the other half" into "everyone" per round trip
-                    const auto t0 = std::chrono::steady_clock::now();
-                    while (std::chrono::steady_clock::now() - t0 < std::chrono::nanoseconds(s->collect_ns)) __builtin_ia32_pause();
-                }
-                std::vector<Req*>& batch = s->batch;
-                batch.clear();
-                for (Req* r = s->pending.exchange(nullptr, std::memory_order_acquire); r; r = r->next) batch.push_back(r);
-                std::reverse(batch.begin(), batch.end());  // arrival order
-                s->last_batch = batch.size();
-                serve(s, batch);
-                for (Req* r : batch)
-                    if (r != mine) r->done.store(1, std::memory_order_release);  // last touch of *r: it lives on its caller's stack
-            }
-            s->busy.store(0, std::memory_order_release);
-            s->mu.unlock();
-            return mine->rc;
-        }
-        // somebody else is on the device (8-11 us), or a compound call holds the lock: spin — on the own flag and a shared read
-        // of `busy`, nothing that takes a cache line away from the thread that serves — (a futex sleep + wake costs more than
-        // the wait), give the core away when it takes longer (more callers than cores), and sleep in earnest when it takes much
-        // longer (a snapshot, a reclaim, a big batched call)
-        if (spin < 2048) { for (unsigned q = 0, e = spin < 16 ? 1u : 8u; q < e; ++q) __builtin_ia32_pause(); }
-        else if (spin < 8192) sched_yield();
-        else { const timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
+        const uint64_t t = s->ticket.fetch_add(1, std::memory_order_acq_rel);
+        gen = t >> 32;
+        idx = (uint32_t)t;
+        if (idx < kSlots) break;
+        // the generation is full (more callers than slots): wait until its server closes it, then take a ticket of the next one
+        while ((s->ticket.load(std::memory_order_acquire) >> 32) == gen) wait_step(spin++, t0, 300000);
     }
+    Slot& mys = s->slots[gen & 1][idx];
+    mys.row = mine->row;
+    mys.req = mine->req;
+    mys.r = mine;
+    mys.tag.store(((gen + 1) << 8) | (uint64_t)mine->kind, std::memory_order_release);
+    if (idx != 0) {
+        // Somebody took ticket 0 of this generation: THAT caller serves it, our request included.  We only wait for our result,
+        // on a cache line nobody else touches: no lock word, no shared flag (64 waiters trying the lock left it free for 33 us per
+        // batch — everyone was asleep or yielding when it was released — and stormed it when it was not).
+        uint64_t w;
+        for (unsigned spin = 0; !((w = mine->result.load(std::memory_order_acquire)) & Req::kDone); ++spin) wait_step(spin, t0, 300000);
+        mine->unpack(w);
+        return mine->rc;
+    }
+    // Ticket 0: the server of everything published in this generation, from now until we close it.  (One spinning thread per
+    // generation: it may spin long — the lock is handed over within a device round trip unless a compound call holds it.)
+    for (unsigned spin = 0;; ++spin) {
+        if (!s->busy.load(std::memory_order_relaxed) && s->mu.try_lock()) break;
+        wait_step(spin, t0, 5000000);
+    }
+    s->busy.store(1, std::memory_order_relaxed);
+    if (s->collect_ns > 1 && s->last_batch > 1) {
+        // other callers are active: the ones the last batch served are on their way back with their next request (closed-loop
+        // callers alternate between two cohorts otherwise, each batch carrying half of them) — a microsecond or two of
+        // collecting turns "half, then the other half" into "everyone" per round trip
+        const auto c0 = std::chrono::steady_clock::now();
+        while (std::chrono::steady_clock::now() - c0 < std::chrono::nanoseconds(s->collect_ns)) __builtin_ia32_pause();
+    }
+    // close the generation: whoever takes a ticket from now on belongs to the next one (and its ticket 0 waits for this lock)
+    const uint64_t closed = s->ticket.exchange((gen + 1) << 32, std::memory_order_acq_rel);
+    const uint32_t n = (uint32_t)closed < kSlots ? (uint32_t)closed : kSlots;
+    std::vector<Req*>& batch = s->batch;
+    batch.resize(n);
+    s->sv_kind.resize(n); s->sv_row.resize(n); s->sv_req.resize(n);
+    Slot* sl = s->slots[gen & 1];
+    for (uint32_t i = 0; i < n; ++i) {  // arrival (ticket) order; a caller between its ticket and its tag is waited for
+        uint64_t tag;
+        while (((tag = sl[i].tag.load(std::memory_order_acquire)) >> 8) != gen + 1) __builtin_ia32_pause();
+        s->sv_kind[i] = (int)(tag & 0xFFu);
+        s->sv_row[i] = sl[i].row;
+        s->sv_req[i] = sl[i].req;
+        batch[i] = sl[i].r;
+    }
+    s->last_batch = n;
+    serve(s, batch, s->results);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (batch[i] == mine) mine->unpack(s->results[i]);
+        else batch[i]->result.store(s->results[i], std::memory_order_release);  // last touch of that request: it lives on its caller's stack
+    }
+    s->busy.store(0, std::memory_order_release);
+    s->mu.unlock();
+    return mine->rc;
 }
 
 // A single-object call: intern under imu — shared first: a key and an address that are already known change nothing, and
@@ -634,8 +717,8 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     s->gp = gp;
     s->max_objects = cfg->max_objects;
     s->max_nodes = cfg->max_nodes;
-    s->pushed_version = s->node_version;  // the empty node table is on the device
-    s->pushed_shape = s->shape_version;
+    s->pushed_version = s->node_version.load();  // the empty node table is on the device
+    s->pushed_shape = s->shape_version.load();
     s->shadow.init(cfg->max_objects, cfg->max_nodes, (cfg->flags & RIO_OP_CFG_NO_HOST_SHADOW) == 0);
     s->collect_ns = cfg->collect_ns ? cfg->collect_ns : RIO_OP_DEFAULT_COLLECT_NS;
     s->self_assign = (cfg->flags & RIO_OP_CFG_LIVE_FIRST_TOUCH) == 0;

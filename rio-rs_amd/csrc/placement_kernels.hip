@@ -3157,10 +3157,11 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_verdict(u32 m, const u64* __r
     }
 }
 
-// The answers in batch order, densely: records -> the caller's node / flag columns (final verdict only), then the completion word
+// The answers in batch order, densely: records -> the caller's node / flag columns (final verdict only).  (No completion word
+// here: a fence per workgroup — 2 048 of them, each behind a burst of stores — made this 30 us copy take 290: the caller
+// waits for the stream.)
 __global__ __launch_bounds__(256) void k_pp_win_split(const uint2* __restrict__ vrec, u64 n, u32* __restrict__ out_node,
-                                                      u32* __restrict__ out_flag, const u32* __restrict__ verdict,
-                                                      unsigned int* ticket, u32* done, u32 seq) {
+                                                      u32* __restrict__ out_flag, const u32* __restrict__ verdict) {
     if (*verdict == 1u) {
         const u64 nv = n >> 1, stride = (u64)gridDim.x * 256;
         for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += stride) {  // two requests (one 16-byte read) per lane
@@ -3174,7 +3175,6 @@ __global__ __launch_bounds__(256) void k_pp_win_split(const uint2* __restrict__ 
             if (out_flag) out_flag[n - 1] = pp_ans_flag(r.x);
         }
     }
-    signal_done_grid(ticket, done, seq);
 }
 
 #undef RIOGP_PART_DESCRIPTORS
@@ -4650,10 +4650,8 @@ void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* us
     hipLaunchKernelGGL(k_pp_win_verdict, dim3(1), dim3(kBlock), 0, s, m, cap, alive_bits, used, claim_fast, claim_fast + m, st,
                        verdict_dev, verdict_host);
 }
-void launch_pp_win_split(const uint2* vrec, u64 n, u32* out_node, u32* out_flag, const u32* verdict, unsigned int* ticket, u32* done,
-                         u32 seq, hipStream_t s) {
-    hipLaunchKernelGGL(k_pp_win_split, dim3(grid_for((n + 1) / 2, 256, 2048)), dim3(256), 0, s, vrec, n, out_node, out_flag, verdict,
-                       ticket, done, seq);
+void launch_pp_win_split(const uint2* vrec, u64 n, u32* out_node, u32* out_flag, const u32* verdict, hipStream_t s) {
+    hipLaunchKernelGGL(k_pp_win_split, dim3(grid_for((n + 1) / 2, 256, 2048)), dim3(256), 0, s, vrec, n, out_node, out_flag, verdict);
 }
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,

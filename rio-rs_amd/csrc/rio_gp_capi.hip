@@ -1434,9 +1434,8 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
             launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
         launch_pp_win_verdict(h->m, h->cap, h->alive_bits, h->used, h->pp_claim, h->dstats, h->pp_bad + 1, h->d_small + 4 * kSmallBatch,
                               h->stream);
-        const u32 seq1 = small_begin(h);
-        launch_pp_win_split((const uint2*)h->vrec.p, n, d_out, d_flag, h->pp_bad + 1, h->mid_ticket, small_done_dev(h), seq1, h->stream);
-        if ((rc = small_wait(h, seq1))) return rc;
+        launch_pp_win_split((const uint2*)h->vrec.p, n, d_out, d_flag, h->pp_bad + 1, h->stream);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         if (*h_bad || *h_status == 3) return fail(h, RIO_GP_EINVAL, std::string(who) + ": object index or requester out of range (nothing was changed)");
         if (*h_status == 1) {  // final: `used` has taken the claims in place
