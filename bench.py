@@ -94,8 +94,10 @@ def parse():
     ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 record (10 % churn per tick, 110 ticks + oracle replay)")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaled config-3 second measurement")
     ap.add_argument("--no-sharded-churn", action="store_true", help="N>1: skip the committed / churn tick streams of the sharded table")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "round4_traffic.json"),
-                    help="fallback for roofline.traffic when the in-run PMC passes are skipped or fail")
+    import glob
+    newest = (sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json"))) or [os.path.join(ROOT, "profiles", "round5_traffic.json")])[-1]
+    ap.add_argument("--traffic-json", default=newest,
+                    help="fallback for roofline.traffic when the in-run PMC passes are skipped or fail (default: the newest profiles/round*_traffic.json)")
     return ap.parse_args()
 
 

@@ -3045,7 +3045,7 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
                                                           u32 m, const u32* __restrict__ alive_bits,
                                                           const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
                                                           u32 nchunks, const u32 wshift, uint2* __restrict__ vrec,
-                                                          u32* __restrict__ dead_bits, u32* __restrict__ out_flag,
+                                                          u32* __restrict__ dead_bits,
                                                           u32* __restrict__ aff_life, const DevStats* __restrict__ st,
                                                           u64* __restrict__ claim, u64* __restrict__ fast, const u32 lds_hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3090,9 +3090,8 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
             const u32 K = (u32)(EW >> 32), rq = (u32)EW;                                                           \
             const bool dead = C < m && !bit_of(alive_bits, C);  /* service.rs:227-237: clean_server of that node */ \
             u32 fl, nd;                                                                                            \
-            if (dead) {                                                                                            \
+            if (dead) {  /* (RIO_GP_FLAG_REPLACED travels in the record's flag byte: k_pp_win_output reads it there) */ \
                 atomicOr(&dead_bits[C >> 5], 1u << (C & 31));                                                      \
-                if (out_flag) out_flag[K] = kFlagReplaced;                                                         \
                 ++slow;                                                                                            \
             }                                                                                                      \
             /* row lifecycle: an object from its first request on, home = the requester (a row on a dead node: once */ \
@@ -3187,7 +3186,9 @@ __global__ __launch_bounds__(256) void k_pp_win_output(const u32* __restrict__ i
                                                        const u32* __restrict__ vnext, const u32* __restrict__ alive_bits,
                                                        const u32* __restrict__ cutidx, u32 m, u32* __restrict__ out_node,
                                                        u32* __restrict__ out_flag, u32* __restrict__ aff_life,
-                                                       const DevStats* __restrict__ st, u32 sa) {
+                                                       const DevStats* __restrict__ st, u32 sa, const uint2* __restrict__ vrec) {
+    // vrec: the window kernel's answer records — RIO_GP_FLAG_REPLACED of a request that found its object on a dead node sits in
+    // the record's flag byte (the caller's flag column is written here, once; nobody has to clear it first)
     if (st->err) return;  // the batch holds an invalid entry: the call fails
     const u64 nv = (n + 3) >> 2;
     for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += (u64)gridDim.x * 256) {
@@ -3198,12 +3199,13 @@ __global__ __launch_bounds__(256) void k_pp_win_output(const u32* __restrict__ i
             x = *reinterpret_cast<const uint4*>(vnext + k0);
             r = *reinterpret_cast<const uint4*>(req + k0);
             l = *reinterpret_cast<const uint4*>(vload + k0);
-            f = out_flag ? *reinterpret_cast<const uint4*>(out_flag + k0) : make_uint4(0, 0, 0, 0);
+            const uint4 ra = *reinterpret_cast<const uint4*>(vrec + k0), rb = *reinterpret_cast<const uint4*>(vrec + k0 + 2);
+            f = make_uint4(pp_ans_flag(ra.x), pp_ans_flag(ra.z), pp_ans_flag(rb.x), pp_ans_flag(rb.z));
         } else {
             u32 t[5][4] = {};
             for (u32 e = 0; k0 + e < n; ++e) {
                 t[0][e] = vcur[k0 + e]; t[1][e] = vnext[k0 + e]; t[2][e] = req[k0 + e]; t[3][e] = vload[k0 + e];
-                t[4][e] = out_flag ? out_flag[k0 + e] : 0u;
+                t[4][e] = pp_ans_flag(vrec[k0 + e].x);
             }
             c = make_uint4(t[0][0], t[0][1], t[0][2], t[0][3]); x = make_uint4(t[1][0], t[1][1], t[1][2], t[1][3]);
             r = make_uint4(t[2][0], t[2][1], t[2][2], t[2][3]); l = make_uint4(t[3][0], t[3][1], t[3][2], t[3][3]);
@@ -4621,28 +4623,27 @@ void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u3
 }
 // place_pending over a window-sorted batch (k_pp_win_*): scratch = part_scratch_words(n_obj, n) words (records + chunk table)
 void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s,
-                   u32* dead_bits, u32* out_flag, u64* claim_fast) {
+                   u32* dead_bits, u64* claim_fast) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
     uint2* rec2 = reinterpret_cast<uint2*>(scratch);
     unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
     hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx, req, n,
-                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, out_flag, dead_bits, (m + 31) / 32,
+                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
                        claim_fast, m + 1);
 }
 // claim_fast: [m] claim loads + [1] the "could not answer by itself" counter, zeroed by launch_pp_bin
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
-                          uint2* vrec, u32* dead_bits, u32* out_flag, u32* aff_life, const DevStats* st, u64* claim_fast,
-                          hipStream_t s) {
+                          uint2* vrec, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
     const uint2* rec2 = reinterpret_cast<const uint2*>(scratch);
     const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
-    // (dead_bits, out_flag and claim_fast were cleared by the binning kernel: launch_pp_bin)
+    // (dead_bits and claim_fast were cleared by the binning kernel: launch_pp_bin)
     const size_t win = ((size_t)1 << wshift) * sizeof(u64);
     const u32 lds_hist = win + (size_t)m * sizeof(u64) <= (size_t)160 * 1024 ? 1u : 0u;  // else: global atomics per first touch
     hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), win + (lds_hist ? (size_t)m * sizeof(u64) : 0), s, assign, load,
-                       n_obj, m, alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, out_flag, aff_life, st, claim_fast,
+                       n_obj, m, alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, aff_life, st, claim_fast,
                        claim_fast + m, lds_hist);
 }
 void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* used, const u64* claim_fast, const DevStats* st,
@@ -4655,9 +4656,9 @@ void launch_pp_win_split(const uint2* vrec, u64 n, u32* out_node, u32* out_flag,
 }
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,
-                          const DevStats* st, hipStream_t s, u32 sa) {
+                          const DevStats* st, hipStream_t s, u32 sa, const uint2* vrec) {
     hipLaunchKernelGGL(k_pp_win_output, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, idx, req, n, vcur, vload, vnext,
-                       alive_bits, cutidx, m, out_node, out_flag, aff_life, st, sa);
+                       alive_bits, cutidx, m, out_node, out_flag, aff_life, st, sa, vrec);
 }
 bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req) {
     // (the windows' rows are only READ here, once and densely: it pays for sparser batches than the CRUD forms' n_obj / 8)

@@ -1423,13 +1423,13 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         *h_bad = 0;
         u32* const h_status = h->h_small + 4 * kSmallBatch;
         *h_status = 0;
-        launch_pp_bin(h->n, h->m, d_idx, d_req, n, (u32*)h->part.p, h->dstats, h->d_cs + h->cs_words + 2, h->stream, h->dead_bits, d_flag,
+        launch_pp_bin(h->n, h->m, d_idx, d_req, n, (u32*)h->part.p, h->dstats, h->d_cs + h->cs_words + 2, h->stream, h->dead_bits,
                       h->pp_claim);
         // The window kernel answers every request it can by itself — sticky hits, first touches on requesters that are active
         // members, later requests of an object — and records what the first touches ask of every requester; when every total
         // fits (k_pp_win_verdict) the answers are final and k_pp_win_split hands them out: no virtual table, no solve.
         launch_pp_win_gather(assign, h->load, h->n, h->m, h->alive_bits, n, (const u32*)h->part.p, (uint2*)h->vrec.p, h->dead_bits,
-                             d_flag, aff_life(h), h->dstats, h->pp_claim, h->stream);
+                             aff_life(h), h->dstats, h->pp_claim, h->stream);
         if (!h->all_alive)  // service.rs:227-237: every object of a dead node a request ran into is un-placed
             launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
         launch_pp_win_verdict(h->m, h->cap, h->alive_bits, h->used, h->pp_claim, h->dstats, h->pp_bad + 1, h->d_small + 4 * kSmallBatch,
@@ -1459,7 +1459,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         launch_resolve(vp, vnt, h->sb, slot_dev(h, 0), h->stream);
         enqueue_slow(h, vp, vtab, vnt, true, false);  // ahead of the verdict: its kernels guard themselves on the device
         launch_pp_win_output(d_idx, d_req, n, vcur, vload, vnext, h->alive_bits, h->sb.cutidx, h->m, d_out, d_flag, aff_life(h), h->dstats,
-                             h->stream, h->sa);
+                             h->stream, h->sa, (const uint2*)h->vrec.p);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         const DevStats v = reduce_slot(h, 0, h->m);

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copy the summaries of one evidence pass (tools/round4_pass.sh <tag>, merged back under gpurun_out/) into profiles/ under
+"""Copy the summaries of one evidence pass (tools/round5_pass.sh <tag> a|b, merged back under gpurun_out/) into profiles/ under
 the round prefix: gpurun_out/ is scratch, profiles/ is tracked.  Usage: collect_profiles.py <tag> [round-prefix]"""
 import glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pre = sys.argv[2] if len(sys.argv) > 2 else "round4"
+pre = sys.argv[2] if len(sys.argv) > 2 else "round5"
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 def cp(a, b):
     a = os.path.join(src, a)
@@ -15,7 +15,8 @@ for name in ("bench_n1.json", "bench_c5.json", "kernel_roofline.json", "kernel_r
              "ops.json", "pytest_gpu.log", "smoke.log", "slowpath_churn.json", "slowpath_contended.json", "slowpath_skew.json",
              "latency.txt", "place_pending.json", "place_pending_timeline.txt", "clean.json",
              "bench_sharded_2ranks_one_gpu.json", "bench_sharded_8ranks_one_gpu.json", "c5_variants.json", "c4_variants.json", "fill_trace.json",
-             "pp_host_batches.txt", "c4_tick.json", "fuzz.json"):
+             "pp_host_batches.txt", "c4_tick.json", "fuzz.json", "pp_sizes.json", "pp_sizes.txt", "pp_mid_timeline.txt",
+             "c_host.json", "c_host_threads.json", "soak_sharded.json"):
     cp("%s_%s" % (tag, name), "%s_%s" % (pre, name))
 cp("crud_ab.json", pre + "_crud_ab.json")
 for f in glob.glob(os.path.join(src, tag + "_prof", "*kernel_stats.csv")):

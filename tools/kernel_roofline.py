@@ -70,17 +70,20 @@ def specs(pending_rows):
         ("crud", r"k_clean", "k_clean (10 % of the nodes)", 4 * N + 4 * N // 10, "4 B/row read + 4 B per evicted row"),
         ("clean1", r"k_clean", "k_clean (one node)", 4 * N, "4 B/row read (+4 B per evicted row: 0.1 %)"),
         ("pp", r"k_part_bin<true>", "k_part_bin (place_pending, 1 M requests)", 16 * 1000000, "idx + requester in, one 8-byte record out per request"),
-        ("pp", r"k_pp_win_gather", "k_pp_win_gather (1 M requests)", 20 * 1000000 + 8 * N, "record in + virtual row out + the first touch's dense write per request; the windows' assignment and load columns once"),
-        ("pp", r"k_scan<true, true, 1, 3", "k_scan<VIRT> (1 M requests)", 24 * 1000000, "8-byte record + requester in, the two columns + the decision out per virtual row"),
-        ("pp", r"k_pp_win_output", "k_pp_win_output (1 M requests)", 28 * 1000000, "five columns in, node + flag out"),
+        ("pp", r"k_pp_win_gather", "k_pp_win_gather (1 M requests)", 20 * 1000000 + 8 * N, "record in + answer record out + the first touch's dense write per request; the windows' assignment and load columns once"),
+        ("pp", r"k_pp_win_split", "k_pp_win_split (1 M requests)", 16 * 1000000, "answer record in, node + flag out"),
         ("pp10", r"k_part_bin<true>", "k_part_bin (place_pending, 10 M requests)", 16 * 10000000, "idx + requester in, one 8-byte record out per request"),
-        ("pp10", r"k_pp_win_gather", "k_pp_win_gather (10 M requests)", 20 * 10000000 + 8 * N, "record in + virtual row out + the first touch's dense write per request; the windows' assignment and load columns once"),
-        ("pp10", r"k_scan<true, true, 1, 3", "k_scan<VIRT> (10 M requests)", 24 * 10000000, "8-byte record + requester in, the two columns + the decision out per virtual row"),
-        ("pp10", r"k_pp_win_output", "k_pp_win_output (10 M requests)", 28 * 10000000, "five columns in, node + flag out"),
+        ("pp10", r"k_pp_win_gather", "k_pp_win_gather (10 M requests)", 20 * 10000000 + 8 * N, "record in + answer record out + the first touch's dense write per request; the windows' assignment and load columns once"),
+        ("pp10", r"k_pp_win_verdict", "k_pp_win_verdict (10 M requests)", 24 * M, "claim, cap, used per requester"),
+        ("pp10", r"k_pp_win_split", "k_pp_win_split (10 M requests)", 16 * 10000000, "answer record in, node + flag out"),
+        ("pp_mid", r"k_ppm_first", "k_ppm_first (16 384 device-resident requests)", 12 * 16384, "idx + requester in, the election word"),
+        ("pp_mid", r"k_ppm_gather", "k_ppm_gather (16 384 requests)", 24 * 16384, "idx in, election word + row + load gathered, three columns out"),
+        ("pp_mid", r"k_scan<true, true, 1, 0", "k_scan<VIRT> (16 384 requests)", 16 * 16384, "three columns in, the decision out"),
+        ("pp_mid", r"k_ppm_output", "k_ppm_output (16 384 requests)", 28 * 16384, "five columns in, node + flag out, the first touches into the table"),
         ("pp_small", r"k_pp_stage", "k_pp_stage (4 096 host-buffer requests: requests + rows -> staging table)", 12 * 4096, "idx + requester in over PCIe, the rows"),
         ("pp_small", r"k_pp_decide", "k_pp_decide (one workgroup: the decision over the staged records)", 40 * 4096, "32 B staged record in, 8 B result out"),
         ("pp_small", r"k_pp_apply", "k_pp_apply (results out over PCIe, first touches into the column)", 16 * 4096, "8 B result in, node + flag out"),
-        ("pp_1000", r"k_pp_one<1024, 4>", "k_pp_one (1 000 host-buffer requests, one launch)", 28 * 1000, "idx + requester in over PCIe, node + flag out, the rows"),
+        ("pp_256", r"k_pp_one<256, 1>", "k_pp_one (256 host-buffer requests, one launch)", 28 * 256, "idx + requester in over PCIe, node + flag out, the rows"),
     ]
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """place_pending rates: device-resident batches of 1 M / 10 M requests over the cold 10 M x 1 024 table (HIP events on the
-library's stream), host-buffer batches of 1 .. 4 096 requests (wall clock per call)."""
+library's stream).  Smaller batches: tools/pp_sizes.py."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
@@ -37,16 +37,7 @@ for rep in range(3):
     ts.append(g.timer_end() * 1e-3)
 t = float(np.mean(ts[1:]))
 out["dev_10M_sticky"] = {"us": t * 1e6, "req_per_s": n / t, "frac": 28 * n / t / 1e9 / 8000}
-for k in (1, 256, 1000, 4096):
-    ii, rq = perm[:k].copy(), reqp[:k].copy()
-    g.set_assign(none); g.get_nodes()
-    g.place_pending(ii, rq)          # first touch
-    t0 = time.perf_counter()
-    for rep in range(200):
-        g.place_pending(ii, rq)      # sticky hits
-    t = (time.perf_counter() - t0) / 200
-    g.set_assign(none); g.get_nodes(); g.sync()
-    t1 = time.perf_counter(); g.place_pending(ii, rq); tf = time.perf_counter() - t1
-    out["host_%d" % k] = {"us_sticky": t * 1e6, "req_per_s_sticky": k / t, "us_first_touch": tf * 1e6, "req_per_s_first_touch": k / tf}
+# (batches of 1 .. 262 143 requests, host buffers and device-resident, first touch and sticky over >= 50 warmed calls each:
+#  tools/pp_sizes.py — one method for every size)
 print(json.dumps(out))
 g.close()

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """One PHASE of the hot path per process, for the rocprofv3 passes of tools/kernel_roofline.sh (kernel trace + the two PMC
 passes): every kernel DESIGN.md section 4 names runs in exactly one phase with known algorithmic bytes, so that its
-duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round4_kernel_roofline.json).
-Usage: roofline_workload.py <fast|churn|churn_noinc|churn_unpacked|contended|contended_packed|crud|crud_plain|lookup_seq|clean1|pp|pp10|pp_small|probes> [reps]"""
+duration, its algorithmic bytes and its counter bytes can be put side by side (profiles/round5_kernel_roofline.json).
+Usage: roofline_workload.py <fast|churn|churn_noinc|churn_unpacked|contended|contended_packed|crud|crud_plain|lookup_seq|clean1|pp|pp10|pp_small|pp_256|pp_mid|probes> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -41,7 +41,7 @@ elif phase in ("contended", "contended_packed"):   # the same fix-up kernels ove
     g.set_compact("auto", cut_pack="always" if phase == "contended_packed" else "never")
     for _ in range(reps):
         g.solve()
-elif phase in ("crud", "crud_plain", "pp", "pp10", "pp_small", "pp_1000", "clean1", "lookup_seq"):
+elif phase in ("crud", "crud_plain", "pp", "pp10", "pp_small", "pp_256", "pp_mid", "clean1", "lookup_seq"):
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from hipbuf import DevBuf
@@ -73,13 +73,17 @@ elif phase in ("crud", "crud_plain", "pp", "pp10", "pp_small", "pp_1000", "clean
             g.set_assign(synth.warm_assign(n, m))
             g.get_nodes()
             g.clean_server(3 + k)
-    elif phase in ("pp_small", "pp_1000"):   # 4 096 requests (three launches) / 1 000 (k_pp_one) from host buffers, first touch then sticky
-        kk = 4096 if phase == "pp_small" else 1000
+    elif phase in ("pp_small", "pp_256"):   # 4 096 requests (three launches) / 256 (k_pp_one, one launch) from host buffers, first touch then sticky
+        kk = 4096 if phase == "pp_small" else 256
         ii = (synth.r(np.arange(kk, dtype=np.uint64), 7) % np.uint64(n)).astype(np.uint32)
         rq = cfg["aff"][ii]
         for _ in range(reps):
             g.place_pending(ii, rq)
-    else:                                # the window-sorted request path + the virtual-table solve, 1 M / 10 M requests on a cold table
+    elif phase == "pp_mid":              # 16 384 device-resident requests: the general path (k_ppm_first / gather / solve / output)
+        for r in range(reps):
+            off = 4 * 16384 * r
+            L.rio_gp_place_pending_dev(h, 16384, vp(idx.ptr + off), vp(node.ptr + off), vp(outb.ptr), vp(flg.ptr))
+    else:                                # the window-sorted request path (answers from the window kernel), 1 M / 10 M requests on a cold table
         k = 10_000_000 if phase == "pp10" else 1_000_000
         for _ in range(3):
             g.set_assign(np.full(n, 0xFFFFFFFF, np.uint32))
