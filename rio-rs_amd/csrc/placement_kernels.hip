@@ -3056,15 +3056,52 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
     const u64 base = (u64)b << wshift;
-    RIOGP_PART_DESCRIPTORS()
     for (u32 r = tid; r < W; r += kBlock) wfirst[r] = ~0ull;
     if (lds_hist)
         for (u32 j = tid; j < m; j += kBlock) hist[j] = 0;
     __syncthreads();
-    // the first request of every row decides: ds_min_u64 on {position | requester} (one walk gives both)
-    part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) {
-        atomicMin(&wfirst[x.x & (W - 1)], ((u64)x.y << 32) | (u64)(x.x >> kPartShiftMax));
-    });
+    // The first request of every row decides: ds_min_u64 on {position | requester} (one walk gives both).  The records this
+    // lane reads — one per piece, up to kPartIters of them — STAY IN REGISTERS for the answers of the later requests further
+    // down: a second walk over the sorted records (what round 4 did) reads the 80 MB again, in ~13-record pieces, 50 of this
+    // kernel's 230 us at 10 M requests.  Only the records past a piece's first sixteen (a fifth of the pieces have some) are
+    // read twice.
+    uint2 xr[kPartIters];
+    bool tail = false;  // some piece of this lane holds more than 16 records
+    constexpr int kGrp = 8;  // pieces per lane whose descriptors, then records, are in flight together (the descriptors die with
+                             // their group: all 32 next to the 32 records would not fit the register file)
+    auto piece = [&](u32 i, u32& pb, u32& pc) {  // piece i of this quarter wave: first record and record count
+        const u32 f = i * 64u + (u32)wave * 4u + (u32)(lane >> 4);
+        const bool in = f < nchunks;
+        const u32 s0 = in ? start16[(size_t)b * nchunks + f] : 0u;
+        const u32 s1 = in ? start16[(size_t)(b + 1) * nchunks + f] : 0u;
+        pb = f * kPartSub + s0;
+        pc = s1 - s0;
+    };
+#pragma unroll
+    for (int i = 0; i < kPartIters; i += kGrp) {
+        u32 pb[kGrp], pc[kGrp];
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) piece((u32)(i + q), pb[q], pc[q]);
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) {
+            xr[i + q] = o16 < pc[q] ? rec2[pb[q] + o16] : make_uint2(0u, kNone);
+            tail |= pc[q] > 16u;
+        }
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q)
+            if (xr[i + q].y != kNone) atomicMin(&wfirst[xr[i + q].x & (W - 1)], ((u64)xr[i + q].y << 32) | (u64)(xr[i + q].x >> kPartShiftMax));
+    }
+    if (__ballot(tail)) {  // (wave-uniform) the pieces' records past their first sixteen
+#pragma unroll 1
+        for (u32 i = 0; i < (u32)kPartIters; ++i) {
+            u32 pb, pc;
+            piece(i, pb, pc);
+            for (u32 o = 16u + o16; o < pc; o += 16u) {
+                const uint2 x = rec2[pb + o];
+                atomicMin(&wfirst[x.x & (W - 1)], ((u64)x.y << 32) | (u64)(x.x >> kPartShiftMax));
+            }
+        }
+    }
     __syncthreads();
     // The requested rows of the window, in row order, read ONCE and densely.  Each gets its answer: sticky (the node it is on),
     // or — pending: unplaced, or found on a dead node — its first requester when that one is an active member: written into
@@ -3115,12 +3152,23 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
     }
     __syncthreads();
     // later requests of an object observe the first's (LOCAL / REDIRECT, or UNPLACED): their record carries the answer and
-    // the position of the first
-    part_walk(rec2, pbase, pcnt, o16, [&](const uint2 x) {
+    // the position of the first — out of the records held in registers
+    auto later = [&](const uint2 x) {
         const u64 e = wfirst[x.x & (W - 1)];
         const u32 k = x.y, f = (u32)(e >> 32), nd = (u32)e, rq = x.x >> kPartShiftMax;
         if (f != k) vrec[k] = make_uint2(pp_ans(nd, nd == kNone ? 4u : (nd == rq ? 0u : 1u), true), f);
-    });
+    };
+#pragma unroll
+    for (int i = 0; i < kPartIters; ++i)
+        if (xr[i].y != kNone) later(xr[i]);
+    if (__ballot(tail)) {  // the pieces' records past their first sixteen: descriptors again (two u16 reads a piece), then the records
+#pragma unroll 1
+        for (u32 i = 0; i < (u32)kPartIters; ++i) {
+            u32 pb, pc;
+            piece(i, pb, pc);
+            for (u32 o = 16u + o16; o < pc; o += 16u) later(rec2[pb + o]);
+        }
+    }
     if (lds_hist)
         for (u32 j = tid; j < m; j += kBlock)
             if (hist[j]) atomicAdd(&claim[j], hist[j]);
