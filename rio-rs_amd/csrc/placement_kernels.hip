@@ -3468,7 +3468,8 @@ __global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assig
                                                    const u32* __restrict__ alive_bits, const u32* __restrict__ idx,
                                                    const u32* __restrict__ req, u64 n, u32* __restrict__ pos,
                                                    u32* __restrict__ s_idx, u32* __restrict__ s_req,
-                                                   u32* __restrict__ dead_bits, u32* __restrict__ vflag, u32* __restrict__ bad) {
+                                                   u32* __restrict__ dead_bits, u32* __restrict__ vflag, u32* __restrict__ bad,
+                                                   const u32 vec) {  // vec: every array is 16-byte aligned (else one entry per lane)
     // s_idx / s_req (host_io): idx / req are mapped host memory, read ONCE here, 16 bytes per lane, and left in device memory
     // for the kernels behind; dead_bits / vflag (some node is not alive): RIO_GP_FLAG_REPLACED for a request that finds its
     // object on a dead node, 0 otherwise — the output kernel keeps the bit for the FIRST request of the object (service.rs:268-285)
@@ -3482,7 +3483,7 @@ __global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assig
         if (dead) atomicOr(&dead_bits[c >> 5], 1u << (c & 31));
         return dead ? kFlagReplaced : 0u;
     };
-    const u64 nvec = n >> 2, stride = (u64)gridDim.x * 256;
+    const u64 nvec = vec ? n >> 2 : 0, stride = (u64)gridDim.x * 256;
     for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
         const uint4 iv = *reinterpret_cast<const uint4*>(idx + 4 * v), rv = *reinterpret_cast<const uint4*>(req + 4 * v);
         if (s_idx) { *reinterpret_cast<uint4*>(s_idx + 4 * v) = iv; *reinterpret_cast<uint4*>(s_req + 4 * v) = rv; }
@@ -3491,8 +3492,7 @@ __global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assig
         f.z = one(4 * v + 2, iv.z, rv.z); f.w = one(4 * v + 3, iv.w, rv.w);
         if (dead_bits) *reinterpret_cast<uint4*>(vflag + 4 * v) = f;
     }
-    const u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x;  // ragged tail (< 4 entries)
-    if (k < n) {
+    for (u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {  // ragged tail, or arrays that are not aligned
         const u32 i = idx[k], r = req[k];
         if (s_idx) { s_idx[k] = i; s_req[k] = r; }
         const u32 f = one(k, i, r);
@@ -3504,9 +3504,9 @@ __global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assig
 __global__ __launch_bounds__(256) void k_ppm_gather(const u32* __restrict__ assign, const u32* __restrict__ load,
                                                     const u32* __restrict__ idx, u64 n, const u32* __restrict__ pos,
                                                     u32* __restrict__ vcur, u32* __restrict__ vload, u32* __restrict__ vfirst,
-                                                    const u32* __restrict__ bad) {
+                                                    const u32* __restrict__ bad, const u32 vec) {
     if (*bad) return;  // (every entry is valid from here on)
-    const u64 nvec = n >> 2, stride = (u64)gridDim.x * 256;
+    const u64 nvec = vec ? n >> 2 : 0, stride = (u64)gridDim.x * 256;
     for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
         const uint4 iv = *reinterpret_cast<const uint4*>(idx + 4 * v);
         // twelve independent gathers in flight per lane before the first is used
@@ -3519,8 +3519,7 @@ __global__ __launch_bounds__(256) void k_ppm_gather(const u32* __restrict__ assi
                                                              p2 == k0 + 2 ? a2 : kSkipMark, p3 == k0 + 3 ? a3 : kSkipMark);
         *reinterpret_cast<uint4*>(vload + 4 * v) = lv;
     }
-    const u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x;
-    if (k < n) {
+    for (u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
         const u32 i = idx[k], f = pos[i];
         vfirst[k] = f;
         vcur[k] = f == (u32)k ? assign[i] : kSkipMark;
@@ -3533,7 +3532,7 @@ struct PpmOutArgs {
     const u32* vcur; const u32* vnext; const u32* vfirst; const u32* vflag;  // vflag: nullptr when every node is alive
     u32* pos; const u32* alive_bits; const u32* cutidx; u32 m; u32 sa;
     u32* out_node; u32* out_flag; u32* aff_life;
-    u32* bad; const DevStats* stats; const u32* bsp_cnt; u32 G; u32 fixup_done;
+    u32* bad; const DevStats* stats; const u32* bsp_cnt; u32 G; u32 fixup_done; u32 vec;
     u32* status; unsigned int* ticket; u32* done; u32 seq;
 };
 __global__ __launch_bounds__(256) void k_ppm_output(const PpmOutArgs a) {
@@ -3577,7 +3576,7 @@ __global__ __launch_bounds__(256) void k_ppm_output(const PpmOutArgs a) {
             nd_out = nd;
             return fl;
         };
-        const u64 nvec = a.n >> 2;
+        const u64 nvec = a.vec ? a.n >> 2 : 0;
         for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
             const uint4 iv = *reinterpret_cast<const uint4*>(a.idx + 4 * v), rv = *reinterpret_cast<const uint4*>(a.req + 4 * v);
             const uint4 fv = *reinterpret_cast<const uint4*>(a.vfirst + 4 * v);
@@ -3587,8 +3586,7 @@ __global__ __launch_bounds__(256) void k_ppm_output(const PpmOutArgs a) {
             *reinterpret_cast<uint4*>(a.out_node + 4 * v) = on;
             if (a.out_flag) *reinterpret_cast<uint4*>(a.out_flag + 4 * v) = of;
         }
-        const u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x;
-        if (k < a.n) {
+        for (u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x; k < a.n; k += stride) {
             u32 nd;
             const u32 fl = one(k, a.idx[k], a.req[k], a.vfirst[k], nd);
             a.out_node[k] = nd;
@@ -4779,16 +4777,21 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
                            used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk, trace_flag(), sa);
     }
 }
+// every non-null pointer is 16-byte aligned (the kernels' dwordx4 paths; a caller's device arrays may start anywhere)
+template <typename... P>
+static inline bool aligned16(P... p) { return ((... | reinterpret_cast<uintptr_t>(p)) & 15u) == 0; }
 void launch_ppm_first(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req, u64 n,
                       u32* pos, u32* s_idx, u32* s_req, u32* dead_bits, u32* vflag, u32* bad, hipStream_t s) {
     if (dead_bits) (void)hipMemsetAsync(dead_bits, 0, (size_t)((m + 31) / 32) * sizeof(u32), s);
-    hipLaunchKernelGGL(k_ppm_first, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, alive_bits, idx, req,
-                       n, pos, s_idx, s_req, dead_bits, vflag, bad);
+    const u32 vec = aligned16(idx, req, s_idx, s_req, vflag) ? 1u : 0u;
+    hipLaunchKernelGGL(k_ppm_first, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 4096)), dim3(256), 0, s, assign, n_obj, m, alive_bits, idx, req,
+                       n, pos, s_idx, s_req, dead_bits, vflag, bad, vec);
 }
 void launch_ppm_gather(const u32* assign, const u32* load, const u32* idx, u64 n, const u32* pos, u32* vcur, u32* vload,
                        u32* vfirst, const u32* bad, hipStream_t s) {
-    hipLaunchKernelGGL(k_ppm_gather, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, assign, load, idx, n, pos, vcur,
-                       vload, vfirst, bad);
+    const u32 vec = aligned16(idx, vcur, vload, vfirst) ? 1u : 0u;
+    hipLaunchKernelGGL(k_ppm_gather, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 4096)), dim3(256), 0, s, assign, load, idx, n, pos, vcur,
+                       vload, vfirst, bad, vec);
 }
 void launch_ppm_output(u32* assign, u64 n_obj, const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vnext,
                        const u32* vfirst, const u32* vflag, u32* pos, const u32* alive_bits, const SolveBufs& b, const Plan& vp,
@@ -4801,7 +4804,8 @@ void launch_ppm_output(u32* assign, u64 n_obj, const u32* idx, const u32* req, u
     a.out_node = out_node; a.out_flag = out_flag; a.aff_life = aff_life;
     a.bad = bad; a.stats = b.stats; a.bsp_cnt = b.bsp_cnt[0]; a.G = vp.G; a.fixup_done = fixup_done ? 1u : 0u;
     a.status = status; a.ticket = ticket; a.done = done; a.seq = seq;
-    hipLaunchKernelGGL(k_ppm_output, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, s, a);
+    a.vec = aligned16(idx, req, vfirst, out_node, out_flag) ? 1u : 0u;
+    hipLaunchKernelGGL(k_ppm_output, dim3(grid_for(a.vec ? (n + 3) / 4 : n, 256, 4096)), dim3(256), 0, s, a);
 }
 
 void launch_shard_pack1(const Plan& p, const SolveBufs& b, u64* X, hipStream_t s) {

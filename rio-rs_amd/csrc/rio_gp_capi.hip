@@ -1410,7 +1410,8 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     h->sb.fx = FxRows{};  // nobody reads the fix-up counters of the virtual-table solve: plain DevStats atomics, no pinned slot touched
     if ((rc = ensure_used(h))) return rc;
     const char* const who = dev_api ? "rio_gp_place_pending_dev" : "rio_gp_place_pending";
-    if (h->part_mode != 2 && !host_io && pp_win_applicable(h->n, n, d_idx, d_req)) {
+    if (h->part_mode != 2 && !host_io && pp_win_applicable(h->n, n, d_idx, d_req) &&
+        (((uintptr_t)d_out | (uintptr_t)d_flag) & 15u) == 0) {  // (its output kernels store whole vectors)
         // Big batch: sorted by row window once, the row-side step out of LDS (k_pp_win_gather), the decisions written into the
         // real column by the solve itself: two random accesses per request instead of nine.  The entries are validated by the
         // binning kernel, which changes nothing.

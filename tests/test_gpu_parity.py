@@ -1158,6 +1158,39 @@ def test_place_pending_general_path_no_host_round_trip(gp, oracle, speculate):
     g.close()
 
 
+def test_place_pending_dev_arrays_that_are_not_16_byte_aligned(gp, oracle):
+    """A caller's device arrays may start anywhere (4-byte aligned): the one-workgroup kernel, the general path's dwordx4
+    loops and the window-sorted form's whole-vector stores all step aside for arrays that are not 16-byte aligned — same
+    answers, every batch-size regime."""
+    from hipbuf import DevBuf
+    rng = np.random.default_rng(4242)
+    n, m = 400_000, 64
+    load = rng.integers(0, 20, n).astype(np.uint32)
+    cap = np.full(m, int(load.sum() // m // 2), np.uint64)
+    alive = np.ones(m, np.uint8)
+    alive[[3, 50]] = 0
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    used = np.zeros(m, np.uint64)
+    for step, (k, off) in enumerate(((700, 1), (4096, 3), (5001, 1), (70_000, 2), (300_000, 1), (300_001, 3))):
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        req = rng.integers(0, m, k).astype(np.uint32)
+        pad = np.zeros(off, np.uint32)
+        d_idx, d_req = DevBuf(np.concatenate([pad, idx])), DevBuf(np.concatenate([pad, req]))
+        d_node, d_flag = DevBuf(nbytes=4 * (k + off)), DevBuf(nbytes=4 * (k + off))
+        sh = 4 * off
+        g.place_pending_dev(k, d_idx.ptr + sh, d_req.ptr + sh, d_node.ptr + sh, d_flag.ptr + sh)
+        wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
+        assert np.array_equal(d_node.to_host()[off:], wnode), (step, k)
+        assert np.array_equal(d_flag.to_host()[off:], wflag), (step, k)
+        assert np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], used), (step, k)
+        for x in (d_idx, d_req, d_node, d_flag):
+            x.free()
+    g.close()
+
+
 def test_place_pending_dev_small_batches_one_launch(gp, oracle):
     """Device-resident batches of up to 4 096 requests go through the one-workgroup kernel first, reading the caller's
     arrays in place: sizes that are not multiples of four (no vector past the end of an exact-size array), duplicates, a
