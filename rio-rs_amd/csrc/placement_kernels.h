@@ -279,7 +279,8 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
                    void* stage = nullptr, unsigned int* ticket = nullptr, u32 sa = 0, bool host_io = false);
 // --- place_pending, the general request path (k_ppm_first / k_ppm_gather / solve of the virtual table / k_ppm_output) ---
 // bad: device word, 0 between calls (raised by k_ppm_first on an invalid entry, put back by k_ppm_output's last workgroup);
-// s_idx / s_req != nullptr: idx / req are mapped HOST memory, copied to these device arrays on the way (use them afterwards);
+// s_idx / s_req: the library's padded device copies of the requests, written on the way (use THEM afterwards: idx / req may be
+// mapped host memory, or a caller's exact-size device arrays the solve's tile-wide reads must not run past);
 // dead_bits / vflag != nullptr: some node is not alive — nodes that requests run into are marked, REPLACED bits per request
 void launch_ppm_first(const u32* assign, u64 n_obj, u32 m, const u32* alive_bits, const u32* idx, const u32* req, u64 n,
                       u32* pos_scratch, u32* s_idx, u32* s_req, u32* dead_bits, u32* vflag, u32* bad, hipStream_t s);

@@ -3470,8 +3470,8 @@ __global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assig
                                                    u32* __restrict__ s_idx, u32* __restrict__ s_req,
                                                    u32* __restrict__ dead_bits, u32* __restrict__ vflag, u32* __restrict__ bad,
                                                    const u32 vec) {  // vec: every array is 16-byte aligned (else one entry per lane)
-    // s_idx / s_req (host_io): idx / req are mapped host memory, read ONCE here, 16 bytes per lane, and left in device memory
-    // for the kernels behind; dead_bits / vflag (some node is not alive): RIO_GP_FLAG_REPLACED for a request that finds its
+    // s_idx / s_req: the requests are read ONCE here, 16 bytes per lane (they may live in mapped host memory), and left in the
+    // library's own padded device arrays for the kernels behind; dead_bits / vflag (some node is not alive): RIO_GP_FLAG_REPLACED for a request that finds its
     // object on a dead node, 0 otherwise — the output kernel keeps the bit for the FIRST request of the object (service.rs:268-285)
     u32 nbad = 0;
     auto one = [&](u64 k, u32 i, u32 r) -> u32 {
@@ -3486,7 +3486,8 @@ __global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assig
     const u64 nvec = vec ? n >> 2 : 0, stride = (u64)gridDim.x * 256;
     for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
         const uint4 iv = *reinterpret_cast<const uint4*>(idx + 4 * v), rv = *reinterpret_cast<const uint4*>(req + 4 * v);
-        if (s_idx) { *reinterpret_cast<uint4*>(s_idx + 4 * v) = iv; *reinterpret_cast<uint4*>(s_req + 4 * v) = rv; }
+        *reinterpret_cast<uint4*>(s_idx + 4 * v) = iv;
+        *reinterpret_cast<uint4*>(s_req + 4 * v) = rv;
         uint4 f;
         f.x = one(4 * v + 0, iv.x, rv.x); f.y = one(4 * v + 1, iv.y, rv.y);
         f.z = one(4 * v + 2, iv.z, rv.z); f.w = one(4 * v + 3, iv.w, rv.w);
@@ -3494,7 +3495,8 @@ __global__ __launch_bounds__(256) void k_ppm_first(const u32* __restrict__ assig
     }
     for (u64 k = nvec * 4 + (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {  // ragged tail, or arrays that are not aligned
         const u32 i = idx[k], r = req[k];
-        if (s_idx) { s_idx[k] = i; s_req[k] = r; }
+        s_idx[k] = i;
+        s_req[k] = r;
         const u32 f = one(k, i, r);
         if (dead_bits) vflag[k] = f;
     }

@@ -1445,7 +1445,13 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         }
         if (*h_status != 2) return fail(h, RIO_GP_EUPSTREAM, std::string(who) + ": the window kernels left no verdict");
         // The batch needs the solve (a requester would run full, a dead node was in the way, a requester is not an active
-        // member): over the same records, the window kernel's placements standing as the optimistic ones.
+        // member): over the same records, the window kernel's placements standing as the optimistic ones.  The solve's kernels
+        // read whole tiles of the object and requester columns: they get padded copies (the caller's arrays end where they end).
+        if ((rc = ensure(h, h->stage[0], bytes)) || (rc = ensure(h, h->stage[1], bytes))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->stage[0].p, d_idx, bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->stage[1].p, d_req, bytes, hipMemcpyDeviceToDevice, h->stream));
+        d_idx = (const u32*)h->stage[0].p;
+        d_req = (const u32*)h->stage[1].p;
         Plan vp = hplan(h, n);
         const u64 seq = ++h->wait_seq;
         vp.mark = seq;
@@ -1471,12 +1477,13 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         h->have_solved = false; ++h->mut_epoch;
         return RIO_GP_OK;
     }
-    // device copies of requests that live in mapped host memory; the REPLACED bits of requests that ran into a dead node
+    // The library's own (padded) copies of the requests, made by the first kernel on its way: requests in mapped host memory
+    // are read over PCIe once — and a caller's device arrays end where they end, while the solve's kernels read whole tiles
+    // (the requesters are the affinity column of the virtual table): past the end of an exact-size array that is somebody
+    // else's page (found by the fuzz: a memory access fault at sizes a few hundred bytes short of a page).
     u32 *s_idx = nullptr, *s_req = nullptr, *vflag = nullptr;
-    if (host_io) {
-        if ((rc = ensure(h, h->stage[0], bytes)) || (rc = ensure(h, h->stage[1], bytes))) return rc;
-        s_idx = (u32*)h->stage[0].p; s_req = (u32*)h->stage[1].p;
-    }
+    if ((rc = ensure(h, h->stage[0], bytes)) || (rc = ensure(h, h->stage[1], bytes))) return rc;
+    s_idx = (u32*)h->stage[0].p; s_req = (u32*)h->stage[1].p;
     const bool mark = !h->all_alive;  // (1) service.rs:227-237 — requested rows on dead nodes trigger clean_server of those nodes
     if (mark) {
         if ((rc = ensure(h, h->stage[2], bytes))) return rc;
@@ -1487,8 +1494,9 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     *h_status = 2;  // neither 0, 1 nor 3: the output kernel must write it
     launch_ppm_first(assign, h->n, h->m, h->alive_bits, d_idx, d_req, n, h->pos, s_idx, s_req, mark ? h->dead_bits : nullptr, vflag,
                      h->pp_bad, h->stream);
-    const u32* const k_idx = host_io ? s_idx : d_idx;
-    const u32* const k_req = host_io ? s_req : d_req;
+    const u32* const k_idx = s_idx;
+    const u32* const k_req = s_req;
+    (void)host_io;
     if (mark) launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h), 0, h->pp_bad);
     // (2)(3) the virtual table (rows = requests): the first request per row decides
     launch_ppm_gather(assign, h->load, k_idx, n, h->pos, vcur, vload, vaff /* position of the row's first request */, h->pp_bad, h->stream);

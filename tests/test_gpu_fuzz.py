@@ -9,7 +9,7 @@ affinities / capacities.  A second kind of scenario drives the ROW-SHARDED solve
 boundaries with empty shards, streams of committed ticks with liveness changes) against the whole-table oracle.  The fix-up policies the product picks adaptively are also forced through the lab build's knobs, by
 seed.  The seeds are fixed: a failure names the seed and the operation.
 
-    python tests/test_gpu_fuzz.py <seconds> [first_seed]     # a longer campaign (tools/round4_pass.sh runs one)
+    python tests/test_gpu_fuzz.py <seconds> [first_seed]     # a longer campaign (tools/round5_pass.sh runs one)
 """
 import os
 import sys
@@ -25,7 +25,7 @@ AFF_INACTIVE = 0xFFFFFFFE
 INF = 0xFFFFFFFFFFFFFFFF
 
 _SIZES = (1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 16383, 16384, 16385, 65536, 262143, 262144, 262145)
-_BATCHES = (1, 2, 4, 5, 255, 256, 257, 1000, 1024, 1025, 4095, 4096, 4097, 20000)
+_BATCHES = (1, 2, 4, 5, 255, 256, 257, 1000, 1024, 1025, 4095, 4096, 4097, 20000, 65535, 65536, 65537, 131072)
 
 
 def _pick(rng, table, hi):
@@ -152,7 +152,7 @@ class Scenario:
     def _idx(self, k=None, big_ok=True):
         rng, n = self.rng, self.n
         if k is None:
-            k = _pick(rng, _BATCHES, 20000)
+            k = _pick(rng, _BATCHES, 140000 if n >= 20000 else 20000)
             if big_ok and n >= 20000 and rng.random() < 0.2:
                 k = int(rng.integers(262144, 600000))     # the window-sorted forms
                 self.count["batches >= 2^18"] = self.count.get("batches >= 2^18", 0) + 1
@@ -200,7 +200,20 @@ class Scenario:
         if self.rng.random() < 0.3:
             req[:] = int(self.rng.integers(self.m))
         used = self.oracle.recompute_used(self.ref, self.load, self.m)
-        node, flag = self.g.place_pending(idx, req)
+        if self.rng.random() < 0.3:   # the same call over device-resident arrays (validated on the device; sometimes not 16-byte aligned)
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+            from hipbuf import DevBuf
+            off = int(self.rng.integers(0, 2)) * int(self.rng.integers(1, 4))
+            pad = np.zeros(off, np.uint32)
+            d_idx, d_req = DevBuf(np.concatenate([pad, idx])), DevBuf(np.concatenate([pad, req]))
+            d_node, d_flag = DevBuf(nbytes=4 * (idx.size + off)), DevBuf(nbytes=4 * (idx.size + off))
+            self.g.place_pending_dev(idx.size, d_idx.ptr + 4 * off, d_req.ptr + 4 * off, d_node.ptr + 4 * off, d_flag.ptr + 4 * off)
+            node, flag = d_node.to_host()[off:], d_flag.to_host()[off:]
+            for x in (d_idx, d_req, d_node, d_flag):
+                x.free()
+            self.count["place_dev"] = self.count.get("place_dev", 0) + 1
+        else:
+            node, flag = self.g.place_pending(idx, req)
         wnode, wflag = self.oracle.place_pending(self.ref, self.load, self.cap, self.alive, used, idx, req, self.rounds, self.oflags)
         bad = np.flatnonzero((node != wnode) | (flag != wflag))
         assert bad.size == 0, (self.seed, "place_pending", self.log[-6:], idx.size, bad[:8], node[bad[:8]], wnode[bad[:8]], flag[bad[:8]], wflag[bad[:8]])
