@@ -3760,7 +3760,7 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
 // on such a batch is not the decision: of the 38 us of a 4 096-request first-touch batch 21 go into reading the requests
 // over PCIe and gathering every request's row and node operands from ONE compute unit (sixteen thousand random lane-requests
 // through one texture path), 10 into draining 8 192 scattered stores and atomics and the results' PCIe writes behind one
-// fence (its own phase stamps: tools/pp_one_trace.py).  Both ends are spread over the chip here, the decision stays where
+// fence (its own phase stamps, round 4: profiles/archive/round4_pp_host_batches.txt).  Both ends are spread over the chip here, the decision stays where
 // it was — one workgroup, one LDS table, no cross-workgroup protocol (kernel boundaries order the three):
 //   k_pp_stage   256 threads x 1 request: request (mapped host or device memory) -> {row, requester, cur, load | free
 //                capacity of the requester, its liveness} in a device staging table; an entry out of range raises the flag
@@ -4755,7 +4755,7 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
     // Three launches (stage | decide | apply) when the requests and results are mapped HOST memory and the batch is beyond the
     // small kernel's 256: the one-workgroup kernel reads them over PCIe from ONE compute unit.  Same run, us per call,
     // one workgroup -> three launches: 300 requests 26-28 -> 24.7-24.9, 1 000: 28.3-33 -> 25.2-26, 1 024: 28.5-33 -> 24.8-26.4
-    // (tools/pp_staged_ab.py).  Device-resident requests (_dev) stay with the single launch up to 1 024.
+    // (round 4's A/B: profiles/archive/round4_pp_staged_ab.json).  Device-resident requests (_dev) stay with the single launch up to 1 024.
     if (stage && ticket && done && n > (u32)(host_io ? g_pp_staged_from : kOneBatch / 4) && m <= kPpTot) {
         uint4* rec = static_cast<uint4*>(stage);
         uint4* rec2 = rec + kOneBatch;
