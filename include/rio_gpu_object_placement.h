@@ -40,11 +40,11 @@ typedef struct rio_op_cfg {
                             * RIO_GP_CFG_REF_SELF_ASSIGN; that bit is accepted here and changes nothing).
                             * RIO_OP_CFG_LIVE_FIRST_TOUCH opts OUT: a requester that membership marks inactive is not a
                             * placement target, its first touches go to the water-fill (the capacity-aware extension) */
-    uint32_t collect_ns;   /* single-object calls that need the device share round trips (flat combining): how long a thread that
-                            * takes over the device waits for more callers to publish before it takes its batch, in ns, when the
-                            * batch before was shared; 0 = the default (RIO_OP_DEFAULT_COLLECT_NS), 1 = do not wait */
+    uint32_t collect_ns;   /* single-object calls that need the device share round trips (flat combining): how long, at most, a
+                            * thread that takes over the device waits until about as many callers have published as the last two
+                            * batches carried together, in ns; 0 = the default (RIO_OP_DEFAULT_COLLECT_NS), 1 = do not wait */
 } rio_op_cfg;
-#define RIO_OP_DEFAULT_COLLECT_NS 1500u
+#define RIO_OP_DEFAULT_COLLECT_NS 6000u
 #define RIO_OP_CFG_LIVE_FIRST_TOUCH 4u
 /* Host shadow of the assignment column.  The reference calls lookup / get_or_create_placement once per request from one task per
  * connection (server.rs:292-304) and LocalObjectPlacement answers a hit from a hash map (local.rs:42-49); a device round trip per
