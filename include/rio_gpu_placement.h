@@ -227,6 +227,34 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
 int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_requester,
                              uint32_t* d_out_node, uint32_t* d_out_flag);
 
+/* Up to 256 entries of EACH of update / remove / lookup / place_pending in one call: exactly rio_gp_update_batch, then
+ * rio_gp_remove_batch, then rio_gp_lookup_batch, then rio_gp_place_pending over the given arrays (a count of 0 skips the
+ * kind) — but ONE enqueue and ONE host wait for all of them (four one-workgroup kernels back to back on the handle's stream).
+ * This is what the connections of one reference Server ask for at the same moment (lookups, first touches and removals
+ * mixed: service.rs:193-254, server.rs:292-304; local.rs:22-68); the string layer's combiner sends one such call per
+ * generation of concurrent callers.  rc[k] = what the k-th of those calls would have returned (0 update, 1 remove, 2 lookup,
+ * 3 place_pending): a kind with an out-of-range entry changes nothing and reports RIO_GP_EINVAL there, the other kinds still
+ * run.  The return value is about the call as a whole (arguments, device). */
+typedef struct rio_gp_mixed {
+    uint32_t struct_size; /* sizeof(rio_gp_mixed) */
+    uint32_t n_update;
+    const uint32_t* update_idx;
+    const uint32_t* update_node;
+    uint32_t n_remove;
+    uint32_t n_lookup;
+    const uint32_t* remove_idx;
+    const uint32_t* lookup_idx;
+    uint32_t* lookup_out;
+    uint32_t n_place;
+    uint32_t reserved;
+    const uint32_t* place_idx;
+    const uint32_t* place_requester;
+    uint32_t* place_node;
+    uint32_t* place_flag; /* may be NULL */
+    int32_t rc[4];
+} rio_gp_mixed;
+int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops);
+
 /* Whole-table solve: every row gets a decision in one call (the eager form of the lazy
  * per-request path of service.rs:193-254 + the clean_server stream of SURVEY §3.2):
  * keep if alive (sticky) | claim affinity node by index-ordered prefix | water-fill | NONE.

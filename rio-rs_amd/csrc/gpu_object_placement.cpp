@@ -166,7 +166,8 @@ struct State {
     alignas(64) std::vector<Req*> batch;  // (under mu) the requests the serving thread took off the list, oldest first
     std::vector<uint64_t> results;        // (under mu) their packed answers
     std::vector<int> sv_kind;             // (under mu) serve()'s scratch: no allocation per batch
-    std::vector<uint32_t> sv_row, sv_req, sv_rows, sv_reqs, sv_res, sv_fl, sv_who;
+    std::vector<uint32_t> sv_row, sv_req;
+    struct KindBuf { std::vector<uint32_t> rows, reqs, res, fl, who; } sv_kb[4];  // the batch split by kind
     Shadow shadow;
     uint64_t dev_batches = 0, dev_requests = 0;  // (under mu) device round trips of combined batches / requests they carried
     size_t last_batch = 0, prev_batch = 0;       // (under mu) requests of the last two combined batches
@@ -509,34 +510,85 @@ void serve(State* s, std::vector<Req*>& batch, std::vector<uint64_t>& results) {
     s->dev_requests += batch.size();
     // (the requests' inputs were copied out of the slots by the caller: sv_kind / sv_row / sv_req)
     std::vector<int>& kinds = s->sv_kind;
-    std::vector<uint32_t>&arow = s->sv_row, &areq = s->sv_req, &rows = s->sv_rows, &reqs = s->sv_reqs, &res = s->sv_res, &fl = s->sv_fl;
-    std::vector<uint32_t>& who = s->sv_who;
+    std::vector<uint32_t>&arow = s->sv_row, &areq = s->sv_req;
+    State::KindBuf* kb = s->sv_kb;
+    int present = 0;
+    bool micro = true;
+    for (int kind = 0; kind < 4; ++kind) { kb[kind].rows.clear(); kb[kind].reqs.clear(); kb[kind].who.clear(); }
+    for (size_t i = 0; i < batch.size(); ++i) {
+        State::KindBuf& b = kb[kinds[i]];
+        b.rows.push_back(arow[i]); b.reqs.push_back(areq[i]); b.who.push_back((uint32_t)i);
+    }
+    for (int kind = 0; kind < 4; ++kind) {
+        kb[kind].res.assign(kb[kind].who.size(), RIO_GP_NONE);
+        kb[kind].fl.assign(kb[kind].who.size(), 0);
+        present += !kb[kind].who.empty();
+        micro = micro && kb[kind].who.size() <= 256;
+    }
+    auto answer = [&](int kind, int rc) {
+        const State::KindBuf& b = kb[kind];
+        for (size_t k = 0; k < b.who.size(); ++k) {
+            if (rc) batch[b.who[k]]->err = t_err;
+            results[b.who[k]] = Req::pack(rc, b.res[k], b.fl[k]);
+        }
+    };
+    bool done[4] = {false, false, false, false};
     // writes first, in arrival order (sequential last-writer-wins, local.rs:22-40), then the reads and the policy calls:
     // a caller only returns after the batch, so any order inside it is a valid linearisation of concurrent calls
-    for (int kind : {2, 3, 0, 1}) {
-        rows.clear(); reqs.clear(); who.clear();
-        for (size_t i = 0; i < batch.size(); ++i)
-            if (kinds[i] == kind) { rows.push_back(arow[i]); reqs.push_back(areq[i]); who.push_back((uint32_t)i); }
-        if (who.empty()) continue;
-        res.assign(who.size(), RIO_GP_NONE);
-        fl.assign(who.size(), 0);
-        int rc = run_kind(s, kind, rows, reqs, res.data(), fl.data());
-        if (rc == RIO_GP_OK || who.size() == 1) {
-            for (size_t k = 0; k < who.size(); ++k) {
-                if (rc) batch[who[k]]->err = t_err;
-                results[who[k]] = Req::pack(rc, res[k], fl[k]);
+    static const int kOrder[4] = {2, 3, 0, 1};
+    if (present >= 2 && micro) {
+        // The callers of this generation asked for different things (a server's connections mix lookups, first touches and
+        // removals): ONE device round trip for all of it — rio_gp_mixed_batch runs the four micro-batch kernels back to back
+        // in exactly this order — instead of one per kind.
+        bool any_malformed;
+        {
+            std::shared_lock<std::shared_mutex> li(s->imu);
+            any_malformed = s->n_malformed != 0;  // (rare: policy_batch's own pre-pass handles those records)
+        }
+        if (!any_malformed) {
+            rio_gp_mixed m;
+            memset(&m, 0, sizeof m);
+            m.struct_size = (uint32_t)sizeof m;
+            m.n_update = (uint32_t)kb[2].who.size(); m.update_idx = kb[2].rows.data(); m.update_node = kb[2].reqs.data();
+            m.n_remove = (uint32_t)kb[3].who.size(); m.remove_idx = kb[3].rows.data();
+            m.n_lookup = (uint32_t)kb[0].who.size(); m.lookup_idx = kb[0].rows.data(); m.lookup_out = kb[0].res.data();
+            m.n_place = (uint32_t)kb[1].who.size(); m.place_idx = kb[1].rows.data(); m.place_requester = kb[1].reqs.data();
+            m.place_node = kb[1].res.data(); m.place_flag = kb[1].fl.data();
+            if (rio_gp_mixed_batch(s->gp, &m) == RIO_GP_OK) {
+                static const int kRcOf[4] = {2, 3, 0, 1};  // kind -> index into rio_gp_mixed.rc (update, remove, lookup, place)
+                for (int kind : kOrder) {  // the shadow follows in the order the device applied them
+                    const State::KindBuf& b = kb[kind];
+                    if (b.who.empty() || m.rc[kRcOf[kind]] != RIO_GP_OK) continue;  // a refused kind changed nothing: one by one below
+                    if (kind == 1) {
+                        bool cleaned = false;
+                        for (size_t k = 0; k < b.who.size() && !cleaned; ++k) cleaned = (b.fl[k] & RIO_GP_FLAG_REPLACED) != 0;
+                        if (cleaned) s->shadow.invalidate_all();
+                    }
+                    for (size_t k = 0; k < b.who.size(); ++k)
+                        s->shadow.put(b.rows[k], kind == 2 ? b.reqs[k] : kind == 3 ? RIO_GP_NONE : b.res[k]);
+                    answer(kind, RIO_GP_OK);
+                    done[kind] = true;
+                }
             }
+        }
+    }
+    for (int kind : kOrder) {
+        State::KindBuf& b = kb[kind];
+        if (b.who.empty() || done[kind]) continue;
+        int rc = run_kind(s, kind, b.rows, b.reqs, b.res.data(), b.fl.data());
+        if (rc == RIO_GP_OK || b.who.size() == 1) {
+            answer(kind, rc);
             continue;
         }
         // The batched call was refused (the dense layer validates before it mutates): run the requests one by one, in
         // order, so that only the offender sees the error — its batch-mates are other callers' requests.
         std::vector<uint32_t> r1(1), q1(1);
-        for (size_t k = 0; k < who.size(); ++k) {
-            r1[0] = rows[k]; q1[0] = reqs[k];
+        for (size_t k = 0; k < b.who.size(); ++k) {
+            r1[0] = b.rows[k]; q1[0] = b.reqs[k];
             uint32_t nd = RIO_GP_NONE, f = 0;
             rc = run_kind(s, kind, r1, q1, &nd, &f);
-            if (rc) batch[who[k]]->err = t_err;
-            results[who[k]] = Req::pack(rc, nd, f);
+            if (rc) batch[b.who[k]]->err = t_err;
+            results[b.who[k]] = Req::pack(rc, nd, f);
         }
     }
 }

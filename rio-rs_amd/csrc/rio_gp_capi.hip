@@ -707,8 +707,8 @@ bool small_inline(SmallInline* inl, uint64_t n, const uint32_t* a, const uint32_
     }
     return true;
 }
-int small_wait(rio_gp* h, u32 seq) {
-    volatile u32* w = h->h_small + 5 * kSmallBatch;
+int small_wait(rio_gp* h, u32 seq, volatile u32* w = nullptr) {
+    if (!w) w = h->h_small + 5 * kSmallBatch;
     const auto t0 = std::chrono::steady_clock::now();
     for (u32 spins = 1; *w != seq; ++spins) {
         __builtin_ia32_pause();
@@ -1541,19 +1541,13 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
     return RIO_GP_OK;
 }
 
-int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* requester,
-                         uint32_t* out_node, uint32_t* out_flag) {
-    if (!h || (n && (!idx || !requester || !out_node))) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
-    for (uint64_t k = 0; k < n; ++k)
-        if (idx[k] >= h->n || requester[k] >= h->m)
-            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: object index or requester out of range");
-    if (!n) return RIO_GP_OK;
-    if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: batch too large");
-    HIPCHK(h, hipSetDevice(h->device));
+// rio_gp_place_pending with the handle locked and the entries validated; micro_tried: the one-workgroup kernel has already run
+// over this batch and handed it over untouched (rio_gp_mixed_batch)
+static int place_pending_host_locked(rio_gp* h, uint64_t n, const uint32_t* idx, const uint32_t* requester, uint32_t* out_node,
+                                     uint32_t* out_flag, bool micro_tried) {
     flush_alive(h);
     int rc;
-    if (n <= (uint64_t)kSmallBatch) {
+    if (n <= (uint64_t)kSmallBatch && !micro_tried) {
         // micro-batch: one workgroup, one launch, request/result arrays in mapped pinned memory (no staging copies)
         if ((rc = ensure_used(h))) return rc;
         u32 *hs = h->h_small, *ds = h->d_small;
@@ -1633,6 +1627,130 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
     if (out_flag) HIPCHK(h, hipMemcpyAsync(out_flag, d_flag, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    return RIO_GP_OK;
+}
+
+int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* requester,
+                         uint32_t* out_node, uint32_t* out_flag) {
+    if (!h || (n && (!idx || !requester || !out_node))) return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint64_t k = 0; k < n; ++k)
+        if (idx[k] >= h->n || requester[k] >= h->m)
+            return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: object index or requester out of range");
+    if (!n) return RIO_GP_OK;
+    if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: batch too large");
+    HIPCHK(h, hipSetDevice(h->device));
+    return place_pending_host_locked(h, n, idx, requester, out_node, out_flag, false);
+}
+
+// Up to kSmallBatch entries of EACH of update / remove / lookup / place_pending, executed in that order, as ONE enqueue and ONE
+// host wait: the four micro-batch kernels go onto the stream back to back (each a single workgroup, the stream orders them),
+// only the last one stores the completion word.  What the string layer's combiner sends when the callers of one generation
+// asked for different things (a server's connections mix lookups, first touches and removals: service.rs:193-254,
+// server.rs:292-304): one round trip instead of one per kind.
+int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
+    if (!h || !ops || ops->struct_size < sizeof(rio_gp_mixed)) return RIO_GP_EINVAL;
+    const uint32_t nu = ops->n_update, nr = ops->n_remove, nl = ops->n_lookup, np = ops->n_place;
+    if ((nu && (!ops->update_idx || !ops->update_node)) || (nr && !ops->remove_idx) ||
+        (nl && (!ops->lookup_idx || !ops->lookup_out)) || (np && (!ops->place_idx || !ops->place_requester || !ops->place_node)))
+        return RIO_GP_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (nu > (uint32_t)kSmallBatch || nr > (uint32_t)kSmallBatch || nl > (uint32_t)kSmallBatch || np > (uint32_t)kSmallBatch)
+        return fail(h, RIO_GP_EINVAL, "rio_gp_mixed_batch: at most 256 entries of each kind");
+    // every kind is validated before anything is enqueued; a kind with an invalid entry is skipped as a whole (its own call
+    // would have changed nothing either) and says so in rc[], the others run
+    bool run[4] = {nu != 0, nr != 0, nl != 0, np != 0};
+    for (int k = 0; k < 4; ++k) ops->rc[k] = RIO_GP_OK;
+    for (uint32_t k = 0; k < nu && run[0]; ++k)
+        if (ops->update_idx[k] >= h->n || (ops->update_node[k] != RIO_GP_NONE && ops->update_node[k] >= h->m)) {
+            ops->rc[0] = fail(h, RIO_GP_EINVAL, "rio_gp_update_batch: index or node out of range");
+            run[0] = false;
+        }
+    for (uint32_t k = 0; k < nr && run[1]; ++k)
+        if (ops->remove_idx[k] >= h->n) {
+            ops->rc[1] = fail(h, RIO_GP_EINVAL, "rio_gp_remove_batch: object index out of range");
+            run[1] = false;
+        }
+    for (uint32_t k = 0; k < nl && run[2]; ++k)
+        if (ops->lookup_idx[k] >= h->n) {
+            ops->rc[2] = fail(h, RIO_GP_EINVAL, "rio_gp_lookup_batch: object index out of range");
+            run[2] = false;
+        }
+    for (uint32_t k = 0; k < np && run[3]; ++k)
+        if (ops->place_idx[k] >= h->n || ops->place_requester[k] >= h->m) {
+            ops->rc[3] = fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: object index or requester out of range");
+            run[3] = false;
+        }
+    int last = -1;
+    for (int k = 0; k < 4; ++k)
+        if (run[k]) last = k;
+    if (last < 0) return RIO_GP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    // staging: the place_pending entries where its own call has them (h_small); update / remove / lookup in the first row of the
+    // medium-batch area (mapped pinned memory as well) — [0] update idx | [1] update node | [2] remove idx | [3] lookup idx |
+    // [4] lookup out.  The lookup kernel has its own completion word (h_small row 5, word 16: only ever holds sequence
+    // numbers): its results are host memory, the host reads them behind a fence of the kernel that wrote them
+    u32 *hm = h->h_mid, *dm = h->d_mid;
+    const u32 seq = small_begin(h);
+    SmallInline inl;
+    if (run[0]) {
+        const bool in_args = small_inline(&inl, nu, ops->update_idx, ops->update_node);
+        if (!in_args) {
+            memcpy(hm, ops->update_idx, nu * sizeof(u32));
+            memcpy(hm + kSmallBatch, ops->update_node, nu * sizeof(u32));
+        }
+        fold_used(h);
+        launch_update_small(h->assign[h->cur], dm, dm + kSmallBatch, nu, h->stream, aff_life(h), last == 0 ? small_done_dev(h) : nullptr,
+                            seq, in_args ? &inl : nullptr, h->used_valid ? h->used : nullptr, h->load, h->m);
+        h->have_solved = false; ++h->mut_epoch;
+    }
+    if (run[1]) {
+        const bool in_args = small_inline(&inl, nr, ops->remove_idx, nullptr);
+        if (!in_args) memcpy(hm + 2 * kSmallBatch, ops->remove_idx, nr * sizeof(u32));
+        fold_used(h);
+        launch_remove_small(h->assign[h->cur], h->m, h->load, dm + 2 * kSmallBatch, nr, h->used_valid ? h->used : nullptr, h->stream,
+                            aff_life(h), last == 1 ? small_done_dev(h) : nullptr, seq, in_args ? &inl : nullptr);
+        h->have_solved = false; ++h->mut_epoch;
+    }
+    if (run[2]) {
+        const bool in_args = small_inline(&inl, nl, ops->lookup_idx, nullptr);
+        if (!in_args) memcpy(hm + 3 * kSmallBatch, ops->lookup_idx, nl * sizeof(u32));
+        launch_lookup_small(h->assign[h->cur], h->n, dm + 3 * kSmallBatch, nl, dm + 4 * kSmallBatch, h->dstats, h->stream,
+                            last == 2 ? small_done_dev(h) : small_done_dev(h) + 16, seq, in_args ? &inl : nullptr);
+    }
+    u32 *hs = h->h_small, *ds = h->d_small;
+    if (run[3]) {
+        flush_alive(h);
+        if ((rc = ensure_used(h))) return rc;
+        const bool in_args = small_inline(&inl, np, ops->place_idx, ops->place_requester);
+        if (!in_args) {
+            memcpy(hs, ops->place_idx, np * sizeof(u32));
+            memcpy(hs + kSmallBatch, ops->place_requester, np * sizeof(u32));
+        }
+        hs[4 * kSmallBatch] = 2;  // neither 0 nor 1: the kernel must write it
+        launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, ds, ds + kSmallBatch, np,
+                      ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h), small_done_dev(h), seq,
+                      in_args ? &inl : nullptr, 0, nullptr, nullptr, h->sa);
+    }
+    if ((rc = small_wait(h, seq))) return rc;
+    if (run[2]) {
+        if (last != 2 && (rc = small_wait(h, seq, h->h_small + 5 * kSmallBatch + 16))) return rc;
+        memcpy(ops->lookup_out, hm + 4 * kSmallBatch, nl * sizeof(u32));
+    }
+    if (run[3]) {
+        const u32 status = hs[4 * kSmallBatch];
+        if (status == 0) {
+            memcpy(ops->place_node, hs + 2 * kSmallBatch, np * sizeof(u32));
+            if (ops->place_flag) memcpy(ops->place_flag, hs + 3 * kSmallBatch, np * sizeof(u32));
+            h->have_solved = false; ++h->mut_epoch;
+        } else if (status == 1) {
+            // a dead node / a dead or full requester is involved: nothing of the place_pending part was changed, the general path
+            ops->rc[3] = place_pending_host_locked(h, np, ops->place_idx, ops->place_requester, ops->place_node, ops->place_flag, true);
+        } else {
+            return fail(h, RIO_GP_EUPSTREAM, "rio_gp_mixed_batch: micro-batch kernel left no status");
+        }
+    }
     return RIO_GP_OK;
 }
 

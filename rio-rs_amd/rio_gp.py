@@ -57,6 +57,14 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
 
 
+class Mixed(C.Structure):
+    """rio_gp_mixed (include/rio_gpu_placement.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("n_update", C.c_uint32), ("update_idx", C.c_void_p), ("update_node", C.c_void_p),
+                ("n_remove", C.c_uint32), ("n_lookup", C.c_uint32), ("remove_idx", C.c_void_p), ("lookup_idx", C.c_void_p),
+                ("lookup_out", C.c_void_p), ("n_place", C.c_uint32), ("reserved", C.c_uint32), ("place_idx", C.c_void_p),
+                ("place_requester", C.c_void_p), ("place_node", C.c_void_p), ("place_flag", C.c_void_p), ("rc", C.c_int32 * 4)]
+
+
 def _build_one(path, srcs, extra, force, verbose):
     deps = srcs + [x for x in HEADERS if os.path.exists(x)]
     if not force and os.path.exists(path) and all(os.path.getmtime(d) <= os.path.getmtime(path) for d in deps):
@@ -145,6 +153,7 @@ def _load(lab):
         L.rio_gp_get_objects.argtypes = [_vp, C.c_uint64, _vp, _vp]
         L.rio_gp_set_num_objects.argtypes = [_vp, C.c_uint64]
         L.rio_gp_place_pending_dev.argtypes = [_vp, C.c_uint64, _vp, _vp, _vp, _vp]
+        L.rio_gp_mixed_batch.argtypes = [_vp, C.POINTER(Mixed)]
         if lab:
             L.rio_gp_debug_set_scan_nt.argtypes = [C.c_int]
             L.rio_gp_debug_set_scan_nt.restype = None
@@ -311,6 +320,21 @@ class GpuPlacement:
         node, flag = np.empty(len(idx), np.uint32), np.empty(len(idx), np.uint32)
         self._chk(self._L.rio_gp_place_pending(self._h, len(idx), _ptr(idx), _ptr(requester), _ptr(node), _ptr(flag)))
         return node, flag
+
+    def mixed_batch(self, update=None, remove=None, lookup=None, place=None):
+        """rio_gp_mixed_batch: update=(idx, node), remove=idx, lookup=idx, place=(idx, requester), at most 256 entries each, one
+        device round trip.  Returns (rc[4], lookup_out, place_node, place_flag)."""
+        e = np.empty(0, np.uint32)
+        ui, un = (_u32(update[0]), _u32(update[1])) if update is not None else (e, e)
+        ri = _u32(remove) if remove is not None else e
+        li = _u32(lookup) if lookup is not None else e
+        pi, pr = (_u32(place[0]), _u32(place[1])) if place is not None else (e, e)
+        lo, pn, pf = np.empty(len(li), np.uint32), np.empty(len(pi), np.uint32), np.empty(len(pi), np.uint32)
+        ops = Mixed(struct_size=C.sizeof(Mixed), n_update=len(ui), update_idx=_ptr(ui), update_node=_ptr(un), n_remove=len(ri),
+                    n_lookup=len(li), remove_idx=_ptr(ri), lookup_idx=_ptr(li), lookup_out=_ptr(lo), n_place=len(pi),
+                    place_idx=_ptr(pi), place_requester=_ptr(pr), place_node=_ptr(pn), place_flag=_ptr(pf))
+        self._chk(self._L.rio_gp_mixed_batch(self._h, C.byref(ops)))
+        return list(ops.rc), lo, pn, pf
 
     def place_pending_dev(self, n, d_idx, d_requester, d_out_node, d_out_flag=None):
         """Device pointers (ints): request and result arrays already resident in HBM."""

@@ -27,11 +27,14 @@ struct rio_gp {
 // the way a launch + wait does — the string layer's combiner is then measured against something shaped like a device
 #ifdef STUB_LATENCY_US
 #include <chrono>
+static thread_local bool t_in_mixed = false;  // rio_gp_mixed_batch: ONE round trip for its four parts
 static void device_latency() {
+    if (t_in_mixed) return;
     const auto t0 = std::chrono::steady_clock::now();
     while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(STUB_LATENCY_US)) {}
 }
 #else
+static thread_local bool t_in_mixed = false;
 static void device_latency() {}
 #endif
 
@@ -170,6 +173,19 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
         out_node[k] = a;
         if (out_flag) out_flag[k] = fl;
     }
+    return RIO_GP_OK;
+}
+int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {  // the four calls in order; a refused kind changes nothing, the others run
+    if (!h || !ops || ops->struct_size < sizeof(rio_gp_mixed)) return RIO_GP_EINVAL;
+    if (ops->n_update > 256 || ops->n_remove > 256 || ops->n_lookup > 256 || ops->n_place > 256) return RIO_GP_EINVAL;
+    device_latency();
+    t_in_mixed = true;
+    ops->rc[0] = ops->n_update ? rio_gp_update_batch(h, ops->n_update, ops->update_idx, ops->update_node) : RIO_GP_OK;
+    ops->rc[1] = ops->n_remove ? rio_gp_remove_batch(h, ops->n_remove, ops->remove_idx) : RIO_GP_OK;
+    ops->rc[2] = ops->n_lookup ? rio_gp_lookup_batch(h, ops->n_lookup, ops->lookup_idx, ops->lookup_out) : RIO_GP_OK;
+    ops->rc[3] = ops->n_place ? rio_gp_place_pending(h, ops->n_place, ops->place_idx, ops->place_requester, ops->place_node, ops->place_flag)
+                              : RIO_GP_OK;
+    t_in_mixed = false;
     return RIO_GP_OK;
 }
 int rio_gp_tick(rio_gp_t* h, rio_gp_stats* st) {

@@ -218,6 +218,33 @@ class Scenario:
         bad = np.flatnonzero((node != wnode) | (flag != wflag))
         assert bad.size == 0, (self.seed, "place_pending", self.log[-6:], idx.size, bad[:8], node[bad[:8]], wnode[bad[:8]], flag[bad[:8]], wflag[bad[:8]])
 
+    def op_mixed(self):
+        """rio_gp_mixed_batch: up to 256 entries of each kind, one round trip — against the oracle's four calls in order."""
+        rng = self.rng
+        def some():
+            return self._idx(k=int(_pick(rng, (1, 2, 4, 5, 31, 64, 200, 256), 256)), big_ok=False) if rng.random() < 0.7 else None
+        ui, ri, li, pi = some(), some(), some(), some()
+        un = pr = None
+        if ui is not None:
+            un = rng.integers(0, self.m, ui.size).astype(np.uint32)
+            un[rng.random(ui.size) < 0.05] = NONE
+        if pi is not None:
+            pr = rng.integers(0, self.m, pi.size).astype(np.uint32)
+        rc, lo, pn, pf = self.g.mixed_batch(update=None if ui is None else (ui, un), remove=ri, lookup=li,
+                                            place=None if pi is None else (pi, pr))
+        assert rc == [0, 0, 0, 0], (self.seed, "mixed rc", rc)
+        if ui is not None:
+            self.oracle.update_batch(self.ref, self.m, ui, un)
+        if ri is not None:
+            self.oracle.remove_batch(self.ref, ri)
+        if li is not None:
+            assert np.array_equal(lo, self.oracle.lookup_batch(self.ref, li)), (self.seed, "mixed lookup", self.log[-6:])
+        if pi is not None:
+            used = self.oracle.recompute_used(self.ref, self.load, self.m)
+            wnode, wflag = self.oracle.place_pending(self.ref, self.load, self.cap, self.alive, used, pi, pr, self.rounds, self.oflags)
+            bad = np.flatnonzero((pn != wnode) | (pf != wflag))
+            assert bad.size == 0, (self.seed, "mixed place_pending", self.log[-6:], pi.size, bad[:8], pn[bad[:8]], wnode[bad[:8]])
+
     def op_attrs(self):
         idx = np.unique(self._idx(big_ok=False))
         load = self.rng.integers(0, 500, idx.size).astype(np.uint32)
@@ -232,7 +259,7 @@ class Scenario:
         self.g.set_nodes(self.cap, self.alive, m=self.m)
 
     OPS = (("tick", 5), ("solve", 2), ("async", 3), ("flip", 4), ("update", 2), ("remove", 2), ("lookup", 1), ("clean", 2),
-           ("place", 4), ("attrs", 1), ("caps", 1))
+           ("place", 4), ("mixed", 3), ("attrs", 1), ("caps", 1))
 
     def run(self):
         names = [a for a, w in self.OPS for _ in range(w)]

@@ -1312,3 +1312,76 @@ def test_soak_churn_stream_against_the_oracle():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["all_ticks_equal_oracle"] is True
 
+
+
+def test_mixed_batch_is_the_four_calls_in_one_round_trip(gp, oracle):
+    """rio_gp_mixed_batch (what the combiner sends when the callers of one generation asked for different things): update,
+    remove, lookup and place_pending over up to 256 entries each, in that order, one enqueue and one wait — against the
+    oracle's four calls, for every subset of kinds, entries riding in the kernel arguments (<= 4) and staged ones, duplicates
+    across the kinds, a dead node in the way (the place_pending part hands over to the general path), tight capacities."""
+    rng = np.random.default_rng(1234)
+    n, m = 50_000, 48
+    load = rng.integers(0, 30, n).astype(np.uint32)
+    cap = np.full(m, int(load.sum() // m // 4), np.uint64)
+    alive = np.ones(m, np.uint8)
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(cap, alive)
+    g.set_objects(n, load, None)
+    ref = np.full(n, NONE, np.uint32)
+    for step in range(60):
+        if step == 30:
+            alive[[5, 17]] = 0
+            g.set_alive_all(alive)
+        mask = step % 15 + 1                                  # every non-empty subset of the four kinds
+        def some(bit):
+            if not mask >> bit & 1:
+                return None
+            k = int(rng.choice((1, 3, 4, 5, 60, 255, 256)))
+            return rng.integers(0, 2000 if step % 2 else n, k).astype(np.uint32)   # narrow range: the kinds hit the same rows
+        ui, ri, li, pi = some(0), some(1), some(2), some(3)
+        un = None if ui is None else rng.integers(0, m, ui.size).astype(np.uint32)
+        if un is not None:
+            un[rng.random(un.size) < 0.1] = NONE
+        pr = None if pi is None else rng.integers(0, m, pi.size).astype(np.uint32)
+        rc, lo, pn, pf = g.mixed_batch(update=None if ui is None else (ui, un), remove=ri, lookup=li,
+                                       place=None if pi is None else (pi, pr))
+        assert rc == [0, 0, 0, 0], (step, rc)
+        if ui is not None:
+            oracle.update_batch(ref, m, ui, un)
+        if ri is not None:
+            oracle.remove_batch(ref, ri)
+        if li is not None:
+            assert np.array_equal(lo, oracle.lookup_batch(ref, li)), step
+        if pi is not None:
+            used = oracle.recompute_used(ref, load, m)
+            wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, pi, pr)
+            assert np.array_equal(pn, wnode) and np.array_equal(pf, wflag), step
+        assert np.array_equal(g.get_assign(), ref), step
+        assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m)), step
+    g.close()
+
+
+def test_mixed_batch_refuses_one_kind_and_runs_the_others(gp, oracle):
+    """A kind with an out-of-range entry changes nothing and says so in rc[] (what its own call would have returned); the
+    other kinds of the same call run.  More than 256 entries of a kind: the whole call is RIO_GP_EINVAL, nothing runs."""
+    n, m = 1000, 8
+    g = gp.GpuPlacement(n, m)
+    g.set_nodes(np.full(m, INF, np.uint64), np.ones(m, np.uint8))
+    g.set_objects(n, np.ones(n, np.uint32), None)
+    rc, lo, pn, pf = g.mixed_batch(update=(np.array([1, 2, n], np.uint32), np.array([0, 1, 2], np.uint32)),   # row n: out of range
+                                   remove=np.array([7], np.uint32), lookup=np.array([1, 2, 3], np.uint32),
+                                   place=(np.array([3, 4], np.uint32), np.array([5, 6], np.uint32)))
+    assert rc == [gp.EINVAL, 0, 0, 0]
+    assert list(lo) == [NONE, NONE, NONE]                     # the refused update wrote nothing
+    assert list(pn) == [5, 6] and list(pf) == [gp.FLAG_PLACED, gp.FLAG_PLACED]
+    rc, lo, pn, pf = g.mixed_batch(update=(np.array([1, 2], np.uint32), np.array([0, 1], np.uint32)),
+                                   remove=np.array([3], np.uint32), lookup=np.array([1, 2, 3, 4, n + 5], np.uint32),
+                                   place=(np.array([9], np.uint32), np.array([m], np.uint32)))             # requester m: out of range
+    assert rc == [0, 0, gp.EINVAL, gp.EINVAL]
+    a = g.get_assign()
+    assert a[1] == 0 and a[2] == 1 and a[3] == NONE and a[4] == 6 and a[9] == NONE
+    with pytest.raises(gp.ObjectPlacementError):
+        g.mixed_batch(lookup=np.zeros(257, np.uint32))
+    rc, lo, pn, pf = g.mixed_batch()
+    assert rc == [0, 0, 0, 0]
+    g.close()
