@@ -472,9 +472,9 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
 // roles settled at publication: a caller interns its key, takes a TICKET of the current generation, fills the slot the ticket
 // names (32 bytes, in parallel with every other caller) and tags it.  Ticket 0 serves its generation: it waits for `mu`,
 // closes the generation (later tickets belong to the next one, whose ticket 0 is already waiting for the lock), reads the
-// slots as an array, runs ONE batched device call per kind (the micro-batch kernels: one launch + one wait for <= 256
-// requests), answers every caller with one store into that caller's own cache line and releases the lock.  Everybody else
-// waits for its answer on a line nobody else touches.  Tenure is exactly one batch, so a server always returns to its own
+// slots as an array, makes ONE device round trip (rio_gp_mixed_batch: the micro-batch kernels of the kinds that were asked for,
+// back to back, one wait), answers every caller with one exchange on that caller's own cache line and releases the lock.
+// Everybody else waits for its answer on a line nobody else touches — spinning at first, asleep on it after that.  Tenure is exactly one batch, so a server always returns to its own
 // caller (round-2 advisor finding).  A lone caller pays exactly what it paid before; N concurrent callers share a round trip.
 // Requests of one batch keep their arrival (ticket) order: the first request for an object decides, as in
 // rio_gp_place_pending.  What this replaced, measured at 64 callers on the 2-socket host: round 4's queue + condition variable
