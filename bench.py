@@ -103,6 +103,25 @@ def parse():
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 
+def usable_cpus():
+    """CPUs this process may keep busy at once: the affinity mask, cut by a cgroup CPU quota (cpu.max / cfs_quota_us).  The GPU
+    boxes of the pool show 256 hardware threads and grant 16 CPUs: more threads than that are throttled as a group."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, sample, array_oracle_seconds=None, gpu_cold_column=None):
     """Time the oracle port of the reference's per-object path on this box's host cores (bounded).  The map the
     single-thread leg builds is not thrown away: every object is looked up again and the answers are compared with the
@@ -110,7 +129,7 @@ def cpu_baseline(cfg, sample, array_oracle_seconds=None, gpu_cold_column=None):
     import pyoracle
     n = min(sample, cfg["n"])
     aff = np.ascontiguousarray(cfg["aff"][:n])
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()   # the multi-thread leg runs on what the container may use, not on every thread it can see
     t1, port_nodes = pyoracle.policy_readback(n, cfg["m"], aff)                      # cold: miss -> first touch -> update
     against_port = None
     if gpu_cold_column is not None:
@@ -142,9 +161,9 @@ def cpu_baseline(cfg, sample, array_oracle_seconds=None, gpu_cold_column=None):
         "value": best_v, "unit": "decisions/s", "cores": best_c, "kind": "port",
         "sample": "cold get_or_create_placement per object (service.rs:193-254 restated in C++: string keys, "
                   "unordered_map behind a shared_mutex, %d-member LocalStorage) over the first %d objects of the "
-                  "workload on 1 thread, and over the first %d objects on all %d hardware threads sharing one map; "
+                  "workload on 1 thread, and over the first %d objects on %d threads (the CPUs this process may use) sharing one map; "
                   "value = the faster of the two" % (cfg["m"], n, nT, cores),
-        "value_1thread": v1, "value_allcores": vT, "host_cores": cores, "cpu_model": model,
+        "value_1thread": v1, "value_allcores": vT, "host_cores": cores, "hardware_threads_visible": os.cpu_count(), "cpu_model": model,
         "warm_sticky_hits_1thread": {"value": nW / tW, "unit": "decisions/s", "rows": nW,
                                      "note": "every call hits and pays the O(M) is_active member scan (cluster/storage/mod.rs:95-110)"},
         "array_oracle_1thread": {"value": cfg["n"] / array_oracle_seconds, "unit": "decisions/s", "rows": cfg["n"],
