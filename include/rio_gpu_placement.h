@@ -229,7 +229,7 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
 
 /* Up to 256 entries of EACH of update / remove / lookup / place_pending in one call: exactly rio_gp_update_batch, then
  * rio_gp_remove_batch, then rio_gp_lookup_batch, then rio_gp_place_pending over the given arrays (a count of 0 skips the
- * kind) — but ONE enqueue and ONE host wait for all of them (four one-workgroup kernels back to back on the handle's stream).
+ * kind) — but ONE launch and ONE host wait for all of them (one workgroup runs the parts one after the other).
  * This is what the connections of one reference Server ask for at the same moment (lookups, first touches and removals
  * mixed: service.rs:193-254, server.rs:292-304; local.rs:22-68); the string layer's combiner sends one such call per
  * generation of concurrent callers.  rc[k] = what the k-th of those calls would have returned (0 update, 1 remove, 2 lookup,

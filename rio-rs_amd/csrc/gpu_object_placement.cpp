@@ -519,8 +519,8 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
 // roles settled at publication: a caller interns its key, takes a TICKET of the current generation, fills the slot the ticket
 // names (32 bytes, in parallel with every other caller) and tags it.  Ticket 0 serves its generation: it waits for `mu`,
 // closes the generation (later tickets belong to the next one, whose ticket 0 is already waiting for the lock), reads the
-// slots as an array, makes ONE device round trip (rio_gp_mixed_batch: the micro-batch kernels of the kinds that were asked for,
-// back to back, one wait), answers every caller with one exchange on that caller's own cache line and releases the lock.
+// slots as an array, makes ONE device round trip (rio_gp_mixed_batch: one launch runs the kinds that were asked for one after
+// the other, one wait), answers every caller with one exchange on that caller's own cache line and releases the lock.
 // Everybody else waits for its answer on a line nobody else touches — spinning at first, asleep on it after that.  Tenure is exactly one batch, so a server always returns to its own
 // caller (round-2 advisor finding).  A lone caller pays exactly what it paid before; N concurrent callers share a round trip.
 // Requests of one batch keep their arrival (ticket) order: the first request for an object decides, as in
@@ -594,8 +594,8 @@ void serve(State* s, std::vector<Req*>& batch, std::vector<uint64_t>& results) {
     static const int kOrder[4] = {2, 3, 0, 1};
     if (present >= 2 && micro) {
         // The callers of this generation asked for different things (a server's connections mix lookups, first touches and
-        // removals): ONE device round trip for all of it — rio_gp_mixed_batch runs the four micro-batch kernels back to back
-        // in exactly this order — instead of one per kind.
+        // removals): ONE device round trip for all of it — rio_gp_mixed_batch runs the four kinds in exactly this order in
+        // one launch — instead of one per kind.
         bool any_malformed;
         {
             std::shared_lock<TableLock> li(s->imu);

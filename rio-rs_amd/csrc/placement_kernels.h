@@ -273,10 +273,23 @@ constexpr int kOneBatch = 4096;
 // k_pp_apply) — instead of one workgroup doing all of it
 constexpr int kPpStagedFrom = 256;
 inline size_t pp_stage_bytes() { return (size_t)kOneBatch * (16 + 16 + 8) + 64; }
+// the update / remove / lookup parts of a mixed micro-batch (<= kSmallBatch validated entries each; *_inl: n <= 4 entries in
+// the kernel arguments): run by the one workgroup of k_pp_one<kSmallBatch, 1> in front of the requests, or alone
+struct CrudSmallArgs {
+    u32 nu = 0, nr = 0, nl = 0;
+    const u32 *u_idx = nullptr, *u_node = nullptr, *r_idx = nullptr, *l_idx = nullptr;
+    u32* l_out = nullptr;
+    const SmallInline *u_inl = nullptr, *r_inl = nullptr, *l_inl = nullptr;
+    u64 n_obj = 0;
+    DevStats* st = nullptr;
+};
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
                    u32* aff_life = nullptr, u32* done = nullptr, u32 seq = 0, const SmallInline* inl = nullptr, u32 n_obj_chk = 0,
-                   void* stage = nullptr, unsigned int* ticket = nullptr, u32 sa = 0, bool host_io = false);
+                   void* stage = nullptr, unsigned int* ticket = nullptr, u32 sa = 0, bool host_io = false,
+                   const CrudSmallArgs* crud = nullptr);
+void launch_crud_small(const CrudSmallArgs& c, u32* assign, const u32* load, u32 m, u64* used_or_null, u32* aff_life, u32* done,
+                       u32 seq, hipStream_t s);
 // --- place_pending, the general request path (k_ppm_first / k_ppm_gather / solve of the virtual table / k_ppm_output) ---
 // bad: device word, 0 between calls (raised by k_ppm_first on an invalid entry, put back by k_ppm_output's last workgroup);
 // s_idx / s_req: the library's padded device copies of the requests, written on the way (use THEM afterwards: idx / req may be

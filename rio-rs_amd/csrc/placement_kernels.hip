@@ -2533,15 +2533,19 @@ __device__ __forceinline__ u32 inl_sel(const uint4 v, u32 k) { return k == 0 ? v
 
 // lookup, micro-batch (n <= kSmallBatch): one workgroup; requests inline (ninl = n <= 4) or in mapped pinned memory,
 // results into mapped pinned memory, then the completion word
-__global__ __launch_bounds__(kSmallBatch) void k_lookup_small(const u32* __restrict__ assign, u64 n_obj,
-                                                              const u32* __restrict__ idx, u32 n, u32* __restrict__ out,
-                                                              DevStats* st, u32* done, u32 seq, u32 ninl, uint4 ia) {
+__device__ __forceinline__ void dev_lookup_small(const u32* __restrict__ assign, u64 n_obj, const u32* __restrict__ idx, u32 n,
+                                                 u32* __restrict__ out, DevStats* st, u32 ninl, uint4 ia) {
     const u32 k = threadIdx.x;
     if (k < n) {
         const u32 i = ninl ? inl_sel(ia, k) : idx[k];
         if (i < n_obj) out[k] = assign[i];
         else { out[k] = kNone; atomicAdd(&st->err, 1ull); }
     }
+}
+__global__ __launch_bounds__(kSmallBatch) void k_lookup_small(const u32* __restrict__ assign, u64 n_obj,
+                                                              const u32* __restrict__ idx, u32 n, u32* __restrict__ out,
+                                                              DevStats* st, u32* done, u32 seq, u32 ninl, uint4 ia) {
+    dev_lookup_small(assign, n_obj, idx, n, out, st, ninl, ia);
     signal_done(done, seq);
 }
 
@@ -2635,17 +2639,15 @@ __global__ void k_update_apply(u32* __restrict__ assign, u64 n_obj, u32 m, const
 }
 // update, micro-batch (n <= kSmallBatch): one workgroup, one launch; entries were validated by the host and may sit in
 // mapped host memory.  Sequential last-writer-wins inside the batch: an entry loses to any LATER entry for the same row.
-__global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
-                                                              const u32* __restrict__ node, u32 n,
-                                                              u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl,
-                                                              uint4 ia, uint4 ib, u64* __restrict__ used,
-                                                              const u32* __restrict__ load, u32 m) {
+// (the body: every one of the workgroup's kSmallBatch threads calls it; hkey / hpos = 2 * kSmallBatch LDS words each)
+__device__ __forceinline__ void dev_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
+                                                 const u32* __restrict__ node, u32 n, u32* __restrict__ aff_life, u32 ninl,
+                                                 uint4 ia, uint4 ib, u64* __restrict__ used, const u32* __restrict__ load,
+                                                 u32 m, u32* hkey, u32* hpos) {
     // Last writer per row through a small open-addressing table in LDS (2 x kSmallBatch slots, linear probing): the row id
     // claims a slot with a compare-and-swap, the batch positions meet in an atomic max.  (Comparing every entry with every
     // later one, the first version, is 256 dependent LDS reads for the first entry of a full batch: 7.5 us of kernel time.)
     constexpr u32 kSlots = 2 * kSmallBatch;
-    __shared__ u32 hkey[kSlots];
-    __shared__ u32 hpos[kSlots];
     const u32 k = threadIdx.x;
     for (u32 q = k; q < kSlots; q += kSmallBatch) { hkey[q] = kNone; hpos[q] = 0; }
     u32 i = kNone, nd = kNone, old = kNone, li = 0;
@@ -2675,15 +2677,23 @@ __global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ 
             if (nd < m) atomicAdd(&used[nd], (u64)li);
         }
     }
+}
+__global__ __launch_bounds__(kSmallBatch) void k_update_small(u32* __restrict__ assign, const u32* __restrict__ idx,
+                                                              const u32* __restrict__ node, u32 n,
+                                                              u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl,
+                                                              uint4 ia, uint4 ib, u64* __restrict__ used,
+                                                              const u32* __restrict__ load, u32 m) {
+    __shared__ u32 hkey[2 * kSmallBatch];
+    __shared__ u32 hpos[2 * kSmallBatch];
+    dev_update_small(assign, idx, node, n, aff_life, ninl, ia, ib, used, load, m, hkey, hpos);
     signal_done(done, seq);  // the host may reuse the staging rows once the word is there
 }
 
 // remove, micro-batch (n <= kSmallBatch): one small workgroup, the released load goes straight to `used` (a handful of atomics;
 // the big kernel's per-node LDS histogram — 1 024 threads, two passes over m words — was 12 us of a one-entry call)
-__global__ __launch_bounds__(kSmallBatch) void k_remove_small(u32* __restrict__ assign, u32 m, const u32* __restrict__ load,
-                                                              const u32* __restrict__ idx, u32 n, u64* __restrict__ used,
-                                                              u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl,
-                                                              uint4 ia) {
+__device__ __forceinline__ void dev_remove_small(u32* __restrict__ assign, u32 m, const u32* __restrict__ load,
+                                                 const u32* __restrict__ idx, u32 n, u64* __restrict__ used,
+                                                 u32* __restrict__ aff_life, u32 ninl, uint4 ia) {
     const u32 k = threadIdx.x;
     if (k < n) {
         const u32 i = ninl ? inl_sel(ia, k) : idx[k];
@@ -2692,6 +2702,50 @@ __global__ __launch_bounds__(kSmallBatch) void k_remove_small(u32* __restrict__ 
         if (used && old < m) atomicAdd(&used[old], (u64)0 - (u64)li);
         if (aff_life) aff_life[i] = kAffInactive;  // row lifecycle: a removed key is no longer an object
     }
+}
+__global__ __launch_bounds__(kSmallBatch) void k_remove_small(u32* __restrict__ assign, u32 m, const u32* __restrict__ load,
+                                                              const u32* __restrict__ idx, u32 n, u64* __restrict__ used,
+                                                              u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl,
+                                                              uint4 ia) {
+    dev_remove_small(assign, m, load, idx, n, used, aff_life, ninl, ia);
+    signal_done(done, seq);
+}
+
+// The update / remove / lookup parts of a mixed micro-batch (rio_gp_mixed_batch), each <= kSmallBatch validated entries, run
+// in that order by ONE workgroup of kSmallBatch threads — alone (k_crud_small) or in front of the place_pending part
+// (k_pp_one<kSmallBatch, 1>): the callers of one generation asked for different things, the device is asked once.  Between
+// the parts the workgroup fences its stores at device scope and meets at a barrier: the next part reads what this one wrote.
+struct CrudSmall {
+    u32 nu, nr, nl;               // entries per part (0: the part is absent)
+    u32 u_ninl, r_ninl, l_ninl;   // != 0: the part's entries ride in the kernel arguments (n <= 4)
+    const u32 *u_idx, *u_node, *r_idx, *l_idx;
+    u32* l_out;
+    uint4 u_ia, u_ib, r_ia, l_ia;
+    u64 n_obj;
+    DevStats* st;
+};
+__device__ __forceinline__ void dev_crud_small(const CrudSmall& c, u32* __restrict__ assign, const u32* __restrict__ load, u32 m,
+                                               u64* __restrict__ used, u32* __restrict__ aff_life, u32* hkey, u32* hpos,
+                                               bool more_follows) {
+    if (c.nu) {
+        dev_update_small(assign, c.u_idx, c.u_node, c.nu, aff_life, c.u_ninl, c.u_ia, c.u_ib, used, load, m, hkey, hpos);
+        if (c.nr | c.nl || more_follows) { __threadfence(); __syncthreads(); }
+    }
+    if (c.nr) {
+        dev_remove_small(assign, m, load, c.r_idx, c.nr, used, aff_life, c.r_ninl, c.r_ia);
+        if (c.nl || more_follows) { __threadfence(); __syncthreads(); }
+    }
+    if (c.nl) {
+        dev_lookup_small(assign, c.n_obj, c.l_idx, c.nl, c.l_out, c.st, c.l_ninl, c.l_ia);
+        if (more_follows) __syncthreads();  // (reads only: nothing to fence; the LDS tables are reused)
+    }
+}
+__global__ __launch_bounds__(kSmallBatch) void k_crud_small(CrudSmall c, u32* __restrict__ assign, const u32* __restrict__ load,
+                                                            u32 m, u64* __restrict__ used, u32* __restrict__ aff_life, u32* done,
+                                                            u32 seq) {
+    __shared__ u32 hkey[2 * kSmallBatch];
+    __shared__ u32 hpos[2 * kSmallBatch];
+    dev_crud_small(c, assign, load, m, used, aff_life, hkey, hpos, false);
     signal_done(done, seq);
 }
 
@@ -3631,7 +3685,8 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
                                                     const u32* __restrict__ req, u32 n, u32* __restrict__ out_node,
                                                     u32* __restrict__ out_flag, u32* __restrict__ status,
                                                     u32* __restrict__ aff_life, u32* done, u32 seq, u32 ninl, uint4 ia,
-                                                    uint4 ib, u32 n_obj_chk, u32 trace, u32 sa) {
+                                                    uint4 ib, u32 n_obj_chk, u32 trace, u32 sa, const CrudSmall crud) {
+    // crud (micro-batches only): the update / remove / lookup parts of a mixed batch, applied before the requests are looked at
     // n_obj_chk != 0 (requests the host has not seen: rio_gp_place_pending_dev): the number of rows — an object index or a
     // requester out of range ends the call with status 3 and nothing changed; the arrays are then exactly n entries long
     // (no whole vector past the end)
@@ -3644,6 +3699,8 @@ __global__ __launch_bounds__(THREADS) void k_pp_one(u32* __restrict__ assign, co
     const u32 tid = threadIdx.x;
     (void)trace;
     RIOGP_KTF(trace, 6, 0);
+    if (PER == 1 && THREADS == kSmallBatch && (crud.nu | crud.nr | crud.nl))
+        dev_crud_small(crud, assign, load, m, used, aff_life, hkey, hpos, true);  // (its tables: this kernel's, kSlots = 2 * kSmallBatch)
     if (tid == 0) { s_general = m > kPpTot ? 1u : 0u; s_bad = 0; }
     for (u32 q = tid; q < kSlots; q += THREADS) { hkey[q] = kNone; hpos[q] = kNone; }
     for (u32 q = tid; q < kPpTot; q += THREADS) s_tot[q] = 0;
@@ -4748,10 +4805,20 @@ void launch_pack_alive(const uint8_t* alive_bytes, u32 m, u32* alive_bits, hipSt
     if (!w) return;
     hipLaunchKernelGGL(k_pack_alive, dim3((w + 63) / 64), dim3(64), 0, s, alive_bytes, m, alive_bits);
 }
+static CrudSmall crud_small_of(const CrudSmallArgs& a) {
+    CrudSmall c = CrudSmall();
+    c.nu = a.nu; c.nr = a.nr; c.nl = a.nl;
+    c.u_idx = a.u_idx; c.u_node = a.u_node; c.r_idx = a.r_idx; c.l_idx = a.l_idx; c.l_out = a.l_out;
+    c.n_obj = a.n_obj; c.st = a.st;
+    if (a.u_inl) { c.u_ninl = a.nu; c.u_ia = inl_a(a.u_inl); c.u_ib = inl_b(a.u_inl); }
+    if (a.r_inl) { c.r_ninl = a.nr; c.r_ia = inl_a(a.r_inl); }
+    if (a.l_inl) { c.l_ninl = a.nl; c.l_ia = inl_a(a.l_inl); }
+    return c;
+}
 void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u32* alive_bits, u64* used,
                    const u32* idx, const u32* req, u32 n, u32* out_node, u32* out_flag, u32* status, hipStream_t s,
                    u32* aff_life, u32* done, u32 seq, const SmallInline* inl, u32 n_obj_chk, void* stage, unsigned int* ticket, u32 sa,
-                   bool host_io) {
+                   bool host_io, const CrudSmallArgs* crud) {
     // Three launches (stage | decide | apply) when the requests and results are mapped HOST memory and the batch is beyond the
     // small kernel's 256: the one-workgroup kernel reads them over PCIe from ONE compute unit.  Same run, us per call,
     // one workgroup -> three launches: 300 requests 26-28 -> 24.7-24.9, 1 000: 28.3-33 -> 25.2-26, 1 024: 28.5-33 -> 24.8-26.4
@@ -4769,15 +4836,21 @@ void launch_pp_one(u32* assign, const u32* load, u32 m, const u64* cap, const u3
         hipLaunchKernelGGL(k_pp_apply, dim3(g), dim3(256), 0, s, assign, rec, res, n, out_node, out_flag, st, aff_life, ticket, done, seq);
         return;
     }
+    const CrudSmall none = CrudSmall();
     if (n <= (u32)kSmallBatch) {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kSmallBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kSmallBatch, 1>), dim3(1), dim3(kSmallBatch), lds, s, assign, load, m, cap, alive_bits, used,
-                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl), n_obj_chk, trace_flag(), sa);
+                           idx, req, n, out_node, out_flag, status, aff_life, done, seq, inl ? n : 0u, inl_a(inl), inl_b(inl), n_obj_chk, trace_flag(), sa,
+                           crud ? crud_small_of(*crud) : none);
     } else {
         const size_t lds = (size_t)kPpTot * sizeof(u64) + (size_t)2 * (2 * kOneBatch) * sizeof(u32);
         hipLaunchKernelGGL((k_pp_one<kBlock, kOneBatch / kBlock>), dim3(1), dim3(kBlock), lds, s, assign, load, m, cap, alive_bits,
-                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk, trace_flag(), sa);
+                           used, idx, req, n, out_node, out_flag, status, aff_life, done, seq, 0u, inl_a(nullptr), inl_b(nullptr), n_obj_chk, trace_flag(), sa, none);
     }
+}
+void launch_crud_small(const CrudSmallArgs& c, u32* assign, const u32* load, u32 m, u64* used, u32* aff_life, u32* done, u32 seq,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_crud_small, dim3(1), dim3(kSmallBatch), 0, s, crud_small_of(c), assign, load, m, used, aff_life, done, seq);
 }
 // every non-null pointer is 16-byte aligned (the kernels' dwordx4 paths; a caller's device arrays may start anywhere)
 template <typename... P>

@@ -1643,9 +1643,9 @@ int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uin
     return place_pending_host_locked(h, n, idx, requester, out_node, out_flag, false);
 }
 
-// Up to kSmallBatch entries of EACH of update / remove / lookup / place_pending, executed in that order, as ONE enqueue and ONE
-// host wait: the four micro-batch kernels go onto the stream back to back (each a single workgroup, the stream orders them),
-// only the last one stores the completion word.  What the string layer's combiner sends when the callers of one generation
+// Up to kSmallBatch entries of EACH of update / remove / lookup / place_pending, executed in that order, as ONE launch and ONE
+// host wait: one workgroup runs the parts one after the other (k_pp_one<256, 1> with the other parts in front of the requests,
+// k_crud_small when there are no requests), a device-scope fence and a barrier between them, one completion word.  What the string layer's combiner sends when the callers of one generation
 // asked for different things (a server's connections mix lookups, first touches and removals: service.rs:193-254,
 // server.rs:292-304): one round trip instead of one per kind.
 int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
@@ -1681,18 +1681,61 @@ int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
             ops->rc[3] = fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: object index or requester out of range");
             run[3] = false;
         }
-    int last = -1;
-    for (int k = 0; k < 4; ++k)
-        if (run[k]) last = k;
-    if (last < 0) return RIO_GP_OK;
+    const int kinds = (int)run[0] + (int)run[1] + (int)run[2] + (int)run[3];
+    if (!kinds) return RIO_GP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     // staging: the place_pending entries where its own call has them (h_small); update / remove / lookup in the first row of the
     // medium-batch area (mapped pinned memory as well) — [0] update idx | [1] update node | [2] remove idx | [3] lookup idx |
-    // [4] lookup out.  The lookup kernel has its own completion word (h_small row 5, word 16: only ever holds sequence
-    // numbers): its results are host memory, the host reads them behind a fence of the kernel that wrote them
+    // [4] lookup out
     u32 *hm = h->h_mid, *dm = h->d_mid;
+    u32 *hs = h->h_small, *ds = h->d_small;
     const u32 seq = small_begin(h);
+    if (kinds >= 2) {
+        // ONE launch: the update / remove / lookup parts run in front of the requests inside the one-workgroup request kernel
+        // (k_pp_one<256, 1>), or alone (k_crud_small) when nobody asked for a placement
+        SmallInline iu, ir, il, ip;
+        CrudSmallArgs c;
+        c.n_obj = h->n; c.st = h->dstats;
+        fold_used(h);
+        if (run[3]) {
+            flush_alive(h);
+            if ((rc = ensure_used(h))) return rc;
+        }
+        if (run[0]) {
+            c.nu = nu; c.u_idx = dm; c.u_node = dm + kSmallBatch;
+            if (small_inline(&iu, nu, ops->update_idx, ops->update_node)) c.u_inl = &iu;
+            else {
+                memcpy(hm, ops->update_idx, nu * sizeof(u32));
+                memcpy(hm + kSmallBatch, ops->update_node, nu * sizeof(u32));
+            }
+        }
+        if (run[1]) {
+            c.nr = nr; c.r_idx = dm + 2 * kSmallBatch;
+            if (small_inline(&ir, nr, ops->remove_idx, nullptr)) c.r_inl = &ir;
+            else memcpy(hm + 2 * kSmallBatch, ops->remove_idx, nr * sizeof(u32));
+        }
+        if (run[2]) {
+            c.nl = nl; c.l_idx = dm + 3 * kSmallBatch; c.l_out = dm + 4 * kSmallBatch;
+            if (small_inline(&il, nl, ops->lookup_idx, nullptr)) c.l_inl = &il;
+            else memcpy(hm + 3 * kSmallBatch, ops->lookup_idx, nl * sizeof(u32));
+        }
+        if (run[0] || run[1] || run[3]) { h->have_solved = false; ++h->mut_epoch; }
+        if (run[3]) {
+            const bool in_args = small_inline(&ip, np, ops->place_idx, ops->place_requester);
+            if (!in_args) {
+                memcpy(hs, ops->place_idx, np * sizeof(u32));
+                memcpy(hs + kSmallBatch, ops->place_requester, np * sizeof(u32));
+            }
+            hs[4 * kSmallBatch] = 2;  // neither 0 nor 1: the kernel must write it
+            launch_pp_one(h->assign[h->cur], h->load, h->m, h->cap, h->alive_bits, h->used, ds, ds + kSmallBatch, np,
+                          ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h), small_done_dev(h), seq,
+                          in_args ? &ip : nullptr, 0, nullptr, nullptr, h->sa, false, &c);
+        } else {
+            launch_crud_small(c, h->assign[h->cur], h->load, h->m, h->used_valid ? h->used : nullptr, aff_life(h), small_done_dev(h), seq,
+                              h->stream);
+        }
+    } else {
     SmallInline inl;
     if (run[0]) {
         const bool in_args = small_inline(&inl, nu, ops->update_idx, ops->update_node);
@@ -1701,7 +1744,7 @@ int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
             memcpy(hm + kSmallBatch, ops->update_node, nu * sizeof(u32));
         }
         fold_used(h);
-        launch_update_small(h->assign[h->cur], dm, dm + kSmallBatch, nu, h->stream, aff_life(h), last == 0 ? small_done_dev(h) : nullptr,
+        launch_update_small(h->assign[h->cur], dm, dm + kSmallBatch, nu, h->stream, aff_life(h), small_done_dev(h),
                             seq, in_args ? &inl : nullptr, h->used_valid ? h->used : nullptr, h->load, h->m);
         h->have_solved = false; ++h->mut_epoch;
     }
@@ -1710,16 +1753,15 @@ int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
         if (!in_args) memcpy(hm + 2 * kSmallBatch, ops->remove_idx, nr * sizeof(u32));
         fold_used(h);
         launch_remove_small(h->assign[h->cur], h->m, h->load, dm + 2 * kSmallBatch, nr, h->used_valid ? h->used : nullptr, h->stream,
-                            aff_life(h), last == 1 ? small_done_dev(h) : nullptr, seq, in_args ? &inl : nullptr);
+                            aff_life(h), small_done_dev(h), seq, in_args ? &inl : nullptr);
         h->have_solved = false; ++h->mut_epoch;
     }
     if (run[2]) {
         const bool in_args = small_inline(&inl, nl, ops->lookup_idx, nullptr);
         if (!in_args) memcpy(hm + 3 * kSmallBatch, ops->lookup_idx, nl * sizeof(u32));
         launch_lookup_small(h->assign[h->cur], h->n, dm + 3 * kSmallBatch, nl, dm + 4 * kSmallBatch, h->dstats, h->stream,
-                            last == 2 ? small_done_dev(h) : small_done_dev(h) + 16, seq, in_args ? &inl : nullptr);
+                            small_done_dev(h), seq, in_args ? &inl : nullptr);
     }
-    u32 *hs = h->h_small, *ds = h->d_small;
     if (run[3]) {
         flush_alive(h);
         if ((rc = ensure_used(h))) return rc;
@@ -1733,11 +1775,9 @@ int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
                       ds + 2 * kSmallBatch, ds + 3 * kSmallBatch, ds + 4 * kSmallBatch, h->stream, aff_life(h), small_done_dev(h), seq,
                       in_args ? &inl : nullptr, 0, nullptr, nullptr, h->sa);
     }
-    if ((rc = small_wait(h, seq))) return rc;
-    if (run[2]) {
-        if (last != 2 && (rc = small_wait(h, seq, h->h_small + 5 * kSmallBatch + 16))) return rc;
-        memcpy(ops->lookup_out, hm + 4 * kSmallBatch, nl * sizeof(u32));
     }
+    if ((rc = small_wait(h, seq))) return rc;
+    if (run[2]) memcpy(ops->lookup_out, hm + 4 * kSmallBatch, nl * sizeof(u32));  // (stored by the kernel whose fence precedes the word)
     if (run[3]) {
         const u32 status = hs[4 * kSmallBatch];
         if (status == 0) {
