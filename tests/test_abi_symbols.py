@@ -229,6 +229,33 @@ def test_ctypes_binding_matches_the_headers():
     assert checked >= 60
 
 
+def test_ctypes_structures_have_the_c_layout(tmp_path):
+    """Every ctypes.Structure of the binding against the C compiler's view of the same typedef: size and the offset of every
+    field (a struct that drifts corrupts a call silently — rio_gp_mixed carries eleven pointers)."""
+    import ctypes as C
+    import rio_gp
+    pairs = (("rio_gp_cfg", rio_gp.Cfg), ("rio_gp_stats", rio_gp.Stats), ("rio_gp_mixed", rio_gp.Mixed), ("rio_op_cfg", rio_gp.OpCfg))
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "rio_gpu_object_placement.h"', "int main(void) {"]
+    for cname, st in pairs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f in st._fields_:
+            lines.append('printf(" %s=%%zu", offsetof(%s, %s));' % (f[0], cname, f[0]))
+        lines.append('printf("\\n");')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == len(pairs)
+    for line, (cname, st) in zip(out, pairs):
+        parts = line.split()
+        assert parts[0] == cname and int(parts[1]) == C.sizeof(st), (cname, parts[1], C.sizeof(st))
+        for tok in parts[2:]:
+            name, off = tok.split("=")
+            assert getattr(st, name).offset == int(off), (cname, name, getattr(st, name).offset, off)
+
+
 def test_rust_structs_mirror_the_c_layout():
     """#[repr(C)] structs of gpu.rs: same field names, in the same order, as the header's typedefs."""
     rs = open(os.path.join(ROOT, "rio-rs_amd", "rust", "src", "gpu.rs")).read()
