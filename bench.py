@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC passes (roofline.traffic falls back to profiles/)")
     ap.add_argument("--no-c4", action="store_true", help="N=1: skip the config-4-on-one-GPU data point (100 M x 4 096)")
     ap.add_argument("--no-c2", action="store_true", help="N=1: skip the config-2 record (1 M x 256)")
+    ap.add_argument("--no-binding", action="store_true",
+                    help="N=1: skip the two records of the solve in which capacity binds (config3_contended, config3_skew)")
     ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 record (10 % churn per tick, 110 ticks + oracle replay)")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaled config-3 second measurement")
     ap.add_argument("--no-sharded-churn", action="store_true", help="N>1: skip the committed / churn tick streams of the sharded table")
@@ -517,6 +519,74 @@ def churn_record(a, g, cfg, rio_gp, local_rank, steps=None, warmup=None):
                              "bitmap from mapped pinned memory) + k_rebal (pending rows dealt out evenly, per-block histograms) + "
                              "k_resolve<SEARCH> + k_fill (round 0) + k_fill (round 1)",
     }
+
+
+def binding_record(a, cfg, rio_gp, local_rank, which, reps=30, warmup=4):
+    """The solve in which CAPACITY BINDS, on the driver's line (north_star: "min-cost bin-packing placements for all pending
+    activations at once").  The headline ticks of config 3 never cut or spill; these two tables do:
+      contended  config 3 with 0.72 x its capacities (0.9 x the load fits): ~1 020 of the 1 024 nodes are cut, ~1 M rows
+                 go on to the water-fill, most of them stay unplaced;
+      skew       config 3 with Lomax(1.1) affinities: a few servers asked for by most objects, ~94 % of the rows water-filled.
+    A step = ONE committed whole-table solve of the COLD table (rio_gp_tick: scan, resolve, exact cuts, water-fill rounds,
+    commit, the host reads the counters); the table is put back to all-NONE between two steps by a device-to-device copy that
+    is NOT timed.  Second figure: round 5's method (the same cold table re-solved back to back, rio_gp_solve, never committed).
+    Parity: the committed column, `used` and the counters against orc_tick of the same table at full size, in this run."""
+    import pyoracle
+    import synth
+    import hipbuf
+    n, m = cfg["n"], cfg["m"]
+    if which == "contended":
+        cap, aff = synth.contended_cap(cfg), cfg["aff"]
+        what = "config 3 (%d objects x %d nodes, Zipf(1.1) load) with 0.72 x the capacities: 0.9 x the total load fits" % (n, m)
+    else:
+        cap, aff = cfg["cap"], synth.skew_affinity(n, m)
+        what = "config 3 (%d objects x %d nodes, Zipf(1.1) load, cap 1.25x) with Lomax(1.1) affinities (synth.skew_affinity)" % (n, m)
+    g = rio_gp.GpuPlacement(n, m, device=local_rank)
+    g.set_nodes(cap, cfg["alive"])
+    g.set_objects(n, cfg["load"], aff)
+    cold = hipbuf.DevBuf(cfg["cur"])
+    st = rio_gp.Stats()
+    wall = []
+    for k in range(warmup + reps):
+        g.set_assign_dev(n, cold.ptr)     # (waits for the copy: nothing of it is inside the timed call)
+        t0 = time.perf_counter()
+        g.tick_struct(st)                 # solve + fix-up + commit; returns with the counters
+        if k >= warmup:
+            wall.append(time.perf_counter() - t0)
+    last = st.as_dict()
+    parity = None
+    if not a.no_parity:
+        t1 = time.perf_counter()
+        want, used, ost = pyoracle.tick(cfg["cur"], cfg["load"], aff, cap, cfg["alive"], 2)
+        eq_a = bool(np.array_equal(g.get_assign(), want))
+        eq_u = bool(np.array_equal(g.get_nodes()[2], used))
+        parity = {"checked_rows": int(n), "equal": eq_a and eq_u and last == ost, "assign_equal": eq_a, "used_equal": eq_u,
+                  "stats_equal": last == ost, "against": "oracle/placement_oracle.c orc_tick on the same table, same run "
+                  "(the table as the last timed committed solve left it)", "oracle_seconds": time.perf_counter() - t1}
+        if last != ost:
+            parity["stats_gpu"], parity["stats_oracle"] = last, ost
+    g.set_assign_dev(n, cold.ptr)
+    for _ in range(warmup):
+        g.solve()
+    g.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ust = g.solve()
+    unc = (time.perf_counter() - t0) / reps
+    g.close()
+    cold.free()
+    sec = float(np.median(wall))
+    fr = lambda s_: ALGO_BYTES_PER_DECISION * n / s_ / 1e9 / HBM_PEAK_GBPS
+    return {"workload": what, "steps": reps, "warmup": warmup,
+            "us_per_solve": sec * 1e6, "us_per_solve_p10_p90": [float(np.percentile(wall, 10)) * 1e6, float(np.percentile(wall, 90)) * 1e6],
+            "value": n / sec, "unit": "decisions/s", "frac": fr(sec),
+            "step": "rio_gp_tick on the cold table: ONE committed whole-table solve per step, synchronous (median of the steps; "
+                    "the reset of the table between steps is not timed)",
+            "slow_path": int(last["slow_path"]), "cut_nodes": int(last["cut_nodes"]), "stats": last,
+            "uncommitted_back_to_back": {"us_per_solve": unc * 1e6, "frac": fr(unc), "equal_counters": ust == last,
+                                         "step": "rio_gp_solve of the same cold table, back to back, never committed (round 5's method)"},
+            "launches": "k_scan + k_resolve + k_cut_find + k_fill (round 0: re-mark, pack, water-fill) + k_fill (round 1)",
+            "parity": parity}
 
 
 def bench_churn(a, g, cfg, saved_stdout, rio_gp, local_rank):
@@ -1141,6 +1211,13 @@ def main():
                      "note": "16 MB of columns: every launch is a handful of microseconds — latency, not bandwidth", "parity": par2}
         except Exception as e:  # measurement aid only
             c2rec = {"error": repr(e)}
+    bind = {}
+    if not a.no_binding and workload == "c3" and not a.objects:
+        for which in ("contended", "skew"):
+            try:
+                bind[which] = binding_record(a, cfg, rio_gp, local_rank, which)
+            except Exception as e:  # a second measurement: it must not take the line down with it
+                bind[which] = {"error": repr(e)}
     c5rec = None
     if not a.no_c5 and workload == "c3" and not a.objects:
         try:
@@ -1210,6 +1287,8 @@ def main():
             "weak_config3_committed_tick": ({"value": total_decisions / dt, "unit": "decisions/s", "ms_per_tick": tick_s * 1e3, "n_gpus": 1,
                                              "rows_total": n, "exchange": None, "definition": DEF_WEAK} if workload == "c3" and not a.objects else None)},
         "config2": c2rec,
+        "config3_contended": bind.get("contended"),
+        "config3_skew": bind.get("skew"),
         "config4_single_gpu": c4one,
         "config5_churn": c5rec,
         "stats_last_step": st,          # last committed tick of the stream: every row kept where the first tick put it
@@ -1231,7 +1310,8 @@ def main():
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
     bad = [p for p in (parity, (c4one or {}).get("parity"), ((c4one or {}).get("churn_tick_pipelined") or {}).get("parity"),
-                       (c2rec or {}).get("parity"), (c5rec or {}).get("parity"))
+                       (c2rec or {}).get("parity"), (c5rec or {}).get("parity"),
+                       (bind.get("contended") or {}).get("parity"), (bind.get("skew") or {}).get("parity"))
            if p is not None and not p["equal"]]
     if bad:
         sys.exit(3)

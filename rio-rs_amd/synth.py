@@ -114,3 +114,19 @@ def churn_mask(m, tick, frac=0.10, seed=SEED):
     alive = np.ones(m, np.uint8)
     alive[dead] = 0
     return alive
+
+
+# ---- the two tables on which CAPACITY BINDS (the solver's bin-packing part runs: cuts, water-fill, unplaced rows) ----
+
+def contended_cap(cfg, factor=0.72):
+    """Config 3 with 0.72 x its capacities: 0.9 x the total load fits, every node is cut, ~10 % of the rows go on to the
+    water-fill and most of those stay unplaced (service.rs:244-252 has no such limit: this is the solver's own rule)."""
+    return (cfg["cap"].astype(np.float64) * factor).astype(np.uint64)
+
+
+def skew_affinity(n, m, shape=1.1, stream=5, seed=SEED, start=0):
+    """Affinities from a Lomax(shape) tail by inverse CDF over r(i, 5), clipped to the last node: most objects ask for
+    the first few servers, which are cut within their first claimants; ~94 % of the rows are water-filled elsewhere."""
+    u = (r(np.arange(start, start + n, dtype=np.uint64), stream, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    x = np.power(1.0 - u, -1.0 / shape) - 1.0
+    return np.minimum(x, float(m - 1)).astype(np.int64).astype(np.uint32)
