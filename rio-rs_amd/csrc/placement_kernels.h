@@ -204,6 +204,12 @@ void launch_cut_find(const Plan& p, const Table& t, const NodeTab& nt, const Sol
 void launch_fill(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool apply, bool fill,
                  int round, bool last, hipStream_t s, const PackOut* pack = nullptr);
 bool fill_can_pack(u32 m);
+// k_cut_apply (real table of one GPU, whole-table solves): the exact cut search and the re-marking pass as ONE pass over the
+// rows — replaces launch_cut_find + the apply half of round 0; the rounds behind it are launch_fill(apply = false) from round 0
+// on, over pk (pack: Plan::wcnt = pk.wcnt, Table::none_prewritten) or over the table (pk is scratch for the undecided rows)
+bool cut_apply_fits(u32 m);
+void launch_cut_apply(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, const PackOut& pk, bool pack,
+                      bool all_alive, hipStream_t s);
 // used[j] += D[0][j] + ... + D[rounds-1][j]
 void launch_used_fold(u64* used, const u64* D, u32 m, u32 rounds, hipStream_t s);
 #ifdef RIO_GP_LAB

@@ -2062,6 +2062,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
     if (p.wcnt && wstart + wc < wend) wend = wstart + wc;  // packed rows: only the first wcnt[gw] positions hold rows
     u64 bstart = wstart, bend = wend;                      // pass B's rows
     if (FILL && !APPLY && pc == 0) bend = bstart;          // no pending row in this wave's range (later rounds: most waves)
+    u32 own_cnt = pc;                                      // pending rows of this wave's range (APPLY: counted by pass A)
     // first tile of the wave's rows: pass A's columns (APPLY) or pass B's (FILL only)
     const u64 rs = (wstart < wend ? wstart : 0ull) + (u64)lane * 4;
     uint4 cvn = make_uint4(0, 0, 0, 0), avn = cvn, lvn = cvn, nvn = cvn, ivn = cvn;
@@ -2268,6 +2269,7 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
         // pass B runs over what pass A left: the packed rows (PACK) or the same rows with their new marks
         if (PACK) { bstart = wstart; bend = pk_pos; }
         if (sp_cnt == 0) bend = bstart;
+        own_cnt = sp_cnt;
         __syncthreads();  // wsum complete; thr / alv / rings are dead: the region becomes adm.  (Also orders this wave's
                           // mark / pack stores before its own loads of the same rows below.)
         const u64 rb = (bstart < bend ? bstart : 0ull) + (u64)lane * 4;
@@ -2308,7 +2310,19 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
         lo_run = lo;
     }
     const int last = a.last;
+    // Rows that cannot be placed AND need no store are not read: once the ordered prefix has passed this round's total free
+    // capacity (a cluster that is full: every wave but the first few, from their first row) nothing behind it in the wave's
+    // range can be placed, and no row has to be written when the rows keep their marks for the next round, or (last round over
+    // packed rows whose real rows hold NONE already) nobody reads them again.  What is left is counted from the totals the
+    // previous launch left for this wave.
+    const bool quiet_tail = !last || (bscat && last == 2);
+    const u64 run0 = run;
     for (u64 it = bstart; it < bend; it += kTile) {
+        if (quiet_tail && (cnt == 0 || run >= F)) {  // (wave-uniform)
+            const u32 seen = wave_sum32(pl_cnt + rem_cnt);
+            if (lane == 0) { rem_sum += wsum[wave] - (run - run0); rem_cnt += own_cnt - seen; }
+            break;
+        }
         const u64 i0 = it + (u64)lane * 4;
         const uint4 nv = nvn, lv = lvn, iv = ivn;
         const u64 pit = it + kTile < bend ? it + kTile : it;  // next tile in flight (the last iteration re-reads its own)
@@ -2466,6 +2480,477 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
         if (last && red[5]) { atomicAdd(&a.stats->unplaced, red[5]); atomicAdd(&a.stats->load_unplaced, red[4]); }
     }
     RIOGP_KT(p, kt, 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4c k_cut_apply — the exact cuts AND the re-marking (AND the packing) of a whole-table solve in ONE pass over the rows.
+//     Before: k_cut_find (a pass over the blocks that own cuts, 25 us at 10 M rows) and then pass A of k_fill (another
+//     12 B/row) — two table-wide passes between k_resolve and the water-fill.  What makes one pass enough: after k_resolve a
+//     claimant of node a in block b is admitted when cutblk[a] > b, rejected when cutblk[a] < b, and UNDECIDED only when
+//     cutblk[a] == b — a few dozen rows per (node, block).  A block none of whose nodes is cut at or before it and that holds
+//     no spill candidate has nothing to re-mark and returns at once (a contended cluster: the first 70-90 % of the blocks).
+//     The pass
+//       * streams cur / aff / load once (12 B/row, two tiles in flight), rebuilds the rows' `next` values, rejects and admits
+//         wholesale by cut block;
+//       * packs, in index order, through per-wave LDS rings: PACK — every row that goes on to the water-fill plus the
+//         undecided ones (marked kUndTag | node); else — the undecided rows only (scratch);
+//       * adds every undecided row's load to T[slot][wave] (LDS; slot = the node's number among the nodes cut in this block)
+//         and keeps {packed position, row, load, node} of the wave's undecided rows in an LDS list.
+//     Then, in the blocks that own cuts only: per slot an ordered walk over its sixteen wave sums finds the wave in which the
+//     claim prefix crosses the budget k_resolve left; every wave settles its undecided rows from its list (no global read) —
+//     earlier wave: admitted, later wave: rejected, the cut wave itself: exactly, by load prefix in index order.  Inside the
+//     cut wave a slot's rows of one step (64 rows) are summed without order first; only the ONE step in which the prefix
+//     crosses the budget needs the ordered scan (one DPP scan per crossing).  A wave whose list overflowed (a nearly full
+//     cluster cuts every node in block 0: every row of the block is undecided) walks its packed rows instead; more slots than
+//     fit the LDS: groups of kmax slots, one more walk per further group.
+//     Out: `next` re-marked (PACK: NONE in every row that goes on, so the last round only writes what it places), the packed
+//     rows {row, load, spill mark} + per-wave counts, the ordered spill totals per wave / block (what k_fill<FILL>'s prefix
+//     starts from: R / RP are not needed), cutidx / used_cur of the cut nodes, the rejected rows' counters.
+//     Real table of one GPU only (the request path's virtual table and the row-sharded solve keep k_cut_find + k_fill<APPLY>).
+// ------------------------------------------------------------------------------------------------
+// st[node], and st[m] for every affinity that is not a node: no cut at or before this block | cut in an earlier block | not a
+// claim target (a node that is not alive — unless claims need no live node, Plan::sa — or no node at all) | else: slot
+constexpr u32 kStAdmit = 0xFFFFu, kStReject = 0xFFFEu, kStNoClaim = 0xFFFDu;
+constexpr u32 kUndTag = 0x80000000u;                      // packed mark of an undecided row: kUndTag | node
+constexpr u32 kCaRingCols = 3;
+constexpr u32 kCaList = 256;                              // undecided rows a wave keeps in its LDS list: {node << 19 | packed position, row, load}
+constexpr u32 kCaPosBits = 19;                            // (a wave range of up to 2^19 rows: tables of up to 2^31 rows; beyond: the list is not used)
+struct CaLds { size_t st, node_of, alv, rings, ulist, grp; u32 kmax; size_t total; };
+__host__ __device__ __forceinline__ CaLds ca_lds(u32 m, u32 mwords) {
+    CaLds L;
+    const u32 mr = (m + 8) & ~7u;                           // (m + 1 states)
+    size_t off = 256;                                       // small: counters, per-wave words
+    L.st = off; off += (size_t)mr * 2;
+    L.node_of = off; off += (size_t)mr * 2;
+    off = (off + 15) & ~(size_t)15;
+    L.alv = off; off += (size_t)((mwords + 3) & ~3u) * 4;
+    L.rings = off; off += (size_t)kWaves * kCaRingCols * kStageCap * 4;
+    L.ulist = off; off += (size_t)kWaves * 3 * kCaList * 4;
+    off = (off + 15) & ~(size_t)15;
+    L.grp = off;
+    const size_t per = 17 * 8 + 5 * 8 + 2 * 4;             // T row (odd stride) | rem, pre, accw, ssum, admw | cw, cutrow
+    const size_t avail = (size_t)152 * 1024 - 128 - off;   // (a launch with 163 712 bytes of dynamic LDS was refused: stay clear of the limit)
+    u32 k = (u32)(avail / per);
+    if (k > m) k = (m + 7) & ~7u;
+    if (k > 1024u) k = 1024u;
+    if (k < 8u) k = 8u;
+    L.kmax = k & ~7u;
+    L.total = off + (size_t)L.kmax * per + 64;
+    return L;
+}
+struct CutApplyArgs {
+    const u32* cur; const u32* load; const u32* aff; u32* next;
+    const u32* alive_bits; Plan p;
+    const u32* cutblk; const u64* budget; const u64* admpre; const u64* used_kept;
+    u32* cutidx; u64* used_cur;
+    u64* wsp_sum_out; u32* wsp_cnt_out; u64* bsp_sum_out; u32* bsp_cnt_out;
+    const u32* bsp_cnt_in;           // k_scan's spill candidates per block
+    DevStats* stats; FxRows fx;
+    PackOut pko;                     // PACK: the rows that go on + the undecided ones; else: scratch for the undecided rows
+};
+
+template <bool PACK, bool ALLALIVE>
+__global__ __launch_bounds__(kBlock) void k_cut_apply(const CutApplyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Plan& p = a.p;
+    const u32 m = p.m;
+    const bool sa_ = p.sa != 0;
+    const CaLds L = ca_lds(m, p.mwords);
+    u32& nslot = *reinterpret_cast<u32*>(smem);
+    u64* red = reinterpret_cast<u64*>(smem + 16);                             // [4] pending load, pending rows, rejected rows, rejected load
+    unsigned short* st = reinterpret_cast<unsigned short*>(smem + L.st);      // [mr]
+    unsigned short* node_of = reinterpret_cast<unsigned short*>(smem + L.node_of);
+    u32* alv = reinterpret_cast<u32*>(smem + L.alv);
+    const u32 kmax = L.kmax;
+    u64* T = reinterpret_cast<u64*>(smem + L.grp);                            // [kmax][17]
+    u64* g_rem = T + (size_t)kmax * 17;                                       // [kmax] budget left at the start of the cut wave
+    u64* g_pre = g_rem + kmax;                                                // [kmax] admitted in the waves before it (this block)
+    u64* g_acc = g_pre + kmax;                                                // [kmax] the cut wave's claim load so far
+    u64* g_ssum = g_acc + kmax;                                               // [kmax] ... of the current step
+    u64* g_adm = g_ssum + kmax;                                               // [kmax] admitted inside the cut wave
+    u32* g_cw = reinterpret_cast<u32*>(g_adm + kmax);                         // [kmax] the cut wave (16: none)
+    u32* g_row = g_cw + kmax;                                                 // [kmax] first rejected row
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 b = blockIdx.x;
+    const u64 gw = (u64)b * kWaves + wave;
+    RIOGP_KT(p, 6, 0);
+    // one round trip: the cut flag, this block's spill candidates, the thread's first cutblk word and liveness word
+    const u64 ncut = a.stats->n_cut;
+    const u32 scand = a.bsp_cnt_in[b];
+    const u32 cb0 = a.cutblk[(u32)tid < m ? (u32)tid : m - 1];
+    const u32 ak = (u32)tid < p.mwords ? (u32)tid : p.mwords - 1;
+    const u32 aw = a.alive_bits[ak];
+    u64 wstart, wend;
+    wave_range(p, gw, wstart, wend);
+    // speculative launch behind a solve that needs no fix-up / whose spill candidates k_scan has already marked and counted
+    if (ncut == 0) {
+        if (!PACK) return;
+        if (scand == 0) {
+            if (lane == 0) a.pko.wcnt[gw] = 0;
+            return;
+        }
+    }
+    if (tid == 0) nslot = 0;
+    if (tid < 4) red[tid] = 0;
+    alv[ak] = aw;
+    __syncthreads();
+    bool work = false;  // a node whose claimants of this block are not all admitted
+    for (u32 j = tid; j < m; j += kBlock) {
+        const u32 cb = j == (u32)tid ? cb0 : a.cutblk[j];
+        u32 s = kStAdmit;
+        if (!ALLALIVE && !sa_ && !bit_of(alv, j)) s = kStNoClaim;  // (a node without claimants has no cut)
+        else if (cb < b) s = kStReject;
+        else if (cb == b) { s = atomicAdd(&nslot, 1u); node_of[s] = (unsigned short)j; }
+        st[j] = (unsigned short)s;
+        work |= s == kStReject || s < kStNoClaim;
+    }
+    if (tid == 0) st[m] = (unsigned short)kStNoClaim;
+    if (!__syncthreads_or(work) && scand == 0) {
+        // every claimant of this block is admitted and k_scan found no spill candidate in it: its rows stand as k_scan wrote them
+        if (lane == 0) {
+            a.pko.wcnt[gw] = 0;
+            a.wsp_sum_out[gw] = 0;
+            a.wsp_cnt_out[gw] = 0;
+        }
+        if (tid == 0) { a.bsp_sum_out[b] = 0; a.bsp_cnt_out[b] = 0; }
+        return;
+    }
+    const u32 ns = nslot;
+    const u64 span = wend > wstart ? wend - wstart : 0;
+    const u64 wgrp = wstart + (span / (kTile * 2)) * (kTile * 2);
+    u64 it = wstart;
+    uint4 cv[2], av[2], lv[2];
+    if (it < wgrp) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u64 i = it + (u64)q * kTile + (u64)lane * 4;
+            cv[q] = *reinterpret_cast<const uint4*>(a.cur + i);
+            av[q] = *reinterpret_cast<const uint4*>(a.aff + i);
+            lv[q] = *reinterpret_cast<const uint4*>(a.load + i);
+        }
+    }
+    if (ns) {
+        const u32 k0 = (ns < kmax ? ns : kmax) * 17;
+        for (u32 k = tid; k < k0; k += kBlock) T[k] = 0;
+        __syncthreads();
+    }
+    RIOGP_KT(p, 6, 1);
+
+    // Counters of the main pass: pending = rows that go on to the water-fill (rejected claimants + spill candidates); the
+    // candidates (k_scan's spill marks: rare) are counted apart, the rejected rows are the difference.  Row counts are
+    // wave-uniform popcounts of ballots; the loads are summed per lane.
+    u64 pend_sum = 0, cand_sum = 0;        // per lane
+    u32 pend_cnt = 0, cand_cnt = 0;        // wave-uniform
+    u64 sp_sum = 0, rej_sum = 0;           // what the settle step adds (per lane)
+    u32 sp_cnt = 0, rej_cnt = 0;
+    u64 pk_pos = wstart;
+    u32* stage = reinterpret_cast<u32*>(smem + L.rings) + (size_t)wave * kCaRingCols * kStageCap;
+    u32* ul = reinterpret_cast<u32*>(smem + L.ulist) + (size_t)wave * 3 * kCaList;  // [3][kCaList] node << 19 | position (from wstart) | row | load
+    // undecided rows of this wave (all of them: beyond kCaList the list is not used; nor when a position does not fit its field)
+    u32 ul_n = (wend - wstart) >> kCaPosBits ? kCaList + 1 : 0;
+    u32 st_head = 0, st_fill = 0;
+    const u64 lt = (1ull << lane) - 1ull;
+    u64* const Tw = T + wave;
+    constexpr u32 kMark = PACK ? kNone : kSpillMark;
+
+    // One tile.  The blocks behind the cuts of a contended cluster are bound by the INSTRUCTIONS of this body (60 busy CUs, every
+    // row of theirs packed: 16 waves x 10 tiles per CU), so the row classes stay lane masks (compares feeding selects and
+    // ballots: scalar registers, no vector bit-fiddling), the row counters are popcounts, and everything that is rare — spill
+    // candidates, undecided rows, partly packed tiles — sits behind a wave-uniform branch.
+#ifdef RIO_GP_LAB   // timing experiments only (results are wrong): trace flag bit 1 = no pack stores, bit 2 = no `next` stores
+    const bool dbg_nopack = (p.trace & 2u) != 0, dbg_nonext = (p.trace & 4u) != 0;
+#else
+    constexpr bool dbg_nopack = false, dbg_nonext = false;
+#endif
+    auto tile = [&](const uint4 c, const uint4 aa, const uint4 l, const u64 i0, const bool check) {
+        uint4 ov;
+        // A row is pending unless it sits on a live node; what becomes of a pending row is ONE table look-up by its affinity
+        // (st[], liveness of the claim target folded in): admitted | rejected | undecided (slot) | no claim target.
+#define RIOGP_ROW(CC, A, LL, O, E, PD, UN, SP, AX)                                                    \
+        const bool nk##E = (!check || i0 + E < wend) && !(CC < m && (ALLALIVE || bit_of(alv, CC < m ? CC : 0u)));  \
+        const u32 AX = A < m ? A : m;                                                                 \
+        const u32 sx##E = (u32)st[AX];                                                                \
+        const bool UN = nk##E && sx##E < kStNoClaim;                                                  \
+        const bool SP = nk##E && sx##E == kStNoClaim && A != kAffInactive;                            \
+        const bool PD = (nk##E && sx##E == kStReject) || SP;                                          \
+        O = !nk##E ? CC : ((sx##E == kStAdmit || sx##E < kStNoClaim) ? A : (A == kAffInactive ? kNone : kMark)); \
+        pend_sum += PD ? (u64)LL : 0ull;
+        RIOGP_ROW(c.x, aa.x, l.x, ov.x, 0, pd0, un0, sp0, ax0)
+        RIOGP_ROW(c.y, aa.y, l.y, ov.y, 1, pd1, un1, sp1, ax1)
+        RIOGP_ROW(c.z, aa.z, l.z, ov.z, 2, pd2, un2, sp2, ax2)
+        RIOGP_ROW(c.w, aa.w, l.w, ov.w, 3, pd3, un3, sp3, ax3)
+#undef RIOGP_ROW
+        const u64 d0 = __ballot(pd0), d1 = __ballot(pd1), d2 = __ballot(pd2), d3 = __ballot(pd3);
+        pend_cnt += (u32)(__popcll(d0) + __popcll(d1) + __popcll(d2) + __popcll(d3));
+        if (__ballot(sp0 | sp1 | sp2 | sp3)) {  // (wave-uniform, rare) spill candidates: counted apart
+            cand_sum += (sp0 ? (u64)l.x : 0ull) + (sp1 ? (u64)l.y : 0ull) + (sp2 ? (u64)l.z : 0ull) + (sp3 ? (u64)l.w : 0ull);
+            cand_cnt += (u32)(__popcll(__ballot(sp0)) + __popcll(__ballot(sp1)) + __popcll(__ballot(sp2)) + __popcll(__ballot(sp3)));
+        }
+        // the rows' `next` values: a wave that changes anything writes its whole kilobyte (PACK: every row that goes on takes
+        // NONE; else: the rejected claimants take the spill mark — the candidates hold it since k_scan)
+        if (!dbg_nonext && (PACK ? (d0 | d1 | d2 | d3) != 0 : __ballot((pd0 && !sp0) | (pd1 && !sp1) | (pd2 && !sp2) | (pd3 && !sp3)) != 0))
+            *reinterpret_cast<uint4*>(a.next + i0) = ov;
+        const u64 u0 = __ballot(un0), u1 = __ballot(un1), u2 = __ballot(un2), u3 = __ballot(un3);
+        const bool anyu = (u0 | u1 | u2 | u3) != 0;
+        if (PACK && !anyu && (d0 & d1 & d2 & d3) == ~0ull) {
+            // EVERY row of the tile goes on and none is undecided (the blocks behind the cuts: every tile): the records leave
+            // straight from the registers as three 16-byte stores per lane — what is still in the ring first
+            if (st_fill) {
+                u32 x = st_head + (u32)lane;
+                x = x >= kStageCap ? x - kStageCap : x;
+                if ((u32)lane < st_fill) {
+                    const u64 o = pk_pos + (u32)lane;
+                    a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = stage[2 * kStageCap + x];
+                }
+                pk_pos += st_fill;
+                st_fill = 0;
+                st_head = 0;
+            }
+            const u64 o = pk_pos + (u64)lane * 4;
+            u32x4u vi, vl, vm;
+            vi.x = (u32)i0; vi.y = (u32)i0 + 1u; vi.z = (u32)i0 + 2u; vi.w = (u32)i0 + 3u;
+            vl.x = l.x; vl.y = l.y; vl.z = l.z; vl.w = l.w;
+            vm.x = kSpillMark; vm.y = kSpillMark; vm.z = kSpillMark; vm.w = kSpillMark;
+            if (!dbg_nopack) {
+                *reinterpret_cast<u32x4u*>(a.pko.idx + o) = vi;
+                *reinterpret_cast<u32x4u*>(a.pko.load + o) = vl;
+                *reinterpret_cast<u32x4u*>(a.pko.next + o) = vm;
+            }
+            pk_pos += kTile;
+            return;
+        }
+        // what is packed: PACK — the rows that go on and the undecided ones; else the undecided rows only
+        const u64 b0 = PACK ? d0 | u0 : u0, b1 = PACK ? d1 | u1 : u1, b2 = PACK ? d2 | u2 : u2, b3 = PACK ? d3 | u3 : u3;
+        if (!(b0 | b1 | b2 | b3)) return;  // (wave-uniform)
+        {   // through the wave's ring, index order = lane-major, then element
+            const bool p0 = PACK ? (pd0 || un0) : un0, p1 = PACK ? (pd1 || un1) : un1, p2 = PACK ? (pd2 || un2) : un2,
+                       p3 = PACK ? (pd3 || un3) : un3;
+            const u32 rank = (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+            u32 e = st_head + st_fill + rank;
+            u32 pe = (u32)(pk_pos - wstart) + st_fill + rank;   // position of the lane's first packed row, from the wave's first
+            u32 ue = 0;
+            if (anyu) {  // (wave-uniform)
+                ue = ul_n + (u32)(__popcll(u0 & lt) + __popcll(u1 & lt) + __popcll(u2 & lt) + __popcll(u3 & lt));
+                const u32 add = (u32)(__popcll(u0) + __popcll(u1) + __popcll(u2) + __popcll(u3));
+                ul_n = ul_n > kCaList ? ul_n : ul_n + add;   // (saturates beyond the list: "not listed")
+            }
+#define RIOGP_PK(E, P, UN, AX, LL)                                                                        \
+            if (P) {                                                                                      \
+                const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
+                stage[x] = (u32)i0 + E; stage[kStageCap + x] = LL; stage[2 * kStageCap + x] = UN ? (kUndTag | AX) : kSpillMark;  \
+                if (UN) {                                                                                 \
+                    if (sx##E < kmax) atomicAdd(Tw + (size_t)sx##E * 17, (u64)LL);                        \
+                    if (ue < kCaList) { ul[ue] = (AX << kCaPosBits) | pe; ul[kCaList + ue] = (u32)i0 + E; ul[2 * kCaList + ue] = LL; }  \
+                    ++ue;                                                                                 \
+                }                                                                                         \
+                ++e; ++pe;                                                                                \
+            }
+            RIOGP_PK(0, p0, un0, ax0, l.x)
+            RIOGP_PK(1, p1, un1, ax1, l.y)
+            RIOGP_PK(2, p2, un2, ax2, l.z)
+            RIOGP_PK(3, p3, un3, ax3, l.w)
+#undef RIOGP_PK
+            st_fill += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            __builtin_amdgcn_wave_barrier();
+            while (st_fill >= 64u) {  // wave-uniform: 64 records leave as three coalesced 256-byte stores
+                u32 x = st_head + (u32)lane;
+                x = x >= kStageCap ? x - kStageCap : x;
+                const u64 o = pk_pos + (u32)lane;
+                a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = stage[2 * kStageCap + x];
+                st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
+                st_fill -= 64u;
+                pk_pos += 64u;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    while (it < wgrp) {
+        const u64 nit = it + (u64)kTile * 2;
+        const u64 pit = nit < wgrp ? nit : it;  // (the last iteration re-requests its own group: a hit, no over-read)
+        uint4 cn[2], an[2], ln[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
+            cn[q] = *reinterpret_cast<const uint4*>(a.cur + i);
+            an[q] = *reinterpret_cast<const uint4*>(a.aff + i);
+            ln[q] = *reinterpret_cast<const uint4*>(a.load + i);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tile(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, false);
+        it = nit;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
+    }
+    for (; it < wend; it += kTile) {  // the leftover tile and the ragged last tile of the table
+        const u64 i = it + (u64)lane * 4;
+        const uint4 c1 = *reinterpret_cast<const uint4*>(a.cur + i);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(a.aff + i);
+        const uint4 l1 = *reinterpret_cast<const uint4*>(a.load + i);
+        tile(c1, a1, l1, i, it + kTile > wend);
+    }
+    if (st_fill) {  // what is left in the ring (< 64 records)
+        u32 x = st_head + (u32)lane;
+        x = x >= kStageCap ? x - kStageCap : x;
+        if ((u32)lane < st_fill) {
+            const u64 o = pk_pos + (u32)lane;
+            a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = stage[2 * kStageCap + x];
+        }
+        pk_pos += st_fill;
+    }
+    RIOGP_KT(p, 6, 2);
+    const u64 pend = pk_pos;                      // end of this wave's packed rows
+    const bool listed = ul_n <= kCaList;          // the list holds every undecided row of this wave
+
+    // ---- the blocks that own cuts: settle the undecided rows, a group of kmax slots at a time
+    if (ns) {  // (block-uniform)
+        // one step = up to 64 undecided rows in index order, one per lane: {is one, node, load, row, packed position}
+        u32 g0 = 0, kn = 0;
+        auto settle = [&](const bool u, const u32 nd, const u32 lw, const u32 ix, const u64 pos) {
+            const u32 sl = u ? (u32)st[nd] - g0 : ~0u;
+            u32 vd = 3;  // 0 admitted | 1 rejected | 2 the slot's prefix crosses its budget in this step | 3 not of this group
+            bool mine = false;
+            if (sl < kn) {
+                const u32 cw = g_cw[sl];
+                vd = (u32)wave < cw ? 0u : 1u;
+                mine = (u32)wave == cw;
+            }
+            if (__ballot(mine)) {  // rows whose slot is cut in THIS wave
+                if (mine) atomicAdd(&g_ssum[sl], (u64)lw);
+                __builtin_amdgcn_wave_barrier();
+                if (mine) {
+                    const u64 base = g_acc[sl], tot = g_ssum[sl], rm = g_rem[sl];
+                    vd = base > rm ? 1u : (base + tot <= rm ? 0u : 2u);
+                }
+                u64 cross = __ballot(vd == 2u);
+                while (cross) {  // one ordered scan per slot whose prefix crosses its budget in this step
+                    const int fl = __ffsll((long long)cross) - 1;
+                    const u32 s0 = (u32)__builtin_amdgcn_readlane((int)sl, fl);
+                    const u64 base = g_acc[s0], rm = g_rem[s0];
+                    const bool k = mine && sl == s0;
+                    const u64 inc = wave_incl_scan(k ? (u64)lw : 0ull, lane);
+                    if (k) vd = base + inc <= rm ? 0u : 1u;
+                    cross = __ballot(vd == 2u);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (mine) {
+                    atomicAdd(&g_acc[sl], (u64)lw);
+                    g_ssum[sl] = 0;
+                    if (vd == 0u) atomicAdd(&g_adm[sl], (u64)lw);
+                    else atomicMin(&g_row[sl], ix);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // an admitted row's mark becomes inert (its node), a rejected row's the spill mark — and its real row, which still
+            // holds the optimistic affinity, takes the mark of a row that goes on
+            if (vd == 0u) {
+                a.pko.next[pos] = nd;
+            } else if (vd == 1u) {
+                a.pko.next[pos] = kSpillMark;
+                a.next[ix] = kMark;
+                sp_sum += (u64)lw; ++sp_cnt;
+                rej_sum += (u64)lw; ++rej_cnt;
+            }
+        };
+        for (g0 = 0; g0 < ns; g0 += kmax) {
+            kn = ns - g0 < kmax ? ns - g0 : kmax;
+            if (g0) {  // the later groups' wave sums: one more pass over the undecided rows
+                __syncthreads();
+                for (u32 k = tid; k < kn * 17; k += kBlock) T[k] = 0;
+                __syncthreads();
+                if (listed) {
+                    for (u32 q = lane; q < ul_n; q += 64) {
+                        const u32 sx = (u32)st[ul[q] >> kCaPosBits] - g0;
+                        if (sx < kn) atomicAdd(Tw + (size_t)sx * 17, (u64)ul[2 * kCaList + q]);
+                    }
+                } else {
+                    for (u64 t0 = wstart; t0 < pend; t0 += 64) {
+                        const u64 i0 = t0 + (u64)lane;
+                        const u32 mq = i0 < pend ? a.pko.next[i0] : 0u;
+                        if ((mq >> 16) == (kUndTag >> 16)) {
+                            const u32 sx = (u32)st[mq & 0xFFFFu] - g0;
+                            if (sx < kn) atomicAdd(Tw + (size_t)sx * 17, (u64)a.pko.load[i0]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // T complete (group 0: the main pass's atomics; this wave's pack stores are ordered by it too)
+            for (u32 ls = tid; ls < kn; ls += kBlock) {  // the wave in which the slot's claim prefix crosses the budget
+                const u32 nd = node_of[g0 + ls];
+                const u64 bud = a.budget[nd];
+                const u64* Tj = T + (size_t)ls * 17;
+                u64 acc = 0, pre = 0;
+                u32 cw = kWaves;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) {
+                    const u64 nv = acc + Tj[w];
+                    const bool hit = cw == (u32)kWaves && nv > bud;
+                    pre = hit ? acc : pre;
+                    cw = hit ? (u32)w : cw;
+                    acc = nv;
+                }
+                if (cw == (u32)kWaves) pre = acc;  // (cannot happen: k_resolve found the block's prefix crossing the budget)
+                g_cw[ls] = cw;
+                g_pre[ls] = pre;
+                g_rem[ls] = bud - pre;
+                g_acc[ls] = 0; g_ssum[ls] = 0; g_adm[ls] = 0;
+                g_row[ls] = kNoCut;
+            }
+            __syncthreads();
+            RIOGP_KT(p, 6, 3);
+            if (listed) {
+                for (u32 q0 = 0; q0 < ul_n; q0 += 64) {  // (wave-uniform)
+                    const u32 q = q0 + (u32)lane;
+                    const bool u = q < ul_n;
+                    const u32 qq = u ? q : 0u;
+                    const u32 w0 = ul[qq];
+                    settle(u, w0 >> kCaPosBits, ul[2 * kCaList + qq], ul[kCaList + qq], wstart + (w0 & ((1u << kCaPosBits) - 1u)));
+                }
+            } else {
+                // the wave's packed rows once more, 64 positions a step, the next step's words in flight
+                u32 mq = 0, lw = 0, ix = 0;
+                if (wstart < pend) {
+                    const u64 i0 = wstart + (u64)lane;
+                    mq = a.pko.next[i0]; lw = a.pko.load[i0]; ix = a.pko.idx[i0];
+                }
+                for (u64 t0 = wstart; t0 < pend; t0 += 64) {
+                    const u64 i0 = t0 + (u64)lane;
+                    const u32 mc = mq, lc = lw, ic = ix;
+                    const u64 nx = (t0 + 64 < pend ? t0 + 64 : t0) + (u64)lane;  // (positions past the count: padding of the columns)
+                    mq = a.pko.next[nx]; lw = a.pko.load[nx]; ix = a.pko.idx[nx];
+                    const bool u = i0 < pend && (mc >> 16) == (kUndTag >> 16);
+                    if (!__ballot(u)) continue;
+                    settle(u, mc & 0xFFFFu, lc, ic, i0);
+                }
+            }
+            __syncthreads();
+            for (u32 ls = tid; ls < kn; ls += kBlock) {
+                const u32 nd = node_of[g0 + ls];
+                a.cutidx[nd] = g_row[ls];
+                a.used_cur[nd] = a.used_kept[nd] + a.admpre[nd] + g_pre[ls] + g_adm[ls];
+            }
+        }
+    }
+    RIOGP_KT(p, 6, 4);
+    // ---- what goes on to the water-fill, per wave and per block (the rounds' ordered prefix starts from these)
+    // (main pass: pending = rejected + candidates; settle step: rejected rows, all of them pending)
+    sp_sum = wave_sum(sp_sum + pend_sum);
+    sp_cnt = wave_sum32(sp_cnt) + pend_cnt;
+    rej_sum = wave_sum(rej_sum + pend_sum - cand_sum);
+    rej_cnt = wave_sum32(rej_cnt) + pend_cnt - cand_cnt;
+    if (lane == 0) {
+        a.pko.wcnt[gw] = (u32)(pend - wstart);
+        a.wsp_sum_out[gw] = sp_sum;
+        a.wsp_cnt_out[gw] = sp_cnt;
+        if (sp_cnt) { atomicAdd(&red[0], sp_sum); atomicAdd(&red[1], (u64)sp_cnt); }
+        if (rej_cnt) { atomicAdd(&red[2], (u64)rej_cnt); atomicAdd(&red[3], rej_sum); }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        fx_add_rejected(a.fx, a.stats, red[2], red[3]);
+        a.bsp_sum_out[b] = red[0];
+        a.bsp_cnt_out[b] = (u32)red[1];
+    }
+    RIOGP_KT(p, 6, 7);
 }
 
 // committed `used` = U0 + the rounds' admitted loads (see k_fill); D rows are left as they are (k_resolve zeroes them)
@@ -4613,6 +5098,33 @@ void launch_fill(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
     } else {
         if (virt) hipLaunchKernelGGL((k_fill<true, true, false, false>), dim3(p.G), dim3(kBlock), lds, s, a);
         else hipLaunchKernelGGL((k_fill<false, true, false, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+    }
+}
+
+// k_cut_apply: exact cuts + re-marking (+ packing) of a whole-table solve of the REAL table in one pass.  pack: the rows
+// that go on to the water-fill are packed into pk (the rounds then run over pk with Plan::wcnt = pk.wcnt); else pk is only the
+// scratch of the undecided rows and the rounds run over the table.  The rounds that follow are k_fill<FILL> from round 0 on.
+bool cut_apply_fits(u32 m) { return m >= 1 && ca_lds(m, (m + 31) / 32).total <= (size_t)152 * 1024; }
+void launch_cut_apply(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, const PackOut& pk, bool pack,
+                      bool all_alive, hipStream_t s) {
+    CutApplyArgs a;
+    a.cur = t.cur; a.load = t.load; a.aff = t.aff; a.next = t.next;
+    a.alive_bits = nt.alive_bits;
+    a.p = p;
+    a.p.wcnt = nullptr;
+    a.cutblk = b.cutblk; a.budget = b.budget; a.admpre = b.admpre; a.used_kept = b.used_kept;
+    a.cutidx = b.cutidx; a.used_cur = b.used_cur;
+    a.wsp_sum_out = b.wsp_sum[0]; a.wsp_cnt_out = b.wsp_cnt[0]; a.bsp_sum_out = b.bsp_sum[0]; a.bsp_cnt_out = b.bsp_cnt[0];
+    a.bsp_cnt_in = b.bsp_cnt[0];
+    a.stats = b.stats; a.fx = b.fx;
+    a.pko = pk;
+    const size_t lds = ca_lds(p.m, p.mwords).total;
+    if (pack) {
+        if (all_alive) hipLaunchKernelGGL((k_cut_apply<true, true>), dim3(p.G), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_cut_apply<true, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+    } else {
+        if (all_alive) hipLaunchKernelGGL((k_cut_apply<false, true>), dim3(p.G), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_cut_apply<false, false>), dim3(p.G), dim3(kBlock), lds, s, a);
     }
 }
 

@@ -204,6 +204,7 @@ struct rio_gp {
     PackOut pk2{};              // the balanced pack columns (k_rebal)
     Plan vplan{};               // the plan of the packed table the fix-up of the solve in flight runs over
     int cutpack_mode = 0;  // the same for packing at the cut pass of whole-table solves (bits 5-6 of rio_gp_debug_set_compact)
+    int cutapply_mode = 0; // whole-table fix-up: 0 k_cut_apply (cuts + re-marking in one pass) | 2 k_cut_find + k_fill<APPLY> (bits 9-10)
     u64 last_fix_rows = 0;  // rows the previous solve sent to the water-fill (spill candidates + rejected claimants)
     bool last_fix_valid = false;
     int spec_mode = 0;     // speculative fix-up enqueue: 0 auto (after a solve that needed it) | 1 always | 2 never
@@ -365,6 +366,9 @@ NodeTab scan_nodes(rio_gp* h) {
     return nt;
 }
 
+// the whole-table fix-up of the real table runs k_cut_apply (exact cuts + re-marking in one pass), not k_cut_find + k_fill<APPLY>
+bool use_cut_apply(rio_gp* h, u32 m) { return h->cutapply_mode != 2 && !h->sb.forced_bits && cut_apply_fits(m); }
+
 // The fix-up of a solve whose fast path said it needs one (or may need one: every kernel here guards itself on the
 // device, so the sequence can be enqueued before the host has read the verdict):
 //   the exact cut search — k_cut_find, unless launch_resolve already searched (packed pending rows: `searched`);
@@ -372,6 +376,23 @@ NodeTab scan_nodes(rio_gp* h) {
 //   the later rounds run over those rows only); rounds 1.. = k_fill<FILL>.
 void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, bool virt, bool searched, bool cutpack = false) {
     cutpack = cutpack && !virt && !p.wcnt && h->rounds >= 1 && fill_can_pack(p.m);
+    // Whole-table solve of the real table: ONE pass finds the exact cuts, re-marks and (cutpack) packs — k_cut_apply — and
+    // every round, the first included, is a plain water-fill round (over the packed rows / over the table).
+    if (!virt && !searched && !p.wcnt && use_cut_apply(h, p.m)) {
+        launch_cut_apply(p, t, nt, h->sb, h->pk, cutpack, h->all_alive, h->stream);
+        if (cutpack) {
+            Plan pp = p;
+            pp.wcnt = h->pk.wcnt;
+            Table vt{h->pos /* all-NONE column: every packed row is pending */, h->pk.load, h->pk.aff, h->pk.next};
+            vt.pk_idx = h->pk.idx;
+            vt.real_next = t.next;
+            vt.none_prewritten = true;
+            for (u32 r = 0; r < h->rounds; ++r) launch_fill(pp, vt, nt, h->sb, true, false, true, (int)r, r + 1 == h->rounds, h->stream);
+        } else {
+            for (u32 r = 0; r < h->rounds; ++r) launch_fill(p, t, nt, h->sb, false, false, true, (int)r, r + 1 == h->rounds, h->stream);
+        }
+        return;
+    }
     if (!searched) launch_cut_find(p, t, nt, h->sb, virt, h->stream, true);
     launch_fill(p, t, nt, h->sb, virt, true, true, 0, h->rounds == 1, h->stream, cutpack ? &h->pk : nullptr);
     if (cutpack) {
@@ -403,13 +424,17 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     h->solve_inplace = inc != 0;
     const PackOut& pkx = inc == 2 ? h->pk2 : h->pk;  // where the fix-up finds the packed rows
     h->vplan = h->plan;
+    // a whole-table fix-up by k_cut_apply takes its ordered spill totals from its own pass: k_scan / k_resolve need not
+    // maintain the rejected-load tables R / RP (k_resolve: one prefix over the blocks per node group that owns a cut)
+    SolveBufs rb = h->sb;
+    if (!compact && !inc && use_cut_apply(h, h->m)) { rb.R = nullptr; rb.RP = nullptr; }
     if (inc) {
         // (t.cur is read AND written: the tick is committed, nobody is promised the table as it was)
         launch_inc_scan(h->plan, h->assign[h->cur], h->load, h->aff, nt, h->sb, h->pk, h->stream);
         h->vplan = rebal_plan(h->plan);
         launch_rebal(h->plan, h->vplan, h->pk, nt, h->pk2, h->sb, h->stream);
     } else {
-        launch_scan(h->plan, t, nt, h->sb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
+        launch_scan(h->plan, t, nt, rb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
     }
     h->vplan.wcnt = compact ? pkx.wcnt : nullptr;
     // The exact cut search rides in k_resolve when a block's packed rows are few enough for a wave pair per node to stream
@@ -419,7 +444,7 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     h->searched = compact && h->plan.G && h->n / h->plan.G <= kSearchMaxBlockRows;
     Plan rp = h->vplan;
     if (!h->searched) rp.wcnt = nullptr;
-    launch_resolve(rp, nt, h->sb, host_rows, h->stream, nullptr, nullptr, h->searched ? &pkx : nullptr,
+    launch_resolve(rp, nt, rb, host_rows, h->stream, nullptr, nullptr, h->searched ? &pkx : nullptr,
                    h->used_parts ? h->used : nullptr, h->parts_rounds, inc ? h->used : nullptr);
     h->used_parts = false;
 }
@@ -2557,13 +2582,14 @@ uint64_t rio_gp_debug_wave_row_lo(uint64_t n_objects, uint32_t n_nodes, uint32_t
 }
 
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
-    if (!h || mode < 0 || mode >= 512 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
+    if (!h || mode < 0 || mode >= 2048 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
     std::lock_guard<std::mutex> g(h->mu);
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
     h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
     h->compact_mode = mode & 15;
     h->inc_mode = (mode >> 7) & 3;       // bits 7-8: in-place scan of committed ticks, 0 auto | 1 whatever the table's size | 2 never
     if (h->inc_mode == 3) h->inc_mode = 0;
+    h->cutapply_mode = ((mode >> 9) & 3) == 2 ? 2 : 0;  // bits 9-10: 2 = the two-pass whole-table fix-up (k_cut_find, then k_fill<APPLY>)
     return RIO_GP_OK;
 }
 

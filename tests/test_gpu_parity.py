@@ -27,7 +27,24 @@ def gp():
 # search inside k_resolve | whole table with round 0 of k_fill packing the rows that go on to the water-fill; enqueued after
 # the host has read the verdict | speculatively behind k_resolve (every kernel guards itself on the device)
 FIXUP_VARIANTS = (("never", "never"), ("always", "never"), ("never", "always"), ("always", "always"),
-                  ("cutpack", "never"), ("cutpack", "always"))
+                  ("cutpack", "never"), ("cutpack", "always"),
+                  # the two-pass whole-table fix-up (k_cut_find, then the re-marking inside round 0 of k_fill): what the request
+                  # path's virtual table and the row-sharded solve still run, kept under test on the real table too
+                  ("twopass", "never"), ("twopass-cutpack", "always"))
+
+
+def apply_variant(g, mode):
+    """(packed fix-up | whole-table fix-up by k_cut_apply, packing or not | the two-pass form, packing or not, speculation)"""
+    kind, spec = mode
+    if kind == "cutpack":
+        g.set_compact("never", cut_pack="always")
+    elif kind == "twopass":
+        g.set_compact("never", cut_pack="never", cut_apply="never")
+    elif kind == "twopass-cutpack":
+        g.set_compact("never", cut_pack="always", cut_apply="never")
+    else:
+        g.set_compact(kind, cut_pack="never")
+    g.set_speculate(spec)
 
 
 def _mk(gp, n, m, load, aff, cap, alive, cur=None, rounds=2, lab=False):
@@ -45,14 +62,8 @@ def _check_tick(gp, oracle, cur, load, aff, cap, alive, rounds=2):
     # Every policy of the fix-up must give the same bytes — and so must the product library left to itself (first variant).
     for mode in (None,) + FIXUP_VARIANTS:
         g = _mk(gp, n, m, load, aff, cap, alive, cur, rounds, lab=mode is not None)
-        if mode is None:
-            pass
-        elif mode[0] == "cutpack":
-            g.set_compact("never", cut_pack="always")
-        else:
-            g.set_compact(mode[0], cut_pack="never")
         if mode is not None:
-            g.set_speculate(mode[1])
+            apply_variant(g, mode)
         st = g.solve()
         got = g.get_solved()
         assert np.array_equal(got, want), (mode, np.flatnonzero(got != want)[:10])
@@ -368,7 +379,7 @@ def test_invalid_arguments_are_unknown_errors(gp):
     g.close()
     # the lab build's knobs reject what they do not know (modes are 0 | 1 | 2 in every field)
     gl = gp.LabPlacement(10, 2)
-    for bad in (3, 3 << 5, 7):
+    for bad in (3, 3 << 5, 7, 1 << 11):
         assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, bad) == gp.EINVAL
     assert gp.lab_lib().rio_gp_debug_set_speculate(gl.handle, 3) == gp.EINVAL
     assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, 2 | 16 | (1 << 5)) == 0   # never | plain CRUD | cut-pass packing always
@@ -531,8 +542,7 @@ def test_reference_self_assign_ticks_and_requests(gp, oracle, seed, n, m):
         g.set_objects(n, load, aff)
         g.set_assign(cur)
         if mode is not None:
-            g.set_compact("never" if mode[0] == "cutpack" else mode[0], cut_pack="always" if mode[0] == "cutpack" else "never")
-            g.set_speculate(mode[1])
+            apply_variant(g, mode)
         assert g.solve() == ost, mode
         assert np.array_equal(g.get_solved(), want), mode
         g.commit()

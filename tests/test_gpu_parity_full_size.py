@@ -65,15 +65,11 @@ def test_config2_exact_every_fixup_variant(gp, oracle):
     assert st["slow_path"] == 0 and st["claimed"] == cfg["n"]
     g.close()
     tight = dict(cfg, cap=np.full(256, 3000, np.uint64))
-    for compact, spec in ((None, None), ("never", "never"), ("always", "never"), ("never", "always"), ("always", "always"),
-                          ("cutpack", "never"), ("cutpack", "always")):
+    from test_gpu_parity import FIXUP_VARIANTS, apply_variant
+    for compact, spec in ((None, None),) + FIXUP_VARIANTS:
         g = _mk(gp, tight, lab=compact is not None)   # (None: the product library left to itself)
-        if compact == "cutpack":
-            g.set_compact("never", cut_pack="always")
-        elif compact is not None:
-            g.set_compact(compact, cut_pack="never")
-        if spec is not None:
-            g.set_speculate(spec)
+        if compact is not None:
+            apply_variant(g, (compact, spec))
         _, _, st = _same(g, oracle, tight["cur"], tight)
         assert st["cut_nodes"] == 256 and st["unplaced"] > 0, (compact, spec)
         g.close()
@@ -106,7 +102,32 @@ def test_config3_contended_at_10m(gp, oracle):
     _, _, st2 = _same(g, oracle, tight["cur"], tight, commit=False)
     assert st2 == st
     g.set_compact("auto", cut_pack="never")
-    _, _, st3 = _same(g, oracle, tight["cur"], tight)
+    _, _, st3 = _same(g, oracle, tight["cur"], tight, commit=False)
+    assert st3 == st
+    # the two-pass form of the whole-table fix-up (k_cut_find, then the re-marking inside round 0), packing and not
+    for cp in ("always", "never"):
+        g.set_compact("auto", cut_pack=cp, cut_apply="never")
+        _, _, st4 = _same(g, oracle, tight["cur"], tight, commit=False)
+        assert st4 == st, cp
+    g.set_compact("auto")
+    _, _, st5 = _same(g, oracle, tight["cur"], tight)
+    assert st5 == st
+    g.close()
+
+
+def test_config3_skew_at_10m(gp, oracle):
+    """The headline table with Lomax(1.1) affinities: two dozen servers asked for by most objects are cut within their first
+    claimants, ~94 % of the rows are water-filled elsewhere (bench.py's config3_skew record)."""
+    cfg = cfg_of("c3")
+    skew = dict(cfg, aff=synth.skew_affinity(cfg["n"], cfg["m"]))
+    g = _mk(gp, skew, lab=True)
+    _, _, st = _same(g, oracle, skew["cur"], skew, commit=False)
+    assert 10 < st["cut_nodes"] < 100 and st["spilled"] > 9_000_000
+    g.set_compact("auto", cut_apply="never")
+    _, _, st2 = _same(g, oracle, skew["cur"], skew, commit=False)
+    assert st2 == st
+    g.set_compact("auto", cut_pack="always")     # (packs 94 % of the table: what the adaptive rule never picks here)
+    _, _, st3 = _same(g, oracle, skew["cur"], skew)
     assert st3 == st
     g.close()
 
