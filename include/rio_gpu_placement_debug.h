@@ -23,8 +23,9 @@ extern "C" {
  * + (inc << 7): the in-place scan of COMMITTED ticks over a mostly-placed table (k_inc_scan: the assignment column is updated
  * in place, then k_rebal deals the pending rows out evenly to the fix-up's workgroups) — 0 or 1 = whenever the packed fix-up
  * is used and the `used` vector is valid (default) | 2 = never (k_scan<COMPACT>).
- * + (ca << 9): the whole-table fix-up — 0 = k_cut_apply, the exact cuts and the re-marking in one pass over the rows (default) |
- * 2 = k_cut_find, then the re-marking pass inside round 0 of k_fill (two passes: round 5's form). */
+ * + (ca << 9): the whole-table fix-up by k_cut_apply + k_cut_settle (the exact cuts and the re-marking in one pass over the wave
+ * ranges that have work) — 0 = when the solve packs at the cut pass (default) | 1 = always | 2 = never: k_cut_find, then the
+ * re-marking pass inside round 0 of k_fill (two passes: round 5's form). */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 /* speculative enqueue of the fix-up behind k_resolve, without waiting for the verdict: 0 (default) = when the previous
  * solve needed it | 1 = always | 2 = never. */

@@ -118,6 +118,8 @@ struct SolveBufs {
                      //   used_cur + D[0..r) and adds into D[r]; the committed `used` is used_cur + sum D (launch_used_fold).
                      //   nullptr (row-sharded solve): the rounds read used_snap and add straight into used_cur
     const u64* used_snap;  // row-sharded solve: the global `used` vector as the last exchange left it (nobody writes it during a round)
+    u64* Tg = nullptr;     // [m][16] k_cut_apply's per-wave claim sums of the undecided rows: k_resolve zeroes the rows of the nodes
+                           //   it finds a cut for (nullptr: the solve's fix-up does not use k_cut_apply)
     DevStats* stats;
     FxRows fx;
 };
@@ -208,8 +210,8 @@ bool fill_can_pack(u32 m);
 // rows — replaces launch_cut_find + the apply half of round 0; the rounds behind it are launch_fill(apply = false) from round 0
 // on, over pk (pack: Plan::wcnt = pk.wcnt, Table::none_prewritten) or over the table (pk is scratch for the undecided rows)
 bool cut_apply_fits(u32 m);
-void launch_cut_apply(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, const PackOut& pk, bool pack,
-                      bool all_alive, hipStream_t s);
+void launch_cut_apply(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, const PackOut& pk, const PackOut& ul,
+                      u64* Tg, bool pack, bool all_alive, hipStream_t s);
 // used[j] += D[0][j] + ... + D[rounds-1][j]
 void launch_used_fold(u64* used, const u64* D, u32 m, u32 rounds, hipStream_t s);
 #ifdef RIO_GP_LAB

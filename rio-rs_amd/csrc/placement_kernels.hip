@@ -114,6 +114,13 @@ __device__ __forceinline__ void wave_range(const Plan& p, u64 gw, u64& wstart, u
         if (e < wend) wend = e;
     }
 }
+// ... of the whole table, whatever Plan::wcnt says (no load behind a branch: see k_cut_apply's step loop)
+__device__ __forceinline__ void wave_range_plain(const Plan& p, u64 gw, u64& wstart, u64& wend) {
+    wstart = wave_row_lo(p, gw);
+    wend = wave_row_lo(p, gw + 1);
+    if (wend > p.n) wend = p.n;
+    if (wstart > wend) wstart = wend;
+}
 // the wave whose range contains row position i (inverse of wave_row_lo), and whether i is a live packed position
 __device__ __forceinline__ bool packed_live(const Plan& p, u64 i) {
     if (!p.wcnt) return true;
@@ -949,6 +956,8 @@ struct ResolveArgs {
     u32 fold_rounds;
     // SEARCH: the packed pending rows (affinity, load) of every wave range
     const u32* pk_aff; const u32* pk_load;
+    u64* Tg;           // [m][16] claim load of a cut node's undecided rows per wave of its cut block (k_cut_apply adds, k_cut_settle
+                       // reads): the rows of the nodes that have a cut are zeroed here (nullptr: none)
     // the scan built no kept histogram (k_inc_scan): the kept load of node j is this committed vector's entry (after the fold
     // above, when it is the vector folded into) where j is alive, 0 where it is not; nullptr: the column sums of H
     const u64* kept_from;
@@ -1071,6 +1080,11 @@ __global__ __launch_bounds__(SEARCH ? kBlock : 256) void k_resolve(const Resolve
                     a.cutblk[jq] = (u32)(lane * 4 + e);
                     a.budget[jq] = fre - cum;
                     a.admpre[jq] = cum;
+                    if (a.Tg) {
+                        uint4* z = reinterpret_cast<uint4*>(a.Tg + (size_t)jq * kWaves);
+#pragma unroll
+                        for (int w = 0; w < kWaves / 2; ++w) z[w] = make_uint4(0, 0, 0, 0);
+                    }
                     s_cb[q] = (u32)(lane * 4 + e);
                     s_bud[q] = fre - cum;
                     s_adm[q] = cum;
@@ -2483,70 +2497,56 @@ __global__ __launch_bounds__(kBlock) void k_fill(const FillArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4c k_cut_apply — the exact cuts AND the re-marking (AND the packing) of a whole-table solve in ONE pass over the rows.
-//     Before: k_cut_find (a pass over the blocks that own cuts, 25 us at 10 M rows) and then pass A of k_fill (another
-//     12 B/row) — two table-wide passes between k_resolve and the water-fill.  What makes one pass enough: after k_resolve a
-//     claimant of node a in block b is admitted when cutblk[a] > b, rejected when cutblk[a] < b, and UNDECIDED only when
-//     cutblk[a] == b — a few dozen rows per (node, block).  A block none of whose nodes is cut at or before it and that holds
-//     no spill candidate has nothing to re-mark and returns at once (a contended cluster: the first 70-90 % of the blocks).
-//     The pass
-//       * streams cur / aff / load once (12 B/row, two tiles in flight), rebuilds the rows' `next` values, rejects and admits
-//         wholesale by cut block;
-//       * packs, in index order, through per-wave LDS rings: PACK — every row that goes on to the water-fill plus the
-//         undecided ones (marked kUndTag | node); else — the undecided rows only (scratch);
-//       * adds every undecided row's load to T[slot][wave] (LDS; slot = the node's number among the nodes cut in this block)
-//         and keeps {packed position, row, load, node} of the wave's undecided rows in an LDS list.
-//     Then, in the blocks that own cuts only: per slot an ordered walk over its sixteen wave sums finds the wave in which the
-//     claim prefix crosses the budget k_resolve left; every wave settles its undecided rows from its list (no global read) —
-//     earlier wave: admitted, later wave: rejected, the cut wave itself: exactly, by load prefix in index order.  Inside the
-//     cut wave a slot's rows of one step (64 rows) are summed without order first; only the ONE step in which the prefix
-//     crosses the budget needs the ordered scan (one DPP scan per crossing).  A wave whose list overflowed (a nearly full
-//     cluster cuts every node in block 0: every row of the block is undecided) walks its packed rows instead; more slots than
-//     fit the LDS: groups of kmax slots, one more walk per further group.
+// K4c k_cut_apply + k_cut_settle — the exact cuts AND the re-marking (AND the packing) of a whole-table solve in ONE pass over
+//     the rows that need it.  Before: k_cut_find (a pass over the blocks that own cuts, 25 us at 10 M rows) and then pass A of
+//     k_fill (another 12 B/row) — two table-wide passes between k_resolve and the water-fill.
+//     What makes one pass enough: after k_resolve a claimant of node a in block b is admitted when cutblk[a] > b, rejected when
+//     cutblk[a] < b, and UNDECIDED only when cutblk[a] == b — a few dozen rows per (node, block).  And a block none of whose
+//     nodes is cut at or before it and that holds no spill candidate has nothing to re-mark at all (a contended cluster: the
+//     first 70-90 % of the blocks).
+//     What decides the launch shape: a CU streams ~25 GB/s whatever the rest of the chip does (256 of them are the chip's
+//     6.4 TB/s), so the blocks that DO have work — the last 10-30 % of the index range — must not be left to their own CUs: the
+//     first version of this kernel (workgroup b = block b) took as long over a fifth of the table as over all of it.  The wave
+//     ranges (the unit whose rows are packed in order) are therefore DEALT OUT: wave w of workgroup g takes wave range
+//     w * G + g, i.e. the sixteen waves of a workgroup work in sixteen different blocks spread evenly over the table, and every
+//     CU gets its share of whatever part of the table has work.  Nothing of a block lives in one workgroup's LDS any more:
+//       k_cut_apply   per wave range: stream cur / aff / load once (12 B/row, two tiles in flight), rebuild the rows' `next`
+//                     values, admit and reject wholesale by cut block (one LDS look-up per row: the cut block of its affinity
+//                     node, liveness folded in), pack in index order through the wave's LDS ring — PACK: every row that goes
+//                     on to the water-fill plus the undecided ones (marked kUndTag | node); else the undecided rows only
+//                     (scratch); an undecided row adds its load to Tg[node][wave of its block] (global atomic, no return) and
+//                     leaves {packed position, row, load, node} in the range's list (global scratch).
+//       k_cut_settle  workgroup b = block b, only where nodes are cut: per node an ordered walk over its sixteen wave sums
+//                     finds the wave in which the claim prefix crosses the budget k_resolve left; wave w settles the undecided
+//                     rows of wave range (b, w) from its list — earlier wave: admitted, later wave: rejected, the cut wave
+//                     itself: exactly, by load prefix in index order.  Inside the cut wave a node's rows of one step (64 rows)
+//                     are summed without order first; only the ONE step in which the prefix crosses the budget needs the
+//                     ordered scan (one DPP scan per crossing).  More cut nodes in a block than fit the LDS (a nearly full
+//                     cluster cuts every node in block 0): groups of kmax, one more walk over the list per further group.
+//                     Every workgroup: the block's spill totals from its sixteen ranges.
 //     Out: `next` re-marked (PACK: NONE in every row that goes on, so the last round only writes what it places), the packed
-//     rows {row, load, spill mark} + per-wave counts, the ordered spill totals per wave / block (what k_fill<FILL>'s prefix
+//     rows {row, load, spill mark} + per-range counts, the ordered spill totals per range / block (what k_fill<FILL>'s prefix
 //     starts from: R / RP are not needed), cutidx / used_cur of the cut nodes, the rejected rows' counters.
 //     Real table of one GPU only (the request path's virtual table and the row-sharded solve keep k_cut_find + k_fill<APPLY>).
 // ------------------------------------------------------------------------------------------------
-// st[node], and st[m] for every affinity that is not a node: no cut at or before this block | cut in an earlier block | not a
-// claim target (a node that is not alive — unless claims need no live node, Plan::sa — or no node at all) | else: slot
-constexpr u32 kStAdmit = 0xFFFFu, kStReject = 0xFFFEu, kStNoClaim = 0xFFFDu;
-constexpr u32 kUndTag = 0x80000000u;                      // packed mark of an undecided row: kUndTag | node
+constexpr u32 kCbNoClaim = 0xFFFFFFFEu;   // cbt[] entry of an affinity that is no claim target (a node that is not alive — unless
+                                          // claims need no live node, Plan::sa —, or no node at all: cbt[m]); kNoCut = no cut
+constexpr u32 kUndTag = 0x80000000u;      // packed mark of an undecided row: kUndTag | node
 constexpr u32 kCaRingCols = 3;
-constexpr u32 kCaList = 256;                              // undecided rows a wave keeps in its LDS list: {node << 19 | packed position, row, load}
-constexpr u32 kCaPosBits = 19;                            // (a wave range of up to 2^19 rows: tables of up to 2^31 rows; beyond: the list is not used)
-struct CaLds { size_t st, node_of, alv, rings, ulist, grp; u32 kmax; size_t total; };
-__host__ __device__ __forceinline__ CaLds ca_lds(u32 m, u32 mwords) {
-    CaLds L;
-    const u32 mr = (m + 8) & ~7u;                           // (m + 1 states)
-    size_t off = 256;                                       // small: counters, per-wave words
-    L.st = off; off += (size_t)mr * 2;
-    L.node_of = off; off += (size_t)mr * 2;
-    off = (off + 15) & ~(size_t)15;
-    L.alv = off; off += (size_t)((mwords + 3) & ~3u) * 4;
-    L.rings = off; off += (size_t)kWaves * kCaRingCols * kStageCap * 4;
-    L.ulist = off; off += (size_t)kWaves * 3 * kCaList * 4;
-    off = (off + 15) & ~(size_t)15;
-    L.grp = off;
-    const size_t per = 17 * 8 + 5 * 8 + 2 * 4;             // T row (odd stride) | rem, pre, accw, ssum, admw | cw, cutrow
-    const size_t avail = (size_t)152 * 1024 - 128 - off;   // (a launch with 163 712 bytes of dynamic LDS was refused: stay clear of the limit)
-    u32 k = (u32)(avail / per);
-    if (k > m) k = (m + 7) & ~7u;
-    if (k > 1024u) k = 1024u;
-    if (k < 8u) k = 8u;
-    L.kmax = k & ~7u;
-    L.total = off + (size_t)L.kmax * per + 64;
-    return L;
+__host__ __device__ __forceinline__ size_t ca_lds_bytes(u32 m, u32 mwords) {
+    return 1024 + (size_t)((m + 4) & ~3u) * 4 + (size_t)((mwords + 3) & ~3u) * 4 + 64;
 }
+struct UndList { u32* pos; u32* row; u32* load; u32* node; u32* cnt; };  // per wave range, at the front of the range: the undecided rows
 struct CutApplyArgs {
     const u32* cur; const u32* load; const u32* aff; u32* next;
     const u32* alive_bits; Plan p;
-    const u32* cutblk; const u64* budget; const u64* admpre; const u64* used_kept;
-    u32* cutidx; u64* used_cur;
-    u64* wsp_sum_out; u32* wsp_cnt_out; u64* bsp_sum_out; u32* bsp_cnt_out;
+    const u32* cutblk;
+    u64* Tg;                         // [m][16] claim load of node j's undecided rows per wave of its cut block (zeroed by k_resolve)
+    u64* wsp_sum_out; u32* wsp_cnt_out;
     const u32* bsp_cnt_in;           // k_scan's spill candidates per block
     DevStats* stats; FxRows fx;
     PackOut pko;                     // PACK: the rows that go on + the undecided ones; else: scratch for the undecided rows
+    UndList ul;
 };
 
 template <bool PACK, bool ALLALIVE>
@@ -2555,12 +2555,307 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply(const CutApplyArgs a) {
     const Plan& p = a.p;
     const u32 m = p.m;
     const bool sa_ = p.sa != 0;
-    const CaLds L = ca_lds(m, p.mwords);
+    // small: [0] first block with a cut | [16..48) rejected rows / load of this workgroup | [64..) per range of this workgroup
+    u32* fbp = reinterpret_cast<u32*>(smem);
+    u64* red = reinterpret_cast<u64*>(smem + 16);                             // [2]
+    u32* wlist = reinterpret_cast<u32*>(smem + 64);                           // [16] which of this workgroup's ranges have work (k), [16] = how many
+    u32* pcnt = reinterpret_cast<u32*>(smem + 192);                           // [2][16] rows a wave packs in this step (two steps alive)
+    u32* ucnt = pcnt + 2 * kWaves;                                            // [2][16] ... of them undecided
+    u64* rsum = reinterpret_cast<u64*>(smem + 512);                           // [16][4] per range: pending load, candidates' load, pending rows, candidates
+    u32* cbt = reinterpret_cast<u32*>(smem + 1024);                           // [m + 1] cut block by node | kCbNoClaim
+    u32* alv = cbt + ((m + 4) & ~3u);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RIOGP_KT(p, 6, 0);
+    // one round trip: the cut flag, the spill candidates of the blocks of this workgroup's ranges, cutblk and liveness words
+    const u64 ncut = a.stats->n_cut;
+    // gridDim.x = a small multiple of the plan's G (two workgroups per CU: while one waits for its step's loads and stores the
+    // other computes): this workgroup's ranges are k * gridDim.x + blockIdx.x
+    const u32 GG = gridDim.x, nk = (p.nw + GG - 1 - blockIdx.x) / GG;          // (ranges of this workgroup: <= 16)
+    const u32 kk = (u32)tid & (kWaves - 1);
+    const u64 gwk = (u64)kk * GG + blockIdx.x;                                 // the workgroup's k-th range (thread kk looks at it)
+    const u32 scand_k = kk < nk ? a.bsp_cnt_in[(u32)(gwk / kWaves)] : 0u;
+    const u32 cb0 = a.cutblk[(u32)tid < m ? (u32)tid : m - 1];
+    const u32 ak = (u32)tid < p.mwords ? (u32)tid : p.mwords - 1;
+    const u32 aw = a.alive_bits[ak];
+    // speculative launch behind a solve that needs no fix-up: k_scan's marks, counts and totals stand
+    if (ncut == 0 && !PACK) return;
+    if (tid < 2) red[tid] = 0;
+    if (tid == 0) *fbp = kNoCut;
+    if (tid < kWaves * 4) rsum[tid] = 0;
+    alv[ak] = aw;
+    __syncthreads();
+    u32 fmin = kNoCut;
+    for (u32 j = tid; j < m; j += kBlock) {
+        u32 cb = j == (u32)tid ? cb0 : a.cutblk[j];
+        if (!ALLALIVE && !sa_ && !bit_of(alv, j)) cb = kCbNoClaim;  // (a node without claimants has no cut)
+        cbt[j] = cb;
+        fmin = cb < fmin ? cb : fmin;
+    }
+    if (tid == 0) cbt[m] = kCbNoClaim;
+    {
+        u32 t;  // minimum over the wave, then over the workgroup
+        t = (u32)__shfl_xor((int)fmin, 1, 64); fmin = t < fmin ? t : fmin;
+        t = (u32)__shfl_xor((int)fmin, 2, 64); fmin = t < fmin ? t : fmin;
+        t = (u32)__shfl_xor((int)fmin, 4, 64); fmin = t < fmin ? t : fmin;
+        t = (u32)__shfl_xor((int)fmin, 8, 64); fmin = t < fmin ? t : fmin;
+        t = (u32)__shfl_xor((int)fmin, 16, 64); fmin = t < fmin ? t : fmin;
+        t = (u32)__shfl_xor((int)fmin, 32, 64); fmin = t < fmin ? t : fmin;
+        if (lane == 0 && fmin != kNoCut) atomicMin(fbp, fmin);
+    }
+    __syncthreads();
+    const u32 fb = *fbp;
+    // which ranges have work: a range of a block no node is cut in or before, without spill candidates, stands as k_scan wrote it
+    // (blocks are in index order: a node cut in block c makes every block >= c a block with work); wave 0 lists them in order
+    if (wave == 0) {
+        u64 ws = 0, we = 0;
+        bool wk = false;
+        if (lane < kWaves && (u32)lane < nk) {
+            wave_range_plain(p, gwk, ws, we);
+            wk = ws < we && ((u32)(gwk / kWaves) >= fb || scand_k != 0);
+            if (!wk) {  // nothing goes on from this range
+                a.pko.wcnt[gwk] = 0;
+                a.ul.cnt[gwk] = 0;
+                a.wsp_sum_out[gwk] = 0;
+                a.wsp_cnt_out[gwk] = 0;
+            }
+        }
+        const u64 bal = __ballot(wk);
+        if (wk) wlist[__popcll(bal & ((1ull << lane) - 1ull))] = (u32)lane;
+        if (lane == 0) wlist[kWaves] = (u32)__popcll(bal);
+    }
+    __syncthreads();
+    const u32 nwork = wlist[kWaves];
+    RIOGP_KT(p, 6, 1);
+
+    // ---- the ranges with work, one after the other; a STEP = sixteen consecutive tiles of the range, one per wave, so that a
+    //      range's rows are in flight in sixteen waves at once (a wave that walks a whole range alone takes 1.7 us per tile:
+    //      instruction and memory latency in series, nothing to overlap them with).  The packed positions need the waves'
+    //      counts in order: one barrier per step (counts double-buffered in the LDS).
+    constexpr u32 kMark = PACK ? kNone : kSpillMark;
+    const u64 lt = (1ull << lane) - 1ull;
+    u64 rej_sum = 0, rej_cnt = 0;  // (wave-uniform totals are added at the end)
+    // the step the wave works on and the one it has requested
+    u32 wi = 0;                    // index into wlist
+    u64 rs = 0, re = 0, chunk = 0; // the range and the first row of the step
+    auto range_of = [&](const u32 w_i, u64& s_, u64& e_) {
+        const u64 g = (u64)wlist[w_i] * GG + blockIdx.x;
+        wave_range_plain(p, g, s_, e_);
+    };
+    uint4 cq = make_uint4(0, 0, 0, 0), aq = cq, lq = cq;  // the requested step's tile
+    auto request = [&](const u64 c0, const u64 e_) {
+        const u64 t0 = c0 + (u64)wave * kTile;
+        const u64 i = (t0 < e_ ? t0 : c0) + (u64)lane * 4;   // (waves past the range's end re-read its first tile: a hit, no over-read)
+        cq = *reinterpret_cast<const uint4*>(a.cur + i);
+        aq = *reinterpret_cast<const uint4*>(a.aff + i);
+        lq = *reinterpret_cast<const uint4*>(a.load + i);
+    };
+    if (nwork) { range_of(0, rs, re); chunk = rs; request(chunk, re); }
+    u32 base = 0, ubase = 0;       // rows packed / undecided rows listed of the range so far (workgroup-uniform)
+    u32 par = 0;
+    while (wi < nwork) {           // (workgroup-uniform)
+        const uint4 c = cq, aa = aq, l = lq;
+        const u64 t0 = chunk + (u64)wave * kTile;
+        const bool live = t0 < re;                          // this wave has a tile in this step (wave-uniform)
+        const u64 i0 = t0 + (u64)lane * 4;
+        // the next step: the range's next sixteen tiles, or the next range's first
+        u32 nwi = wi;
+        u64 nrs = rs, nre = re, nchunk = chunk + (u64)kWaves * kTile;
+        if (nchunk >= re) {
+            nwi = wi + 1;
+            if (nwi < nwork) { range_of(nwi, nrs, nre); nchunk = nrs; }
+        }
+        if (nwi < nwork) request(nchunk, nre);
+        const u32 k = wlist[wi];
+        const u64 gw = (u64)k * GG + blockIdx.x;
+        const u32 vb = (u32)(gw / kWaves), vw = (u32)(gw % kWaves);
+        const bool check = t0 + kTile > re;
+        uint4 ov;
+        // A row is pending unless it sits on a live node; what becomes of a pending row is ONE table look-up by its affinity (the
+        // node's cut block against this range's block): admitted | rejected | undecided | no claim target.
+#define RIOGP_ROW(CC, A, LL, O, E, PD, UN, SP, AX)                                                    \
+        const bool nk##E = live && (!check || i0 + E < re) && !(CC < m && (ALLALIVE || bit_of(alv, CC < m ? CC : 0u)));  \
+        const u32 AX = A < m ? A : m;                                                                 \
+        const u32 cb##E = cbt[AX];                                                                    \
+        const bool UN = nk##E && cb##E == vb;                                                         \
+        const bool SP = nk##E && cb##E == kCbNoClaim && A != kAffInactive;                            \
+        const bool PD = (nk##E && cb##E < vb) || SP;                                                  \
+        O = !nk##E ? CC : ((cb##E >= vb && cb##E != kCbNoClaim) ? A : (A == kAffInactive ? kNone : kMark));
+        RIOGP_ROW(c.x, aa.x, l.x, ov.x, 0, pd0, un0, sp0, ax0)
+        RIOGP_ROW(c.y, aa.y, l.y, ov.y, 1, pd1, un1, sp1, ax1)
+        RIOGP_ROW(c.z, aa.z, l.z, ov.z, 2, pd2, un2, sp2, ax2)
+        RIOGP_ROW(c.w, aa.w, l.w, ov.w, 3, pd3, un3, sp3, ax3)
+#undef RIOGP_ROW
+        const u64 d0 = __ballot(pd0), d1 = __ballot(pd1), d2 = __ballot(pd2), d3 = __ballot(pd3);
+        const u64 u0 = __ballot(un0), u1 = __ballot(un1), u2 = __ballot(un2), u3 = __ballot(un3);
+        const bool anyu = (u0 | u1 | u2 | u3) != 0;
+        // what is packed: PACK — the rows that go on and the undecided ones; else the undecided rows only
+        const u64 b0 = PACK ? d0 | u0 : u0, b1 = PACK ? d1 | u1 : u1, b2 = PACK ? d2 | u2 : u2, b3 = PACK ? d3 | u3 : u3;
+        const u32 mycnt = (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+        const u32 myund = (u32)(__popcll(u0) + __popcll(u1) + __popcll(u2) + __popcll(u3));
+        if (lane == 0) { pcnt[par * kWaves + wave] = mycnt; ucnt[par * kWaves + wave] = myund; }
+        // the rows' `next` values: a wave that changes anything writes its whole kilobyte (PACK: every row that goes on takes
+        // NONE; else: the rejected claimants take the spill mark — the candidates hold it since k_scan)
+        if (live && (PACK ? (d0 | d1 | d2 | d3) != 0 : __ballot((pd0 && !sp0) | (pd1 && !sp1) | (pd2 && !sp2) | (pd3 && !sp3)) != 0))
+            *reinterpret_cast<uint4*>(a.next + i0) = ov;
+        // the range's totals (LDS, per range of this workgroup)
+        if (d0 | d1 | d2 | d3) {  // (wave-uniform)
+            const u64 ps = wave_sum((pd0 ? (u64)l.x : 0ull) + (pd1 ? (u64)l.y : 0ull) + (pd2 ? (u64)l.z : 0ull) + (pd3 ? (u64)l.w : 0ull));
+            const u32 pc = (u32)(__popcll(d0) + __popcll(d1) + __popcll(d2) + __popcll(d3));
+            u64 cs = 0;
+            u32 cc = 0;
+            if (__ballot(sp0 | sp1 | sp2 | sp3)) {  // (rare) spill candidates: counted apart, the rejected rows are the difference
+                cs = wave_sum((sp0 ? (u64)l.x : 0ull) + (sp1 ? (u64)l.y : 0ull) + (sp2 ? (u64)l.z : 0ull) + (sp3 ? (u64)l.w : 0ull));
+                cc = (u32)(__popcll(__ballot(sp0)) + __popcll(__ballot(sp1)) + __popcll(__ballot(sp2)) + __popcll(__ballot(sp3)));
+            }
+            if (lane == 0) {
+                atomicAdd(&rsum[k * 4 + 0], ps); atomicAdd(&rsum[k * 4 + 2], (u64)pc);
+                if (cc) { atomicAdd(&rsum[k * 4 + 1], cs); atomicAdd(&rsum[k * 4 + 3], (u64)cc); }
+            }
+            rej_sum += ps - cs;
+            rej_cnt += pc - cc;
+        }
+        __syncthreads();  // the step's counts are complete (and the previous step's are dead: the other half of the buffers)
+        u32 off = base, uoff = ubase, tot = 0, utot = 0;
+        {
+            const u32 pv = lane < kWaves ? pcnt[par * kWaves + (lane & (kWaves - 1))] : 0u;
+            const u32 uv = lane < kWaves ? ucnt[par * kWaves + (lane & (kWaves - 1))] : 0u;
+            const u64 both = wave_incl_scan((u64)pv | ((u64)uv << 32), lane);            // (two 32-bit prefixes in one scan)
+            const u64 mine = wave ? shfl64(both, wave - 1) : 0ull;
+            const u64 all = shfl64(both, kWaves - 1);
+            off += (u32)mine; uoff += (u32)(mine >> 32);
+            tot = (u32)all; utot = (u32)(all >> 32);
+        }
+        if (mycnt) {  // (wave-uniform) this wave's records, in index order = lane-major, then element
+            const u64 o0 = rs + off;
+            if (PACK && !anyu && mycnt == (u32)kTile) {
+                // EVERY row of the tile goes on and none is undecided (the blocks behind the cuts: every tile): three 16-byte
+                // stores per lane, straight from the registers
+                const u64 o = o0 + (u64)lane * 4;
+                u32x4u vi, vl, vm;
+                vi.x = (u32)i0; vi.y = (u32)i0 + 1u; vi.z = (u32)i0 + 2u; vi.w = (u32)i0 + 3u;
+                vl.x = l.x; vl.y = l.y; vl.z = l.z; vl.w = l.w;
+                vm.x = kSpillMark; vm.y = kSpillMark; vm.z = kSpillMark; vm.w = kSpillMark;
+                *reinterpret_cast<u32x4u*>(a.pko.idx + o) = vi;
+                *reinterpret_cast<u32x4u*>(a.pko.load + o) = vl;
+                *reinterpret_cast<u32x4u*>(a.pko.next + o) = vm;
+            } else {
+                const bool p0 = PACK ? (pd0 || un0) : un0, p1 = PACK ? (pd1 || un1) : un1, p2 = PACK ? (pd2 || un2) : un2,
+                           p3 = PACK ? (pd3 || un3) : un3;
+                u32 pe = off + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));  // from the range's first
+                u64 ue = 0;
+                // a HOT node (a skewed cluster: half the rows of a block ask for one server): >= 16 undecided rows of one element
+                // share their node — one global atomic for their sum instead of 16+ on one address
+                bool hot0 = false, hot1 = false, hot2 = false, hot3 = false;
+                u64* const Tw = a.Tg + vw;
+                if (anyu) {
+                    ue = rs + uoff + (u32)(__popcll(u0 & lt) + __popcll(u1 & lt) + __popcll(u2 & lt) + __popcll(u3 & lt));
+#define RIOGP_HOT(UB, UN, AX, LL, HOT)                                                                    \
+                    if (__popcll(UB) >= 16) {                                                             \
+                        const u32 n0 = (u32)__builtin_amdgcn_readlane((int)AX, __ffsll((long long)UB) - 1); \
+                        const bool same = UN && AX == n0;                                                 \
+                        if (__popcll(__ballot(same)) >= 16) {                                             \
+                            const u64 sum = wave_sum(same ? (u64)LL : 0ull);                              \
+                            if (lane == 0) atomicAdd(Tw + (size_t)n0 * kWaves, sum);                      \
+                            HOT = same;                                                                   \
+                        }                                                                                 \
+                    }
+                    RIOGP_HOT(u0, un0, ax0, l.x, hot0)
+                    RIOGP_HOT(u1, un1, ax1, l.y, hot1)
+                    RIOGP_HOT(u2, un2, ax2, l.z, hot2)
+                    RIOGP_HOT(u3, un3, ax3, l.w, hot3)
+#undef RIOGP_HOT
+                }
+#define RIOGP_PK(E, P, UN, AX, LL, HOT)                                                                   \
+                if (P) {                                                                                  \
+                    const u64 o = rs + pe;                                                                \
+                    a.pko.idx[o] = (u32)i0 + E; a.pko.load[o] = LL; a.pko.next[o] = UN ? (kUndTag | AX) : kSpillMark;  \
+                    if (UN) {                                                                             \
+                        if (!HOT) atomicAdd(Tw + (size_t)AX * kWaves, (u64)LL);                           \
+                        a.ul.pos[ue] = pe; a.ul.row[ue] = (u32)i0 + E; a.ul.load[ue] = LL; a.ul.node[ue] = AX;  \
+                        ++ue;                                                                             \
+                    }                                                                                     \
+                    ++pe;                                                                                 \
+                }
+                RIOGP_PK(0, p0, un0, ax0, l.x, hot0)
+                RIOGP_PK(1, p1, un1, ax1, l.y, hot1)
+                RIOGP_PK(2, p2, un2, ax2, l.z, hot2)
+                RIOGP_PK(3, p3, un3, ax3, l.w, hot3)
+#undef RIOGP_PK
+            }
+        }
+        base += tot; ubase += utot;
+        par ^= 1;
+        if (nwi != wi) {  // the range is through: its counts (thread 0), then the next range starts from zero
+            if (tid == 0) { a.pko.wcnt[gw] = base; a.ul.cnt[gw] = ubase; }
+            base = 0; ubase = 0;
+        }
+        wi = nwi; rs = nrs; re = nre; chunk = nchunk;
+    }
+    RIOGP_KT(p, 6, 2);
+    __syncthreads();
+    // ---- what goes on to the water-fill from each range (k_cut_settle adds the undecided rows it rejects and the block totals)
+    if ((u32)tid < nwork) {
+        const u32 k = wlist[tid];
+        const u64 gw = (u64)k * GG + blockIdx.x;
+        a.wsp_sum_out[gw] = rsum[k * 4 + 0];
+        a.wsp_cnt_out[gw] = (u32)rsum[k * 4 + 2];
+    }
+    if (lane == 0 && rej_cnt) { atomicAdd(&red[0], rej_cnt); atomicAdd(&red[1], rej_sum); }
+    __syncthreads();
+    if (tid == 0 && red[0]) {  // (several workgroups share a counter row: atomics)
+        if (a.fx.dev) {
+            u64* r = a.fx.dev + (size_t)(blockIdx.x % p.G) * 8;
+            atomicAdd(&r[0], red[0]);
+            atomicAdd(&r[1], red[1]);
+        } else {
+            atomicAdd(&a.stats->rejected, red[0]);
+            atomicAdd(&a.stats->load_rejected, red[1]);
+        }
+    }
+    RIOGP_KT(p, 6, 7);
+}
+
+// k_cut_settle's LDS: small | slot[mr] u16 | node_of[mr] u16 | per group of kmax cut nodes: T[kmax][17] and five words of state
+struct CsLds { size_t slot, node_of, grp; u32 kmax; size_t total; };
+__host__ __device__ __forceinline__ CsLds cs_lds(u32 m) {
+    CsLds L;
+    const u32 mr = (m + 7) & ~7u;
+    size_t off = 256;
+    L.slot = off; off += (size_t)mr * 2;
+    L.node_of = off; off += (size_t)mr * 2;
+    off = (off + 15) & ~(size_t)15;
+    L.grp = off;
+    const size_t per = 17 * 8 + 5 * 8 + 2 * 4;             // T row (odd stride) | rem, pre, acc, ssum, adm | cw, cutrow
+    const size_t avail = (size_t)144 * 1024 - off;
+    u32 k = (u32)(avail / per);
+    if (k > m) k = (m + 7) & ~7u;
+    if (k > 1024u) k = 1024u;
+    if (k < 8u) k = 8u;
+    L.kmax = k & ~7u;
+    L.total = off + (size_t)L.kmax * per + 64;
+    return L;
+}
+struct CutSettleArgs {
+    u32* next; Plan p;
+    const u32* cutblk; const u64* budget; const u64* admpre; const u64* used_kept;
+    u32* cutidx; u64* used_cur;
+    const u64* Tg;
+    u64* wsp_sum; u32* wsp_cnt; u64* bsp_sum; u32* bsp_cnt;   // in: the ranges' totals without the undecided rows; out: final (+ the blocks')
+    DevStats* stats; FxRows fx;
+    u32* pk_next;                    // the packed rows' marks (PACK: what the rounds read; else scratch)
+    UndList ul;
+    u32 pack;                        // rejected rows take NONE (the rounds run over the packed rows) | the spill mark
+};
+
+__global__ __launch_bounds__(kBlock) void k_cut_settle(const CutSettleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Plan& p = a.p;
+    const u32 m = p.m;
+    const CsLds L = cs_lds(m);
     u32& nslot = *reinterpret_cast<u32*>(smem);
     u64* red = reinterpret_cast<u64*>(smem + 16);                             // [4] pending load, pending rows, rejected rows, rejected load
-    unsigned short* st = reinterpret_cast<unsigned short*>(smem + L.st);      // [mr]
+    unsigned short* slot = reinterpret_cast<unsigned short*>(smem + L.slot);  // [mr] slot of a node cut in this block (else 0xFFFF)
     unsigned short* node_of = reinterpret_cast<unsigned short*>(smem + L.node_of);
-    u32* alv = reinterpret_cast<u32*>(smem + L.alv);
     const u32 kmax = L.kmax;
     u64* T = reinterpret_cast<u64*>(smem + L.grp);                            // [kmax][17]
     u64* g_rem = T + (size_t)kmax * 17;                                       // [kmax] budget left at the start of the cut wave
@@ -2573,248 +2868,42 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply(const CutApplyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 b = blockIdx.x;
     const u64 gw = (u64)b * kWaves + wave;
-    RIOGP_KT(p, 6, 0);
-    // one round trip: the cut flag, this block's spill candidates, the thread's first cutblk word and liveness word
+    RIOGP_KT(p, 0, 0);
     const u64 ncut = a.stats->n_cut;
-    const u32 scand = a.bsp_cnt_in[b];
     const u32 cb0 = a.cutblk[(u32)tid < m ? (u32)tid : m - 1];
-    const u32 ak = (u32)tid < p.mwords ? (u32)tid : p.mwords - 1;
-    const u32 aw = a.alive_bits[ak];
+    if (ncut == 0 && !a.pack) return;  // (k_cut_apply returned as well: k_scan's totals stand)
+    u64 sp_sum = lane == 0 ? a.wsp_sum[gw] : 0ull;   // this range's totals so far (lane 0), the settle step adds per lane
+    u32 sp_cnt = lane == 0 ? a.wsp_cnt[gw] : 0u;
+    const u32 ul_n = a.ul.cnt[gw];
     u64 wstart, wend;
     wave_range(p, gw, wstart, wend);
-    // speculative launch behind a solve that needs no fix-up / whose spill candidates k_scan has already marked and counted
-    if (ncut == 0) {
-        if (!PACK) return;
-        if (scand == 0) {
-            if (lane == 0) a.pko.wcnt[gw] = 0;
-            return;
-        }
-    }
     if (tid == 0) nslot = 0;
     if (tid < 4) red[tid] = 0;
-    alv[ak] = aw;
     __syncthreads();
-    bool work = false;  // a node whose claimants of this block are not all admitted
     for (u32 j = tid; j < m; j += kBlock) {
         const u32 cb = j == (u32)tid ? cb0 : a.cutblk[j];
-        u32 s = kStAdmit;
-        if (!ALLALIVE && !sa_ && !bit_of(alv, j)) s = kStNoClaim;  // (a node without claimants has no cut)
-        else if (cb < b) s = kStReject;
-        else if (cb == b) { s = atomicAdd(&nslot, 1u); node_of[s] = (unsigned short)j; }
-        st[j] = (unsigned short)s;
-        work |= s == kStReject || s < kStNoClaim;
+        u32 s = 0xFFFFu;
+        if (cb == b) { s = atomicAdd(&nslot, 1u); node_of[s] = (unsigned short)j; }
+        slot[j] = (unsigned short)s;
     }
-    if (tid == 0) st[m] = (unsigned short)kStNoClaim;
-    if (!__syncthreads_or(work) && scand == 0) {
-        // every claimant of this block is admitted and k_scan found no spill candidate in it: its rows stand as k_scan wrote them
-        if (lane == 0) {
-            a.pko.wcnt[gw] = 0;
-            a.wsp_sum_out[gw] = 0;
-            a.wsp_cnt_out[gw] = 0;
-        }
-        if (tid == 0) { a.bsp_sum_out[b] = 0; a.bsp_cnt_out[b] = 0; }
-        return;
-    }
+    __syncthreads();
     const u32 ns = nslot;
-    const u64 span = wend > wstart ? wend - wstart : 0;
-    const u64 wgrp = wstart + (span / (kTile * 2)) * (kTile * 2);
-    u64 it = wstart;
-    uint4 cv[2], av[2], lv[2];
-    if (it < wgrp) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const u64 i = it + (u64)q * kTile + (u64)lane * 4;
-            cv[q] = *reinterpret_cast<const uint4*>(a.cur + i);
-            av[q] = *reinterpret_cast<const uint4*>(a.aff + i);
-            lv[q] = *reinterpret_cast<const uint4*>(a.load + i);
-        }
-    }
-    if (ns) {
-        const u32 k0 = (ns < kmax ? ns : kmax) * 17;
-        for (u32 k = tid; k < k0; k += kBlock) T[k] = 0;
-        __syncthreads();
-    }
-    RIOGP_KT(p, 6, 1);
-
-    // Counters of the main pass: pending = rows that go on to the water-fill (rejected claimants + spill candidates); the
-    // candidates (k_scan's spill marks: rare) are counted apart, the rejected rows are the difference.  Row counts are
-    // wave-uniform popcounts of ballots; the loads are summed per lane.
-    u64 pend_sum = 0, cand_sum = 0;        // per lane
-    u32 pend_cnt = 0, cand_cnt = 0;        // wave-uniform
-    u64 sp_sum = 0, rej_sum = 0;           // what the settle step adds (per lane)
-    u32 sp_cnt = 0, rej_cnt = 0;
-    u64 pk_pos = wstart;
-    u32* stage = reinterpret_cast<u32*>(smem + L.rings) + (size_t)wave * kCaRingCols * kStageCap;
-    u32* ul = reinterpret_cast<u32*>(smem + L.ulist) + (size_t)wave * 3 * kCaList;  // [3][kCaList] node << 19 | position (from wstart) | row | load
-    // undecided rows of this wave (all of them: beyond kCaList the list is not used; nor when a position does not fit its field)
-    u32 ul_n = (wend - wstart) >> kCaPosBits ? kCaList + 1 : 0;
-    u32 st_head = 0, st_fill = 0;
-    const u64 lt = (1ull << lane) - 1ull;
-    u64* const Tw = T + wave;
-    constexpr u32 kMark = PACK ? kNone : kSpillMark;
-
-    // One tile.  The blocks behind the cuts of a contended cluster are bound by the INSTRUCTIONS of this body (60 busy CUs, every
-    // row of theirs packed: 16 waves x 10 tiles per CU), so the row classes stay lane masks (compares feeding selects and
-    // ballots: scalar registers, no vector bit-fiddling), the row counters are popcounts, and everything that is rare — spill
-    // candidates, undecided rows, partly packed tiles — sits behind a wave-uniform branch.
-#ifdef RIO_GP_LAB   // timing experiments only (results are wrong): trace flag bit 1 = no pack stores, bit 2 = no `next` stores
-    const bool dbg_nopack = (p.trace & 2u) != 0, dbg_nonext = (p.trace & 4u) != 0;
-#else
-    constexpr bool dbg_nopack = false, dbg_nonext = false;
-#endif
-    auto tile = [&](const uint4 c, const uint4 aa, const uint4 l, const u64 i0, const bool check) {
-        uint4 ov;
-        // A row is pending unless it sits on a live node; what becomes of a pending row is ONE table look-up by its affinity
-        // (st[], liveness of the claim target folded in): admitted | rejected | undecided (slot) | no claim target.
-#define RIOGP_ROW(CC, A, LL, O, E, PD, UN, SP, AX)                                                    \
-        const bool nk##E = (!check || i0 + E < wend) && !(CC < m && (ALLALIVE || bit_of(alv, CC < m ? CC : 0u)));  \
-        const u32 AX = A < m ? A : m;                                                                 \
-        const u32 sx##E = (u32)st[AX];                                                                \
-        const bool UN = nk##E && sx##E < kStNoClaim;                                                  \
-        const bool SP = nk##E && sx##E == kStNoClaim && A != kAffInactive;                            \
-        const bool PD = (nk##E && sx##E == kStReject) || SP;                                          \
-        O = !nk##E ? CC : ((sx##E == kStAdmit || sx##E < kStNoClaim) ? A : (A == kAffInactive ? kNone : kMark)); \
-        pend_sum += PD ? (u64)LL : 0ull;
-        RIOGP_ROW(c.x, aa.x, l.x, ov.x, 0, pd0, un0, sp0, ax0)
-        RIOGP_ROW(c.y, aa.y, l.y, ov.y, 1, pd1, un1, sp1, ax1)
-        RIOGP_ROW(c.z, aa.z, l.z, ov.z, 2, pd2, un2, sp2, ax2)
-        RIOGP_ROW(c.w, aa.w, l.w, ov.w, 3, pd3, un3, sp3, ax3)
-#undef RIOGP_ROW
-        const u64 d0 = __ballot(pd0), d1 = __ballot(pd1), d2 = __ballot(pd2), d3 = __ballot(pd3);
-        pend_cnt += (u32)(__popcll(d0) + __popcll(d1) + __popcll(d2) + __popcll(d3));
-        if (__ballot(sp0 | sp1 | sp2 | sp3)) {  // (wave-uniform, rare) spill candidates: counted apart
-            cand_sum += (sp0 ? (u64)l.x : 0ull) + (sp1 ? (u64)l.y : 0ull) + (sp2 ? (u64)l.z : 0ull) + (sp3 ? (u64)l.w : 0ull);
-            cand_cnt += (u32)(__popcll(__ballot(sp0)) + __popcll(__ballot(sp1)) + __popcll(__ballot(sp2)) + __popcll(__ballot(sp3)));
-        }
-        // the rows' `next` values: a wave that changes anything writes its whole kilobyte (PACK: every row that goes on takes
-        // NONE; else: the rejected claimants take the spill mark — the candidates hold it since k_scan)
-        if (!dbg_nonext && (PACK ? (d0 | d1 | d2 | d3) != 0 : __ballot((pd0 && !sp0) | (pd1 && !sp1) | (pd2 && !sp2) | (pd3 && !sp3)) != 0))
-            *reinterpret_cast<uint4*>(a.next + i0) = ov;
-        const u64 u0 = __ballot(un0), u1 = __ballot(un1), u2 = __ballot(un2), u3 = __ballot(un3);
-        const bool anyu = (u0 | u1 | u2 | u3) != 0;
-        if (PACK && !anyu && (d0 & d1 & d2 & d3) == ~0ull) {
-            // EVERY row of the tile goes on and none is undecided (the blocks behind the cuts: every tile): the records leave
-            // straight from the registers as three 16-byte stores per lane — what is still in the ring first
-            if (st_fill) {
-                u32 x = st_head + (u32)lane;
-                x = x >= kStageCap ? x - kStageCap : x;
-                if ((u32)lane < st_fill) {
-                    const u64 o = pk_pos + (u32)lane;
-                    a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = stage[2 * kStageCap + x];
-                }
-                pk_pos += st_fill;
-                st_fill = 0;
-                st_head = 0;
-            }
-            const u64 o = pk_pos + (u64)lane * 4;
-            u32x4u vi, vl, vm;
-            vi.x = (u32)i0; vi.y = (u32)i0 + 1u; vi.z = (u32)i0 + 2u; vi.w = (u32)i0 + 3u;
-            vl.x = l.x; vl.y = l.y; vl.z = l.z; vl.w = l.w;
-            vm.x = kSpillMark; vm.y = kSpillMark; vm.z = kSpillMark; vm.w = kSpillMark;
-            if (!dbg_nopack) {
-                *reinterpret_cast<u32x4u*>(a.pko.idx + o) = vi;
-                *reinterpret_cast<u32x4u*>(a.pko.load + o) = vl;
-                *reinterpret_cast<u32x4u*>(a.pko.next + o) = vm;
-            }
-            pk_pos += kTile;
-            return;
-        }
-        // what is packed: PACK — the rows that go on and the undecided ones; else the undecided rows only
-        const u64 b0 = PACK ? d0 | u0 : u0, b1 = PACK ? d1 | u1 : u1, b2 = PACK ? d2 | u2 : u2, b3 = PACK ? d3 | u3 : u3;
-        if (!(b0 | b1 | b2 | b3)) return;  // (wave-uniform)
-        {   // through the wave's ring, index order = lane-major, then element
-            const bool p0 = PACK ? (pd0 || un0) : un0, p1 = PACK ? (pd1 || un1) : un1, p2 = PACK ? (pd2 || un2) : un2,
-                       p3 = PACK ? (pd3 || un3) : un3;
-            const u32 rank = (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
-            u32 e = st_head + st_fill + rank;
-            u32 pe = (u32)(pk_pos - wstart) + st_fill + rank;   // position of the lane's first packed row, from the wave's first
-            u32 ue = 0;
-            if (anyu) {  // (wave-uniform)
-                ue = ul_n + (u32)(__popcll(u0 & lt) + __popcll(u1 & lt) + __popcll(u2 & lt) + __popcll(u3 & lt));
-                const u32 add = (u32)(__popcll(u0) + __popcll(u1) + __popcll(u2) + __popcll(u3));
-                ul_n = ul_n > kCaList ? ul_n : ul_n + add;   // (saturates beyond the list: "not listed")
-            }
-#define RIOGP_PK(E, P, UN, AX, LL)                                                                        \
-            if (P) {                                                                                      \
-                const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
-                stage[x] = (u32)i0 + E; stage[kStageCap + x] = LL; stage[2 * kStageCap + x] = UN ? (kUndTag | AX) : kSpillMark;  \
-                if (UN) {                                                                                 \
-                    if (sx##E < kmax) atomicAdd(Tw + (size_t)sx##E * 17, (u64)LL);                        \
-                    if (ue < kCaList) { ul[ue] = (AX << kCaPosBits) | pe; ul[kCaList + ue] = (u32)i0 + E; ul[2 * kCaList + ue] = LL; }  \
-                    ++ue;                                                                                 \
-                }                                                                                         \
-                ++e; ++pe;                                                                                \
-            }
-            RIOGP_PK(0, p0, un0, ax0, l.x)
-            RIOGP_PK(1, p1, un1, ax1, l.y)
-            RIOGP_PK(2, p2, un2, ax2, l.z)
-            RIOGP_PK(3, p3, un3, ax3, l.w)
-#undef RIOGP_PK
-            st_fill += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-            __builtin_amdgcn_wave_barrier();
-            while (st_fill >= 64u) {  // wave-uniform: 64 records leave as three coalesced 256-byte stores
-                u32 x = st_head + (u32)lane;
-                x = x >= kStageCap ? x - kStageCap : x;
-                const u64 o = pk_pos + (u32)lane;
-                a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = stage[2 * kStageCap + x];
-                st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
-                st_fill -= 64u;
-                pk_pos += 64u;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    };
-    while (it < wgrp) {
-        const u64 nit = it + (u64)kTile * 2;
-        const u64 pit = nit < wgrp ? nit : it;  // (the last iteration re-requests its own group: a hit, no over-read)
-        uint4 cn[2], an[2], ln[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
-            cn[q] = *reinterpret_cast<const uint4*>(a.cur + i);
-            an[q] = *reinterpret_cast<const uint4*>(a.aff + i);
-            ln[q] = *reinterpret_cast<const uint4*>(a.load + i);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) tile(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, false);
-        it = nit;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { cv[q] = cn[q]; av[q] = an[q]; lv[q] = ln[q]; }
-    }
-    for (; it < wend; it += kTile) {  // the leftover tile and the ragged last tile of the table
-        const u64 i = it + (u64)lane * 4;
-        const uint4 c1 = *reinterpret_cast<const uint4*>(a.cur + i);
-        const uint4 a1 = *reinterpret_cast<const uint4*>(a.aff + i);
-        const uint4 l1 = *reinterpret_cast<const uint4*>(a.load + i);
-        tile(c1, a1, l1, i, it + kTile > wend);
-    }
-    if (st_fill) {  // what is left in the ring (< 64 records)
-        u32 x = st_head + (u32)lane;
-        x = x >= kStageCap ? x - kStageCap : x;
-        if ((u32)lane < st_fill) {
-            const u64 o = pk_pos + (u32)lane;
-            a.pko.idx[o] = stage[x]; a.pko.load[o] = stage[kStageCap + x]; a.pko.next[o] = stage[2 * kStageCap + x];
-        }
-        pk_pos += st_fill;
-    }
-    RIOGP_KT(p, 6, 2);
-    const u64 pend = pk_pos;                      // end of this wave's packed rows
-    const bool listed = ul_n <= kCaList;          // the list holds every undecided row of this wave
-
-    // ---- the blocks that own cuts: settle the undecided rows, a group of kmax slots at a time
+    u64 rej_sum = 0;
+    u32 rej_cnt = 0;
+    const u32 mark = a.pack ? kNone : kSpillMark;
     if (ns) {  // (block-uniform)
-        // one step = up to 64 undecided rows in index order, one per lane: {is one, node, load, row, packed position}
         u32 g0 = 0, kn = 0;
+        // one step = up to 64 undecided rows in index order, one per lane: {is one, node, load, row, packed position}
         auto settle = [&](const bool u, const u32 nd, const u32 lw, const u32 ix, const u64 pos) {
-            const u32 sl = u ? (u32)st[nd] - g0 : ~0u;
-            u32 vd = 3;  // 0 admitted | 1 rejected | 2 the slot's prefix crosses its budget in this step | 3 not of this group
+            const u32 sl = u ? (u32)slot[nd] - g0 : ~0u;
+            u32 vd = 3;  // 0 admitted | 1 rejected | 2 the node's prefix crosses its budget in this step | 3 not of this group
             bool mine = false;
             if (sl < kn) {
                 const u32 cw = g_cw[sl];
                 vd = (u32)wave < cw ? 0u : 1u;
                 mine = (u32)wave == cw;
             }
-            if (__ballot(mine)) {  // rows whose slot is cut in THIS wave
+            if (__ballot(mine)) {  // rows whose node is cut in THIS wave
                 if (mine) atomicAdd(&g_ssum[sl], (u64)lw);
                 __builtin_amdgcn_wave_barrier();
                 if (mine) {
@@ -2822,7 +2911,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply(const CutApplyArgs a) {
                     vd = base > rm ? 1u : (base + tot <= rm ? 0u : 2u);
                 }
                 u64 cross = __ballot(vd == 2u);
-                while (cross) {  // one ordered scan per slot whose prefix crosses its budget in this step
+                while (cross) {  // one ordered scan per node whose prefix crosses its budget in this step
                     const int fl = __ffsll((long long)cross) - 1;
                     const u32 s0 = (u32)__builtin_amdgcn_readlane((int)sl, fl);
                     const u64 base = g_acc[s0], rm = g_rem[s0];
@@ -2843,38 +2932,24 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply(const CutApplyArgs a) {
             // an admitted row's mark becomes inert (its node), a rejected row's the spill mark — and its real row, which still
             // holds the optimistic affinity, takes the mark of a row that goes on
             if (vd == 0u) {
-                a.pko.next[pos] = nd;
+                a.pk_next[pos] = nd;
             } else if (vd == 1u) {
-                a.pko.next[pos] = kSpillMark;
-                a.next[ix] = kMark;
+                a.pk_next[pos] = kSpillMark;
+                a.next[ix] = mark;
                 sp_sum += (u64)lw; ++sp_cnt;
                 rej_sum += (u64)lw; ++rej_cnt;
             }
         };
         for (g0 = 0; g0 < ns; g0 += kmax) {
             kn = ns - g0 < kmax ? ns - g0 : kmax;
-            if (g0) {  // the later groups' wave sums: one more pass over the undecided rows
-                __syncthreads();
-                for (u32 k = tid; k < kn * 17; k += kBlock) T[k] = 0;
-                __syncthreads();
-                if (listed) {
-                    for (u32 q = lane; q < ul_n; q += 64) {
-                        const u32 sx = (u32)st[ul[q] >> kCaPosBits] - g0;
-                        if (sx < kn) atomicAdd(Tw + (size_t)sx * 17, (u64)ul[2 * kCaList + q]);
-                    }
-                } else {
-                    for (u64 t0 = wstart; t0 < pend; t0 += 64) {
-                        const u64 i0 = t0 + (u64)lane;
-                        const u32 mq = i0 < pend ? a.pko.next[i0] : 0u;
-                        if ((mq >> 16) == (kUndTag >> 16)) {
-                            const u32 sx = (u32)st[mq & 0xFFFFu] - g0;
-                            if (sx < kn) atomicAdd(Tw + (size_t)sx * 17, (u64)a.pko.load[i0]);
-                        }
-                    }
-                }
+            if (g0) __syncthreads();  // (the previous group's state is dead from here on)
+            // the group's wave sums (k_cut_apply's atomics, complete since the launch boundary)
+            for (u32 k = tid; k < kn * kWaves; k += kBlock) {
+                const u32 ls = k / kWaves, w = k % kWaves;
+                T[(size_t)ls * 17 + w] = a.Tg[(size_t)node_of[g0 + ls] * kWaves + w];
             }
-            __syncthreads();  // T complete (group 0: the main pass's atomics; this wave's pack stores are ordered by it too)
-            for (u32 ls = tid; ls < kn; ls += kBlock) {  // the wave in which the slot's claim prefix crosses the budget
+            __syncthreads();
+            for (u32 ls = tid; ls < kn; ls += kBlock) {  // the wave in which the node's claim prefix crosses the budget
                 const u32 nd = node_of[g0 + ls];
                 const u64 bud = a.budget[nd];
                 const u64* Tj = T + (size_t)ls * 17;
@@ -2896,30 +2971,23 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply(const CutApplyArgs a) {
                 g_row[ls] = kNoCut;
             }
             __syncthreads();
-            RIOGP_KT(p, 6, 3);
-            if (listed) {
+            RIOGP_KT(p, 0, 3);
+            // this range's undecided rows, 64 a step, the next step's words in flight
+            if (ul_n) {
+                u32 po = 0, ro = 0, lo = 0, no = 0;
+                {
+                    const u64 i0 = wstart + (u64)((u32)lane < ul_n ? (u32)lane : 0u);
+                    po = a.ul.pos[i0]; ro = a.ul.row[i0]; lo = a.ul.load[i0]; no = a.ul.node[i0];
+                }
                 for (u32 q0 = 0; q0 < ul_n; q0 += 64) {  // (wave-uniform)
                     const u32 q = q0 + (u32)lane;
-                    const bool u = q < ul_n;
-                    const u32 qq = u ? q : 0u;
-                    const u32 w0 = ul[qq];
-                    settle(u, w0 >> kCaPosBits, ul[2 * kCaList + qq], ul[kCaList + qq], wstart + (w0 & ((1u << kCaPosBits) - 1u)));
-                }
-            } else {
-                // the wave's packed rows once more, 64 positions a step, the next step's words in flight
-                u32 mq = 0, lw = 0, ix = 0;
-                if (wstart < pend) {
-                    const u64 i0 = wstart + (u64)lane;
-                    mq = a.pko.next[i0]; lw = a.pko.load[i0]; ix = a.pko.idx[i0];
-                }
-                for (u64 t0 = wstart; t0 < pend; t0 += 64) {
-                    const u64 i0 = t0 + (u64)lane;
-                    const u32 mc = mq, lc = lw, ic = ix;
-                    const u64 nx = (t0 + 64 < pend ? t0 + 64 : t0) + (u64)lane;  // (positions past the count: padding of the columns)
-                    mq = a.pko.next[nx]; lw = a.pko.load[nx]; ix = a.pko.idx[nx];
-                    const bool u = i0 < pend && (mc >> 16) == (kUndTag >> 16);
-                    if (!__ballot(u)) continue;
-                    settle(u, mc & 0xFFFFu, lc, ic, i0);
+                    const u32 pc = po, rc = ro, lc = lo, nc = no;
+                    {
+                        const u32 qn = q + 64 < ul_n ? q + 64 : (ul_n - 1);
+                        const u64 i1 = wstart + qn;
+                        po = a.ul.pos[i1]; ro = a.ul.row[i1]; lo = a.ul.load[i1]; no = a.ul.node[i1];
+                    }
+                    settle(q < ul_n, nc, lc, rc, wstart + pc);
                 }
             }
             __syncthreads();
@@ -2930,27 +2998,25 @@ __global__ __launch_bounds__(kBlock) void k_cut_apply(const CutApplyArgs a) {
             }
         }
     }
-    RIOGP_KT(p, 6, 4);
-    // ---- what goes on to the water-fill, per wave and per block (the rounds' ordered prefix starts from these)
-    // (main pass: pending = rejected + candidates; settle step: rejected rows, all of them pending)
-    sp_sum = wave_sum(sp_sum + pend_sum);
-    sp_cnt = wave_sum32(sp_cnt) + pend_cnt;
-    rej_sum = wave_sum(rej_sum + pend_sum - cand_sum);
-    rej_cnt = wave_sum32(rej_cnt) + pend_cnt - cand_cnt;
+    RIOGP_KT(p, 0, 4);
+    // ---- the range's and the block's final spill totals (the rounds' ordered prefix starts from these)
+    sp_sum = wave_sum(sp_sum);
+    sp_cnt = wave_sum32(sp_cnt);
+    rej_sum = wave_sum(rej_sum);
+    rej_cnt = wave_sum32(rej_cnt);
     if (lane == 0) {
-        a.pko.wcnt[gw] = (u32)(pend - wstart);
-        a.wsp_sum_out[gw] = sp_sum;
-        a.wsp_cnt_out[gw] = sp_cnt;
+        a.wsp_sum[gw] = sp_sum;
+        a.wsp_cnt[gw] = sp_cnt;
         if (sp_cnt) { atomicAdd(&red[0], sp_sum); atomicAdd(&red[1], (u64)sp_cnt); }
         if (rej_cnt) { atomicAdd(&red[2], (u64)rej_cnt); atomicAdd(&red[3], rej_sum); }
     }
     __syncthreads();
     if (tid == 0) {
-        fx_add_rejected(a.fx, a.stats, red[2], red[3]);
-        a.bsp_sum_out[b] = red[0];
-        a.bsp_cnt_out[b] = (u32)red[1];
+        if (red[2]) fx_add_rejected(a.fx, a.stats, red[2], red[3]);
+        a.bsp_sum[b] = red[0];
+        a.bsp_cnt[b] = (u32)red[1];
     }
-    RIOGP_KT(p, 6, 7);
+    RIOGP_KT(p, 0, 7);
 }
 
 // committed `used` = U0 + the rounds' admitted loads (see k_fill); D rows are left as they are (k_resolve zeroes them)
@@ -5014,6 +5080,7 @@ void launch_resolve(const Plan& p, const NodeTab& nt, const SolveBufs& b, u64* h
     a.partial = b.partial; a.host_partial = host_partial; a.budget = b.budget; a.admpre = b.admpre; a.stats = b.stats;
     a.RP = b.RP; a.D = b.D; a.fold_into = b.D ? fold_into : nullptr; a.fold_rounds = fold_rounds;
     a.pk_aff = search ? search->aff : nullptr; a.pk_load = search ? search->load : nullptr;
+    a.Tg = b.Tg;
     a.kept_from = kept_from;
     const bool srch = search != nullptr && p.wcnt != nullptr;
     if (e0 && e1) {
@@ -5101,31 +5168,46 @@ void launch_fill(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
     }
 }
 
-// k_cut_apply: exact cuts + re-marking (+ packing) of a whole-table solve of the REAL table in one pass.  pack: the rows
-// that go on to the water-fill are packed into pk (the rounds then run over pk with Plan::wcnt = pk.wcnt); else pk is only the
-// scratch of the undecided rows and the rounds run over the table.  The rounds that follow are k_fill<FILL> from round 0 on.
-bool cut_apply_fits(u32 m) { return m >= 1 && ca_lds(m, (m + 31) / 32).total <= (size_t)152 * 1024; }
-void launch_cut_apply(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, const PackOut& pk, bool pack,
-                      bool all_alive, hipStream_t s) {
+// k_cut_apply + k_cut_settle: exact cuts + re-marking (+ packing) of a whole-table solve of the REAL table in one pass.  pack:
+// the rows that go on to the water-fill are packed into pk (the rounds then run over pk with Plan::wcnt = pk.wcnt); else pk is
+// only the scratch of the undecided rows and the rounds run over the table.  ul: four more scratch columns + one count per wave
+// range (the undecided rows' list); Tg: [m][16] u64, zeroed for every cut node by k_resolve (ResolveArgs::Tg).  The rounds that
+// follow are k_fill<FILL> from round 0 on.
+bool cut_apply_fits(u32 m) { return m >= 1 && ca_lds_bytes(m, (m + 31) / 32) <= (size_t)150 * 1024; }
+void launch_cut_apply(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, const PackOut& pk, const PackOut& ul,
+                      u64* Tg, bool pack, bool all_alive, hipStream_t s) {
     CutApplyArgs a;
     a.cur = t.cur; a.load = t.load; a.aff = t.aff; a.next = t.next;
     a.alive_bits = nt.alive_bits;
     a.p = p;
     a.p.wcnt = nullptr;
-    a.cutblk = b.cutblk; a.budget = b.budget; a.admpre = b.admpre; a.used_kept = b.used_kept;
-    a.cutidx = b.cutidx; a.used_cur = b.used_cur;
-    a.wsp_sum_out = b.wsp_sum[0]; a.wsp_cnt_out = b.wsp_cnt[0]; a.bsp_sum_out = b.bsp_sum[0]; a.bsp_cnt_out = b.bsp_cnt[0];
+    a.cutblk = b.cutblk;
+    a.Tg = Tg;
+    a.wsp_sum_out = b.wsp_sum[0]; a.wsp_cnt_out = b.wsp_cnt[0];
     a.bsp_cnt_in = b.bsp_cnt[0];
     a.stats = b.stats; a.fx = b.fx;
     a.pko = pk;
-    const size_t lds = ca_lds(p.m, p.mwords).total;
+    a.ul = UndList{ul.idx, ul.load, ul.aff, ul.next, ul.wcnt};
+    const size_t lds = ca_lds_bytes(p.m, p.mwords);
+    const unsigned grid = p.G;       // (two workgroups per CU are not co-resident: ~100 SGPRs cap a SIMD at 6 waves)
     if (pack) {
-        if (all_alive) hipLaunchKernelGGL((k_cut_apply<true, true>), dim3(p.G), dim3(kBlock), lds, s, a);
-        else hipLaunchKernelGGL((k_cut_apply<true, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+        if (all_alive) hipLaunchKernelGGL((k_cut_apply<true, true>), dim3(grid), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_cut_apply<true, false>), dim3(grid), dim3(kBlock), lds, s, a);
     } else {
-        if (all_alive) hipLaunchKernelGGL((k_cut_apply<false, true>), dim3(p.G), dim3(kBlock), lds, s, a);
-        else hipLaunchKernelGGL((k_cut_apply<false, false>), dim3(p.G), dim3(kBlock), lds, s, a);
+        if (all_alive) hipLaunchKernelGGL((k_cut_apply<false, true>), dim3(grid), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_cut_apply<false, false>), dim3(grid), dim3(kBlock), lds, s, a);
     }
+    CutSettleArgs c;
+    c.next = t.next; c.p = a.p;
+    c.cutblk = b.cutblk; c.budget = b.budget; c.admpre = b.admpre; c.used_kept = b.used_kept;
+    c.cutidx = b.cutidx; c.used_cur = b.used_cur;
+    c.Tg = Tg;
+    c.wsp_sum = b.wsp_sum[0]; c.wsp_cnt = b.wsp_cnt[0]; c.bsp_sum = b.bsp_sum[0]; c.bsp_cnt = b.bsp_cnt[0];
+    c.stats = b.stats; c.fx = b.fx;
+    c.pk_next = pk.next;
+    c.ul = a.ul;
+    c.pack = pack ? 1u : 0u;
+    hipLaunchKernelGGL(k_cut_settle, dim3(p.G), dim3(kBlock), cs_lds(p.m).total, s, c);
 }
 
 void launch_used_fold(u64* used, const u64* D, u32 m, u32 rounds, hipStream_t s) {

@@ -201,10 +201,13 @@ struct rio_gp {
     int inc_mode = 0;
     int inc_now = 0;            // how the solve waiting for its commit scanned: 0 k_scan | 2 k_inc_scan + k_rebal
     bool solve_inplace = false; // ... and wrote its decisions into the committed column itself: the commit swaps no columns
-    PackOut pk2{};              // the balanced pack columns (k_rebal)
+    PackOut pk2{};              // the balanced pack columns (k_rebal); the undecided rows' lists of k_cut_apply
+    u64* Tg = nullptr;          // [max_nodes][16] k_cut_apply's wave sums of the undecided rows (placement_kernels.h, SolveBufs::Tg)
     Plan vplan{};               // the plan of the packed table the fix-up of the solve in flight runs over
     int cutpack_mode = 0;  // the same for packing at the cut pass of whole-table solves (bits 5-6 of rio_gp_debug_set_compact)
-    int cutapply_mode = 0; // whole-table fix-up: 0 k_cut_apply (cuts + re-marking in one pass) | 2 k_cut_find + k_fill<APPLY> (bits 9-10)
+    bool ca_now = false;   // the whole-table fix-up of the solve being enqueued is k_cut_apply (set by the caller of enqueue_scan_resolve)
+    int cutapply_mode = 0; // whole-table fix-up by k_cut_apply (cuts + re-marking in one pass): 0 when the solve packs at the cut pass
+                           // | 1 always | 2 never (k_cut_find + k_fill<APPLY>) (bits 9-10 of rio_gp_debug_set_compact)
     u64 last_fix_rows = 0;  // rows the previous solve sent to the water-fill (spill candidates + rejected claimants)
     bool last_fix_valid = false;
     int spec_mode = 0;     // speculative fix-up enqueue: 0 auto (after a solve that needed it) | 1 always | 2 never
@@ -368,6 +371,11 @@ NodeTab scan_nodes(rio_gp* h) {
 
 // the whole-table fix-up of the real table runs k_cut_apply (exact cuts + re-marking in one pass), not k_cut_find + k_fill<APPLY>
 bool use_cut_apply(rio_gp* h, u32 m) { return h->cutapply_mode != 2 && !h->sb.forced_bits && cut_apply_fits(m); }
+// ... which it is when the solve packs at the cut pass (few rows go on to the water-fill: the ranges with work are a fraction of
+// the table and k_cut_apply deals them out over the chip); a solve that re-marks most of the table keeps the two-pass form
+bool cut_apply_for(rio_gp* h, bool cutpack) {
+    return use_cut_apply(h, h->m) && (h->cutapply_mode == 1 || (cutpack && h->rounds >= 1 && fill_can_pack(h->m)));
+}
 
 // The fix-up of a solve whose fast path said it needs one (or may need one: every kernel here guards itself on the
 // device, so the sequence can be enqueued before the host has read the verdict):
@@ -378,8 +386,8 @@ void enqueue_slow(rio_gp* h, const Plan& p, const Table& t, const NodeTab& nt, b
     cutpack = cutpack && !virt && !p.wcnt && h->rounds >= 1 && fill_can_pack(p.m);
     // Whole-table solve of the real table: ONE pass finds the exact cuts, re-marks and (cutpack) packs — k_cut_apply — and
     // every round, the first included, is a plain water-fill round (over the packed rows / over the table).
-    if (!virt && !searched && !p.wcnt && use_cut_apply(h, p.m)) {
-        launch_cut_apply(p, t, nt, h->sb, h->pk, cutpack, h->all_alive, h->stream);
+    if (!virt && !searched && !p.wcnt && h->ca_now) {
+        launch_cut_apply(p, t, nt, h->sb, h->pk, h->pk2, h->Tg, cutpack, h->all_alive, h->stream);
         if (cutpack) {
             Plan pp = p;
             pp.wcnt = h->pk.wcnt;
@@ -427,7 +435,8 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     // a whole-table fix-up by k_cut_apply takes its ordered spill totals from its own pass: k_scan / k_resolve need not
     // maintain the rejected-load tables R / RP (k_resolve: one prefix over the blocks per node group that owns a cut)
     SolveBufs rb = h->sb;
-    if (!compact && !inc && use_cut_apply(h, h->m)) { rb.R = nullptr; rb.RP = nullptr; }
+    h->ca_now = h->ca_now && !compact && !inc;
+    if (h->ca_now) { rb.R = nullptr; rb.RP = nullptr; rb.Tg = h->Tg; }
     if (inc) {
         // (t.cur is read AND written: the tick is committed, nobody is promised the table as it was)
         launch_inc_scan(h->plan, h->assign[h->cur], h->load, h->aff, nt, h->sb, h->pk, h->stream);
@@ -593,6 +602,7 @@ int solve_locked(rio_gp* h, rio_gp_stats* stats, bool commit = false) {
     // ... and when the tick is committed and the library's `used` vector is valid, the scan streams the assignment column
     // alone and works in place (k_inc_scan)
     const int inc = inc_choice(h, compact, commit);
+    h->ca_now = cut_apply_for(h, cutpack);
     enqueue_scan_resolve(h, t, nt, compact, slot_dev(h, 0), inc);
     DevStats v;
     bool slow = false;
@@ -699,6 +709,7 @@ int tick_async_locked(rio_gp* h) {
     h->tick_epoch[k] = h->mut_epoch;
     h->tick_quiet[k] = quiet;
     h->tick_mark[k] = h->plan.mark = (1ull << 40) | ++h->wait_seq;  // column 7 of the verdict rows: peek_ticks knows them by it
+    h->ca_now = cut_apply_for(h, false);
     enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, inc_choice(h, compact, true));
     if (quiet) {
         // (k_scan + k_resolve only)
@@ -844,6 +855,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->sb.R, (size_t)kMaxBlocks); A(h->sb.RP, (size_t)kMaxBlocks * resolve_blocks((u32)M)); A(h->D, (size_t)kFillRounds * M);
     A(h->pk.idx, R); A(h->pk.load, R); A(h->pk.aff, R); A(h->pk.next, R); A(h->pk.wcnt, W);
     A(h->pk2.idx, R2); A(h->pk2.load, R2); A(h->pk2.aff, R2); A(h->pk2.next, R2); A(h->pk2.wcnt, W);
+    A(h->Tg, M * kWaves);
     A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
 #undef A
@@ -1920,6 +1932,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
     use_fx_slot(h, 0);
     const Table t = real_table(h);
     const NodeTab nt = scan_nodes(h);
+    h->ca_now = cut_apply_for(h, false);
     enqueue_scan_resolve(h, t, nt, false, slot_dev(h, h->ring_n));
     HIPCHK(h, hipGetLastError());
     h->ring_n++;
@@ -2589,7 +2602,8 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     h->compact_mode = mode & 15;
     h->inc_mode = (mode >> 7) & 3;       // bits 7-8: in-place scan of committed ticks, 0 auto | 1 whatever the table's size | 2 never
     if (h->inc_mode == 3) h->inc_mode = 0;
-    h->cutapply_mode = ((mode >> 9) & 3) == 2 ? 2 : 0;  // bits 9-10: 2 = the two-pass whole-table fix-up (k_cut_find, then k_fill<APPLY>)
+    h->cutapply_mode = (mode >> 9) & 3;  // bits 9-10: 0 = k_cut_apply when the solve packs at the cut pass | 1 = always | 2 = never
+    if (h->cutapply_mode == 3) h->cutapply_mode = 0;
     return RIO_GP_OK;
 }
 

@@ -419,8 +419,9 @@ class GpuPlacement:
         modes for packing at the cut pass of whole-table solves (round 0 of k_fill packs).  inc: the in-place scan of
         committed ticks over a mostly-placed table (k_inc_scan, then k_rebal deals the pending rows out evenly to the
         fix-up's workgroups) — "auto": whenever the packed fix-up is used and `used` is valid | "never": k_scan<COMPACT>.
-        cut_apply: whole-table fix-up — "auto": k_cut_apply (exact cuts + re-marking in one pass) | "never": k_cut_find, then
-        the re-marking pass inside round 0 of k_fill (round 5's form)."""
+        cut_apply: whole-table fix-up — "auto": k_cut_apply + k_cut_settle (exact cuts + re-marking in one pass over the wave
+        ranges that have work) when the solve packs at the cut pass | "always" | "never": k_cut_find, then the re-marking pass
+        inside round 0 of k_fill (round 5's form)."""
         self._need_lab()
         modes = {"auto": 0, "always": 1, "never": 2}
         incs = {"auto": 0, "always": 1, "never": 2}   # ("always" = "auto" since the size limit of the in-place tick went)

@@ -74,7 +74,7 @@ class Scenario:
             k = (seed // 3) % 6
             g.set_compact(("never", "always", "never", "always", "auto", "auto")[k], cut_pack=("never", "never", "always", "never", "auto", "auto")[k],
                           inc=("auto", "always", "never", "never", "always", "never")[k],
-                          cut_apply=("auto", "never")[(seed // 54) % 2])   # (the one-pass / the two-pass whole-table fix-up)
+                          cut_apply=("auto", "never", "always")[(seed // 54) % 3])   # (the one-pass / the two-pass whole-table fix-up)
             g.set_speculate(("never", "always", "auto")[(seed // 18) % 3])
         self.log = []
         self.count = {}

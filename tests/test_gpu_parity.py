@@ -30,7 +30,9 @@ FIXUP_VARIANTS = (("never", "never"), ("always", "never"), ("never", "always"), 
                   ("cutpack", "never"), ("cutpack", "always"),
                   # the two-pass whole-table fix-up (k_cut_find, then the re-marking inside round 0 of k_fill): what the request
                   # path's virtual table and the row-sharded solve still run, kept under test on the real table too
-                  ("twopass", "never"), ("twopass-cutpack", "always"))
+                  ("twopass", "never"), ("twopass-cutpack", "always"),
+                  # ... and k_cut_apply where the adaptive rule would not pick it (a solve that does not pack at the cut pass)
+                  ("onepass", "always"))
 
 
 def apply_variant(g, mode):
@@ -42,6 +44,8 @@ def apply_variant(g, mode):
         g.set_compact("never", cut_pack="never", cut_apply="never")
     elif kind == "twopass-cutpack":
         g.set_compact("never", cut_pack="always", cut_apply="never")
+    elif kind == "onepass":
+        g.set_compact("never", cut_pack="never", cut_apply="always")
     else:
         g.set_compact(kind, cut_pack="never")
     g.set_speculate(spec)

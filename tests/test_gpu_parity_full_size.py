@@ -126,6 +126,9 @@ def test_config3_skew_at_10m(gp, oracle):
     g.set_compact("auto", cut_apply="never")
     _, _, st2 = _same(g, oracle, skew["cur"], skew, commit=False)
     assert st2 == st
+    g.set_compact("auto", cut_apply="always")    # (the one-pass form over a table where every wave range has work)
+    _, _, st2b = _same(g, oracle, skew["cur"], skew, commit=False)
+    assert st2b == st
     g.set_compact("auto", cut_pack="always")     # (packs 94 % of the table: what the adaptive rule never picks here)
     _, _, st3 = _same(g, oracle, skew["cur"], skew)
     assert st3 == st

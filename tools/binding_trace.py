@@ -25,7 +25,7 @@ rio_gp.lab_lib().rio_gp_debug_ktrace(g.handle, flags, 0, None)
 for _ in range(reps):
     st = g.solve()
 out = {"which": which, "last": st}
-names = {3: "k_scan", 6: "k_cut_apply", 1: "k_fill round 0 (apply)", 2: "k_fill rounds (fill only)", 4: "node order inside the last k_fill"}
+names = {3: "k_scan", 6: "k_cut_apply", 0: "k_cut_settle", 1: "k_fill round 0 (apply)", 2: "k_fill rounds (fill only)", 4: "node order inside the last k_fill"}
 tabs = {t: g.ktrace(True, t).astype(np.int64) for t in names}
 g.ktrace(False)
 g.close()
