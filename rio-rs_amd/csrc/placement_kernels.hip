@@ -2876,7 +2876,14 @@ __global__ __launch_bounds__(kBlock) void k_cut_settle(const CutSettleArgs a) {
     u32 sp_cnt = lane == 0 ? a.wsp_cnt[gw] : 0u;
     const u32 ul_n = a.ul.cnt[gw];
     u64 wstart, wend;
-    wave_range(p, gw, wstart, wend);
+    wave_range_plain(p, gw, wstart, wend);
+    // the first 64 entries of this range's list are requested now (clamped to the range's first word: always addressable), not
+    // behind the two dependent round trips that locate the cut waves
+    u32 po0, ro0, lo0, no0;
+    {
+        const u64 i0 = wstart + (u64)((u32)lane < ul_n ? (u32)lane : 0u);
+        po0 = a.ul.pos[i0]; ro0 = a.ul.row[i0]; lo0 = a.ul.load[i0]; no0 = a.ul.node[i0];
+    }
     if (tid == 0) nslot = 0;
     if (tid < 4) red[tid] = 0;
     __syncthreads();
@@ -2946,12 +2953,13 @@ __global__ __launch_bounds__(kBlock) void k_cut_settle(const CutSettleArgs a) {
             // the group's wave sums (k_cut_apply's atomics, complete since the launch boundary)
             for (u32 k = tid; k < kn * kWaves; k += kBlock) {
                 const u32 ls = k / kWaves, w = k % kWaves;
-                T[(size_t)ls * 17 + w] = a.Tg[(size_t)node_of[g0 + ls] * kWaves + w];
+                const u32 nd = node_of[g0 + ls];
+                T[(size_t)ls * 17 + w] = a.Tg[(size_t)nd * kWaves + w];
+                if (w == 0) g_rem[ls] = a.budget[nd];   // (the same round trip as the sums)
             }
             __syncthreads();
             for (u32 ls = tid; ls < kn; ls += kBlock) {  // the wave in which the node's claim prefix crosses the budget
-                const u32 nd = node_of[g0 + ls];
-                const u64 bud = a.budget[nd];
+                const u64 bud = g_rem[ls];
                 const u64* Tj = T + (size_t)ls * 17;
                 u64 acc = 0, pre = 0;
                 u32 cw = kWaves;
@@ -2974,11 +2982,7 @@ __global__ __launch_bounds__(kBlock) void k_cut_settle(const CutSettleArgs a) {
             RIOGP_KT(p, 0, 3);
             // this range's undecided rows, 64 a step, the next step's words in flight
             if (ul_n) {
-                u32 po = 0, ro = 0, lo = 0, no = 0;
-                {
-                    const u64 i0 = wstart + (u64)((u32)lane < ul_n ? (u32)lane : 0u);
-                    po = a.ul.pos[i0]; ro = a.ul.row[i0]; lo = a.ul.load[i0]; no = a.ul.node[i0];
-                }
+                u32 po = po0, ro = ro0, lo = lo0, no = no0;
                 for (u32 q0 = 0; q0 < ul_n; q0 += 64) {  // (wave-uniform)
                     const u32 q = q0 + (u32)lane;
                     const u32 pc = po, rc = ro, lc = lo, nc = no;
