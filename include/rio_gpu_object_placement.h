@@ -42,9 +42,11 @@ typedef struct rio_op_cfg {
                             * placement target, its first touches go to the water-fill (the capacity-aware extension) */
     uint32_t collect_ns;   /* single-object calls that need the device share round trips (flat combining): how long, at most, a
                             * thread that takes over the device waits until about as many callers have published as the last two
-                            * batches carried together, in ns; 0 = the default (RIO_OP_DEFAULT_COLLECT_NS), 1 = do not wait */
+                            * batches carried together, in ns; 0 = the default (RIO_OP_DEFAULT_COLLECT_NS), 1 = do not wait;
+                            * more than RIO_OP_MAX_COLLECT_NS is RIO_GP_EINVAL (a field a version-1 client left uninitialised) */
 } rio_op_cfg;
 #define RIO_OP_DEFAULT_COLLECT_NS 6000u
+#define RIO_OP_MAX_COLLECT_NS 1000000u
 #define RIO_OP_CFG_LIVE_FIRST_TOUCH 4u
 /* Host shadow of the assignment column.  The reference calls lookup / get_or_create_placement once per request from one task per
  * connection (server.rs:292-304) and LocalObjectPlacement answers a hit from a hash map (local.rs:42-49); a device round trip per
@@ -138,6 +140,19 @@ int rio_op_lookup_n(rio_op_t* p, const char* struct_name, size_t struct_name_len
 int rio_op_remove_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id, size_t object_id_len);
 int rio_op_get_or_create_placement_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id,
                                      size_t object_id_len, const char* self_address, char* out, size_t out_cap, uint32_t* flag);
+/* The two calls an unchanged Server makes for EVERY request (server.rs:292-304 -> service.rs:199-200: lookup, then the sticky
+ * branch of get_or_create_placement), answered from the host shadow ONLY: they never touch the device, never wait for a lock a
+ * device call can hold, never intern anything.  RIO_GP_OK: answered, exactly as rio_op_lookup_n / rio_op_get_or_create_placement_n
+ * would have (a key nobody has interned is Ok(None) for the lookup); RIO_GP_EAGAIN: the shadow cannot say — an unknown key or
+ * requester for the request, a row whose last answer has been invalidated, an object that is pending or sits on a server that is
+ * not an active, well-formed member, the table lock held by a writer — nothing was done, make the blocking call.  An async host
+ * calls these inline on its worker thread and pays the hand-off to a blocking thread (tokio::task::spawn_blocking: several
+ * microseconds) only on EAGAIN; LocalObjectPlacement::lookup never yields either (local.rs:42-49).  With
+ * RIO_OP_CFG_NO_HOST_SHADOW every call is EAGAIN. */
+int rio_op_try_lookup_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id, size_t object_id_len,
+                        char* out, size_t out_cap, int* found);
+int rio_op_try_get_or_create_placement_n(rio_op_t* p, const char* struct_name, size_t struct_name_len, const char* object_id,
+                                         size_t object_id_len, const char* self_address, char* out, size_t out_cap, uint32_t* flag);
 int rio_op_snapshot_key_lengths(rio_op_t* p, const size_t** struct_name_lens, const size_t** object_id_lens);
 /* ... and the batched calls: struct_names[k] / object_ids[k] point at struct_name_lens[k] / object_id_lens[k] bytes (any byte, a
  * NUL included); otherwise rio_op_update_batch / rio_op_lookup_batch / rio_op_get_or_create_placement_batch /

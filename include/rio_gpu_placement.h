@@ -46,7 +46,11 @@
 extern "C" {
 #endif
 
-#define RIO_GP_ABI_VERSION 1u
+/* 2: rio_op_cfg.flags == 0 means the reference's first touch (round 5 flipped the default: RIO_OP_CFG_LIVE_FIRST_TOUCH opts out),
+ * rio_op_cfg.reserved became collect_ns, rio_gp_mixed_batch and the rio_op_*_batch_n / rio_op_try_* calls exist, RIO_GP_EAGAIN.
+ * A client built against version 1 that passes flags = 0 gets another placement policy: compare rio_gp_abi_version() with the
+ * header it was built against. */
+#define RIO_GP_ABI_VERSION 2u
 
 /* "not placed": Option::None of lookup (object_placement/mod.rs:50). */
 #define RIO_GP_NONE 0xFFFFFFFFu
@@ -85,6 +89,8 @@ extern "C" {
 #define RIO_GP_ENODEV 3    /* no HIP device / not gfx950: the product path fails loudly */
 #define RIO_GP_ENOMEM 4
 #define RIO_GP_ERANGE 5    /* string layer: the caller's output buffer is too small (nothing is truncated) */
+#define RIO_GP_EAGAIN 6    /* string layer, rio_op_try_*: the host shadow cannot answer without the device (or without a lock a device
+                            * call may hold): nothing was done, make the blocking call */
 
 /* per-request outcome of rio_gp_place_pending (service.rs:193-298 folded into one code) */
 #define RIO_GP_FLAG_LOCAL 0u      /* already placed on the requester (sticky hit, service.rs:241-242,262-264) */

@@ -54,6 +54,18 @@
 
 namespace {
 
+// one spin-wait step that tells the core (and its sibling thread) that this is one
+#if defined(__x86_64__) || defined(__i386__)
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+#elif defined(__aarch64__)
+static inline void cpu_relax() { __asm__ __volatile__("yield" ::: "memory"); }
+#else
+static inline void cpu_relax() { __asm__ __volatile__("" ::: "memory"); }
+#endif
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ != __ORDER_LITTLE_ENDIAN__
+#error "Req::futex_word takes the upper half of a 64-bit word as the word at offset 4: little-endian hosts only"
+#endif
+
 constexpr int kFull = -1000;  // internal: the object table has no free row (reclaim, then retry)
 constexpr int kNoop = -1001;  // internal: nothing to do on the device (an unknown key looked up / removed / deleted)
 constexpr int kUpgrade = -1002;  // internal: the call has to change the interning tables — again, under the exclusive lock
@@ -177,7 +189,7 @@ class TableLock {
         return mine;
     }
     static void backoff(unsigned spin) {
-        if (spin < 256) { __builtin_ia32_pause(); return; }
+        if (spin < 256) { cpu_relax(); return; }
         if (spin < 512) { sched_yield(); return; }
         const timespec ts{0, 50000};  // a reclaim or a big batch's interning holds the lock for milliseconds: do not burn a CPU on it
         nanosleep(&ts, nullptr);
@@ -192,6 +204,13 @@ class TableLock {
             r.fetch_sub(1, std::memory_order_seq_cst);
             while (writer_.load(std::memory_order_acquire)) backoff(spin++);
         }
+    }
+    bool try_lock_shared() {  // never waits: false while a writer holds or wants the lock
+        std::atomic<uint32_t>& r = groups_[my_group()].readers;
+        r.fetch_add(1, std::memory_order_seq_cst);
+        if (!writer_.load(std::memory_order_seq_cst)) return true;
+        r.fetch_sub(1, std::memory_order_seq_cst);
+        return false;
     }
     void unlock_shared() { groups_[my_group()].readers.fetch_sub(1, std::memory_order_release); }
     void lock() {
@@ -509,7 +528,14 @@ int policy_batch(State* s, std::vector<uint32_t>& rows, std::vector<uint32_t>& r
     bool cleaned = false;
     for (uint64_t k = 0; k < n && !cleaned && out_flag; ++k) cleaned = (out_flag[k] & RIO_GP_FLAG_REPLACED) != 0;
     if (cleaned || !out_flag) s->shadow.invalidate_all();
-    for (uint64_t k = 0; k < n; ++k) s->shadow.put(rows[k], out_node[k]);
+    // (a batch that cleaned a server: the device cleans first and places then — a first touch onto a requester that is not an
+    //  active member survives there, where the reference's request order might wipe it again — so such answers are not cached:
+    //  the next call about that row asks the device)
+    std::shared_lock<TableLock> li(s->imu, std::defer_lock);
+    if (cleaned && !tables_locked) li.lock();
+    for (uint64_t k = 0; k < n; ++k)
+        if (!cleaned || out_node[k] == RIO_GP_NONE || (out_node[k] < s->node_alive.size() && s->node_alive[out_node[k]]))
+            s->shadow.put(rows[k], out_node[k]);
     return RIO_GP_OK;
 }
 
@@ -615,13 +641,17 @@ void serve(State* s, std::vector<Req*>& batch, std::vector<uint64_t>& results) {
                 for (int kind : kOrder) {  // the shadow follows in the order the device applied them
                     const State::KindBuf& b = kb[kind];
                     if (b.who.empty() || m.rc[kRcOf[kind]] != RIO_GP_OK) continue;  // a refused kind changed nothing: one by one below
+                    bool cleaned = false;
                     if (kind == 1) {
-                        bool cleaned = false;
                         for (size_t k = 0; k < b.who.size() && !cleaned; ++k) cleaned = (b.fl[k] & RIO_GP_FLAG_REPLACED) != 0;
                         if (cleaned) s->shadow.invalidate_all();
                     }
-                    for (size_t k = 0; k < b.who.size(); ++k)
-                        s->shadow.put(b.rows[k], kind == 2 ? b.reqs[k] : kind == 3 ? RIO_GP_NONE : b.res[k]);
+                    std::shared_lock<TableLock> lk(s->imu, std::defer_lock);
+                    if (cleaned) lk.lock();  // (policy_batch's rule: after a clean, answers on servers that are not active are not cached)
+                    for (size_t k = 0; k < b.who.size(); ++k) {
+                        const uint32_t v = kind == 2 ? b.reqs[k] : kind == 3 ? RIO_GP_NONE : b.res[k];
+                        if (!cleaned || v == RIO_GP_NONE || (v < s->node_alive.size() && s->node_alive[v])) s->shadow.put(b.rows[k], v);
+                    }
                     answer(kind, RIO_GP_OK);
                     done[kind] = true;
                 }
@@ -658,8 +688,8 @@ static inline long long waited_ns(const std::chrono::steady_clock::time_point t0
 // wait); give the core away when it takes longer than `spin_ns` (more callers than cores; a compound call holds the device),
 // sleep in earnest when it takes much longer (a snapshot, a reclaim, a big batched call).
 static inline void wait_step(unsigned spin, const std::chrono::steady_clock::time_point t0, long long spin_ns) {
-    if (spin < 64) { __builtin_ia32_pause(); return; }
-    for (int q = 0; q < 4; ++q) __builtin_ia32_pause();
+    if (spin < 64) { cpu_relax(); return; }
+    for (int q = 0; q < 4; ++q) cpu_relax();
     if ((spin & 63u) != 0) return;
     const long long ns = waited_ns(t0);
     if (ns > 20 * spin_ns) { const timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
@@ -725,7 +755,7 @@ int run_combined(State* s, Req* mine) {
         const long long budget = s->spin_ns.load(std::memory_order_relaxed);
         for (unsigned spin = 1;; ++spin) {
             if ((w = mine->result.load(std::memory_order_acquire)) & Req::kDone) break;
-            __builtin_ia32_pause();
+            cpu_relax();
             if ((spin & 15u) != 0 || waited_ns(t0) < budget) continue;
             w = mine->result.fetch_or(Req::kSleep, std::memory_order_acq_rel);
             if (w & Req::kDone) break;
@@ -752,9 +782,10 @@ int run_combined(State* s, Req* mine) {
         // requests instead of 3 900, 7.1e5 against 5.2e5 calls/s, measured).
         const uint32_t want = (uint32_t)(s->last_batch + s->prev_batch) - 1u;
         const auto c0 = std::chrono::steady_clock::now();
-        while ((uint32_t)s->ticket.load(std::memory_order_relaxed) < want &&
-               std::chrono::steady_clock::now() - c0 < std::chrono::nanoseconds(s->collect_ns))
-            __builtin_ia32_pause();
+        // (wait_step: a window that outlasts its bound by much — the quota throttled the process — yields instead of burning on)
+        for (unsigned spin = 0; (uint32_t)s->ticket.load(std::memory_order_relaxed) < want &&
+                                std::chrono::steady_clock::now() - c0 < std::chrono::nanoseconds(s->collect_ns); ++spin)
+            wait_step(spin, c0, (long long)s->collect_ns);
     }
     // close the generation: whoever takes a ticket from now on belongs to the next one (and its ticket 0 waits for this lock)
     const uint64_t closed = s->ticket.exchange((gen + 1) << 32, std::memory_order_acq_rel);
@@ -765,7 +796,10 @@ int run_combined(State* s, Req* mine) {
     Slot* sl = s->slots[gen & 1];
     for (uint32_t i = 0; i < n; ++i) {  // arrival (ticket) order; a caller between its ticket and its tag is waited for
         uint64_t tag;
-        while (((tag = sl[i].tag.load(std::memory_order_acquire)) >> 8) != gen + 1) __builtin_ia32_pause();
+        // (a publisher preempted between its ticket and its tag — 64-256 callers inside a 16-CPU quota — must get a CPU to finish:
+        //  pause, then yield, then sleep, instead of burning the quantum it is waiting for)
+        const auto w0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0; ((tag = sl[i].tag.load(std::memory_order_acquire)) >> 8) != gen + 1; ++spin) wait_step(spin, w0, 20000);
         s->sv_kind[i] = (int)(tag & 0xFFu);
         s->sv_row[i] = sl[i].row;
         s->sv_req[i] = sl[i].req;
@@ -862,6 +896,8 @@ int rio_op_create(const rio_op_cfg* cfg, rio_op_t** out) {
     if (out) *out = nullptr;
     if (!cfg || !out || cfg->struct_size != sizeof(rio_op_cfg) || cfg->max_objects == 0 || cfg->max_nodes == 0)
         return fail(RIO_GP_EINVAL, "rio_op_create: bad cfg");
+    if (cfg->collect_ns > RIO_OP_MAX_COLLECT_NS)  // (the field was `reserved` in ABI version 1: a client that never set it)
+        return fail(RIO_GP_EINVAL, "rio_op_create: collect_ns above RIO_OP_MAX_COLLECT_NS (1 ms)");
     rio_gp_cfg g;
     memset(&g, 0, sizeof g);
     g.struct_size = sizeof g;
@@ -1069,6 +1105,52 @@ int rio_op_lookup_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, 
 }
 
 size_t rio_op_last_address_len(rio_op_t*) { return t_addr_len; }
+
+// rio_op_try_*: the host shadow or RIO_GP_EAGAIN.  Nothing here takes State::mu, waits for the table lock (a batched call holds
+// it exclusively across its device calls), interns a key or an address, or counts as in flight: a pure read of the interning
+// tables and one shadow word, under the shared side of the table lock when it is free right now.
+namespace {
+struct TrySharedLock {
+    TableLock& l;
+    bool held;
+    explicit TrySharedLock(TableLock& l_) : l(l_), held(l_.try_lock_shared()) {}
+    ~TrySharedLock() { if (held) l.unlock_shared(); }
+};
+}  // namespace
+
+int rio_op_try_lookup_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, size_t id_len, char* out, size_t cap, int* found) {
+    if (!p || !found || (!ty && ty_len) || (!id && id_len)) return RIO_GP_EINVAL;
+    State* s = p->s;
+    *found = 0;
+    t_addr_len = 0;
+    TrySharedLock li(s->imu);
+    if (!li.held || s->reclaiming) return RIO_GP_EAGAIN;
+    const auto it = s->rows.find(key_of(Part(ty, ty_len), Part(id, id_len)));
+    if (it == s->rows.end()) return RIO_GP_OK;  // a key nobody has interned: Ok(None), as rio_op_lookup says without the device
+    uint32_t node;
+    if (!s->shadow.get(it->second, &node)) return RIO_GP_EAGAIN;
+    *found = node != RIO_GP_NONE;
+    return *found ? copy_out(s->node_addr[node], out, cap) : RIO_GP_OK;
+}
+
+int rio_op_try_get_or_create_placement_n(rio_op_t* p, const char* ty, size_t ty_len, const char* id, size_t id_len,
+                                         const char* self_address, char* out, size_t cap, uint32_t* flag) {
+    if (!p || !self_address || (!ty && ty_len) || (!id && id_len)) return RIO_GP_EINVAL;
+    State* s = p->s;
+    t_addr_len = 0;
+    TrySharedLock li(s->imu);
+    if (!li.held || s->reclaiming) return RIO_GP_EAGAIN;
+    const auto it = s->rows.find(key_of(Part(ty, ty_len), Part(id, id_len)));
+    if (it == s->rows.end() || s->row_keep[it->second]) return RIO_GP_EAGAIN;  // a first touch: the device's
+    const auto rq = s->nodes.find(self_address);
+    if (rq == s->nodes.end()) return RIO_GP_EAGAIN;                             // a requester nobody has seen: interned by the call
+    // the sticky path of service.rs:199-242, exactly as op_get_or_create answers it from the shadow
+    uint32_t nd;
+    if (!s->shadow.get(it->second, &nd) || nd == RIO_GP_NONE || nd >= s->node_alive.size() || !s->node_alive[nd] || s->node_malformed[nd])
+        return RIO_GP_EAGAIN;
+    if (flag) *flag = nd == rq->second ? RIO_GP_FLAG_LOCAL : RIO_GP_FLAG_REDIRECT;
+    return copy_out(s->node_addr[nd], out, cap);
+}
 
 int rio_op_clean_server(rio_op_t* p, const char* address) {
     if (!p || !address) return RIO_GP_EINVAL;

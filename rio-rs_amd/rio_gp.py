@@ -22,7 +22,7 @@ OP_CFG_LIVE_FIRST_TOUCH = 4     # RIO_OP_CFG_LIVE_FIRST_TOUCH (string layer, who
 FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleaned and re-placed by this request
 FLAG_MASK = 0x0F
-OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM, ERANGE = range(6)
+OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM, ERANGE, EAGAIN = range(7)
 
 LAB_PATH = os.path.join(_DIR, "librio_gp_lab.so")   # the same sources + -DRIO_GP_LAB + stream_probe.hip (tests / tools only)
 SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "gpu_object_placement.cpp")]
@@ -480,6 +480,9 @@ def _oplib():
         L.rio_op_update_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
         L.rio_op_lookup_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
         L.rio_op_remove_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.rio_op_try_lookup_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.rio_op_try_get_or_create_placement_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p,
+                                                           C.c_size_t, C.POINTER(C.c_uint32)]
         L.rio_op_get_or_create_placement_n.argtypes = [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p,
                                                        C.c_size_t, C.POINTER(C.c_uint32)]
         L.rio_op_snapshot_key_lengths.argtypes = [_vp, C.POINTER(C.POINTER(C.c_size_t)), C.POINTER(C.POINTER(C.c_size_t))]
@@ -587,6 +590,29 @@ class GpuObjectPlacement:
                 continue
             self._chk(rc)
             return buf.value.decode() if found.value else None
+
+    def try_lookup(self, struct_name, object_id, _cap=512):
+        """rio_op_try_lookup_n: (True, Option<String>) when the host shadow answers — never the device, never a wait —,
+        (False, None) on RIO_GP_EAGAIN (make the blocking call).  What the Rust adapter calls inline on the async worker."""
+        buf, found = C.create_string_buffer(_cap), C.c_int(0)
+        t, i = struct_name.encode(), object_id.encode()
+        rc = _oplib().rio_op_try_lookup_n(self._h, t, len(t), i, len(i), buf, _cap, C.byref(found))
+        if rc in (EAGAIN, ERANGE):
+            return False, None
+        self._chk(rc)
+        return True, (buf.value.decode() if found.value else None)
+
+    def try_get_or_create_placement(self, struct_name, object_id, self_address, _cap=512):
+        """rio_op_try_get_or_create_placement_n: (True, address, flag) for the sticky branch of service.rs:199-242 out of the
+        host shadow, (False, None, None) on RIO_GP_EAGAIN."""
+        buf, flag = C.create_string_buffer(_cap), C.c_uint32(0)
+        t, i = struct_name.encode(), object_id.encode()
+        rc = _oplib().rio_op_try_get_or_create_placement_n(self._h, t, len(t), i, len(i), self_address.encode(), buf, _cap,
+                                                           C.byref(flag))
+        if rc in (EAGAIN, ERANGE):
+            return False, None, None
+        self._chk(rc)
+        return True, buf.value.decode(), int(flag.value)
 
     def clean_server(self, address):
         self._chk(_oplib().rio_op_clean_server(self._h, address.encode()))

@@ -13,11 +13,15 @@
 //! `../Cargo.toml.patch` (feature + dependency), `../build.rs` (link search path) and
 //! `../tests/object_placement_backend_gpu.rs` (the `gpu` twin of the reference's conformance block).
 //!
-//! Blocking: a native call is a device round trip (15-25 us when the caller is alone; callers that
-//! arrive meanwhile are combined into the same round trip and spin, yield, then sleep on a condvar).
-//! `LocalObjectPlacement` returns in nanoseconds, so it may run inline on a tokio worker; this
-//! provider must not — every trait method hands its FFI call to `tokio::task::spawn_blocking`
-//! (the blocking pool is where the reference's own SQL providers effectively wait, too).
+//! Blocking: a native call that needs the device is a round trip (8-25 us when the caller is alone;
+//! callers that arrive meanwhile are combined into the same round trip and spin, yield, then sleep).
+//! `LocalObjectPlacement` returns in nanoseconds and runs inline on a tokio worker (local.rs:42-49
+//! never yields).  This provider does the same for what its host shadow can answer: `lookup` — and
+//! the sticky branch of `get_or_create_placement` — first call `rio_op_try_*` INLINE on the async
+//! worker (a hash-map read under a reader lock, ~0.25 us, never the device, never a lock a device
+//! call holds) and only on `RIO_GP_EAGAIN` hand the blocking call to `tokio::task::spawn_blocking`
+//! (a thread hand-off of several microseconds; the blocking pool is where the reference's own SQL
+//! providers effectively wait, too).  Every other trait method goes to the blocking pool.
 
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
 use std::fmt;
@@ -45,6 +49,8 @@ const RIO_OP_CFG_LIVE_FIRST_TOUCH: u32 = 4; // include/rio_gpu_object_placement.
 const RIO_GP_EINVAL: c_int = 1;
 /// the output buffer was too small: nothing is truncated, `rio_op_last_address_len` says what is needed
 const RIO_GP_ERANGE: c_int = 5;
+/// `rio_op_try_*`: the host shadow cannot answer; nothing was done — make the blocking call
+const RIO_GP_EAGAIN: c_int = 6;
 /// `rio_gp_stats` (include/rio_gpu_placement.h): counters of one whole-table solve.
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -76,6 +82,12 @@ extern "C" {
                        addr: *const c_char) -> c_int;
     fn rio_op_lookup_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize,
                        out: *mut c_char, cap: usize, found: *mut c_int) -> c_int;
+    // ... answered from the host shadow or RIO_GP_EAGAIN: never the device, never a wait (called inline on the async worker)
+    fn rio_op_try_lookup_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize,
+                           out: *mut c_char, cap: usize, found: *mut c_int) -> c_int;
+    fn rio_op_try_get_or_create_placement_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize,
+                                            self_addr: *const c_char, out: *mut c_char, cap: usize,
+                                            flag: *mut u32) -> c_int;
     fn rio_op_last_address_len(p: *mut c_void) -> usize;
     fn rio_op_clean_server(p: *mut c_void, addr: *const c_char) -> c_int;
     fn rio_op_remove_n(p: *mut c_void, ty: *const c_char, ty_len: usize, id: *const c_char, id_len: usize) -> c_int;
@@ -157,9 +169,29 @@ impl GpuObjectPlacement {
         check(unsafe { rio_op_set_member(self.inner.0, a.as_ptr(), active as c_int, capacity.unwrap_or(u64::MAX)) }, self)
     }
 
+    /// `get_or_create_placement` for an async caller: the sticky branch (service.rs:199-242 — the object sits on a server that
+    /// is an active member) is answered inline from the host shadow; a first touch, an object on a dead server, an unknown
+    /// requester go to the blocking pool.  What an unchanged `Service` would call per request.
+    pub async fn get_or_create_placement_async(&self, object_id: &ObjectId, self_address: &str)
+        -> Result<(Option<String>, u32), ObjectPlacementError> {
+        let me_addr = cstr(self_address)?;
+        let (ty, id) = (&object_id.0, &object_id.1);
+        let mut buf = [0 as c_char; 256];
+        let mut flag = 0u32;
+        let rc = unsafe { rio_op_try_get_or_create_placement_n(self.inner.0, ty.as_ptr() as *const c_char, ty.len(),
+                                                               id.as_ptr() as *const c_char, id.len(), me_addr.as_ptr(),
+                                                               buf.as_mut_ptr(), buf.len(), &mut flag) };
+        if rc == RIO_GP_OK {
+            return Ok((Some(unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()), flag));
+        }
+        if rc != RIO_GP_EAGAIN && rc != RIO_GP_ERANGE { return Err(to_err(rc, self.inner.0)); }
+        let (me, oid, addr) = (self.clone(), object_id.clone(), self_address.to_string());
+        blocking(move || me.get_or_create_placement(&oid, &addr)).await
+    }
+
     /// Batched replacement of `Service::get_or_create_placement` + `check_address_mismatch`
     /// (rio-rs/src/service.rs:193-298) for callers that want one call instead of
-    /// lookup + is_active + clean_server + update.
+    /// lookup + is_active + clean_server + update.  Blocking (a device round trip unless the shadow answers).
     pub fn get_or_create_placement(&self, object_id: &ObjectId, self_address: &str)
         -> Result<(Option<String>, u32), ObjectPlacementError> {
         let (ty, id, me) = (&object_id.0, &object_id.1, cstr(self_address)?);
@@ -325,8 +357,20 @@ impl ObjectPlacement for GpuObjectPlacement {
         .await
     }
 
-    // mod.rs:50 / local.rs:42-49: a miss is Ok(None)
+    // mod.rs:50 / local.rs:42-49: a miss is Ok(None).  The call an unchanged Server makes for every request
+    // (server.rs:292-304 -> service.rs:199-200): answered inline when the host shadow can (no thread hand-off, like
+    // LocalObjectPlacement's hash-map read), on the blocking pool only when the device has to be asked.
     async fn lookup(&self, object_id: &ObjectId) -> Result<Option<String>, ObjectPlacementError> {
+        let (ty, id) = (&object_id.0, &object_id.1);
+        let mut buf = [0 as c_char; 256];
+        let mut found: c_int = 0;
+        let rc = unsafe { rio_op_try_lookup_n(self.inner.0, ty.as_ptr() as *const c_char, ty.len(), id.as_ptr() as *const c_char,
+                                              id.len(), buf.as_mut_ptr(), buf.len(), &mut found) };
+        if rc == RIO_GP_OK {
+            return Ok(if found != 0 { Some(unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()) } else { None });
+        }
+        // RIO_GP_ERANGE (an address longer than the stack buffer) takes the blocking path as well: it sizes its buffer
+        if rc != RIO_GP_EAGAIN && rc != RIO_GP_ERANGE { return Err(to_err(rc, self.inner.0)); }
         let (ty, id) = (object_id.0.clone(), object_id.1.clone());
         let me = self.clone();
         blocking(move || lookup_owned(&me, &ty, &id)).await

@@ -28,6 +28,7 @@ static rio_op_t* make(uint64_t max_objects, uint32_t max_nodes) {
 
 int main() {
     std::atomic<int> bad{0};
+    std::atomic<long> try_hits{0};
     // ---------------------------------------------------------------- phase 1
     rio_op_t* p = make(4096, 64);
     if (!p) return 1;
@@ -43,6 +44,22 @@ int main() {
             if (rio_op_get_or_create_placement(mine, "Obj", id.c_str(), self.c_str(), out, sizeof out, &flag) != RIO_GP_OK) ++bad;
             else if (!out[0] || flag > RIO_GP_FLAG_PLACED) ++bad;   // all four servers stay up: LOCAL, REDIRECT or PLACED
             if (rio_op_lookup(mine, "Obj", id.c_str(), out, sizeof out, &found) != RIO_GP_OK || !found) ++bad;
+            {   // the non-blocking twins (what an async host calls inline): the shadow's answer or RIO_GP_EAGAIN, nothing else —
+                // while other threads intern keys, write, clean and take snapshots
+                char o2[64];
+                int f2 = 0;
+                uint32_t fl2 = 99;
+                int rc = rio_op_try_lookup_n(mine, "Obj", 3, id.c_str(), id.size(), o2, sizeof o2, &f2);
+                if (rc == RIO_GP_OK) { if (!f2 || strncmp(o2, "10.0.0.", 7) != 0) ++bad; ++try_hits; }
+                else if (rc != RIO_GP_EAGAIN) ++bad;
+                rc = rio_op_try_get_or_create_placement_n(mine, "Obj", 3, id.c_str(), id.size(), self.c_str(), o2, sizeof o2, &fl2);
+                if (rc == RIO_GP_OK) { if (!o2[0] || fl2 > RIO_GP_FLAG_REDIRECT) ++bad; ++try_hits; }
+                else if (rc != RIO_GP_EAGAIN) ++bad;
+                // a key nobody has interned: Ok(None) for the lookup, EAGAIN (a first touch) for the request
+                rc = rio_op_try_lookup_n(mine, "Nope", 4, id.c_str(), id.size(), o2, sizeof o2, &f2);
+                if (!(rc == RIO_GP_EAGAIN || (rc == RIO_GP_OK && !f2))) ++bad;
+                if (rio_op_try_get_or_create_placement_n(mine, "Nope", 4, id.c_str(), id.size(), self.c_str(), o2, sizeof o2, &fl2) != RIO_GP_EAGAIN) ++bad;
+            }
             if (k % 50 == 0) {                                      // a server that was never a member: nothing to clean
                 rio_op_clean_server(mine, "10.9.9.9:1");
                 rio_op_set_member(mine, self.c_str(), 1, RIO_GP_CAP_INF);
@@ -211,7 +228,8 @@ int main() {
     rio_op_release(p);
     const int bad4 = bad.load() - bad1 - bad2 - bad3;
 
-    printf("wrong=%d (phase1 %d phase2 %d phase3 %d phase4 %d) nonok=%d placed=%llu\n", bad.load(), bad1, bad2, bad3, bad4,
-           nonok.load(), (unsigned long long)n);
+    if (try_hits.load() == 0) ++bad;  // (the shadow answered none of thousands of repeated lookups: the try calls are dead)
+    printf("wrong=%d (phase1 %d phase2 %d phase3 %d phase4 %d) nonok=%d placed=%llu try_hits=%ld\n", bad.load(), bad1, bad2, bad3, bad4,
+           nonok.load(), (unsigned long long)n, try_hits.load());
     return (bad.load() || nonok.load()) ? 2 : 0;
 }

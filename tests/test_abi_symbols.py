@@ -51,7 +51,7 @@ def test_lab_library_is_the_product_plus_the_debug_header(built):
 
 
 def test_abi_version(built):
-    assert built.lib().rio_gp_abi_version() == 1
+    assert built.lib().rio_gp_abi_version() == 2
 
 
 def test_headers_cite_reference_lines():
@@ -117,7 +117,7 @@ def test_headers_are_plain_c99_and_a_c_host_links(built, tmp_path):
                     "-L", libdir, "-lrio_gp", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi=1" in r.stdout
+    assert "abi=2" in r.stdout
     if torch.cuda.is_available():
         assert "rc=0" in r.stdout and "backend=hip:gfx950" in r.stdout
     else:

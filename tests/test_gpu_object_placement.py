@@ -250,6 +250,7 @@ def test_host_shadow_answers_exactly_what_the_device_would(gp, seed):
         for p in (a, b):
             p.set_member(x, True, capacity=40 if seed % 2 else gp.CAP_INF)     # (odd seeds: capacities bind, rows spill)
     keys = [("T%d" % (k % 3), "k%d" % k) for k in range(140)]
+    tries = {"lookup": 0, "request": 0}
     for step in range(700):
         r = rng.random()
         ty, oid = keys[int(rng.integers(len(keys)))]
@@ -294,9 +295,25 @@ def test_host_shadow_answers_exactly_what_the_device_would(gp, seed):
                 keys.append(nk)
         elif r < 0.70:
             me = addrs[int(rng.integers(len(addrs) - 1))]
-            assert a.get_or_create_placement(ty, oid, me) == b.get_or_create_placement(ty, oid, me), (step, ty, oid, me)
+            # the non-blocking twin first (rio_op_try_*: the shadow or RIO_GP_EAGAIN, never the device): when it answers, it
+            # answers what the provider WITHOUT a shadow gets from the device
+            before = a.device_round_trips()
+            ok, taddr, tflag = a.try_get_or_create_placement(ty, oid, me)
+            assert a.device_round_trips() == before and b.try_get_or_create_placement(ty, oid, me)[0] is False
+            want = b.get_or_create_placement(ty, oid, me)
+            if ok:
+                tries["request"] += 1
+                assert (taddr, tflag) == want and tflag in (gp.FLAG_LOCAL, gp.FLAG_REDIRECT), (step, ty, oid, me)
+            assert a.get_or_create_placement(ty, oid, me) == want, (step, ty, oid, me)
         else:
-            assert a.lookup(ty, oid) == b.lookup(ty, oid), (step, ty, oid)
+            before = a.device_round_trips()
+            ok, taddr = a.try_lookup(ty, oid)
+            assert a.device_round_trips() == before
+            want = b.lookup(ty, oid)
+            if ok:
+                tries["lookup"] += 1
+                assert taddr == want, (step, ty, oid)
+            assert a.lookup(ty, oid) == want, (step, ty, oid)
     for k in keys:
         assert a.lookup(*k) == b.lookup(*k)
     assert len(a) == len(b) and sorted(a.snapshot()) == sorted(b.snapshot())
@@ -315,6 +332,21 @@ def test_host_shadow_answers_exactly_what_the_device_would(gp, seed):
                 calls += 1
     (_, ra2), (_, rb2) = a.device_round_trips(), b.device_round_trips()
     assert rb2 - rb >= calls - 2 * len(keys) and ra2 - ra < 0.6 * (rb2 - rb), (ra2 - ra, rb2 - rb, calls)
+    # the try calls did answer (a dead entry point would pass every comparison above), and now that every key has been looked
+    # up they answer every lookup of a known key — without a round trip
+    assert tries["lookup"] > 0 and tries["request"] > 0, tries
+    before = a.device_round_trips()
+    for k in keys:                       # (one more pass of blocking lookups: whatever a late clean invalidated is back)
+        a.lookup(*k)
+    before = a.device_round_trips()
+    for k in keys:
+        ok, addr = a.try_lookup(*k)
+        assert ok and addr == b.lookup(*k), k
+    assert a.try_lookup("Never", "seen") == (True, None)          # a key nobody has interned: Ok(None), no device work
+    assert b.try_lookup("Never", "seen") == (True, None)
+    placed = [k for k in keys if b.lookup(*k) is not None]
+    assert placed and all(b.try_lookup(*k)[0] is False for k in placed)   # without a shadow every interned key is EAGAIN
+    assert a.device_round_trips() == before
     a.close(); b.close()
 
 
@@ -384,9 +416,18 @@ def test_concurrent_single_object_calls_share_round_trips(gp, tmp_path):
     r = subprocess.run([str(exe), "5000", "400", "8"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    # 2 providers (host shadow | every call on the device) x 3 calls x threads {1, 4}; 8 is not in the ladder
-    assert len(rows) == 12 and all(x["wrong"] == 0 for x in rows)
-    pick = lambda prov, call, t: [x for x in rows if x["provider"] == prov and x["call"] == call and x["threads"] == t][0]
+    # 2 providers (host shadow | every call on the device) x 3 calls x threads {1, 4}; 8 is not in the ladder — and, with the
+    # shadow, the two hand-off entries (every call through a pool of blocking threads | rio_op_try_* inline, the pool on EAGAIN)
+    # x 3 calls at one thread
+    assert len(rows) == 18 and all(x["wrong"] == 0 for x in rows)
+    pick = lambda prov, call, t, entry="direct": [x for x in rows if x["provider"] == prov and x["call"] == call and
+                                                  x["threads"] == t and x["entry"] == entry][0]
+    for call in ("lookup", "get_or_create_placement"):   # known, placed keys: every try call is answered, none reaches the device
+        x, y = pick("shadow", call, 1, "try"), pick("shadow", call, 1, "pool")
+        assert x["try_calls"] == x["calls"] and x["try_answered"] == x["try_calls"] and x["requests_on_device"] == 0, x
+        assert x["calls_per_s"] > 2 * y["calls_per_s"], (x, y)      # (the hand-off costs several times the hit it carries)
+    x = pick("shadow", "churn", 1, "try")                # a tenth of the calls are first touches: those take the hand-off
+    assert 0 < x["try_answered"] < x["try_calls"] and x["requests_on_device"] > 0, x
     for call in ("lookup", "get_or_create_placement", "churn"):
         one, four = pick("device", call, 1), pick("device", call, 4)
         assert four["calls_per_s"] > 0.5 * one["calls_per_s"], (call, one, four)   # shares round trips; the bound only guards against a convoy

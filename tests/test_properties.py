@@ -152,6 +152,9 @@ def oplib(tmp_path_factory):
     L.rio_op_set_member.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint64]
     L.rio_op_get_or_create_placement.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
     L.rio_op_len.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rio_op_try_lookup_n.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.rio_op_try_get_or_create_placement_n.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p,
+                                                       C.c_size_t, C.POINTER(C.c_uint32)]
     return L
 
 
@@ -214,6 +217,13 @@ def test_string_layer_equals_the_reference_restatement(oracle, oplib, ops):
                 assert oplib.rio_op_update(op.h, ty.encode(), oid.encode(), None if addr is None else addr.encode()) == 0
                 ref.update(ty, oid, addr)
             elif kind == "lookup":
+                # the non-blocking twin first: RIO_GP_EAGAIN (6), or the answer — the reference's, like the blocking call's
+                ty, oid = (v.encode() for v in KEYS[x])
+                buf, found = C.create_string_buffer(128), C.c_int(0)
+                rc = oplib.rio_op_try_lookup_n(op.h, ty, len(ty), oid, len(oid), buf, 128, C.byref(found))
+                assert rc in (0, 6)
+                if rc == 0:
+                    assert (buf.value.decode() if found.value else None) == ref.lookup(*KEYS[x])
                 assert op.lookup(*KEYS[x]) == ref.lookup(*KEYS[x])
             elif kind == "remove":
                 assert oplib.rio_op_remove(op.h, KEYS[x][0].encode(), KEYS[x][1].encode()) == 0
@@ -229,10 +239,16 @@ def test_string_layer_equals_the_reference_restatement(oracle, oplib, ops):
             else:  # a request arriving at ANY member: the reference first-touches self.address whatever membership says about it
                 me = ADDRS[y]  # (service.rs:244-252) — and so does the string layer by default (round-4 verdict, item 6)
                 ty, oid = KEYS[x]
+                tbuf, tflag = C.create_string_buffer(128), C.c_uint32(0)
+                trc = oplib.rio_op_try_get_or_create_placement_n(op.h, ty.encode(), len(ty.encode()), oid.encode(), len(oid.encode()),
+                                                                 me.encode(), tbuf, 128, C.byref(tflag))
+                assert trc in (0, 6)
                 buf, flag = C.create_string_buffer(128), C.c_uint32(0)
                 assert oplib.rio_op_get_or_create_placement(op.h, ty.encode(), oid.encode(), me.encode(), buf, 128, C.byref(flag)) == 0
                 want = oracle.get_or_create_placement(ref, members, me, ty, oid)
                 assert buf.value.decode() == want
+                if trc == 0:   # (the sticky branch: nothing changes, so the blocking call behind it says the same)
+                    assert tbuf.value.decode() == want and tflag.value == flag.value and tflag.value in (0, 1)
         for key in KEYS:
             assert op.lookup(*key) == ref.lookup(*key)
         n = C.c_uint64(0)

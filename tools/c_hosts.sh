@@ -1,7 +1,8 @@
 #!/bin/bash
 # The two C hosts of examples/ against the library of this tree: pipelined solves + churn ticks from C99 (c_host), and the
 # trait-shaped single-object calls from 1 / 4 / 16 / 64 / 256 pthreads sharing one provider (c_host_threads: with the host
-# shadow and with every call on the device, default collect window and none).  Usage: tools/c_hosts.sh <tag>
+# shadow and with every call on the device, default collect window and none; with the shadow also through the two hand-off
+# entries — every call behind a pool of blocking threads | rio_op_try_* inline, the pool on EAGAIN).  Usage: tools/c_hosts.sh <tag>
 TAG=${1:-chost}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
