@@ -22,7 +22,10 @@ constexpr int kTile = 256;           // objects per wave-iteration: 64 lanes x d
 constexpr u32 kMaxBlocks = 256;      // = CUs; rows of the per-block histogram table
 constexpr u32 kMaxSubs = 256;
 constexpr int kMidBatch = 16384;     // lookups of up to this many entries go through mapped pinned memory and a completion word
-constexpr int kReqBatch = 65536;     // place_pending batches from host buffers of up to this many requests: mapped pinned memory, no staging copies
+constexpr int kReqBatch = 131072;    // place_pending batches from host buffers of up to this many requests: mapped pinned memory the kernels
+                                     // read and write over PCIe themselves; bigger ones: the caller's arrays registered for the call, DMA copies
+                                     // (measured per size, profiles/round6_pp_sizes.txt: 65 536 requests 125 us through the pinned rows against
+                                     //  137-182 through registered arrays; 262 143: 398 against 249-373)
 constexpr int kSmallBatch = 256;     // place_pending / lookup micro-batches served by one workgroup and one launch        // sub-chunks per block for the exact-cut refinement
 
 // Work decomposition of a table of n rows.  Index order is the only order that matters:
