@@ -323,14 +323,17 @@ bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req);
 // claim_fast: [m + 1] u64 of device memory — the load the batch's first touches put on every requester + the count of requests
 // the window kernel could not answer by itself; cleared by launch_pp_bin, filled by launch_pp_win_gather, judged by
 // launch_pp_win_verdict (*verdict: 1 every answer is final, `used` has taken the claims | 2 the batch needs the solve over the
-// records, nothing else was changed | 3 invalid entry), handed out by launch_pp_win_split (verdict 1 only)
+// records, nothing else was changed | 3 invalid entry), handed out by launch_pp_win_unsort
 void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s,
                    u32* dead_bits, u64* claim_fast);  // (clears the two)
+// ans0 / ans1: the answer records' two words, [n] each, in the SORTED order of launch_pp_bin's records (launch_pp_win_unsort
+// carries them back to batch order: the caller's columns on verdict 1, vrec on verdict 2)
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
-                          uint2* vrec, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s);
+                          u32* ans0, u32* ans1, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s);
+void launch_pp_win_unsort(const u32* scratch, const u32* ans0, const u32* ans1, u64 n, uint2* vrec, u32* out_node, u32* out_flag,
+                          const u32* verdict, hipStream_t s);
 void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* used, const u64* claim_fast, const DevStats* st,
                            u32* verdict_dev, u32* verdict_host, hipStream_t s);
-void launch_pp_win_split(const uint2* vrec, u64 n, u32* out_node, u32* out_flag, const u32* verdict, hipStream_t s);
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,
                           const DevStats* st, hipStream_t s, u32 sa, const uint2* vrec);

@@ -3653,7 +3653,7 @@ __device__ __forceinline__ void part_walk(const uint2* __restrict__ rec2, const 
 __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
                                                           u32 m, const u32* __restrict__ alive_bits,
                                                           const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
-                                                          u32 nchunks, const u32 wshift, uint2* __restrict__ vrec,
+                                                          u32 nchunks, const u32 wshift, u32* __restrict__ ans0, u32* __restrict__ ans1,
                                                           u32* __restrict__ dead_bits,
                                                           u32* __restrict__ aff_life, const DevStats* __restrict__ st,
                                                           u64* __restrict__ claim, u64* __restrict__ fast, const u32 lds_hist) {
@@ -3718,8 +3718,7 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
     // store per first touch: 130 of its 174 us at 10 M requests).  If the batch turns out to need the solve (k_pp_win_verdict)
     // that placement is the optimistic one the fix-up overwrites through the same row when the claim is rejected; and
     // clean_server (which runs behind this kernel for the dead nodes the requests ran into) cannot take it for a row of a dead
-    // node: its value is a live node now.  The first request's record goes to its batch position (the one random store of
-    // this kernel per object).
+    // node: its value is a live node now.  The row's answer stays in the LDS word; the records are written in the walk below.
     u32 slow = 0;
 #pragma unroll
     for (int q = 0; q < kPartRowVecs; ++q) {
@@ -3749,8 +3748,9 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
                 O = rq; chg = true;                                                                                \
                 if (lds_hist) atomicAdd(&hist[rq], (u64)L); else if (L) atomicAdd(&claim[rq], (u64)L);             \
             } else { nd = kNone; fl = 4u | (dead ? kFlagReplaced : 0u); ++slow; }  /* the solve's to decide */       \
-            vrec[K] = make_uint2(pp_ans(nd, fl, false), L);                                                        \
-            wfirst[r4 + E] = (EW & 0xFFFFFFFF00000000ull) | nd;  /* what later requests of the row observe */       \
+            /* what the row's requests are answered from below: {first position | flag | node} */                  \
+            wfirst[r4 + E] = (EW & 0xFFFFFFFF00000000ull) | ((u64)fl << 16) | (nd == kNone ? 0xFFFFull : (u64)nd); \
+            (void)K;                                                                                               \
         }
         RIOGP_FIRST(e0, cv.x, lv.x, ov.x, 0)
         RIOGP_FIRST(e1, cv.y, lv.y, ov.y, 1)
@@ -3760,22 +3760,39 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
         if (__ballot(chg)) *reinterpret_cast<uint4*>(assign + base + r4) = ov;  // (whole lines; unchanged rows keep their value)
     }
     __syncthreads();
-    // later requests of an object observe the first's (LOCAL / REDIRECT, or UNPLACED): their record carries the answer and
-    // the position of the first — out of the records held in registers
-    auto later = [&](const uint2 x) {
+    // Every request's answer record {node | flag | later, load or the first request's position}, written AT THE REQUEST'S OWN
+    // PLACE IN THE SORTED ORDER (two 4-byte columns): the sixteen lanes of a quarter wave store sixteen consecutive words of a
+    // piece — where this kernel used to store one 8-byte record per request at its BATCH position, 10 M random stores, 2.35x the
+    // bytes, two thirds of its time.  k_pp_win_unsort carries them back to batch order chunk by chunk, through the LDS.  The
+    // first request of a row takes the row's answer and its load (one 4-byte read out of the window's rows, just streamed);
+    // later requests observe (LOCAL / REDIRECT, or UNPLACED) and carry the position of the first.
+    auto answer = [&](const uint2 x, const u32 at) {
         const u64 e = wfirst[x.x & (W - 1)];
-        const u32 k = x.y, f = (u32)(e >> 32), nd = (u32)e, rq = x.x >> kPartShiftMax;
-        if (f != k) vrec[k] = make_uint2(pp_ans(nd, nd == kNone ? 4u : (nd == rq ? 0u : 1u), true), f);
+        const u32 k = x.y, f = (u32)(e >> 32), nd16 = (u32)e & 0xFFFFu, rq = x.x >> kPartShiftMax;
+        const u32 nd = nd16 == 0xFFFFu ? kNone : nd16;
+        if (f == k) {
+            ans0[at] = pp_ans(nd, ((u32)e >> 16) & 0xFFu, false);
+            ans1[at] = load[base + (x.x & (W - 1))];
+        } else {
+            ans0[at] = pp_ans(nd, nd == kNone ? 4u : (nd == rq ? 0u : 1u), true);
+            ans1[at] = f;
+        }
     };
 #pragma unroll
-    for (int i = 0; i < kPartIters; ++i)
-        if (xr[i].y != kNone) later(xr[i]);
+    for (int i = 0; i < kPartIters; i += kGrp) {
+        u32 pb[kGrp], pc[kGrp];
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) piece((u32)(i + q), pb[q], pc[q]);
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q)
+            if (xr[i + q].y != kNone) answer(xr[i + q], pb[q] + o16);
+    }
     if (__ballot(tail)) {  // the pieces' records past their first sixteen: descriptors again (two u16 reads a piece), then the records
 #pragma unroll 1
         for (u32 i = 0; i < (u32)kPartIters; ++i) {
             u32 pb, pc;
             piece(i, pb, pc);
-            for (u32 o = 16u + o16; o < pc; o += 16u) later(rec2[pb + o]);
+            for (u32 o = 16u + o16; o < pc; o += 16u) answer(rec2[pb + o], pb + o);
         }
     }
     if (lds_hist)
@@ -3813,23 +3830,34 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_verdict(u32 m, const u64* __r
     }
 }
 
-// The answers in batch order, densely: records -> the caller's node / flag columns (final verdict only).  (No completion word
-// here: a fence per workgroup — 2 048 of them, each behind a burst of stores — made this 30 us copy take 290: the caller
-// waits for the stream.)
-__global__ __launch_bounds__(256) void k_pp_win_split(const uint2* __restrict__ vrec, u64 n, u32* __restrict__ out_node,
-                                                      u32* __restrict__ out_flag, const u32* __restrict__ verdict) {
-    if (*verdict == 1u) {
-        const u64 nv = n >> 1, stride = (u64)gridDim.x * 256;
-        for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nv; v += stride) {  // two requests (one 16-byte read) per lane
-            const uint4 r = *reinterpret_cast<const uint4*>(vrec + 2 * v);
-            *reinterpret_cast<uint2*>(out_node + 2 * v) = make_uint2(pp_ans_node(r.x), pp_ans_node(r.z));
-            if (out_flag) *reinterpret_cast<uint2*>(out_flag + 2 * v) = make_uint2(pp_ans_flag(r.x), pp_ans_flag(r.z));
+// The answers back in BATCH order: a chunk of the batch (kPartSub consecutive positions) was sorted by row window inside the
+// chunk, so its answers sit in the chunk's own 8 192 sorted slots — one workgroup reads them densely together with the sorted
+// records' batch positions, turns them round in the LDS and writes the chunk's positions densely: the caller's node / flag
+// columns when the answers are final (verdict 1: what k_pp_win_split did from the records), the 8-byte records the solve and
+// k_pp_win_output read when the batch needs the solve (verdict 2).  An invalid entry (3): nothing.
+__global__ __launch_bounds__(kBlock) void k_pp_win_unsort(const uint2* __restrict__ rec2, const u32* __restrict__ ans0,
+                                                          const u32* __restrict__ ans1, u64 n, uint2* __restrict__ vrec,
+                                                          u32* __restrict__ out_node, u32* __restrict__ out_flag,
+                                                          const u32* __restrict__ verdict) {
+    __shared__ u32 w0[kPartSub], w1[kPartSub];
+    const u32 v = *verdict;
+    if (v != 1u && v != 2u) return;
+    const int tid = threadIdx.x;
+    const u64 lo = (u64)blockIdx.x * kPartSub;
+    const u32 cnt = (u32)(n - lo < (u64)kPartSub ? n - lo : (u64)kPartSub);
+    for (u32 j = tid; j < cnt; j += kBlock) {
+        const u32 k = rec2[lo + j].y - (u32)lo;  // the record's batch position, inside this chunk
+        w0[k] = ans0[lo + j];
+        if (v == 2u) w1[k] = ans1[lo + j];
+    }
+    __syncthreads();
+    if (v == 1u) {
+        for (u32 j = tid; j < cnt; j += kBlock) {
+            out_node[lo + j] = pp_ans_node(w0[j]);
+            if (out_flag) out_flag[lo + j] = pp_ans_flag(w0[j]);
         }
-        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-            const uint2 r = vrec[n - 1];
-            out_node[n - 1] = pp_ans_node(r.x);
-            if (out_flag) out_flag[n - 1] = pp_ans_flag(r.x);
-        }
+    } else {
+        for (u32 j = tid; j < cnt; j += kBlock) vrec[lo + j] = make_uint2(w0[j], w1[j]);
     }
 }
 
@@ -5337,7 +5365,7 @@ void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32*
 }
 // claim_fast: [m] claim loads + [1] the "could not answer by itself" counter, zeroed by launch_pp_bin
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
-                          uint2* vrec, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s) {
+                          u32* ans0, u32* ans1, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s) {
     const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
     const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
     const uint2* rec2 = reinterpret_cast<const uint2*>(scratch);
@@ -5346,7 +5374,7 @@ void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const 
     const size_t win = ((size_t)1 << wshift) * sizeof(u64);
     const u32 lds_hist = win + (size_t)m * sizeof(u64) <= (size_t)160 * 1024 ? 1u : 0u;  // else: global atomics per first touch
     hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), win + (lds_hist ? (size_t)m * sizeof(u64) : 0), s, assign, load,
-                       n_obj, m, alive_bits, rec2, start16, chunks, wshift, vrec, dead_bits, aff_life, st, claim_fast,
+                       n_obj, m, alive_bits, rec2, start16, chunks, wshift, ans0, ans1, dead_bits, aff_life, st, claim_fast,
                        claim_fast + m, lds_hist);
 }
 void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* used, const u64* claim_fast, const DevStats* st,
@@ -5354,8 +5382,11 @@ void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* us
     hipLaunchKernelGGL(k_pp_win_verdict, dim3(1), dim3(kBlock), 0, s, m, cap, alive_bits, used, claim_fast, claim_fast + m, st,
                        verdict_dev, verdict_host);
 }
-void launch_pp_win_split(const uint2* vrec, u64 n, u32* out_node, u32* out_flag, const u32* verdict, hipStream_t s) {
-    hipLaunchKernelGGL(k_pp_win_split, dim3(grid_for((n + 1) / 2, 256, 2048)), dim3(256), 0, s, vrec, n, out_node, out_flag, verdict);
+void launch_pp_win_unsort(const u32* scratch, const u32* ans0, const u32* ans1, u64 n, uint2* vrec, u32* out_node, u32* out_flag,
+                          const u32* verdict, hipStream_t s) {
+    const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
+    hipLaunchKernelGGL(k_pp_win_unsort, dim3(chunks), dim3(kBlock), 0, s, reinterpret_cast<const uint2*>(scratch), ans0, ans1, n, vrec,
+                       out_node, out_flag, verdict);
 }
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,

@@ -1466,13 +1466,14 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         // The window kernel answers every request it can by itself — sticky hits, first touches on requesters that are active
         // members, later requests of an object — and records what the first touches ask of every requester; when every total
         // fits (k_pp_win_verdict) the answers are final and k_pp_win_split hands them out: no virtual table, no solve.
-        launch_pp_win_gather(assign, h->load, h->n, h->m, h->alive_bits, n, (const u32*)h->part.p, (uint2*)h->vrec.p, h->dead_bits,
+        launch_pp_win_gather(assign, h->load, h->n, h->m, h->alive_bits, n, (const u32*)h->part.p, vaff, vnext, h->dead_bits,
                              aff_life(h), h->dstats, h->pp_claim, h->stream);
         if (!h->all_alive)  // service.rs:227-237: every object of a dead node a request ran into is un-placed
             launch_clean(assign, h->n, h->m, h->dead_bits, h->used, h->dstats, h->stream, nullptr, nullptr, nullptr, aff_life(h));
         launch_pp_win_verdict(h->m, h->cap, h->alive_bits, h->used, h->pp_claim, h->dstats, h->pp_bad + 1, h->d_small + 4 * kSmallBatch,
                               h->stream);
-        launch_pp_win_split((const uint2*)h->vrec.p, n, d_out, d_flag, h->pp_bad + 1, h->stream);
+        // (the answers' two words sit in vaff / vnext, in the sorted order, until here: the solve below writes vnext afterwards)
+        launch_pp_win_unsort((const u32*)h->part.p, vaff, vnext, n, (uint2*)h->vrec.p, d_out, d_flag, h->pp_bad + 1, h->stream);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         if (*h_bad || *h_status == 3) return fail(h, RIO_GP_EINVAL, std::string(who) + ": object index or requester out of range (nothing was changed)");
