@@ -4581,8 +4581,10 @@ __device__ __forceinline__ void p2p_wait(const u64* flags, u32 R, u64 seq, u64* 
     if (threadIdx.x < R) {
         const u64* f = flags + (size_t)threadIdx.x * 8;
         const u64 t0 = wall_clock64();
-        while (RIOGP_SYS_LOAD(f) != seq) {
-            if (wall_clock64() - t0 > kP2PTimeoutTicks) {
+        for (u32 tries = 0; RIOGP_SYS_LOAD(f) != seq; ++tries) {
+            // (a peer that is gone: the first wait of the chain runs into the time-out and raises the word; every wait behind it
+            //  — the rest of this tick's exchanges, the ticks enqueued after it — gives up as soon as it sees the word)
+            if (wall_clock64() - t0 > kP2PTimeoutTicks || ((tries & 63u) == 63u && RIOGP_SYS_LOAD(err) != 0)) {
                 RIOGP_SYS_STORE(err, 1ull);
                 break;
             }
@@ -4635,7 +4637,7 @@ __device__ __forceinline__ u64 xchg_get(const u64* row, size_t v, u32 tag, u64* 
     for (int tries = 0;; ++tries) {
         const u64 g0 = RIOGP_SYS_LOAD(row + 2 * v), g1 = RIOGP_SYS_LOAD(row + 2 * v + 1);
         if ((u32)(g0 >> 32) == tag && (u32)(g1 >> 32) == tag) return (g0 & 0xFFFFFFFFull) | (g1 << 32);
-        if (wall_clock64() - t0 > kP2PTimeoutTicks) {
+        if (wall_clock64() - t0 > kP2PTimeoutTicks || ((tries & 63) == 63 && RIOGP_SYS_LOAD(err) != 0)) {  // (p2p_wait's comment)
             RIOGP_SYS_STORE(err, 1ull);
             return 0;
         }

@@ -2333,7 +2333,13 @@ static int p2p_check(rio_gp* h) {  // after a wait on the stream: did any in-ker
     u64 err = 0;
     HIPCHK(h, hipMemcpyAsync(&err, h->p2p->d_err, sizeof err, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (err) return fail(h, RIO_GP_EUPSTREAM, "peer-to-peer exchange timed out waiting for a rank's record");
+    if (err) {
+        // a peer never delivered (it is gone, or minutes behind): whatever was enqueued behind the wait ran on records that are
+        // not there, and this rank's sequence numbers are ahead of anything the peers will see — the session is over
+        h->p2p->out_of_step = true;
+        return fail(h, RIO_GP_EUPSTREAM, "peer-to-peer exchange timed out waiting for a rank's record (the session is out of step: "
+                                         "rio_gp_shard_p2p_close, then fresh windows or another exchange path)");
+    }
     return RIO_GP_OK;
 }
 

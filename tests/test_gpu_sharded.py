@@ -2,6 +2,7 @@
 ShardedSolver the multi-GPU bench uses, against the whole-table CPU oracle — bit-exact.  One MI355X is
 enough: G shards = G handles on the device (LocalExchange), a world_size-1 RCCL group (DistExchange,
 "nccl"), and two PROCESSES sharing the GPU over gloo."""
+import json
 import os
 import socket
 import sys
@@ -294,6 +295,95 @@ def test_hip_shards_several_processes_one_gpu(gp, oracle, tmp_path, exchange, wo
             assert np.array_equal(z["used2"], used)
             assert z["st2"].astype(np.int64).tolist() == osts
         assert any(o[sorted(ost).index("slow_path")] for o in osts)
+
+
+def _proc_lost(rank, world, port, out_dir):
+    """Three ranks share the peer-to-peer windows; the last one disappears between two rio_gp_shard_tick_async calls."""
+    for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import time
+    import torch
+    import torch.distributed as dist
+    import rio_gp
+    import sharded
+    from test_sharded_protocol import random_case
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    case = random_case(33, n=120_000, m=40, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
+    cur, load, aff, cap, alive = case
+    b = sharded.shard_bounds(len(cur), world)
+    eng = make_engines(rio_gp, case, [b[rank], b[rank + 1]])[0]
+    survivors = dist.new_group(list(range(world - 1)))   # (made while everybody is still there)
+    ex = sharded.P2PExchange(eng)
+    sol = sharded.ShardedSolver([eng], ex)
+    for k in range(2):                                   # a healthy stream first
+        eng.g.set_alive_all(_async_mask(len(cap), k))
+        sol.tick_async()
+    healthy = sol.tick_wait()
+    dist.barrier()
+    if rank == world - 1:
+        os._exit(0)                                      # gone: no close, no goodbye — its windows' words never change again
+    rec = {"healthy_ticks": len(healthy)}
+    t0 = time.time()
+    eng.tick_async()                                     # two ticks enqueued against a peer that is not there
+    eng.tick_async()
+    try:
+        eng.tick_wait()
+        rec["wait_rc"] = 0
+    except rio_gp.ObjectPlacementError as e:
+        rec["wait_rc"], rec["wait_kind"], rec["wait_text"] = e.rc, e.kind, str(e)
+    rec["wait_seconds"] = time.time() - t0
+    try:                                                 # the session is marked: the next call fails at once, nothing is enqueued
+        t1 = time.time()
+        eng.tick_async()
+        rec["next_rc"] = 0
+    except rio_gp.ObjectPlacementError as e:
+        rec["next_rc"], rec["next_text"], rec["next_seconds"] = e.rc, str(e), time.time() - t1
+    ex.close()                                           # rio_gp_shard_p2p_close: unmaps the dead rank's window as well
+    rec["ready_after_close"] = int(sharded._lib().rio_gp_shard_p2p_ready(eng.g.handle))
+    # ... and the handle is as good as new: the survivors' rows as a table of their own, solved over the exchange rung that
+    # works between processes on one device (torch.distributed; with a GPU per rank that is where the RCCL rungs come in)
+    eng.g.set_alive_all(alive)
+    eng.g.set_assign(cur[b[rank]:b[rank + 1]])
+    sol2 = sharded.ShardedSolver([eng], sharded.DistExchange(group=survivors, stage_through_host=True))
+    st = sol2.tick()
+    np.savez(os.path.join(out_dir, "lost%d.npz" % rank), a=eng.g.get_assign(), used=eng.g.get_nodes()[2],
+             st=np.array([st[k] for k in sorted(st)], np.uint64), rec=np.array([json.dumps(rec)]))
+    eng.g.close()
+    os._exit(0)                                          # (no collective teardown with a rank that is gone)
+
+
+def test_peer_lost_mid_stream(gp, oracle, tmp_path):
+    """A rank that disappears MID-stream on the peer-to-peer rung (round-5 verdict: only set-up failures had been injected).
+    The survivors' kernels poll IPC-mapped windows for words that will never come: the first wait runs into the 3 s time-out
+    and raises the error word, every wait behind it gives up at once, rio_gp_shard_tick_wait returns RIO_GP_EUPSTREAM
+    (ObjectPlacementError::Upstream) and marks the session out of step, the next call fails immediately with the text that
+    names the way out, rio_gp_shard_p2p_close works — no hang, no device fault — and the same handles then solve the
+    survivors' rows over another exchange rung, equal to the oracle."""
+    import torch.multiprocessing as mp
+    from test_sharded_protocol import random_case
+    world = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_proc_lost, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    cur, load, aff, cap, alive = random_case(33, n=120_000, m=40, cap_scale=0.92, dead_frac=0.1, zero_load=0.05)
+    import sharded
+    b = sharded.shard_bounds(len(cur), world)
+    nsurv = b[world - 1]
+    want, used, ost = oracle.tick(cur[:nsurv], load[:nsurv], aff[:nsurv], cap, alive, 2)
+    parts = [np.load(os.path.join(str(tmp_path), "lost%d.npz" % r)) for r in range(world - 1)]
+    for z in parts:
+        rec = json.loads(str(z["rec"][0]))
+        assert rec["healthy_ticks"] == 2
+        assert rec["wait_rc"] == gp.EUPSTREAM and rec["wait_kind"] == "Upstream" and "timed out" in rec["wait_text"], rec
+        assert 2.5 < rec["wait_seconds"] < 12, rec          # ONE time-out for the two ticks' fourteen launches each, not one per wait
+        assert rec["next_rc"] == gp.EUPSTREAM and "lost step" in rec["next_text"] and rec["next_seconds"] < 0.5, rec
+        assert rec["ready_after_close"] == 0
+        assert np.array_equal(z["used"], used)
+        assert [int(v) for v in z["st"]] == [ost[k] for k in sorted(ost)]
+    assert np.array_equal(np.concatenate([z["a"] for z in parts]), want)
 
 
 def test_soak_three_processes_peer_to_peer(gp):
