@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--no-c2", action="store_true", help="N=1: skip the config-2 record (1 M x 256)")
     ap.add_argument("--no-binding", action="store_true",
                     help="N=1: skip the two records of the solve in which capacity binds (config3_contended, config3_skew)")
-    ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 record (10 % churn per tick, 110 ticks + oracle replay)")
+    ap.add_argument("--no-c5", action="store_true", help="N=1: skip the config-5 record (10 %% churn per tick, 110 ticks + oracle replay)")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaled config-3 second measurement")
     ap.add_argument("--no-sharded-churn", action="store_true", help="N>1: skip the committed / churn tick streams of the sharded table")
     import glob
@@ -585,7 +585,10 @@ def binding_record(a, cfg, rio_gp, local_rank, which, reps=30, warmup=4):
             "slow_path": int(last["slow_path"]), "cut_nodes": int(last["cut_nodes"]), "stats": last,
             "uncommitted_back_to_back": {"us_per_solve": unc * 1e6, "frac": fr(unc), "equal_counters": ust == last,
                                          "step": "rio_gp_solve of the same cold table, back to back, never committed (round 5's method)"},
-            "launches": "k_scan + k_resolve + k_cut_find + k_fill (round 0: re-mark, pack, water-fill) + k_fill (round 1)",
+            "launches": ("k_scan + k_resolve + k_cut_apply (exact cuts applied + the undecided rows packed, one pass) + k_cut_settle + "
+                         "k_fill x 2 over the packed rows (the route when <= 25 % of the rows are pending)" if which == "contended" else
+                         "k_scan + k_resolve + k_cut_find + k_fill (round 0: re-mark, water-fill over the table) + k_fill (round 1) "
+                         "(the route when most of the table is pending: packing would cost more than it saves)"),
             "parity": parity}
 
 
