@@ -330,7 +330,7 @@ void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32*
 // carries them back to batch order: the caller's columns on verdict 1, vrec on verdict 2)
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
                           u32* ans0, u32* ans1, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s);
-void launch_pp_win_unsort(const u32* scratch, const u32* ans0, const u32* ans1, u64 n, uint2* vrec, u32* out_node, u32* out_flag,
+void launch_pp_win_unsort(u64 n_obj, const u32* scratch, const u32* ans0, const u32* ans1, u64 n, uint2* vrec, u32* out_node, u32* out_flag,
                           const u32* verdict, hipStream_t s);
 void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* used, const u64* claim_fast, const DevStats* st,
                            u32* verdict_dev, u32* verdict_host, hipStream_t s);

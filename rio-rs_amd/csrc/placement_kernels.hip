@@ -135,7 +135,7 @@ __device__ __forceinline__ bool bit_of(const u32* bits, u32 j) { return (bits[j 
 // Phase traces (lab build only; compiled out of the product): workgroup b stores wall_clock64() (100 MHz) at phase
 // boundary `slot` of kernel table `tab` into g_kt[tab][b][slot] when the plan's trace flag is set.
 #ifdef RIO_GP_LAB
-constexpr int kKtTables = 7;
+constexpr int kKtTables = 8;
 __device__ u64 g_kt[kKtTables][kMaxBlocks * 8];
 static int g_trace_host = 0;
 #define RIOGP_KT(pl, tab, slot) do { if (threadIdx.x == 0 && (pl).trace && blockIdx.x < kMaxBlocks) g_kt[tab][(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
@@ -3354,14 +3354,19 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
 //     k_part_remove the same with a flag per row; the released load goes through an LDS histogram per node.
 //   Batches of more than 2 048 chunks are applied slice by slice, in order.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 kPartSub = 8192;        // entries per chunk = workgroup of k_part_bin (8 per lane)
-constexpr u32 kPartMaxChunks = 2048;  // chunks per slice of the batch (16.7 M entries): the apply kernels' LDS tables
+constexpr u32 kPartSub = 8192;        // entries per chunk = workgroup of k_part_bin: the small form (8 per lane) ...
+constexpr u32 kPartSubBig = 16384;    // ... and the big one (16 per lane; round 6): a window's piece of a chunk is twice as long — ~27
+                                      // records on a 10 M-row table instead of ~13, i.e. 1.6x instead of 2.2x the records' bytes in
+                                      // 128-byte lines for the apply kernels' walk — and there are half as many pieces and descriptors.
+                                      // The sorted chunk's staging buffer is then 128 KiB of LDS: tables of up to kPartBigMaxBins windows.
+constexpr u32 kPartSliceMax = 2048u * kPartSub;  // entries per slice of the batch (16.7 M): 2 048 small / 1 024 big chunks
+constexpr u32 kPartMaxChunks = 2048;  // (small) chunks per slice
 constexpr u32 kPartShiftMax = 14;     // rows per window <= 16 384: W u64 election words = 128 KiB of LDS
 constexpr u32 kPartMaxBins = 8192;    // 134 M rows at the largest window
 constexpr u32 kNodeNoneCode = 0x3FFFu;  // 14-bit code of RIO_GP_NONE (node ids are < 8 192)
 
 // records: updates {row in window | node code << 14, position in the slice} (8 bytes), removals the row in window (4 bytes)
-template <bool UPDATE>
+template <bool UPDATE, int PER>
 __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32* __restrict__ idx,
                                                      const u32* __restrict__ node, u64 n, u32 nbins, const u32 wshift,
                                                      u32* __restrict__ rec, uint2* __restrict__ rec2,
@@ -3379,9 +3384,11 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     u32* off = hist + nbins;                                  // [nbins + 1] where a window's records start in the sorted chunk
     unsigned char* stage = smem + kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16;  // [kPartSub] records
     const int tid = threadIdx.x;
+    constexpr u32 SUB = (u32)PER * kBlock;  // entries of this chunk
+    constexpr int NV = PER / 4;             // dwordx4 loads per column and lane
     const u32 wmask = (1u << wshift) - 1u, nchunks = gridDim.x, c = blockIdx.x;
-    const u64 lo = (u64)c * kPartSub;
-    const u64 hi = lo + kPartSub < n ? lo + kPartSub : n;
+    const u64 lo = (u64)c * SUB;
+    const u64 hi = lo + SUB < n ? lo + SUB : n;
     auto load4 = [&](const u32* p, u64 k) -> uint4 {  // entries k..k+3 of a column, zero past hi (k is a multiple of 4)
         if (k + 4 <= hi) return *reinterpret_cast<const uint4*>(p + k);
         uint4 r = make_uint4(0, 0, 0, 0);
@@ -3390,14 +3397,18 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
         if (k + 2 < hi) r.z = p[k + 2];
         return r;
     };
-    const u64 k0 = lo + (u64)tid * 4, k1 = k0 + (u64)kBlock * 4;
-    const uint4 ia = load4(idx, k0), ib = load4(idx, k1);
-    uint4 na = make_uint4(0, 0, 0, 0), nb = na;
-    if (UPDATE) { na = load4(node, k0); nb = load4(node, k1); }
+    const u64 k0 = lo + (u64)tid * 4;  // vector q of this lane: entries k0 + q * 4 096 .. + 3
+    uint4 iv[NV], nv[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        iv[q] = load4(idx, k0 + (u64)q * kBlock * 4);
+        nv[q] = UPDATE ? load4(node, k0 + (u64)q * kBlock * 4) : make_uint4(0, 0, 0, 0);
+    }
     for (u32 b = tid; b < nbins; b += kBlock) hist[b] = 0;
     if (zero_flags) {
         const bool al = (reinterpret_cast<uintptr_t>(zero_flags) & 15u) == 0;
-        for (u64 k = k0; k <= k1; k += k1 - k0) {
+        for (int q = 0; q < NV; ++q) {
+            const u64 k = k0 + (u64)q * kBlock * 4;
             if (al && k + 4 <= hi) *reinterpret_cast<uint4*>(zero_flags + k) = make_uint4(0, 0, 0, 0);
             else
                 for (u32 e = 0; e < 4 && k + e < hi; ++e) zero_flags[k + e] = 0;
@@ -3408,16 +3419,20 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     if (zero_u64 && c == (nchunks > 1 ? 1u : 0u))  // (place_pending: the per-requester claim loads + the window kernel's counter)
         for (u32 w = tid; w < zero_u64_words; w += kBlock) zero_u64[w] = 0;
     __syncthreads();
-    const u32 I[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-    const u32 N[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
-    u32 rk[8];
+    u32 I[PER], N[PER];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        I[4 * q] = iv[q].x; I[4 * q + 1] = iv[q].y; I[4 * q + 2] = iv[q].z; I[4 * q + 3] = iv[q].w;
+        N[4 * q] = nv[q].x; N[4 * q + 1] = nv[q].y; N[4 * q + 2] = nv[q].z; N[4 * q + 3] = nv[q].w;
+    }
+    u32 rk[PER];  // {the entry's rank in its window of this chunk (< 2^15) | its node code << 16}, all ones: not a valid entry
     u32 bad = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const u64 k = (j < 4 ? k0 : k1) + (u64)(j & 3);
-        const bool in = k < hi;
+    for (int j = 0; j < PER; ++j) {
+        const bool in = (u32)tid * 4u + (u32)(j >> 2) * (kBlock * 4u) + (u32)(j & 3) < (u32)(hi - lo);  // (32-bit: in-chunk offsets)
         const bool ok = in && I[j] < n_obj && (!UPDATE || (none_ok && N[j] == kNone) || N[j] < m);
-        rk[j] = ok ? atomicAdd(&hist[I[j] >> wshift], 1u) : 0xFFFFFFFFu;  // the returned count = the entry's rank in its window
+        const u32 code = UPDATE ? (N[j] == kNone ? kNodeNoneCode : N[j]) : 0u;
+        rk[j] = ok ? (atomicAdd(&hist[I[j] >> wshift], 1u) | (code << 16)) : 0xFFFFFFFFu;  // the returned count = the entry's rank
         bad += in && !ok;
     }
     if (bad) {
@@ -3453,11 +3468,11 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < PER; ++j)
         if (rk[j] != 0xFFFFFFFFu) {
-            const u32 pos = off[I[j] >> wshift] + rk[j];
-            const u32 r = (I[j] & wmask) | ((UPDATE ? (N[j] == kNone ? kNodeNoneCode : N[j]) : 0u) << kPartShiftMax);
-            const u32 k = (u32)((j < 4 ? k0 : k1) + (u64)(j & 3));
+            const u32 pos = off[I[j] >> wshift] + (rk[j] & 0xFFFFu);
+            const u32 r = (I[j] & wmask) | ((rk[j] >> 16) << kPartShiftMax);
+            const u32 k = (u32)lo + (u32)tid * 4u + (u32)(j >> 2) * (kBlock * 4u) + (u32)(j & 3);  // position in the slice
             if (UPDATE) reinterpret_cast<uint2*>(stage)[pos] = make_uint2(r, k);
             else reinterpret_cast<u32*>(stage)[pos] = r;
         }
@@ -3469,25 +3484,28 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     }
 }
 
-// The apply kernels walk the window's piece of every chunk (~13 records on a 10 M batch): a QUARTER wave (16 lanes) per
-// piece, so a wave instruction covers four pieces; quarter-wave g of wave w takes the chunks 64 i + 4 w + g.  Every
-// descriptor (two u16 reads) is requested before the first record, records go out four pieces per lane at a time.
-constexpr int kPartIters = kPartMaxChunks / 64;  // 32 pieces per quarter wave at most
-constexpr int kPartFlight = 4;   // pieces per lane requested before the first is used (8 was measured: no gain — the loop is bound by
+// The apply kernels walk the window's piece of every chunk (~13 records of a small chunk on a 10 M-row table, ~27 of a big
+// one): LP lanes per piece — a QUARTER wave (16) for small chunks, a HALF wave (32) for big ones — so a wave instruction covers
+// 64 / LP pieces; lane group g of wave w takes the chunks (1024 / LP) i + (64 / LP) w + g.  Every descriptor (two u16
+// reads) is requested before the first record, records go out four pieces per lane at a time.  LP * 512 = the chunk's size.
+constexpr int kPartIters = kPartMaxChunks / 64;  // 32 pieces per lane group at most (2 048 small or 1 024 big chunks a slice)
+constexpr int kPartFlight = 8;   // pieces per lane requested before the first is used (8 was measured: no gain — the loop is bound by
                                  // the partial-line reads of the ~13-record pieces, not by its round trips)
 constexpr int kPartRowVecs = (1 << kPartShiftMax) / (kBlock * 4);  // 16-byte vectors of the window's rows per thread (4)
 
 #define RIOGP_PART_DESCRIPTORS()                                                                          \
     u32 pbase[kPartIters], pcnt[kPartIters];                                                              \
     _Pragma("unroll") for (int i = 0; i < kPartIters; ++i) {                                              \
-        const u32 f = (u32)i * 64u + (u32)wave * 4u + (u32)(lane >> 4);                                   \
+        const u32 f = (u32)i * (1024u / LP) + (u32)wave * (64u / LP) + (u32)lane / LP;                    \
         const bool in = f < nchunks;                                                                      \
-        const u32 s0 = in ? start16[(size_t)b * nchunks + f] : 0u;                                        \
-        const u32 s1 = in ? start16[(size_t)(b + 1) * nchunks + f] : 0u;                                  \
-        pbase[i] = f * kPartSub + s0;                                                                     \
-        pcnt[i] = s1 - s0;                                                                                \
+        const u32 fc = in ? f : 0u;  /* clamped, not predicated: a load behind a branch makes every later */ \
+        const u32 s0 = start16[(size_t)b * nchunks + fc];           /* wait a wait for ALL loads (LESSONS 1): */ \
+        const u32 s1 = start16[(size_t)(b + 1) * nchunks + fc];     /* 32 round trips in a row, found in round 6 */ \
+        pbase[i] = f * (LP * 512u) + s0;                                                                  \
+        pcnt[i] = in ? s1 - s0 : 0u;                                                                      \
     }
 
+template <u32 LP>
 __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign, u64 n_obj, const uint2* __restrict__ rec2,
                                                         const unsigned short* __restrict__ start16, u32 nchunks,
                                                         u32* __restrict__ aff_life, const u32 wshift) {
@@ -3495,7 +3513,7 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
     const u32 W = 1u << wshift;
     u64* win = reinterpret_cast<u64*>(smem);  // [W] {position + 1 | node code} of the last writer, 0 = untouched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
+    const u32 b = blockIdx.x, o16 = (u32)lane & (LP - 1u);
     const u64 base = (u64)b << wshift;
     RIOGP_PART_DESCRIPTORS()
     for (u32 r = tid; r < W; r += kBlock) win[r] = 0;
@@ -3504,7 +3522,7 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
     for (int i = 0; i < kPartIters; i += kPartFlight) {  // kPartFlight pieces per lane in flight: the loop is a chain of round trips
         uint2 x[kPartFlight];
 #pragma unroll
-        for (int q = 0; q < kPartFlight; ++q) x[q] = o16 < pcnt[i + q] ? rec2[pbase[i + q] + o16] : make_uint2(0, 0);
+        for (int q = 0; q < kPartFlight; ++q) x[q] = rec2[o16 < pcnt[i + q] ? pbase[i + q] + o16 : 0u];  // (clamped: record 0 exists)
 #pragma unroll
         for (int q = 0; q < kPartFlight; ++q)
             if (o16 < pcnt[i + q]) atomicMax(&win[x[q].x & (W - 1)], ((u64)(x[q].y + 1u) << 16) | (u64)(x[q].x >> kPartShiftMax));
@@ -3518,8 +3536,8 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
         curv[q] = (r4 < W && base + r4 < n_obj) ? *reinterpret_cast<const uint4*>(assign + base + r4) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll 1
-    for (int i = 0; i < kPartIters; ++i)  // pieces of more than 16 records
-        for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) {
+    for (int i = 0; i < kPartIters; ++i)  // pieces of more than LP records
+        for (u32 o = LP + o16; o < pcnt[i]; o += LP) {
             const uint2 x = rec2[pbase[i] + o];
             atomicMax(&win[x.x & (W - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShiftMax));
         }
@@ -3547,6 +3565,7 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
     }
 }
 
+template <u32 LP>
 __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                         const u32* __restrict__ load, const u32* __restrict__ rec,
                                                         const unsigned short* __restrict__ start16, u32 nchunks,
@@ -3556,7 +3575,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
     u32* flag = reinterpret_cast<u32*>(smem);               // [W] row of this window is in the batch
     u64* rel = reinterpret_cast<u64*>(flag + W);            // [m] load released per node (when `used` is maintained)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
+    const u32 b = blockIdx.x, o16 = (u32)lane & (LP - 1u);
     RIOGP_PART_DESCRIPTORS()
     for (u32 r = tid; r < W; r += kBlock) flag[r] = 0;
     if (used)
@@ -3566,7 +3585,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
     for (int i = 0; i < kPartIters; i += kPartFlight) {
         u32 x[kPartFlight];
 #pragma unroll
-        for (int q = 0; q < kPartFlight; ++q) x[q] = o16 < pcnt[i + q] ? rec[pbase[i + q] + o16] : 0u;
+        for (int q = 0; q < kPartFlight; ++q) x[q] = rec[o16 < pcnt[i + q] ? pbase[i + q] + o16 : 0u];  // (clamped: record 0 exists)
 #pragma unroll
         for (int q = 0; q < kPartFlight; ++q)
             if (o16 < pcnt[i + q]) flag[x[q] & (W - 1)] = 1u;  // duplicates: the same store
@@ -3580,7 +3599,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
     }
 #pragma unroll 1
     for (int i = 0; i < kPartIters; ++i)
-        for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) flag[rec[pbase[i] + o] & (W - 1)] = 1u;
+        for (u32 o = LP + o16; o < pcnt[i]; o += LP) flag[rec[pbase[i] + o] & (W - 1)] = 1u;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kPartRowVecs; ++q) {
@@ -3629,89 +3648,118 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
 //                    reads the first's (one random read per duplicate).
 // Two random accesses per request instead of nine.
 // ------------------------------------------------------------------------------------------------
-template <typename F>
-__device__ __forceinline__ void part_walk(const uint2* __restrict__ rec2, const u32 (&pbase)[kPartIters], const u32 (&pcnt)[kPartIters],
-                                          const u32 o16, F body) {
-#pragma unroll
-    for (int i = 0; i < kPartIters; i += kPartFlight) {  // kPartFlight pieces per lane in flight
-        uint2 x[kPartFlight];
-#pragma unroll
-        for (int q = 0; q < kPartFlight; ++q) x[q] = o16 < pcnt[i + q] ? rec2[pbase[i + q] + o16] : make_uint2(0, 0);
-#pragma unroll
-        for (int q = 0; q < kPartFlight; ++q)
-            if (o16 < pcnt[i + q]) body(x[q]);
-    }
-#pragma unroll 1
-    for (int i = 0; i < kPartIters; ++i)  // pieces of more than 16 records
-        for (u32 o = 16u + o16; o < pcnt[i]; o += 16u) body(rec2[pbase[i] + o]);
-}
-
 // fast[0] = requests this kernel could not answer by itself (an object on a dead node: clean_server first; a pending object
 // whose requester is not an active member: water-fill, or the reference's unconditional self-assignment) — the call then runs
 // the solve over the records; claim[m] = load the first touches put on every requester (k_pp_win_verdict checks it against
 // the free capacity).  Both zeroed by the binning kernel.
+template <u32 LP>
 __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
                                                           u32 m, const u32* __restrict__ alive_bits,
                                                           const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
                                                           u32 nchunks, const u32 wshift, u32* __restrict__ ans0, u32* __restrict__ ans1,
                                                           u32* __restrict__ dead_bits,
                                                           u32* __restrict__ aff_life, const DevStats* __restrict__ st,
-                                                          u64* __restrict__ claim, u64* __restrict__ fast, const u32 lds_hist) {
+                                                          u64* __restrict__ claim, u64* __restrict__ fast, const u32 lds_hist,
+                                                          const u32 trace) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->err) return;  // the binning kernel found an invalid entry: the call fails, nothing is touched
+    RIOGP_KTF(trace, 7, 0);  // (lab build: phase boundaries of the first 256 windows' workgroups, trace table 7)
     const u32 W = 1u << wshift;
     u64* wfirst = reinterpret_cast<u64*>(smem);  // [W] {first batch position that asks for the row | its requester}, then {.. | the row's node}
     u64* hist = wfirst + W;                      // [m] claim load per requester (lds_hist; else straight into `claim`)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 b = blockIdx.x, o16 = (u32)lane & 15u;
+    const u32 b = blockIdx.x, o16 = (u32)lane & (LP - 1u);
     const u64 base = (u64)b << wshift;
     for (u32 r = tid; r < W; r += kBlock) wfirst[r] = ~0ull;
     if (lds_hist)
         for (u32 j = tid; j < m; j += kBlock) hist[j] = 0;
     __syncthreads();
+    RIOGP_KTF(trace, 7, 1);
     // The first request of every row decides: ds_min_u64 on {position | requester} (one walk gives both).  The records this
     // lane reads — one per piece, up to kPartIters of them — STAY IN REGISTERS for the answers of the later requests further
     // down: a second walk over the sorted records (what round 4 did) reads the 80 MB again, in ~13-record pieces, 50 of this
     // kernel's 230 us at 10 M requests.  Only the records past a piece's first sixteen (a fifth of the pieces have some) are
     // read twice.
-    uint2 xr[kPartIters];
-    bool tail = false;  // some piece of this lane holds more than 16 records
-    constexpr int kGrp = 8;  // pieces per lane whose descriptors, then records, are in flight together (the descriptors die with
+    // ... the first kKeep pieces' records, that is: all 32 are 64 registers next to everything the rows pass needs, and the
+    // kernel spilled ~100 bytes a lane into the middle of its walks (round 6: the spill reloads sat between the LDS atomics, each
+    // with a wait for every load in flight).  The pieces past kKeep (batches of more than kKeep / 32 of a slice: > 10.4 M
+    // requests) are read again by the answer walk.
+    constexpr int kKeep = 20;
+    uint2 xr[kKeep];
+    u32 tailmask = 0;  // bit i: piece i of this lane group holds more than LP records
+    // Where piece i's records start (and its answers go) is kept ACROSS THE LANES of the group: lane o holds the start of the
+    // pieces o, o + LP, ... — one or two registers instead of 32, and the answer walk needs no descriptor round trips (round 6:
+    // 4 groups x ~2 us of its 22 us per workgroup).
+    u32 pbv[kPartIters / LP];
+#pragma unroll
+    for (u32 e = 0; e < kPartIters / LP; ++e) pbv[e] = 0;
+    constexpr int kGrp = 4;  // pieces per lane whose descriptors, then records, are in flight together (the descriptors die with
                              // their group: all 32 next to the 32 records would not fit the register file)
-    auto piece = [&](u32 i, u32& pb, u32& pc) {  // piece i of this quarter wave: first record and record count
-        const u32 f = i * 64u + (u32)wave * 4u + (u32)(lane >> 4);
+    auto piece = [&](u32 i, u32& pb, u32& pc) {  // piece i of this lane group: first record and record count
+        const u32 f = i * (1024u / LP) + (u32)wave * (64u / LP) + (u32)lane / LP;
         const bool in = f < nchunks;
-        const u32 s0 = in ? start16[(size_t)b * nchunks + f] : 0u;
-        const u32 s1 = in ? start16[(size_t)(b + 1) * nchunks + f] : 0u;
-        pb = f * kPartSub + s0;
-        pc = s1 - s0;
+        const u32 fc = in ? f : 0u;  // (clamped, not predicated: see RIOGP_PART_DESCRIPTORS)
+        const u32 s0 = start16[(size_t)b * nchunks + fc];
+        const u32 s1 = start16[(size_t)(b + 1) * nchunks + fc];
+        pb = f * (LP * 512u) + s0;
+        pc = in ? s1 - s0 : 0u;
     };
 #pragma unroll
-    for (int i = 0; i < kPartIters; i += kGrp) {
+    for (int i = 0; i < kKeep; i += kGrp) {
         u32 pb[kGrp], pc[kGrp];
 #pragma unroll
         for (int q = 0; q < kGrp; ++q) piece((u32)(i + q), pb[q], pc[q]);
 #pragma unroll
         for (int q = 0; q < kGrp; ++q) {
-            xr[i + q] = o16 < pc[q] ? rec2[pb[q] + o16] : make_uint2(0u, kNone);
-            tail |= pc[q] > 16u;
+            xr[i + q] = rec2[o16 < pc[q] ? pb[q] + o16 : 0u];  // (clamped: record 0 exists)
+            if (!(o16 < pc[q])) xr[i + q] = make_uint2(0u, kNone);
+            tailmask |= (pc[q] > LP ? 1u : 0u) << (i + q);
+            if (o16 == (u32)(i + q) % LP) pbv[(u32)(i + q) / LP] = pb[q];
         }
 #pragma unroll
         for (int q = 0; q < kGrp; ++q)
             if (xr[i + q].y != kNone) atomicMin(&wfirst[xr[i + q].x & (W - 1)], ((u64)xr[i + q].y << 32) | (u64)(xr[i + q].x >> kPartShiftMax));
     }
-    if (__ballot(tail)) {  // (wave-uniform) the pieces' records past their first sixteen
 #pragma unroll 1
-        for (u32 i = 0; i < (u32)kPartIters; ++i) {
-            u32 pb, pc;
-            piece(i, pb, pc);
-            for (u32 o = 16u + o16; o < pc; o += 16u) {
-                const uint2 x = rec2[pb + o];
-                atomicMin(&wfirst[x.x & (W - 1)], ((u64)x.y << 32) | (u64)(x.x >> kPartShiftMax));
-            }
+    for (u32 i = kKeep; i < (u32)kPartIters; i += kGrp) {  // the pieces whose records are not kept
+        if (i * (1024u / LP) >= nchunks) break;  // (uniform: no chunk this far)
+        u32 pb[kGrp], pc[kGrp];
+        uint2 x[kGrp];
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) piece(i + (u32)q, pb[q], pc[q]);
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) {
+            x[q] = rec2[o16 < pc[q] ? pb[q] + o16 : 0u];
+            tailmask |= (pc[q] > LP ? 1u : 0u) << (i + (u32)q);
+        }
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q)
+            if (o16 < pc[q]) atomicMin(&wfirst[x[q].x & (W - 1)], ((u64)x[q].y << 32) | (u64)(x[q].x >> kPartShiftMax));
+    }
+    RIOGP_KTF(trace, 7, 2);
+    // the pieces' records past their first LP (an eighth of the big chunks' pieces on a 10 M-row table): only the pieces some
+    // lane group of this wave flagged are looked at again — walking all 32 descriptors of every lane for them was 9 + 12 us of
+    // a workgroup's 66
+#pragma unroll 1
+    for (u32 i = 0; i < (u32)kPartIters; ++i) {
+        if (!__ballot((tailmask >> i) & 1u)) continue;  // (wave-uniform)
+        u32 pb, pc;
+        piece(i, pb, pc);
+        for (u32 o = LP + o16; o < pc; o += LP) {
+            const uint2 x = rec2[pb + o];
+            atomicMin(&wfirst[x.x & (W - 1)], ((u64)x.y << 32) | (u64)(x.x >> kPartShiftMax));
         }
     }
+    // the window's rows: vector q of this thread is requested one step ahead of its use, the first one here, ahead of the barrier
+    // (the addresses depend on nothing the walk produced; a vector outside the window or the table reads the window's first)
+    auto rows_at = [&](int q) -> u64 {
+        const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
+        return base + ((r4 < W && base + r4 < n_obj) ? r4 : 0u);
+    };
+    uint4 cvn = *reinterpret_cast<const uint4*>(assign + rows_at(0));
+    uint4 lvn = *reinterpret_cast<const uint4*>(load + rows_at(0));
     __syncthreads();
+    RIOGP_KTF(trace, 7, 3);
     // The requested rows of the window, in row order, read ONCE and densely.  Each gets its answer: sticky (the node it is on),
     // or — pending: unplaced, or found on a dead node — its first requester when that one is an active member: written into
     // the real column right here, densely, as its placement (what the solve's scan used to do with one scattered 4-byte
@@ -3723,11 +3771,14 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
 #pragma unroll
     for (int q = 0; q < kPartRowVecs; ++q) {
         const u32 r4 = ((u32)q * kBlock + (u32)tid) * 4u;
+        const uint4 cv = cvn, lv = lvn;
+        if (q + 1 < kPartRowVecs) {
+            cvn = *reinterpret_cast<const uint4*>(assign + rows_at(q + 1));
+            lvn = *reinterpret_cast<const uint4*>(load + rows_at(q + 1));
+        }
         if (r4 >= W || base + r4 >= n_obj) continue;
         const u64 e0 = wfirst[r4], e1 = wfirst[r4 + 1], e2 = wfirst[r4 + 2], e3 = wfirst[r4 + 3];
         if (!__ballot((e0 & e1 & e2 & e3) != ~0ull)) continue;  // nobody asks for any of the wave's 256 rows
-        const uint4 cv = *reinterpret_cast<const uint4*>(assign + base + r4);
-        const uint4 lv = *reinterpret_cast<const uint4*>(load + base + r4);
         uint4 ov = cv;
         bool chg = false;
 #define RIOGP_FIRST(EW, C, L, O, E)                                                                                \
@@ -3748,9 +3799,10 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
                 O = rq; chg = true;                                                                                \
                 if (lds_hist) atomicAdd(&hist[rq], (u64)L); else if (L) atomicAdd(&claim[rq], (u64)L);             \
             } else { nd = kNone; fl = 4u | (dead ? kFlagReplaced : 0u); ++slow; }  /* the solve's to decide */       \
-            /* what the row's requests are answered from below: {first position | flag | node} */                  \
-            wfirst[r4 + E] = (EW & 0xFFFFFFFF00000000ull) | ((u64)fl << 16) | (nd == kNone ? 0xFFFFull : (u64)nd); \
-            (void)K;                                                                                               \
+            /* what the row's requests are answered from below: {first position, 24 bits | flag, 8 | load, 16 | node, 16}: */ \
+            /* a load of 65 535 or more is looked up in the column by the one request that needs it */            \
+            wfirst[r4 + E] = ((u64)K << 40) | ((u64)fl << 32) | ((u64)(L < 0xFFFFu ? L : 0xFFFFu) << 16) |         \
+                             (nd == kNone ? 0xFFFFull : (u64)nd);                                                  \
         }
         RIOGP_FIRST(e0, cv.x, lv.x, ov.x, 0)
         RIOGP_FIRST(e1, cv.y, lv.y, ov.y, 1)
@@ -3760,46 +3812,60 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
         if (__ballot(chg)) *reinterpret_cast<uint4*>(assign + base + r4) = ov;  // (whole lines; unchanged rows keep their value)
     }
     __syncthreads();
+    RIOGP_KTF(trace, 7, 4);
     // Every request's answer record {node | flag | later, load or the first request's position}, written AT THE REQUEST'S OWN
     // PLACE IN THE SORTED ORDER (two 4-byte columns): the sixteen lanes of a quarter wave store sixteen consecutive words of a
     // piece — where this kernel used to store one 8-byte record per request at its BATCH position, 10 M random stores, 2.35x the
     // bytes, two thirds of its time.  k_pp_win_unsort carries them back to batch order chunk by chunk, through the LDS.  The
-    // first request of a row takes the row's answer and its load (one 4-byte read out of the window's rows, just streamed);
-    // later requests observe (LOCAL / REDIRECT, or UNPLACED) and carry the position of the first.
+    // first request of a row takes the row's answer and its load — out of the row's LDS word (round 6; a gather from the column
+    // per first request before: a memory round trip between every two stores of this walk, 22 us per workgroup); later requests
+    // observe (LOCAL / REDIRECT, or UNPLACED) and carry the position of the first.
     auto answer = [&](const uint2 x, const u32 at) {
         const u64 e = wfirst[x.x & (W - 1)];
-        const u32 k = x.y, f = (u32)(e >> 32), nd16 = (u32)e & 0xFFFFu, rq = x.x >> kPartShiftMax;
+        const u32 elo = (u32)e, ehi = (u32)(e >> 32);
+        const u32 k = x.y, f = ehi >> 8, nd16 = elo & 0xFFFFu, l16 = elo >> 16, rq = x.x >> kPartShiftMax;
         const u32 nd = nd16 == 0xFFFFu ? kNone : nd16;
         if (f == k) {
-            ans0[at] = pp_ans(nd, ((u32)e >> 16) & 0xFFu, false);
-            ans1[at] = load[base + (x.x & (W - 1))];
+            ans0[at] = pp_ans(nd, ehi & 0xFFu, false);
+            ans1[at] = l16 != 0xFFFFu ? l16 : load[base + (x.x & (W - 1))];
         } else {
             ans0[at] = pp_ans(nd, nd == kNone ? 4u : (nd == rq ? 0u : 1u), true);
             ans1[at] = f;
         }
     };
 #pragma unroll
-    for (int i = 0; i < kPartIters; i += kGrp) {
+    for (int i = 0; i < kKeep; ++i) {
+        const u32 pbi = (u32)__shfl((int)pbv[(u32)i / LP], (int)(((u32)lane & ~(LP - 1u)) | ((u32)i % LP)), 64);  // (every lane)
+        if (xr[i].y != kNone) answer(xr[i], pbi + o16);
+    }
+#pragma unroll 1
+    for (u32 i = kKeep; i < (u32)kPartIters; i += kGrp) {  // the pieces whose records were not kept: read again
+        if (i * (1024u / LP) >= nchunks) break;
         u32 pb[kGrp], pc[kGrp];
+        uint2 x[kGrp];
 #pragma unroll
-        for (int q = 0; q < kGrp; ++q) piece((u32)(i + q), pb[q], pc[q]);
+        for (int q = 0; q < kGrp; ++q) piece(i + (u32)q, pb[q], pc[q]);
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) x[q] = rec2[o16 < pc[q] ? pb[q] + o16 : 0u];
 #pragma unroll
         for (int q = 0; q < kGrp; ++q)
-            if (xr[i + q].y != kNone) answer(xr[i + q], pb[q] + o16);
+            if (o16 < pc[q]) answer(x[q], pb[q] + o16);
     }
-    if (__ballot(tail)) {  // the pieces' records past their first sixteen: descriptors again (two u16 reads a piece), then the records
+    RIOGP_KTF(trace, 7, 5);
 #pragma unroll 1
-        for (u32 i = 0; i < (u32)kPartIters; ++i) {
-            u32 pb, pc;
-            piece(i, pb, pc);
-            for (u32 o = 16u + o16; o < pc; o += 16u) answer(rec2[pb + o], pb + o);
-        }
+    for (u32 i = 0; i < (u32)kPartIters; ++i) {  // the flagged pieces' records past their first LP: descriptors again, then the records
+        if (!__ballot((tailmask >> i) & 1u)) continue;
+        u32 pb, pc;
+        piece(i, pb, pc);
+        for (u32 o = LP + o16; o < pc; o += LP) answer(rec2[pb + o], pb + o);
     }
     if (lds_hist)
         for (u32 j = tid; j < m; j += kBlock)
             if (hist[j]) atomicAdd(&claim[j], hist[j]);
     slow = wave_sum32(slow);
     if (lane == 0 && slow) atomicAdd(fast, (u64)slow);
+    __syncthreads();
+    RIOGP_KTF(trace, 7, 7);
 }
 
 // Does the batch need the solve?  No, when every request was answered by the window kernel and every requester's first
@@ -3838,13 +3904,15 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_verdict(u32 m, const u64* __r
 __global__ __launch_bounds__(kBlock) void k_pp_win_unsort(const uint2* __restrict__ rec2, const u32* __restrict__ ans0,
                                                           const u32* __restrict__ ans1, u64 n, uint2* __restrict__ vrec,
                                                           u32* __restrict__ out_node, u32* __restrict__ out_flag,
-                                                          const u32* __restrict__ verdict) {
-    __shared__ u32 w0[kPartSub], w1[kPartSub];
+                                                          const u32* __restrict__ verdict, const u32 sub) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32* w0 = reinterpret_cast<u32*>(smem);  // [sub]
+    u32* w1 = w0 + sub;                      // [sub]
     const u32 v = *verdict;
     if (v != 1u && v != 2u) return;
     const int tid = threadIdx.x;
-    const u64 lo = (u64)blockIdx.x * kPartSub;
-    const u32 cnt = (u32)(n - lo < (u64)kPartSub ? n - lo : (u64)kPartSub);
+    const u64 lo = (u64)blockIdx.x * sub;
+    const u32 cnt = (u32)(n - lo < (u64)sub ? n - lo : (u64)sub);
     for (u32 j = tid; j < cnt; j += kBlock) {
         const u32 k = rec2[lo + j].y - (u32)lo;  // the record's batch position, inside this chunk
         w0[k] = ans0[lo + j];
@@ -5301,13 +5369,30 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
 int g_part_shift = 14;  // rows per window = 1 << shift (rio_gp_debug_set_part_shift: 12..14)
+bool g_part_big = true; // 16 384-entry chunks where part_sub() says so (bit 6 of rio_gp_debug_set_part_shift: small chunks only; A/B runs)
+bool g_part_big_all = false;  // ... (bit 7) wherever they fit: CRUD batches and small request batches too (A/B runs, parity tests)
 int g_pp_staged_from = kPpStagedFrom;  // host-buffer batches (lab builds: bits 8.. of rio_gp_debug_set_part_shift, A/B runs)
 void set_part_shift(int v) {
-    const int shift = v & 0xFF;
+    const int shift = v & 0x3F;
     g_part_shift = shift < 12 ? 12 : shift > (int)kPartShiftMax ? (int)kPartShiftMax : shift;
+    g_part_big = !(v & 0x40);
+    g_part_big_all = (v & 0x80) != 0;
     if (v >> 8) g_pp_staged_from = v >> 8;
 }
 static inline u64 part_bins(u64 n_obj) { return (n_obj + ((u64)1 << g_part_shift) - 1) >> g_part_shift; }
+static size_t part_bin_lds(u32 nbins, size_t rec_bytes, u32 sub) {
+    return kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16 + (size_t)sub * rec_bytes;
+}
+// Entries per chunk.  Measured on the 10 M x 1 024 table (round 6, profiles/round6_crud_ab.json, round6_pp_chunks.json): the big
+// form takes 24 us off k_pp_win_gather at 10 M requests and costs k_part_bin 15 (half as many workgroups, each twice as long:
+// 611 on 256 CUs are three rounds of 16 units where 1 221 were five of 8), so a request batch takes it from 4 M requests on —
+// below that the binning kernel is a single round of workgroups either way and twice as long with big chunks; the CRUD batches
+// (k_part_update - 5 us, k_part_bin + 13) keep the small form.  pp: a place_pending batch.
+static inline u32 part_sub(u64 n_obj, u64 n, bool pp) {
+    const bool fits = part_bin_lds((u32)part_bins(n_obj), sizeof(uint2), kPartSubBig) <= (size_t)150 * 1024;
+    if (g_part_big_all && fits) return kPartSubBig;
+    return (g_part_big && pp && fits && n >= ((u64)1 << 22)) ? kPartSubBig : kPartSub;
+}
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node) {
     const u64 nbins = part_bins(n_obj);
     // dense enough that rewriting whole windows pays (a sparse batch touches few rows of each), columns 16-byte aligned
@@ -5315,80 +5400,105 @@ bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node) {
            (((uintptr_t)idx | (uintptr_t)node) & 15u) == 0;
 }
 // one slice of the batch at a time: records (8 B each) + the u16 chunk table [nbins + 1][chunks]
-size_t part_scratch_words(u64 n_obj, u64 n) {
-    const u64 slice = n < (u64)kPartMaxChunks * kPartSub ? n : (u64)kPartMaxChunks * kPartSub;
-    const u64 chunks = (slice + kPartSub - 1) / kPartSub;
-    return (size_t)(2 * chunks * kPartSub + ((part_bins(n_obj) + 1) * chunks + 1) / 2 + 64);
-}
-static size_t part_bin_lds(u32 nbins, size_t rec_bytes) {
-    return kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16 + (size_t)kPartSub * rec_bytes;
+size_t part_scratch_words(u64 n_obj, u64 n) {  // (sized for either chunk form: whole big chunks of records, the small form's table)
+    const u64 slice = n < (u64)kPartSliceMax ? n : (u64)kPartSliceMax;
+    const u64 big = (slice + kPartSubBig - 1) / kPartSubBig, small = (slice + kPartSub - 1) / kPartSub;
+    return (size_t)(2 * big * kPartSubBig + ((part_bins(n_obj) + 1) * small + 1) / 2 + 64);
 }
 void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
                         hipStream_t s, u32* aff_life) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
-    const u64 slice_max = (u64)kPartMaxChunks * kPartSub;
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, false);
+    const u64 slice_max = (u64)kPartSliceMax;
     for (u64 at = 0; at < n; at += slice_max) {  // slices in batch order: a later slice overwrites an earlier one's rows
         const u64 ns = n - at < slice_max ? n - at : slice_max;
-        const u32 chunks = (u32)((ns + kPartSub - 1) / kPartSub);
+        const u32 chunks = (u32)((ns + sub - 1) / sub);
         uint2* rec2 = reinterpret_cast<uint2*>(scratch);
-        unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
-        hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx + at,
-                           node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st, true);
+        unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * sub);
+        const size_t blds = part_bin_lds(nbins, sizeof(uint2), sub);
         const size_t lds = ((size_t)1 << wshift) * sizeof(u64);
-        hipLaunchKernelGGL(k_part_update, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, wshift);
+        if (sub == kPartSubBig) {
+            hipLaunchKernelGGL((k_part_bin<true, 16>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
+                               node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st, true);
+            hipLaunchKernelGGL(k_part_update<32>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, wshift);
+        } else {
+            hipLaunchKernelGGL((k_part_bin<true, 8>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
+                               node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st, true);
+            hipLaunchKernelGGL(k_part_update<16>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, wshift);
+        }
     }
 }
 void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u32* scratch, u64* used,
                         DevStats* st, hipStream_t s, u32* aff_life) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
-    const u64 slice_max = (u64)kPartMaxChunks * kPartSub;
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, false);
+    const u64 slice_max = (u64)kPartSliceMax;
     for (u64 at = 0; at < n; at += slice_max) {
         const u64 ns = n - at < slice_max ? n - at : slice_max;
-        const u32 chunks = (u32)((ns + kPartSub - 1) / kPartSub);
+        const u32 chunks = (u32)((ns + sub - 1) / sub);
         u32* rec = scratch;
-        unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
-        hipLaunchKernelGGL(k_part_bin<false>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(u32)), s, n_obj, m, idx + at,
-                           (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st, true);
+        unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * sub);
+        const size_t blds = part_bin_lds(nbins, sizeof(u32), sub);
         const size_t lds = ((size_t)1 << wshift) * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0) + 16;
-        hipLaunchKernelGGL(k_part_remove, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, m, load, rec, start16, chunks, used, aff_life,
-                           wshift);
+        if (sub == kPartSubBig) {
+            hipLaunchKernelGGL((k_part_bin<false, 16>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
+                               (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st, true);
+            hipLaunchKernelGGL(k_part_remove<32>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, m, load, rec, start16, chunks, used,
+                               aff_life, wshift);
+        } else {
+            hipLaunchKernelGGL((k_part_bin<false, 8>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
+                               (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st, true);
+            hipLaunchKernelGGL(k_part_remove<16>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, m, load, rec, start16, chunks, used,
+                               aff_life, wshift);
+        }
     }
 }
 // place_pending over a window-sorted batch (k_pp_win_*): scratch = part_scratch_words(n_obj, n) words (records + chunk table)
 void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s,
                    u32* dead_bits, u64* claim_fast) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
-    const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, true);
+    const u32 chunks = (u32)((n + sub - 1) / sub);
     uint2* rec2 = reinterpret_cast<uint2*>(scratch);
-    unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
-    hipLaunchKernelGGL(k_part_bin<true>, dim3(chunks), dim3(kBlock), part_bin_lds(nbins, sizeof(uint2)), s, n_obj, m, idx, req, n,
-                       nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
-                       claim_fast, m + 1);
+    unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * sub);
+    const size_t blds = part_bin_lds(nbins, sizeof(uint2), sub);
+    if (sub == kPartSubBig)
+        hipLaunchKernelGGL((k_part_bin<true, 16>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx, req, n,
+                           nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
+                           claim_fast, m + 1);
+    else
+        hipLaunchKernelGGL((k_part_bin<true, 8>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx, req, n,
+                           nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
+                           claim_fast, m + 1);
 }
 // claim_fast: [m] claim loads + [1] the "could not answer by itself" counter, zeroed by launch_pp_bin
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
                           u32* ans0, u32* ans1, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj);
-    const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
+    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, true);
+    const u32 chunks = (u32)((n + sub - 1) / sub);
     const uint2* rec2 = reinterpret_cast<const uint2*>(scratch);
-    const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * kPartSub);
+    const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * sub);
     // (dead_bits and claim_fast were cleared by the binning kernel: launch_pp_bin)
     const size_t win = ((size_t)1 << wshift) * sizeof(u64);
-    const u32 lds_hist = win + (size_t)m * sizeof(u64) <= (size_t)160 * 1024 ? 1u : 0u;  // else: global atomics per first touch
-    hipLaunchKernelGGL(k_pp_win_gather, dim3(nbins), dim3(kBlock), win + (lds_hist ? (size_t)m * sizeof(u64) : 0), s, assign, load,
-                       n_obj, m, alive_bits, rec2, start16, chunks, wshift, ans0, ans1, dead_bits, aff_life, st, claim_fast,
-                       claim_fast + m, lds_hist);
+    const u32 lds_hist = win + (size_t)m * sizeof(u64) <= (size_t)150 * 1024 ? 1u : 0u;  // else: global atomics per first touch
+    const size_t lds = win + (lds_hist ? (size_t)m * sizeof(u64) : 0);
+    if (sub == kPartSubBig)
+        hipLaunchKernelGGL(k_pp_win_gather<32>, dim3(nbins), dim3(kBlock), lds, s, assign, load,
+                           n_obj, m, alive_bits, rec2, start16, chunks, wshift, ans0, ans1, dead_bits, aff_life, st, claim_fast,
+                           claim_fast + m, lds_hist, trace_flag());
+    else
+        hipLaunchKernelGGL(k_pp_win_gather<16>, dim3(nbins), dim3(kBlock), lds, s, assign, load,
+                           n_obj, m, alive_bits, rec2, start16, chunks, wshift, ans0, ans1, dead_bits, aff_life, st, claim_fast,
+                           claim_fast + m, lds_hist, trace_flag());
 }
 void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* used, const u64* claim_fast, const DevStats* st,
                            u32* verdict_dev, u32* verdict_host, hipStream_t s) {
     hipLaunchKernelGGL(k_pp_win_verdict, dim3(1), dim3(kBlock), 0, s, m, cap, alive_bits, used, claim_fast, claim_fast + m, st,
                        verdict_dev, verdict_host);
 }
-void launch_pp_win_unsort(const u32* scratch, const u32* ans0, const u32* ans1, u64 n, uint2* vrec, u32* out_node, u32* out_flag,
-                          const u32* verdict, hipStream_t s) {
-    const u32 chunks = (u32)((n + kPartSub - 1) / kPartSub);
-    hipLaunchKernelGGL(k_pp_win_unsort, dim3(chunks), dim3(kBlock), 0, s, reinterpret_cast<const uint2*>(scratch), ans0, ans1, n, vrec,
-                       out_node, out_flag, verdict);
+void launch_pp_win_unsort(u64 n_obj, const u32* scratch, const u32* ans0, const u32* ans1, u64 n, uint2* vrec, u32* out_node,
+                          u32* out_flag, const u32* verdict, hipStream_t s) {
+    const u32 sub = part_sub(n_obj, n, true);
+    const u32 chunks = (u32)((n + sub - 1) / sub);
+    hipLaunchKernelGGL(k_pp_win_unsort, dim3(chunks), dim3(kBlock), (size_t)2 * sub * sizeof(u32), s,
+                       reinterpret_cast<const uint2*>(scratch), ans0, ans1, n, vrec, out_node, out_flag, verdict, sub);
 }
 void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur, const u32* vload, const u32* vnext,
                           const u32* alive_bits, const u32* cutidx, u32 m, u32* out_node, u32* out_flag, u32* aff_life,
@@ -5399,7 +5509,7 @@ void launch_pp_win_output(const u32* idx, const u32* req, u64 n, const u32* vcur
 bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req) {
     // (the windows' rows are only READ here, once and densely: it pays for sparser batches than the CRUD forms' n_obj / 8)
     const u64 nbins = part_bins(n_obj);
-    return n >= ((u64)1 << 18) && n <= (u64)kPartMaxChunks * kPartSub && n * 32 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
+    return n >= ((u64)1 << 18) && n <= (u64)kPartSliceMax && n * 32 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
            (((uintptr_t)idx | (uintptr_t)req) & 15u) == 0;
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,

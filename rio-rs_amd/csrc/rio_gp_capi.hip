@@ -1473,7 +1473,7 @@ static int place_pending_general(rio_gp* h, uint64_t n, const u32* d_idx, const 
         launch_pp_win_verdict(h->m, h->cap, h->alive_bits, h->used, h->pp_claim, h->dstats, h->pp_bad + 1, h->d_small + 4 * kSmallBatch,
                               h->stream);
         // (the answers' two words sit in vaff / vnext, in the sorted order, until here: the solve below writes vnext afterwards)
-        launch_pp_win_unsort((const u32*)h->part.p, vaff, vnext, n, (uint2*)h->vrec.p, d_out, d_flag, h->pp_bad + 1, h->stream);
+        launch_pp_win_unsort(h->n, (const u32*)h->part.p, vaff, vnext, n, (uint2*)h->vrec.p, d_out, d_flag, h->pp_bad + 1, h->stream);
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         if (*h_bad || *h_status == 3) return fail(h, RIO_GP_EINVAL, std::string(who) + ": object index or requester out of range (nothing was changed)");
@@ -1679,21 +1679,17 @@ static int place_pending_host_locked(rio_gp* h, uint64_t n, const uint32_t* idx,
         if (out_flag) memcpy(out_flag, hq + 3 * kReqBatch, bytes);
         return RIO_GP_OK;
     }
-    // Bigger batches: the copy engine, out of and into the CALLER's arrays, registered for the duration of the call (6 us for the
-    // four of them on this driver; measured, tools/reg_probe.py: 1 MB each way 55 us registered against 106 us through the
-    // runtime's staging of pageable memory — and a kernel that reads its requests from mapped host memory itself gets ~10 GB/s
-    // out of the link: 262 143 requests 398 us through the pinned rows).  The entries are validated on the DEVICE (the first
-    // kernel raises a word every later kernel looks at: an invalid entry changes nothing) — no pass of the host over 2 MB.
-    // A registration that fails (a page that is registered already) only costs the speed.
+    // Bigger batches: the runtime's copies out of and into the caller's pageable arrays (staged through its own pinned buffers:
+    // ~106 us per MB and direction on this driver, tools/reg_probe.py).  The entries are validated on the DEVICE (the first kernel
+    // raises a word every later kernel looks at: an invalid entry changes nothing) — no pass of the host over 2 MB.
+    // Round 6 registered the caller's four arrays for the duration of the call instead (hipHostRegister / hipHostUnregister:
+    // 55 us per MB, 262 143 requests 249 us instead of ~370) — and two of eight processes of the parity test aborted inside a LATER,
+    // unrelated hipMemcpy into a fresh numpy array (none of eight without the registration): the runtime does not survive user pages
+    // that are registered, unregistered, freed and mapped again at the same address.  Removed (docs/LESSONS.md 39); a caller that
+    // wants the copy engine's rate hands over device arrays (rio_gp_place_pending_dev) or its own pinned ones.
     for (int q = 0; q < 2; ++q)
         if ((rc = ensure(h, h->rq[q], bytes)) || (rc = ensure(h, h->rq[2 + q], bytes))) return rc;
     u32 *d_idx = (u32*)h->rq[0].p, *d_req = (u32*)h->rq[1].p, *d_out = (u32*)h->rq[2].p, *d_flag = (u32*)h->rq[3].p;
-    struct Registered {  // (unregistered on every way out)
-        void* p[4] = {nullptr, nullptr, nullptr, nullptr};
-        void add(int k, const void* q, size_t b) { if (q && hipHostRegister(const_cast<void*>(q), b, hipHostRegisterDefault) == hipSuccess) p[k] = const_cast<void*>(q); else (void)hipGetLastError(); }
-        ~Registered() { for (void* q : p) if (q) (void)hipHostUnregister(q); }
-    } reg;
-    reg.add(0, idx, bytes); reg.add(1, requester, bytes); reg.add(2, out_node, bytes); reg.add(3, out_flag, bytes);
     HIPCHK(h, hipMemcpyAsync(d_idx, idx, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d_req, requester, bytes, hipMemcpyHostToDevice, h->stream));
     if ((rc = place_pending_general(h, n, d_idx, d_req, d_out, d_flag, false, false))) return rc;

@@ -311,6 +311,12 @@ def test_crud_big_batches_partitioned_by_row_window(gp, oracle, seed, n, m, k):
     plain.set_compact("auto", partitioned_crud=False)
     plain.set_nodes(m=m, alive=np.ones(m, np.uint8))
     plain.set_objects(n, load, None)
+    # the product sorts these batches in chunks of 8 192 entries; `small` (the name is history): the 16 384-entry form that
+    # request batches of 4 M and more take, forced through the lab build's knob (process-wide in that library: reset below)
+    small = gp.LabPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
+    small.set_nodes(m=m, alive=np.ones(m, np.uint8))
+    small.set_objects(n, load, None)
+    gp.lab_lib().rio_gp_debug_set_part_shift(14 | 0x80)
     ref = np.full(n, NONE, np.uint32)
     life = np.zeros(n, bool)
     for step in range(2):
@@ -318,25 +324,30 @@ def test_crud_big_batches_partitioned_by_row_window(gp, oracle, seed, n, m, k):
         idx[: k // 4] = rng.integers(0, 5000, k // 4).astype(np.uint32)       # a quarter of the batch fights over 5 000 rows
         node = rng.integers(0, m, k).astype(np.uint32)
         node[rng.random(k) < 0.1] = NONE
-        for h in (g, plain):
+        for h in (g, plain, small):
             h.update_batch(idx, node)
         assert oracle.update_batch(ref, m, idx, node) == 0
         got = g.get_assign()
         assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:10]
-        assert np.array_equal(plain.get_assign(), ref)
+        assert np.array_equal(plain.get_assign(), ref) and np.array_equal(small.get_assign(), ref)
         life[idx] = ref[idx] != NONE
         assert np.array_equal(g.get_objects()[1] != gp.AFF_INACTIVE, life)
         assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))   # rebuilt from scratch after raw updates
         rm = rng.integers(0, n, max(k // 2, 262_144)).astype(np.uint32)        # duplicates and absent rows included
-        for h in (g, plain):
+        for h in (g, plain, small):
             h.remove_batch(rm)
         oracle.remove_batch(ref, rm)
         life[rm] = False
         assert np.array_equal(g.get_assign(), ref) and np.array_equal(plain.get_assign(), ref)
+        assert np.array_equal(small.get_assign(), ref)
         assert np.array_equal(g.get_nodes()[2], oracle.recompute_used(ref, load, m))   # incremental == scratch
+        assert np.array_equal(small.get_nodes()[2], g.get_nodes()[2])
         assert np.array_equal(g.get_objects()[1] != gp.AFF_INACTIVE, life)
+        assert np.array_equal(small.get_objects()[1], g.get_objects()[1])
+    gp.lab_lib().rio_gp_debug_set_part_shift(14)
     g.close()
     plain.close()
+    small.close()
 
 
 def test_crud_big_batch_dev_skips_invalid_entries(gp, oracle):
@@ -1032,7 +1043,9 @@ def test_place_pending_big_batches_partitioned_by_row_window(gp, oracle, seed, c
     g = gp.GpuPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)
     plain = gp.LabPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)          # the same calls through the plain per-request kernels
     plain.set_compact("auto", partitioned_crud=False)
-    for h in (g, plain):
+    small = gp.LabPlacement(n, m, flags=gp.CFG_ROW_LIFECYCLE)          # ... and through 16 384-entry chunks (the form of >= 4 M requests)
+    gp.lab_lib().rio_gp_debug_set_part_shift(14 | 0x80)
+    for h in (g, plain, small):
         h.set_nodes(cap, alive)
         h.set_objects(n, load, None)
     ref = np.full(n, NONE, np.uint32)
@@ -1041,8 +1054,8 @@ def test_place_pending_big_batches_partitioned_by_row_window(gp, oracle, seed, c
         if step >= 1:
             for j in rng.integers(0, m, 12):
                 alive[j] ^= 1
-            g.set_alive_all(alive)
-            plain.set_alive_all(alive)
+            for h in (g, plain, small):
+                h.set_alive_all(alive)
         idx = rng.integers(0, n if step % 2 else n // 3, k).astype(np.uint32)   # (a third of the table: heavy duplication)
         req = rng.integers(0, m, k).astype(np.uint32)
         if step % 2 == 0:
@@ -1054,14 +1067,19 @@ def test_place_pending_big_batches_partitioned_by_row_window(gp, oracle, seed, c
             for x in (d_idx, d_req, d_node, d_flag):
                 x.free()
         pnode, pflag = plain.place_pending(idx, req)
+        snode, sflag = small.place_pending(idx, req)
         wnode, wflag = oracle.place_pending(ref, load, cap, alive, used, idx, req)
         assert np.array_equal(node, wnode), (step, np.flatnonzero(node != wnode)[:5])
         assert np.array_equal(flag, wflag), (step, np.flatnonzero(flag != wflag)[:5])
         assert np.array_equal(pnode, wnode) and np.array_equal(pflag, wflag), step
-        assert np.array_equal(g.get_assign(), ref), step
-        assert np.array_equal(g.get_nodes()[2], used), step
+        assert np.array_equal(snode, wnode) and np.array_equal(sflag, wflag), step
+        assert np.array_equal(g.get_assign(), ref) and np.array_equal(small.get_assign(), ref), step
+        assert np.array_equal(g.get_nodes()[2], used) and np.array_equal(small.get_nodes()[2], used), step
         assert np.array_equal(g.get_objects()[1], plain.get_objects()[1]), step   # row lifecycle column: same as the plain kernels
+        assert np.array_equal(small.get_objects()[1], plain.get_objects()[1]), step
+    gp.lab_lib().rio_gp_debug_set_part_shift(14)
     plain.close()
+    small.close()
     # one index out of range: the call fails and NOTHING has changed (the kernels enqueued behind the validating one see its
     # counter and do nothing) — then the same handle goes on working
     life = g.get_objects()[1].copy()

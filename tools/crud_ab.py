@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the big random CRUD batches on config 3's table (10 M rows x 1 024 nodes): window-partitioned kernels at
-windows of 4 096 / 8 192 / 16 384 rows against the plain per-entry kernels; 10 M random entries with duplicates.
+windows of 4 096 / 8 192 / 16 384 rows (chunks of 8 192 entries, round 5's form, and of 16 384, round 6's) against the plain
+per-entry kernels; 10 M random entries with duplicates.
 HIP events on the library stream around the whole call (kernels + the stats read-back).  Usage: crud_ab.py [reps]"""
 import ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,10 @@ idx = DevBuf((synth.r(np.arange(n, dtype=np.uint64), 7) % np.uint64(n)).astype(n
 node = DevBuf(synth.warm_assign(n, m, stream=8))
 warm = synth.warm_assign(n, m)
 out = {}
-for name, shift, part in (("plain", 14, False), ("part_w4096", 12, True), ("part_w8192", 13, True), ("part_w16384", 14, True)):
+# (bit 7 of the shift word: 16 384-entry chunks wherever they fit; else the product's rule — 8 192-entry chunks for CRUD batches)
+for name, shift, part in (("plain", 14, False), ("part_w4096", 12, True), ("part_w8192", 13, True),
+                          ("part_w16384", 14, True), ("part_w8192_bigchunks", 13 | 0x80, True), ("part_w16384_bigchunks", 14 | 0x80, True),
+                          ("part_w16384#2", 14, True), ("part_w16384_bigchunks#2", 14 | 0x80, True)):
     L.rio_gp_debug_set_part_shift(shift)
     g = rio_gp.LabPlacement(n, m)
     g.set_compact("auto", partitioned_crud=part)

@@ -10,7 +10,11 @@ import rio_gp, synth
 from hipbuf import DevBuf
 cfg = synth.config("c3")
 n, m = cfg["n"], cfg["m"]
-g = rio_gp.GpuPlacement(n, m)
+if os.environ.get("RIO_PART_SHIFT"):   # lab build: rio_gp_debug_set_part_shift word (78 = 14 | 0x40: 8 192-entry chunks only; 142 = 14 | 0x80: 16 384-entry chunks at every size)
+    rio_gp.lab_lib().rio_gp_debug_set_part_shift(int(os.environ["RIO_PART_SHIFT"]))
+    g = rio_gp.LabPlacement(n, m)
+else:
+    g = rio_gp.GpuPlacement(n, m)
 g.set_nodes(cfg["cap"], cfg["alive"])
 g.set_objects(n, cfg["load"], cfg["aff"])
 perm = (synth.r(np.arange(n, dtype=np.uint64), 9) % np.uint64(n)).astype(np.uint32)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# per-kernel durations of the window-partitioned batches (random CRUD of 10 M entries, place_pending of 1 M / 10 M requests) in
+# both chunk forms (8 192 / 16 384 entries): rocprofv3 --kernel-trace --stats over tools/crud_ab.py and tools/pp_probe.py.
+# Usage: tools/prof_crud.sh <tag>
+TAG=${1:-round6}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+show() {
+  python - "$1" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    if "k_part" in r["Name"] or "k_pp_win" in r["Name"] or "k_clean" in r["Name"]:
+        print("%-70s calls %5s avg %9.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+}
+rm -rf /tmp/pc_crud /tmp/pc_pp /tmp/pc_pps
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_crud -o pc -- python $ROOT/tools/crud_ab.py 4 > $OUT/${TAG}_prof_crud.log 2>&1
+f=$(find /tmp/pc_crud -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_crud_kernel_stats.csv; echo "---- crud (both forms)"; show $f
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_pp -o pc -- python $ROOT/tools/pp_probe.py > $OUT/${TAG}_prof_pp.log 2>&1
+f=$(find /tmp/pc_pp -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_pp_kernel_stats.csv; echo "---- place_pending, 16 384-entry chunks"; show $f
+RIO_PART_SHIFT=78 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_pps -o pc -- python $ROOT/tools/pp_probe.py > $OUT/${TAG}_prof_pp_small.log 2>&1
+f=$(find /tmp/pc_pps -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_pp_small_kernel_stats.csv; echo "---- place_pending, 8 192-entry chunks"; show $f
