@@ -3362,13 +3362,26 @@ constexpr u32 kPartSubBig = 16384;    // ... and the big one (16 per lane; round
 constexpr u32 kPartSliceMax = 2048u * kPartSub;  // entries per slice of the batch (16.7 M): 2 048 small / 1 024 big chunks
 constexpr u32 kPartMaxChunks = 2048;  // (small) chunks per slice
 constexpr u32 kPartShiftMax = 14;     // rows per window <= 16 384: W u64 election words = 128 KiB of LDS
+constexpr u32 kPartRowMask = (1u << kPartShiftMax) - 1u;  // a record's row inside its window
+constexpr u32 kPartCUs = 256;         // workgroups of one round: the apply kernels (one window each) and k_part_bin (one chunk each) run
+                                      // one workgroup per CU
+// Geometry of one partitioned batch (round 6: neither size has to be a power of two).  611 windows of 16 384 rows on 256 CUs are
+// three rounds of workgroups, the last one 39 % full; 766 windows of 13 056 rows are three FULL rounds of workgroups that are each
+// a fifth shorter.  The same for the chunks of the batch (768 chunks of 13 024 entries instead of 611 of 16 384).  The window of a
+// row is one multiply-shift: row * ceil(2^44 / W) >> 44, exact for rows < 2^27 and 256 <= W <= 2^14 (error term row / 2^44 < 1 / W).
+struct PartGeo {
+    u32 W;       // rows per window (a multiple of 256, <= 1 << kPartShiftMax)
+    u32 sub;     // entries per chunk (a multiple of 4, <= 8 192 or 16 384: the PER of k_part_bin / the LP of the apply kernels)
+    u64 wmagic;  // ceil(2^44 / W)
+};
+__host__ __device__ __forceinline__ u32 part_win_of(const PartGeo& pg, u32 row) { return (u32)(((u64)row * pg.wmagic) >> 44); }
 constexpr u32 kPartMaxBins = 8192;    // 134 M rows at the largest window
 constexpr u32 kNodeNoneCode = 0x3FFFu;  // 14-bit code of RIO_GP_NONE (node ids are < 8 192)
 
 // records: updates {row in window | node code << 14, position in the slice} (8 bytes), removals the row in window (4 bytes)
 template <bool UPDATE, int PER>
 __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32* __restrict__ idx,
-                                                     const u32* __restrict__ node, u64 n, u32 nbins, const u32 wshift,
+                                                     const u32* __restrict__ node, u64 n, u32 nbins, const PartGeo pg,
                                                      u32* __restrict__ rec, uint2* __restrict__ rec2,
                                                      unsigned short* __restrict__ start16, DevStats* st, const bool none_ok,
                                                      u32* __restrict__ host_err = nullptr, u32* __restrict__ zero_flags = nullptr,
@@ -3382,13 +3395,12 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     u64* part = reinterpret_cast<u64*>(smem);                 // [16] block-scan partials
     u32* hist = reinterpret_cast<u32*>(smem + kSmall);        // [nbins] entries of this chunk per window
     u32* off = hist + nbins;                                  // [nbins + 1] where a window's records start in the sorted chunk
-    unsigned char* stage = smem + kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16;  // [kPartSub] records
+    unsigned char* stage = smem + kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16;  // [pg.sub] records
     const int tid = threadIdx.x;
-    constexpr u32 SUB = (u32)PER * kBlock;  // entries of this chunk
-    constexpr int NV = PER / 4;             // dwordx4 loads per column and lane
-    const u32 wmask = (1u << wshift) - 1u, nchunks = gridDim.x, c = blockIdx.x;
-    const u64 lo = (u64)c * SUB;
-    const u64 hi = lo + SUB < n ? lo + SUB : n;
+    constexpr int NV = PER / 4;             // dwordx4 loads per column and lane (pg.sub <= PER * 1 024 entries in this chunk)
+    const u32 nchunks = gridDim.x, c = blockIdx.x;
+    const u64 lo = (u64)c * pg.sub;
+    const u64 hi = lo + pg.sub < n ? lo + pg.sub : n;
     auto load4 = [&](const u32* p, u64 k) -> uint4 {  // entries k..k+3 of a column, zero past hi (k is a multiple of 4)
         if (k + 4 <= hi) return *reinterpret_cast<const uint4*>(p + k);
         uint4 r = make_uint4(0, 0, 0, 0);
@@ -3432,7 +3444,7 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
         const bool in = (u32)tid * 4u + (u32)(j >> 2) * (kBlock * 4u) + (u32)(j & 3) < (u32)(hi - lo);  // (32-bit: in-chunk offsets)
         const bool ok = in && I[j] < n_obj && (!UPDATE || (none_ok && N[j] == kNone) || N[j] < m);
         const u32 code = UPDATE ? (N[j] == kNone ? kNodeNoneCode : N[j]) : 0u;
-        rk[j] = ok ? (atomicAdd(&hist[I[j] >> wshift], 1u) | (code << 16)) : 0xFFFFFFFFu;  // the returned count = the entry's rank
+        rk[j] = ok ? (atomicAdd(&hist[part_win_of(pg, I[j])], 1u) | (code << 16)) : 0xFFFFFFFFu;  // the returned count = the entry's rank
         bad += in && !ok;
     }
     if (bad) {
@@ -3470,8 +3482,9 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
 #pragma unroll
     for (int j = 0; j < PER; ++j)
         if (rk[j] != 0xFFFFFFFFu) {
-            const u32 pos = off[I[j] >> wshift] + (rk[j] & 0xFFFFu);
-            const u32 r = (I[j] & wmask) | ((rk[j] >> 16) << kPartShiftMax);
+            const u32 wn = part_win_of(pg, I[j]);
+            const u32 pos = off[wn] + (rk[j] & 0xFFFFu);
+            const u32 r = (I[j] - wn * pg.W) | ((rk[j] >> 16) << kPartShiftMax);
             const u32 k = (u32)lo + (u32)tid * 4u + (u32)(j >> 2) * (kBlock * 4u) + (u32)(j & 3);  // position in the slice
             if (UPDATE) reinterpret_cast<uint2*>(stage)[pos] = make_uint2(r, k);
             else reinterpret_cast<u32*>(stage)[pos] = r;
@@ -3501,20 +3514,20 @@ constexpr int kPartRowVecs = (1 << kPartShiftMax) / (kBlock * 4);  // 16-byte ve
         const u32 fc = in ? f : 0u;  /* clamped, not predicated: a load behind a branch makes every later */ \
         const u32 s0 = start16[(size_t)b * nchunks + fc];           /* wait a wait for ALL loads (LESSONS 1): */ \
         const u32 s1 = start16[(size_t)(b + 1) * nchunks + fc];     /* 32 round trips in a row, found in round 6 */ \
-        pbase[i] = f * (LP * 512u) + s0;                                                                  \
+        pbase[i] = f * pg.sub + s0;                                                                       \
         pcnt[i] = in ? s1 - s0 : 0u;                                                                      \
     }
 
 template <u32 LP>
 __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign, u64 n_obj, const uint2* __restrict__ rec2,
                                                         const unsigned short* __restrict__ start16, u32 nchunks,
-                                                        u32* __restrict__ aff_life, const u32 wshift) {
+                                                        u32* __restrict__ aff_life, const PartGeo pg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 W = 1u << wshift;
+    const u32 W = pg.W;
     u64* win = reinterpret_cast<u64*>(smem);  // [W] {position + 1 | node code} of the last writer, 0 = untouched
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x, o16 = (u32)lane & (LP - 1u);
-    const u64 base = (u64)b << wshift;
+    const u64 base = (u64)b * W;
     RIOGP_PART_DESCRIPTORS()
     for (u32 r = tid; r < W; r += kBlock) win[r] = 0;
     __syncthreads();
@@ -3525,7 +3538,7 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
         for (int q = 0; q < kPartFlight; ++q) x[q] = rec2[o16 < pcnt[i + q] ? pbase[i + q] + o16 : 0u];  // (clamped: record 0 exists)
 #pragma unroll
         for (int q = 0; q < kPartFlight; ++q)
-            if (o16 < pcnt[i + q]) atomicMax(&win[x[q].x & (W - 1)], ((u64)(x[q].y + 1u) << 16) | (u64)(x[q].x >> kPartShiftMax));
+            if (o16 < pcnt[i + q]) atomicMax(&win[x[q].x & kPartRowMask], ((u64)(x[q].y + 1u) << 16) | (u64)(x[q].x >> kPartShiftMax));
     }
     // this thread's rows of the window as they are now (the columns are padded to whole tiles): requested here, behind the
     // main loop (its registers are free again) and ahead of the tail loop and the barrier
@@ -3539,7 +3552,7 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
     for (int i = 0; i < kPartIters; ++i)  // pieces of more than LP records
         for (u32 o = LP + o16; o < pcnt[i]; o += LP) {
             const uint2 x = rec2[pbase[i] + o];
-            atomicMax(&win[x.x & (W - 1)], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShiftMax));
+            atomicMax(&win[x.x & kPartRowMask], ((u64)(x.y + 1u) << 16) | (u64)(x.x >> kPartShiftMax));
         }
     __syncthreads();
     // The window's rows leave as whole 16-byte vectors merged with their current values (requested at the top of the kernel),
@@ -3569,9 +3582,9 @@ template <u32 LP>
 __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign, u64 n_obj, u32 m,
                                                         const u32* __restrict__ load, const u32* __restrict__ rec,
                                                         const unsigned short* __restrict__ start16, u32 nchunks,
-                                                        u64* __restrict__ used, u32* __restrict__ aff_life, const u32 wshift) {
+                                                        u64* __restrict__ used, u32* __restrict__ aff_life, const PartGeo pg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 W = 1u << wshift;
+    const u32 W = pg.W;
     u32* flag = reinterpret_cast<u32*>(smem);               // [W] row of this window is in the batch
     u64* rel = reinterpret_cast<u64*>(flag + W);            // [m] load released per node (when `used` is maintained)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3588,9 +3601,9 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
         for (int q = 0; q < kPartFlight; ++q) x[q] = rec[o16 < pcnt[i + q] ? pbase[i + q] + o16 : 0u];  // (clamped: record 0 exists)
 #pragma unroll
         for (int q = 0; q < kPartFlight; ++q)
-            if (o16 < pcnt[i + q]) flag[x[q] & (W - 1)] = 1u;  // duplicates: the same store
+            if (o16 < pcnt[i + q]) flag[x[q] & kPartRowMask] = 1u;  // duplicates: the same store
     }
-    const u64 base = (u64)b << wshift;
+    const u64 base = (u64)b * W;
     uint4 curv[kPartRowVecs];  // the window's rows as they are now (as in k_part_update: whole vectors go back)
 #pragma unroll
     for (int q = 0; q < kPartRowVecs; ++q) {
@@ -3599,7 +3612,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
     }
 #pragma unroll 1
     for (int i = 0; i < kPartIters; ++i)
-        for (u32 o = LP + o16; o < pcnt[i]; o += LP) flag[rec[pbase[i] + o] & (W - 1)] = 1u;
+        for (u32 o = LP + o16; o < pcnt[i]; o += LP) flag[rec[pbase[i] + o] & kPartRowMask] = 1u;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kPartRowVecs; ++q) {
@@ -3656,7 +3669,7 @@ template <u32 LP>
 __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
                                                           u32 m, const u32* __restrict__ alive_bits,
                                                           const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
-                                                          u32 nchunks, const u32 wshift, u32* __restrict__ ans0, u32* __restrict__ ans1,
+                                                          u32 nchunks, const PartGeo pg, u32* __restrict__ ans0, u32* __restrict__ ans1,
                                                           u32* __restrict__ dead_bits,
                                                           u32* __restrict__ aff_life, const DevStats* __restrict__ st,
                                                           u64* __restrict__ claim, u64* __restrict__ fast, const u32 lds_hist,
@@ -3664,12 +3677,12 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->err) return;  // the binning kernel found an invalid entry: the call fails, nothing is touched
     RIOGP_KTF(trace, 7, 0);  // (lab build: phase boundaries of the first 256 windows' workgroups, trace table 7)
-    const u32 W = 1u << wshift;
+    const u32 W = pg.W;
     u64* wfirst = reinterpret_cast<u64*>(smem);  // [W] {first batch position that asks for the row | its requester}, then {.. | the row's node}
     u64* hist = wfirst + W;                      // [m] claim load per requester (lds_hist; else straight into `claim`)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 b = blockIdx.x, o16 = (u32)lane & (LP - 1u);
-    const u64 base = (u64)b << wshift;
+    const u64 base = (u64)b * W;
     for (u32 r = tid; r < W; r += kBlock) wfirst[r] = ~0ull;
     if (lds_hist)
         for (u32 j = tid; j < m; j += kBlock) hist[j] = 0;
@@ -3683,8 +3696,8 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
     // ... the first kKeep pieces' records, that is: all 32 are 64 registers next to everything the rows pass needs, and the
     // kernel spilled ~100 bytes a lane into the middle of its walks (round 6: the spill reloads sat between the LDS atomics, each
     // with a wait for every load in flight).  The pieces past kKeep (batches of more than kKeep / 32 of a slice: > 10.4 M
-    // requests) are read again by the answer walk.
-    constexpr int kKeep = 20;
+    // requests at 768 chunks of a slice) are read again by the answer walk.
+    constexpr int kKeep = 24;
     uint2 xr[kKeep];
     u32 tailmask = 0;  // bit i: piece i of this lane group holds more than LP records
     // Where piece i's records start (and its answers go) is kept ACROSS THE LANES of the group: lane o holds the start of the
@@ -3701,7 +3714,7 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
         const u32 fc = in ? f : 0u;  // (clamped, not predicated: see RIOGP_PART_DESCRIPTORS)
         const u32 s0 = start16[(size_t)b * nchunks + fc];
         const u32 s1 = start16[(size_t)(b + 1) * nchunks + fc];
-        pb = f * (LP * 512u) + s0;
+        pb = f * pg.sub + s0;
         pc = in ? s1 - s0 : 0u;
     };
 #pragma unroll
@@ -3718,7 +3731,7 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
         }
 #pragma unroll
         for (int q = 0; q < kGrp; ++q)
-            if (xr[i + q].y != kNone) atomicMin(&wfirst[xr[i + q].x & (W - 1)], ((u64)xr[i + q].y << 32) | (u64)(xr[i + q].x >> kPartShiftMax));
+            if (xr[i + q].y != kNone) atomicMin(&wfirst[xr[i + q].x & kPartRowMask], ((u64)xr[i + q].y << 32) | (u64)(xr[i + q].x >> kPartShiftMax));
     }
 #pragma unroll 1
     for (u32 i = kKeep; i < (u32)kPartIters; i += kGrp) {  // the pieces whose records are not kept
@@ -3734,7 +3747,7 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
         }
 #pragma unroll
         for (int q = 0; q < kGrp; ++q)
-            if (o16 < pc[q]) atomicMin(&wfirst[x[q].x & (W - 1)], ((u64)x[q].y << 32) | (u64)(x[q].x >> kPartShiftMax));
+            if (o16 < pc[q]) atomicMin(&wfirst[x[q].x & kPartRowMask], ((u64)x[q].y << 32) | (u64)(x[q].x >> kPartShiftMax));
     }
     RIOGP_KTF(trace, 7, 2);
     // the pieces' records past their first LP (an eighth of the big chunks' pieces on a 10 M-row table): only the pieces some
@@ -3747,7 +3760,7 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
         piece(i, pb, pc);
         for (u32 o = LP + o16; o < pc; o += LP) {
             const uint2 x = rec2[pb + o];
-            atomicMin(&wfirst[x.x & (W - 1)], ((u64)x.y << 32) | (u64)(x.x >> kPartShiftMax));
+            atomicMin(&wfirst[x.x & kPartRowMask], ((u64)x.y << 32) | (u64)(x.x >> kPartShiftMax));
         }
     }
     // the window's rows: vector q of this thread is requested one step ahead of its use, the first one here, ahead of the barrier
@@ -3821,13 +3834,13 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
     // per first request before: a memory round trip between every two stores of this walk, 22 us per workgroup); later requests
     // observe (LOCAL / REDIRECT, or UNPLACED) and carry the position of the first.
     auto answer = [&](const uint2 x, const u32 at) {
-        const u64 e = wfirst[x.x & (W - 1)];
+        const u64 e = wfirst[x.x & kPartRowMask];
         const u32 elo = (u32)e, ehi = (u32)(e >> 32);
         const u32 k = x.y, f = ehi >> 8, nd16 = elo & 0xFFFFu, l16 = elo >> 16, rq = x.x >> kPartShiftMax;
         const u32 nd = nd16 == 0xFFFFu ? kNone : nd16;
         if (f == k) {
             ans0[at] = pp_ans(nd, ehi & 0xFFu, false);
-            ans1[at] = l16 != 0xFFFFu ? l16 : load[base + (x.x & (W - 1))];
+            ans1[at] = l16 != 0xFFFFu ? l16 : load[base + (x.x & kPartRowMask)];
         } else {
             ans0[at] = pp_ans(nd, nd == kNone ? 4u : (nd == rq ? 0u : 1u), true);
             ans1[at] = f;
@@ -5368,124 +5381,168 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
 }
 // The partitioned forms (see k_part_bin).  scratch: rec[n] | kk[n] (updates) | frag_off[nbins * 256] | frag_cnt[nbins * 256] u32 words,
 // provided by the caller (part_scratch_words).  false: this batch / table does not qualify — use the plain kernels.
-int g_part_shift = 14;  // rows per window = 1 << shift (rio_gp_debug_set_part_shift: 12..14)
-bool g_part_big = true; // 16 384-entry chunks where part_sub() says so (bit 6 of rio_gp_debug_set_part_shift: small chunks only; A/B runs)
+int g_part_shift = 14;  // rows per window <= 1 << shift (rio_gp_debug_set_part_shift: 12..14)
+bool g_part_balance = true;   // window and chunk sizes that fill whole rounds of workgroups (bit 5 of the knob: powers of two, round 5's)
+bool g_part_big = true; // 16 384-entry chunks where part_form() says so (bit 6 of rio_gp_debug_set_part_shift: small chunks only; A/B runs)
 bool g_part_big_all = false;  // ... (bit 7) wherever they fit: CRUD batches and small request batches too (A/B runs, parity tests)
 int g_pp_staged_from = kPpStagedFrom;  // host-buffer batches (lab builds: bits 8.. of rio_gp_debug_set_part_shift, A/B runs)
 void set_part_shift(int v) {
-    const int shift = v & 0x3F;
+    const int shift = v & 0x1F;
     g_part_shift = shift < 12 ? 12 : shift > (int)kPartShiftMax ? (int)kPartShiftMax : shift;
+    g_part_balance = !(v & 0x20);
     g_part_big = !(v & 0x40);
     g_part_big_all = (v & 0x80) != 0;
     if (v >> 8) g_pp_staged_from = v >> 8;
 }
-static inline u64 part_bins(u64 n_obj) { return (n_obj + ((u64)1 << g_part_shift) - 1) >> g_part_shift; }
+// rows per window: the largest (1 << g_part_shift), or — balanced — the size at which the windows fill R whole rounds of kPartCUs
+// workgroups, R = the rounds the largest size needs (10 M rows: 611 windows of 16 384 -> 766 of 13 056)
+static u32 part_window(u64 n_obj) {
+    const u64 wmax = (u64)1 << g_part_shift;
+    if (!g_part_balance) return (u32)wmax;
+    const u64 full = (n_obj + wmax - 1) / wmax;
+    const u64 R = (full + kPartCUs - 1) / kPartCUs;
+    u64 W = (n_obj + (u64)kPartCUs * R - 1) / ((u64)kPartCUs * R);
+    W = (W + 255) & ~(u64)255;
+    if (W < 4096) W = 4096;
+    if (W > wmax || (n_obj + W - 1) / W > kPartMaxBins) W = wmax;
+    return (u32)W;
+}
+static inline u64 part_bins(u64 n_obj) { const u64 W = part_window(n_obj); return (n_obj + W - 1) / W; }
 static size_t part_bin_lds(u32 nbins, size_t rec_bytes, u32 sub) {
     return kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16 + (size_t)sub * rec_bytes;
 }
-// Entries per chunk.  Measured on the 10 M x 1 024 table (round 6, profiles/round6_crud_ab.json, round6_pp_chunks.json): the big
-// form takes 24 us off k_pp_win_gather at 10 M requests and costs k_part_bin 15 (half as many workgroups, each twice as long:
-// 611 on 256 CUs are three rounds of 16 units where 1 221 were five of 8), so a request batch takes it from 4 M requests on —
-// below that the binning kernel is a single round of workgroups either way and twice as long with big chunks; the CRUD batches
-// (k_part_update - 5 us, k_part_bin + 13) keep the small form.  pp: a place_pending batch.
-static inline u32 part_sub(u64 n_obj, u64 n, bool pp) {
+// The chunk FORM (the largest chunk: 8 192 entries, 8 per lane of k_part_bin and a quarter wave per piece in the apply kernels |
+// 16 384, 16 per lane and a half wave).  Measured on the 10 M x 1 024 table (round 6, profiles/round6_crud_ab.json): the big form
+// takes 24 us off k_pp_win_gather at 10 M requests and costs k_part_bin 15, so a request batch takes it from 4 M requests on; the CRUD
+// batches (k_part_update - 5 us, k_part_bin + 13) keep the small form.  pp: a place_pending batch.
+static inline u32 part_form(u64 n_obj, u64 n, bool pp) {
     const bool fits = part_bin_lds((u32)part_bins(n_obj), sizeof(uint2), kPartSubBig) <= (size_t)150 * 1024;
     if (g_part_big_all && fits) return kPartSubBig;
     return (g_part_big && pp && fits && n >= ((u64)1 << 22)) ? kPartSubBig : kPartSub;
+}
+// entries per chunk for a slice of ns entries: the form's size, or — balanced, from two rounds of chunks on — the size at which the
+// chunks fill whole rounds (10 M entries: 611 chunks of 16 384 -> 768 of 13 024)
+static u32 part_chunk(u64 ns, u32 form) {
+    if (!g_part_balance) return form;
+    const u64 R = (ns + (u64)kPartCUs * form - 1) / ((u64)kPartCUs * form);
+    if (R < 2) return form;
+    u64 sub = (ns + (u64)kPartCUs * R - 1) / ((u64)kPartCUs * R);
+    sub = (sub + 3) & ~(u64)3;
+    return sub > form ? form : (u32)sub;
+}
+struct PartPlan { PartGeo g; u32 nbins; u32 form; u64 slice_max; };
+static PartPlan part_plan(u64 n_obj, u64 n, bool pp) {
+    PartPlan q;
+    q.g.W = part_window(n_obj);
+    q.g.wmagic = (((u64)1 << 44) + q.g.W - 1) / q.g.W;
+    q.nbins = (u32)((n_obj + q.g.W - 1) / q.g.W);
+    q.form = part_form(n_obj, n, pp);
+    const u64 ns = n < (u64)kPartSliceMax ? n : (u64)kPartSliceMax;
+    q.g.sub = part_chunk(ns, q.form);
+    q.slice_max = (u64)(kPartSliceMax / q.form) * q.g.sub;  // 2 048 small / 1 024 big chunks a launch: the apply kernels' 32 pieces per lane group
+    return q;
 }
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node) {
     const u64 nbins = part_bins(n_obj);
     // dense enough that rewriting whole windows pays (a sparse batch touches few rows of each), columns 16-byte aligned
     return n >= ((u64)1 << 18) && n <= 0x7FFFFFFFull && n * 8 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
-           (((uintptr_t)idx | (uintptr_t)node) & 15u) == 0;
+           n_obj <= ((u64)1 << 27) && (((uintptr_t)idx | (uintptr_t)node) & 15u) == 0;
 }
-// one slice of the batch at a time: records (8 B each) + the u16 chunk table [nbins + 1][chunks]
-size_t part_scratch_words(u64 n_obj, u64 n) {  // (sized for either chunk form: whole big chunks of records, the small form's table)
-    const u64 slice = n < (u64)kPartSliceMax ? n : (u64)kPartSliceMax;
-    const u64 big = (slice + kPartSubBig - 1) / kPartSubBig, small = (slice + kPartSub - 1) / kPartSub;
-    return (size_t)(2 * big * kPartSubBig + ((part_bins(n_obj) + 1) * small + 1) / 2 + 64);
+// one slice of the batch at a time: records (8 B each, whole chunks) + the u16 chunk table [nbins + 1][chunks]; sized for either form
+size_t part_scratch_words(u64 n_obj, u64 n) {
+    size_t need = 0;
+    for (int pp = 0; pp < 2; ++pp) {
+        const PartPlan q = part_plan(n_obj, n, pp != 0);
+        const u64 ns = n < q.slice_max ? n : q.slice_max;
+        const u64 chunks = (ns + q.g.sub - 1) / q.g.sub;
+        const size_t w = (size_t)(2 * chunks * q.g.sub + (((u64)q.nbins + 1) * chunks + 1) / 2 + 64);
+        need = w > need ? w : need;
+    }
+    return need;
 }
 void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
                         hipStream_t s, u32* aff_life) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, false);
-    const u64 slice_max = (u64)kPartSliceMax;
-    for (u64 at = 0; at < n; at += slice_max) {  // slices in batch order: a later slice overwrites an earlier one's rows
-        const u64 ns = n - at < slice_max ? n - at : slice_max;
+    const PartPlan q = part_plan(n_obj, n, false);
+    const u32 nbins = q.nbins, sub = q.g.sub;
+    for (u64 at = 0; at < n; at += q.slice_max) {  // slices in batch order: a later slice overwrites an earlier one's rows
+        const u64 ns = n - at < q.slice_max ? n - at : q.slice_max;
         const u32 chunks = (u32)((ns + sub - 1) / sub);
         uint2* rec2 = reinterpret_cast<uint2*>(scratch);
         unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * sub);
         const size_t blds = part_bin_lds(nbins, sizeof(uint2), sub);
-        const size_t lds = ((size_t)1 << wshift) * sizeof(u64);
-        if (sub == kPartSubBig) {
+        const size_t lds = (size_t)q.g.W * sizeof(u64);
+        if (q.form == kPartSubBig) {
             hipLaunchKernelGGL((k_part_bin<true, 16>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
-                               node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st, true);
-            hipLaunchKernelGGL(k_part_update<32>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, wshift);
+                               node + at, ns, nbins, q.g, (u32*)nullptr, rec2, start16, st, true);
+            hipLaunchKernelGGL(k_part_update<32>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, q.g);
         } else {
             hipLaunchKernelGGL((k_part_bin<true, 8>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
-                               node + at, ns, nbins, wshift, (u32*)nullptr, rec2, start16, st, true);
-            hipLaunchKernelGGL(k_part_update<16>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, wshift);
+                               node + at, ns, nbins, q.g, (u32*)nullptr, rec2, start16, st, true);
+            hipLaunchKernelGGL(k_part_update<16>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, rec2, start16, chunks, aff_life, q.g);
         }
     }
 }
 void launch_remove_part(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* idx, u64 n, u32* scratch, u64* used,
                         DevStats* st, hipStream_t s, u32* aff_life) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, false);
-    const u64 slice_max = (u64)kPartSliceMax;
-    for (u64 at = 0; at < n; at += slice_max) {
-        const u64 ns = n - at < slice_max ? n - at : slice_max;
+    const PartPlan q = part_plan(n_obj, n, false);
+    const u32 nbins = q.nbins, sub = q.g.sub;
+    for (u64 at = 0; at < n; at += q.slice_max) {
+        const u64 ns = n - at < q.slice_max ? n - at : q.slice_max;
         const u32 chunks = (u32)((ns + sub - 1) / sub);
         u32* rec = scratch;
         unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * sub);
         const size_t blds = part_bin_lds(nbins, sizeof(u32), sub);
-        const size_t lds = ((size_t)1 << wshift) * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0) + 16;
-        if (sub == kPartSubBig) {
+        const size_t lds = (size_t)q.g.W * sizeof(u32) + (used ? (size_t)m * sizeof(u64) : 0) + 16;
+        if (q.form == kPartSubBig) {
             hipLaunchKernelGGL((k_part_bin<false, 16>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
-                               (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st, true);
+                               (const u32*)nullptr, ns, nbins, q.g, rec, (uint2*)nullptr, start16, st, true);
             hipLaunchKernelGGL(k_part_remove<32>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, m, load, rec, start16, chunks, used,
-                               aff_life, wshift);
+                               aff_life, q.g);
         } else {
             hipLaunchKernelGGL((k_part_bin<false, 8>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx + at,
-                               (const u32*)nullptr, ns, nbins, wshift, rec, (uint2*)nullptr, start16, st, true);
+                               (const u32*)nullptr, ns, nbins, q.g, rec, (uint2*)nullptr, start16, st, true);
             hipLaunchKernelGGL(k_part_remove<16>, dim3(nbins), dim3(kBlock), lds, s, assign, n_obj, m, load, rec, start16, chunks, used,
-                               aff_life, wshift);
+                               aff_life, q.g);
         }
     }
 }
 // place_pending over a window-sorted batch (k_pp_win_*): scratch = part_scratch_words(n_obj, n) words (records + chunk table)
 void launch_pp_bin(u64 n_obj, u32 m, const u32* idx, const u32* req, u64 n, u32* scratch, DevStats* st, u32* host_err, hipStream_t s,
                    u32* dead_bits, u64* claim_fast) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, true);
+    const PartPlan q = part_plan(n_obj, n, true);
+    const u32 nbins = q.nbins, sub = q.g.sub;
     const u32 chunks = (u32)((n + sub - 1) / sub);
     uint2* rec2 = reinterpret_cast<uint2*>(scratch);
     unsigned short* start16 = reinterpret_cast<unsigned short*>(scratch + 2 * (size_t)chunks * sub);
     const size_t blds = part_bin_lds(nbins, sizeof(uint2), sub);
-    if (sub == kPartSubBig)
+    if (q.form == kPartSubBig)
         hipLaunchKernelGGL((k_part_bin<true, 16>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx, req, n,
-                           nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
+                           nbins, q.g, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
                            claim_fast, m + 1);
     else
         hipLaunchKernelGGL((k_part_bin<true, 8>), dim3(chunks), dim3(kBlock), blds, s, n_obj, m, idx, req, n,
-                           nbins, wshift, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
+                           nbins, q.g, (u32*)nullptr, rec2, start16, st, false, host_err, (u32*)nullptr, dead_bits, (m + 31) / 32,
                            claim_fast, m + 1);
 }
 // claim_fast: [m] claim loads + [1] the "could not answer by itself" counter, zeroed by launch_pp_bin
 void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const u32* alive_bits, u64 n, const u32* scratch,
                           u32* ans0, u32* ans1, u32* dead_bits, u32* aff_life, const DevStats* st, u64* claim_fast, hipStream_t s) {
-    const u32 wshift = (u32)g_part_shift, nbins = (u32)part_bins(n_obj), sub = part_sub(n_obj, n, true);
+    const PartPlan q = part_plan(n_obj, n, true);
+    const u32 nbins = q.nbins, sub = q.g.sub;
     const u32 chunks = (u32)((n + sub - 1) / sub);
     const uint2* rec2 = reinterpret_cast<const uint2*>(scratch);
     const unsigned short* start16 = reinterpret_cast<const unsigned short*>(scratch + 2 * (size_t)chunks * sub);
     // (dead_bits and claim_fast were cleared by the binning kernel: launch_pp_bin)
-    const size_t win = ((size_t)1 << wshift) * sizeof(u64);
+    const size_t win = (size_t)q.g.W * sizeof(u64);
     const u32 lds_hist = win + (size_t)m * sizeof(u64) <= (size_t)150 * 1024 ? 1u : 0u;  // else: global atomics per first touch
     const size_t lds = win + (lds_hist ? (size_t)m * sizeof(u64) : 0);
-    if (sub == kPartSubBig)
+    if (q.form == kPartSubBig)
         hipLaunchKernelGGL(k_pp_win_gather<32>, dim3(nbins), dim3(kBlock), lds, s, assign, load,
-                           n_obj, m, alive_bits, rec2, start16, chunks, wshift, ans0, ans1, dead_bits, aff_life, st, claim_fast,
+                           n_obj, m, alive_bits, rec2, start16, chunks, q.g, ans0, ans1, dead_bits, aff_life, st, claim_fast,
                            claim_fast + m, lds_hist, trace_flag());
     else
         hipLaunchKernelGGL(k_pp_win_gather<16>, dim3(nbins), dim3(kBlock), lds, s, assign, load,
-                           n_obj, m, alive_bits, rec2, start16, chunks, wshift, ans0, ans1, dead_bits, aff_life, st, claim_fast,
+                           n_obj, m, alive_bits, rec2, start16, chunks, q.g, ans0, ans1, dead_bits, aff_life, st, claim_fast,
                            claim_fast + m, lds_hist, trace_flag());
 }
 void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* used, const u64* claim_fast, const DevStats* st,
@@ -5495,7 +5552,7 @@ void launch_pp_win_verdict(u32 m, const u64* cap, const u32* alive_bits, u64* us
 }
 void launch_pp_win_unsort(u64 n_obj, const u32* scratch, const u32* ans0, const u32* ans1, u64 n, uint2* vrec, u32* out_node,
                           u32* out_flag, const u32* verdict, hipStream_t s) {
-    const u32 sub = part_sub(n_obj, n, true);
+    const u32 sub = part_plan(n_obj, n, true).g.sub;
     const u32 chunks = (u32)((n + sub - 1) / sub);
     hipLaunchKernelGGL(k_pp_win_unsort, dim3(chunks), dim3(kBlock), (size_t)2 * sub * sizeof(u32), s,
                        reinterpret_cast<const uint2*>(scratch), ans0, ans1, n, vrec, out_node, out_flag, verdict, sub);
@@ -5510,7 +5567,7 @@ bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req) {
     // (the windows' rows are only READ here, once and densely: it pays for sparser batches than the CRUD forms' n_obj / 8)
     const u64 nbins = part_bins(n_obj);
     return n >= ((u64)1 << 18) && n <= (u64)kPartSliceMax && n * 32 >= n_obj && nbins >= 32 && nbins <= kPartMaxBins &&
-           (((uintptr_t)idx | (uintptr_t)req) & 15u) == 0;
+           n_obj <= ((u64)1 << 27) && (((uintptr_t)idx | (uintptr_t)req) & 15u) == 0;
 }
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
                   u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life, u32 seq, const u32* skip_if) {

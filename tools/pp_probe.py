@@ -22,7 +22,8 @@ reqp = cfg["aff"][perm]
 out = {}
 d_idx, d_req, d_node, d_flag = DevBuf(perm), DevBuf(reqp), DevBuf(nbytes=4 * n), DevBuf(nbytes=4 * n)
 none = np.full(n, 0xFFFFFFFF, np.uint32)
-for k in (1_000_000, 10_000_000):
+sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1_000_000, 10_000_000]   # (one size: per-kernel profiles)
+for k in sizes:
     ts = []
     for rep in range(4):
         g.set_assign(none); g.get_nodes(); g.sync()
@@ -31,6 +32,8 @@ for k in (1_000_000, 10_000_000):
         ts.append(g.timer_end() * 1e-3)
     t = float(np.mean(ts[1:]))
     out["dev_%d" % k] = {"us": t * 1e6, "req_per_s": k / t, "GBps_28B": 28 * k / t / 1e9, "frac": 28 * k / t / 1e9 / 8000}
+if len(sys.argv) > 1:
+    print(json.dumps(out)); g.close(); sys.exit(0)
 # warm (sticky) requests: every object already placed
 g.set_assign(none); g.get_nodes()
 g.place_pending_dev(n, d_idx.ptr, d_req.ptr, d_node.ptr, d_flag.ptr)

@@ -13,14 +13,18 @@ show() {
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
-    if "k_part" in r["Name"] or "k_pp_win" in r["Name"] or "k_clean" in r["Name"]:
+    if float(r["AverageNs"]) > 3000 and not r["Name"].startswith("__amd"):
         print("%-70s calls %5s avg %9.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 }
-rm -rf /tmp/pc_crud /tmp/pc_pp /tmp/pc_pps
+rm -rf /tmp/pc_crud
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_crud -o pc -- python $ROOT/tools/crud_ab.py 4 > $OUT/${TAG}_prof_crud.log 2>&1
 f=$(find /tmp/pc_crud -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_crud_kernel_stats.csv; echo "---- crud (both forms)"; show $f
-timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_pp -o pc -- python $ROOT/tools/pp_probe.py > $OUT/${TAG}_prof_pp.log 2>&1
-f=$(find /tmp/pc_pp -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_pp_kernel_stats.csv; echo "---- place_pending, 16 384-entry chunks"; show $f
-RIO_PART_SHIFT=78 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_pps -o pc -- python $ROOT/tools/pp_probe.py > $OUT/${TAG}_prof_pp_small.log 2>&1
-f=$(find /tmp/pc_pps -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_pp_small_kernel_stats.csv; echo "---- place_pending, 8 192-entry chunks"; show $f
+for sz in 1000000 10000000; do
+  rm -rf /tmp/pc_pp_$sz
+  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_pp_$sz -o pc -- python $ROOT/tools/pp_probe.py $sz > $OUT/${TAG}_prof_pp_$sz.log 2>&1
+  f=$(find /tmp/pc_pp_$sz -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_pp_${sz}_kernel_stats.csv; echo "---- place_pending, $sz requests (the product's chunk form)"; show $f
+done
+rm -rf /tmp/pc_pps
+RIO_PART_SHIFT=78 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_pps -o pc -- python $ROOT/tools/pp_probe.py 10000000 > $OUT/${TAG}_prof_pp_small.log 2>&1
+f=$(find /tmp/pc_pps -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_pp_small_kernel_stats.csv; echo "---- place_pending, 10 M requests, 8 192-entry chunks"; show $f
