@@ -255,6 +255,8 @@ void launch_remove(u32* assign, u64 n_obj, u32 m, const u32* load, const u32* id
 // scratch = part_scratch_words(n_obj, n) u32 words of device memory
 bool part_applicable(u64 n_obj, u64 n, const void* idx, const void* node_or_null);
 size_t part_scratch_words(u64 n_obj, u64 n);
+// end of a synchronous call: the error counter (as 0 / 1) into a mapped host word, then the completion word (the host spins on it)
+void launch_finish_err(const DevStats* st, u32* host_err, u32* done, u32 seq, hipStream_t s);
 void set_part_shift(int shift);  // rows per window = 1 << shift, 12..14 (A/B runs)
 void launch_update_part(u32* assign, u64 n_obj, u32 m, const u32* idx, const u32* node, u64 n, u32* scratch, DevStats* st,
                         hipStream_t s, u32* aff_life = nullptr);

@@ -3346,7 +3346,8 @@ __global__ __launch_bounds__(kBlock) void k_remove(u32* __restrict__ assign, u64
 //                   scan, the records {row in window | node code, batch position} go to their sorted place in an LDS
 //                   staging buffer and leave as ONE coalesced copy — a first version scattered them straight to global
 //                   memory, 611 write streams per workgroup: 88 us of partial-line writes for 10 M entries; the chunk's
-//                   window boundaries go to a u16 table [window][chunk];
+//                   window boundaries go to a u16 table [window][chunk] (the transposed table — a row of its own per workgroup, whole lines — was
+//                   measured in round 6: no difference);
 //     k_part_update one workgroup per window: the window's piece of every chunk (~13 records each on a 10 M batch) is
 //                   addressed through a prefix over the chunk table, one lane per record, and streams through an LDS
 //                   table of W u64 words — last-writer-wins is a ds_max_u64 on {position + 1 | node code}; the window's rows
@@ -5593,6 +5594,16 @@ void launch_count_placed(const u32* assign, u64 n_obj, DevStats* st, hipStream_t
 void launch_fill_u32(u32* p, u64 n, u32 v, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, p, n, v);
+}
+// End of a synchronous call of several big kernels: one thread, behind them in the stream, copies the error counter into a
+// mapped host word and stores the completion word — the host spins on it instead of a counter copy-back + hipStreamSynchronize
+// (~25 us of a 130 us update_batch of 10 M entries).  No fence inside the big kernels (LESSONS 25): the launch boundary orders them.
+__global__ void k_finish_err(const DevStats* __restrict__ st, u32* __restrict__ host_err, u32* __restrict__ done, u32 seq) {
+    __hip_atomic_store(host_err, st->err ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_finish_err(const DevStats* st, u32* host_err, u32* done, u32 seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_finish_err, dim3(1), dim3(1), 0, s, st, host_err, done, seq);
 }
 void launch_store_words(const WordPack& pack, u32 nwords, u32* dst, hipStream_t s) {
     if (!nwords) return;

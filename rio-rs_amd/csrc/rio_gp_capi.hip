@@ -1245,12 +1245,27 @@ int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* 
     return RIO_GP_OK;
 }
 
+// End of a synchronous call of the window-partitioned kernels: the error counter and the completion word arrive in mapped host
+// memory (k_finish_err); no counter copy-back, no hipStreamSynchronize.
+static int finish_err(rio_gp* h, const char* what) {
+    const u32 seq = small_begin(h);
+    h->h_small[4 * kSmallBatch] = 0;
+    launch_finish_err(h->dstats, h->d_small + 4 * kSmallBatch, small_done_dev(h), seq, h->stream);
+    int rc = small_wait(h, seq);
+    if (rc) return rc;
+    if (h->h_small[4 * kSmallBatch]) return fail(h, RIO_GP_EINVAL, what);
+    return RIO_GP_OK;
+}
+
 static int update_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node) {
     int rc = zero_stats(h);
     if (rc) return rc;
     if (h->part_mode != 2 && part_applicable(h->n, n, d_idx, d_node)) {  // big batch: binned by row window, elected in LDS, written densely
         if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32)))) return rc;
         launch_update_part(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, (u32*)h->part.p, h->dstats, h->stream, aff_life(h));
+        h->used_valid = false;
+        h->have_solved = false; ++h->mut_epoch;
+        return finish_err(h, "rio_gp_update_batch: invalid entries were skipped");
     } else {
         launch_update(h->assign[h->cur], h->n, h->m, d_idx, d_node, n, h->pos, h->dstats, h->stream, aff_life(h));
     }
@@ -1321,6 +1336,8 @@ static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
         if ((rc = ensure(h, h->part, part_scratch_words(h->n, n) * sizeof(u32)))) return rc;
         launch_remove_part(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, (u32*)h->part.p, h->used_valid ? h->used : nullptr,
                            h->dstats, h->stream, aff_life(h));
+        h->have_solved = false; ++h->mut_epoch;
+        return finish_err(h, "rio_gp_remove_batch: invalid entries were skipped");
     } else {
         launch_remove(h->assign[h->cur], h->n, h->m, h->load, d_idx, n, h->used_valid ? h->used : nullptr, h->dstats,
                       h->stream, aff_life(h));

@@ -2,7 +2,7 @@
 """A/B of the big random CRUD batches on config 3's table (10 M rows x 1 024 nodes): window-partitioned kernels at
 windows of 4 096 / 8 192 / 16 384 rows (chunks of 8 192 entries, round 5's form, and of 16 384, round 6's) against the plain
 per-entry kernels; 10 M random entries with duplicates.
-HIP events on the library stream around the whole call (kernels + the stats read-back).  Usage: crud_ab.py [reps]"""
+HIP events on the library stream around the whole call (kernels + the stats read-back).  Usage: crud_ab.py [reps] [variant,variant...]"""
 import ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
@@ -22,6 +22,8 @@ out = {}
 for name, shift, part in (("plain", 14, False), ("part_w4096", 12, True), ("part_w8192", 13, True),
                           ("part_w16384", 14, True), ("part_w8192_bigchunks", 13 | 0x80, True), ("part_w16384_bigchunks", 14 | 0x80, True),
                           ("part_w16384#2", 14, True), ("part_w16384_bigchunks#2", 14 | 0x80, True)):
+    if len(sys.argv) > 2 and name not in sys.argv[2].split(","):   # (one variant: per-kernel profiles)
+        continue
     L.rio_gp_debug_set_part_shift(shift)
     g = rio_gp.LabPlacement(n, m)
     g.set_compact("auto", partitioned_crud=part)

@@ -18,8 +18,8 @@ for r in rows:
 PY
 }
 rm -rf /tmp/pc_crud
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_crud -o pc -- python $ROOT/tools/crud_ab.py 4 > $OUT/${TAG}_prof_crud.log 2>&1
-f=$(find /tmp/pc_crud -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_crud_kernel_stats.csv; echo "---- crud (both forms)"; show $f
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_crud -o pc -- python $ROOT/tools/crud_ab.py 6 part_w16384 > $OUT/${TAG}_prof_crud.log 2>&1
+f=$(find /tmp/pc_crud -name "*kernel_stats.csv" | head -1); cp $f $OUT/${TAG}_crud_kernel_stats.csv; echo "---- crud, 10 M random entries (the product's geometry)"; show $f
 for sz in 1000000 10000000; do
   rm -rf /tmp/pc_pp_$sz
   timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_pp_$sz -o pc -- python $ROOT/tools/pp_probe.py $sz > $OUT/${TAG}_prof_pp_$sz.log 2>&1
