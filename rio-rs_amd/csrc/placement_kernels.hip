@@ -18,6 +18,7 @@
 //   * all cross-row decisions are integer sums and index-ordered prefixes: results do not depend
 //     on dispatch order, so the output is bit-identical to the sequential oracle.
 #include "placement_kernels.h"
+#include <cstdlib>
 
 #include <hip/hip_ext.h>
 
@@ -3369,13 +3370,14 @@ constexpr u32 kPartCUs = 256;         // workgroups of one round: the apply kern
 // Geometry of one partitioned batch (round 6: neither size has to be a power of two).  611 windows of 16 384 rows on 256 CUs are
 // three rounds of workgroups, the last one 39 % full; 766 windows of 13 056 rows are three FULL rounds of workgroups that are each
 // a fifth shorter.  The same for the chunks of the batch (768 chunks of 13 024 entries instead of 611 of 16 384).  The window of a
-// row is one multiply-shift: row * ceil(2^44 / W) >> 44, exact for rows < 2^27 and 256 <= W <= 2^14 (error term row / 2^44 < 1 / W).
+// row is one multiply-high and a shift: row * ceil(2^42 / W) >> 42, exact for rows < 2^27 and 2^12 <= W <= 2^14 (the magic number
+// fits 32 bits; error term row / 2^42 < 2^-15 < 1 / W).
 struct PartGeo {
-    u32 W;       // rows per window (a multiple of 256, <= 1 << kPartShiftMax)
+    u32 W;       // rows per window (a multiple of 256, 4 096 .. 1 << kPartShiftMax)
     u32 sub;     // entries per chunk (a multiple of 4, <= 8 192 or 16 384: the PER of k_part_bin / the LP of the apply kernels)
-    u64 wmagic;  // ceil(2^44 / W)
+    u32 wmagic;  // ceil(2^42 / W)
 };
-__host__ __device__ __forceinline__ u32 part_win_of(const PartGeo& pg, u32 row) { return (u32)(((u64)row * pg.wmagic) >> 44); }
+__host__ __device__ __forceinline__ u32 part_win_of(const PartGeo& pg, u32 row) { return (u32)(((u64)row * pg.wmagic) >> 42); }
 constexpr u32 kPartMaxBins = 8192;    // 134 M rows at the largest window
 constexpr u32 kNodeNoneCode = 0x3FFFu;  // 14-bit code of RIO_GP_NONE (node ids are < 8 192)
 
@@ -3402,29 +3404,34 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     const u32 nchunks = gridDim.x, c = blockIdx.x;
     const u64 lo = (u64)c * pg.sub;
     const u64 hi = lo + pg.sub < n ? lo + pg.sub : n;
-    auto load4 = [&](const u32* p, u64 k) -> uint4 {  // entries k..k+3 of a column, zero past hi (k is a multiple of 4)
-        if (k + 4 <= hi) return *reinterpret_cast<const uint4*>(p + k);
+    // the chunk's columns through a UNIFORM base (idx + lo) and 32-bit in-chunk offsets: one offset register per vector, shared by
+    // both columns — 64-bit per-lane addresses for the eight vectors of the 16-per-lane form were 16 registers of its spill
+    const u32 cn = (u32)(hi - lo);  // entries of this chunk
+    auto load4 = [&](const u32* cb, u32 o) -> uint4 {  // entries o..o+3 of the chunk's column, zero past its end (o is a multiple of 4)
+        if (o + 4u <= cn) return *reinterpret_cast<const uint4*>(cb + o);
         uint4 r = make_uint4(0, 0, 0, 0);
-        if (k + 0 < hi) r.x = p[k + 0];
-        if (k + 1 < hi) r.y = p[k + 1];
-        if (k + 2 < hi) r.z = p[k + 2];
+        if (o + 0u < cn) r.x = cb[o + 0u];
+        if (o + 1u < cn) r.y = cb[o + 1u];
+        if (o + 2u < cn) r.z = cb[o + 2u];
         return r;
     };
-    const u64 k0 = lo + (u64)tid * 4;  // vector q of this lane: entries k0 + q * 4 096 .. + 3
+    const u32* const ib = idx + lo;  // vector q of this lane: entries tid * 4 + q * 4 096 .. + 3 of the chunk
+    const u32* const nb = UPDATE ? node + lo : nullptr;
     uint4 iv[NV], nv[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-        iv[q] = load4(idx, k0 + (u64)q * kBlock * 4);
-        nv[q] = UPDATE ? load4(node, k0 + (u64)q * kBlock * 4) : make_uint4(0, 0, 0, 0);
+        iv[q] = load4(ib, (u32)tid * 4u + (u32)q * (kBlock * 4u));
+        nv[q] = UPDATE ? load4(nb, (u32)tid * 4u + (u32)q * (kBlock * 4u)) : make_uint4(0, 0, 0, 0);
     }
     for (u32 b = tid; b < nbins; b += kBlock) hist[b] = 0;
     if (zero_flags) {
-        const bool al = (reinterpret_cast<uintptr_t>(zero_flags) & 15u) == 0;
+        u32* const zb = zero_flags + lo;  // (uniform base, 32-bit in-chunk offsets: as the loads above)
+        const bool al = (reinterpret_cast<uintptr_t>(zb) & 15u) == 0;
         for (int q = 0; q < NV; ++q) {
-            const u64 k = k0 + (u64)q * kBlock * 4;
-            if (al && k + 4 <= hi) *reinterpret_cast<uint4*>(zero_flags + k) = make_uint4(0, 0, 0, 0);
+            const u32 o = (u32)tid * 4u + (u32)q * (kBlock * 4u);
+            if (al && o + 4u <= cn) *reinterpret_cast<uint4*>(zb + o) = make_uint4(0, 0, 0, 0);
             else
-                for (u32 e = 0; e < 4 && k + e < hi; ++e) zero_flags[k + e] = 0;
+                for (u32 e = 0; e < 4 && o + e < cn; ++e) zb[o + e] = 0;
         }
     }
     if (zero_bits && c == 0)
@@ -3438,15 +3445,21 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
         I[4 * q] = iv[q].x; I[4 * q + 1] = iv[q].y; I[4 * q + 2] = iv[q].z; I[4 * q + 3] = iv[q].w;
         N[4 * q] = nv[q].x; N[4 * q + 1] = nv[q].y; N[4 * q + 2] = nv[q].z; N[4 * q + 3] = nv[q].w;
     }
-    u32 rk[PER];  // {the entry's rank in its window of this chunk (< 2^15) | its node code << 16}, all ones: not a valid entry
+    // Counting and placing are two rounds of LDS atomics (round 6): the count needs no return value, and the entry's place in the
+    // sorted chunk is the returned value of a second atomic on the window's running offset, after the scan.  (One returning atomic
+    // — count = rank — before: sixteen ranks in registers across the scan next to the sixteen entries spilled 76 bytes a lane in
+    // the 16-per-lane form.)  The order of a window's entries inside the chunk is whatever the atomics make it, as before.
+    u32 okmask = 0;  // bit j: entry j of this lane is valid
+    u32 c2[PER / 2];  // the entries' 14-bit node codes, two to a register (what is left of the node column after this loop)
     u32 bad = 0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const bool in = (u32)tid * 4u + (u32)(j >> 2) * (kBlock * 4u) + (u32)(j & 3) < (u32)(hi - lo);  // (32-bit: in-chunk offsets)
-        const bool ok = in && I[j] < n_obj && (!UPDATE || (none_ok && N[j] == kNone) || N[j] < m);
-        const u32 code = UPDATE ? (N[j] == kNone ? kNodeNoneCode : N[j]) : 0u;
-        rk[j] = ok ? (atomicAdd(&hist[part_win_of(pg, I[j])], 1u) | (code << 16)) : 0xFFFFFFFFu;  // the returned count = the entry's rank
+        const bool ok = in && I[j] < (u32)n_obj && (!UPDATE || (none_ok && N[j] == kNone) || N[j] < m);  // (n_obj <= 2^27 here)
+        if (ok) { atomicAdd(&hist[part_win_of(pg, I[j])], 1u); okmask |= 1u << j; }
         bad += in && !ok;
+        const u32 code = UPDATE ? (N[j] == kNone ? kNodeNoneCode : (N[j] & kNodeNoneCode)) : 0u;
+        if (j & 1) c2[j >> 1] |= code << 16; else c2[j >> 1] = code;
     }
     if (bad) {
         atomicAdd(&st->err, (u64)bad);
@@ -3481,15 +3494,20 @@ __global__ __launch_bounds__(kBlock) void k_part_bin(u64 n_obj, u32 m, const u32
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < PER; ++j)
-        if (rk[j] != 0xFFFFFFFFu) {
-            const u32 wn = part_win_of(pg, I[j]);
-            const u32 pos = off[wn] + (rk[j] & 0xFFFFu);
-            const u32 r = (I[j] - wn * pg.W) | ((rk[j] >> 16) << kPartShiftMax);
+    for (int j = 0; j < PER; ++j) {
+        if ((okmask >> j) & 1u) {
+            u32 ij = I[j];
+            asm volatile("" : "+v"(ij));  // the window is computed AGAIN (one multiply): kept from the counting loop, sixteen of them spill
+            const u32 wn = part_win_of(pg, ij);
+            const u32 pos = atomicAdd(&off[wn], 1u);
+            const u32 code = (c2[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+            const u32 r = (ij - wn * pg.W) | (code << kPartShiftMax);
             const u32 k = (u32)lo + (u32)tid * 4u + (u32)(j >> 2) * (kBlock * 4u) + (u32)(j & 3);  // position in the slice
             if (UPDATE) reinterpret_cast<uint2*>(stage)[pos] = make_uint2(r, k);
             else reinterpret_cast<u32*>(stage)[pos] = r;
         }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four entries at a time: all sixteen interleaved do not fit the register file
+    }
     __syncthreads();
     const u32 total = off[nbins];
     for (u32 t = tid; t < total; t += kBlock) {  // the sorted chunk leaves in one coalesced copy
@@ -4017,7 +4035,7 @@ __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 
                                                const u32* __restrict__ dead_bits, u64* __restrict__ used,
                                                u64* __restrict__ counter, unsigned int* __restrict__ ticket,
                                                u64* __restrict__ host_out, u32* __restrict__ aff_life, u32 seq,
-                                               const u32* __restrict__ skip_if) {
+                                               const u32* __restrict__ skip_if, const u32 full_from) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (skip_if && *skip_if) return;  // request path: the batch holds an invalid entry, the call changes nothing (asynchronous form only)
     u32* db = reinterpret_cast<u32*>(smem);
@@ -4074,7 +4092,7 @@ __global__ __launch_bounds__(kBlock) void k_clean(u32* __restrict__ assign, u64 
             const u64 bal = __ballot(mine_ev);
             if (bal) {
                 x.x = e0 ? kNone : x.x; x.y = e1 ? kNone : x.y; x.z = e2 ? kNone : x.z; x.w = e3 ? kNone : x.w;
-                if (i0 < n_obj && (mine_ev || __popcll(bal) > 16)) *reinterpret_cast<uint4*>(assign + i0) = x;
+                if (i0 < n_obj && (mine_ev || (u32)__popcll(bal) > full_from)) *reinterpret_cast<uint4*>(assign + i0) = x;
             }
             if (mine_ev) {
                 if (aff_life) {  // row lifecycle: retain() drops the entries (local.rs:51-58); they come back on their next request
@@ -5413,13 +5431,14 @@ static size_t part_bin_lds(u32 nbins, size_t rec_bytes, u32 sub) {
     return kSmall + (((size_t)2 * nbins + 1) * sizeof(u32) + 15) / 16 * 16 + (size_t)sub * rec_bytes;
 }
 // The chunk FORM (the largest chunk: 8 192 entries, 8 per lane of k_part_bin and a quarter wave per piece in the apply kernels |
-// 16 384, 16 per lane and a half wave).  Measured on the 10 M x 1 024 table (round 6, profiles/round6_crud_ab.json): the big form
-// takes 24 us off k_pp_win_gather at 10 M requests and costs k_part_bin 15, so a request batch takes it from 4 M requests on; the CRUD
-// batches (k_part_update - 5 us, k_part_bin + 13) keep the small form.  pp: a place_pending batch.
-static inline u32 part_form(u64 n_obj, u64 n, bool pp) {
+// 16 384, 16 per lane and a half wave).  Big chunks make the apply kernels' pieces twice as long (less of every 128-byte line read
+// for nothing, half as many descriptors) and k_part_bin's workgroups twice as long; measured on the 10 M x 1 024 table with 10 M
+// entries (round 6, profiles/round6_crud_ab.json, round6_pp_chunks.json): they pay from 4 M entries on (below that k_part_bin is a
+// single round of workgroups either way, and twice as long with big chunks).
+static inline u32 part_form(u64 n_obj, u64 n) {
     const bool fits = part_bin_lds((u32)part_bins(n_obj), sizeof(uint2), kPartSubBig) <= (size_t)150 * 1024;
     if (g_part_big_all && fits) return kPartSubBig;
-    return (g_part_big && pp && fits && n >= ((u64)1 << 22)) ? kPartSubBig : kPartSub;
+    return (g_part_big && fits && n >= ((u64)1 << 22)) ? kPartSubBig : kPartSub;
 }
 // entries per chunk for a slice of ns entries: the form's size, or — balanced, from two rounds of chunks on — the size at which the
 // chunks fill whole rounds (10 M entries: 611 chunks of 16 384 -> 768 of 13 024)
@@ -5435,9 +5454,9 @@ struct PartPlan { PartGeo g; u32 nbins; u32 form; u64 slice_max; };
 static PartPlan part_plan(u64 n_obj, u64 n, bool pp) {
     PartPlan q;
     q.g.W = part_window(n_obj);
-    q.g.wmagic = (((u64)1 << 44) + q.g.W - 1) / q.g.W;
+    q.g.wmagic = (u32)((((u64)1 << 42) + q.g.W - 1) / q.g.W);
     q.nbins = (u32)((n_obj + q.g.W - 1) / q.g.W);
-    q.form = part_form(n_obj, n, pp);
+    q.form = part_form(n_obj, n);
     const u64 ns = n < (u64)kPartSliceMax ? n : (u64)kPartSliceMax;
     q.g.sub = part_chunk(ns, q.form);
     q.slice_max = (u64)(kPartSliceMax / q.form) * q.g.sub;  // 2 048 small / 1 024 big chunks a launch: the apply kernels' 32 pieces per lane group
@@ -5573,8 +5592,15 @@ bool pp_win_applicable(u64 n_obj, u64 n, const void* idx, const void* req) {
 void launch_clean(u32* assign, u64 n_obj, u32 m, const u32* dead_bits, u64* used, DevStats* st, hipStream_t s,
                   u64* counter, unsigned int* ticket, u64* host_out, u32* aff_life, u32 seq, const u32* skip_if) {
     const size_t lds = (size_t)((m + 31) / 32 + 4) * sizeof(u32);
+    // a wave in which more than `full_from` lanes evict writes its whole kilobyte back (k_clean's comment); 64 = only the changed
+    // 16-byte vectors ever.  16: measured in round 6 (profiles/round6_clean_ab.json, lab builds read RIO_GP_CLEAN_FULL_FROM)
+    u32 full_from = 16;
+#ifdef RIO_GP_LAB
+    static const char* e = getenv("RIO_GP_CLEAN_FULL_FROM");
+    if (e) full_from = (u32)atoi(e);
+#endif
     hipLaunchKernelGGL(k_clean, dim3(grid_for((n_obj + 3) / 4, kBlock, 256)), dim3(kBlock), lds, s, assign, n_obj, m,
-                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out, aff_life, seq, skip_if);
+                       dead_bits, used, counter ? counter : &st->evicted_clean, ticket, host_out, aff_life, seq, skip_if, full_from);
 }
 void launch_recompute_used(const u32* assign, const u32* load, u64 n_obj, u32 m, u64* used, hipStream_t s) {
     (void)hipMemsetAsync(used, 0, (size_t)m * sizeof(u64), s);

@@ -8,7 +8,8 @@ import numpy as np
 import rio_gp, synth
 cfg = synth.config("c3")
 n, m = cfg["n"], cfg["m"]
-g = rio_gp.GpuPlacement(n, m)
+# RIO_GP_CLEAN_FULL_FROM (lab build): lanes of a wave that must evict before the wave writes its whole kilobyte back (16; 64 = never)
+g = rio_gp.LabPlacement(n, m) if os.environ.get("RIO_GP_CLEAN_FULL_FROM") else rio_gp.GpuPlacement(n, m)
 g.set_nodes(cfg["cap"], cfg["alive"])
 g.set_objects(n, cfg["load"], cfg["aff"])
 warm = synth.warm_assign(n, m)
