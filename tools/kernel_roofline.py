@@ -56,26 +56,27 @@ def specs(pending_rows):
         ("contended", r"k_cut_find<false>", "k_cut_find (whole table, contended)", 12 * N, "one pass over the blocks that own cuts (all)"),
         ("contended", r"k_fill<false, true, true, false>", "k_fill round 0 (whole table, contended)", 20 * N, "pass A 12 B/row + pass B next/load 8 B/row"),
         ("contended", r"k_fill<false, false, true, false>", "k_fill round 1 (whole table, contended)", 8 * N, "next + load per row"),
-        ("contended_packed", r"k_fill<false, true, true, true>", "k_fill<PACK> round 0 (whole table, contended: packs the water-fill rows)", 16 * N, "12 B read + 4 B written per row (+12 B per packed row)"),
-        ("contended_packed", r"k_fill<false, false, true, false>", "k_fill round 1 (contended, rows packed at the cut pass)", 12 * N // 10, "next + load + idx of ~1 M packed rows"),
+        ("contended_packed", r"k_cut_apply<true", "k_cut_apply<PACK> (whole table, contended: exact cuts applied, water-fill rows packed, one pass)", 16 * N, "12 B read + 4 B written per row (+12 B per packed row)"),
+        ("contended_packed", r"k_cut_settle", "k_cut_settle (the undecided rows of the cut blocks, final spill totals)", 2 * M * 16 * 8 + 16 * 50000, "Tg [m][16] u64 read + ~16 B per undecided row (a few dozen per cut node); latency-bound"),
+        ("contended_packed", r"k_fill<false, false, true, false>", "k_fill rounds 0 and 1 (contended, rows packed by k_cut_apply; average of both launches)", 12 * N // 10, "next + load + idx of ~1 M packed rows"),
         ("crud", r"k_lookup4", "k_lookup4 (10 M random indices)", 12 * N, "idx + gather + out per lookup"),
         ("lookup_seq", r"k_lookup4", "k_lookup4 (10 M sequential indices)", 12 * N, "idx + gather + out per lookup"),
-        ("crud", r"k_part_bin<true>", "k_part_bin<update> (10 M random)", 8 * N, "idx + node per entry (update = bin + apply: 8 B/op over both)"),
+        ("crud", r"k_part_bin<true", "k_part_bin<update> (10 M random)", 8 * N, "idx + node per entry (update = bin + apply: 8 B/op over both)"),
         ("crud", r"k_part_update", "k_part_update (10 M random)", 8 * N, "see k_part_bin"),
-        ("crud", r"k_part_bin<false>", "k_part_bin<remove> (10 M random)", 8 * N, "idx + row per removal (remove = bin + apply)"),
+        ("crud", r"k_part_bin<false", "k_part_bin<remove> (10 M random)", 8 * N, "idx + row per removal (remove = bin + apply)"),
         ("crud", r"k_part_remove", "k_part_remove (10 M random)", 8 * N, "see k_part_bin"),
         ("crud_plain", r"k_update_elect", "k_update_elect (plain kernels, 10 M random)", 8 * N, "idx + node per entry (update = elect + apply)"),
         ("crud_plain", r"k_update_apply", "k_update_apply (plain kernels, 10 M random)", 8 * N, "see k_update_elect"),
         ("crud_plain", r"k_remove", "k_remove (plain kernel, 10 M random)", 8 * N, "idx + row per removal"),
         ("crud", r"k_clean", "k_clean (10 % of the nodes)", 4 * N + 4 * N // 10, "4 B/row read + 4 B per evicted row"),
         ("clean1", r"k_clean", "k_clean (one node)", 4 * N, "4 B/row read (+4 B per evicted row: 0.1 %)"),
-        ("pp", r"k_part_bin<true>", "k_part_bin (place_pending, 1 M requests)", 16 * 1000000, "idx + requester in, one 8-byte record out per request"),
+        ("pp", r"k_part_bin<true", "k_part_bin (place_pending, 1 M requests)", 16 * 1000000, "idx + requester in, one 8-byte record out per request"),
         ("pp", r"k_pp_win_gather", "k_pp_win_gather (1 M requests)", 20 * 1000000 + 8 * N, "record in + answer record out + the first touch's dense write per request; the windows' assignment and load columns once"),
-        ("pp", r"k_pp_win_split", "k_pp_win_split (1 M requests)", 16 * 1000000, "answer record in, node + flag out"),
-        ("pp10", r"k_part_bin<true>", "k_part_bin (place_pending, 10 M requests)", 16 * 10000000, "idx + requester in, one 8-byte record out per request"),
+        ("pp", r"k_pp_win_unsort", "k_pp_win_unsort (1 M requests)", 16 * 1000000, "sorted answer + batch position in, node + flag out in batch order"),
+        ("pp10", r"k_part_bin<true", "k_part_bin (place_pending, 10 M requests)", 16 * 10000000, "idx + requester in, one 8-byte record out per request"),
         ("pp10", r"k_pp_win_gather", "k_pp_win_gather (10 M requests)", 20 * 10000000 + 8 * N, "record in + answer record out + the first touch's dense write per request; the windows' assignment and load columns once"),
         ("pp10", r"k_pp_win_verdict", "k_pp_win_verdict (10 M requests)", 24 * M, "claim, cap, used per requester"),
-        ("pp10", r"k_pp_win_split", "k_pp_win_split (10 M requests)", 16 * 10000000, "answer record in, node + flag out"),
+        ("pp10", r"k_pp_win_unsort", "k_pp_win_unsort (10 M requests)", 16 * 10000000, "sorted answer + batch position in, node + flag out in batch order"),
         ("pp_mid", r"k_ppm_first", "k_ppm_first (16 384 device-resident requests)", 12 * 16384, "idx + requester in, the election word"),
         ("pp_mid", r"k_ppm_gather", "k_ppm_gather (16 384 requests)", 24 * 16384, "idx in, election word + row + load gathered, three columns out"),
         ("pp_mid", r"k_scan<true, true, 1, 0", "k_scan<VIRT> (16 384 requests)", 16 * 16384, "three columns in, the decision out"),
