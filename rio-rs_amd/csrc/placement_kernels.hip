@@ -3552,6 +3552,7 @@ __global__ __launch_bounds__(kBlock) void k_part_update(u32* __restrict__ assign
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kPartIters; i += kPartFlight) {  // kPartFlight pieces per lane in flight: the loop is a chain of round trips
+        if ((u32)i * (1024u / LP) >= nchunks) break;  // (uniform: no chunk this far — the clamped loads below would be dummies)
         uint2 x[kPartFlight];
 #pragma unroll
         for (int q = 0; q < kPartFlight; ++q) x[q] = rec2[o16 < pcnt[i + q] ? pbase[i + q] + o16 : 0u];  // (clamped: record 0 exists)
@@ -3615,6 +3616,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kPartIters; i += kPartFlight) {
+        if ((u32)i * (1024u / LP) >= nchunks) break;  // (uniform: no chunk this far)
         u32 x[kPartFlight];
 #pragma unroll
         for (int q = 0; q < kPartFlight; ++q) x[q] = rec[o16 < pcnt[i + q] ? pbase[i + q] + o16 : 0u];  // (clamped: record 0 exists)
