@@ -3686,7 +3686,7 @@ __global__ __launch_bounds__(kBlock) void k_part_remove(u32* __restrict__ assign
 // whose requester is not an active member: water-fill, or the reference's unconditional self-assignment) — the call then runs
 // the solve over the records; claim[m] = load the first touches put on every requester (k_pp_win_verdict checks it against
 // the free capacity).  Both zeroed by the binning kernel.
-template <u32 LP>
+template <u32 LP, int kKeep>
 __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assign, const u32* __restrict__ load, u64 n_obj,
                                                           u32 m, const u32* __restrict__ alive_bits,
                                                           const uint2* __restrict__ rec2, const unsigned short* __restrict__ start16,
@@ -3718,7 +3718,8 @@ __global__ __launch_bounds__(kBlock) void k_pp_win_gather(u32* __restrict__ assi
     // kernel spilled ~100 bytes a lane into the middle of its walks (round 6: the spill reloads sat between the LDS atomics, each
     // with a wait for every load in flight).  The pieces past kKeep (batches of more than kKeep / 32 of a slice: > 10.4 M
     // requests at 768 chunks of a slice) are read again by the answer walk.
-    constexpr int kKeep = 24;
+    // (kKeep = 24, or 4 for batches whose chunks fit four steps — up to 2 M requests: the unrolled steps past the last chunk are
+    // dummy loads, and a uniform exit from the unrolled loops cost the 10 M batch 90 us when it was tried)
     uint2 xr[kKeep];
     u32 tailmask = 0;  // bit i: piece i of this lane group holds more than LP records
     // Where piece i's records start (and its answers go) is kept ACROSS THE LANES of the group: lane o holds the start of the
@@ -5559,11 +5560,15 @@ void launch_pp_win_gather(u32* assign, const u32* load, u64 n_obj, u32 m, const 
     const u32 lds_hist = win + (size_t)m * sizeof(u64) <= (size_t)150 * 1024 ? 1u : 0u;  // else: global atomics per first touch
     const size_t lds = win + (lds_hist ? (size_t)m * sizeof(u64) : 0);
     if (q.form == kPartSubBig)
-        hipLaunchKernelGGL(k_pp_win_gather<32>, dim3(nbins), dim3(kBlock), lds, s, assign, load,
+        hipLaunchKernelGGL((k_pp_win_gather<32, 24>), dim3(nbins), dim3(kBlock), lds, s, assign, load,
+                           n_obj, m, alive_bits, rec2, start16, chunks, q.g, ans0, ans1, dead_bits, aff_life, st, claim_fast,
+                           claim_fast + m, lds_hist, trace_flag());
+    else if (chunks <= 4 * 64)
+        hipLaunchKernelGGL((k_pp_win_gather<16, 4>), dim3(nbins), dim3(kBlock), lds, s, assign, load,
                            n_obj, m, alive_bits, rec2, start16, chunks, q.g, ans0, ans1, dead_bits, aff_life, st, claim_fast,
                            claim_fast + m, lds_hist, trace_flag());
     else
-        hipLaunchKernelGGL(k_pp_win_gather<16>, dim3(nbins), dim3(kBlock), lds, s, assign, load,
+        hipLaunchKernelGGL((k_pp_win_gather<16, 24>), dim3(nbins), dim3(kBlock), lds, s, assign, load,
                            n_obj, m, alive_bits, rec2, start16, chunks, q.g, ans0, ans1, dead_bits, aff_life, st, claim_fast,
                            claim_fast + m, lds_hist, trace_flag());
 }

@@ -1050,7 +1050,8 @@ def test_place_pending_big_batches_partitioned_by_row_window(gp, oracle, seed, c
         h.set_objects(n, load, None)
     ref = np.full(n, NONE, np.uint32)
     used = np.zeros(m, np.uint64)
-    for step, k in enumerate((300_000, 1_000_000, 262_144, 700_001)):
+    # (2.2 M requests: more than four steps of chunks — the window kernel's long form with 8 192-entry chunks; the others its short one)
+    for step, k in enumerate((300_000, 1_000_000, 262_144, 700_001, 2_200_000)):
         if step >= 1:
             for j in rng.integers(0, m, 12):
                 alive[j] ^= 1
