@@ -23,6 +23,7 @@ FLAG_LOCAL, FLAG_REDIRECT, FLAG_PLACED, FLAG_SPILLED, FLAG_UNPLACED = range(5)
 FLAG_REPLACED = 0x10   # OR-ed on: the object was found on a dead server, cleaned and re-placed by this request
 FLAG_MASK = 0x0F
 OK, EINVAL, EUPSTREAM, ENODEV, ENOMEM, ERANGE, EAGAIN = range(7)
+ABI_VERSION = 2    # include/rio_gpu_placement.h RIO_GP_ABI_VERSION
 
 LAB_PATH = os.path.join(_DIR, "librio_gp_lab.so")   # the same sources + -DRIO_GP_LAB + stream_probe.hip (tests / tools only)
 SOURCES = [os.path.join(_DIR, "csrc", f) for f in ("placement_kernels.hip", "rio_gp_capi.hip", "gpu_object_placement.cpp")]
@@ -118,6 +119,9 @@ def _load(lab):
         L.rio_gp_backend.argtypes = [_vp]
         L.rio_gp_backend.restype = C.c_char_p
         L.rio_gp_abi_version.restype = C.c_uint32
+        if L.rio_gp_abi_version() != ABI_VERSION:   # (the flag defaults changed between versions 1 and 2: refuse, do not guess)
+            raise RuntimeError("%s speaks ABI version %d, this binding was written against %d"
+                               % (os.path.basename(path), L.rio_gp_abi_version(), ABI_VERSION))
         L.rio_gp_sync.argtypes = [_vp]
         L.rio_gp_set_nodes.argtypes = [_vp, C.c_uint32, _vp, _vp]
         L.rio_gp_set_alive.argtypes = [_vp, C.c_uint32, C.c_uint8]

@@ -51,6 +51,9 @@ const RIO_GP_EINVAL: c_int = 1;
 const RIO_GP_ERANGE: c_int = 5;
 /// `rio_op_try_*`: the host shadow cannot answer; nothing was done — make the blocking call
 const RIO_GP_EAGAIN: c_int = 6;
+/// include/rio_gpu_placement.h RIO_GP_ABI_VERSION: the defaults of the flags changed between 1 and 2 (first touch follows the
+/// reference unless RIO_OP_CFG_LIVE_FIRST_TOUCH is set) — a library of another version is refused, not guessed at
+const RIO_GP_ABI_VERSION: u32 = 2;
 /// `rio_gp_stats` (include/rio_gpu_placement.h): counters of one whole-table solve.
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -72,6 +75,7 @@ pub const FLAG_MASK: u32 = 0x0F;
 
 #[link(name = "rio_gp")]
 extern "C" {
+    fn rio_gp_abi_version() -> u32;
     fn rio_op_create(cfg: *const RioOpCfg, out: *mut *mut c_void) -> c_int;
     fn rio_op_clone(p: *mut c_void) -> *mut c_void;
     fn rio_op_release(p: *mut c_void);
@@ -154,6 +158,11 @@ impl GpuObjectPlacement {
             device, max_objects, max_nodes, spill_rounds,
             flags: if reference_self_assign { 0 } else { RIO_OP_CFG_LIVE_FIRST_TOUCH }, collect_ns: 0,
         };
+        let abi = unsafe { rio_gp_abi_version() };
+        if abi != RIO_GP_ABI_VERSION {
+            return Err(ObjectPlacementError::Unknown(format!(
+                "librio_gp speaks ABI version {abi}, this binding was written against {RIO_GP_ABI_VERSION}")));
+        }
         let mut h: *mut c_void = std::ptr::null_mut();
         let rc = unsafe { rio_op_create(&cfg, &mut h) };
         if rc != RIO_GP_OK {
