@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copy the summaries of one evidence pass (tools/round5_pass.sh <tag> a|b, merged back under gpurun_out/) into profiles/ under
+"""Copy the summaries of one evidence pass (tools/round6_pass.sh <tag> a|b, merged back under gpurun_out/) into profiles/ under
 the round prefix: gpurun_out/ is scratch, profiles/ is tracked.  Usage: collect_profiles.py <tag> [round-prefix]"""
 import glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pre = sys.argv[2] if len(sys.argv) > 2 else "round5"
+pre = sys.argv[2] if len(sys.argv) > 2 else tag
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 def cp(a, b):
     a = os.path.join(src, a)
@@ -16,9 +16,14 @@ for name in ("bench_n1.json", "bench_c5.json", "kernel_roofline.json", "kernel_r
              "latency.txt", "place_pending.json", "place_pending_timeline.txt", "clean.json",
              "bench_sharded_2ranks_one_gpu.json", "bench_sharded_8ranks_one_gpu.json", "c5_variants.json", "c4_variants.json", "fill_trace.json",
              "pp_host_batches.txt", "c4_tick.json", "fuzz.json", "pp_sizes.json", "pp_sizes.txt", "pp_mid_timeline.txt",
-             "c_host.json", "c_host_threads.json", "soak_sharded.json"):
+             "c_host.json", "c_host_threads.json", "soak_sharded.json",
+             # round 6: per-kernel durations of the window-partitioned batches and of the solves in which capacity binds, A/Bs, traces
+             "crud_ab.json", "crud_ab.log", "prof_crud.txt", "prof_binding.txt", "clean_ab.json", "pp_gather_trace.json",
+             "binding_trace_contended.json", "c5_scan_variants.json", "binding_contended_kernel_stats.csv", "binding_skew_kernel_stats.csv",
+             "crud_kernel_stats.csv", "pp_1000000_kernel_stats.csv", "pp_10000000_kernel_stats.csv", "pp_small_kernel_stats.csv"):
     cp("%s_%s" % (tag, name), "%s_%s" % (pre, name))
-cp("crud_ab.json", pre + "_crud_ab.json")
+if not os.path.exists(os.path.join(src, tag + "_crud_ab.json")):
+    cp("crud_ab.json", pre + "_crud_ab.json")
 for f in glob.glob(os.path.join(src, tag + "_prof", "*kernel_stats.csv")):
     shutil.copyfile(f, os.path.join(dst, pre + "_kernel_stats.csv")); print("profiles/%s_kernel_stats.csv" % pre)
 for f in glob.glob(os.path.join(src, tag + "_prof_churn", "*kernel_stats.csv")):
