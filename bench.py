@@ -7,8 +7,10 @@ A "step" is one whole-table pass of the placement solver (every row of the table
   N = 1   BASELINE.json config 3 (the configuration the metric is quoted on): 10 M objects x 1 024 nodes, Zipf(1.1) loads.
           value = a pipelined stream of COMMITTED ticks (rio_gp_tick_async: k_scan + k_resolve (+ fix-up) + commit), starting
           from the cold table.  The same line carries the un-committed cold re-solves (round 2's headline, named as such), the
-          synchronous dependent tick, config 2, config 4 on one GPU and the config-5 churn stream (synchronous + pipelined,
-          per-kernel spans, parity of the whole 110-tick stream against the oracle chain).
+          synchronous dependent tick, config 2, config 4 on one GPU, the config-5 churn stream (synchronous + pipelined,
+          per-kernel spans, parity of the whole 110-tick stream against the oracle chain) and — the headline ticks never cut or
+          spill — the solve in which CAPACITY BINDS: `config3_contended` (0.72 x the capacities) and `config3_skew` (Lomax(1.1)
+          affinities), one committed cold solve per step, parity at 10 M rows in the run (binding_record).
   N > 1   BASELINE.json config 4 as north_star states it: ONE table of 100 M objects x 4 096 nodes, rows sharded over
           the N ranks (12.5 M rows per GPU at N = 8), "scaling": "strong"; the weak-scaled config 3 (10 M rows per
           GPU of one N x 10 M-row table) is measured in the same run and reported under "weak_config3".  value = a stream
@@ -28,7 +30,9 @@ A "step" is one whole-table pass of the placement solver (every row of the table
                  cur+load+aff, write assign) / its per-launch HIP-event time, on the cold table; `traffic` = HBM bytes per
                  launch from rocprofv3 PMC passes run by this script; frac_dram_bound / frac_committed_tick /
                  frac_dependent_tick = the same ratio for the whole step beyond the Infinity Cache and for whole ticks
-  cpu_baseline = the CPU oracle port of the reference's per-object path, on a bounded sample
+  cpu_baseline = the CPU oracle port of the reference's per-object path, on a bounded sample: 1 thread, and as many threads as
+                 the process may use CPUs (the cgroup's quota: 16 on this pool, where 256 hardware threads are visible); `value`
+                 is the faster of the two, both are in the record
 """
 import argparse
 import json
