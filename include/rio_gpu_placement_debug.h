@@ -25,7 +25,9 @@ extern "C" {
  * is used and the `used` vector is valid (default) | 2 = never (k_scan<COMPACT>).
  * + (ca << 9): the whole-table fix-up by k_cut_apply + k_cut_settle (the exact cuts and the re-marking in one pass over the wave
  * ranges that have work) — 0 = when the solve packs at the cut pass (default) | 1 = always | 2 = never: k_cut_find, then the
- * re-marking pass inside round 0 of k_fill (two passes: round 5's form). */
+ * re-marking pass inside round 0 of k_fill (two passes: round 5's form).
+ * + 2048: the k_resolve of a quiet asynchronous tick (rio_gp_tick_async on a table nothing has changed in: k_scan + k_resolve,
+ * no fix-up) stays on the main stream; by default it runs on a stream of its own beside the next tick's k_scan. */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 /* speculative enqueue of the fix-up behind k_resolve, without waiting for the verdict: 0 (default) = when the previous
  * solve needed it | 1 = always | 2 = never. */

@@ -5102,7 +5102,8 @@ static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, cons
     Plan pp = p;
     pp.alive_dst = nt.alive_src ? const_cast<u32*>(nt.alive_bits) : nullptr;
     const u32* abits = nt.alive_src ? nt.alive_src : nt.alive_bits;
-    if (e0 && e1)  // start/stop events taken from the dispatch packet itself: the kernel's own duration
+    if (e0 || e1)  // start / stop events taken from the dispatch packet itself: the kernel's own duration, or (stop event alone) the
+                   // completion another stream waits for, without a marker packet behind the kernel
         hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
                               t.cur, t.load, t.aff, t.next, abits, pp, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
                               b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);

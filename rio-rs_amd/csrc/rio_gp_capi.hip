@@ -206,6 +206,20 @@ struct rio_gp {
     Plan vplan{};               // the plan of the packed table the fix-up of the solve in flight runs over
     int cutpack_mode = 0;  // the same for packing at the cut pass of whole-table solves (bits 5-6 of rio_gp_debug_set_compact)
     bool ca_now = false;   // the whole-table fix-up of the solve being enqueued is k_cut_apply (set by the caller of enqueue_scan_resolve)
+    // Quiet ticks overlap (round 6): a tick that cannot need the fix-up is k_scan + k_resolve, and the NEXT tick's scan reads
+    // nothing this tick's k_resolve writes — so k_resolve runs on a stream of its own, behind an event of its scan, while the
+    // next scan already streams (H / blkstat alternate between two buffers).  Every other entry point first makes the main
+    // stream wait for the last such k_resolve (side_join, in the Locked guard every entry takes).
+    // The main stream carries nothing but the scans: each scan's completion IS its event (hipExtLaunchKernel's stop event: no
+    // marker packet behind it), and the histograms rotate through a ring of buffers as long as the ticks' ring, so a scan never
+    // has to wait for the k_resolve that read its buffer last (checked on the host; a wait is enqueued only if it is not done).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_scan[kRing] = {}, ev_res[kRing] = {};
+    bool ev_res_valid[kRing] = {};
+    bool side_pending = false;
+    u32 side_last = 0, ov_count = 0, ov_bufs = 0;
+    u64* H_ring[kRing] = {}; u64* blk_ring[kRing] = {};
+    int overlap_mode = 0;  // 0 on | 2 never (lab builds: bit 11 of rio_gp_debug_set_compact)
     int cutapply_mode = 0; // whole-table fix-up by k_cut_apply (cuts + re-marking in one pass): 0 when the solve packs at the cut pass
                            // | 1 always | 2 never (k_cut_find + k_fill<APPLY>) (bits 9-10 of rio_gp_debug_set_compact)
     u64 last_fix_rows = 0;  // rows the previous solve sent to the water-fill (spill candidates + rejected claimants)
@@ -370,6 +384,21 @@ NodeTab scan_nodes(rio_gp* h) {
 }
 
 // the whole-table fix-up of the real table runs k_cut_apply (exact cuts + re-marking in one pass), not k_cut_find + k_fill<APPLY>
+// the main stream waits for the k_resolve of the last overlapped quiet tick (no-op when there is none in flight)
+void side_join(rio_gp* h) {
+    if (!h->side_pending) return;
+    (void)hipSetDevice(h->device);
+    if (hipStreamWaitEvent(h->stream, h->ev_res[h->side_last], 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->side);
+    }
+    h->side_pending = false;
+}
+// what every entry point holds: the handle's mutex, with the side stream joined (rio_gp_tick_async joins only when it must)
+struct Locked {
+    std::unique_lock<std::mutex> l;
+    explicit Locked(rio_gp* h, bool join = true) : l(h->mu) { if (join) side_join(h); }
+};
 bool use_cut_apply(rio_gp* h, u32 m) { return h->cutapply_mode != 2 && !h->sb.forced_bits && cut_apply_fits(m); }
 // ... which it is when the solve packs at the cut pass (few rows go on to the water-fill: the ranges with work are a fraction of
 // the table and k_cut_apply deals them out over the chip); a solve that re-marks most of the table keeps the two-pass form
@@ -425,7 +454,7 @@ void fold_used(rio_gp* h) {
 }
 // scan + resolve of one solve over the REAL table: the packed pending rows' cuts are searched inside k_resolve, the previous
 // committed solve's D rows are folded into the committed vector before k_resolve zeroes them
-void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool compact, u64* host_rows, int inc = 0) {
+void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool compact, u64* host_rows, int inc = 0, bool overlap = false) {
     h->sb.D = h->D;
     h->solve_used_D = h->sb.D != nullptr;
     h->inc_now = inc;
@@ -437,13 +466,28 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     SolveBufs rb = h->sb;
     h->ca_now = h->ca_now && !compact && !inc;
     if (h->ca_now) { rb.R = nullptr; rb.RP = nullptr; rb.Tg = h->Tg; }
+    hipStream_t rs = h->stream;  // where k_resolve goes
+    u32 par = 0;
+    if (overlap) {  // (a quiet tick: plain k_scan, no fix-up behind it — the cuts' tables are not maintained)
+        par = h->ov_count++ % h->ov_bufs;
+        rb.R = nullptr; rb.RP = nullptr; rb.Tg = nullptr;
+        rb.H = h->H_ring[par]; rb.blkstat = h->blk_ring[par];
+        // this scan rewrites the histograms the k_resolve of ov_bufs ticks ago read: done long ago (the ring of ticks is harvested
+        // at least as often) — if the runtime does not say so, the main stream waits for it
+        if (h->ev_res_valid[par] && hipEventQuery(h->ev_res[par]) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamWaitEvent(h->stream, h->ev_res[par], 0);
+        }
+        rs = h->side;
+    }
     if (inc) {
         // (t.cur is read AND written: the tick is committed, nobody is promised the table as it was)
         launch_inc_scan(h->plan, h->assign[h->cur], h->load, h->aff, nt, h->sb, h->pk, h->stream);
         h->vplan = rebal_plan(h->plan);
         launch_rebal(h->plan, h->vplan, h->pk, nt, h->pk2, h->sb, h->stream);
     } else {
-        launch_scan(h->plan, t, nt, rb, false, h->all_alive, h->stream, nullptr, nullptr, compact ? &h->pk : nullptr);
+        launch_scan(h->plan, t, nt, rb, false, h->all_alive, h->stream, nullptr, overlap ? h->ev_scan[par] : nullptr,
+                    compact ? &h->pk : nullptr);
     }
     h->vplan.wcnt = compact ? pkx.wcnt : nullptr;
     // The exact cut search rides in k_resolve when a block's packed rows are few enough for a wave pair per node to stream
@@ -453,8 +497,15 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     h->searched = compact && h->plan.G && h->n / h->plan.G <= kSearchMaxBlockRows;
     Plan rp = h->vplan;
     if (!h->searched) rp.wcnt = nullptr;
-    launch_resolve(rp, nt, rb, host_rows, h->stream, nullptr, nullptr, h->searched ? &pkx : nullptr,
+    if (overlap) (void)hipStreamWaitEvent(rs, h->ev_scan[par], 0);  // (the scan's own stop event)
+    launch_resolve(rp, nt, rb, host_rows, rs, nullptr, nullptr, h->searched ? &pkx : nullptr,
                    h->used_parts ? h->used : nullptr, h->parts_rounds, inc ? h->used : nullptr);
+    if (overlap) {
+        (void)hipEventRecord(h->ev_res[par], rs);
+        h->ev_res_valid[par] = true;
+        h->side_pending = true;
+        h->side_last = par;
+    }
     h->used_parts = false;
 }
 // the fix-up over the rows the scan packed (compact): the water-fill writes every decision through the packed rows' indices
@@ -661,6 +712,7 @@ void peek_ticks(rio_gp* h) {
 
 int harvest_ticks(rio_gp* h) {
     if (!h->tick_n) return RIO_GP_OK;
+    side_join(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
     h->tick_peeked = 0;
@@ -697,6 +749,8 @@ int tick_async_locked(rio_gp* h) {
     // nothing has changed since a tick that left every object placed: this one keeps every row, no fix-up can be needed
     // (lab builds: rio_gp_debug_set_speculate(always) keeps the launches)
     const bool quiet = h->quiet_epoch == h->mut_epoch && h->spec_mode != 1;
+    const bool overlap = quiet && h->overlap_mode != 2 && h->side && h->stream == h->own_stream;
+    if (!overlap) side_join(h);
     InplaceGuard ipg{h};
     h->plan = hplan(h, h->n);
     const Table t = real_table(h);
@@ -710,7 +764,8 @@ int tick_async_locked(rio_gp* h) {
     h->tick_quiet[k] = quiet;
     h->tick_mark[k] = h->plan.mark = (1ull << 40) | ++h->wait_seq;  // column 7 of the verdict rows: peek_ticks knows them by it
     h->ca_now = cut_apply_for(h, false);
-    enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, inc_choice(h, compact, true));
+    enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, inc_choice(h, compact, true),
+                         overlap);
     if (quiet) {
         // (k_scan + k_resolve only)
     } else if (compact) {
@@ -838,6 +893,14 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         h->err = "stream/event creation failed";
         return bail(RIO_GP_EUPSTREAM);
     }
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->side = nullptr; }
+    for (int q = 0; q < kRing && h->side; ++q)
+        if (hipEventCreate(&h->ev_scan[q]) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_res[q], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamDestroy(h->side);
+            h->side = nullptr;  // (no overlap: everything else works)
+        }
     const size_t R = h->cap_rows, M = h->cap_nodes, W = (size_t)kMaxBlocks * kWaves;
     // the balanced pack columns (k_rebal) have uniform wave ranges: up to a tile per wave range more than the table; the
     // all-NONE column stands in for their `cur` column as well
@@ -847,6 +910,14 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->cap, M); A(h->used, M); A(h->alive_bits, (M + 31) / 32 + 4); A(h->dead_bits, (M + 31) / 32 + 4);
     A(h->alive_bytes, M);
     A(h->sb.H, (size_t)((M + 7) / 8) * kMaxBlocks * 16); A(h->sb.blkstat, (size_t)kMaxBlocks * 4);
+    {   // the histogram ring of overlapped quiet ticks: as many buffers as ticks may be in flight, within 256 MiB
+        const size_t hwords = (size_t)((M + 7) / 8) * kMaxBlocks * 16;
+        size_t nb = ((size_t)256 << 20) / (hwords * sizeof(u64));
+        nb = nb > (size_t)kRing ? (size_t)kRing : nb < 2 ? 2 : nb;
+        h->H_ring[0] = h->sb.H; h->blk_ring[0] = h->sb.blkstat;
+        for (size_t q = 1; q < nb; ++q) { A(h->H_ring[q], hwords); A(h->blk_ring[q], (size_t)kMaxBlocks * 4); }
+        h->ov_bufs = (u32)nb;
+    }
     A(h->sb.partial, (size_t)resolve_blocks((u32)M) * 8 + 8);
     A(h->sb.wsp_sum[0], W); A(h->sb.wsp_sum[1], W); A(h->sb.wsp_cnt[0], W); A(h->sb.wsp_cnt[1], W);
     A(h->sb.bsp_sum[0], (size_t)kMaxBlocks); A(h->sb.bsp_sum[1], (size_t)kMaxBlocks); A(h->sb.bsp_cnt[0], (size_t)kMaxBlocks); A(h->sb.bsp_cnt[1], (size_t)kMaxBlocks);
@@ -963,6 +1034,11 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->h_req) (void)hipHostFree(h->h_req);
     if (h->h_cs) (void)hipHostFree(h->h_cs);
     if (h->h_alive_ring) (void)hipHostFree(h->h_alive_ring);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    for (int q = 0; q < kRing; ++q) {
+        if (h->ev_scan[q]) (void)hipEventDestroy(h->ev_scan[q]);
+        if (h->ev_res[q]) (void)hipEventDestroy(h->ev_res[q]);
+    }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -973,7 +1049,7 @@ void rio_gp_destroy(rio_gp_t* h) {
 
 int rio_gp_set_flags(rio_gp_t* h, uint32_t flags) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     const uint32_t fixed = h->lifecycle ? RIO_GP_CFG_ROW_LIFECYCLE : 0u;
     if ((flags & ~RIO_GP_CFG_REF_SELF_ASSIGN) != fixed) return fail(h, RIO_GP_EINVAL, "rio_gp_set_flags: only RIO_GP_CFG_REF_SELF_ASSIGN may change");
     const u32 sa = (flags & RIO_GP_CFG_REF_SELF_ASSIGN) ? 1u : 0u;
@@ -984,7 +1060,7 @@ int rio_gp_set_flags(rio_gp_t* h, uint32_t flags) {
 
 int rio_gp_sync(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RIO_GP_OK;
 }
@@ -996,7 +1072,7 @@ uint32_t rio_gp_num_nodes(rio_gp_t* h) { return h ? h->m : 0; }
 
 int rio_gp_set_nodes(rio_gp_t* h, uint32_t m, const uint64_t* cap, const uint8_t* alive) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (m > h->cap_nodes) return fail(h, RIO_GP_EINVAL, "rio_gp_set_nodes: m exceeds max_nodes");
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<u64> c(m ? m : 1, RIO_GP_CAP_INF);
@@ -1040,7 +1116,7 @@ static int push_alive_bits(rio_gp* h) {
 
 int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive) {
     if (!h || !alive) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (m != h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive_all: m differs from the node table");
     HIPCHK(h, hipSetDevice(h->device));
     for (uint32_t j = 0; j < m; ++j) h->h_alive[j] = alive[j] ? 1 : 0;
@@ -1049,7 +1125,7 @@ int rio_gp_set_alive_all(rio_gp_t* h, uint32_t m, const uint8_t* alive) {
 
 int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (node >= h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_set_alive: node out of range");
     HIPCHK(h, hipSetDevice(h->device));
     h->h_alive[node] = alive ? 1 : 0;
@@ -1058,7 +1134,7 @@ int rio_gp_set_alive(rio_gp_t* h, uint32_t node, uint8_t alive) {
 
 int rio_gp_get_nodes(rio_gp_t* h, uint32_t m, uint64_t* cap, uint8_t* alive, uint64_t* used) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (m != h->m) return fail(h, RIO_GP_EINVAL, "rio_gp_get_nodes: m differs from the node table");
     HIPCHK(h, hipSetDevice(h->device));
     if (used) { int rc = ensure_used(h); if (rc) return rc; }
@@ -1073,7 +1149,7 @@ int rio_gp_get_nodes(rio_gp_t* h, uint32_t m, uint64_t* cap, uint8_t* alive, uin
 
 static int set_objects_impl(rio_gp_t* h, uint64_t n, const uint32_t* load, const uint32_t* aff, hipMemcpyKind kind) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (n > h->cap_obj) return fail(h, RIO_GP_EINVAL, "rio_gp_set_objects: n exceeds max_objects");
     HIPCHK(h, hipSetDevice(h->device));
     if (load) { if (n) HIPCHK(h, hipMemcpyAsync(h->load, load, n * sizeof(u32), kind, h->stream)); }
@@ -1098,7 +1174,7 @@ int rio_gp_set_objects_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_load, cons
 
 static int set_assign_impl(rio_gp_t* h, uint64_t n, const uint32_t* assign, hipMemcpyKind kind) {
     if (!h || !assign) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (n != h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_set_assign: n differs from the object table");
     if (kind == hipMemcpyHostToDevice)
         for (uint64_t i = 0; i < n; ++i)
@@ -1116,7 +1192,7 @@ int rio_gp_set_assign_dev(rio_gp_t* h, uint64_t n, const uint32_t* a) { return s
 
 int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out) {
     if (!h || !out) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (n != h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_get_assign: n differs from the object table");
     HIPCHK(h, hipSetDevice(h->device));
     if (n) HIPCHK(h, hipMemcpyAsync(out, h->assign[h->cur], n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
@@ -1125,7 +1201,7 @@ int rio_gp_get_assign(rio_gp_t* h, uint64_t n, uint32_t* out) {
 }
 int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out) {
     if (!h || !out) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (n != h->n || !h->have_solved) return fail(h, RIO_GP_EINVAL, "rio_gp_get_solved: no solve / size mismatch");
     HIPCHK(h, hipSetDevice(h->device));
     if (n) HIPCHK(h, hipMemcpyAsync(out, h->assign[h->cur ^ 1], n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
@@ -1134,7 +1210,7 @@ int rio_gp_get_solved(rio_gp_t* h, uint64_t n, uint32_t* out) {
 }
 int rio_gp_get_objects(rio_gp_t* h, uint64_t n, uint32_t* out_load, uint32_t* out_aff) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (n != h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_get_objects: n differs from the object table");
     HIPCHK(h, hipSetDevice(h->device));
     if (n && out_load) HIPCHK(h, hipMemcpyAsync(out_load, h->load, n * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
@@ -1144,7 +1220,7 @@ int rio_gp_get_objects(rio_gp_t* h, uint64_t n, uint32_t* out_load, uint32_t* ou
 }
 int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* load, const uint32_t* aff) {
     if (!h || (n && !idx)) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_set_object_attrs: object index out of range");
     if (!n || (!load && !aff)) return RIO_GP_OK;
@@ -1165,7 +1241,7 @@ int rio_gp_set_object_attrs(rio_gp_t* h, uint64_t n, const uint32_t* idx, const 
 
 int rio_gp_count_placed(rio_gp_t* h, uint64_t* out) {
     if (!h || !out) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = zero_stats(h);
     if (rc) return rc;
@@ -1177,7 +1253,7 @@ int rio_gp_count_placed(rio_gp_t* h, uint64_t* out) {
 
 int rio_gp_set_num_objects(rio_gp_t* h, uint64_t n) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (n > h->cap_obj) return fail(h, RIO_GP_EINVAL, "rio_gp_set_num_objects: n exceeds max_objects");
     // rows keep their contents: rows >= n simply take no part (and are rejected as indices) until n grows again — but a
     // placed row that drops out (or comes back) changes what `used` must count, so the vector is rebuilt before its next use
@@ -1195,7 +1271,7 @@ const uint32_t* rio_gp_solved_dev(rio_gp_t* h) { return h ? h->assign[h->cur ^ 1
 
 int rio_gp_lookup_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, uint32_t* d_out) {
     if (!h || (n && (!d_idx || !d_out))) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = zero_stats(h);
     if (rc) return rc;
@@ -1207,7 +1283,7 @@ int rio_gp_lookup_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, uint
 
 int rio_gp_lookup_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, uint32_t* out_node) {
     if (!h || (n && (!idx || !out_node))) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_lookup_batch: object index out of range");
     if (!n) return RIO_GP_OK;
@@ -1278,14 +1354,14 @@ static int update_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx, const
 
 int rio_gp_update_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_node) {
     if (!h || (n && (!d_idx || !d_node))) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     return update_dev_locked(h, n, d_idx, d_node);
 }
 
 int rio_gp_update_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* node) {
     if (!h || (n && (!idx || !node))) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n || (node[k] != RIO_GP_NONE && node[k] >= h->m))
             return fail(h, RIO_GP_EINVAL, "rio_gp_update_batch: index or node out of range");
@@ -1350,14 +1426,14 @@ static int remove_dev_locked(rio_gp* h, uint64_t n, const uint32_t* d_idx) {
 
 int rio_gp_remove_batch_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx) {
     if (!h || (n && !d_idx)) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     return remove_dev_locked(h, n, d_idx);
 }
 
 int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
     if (!h || (n && !idx)) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     for (uint64_t k = 0; k < n; ++k)
         if (idx[k] >= h->n) return fail(h, RIO_GP_EINVAL, "rio_gp_remove_batch: object index out of range");
     if (!n) return RIO_GP_OK;
@@ -1390,7 +1466,7 @@ int rio_gp_remove_batch(rio_gp_t* h, uint64_t n, const uint32_t* idx) {
 
 int rio_gp_clean_servers(rio_gp_t* h, const uint64_t* dead_bitmap, uint64_t* evicted) {
     if (!h || !dead_bitmap) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     // one launch + one wait: the kernel reads the bitmap from mapped pinned memory and its last workgroup writes the
     // evicted count back into it (no staging copy, no counter memset, no copy-back)
@@ -1432,7 +1508,7 @@ int rio_gp_clean_server(rio_gp_t* h, uint32_t node, uint64_t* evicted) {
     if (!h) return RIO_GP_EINVAL;
     u32 m;
     {
-        std::lock_guard<std::mutex> g(h->mu);
+        Locked g(h);
         m = h->m;
         if (node >= m) {  // an address nothing was ever placed on: retain() removes nothing (local.rs:56)
             if (evicted) *evicted = 0;
@@ -1720,7 +1796,7 @@ static int place_pending_host_locked(rio_gp* h, uint64_t n, const uint32_t* idx,
 int rio_gp_place_pending(rio_gp_t* h, uint64_t n, const uint32_t* idx, const uint32_t* requester,
                          uint32_t* out_node, uint32_t* out_flag) {
     if (!h || (n && (!idx || !requester || !out_node))) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (!n) return RIO_GP_OK;
     if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending: batch too large");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1739,7 +1815,7 @@ int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
     if ((nu && (!ops->update_idx || !ops->update_node)) || (nr && !ops->remove_idx) ||
         (nl && (!ops->lookup_idx || !ops->lookup_out)) || (np && (!ops->place_idx || !ops->place_requester || !ops->place_node)))
         return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (nu > (uint32_t)kSmallBatch || nr > (uint32_t)kSmallBatch || nl > (uint32_t)kSmallBatch || np > (uint32_t)kSmallBatch)
         return fail(h, RIO_GP_EINVAL, "rio_gp_mixed_batch: at most 256 entries of each kind");
     // every kind is validated before anything is enqueued; a kind with an invalid entry is skipped as a whole (its own call
@@ -1882,7 +1958,7 @@ int rio_gp_mixed_batch(rio_gp_t* h, rio_gp_mixed* ops) {
 int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, const uint32_t* d_requester,
                              uint32_t* d_out_node, uint32_t* d_out_flag) {
     if (!h || (n && (!d_idx || !d_requester || !d_out_node))) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (!n) return RIO_GP_OK;
     if (n > 0x7FFFF000ull) return fail(h, RIO_GP_EINVAL, "rio_gp_place_pending_dev: batch too large");
     // an empty table (or no nodes): every entry is out of range, and the one-workgroup kernel's "0 rows = the host has
@@ -1917,14 +1993,14 @@ int rio_gp_place_pending_dev(rio_gp_t* h, uint64_t n, const uint32_t* d_idx, con
 
 int rio_gp_solve(rio_gp_t* h, rio_gp_stats* stats) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     return solve_locked(h, stats);
 }
 
 int rio_gp_commit(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = commit_locked(h);
     if (rc) return rc;
@@ -1934,21 +2010,21 @@ int rio_gp_commit(rio_gp_t* h) {
 
 int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     return solve_locked(h, stats, true);
 }
 
 int rio_gp_tick_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h, false);  // (a quiet tick does not wait for the previous tick's k_resolve: tick_async_locked)
     HIPCHK(h, hipSetDevice(h->device));
     return tick_async_locked(h);
 }
 
 int rio_gp_tick_wait(rio_gp_t* h, rio_gp_stats* out, uint32_t cap, uint32_t* n_out) {
     if (!h || !n_out || (cap && !out)) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = harvest_ticks(h);
     if (rc) return rc;
@@ -1962,7 +2038,7 @@ int rio_gp_tick_wait(rio_gp_t* h, rio_gp_stats* out, uint32_t cap, uint32_t* n_o
 
 int rio_gp_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));  // a host with several handles (one per GPU) calls from any thread
     if (h->sh_tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_solve_async: row-sharded ticks are in flight (call rio_gp_shard_tick_wait)");
     // the verdict ring holds kRing solves: fold the oldest slot's verdict into the running count before it is overwritten
@@ -1991,7 +2067,7 @@ int rio_gp_solve_async(rio_gp_t* h) {
 
 int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
@@ -2021,7 +2097,7 @@ int rio_gp_solve_wait(rio_gp_t* h, rio_gp_stats* stats, uint32_t* n_slow) {
 
 int rio_gp_solve_profiled(rio_gp_t* h, float* scan_ms, float* resolve_ms) {
     if (!h || !scan_ms || !resolve_ms) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->ev2) { HIPCHK(h, hipEventCreate(&h->ev2)); HIPCHK(h, hipEventCreate(&h->ev3)); }
     reset_inplace(h);
@@ -2053,7 +2129,7 @@ static int p2p_check(rio_gp* h);
 
 int rio_gp_set_stream(rio_gp_t* h, void* hip_stream) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
@@ -2090,7 +2166,7 @@ static SolveBufs shard_bufs(rio_gp* h) {
 
 int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
     if (!h || !d_x) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sa) return fail(h, RIO_GP_EINVAL, "row-sharded solves do not implement RIO_GP_CFG_REF_SELF_ASSIGN (single-GPU handles only)");
     reset_inplace(h);
     h->plan = hplan(h, h->n);
@@ -2110,7 +2186,7 @@ int rio_gp_shard_scan(rio_gp_t* h, uint64_t* d_x) {
 
 int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uint64_t* d_xg, void* on_stream) {
     if (!h || !d_xg || n_ranks == 0 || rank >= n_ranks) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sh_state != 1) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_resolve: call rio_gp_shard_scan first");
     h->sh_rank = rank;
     h->sh_R = n_ranks;
@@ -2127,7 +2203,7 @@ int rio_gp_shard_resolve(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const uin
 
 int rio_gp_shard_verdict(rio_gp_t* h, rio_gp_shard_info* out, uint32_t* n_slow) {
     if (!h || !out) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sh_state != 2) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_verdict: call rio_gp_shard_resolve first");
     HIPCHK(h, hipSetDevice(h->device));
     if (h->sh_side) HIPCHK(h, hipStreamSynchronize(h->sh_side));  // the exchange stream of a pipelined caller
@@ -2162,7 +2238,7 @@ int rio_gp_shard_verdict(rio_gp_t* h, rio_gp_shard_info* out, uint32_t* n_slow) 
 
 int rio_gp_shard_cut(rio_gp_t* h, int run_local_fixup, uint64_t* d_y) {
     if (!h || !d_y) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sh_state != 2 || !h->sh_slow) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_cut: no fix-up pending");
     HIPCHK(h, hipSetDevice(h->device));
     const SolveBufs b = shard_bufs(h);
@@ -2177,7 +2253,7 @@ int rio_gp_shard_cut(rio_gp_t* h, int run_local_fixup, uint64_t* d_y) {
 
 int rio_gp_shard_merge(rio_gp_t* h, const uint64_t* d_yg, uint64_t* pending_rows, uint64_t* pending_load) {
     if (!h || !d_yg) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sh_state != 3 && h->sh_state != 5) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_merge: nothing exported");
     HIPCHK(h, hipSetDevice(h->device));
     launch_shard_import_delta(h->plan, shard_bufs(h), reinterpret_cast<const u64*>(d_yg), h->sh_rank, h->sh_R,
@@ -2193,7 +2269,7 @@ int rio_gp_shard_merge(rio_gp_t* h, const uint64_t* d_yg, uint64_t* pending_rows
 
 int rio_gp_shard_spill(rio_gp_t* h, uint32_t round, int last, uint64_t* d_y) {
     if (!h || !d_y) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sh_state != 4) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_spill: call rio_gp_shard_merge first");
     HIPCHK(h, hipSetDevice(h->device));
     const SolveBufs b = shard_bufs(h);
@@ -2205,7 +2281,7 @@ int rio_gp_shard_spill(rio_gp_t* h, uint32_t round, int last, uint64_t* d_y) {
 
 int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sh_state != 2 && h->sh_state != 4)
         return fail(h, RIO_GP_EINVAL, "rio_gp_shard_finish: solve not resolved / last exchange not merged");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2239,7 +2315,7 @@ int rio_gp_shard_finish(rio_gp_t* h, rio_gp_stats* local_stats) {
 
 int rio_gp_shard_p2p_export(rio_gp_t* h, uint32_t n_ranks, void* out_handle64) {
     if (!h || !out_handle64 || n_ranks == 0 || n_ranks > 32) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->p2p) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_p2p_export: window already exported");
     HIPCHK(h, hipSetDevice(h->device));
     P2P* q = new P2P();
@@ -2272,7 +2348,7 @@ int rio_gp_shard_p2p_export(rio_gp_t* h, uint32_t n_ranks, void* out_handle64) {
 
 int rio_gp_shard_p2p_connect(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const void* handles) {
     if (!h || !handles || n_ranks == 0 || rank >= n_ranks) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     P2P* q = h->p2p;
     if (!q || q->R != n_ranks || q->d_peers) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_p2p_connect: export first / rank count differs");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2332,7 +2408,7 @@ int rio_gp_shard_p2p_ready(rio_gp_t* h) { return h && h->p2p && h->p2p->d_peers 
 
 int rio_gp_shard_p2p_close(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipGetLastError();
@@ -2388,7 +2464,7 @@ int rio_gp_shard_comm_unique_id(void* out128, const char* rccl_path) {
 
 int rio_gp_shard_comm_init(rio_gp_t* h, uint32_t rank, uint32_t n_ranks, const void* id128, const char* rccl_path) {
     if (!h || !id128 || n_ranks == 0 || rank >= n_ranks) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sc) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_comm_init: communicator already set up");
     HIPCHK(h, hipSetDevice(h->device));
     ShardComm* sc = new ShardComm();
@@ -2424,7 +2500,7 @@ uint32_t rio_gp_shard_comm_ranks(rio_gp_t* h) { return h && h->sc ? h->sc->R : 0
 // Back-to-back calls overlap solve k's exchange with solve k+1's scan.
 int rio_gp_shard_solve_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sa) return fail(h, RIO_GP_EINVAL, "row-sharded solves do not implement RIO_GP_CFG_REF_SELF_ASSIGN (single-GPU handles only)");
     if (h->sh_tick_n) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_solve_async: row-sharded ticks are in flight (call rio_gp_shard_tick_wait)");
     if (h->p2p && h->p2p->d_peers) {
@@ -2516,7 +2592,7 @@ static void shard_exchange_y(rio_gp* h, const SolveBufs& b, const u64* base, int
 
 int rio_gp_shard_tick_async(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->sa) return fail(h, RIO_GP_EINVAL, "row-sharded solves do not implement RIO_GP_CFG_REF_SELF_ASSIGN (single-GPU handles only)");
     P2P* q = h->p2p;
     if (!q || !q->d_peers) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_tick_async: peer-to-peer windows only (rio_gp_shard_p2p_connect first)");
@@ -2574,7 +2650,7 @@ int rio_gp_shard_tick_async(rio_gp_t* h) {
 
 int rio_gp_shard_tick_wait(rio_gp_t* h, rio_gp_shard_tick_info* out, uint32_t cap, uint32_t* n_out) {
     if (!h || !n_out || (cap && !out)) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     *n_out = 0;
     if (!h->sh_tick_n) return RIO_GP_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -2617,7 +2693,7 @@ int rio_gp_shard_tick_wait(rio_gp_t* h, rio_gp_shard_tick_info* out, uint32_t ca
 // all-gather of `words` u64 per rank on the handle's stream (the Y records of the fix-up path, counters)
 int rio_gp_shard_exchange(rio_gp_t* h, const uint64_t* d_in, uint64_t* d_out, uint64_t words) {
     if (!h || !d_in || !d_out) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (h->p2p && h->p2p->d_peers) {
         P2P* q = h->p2p;
         if (words > q->W) return fail(h, RIO_GP_EINVAL, "rio_gp_shard_exchange: record larger than the window row");
@@ -2649,8 +2725,8 @@ uint64_t rio_gp_debug_wave_row_lo(uint64_t n_objects, uint32_t n_nodes, uint32_t
 }
 
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
-    if (!h || mode < 0 || mode >= 2048 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
-    std::lock_guard<std::mutex> g(h->mu);
+    if (!h || mode < 0 || mode >= 4096 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
+    Locked g(h);
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
     h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
     h->compact_mode = mode & 15;
@@ -2658,19 +2734,20 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     if (h->inc_mode == 3) h->inc_mode = 0;
     h->cutapply_mode = (mode >> 9) & 3;  // bits 9-10: 0 = k_cut_apply when the solve packs at the cut pass | 1 = always | 2 = never
     if (h->cutapply_mode == 3) h->cutapply_mode = 0;
+    h->overlap_mode = (mode & 2048) ? 2 : 0;  // bit 11: quiet ticks do not overlap (k_resolve on the main stream, as before round 6)
     return RIO_GP_OK;
 }
 
 int rio_gp_debug_set_speculate(rio_gp_t* h, int speculate) {
     if (!h || speculate < 0 || speculate > 2) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     h->spec_mode = speculate;
     return RIO_GP_OK;
 }
 
 int rio_gp_debug_ktrace(rio_gp_t* h, int enable, int table, uint64_t* out2048) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (out2048 && ktrace_read(table, reinterpret_cast<u64*>(out2048)) != 0) return fail(h, RIO_GP_EUPSTREAM, "ktrace read failed");
@@ -2680,7 +2757,7 @@ int rio_gp_debug_ktrace(rio_gp_t* h, int enable, int table, uint64_t* out2048) {
 
 int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms) {
     if (!h || !ms || reps < 1) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipSetDevice(h->device));
     if (mode >= 20 && mode <= 23) {  // host round-trip probes: microseconds per call / 1000
         *ms = sync_probe(mode, reps, h->stream);
@@ -2698,7 +2775,7 @@ int rio_gp_debug_stream_probe(rio_gp_t* h, int mode, int reps, float* ms) {
 
 int rio_gp_timer_begin(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     h->timer_stopped = false;
     return RIO_GP_OK;
@@ -2706,7 +2783,7 @@ int rio_gp_timer_begin(rio_gp_t* h) {
 
 int rio_gp_timer_stop(rio_gp_t* h) {
     if (!h) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->timer_stopped = true;
     return RIO_GP_OK;
@@ -2714,7 +2791,7 @@ int rio_gp_timer_stop(rio_gp_t* h) {
 
 int rio_gp_timer_end(rio_gp_t* h, float* ms) {
     if (!h || !ms) return RIO_GP_EINVAL;
-    std::lock_guard<std::mutex> g(h->mu);
+    Locked g(h);
     if (!h->timer_stopped) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->timer_stopped = false;
     HIPCHK(h, hipEventSynchronize(h->ev1));

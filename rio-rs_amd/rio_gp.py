@@ -417,7 +417,7 @@ class GpuPlacement:
         self._chk(self._L.rio_gp_debug_ktrace(self._h, 1 if enable else 0, 0 if table is None else table, out))
         return np.ctypeslib.as_array(out).reshape(256, 8).copy() if table is not None else None
 
-    def set_compact(self, mode, partitioned_crud=True, cut_pack="auto", inc="auto", cut_apply="auto"):
+    def set_compact(self, mode, partitioned_crud=True, cut_pack="auto", inc="auto", cut_apply="auto", overlap=True):
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode).  partitioned_crud=False: big
         update / remove batches through the plain per-entry kernels (A/B runs, parity tests).  cut_pack: the same three
         modes for packing at the cut pass of whole-table solves (round 0 of k_fill packs).  inc: the in-place scan of
@@ -425,13 +425,14 @@ class GpuPlacement:
         fix-up's workgroups) — "auto": whenever the packed fix-up is used and `used` is valid | "never": k_scan<COMPACT>.
         cut_apply: whole-table fix-up — "auto": k_cut_apply + k_cut_settle (exact cuts + re-marking in one pass over the wave
         ranges that have work) when the solve packs at the cut pass | "always" | "never": k_cut_find, then the re-marking pass
-        inside round 0 of k_fill (round 5's form)."""
+        inside round 0 of k_fill (round 5's form).  overlap=False: the k_resolve of a quiet asynchronous tick stays on the main
+        stream (it runs beside the next tick's scan otherwise)."""
         self._need_lab()
         modes = {"auto": 0, "always": 1, "never": 2}
         incs = {"auto": 0, "always": 1, "never": 2}   # ("always" = "auto" since the size limit of the in-place tick went)
         self._chk(self._L.rio_gp_debug_set_compact(self._h, modes.get(mode, mode) | (0 if partitioned_crud else 16) |
                                                    (modes.get(cut_pack, cut_pack) << 5) | (incs.get(inc, inc) << 7) |
-                                                   (modes.get(cut_apply, cut_apply) << 9)))
+                                                   (modes.get(cut_apply, cut_apply) << 9) | (0 if overlap else 2048)))
 
     def set_speculate(self, speculate="auto"):
         """speculative enqueue of the fix-up behind k_resolve: auto | always | never (results identical in every mode)."""

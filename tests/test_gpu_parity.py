@@ -394,7 +394,7 @@ def test_invalid_arguments_are_unknown_errors(gp):
     g.close()
     # the lab build's knobs reject what they do not know (modes are 0 | 1 | 2 in every field)
     gl = gp.LabPlacement(10, 2)
-    for bad in (3, 3 << 5, 7, 1 << 11):
+    for bad in (3, 3 << 5, 7, 1 << 12):
         assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, bad) == gp.EINVAL
     assert gp.lab_lib().rio_gp_debug_set_speculate(gl.handle, 3) == gp.EINVAL
     assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, 2 | 16 | (1 << 5)) == 0   # never | plain CRUD | cut-pass packing always
@@ -779,9 +779,11 @@ def test_async_ticks_equal_the_synchronous_stream(gp, oracle):
     g.close()
 
 
-def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap):
     """A tick that took the fast path leaves every object placed: until an input of the solve changes, rio_gp_tick_async
-    enqueues k_scan + k_resolve only (no speculative fix-up).  Every kind of change must end that: liveness, removals,
+    enqueues k_scan + k_resolve only (no speculative fix-up) — and k_resolve on a stream of its own beside the next tick's scan
+    (overlap: the product library as it is; False: the lab build with that switched off).  Every kind of change must end that: liveness, removals,
     updates onto other nodes, new loads / affinities, a new table, clean_server, requests — the tick right behind each is
     compared with the oracle chain, with the verdicts of the earlier ticks given time to land (so the quiet rule is
     actually in force when the change arrives)."""
@@ -791,7 +793,9 @@ def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle):
     load, aff, cap = cfg["load"].copy(), cfg["aff"].copy(), cfg["cap"]
     ref = synth.warm_assign(n, m)
     alive = np.ones(m, np.uint8)
-    g = _mk(gp, n, m, load, aff, cap, alive, ref)
+    g = _mk(gp, n, m, load, aff, cap, alive, ref, lab=not overlap)
+    if not overlap:
+        g.set_compact("auto", overlap=False)
     rng = np.random.default_rng(99)
     want = []
 

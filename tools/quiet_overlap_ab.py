@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Quiet committed ticks of config 3 (nothing changes between ticks: k_scan + k_resolve per tick, no fix-up) with k_resolve on a
+stream of its own beside the next tick's scan (the product's way since round 6) and on the main stream (lab knob: overlap=False),
+alternating in ONE run; final table and `used` compared.  Usage: quiet_overlap_ab.py [ticks=200] [config=c3|c4]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np
+import rio_gp, synth
+ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+cfg = synth.config(sys.argv[2] if len(sys.argv) > 2 else "c3")
+n, m = cfg["n"], cfg["m"]
+out = {"n": n, "m": m, "ticks": ticks, "runs": []}
+final = {}
+for name, ov in (("overlap", True), ("main stream", False), ("overlap#2", True), ("main stream#2", False)):
+    g = rio_gp.LabPlacement(n, m)
+    g.set_compact("auto", overlap=ov)
+    g.set_nodes(cfg["cap"], cfg["alive"])
+    g.set_objects(n, cfg["load"], cfg["aff"])
+    g.set_assign(cfg["cur"])
+    for _ in range(20):
+        g.tick_async()
+    g.tick_wait(); g.sync()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        g.tick_async()
+    t1 = time.perf_counter()
+    sts = g.tick_wait()
+    t2 = time.perf_counter()
+    us = (t2 - t0) / ticks * 1e6
+    out["runs"].append({"k_resolve": name, "us_per_tick": us, "host_enqueue_us_per_tick": (t1 - t0) / ticks * 1e6,
+                        "frac_of_8TBps": 16 * n / (us * 1e-6) / 8e12, "slow_path_ticks": sum(x["slow_path"] for x in sts)})
+    final[name] = (g.get_assign(), g.get_nodes()[2], sts[-1])
+    g.close()
+a0 = final["overlap"]
+out["equal"] = all(np.array_equal(a0[0], v[0]) and np.array_equal(a0[1], v[1]) and a0[2] == v[2] for v in final.values())
+print(json.dumps(out, indent=1))
