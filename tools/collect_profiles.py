@@ -18,7 +18,7 @@ for name in ("bench_n1.json", "bench_c5.json", "kernel_roofline.json", "kernel_r
              "pp_host_batches.txt", "c4_tick.json", "fuzz.json", "pp_sizes.json", "pp_sizes.txt", "pp_mid_timeline.txt",
              "c_host.json", "c_host_threads.json", "soak_sharded.json",
              # round 6: per-kernel durations of the window-partitioned batches and of the solves in which capacity binds, A/Bs, traces
-             "crud_ab.json", "crud_ab.log", "prof_crud.txt", "prof_binding.txt", "clean_ab.json", "pp_gather_trace.json",
+             "crud_ab.json", "crud_ab.log", "quiet_overlap_ab.json", "prof_crud.txt", "prof_binding.txt", "clean_ab.json", "pp_gather_trace.json",
              "binding_trace_contended.json", "c5_scan_variants.json", "binding_contended_kernel_stats.csv", "binding_skew_kernel_stats.csv",
              "crud_kernel_stats.csv", "pp_1000000_kernel_stats.csv", "pp_10000000_kernel_stats.csv", "pp_small_kernel_stats.csv"):
     cp("%s_%s" % (tag, name), "%s_%s" % (pre, name))

@@ -46,6 +46,7 @@ else
   bash tools/prof_crud.sh ${TAG} > $OUT/${TAG}_prof_crud.txt 2>&1        # per-kernel durations: CRUD 10 M, requests 1 M / 10 M, both chunk forms
   bash tools/prof_binding.sh ${TAG} > $OUT/${TAG}_prof_binding.txt 2>&1  # ... of the solves in which capacity binds (contended / skew)
   bash tools/clean_ab.sh ${TAG} > /dev/null 2>&1
+  timeout 200 python tools/quiet_overlap_ab.py 200 > $OUT/${TAG}_quiet_overlap_ab.json 2>&1   # quiet ticks: k_resolve beside the next scan | on the main stream
   timeout 150 python tools/pp_gather_trace.py 10000000 > $OUT/${TAG}_pp_gather_trace.json 2>&1
   timeout 200 python tools/binding_trace.py contended 6 > $OUT/${TAG}_binding_trace_contended.json 2>&1
   ( timeout 200 python tools/sync_probe.py; timeout 200 python tools/latency_probe.py | tail -1; timeout 200 python tools/latency_small_ops.py | tail -1; timeout 200 python tools/tick_rate_probe.py ) > $OUT/${TAG}_latency.txt 2>&1
@@ -64,6 +65,7 @@ else
   echo "---- ops"; tail -25 $OUT/${TAG}_ops.log
   echo "---- clean"; cat $OUT/${TAG}_clean.json
   echo "---- crud"; tail -9 $OUT/${TAG}_crud_ab.log; cat $OUT/${TAG}_prof_crud.txt; cat $OUT/${TAG}_prof_binding.txt | cut -c1-200
+  echo "---- quiet ticks"; grep -E "k_resolve|us_per_tick|equal" $OUT/${TAG}_quiet_overlap_ab.json
   echo "---- gather phases"; head -12 $OUT/${TAG}_pp_gather_trace.json
   echo "---- slow path"; for w in churn contended skew; do cut -c1-260 $OUT/${TAG}_slowpath_$w.json; done
   echo "---- churn variants"; cut -c1-1200 $OUT/${TAG}_c5_scan_variants.json
