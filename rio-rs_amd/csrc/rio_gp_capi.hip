@@ -749,7 +749,14 @@ int tick_async_locked(rio_gp* h) {
     // nothing has changed since a tick that left every object placed: this one keeps every row, no fix-up can be needed
     // (lab builds: rio_gp_debug_set_speculate(always) keeps the launches)
     const bool quiet = h->quiet_epoch == h->mut_epoch && h->spec_mode != 1;
-    const bool overlap = quiet && h->overlap_mode != 2 && h->side && h->stream == h->own_stream;
+    // ... where it pays: the scan long enough to hide the event's cost behind it (config 2's 6 us scan lost 3-8 us per tick to it)
+    // and a histogram ring as long as the ticks' ring (64 buffers within 256 MiB: up to 1 024 nodes), so that no scan ever waits
+    // for a resolve.  Config 4 on one GPU (4 096 nodes: 16 MB of histograms per tick) was measured both ways — 16 buffers: the
+    // host runs 64 ticks ahead and every scan waits for a resolve that is itself starved beside a scan; 64 buffers (1 GB): no
+    // waits, and still 330 against 313 us per tick: a k_resolve of 512 workgroups over 16 MB beside a DRAM-bound scan costs the
+    // scan more than it saves.
+    const bool overlap = quiet && h->overlap_mode != 2 && h->side && h->stream == h->own_stream &&
+                         h->n >= ((u64)1 << 22) && h->ov_bufs >= (u32)kRing;
     if (!overlap) side_join(h);
     InplaceGuard ipg{h};
     h->plan = hplan(h, h->n);
