@@ -275,7 +275,10 @@ int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats);
  * rio_gp_set_alive* pushed in between, in stream order).  rio_gp_tick_wait waits for all of them and hands out their
  * counters, oldest first: *n_out = ticks completed since the last wait, out[0..min(cap, *n_out)) = the most recent ones.
  * The tables are exactly what the same sequence of rio_gp_tick calls produces; only the counters arrive later.  (A
- * server that pushes a membership change and rebalances has no use for the counters before the next push.) */
+ * server that pushes a membership change and rebalances has no use for the counters before the next push.)
+ * On the handle's OWN stream a tick that cannot need the fix-up (nothing has changed since a tick that left every object
+ * placed) runs its resolve step on an internal second stream, beside the next tick's scan; every other call of the handle
+ * orders itself behind it.  On a caller's stream (rio_gp_set_stream) everything stays on that one stream. */
 int rio_gp_tick_async(rio_gp_t* h);
 int rio_gp_tick_wait(rio_gp_t* h, rio_gp_stats* out, uint32_t cap, uint32_t* n_out);
 /* Enqueue one solve on the handle's stream without waiting.  rio_gp_solve_wait drains the
