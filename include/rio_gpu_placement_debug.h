@@ -27,8 +27,15 @@ extern "C" {
  * ranges that have work) — 0 = when the solve packs at the cut pass (default) | 1 = always | 2 = never: k_cut_find, then the
  * re-marking pass inside round 0 of k_fill (two passes: round 5's form).
  * + 2048: the k_resolve of a quiet asynchronous tick (rio_gp_tick_async on a table nothing has changed in: k_scan + k_resolve,
- * no fix-up) stays on the main stream; by default it runs on a stream of its own beside the next tick's k_scan. */
+ * no fix-up) stays on the main stream; by default it runs on a stream of its own beside the next tick's k_scan.
+ * + 4096: the scans of such ticks are not CHAINED (every scan on the main stream, one launch after the other); by default they
+ * alternate between two streams and hand their rows over workgroup by workgroup (ScanChain, placement_kernels.h).
+ * Environment, read when a handle of the lab build is created: RIO_GP_OVERLAP_MIN_ROWS (the smallest table whose quiet ticks
+ * overlap / chain; 2^22 rows in the product), RIO_GP_CHAIN_TPI (1 | 2 tiles per wave-iteration of the chained scan),
+ * RIO_GP_CHAIN_DIAG (timing experiments without the waits: NOT correct, tools/quiet_overlap_ab.py). */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
+/* chained scans enqueued by this handle so far (0: its quiet ticks have never met the conditions) */
+uint64_t rio_gp_debug_chained_scans(rio_gp_t* h);
 /* speculative enqueue of the fix-up behind k_resolve, without waiting for the verdict: 0 (default) = when the previous
  * solve needed it | 1 = always | 2 = never. */
 int rio_gp_debug_set_speculate(rio_gp_t* h, int speculate);

@@ -172,9 +172,23 @@ struct NodeTab {
     const u32* alive_src = nullptr;
 };
 
+// Chained quiet ticks (rio_gp_tick_async over a table nothing has changed in): the scans of consecutive ticks alternate between
+// two streams and hand their rows over workgroup by workgroup — workgroup b of tick k + 1 reads what workgroup b of tick k
+// wrote (and writes what it read), so it waits for THAT workgroup's flag instead of for the whole launch; the ramp-down of
+// one scan and the ramp-up of the next overlap.  flags[b] = `set` of the last chained scan whose workgroup b is through.
+struct ScanChain {
+    u32* flags;   // [kMaxBlocks], device memory
+    u32* err;     // one word of mapped host memory: raised when a wait gave up (the tables are then stale)
+    u32 wait;     // sequence number of the scan to wait for (0: none — the stream orders this scan behind what it depends on)
+    u32 set;      // this scan's sequence number
+};
+
+bool scan_chain_fits(u32 m);  // two workgroups of the chained scan per CU (what makes the in-kernel wait deadlock-free)
+
 // --- solve pipeline ---
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
-                 hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const PackOut* pack = nullptr);
+                 hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const PackOut* pack = nullptr,
+                 const ScanChain* chain = nullptr);
 // host_partial: pinned host rows [resolve_blocks(m)][8] = load_kept, load_claim_tot, n_cut, kept, evicted,
 // claimants, spillcand, present — the caller adds the rows up (no atomics / copy kernel on the stream).
 // search (with p.wcnt set): the packed pending rows — k_resolve also finds the exact cut rows (no k_cut_find launch).

@@ -243,6 +243,7 @@ __host__ __device__ __forceinline__ u32 pp_ans_cur(u32 w) {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // four consecutive words at any word address
+constexpr u64 kChainTimeoutTicks = 100000000ull;  // wall_clock64 runs at 100 MHz: 1 s, then ScanChain::err is raised
 constexpr u32 kStageCap = 320;  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
 
 // NT: non-temporal column streams for tables beyond the 256 MiB Infinity Cache (measured +1-2 % at 40-100 M rows and
@@ -255,6 +256,25 @@ __device__ __forceinline__ uint4 ld4(const u32* p) {
     }
     return *reinterpret_cast<const uint4*>(p);
 }
+// CHAIN (chained quiet ticks, k_scan): a workgroup's rows of the assignment columns are handed from one LAUNCH to the next
+// while both run, to whatever CU and XCD the next tick's workgroup sits on.  Both sides go through to the fabric: 16-byte
+// `sc0 sc1` stores (same cost as plain ones; the 8-byte agent atomics the compiler would pick cost 2.7x per byte) and
+// `sc0 sc1` loads (never served by a vector L1 or by another XCD's stale line) — buffer instructions, because they are the
+// 16-byte accesses that take a cache policy from C++ and are counted in vmcnt by the compiler like any other.
+typedef u32 u32x4b __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc0Sc1 = 17;  // cache policy operand of the raw buffer builtins on gfx940+: sc0 = 1, nt = 2, sc1 = 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t col_rsrc(const u32* col) {  // raw buffer over a whole column: byte offsets, no bound
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(col), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ uint4 ld4_fabric(__amdgpu_buffer_rsrc_t r, u64 row) {
+    const u32x4b v = __builtin_amdgcn_raw_buffer_load_b128(r, (u32)(row * 4u), 0, kAuxSc0Sc1);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_fabric(__amdgpu_buffer_rsrc_t r, u64 row, const uint4 v) {
+    u32x4b x;
+    x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (u32)(row * 4u), 0, kAuxSc0Sc1);
+}
 template <bool NT>
 __device__ __forceinline__ void st4(u32* p, const uint4 v) {
     if (NT) {
@@ -266,13 +286,14 @@ __device__ __forceinline__ void st4(u32* p, const uint4 v) {
     }
 }
 
-template <bool VIRT, bool ALLALIVE, bool CHECK, int COMPACT = 0, bool NT = false>
+template <bool VIRT, bool ALLALIVE, bool CHECK, int COMPACT = 0, bool NT = false, bool CHAIN = false>
 __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const uint4 lv, const u64 i0, const u64 wend,
                                           const u32 m, const u32* alv, u64* hist, u32* __restrict__ next,
                                           u64& sp_sum, u32& sp_cnt, u32& kept_cnt, u32& evict_cnt, u32& claim_cnt,
                                           const PackOut* pk = nullptr, u64* pk_pos = nullptr, u32* stage = nullptr,
                                           u32* st_head = nullptr, u32* st_fill = nullptr,
-                                          const uint4 xv = make_uint4(0, 0, 0, 0), const u32 sa = 0) {
+                                          const uint4 xv = make_uint4(0, 0, 0, 0), const u32 sa = 0,
+                                          const __amdgpu_buffer_rsrc_t* nrs = nullptr) {
     // COMPACT == 3 (virtual table of a big place_pending batch): rows are requests, xv = the objects they ask for; a claimant's
     // optimistic node also goes straight into the REAL assignment column, pk->next[object] (one scattered store per first touch:
     // the fix-up patches the same rows through the same indices, so no pass carries the decisions back afterwards) — unless
@@ -369,7 +390,12 @@ __device__ __forceinline__ void scan_tile(const uint4 cv, const uint4 av, const 
         sp_cnt += c;
     }
     if (!CHECK || i0 + 3 < wend) {
-        st4<NT>(next + i0, ov);
+        if (CHAIN) st4_fabric(*nrs, i0, ov);
+        else st4<NT>(next + i0, ov);
+    } else if (CHAIN) {  // (the ragged last tile of the table: single words, agent scope)
+        if (i0 + 0 < wend) __hip_atomic_store(next + i0 + 0, ov.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i0 + 1 < wend) __hip_atomic_store(next + i0 + 1, ov.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i0 + 2 < wend) __hip_atomic_store(next + i0 + 2, ov.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         if (i0 + 0 < wend) next[i0 + 0] = ov.x;
         if (i0 + 1 < wend) next[i0 + 1] = ov.y;
@@ -382,14 +408,14 @@ __host__ __device__ __forceinline__ size_t h_line(u32 g, u32 b, u32 G) { return 
 
 // TPI = tiles (of 256 rows) a wave processes per loop iteration; the next TPI tiles are always in
 // flight while the current ones are processed.
-template <bool VIRT, bool ALLALIVE, int TPI, int COMPACT = 0, bool NT = false>
-__global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, const u32* __restrict__ load,
+template <bool VIRT, bool ALLALIVE, int TPI, int COMPACT = 0, bool NT = false, bool CHAIN = false>
+__global__ __launch_bounds__(kBlock, CHAIN ? 8 : 1) void k_scan(const u32* __restrict__ cur, const u32* __restrict__ load,
                                                  const u32* __restrict__ aff, u32* __restrict__ next,
                                                  const u32* __restrict__ alive_bits, Plan p, u64* __restrict__ H,
                                                  u64* __restrict__ blkstat, u64* __restrict__ wsp_sum,
                                                  u32* __restrict__ wsp_cnt, DevStats* __restrict__ stats, PackOut pko,
                                                  FxRows fx, u64* __restrict__ bsp_sum, u32* __restrict__ bsp_cnt,
-                                                 u64* __restrict__ R, u64* __restrict__ RP) {
+                                                 u64* __restrict__ R, u64* __restrict__ RP, ScanChain ch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m = p.m;
     u32* bst = reinterpret_cast<u32*>(smem);                 // [4] (first 128 B: small scratch, G17)
@@ -418,11 +444,12 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     const u32* const csrc = vrec ? pko.aff : cur;
     const u32* const lsrc = vrec ? pko.aff + 4 : load;
     const int vsh = vrec ? 1 : 0;  // (records: 2 words per row)
+    const __amdgpu_buffer_rsrc_t crs = col_rsrc(cur), nrs = col_rsrc(next);  // (CHAIN only: the two assignment columns through the fabric)
     if (it < wgrp) {
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u64 i = it + (u64)q * kTile + (u64)lane * 4;
-            cv[q] = ld4<NT>(csrc + (i << vsh));
+            if (!CHAIN) cv[q] = ld4<NT>(csrc + (i << vsh));  // (CHAIN: the previous tick's workgroup may still be writing them)
             av[q] = ld4<NT>(aff + i);
             lv[q] = ld4<NT>(lsrc + (i << vsh));
             if (COMPACT == 3) xv[q] = ld4<NT>(pko.idx + i);
@@ -463,7 +490,27 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         stats->local_fixup = 0;
         stats->global_slow = 0;
     }
+    if (CHAIN && tid == 0 && ch.wait) {
+        // Chained quiet ticks: this workgroup's rows of `cur` are what workgroup blockIdx.x of the previous tick's scan wrote
+        // (the same plan), and its rows of `next` are what that workgroup read — it may still be running, on the other scan
+        // stream.  Wait for ITS flag, not for its launch.  (It is resident or finished: a launch of the chain is dispatched
+        // only after the launch two ticks back has completed, so every slot this launch's workgroups hold was vacated by a
+        // workgroup of the previous tick's launch or is one that launch never needed.)
+        const u64 t0 = wall_clock64();
+        u32 tries = 0;
+        while ((int)(__hip_atomic_load(ch.flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.wait) < 0) {
+            if ((++tries & 15u) == 0 && wall_clock64() - t0 > kChainTimeoutTicks) {  // never seen; must not hang the device if it is
+                __hip_atomic_store(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
     __syncthreads();
+    if (CHAIN && it < wgrp) {
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) cv[q] = ld4_fabric(crs, it + (u64)q * kTile + (u64)lane * 4);
+    }
 
     u64 sp_sum = 0;
     u32 sp_cnt = 0, kept_cnt = 0, evict_cnt = 0, claim_cnt = 0;  // kept/evict/claim are wave-uniform
@@ -482,7 +529,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
-            cn[q] = ld4<NT>(csrc + (i << vsh));
+            cn[q] = CHAIN ? ld4_fabric(crs, i) : ld4<NT>(csrc + (i << vsh));
             an[q] = ld4<NT>(aff + i);
             ln[q] = ld4<NT>(lsrc + (i << vsh));
             if (COMPACT == 3) xn[q] = ld4<NT>(pko.idx + i);
@@ -490,10 +537,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             if (COMPACT == 3) unrec(cv[q], lv[q], it + (u64)q * kTile + (u64)lane * 4);
-            scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
+            scan_tile<VIRT, ALLALIVE, false, COMPACT, NT, CHAIN>(cv[q], av[q], lv[q], it + (u64)q * kTile + (u64)lane * 4, wend,
                                                           m, alv, hist, next, sp_sum, sp_cnt, kept_cnt, evict_cnt,
                                                           claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill,
-                                                          COMPACT == 3 ? xv[q] : make_uint4(0, 0, 0, 0), p.sa);
+                                                          COMPACT == 3 ? xv[q] : make_uint4(0, 0, 0, 0), p.sa, &nrs);
         }
         it = nit;
 #pragma unroll
@@ -501,17 +548,17 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     }
     for (; it < wend; it += kTile) {  // leftover full tiles (< TPI) and the ragged last tile of the table
         const u64 i = it + (u64)lane * 4;
-        uint4 c1 = *reinterpret_cast<const uint4*>(csrc + (i << vsh));
+        uint4 c1 = CHAIN ? ld4_fabric(crs, i) : *reinterpret_cast<const uint4*>(csrc + (i << vsh));
         const uint4 a1 = *reinterpret_cast<const uint4*>(aff + i);
         uint4 l1 = *reinterpret_cast<const uint4*>(lsrc + (i << vsh));
         const uint4 x1 = COMPACT == 3 ? *reinterpret_cast<const uint4*>(pko.idx + i) : make_uint4(0, 0, 0, 0);
         if (COMPACT == 3) unrec(c1, l1, i);
         if (it < wfull)
-            scan_tile<VIRT, ALLALIVE, false, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                          evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1, p.sa);
+            scan_tile<VIRT, ALLALIVE, false, COMPACT, NT, CHAIN>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                                          evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1, p.sa, &nrs);
         else
-            scan_tile<VIRT, ALLALIVE, true, COMPACT, NT>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
-                                                         evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1, p.sa);
+            scan_tile<VIRT, ALLALIVE, true, COMPACT, NT, CHAIN>(c1, a1, l1, i, wend, m, alv, hist, next, sp_sum, sp_cnt, kept_cnt,
+                                                         evict_cnt, claim_cnt, &pko, &pk_pos, stage, &st_head, &st_fill, x1, p.sa, &nrs);
     }
     if (COMPACT == 2 && st_fill) {  // what is left in the ring (< 64 records)
         u32 x = st_head + (u32)lane;
@@ -527,6 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
     // per-wave spill-candidate totals (index-ordered prefix over wave ranges comes later)
     sp_sum = wave_sum(sp_sum);
     sp_cnt = wave_sum32(sp_cnt);
+    if (CHAIN) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's row stores (write-through) have landed
     if (lane == 0) {
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
@@ -538,6 +586,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(const u32* __restrict__ cur, co
         if (sp_sum) atomicAdd(&bsum, sp_sum);
     }
     __syncthreads();
+    if (CHAIN && tid == 0)  // this workgroup's rows are done, read and written (every wave has drained its stores in front of the
+                            // barrier, and they went through to the fabric): the next tick's workgroup blockIdx.x may go
+        __hip_atomic_store(ch.flags + blockIdx.x, ch.set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) { bsp_sum[blockIdx.x] = bsum; bsp_cnt[blockIdx.x] = bst[3]; }
     // this block's sums, node-group major: line (g, b) = {kept of nodes 8g..8g+7 | their claim loads} — 16 consecutive
     // threads store one 128-byte line, so k_resolve's workgroup g reads G contiguous lines and nothing else
@@ -5094,9 +5145,10 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
     return (unsigned)g;
 }
 
-template <bool VIRT, bool AA, int TPI, int COMPACT = 0, bool NT = false>
+template <bool VIRT, bool AA, int TPI, int COMPACT = 0, bool NT = false, bool CHAIN = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
-                          hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr) {
+                          hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr, const ScanChain* chain = nullptr) {
+    const ScanChain ch = chain ? *chain : ScanChain{nullptr, nullptr, 0, 0};
     const size_t lds = scan_lds_bytes(p.m) + (COMPACT == 2 ? (size_t)kWaves * 4 * kStageCap * sizeof(u32) : 0);
     const PackOut pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     Plan pp = p;
@@ -5104,13 +5156,13 @@ static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, cons
     const u32* abits = nt.alive_src ? nt.alive_src : nt.alive_bits;
     if (e0 || e1)  // start / stop events taken from the dispatch packet itself: the kernel's own duration, or (stop event alone) the
                    // completion another stream waits for, without a marker packet behind the kernel
-        hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
+        hipExtLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT, CHAIN>), dim3(p.G), dim3(kBlock), (uint32_t)lds, s, e0, e1, 0,
                               t.cur, t.load, t.aff, t.next, abits, pp, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0],
-                              b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP);
+                              b.stats, pko, b.fx, b.bsp_sum[0], b.bsp_cnt[0], b.R, b.RP, ch);
     else
-        hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
+        hipLaunchKernelGGL((k_scan<VIRT, AA, TPI, COMPACT, NT, CHAIN>), dim3(p.G), dim3(kBlock), lds, s, t.cur, t.load, t.aff,
                            t.next, abits, pp, b.H, b.blkstat, b.wsp_sum[0], b.wsp_cnt[0], b.stats, pko, b.fx, b.bsp_sum[0],
-                           b.bsp_cnt[0], b.R, b.RP);
+                           b.bsp_cnt[0], b.R, b.RP, ch);
 }
 
 // Tiles per wave-iteration: 2 on the plain whole-table scan (measured +2.5 % over 1; 4 loses to its unpipelined tail),
@@ -5126,8 +5178,44 @@ void set_scan_nt(int mode) {
     g_inc_tpi = ((mode >> 5) & 3) == 1 ? 1 : ((mode >> 5) & 3) == 2 ? 4 : 2;
 }
 
+// Two launches of the chain are in flight at any time and the later one's workgroups WAIT, resident, for the earlier one's:
+// that cannot deadlock only if both fit the chip at once — two workgroups per CU (64 VGPRs: __launch_bounds__(kBlock, 8)).
+// Tiles per wave-iteration of the chained scan: 1 (measured, same run: 26.7-27.0 us per tick against 28.9-29.4 with 2, whose
+// 64-register form waits for a group's loads before it requests the next one)
+static int chain_tpi() {
+#ifdef RIO_GP_LAB
+    static const int v = [] { const char* e = getenv("RIO_GP_CHAIN_TPI"); return e && atoi(e) == 2 ? 2 : 1; }();
+    return v;
+#else
+    return 1;
+#endif
+}
+bool scan_chain_fits(u32 m) {
+    const size_t lds = scan_lds_bytes(m);
+    int nb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t e = hipSuccess;
+#define RIOGP_OCC(K, AA, TPI_, NT_) if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[K], k_scan<false, AA, TPI_, 0, NT_, true>, kBlock, lds)
+    RIOGP_OCC(0, true, 2, false); RIOGP_OCC(1, false, 2, false); RIOGP_OCC(2, true, 2, true); RIOGP_OCC(3, false, 2, true);
+    RIOGP_OCC(4, true, 1, false); RIOGP_OCC(5, false, 1, false); RIOGP_OCC(6, true, 1, true); RIOGP_OCC(7, false, 1, true);
+#undef RIOGP_OCC
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (int k = 0; k < 8; ++k) if (nb[k] < 2) return false;
+    return true;
+}
+
 void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, bool virt, bool all_alive,
-                 hipStream_t s, hipEvent_t e0, hipEvent_t e1, const PackOut* pack) {
+                 hipStream_t s, hipEvent_t e0, hipEvent_t e1, const PackOut* pack, const ScanChain* chain) {
+    if (chain && !pack && !virt) {  // a chained quiet tick: the plain whole-table scan, handed over workgroup by workgroup
+        const bool ntl = g_scan_nt_mode == 1 || (g_scan_nt_mode == 0 && p.n >= kScanNtRows);
+#define RIOGP_CH(TPI_) do { \
+            if (ntl) { if (all_alive) launch_scan_t<false, true, TPI_, 0, true, true>(p, t, nt, b, s, e0, e1, nullptr, chain); \
+                       else launch_scan_t<false, false, TPI_, 0, true, true>(p, t, nt, b, s, e0, e1, nullptr, chain); } \
+            else { if (all_alive) launch_scan_t<false, true, TPI_, 0, false, true>(p, t, nt, b, s, e0, e1, nullptr, chain); \
+                   else launch_scan_t<false, false, TPI_, 0, false, true>(p, t, nt, b, s, e0, e1, nullptr, chain); } } while (0)
+        if (chain_tpi() == 1) RIOGP_CH(1); else RIOGP_CH(2);
+#undef RIOGP_CH
+        return;
+    }
     if (pack && !virt) {  // k_scan that also packs the pending rows of every wave (adaptive fix-up, rio_gp_capi.hip)
         // through per-wave LDS rings when they fit next to the histograms (m up to ~4 800), straight from registers else
         const bool staged = g_scan_stage && scan_lds_bytes(p.m) + (size_t)kWaves * 4 * kStageCap * sizeof(u32) <= (size_t)160 * 1024;

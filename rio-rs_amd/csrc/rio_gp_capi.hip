@@ -220,6 +220,21 @@ struct rio_gp {
     u32 side_last = 0, ov_count = 0, ov_bufs = 0;
     u64* H_ring[kRing] = {}; u64* blk_ring[kRing] = {};
     int overlap_mode = 0;  // 0 on | 2 never (lab builds: bit 11 of rio_gp_debug_set_compact)
+    // ... and CHAIN (ScanChain, placement_kernels.h): the scans of a run of overlapped quiet ticks alternate between the main
+    // stream and `scan2` and hand their rows over workgroup by workgroup (a flag per workgroup), so the ramp-down of one scan and
+    // the ramp-up of the next overlap.  A run starts on the main stream (which orders it behind everything else) and ends with
+    // the first side_join: the last k_resolve waits for the last scan, and that scan's workgroups have waited for every earlier one.
+    hipStream_t scan2 = nullptr;
+    u32* chain_flags = nullptr;                       // [kMaxBlocks]
+    u32 *h_chain_err = nullptr, *d_chain_err = nullptr;  // mapped host word: a chained wait gave up
+    u32 chain_seq = 0, chain_prev = 0, chain_pos = 0;  // last sequence number handed out | the run's last scan (0: no run) | its length
+    hipEvent_t ev_run = nullptr;  // recorded on the main stream in front of a run's first scan: the run's first scan on `scan2` waits for
+                                  // it, so that nothing but the two scans of the chain competes for the chip while one of them waits
+    u64 overlap_min_rows = (u64)1 << 22;  // (lab builds, RIO_GP_OVERLAP_MIN_ROWS: the parity tests run the overlapped / chained ticks on small tables)
+    int chain_diag = 0;           // lab builds, RIO_GP_CHAIN_DIAG: 1 = the chained kernel on the main stream, no waits | 2 = alternating streams, no waits
+    bool chain_ok = false;        // two workgroups of the chained scan fit a CU (scan_chain_fits at the table's node count)
+    u64 chain_total = 0;   // chained scans enqueued so far (lab builds: rio_gp_debug_chained_scans)
+    int chain_mode = 0;    // 0 on | 2 never (lab builds: bit 12 of rio_gp_debug_set_compact)
     int cutapply_mode = 0; // whole-table fix-up by k_cut_apply (cuts + re-marking in one pass): 0 when the solve packs at the cut pass
                            // | 1 always | 2 never (k_cut_find + k_fill<APPLY>) (bits 9-10 of rio_gp_debug_set_compact)
     u64 last_fix_rows = 0;  // rows the previous solve sent to the water-fill (spill candidates + rejected claimants)
@@ -383,7 +398,20 @@ NodeTab scan_nodes(rio_gp* h) {
     return nt;
 }
 
-// the whole-table fix-up of the real table runs k_cut_apply (exact cuts + re-marking in one pass), not k_cut_find + k_fill<APPLY>
+// One run of chained scans per process at a time: the chain's progress argument counts the workgroup slots of ONE pair of
+// launches (two per CU); a second handle's pair on the same device could hold the slots the first one's earlier launch needs.
+std::atomic<rio_gp*> g_chain_owner{nullptr};
+bool chain_begin(rio_gp* h) {
+    if (h->chain_prev) return true;  // (a run in progress is this handle's)
+    rio_gp* none = nullptr;
+    return g_chain_owner.compare_exchange_strong(none, h, std::memory_order_acq_rel) || none == h;
+}
+void chain_end(rio_gp* h) {
+    h->chain_prev = 0;
+    h->chain_pos = 0;
+    rio_gp* me = h;
+    (void)g_chain_owner.compare_exchange_strong(me, nullptr, std::memory_order_acq_rel);
+}
 // the main stream waits for the k_resolve of the last overlapped quiet tick (no-op when there is none in flight)
 void side_join(rio_gp* h) {
     if (!h->side_pending) return;
@@ -393,6 +421,7 @@ void side_join(rio_gp* h) {
         (void)hipStreamSynchronize(h->side);
     }
     h->side_pending = false;
+    chain_end(h);  // (the run of chained scans ends here: the next one starts on the main stream, behind this wait)
 }
 // what every entry point holds: the handle's mutex, with the side stream joined (rio_gp_tick_async joins only when it must)
 struct Locked {
@@ -454,7 +483,8 @@ void fold_used(rio_gp* h) {
 }
 // scan + resolve of one solve over the REAL table: the packed pending rows' cuts are searched inside k_resolve, the previous
 // committed solve's D rows are folded into the committed vector before k_resolve zeroes them
-void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool compact, u64* host_rows, int inc = 0, bool overlap = false) {
+void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool compact, u64* host_rows, int inc = 0, bool overlap = false,
+                          bool chained = false) {
     h->sb.D = h->D;
     h->solve_used_D = h->sb.D != nullptr;
     h->inc_now = inc;
@@ -467,6 +497,21 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     h->ca_now = h->ca_now && !compact && !inc;
     if (h->ca_now) { rb.R = nullptr; rb.RP = nullptr; rb.Tg = h->Tg; }
     hipStream_t rs = h->stream;  // where k_resolve goes
+    hipStream_t ss = h->stream;  // where the scan goes
+    ScanChain ch{h->chain_flags, h->d_chain_err, 0, 0};
+    if (chained) {
+        if (!h->chain_prev) {
+            (void)hipEventRecord(h->ev_run, h->stream);
+        } else if ((h->chain_pos & 1u) && h->chain_diag != 1) {
+            ss = h->scan2;
+            if (h->chain_pos == 1) (void)hipStreamWaitEvent(ss, h->ev_run, 0);
+        }
+        ch.wait = h->chain_diag ? 0 : h->chain_prev;
+        ch.set = ++h->chain_seq;
+        ++h->chain_total;
+        h->chain_prev = ch.set;
+        ++h->chain_pos;
+    }
     u32 par = 0;
     if (overlap) {  // (a quiet tick: plain k_scan, no fix-up behind it — the cuts' tables are not maintained)
         par = h->ov_count++ % h->ov_bufs;
@@ -476,7 +521,7 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
         // at least as often) — if the runtime does not say so, the main stream waits for it
         if (h->ev_res_valid[par] && hipEventQuery(h->ev_res[par]) != hipSuccess) {
             (void)hipGetLastError();
-            (void)hipStreamWaitEvent(h->stream, h->ev_res[par], 0);
+            (void)hipStreamWaitEvent(ss, h->ev_res[par], 0);
         }
         rs = h->side;
     }
@@ -486,8 +531,8 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
         h->vplan = rebal_plan(h->plan);
         launch_rebal(h->plan, h->vplan, h->pk, nt, h->pk2, h->sb, h->stream);
     } else {
-        launch_scan(h->plan, t, nt, rb, false, h->all_alive, h->stream, nullptr, overlap ? h->ev_scan[par] : nullptr,
-                    compact ? &h->pk : nullptr);
+        launch_scan(h->plan, t, nt, rb, false, h->all_alive, ss, nullptr, overlap ? h->ev_scan[par] : nullptr,
+                    compact ? &h->pk : nullptr, chained ? &ch : nullptr);
     }
     h->vplan.wcnt = compact ? pkx.wcnt : nullptr;
     // The exact cut search rides in k_resolve when a block's packed rows are few enough for a wave pair per node to stream
@@ -715,6 +760,11 @@ int harvest_ticks(rio_gp* h) {
     side_join(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    if (h->h_chain_err && *reinterpret_cast<volatile u32*>(h->h_chain_err)) {  // never seen; must not pass silently if it happens
+        *h->h_chain_err = 0;
+        h->tick_n = 0;
+        return fail(h, RIO_GP_EUPSTREAM, "rio_gp_tick_wait: a chained scan gave up waiting for the previous tick's rows (tables are stale: reload them)");
+    }
     h->tick_peeked = 0;
     for (u32 k = 0; k < h->tick_n; ++k) {
         DevStats v = reduce_tick_slot(h, k, h->m);
@@ -756,7 +806,7 @@ int tick_async_locked(rio_gp* h) {
     // waits, and still 330 against 313 us per tick: a k_resolve of 512 workgroups over 16 MB beside a DRAM-bound scan costs the
     // scan more than it saves.
     const bool overlap = quiet && h->overlap_mode != 2 && h->side && h->stream == h->own_stream &&
-                         h->n >= ((u64)1 << 22) && h->ov_bufs >= (u32)kRing;
+                         h->n >= h->overlap_min_rows && h->ov_bufs >= (u32)kRing;
     if (!overlap) side_join(h);
     InplaceGuard ipg{h};
     h->plan = hplan(h, h->n);
@@ -771,8 +821,17 @@ int tick_async_locked(rio_gp* h) {
     h->tick_quiet[k] = quiet;
     h->tick_mark[k] = h->plan.mark = (1ull << 40) | ++h->wait_seq;  // column 7 of the verdict rows: peek_ticks knows them by it
     h->ca_now = cut_apply_for(h, false);
+    // (chained: only the scan's completion as its own event orders its k_resolve — and a pushed liveness bitmap rides in a scan
+    //  that nothing behind it may overtake: a quiet tick has none)
+    if (overlap && h->chain_seq >= 0x70000000u) {  // (sequence numbers compare by signed difference: start over long before they wrap)
+        side_join(h);
+        (void)hipMemsetAsync(h->chain_flags, 0, kMaxBlocks * sizeof(u32), h->stream);
+        h->chain_seq = 0;
+    }
+    const bool chained = overlap && h->chain_mode != 2 && h->scan2 && h->chain_ok && !nt.alive_src && chain_begin(h);
+    if (!chained && h->chain_prev) side_join(h);  // (cannot happen: what ends a run joins first; kept so that it could not pass silently)
     enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, inc_choice(h, compact, true),
-                         overlap);
+                         overlap, chained);
     if (quiet) {
         // (k_scan + k_resolve only)
     } else if (compact) {
@@ -908,6 +967,17 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
             (void)hipStreamDestroy(h->side);
             h->side = nullptr;  // (no overlap: everything else works)
         }
+    if (h->side && (hipStreamCreateWithFlags(&h->scan2, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_run, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipGetLastError();
+        if (h->scan2) (void)hipStreamDestroy(h->scan2);
+        h->scan2 = nullptr;  // (no chain: everything else works)
+    }
+    h->chain_ok = h->scan2 && scan_chain_fits((u32)h->cap_nodes);
+#ifdef RIO_GP_LAB
+    if (const char* e = getenv("RIO_GP_CHAIN_DIAG")) h->chain_diag = atoi(e);
+    if (const char* e = getenv("RIO_GP_OVERLAP_MIN_ROWS")) h->overlap_min_rows = strtoull(e, nullptr, 10);  // (timing experiments only: the waits are what makes the chain correct)
+#endif
     const size_t R = h->cap_rows, M = h->cap_nodes, W = (size_t)kMaxBlocks * kWaves;
     // the balanced pack columns (k_rebal) have uniform wave ranges: up to a tile per wave range more than the table; the
     // all-NONE column stands in for their `cur` column as well
@@ -934,6 +1004,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->pk.idx, R); A(h->pk.load, R); A(h->pk.aff, R); A(h->pk.next, R); A(h->pk.wcnt, W);
     A(h->pk2.idx, R2); A(h->pk2.load, R2); A(h->pk2.aff, R2); A(h->pk2.next, R2); A(h->pk2.wcnt, W);
     A(h->Tg, M * kWaves);
+    A(h->chain_flags, (size_t)kMaxBlocks);
     A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
 #undef A
@@ -943,6 +1014,12 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
         h->err = "hipHostMalloc failed";
         return bail(RIO_GP_ENOMEM);
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->h_chain_err), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_chain_err), h->h_chain_err, 0) != hipSuccess) {
+        h->err = "hipHostMalloc(chain error word) failed";
+        return bail(RIO_GP_ENOMEM);
+    }
+    memset(h->h_chain_err, 0, 64);
     h->slot_rows = resolve_blocks(h->cap_nodes);
     if (hipHostMalloc(reinterpret_cast<void**>(&h->h_slots), (size_t)2 * kRing * h->slot_rows * 8 * sizeof(u64),
                       hipHostMallocMapped) != hipSuccess ||
@@ -1013,6 +1090,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     (void)hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream);
     (void)hipMemsetAsync(h->D, 0, (size_t)kFillRounds * M * sizeof(u64), h->stream);
     (void)hipMemsetAsync(h->sb.R, 0, (size_t)kMaxBlocks * sizeof(u64), h->stream);
+    (void)hipMemsetAsync(h->chain_flags, 0, (size_t)kMaxBlocks * sizeof(u32), h->stream);
     if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
         h->err = "initial fill failed (no gfx950 code object loaded?)";
         return bail(RIO_GP_EUPSTREAM);
@@ -1034,6 +1112,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->vrec.p) (void)hipFree(h->vrec.p);
     if (h->part.p) (void)hipFree(h->part.p);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
+    if (h->h_chain_err) (void)hipHostFree(h->h_chain_err);
     if (h->h_slots) (void)hipHostFree(h->h_slots);
     if (h->h_fx) (void)hipHostFree(h->h_fx);
     if (h->h_small) (void)hipHostFree(h->h_small);
@@ -1041,6 +1120,9 @@ void rio_gp_destroy(rio_gp_t* h) {
     if (h->h_req) (void)hipHostFree(h->h_req);
     if (h->h_cs) (void)hipHostFree(h->h_cs);
     if (h->h_alive_ring) (void)hipHostFree(h->h_alive_ring);
+    chain_end(h);
+    if (h->scan2) { (void)hipStreamSynchronize(h->scan2); (void)hipStreamDestroy(h->scan2); }
+    if (h->ev_run) (void)hipEventDestroy(h->ev_run);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     for (int q = 0; q < kRing; ++q) {
         if (h->ev_scan[q]) (void)hipEventDestroy(h->ev_scan[q]);
@@ -2732,7 +2814,7 @@ uint64_t rio_gp_debug_wave_row_lo(uint64_t n_objects, uint32_t n_nodes, uint32_t
 }
 
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
-    if (!h || mode < 0 || mode >= 4096 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
+    if (!h || mode < 0 || mode >= 8192 || (mode & 15) > 2 || ((mode >> 5) & 3) == 3) return RIO_GP_EINVAL;  // nothing is changed
     Locked g(h);
     h->part_mode = (mode & 16) ? 2 : 0;  // bit 4: big update / remove batches through the plain kernels (A/B runs, parity tests)
     h->cutpack_mode = (mode >> 5) & 3;   // bits 5-6: packing at the cut pass of whole-table solves, 0 auto | 1 always | 2 never
@@ -2742,7 +2824,14 @@ int rio_gp_debug_set_compact(rio_gp_t* h, int mode) {
     h->cutapply_mode = (mode >> 9) & 3;  // bits 9-10: 0 = k_cut_apply when the solve packs at the cut pass | 1 = always | 2 = never
     if (h->cutapply_mode == 3) h->cutapply_mode = 0;
     h->overlap_mode = (mode & 2048) ? 2 : 0;  // bit 11: quiet ticks do not overlap (k_resolve on the main stream, as before round 6)
+    h->chain_mode = (mode & 4096) ? 2 : 0;    // bit 12: overlapped quiet ticks are not chained (every scan on the main stream)
     return RIO_GP_OK;
+}
+
+uint64_t rio_gp_debug_chained_scans(rio_gp_t* h) {
+    if (!h) return 0;
+    Locked g(h);
+    return h->chain_total;
 }
 
 int rio_gp_debug_set_speculate(rio_gp_t* h, int speculate) {

@@ -166,6 +166,8 @@ def _load(lab):
             L.rio_gp_debug_stream_probe.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
             L.rio_gp_debug_set_compact.argtypes = [_vp, C.c_int]
             L.rio_gp_debug_set_speculate.argtypes = [_vp, C.c_int]
+            L.rio_gp_debug_chained_scans.argtypes = [_vp]
+            L.rio_gp_debug_chained_scans.restype = C.c_uint64
             L.rio_gp_debug_ktrace.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
             L.rio_gp_debug_wave_row_lo.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
             L.rio_gp_debug_wave_row_lo.restype = C.c_uint64
@@ -417,7 +419,7 @@ class GpuPlacement:
         self._chk(self._L.rio_gp_debug_ktrace(self._h, 1 if enable else 0, 0 if table is None else table, out))
         return np.ctypeslib.as_array(out).reshape(256, 8).copy() if table is not None else None
 
-    def set_compact(self, mode, partitioned_crud=True, cut_pack="auto", inc="auto", cut_apply="auto", overlap=True):
+    def set_compact(self, mode, partitioned_crud=True, cut_pack="auto", inc="auto", cut_apply="auto", overlap=True, chain=True):
         """0 adaptive | 1 always | 2 never: packed fix-up (results identical in every mode).  partitioned_crud=False: big
         update / remove batches through the plain per-entry kernels (A/B runs, parity tests).  cut_pack: the same three
         modes for packing at the cut pass of whole-table solves (round 0 of k_fill packs).  inc: the in-place scan of
@@ -426,13 +428,20 @@ class GpuPlacement:
         cut_apply: whole-table fix-up — "auto": k_cut_apply + k_cut_settle (exact cuts + re-marking in one pass over the wave
         ranges that have work) when the solve packs at the cut pass | "always" | "never": k_cut_find, then the re-marking pass
         inside round 0 of k_fill (round 5's form).  overlap=False: the k_resolve of a quiet asynchronous tick stays on the main
-        stream (it runs beside the next tick's scan otherwise)."""
+        stream (it runs beside the next tick's scan otherwise).  chain=False: the scans of overlapped quiet ticks all go onto
+        the main stream (by default they alternate between two streams and hand their rows over workgroup by workgroup)."""
         self._need_lab()
         modes = {"auto": 0, "always": 1, "never": 2}
         incs = {"auto": 0, "always": 1, "never": 2}   # ("always" = "auto" since the size limit of the in-place tick went)
         self._chk(self._L.rio_gp_debug_set_compact(self._h, modes.get(mode, mode) | (0 if partitioned_crud else 16) |
                                                    (modes.get(cut_pack, cut_pack) << 5) | (incs.get(inc, inc) << 7) |
-                                                   (modes.get(cut_apply, cut_apply) << 9) | (0 if overlap else 2048)))
+                                                   (modes.get(cut_apply, cut_apply) << 9) | (0 if overlap else 2048) |
+                                                   (0 if chain else 4096)))
+
+    def chained_scans(self):
+        """scans of quiet asynchronous ticks this handle has enqueued as links of a chain (two streams, workgroup-by-workgroup hand-over)"""
+        self._need_lab()
+        return int(self._L.rio_gp_debug_chained_scans(self._h))
 
     def set_speculate(self, speculate="auto"):
         """speculative enqueue of the fix-up behind k_resolve: auto | always | never (results identical in every mode)."""

@@ -779,11 +779,13 @@ def test_async_ticks_equal_the_synchronous_stream(gp, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap):
+@pytest.mark.parametrize("overlap", [True, False, "chained", "overlapped"])
+def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap, monkeypatch):
     """A tick that took the fast path leaves every object placed: until an input of the solve changes, rio_gp_tick_async
     enqueues k_scan + k_resolve only (no speculative fix-up) — and k_resolve on a stream of its own beside the next tick's scan
-    (overlap: the product library as it is; False: the lab build with that switched off).  Every kind of change must end that: liveness, removals,
+    (overlap: the product library as it is; False: the lab build with that switched off; "chained" / "overlapped": the lab build with
+    the size threshold of the overlap taken away, so that this table's quiet ticks run the way a 10 M-row table's do — their scans
+    chained over two streams, workgroup by workgroup — and the same without the chain).  Every kind of change must end that: liveness, removals,
     updates onto other nodes, new loads / affinities, a new table, clean_server, requests — the tick right behind each is
     compared with the oracle chain, with the verdicts of the earlier ticks given time to land (so the quiet rule is
     actually in force when the change arrives)."""
@@ -793,9 +795,13 @@ def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap):
     load, aff, cap = cfg["load"].copy(), cfg["aff"].copy(), cfg["cap"]
     ref = synth.warm_assign(n, m)
     alive = np.ones(m, np.uint8)
-    g = _mk(gp, n, m, load, aff, cap, alive, ref, lab=not overlap)
+    if isinstance(overlap, str):
+        monkeypatch.setenv("RIO_GP_OVERLAP_MIN_ROWS", "1")
+    g = _mk(gp, n, m, load, aff, cap, alive, ref, lab=overlap is not True)
     if not overlap:
         g.set_compact("auto", overlap=False)
+    elif overlap == "overlapped":
+        g.set_compact("auto", chain=False)
     rng = np.random.default_rng(99)
     want = []
 
@@ -843,6 +849,53 @@ def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap):
     for k in range(len(want)):
         assert got[k] == want[k], (k, got[k], want[k])
     assert np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], used)
+    if isinstance(overlap, str):   # the quiet ticks of this run were links of a chain — or none of them was
+        assert (g.chained_scans() > 20) == (overlap == "chained"), g.chained_scans()
+    g.close()
+
+
+@pytest.mark.parametrize("lab", [False, True])
+def test_chained_quiet_ticks_hand_over_what_the_tick_before_them_wrote(gp, oracle, lab):
+    """A table big enough for the product's own rule (2^22 rows and more): once a tick's verdict says "fast path, nothing
+    changed since", the scans of the following ticks alternate between two streams and hand their rows over workgroup by
+    workgroup.  What a broken hand-over would show: the SECOND link of a run reads the column the first link wrote while that
+    launch is still running — a stale read there sees the table as it was before the run (rows on dead nodes, rows not yet
+    placed) and counts evictions / claims where the oracle chain counts kept rows.  Every tick's counters, the table and
+    `used` after every run; cold start, then two rounds of node deaths with runs of back-to-back quiet ticks behind them."""
+    import time
+    cfg = synth.config("c3", n_override=(1 << 22) + 12_345)
+    n, m = cfg["n"], cfg["m"]
+    load, aff, cap = cfg["load"], cfg["aff"], cfg["cap"]
+    alive = np.ones(m, np.uint8)
+    ref = np.full(n, NONE, np.uint32)
+    g = _mk(gp, n, m, load, aff, cap, alive, ref, lab=lab)
+    want = []
+
+    def tick():
+        nonlocal ref
+        g.tick_async()
+        ref, used, ost = oracle.tick(ref, load, aff, cap, alive, 2)
+        want.append(ost)
+        return used
+
+    for rnd in range(3):
+        if rnd:
+            alive = synth.churn_mask(m, 40 + rnd)
+            g.set_alive_all(alive)
+        for _ in range(3):          # the tick that changes the table, and two more until a verdict has certainly landed
+            used = tick()
+            time.sleep(0.01)
+        for _ in range(70):         # a run longer than the ring of ticks: harvested in the middle, started again
+            used = tick()
+        got = g.tick_wait()
+        assert len(got) == len(want)
+        for k in range(len(want)):
+            assert got[k] == want[k], (rnd, k, got[k], want[k])
+        want = []
+        assert np.array_equal(g.get_assign(), ref), rnd
+        assert np.array_equal(g.get_nodes()[2], used), rnd
+    if lab:
+        assert g.chained_scans() >= 3 * 60, g.chained_scans()
     g.close()
 
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Quiet committed ticks of config 3 (nothing changes between ticks: k_scan + k_resolve per tick, no fix-up) with k_resolve on a
-stream of its own beside the next tick's scan (the product's way since round 6) and on the main stream (lab knob: overlap=False),
-alternating in ONE run; final table and `used` compared.  Usage: quiet_overlap_ab.py [ticks=200] [config=c3|c4]"""
+stream of its own beside the next tick's scan, the scans themselves CHAINED over two streams (workgroup b of tick k + 1 waits
+for workgroup b of tick k, not for its launch: the product's way), the same without the chain (lab knob: chain=False) and
+everything on the main stream (overlap=False), alternating in ONE run; final table and `used` compared.  Usage: quiet_overlap_ab.py [ticks=200] [config=c3|c4]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rio-rs_amd"), os.path.join(ROOT, "oracle")):
@@ -13,9 +14,14 @@ cfg = synth.config(sys.argv[2] if len(sys.argv) > 2 else "c3")
 n, m = cfg["n"], cfg["m"]
 out = {"n": n, "m": m, "ticks": ticks, "runs": []}
 final = {}
-for name, ov in (("overlap", True), ("main stream", False), ("overlap#2", True), ("main stream#2", False)):
+for name, ov, chn in (("chained", True, True), ("overlap", True, False), ("main stream", False, False),
+                      ("chained#2", True, True), ("overlap#2", True, False), ("main stream#2", False, False)) + (
+                      tuple(("diag%d: %s" % (d, {1: "chained kernel, one stream, no waits", 2: "two streams, no waits"}[d]), True, True) for d in (1, 2))
+                      if os.environ.get("CHAIN_DIAGS") else ()):
+    if name.startswith("diag"):
+        os.environ["RIO_GP_CHAIN_DIAG"] = name[4]
     g = rio_gp.LabPlacement(n, m)
-    g.set_compact("auto", overlap=ov)
+    g.set_compact("auto", overlap=ov, chain=chn)
     g.set_nodes(cfg["cap"], cfg["alive"])
     g.set_objects(n, cfg["load"], cfg["aff"])
     g.set_assign(cfg["cur"])
@@ -33,6 +39,6 @@ for name, ov in (("overlap", True), ("main stream", False), ("overlap#2", True),
                         "frac_of_8TBps": 16 * n / (us * 1e-6) / 8e12, "slow_path_ticks": sum(x["slow_path"] for x in sts)})
     final[name] = (g.get_assign(), g.get_nodes()[2], sts[-1])
     g.close()
-a0 = final["overlap"]
+a0 = final["main stream"]
 out["equal"] = all(np.array_equal(a0[0], v[0]) and np.array_equal(a0[1], v[1]) and a0[2] == v[2] for v in final.values())
 print(json.dumps(out, indent=1))
