@@ -394,7 +394,7 @@ def test_invalid_arguments_are_unknown_errors(gp):
     g.close()
     # the lab build's knobs reject what they do not know (modes are 0 | 1 | 2 in every field)
     gl = gp.LabPlacement(10, 2)
-    for bad in (3, 3 << 5, 7, 1 << 12):
+    for bad in (3, 3 << 5, 7, 1 << 13):
         assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, bad) == gp.EINVAL
     assert gp.lab_lib().rio_gp_debug_set_speculate(gl.handle, 3) == gp.EINVAL
     assert gp.lab_lib().rio_gp_debug_set_compact(gl.handle, 2 | 16 | (1 << 5)) == 0   # never | plain CRUD | cut-pass packing always
