@@ -66,7 +66,15 @@ class Scenario:
             self.ref = rng.integers(0, m, n).astype(np.uint32)
             self.ref[rng.random(n) < (0.02 if start == 1 else 0.5)] = NONE
         self.lab = seed % 3 == 2
-        g = self.g = gp.GpuPlacement(n, m, spill_rounds=self.rounds, flags=self.flags, lab=self.lab)
+        # half of the lab scenarios: the quiet asynchronous ticks overlap / chain whatever the table's size (the product's rule
+        # needs 2^22 rows) — their scans alternate between two streams and hand the rows over workgroup by workgroup
+        self.chain_small = self.lab and (seed // 3) % 2 == 1
+        if self.chain_small:
+            os.environ["RIO_GP_OVERLAP_MIN_ROWS"] = "1"
+        try:
+            g = self.g = gp.GpuPlacement(n, m, spill_rounds=self.rounds, flags=self.flags, lab=self.lab)
+        finally:
+            os.environ.pop("RIO_GP_OVERLAP_MIN_ROWS", None)
         g.set_nodes(self.cap, self.alive, m=m)
         g.set_objects(n, self.load, self.aff)
         g.set_assign(self.ref)
@@ -124,14 +132,17 @@ class Scenario:
 
     def op_async(self):
         k = int(self.rng.integers(1, 5))
+        quiet_run = self.chain_small and self.rng.random() < 0.5   # a longer stream without changes: verdicts land, the ticks chain
+        if quiet_run:
+            k += 6
         want_st = []
         for i in range(k):
-            if i and self.rng.random() < 0.5:
+            if i and not quiet_run and self.rng.random() < 0.5:
                 self.op_flip()
             self.g.tick_async()
             self.ref, used, ost = self.otick()
             want_st.append(ost)
-            if self.rng.random() < 0.3:
+            if self.rng.random() < 0.3 or (quiet_run and i < 3):
                 time.sleep(0.002)
         got = self.g.tick_wait()
         assert got == want_st, (self.seed, "tick_async", self.log[-6:], got, want_st)
@@ -272,6 +283,7 @@ class Scenario:
                 self.count[op] = self.count.get(op, 0) + 1
                 getattr(self, "op_" + op)()
                 self.check_table(op)
+            self.chained = self.g.chained_scans() if self.lab else 0
         finally:
             self.g.close()
         return k
@@ -381,8 +393,9 @@ if __name__ == "__main__":
         for k, v in sc.count.items():
             cov[k] = cov.get(k, 0) + v
         for k, on in (("tables >= 10^5 rows", sc.n >= 100_000), ("tables >= 2^19 rows", sc.n >= 524288), ("self-assign", sc.sa),
-                      ("forced policies (lab build)", sc.lab)):
+                      ("forced policies (lab build)", sc.lab), ("scenarios with chained quiet ticks", sc.chained > 0)):
             cov[k] = cov.get(k, 0) + int(on)
+        cov["chained scans"] = cov.get("chained scans", 0) + sc.chained
         seed += 1
     print(json.dumps({"scenarios": seed - first, "first_seed": first, "operations_checked": ops, "seconds": round(time.time() - t0, 1),
                       "mismatches": 0, "coverage": cov}))
