@@ -177,10 +177,11 @@ struct NodeTab {
 // wrote (and writes what it read), so it waits for THAT workgroup's flag instead of for the whole launch; the ramp-down of
 // one scan and the ramp-up of the next overlap.  flags[b] = `set` of the last chained scan whose workgroup b is through.
 struct ScanChain {
-    u32* flags;   // [kMaxBlocks], device memory
+    u32* flags;   // [kMaxBlocks] per workgroup, then [kMaxBlocks * kWaves] per wave range; device memory
     u32* err;     // one word of mapped host memory: raised when a wait gave up (the tables are then stale)
     u32 wait;     // sequence number of the scan to wait for (0: none — the stream orders this scan behind what it depends on)
     u32 set;      // this scan's sequence number
+    u32 per_wave; // the hand-over is per wave range (a flag per wave, no barrier on its path) instead of per workgroup
 };
 
 bool scan_chain_fits(u32 m);  // two workgroups of the chained scan per CU (what makes the in-kernel wait deadlock-free)

@@ -490,23 +490,24 @@ __global__ __launch_bounds__(kBlock, CHAIN ? 8 : 1) void k_scan(const u32* __res
         stats->local_fixup = 0;
         stats->global_slow = 0;
     }
-    if (CHAIN && tid == 0 && ch.wait) {
-        // Chained quiet ticks: this workgroup's rows of `cur` are what workgroup blockIdx.x of the previous tick's scan wrote
-        // (the same plan), and its rows of `next` are what that workgroup read — it may still be running, on the other scan
-        // stream.  Wait for ITS flag, not for its launch.  (It is resident or finished: a launch of the chain is dispatched
-        // only after the launch two ticks back has completed, so every slot this launch's workgroups hold was vacated by a
-        // workgroup of the previous tick's launch or is one that launch never needed.)
+    auto chain_wait = [&](const u32* flag) {  // (one lane; bounded: must not hang the device if the predecessor never comes)
         const u64 t0 = wall_clock64();
         u32 tries = 0;
-        while ((int)(__hip_atomic_load(ch.flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.wait) < 0) {
-            if ((++tries & 15u) == 0 && wall_clock64() - t0 > kChainTimeoutTicks) {  // never seen; must not hang the device if it is
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.wait) < 0) {
+            if ((++tries & 15u) == 0 && wall_clock64() - t0 > kChainTimeoutTicks) {
                 __hip_atomic_store(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (ch.per_wave) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
         }
-    }
+    };
+    // Chained quiet ticks: this workgroup's rows of `cur` are what workgroup blockIdx.x of the previous tick's scan wrote (the same
+    // plan), and its rows of `next` are what that workgroup read — it may still be running, on the other scan stream.  Wait for
+    // ITS flag, not for its launch.  (It is resident or finished: two workgroups of this kernel fit a CU and at most two launches
+    // of the chain are in flight.)  per_wave: the same per wave range — a flag per wave, no barrier on the hand-over's path.
+    if (CHAIN && tid == 0 && ch.wait && !ch.per_wave) chain_wait(ch.flags + blockIdx.x);
     __syncthreads();
+    if (CHAIN && ch.per_wave && ch.wait && lane == 0) chain_wait(ch.flags + kMaxBlocks + gw);
     if (CHAIN && it < wgrp) {
 #pragma unroll
         for (int q = 0; q < TPI; ++q) cv[q] = ld4_fabric(crs, it + (u64)q * kTile + (u64)lane * 4);
@@ -574,7 +575,10 @@ __global__ __launch_bounds__(kBlock, CHAIN ? 8 : 1) void k_scan(const u32* __res
     // per-wave spill-candidate totals (index-ordered prefix over wave ranges comes later)
     sp_sum = wave_sum(sp_sum);
     sp_cnt = wave_sum32(sp_cnt);
-    if (CHAIN) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's row stores (write-through) have landed
+    if (CHAIN) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's row stores (write-through) have landed
+        if (ch.per_wave && lane == 0) __hip_atomic_store(ch.flags + kMaxBlocks + gw, ch.set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (lane == 0) {
         wsp_sum[gw] = sp_sum;
         wsp_cnt[gw] = sp_cnt;
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(kBlock, CHAIN ? 8 : 1) void k_scan(const u32* __res
         if (sp_sum) atomicAdd(&bsum, sp_sum);
     }
     __syncthreads();
-    if (CHAIN && tid == 0)  // this workgroup's rows are done, read and written (every wave has drained its stores in front of the
+    if (CHAIN && tid == 0 && !ch.per_wave)  // this workgroup's rows are done, read and written (every wave has drained its stores in front of the
                             // barrier, and they went through to the fabric): the next tick's workgroup blockIdx.x may go
         __hip_atomic_store(ch.flags + blockIdx.x, ch.set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) { bsp_sum[blockIdx.x] = bsum; bsp_cnt[blockIdx.x] = bst[3]; }
@@ -5148,7 +5152,7 @@ static inline unsigned grid_for(u64 n, unsigned block, unsigned cap) {
 template <bool VIRT, bool AA, int TPI, int COMPACT = 0, bool NT = false, bool CHAIN = false>
 static void launch_scan_t(const Plan& p, const Table& t, const NodeTab& nt, const SolveBufs& b, hipStream_t s,
                           hipEvent_t e0, hipEvent_t e1, const PackOut* pack = nullptr, const ScanChain* chain = nullptr) {
-    const ScanChain ch = chain ? *chain : ScanChain{nullptr, nullptr, 0, 0};
+    const ScanChain ch = chain ? *chain : ScanChain{nullptr, nullptr, 0, 0, 0};
     const size_t lds = scan_lds_bytes(p.m) + (COMPACT == 2 ? (size_t)kWaves * 4 * kStageCap * sizeof(u32) : 0);
     const PackOut pko = pack ? *pack : PackOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     Plan pp = p;

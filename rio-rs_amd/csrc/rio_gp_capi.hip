@@ -231,6 +231,8 @@ struct rio_gp {
     hipEvent_t ev_run = nullptr;  // recorded on the main stream in front of a run's first scan: the run's first scan on `scan2` waits for
                                   // it, so that nothing but the two scans of the chain competes for the chip while one of them waits
     u64 overlap_min_rows = (u64)1 << 22;  // (lab builds, RIO_GP_OVERLAP_MIN_ROWS: the parity tests run the overlapped / chained ticks on small tables)
+    u32 chain_per_wave = 1;       // ScanChain::per_wave: the hand-over per wave range (same-run A/B: 25.6-25.9 against 26.2-26.5 us per tick per
+                                  // workgroup; lab builds: RIO_GP_CHAIN_PER_WAVE=0 for the other form)
     int chain_diag = 0;           // lab builds, RIO_GP_CHAIN_DIAG: 1 = the chained kernel on the main stream, no waits | 2 = alternating streams, no waits
     bool chain_ok = false;        // two workgroups of the chained scan fit a CU (scan_chain_fits at the table's node count)
     u64 chain_total = 0;   // chained scans enqueued so far (lab builds: rio_gp_debug_chained_scans)
@@ -498,7 +500,7 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     if (h->ca_now) { rb.R = nullptr; rb.RP = nullptr; rb.Tg = h->Tg; }
     hipStream_t rs = h->stream;  // where k_resolve goes
     hipStream_t ss = h->stream;  // where the scan goes
-    ScanChain ch{h->chain_flags, h->d_chain_err, 0, 0};
+    ScanChain ch{h->chain_flags, h->d_chain_err, 0, 0, h->chain_per_wave};
     if (chained) {
         if (!h->chain_prev) {
             (void)hipEventRecord(h->ev_run, h->stream);
@@ -825,7 +827,7 @@ int tick_async_locked(rio_gp* h) {
     //  that nothing behind it may overtake: a quiet tick has none)
     if (overlap && h->chain_seq >= 0x70000000u) {  // (sequence numbers compare by signed difference: start over long before they wrap)
         side_join(h);
-        (void)hipMemsetAsync(h->chain_flags, 0, kMaxBlocks * sizeof(u32), h->stream);
+        (void)hipMemsetAsync(h->chain_flags, 0, (size_t)kMaxBlocks * (1 + kWaves) * sizeof(u32), h->stream);
         h->chain_seq = 0;
     }
     const bool chained = overlap && h->chain_mode != 2 && h->scan2 && h->chain_ok && !nt.alive_src && chain_begin(h);
@@ -976,6 +978,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     h->chain_ok = h->scan2 && scan_chain_fits((u32)h->cap_nodes);
 #ifdef RIO_GP_LAB
     if (const char* e = getenv("RIO_GP_CHAIN_DIAG")) h->chain_diag = atoi(e);
+    if (const char* e = getenv("RIO_GP_CHAIN_PER_WAVE")) h->chain_per_wave = (u32)atoi(e);
     if (const char* e = getenv("RIO_GP_OVERLAP_MIN_ROWS")) h->overlap_min_rows = strtoull(e, nullptr, 10);  // (timing experiments only: the waits are what makes the chain correct)
 #endif
     const size_t R = h->cap_rows, M = h->cap_nodes, W = (size_t)kMaxBlocks * kWaves;
@@ -1004,7 +1007,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     A(h->pk.idx, R); A(h->pk.load, R); A(h->pk.aff, R); A(h->pk.next, R); A(h->pk.wcnt, W);
     A(h->pk2.idx, R2); A(h->pk2.load, R2); A(h->pk2.aff, R2); A(h->pk2.next, R2); A(h->pk2.wcnt, W);
     A(h->Tg, M * kWaves);
-    A(h->chain_flags, (size_t)kMaxBlocks);
+    A(h->chain_flags, (size_t)kMaxBlocks * (1 + kWaves));
     A(h->sh_lkept, M); A(h->sh_lclaim, M); A(h->sh_lcur, M); A(h->sh_lcutblk, M); A(h->sh_lcutidx, M);
     A(h->sh_gprev, M); A(h->sh_gfinal, M); A(h->sh_rank_base, 2); A(h->sh_verdict, 8); A(h->sh_forced, (M + 31) / 32 + 4);
 #undef A
@@ -1090,7 +1093,7 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     (void)hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream);
     (void)hipMemsetAsync(h->D, 0, (size_t)kFillRounds * M * sizeof(u64), h->stream);
     (void)hipMemsetAsync(h->sb.R, 0, (size_t)kMaxBlocks * sizeof(u64), h->stream);
-    (void)hipMemsetAsync(h->chain_flags, 0, (size_t)kMaxBlocks * sizeof(u32), h->stream);
+    (void)hipMemsetAsync(h->chain_flags, 0, (size_t)kMaxBlocks * (1 + kWaves) * sizeof(u32), h->stream);
     if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
         h->err = "initial fill failed (no gfx950 code object loaded?)";
         return bail(RIO_GP_EUPSTREAM);

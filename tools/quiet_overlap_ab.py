@@ -16,8 +16,10 @@ out = {"n": n, "m": m, "ticks": ticks, "runs": []}
 final = {}
 for name, ov, chn in (("chained", True, True), ("overlap", True, False), ("main stream", False, False),
                       ("chained#2", True, True), ("overlap#2", True, False), ("main stream#2", False, False)) + (
+                      tuple(("chained, hand-over per workgroup#%d" % k if k % 2 else "chained#%d" % (3 + k), True, True) for k in range(8)) if os.environ.get("CHAIN_PER_WAVE_AB") else ()) + (
                       tuple(("diag%d: %s" % (d, {1: "chained kernel, one stream, no waits", 2: "two streams, no waits"}[d]), True, True) for d in (1, 2))
                       if os.environ.get("CHAIN_DIAGS") else ()):
+    os.environ["RIO_GP_CHAIN_PER_WAVE"] = "0" if "per workgroup" in name else "1"
     if name.startswith("diag"):
         os.environ["RIO_GP_CHAIN_DIAG"] = name[4]
     g = rio_gp.LabPlacement(n, m)
