@@ -1261,8 +1261,8 @@ def main():
                    "step": "rio_gp_tick_async = k_scan + k_resolve (+ the fix-up, guarded on the device) + commit; nothing waits on the "
                            "host between ticks, every tick's counters are read at the end.  Once a tick's verdict says nothing is "
                            "left to fix and nothing has changed since, the following ticks are k_scan + k_resolve only: the scans "
-                           "alternate between two streams and hand their rows over workgroup by workgroup (workgroup b of tick "
-                           "k + 1 waits for workgroup b of tick k, not for its launch), k_resolve runs on a third stream behind "
+                           "alternate between two streams and hand their rows over wave range by wave range (wave w of tick "
+                           "k + 1 waits for wave w of tick k, not for its launch), k_resolve runs on a third stream behind "
                            "its scan",
                    "exchange": None, "slow_path_steps": n_slow},
         "gpu_ms_per_step_events": gpu_ms / a.steps,

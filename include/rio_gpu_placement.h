@@ -279,7 +279,7 @@ int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats);
  * On the handle's OWN stream a tick that cannot need the fix-up (nothing has changed since a tick that left every object
  * placed) runs its resolve step on an internal second stream, beside the next tick's scan, and on tables of 2^22 rows and
  * more (up to 1 024 nodes) the scans of such ticks alternate between the handle's stream and a third internal one, each
- * workgroup starting as soon as the same workgroup of the previous tick's scan has finished its rows (a dependency per row
+ * wave starting as soon as the same wave of the previous tick's scan has finished its rows (a dependency per row
  * range instead of per launch: the data dependency between two ticks is exactly that).  Every other call of the handle
  * orders itself behind all of it.  On a caller's stream (rio_gp_set_stream) everything stays on that one stream. */
 int rio_gp_tick_async(rio_gp_t* h);

@@ -29,7 +29,7 @@ extern "C" {
  * + 2048: the k_resolve of a quiet asynchronous tick (rio_gp_tick_async on a table nothing has changed in: k_scan + k_resolve,
  * no fix-up) stays on the main stream; by default it runs on a stream of its own beside the next tick's k_scan.
  * + 4096: the scans of such ticks are not CHAINED (every scan on the main stream, one launch after the other); by default they
- * alternate between two streams and hand their rows over workgroup by workgroup (ScanChain, placement_kernels.h).
+ * alternate between two streams and hand their rows over wave range by wave range (ScanChain, placement_kernels.h).
  * Environment, read when a handle of the lab build is created: RIO_GP_OVERLAP_MIN_ROWS (the smallest table whose quiet ticks
  * overlap / chain; 2^22 rows in the product), RIO_GP_CHAIN_TPI (1 | 2 tiles per wave-iteration of the chained scan),
  * RIO_GP_CHAIN_DIAG (timing experiments without the waits: NOT correct, tools/quiet_overlap_ab.py). */

@@ -173,7 +173,7 @@ struct NodeTab {
 };
 
 // Chained quiet ticks (rio_gp_tick_async over a table nothing has changed in): the scans of consecutive ticks alternate between
-// two streams and hand their rows over workgroup by workgroup — workgroup b of tick k + 1 reads what workgroup b of tick k
+// two streams and hand their rows over wave range by wave range (per workgroup in the other form) — workgroup b of tick k + 1 reads what workgroup b of tick k
 // wrote (and writes what it read), so it waits for THAT workgroup's flag instead of for the whole launch; the ramp-down of
 // one scan and the ramp-up of the next overlap.  flags[b] = `set` of the last chained scan whose workgroup b is through.
 struct ScanChain {

@@ -221,7 +221,7 @@ struct rio_gp {
     u64* H_ring[kRing] = {}; u64* blk_ring[kRing] = {};
     int overlap_mode = 0;  // 0 on | 2 never (lab builds: bit 11 of rio_gp_debug_set_compact)
     // ... and CHAIN (ScanChain, placement_kernels.h): the scans of a run of overlapped quiet ticks alternate between the main
-    // stream and `scan2` and hand their rows over workgroup by workgroup (a flag per workgroup), so the ramp-down of one scan and
+    // stream and `scan2` and hand their rows over wave range by wave range (a flag per wave; per workgroup in the other form), so the ramp-down of one scan and
     // the ramp-up of the next overlap.  A run starts on the main stream (which orders it behind everything else) and ends with
     // the first side_join: the last k_resolve waits for the last scan, and that scan's workgroups have waited for every earlier one.
     hipStream_t scan2 = nullptr;
