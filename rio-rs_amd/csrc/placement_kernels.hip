@@ -576,7 +576,8 @@ __global__ __launch_bounds__(kBlock, CHAIN ? 8 : 1) void k_scan(const u32* __res
     sp_sum = wave_sum(sp_sum);
     sp_cnt = wave_sum32(sp_cnt);
     if (CHAIN) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's row stores (write-through) have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's row stores (through to the fabric) have landed — inline asm: no
+                                                          // pass may decide the counter is known to be empty and drop the wait
         if (ch.per_wave && lane == 0) __hip_atomic_store(ch.flags + kMaxBlocks + gw, ch.set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0) {
