@@ -899,6 +899,48 @@ def test_chained_quiet_ticks_hand_over_what_the_tick_before_them_wrote(gp, oracl
     g.close()
 
 
+def test_two_handles_tick_side_by_side_one_chain_at_a_time(gp, oracle):
+    """Two handles of one process, a thread each, both running quiet tick streams over tables big enough to chain: one handle
+    per process chains at a time (the chain's progress argument counts the workgroup slots of ONE pair of launches), the
+    other's quiet ticks overlap without the chain, and the turn changes hands whenever a run ends.  Both tables, `used` and
+    every tick's counters against the oracle."""
+    import threading
+    import time
+    cfgs = [synth.config("c3", n_override=(1 << 22) + 1000 * (k + 1)) for k in range(2)]
+    out, errs = [None, None], []
+
+    def run(k):
+        try:
+            cfg = cfgs[k]
+            n, m = cfg["n"], cfg["m"]
+            alive = np.ones(m, np.uint8) if k == 0 else synth.churn_mask(m, 77)
+            ref = np.full(n, NONE, np.uint32)
+            g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], alive, ref, lab=True)
+            want, got = [], []
+            for rnd in range(4):
+                for i in range(40):
+                    g.tick_async()
+                    ref, used, ost = oracle.tick(ref, cfg["load"], cfg["aff"], cfg["cap"], alive, 2)
+                    want.append(ost)
+                    if i < 3:
+                        time.sleep(0.005)
+                got += g.tick_wait()
+            out[k] = (got == want, np.array_equal(g.get_assign(), ref), np.array_equal(g.get_nodes()[2], used), g.chained_scans())
+            g.close()
+        except Exception as e:   # (a thread's exception must fail the test, not vanish)
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        assert out[k][:3] == (True, True, True), (k, out[k])
+    assert out[0][3] + out[1][3] > 0, out   # (somebody chained)
+
+
 # ---- place_pending ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("seed,cap_inf", [(0, True), (1, False), (2, False), (3, True)])
