@@ -6,7 +6,8 @@ A "step" is one whole-table pass of the placement solver (every row of the table
 
   N = 1   BASELINE.json config 3 (the configuration the metric is quoted on): 10 M objects x 1 024 nodes, Zipf(1.1) loads.
           value = a pipelined stream of COMMITTED ticks (rio_gp_tick_async: k_scan + k_resolve (+ fix-up) + commit), starting
-          from the cold table.  The same line carries the un-committed cold re-solves (round 2's headline, named as such), the
+          from the cold table; once the stream is quiet (nothing left to fix, nothing changed) the ticks' scans are chained over
+          two streams, wave range by wave range, and k_resolve runs beside the next scan (config.step).  The same line carries the un-committed cold re-solves (round 2's headline, named as such), the
           synchronous dependent tick, config 2, config 4 on one GPU, the config-5 churn stream (synchronous + pipelined,
           per-kernel spans, parity of the whole 110-tick stream against the oracle chain) and — the headline ticks never cut or
           spill — the solve in which CAPACITY BINDS: `config3_contended` (0.72 x the capacities) and `config3_skew` (Lomax(1.1)
@@ -29,7 +30,9 @@ A "step" is one whole-table pass of the placement solver (every row of the table
   roofline     = k_scan (the streaming kernel, >85 % of a step): algorithmic 16 B/decision (read
                  cur+load+aff, write assign) / its per-launch HIP-event time, on the cold table; `traffic` = HBM bytes per
                  launch from rocprofv3 PMC passes run by this script; frac_dram_bound / frac_committed_tick /
-                 frac_dependent_tick = the same ratio for the whole step beyond the Infinity Cache and for whole ticks
+                 frac_dependent_tick = the same ratio for the whole step beyond the Infinity Cache and for whole ticks (a chained
+                 tick costs less than k_scan's own launch duration: the ramp-up and the tail of consecutive scans overlap — the
+                 roofline's kernel_ms is the plain k_scan alone on one stream, which is what a rocprofv3 trace shows for it)
   cpu_baseline = the CPU oracle port of the reference's per-object path, on a bounded sample: 1 thread, and as many threads as
                  the process may use CPUs (the cgroup's quota: 16 on this pool, where 256 hardware threads are visible); `value`
                  is the faster of the two, both are in the record
