@@ -244,7 +244,8 @@ __host__ __device__ __forceinline__ u32 pp_ans_cur(u32 w) {
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // four consecutive words at any word address
 constexpr u64 kChainTimeoutTicks = 100000000ull;  // wall_clock64 runs at 100 MHz: 1 s, then ScanChain::err is raised
-constexpr u32 kStageCap = 320;  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
+constexpr u32 kStageCap = 320;
+constexpr u32 kIncFlush = 256, kIncCap = 512;  // k_inc_scan's rings: records per flush (four per lane), words per ring column  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
 
 // NT: non-temporal column streams for tables beyond the 256 MiB Infinity Cache (measured +1-2 % at 40-100 M rows and
 // -25 % at 10 M rows, where the cache serves part of every pass: launch_scan picks by table size)
@@ -681,7 +682,8 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
     u32 kept_cnt = 0, evict_cnt = 0, claim_cnt = 0, sp_cnt = 0;  // per LANE here (summed over the wave at the end)
     u64 pk_pos = wstart;  // this wave's packed write cursor (wave-uniform)
     // this wave's packing ring: three columns of kStageCap words behind the bitmap
-    u32* stage = reinterpret_cast<u32*>(smem + inc_lds_base(m)) + (size_t)wave * 3 * kStageCap;
+    // (kIncCap words per column: < kIncFlush left over + one tile of new records; a flush is kIncFlush records, four per lane)
+    u32* stage = reinterpret_cast<u32*>(smem + inc_lds_base(m)) + (size_t)wave * 3 * kIncCap;
     u32 st_head = 0, st_fill = 0;
     const u64 lt = (1ull << lane) - 1ull;
 
@@ -723,8 +725,8 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
             u32 e = st_head + st_fill + (u32)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
 #define RIOGP_PK(E, A, L)                                                                                 \
             if (km & (1u << E)) {                                                                         \
-                const u32 x = e >= kStageCap ? (e >= 2 * kStageCap ? e - 2 * kStageCap : e - kStageCap) : e;  \
-                stage[x] = (u32)(i0 + E); stage[kStageCap + x] = L; stage[2 * kStageCap + x] = A;         \
+                const u32 x = e & (kIncCap - 1u);                                                         \
+                stage[x] = (u32)(i0 + E); stage[kIncCap + x] = L; stage[2 * kIncCap + x] = A;             \
                 ++e;                                                                                      \
             }
             RIOGP_PK(0, a.x, l.x)
@@ -734,14 +736,18 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
 #undef RIOGP_PK
             st_fill += (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
             __builtin_amdgcn_wave_barrier();
-            while (st_fill >= 64u) {  // wave-uniform: 64 records leave as three coalesced 256-byte stores
-                u32 x = st_head + (u32)lane;
-                x = x >= kStageCap ? x - kStageCap : x;
-                const u64 o = pk_pos + (u32)lane;
-                pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
-                st_head = st_head + 64u >= kStageCap ? st_head + 64u - kStageCap : st_head + 64u;
-                st_fill -= 64u;
-                pk_pos += 64u;
+            if (st_fill >= kIncFlush) {  // wave-uniform: 256 records leave as three coalesced 1 KB stores, four records per lane
+                // (a flush is a store instruction per column every ~10 tiles instead of one every ~2.5: the stores of a wave
+                //  retire in order with its loads, so every flush is a moment at which the prefetch is waited for together
+                //  with the stores in front of it — same-run: 6 us of the kernel's span were these moments)
+                const u32 x = st_head + 4u * (u32)lane;   // (st_head is 0 or kIncFlush: no wrap inside a flush)
+                const u64 o = pk_pos + 4u * (u32)lane;
+                *reinterpret_cast<uint4*>(pko.idx + o) = *reinterpret_cast<const uint4*>(stage + x);
+                *reinterpret_cast<uint4*>(pko.load + o) = *reinterpret_cast<const uint4*>(stage + kIncCap + x);
+                *reinterpret_cast<uint4*>(pko.aff + o) = *reinterpret_cast<const uint4*>(stage + 2 * kIncCap + x);
+                st_head = (st_head + kIncFlush) & (kIncCap - 1u);
+                st_fill -= kIncFlush;
+                pk_pos += kIncFlush;
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -771,12 +777,11 @@ __global__ __launch_bounds__(kBlock) void k_inc_scan(u32* __restrict__ assign, c
         const uint4 l1 = *reinterpret_cast<const uint4*>(load + i);
         tile(c1, a1, l1, i);
     }
-    if (st_fill) {  // what is left in the ring (< 64 records)
-        u32 x = st_head + (u32)lane;
-        x = x >= kStageCap ? x - kStageCap : x;
-        if ((u32)lane < st_fill) {
-            const u64 o = pk_pos + (u32)lane;
-            pko.idx[o] = stage[x]; pko.load[o] = stage[kStageCap + x]; pko.aff[o] = stage[2 * kStageCap + x];
+    if (st_fill) {  // what is left in the ring (< kIncFlush records)
+        for (u32 r = (u32)lane; r < st_fill; r += 64u) {
+            const u32 x = (st_head + r) & (kIncCap - 1u);
+            const u64 o = pk_pos + r;
+            pko.idx[o] = stage[x]; pko.load[o] = stage[kIncCap + x]; pko.aff[o] = stage[2 * kIncCap + x];
         }
         pk_pos += st_fill;
     }
@@ -5259,7 +5264,7 @@ void launch_scan(const Plan& p, const Table& t, const NodeTab& nt, const SolveBu
 
 // The scan of a committed tick over a mostly-placed table (k_inc_scan): the assignment column is read and updated in place,
 // the pending rows go to `pack` (per wave range of p); launch_rebal deals them out evenly and builds the fix-up's histograms.
-static size_t inc_lds_bytes(u32 m) { return inc_lds_base(m) + (size_t)kWaves * 3 * kStageCap * sizeof(u32); }
+static size_t inc_lds_bytes(u32 m) { return inc_lds_base(m) + (size_t)kWaves * 3 * kIncCap * sizeof(u32); }
 bool inc_scan_fits(u32 m) { return inc_lds_bytes(m) <= (size_t)160 * 1024; }
 void launch_inc_scan(const Plan& p, u32* assign, const u32* load, const u32* aff, const NodeTab& nt, const SolveBufs& b,
                      const PackOut& pack, hipStream_t s) {
