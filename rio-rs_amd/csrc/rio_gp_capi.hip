@@ -233,7 +233,8 @@ struct rio_gp {
     u64 overlap_min_rows = (u64)1 << 22;  // (lab builds, RIO_GP_OVERLAP_MIN_ROWS: the parity tests run the overlapped / chained ticks on small tables)
     u32 chain_per_wave = 1;       // ScanChain::per_wave: the hand-over per wave range (same-run A/B: 25.6-25.9 against 26.2-26.5 us per tick per
                                   // workgroup; lab builds: RIO_GP_CHAIN_PER_WAVE=0 for the other form)
-    int chain_diag = 0;           // lab builds, RIO_GP_CHAIN_DIAG: 1 = the chained kernel on the main stream, no waits | 2 = alternating streams, no waits
+    int chain_diag = 0;           // lab builds, RIO_GP_CHAIN_DIAG: 1 = the chained kernel on the main stream, no waits | 2 = alternating streams, no waits | 3 = every link waits
+                                  // for a sequence number nobody will ever store (the bounded spin and the error path under test)
     bool chain_ok = false;        // two workgroups of the chained scan fit a CU (scan_chain_fits at the table's node count)
     u64 chain_total = 0;   // chained scans enqueued so far (lab builds: rio_gp_debug_chained_scans)
     int chain_mode = 0;    // 0 on | 2 never (lab builds: bit 12 of rio_gp_debug_set_compact)
@@ -508,7 +509,7 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
             ss = h->scan2;
             if (h->chain_pos == 1) (void)hipStreamWaitEvent(ss, h->ev_run, 0);
         }
-        ch.wait = h->chain_diag ? 0 : h->chain_prev;
+        ch.wait = (h->chain_diag == 3 && h->chain_prev) ? h->chain_prev + 1000u : h->chain_diag ? 0 : h->chain_prev;  // (3: a predecessor that never comes)
         ch.set = ++h->chain_seq;
         ++h->chain_total;
         h->chain_prev = ch.set;

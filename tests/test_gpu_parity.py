@@ -899,6 +899,37 @@ def test_chained_quiet_ticks_hand_over_what_the_tick_before_them_wrote(gp, oracl
     g.close()
 
 
+def test_a_chained_wait_that_never_ends_gives_up_and_fails_loudly(gp, oracle, monkeypatch):
+    """The in-kernel wait of a chained scan is bounded: if the workgroup it waits for never raises its flag (here: the lab build
+    makes every link wait for a sequence number nobody stores), every wave gives up after a second, a word in mapped host memory
+    is raised and rio_gp_tick_wait fails with Upstream — no hang, no silent result — and the handle works again once the table
+    has been loaded anew."""
+    monkeypatch.setenv("RIO_GP_CHAIN_DIAG", "3")
+    monkeypatch.setenv("RIO_GP_OVERLAP_MIN_ROWS", "1")
+    cfg = synth.config("c3", n_override=300_000)
+    n, m = cfg["n"], cfg["m"]
+    alive = np.ones(m, np.uint8)
+    ref = synth.warm_assign(n, m)
+    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], alive, ref, lab=True)
+    import time
+    g.tick_async()
+    g.tick_wait()                       # (nothing chained yet: a verdict has to land first)
+    for _ in range(3):
+        g.tick_async()                  # a run: its second link waits for what never comes
+    t0 = time.time()
+    with pytest.raises(gp.ObjectPlacementError) as e:
+        g.tick_wait()
+    assert e.value.kind == "Upstream" and "chained scan gave up" in str(e.value), str(e.value)
+    assert time.time() - t0 < 20
+    monkeypatch.delenv("RIO_GP_CHAIN_DIAG")
+    g.close()
+    g = _mk(gp, n, m, cfg["load"], cfg["aff"], cfg["cap"], alive, ref, lab=True)   # (a fresh handle: the process is fine)
+    st = g.tick()
+    want, used, ost = oracle.tick(ref, cfg["load"], cfg["aff"], cfg["cap"], alive, 2)
+    assert st == ost and np.array_equal(g.get_assign(), want)
+    g.close()
+
+
 def test_two_handles_tick_side_by_side_one_chain_at_a_time(gp, oracle):
     """Two handles of one process, a thread each, both running quiet tick streams over tables big enough to chain: one handle
     per process chains at a time (the chain's progress argument counts the workgroup slots of ONE pair of launches), the
