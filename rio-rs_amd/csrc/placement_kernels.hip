@@ -271,6 +271,11 @@ __device__ __forceinline__ uint4 ld4_fabric(__amdgpu_buffer_rsrc_t r, u64 row) {
     const u32x4b v = __builtin_amdgcn_raw_buffer_load_b128(r, (u32)(row * 4u), 0, kAuxSc0Sc1);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+template <bool NT>
+__device__ __forceinline__ uint4 ld4_o32(const u32* base, u64 row) {  // (chained scan: tables below 2^30 rows — a 32-bit byte offset off a uniform base)
+    const u32 off = (u32)row * 4u;
+    return ld4<NT>(reinterpret_cast<const u32*>(reinterpret_cast<const char*>(base) + off));
+}
 __device__ __forceinline__ void st4_fabric(__amdgpu_buffer_rsrc_t r, u64 row, const uint4 v) {
     u32x4b x;
     x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
@@ -451,8 +456,8 @@ __global__ __launch_bounds__(kBlock, CHAIN ? 8 : 1) void k_scan(const u32* __res
         for (int q = 0; q < TPI; ++q) {
             const u64 i = it + (u64)q * kTile + (u64)lane * 4;
             if (!CHAIN) cv[q] = ld4<NT>(csrc + (i << vsh));  // (CHAIN: the previous tick's workgroup may still be writing them)
-            av[q] = ld4<NT>(aff + i);
-            lv[q] = ld4<NT>(lsrc + (i << vsh));
+            av[q] = CHAIN ? ld4_o32<NT>(aff, i) : ld4<NT>(aff + i);
+            lv[q] = CHAIN ? ld4_o32<NT>(load, i) : ld4<NT>(lsrc + (i << vsh));
             if (COMPACT == 3) xv[q] = ld4<NT>(pko.idx + i);
         }
     }
@@ -532,8 +537,8 @@ __global__ __launch_bounds__(kBlock, CHAIN ? 8 : 1) void k_scan(const u32* __res
         for (int q = 0; q < TPI; ++q) {
             const u64 i = pit + (u64)q * kTile + (u64)lane * 4;
             cn[q] = CHAIN ? ld4_fabric(crs, i) : ld4<NT>(csrc + (i << vsh));
-            an[q] = ld4<NT>(aff + i);
-            ln[q] = ld4<NT>(lsrc + (i << vsh));
+            an[q] = CHAIN ? ld4_o32<NT>(aff, i) : ld4<NT>(aff + i);
+            ln[q] = CHAIN ? ld4_o32<NT>(load, i) : ld4<NT>(lsrc + (i << vsh));
             if (COMPACT == 3) xn[q] = ld4<NT>(pko.idx + i);
         }
 #pragma unroll

@@ -838,7 +838,9 @@ int tick_async_locked(rio_gp* h) {
         (void)hipMemsetAsync(h->chain_flags, 0, (size_t)kMaxBlocks * (1 + kWaves) * sizeof(u32), h->stream);
         h->chain_seq = 0;
     }
-    const bool chained = overlap && h->chain_mode != 2 && h->scan2 && h->chain_ok && !nt.alive_src && chain_begin(h);
+    // (the chained scan addresses its columns by 32-bit byte offsets: tables below 2^30 rows — 4 GiB a column)
+    const bool chained = overlap && h->chain_mode != 2 && h->scan2 && h->chain_ok && !nt.alive_src && h->cap_rows < ((size_t)1 << 30) &&
+                         chain_begin(h);
     if (!chained && h->chain_prev) side_join(h);  // (cannot happen: what ends a run joins first; kept so that it could not pass silently)
     enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, inc_choice(h, compact, true),
                          overlap, chained);
