@@ -244,8 +244,8 @@ __host__ __device__ __forceinline__ u32 pp_ans_cur(u32 w) {
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // four consecutive words at any word address
 constexpr u64 kChainTimeoutTicks = 100000000ull;  // wall_clock64 runs at 100 MHz: 1 s, then ScanChain::err is raised
-constexpr u32 kStageCap = 320;
-constexpr u32 kIncFlush = 256, kIncCap = 512;  // k_inc_scan's rings: records per flush (four per lane), words per ring column  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
+constexpr u32 kStageCap = 320;  // words per column of a wave's packing ring: < 64 left over + one tile (256) of new records
+constexpr u32 kIncFlush = 256, kIncCap = 512;  // k_inc_scan's rings: records per flush (four per lane), words per ring column
 
 // NT: non-temporal column streams for tables beyond the 256 MiB Infinity Cache (measured +1-2 % at 40-100 M rows and
 // -25 % at 10 M rows, where the cache serves part of every pass: launch_scan picks by table size)
