@@ -225,7 +225,7 @@ struct rio_gp {
     // the ramp-up of the next overlap.  A run starts on the main stream (which orders it behind everything else) and ends with
     // the first side_join: the last k_resolve waits for the last scan, and that scan's workgroups have waited for every earlier one.
     hipStream_t scan2 = nullptr;
-    u32* chain_flags = nullptr;                       // [kMaxBlocks]
+    u32* chain_flags = nullptr;                       // [kMaxBlocks] per workgroup + [kMaxBlocks * kWaves] per wave range
     u32 *h_chain_err = nullptr, *d_chain_err = nullptr;  // mapped host word: a chained wait gave up
     u32 chain_seq = 0, chain_prev = 0, chain_pos = 0;  // last sequence number handed out | the run's last scan (0: no run) | its length
     hipEvent_t ev_run = nullptr;  // recorded on the main stream in front of a run's first scan: the run's first scan on `scan2` waits for
@@ -987,9 +987,9 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
     }
     h->chain_ok = h->scan2 && scan_chain_fits((u32)h->cap_nodes);
 #ifdef RIO_GP_LAB
-    if (const char* e = getenv("RIO_GP_CHAIN_DIAG")) h->chain_diag = atoi(e);
+    if (const char* e = getenv("RIO_GP_CHAIN_DIAG")) h->chain_diag = atoi(e);  // (1, 2: timing experiments only — the waits are what makes the chain correct)
     if (const char* e = getenv("RIO_GP_CHAIN_PER_WAVE")) h->chain_per_wave = (u32)atoi(e);
-    if (const char* e = getenv("RIO_GP_OVERLAP_MIN_ROWS")) h->overlap_min_rows = strtoull(e, nullptr, 10);  // (timing experiments only: the waits are what makes the chain correct)
+    if (const char* e = getenv("RIO_GP_OVERLAP_MIN_ROWS")) h->overlap_min_rows = strtoull(e, nullptr, 10);
 #endif
     const size_t R = h->cap_rows, M = h->cap_nodes, W = (size_t)kMaxBlocks * kWaves;
     // the balanced pack columns (k_rebal) have uniform wave ranges: up to a tile per wave range more than the table; the
