@@ -277,8 +277,9 @@ int rio_gp_tick(rio_gp_t* h, rio_gp_stats* stats);
  * The tables are exactly what the same sequence of rio_gp_tick calls produces; only the counters arrive later.  (A
  * server that pushes a membership change and rebalances has no use for the counters before the next push.)
  * On the handle's OWN stream a tick that cannot need the fix-up (nothing has changed since a tick that left every object
- * placed) runs its resolve step on an internal second stream, beside the next tick's scan, and on tables of 2^22 rows and
- * more (up to 1 024 nodes) the scans of such ticks alternate between the handle's stream and a third internal one, each
+ * placed) runs its resolve step beside the next tick's scan, and on tables of 2^18 rows and more (up to 1 024 nodes) the
+ * scans of such ticks alternate between the handle's stream and a second internal one (the resolve steps in line behind their
+ * scans below 5 M rows, on a third stream behind the scan's completion from there on), each
  * wave starting as soon as the same wave of the previous tick's scan has finished its rows (a dependency per row
  * range instead of per launch: the data dependency between two ticks is exactly that).  Every other call of the handle
  * orders itself behind all of it.  On a caller's stream (rio_gp_set_stream) everything stays on that one stream. */

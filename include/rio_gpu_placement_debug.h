@@ -31,7 +31,9 @@ extern "C" {
  * + 4096: the scans of such ticks are not CHAINED (every scan on the main stream, one launch after the other); by default they
  * alternate between two streams and hand their rows over wave range by wave range (ScanChain, placement_kernels.h).
  * Environment, read when a handle of the lab build is created: RIO_GP_OVERLAP_MIN_ROWS (the smallest table whose quiet ticks
- * overlap / chain; 2^22 rows in the product), RIO_GP_CHAIN_TPI (1 | 2 tiles per wave-iteration of the chained scan),
+ * overlap / chain; 2^18 rows in the product, 2^22 for the form without the chain), RIO_GP_CHAIN_INLINE_BELOW (tables below this
+ * many rows run a chained tick's k_resolve in line behind its scan: 5 * 2^20 in the product, 0 = never), RIO_GP_CHAIN_PER_WAVE
+ * (0: the hand-over per workgroup instead of per wave range), RIO_GP_CHAIN_TPI (1 | 2 tiles per wave-iteration of the chained scan),
  * RIO_GP_CHAIN_DIAG (timing experiments without the waits: NOT correct, tools/quiet_overlap_ab.py). */
 int rio_gp_debug_set_compact(rio_gp_t* h, int mode);
 /* chained scans enqueued by this handle so far (0: its quiet ticks have never met the conditions) */

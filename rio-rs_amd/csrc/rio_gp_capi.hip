@@ -230,7 +230,17 @@ struct rio_gp {
     u32 chain_seq = 0, chain_prev = 0, chain_pos = 0;  // last sequence number handed out | the run's last scan (0: no run) | its length
     hipEvent_t ev_run = nullptr;  // recorded on the main stream in front of a run's first scan: the run's first scan on `scan2` waits for
                                   // it, so that nothing but the two scans of the chain competes for the chip while one of them waits
-    u64 overlap_min_rows = (u64)1 << 22;  // (lab builds, RIO_GP_OVERLAP_MIN_ROWS: the parity tests run the overlapped / chained ticks on small tables)
+    u64 overlap_event_min_rows = (u64)1 << 22;  // ... and with its k_resolve behind events on the side stream from here on
+    u64 overlap_min_rows = (u64)1 << 18;  // (2^22 until the in-line form of the chain: below it the events cost more than they hid; lab builds,
+                                          //  RIO_GP_OVERLAP_MIN_ROWS: the parity tests run the overlapped / chained ticks on small tables)
+    // Small tables (below `inline_below` rows): the k_resolve of a chained tick goes onto ITS SCAN'S stream, right behind the scan —
+    // no event ties the two together and none ties the histogram ring to the resolves (a buffer comes round again on the same
+    // stream, 64 ticks later): a tick is two plain launches, and the host's enqueue (15.7 us per tick with the events, 7.1
+    // without) stops being what bounds a 6 us scan.  On big tables it is the wrong trade: the next scan on that stream then sits
+    // behind the resolve while its waves are needed resident (10 M rows: 28.6 against 25.5 us per tick).
+    u64 inline_below = (u64)5 << 20;  // (same-run A/Bs at 0.26 / 0.5 / 1 / 2 / 4 / 10 M rows: the two forms cross at ~5 M; lab builds: RIO_GP_CHAIN_INLINE_BELOW)
+    bool side_inline = false;     // what side_join has to join is the second scan stream (a chained run), not a k_resolve's event
+    hipEvent_t ev_join = nullptr;
     u32 chain_per_wave = 1;       // ScanChain::per_wave: the hand-over per wave range (same-run A/B: 25.6-25.9 against 26.2-26.5 us per tick per
                                   // workgroup; lab builds: RIO_GP_CHAIN_PER_WAVE=0 for the other form)
     int chain_diag = 0;           // lab builds, RIO_GP_CHAIN_DIAG: 1 = the chained kernel on the main stream, no waits | 2 = alternating streams, no waits | 3 = every link waits
@@ -419,11 +429,18 @@ void chain_end(rio_gp* h) {
 void side_join(rio_gp* h) {
     if (!h->side_pending) return;
     (void)hipSetDevice(h->device);
-    if (hipStreamWaitEvent(h->stream, h->ev_res[h->side_last], 0) != hipSuccess) {
+    if (h->side_inline) {  // a chained run with its resolves in line: what is not on the main stream is on `scan2`
+        if (h->chain_pos >= 2 &&
+            (hipEventRecord(h->ev_join, h->scan2) != hipSuccess || hipStreamWaitEvent(h->stream, h->ev_join, 0) != hipSuccess)) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(h->scan2);
+        }
+    } else if (hipStreamWaitEvent(h->stream, h->ev_res[h->side_last], 0) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(h->side);
     }
     h->side_pending = false;
+    h->side_inline = false;
     chain_end(h);  // (the run of chained scans ends here: the next one starts on the main stream, behind this wait)
 }
 // what every entry point holds: the handle's mutex, with the side stream joined (rio_gp_tick_async joins only when it must)
@@ -516,6 +533,7 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
         ++h->chain_pos;
     }
     u32 par = 0;
+    const bool inl = chained && h->n < h->inline_below && h->ev_join && h->chain_diag == 0;
     if (overlap) {  // (a quiet tick: plain k_scan, no fix-up behind it — the cuts' tables are not maintained)
         par = h->ov_count++ % h->ov_bufs;
         rb.R = nullptr; rb.RP = nullptr; rb.Tg = nullptr;
@@ -526,7 +544,8 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
             (void)hipGetLastError();
             (void)hipStreamWaitEvent(ss, h->ev_res[par], 0);
         }
-        rs = h->side;
+        rs = inl ? ss : h->side;
+        if (inl) h->ev_res_valid[par] = false;  // (nothing of this tick is behind an event: stream order and the run's join order it)
     }
     if (inc) {
         // (t.cur is read AND written: the tick is committed, nobody is promised the table as it was)
@@ -534,7 +553,7 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
         h->vplan = rebal_plan(h->plan);
         launch_rebal(h->plan, h->vplan, h->pk, nt, h->pk2, h->sb, h->stream);
     } else {
-        launch_scan(h->plan, t, nt, rb, false, h->all_alive, ss, nullptr, overlap ? h->ev_scan[par] : nullptr,
+        launch_scan(h->plan, t, nt, rb, false, h->all_alive, ss, nullptr, (overlap && !inl) ? h->ev_scan[par] : nullptr,
                     compact ? &h->pk : nullptr, chained ? &ch : nullptr);
     }
     h->vplan.wcnt = compact ? pkx.wcnt : nullptr;
@@ -545,10 +564,13 @@ void enqueue_scan_resolve(rio_gp* h, const Table& t, const NodeTab& nt, bool com
     h->searched = compact && h->plan.G && h->n / h->plan.G <= kSearchMaxBlockRows;
     Plan rp = h->vplan;
     if (!h->searched) rp.wcnt = nullptr;
-    if (overlap) (void)hipStreamWaitEvent(rs, h->ev_scan[par], 0);  // (the scan's own stop event)
+    if (overlap && !inl) (void)hipStreamWaitEvent(rs, h->ev_scan[par], 0);  // (the scan's own stop event)
     launch_resolve(rp, nt, rb, host_rows, rs, nullptr, nullptr, h->searched ? &pkx : nullptr,
                    h->used_parts ? h->used : nullptr, h->parts_rounds, inc ? h->used : nullptr);
-    if (overlap) {
+    if (overlap && inl) {
+        h->side_pending = true;
+        h->side_inline = true;
+    } else if (overlap) {
         (void)hipEventRecord(h->ev_res[par], rs);
         h->ev_res_valid[par] = true;
         h->side_pending = true;
@@ -815,9 +837,21 @@ int tick_async_locked(rio_gp* h) {
     // host runs 64 ticks ahead and every scan waits for a resolve that is itself starved beside a scan; 64 buffers (1 GB): no
     // waits, and still 330 against 313 us per tick: a k_resolve of 512 workgroups over 16 MB beside a DRAM-bound scan costs the
     // scan more than it saves.
-    const bool overlap = quiet && h->overlap_mode != 2 && h->side && h->stream == h->own_stream &&
-                         h->n >= h->overlap_min_rows && h->ov_bufs >= (u32)kRing;
-    if (!overlap) side_join(h);
+    // Tables below 2^22 rows overlap only as links of a chain with the resolves in line (two plain launches a tick: 9.4-11.5 us
+    // against 11.2-14.5 at 0.26-2 M rows); with the events of the other form they lose (15.8-17.7).
+    const bool ov_can = quiet && h->overlap_mode != 2 && h->side && h->stream == h->own_stream && h->n >= h->overlap_min_rows &&
+                        h->ov_bufs >= (u32)kRing;
+    if (ov_can && h->chain_seq >= 0x70000000u) {  // (sequence numbers compare by signed difference: start over long before they wrap)
+        side_join(h);
+        (void)hipMemsetAsync(h->chain_flags, 0, (size_t)kMaxBlocks * (1 + kWaves) * sizeof(u32), h->stream);
+        h->chain_seq = 0;
+    }
+    // (chained: a pushed liveness bitmap rides in a scan that nothing behind it may overtake — a quiet tick has none; the chained
+    //  scan addresses its columns by 32-bit byte offsets: tables below 2^30 rows, 4 GiB a column)
+    const bool chained = ov_can && h->chain_mode != 2 && h->scan2 && h->chain_ok && !h->alive_dirty && h->cap_rows < ((size_t)1 << 30) &&
+                         chain_begin(h);
+    const bool overlap = ov_can && (chained || h->n >= h->overlap_event_min_rows);
+    if (!overlap || (!chained && h->chain_prev)) side_join(h);
     InplaceGuard ipg{h};
     h->plan = hplan(h, h->n);
     const Table t = real_table(h);
@@ -831,17 +865,6 @@ int tick_async_locked(rio_gp* h) {
     h->tick_quiet[k] = quiet;
     h->tick_mark[k] = h->plan.mark = (1ull << 40) | ++h->wait_seq;  // column 7 of the verdict rows: peek_ticks knows them by it
     h->ca_now = cut_apply_for(h, false);
-    // (chained: only the scan's completion as its own event orders its k_resolve — and a pushed liveness bitmap rides in a scan
-    //  that nothing behind it may overtake: a quiet tick has none)
-    if (overlap && h->chain_seq >= 0x70000000u) {  // (sequence numbers compare by signed difference: start over long before they wrap)
-        side_join(h);
-        (void)hipMemsetAsync(h->chain_flags, 0, (size_t)kMaxBlocks * (1 + kWaves) * sizeof(u32), h->stream);
-        h->chain_seq = 0;
-    }
-    // (the chained scan addresses its columns by 32-bit byte offsets: tables below 2^30 rows — 4 GiB a column)
-    const bool chained = overlap && h->chain_mode != 2 && h->scan2 && h->chain_ok && !nt.alive_src && h->cap_rows < ((size_t)1 << 30) &&
-                         chain_begin(h);
-    if (!chained && h->chain_prev) side_join(h);  // (cannot happen: what ends a run joins first; kept so that it could not pass silently)
     enqueue_scan_resolve(h, t, nt, compact, h->d_slots + (size_t)(kTickSlot0 + k) * h->slot_rows * 8, inc_choice(h, compact, true),
                          overlap, chained);
     if (quiet) {
@@ -980,7 +1003,8 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
             h->side = nullptr;  // (no overlap: everything else works)
         }
     if (h->side && (hipStreamCreateWithFlags(&h->scan2, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&h->ev_run, hipEventDisableTiming) != hipSuccess)) {
+                    hipEventCreateWithFlags(&h->ev_run, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
         (void)hipGetLastError();
         if (h->scan2) (void)hipStreamDestroy(h->scan2);
         h->scan2 = nullptr;  // (no chain: everything else works)
@@ -989,7 +1013,8 @@ int rio_gp_create(const rio_gp_cfg* cfg, rio_gp_t** out) {
 #ifdef RIO_GP_LAB
     if (const char* e = getenv("RIO_GP_CHAIN_DIAG")) h->chain_diag = atoi(e);  // (1, 2: timing experiments only — the waits are what makes the chain correct)
     if (const char* e = getenv("RIO_GP_CHAIN_PER_WAVE")) h->chain_per_wave = (u32)atoi(e);
-    if (const char* e = getenv("RIO_GP_OVERLAP_MIN_ROWS")) h->overlap_min_rows = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("RIO_GP_CHAIN_INLINE_BELOW")) h->inline_below = strtoull(e, nullptr, 10);
+    if (const char* e = getenv("RIO_GP_OVERLAP_MIN_ROWS")) h->overlap_min_rows = h->overlap_event_min_rows = strtoull(e, nullptr, 10);
 #endif
     const size_t R = h->cap_rows, M = h->cap_nodes, W = (size_t)kMaxBlocks * kWaves;
     // the balanced pack columns (k_rebal) have uniform wave ranges: up to a tile per wave range more than the table; the
@@ -1136,6 +1161,7 @@ void rio_gp_destroy(rio_gp_t* h) {
     chain_end(h);
     if (h->scan2) { (void)hipStreamSynchronize(h->scan2); (void)hipStreamDestroy(h->scan2); }
     if (h->ev_run) (void)hipEventDestroy(h->ev_run);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     for (int q = 0; q < kRing; ++q) {
         if (h->ev_scan[q]) (void)hipEventDestroy(h->ev_scan[q]);

@@ -71,10 +71,13 @@ class Scenario:
         self.chain_small = self.lab and (seed // 3) % 2 == 1
         if self.chain_small:
             os.environ["RIO_GP_OVERLAP_MIN_ROWS"] = "1"
+            if (seed // 6) % 2:   # ... in the form big tables use (k_resolve on the side stream behind the scan's stop event)
+                os.environ["RIO_GP_CHAIN_INLINE_BELOW"] = "0"
         try:
             g = self.g = gp.GpuPlacement(n, m, spill_rounds=self.rounds, flags=self.flags, lab=self.lab)
         finally:
             os.environ.pop("RIO_GP_OVERLAP_MIN_ROWS", None)
+            os.environ.pop("RIO_GP_CHAIN_INLINE_BELOW", None)
         g.set_nodes(self.cap, self.alive, m=m)
         g.set_objects(n, self.load, self.aff)
         g.set_assign(self.ref)

@@ -779,13 +779,14 @@ def test_async_ticks_equal_the_synchronous_stream(gp, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("overlap", [True, False, "chained", "overlapped"])
+@pytest.mark.parametrize("overlap", [True, False, "chained", "chained-events", "overlapped"])
 def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap, monkeypatch):
     """A tick that took the fast path leaves every object placed: until an input of the solve changes, rio_gp_tick_async
     enqueues k_scan + k_resolve only (no speculative fix-up) — and k_resolve on a stream of its own beside the next tick's scan
     (overlap: the product library as it is; False: the lab build with that switched off; "chained" / "overlapped": the lab build with
-    the size threshold of the overlap taken away, so that this table's quiet ticks run the way a 10 M-row table's do — their scans
-    chained over two streams, workgroup by workgroup — and the same without the chain).  Every kind of change must end that: liveness, removals,
+    the size threshold of the overlap taken away and the chain in either of its forms — k_resolve in line behind its scan, what
+    tables below 5 M rows get (also what the product does with this table: overlap=True), or on the side stream behind the scan's
+    stop event, what a 10 M-row table gets — and the same without the chain).  Every kind of change must end that: liveness, removals,
     updates onto other nodes, new loads / affinities, a new table, clean_server, requests — the tick right behind each is
     compared with the oracle chain, with the verdicts of the earlier ticks given time to land (so the quiet rule is
     actually in force when the change arrives)."""
@@ -797,6 +798,8 @@ def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap, 
     alive = np.ones(m, np.uint8)
     if isinstance(overlap, str):
         monkeypatch.setenv("RIO_GP_OVERLAP_MIN_ROWS", "1")
+    if overlap == "chained-events":   # the form big tables use (k_resolve on the side stream behind the scan's stop event), on this small one
+        monkeypatch.setenv("RIO_GP_CHAIN_INLINE_BELOW", "0")
     g = _mk(gp, n, m, load, aff, cap, alive, ref, lab=overlap is not True)
     if not overlap:
         g.set_compact("auto", overlap=False)
@@ -850,12 +853,12 @@ def test_async_ticks_quiet_stream_and_every_kind_of_change(gp, oracle, overlap, 
         assert got[k] == want[k], (k, got[k], want[k])
     assert np.array_equal(g.get_assign(), ref) and np.array_equal(g.get_nodes()[2], used)
     if isinstance(overlap, str):   # the quiet ticks of this run were links of a chain — or none of them was
-        assert (g.chained_scans() > 20) == (overlap == "chained"), g.chained_scans()
+        assert (g.chained_scans() > 20) == overlap.startswith("chained"), g.chained_scans()
     g.close()
 
 
 @pytest.mark.parametrize("lab", [False, True])
-def test_chained_quiet_ticks_hand_over_what_the_tick_before_them_wrote(gp, oracle, lab):
+def test_chained_quiet_ticks_hand_over_what_the_tick_before_them_wrote(gp, oracle, lab, monkeypatch):
     """A table big enough for the product's own rule (2^22 rows and more): once a tick's verdict says "fast path, nothing
     changed since", the scans of the following ticks alternate between two streams and hand their rows over workgroup by
     workgroup.  What a broken hand-over would show: the SECOND link of a run reads the column the first link wrote while that
@@ -868,6 +871,8 @@ def test_chained_quiet_ticks_hand_over_what_the_tick_before_them_wrote(gp, oracl
     load, aff, cap = cfg["load"], cfg["aff"], cfg["cap"]
     alive = np.ones(m, np.uint8)
     ref = np.full(n, NONE, np.uint32)
+    if lab:   # the form tables of 5 M rows and more get (k_resolve on the side stream); the product library runs this one in line
+        monkeypatch.setenv("RIO_GP_CHAIN_INLINE_BELOW", "0")
     g = _mk(gp, n, m, load, aff, cap, alive, ref, lab=lab)
     want = []
 
