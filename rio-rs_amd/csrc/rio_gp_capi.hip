@@ -411,19 +411,22 @@ NodeTab scan_nodes(rio_gp* h) {
     return nt;
 }
 
-// One run of chained scans per process at a time: the chain's progress argument counts the workgroup slots of ONE pair of
-// launches (two per CU); a second handle's pair on the same device could hold the slots the first one's earlier launch needs.
-std::atomic<rio_gp*> g_chain_owner{nullptr};
+// One run of chained scans per process and DEVICE at a time: the chain's progress argument counts the workgroup slots of ONE pair
+// of launches (two per CU); a second handle's pair on the same device could hold the slots the first one's earlier launch needs.
+// (A host that drives one handle per GPU from one process chains on every one of them.)
+constexpr int kChainDevices = 64;
+std::atomic<rio_gp*> g_chain_owner[kChainDevices];
+std::atomic<rio_gp*>& chain_owner(rio_gp* h) { return g_chain_owner[(unsigned)h->device % kChainDevices]; }
 bool chain_begin(rio_gp* h) {
     if (h->chain_prev) return true;  // (a run in progress is this handle's)
     rio_gp* none = nullptr;
-    return g_chain_owner.compare_exchange_strong(none, h, std::memory_order_acq_rel) || none == h;
+    return chain_owner(h).compare_exchange_strong(none, h, std::memory_order_acq_rel) || none == h;
 }
 void chain_end(rio_gp* h) {
     h->chain_prev = 0;
     h->chain_pos = 0;
     rio_gp* me = h;
-    (void)g_chain_owner.compare_exchange_strong(me, nullptr, std::memory_order_acq_rel);
+    (void)chain_owner(h).compare_exchange_strong(me, nullptr, std::memory_order_acq_rel);
 }
 // the main stream waits for the k_resolve of the last overlapped quiet tick (no-op when there is none in flight)
 void side_join(rio_gp* h) {
